@@ -1,0 +1,90 @@
+"""ctypes binding of the lurkhip C ABI (include/lurkhip.h).
+
+The HIP library is the product: there is no Python or CPU fallback.  If
+``liblurkhip.so`` has not been built this module raises at import time, and
+every compute call fails with ``LurkHipError`` when no HIP device is usable.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "liblurkhip.so")
+
+
+class LurkHipError(RuntimeError):
+    def __init__(self, status: int, message: str):
+        super().__init__(f"lurkhip status {status}: {message}")
+        self.status = status
+        self.message = message
+
+
+OK = 0
+ERR_INVALID_ARG = -1
+ERR_NO_DEVICE = -2
+ERR_HIP = -3
+ERR_OOM = -4
+ERR_UNSUPPORTED = -5
+ERR_EXEC = -6
+ERR_PARSE = -7
+
+REPR_CANONICAL = 0
+REPR_MONTY = 1
+
+if not os.path.exists(LIB_PATH):
+    raise ImportError(
+        f"{LIB_PATH} is missing: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+        "(or `make -C lurk_amd/csrc`). lurk_amd has no CPU fallback."
+    )
+
+lib = C.CDLL(LIB_PATH)
+
+_p = C.c_void_p
+_u32p = C.c_void_p  # raw addresses (numpy .ctypes.data, torch .data_ptr())
+_sz = C.c_size_t
+_i32 = C.c_int32
+_i64 = C.c_int64
+
+# name -> (restype, argtypes); kept in the order of include/lurkhip.h
+SIGNATURES = {
+    "lurkhip_abi_version": (_i32, []),
+    "lurkhip_ctx_create": (_i32, [_i32, C.POINTER(_p)]),
+    "lurkhip_ctx_create_on_stream": (_i32, [_i32, _p, C.POINTER(_p)]),
+    "lurkhip_ctx_destroy": (_i32, [_p]),
+    "lurkhip_ctx_sync": (_i32, [_p]),
+    "lurkhip_last_error": (C.c_char_p, [_p]),
+    "lurkhip_malloc": (_i32, [_p, _sz, C.POINTER(_p)]),
+    "lurkhip_free": (_i32, [_p, _p]),
+    "lurkhip_memcpy_h2d": (_i32, [_p, _p, _p, _sz]),
+    "lurkhip_memcpy_d2h": (_i32, [_p, _p, _p, _sz]),
+    "lurkhip_timer_start": (_i32, [_p]),
+    "lurkhip_timer_stop": (_i32, [_p, C.POINTER(C.c_float)]),
+    "lurkhip_poseidon2_num_cols": (_i32, [_i32]),
+    "lurkhip_poseidon2_permute": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_permute_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_hash8": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_hash8_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_wide_witness": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_wide_witness_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+}
+
+
+def _bind():
+    for name, (res, args) in SIGNATURES.items():
+        fn = getattr(lib, name)  # AttributeError here = header/library mismatch
+        fn.restype = res
+        fn.argtypes = args
+
+
+_bind()
+
+
+def last_error(ctx_handle) -> str:
+    msg = lib.lurkhip_last_error(ctx_handle)
+    return msg.decode("utf-8", "replace") if msg else ""
+
+
+def check(status: int, ctx_handle=None) -> None:
+    if status != OK:
+        raise LurkHipError(status, last_error(ctx_handle))

@@ -1,0 +1,86 @@
+"""`Context`: one HIP stream + scratch arenas behind the lurkhip C ABI."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+
+
+def _addr(buf) -> int:
+    """Raw address of a numpy array (host) or a torch tensor (device)."""
+    if isinstance(buf, np.ndarray):
+        return buf.ctypes.data
+    if hasattr(buf, "data_ptr"):
+        return buf.data_ptr()
+    if isinstance(buf, int):
+        return buf
+    raise TypeError(f"cannot take the address of {type(buf)!r}")
+
+
+def as_u32(a) -> np.ndarray:
+    a = np.ascontiguousarray(a, dtype=np.uint32)
+    return a
+
+
+class Context:
+    """Owns a ``lurkhip_ctx``.  ``stream`` may be a raw ``hipStream_t`` value (for
+    example ``torch.cuda.current_stream().cuda_stream``) to enqueue on a caller stream."""
+
+    def __init__(self, device: int = 0, stream: int | None = None):
+        h = C.c_void_p()
+        if stream is None:
+            N.check(N.lib.lurkhip_ctx_create(device, C.byref(h)))
+        else:
+            N.check(N.lib.lurkhip_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)))
+        self.handle = h
+        self.device = device
+
+    def close(self):
+        if getattr(self, "handle", None):
+            N.lib.lurkhip_ctx_destroy(self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def __enter__(self):
+        return self
+
+    def __exit__(self, *exc):
+        self.close()
+
+    def check(self, status: int):
+        N.check(status, self.handle)
+
+    def sync(self):
+        self.check(N.lib.lurkhip_ctx_sync(self.handle))
+
+    def timer_start(self):
+        self.check(N.lib.lurkhip_timer_start(self.handle))
+
+    def timer_stop(self) -> float:
+        ms = C.c_float()
+        self.check(N.lib.lurkhip_timer_stop(self.handle, C.byref(ms)))
+        return float(ms.value)
+
+    # raw device memory (hosts without torch)
+    def malloc(self, nbytes: int) -> int:
+        p = C.c_void_p()
+        self.check(N.lib.lurkhip_malloc(self.handle, nbytes, C.byref(p)))
+        return p.value
+
+    def free(self, ptr: int):
+        self.check(N.lib.lurkhip_free(self.handle, C.c_void_p(ptr)))
+
+    def h2d(self, dev_ptr: int, host: np.ndarray):
+        host = np.ascontiguousarray(host)
+        self.check(N.lib.lurkhip_memcpy_h2d(self.handle, C.c_void_p(dev_ptr), host.ctypes.data, host.nbytes))
+
+    def d2h(self, host: np.ndarray, dev_ptr: int):
+        assert host.flags["C_CONTIGUOUS"]
+        self.check(N.lib.lurkhip_memcpy_d2h(self.handle, host.ctypes.data, C.c_void_p(dev_ptr), host.nbytes))

@@ -1,0 +1,173 @@
+// BabyBear field arithmetic for the gfx950 kernels (and the host code that feeds them).
+//
+// p = 2013265921 = 15 * 2^27 + 1.  Device code keeps every element in Montgomery
+// form x~ = x * 2^32 mod p, canonical range [0, p), which is also the in-memory
+// form of the reference's field type (p3_baby_bear::BabyBear, [UPSTREAM-RECALL]),
+// so a caller holding a RowMajorMatrix<BabyBear> can pass its storage with
+// repr = LURKHIP_REPR_MONTY and no conversion happens at all.
+//
+// Replaces: third-party p3_baby_bear (+, -, *, inverse) as used by the reference at
+// e.g. /root/reference/src/lair/execute.rs:631-640, /root/reference/src/air/builder.rs:159-168.
+//
+// No MFMA here: the products are element-wise 31x31-bit, there is no shared
+// operand to turn them into a matrix product.  One Montgomery product is
+// 2 x v_mul_lo_u32 + 2 x v_mul_hi_u32 (or v_mad_u64_u32) + 3 full-rate VALU ops.
+#pragma once
+#include <stdint.h>
+
+#if defined(__HIPCC__)
+#include <hip/hip_runtime.h>
+#define BB_HD __host__ __device__ __forceinline__
+#else
+#define BB_HD inline
+#endif
+
+namespace bb {
+
+constexpr uint32_t P = 0x78000001u;        // 2013265921
+constexpr uint32_t MU = 0x88000001u;       // p^-1 mod 2^32
+constexpr uint32_t R1 = 0x0ffffffeu;       // 2^32 mod p  (Montgomery 1)
+constexpr uint32_t R2 = 1172168163u;       // 2^64 mod p  (to_monty multiplier)
+constexpr uint32_t GEN = 31u;              // multiplicative generator (canonical)
+constexpr int TWO_ADICITY = 27;
+constexpr uint32_t EXT_W = 11u;            // F[x]/(x^4 - 11)
+
+constexpr uint32_t cmulmod(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); }
+constexpr uint32_t c_to_monty(uint32_t x) { return (uint32_t)((((uint64_t)x) << 32) % P); }
+static_assert(c_to_monty(1) == R1, "R1");
+static_assert(cmulmod(R1, R1) == R2, "R2");
+static_assert((uint32_t)(P * MU) == 1u, "MU");
+
+BB_HD uint32_t umin(uint32_t a, uint32_t b) { return a < b ? a : b; }
+
+BB_HD uint32_t add(uint32_t a, uint32_t b) {
+    uint32_t s = a + b;
+    return umin(s, s - P);
+}
+BB_HD uint32_t sub(uint32_t a, uint32_t b) {
+    uint32_t d = a - b;
+    return umin(d, d + P);
+}
+BB_HD uint32_t neg(uint32_t a) { return sub(0u, a); }
+BB_HD uint32_t dbl(uint32_t a) { return add(a, a); }
+
+// Montgomery reduction of t < p * 2^32: returns t * 2^-32 mod p in [0, p)
+BB_HD uint32_t mred(uint64_t t) {
+    uint32_t lo = (uint32_t)t, hi = (uint32_t)(t >> 32);
+    uint32_t m = lo * MU;
+#if defined(__HIP_DEVICE_COMPILE__)
+    uint32_t u = __umulhi(m, P);
+#else
+    uint32_t u = (uint32_t)(((uint64_t)m * P) >> 32);
+#endif
+    uint32_t r = hi - u;
+    return umin(r, r + P);
+}
+BB_HD uint32_t mul(uint32_t a, uint32_t b) { return mred((uint64_t)a * b); }
+BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
+
+BB_HD uint32_t to_monty(uint32_t x) { return mul(x, R2); }
+BB_HD uint32_t from_monty(uint32_t x) { return mred((uint64_t)x); }
+
+// x^7 the way the reference's witness generator computes it (cube, then x * cube^2):
+// /root/reference/src/poseidon/wide/trace.rs:44-50
+BB_HD uint32_t cube(uint32_t x) { return mul(sqr(x), x); }
+BB_HD uint32_t pow7_from_cube(uint32_t x, uint32_t x3) { return mul(x, sqr(x3)); }
+
+// a^e, a in Montgomery form
+BB_HD uint32_t pow(uint32_t a, uint32_t e) {
+    uint32_t r = R1;
+    while (e) {
+        if (e & 1u) r = mul(r, a);
+        a = sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+// Fermat inverse a^(p-2); inv(0) = 0.  p - 2 = 0x77ffffff.
+BB_HD uint32_t inv(uint32_t a) {
+    // addition chain: a^(2^27-1) then the top nibble 0111 -> exponent 0x77ffffff
+    // = 0b0111_0111_1111_1111_1111_1111_1111_1111
+    uint32_t a2 = sqr(a);            // 2
+    uint32_t a3 = mul(a2, a);        // 3
+    uint32_t a6 = sqr(a3);
+    uint32_t a7 = mul(a6, a);        // 2^3-1
+    uint32_t t = a7;
+    // build 2^27 - 1 = 27 ones: (2^3-1) -> 2^6-1 -> 2^12-1 -> 2^24-1 -> 2^27-1
+    uint32_t x6 = t;
+    for (int i = 0; i < 3; i++) x6 = sqr(x6);
+    x6 = mul(x6, a7);                // 2^6-1
+    uint32_t x12 = x6;
+    for (int i = 0; i < 6; i++) x12 = sqr(x12);
+    x12 = mul(x12, x6);              // 2^12-1
+    uint32_t x24 = x12;
+    for (int i = 0; i < 12; i++) x24 = sqr(x24);
+    x24 = mul(x24, x12);             // 2^24-1
+    uint32_t x27 = x24;
+    for (int i = 0; i < 3; i++) x27 = sqr(x27);
+    x27 = mul(x27, a7);              // 2^27-1
+    // exponent = 0b111 << 28 | 0 << 27 | (2^27-1)  = 7*2^28 + 2^27 - 1
+    uint32_t hi = a7;                // 0b111
+    for (int i = 0; i < 28; i++) hi = sqr(hi);
+    return mul(hi, x27);
+}
+static_assert(7u * (1u << 28) + (1u << 27) - 1u == P - 2u, "inverse exponent");
+
+// ---------------------------------------------------------------------------
+// quartic extension F[x]/(x^4 - 11), coefficients in Montgomery form
+// (p3 BinomialExtensionField<BabyBear,4>; [UPSTREAM-RECALL] for W = 11)
+struct ef {
+    uint32_t c[4];
+};
+constexpr uint32_t EXT_W_M = c_to_monty(EXT_W);
+
+BB_HD ef ef_zero() { return ef{{0, 0, 0, 0}}; }
+BB_HD ef ef_one() { return ef{{R1, 0, 0, 0}}; }
+BB_HD ef ef_from_base(uint32_t a) { return ef{{a, 0, 0, 0}}; }
+BB_HD ef ef_add(const ef& a, const ef& b) {
+    return ef{{add(a.c[0], b.c[0]), add(a.c[1], b.c[1]), add(a.c[2], b.c[2]), add(a.c[3], b.c[3])}};
+}
+BB_HD ef ef_sub(const ef& a, const ef& b) {
+    return ef{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
+}
+BB_HD ef ef_scale(const ef& a, uint32_t s) {
+    return ef{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}};
+}
+BB_HD ef ef_add_base(const ef& a, uint32_t s) { return ef{{add(a.c[0], s), a.c[1], a.c[2], a.c[3]}}; }
+BB_HD ef ef_mul(const ef& a, const ef& b) {
+    // schoolbook with the x^4 = 11 fold; every partial product is < p so a sum of
+    // four of them fits 64 bits long before reduction: accumulate then reduce once.
+    uint64_t t0 = (uint64_t)a.c[0] * b.c[0];
+    uint64_t t1 = (uint64_t)a.c[0] * b.c[1] + (uint64_t)a.c[1] * b.c[0];
+    uint64_t t2 = (uint64_t)a.c[0] * b.c[2] + (uint64_t)a.c[1] * b.c[1] + (uint64_t)a.c[2] * b.c[0];
+    uint64_t t3 = (uint64_t)a.c[0] * b.c[3] + (uint64_t)a.c[1] * b.c[2] + (uint64_t)a.c[2] * b.c[1] +
+                  (uint64_t)a.c[3] * b.c[0];
+    uint64_t t4 = (uint64_t)a.c[1] * b.c[3] + (uint64_t)a.c[2] * b.c[2] + (uint64_t)a.c[3] * b.c[1];
+    uint64_t t5 = (uint64_t)a.c[2] * b.c[3] + (uint64_t)a.c[3] * b.c[2];
+    uint64_t t6 = (uint64_t)a.c[3] * b.c[3];
+    // each t < 4 * p^2 < 2^64 (p^2 < 2^62): reduce mod p * 2^32 domain via mred after a
+    // conditional subtraction so the mred precondition t < p * 2^32 holds.
+    const uint64_t PP = (uint64_t)P << 32;
+    auto red = [&](uint64_t t) -> uint32_t {
+        // t < 2^64; bring below p * 2^32 (= 0x78000001_00000000) by subtracting it at most twice
+        if (t >= PP) t -= PP;
+        if (t >= PP) t -= PP;
+        return mred(t);
+    };
+    uint32_t r0 = red(t0), r1 = red(t1), r2 = red(t2), r3 = red(t3);
+    uint32_t r4 = red(t4), r5 = red(t5), r6 = red(t6);
+    return ef{{add(r0, mul(EXT_W_M, r4)), add(r1, mul(EXT_W_M, r5)), add(r2, mul(EXT_W_M, r6)), r3}};
+}
+BB_HD ef ef_sqr(const ef& a) { return ef_mul(a, a); }
+BB_HD bool ef_is_zero(const ef& a) { return (a.c[0] | a.c[1] | a.c[2] | a.c[3]) == 0; }
+// inverse by two conjugations down to the base field (x -> -x, then x^2 -> -x^2)
+BB_HD ef ef_inv(const ef& a) {
+    ef a1{{a.c[0], neg(a.c[1]), a.c[2], neg(a.c[3])}};
+    ef b = ef_mul(a, a1);  // in span{1, x^2}
+    ef b1{{b.c[0], 0, neg(b.c[2]), 0}};
+    ef n = ef_mul(b, b1);  // in F
+    uint32_t ninv = inv(n.c[0]);
+    return ef_scale(ef_mul(a1, b1), ninv);
+}
+
+}  // namespace bb

@@ -1,0 +1,159 @@
+// Context, memory helpers and the HIP-event stopwatch of the lurkhip C ABI.
+#include "ctx.h"
+
+#include <cstring>
+
+namespace lurkhip {
+
+static thread_local std::string g_tls_err;
+
+int32_t set_error(lurkhip_ctx* ctx, int32_t code, const char* fmt, ...) {
+    char buf[1024];
+    va_list ap;
+    va_start(ap, fmt);
+    vsnprintf(buf, sizeof buf, fmt, ap);
+    va_end(ap);
+    if (ctx) ctx->err = buf;
+    g_tls_err = buf;
+    return code;
+}
+
+int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->arena_bytes[slot] < bytes) {
+        if (ctx->arena[slot]) {
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            LH_HIP(ctx, hipFree(ctx->arena[slot]));
+            ctx->arena[slot] = nullptr;
+            ctx->arena_bytes[slot] = 0;
+        }
+        size_t want = bytes + bytes / 4;
+        hipError_t e = hipMalloc(&ctx->arena[slot], want);
+        if (e != hipSuccess) {
+            want = bytes;
+            LH_HIP(ctx, hipMalloc(&ctx->arena[slot], want));
+        }
+        ctx->arena_bytes[slot] = want;
+    }
+    *out = ctx->arena[slot];
+    return LURKHIP_OK;
+}
+
+static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkhip_ctx** out) {
+    if (!out) return set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    int count = 0;
+    hipError_t e = hipGetDeviceCount(&count);
+    if (e != hipSuccess || count == 0)
+        return set_error(nullptr, LURKHIP_ERR_NO_DEVICE,
+                         "no usable HIP device (%s); lurkhip has no CPU fallback",
+                         e != hipSuccess ? hipGetErrorString(e) : "device count is 0");
+    if (device_id < 0 || device_id >= count)
+        return set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "device_id %d out of range [0,%d)", device_id, count);
+    lurkhip_ctx* ctx = new lurkhip_ctx();
+    ctx->device = device_id;
+    auto fail = [&](hipError_t err, const char* what) {
+        int32_t s = set_error(nullptr, LURKHIP_ERR_HIP, "%s failed: %s", what, hipGetErrorString(err));
+        delete ctx;
+        return s;
+    };
+    if ((e = hipSetDevice(device_id)) != hipSuccess) return fail(e, "hipSetDevice");
+    if (borrow) {
+        ctx->stream = (hipStream_t)stream;
+        ctx->owns_stream = false;
+    } else {
+        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
+            return fail(e, "hipStreamCreateWithFlags");
+        ctx->owns_stream = true;
+    }
+    if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
+    if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
+    *out = ctx;
+    return LURKHIP_OK;
+}
+
+}  // namespace lurkhip
+
+using namespace lurkhip;
+
+extern "C" {
+
+int32_t lurkhip_abi_version(void) { return 1; }
+
+int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out) {
+    return create_common(device_id, nullptr, false, out);
+}
+
+int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhip_ctx** out) {
+    return create_common(device_id, hip_stream, true, out);
+}
+
+int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
+    if (!ctx) return LURKHIP_OK;
+    (void)hipSetDevice(ctx->device);
+    (void)hipStreamSynchronize(ctx->stream);
+    for (int i = 0; i < 4; i++)
+        if (ctx->arena[i]) (void)hipFree(ctx->arena[i]);
+    if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
+    if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_ctx_sync(lurkhip_ctx* ctx) {
+    LH_CHECK_CTX(ctx);
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}
+
+const char* lurkhip_last_error(lurkhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+
+int32_t lurkhip_malloc(lurkhip_ctx* ctx, size_t bytes, void** dev_ptr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, dev_ptr != nullptr, "null dev_ptr");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipMalloc(dev_ptr, bytes ? bytes : 16));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_free(lurkhip_ctx* ctx, void* dev_ptr) {
+    LH_CHECK_CTX(ctx);
+    if (!dev_ptr) return LURKHIP_OK;
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, hipFree(dev_ptr));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_memcpy_h2d(lurkhip_ctx* ctx, void* dev_dst, const void* host_src, size_t bytes) {
+    LH_CHECK_CTX(ctx);
+    if (bytes == 0) return LURKHIP_OK;
+    LH_HIP(ctx, hipMemcpyAsync(dev_dst, host_src, bytes, hipMemcpyHostToDevice, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_memcpy_d2h(lurkhip_ctx* ctx, void* host_dst, const void* dev_src, size_t bytes) {
+    LH_CHECK_CTX(ctx);
+    if (bytes == 0) return LURKHIP_OK;
+    LH_HIP(ctx, hipMemcpyAsync(host_dst, dev_src, bytes, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_timer_start(lurkhip_ctx* ctx) {
+    LH_CHECK_CTX(ctx);
+    LH_HIP(ctx, hipEventRecord(ctx->ev_start, ctx->stream));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_timer_stop(lurkhip_ctx* ctx, float* elapsed_ms) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, elapsed_ms != nullptr, "null elapsed_ms");
+    LH_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
+    LH_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
+    LH_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return LURKHIP_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,176 @@
+// Poseidon2 over BabyBear, device side (gfx950).
+//
+// One permutation per lane: the W-lane state lives in VGPRs for the whole
+// permutation (W <= 48 registers), every inner loop over the state is fully
+// unrolled, the loops over rounds are kept rolled so the kernel body stays a few
+// KB (the instruction cache is shared by two CUs), and the round constants are
+// read with wave-uniform indices from __constant__ memory, i.e. through the
+// scalar cache into SGPRs.  Arithmetic is VALU int32 Montgomery (babybear.h).
+//
+// Replaces on the reference side (P2/P3/P4 in SURVEY.md section 8a):
+//   - p3 Poseidon2::permute as configured by /root/reference/src/poseidon/config.rs:75-94
+//   - layer order /root/reference/src/poseidon/wide/trace.rs:12-82
+//   - internal layer /root/reference/src/poseidon/config.rs:109-118
+//   - Poseidon2Cols row layout /root/reference/src/poseidon/wide/columns.rs:16-32
+#pragma once
+#include "babybear.h"
+#include "p2_params.h"
+
+namespace p2 {
+
+template <int N>
+struct MArr {
+    uint32_t v[N];
+};
+template <int N>
+constexpr MArr<N> monty_table(const uint32_t (&a)[N]) {
+    MArr<N> r{};
+    for (int i = 0; i < N; i++) r.v[i] = bb::c_to_monty(a[i]);
+    return r;
+}
+
+// Per-width parameter block in Montgomery form, placed in __constant__ memory.
+template <int W, int RP>
+struct Params {
+    uint32_t ext_rc[8 * W];
+    uint32_t int_rc[RP];
+    uint32_t diag[W];
+};
+template <int W, int RP>
+constexpr Params<W, RP> make_params(const uint32_t (&ext)[8 * W], const uint32_t (&in)[RP], const uint32_t (&d)[W]) {
+    Params<W, RP> p{};
+    for (int i = 0; i < 8 * W; i++) p.ext_rc[i] = bb::c_to_monty(ext[i]);
+    for (int i = 0; i < RP; i++) p.int_rc[i] = bb::c_to_monty(in[i]);
+    for (int i = 0; i < W; i++) p.diag[i] = bb::c_to_monty(d[i]);
+    return p;
+}
+
+#define LURK_P2_WIDTHS(X) X(4, 21) X(8, 12) X(12, 10) X(16, 13) X(20, 18) X(24, 21) X(28, 25) X(32, 30) X(36, 34) X(40, 38) X(44, 42) X(48, 46)
+
+#define LURK_P2_DECL(W, RP) \
+    __constant__ const Params<W, RP> kParams##W = make_params<W, RP>(LURK_P2_EXT_RC_##W, LURK_P2_INT_RC_##W, LURK_P2_DIAG_##W);
+LURK_P2_WIDTHS(LURK_P2_DECL)
+#undef LURK_P2_DECL
+
+template <int W>
+struct Cfg;
+#define LURK_P2_CFG(W_, RP_)                                                                   \
+    template <>                                                                                \
+    struct Cfg<W_> {                                                                           \
+        static constexpr int W = W_;                                                           \
+        static constexpr int RP = RP_;                                                         \
+        static constexpr int NUM_COLS = 16 * W_ + W_ + (RP_ - 1) + RP_;                        \
+        __device__ __forceinline__ static const Params<W_, RP_>& params() { return kParams##W_; } \
+    };
+LURK_P2_WIDTHS(LURK_P2_CFG)
+#undef LURK_P2_CFG
+
+// M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] on one 4-lane chunk, 7 adds + 2 doublings
+__device__ __forceinline__ void m4(uint32_t& x0, uint32_t& x1, uint32_t& x2, uint32_t& x3) {
+    uint32_t t01 = bb::add(x0, x1);
+    uint32_t t23 = bb::add(x2, x3);
+    uint32_t t0123 = bb::add(t01, t23);
+    uint32_t t01123 = bb::add(t0123, x1);
+    uint32_t t01233 = bb::add(t0123, x3);
+    uint32_t y3 = bb::add(t01233, bb::dbl(x0));
+    uint32_t y1 = bb::add(t01123, bb::dbl(x2));
+    uint32_t y0 = bb::add(t01123, t01);
+    uint32_t y2 = bb::add(t01233, t23);
+    x0 = y0; x1 = y1; x2 = y2; x3 = y3;
+}
+
+template <int W>
+__device__ __forceinline__ void external_layer(uint32_t (&s)[W]) {
+#pragma unroll
+    for (int i = 0; i < W; i += 4) m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
+    if constexpr (W > 4) {
+        uint32_t sums[4];
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            uint32_t acc = s[k];
+#pragma unroll
+            for (int i = k + 4; i < W; i += 4) acc = bb::add(acc, s[i]);
+            sums[k] = acc;
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) s[i] = bb::add(s[i], sums[i & 3]);
+    }
+}
+
+// x_i <- x_i * diag_i + sum_j x_j with explicit diag pointer (uniform address)
+template <int W>
+__device__ __forceinline__ void internal_layer(uint32_t (&s)[W], const uint32_t* __restrict__ diag) {
+    // two interleaved accumulators halve the dependent-add chain
+    uint32_t sa = s[0], sb = s[1];
+#pragma unroll
+    for (int i = 2; i + 1 < W; i += 2) {
+        sa = bb::add(sa, s[i]);
+        sb = bb::add(sb, s[i + 1]);
+    }
+    uint32_t sum = bb::add(sa, sb);
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = bb::add(bb::mul(s[i], diag[i]), sum);
+}
+
+struct NoRecord {
+    __device__ __forceinline__ void ext_state(int, int, uint32_t) {}
+    __device__ __forceinline__ void end_ext_state(int) {}
+    __device__ __forceinline__ void ext_sbox(int, int, uint32_t) {}
+    __device__ __forceinline__ void end_ext_sbox(int) {}
+    __device__ __forceinline__ void int_init(int, uint32_t) {}
+    __device__ __forceinline__ void end_int_init() {}
+    __device__ __forceinline__ void int_state0(int, uint32_t) {}
+    __device__ __forceinline__ void int_sbox(int, uint32_t) {}
+    __device__ __forceinline__ void end_internal() {}
+};
+
+template <int W, class Rec>
+__device__ __forceinline__ void external_round(uint32_t (&s)[W], int r, const uint32_t* __restrict__ ext_rc, Rec& rec) {
+#pragma unroll
+    for (int i = 0; i < W; i++) rec.ext_state(r, i, s[i]);
+    rec.end_ext_state(r);
+#pragma unroll
+    for (int i = 0; i < W; i++) {
+        uint32_t x = bb::add(s[i], ext_rc[r * W + i]);
+        uint32_t x3 = bb::cube(x);
+        rec.ext_sbox(r, i, x3);
+        s[i] = bb::pow7_from_cube(x, x3);
+    }
+    rec.end_ext_sbox(r);
+    external_layer<W>(s);
+}
+
+// The permutation on a Montgomery-form state, parameters given by pointers so the
+// same body serves the built-in tables and a caller-supplied width-16 set.
+template <int W, class Rec>
+__device__ __forceinline__ void permute_core(uint32_t (&s)[W], int rounds_p, const uint32_t* __restrict__ ext_rc,
+                                             const uint32_t* __restrict__ int_rc,
+                                             const uint32_t* __restrict__ diag, Rec& rec) {
+    external_layer<W>(s);
+#pragma unroll 1
+    for (int r = 0; r < 4; r++) external_round<W>(s, r, ext_rc, rec);
+#pragma unroll
+    for (int i = 0; i < W; i++) rec.int_init(i, s[i]);
+    rec.end_int_init();
+#pragma unroll 1
+    for (int r = 0; r < rounds_p; r++) {
+        if (r > 0) rec.int_state0(r - 1, s[0]);
+        uint32_t x = bb::add(s[0], int_rc[r]);
+        uint32_t x3 = bb::cube(x);
+        rec.int_sbox(r, x3);
+        s[0] = bb::pow7_from_cube(x, x3);
+        internal_layer<W>(s, diag);
+    }
+    rec.end_internal();
+#pragma unroll 1
+    for (int r = 4; r < 8; r++) external_round<W>(s, r, ext_rc, rec);
+}
+
+template <int W>
+__device__ __forceinline__ void permute(uint32_t (&s)[W]) {
+    NoRecord rec;
+    const auto& p = Cfg<W>::params();
+    permute_core<W>(s, Cfg<W>::RP, p.ext_rc, p.int_rc, p.diag, rec);
+}
+
+}  // namespace p2
