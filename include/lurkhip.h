@@ -110,6 +110,51 @@ int32_t lurkhip_poseidon2_wide_witness(lurkhip_ctx* ctx, int32_t width, size_t n
 int32_t lurkhip_poseidon2_wide_witness_dev(lurkhip_ctx* ctx, int32_t width, size_t n, const uint32_t* in,
                                            uint32_t* out, int32_t repr);
 
+/* ------------------------------------------------------------------- commit */
+/* The commit stage of the STARK prover: coset low-degree extension of each trace matrix followed by
+ * one Poseidon2-width-16 Merkle tree over all of them.
+ * Replaces p3 TwoAdicFriPcs::commit (Radix2DitParallel::coset_lde_batch + FieldMerkleTreeMmcs::commit)
+ * as run by sphinx-core's `StarkMachine::prove::<LocalProver>` for the main / permutation / quotient
+ * traces (call site: /root/reference/benches/fib.rs:114-124, /root/reference/src/core/cli/repl.rs:196).
+ * The third-party sources are not in /root/reference: parity for this group is UNPINNED. */
+
+typedef struct lurkhip_commitment lurkhip_commitment;
+
+/* Installs the width-16 Poseidon2 parameters of the Merkle hash (canonical values): 8 x 16 external
+ * round constants, `rounds_p` (<= 32) internal ones, the 16-entry internal diagonal.  Default: the
+ * reference's BabyBearConfig16 (/root/reference/src/poseidon/config.rs:190-199).  A shim that wants
+ * sphinx's BabyBearPoseidon2 hash passes RC_16_30 and DiffusionMatrixBabyBear's diagonal here. */
+int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds_p, const uint32_t* ext_rc,
+                                     const uint32_t* int_rc, const uint32_t* diag);
+
+/* out = LDE of the (1 << log_n) x width matrix `in` (evaluations over the size-2^log_n subgroup, natural
+ * order) onto the coset 31 * <w_{2^(log_n+log_blowup)}>, rows in bit-reversed order;
+ * out is (1 << (log_n + log_blowup)) x width. */
+int32_t lurkhip_coset_lde(lurkhip_ctx* ctx, int32_t log_n, int32_t width, int32_t log_blowup, const uint32_t* in,
+                          uint32_t* out, int32_t repr);
+int32_t lurkhip_coset_lde_dev(lurkhip_ctx* ctx, int32_t log_n, int32_t width, int32_t log_blowup, const uint32_t* in,
+                              uint32_t* out, int32_t repr);
+
+/* Commits to n_mats matrices (matrix i is (1 << log_heights[i]) x widths[i], row-major); returns the
+ * 8-lane Merkle root and a handle that keeps the LDE matrices and every tree level on the device for
+ * later openings.  `mats` is a host array of host (lurkhip_commit) or device (lurkhip_commit_dev)
+ * pointers.  keep_coeffs != 0 also keeps the interpolated coefficient matrices. */
+int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, const uint32_t* log_heights,
+                       const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t keep_coeffs,
+                       lurkhip_commitment** out, uint32_t* root);
+int32_t lurkhip_commit_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev,
+                           const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
+                           int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root);
+int32_t lurkhip_commitment_free(lurkhip_ctx* ctx, lurkhip_commitment* c);
+int32_t lurkhip_commitment_root(lurkhip_ctx* ctx, lurkhip_commitment* c, uint32_t* root, int32_t repr);
+/* Device pointer (Montgomery form) and shape of the LDE of matrix `index`. */
+int32_t lurkhip_commitment_matrix_dev(lurkhip_ctx* ctx, lurkhip_commitment* c, int32_t index,
+                                      const uint32_t** lde_dev, uint32_t* log_height, uint32_t* width);
+/* Opens leaf `index` of the tallest LDE: the opened row of every matrix back to back (caller order;
+ * matrix m at row index >> (log_max - log_height_m)) and the log_max sibling digests, leaf level first. */
+int32_t lurkhip_commitment_open(lurkhip_ctx* ctx, lurkhip_commitment* c, uint64_t index, uint32_t* rows,
+                                uint32_t* path, int32_t repr);
+
 #ifdef __cplusplus
 }
 #endif

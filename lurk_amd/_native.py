@@ -38,6 +38,14 @@ if not os.path.exists(LIB_PATH):
         "(or `make -C lurk_amd/csrc`). lurk_amd has no CPU fallback."
     )
 
+# One HIP runtime per process: PyTorch-ROCm bundles its own libamdhip64.so.7 and a process that maps
+# both that copy and /opt/rocm's ends up with two runtimes, the second of which sees no devices.  When
+# torch is installed, load its runtime first so liblurkhip's DT_NEEDED libamdhip64.so.7 resolves to it.
+try:  # pragma: no cover - depends on the environment
+    import torch  # noqa: F401
+except Exception:  # torch is plumbing for device memory / torch.distributed, not a requirement
+    torch = None
+
 lib = C.CDLL(LIB_PATH)
 
 _p = C.c_void_p
@@ -67,6 +75,15 @@ SIGNATURES = {
     "lurkhip_poseidon2_hash8_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_wide_witness": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_wide_witness_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_set_merkle_poseidon2": (_i32, [_p, _i32, _u32p, _u32p, _u32p]),
+    "lurkhip_coset_lde": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
+    "lurkhip_coset_lde_dev": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
+    "lurkhip_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_commit_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_commitment_free": (_i32, [_p, _p]),
+    "lurkhip_commitment_root": (_i32, [_p, _p, _u32p, _i32]),
+    "lurkhip_commitment_matrix_dev": (_i32, [_p, _p, _i32, C.POINTER(_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "lurkhip_commitment_open": (_i32, [_p, _p, C.c_uint64, _u32p, _u32p, _i32]),
 }
 
 

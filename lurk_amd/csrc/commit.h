@@ -1,0 +1,54 @@
+// Internal interfaces of the commit pipeline (coset LDE + Poseidon2-16 Merkle tree).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "ctx.h"
+
+namespace lurkhip {
+
+// ---- NTT ---------------------------------------------------------------------
+struct NttPlan {
+    int log_n = 0;
+    uint32_t* tw_fwd = nullptr;  // w_N^i, i < N/2, Montgomery
+    uint32_t* tw_inv = nullptr;  // w_N^-i
+    int32_t init(lurkhip_ctx* ctx, int log_n);
+    void destroy();
+};
+
+uint32_t two_adic_generator_monty(int bits);
+int32_t fill_powers(lurkhip_ctx* ctx, uint32_t* out, uint32_t root_m, uint32_t scale_m, size_t count);
+int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* dst,
+                uint32_t* scratch, int w, const uint32_t* row_scale, bool in_canonical, bool out_canonical,
+                bool bitrev_store);
+
+// ---- Poseidon2 width-16 parameters for the Merkle hash (device resident, Montgomery) ----
+constexpr int P16_MAX_RP = 32;
+struct P16Params {
+    uint32_t ext_rc[8 * 16];
+    uint32_t int_rc[P16_MAX_RP];
+    uint32_t diag[16];
+    int32_t rounds_p;
+};
+
+// One matrix column of the concatenated leaf row (uniform descriptor, read through the scalar cache)
+struct LeafCol {
+    const uint32_t* base;
+    uint32_t width;
+    uint32_t col;
+};
+
+// digests[level] has (n_leaves >> level) entries of 8 words; stored back to back
+int32_t merkle_leaves(lurkhip_ctx* ctx, const P16Params* params_dev, const LeafCol* cols_dev, uint32_t total_w,
+                      size_t n_rows, uint32_t* digests_out);
+// parents[i] = compress(children[2i], children[2i+1]); if inject_cols: then compress(that, hash(row i))
+int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
+                     const LeafCol* inject_cols_dev, uint32_t inject_w, uint32_t* parents);
+// collapses the levels below `n` nodes down to the root inside one workgroup (n <= 2048, no injection)
+int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n);
+
+int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev);
+int32_t get_ntt_plan(lurkhip_ctx* ctx, int log_n, const NttPlan** out);
+
+}  // namespace lurkhip

@@ -1,0 +1,366 @@
+// C-ABI of the commit stage: coset LDE of every trace matrix + one mixed-height Merkle tree.
+//
+// Replaces (S1 in SURVEY.md 8a; third-party): p3 TwoAdicFriPcs::commit(Vec<(domain, RowMajorMatrix)>)
+// as called by sphinx's prover for the main, permutation and quotient traces [UPSTREAM-RECALL].
+#include <algorithm>
+#include <numeric>
+
+#include "babybear.h"
+#include "commit.h"
+
+struct lurkhip_commitment {
+    int n_mats = 0;
+    int log_blowup = 0;
+    std::vector<uint32_t*> lde;       // device, Montgomery, (1 << log_h[i]) x width[i]
+    std::vector<int> log_h;           // log2 of the LDE height
+    std::vector<uint32_t> width;
+    std::vector<uint32_t*> coeffs;    // device, Montgomery, natural-order coefficients (N x w), may be null
+    uint32_t* digests = nullptr;      // all levels back to back, level 0 first
+    std::vector<size_t> level_off;    // in digests (units of 8 words)
+    int log_max = 0;
+    std::vector<void*> owned;         // extra device allocations (column tables)
+};
+
+namespace lurkhip {
+
+int32_t get_ntt_plan(lurkhip_ctx* ctx, int log_n, const NttPlan** out) {
+    LH_ARG(ctx, log_n >= 0 && log_n <= bb::TWO_ADICITY, "log_n %d outside [0,27]", log_n);
+    if (!ctx->ntt_plans[log_n]) {
+        NttPlan* p = new NttPlan();
+        int32_t s = p->init(ctx, log_n);
+        if (s != LURKHIP_OK) {
+            delete p;
+            return s;
+        }
+        ctx->ntt_plans[log_n] = p;
+        ctx->cleanups.push_back([p]() {
+            p->destroy();
+            delete p;
+        });
+    }
+    *out = (const NttPlan*)ctx->ntt_plans[log_n];
+    return LURKHIP_OK;
+}
+
+namespace {
+
+uint32_t hpow(uint32_t a_m, uint64_t e) {
+    uint32_t r = bb::R1;
+    while (e) {
+        if (e & 1) r = bb::mul(r, a_m);
+        a_m = bb::mul(a_m, a_m);
+        e >>= 1;
+    }
+    return r;
+}
+
+uint32_t brev(uint32_t x, int bits) {
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+}
+
+// evaluations (natural order over H) -> coefficients (natural order), Montgomery, unscaled by 1/N.
+// `scratch` and `coef` are N x w device buffers.
+int32_t interpolate(lurkhip_ctx* ctx, int log_n, int w, const uint32_t* evals, bool canonical, uint32_t* scratch,
+                    uint32_t* coef) {
+    const NttPlan* plan = nullptr;
+    LH_TRY(get_ntt_plan(ctx, log_n, &plan));
+    return ntt_dif(ctx, *plan, /*inverse=*/true, evals, coef, scratch, w, nullptr, canonical, false, /*bitrev_store=*/true);
+}
+
+// coefficients -> LDE on the coset g * <w_{N << b}>, rows in bit-reversed order, Montgomery
+int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_t* coef, uint32_t* lde,
+               uint32_t* row_scale /* N words scratch */, bool out_canonical) {
+    const NttPlan* plan = nullptr;
+    LH_TRY(get_ntt_plan(ctx, log_n, &plan));
+    const size_t n = (size_t)1 << log_n;
+    const uint32_t n_inv = hpow(bb::to_monty((uint32_t)(n % bb::P)), bb::P - 2);
+    const uint32_t g = bb::to_monty(bb::GEN);
+    const uint32_t w_big = two_adic_generator_monty(log_n + log_blowup);
+    for (uint32_t q = 0; q < (1u << log_blowup); q++) {
+        uint32_t s_q = bb::mul(g, hpow(w_big, brev(q, log_blowup)));
+        LH_TRY(fill_powers(ctx, row_scale, s_q, n_inv, n));
+        LH_TRY(ntt_dif(ctx, *plan, /*inverse=*/false, coef, lde + q * n * w, nullptr, w, row_scale, false, out_canonical,
+                       /*bitrev_store=*/false));
+    }
+    return LURKHIP_OK;
+}
+
+void free_commitment(lurkhip_commitment* c) {
+    if (!c) return;
+    for (auto p : c->lde)
+        if (p) (void)hipFree(p);
+    for (auto p : c->coeffs)
+        if (p) (void)hipFree(p);
+    for (auto p : c->owned)
+        if (p) (void)hipFree(p);
+    if (c->digests) (void)hipFree(c->digests);
+    delete c;
+}
+
+// Build (on device) the uniform column table for the matrices in `idx`
+int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int>& idx, LeafCol** out_dev,
+                  uint32_t* total_w) {
+    std::vector<LeafCol> cols;
+    for (int m : idx)
+        for (uint32_t k = 0; k < c->width[m]; k++) cols.push_back(LeafCol{c->lde[m], c->width[m], k});
+    *total_w = (uint32_t)cols.size();
+    void* d = nullptr;
+    LH_HIP(ctx, hipMalloc(&d, std::max<size_t>(cols.size(), 1) * sizeof(LeafCol)));
+    c->owned.push_back(d);
+    if (!cols.empty())
+        LH_HIP(ctx, hipMemcpyAsync(d, cols.data(), cols.size() * sizeof(LeafCol), hipMemcpyHostToDevice, ctx->stream));
+    // the host vector dies at return: wait for the copy
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *out_dev = (LeafCol*)d;
+    return LURKHIP_OK;
+}
+
+int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
+    const P16Params* params = nullptr;
+    LH_TRY(get_merkle_params(ctx, &params));
+    c->log_max = *std::max_element(c->log_h.begin(), c->log_h.end());
+    // stable order by height, tallest first (p3 sorts matrices by height descending)
+    std::vector<int> order(c->n_mats);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return c->log_h[a] > c->log_h[b]; });
+    const size_t n_leaves = (size_t)1 << c->log_max;
+    c->level_off.assign(c->log_max + 1, 0);
+    size_t total = 0;
+    for (int l = 0; l <= c->log_max; l++) {
+        c->level_off[l] = total;
+        total += n_leaves >> l;
+    }
+    LH_HIP(ctx, hipMalloc((void**)&c->digests, total * 8 * sizeof(uint32_t)));
+    // leaves
+    std::vector<int> tallest;
+    for (int m : order)
+        if (c->log_h[m] == c->log_max) tallest.push_back(m);
+    LeafCol* cols = nullptr;
+    uint32_t tw = 0;
+    LH_TRY(make_cols(ctx, c, tallest, &cols, &tw));
+    LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
+    // inner levels
+    for (int l = 1; l <= c->log_max; l++) {
+        const size_t n_parents = n_leaves >> l;
+        const int lh = c->log_max - l;
+        std::vector<int> inject;
+        for (int m : order)
+            if (c->log_h[m] == lh) inject.push_back(m);
+        uint32_t* children = c->digests + c->level_off[l - 1] * 8;
+        uint32_t* parents = c->digests + c->level_off[l] * 8;
+        const int min_log_h = *std::min_element(c->log_h.begin(), c->log_h.end());
+        if (min_log_h > lh && (n_parents << 1) <= 2048) {
+            // nothing left to inject: finish the tree in one workgroup
+            LH_TRY(merkle_top(ctx, params, children, n_parents << 1));
+            break;
+        }
+        LeafCol* icols = nullptr;
+        uint32_t iw = 0;
+        if (!inject.empty()) LH_TRY(make_cols(ctx, c, inject, &icols, &iw));
+        LH_TRY(merkle_level(ctx, params, children, n_parents, icols, iw, parents));
+    }
+    return LURKHIP_OK;
+}
+
+int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
+                    const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
+    LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
+    LH_ARG(ctx, repr == LURKHIP_REPR_CANONICAL || repr == LURKHIP_REPR_MONTY, "bad repr %d", repr);
+    for (int i = 0; i < n_mats; i++) {
+        LH_ARG(ctx, mats[i] != nullptr && widths[i] > 0, "matrix %d is empty", i);
+        LH_ARG(ctx, (int)log_heights[i] + log_blowup <= bb::TWO_ADICITY, "matrix %d too tall", i);
+    }
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    lurkhip_commitment* c = new lurkhip_commitment();
+    c->n_mats = n_mats;
+    c->log_blowup = log_blowup;
+    c->lde.assign(n_mats, nullptr);
+    c->coeffs.assign(n_mats, nullptr);
+    c->log_h.resize(n_mats);
+    c->width.assign(widths, widths + n_mats);
+    auto fail = [&](int32_t s) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_commitment(c);
+        return s;
+    };
+#define TRY_C(expr)                          \
+    do {                                     \
+        int32_t s__ = (expr);                \
+        if (s__ != LURKHIP_OK) return fail(s__); \
+    } while (0)
+#define HIP_C(expr)                                                                                     \
+    do {                                                                                                \
+        hipError_t e__ = (expr);                                                                        \
+        if (e__ != hipSuccess)                                                                          \
+            return fail(set_error(ctx, e__ == hipErrorOutOfMemory ? LURKHIP_ERR_OOM : LURKHIP_ERR_HIP,  \
+                                  "%s failed: %s", #expr, hipGetErrorString(e__)));                     \
+    } while (0)
+
+    for (int i = 0; i < n_mats; i++) {
+        const int log_n = (int)log_heights[i];
+        const int w = (int)widths[i];
+        const size_t n = (size_t)1 << log_n;
+        const size_t bytes = n * w * sizeof(uint32_t);
+        c->log_h[i] = log_n + log_blowup;
+        HIP_C(hipMalloc((void**)&c->lde[i], bytes << log_blowup));
+        uint32_t* coef = nullptr;
+        HIP_C(hipMalloc((void**)&coef, bytes));
+        c->coeffs[i] = coef;
+        const uint32_t* src = mats[i];
+        void* staged = nullptr;
+        if (mats_on_host) {
+            TRY_C(arena_get(ctx, 0, bytes, &staged));
+            HIP_C(hipMemcpyAsync(staged, mats[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+            src = (const uint32_t*)staged;
+        }
+        void* scratch = nullptr;
+        void* row_scale = nullptr;
+        // the LDE buffer doubles as interpolation scratch when it is big enough (blow-up >= 1)
+        if (log_blowup >= 1) scratch = c->lde[i];
+        else TRY_C(arena_get(ctx, 1, bytes, &scratch));
+        TRY_C(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
+        TRY_C(interpolate(ctx, log_n, w, src, repr == LURKHIP_REPR_CANONICAL, (uint32_t*)scratch, coef));
+        TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false));
+        if (!keep_coeffs) {
+            HIP_C(hipStreamSynchronize(ctx->stream));
+            (void)hipFree(coef);
+            c->coeffs[i] = nullptr;
+        }
+    }
+    TRY_C(build_tree(ctx, c));
+    if (root) {
+        uint32_t r[8];
+        const uint32_t* droot = c->digests + c->level_off[c->log_max] * 8;
+        HIP_C(hipMemcpyAsync(r, droot, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+        HIP_C(hipStreamSynchronize(ctx->stream));
+        for (int k = 0; k < 8; k++) root[k] = repr == LURKHIP_REPR_CANONICAL ? bb::from_monty(r[k]) : r[k];
+    }
+#undef TRY_C
+#undef HIP_C
+    *out = c;
+    return LURKHIP_OK;
+}
+
+}  // namespace
+}  // namespace lurkhip
+
+using namespace lurkhip;
+
+extern "C" {
+
+int32_t lurkhip_coset_lde_dev(lurkhip_ctx* ctx, int32_t log_n, int32_t width, int32_t log_blowup, const uint32_t* in,
+                              uint32_t* out, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, log_n >= 0 && log_blowup >= 0 && log_n + log_blowup <= bb::TWO_ADICITY && width > 0, "bad LDE shape");
+    LH_ARG(ctx, in && out, "null buffer");
+    LH_ARG(ctx, repr == LURKHIP_REPR_CANONICAL || repr == LURKHIP_REPR_MONTY, "bad repr %d", repr);
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t n = (size_t)1 << log_n;
+    const size_t bytes = n * width * sizeof(uint32_t);
+    void *coef = nullptr, *scratch = nullptr, *row_scale = nullptr;
+    LH_TRY(arena_get(ctx, 1, bytes, &coef));
+    LH_TRY(arena_get(ctx, 3, bytes, &scratch));
+    LH_TRY(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
+    const bool canon = repr == LURKHIP_REPR_CANONICAL;
+    LH_TRY(interpolate(ctx, log_n, width, in, canon, (uint32_t*)scratch, (uint32_t*)coef));
+    LH_TRY(extend(ctx, log_n, width, log_blowup, (const uint32_t*)coef, out, (uint32_t*)row_scale, canon));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_coset_lde(lurkhip_ctx* ctx, int32_t log_n, int32_t width, int32_t log_blowup, const uint32_t* in,
+                          uint32_t* out, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, log_n >= 0 && log_blowup >= 0 && log_n + log_blowup <= bb::TWO_ADICITY && width > 0, "bad LDE shape");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const size_t bytes = ((size_t)1 << log_n) * width * sizeof(uint32_t);
+    void *din = nullptr, *dout = nullptr;
+    LH_HIP(ctx, hipMalloc(&din, bytes));
+    hipError_t e = hipMalloc(&dout, bytes << log_blowup);
+    if (e != hipSuccess) {
+        (void)hipFree(din);
+        return set_error(ctx, LURKHIP_ERR_OOM, "hipMalloc failed: %s", hipGetErrorString(e));
+    }
+    int32_t s = LURKHIP_OK;
+    if (hipMemcpyAsync(din, in, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
+        s = set_error(ctx, LURKHIP_ERR_HIP, "H2D copy failed");
+    if (s == LURKHIP_OK) s = lurkhip_coset_lde_dev(ctx, log_n, width, log_blowup, (const uint32_t*)din, (uint32_t*)dout, repr);
+    if (s == LURKHIP_OK && hipMemcpyAsync(out, dout, bytes << log_blowup, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        s = set_error(ctx, LURKHIP_ERR_HIP, "D2H copy failed");
+    (void)hipStreamSynchronize(ctx->stream);
+    (void)hipFree(din);
+    (void)hipFree(dout);
+    return s;
+}
+
+int32_t lurkhip_commit_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev, const uint32_t* log_heights,
+                           const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t keep_coeffs,
+                           lurkhip_commitment** out, uint32_t* root) {
+    return commit_impl(ctx, n_mats, mats_dev, false, log_heights, widths, log_blowup, repr, keep_coeffs, out, root);
+}
+
+int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, const uint32_t* log_heights,
+                       const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t keep_coeffs,
+                       lurkhip_commitment** out, uint32_t* root) {
+    return commit_impl(ctx, n_mats, mats, true, log_heights, widths, log_blowup, repr, keep_coeffs, out, root);
+}
+
+int32_t lurkhip_commitment_free(lurkhip_ctx* ctx, lurkhip_commitment* c) {
+    LH_CHECK_CTX(ctx);
+    if (!c) return LURKHIP_OK;
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    free_commitment(c);
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_commitment_matrix_dev(lurkhip_ctx* ctx, lurkhip_commitment* c, int32_t index, const uint32_t** lde_dev,
+                                      uint32_t* log_height, uint32_t* width) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, c && index >= 0 && index < c->n_mats, "bad matrix index %d", index);
+    if (lde_dev) *lde_dev = c->lde[index];
+    if (log_height) *log_height = (uint32_t)c->log_h[index];
+    if (width) *width = c->width[index];
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_commitment_root(lurkhip_ctx* ctx, lurkhip_commitment* c, uint32_t* root, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, c && root, "null argument");
+    uint32_t r[8];
+    LH_HIP(ctx, hipMemcpyAsync(r, c->digests + c->level_off[c->log_max] * 8, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (int k = 0; k < 8; k++) root[k] = repr == LURKHIP_REPR_CANONICAL ? bb::from_monty(r[k]) : r[k];
+    return LURKHIP_OK;
+}
+
+// Opens leaf `index` (a row index of the tallest LDE): writes the opened row of every matrix (in the
+// caller's matrix order, matrix m at row index >> (log_max - log_h[m])) back to back into `rows`, and
+// the log_max sibling digests (leaf level first) into `path`.
+int32_t lurkhip_commitment_open(lurkhip_ctx* ctx, lurkhip_commitment* c, uint64_t index, uint32_t* rows, uint32_t* path,
+                                int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, c && rows && path, "null argument");
+    LH_ARG(ctx, index < ((uint64_t)1 << c->log_max), "leaf index out of range");
+    size_t off = 0;
+    for (int m = 0; m < c->n_mats; m++) {
+        uint64_t r = index >> (c->log_max - c->log_h[m]);
+        LH_HIP(ctx, hipMemcpyAsync(rows + off, c->lde[m] + r * c->width[m], c->width[m] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        off += c->width[m];
+    }
+    for (int l = 0; l < c->log_max; l++) {
+        uint64_t sib = (index >> l) ^ 1;
+        LH_HIP(ctx, hipMemcpyAsync(path + l * 8, c->digests + (c->level_off[l] + sib) * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    if (repr == LURKHIP_REPR_CANONICAL) {
+        for (size_t i = 0; i < off; i++) rows[i] = bb::from_monty(rows[i]);
+        for (int i = 0; i < c->log_max * 8; i++) path[i] = bb::from_monty(path[i]);
+    }
+    return LURKHIP_OK;
+}
+
+}  // extern "C"

@@ -4,7 +4,9 @@
 
 #include <cstdarg>
 #include <cstdio>
+#include <functional>
 #include <string>
+#include <vector>
 
 #include "../../include/lurkhip.h"
 
@@ -17,6 +19,10 @@ struct lurkhip_ctx {
     // grow-only scratch arenas for the host-pointer entry points
     void* arena[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t arena_bytes[4] = {0, 0, 0, 0};
+    // lazily created per-ctx device state owned by other translation units (commit.h)
+    void* merkle_params_dev = nullptr;
+    void* ntt_plans[32] = {};
+    std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
 };
 
 namespace lurkhip {

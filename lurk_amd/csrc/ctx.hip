@@ -92,6 +92,7 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     if (!ctx) return LURKHIP_OK;
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
+    for (auto it = ctx->cleanups.rbegin(); it != ctx->cleanups.rend(); ++it) (*it)();
     for (int i = 0; i < 4; i++)
         if (ctx->arena[i]) (void)hipFree(ctx->arena[i]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);

@@ -1,0 +1,184 @@
+// Poseidon2-width-16 Merkle tree over row-major matrices (the MMCS of the commit stage).
+//
+// Replaces (S1 commit in SURVEY.md 8a; third-party, source absent from /root/reference):
+//   p3 FieldMerkleTreeMmcs<.., PaddingFreeSponge<Perm,16,8,8>, TruncatedPermutation<Perm,2,8,16>, 8>::commit
+//   [UPSTREAM-RECALL, Plonky3 @ a0b92870]:
+//   - leaf digest of row i = sponge over the concatenation of row i of every matrix of maximal height
+//     (rate 8, overwrite-absorb, permute after every full or final partial chunk, squeeze 8 lanes);
+//   - parent = first 8 lanes of Perm(left || right);
+//   - matrices of smaller height h are injected at the level with h nodes:
+//     node = compress(compress(left, right), sponge(row i of those matrices)).
+// The width-16 permutation parameters come from a per-ctx device table (P16Params) so a caller can
+// install sphinx's RC_16_30 / DiffusionMatrixBabyBear constants, which are not in /root/reference;
+// the default is the reference's own BabyBearConfig16 (src/poseidon/config.rs:190-199).
+//
+// One row (or one tree node) per lane; the 16-lane sponge state stays in VGPRs; the concatenated
+// row is described by a uniform LeafCol table read through the scalar cache, so the absorb loop
+// indexes the state with compile-time lane numbers (no scratch).  VALU-bound: ceil(w/8)
+// permutations (~9.2 k int32 instructions each) per w*4 bytes read.
+#include "commit.h"
+#include "poseidon2_dev.h"
+
+namespace lurkhip {
+
+namespace {
+
+constexpr int MBLOCK = 256;
+
+__device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
+    p2::NoRecord rec;
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, rec);
+}
+
+// sponge over the uniform column table for row `row`; state must be zero on entry
+__device__ __forceinline__ void sponge_row(uint32_t (&s)[16], const P16Params* __restrict__ p,
+                                           const LeafCol* __restrict__ cols, uint32_t total_w, size_t row) {
+    for (uint32_t g = 0; g < total_w; g += 8) {
+#pragma unroll
+        for (int j = 0; j < 8; j++) {
+            if (g + j < total_w) {
+                LeafCol d = cols[g + j];
+                s[j] = d.base[row * d.width + d.col];
+            }
+        }
+        perm16(s, p);
+    }
+}
+
+__global__ __launch_bounds__(MBLOCK) void k_leaves(const P16Params* __restrict__ p, const LeafCol* __restrict__ cols,
+                                                    uint32_t total_w, size_t n_rows, uint32_t* __restrict__ out) {
+    size_t row = (size_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (row >= n_rows) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    sponge_row(s, p, cols, total_w, row);
+    uint4* dst = reinterpret_cast<uint4*>(out + row * 8);
+    dst[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+__device__ __forceinline__ void load_pair(const uint32_t* __restrict__ children, size_t i, uint32_t (&s)[16]) {
+    const uint4* src = reinterpret_cast<const uint4*>(children + i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        uint4 v = src[k];
+        s[4 * k] = v.x;
+        s[4 * k + 1] = v.y;
+        s[4 * k + 2] = v.z;
+        s[4 * k + 3] = v.w;
+    }
+}
+
+__global__ __launch_bounds__(MBLOCK) void k_level(const P16Params* __restrict__ p, const uint32_t* __restrict__ children,
+                                                   size_t n_parents, const LeafCol* __restrict__ inject_cols,
+                                                   uint32_t inject_w, uint32_t* __restrict__ parents) {
+    size_t i = (size_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (i >= n_parents) return;
+    uint32_t s[16];
+    load_pair(children, i, s);
+    perm16(s, p);
+    if (inject_cols) {
+        uint32_t t[16];
+#pragma unroll
+        for (int k = 0; k < 16; k++) t[k] = 0;
+        sponge_row(t, p, inject_cols, inject_w, i);
+#pragma unroll
+        for (int k = 0; k < 8; k++) s[8 + k] = t[k];
+        perm16(s, p);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(parents + i * 8);
+    dst[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// Collapse n (<= 2048, power of two) nodes to the root in one workgroup.  The levels are stored back
+// to back after `level_base` exactly as the multi-launch path would store them.
+__global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, uint32_t* __restrict__ level_base, size_t n) {
+    uint32_t* cur = level_base;
+    size_t len = n;
+    while (len > 1) {
+        size_t half = len >> 1;
+        uint32_t* next = cur + len * 8;
+        for (size_t i = threadIdx.x; i < half; i += blockDim.x) {
+            uint32_t s[16];
+            load_pair(cur, i, s);
+            perm16(s, p);
+            uint4* dst = reinterpret_cast<uint4*>(next + i * 8);
+            dst[0] = make_uint4(s[0], s[1], s[2], s[3]);
+            dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
+        }
+        // same-workgroup hand-off through global memory: make the stores visible to the whole group
+        __threadfence_block();
+        __syncthreads();
+        cur = next;
+        len = half;
+    }
+}
+
+}  // namespace
+
+int32_t merkle_leaves(lurkhip_ctx* ctx, const P16Params* params_dev, const LeafCol* cols_dev, uint32_t total_w,
+                      size_t n_rows, uint32_t* digests_out) {
+    size_t blocks = (n_rows + MBLOCK - 1) / MBLOCK;
+    LH_ARG(ctx, blocks <= 0x7fffffffu, "too many Merkle leaves for one launch");
+    hipLaunchKernelGGL(k_leaves, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, cols_dev, total_w,
+                       n_rows, digests_out);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
+                     const LeafCol* inject_cols_dev, uint32_t inject_w, uint32_t* parents) {
+    size_t blocks = (n_parents + MBLOCK - 1) / MBLOCK;
+    hipLaunchKernelGGL(k_level, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents,
+                       inject_cols_dev, inject_w, parents);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n) {
+    LH_ARG(ctx, n <= 2048 && (n & (n - 1)) == 0, "merkle_top needs a power of two <= 2048");
+    if (n <= 1) return LURKHIP_OK;
+    hipLaunchKernelGGL(k_top, dim3(1), dim3(1024), 0, ctx->stream, params_dev, level_base, n);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev) {
+    if (!ctx->merkle_params_dev) {
+        P16Params h{};
+        for (int i = 0; i < 128; i++) h.ext_rc[i] = bb::c_to_monty(LURK_P2_EXT_RC_16[i]);
+        for (int i = 0; i < 13; i++) h.int_rc[i] = bb::c_to_monty(LURK_P2_INT_RC_16[i]);
+        for (int i = 0; i < 16; i++) h.diag[i] = bb::c_to_monty(LURK_P2_DIAG_16[i]);
+        h.rounds_p = 13;
+        void* d = nullptr;
+        LH_HIP(ctx, hipMalloc(&d, sizeof(P16Params)));
+        LH_HIP(ctx, hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        ctx->merkle_params_dev = d;
+        ctx->cleanups.push_back([d]() { (void)hipFree(d); });
+    }
+    *out_dev = (const P16Params*)ctx->merkle_params_dev;
+    return LURKHIP_OK;
+}
+
+}  // namespace lurkhip
+
+extern "C" int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds_p, const uint32_t* ext_rc,
+                                                const uint32_t* int_rc, const uint32_t* diag) {
+    using namespace lurkhip;
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, rounds_p > 0 && rounds_p <= P16_MAX_RP, "rounds_p must be in 1..%d", P16_MAX_RP);
+    LH_ARG(ctx, ext_rc && int_rc && diag, "null parameter table");
+    const P16Params* cur = nullptr;
+    LH_TRY(get_merkle_params(ctx, &cur));
+    P16Params h{};
+    for (int i = 0; i < 128; i++) h.ext_rc[i] = bb::to_monty(ext_rc[i] % bb::P);
+    for (int i = 0; i < rounds_p; i++) h.int_rc[i] = bb::to_monty(int_rc[i] % bb::P);
+    for (int i = 0; i < 16; i++) h.diag[i] = bb::to_monty(diag[i] % bb::P);
+    h.rounds_p = rounds_p;
+    LH_HIP(ctx, hipMemcpyAsync(ctx->merkle_params_dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}

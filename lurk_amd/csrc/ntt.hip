@@ -1,0 +1,237 @@
+// Coset low-degree extension of row-major trace matrices (radix-2 NTT over BabyBear).
+//
+// Replaces (S1 commit in SURVEY.md 8a; third-party, source absent from /root/reference):
+//   p3 TwoAdicFriPcs::commit -> Radix2DitParallel::coset_lde_batch(evals, log_blowup, shift = g)
+//   followed by .bit_reverse_rows()   [UPSTREAM-RECALL, Plonky3 @ a0b92870]
+// i.e. for an N x w matrix of evaluations over H = <w_N> (natural order) produce the (N << b) x w
+// matrix whose row bitrev(j) holds the column polynomials evaluated at g * w_{N<<b}^j, g = 31.
+//
+// Layout decision: everything stays row-major.  A butterfly couples two *rows*; the w columns of a
+// row are independent and contiguous, so lanes run along a row (coalesced w*4-byte segments) and no
+// transpose is ever needed between trace generation (row-major), LDE and Merkle leaf hashing
+// (row-major rows).  Each pass stages a tile of 2^LOG_R rows x C columns in LDS, runs LOG_R
+// decimation-in-frequency stages there, and writes the tile back: 3 passes for N = 2^20.
+//
+// LDE with blow-up 2^b is done as 2^b size-N transforms: block q of the bit-reversed output equals
+// DIF_N(c_i * s_q^i) with s_q = g * w_{N<<b}^{bitrev_b(q)} (the first b stages of the size-(N<<b)
+// DIF on zero-padded coefficients are trivial), so zero padding is never materialised.
+//
+// HBM traffic (algorithmic): iNTT 3 passes r+w over N*w*4 B, forward 2^b * 3 passes
+// r+w over N*w*4 B.
+#include <vector>
+
+#include "babybear.h"
+#include "commit.h"
+#include "ctx.h"
+
+namespace lurkhip {
+
+namespace {
+
+constexpr int NTT_BLOCK = 256;
+
+__host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    return bits == 0 ? 0u : (__brev(x) >> (32 - bits));
+#else
+    uint32_t r = 0;
+    for (int i = 0; i < bits; i++) r |= ((x >> i) & 1u) << (bits - 1 - i);
+    return r;
+#endif
+}
+
+// tw[i] = root^i for i < count (Montgomery), root given in Montgomery form
+__global__ void k_powers(uint32_t* __restrict__ out, uint32_t root_m, uint32_t scale_m, size_t count) {
+    size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    out[i] = bb::mul(bb::pow(root_m, (uint32_t)i), scale_m);
+}
+
+struct PassArgs {
+    const uint32_t* in;    // N x w
+    uint32_t* out;         // N x w (may alias in when !bitrev_store and in-place is wanted)
+    const uint32_t* tw;    // powers of the size-N root (or inverse root), N/2 entries, Montgomery
+    const uint32_t* row_scale;  // optional per-row multiplier applied on load (N entries) or nullptr
+    int log_n;
+    int w;
+    int bit_lo;        // lowest row-index bit handled by this pass
+    int log_r;         // number of stages (tile rows = 1 << log_r)
+    int col_chunk;     // columns per tile
+    int in_canonical;  // convert on load
+    int out_canonical; // convert on store
+    int bitrev_store;  // store row r at bitrev(r, log_n)
+};
+
+// One pass: tile = rows { hi << (bit_lo+log_r) | t << bit_lo | lo : t < 2^log_r } x col_chunk columns.
+__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
+    const int R = 1 << a.log_r;
+    const int n_col_chunks = (a.w + a.col_chunk - 1) / a.col_chunk;
+    const uint32_t tile_id = blockIdx.x / n_col_chunks;
+    const int chunk = blockIdx.x - tile_id * n_col_chunks;
+    const int col0 = chunk * a.col_chunk;
+    const int C = min(a.col_chunk, a.w - col0);
+    const uint32_t lo_mask = (1u << a.bit_lo) - 1u;
+    const uint32_t lo = tile_id & lo_mask;
+    const uint32_t hi = tile_id >> a.bit_lo;
+    const uint32_t row_base = (hi << (a.bit_lo + a.log_r)) | lo;
+
+    const int total = R * C;
+    // load
+    for (int e = threadIdx.x; e < total; e += NTT_BLOCK) {
+        int t = e / C, c = e - t * C;
+        uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
+        uint32_t v = a.in[(size_t)row * a.w + col0 + c];
+        if (a.in_canonical) v = bb::to_monty(v);
+        if (a.row_scale) v = bb::mul(v, a.row_scale[row]);
+        tile[e] = v;
+    }
+    __syncthreads();
+    // DIF stages: s = log_r-1 .. 0, pair distance 2^s tile rows
+    const int half_total = (R >> 1) * C;
+    for (int s = a.log_r - 1; s >= 0; s--) {
+        const int gs = a.bit_lo + s;                     // global stage: half-size 2^gs
+        const int tw_shift = a.log_n - gs - 1;           // w_{2h}^j = w_N^(j << tw_shift)
+        for (int e = threadIdx.x; e < half_total; e += NTT_BLOCK) {
+            int p = e / C, c = e - p * C;
+            int t_lo = p & ((1 << s) - 1);
+            int t = ((p >> s) << (s + 1)) | t_lo;
+            uint32_t j = ((uint32_t)t_lo << a.bit_lo) | lo;  // index inside the half-block
+            uint32_t twv = a.tw[(size_t)j << tw_shift];
+            int i0 = t * C + c, i1 = i0 + (C << s);
+            uint32_t x = tile[i0], y = tile[i1];
+            tile[i0] = bb::add(x, y);
+            tile[i1] = bb::mul(bb::sub(x, y), twv);
+        }
+        __syncthreads();
+    }
+    // store
+    for (int e = threadIdx.x; e < total; e += NTT_BLOCK) {
+        int t = e / C, c = e - t * C;
+        uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
+        if (a.bitrev_store) row = bitrev32(row, a.log_n);
+        uint32_t v = tile[e];
+        if (a.out_canonical) v = bb::from_monty(v);
+        a.out[(size_t)row * a.w + col0 + c] = v;
+    }
+}
+
+// canonical primitive 2^27-th root of unity used by p3 BabyBear: 0x1a427a41 [UPSTREAM-RECALL];
+// any generator of the 2-Sylow subgroup gives the same subgroup H, but the *order of rows* in the
+// LDE depends on which generator is used, so it is a parameter pinned here in one place.
+constexpr uint32_t TWO_ADIC_ROOT_27 = 0x1a427a41u;
+
+uint32_t host_pow(uint32_t a_m, uint64_t e) {
+    uint32_t r = bb::R1;
+    while (e) {
+        if (e & 1) r = bb::mul(r, a_m);
+        a_m = bb::mul(a_m, a_m);
+        e >>= 1;
+    }
+    return r;
+}
+
+}  // namespace
+
+uint32_t two_adic_generator_monty(int bits) {
+    // w_{2^bits} = root27^(2^(27-bits))
+    uint32_t r = bb::to_monty(TWO_ADIC_ROOT_27);
+    for (int i = bits; i < bb::TWO_ADICITY; i++) r = bb::mul(r, r);
+    return r;
+}
+
+int32_t NttPlan::init(lurkhip_ctx* ctx, int log_n_) {
+    log_n = log_n_;
+    size_t half = log_n > 0 ? ((size_t)1 << (log_n - 1)) : 1;
+    LH_HIP(ctx, hipMalloc(&tw_fwd, half * 4));
+    LH_HIP(ctx, hipMalloc(&tw_inv, half * 4));
+    uint32_t root = two_adic_generator_monty(log_n);
+    uint32_t root_inv = host_pow(root, bb::P - 2);
+    unsigned blocks = (unsigned)((half + 255) / 256);
+    hipLaunchKernelGGL(k_powers, dim3(blocks), dim3(256), 0, ctx->stream, tw_fwd, root, bb::R1, half);
+    hipLaunchKernelGGL(k_powers, dim3(blocks), dim3(256), 0, ctx->stream, tw_inv, root_inv, bb::R1, half);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+void NttPlan::destroy() {
+    if (tw_fwd) (void)hipFree(tw_fwd);
+    if (tw_inv) (void)hipFree(tw_inv);
+    tw_fwd = tw_inv = nullptr;
+}
+
+int32_t fill_powers(lurkhip_ctx* ctx, uint32_t* out, uint32_t root_m, uint32_t scale_m, size_t count) {
+    unsigned blocks = (unsigned)((count + 255) / 256);
+    hipLaunchKernelGGL(k_powers, dim3(blocks), dim3(256), 0, ctx->stream, out, root_m, scale_m, count);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+// Pass schedule: split log_n stage bits (from the top) into chunks of at most max_log_r.
+static void schedule(int log_n, int max_log_r, std::vector<std::pair<int, int>>& passes /* (bit_lo, log_r) */) {
+    passes.clear();
+    int remaining = log_n;
+    int n_pass = (log_n + max_log_r - 1) / max_log_r;
+    if (n_pass == 0) n_pass = 1;
+    int base = log_n / n_pass, extra = log_n % n_pass;
+    for (int p = 0; p < n_pass; p++) {
+        int lr = base + (p < extra ? 1 : 0);
+        remaining -= lr;
+        passes.push_back({remaining, lr});
+    }
+}
+
+// Full size-N DIF transform of an N x w row-major matrix.
+//   src -> dst, natural-order input; output bit-reversed, or natural when bitrev_store (the
+//   permutation is fused into the last pass's store).  `scratch` (N x w) is needed when more than one
+//   pass runs and the last pass scatters (it must not alias dst).  row_scale multiplies row i on load.
+int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* dst,
+                uint32_t* scratch, int w, const uint32_t* row_scale, bool in_canonical, bool out_canonical,
+                bool bitrev_store) {
+    const int log_n = plan.log_n;
+    if (log_n == 0) {
+        // 1 x w: identity (times scale)
+        PassArgs a{src, dst, plan.tw_fwd, row_scale, 0, w, 0, 0, w < 64 ? w : 64, in_canonical, out_canonical, 0};
+        int chunks = (w + a.col_chunk - 1) / a.col_chunk;
+        hipLaunchKernelGGL(k_ntt_pass, dim3(chunks), dim3(NTT_BLOCK), (size_t)a.col_chunk * 4, ctx->stream, a);
+        LH_HIP(ctx, hipGetLastError());
+        return LURKHIP_OK;
+    }
+    // tile budget: rows * cols * 4 B <= 64 KiB so two blocks fit a CU
+    int col_chunk = w < 96 ? w : 64;
+    int max_log_r = 7;
+    while (((size_t)1 << max_log_r) * col_chunk * 4 > 64 * 1024 && max_log_r > 1) max_log_r--;
+    std::vector<std::pair<int, int>> passes;
+    schedule(log_n, max_log_r, passes);
+    const int n_chunks = (w + col_chunk - 1) / col_chunk;
+    const uint32_t* cur_in = src;
+    for (size_t p = 0; p < passes.size(); p++) {
+        bool last = p + 1 == passes.size();
+        uint32_t* cur_out;
+        if (last) cur_out = dst;
+        else if (bitrev_store) cur_out = scratch;   // keep dst free for the final scatter
+        else cur_out = dst;                          // in-place chain inside dst
+        PassArgs a;
+        a.in = cur_in;
+        a.out = cur_out;
+        a.tw = inverse ? plan.tw_inv : plan.tw_fwd;
+        a.row_scale = p == 0 ? row_scale : nullptr;
+        a.log_n = log_n;
+        a.w = w;
+        a.bit_lo = passes[p].first;
+        a.log_r = passes[p].second;
+        a.col_chunk = col_chunk;
+        a.in_canonical = (p == 0 && in_canonical) ? 1 : 0;
+        a.out_canonical = (last && out_canonical) ? 1 : 0;
+        a.bitrev_store = (last && bitrev_store) ? 1 : 0;
+        size_t tiles = ((size_t)1 << (log_n - a.log_r)) * n_chunks;
+        LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
+        size_t lds = ((size_t)1 << a.log_r) * col_chunk * 4;
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_BLOCK), lds, ctx->stream, a);
+        LH_HIP(ctx, hipGetLastError());
+        cur_in = cur_out;
+    }
+    return LURKHIP_OK;
+}
+
+}  // namespace lurkhip

@@ -71,3 +71,57 @@ def p2_wide_witness(width: int, x) -> np.ndarray:
 
 def f_inv(a: int) -> int:
     return int(lib().or_f_inv(a))
+
+
+# ---- commit stage (PARITY UNPINNED, see oracle/commit.c) -------------------------------------
+
+def _setup_commit():
+    L = lib()
+    if getattr(L, "_commit_ready", False):
+        return L
+    for name in ("or_lde_naive", "or_lde_fft"):
+        f = getattr(L, name)
+        f.restype = C.c_int
+        f.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p]
+    L.or_merkle_commit.restype = C.c_int
+    L.or_merkle_commit.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
+    L.or_merkle_verify.restype = C.c_int
+    L.or_merkle_verify.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_uint64, C.c_void_p, C.c_void_p, C.c_void_p]
+    L._commit_ready = True
+    return L
+
+
+def lde(mat, log_blowup=1, naive=False) -> np.ndarray:
+    L = _setup_commit()
+    mat = _u32(mat)
+    n, w = mat.shape
+    log_n = n.bit_length() - 1
+    out = np.empty((n << log_blowup, w), dtype=np.uint32)
+    f = L.or_lde_naive if naive else L.or_lde_fft
+    assert f(log_n, w, log_blowup, mat.ctypes.data, out.ctypes.data) == 0
+    return out
+
+
+def merkle_commit(lde_mats):
+    """lde_mats: list of [2^k, w] arrays (already extended).  Returns (root, digests)."""
+    L = _setup_commit()
+    mats = [_u32(m) for m in lde_mats]
+    n = len(mats)
+    ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in mats])
+    lh = np.array([m.shape[0].bit_length() - 1 for m in mats], dtype=np.uint32)
+    ws = np.array([m.shape[1] for m in mats], dtype=np.uint32)
+    log_max = int(lh.max())
+    digests = np.zeros(((2 << log_max) - 1, 8), dtype=np.uint32)
+    root = np.zeros(8, dtype=np.uint32)
+    assert L.or_merkle_commit(n, C.cast(ptrs, C.c_void_p), lh.ctypes.data, ws.ctypes.data, digests.ctypes.data, root.ctypes.data) == 0
+    return root, digests
+
+
+def merkle_verify(log_heights, widths, index, rows, path, root) -> bool:
+    L = _setup_commit()
+    lh = np.asarray(log_heights, dtype=np.uint32)
+    ws = np.asarray(widths, dtype=np.uint32)
+    rows = _u32(rows)
+    path = _u32(path)
+    root = _u32(root)
+    return bool(L.or_merkle_verify(len(lh), lh.ctypes.data, ws.ctypes.data, index, rows.ctypes.data, path.ctypes.data, root.ctypes.data))
