@@ -76,6 +76,16 @@ int32_t lurkhip_memcpy_d2h(lurkhip_ctx* ctx, void* host_dst, const void* dev_src
 int32_t lurkhip_timer_start(lurkhip_ctx* ctx);
 int32_t lurkhip_timer_stop(lurkhip_ctx* ctx, float* elapsed_ms);
 
+/* Per-span device timing with HIP events on the ctx's stream.  While enabled, the library brackets its
+ * named stages ("lde", "merkle_leaves", "merkle_levels", "trace_func", ...) with event pairs;
+ * lurkhip_profile_read waits for the stream and returns the summed milliseconds and the number of
+ * brackets of one span since the last reset. */
+int32_t lurkhip_profile_enable(lurkhip_ctx* ctx, int32_t on);
+int32_t lurkhip_profile_reset(lurkhip_ctx* ctx);
+int32_t lurkhip_profile_read(lurkhip_ctx* ctx, const char* span, double* total_ms, int64_t* count);
+/* Returns cached device blocks of the ctx's allocation pool to the driver. */
+int32_t lurkhip_pool_trim(lurkhip_ctx* ctx);
+
 /* ---------------------------------------------------------------- Poseidon2 */
 /* Widths: 4, 8, ..., 48 (the reference's BabyBearConfig4..48,
  * /root/reference/src/poseidon/config.rs:157-287). */

@@ -68,6 +68,10 @@ SIGNATURES = {
     "lurkhip_memcpy_d2h": (_i32, [_p, _p, _p, _sz]),
     "lurkhip_timer_start": (_i32, [_p]),
     "lurkhip_timer_stop": (_i32, [_p, C.POINTER(C.c_float)]),
+    "lurkhip_profile_enable": (_i32, [_p, _i32]),
+    "lurkhip_profile_reset": (_i32, [_p]),
+    "lurkhip_profile_read": (_i32, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lurkhip_pool_trim": (_i32, [_p]),
     "lurkhip_poseidon2_num_cols": (_i32, [_i32]),
     "lurkhip_poseidon2_permute": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_permute_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),

@@ -68,6 +68,22 @@ class Context:
         self.check(N.lib.lurkhip_timer_stop(self.handle, C.byref(ms)))
         return float(ms.value)
 
+    def profile_enable(self, on: bool = True):
+        self.check(N.lib.lurkhip_profile_enable(self.handle, int(on)))
+
+    def profile_reset(self):
+        self.check(N.lib.lurkhip_profile_reset(self.handle))
+
+    def profile_read(self, span: str):
+        """(total_ms, count) of a named library span since the last reset."""
+        ms = C.c_double()
+        cnt = C.c_int64()
+        self.check(N.lib.lurkhip_profile_read(self.handle, span.encode(), C.byref(ms), C.byref(cnt)))
+        return float(ms.value), int(cnt.value)
+
+    def pool_trim(self):
+        self.check(N.lib.lurkhip_pool_trim(self.handle))
+
     # raw device memory (hosts without torch)
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()

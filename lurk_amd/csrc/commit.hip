@@ -19,6 +19,7 @@ struct lurkhip_commitment {
     std::vector<size_t> level_off;    // in digests (units of 8 words)
     int log_max = 0;
     std::vector<void*> owned;         // extra device allocations (column tables)
+    std::vector<std::vector<lurkhip::LeafCol>> host_cols;  // staging kept alive for the async copies
 };
 
 namespace lurkhip {
@@ -87,32 +88,28 @@ int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_
     return LURKHIP_OK;
 }
 
-void free_commitment(lurkhip_commitment* c) {
+void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     if (!c) return;
-    for (auto p : c->lde)
-        if (p) (void)hipFree(p);
-    for (auto p : c->coeffs)
-        if (p) (void)hipFree(p);
-    for (auto p : c->owned)
-        if (p) (void)hipFree(p);
-    if (c->digests) (void)hipFree(c->digests);
+    for (auto p : c->lde) pool_release(ctx, p);
+    for (auto p : c->coeffs) pool_release(ctx, p);
+    for (auto p : c->owned) pool_release(ctx, p);
+    pool_release(ctx, c->digests);
     delete c;
 }
 
 // Build (on device) the uniform column table for the matrices in `idx`
 int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int>& idx, LeafCol** out_dev,
                   uint32_t* total_w) {
-    std::vector<LeafCol> cols;
+    c->host_cols.emplace_back();
+    std::vector<LeafCol>& cols = c->host_cols.back();  // lives as long as the commitment
     for (int m : idx)
         for (uint32_t k = 0; k < c->width[m]; k++) cols.push_back(LeafCol{c->lde[m], c->width[m], k});
     *total_w = (uint32_t)cols.size();
     void* d = nullptr;
-    LH_HIP(ctx, hipMalloc(&d, std::max<size_t>(cols.size(), 1) * sizeof(LeafCol)));
+    LH_TRY(pool_alloc(ctx, std::max<size_t>(cols.size(), 1) * sizeof(LeafCol), &d));
     c->owned.push_back(d);
     if (!cols.empty())
         LH_HIP(ctx, hipMemcpyAsync(d, cols.data(), cols.size() * sizeof(LeafCol), hipMemcpyHostToDevice, ctx->stream));
-    // the host vector dies at return: wait for the copy
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *out_dev = (LeafCol*)d;
     return LURKHIP_OK;
 }
@@ -132,7 +129,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         c->level_off[l] = total;
         total += n_leaves >> l;
     }
-    LH_HIP(ctx, hipMalloc((void**)&c->digests, total * 8 * sizeof(uint32_t)));
+    LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
     // leaves
     std::vector<int> tallest;
     for (int m : order)
@@ -140,7 +137,10 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
     LH_TRY(make_cols(ctx, c, tallest, &cols, &tw));
+    span_begin(ctx, "merkle_leaves");
     LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
+    span_end(ctx, "merkle_leaves");
+    span_begin(ctx, "merkle_levels");
     // inner levels
     for (int l = 1; l <= c->log_max; l++) {
         const size_t n_parents = n_leaves >> l;
@@ -161,6 +161,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         if (!inject.empty()) LH_TRY(make_cols(ctx, c, inject, &icols, &iw));
         LH_TRY(merkle_level(ctx, params, children, n_parents, icols, iw, parents));
     }
+    span_end(ctx, "merkle_levels");
     return LURKHIP_OK;
 }
 
@@ -185,7 +186,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     c->width.assign(widths, widths + n_mats);
     auto fail = [&](int32_t s) {
         (void)hipStreamSynchronize(ctx->stream);
-        free_commitment(c);
+        free_commitment(ctx, c);
         return s;
     };
 #define TRY_C(expr)                          \
@@ -207,9 +208,9 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         const size_t n = (size_t)1 << log_n;
         const size_t bytes = n * w * sizeof(uint32_t);
         c->log_h[i] = log_n + log_blowup;
-        HIP_C(hipMalloc((void**)&c->lde[i], bytes << log_blowup));
+        TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
         uint32_t* coef = nullptr;
-        HIP_C(hipMalloc((void**)&coef, bytes));
+        TRY_C(pool_alloc(ctx, bytes, (void**)&coef));
         c->coeffs[i] = coef;
         const uint32_t* src = mats[i];
         void* staged = nullptr;
@@ -224,11 +225,12 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         if (log_blowup >= 1) scratch = c->lde[i];
         else TRY_C(arena_get(ctx, 1, bytes, &scratch));
         TRY_C(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
+        span_begin(ctx, "lde");
         TRY_C(interpolate(ctx, log_n, w, src, repr == LURKHIP_REPR_CANONICAL, (uint32_t*)scratch, coef));
         TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false));
+        span_end(ctx, "lde");
         if (!keep_coeffs) {
-            HIP_C(hipStreamSynchronize(ctx->stream));
-            (void)hipFree(coef);
+            pool_release(ctx, coef);  // stream-ordered: only later work can reuse it
             c->coeffs[i] = nullptr;
         }
     }
@@ -312,8 +314,7 @@ int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* 
 int32_t lurkhip_commitment_free(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     LH_CHECK_CTX(ctx);
     if (!c) return LURKHIP_OK;
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    free_commitment(c);
+    free_commitment(ctx, c);
     return LURKHIP_OK;
 }
 

@@ -5,6 +5,7 @@
 #include <cstdarg>
 #include <cstdio>
 #include <functional>
+#include <map>
 #include <string>
 #include <vector>
 
@@ -23,6 +24,18 @@ struct lurkhip_ctx {
     void* merkle_params_dev = nullptr;
     void* ntt_plans[32] = {};
     std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
+    // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)
+    std::multimap<size_t, void*> pool_free;
+    std::map<void*, size_t> pool_live;
+    // optional per-span HIP-event timing (lurkhip_profile_*)
+    bool profiling = false;
+    struct Span {
+        std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
+        double total_ms = 0;
+        long count = 0;
+    };
+    std::map<std::string, Span> spans;
+    std::vector<hipEvent_t> event_pool;
 };
 
 namespace lurkhip {
@@ -30,6 +43,12 @@ namespace lurkhip {
 int32_t set_error(lurkhip_ctx* ctx, int32_t code, const char* fmt, ...);
 // returns a device buffer of at least `bytes` from scratch slot `slot` (grown on demand)
 int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out);
+// pooled device allocations: released blocks are kept and reused for later requests of the same size
+int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
+void pool_release(lurkhip_ctx* ctx, void* ptr);
+// span timing (no-ops unless profiling is enabled)
+void span_begin(lurkhip_ctx* ctx, const char* name);
+void span_end(lurkhip_ctx* ctx, const char* name);
 
 }  // namespace lurkhip
 

@@ -39,6 +39,84 @@ int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out) {
     return LURKHIP_OK;
 }
 
+int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    auto it = ctx->pool_free.find(bytes);
+    if (it != ctx->pool_free.end()) {
+        *out = it->second;
+        ctx->pool_free.erase(it);
+        ctx->pool_live[*out] = bytes;
+        return LURKHIP_OK;
+    }
+    hipError_t e = hipMalloc(out, bytes);
+    if (e != hipSuccess && !ctx->pool_free.empty()) {
+        // give cached blocks back to the driver and retry once
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+        ctx->pool_free.clear();
+        e = hipMalloc(out, bytes);
+    }
+    if (e != hipSuccess)
+        return set_error(ctx, e == hipErrorOutOfMemory ? LURKHIP_ERR_OOM : LURKHIP_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes,
+                         hipGetErrorString(e));
+    ctx->pool_live[*out] = bytes;
+    return LURKHIP_OK;
+}
+
+// Stream-ordered reuse: a released block is only handed out again to work enqueued later on the
+// same stream, so no synchronisation is needed here.
+void pool_release(lurkhip_ctx* ctx, void* ptr) {
+    if (!ptr) return;
+    auto it = ctx->pool_live.find(ptr);
+    if (it == ctx->pool_live.end()) {
+        (void)hipFree(ptr);
+        return;
+    }
+    ctx->pool_free.insert({it->second, ptr});
+    ctx->pool_live.erase(it);
+}
+
+static hipEvent_t get_event(lurkhip_ctx* ctx) {
+    if (!ctx->event_pool.empty()) {
+        hipEvent_t e = ctx->event_pool.back();
+        ctx->event_pool.pop_back();
+        return e;
+    }
+    hipEvent_t e = nullptr;
+    (void)hipEventCreate(&e);
+    return e;
+}
+
+void span_begin(lurkhip_ctx* ctx, const char* name) {
+    if (!ctx->profiling) return;
+    hipEvent_t a = get_event(ctx), b = get_event(ctx);
+    (void)hipEventRecord(a, ctx->stream);
+    ctx->spans[name].pending.push_back({a, b});
+}
+
+void span_end(lurkhip_ctx* ctx, const char* name) {
+    if (!ctx->profiling) return;
+    auto& sp = ctx->spans[name];
+    if (sp.pending.empty()) return;
+    (void)hipEventRecord(sp.pending.back().second, ctx->stream);
+}
+
+static void spans_resolve(lurkhip_ctx* ctx) {
+    (void)hipStreamSynchronize(ctx->stream);
+    for (auto& kv : ctx->spans) {
+        for (auto& pr : kv.second.pending) {
+            float ms = 0;
+            if (hipEventElapsedTime(&ms, pr.first, pr.second) == hipSuccess) {
+                kv.second.total_ms += ms;
+                kv.second.count += 1;
+            }
+            ctx->event_pool.push_back(pr.first);
+            ctx->event_pool.push_back(pr.second);
+        }
+        kv.second.pending.clear();
+    }
+}
+
 static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkhip_ctx** out) {
     if (!out) return set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null out pointer");
     *out = nullptr;
@@ -93,6 +171,10 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     (void)hipSetDevice(ctx->device);
     (void)hipStreamSynchronize(ctx->stream);
     for (auto it = ctx->cleanups.rbegin(); it != ctx->cleanups.rend(); ++it) (*it)();
+    spans_resolve(ctx);
+    for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
     for (int i = 0; i < 4; i++)
         if (ctx->arena[i]) (void)hipFree(ctx->arena[i]);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
@@ -154,6 +236,42 @@ int32_t lurkhip_timer_stop(lurkhip_ctx* ctx, float* elapsed_ms) {
     LH_HIP(ctx, hipEventRecord(ctx->ev_stop, ctx->stream));
     LH_HIP(ctx, hipEventSynchronize(ctx->ev_stop));
     LH_HIP(ctx, hipEventElapsedTime(elapsed_ms, ctx->ev_start, ctx->ev_stop));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_profile_enable(lurkhip_ctx* ctx, int32_t on) {
+    LH_CHECK_CTX(ctx);
+    ctx->profiling = on != 0;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_profile_reset(lurkhip_ctx* ctx) {
+    LH_CHECK_CTX(ctx);
+    spans_resolve(ctx);
+    ctx->spans.clear();
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_profile_read(lurkhip_ctx* ctx, const char* span, double* total_ms, int64_t* count) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, span && total_ms && count, "null argument");
+    spans_resolve(ctx);
+    auto it = ctx->spans.find(span);
+    if (it == ctx->spans.end()) {
+        *total_ms = 0;
+        *count = 0;
+        return LURKHIP_OK;
+    }
+    *total_ms = it->second.total_ms;
+    *count = it->second.count;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_pool_trim(lurkhip_ctx* ctx) {
+    LH_CHECK_CTX(ctx);
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+    ctx->pool_free.clear();
     return LURKHIP_OK;
 }
 
