@@ -68,7 +68,7 @@ def main():
     ap.add_argument("--warmup", type=int, default=2)
     ap.add_argument("--log-rows", type=int, default=LOG_ROWS)
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-sample-log-rows", type=int, default=17)
+    ap.add_argument("--cpu-sample-log-rows", type=int, default=20)
     args = ap.parse_args()
 
     import torch

@@ -60,9 +60,16 @@ struct PassArgs {
     int in_canonical;  // convert on load
     int out_canonical; // convert on store
     int bitrev_store;  // store row r at bitrev(r, log_n)
+    uint32_t magic_c;  // ceil(2^32 / col_chunk): e / C == umulhi(e, magic) for e < 2^17, C < 2^10
+    uint32_t magic_c2; // same for C / 2 (two-column butterflies), 0 when C is odd
 };
 
+__device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
+    return c == 1 ? (int)e : (int)__umulhi(e, magic);
+}
+
 // One pass: tile = rows { hi << (bit_lo+log_r) | t << bit_lo | lo : t < 2^log_r } x col_chunk columns.
+// LDS: [R][C] tile followed by the pass's twiddles: tw_lds[(1 << s) + t_lo] for stage s.
 __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const int R = 1 << a.log_r;
@@ -71,15 +78,25 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
     const int chunk = blockIdx.x - tile_id * n_col_chunks;
     const int col0 = chunk * a.col_chunk;
     const int C = min(a.col_chunk, a.w - col0);
+    const bool full_chunk = C == a.col_chunk;
     const uint32_t lo_mask = (1u << a.bit_lo) - 1u;
     const uint32_t lo = tile_id & lo_mask;
     const uint32_t hi = tile_id >> a.bit_lo;
     const uint32_t row_base = (hi << (a.bit_lo + a.log_r)) | lo;
+    uint32_t* tw_lds = tile + R * a.col_chunk;
 
     const int total = R * C;
+    // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | lo
+    for (int k = threadIdx.x + 1; k < R; k += NTT_BLOCK) {
+        int s = 31 - __clz(k);
+        uint32_t t_lo = (uint32_t)k - (1u << s);
+        uint32_t j = (t_lo << a.bit_lo) | lo;
+        tw_lds[k] = a.tw[(size_t)j << (a.log_n - a.bit_lo - s - 1)];
+    }
     // load
     for (int e = threadIdx.x; e < total; e += NTT_BLOCK) {
-        int t = e / C, c = e - t * C;
+        int t = full_chunk ? fast_div(e, a.magic_c, C) : e / C;
+        int c = e - t * C;
         uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
         uint32_t v = a.in[(size_t)row * a.w + col0 + c];
         if (a.in_canonical) v = bb::to_monty(v);
@@ -88,26 +105,46 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
     }
     __syncthreads();
     // DIF stages: s = log_r-1 .. 0, pair distance 2^s tile rows
-    const int half_total = (R >> 1) * C;
-    for (int s = a.log_r - 1; s >= 0; s--) {
-        const int gs = a.bit_lo + s;                     // global stage: half-size 2^gs
-        const int tw_shift = a.log_n - gs - 1;           // w_{2h}^j = w_N^(j << tw_shift)
-        for (int e = threadIdx.x; e < half_total; e += NTT_BLOCK) {
-            int p = e / C, c = e - p * C;
-            int t_lo = p & ((1 << s) - 1);
-            int t = ((p >> s) << (s + 1)) | t_lo;
-            uint32_t j = ((uint32_t)t_lo << a.bit_lo) | lo;  // index inside the half-block
-            uint32_t twv = a.tw[(size_t)j << tw_shift];
-            int i0 = t * C + c, i1 = i0 + (C << s);
-            uint32_t x = tile[i0], y = tile[i1];
-            tile[i0] = bb::add(x, y);
-            tile[i1] = bb::mul(bb::sub(x, y), twv);
+    if (full_chunk && a.magic_c2) {
+        // two adjacent columns per lane (8-byte LDS accesses; C is even so rows stay 8-byte aligned)
+        const int C2 = C >> 1;
+        const int half_total = (R >> 1) * C2;
+        uint2* tile2 = reinterpret_cast<uint2*>(tile);
+        for (int s = a.log_r - 1; s >= 0; s--) {
+            for (int e = threadIdx.x; e < half_total; e += NTT_BLOCK) {
+                int p = fast_div(e, a.magic_c2, C2), c = e - p * C2;
+                int t_lo = p & ((1 << s) - 1);
+                int t = ((p >> s) << (s + 1)) | t_lo;
+                uint32_t twv = tw_lds[(1 << s) + t_lo];
+                int i0 = t * C2 + c, i1 = i0 + (C2 << s);
+                uint2 x = tile2[i0], y = tile2[i1];
+                tile2[i0] = make_uint2(bb::add(x.x, y.x), bb::add(x.y, y.y));
+                // (x - y + P) < 2P is a valid Montgomery operand next to a reduced twiddle
+                tile2[i1] = make_uint2(bb::mul(x.x + bb::P - y.x, twv), bb::mul(x.y + bb::P - y.y, twv));
+            }
+            __syncthreads();
         }
-        __syncthreads();
+    } else {
+        const int half_total = (R >> 1) * C;
+        for (int s = a.log_r - 1; s >= 0; s--) {
+            for (int e = threadIdx.x; e < half_total; e += NTT_BLOCK) {
+                int p = full_chunk ? fast_div(e, a.magic_c, C) : e / C;
+                int c = e - p * C;
+                int t_lo = p & ((1 << s) - 1);
+                int t = ((p >> s) << (s + 1)) | t_lo;
+                uint32_t twv = tw_lds[(1 << s) + t_lo];
+                int i0 = t * C + c, i1 = i0 + (C << s);
+                uint32_t x = tile[i0], y = tile[i1];
+                tile[i0] = bb::add(x, y);
+                tile[i1] = bb::mul(x + bb::P - y, twv);
+            }
+            __syncthreads();
+        }
     }
     // store
     for (int e = threadIdx.x; e < total; e += NTT_BLOCK) {
-        int t = e / C, c = e - t * C;
+        int t = full_chunk ? fast_div(e, a.magic_c, C) : e / C;
+        int c = e - t * C;
         uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
         if (a.bitrev_store) row = bitrev32(row, a.log_n);
         uint32_t v = tile[e];
@@ -115,6 +152,8 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
         a.out[(size_t)row * a.w + col0 + c] = v;
     }
 }
+
+static uint32_t magic_for(int c) { return c <= 1 ? 0u : (uint32_t)((((uint64_t)1 << 32) + c - 1) / c); }
 
 // canonical primitive 2^27-th root of unity used by p3 BabyBear: 0x1a427a41 [UPSTREAM-RECALL];
 // any generator of the 2-Sylow subgroup gives the same subgroup H, but the *order of rows* in the
@@ -191,9 +230,10 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
     const int log_n = plan.log_n;
     if (log_n == 0) {
         // 1 x w: identity (times scale)
-        PassArgs a{src, dst, plan.tw_fwd, row_scale, 0, w, 0, 0, w < 64 ? w : 64, in_canonical, out_canonical, 0};
+        PassArgs a{src, dst, plan.tw_fwd, row_scale, 0, w, 0, 0, w < 64 ? w : 64, in_canonical, out_canonical, 0, 0, 0};
+        a.magic_c = magic_for(a.col_chunk);
         int chunks = (w + a.col_chunk - 1) / a.col_chunk;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(chunks), dim3(NTT_BLOCK), (size_t)a.col_chunk * 4, ctx->stream, a);
+        hipLaunchKernelGGL(k_ntt_pass, dim3(chunks), dim3(NTT_BLOCK), (size_t)(a.col_chunk + 1) * 4, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         return LURKHIP_OK;
     }
@@ -224,9 +264,11 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         a.in_canonical = (p == 0 && in_canonical) ? 1 : 0;
         a.out_canonical = (last && out_canonical) ? 1 : 0;
         a.bitrev_store = (last && bitrev_store) ? 1 : 0;
+        a.magic_c = magic_for(col_chunk);
+        a.magic_c2 = (col_chunk % 2 == 0 && col_chunk >= 4) ? magic_for(col_chunk / 2) : 0;
         size_t tiles = ((size_t)1 << (log_n - a.log_r)) * n_chunks;
         LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
-        size_t lds = ((size_t)1 << a.log_r) * col_chunk * 4;
+        size_t lds = ((size_t)1 << a.log_r) * (col_chunk + 1) * 4;  // tile + per-pass twiddles
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_BLOCK), lds, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         cur_in = cur_out;
