@@ -165,6 +165,84 @@ int32_t lurkhip_commitment_matrix_dev(lurkhip_ctx* ctx, lurkhip_commitment* c, i
 int32_t lurkhip_commitment_open(lurkhip_ctx* ctx, lurkhip_commitment* c, uint64_t index, uint32_t* rows,
                                 uint32_t* path, int32_t repr);
 
+/* -------------------------------------------------------------------- traces */
+/* Low-level trace kernels (device pointers, asynchronous on the ctx stream).
+ *
+ * lurkhip_trace_func_dev fills the `height` x width FuncChip trace of one function from
+ *   - a degree-resolved micro-program (lurk_amd/csrc/lair/trace_program.h), resident on the device, with
+ *     its TH_WORDS-word header also readable on the host;
+ *   - per-row arrays for the n_real real rows: args [n][input], outputs [n][output], provides [n][2]
+ *     (last_nonce, last_count), depths [n] (partial functions, else NULL);
+ *   - a RowMeta[n] table + a word stream holding, per row, the hints (callee outputs / preimages / pointers /
+ *     loaded values / callee depths, in bytecode order), then its require records (nonce, count), then its
+ *     depth require records.
+ * Row i gets nonce nonce_start + i (padding rows included); everything else of a padding row is zero.
+ * Replaces FuncChip::generate_trace + populate_row, /root/reference/src/lair/trace.rs:72-135,145-418. */
+int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, const uint32_t* program_host_header,
+                               uint32_t n_real, uint32_t height, uint32_t nonce_start, const uint32_t* args_dev,
+                               const uint32_t* outputs_dev, const uint32_t* provides_dev, const uint32_t* depths_dev,
+                               const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr);
+/* MemChip rows [is_real, ptr, last_nonce, last_count, values...]: values [n_real][len], provides [n_real][2].
+ * Replaces MemChip::generate_trace, /root/reference/src/lair/memory.rs:30-69. */
+int32_t lurkhip_trace_mem_dev(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height,
+                              const uint32_t* values_dev, const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr);
+/* BytesChip main trace 65536 x 13 from records [65536][6][2] (range_u8, range_u16, less_than, and, xor, or).
+ * Replaces BytesChip::generate_trace, /root/reference/src/gadgets/bytes/trace.rs:75-101. */
+int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev,
+                                int32_t repr);
+/* BytesChip preprocessed trace 65536 x 6 [i1, i2, i1 < i2, and, xor, or].
+ * Replaces BaseAir::preprocessed_trace, /root/reference/src/gadgets/bytes/trace.rs:49-72. */
+int32_t lurkhip_trace_bytes_preprocessed_dev(lurkhip_ctx* ctx, uint32_t* out_dev, int32_t repr);
+
+/* --------------------------------------------------------------------- Lair */
+/* Host side of Lair (C++ here because the reference's Rust toolchain is absent): functions written in the
+ * surface syntax of the reference's `func!` macro are compiled to bytecode, executed by the memoising
+ * interpreter into a query record, and turned into traces on the device.
+ * Replaces Toplevel::new / execute, QueryRecord, FuncChip, MemChip, BytesChip, LairChip::generate_trace
+ * (/root/reference/src/lair/{toplevel,execute,func_chip,trace,memory,lair_chip}.rs). */
+typedef struct lurkhip_toplevel lurkhip_toplevel;
+typedef struct lurkhip_record lurkhip_record;
+
+/* with_lurk_chips != 0 registers the native chips of /root/reference/src/core/chipset.rs:28-63
+ * (hasher3/4/5, u64_*, big_num_lessthan) for extern_call. */
+int32_t lurkhip_toplevel_new(const char* source, int32_t with_lurk_chips, lurkhip_toplevel** out);
+int32_t lurkhip_toplevel_free(lurkhip_toplevel* top);
+int32_t lurkhip_toplevel_num_funcs(const lurkhip_toplevel* top);
+int32_t lurkhip_toplevel_func_index(const lurkhip_toplevel* top, const char* name);
+/* info[9] = input_size, output_size, partial, invertible, layout {nonce, input, output, aux, sel}
+ * (LayoutSizes, /root/reference/src/lair/func_chip.rs:11-26,90-116) */
+int32_t lurkhip_toplevel_func_info(const lurkhip_toplevel* top, int32_t func_idx, uint32_t* info);
+const char* lurkhip_lair_last_error(void);
+
+int32_t lurkhip_record_new(const lurkhip_toplevel* top, lurkhip_record** out);
+int32_t lurkhip_record_free(lurkhip_record* r);
+int32_t lurkhip_record_clean(lurkhip_record* r);
+/* Toplevel::execute: runs func on canonical args, memoising into the record; out gets output_size values.
+ * LURKHIP_ERR_EXEC carries the reference's bail!/panic cases ("Loop detected", failed assertions, ...). */
+int32_t lurkhip_execute(lurkhip_record* r, int32_t func_idx, const uint32_t* args, uint32_t n_args, uint32_t* out);
+int32_t lurkhip_record_inject_inv_query(lurkhip_record* r, int32_t func_idx, const uint32_t* inp, uint32_t n_inp,
+                                        const uint32_t* out, uint32_t n_out);
+/* kind 0: queries of func `index`; 1: entries of the mem table of length `index`; 2: number of public
+ * values (-1 if unset); 3: distinct byte-pair records; 4: emitted lists */
+int64_t lurkhip_record_count(const lurkhip_record* r, int32_t kind, int32_t index);
+int32_t lurkhip_record_public_values(const lurkhip_record* r, uint32_t* out);
+int64_t lurkhip_record_num_shards(const lurkhip_record* r, uint32_t max_shard_size);
+
+int32_t lurkhip_func_trace_shape(const lurkhip_record* r, int32_t func_idx, uint32_t shard_index,
+                                 uint32_t max_shard_size, uint32_t* n_real, uint32_t* height, uint32_t* width);
+int32_t lurkhip_generate_trace_func(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r,
+                                    int32_t func_idx, uint32_t shard_index, uint32_t max_shard_size,
+                                    uint32_t* out_host, int32_t repr);
+int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r,
+                                        int32_t func_idx, uint32_t shard_index, uint32_t max_shard_size,
+                                        uint32_t* out_dev, int32_t repr);
+int32_t lurkhip_mem_trace_shape(const lurkhip_record* r, uint32_t mem_len, uint32_t* n_real, uint32_t* height,
+                                uint32_t* width);
+int32_t lurkhip_generate_trace_mem(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t mem_len, uint32_t* out_host,
+                                   int32_t repr);
+int32_t lurkhip_generate_trace_bytes(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index,
+                                     uint32_t* out_host, int32_t repr);
+
 #ifdef __cplusplus
 }
 #endif

@@ -88,6 +88,30 @@ SIGNATURES = {
     "lurkhip_commitment_root": (_i32, [_p, _p, _u32p, _i32]),
     "lurkhip_commitment_matrix_dev": (_i32, [_p, _p, _i32, C.POINTER(_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "lurkhip_commitment_open": (_i32, [_p, _p, C.c_uint64, _u32p, _u32p, _i32]),
+    "lurkhip_trace_func_dev": (_i32, [_p, _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _p, _u32p, _u32p, _i32]),
+    "lurkhip_trace_mem_dev": (_i32, [_p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _u32p, _i32]),
+    "lurkhip_trace_bytes_dev": (_i32, [_p, _u32p, _i32, _u32p, _i32]),
+    "lurkhip_trace_bytes_preprocessed_dev": (_i32, [_p, _u32p, _i32]),
+    "lurkhip_toplevel_new": (_i32, [C.c_char_p, _i32, C.POINTER(_p)]),
+    "lurkhip_toplevel_free": (_i32, [_p]),
+    "lurkhip_toplevel_num_funcs": (_i32, [_p]),
+    "lurkhip_toplevel_func_index": (_i32, [_p, C.c_char_p]),
+    "lurkhip_toplevel_func_info": (_i32, [_p, _i32, _u32p]),
+    "lurkhip_lair_last_error": (C.c_char_p, []),
+    "lurkhip_record_new": (_i32, [_p, C.POINTER(_p)]),
+    "lurkhip_record_free": (_i32, [_p]),
+    "lurkhip_record_clean": (_i32, [_p]),
+    "lurkhip_execute": (_i32, [_p, _i32, _u32p, C.c_uint32, _u32p]),
+    "lurkhip_record_inject_inv_query": (_i32, [_p, _i32, _u32p, C.c_uint32, _u32p, C.c_uint32]),
+    "lurkhip_record_count": (_i64, [_p, _i32, _i32]),
+    "lurkhip_record_public_values": (_i32, [_p, _u32p]),
+    "lurkhip_record_num_shards": (_i64, [_p, C.c_uint32]),
+    "lurkhip_func_trace_shape": (_i32, [_p, _i32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "lurkhip_generate_trace_func": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, _u32p, _i32]),
+    "lurkhip_generate_trace_func_dev": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, _u32p, _i32]),
+    "lurkhip_mem_trace_shape": (_i32, [_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "lurkhip_generate_trace_mem": (_i32, [_p, _p, C.c_uint32, _u32p, _i32]),
+    "lurkhip_generate_trace_bytes": (_i32, [_p, _p, C.c_uint32, _u32p, _i32]),
 }
 
 

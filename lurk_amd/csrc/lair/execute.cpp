@@ -1,0 +1,523 @@
+// The memoising Lair interpreter and the host side of the extern chips.
+//
+// Follows /root/reference/src/lair/execute.rs:375-392,436-784 (explicit exec-entry stack and caller
+// stack, IndexMap nonces, `provide.count = 1` for the top-level query, depth bookkeeping for partial
+// functions) and the `execute` halves of /root/reference/src/core/{poseidon,u64}.rs.
+//
+// One addition to the reference's QueryResult: while a query executes, every value that
+// `populate_row` would later re-derive through hash-map lookups (callee outputs, preimages, store
+// pointers, loaded values, callee depths) is appended to `hints` in bytecode order.  The device trace
+// kernel then needs no lookups at all (DESIGN.md "row stream").
+#include <algorithm>
+#include <cstring>
+
+#include "../babybear.h"
+#include "../p2_params.h"
+#include "lair.h"
+
+namespace lair {
+
+// ------------------------------------------------------------------ byte records (gadgets/bytes/record.rs:112-158)
+void BytesRecord::range_check_u8_pair(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& rq) {
+    uint16_t key = (uint16_t)(i1 | (i2 << 8));
+    rq.push_back(records[key].range_u8.new_lookup(nonce));
+}
+void BytesRecord::range_check_u8_iter(const uint8_t* b, size_t n, uint32_t nonce, std::vector<Record>& rq) {
+    for (size_t i = 0; i < n; i += 2) range_check_u8_pair(b[i], i + 1 < n ? b[i + 1] : 0, nonce, rq);
+}
+bool BytesRecord::less_than(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& rq) {
+    uint16_t key = (uint16_t)(i1 | (i2 << 8));
+    rq.push_back(records[key].less_than.new_lookup(nonce));
+    return i1 < i2;
+}
+void BytesRecord::range_check_u16(uint16_t v, uint32_t nonce, std::vector<Record>& rq) {
+    rq.push_back(records[v].range_u16.new_lookup(nonce));
+}
+
+// ------------------------------------------------------------------ host Poseidon2 (for `execute` only)
+namespace {
+
+void host_external_layer(int w, uint32_t* s) {
+    for (int i = 0; i < w; i += 4) {
+        uint32_t x0 = s[i], x1 = s[i + 1], x2 = s[i + 2], x3 = s[i + 3];
+        uint32_t t01 = bb::add(x0, x1), t23 = bb::add(x2, x3), t0123 = bb::add(t01, t23);
+        uint32_t t01123 = bb::add(t0123, x1), t01233 = bb::add(t0123, x3);
+        s[i + 3] = bb::add(t01233, bb::dbl(x0));
+        s[i + 1] = bb::add(t01123, bb::dbl(x2));
+        s[i] = bb::add(t01123, t01);
+        s[i + 2] = bb::add(t01233, t23);
+    }
+    if (w == 4) return;
+    uint32_t sums[4] = {0, 0, 0, 0};
+    for (int i = 0; i < w; i++) sums[i & 3] = bb::add(sums[i & 3], s[i]);
+    for (int i = 0; i < w; i++) s[i] = bb::add(s[i], sums[i & 3]);
+}
+
+// canonical in / canonical out
+void host_poseidon2(int width, const uint32_t* in, uint32_t* out) {
+    const lurk_p2_param_row* row = nullptr;
+    for (int i = 0; i < LURK_P2_NUM_WIDTHS; i++)
+        if (LURK_P2_PARAMS[i].width == width) row = &LURK_P2_PARAMS[i];
+    if (!row) throw ExecError("unsupported Poseidon2 width");
+    uint32_t s[48];
+    for (int i = 0; i < width; i++) s[i] = bb::to_monty(in[i]);
+    auto sbox = [](uint32_t x) { return bb::pow7_from_cube(x, bb::cube(x)); };
+    host_external_layer(width, s);
+    for (int half = 0; half < 2; half++) {
+        for (int r = half * 4; r < half * 4 + 4; r++) {
+            for (int i = 0; i < width; i++) s[i] = sbox(bb::add(s[i], bb::to_monty(row->ext_rc[r * width + i])));
+            host_external_layer(width, s);
+        }
+        if (half == 0) {
+            for (int r = 0; r < row->rounds_p; r++) {
+                s[0] = sbox(bb::add(s[0], bb::to_monty(row->int_rc[r])));
+                uint32_t sum = 0;
+                for (int i = 0; i < width; i++) sum = bb::add(sum, s[i]);
+                for (int i = 0; i < width; i++) s[i] = bb::add(bb::mul(s[i], bb::to_monty(row->diag[i])), sum);
+            }
+        }
+    }
+    for (int i = 0; i < width; i++) out[i] = bb::from_monty(s[i]);
+}
+
+uint64_t into_u64(const uint32_t* v) {
+    uint64_t r = 0;
+    for (int i = 0; i < 8; i++) {
+        if (v[i] > 255) throw ExecError("u64 limb out of byte range");
+        r |= (uint64_t)v[i] << (8 * i);
+    }
+    return r;
+}
+List u64_bytes(uint64_t v) {
+    List r(8);
+    for (int i = 0; i < 8; i++) r[i] = (uint32_t)((v >> (8 * i)) & 0xff);
+    return r;
+}
+
+}  // namespace
+
+List Chip::execute(const List& input, uint32_t nonce, BytesRecord& bytes, std::vector<Record>& rq) const {
+    if (input.size() != input_size) throw ExecError("chip " + name + ": input size mismatch");
+    switch (kind) {
+        case CHIP_HASHER3:
+        case CHIP_HASHER4:
+        case CHIP_HASHER5: {
+            uint32_t out[48];
+            host_poseidon2((int)input_size, input.data(), out);
+            return List(out, out + 8);
+        }
+        case CHIP_U64_ADD:
+        case CHIP_U64_SUB: {
+            // Sum/Diff::populate: 8 result bytes, range-checked in pairs (unsigned/add.rs:65-78,120-133)
+            uint64_t a = into_u64(&input[0]), b = into_u64(&input[8]);
+            uint64_t r = kind == CHIP_U64_ADD ? a + b : a - b;
+            uint8_t by[8];
+            for (int i = 0; i < 8; i++) by[i] = (uint8_t)(r >> (8 * i));
+            bytes.range_check_u8_iter(by, 8, nonce, rq);
+            return u64_bytes(r);
+        }
+        case CHIP_U64_MUL: {
+            // Product::populate (unsigned/mul.rs:24-64,125-133): 8 u16 carry checks, then 4 byte-pair checks
+            uint64_t a = into_u64(&input[0]), b = into_u64(&input[8]);
+            uint32_t products[8] = {0};
+            for (int i = 0; i < 8; i++)
+                for (int j = 0; i + j < 8; j++) products[i + j] += ((a >> (8 * i)) & 0xff) * ((b >> (8 * j)) & 0xff);
+            uint16_t carry = 0;
+            uint8_t res[8];
+            for (int k = 0; k < 8; k++) {
+                uint32_t o = products[k] + carry;
+                res[k] = (uint8_t)(o & 0xff);
+                carry = (uint16_t)((o >> 8) & 0xffff);
+                bytes.range_check_u16(carry, nonce, rq);
+            }
+            bytes.range_check_u8_iter(res, 8, nonce, rq);
+            uint64_t r = 0;
+            for (int k = 0; k < 8; k++) r |= (uint64_t)res[k] << (8 * k);
+            return u64_bytes(r);
+        }
+        case CHIP_U64_LESSTHAN: {
+            // CompareWitness::populate (unsigned/cmp.rs:22-47): one less_than lookup on the most
+            // significant differing byte pair, or on (0, 0) when equal
+            uint64_t a = into_u64(&input[0]), b = into_u64(&input[8]);
+            for (int i = 7; i >= 0; i--) {
+                uint8_t l = (uint8_t)(a >> (8 * i)), r = (uint8_t)(b >> (8 * i));
+                if (l != r) {
+                    bool lt = bytes.less_than(l, r, nonce, rq);
+                    return List{lt ? 1u : 0u};
+                }
+            }
+            bytes.less_than(0, 0, nonce, rq);
+            return List{0u};
+        }
+        case CHIP_U64_ISZERO: {
+            uint64_t a = into_u64(&input[0]);
+            return List{a == 0 ? 1u : 0u};
+        }
+        default:
+            throw ExecError("extern chip " + name + " is not supported by this build");
+    }
+}
+
+std::vector<Chip> lurk_chip_map() {
+    // core/chipset.rs:28-63.  Sizes: core/poseidon.rs:44-59, core/u64.rs:46-83, SURVEY appendix B.
+    auto hasher = [](const char* n, ChipKind k, uint32_t w, uint32_t rp) {
+        Chip c;
+        c.name = n;
+        c.kind = k;
+        c.input_size = w;
+        c.output_size = 8;
+        c.witness_size = 8 + 16 * w + w + (rp - 1) + rp;
+        c.require_size = 0;
+        c.witness_return_size = w;  // populate_witness returns the whole state (core/poseidon.rs:71)
+        return c;
+    };
+    auto u64 = [](const char* n, ChipKind k, uint32_t in, uint32_t out, uint32_t wit, uint32_t req) {
+        Chip c;
+        c.name = n;
+        c.kind = k;
+        c.input_size = in;
+        c.output_size = out;
+        c.witness_size = wit;
+        c.require_size = req;
+        c.witness_return_size = out;
+        return c;
+    };
+    return {
+        hasher("hasher3", CHIP_HASHER3, 24, 21),
+        hasher("hasher4", CHIP_HASHER4, 32, 30),
+        hasher("hasher5", CHIP_HASHER5, 40, 38),
+        u64("u64_add", CHIP_U64_ADD, 16, 8, 8, 4),
+        u64("u64_sub", CHIP_U64_SUB, 16, 8, 8, 4),
+        u64("u64_mul", CHIP_U64_MUL, 16, 8, 16, 12),
+        u64("u64_divrem", CHIP_U64_DIVREM, 16, 16, 0, 0),  // sizes filled in when the gadget lands
+        u64("u64_lessthan", CHIP_U64_LESSTHAN, 16, 1, 12, 1),
+        u64("u64_iszero", CHIP_U64_ISZERO, 8, 1, 9, 0),
+        u64("big_num_lessthan", CHIP_BIGNUM_LESSTHAN, 16, 1, 0, 0),
+    };
+}
+
+// ------------------------------------------------------------------ query maps
+uint32_t QueryMap::insert_full(const List& k, QueryResult v) {
+    auto it = index.find(k);
+    if (it != index.end()) {
+        vals[it->second] = std::move(v);
+        return it->second;
+    }
+    uint32_t i = (uint32_t)keys.size();
+    keys.push_back(k);
+    vals.push_back(std::move(v));
+    index.emplace(k, i);
+    return i;
+}
+
+QueryRecord::QueryRecord(const Toplevel& t) {
+    func_queries.resize(t.funcs.size());
+    for (const auto& f : t.funcs) {
+        if (f.invertible) inv_func_queries.emplace_back(new std::unordered_map<List, List, VecHash>());
+        else inv_func_queries.emplace_back(nullptr);
+    }
+    mem_queries.resize(NUM_MEM_TABLES);
+}
+
+void QueryRecord::clean() {
+    for (auto& q : func_queries) q.clear();
+    for (auto& q : mem_queries) q.clear();
+    bytes.records.clear();
+    emitted.clear();
+}
+
+void QueryRecord::inject_inv_query(uint32_t func_idx, const List& inp, const List& out) {
+    if (func_idx >= inv_func_queries.size() || !inv_func_queries[func_idx]) throw ExecError("Inverse query map not found");
+    (*inv_func_queries[func_idx])[out] = inp;
+}
+
+size_t num_shards(const QueryRecord& r, uint32_t max_shard_size) {
+    size_t mx = 0;
+    for (const auto& q : r.func_queries) mx = std::max(mx, q.size());
+    return mx / max_shard_size + (mx % max_shard_size ? 1 : 0);
+}
+
+// ------------------------------------------------------------------ the interpreter (execute.rs:436-784)
+namespace {
+
+struct ExecEntry {
+    const Op* op;      // non-null: an op
+    const Ctrl* ctrl;  // non-null: a ctrl
+};
+
+struct CallerState {
+    bool preimg;
+    uint32_t func_index;
+    uint32_t nonce;
+    List map;
+    std::vector<Record> requires_;
+    bool partial;
+    std::vector<uint32_t> depths;
+    std::vector<Record> depth_requires;
+    List hints;
+};
+
+void depth_less_than_populate(uint32_t lhs, uint32_t rhs, BytesRecord& bytes, uint32_t nonce, std::vector<Record>& rq) {
+    // LessThanWitness::populate (unsigned/less_than.rs:20-41): one less_than lookup on the most
+    // significant differing byte
+    if (!(lhs < rhs)) throw ExecError("depth ordering violated");
+    for (int i = DEPTH_W - 1; i >= 0; i--) {
+        uint8_t l = (uint8_t)(lhs >> (8 * i)), r = (uint8_t)(rhs >> (8 * i));
+        if (l != r) {
+            bytes.less_than(l, r, nonce, rq);
+            return;
+        }
+    }
+}
+
+}  // namespace
+
+static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& self, const List& args, QueryRecord& q) {
+    uint32_t func_index = self.index;
+    {
+        QueryResult top;
+        top.provide.count = 1;
+        q.func_queries[func_index].insert_full(args, std::move(top));
+    }
+    uint32_t nonce = (uint32_t)q.func_queries[func_index].find(args);
+    List map = args;
+    std::vector<Record> requires_;
+    bool partial = self.partial;
+    std::vector<uint32_t> depths;
+    std::vector<Record> depth_requires;
+    List hints;
+
+    std::vector<ExecEntry> stack;
+    std::vector<CallerState> callers;
+    auto push_block = [&](const Block& b) {
+        stack.push_back(ExecEntry{nullptr, &b.ctrl});
+        for (auto it = b.ops.rbegin(); it != b.ops.rend(); ++it) stack.push_back(ExecEntry{&*it, nullptr});
+    };
+    push_block(self.body);
+
+    auto enter = [&](bool preimg, uint32_t callee_index, List inp) {
+        uint32_t callee_nonce = q.func_queries[callee_index].insert_full(inp, QueryResult());
+        CallerState cs;
+        cs.preimg = preimg;
+        cs.func_index = func_index;
+        cs.nonce = nonce;
+        cs.map.swap(map);
+        cs.requires_.swap(requires_);
+        cs.partial = partial;
+        cs.depths.swap(depths);
+        cs.depth_requires.swap(depth_requires);
+        cs.hints.swap(hints);
+        callers.push_back(std::move(cs));
+        map = std::move(inp);
+        func_index = callee_index;
+        nonce = callee_nonce;
+        const Func& f = t.funcs[func_index];
+        partial = f.partial;
+        push_block(f.body);
+    };
+
+    while (!stack.empty()) {
+        ExecEntry e = stack.back();
+        stack.pop_back();
+        if (e.op) {
+            const Op& op = *e.op;
+            switch (op.kind) {
+                case OpKind::AssertEq:
+                    for (size_t i = 0; i < op.a.size(); i++)
+                        if (map[op.a[i]] != map[op.b[i]]) throw ExecError("assert_eq! failed in " + t.funcs[func_index].name);
+                    break;
+                case OpKind::AssertNe: {
+                    bool unequal = false;
+                    for (size_t i = 0; i < op.a.size(); i++)
+                        if (map[op.a[i]] != map[op.b[i]]) {
+                            unequal = true;
+                            break;
+                        }
+                    if (!unequal) throw ExecError("assert_ne! failed in " + t.funcs[func_index].name);
+                    break;
+                }
+                case OpKind::Contains: {
+                    bool found = false;
+                    for (uint32_t a : op.a) found = found || map[a] == map[op.y];
+                    if (!found) throw ExecError("contains! failed in " + t.funcs[func_index].name);
+                    break;
+                }
+                case OpKind::Call:
+                case OpKind::PreImg: {
+                    const bool pre = op.kind == OpKind::PreImg;
+                    const uint32_t callee = op.x;
+                    List key;
+                    for (uint32_t v : op.a) key.push_back(map[v]);
+                    List inp;
+                    if (pre) {
+                        auto& inv = q.inv_func_queries[callee];
+                        if (!inv) throw ExecError("Missing inverse map");
+                        auto it = inv->find(key);
+                        if (it == inv->end()) throw ExecError("Preimg not found");
+                        inp = it->second;
+                    } else {
+                        inp = key;
+                    }
+                    int idx = q.func_queries[callee].find(inp);
+                    if (idx >= 0) {
+                        QueryResult& res = q.func_queries[callee].vals[idx];
+                        if (!res.has_output) throw ExecError("Loop detected");
+                        if (pre && res.output != key) throw ExecError("memoized output differs from preimage key");
+                        const List& ext = pre ? inp : res.output;
+                        map.insert(map.end(), ext.begin(), ext.end());
+                        hints.insert(hints.end(), ext.begin(), ext.end());
+                        requires_.push_back(res.provide.new_lookup(nonce));
+                        const bool callee_partial = t.funcs[callee].partial;
+                        if (callee_partial) hints.push_back(res.depth);
+                        if (partial && callee_partial) depths.push_back(res.depth);
+                    } else {
+                        enter(pre, callee, std::move(inp));
+                    }
+                    break;
+                }
+                case OpKind::Const:
+                    map.push_back(op.c);
+                    break;
+                case OpKind::Add:
+                    map.push_back(fadd(map[op.x], map[op.y]));
+                    break;
+                case OpKind::Sub:
+                    map.push_back(fsub(map[op.x], map[op.y]));
+                    break;
+                case OpKind::Mul:
+                    map.push_back(fmul(map[op.x], map[op.y]));
+                    break;
+                case OpKind::Inv:
+                    map.push_back(finv(map[op.x]));
+                    break;
+                case OpKind::Not:
+                    map.push_back(map[op.x] == 0 ? 1u : 0u);
+                    break;
+                case OpKind::Store: {
+                    List vals;
+                    for (uint32_t v : op.a) vals.push_back(map[v]);
+                    QueryMap& mm = q.mem_queries[mem_index_from_len((uint32_t)vals.size())];
+                    int i = mm.find(vals);
+                    if (i < 0) i = (int)mm.insert_full(vals, QueryResult());
+                    uint32_t ptr = (uint32_t)(i + 1);
+                    map.push_back(ptr);
+                    hints.push_back(ptr);
+                    requires_.push_back(mm.vals[i].provide.new_lookup(nonce));
+                    break;
+                }
+                case OpKind::Load: {
+                    uint32_t ptr = map[op.y];
+                    QueryMap& mm = q.mem_queries[mem_index_from_len(op.x)];
+                    if (ptr == 0 || ptr > mm.size()) throw ExecError("Unbound pointer");
+                    const List& vals = mm.keys[ptr - 1];
+                    map.insert(map.end(), vals.begin(), vals.end());
+                    hints.insert(hints.end(), vals.begin(), vals.end());
+                    requires_.push_back(mm.vals[ptr - 1].provide.new_lookup(nonce));
+                    break;
+                }
+                case OpKind::ExternCall: {
+                    List in;
+                    for (uint32_t v : op.a) in.push_back(map[v]);
+                    List out = t.chips[op.x].execute(in, nonce, q.bytes, requires_);
+                    map.insert(map.end(), out.begin(), out.end());
+                    break;
+                }
+                case OpKind::Emit: {
+                    List v;
+                    for (uint32_t a : op.a) v.push_back(map[a]);
+                    q.emitted.push_back(v);
+                    break;
+                }
+                case OpKind::RangeU8: {
+                    std::vector<uint8_t> by;
+                    for (uint32_t a : op.a) {
+                        if (map[a] > 255) throw ExecError("Variable not in u8 range");
+                        by.push_back((uint8_t)map[a]);
+                    }
+                    q.bytes.range_check_u8_iter(by.data(), by.size(), nonce, requires_);
+                    break;
+                }
+                case OpKind::Breakpoint:
+                case OpKind::Debug:
+                    break;
+            }
+            continue;
+        }
+        const Ctrl& c = *e.ctrl;
+        if (c.kind == Ctrl::Choose) {
+            const Block* b = c.match_case(List{map[c.var]});
+            if (!b) throw ExecError("No match");
+            push_block(*b);
+            continue;
+        }
+        if (c.kind == Ctrl::ChooseMany) {
+            List k;
+            for (uint32_t v : c.vars) k.push_back(map[v]);
+            const Block* b = c.match_case(k);
+            if (!b) throw ExecError("No match");
+            push_block(*b);
+            continue;
+        }
+        // Return
+        List out;
+        for (uint32_t v : c.ret) out.push_back(map[v]);
+        QueryMap& qm = q.func_queries[func_index];
+        QueryResult& result = qm.vals[nonce];
+        if (result.has_output) throw ExecError("query evaluated twice");
+        const List inp = qm.keys[nonce];
+        if (q.inv_func_queries[func_index]) (*q.inv_func_queries[func_index])[out] = inp;
+        if (partial) {
+            uint32_t depth = 0;
+            for (uint32_t d : depths) depth = std::max(depth, d + 1);
+            uint8_t by[4] = {(uint8_t)depth, (uint8_t)(depth >> 8), (uint8_t)(depth >> 16), (uint8_t)(depth >> 24)};
+            q.bytes.range_check_u8_iter(by, 4, nonce, depth_requires);
+            for (uint32_t d : depths) depth_less_than_populate(d, depth, q.bytes, nonce, depth_requires);
+            result.depth = depth;
+        }
+        result.output = out;
+        result.has_output = true;
+        result.requires_ = std::move(requires_);
+        result.depth_requires = std::move(depth_requires);
+        result.hints = std::move(hints);
+        if (callers.empty()) {
+            if (!stack.empty()) throw ExecError("exec stack not empty at exit");
+            uint32_t depth = 0;
+            for (uint32_t d : depths) depth = std::max(depth, d + 1);
+            return {out, depth};
+        }
+        CallerState cs = std::move(callers.back());
+        callers.pop_back();
+        const bool callee_partial = partial;
+        const uint32_t callee_depth = result.depth;
+        func_index = cs.func_index;
+        nonce = cs.nonce;
+        map = std::move(cs.map);
+        requires_ = std::move(cs.requires_);
+        partial = cs.partial;
+        depths = std::move(cs.depths);
+        depth_requires = std::move(cs.depth_requires);
+        hints = std::move(cs.hints);
+        const List& ext = cs.preimg ? inp : out;
+        map.insert(map.end(), ext.begin(), ext.end());
+        hints.insert(hints.end(), ext.begin(), ext.end());
+        // `result` may have moved if the callee's table grew: it cannot have (same table slot, no
+        // insertion between the Return and here), so the reference stays valid
+        requires_.push_back(result.provide.new_lookup(nonce));
+        if (callee_partial) hints.push_back(callee_depth);
+        if (partial && callee_partial) depths.push_back(callee_depth);
+    }
+    throw ExecError("exec stack exhausted without a return");
+}
+
+List execute(const Toplevel& t, const Func& func, const List& args, QueryRecord& record) {
+    if (args.size() != func.input_size) throw ExecError("Argument mismatch");
+    auto [out, depth] = func_execute(t, func, args, record);
+    record.public_values = args;
+    record.public_values.insert(record.public_values.end(), out.begin(), out.end());
+    if (func.partial)
+        for (int i = 0; i < 4; i++) record.public_values.push_back((depth >> (8 * i)) & 0xff);
+    record.has_public_values = true;
+    return out;
+}
+
+}  // namespace lair

@@ -1,0 +1,284 @@
+// Lair on the host: IR, bytecode, toplevel, interpreter state and column layout.
+//
+// Host-side mirror (C++, because the reference's Rust toolchain is absent here) of the parts of
+// /root/reference/src/lair/ that feed the trace kernels:
+//   expr.rs      -> FuncE / BlockE / OpE / CtrlE          (named IR)
+//   macros.rs    -> parse_funcs(): a text form of the `func!` DSL with the same surface syntax
+//   toplevel.rs  -> Toplevel: expand + compile to index-based bytecode (toplevel.rs:241-879)
+//   bytecode.rs  -> Func / Block / Op / Ctrl
+//   execute.rs   -> QueryRecord, execute() (memoising interpreter, execute.rs:436-784), sharding
+//   func_chip.rs -> LayoutSizes, compute_layout_sizes (func_chip.rs:90-276)
+// Values are canonical BabyBear u32 on the host; the device converts at its boundary.
+#pragma once
+#include <stdint.h>
+
+#include <map>
+#include <memory>
+#include <stdexcept>
+#include <string>
+#include <unordered_map>
+#include <vector>
+
+#include "trace_program.h"
+
+namespace lair {
+
+constexpr uint32_t P = 2013265921u;
+inline uint32_t fadd(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + b) % P); }
+inline uint32_t fsub(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + P - b) % P); }
+inline uint32_t fmul(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); }
+uint32_t finv(uint32_t a);  // panics (throws) on zero like p3's inverse()
+inline uint32_t field_from_i64(int64_t v) {
+    int64_t m = v % (int64_t)P;
+    if (m < 0) m += P;
+    return (uint32_t)m;
+}
+
+struct ExecError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+struct ParseError : std::runtime_error {
+    using std::runtime_error::runtime_error;
+};
+
+using List = std::vector<uint32_t>;
+
+// ---------------------------------------------------------------- IR (expr.rs)
+struct Var {
+    std::string name;  // user names as written; internal names start with '$'
+    int size = 1;
+    bool operator==(const Var& o) const { return name == o.name && size == o.size; }
+};
+
+enum class OpEKind {
+    AssertEq, AssertNe, Contains, Const, Array, Add, Sub, Mul, Div, Inv, Not, Eq,
+    Call, PreImg, Store, Load, Slice, ExternCall, Emit, RangeU8, Breakpoint, Debug
+};
+
+struct OpE {
+    OpEKind kind;
+    std::vector<Var> out;   // targets (Const/Array/arith: 1; Call/Load/...: n)
+    std::vector<Var> in;    // operands
+    std::string name;       // callee / chip name
+    List consts;            // Const (1) / Array (n)
+};
+
+enum class CaseType { Constrained, Unconstrained };
+
+struct BlockE;
+struct CaseE {
+    List keys;  // Match: all values mapping to this branch; MatchMany: one pattern
+    std::shared_ptr<BlockE> block;
+    CaseType constrained = CaseType::Constrained;
+};
+
+enum class CtrlEKind { Match, MatchMany, Choose, ChooseMany, If, Return };
+
+struct CtrlE {
+    CtrlEKind kind = CtrlEKind::Return;
+    Var var;                        // scrutinee
+    std::vector<CaseE> branches;    // for If: unused
+    std::shared_ptr<BlockE> def;    // default case
+    CaseType def_constrained = CaseType::Constrained;
+    std::shared_ptr<BlockE> t, f;   // If
+    std::vector<Var> ret;           // Return
+};
+
+struct BlockE {
+    std::vector<OpE> ops;
+    CtrlE ctrl;
+};
+
+struct FuncE {
+    std::string name;
+    bool invertible = false;
+    bool partial = false;
+    std::vector<Var> input_params;
+    int output_size = 0;
+    BlockE body;
+};
+
+// Parses one or more `fn` definitions written in the func! surface syntax (macros.rs).
+// `symbols` resolves identifiers used as match patterns / constants (e.g. Lurk tags).
+std::vector<FuncE> parse_funcs(const std::string& src, const std::map<std::string, uint32_t>* symbols = nullptr);
+
+// ---------------------------------------------------------------- bytecode (bytecode.rs)
+enum class OpKind {
+    AssertEq, AssertNe, Contains, Const, Add, Sub, Mul, Inv, Not, Call, PreImg, Store, Load, ExternCall,
+    Emit, RangeU8, Breakpoint, Debug
+};
+
+struct Op {
+    OpKind kind;
+    std::vector<uint32_t> a;  // AssertEq/Ne: lhs; Contains: array; Call/PreImg/Store/Extern/Emit/RangeU8: args
+    std::vector<uint32_t> b;  // AssertEq/Ne: rhs
+    uint32_t x = 0, y = 0;    // Add/Sub/Mul: operands; Inv/Not: x; Contains: y = needle; Load: x = len, y = ptr;
+                              // Call/PreImg/ExternCall: x = callee / chip index
+    uint32_t c = 0;           // Const value
+};
+
+struct Block;
+struct Ctrl {
+    enum Kind { Choose, ChooseMany, Return } kind = Return;
+    uint32_t var = 0;                 // Choose
+    std::vector<uint32_t> vars;       // ChooseMany
+    // sorted (key -> branch); several keys may point at the same block (shared_ptr identity)
+    std::vector<std::pair<List, std::shared_ptr<Block>>> branches;
+    std::vector<std::shared_ptr<Block>> unique_branches;  // Choose only: one per source branch
+    std::shared_ptr<Block> def;
+    uint32_t ident = 0;               // Return: selector index
+    std::vector<uint32_t> ret;        // Return: output vars
+    const Block* match_case(const List& key) const;
+};
+
+struct Block {
+    std::vector<Op> ops;
+    Ctrl ctrl;
+    std::vector<uint32_t> return_idents;
+};
+
+struct Func {
+    std::string name;
+    bool invertible = false, partial = false;
+    uint32_t index = 0, input_size = 0, output_size = 0;
+    Block body;
+};
+
+// ---------------------------------------------------------------- chipsets (chipset.rs, core/chipset.rs)
+struct Record {  // air/builder.rs:135-150
+    uint32_t nonce = 0, count = 0;
+    Record new_lookup(uint32_t n) {
+        Record r = *this;
+        nonce = n;
+        count += 1;
+        return r;
+    }
+};
+
+struct BytesInputRecord {  // gadgets/bytes/record.rs:50-71, order fixed by iter_records()
+    Record range_u8, range_u16, less_than, and_, xor_, or_;
+};
+
+struct BytesRecord {  // gadgets/bytes/record.rs:14-17
+    std::map<uint16_t, BytesInputRecord> records;
+    void range_check_u8_pair(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& requires_);
+    void range_check_u8_iter(const uint8_t* bytes, size_t n, uint32_t nonce, std::vector<Record>& requires_);
+    bool less_than(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& requires_);
+    void range_check_u16(uint16_t v, uint32_t nonce, std::vector<Record>& requires_);
+};
+
+struct Chip {
+    std::string name;
+    ChipKind kind = CHIP_NONE;
+    uint32_t input_size = 0, output_size = 0, witness_size = 0, require_size = 0;
+    // number of values populate_witness returns (pushed to the variable map during trace
+    // generation; the reference's Poseidon chip returns the whole state, core/poseidon.rs:65-72)
+    uint32_t witness_return_size = 0;
+    // host execution: returns outputs and appends byte-lookup requires
+    List execute(const List& input, uint32_t nonce, BytesRecord& bytes, std::vector<Record>& requires_) const;
+};
+
+std::vector<Chip> lurk_chip_map();  // core/chipset.rs:28-63, in that order
+
+// ---------------------------------------------------------------- toplevel (toplevel.rs)
+struct Toplevel {
+    std::vector<Func> funcs;          // insertion order = index
+    std::unordered_map<std::string, uint32_t> func_index;
+    std::vector<Chip> chips;
+    std::unordered_map<std::string, uint32_t> chip_index;
+
+    static Toplevel build(const std::vector<FuncE>& funcs, const std::vector<Chip>& chips);
+    const Func& func_by_name(const std::string& n) const;
+};
+
+// ---------------------------------------------------------------- layout (func_chip.rs)
+struct LayoutSizes {
+    uint32_t nonce = 1, input = 0, output = 0, aux = 0, sel = 0;
+    uint32_t total() const { return nonce + input + output + aux + sel; }
+};
+LayoutSizes compute_layout_sizes(const Toplevel& t, const Func& f);
+
+constexpr int DEPTH_W = 4;                 // provenance.rs:11
+constexpr int DEPTH_LESS_THAN_SIZE = 6;    // provenance.rs:121
+constexpr int DEPTH_LT_REQUIRES = 1;
+
+// ---------------------------------------------------------------- execution (execute.rs)
+struct QueryResult {
+    bool has_output = false;
+    List output;
+    Record provide;
+    std::vector<Record> requires_;
+    uint32_t depth = 0;
+    std::vector<Record> depth_requires;
+    // values the row's trace needs that the reference re-derives by hash-map lookups at trace time
+    // (callee outputs, preimages, pointers, loaded values, callee depths), in bytecode order
+    List hints;
+};
+
+struct VecHash {
+    size_t operator()(const List& v) const {
+        uint64_t h = 1469598103934665603ull;
+        for (uint32_t x : v) {
+            h ^= x;
+            h *= 1099511628211ull;
+        }
+        return (size_t)h;
+    }
+};
+
+// insertion-ordered map List -> QueryResult (indexmap::IndexMap)
+struct QueryMap {
+    std::vector<List> keys;
+    std::vector<QueryResult> vals;
+    std::unordered_map<List, uint32_t, VecHash> index;
+    size_t size() const { return keys.size(); }
+    int find(const List& k) const {
+        auto it = index.find(k);
+        return it == index.end() ? -1 : (int)it->second;
+    }
+    // insert_full: replaces the value when the key exists (IndexMap semantics)
+    uint32_t insert_full(const List& k, QueryResult v);
+    void clear() {
+        keys.clear();
+        vals.clear();
+        index.clear();
+    }
+};
+
+constexpr int NUM_MEM_TABLES = 6;
+extern const uint32_t MEM_TABLE_SIZES[NUM_MEM_TABLES];  // {2,3,4,5,6,8}, execute.rs:243-244
+int mem_index_from_len(uint32_t len);
+
+struct QueryRecord {
+    bool has_public_values = false;
+    List public_values;
+    std::vector<QueryMap> func_queries;
+    std::vector<std::unique_ptr<std::unordered_map<List, List, VecHash>>> inv_func_queries;  // null if not invertible
+    std::vector<QueryMap> mem_queries;
+    BytesRecord bytes;
+    std::vector<List> emitted;
+
+    explicit QueryRecord(const Toplevel& t);
+    void clean();
+    void inject_inv_query(uint32_t func_idx, const List& inp, const List& out);
+};
+
+// Toplevel::execute (execute.rs:375-392): runs `func` on `args`, fills `record`, sets public values.
+List execute(const Toplevel& t, const Func& func, const List& args, QueryRecord& record);
+
+struct ShardingConfig {
+    uint32_t max_shard_size = 1u << 22;  // execute.rs:231-241
+};
+inline std::pair<size_t, size_t> shard_range(size_t num_queries, uint32_t shard_index, uint32_t max_shard_size) {
+    size_t start = (size_t)shard_index * max_shard_size;
+    size_t end = std::min((size_t)(shard_index + 1) * max_shard_size, num_queries);
+    if (start > end) start = end;
+    return {start, end};
+}
+size_t num_shards(const QueryRecord& r, uint32_t max_shard_size);  // execute.rs:186-216
+
+// ---------------------------------------------------------------- device program (emit.cpp)
+// Flattened, degree-resolved micro-program of one Func for the trace kernel; see trace_program.h.
+std::vector<uint32_t> build_trace_program(const Toplevel& t, const Func& f, uint32_t* max_vars);
+
+}  // namespace lair

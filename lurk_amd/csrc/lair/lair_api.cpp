@@ -1,0 +1,341 @@
+// C ABI over the Lair host: toplevel construction, execution, layout queries and the
+// generate_trace entry points that feed the device kernels.
+//
+// These are the seams a Rust shim would replace:
+//   Toplevel::{new, execute_by_name}        /root/reference/src/lair/toplevel.rs:28-50, execute.rs:375-417
+//   FuncChip::{from_name, width, generate_trace}   /root/reference/src/lair/func_chip.rs:34-80, trace.rs:72-135
+//   MemChip / BytesChip / Entrypoint generate_trace  /root/reference/src/lair/lair_chip.rs:96-120
+#include <cstring>
+
+#include "../ctx.h"
+#include "lair.h"
+
+struct lurkhip_toplevel {
+    lair::Toplevel t;
+    std::vector<lair::LayoutSizes> layouts;
+    std::vector<std::vector<uint32_t>> programs;  // lazily built
+};
+
+struct lurkhip_record {
+    const lurkhip_toplevel* top;
+    lair::QueryRecord q;
+    explicit lurkhip_record(const lurkhip_toplevel* t) : top(t), q(t->t) {}
+};
+
+extern "C" int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, const uint32_t* program_host_header,
+                                          uint32_t n_real, uint32_t height, uint32_t nonce_start, const uint32_t* args_dev,
+                                          const uint32_t* outputs_dev, const uint32_t* provides_dev, const uint32_t* depths_dev,
+                                          const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr);
+extern "C" int32_t lurkhip_trace_mem_dev(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height,
+                                         const uint32_t* values_dev, const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr);
+extern "C" int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev,
+                                           int32_t repr);
+
+namespace {
+
+thread_local std::string g_err;
+
+int32_t fail(lurkhip_ctx* ctx, int32_t code, const std::string& msg) {
+    g_err = msg;
+    return lurkhip::set_error(ctx, code, "%s", msg.c_str());
+}
+
+template <class F>
+int32_t guarded(lurkhip_ctx* ctx, F&& f) {
+    try {
+        return f();
+    } catch (const lair::ParseError& e) {
+        return fail(ctx, LURKHIP_ERR_PARSE, e.what());
+    } catch (const lair::ExecError& e) {
+        return fail(ctx, LURKHIP_ERR_EXEC, e.what());
+    } catch (const std::exception& e) {
+        return fail(ctx, LURKHIP_ERR_EXEC, std::string("internal error: ") + e.what());
+    }
+}
+
+uint32_t next_pow2(uint32_t n) {
+    uint32_t p = 1;
+    while (p < n) p <<= 1;
+    return p;
+}
+
+const std::vector<uint32_t>& program_of(lurkhip_toplevel* top, uint32_t idx) {
+    if (top->programs.size() != top->t.funcs.size()) top->programs.resize(top->t.funcs.size());
+    if (top->programs[idx].empty()) top->programs[idx] = lair::build_trace_program(top->t, top->t.funcs[idx], nullptr);
+    return top->programs[idx];
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t lurkhip_toplevel_new(const char* source, int32_t with_lurk_chips, lurkhip_toplevel** out) {
+    if (!source || !out) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    return guarded(nullptr, [&]() -> int32_t {
+        auto funcs = lair::parse_funcs(source);
+        auto* top = new lurkhip_toplevel();
+        try {
+            top->t = lair::Toplevel::build(funcs, with_lurk_chips ? lair::lurk_chip_map() : std::vector<lair::Chip>());
+            for (const auto& f : top->t.funcs) top->layouts.push_back(lair::compute_layout_sizes(top->t, f));
+        } catch (...) {
+            delete top;
+            throw;
+        }
+        *out = top;
+        return LURKHIP_OK;
+    });
+}
+
+int32_t lurkhip_toplevel_free(lurkhip_toplevel* top) {
+    delete top;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_toplevel_num_funcs(const lurkhip_toplevel* top) { return top ? (int32_t)top->t.funcs.size() : LURKHIP_ERR_INVALID_ARG; }
+
+int32_t lurkhip_toplevel_func_index(const lurkhip_toplevel* top, const char* name) {
+    if (!top || !name) return LURKHIP_ERR_INVALID_ARG;
+    auto it = top->t.func_index.find(name);
+    return it == top->t.func_index.end() ? LURKHIP_ERR_INVALID_ARG : (int32_t)it->second;
+}
+
+// info[0..8) = input_size, output_size, partial, invertible, layout nonce, input, output, aux, sel
+int32_t lurkhip_toplevel_func_info(const lurkhip_toplevel* top, int32_t func_idx, uint32_t* info) {
+    if (!top || !info || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size()) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "bad func index");
+    const auto& f = top->t.funcs[func_idx];
+    const auto& l = top->layouts[func_idx];
+    uint32_t v[9] = {f.input_size, f.output_size, f.partial, f.invertible, l.nonce, l.input, l.output, l.aux, l.sel};
+    memcpy(info, v, sizeof v);
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_record_new(const lurkhip_toplevel* top, lurkhip_record** out) {
+    if (!top || !out) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "null argument");
+    *out = new lurkhip_record(top);
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_record_free(lurkhip_record* r) {
+    delete r;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_record_clean(lurkhip_record* r) {
+    if (!r) return LURKHIP_ERR_INVALID_ARG;
+    r->q.clean();
+    return LURKHIP_OK;
+}
+
+// Toplevel::execute (execute.rs:375-392); `out` must hold output_size values
+int32_t lurkhip_execute(lurkhip_record* r, int32_t func_idx, const uint32_t* args, uint32_t n_args, uint32_t* out) {
+    if (!r || func_idx < 0 || (size_t)func_idx >= r->top->t.funcs.size()) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "bad func index");
+    return guarded(nullptr, [&]() -> int32_t {
+        lair::List a(args, args + n_args);
+        for (uint32_t v : a)
+            if (v >= lair::P) throw lair::ExecError("argument is not a canonical field element");
+        lair::List o = lair::execute(r->top->t, r->top->t.funcs[func_idx], a, r->q);
+        if (out) memcpy(out, o.data(), o.size() * 4);
+        return LURKHIP_OK;
+    });
+}
+
+int32_t lurkhip_record_inject_inv_query(lurkhip_record* r, int32_t func_idx, const uint32_t* inp, uint32_t n_inp,
+                                        const uint32_t* out, uint32_t n_out) {
+    if (!r) return LURKHIP_ERR_INVALID_ARG;
+    return guarded(nullptr, [&]() -> int32_t {
+        r->q.inject_inv_query((uint32_t)func_idx, lair::List(inp, inp + n_inp), lair::List(out, out + n_out));
+        return LURKHIP_OK;
+    });
+}
+
+// number of queries of a func (kind 0) or mem table of length `index` (kind 1); kind 2: public values length
+int64_t lurkhip_record_count(const lurkhip_record* r, int32_t kind, int32_t index) {
+    if (!r) return LURKHIP_ERR_INVALID_ARG;
+    try {
+        if (kind == 0) return (int64_t)r->q.func_queries.at(index).size();
+        if (kind == 1) return (int64_t)r->q.mem_queries.at(lair::mem_index_from_len((uint32_t)index)).size();
+        if (kind == 2) return r->q.has_public_values ? (int64_t)r->q.public_values.size() : -1;
+        if (kind == 3) return (int64_t)r->q.bytes.records.size();
+        if (kind == 4) return (int64_t)r->q.emitted.size();
+    } catch (...) {
+    }
+    return LURKHIP_ERR_INVALID_ARG;
+}
+
+int32_t lurkhip_record_public_values(const lurkhip_record* r, uint32_t* out) {
+    if (!r || !out || !r->q.has_public_values) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "Public values not set");
+    memcpy(out, r->q.public_values.data(), r->q.public_values.size() * 4);
+    return LURKHIP_OK;
+}
+
+int64_t lurkhip_record_num_shards(const lurkhip_record* r, uint32_t max_shard_size) {
+    if (!r || max_shard_size == 0) return LURKHIP_ERR_INVALID_ARG;
+    return (int64_t)lair::num_shards(r->q, max_shard_size);
+}
+
+// Shape of the FuncChip trace of `func_idx` for one shard: n_real rows, padded height, width.
+int32_t lurkhip_func_trace_shape(const lurkhip_record* r, int32_t func_idx, uint32_t shard_index, uint32_t max_shard_size,
+                                 uint32_t* n_real, uint32_t* height, uint32_t* width) {
+    if (!r || func_idx < 0 || (size_t)func_idx >= r->top->t.funcs.size()) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "bad func index");
+    auto [s, e] = lair::shard_range(r->q.func_queries[func_idx].size(), shard_index, max_shard_size);
+    uint32_t n = (uint32_t)(e - s);
+    if (n_real) *n_real = n;
+    if (height) *height = next_pow2(n);  // `0.next_power_of_two()` is 1 in Rust (trace.rs:79)
+    if (width) *width = r->top->layouts[func_idx].total();
+    return LURKHIP_OK;
+}
+
+// FuncChip::generate_trace (trace.rs:72-135) for one shard, written to a device buffer of height x width words.
+int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
+                                        uint32_t shard_index, uint32_t max_shard_size, uint32_t* out_dev, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    if (!top || !r || r->top != top || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size())
+        return fail(ctx, LURKHIP_ERR_INVALID_ARG, "bad toplevel/record/func index");
+    return guarded(ctx, [&]() -> int32_t {
+        const lair::Func& f = top->t.funcs[func_idx];
+        const lair::QueryMap& qm = r->q.func_queries[func_idx];
+        for (const auto& op_chip : top->t.chips)
+            (void)op_chip;
+        auto [start, end] = lair::shard_range(qm.size(), shard_index, max_shard_size);
+        const uint32_t n = (uint32_t)(end - start), height = next_pow2(n);
+        const std::vector<uint32_t>& prog = program_of(top, (uint32_t)func_idx);
+        // ---- flatten the per-row inputs (args / outputs / provide / depth / stream)
+        std::vector<uint32_t> args((size_t)n * f.input_size), outs((size_t)n * f.output_size), prov((size_t)n * 2), depths(n);
+        std::vector<lair::RowMeta> meta(n);
+        std::vector<uint32_t> stream;
+        for (uint32_t i = 0; i < n; i++) {
+            const lair::List& key = qm.keys[start + i];
+            const lair::QueryResult& res = qm.vals[start + i];
+            if (!res.has_output) throw lair::ExecError("Result not computed");
+            memcpy(&args[(size_t)i * f.input_size], key.data(), f.input_size * 4);
+            memcpy(&outs[(size_t)i * f.output_size], res.output.data(), f.output_size * 4);
+            prov[2 * (size_t)i] = res.provide.nonce;
+            prov[2 * (size_t)i + 1] = res.provide.count;
+            depths[i] = res.depth;
+            if (stream.size() + res.hints.size() + 2 * (res.requires_.size() + res.depth_requires.size()) > 0xffffff00ull)
+                throw lair::ExecError("row stream exceeds 2^32 words; use a smaller shard");
+            meta[i].offset = (uint32_t)stream.size();
+            meta[i].n_hints = (uint32_t)res.hints.size();
+            meta[i].n_requires = (uint32_t)res.requires_.size();
+            meta[i].n_depth_requires = (uint32_t)res.depth_requires.size();
+            stream.insert(stream.end(), res.hints.begin(), res.hints.end());
+            for (const auto& q : res.requires_) {
+                stream.push_back(q.nonce);
+                stream.push_back(q.count);
+            }
+            for (const auto& q : res.depth_requires) {
+                stream.push_back(q.nonce);
+                stream.push_back(q.count);
+            }
+        }
+        // ---- one staging buffer: program | args | outs | prov | depths | meta | stream
+        auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        size_t o_prog = 0, o_args = al(o_prog + prog.size() * 4), o_outs = al(o_args + args.size() * 4),
+               o_prov = al(o_outs + outs.size() * 4), o_dep = al(o_prov + prov.size() * 4), o_meta = al(o_dep + depths.size() * 4),
+               o_str = al(o_meta + meta.size() * sizeof(lair::RowMeta)), total = al(o_str + stream.size() * 4 + 4);
+        std::vector<uint8_t> host(total, 0);
+        memcpy(&host[o_prog], prog.data(), prog.size() * 4);
+        if (n) {
+            memcpy(&host[o_args], args.data(), args.size() * 4);
+            memcpy(&host[o_outs], outs.data(), outs.size() * 4);
+            memcpy(&host[o_prov], prov.data(), prov.size() * 4);
+            memcpy(&host[o_dep], depths.data(), depths.size() * 4);
+            memcpy(&host[o_meta], meta.data(), meta.size() * sizeof(lair::RowMeta));
+            if (!stream.empty()) memcpy(&host[o_str], stream.data(), stream.size() * 4);
+        }
+        void* dev = nullptr;
+        LH_TRY(lurkhip::arena_get(ctx, 3, total, &dev));
+        LH_HIP(ctx, hipMemcpyAsync(dev, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
+        uint8_t* d = (uint8_t*)dev;
+        int32_t s = lurkhip_trace_func_dev(ctx, (const uint32_t*)(d + o_prog), prog.data(), n, height, (uint32_t)start,
+                                           (const uint32_t*)(d + o_args), (const uint32_t*)(d + o_outs), (const uint32_t*)(d + o_prov),
+                                           f.partial ? (const uint32_t*)(d + o_dep) : nullptr, d + o_meta, (const uint32_t*)(d + o_str),
+                                           out_dev, repr);
+        // `host` dies at scope exit: the pageable H2D copy has been staged by then, but be explicit
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return s;
+    });
+}
+
+int32_t lurkhip_generate_trace_func(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
+                                    uint32_t shard_index, uint32_t max_shard_size, uint32_t* out_host, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    uint32_t n = 0, h = 0, w = 0;
+    LH_TRY(lurkhip_func_trace_shape(r, func_idx, shard_index, max_shard_size, &n, &h, &w));
+    void* dout = nullptr;
+    LH_TRY(lurkhip::arena_get(ctx, 1, (size_t)h * w * 4, &dout));
+    LH_TRY(lurkhip_generate_trace_func_dev(ctx, top, r, func_idx, shard_index, max_shard_size, (uint32_t*)dout, repr));
+    LH_HIP(ctx, hipMemcpyAsync(out_host, dout, (size_t)h * w * 4, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}
+
+// MemChip::generate_trace (memory.rs:30-69): height = max(4, next_pow2(len(mem))), width = 4 + mem_len
+int32_t lurkhip_mem_trace_shape(const lurkhip_record* r, uint32_t mem_len, uint32_t* n_real, uint32_t* height, uint32_t* width) {
+    if (!r) return LURKHIP_ERR_INVALID_ARG;
+    return guarded(nullptr, [&]() -> int32_t {
+        const auto& mm = r->q.mem_queries[lair::mem_index_from_len(mem_len)];
+        uint32_t n = (uint32_t)mm.size();
+        if (n_real) *n_real = n;
+        if (height) *height = std::max(4u, next_pow2(n));
+        if (width) *width = 4 + mem_len;
+        return LURKHIP_OK;
+    });
+}
+
+int32_t lurkhip_generate_trace_mem(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t mem_len, uint32_t* out_host, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    if (!r || !out_host) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    return guarded(ctx, [&]() -> int32_t {
+        const auto& mm = r->q.mem_queries[lair::mem_index_from_len(mem_len)];
+        const uint32_t n = (uint32_t)mm.size(), height = std::max(4u, next_pow2(n)), width = 4 + mem_len;
+        std::vector<uint32_t> host((size_t)n * (mem_len + 2) + 1);
+        for (uint32_t i = 0; i < n; i++) {
+            memcpy(&host[(size_t)i * mem_len], mm.keys[i].data(), mem_len * 4);
+            host[(size_t)n * mem_len + 2 * i] = mm.vals[i].provide.nonce;
+            host[(size_t)n * mem_len + 2 * i + 1] = mm.vals[i].provide.count;
+        }
+        void *din = nullptr, *dout = nullptr;
+        LH_TRY(lurkhip::arena_get(ctx, 3, host.size() * 4, &din));
+        LH_TRY(lurkhip::arena_get(ctx, 1, (size_t)height * width * 4, &dout));
+        LH_HIP(ctx, hipMemcpyAsync(din, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LH_TRY(lurkhip_trace_mem_dev(ctx, mem_len, n, height, (const uint32_t*)din, (const uint32_t*)din + (size_t)n * mem_len,
+                                     (uint32_t*)dout, repr));
+        LH_HIP(ctx, hipMemcpyAsync(out_host, dout, (size_t)height * width * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return LURKHIP_OK;
+    });
+}
+
+// BytesChip::generate_trace for this record (65536 x 13); an empty record gives the all-zero trace
+// (bytes/trace.rs:81-84), as does any shard other than 0 (lair_chip.rs:104-111).
+int32_t lurkhip_generate_trace_bytes(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index, uint32_t* out_host, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    if (!r || !out_host) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    return guarded(ctx, [&]() -> int32_t {
+        const bool is_real = shard_index == 0 && !r->q.bytes.records.empty();
+        std::vector<uint32_t> host((size_t)65536 * 12, 0);
+        if (is_real)
+            for (const auto& kv : r->q.bytes.records) {
+                const lair::Record recs[6] = {kv.second.range_u8, kv.second.range_u16, kv.second.less_than,
+                                              kv.second.and_,     kv.second.xor_,      kv.second.or_};
+                for (int k = 0; k < 6; k++) {
+                    host[(size_t)kv.first * 12 + 2 * k] = recs[k].nonce;
+                    host[(size_t)kv.first * 12 + 2 * k + 1] = recs[k].count;
+                }
+            }
+        void *din = nullptr, *dout = nullptr;
+        LH_TRY(lurkhip::arena_get(ctx, 3, host.size() * 4, &din));
+        LH_TRY(lurkhip::arena_get(ctx, 1, (size_t)65536 * 13 * 4, &dout));
+        LH_HIP(ctx, hipMemcpyAsync(din, host.data(), host.size() * 4, hipMemcpyHostToDevice, ctx->stream));
+        LH_TRY(lurkhip_trace_bytes_dev(ctx, (const uint32_t*)din, is_real, (uint32_t*)dout, repr));
+        LH_HIP(ctx, hipMemcpyAsync(out_host, dout, (size_t)65536 * 13 * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        return LURKHIP_OK;
+    });
+}
+
+const char* lurkhip_lair_last_error(void) { return g_err.c_str(); }
+
+}  // extern "C"

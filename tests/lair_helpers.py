@@ -1,0 +1,79 @@
+import json
+import os
+
+GOLDEN = os.path.join(os.path.dirname(__file__), "golden", "lair_traces.json")
+
+
+def load_cases():
+    with open(GOLDEN) as f:
+        return json.load(f)["cases"]
+
+
+# extra programs used by the oracle-vs-GPU tests (not from the reference)
+PARTIAL_SRC = """
+partial fn pfib(n): [1] {
+    let one = 1;
+    match n {
+        0 => {
+            let zero = 0;
+            return zero
+        }
+        1 => {
+            return one
+        }
+    };
+    let n_1 = sub(n, one);
+    let a = call(pfib, n_1);
+    let n_2 = sub(n_1, one);
+    let b = call(pfib, n_2);
+    let res = add(a, b);
+    return res
+}
+partial fn top(n): [2] {
+    let a = call(pfib, n);
+    let two = 2;
+    let b = call(helper, a, two);
+    return (a, b)
+}
+fn helper(x, y): [1] {
+    let p = mul(x, y);
+    let q = div(p, y);
+    let ptr = store(p, q);
+    let (u, v) = load(ptr);
+    let r = add(u, v);
+    let e = eq(r, p);
+    let z = add(e, r);
+    return z
+}
+"""
+
+U64_SRC = """
+fn u64_ops(a: [8], b: [8]): [18] {
+    let s: [8] = extern_call(u64_add, a, b);
+    let d: [8] = extern_call(u64_sub, a, b);
+    let lt = extern_call(u64_lessthan, a, b);
+    let z = extern_call(u64_iszero, d);
+    range_u8!(s, d);
+    return (s, d, lt, z)
+}
+invertible fn hash3(preimg: [24]): [8] {
+    let img: [8] = extern_call(hasher3, preimg);
+    return img
+}
+invertible fn hash4(preimg: [32]): [8] {
+    let img: [8] = extern_call(hasher4, preimg);
+    return img
+}
+invertible fn hash5(preimg: [40]): [8] {
+    let img: [8] = extern_call(hasher5, preimg);
+    return img
+}
+fn chain(x: [8]): [8] {
+    let z = [0; 8];
+    let one = [1; 8];
+    let h: [8] = call(hash3, z, one, x);
+    let (a: [8], b: [8], c: [8]) = preimg(hash3, h);
+    let g: [8] = call(hash4, a, b, c, h);
+    return g
+}
+"""

@@ -1,0 +1,108 @@
+"""CPU tests of the product's host-side Lair (parser, compiler, layout, interpreter) through the C ABI.
+No GPU: nothing here generates a trace."""
+import pytest
+
+from lair_helpers import PARTIAL_SRC, U64_SRC, load_cases
+from lurk_amd import lair
+from oracle import lair as ol
+
+
+@pytest.mark.parametrize("case", load_cases(), ids=lambda c: c["name"])
+def test_layout_and_execution_match_golden_and_oracle(case):
+    top = lair.Toplevel(case["source"], lurk_chips=case["lurk_chips"])
+    otop = ol.Toplevel(case["source"])
+    q, oq = lair.QueryRecord(top), ol.QueryRecord(otop)
+    for name, args in case["calls"]:
+        assert top.execute_by_name(name, args, q) == ol.execute(otop, name, args, oq)
+    for i in range(top.num_funcs()):
+        info = top.func_info(i)
+        lay = otop.layout(otop.funcs[i])
+        got = info["layout"]
+        assert (got.nonce, got.input, got.output, got.aux, got.sel) == (1, lay["input"], lay["output"], lay["aux"], lay["sel"])
+        assert q.num_func_queries(i) == len(oq.func[i])
+    idx = top.func_index(case["func"])
+    assert top.func_info(idx)["layout"].total() == case["width"]
+    if case["layout"]:
+        got = top.func_info(idx)["layout"]
+        assert dict(nonce=got.nonce, input=got.input, aux=got.aux, sel=got.sel, output=got.output) == case["layout"]
+    assert q.expect_public_values() == oq.public_values
+
+
+def test_iterative_interpreter_known_answers():
+    demo = load_cases()[0]["source"]
+    top = lair.Toplevel.new_pure(demo)
+    q = lair.QueryRecord(top)
+    # src/lair/execute.rs:826-834: fib(100000) mod p
+    assert top.execute_by_name("fib", [100000], q) == [1123328132]
+    assert q.num_func_queries(top.func_index("fib")) == 100001
+    # default shard size 2^22 -> 1 shard; shard size 4 -> ceil(100001 / 4)
+    assert len(lair.Shard.new(q).shard(lair.ShardingConfig())) == 1
+    assert len(lair.Shard.new(q).shard(lair.ShardingConfig(4))) == 25001
+
+
+def test_ackermann_sharding_count():
+    # src/lair/trace.rs:655-692: A(3, n) = 2^(n+3) - 3; smaller n here to keep the CPU suite fast
+    src = """
+    fn ackermann(m, n): [1] {
+        let one = 1;
+        match m {
+            0 => {
+                let ret = add(n, one);
+                return ret
+            }
+        };
+        let m_minus_one = sub(m, one);
+        match n {
+            0 => {
+                let ret = call(ackermann, m_minus_one, one);
+                return ret
+            }
+        };
+        let n_minus_one = sub(n, one);
+        let inner = call(ackermann, m, n_minus_one);
+        let ret = call(ackermann, m_minus_one, inner);
+        return ret
+    }
+    """
+    top = lair.Toplevel.new_pure(src)
+    q = lair.QueryRecord(top)
+    assert top.execute_by_name("ackermann", [3, 8], q) == [2**11 - 3]
+
+
+def test_partial_functions_depth_and_public_values():
+    top = lair.Toplevel(PARTIAL_SRC)
+    otop = ol.Toplevel(PARTIAL_SRC)
+    q, oq = lair.QueryRecord(top), ol.QueryRecord(otop)
+    assert top.execute_by_name("top", [9], q) == ol.execute(otop, "top", [9], oq)
+    pv = q.expect_public_values()
+    assert pv == oq.public_values and len(pv) == 1 + 2 + 4  # partial: + 4 depth bytes (execute.rs:384-390)
+    for i in range(3):
+        got = top.func_info(i)["layout"]
+        lay = otop.layout(otop.funcs[i])
+        assert (got.aux, got.sel) == (lay["aux"], lay["sel"])
+
+
+def test_lurk_chip_layout_widths():
+    # SURVEY appendix B worked widths: hash3/4/5 = 493/655/815 (src/core/eval_direct.rs:2053-2055);
+    top = lair.Toplevel(U64_SRC, lurk_chips=True)
+    assert top.func_info(top.func_index("hash3"))["layout"].total() == 493
+    assert top.func_info(top.func_index("hash4"))["layout"].total() == 655
+    assert top.func_info(top.func_index("hash5"))["layout"].total() == 815
+
+
+def test_errors_are_reported_not_thrown():
+    with pytest.raises(lair.LairError) as e:
+        lair.Toplevel("fn f(a): [1] { let b = call(nope, a); return b }")
+    assert e.value.status == -7 and "Unknown function" in e.value.message
+    with pytest.raises(lair.LairError):
+        lair.Toplevel("fn f(a): [2] { return a }")  # return size mismatch (toplevel.rs:328-335)
+    top = lair.Toplevel("fn f(a): [1] { let one = 1; assert_eq!(a, one); return a }")
+    q = lair.QueryRecord(top)
+    assert top.execute_by_name("f", [1], q) == [1]
+    with pytest.raises(lair.LairError) as e:
+        top.execute_by_name("f", [2], q)
+    assert e.value.status == -6
+    loop = lair.Toplevel("fn f(a): [1] { let b = call(f, a); return b }")
+    with pytest.raises(lair.LairError) as e:
+        loop.execute_by_name("f", [1], lair.QueryRecord(loop))
+    assert "Loop detected" in e.value.message  # execute.rs:505-507
