@@ -272,7 +272,8 @@ struct ShardingConfig {
 inline std::pair<size_t, size_t> shard_range(size_t num_queries, uint32_t shard_index, uint32_t max_shard_size) {
     size_t start = (size_t)shard_index * max_shard_size;
     size_t end = std::min((size_t)(shard_index + 1) * max_shard_size, num_queries);
-    if (start > end) start = end;
+    // like Rust's `start..end` with start > end: empty, but `start` keeps its value (it seeds the nonces)
+    if (end < start) end = start;
     return {start, end};
 }
 size_t num_shards(const QueryRecord& r, uint32_t max_shard_size);  // execute.rs:186-216
