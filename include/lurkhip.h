@@ -236,6 +236,16 @@ int32_t lurkhip_generate_trace_func(lurkhip_ctx* ctx, lurkhip_toplevel* top, con
 int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r,
                                         int32_t func_idx, uint32_t shard_index, uint32_t max_shard_size,
                                         uint32_t* out_dev, int32_t repr);
+/* generate_trace split in two for callers that re-run it or want the inputs resident in HBM:
+ * prepare flattens one shard of one function into device buffers (program, per-row arrays, row stream),
+ * run launches the row kernel into a height x width device buffer (asynchronous on the ctx stream).
+ * shape[5] = n_real, height, width, bytes of device-resident inputs, stream words. */
+typedef struct lurkhip_func_trace lurkhip_func_trace;
+int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
+                                   uint32_t shard_index, uint32_t max_shard_size, lurkhip_func_trace** out);
+int32_t lurkhip_func_trace_shape_of(const lurkhip_func_trace* p, uint64_t* shape);
+int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, int32_t repr);
+int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p);
 int32_t lurkhip_mem_trace_shape(const lurkhip_record* r, uint32_t mem_len, uint32_t* n_real, uint32_t* height,
                                 uint32_t* width);
 int32_t lurkhip_generate_trace_mem(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t mem_len, uint32_t* out_host,

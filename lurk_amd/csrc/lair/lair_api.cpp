@@ -186,17 +186,32 @@ int32_t lurkhip_func_trace_shape(const lurkhip_record* r, int32_t func_idx, uint
     return LURKHIP_OK;
 }
 
-// FuncChip::generate_trace (trace.rs:72-135) for one shard, written to a device buffer of height x width words.
-int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
-                                        uint32_t shard_index, uint32_t max_shard_size, uint32_t* out_dev, int32_t repr) {
+// Device-resident inputs of one FuncChip trace (program + per-row arrays + row stream), so that the
+// kernel can be re-run without touching the host (bench.py times exactly that).
+}  // extern "C"
+
+struct lurkhip_func_trace {
+    std::vector<uint32_t> header;  // TH_WORDS words of the program
+    void* dev = nullptr;           // one pooled block: program | args | outs | prov | depths | meta | stream
+    size_t o_prog = 0, o_args = 0, o_outs = 0, o_prov = 0, o_dep = 0, o_meta = 0, o_str = 0, total = 0;
+    uint32_t n = 0, height = 0, width = 0, start = 0;
+    bool partial = false;
+    size_t stream_words = 0;
+};
+
+extern "C" {
+
+// FuncChip::generate_trace (trace.rs:72-135), split in two: `prepare` flattens the shard's queries of one
+// function into device-resident kernel inputs, `run` launches the row kernel into a height x width buffer.
+int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
+                                   uint32_t shard_index, uint32_t max_shard_size, lurkhip_func_trace** out) {
     LH_CHECK_CTX(ctx);
-    if (!top || !r || r->top != top || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size())
+    if (!top || !r || !out || r->top != top || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size())
         return fail(ctx, LURKHIP_ERR_INVALID_ARG, "bad toplevel/record/func index");
+    *out = nullptr;
     return guarded(ctx, [&]() -> int32_t {
         const lair::Func& f = top->t.funcs[func_idx];
         const lair::QueryMap& qm = r->q.func_queries[func_idx];
-        for (const auto& op_chip : top->t.chips)
-            (void)op_chip;
         auto [start, end] = lair::shard_range(qm.size(), shard_index, max_shard_size);
         const uint32_t n = (uint32_t)(end - start), height = next_pow2(n);
         const std::vector<uint32_t>& prog = program_of(top, (uint32_t)func_idx);
@@ -231,31 +246,85 @@ int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top,
         }
         // ---- one staging buffer: program | args | outs | prov | depths | meta | stream
         auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
-        size_t o_prog = 0, o_args = al(o_prog + prog.size() * 4), o_outs = al(o_args + args.size() * 4),
-               o_prov = al(o_outs + outs.size() * 4), o_dep = al(o_prov + prov.size() * 4), o_meta = al(o_dep + depths.size() * 4),
-               o_str = al(o_meta + meta.size() * sizeof(lair::RowMeta)), total = al(o_str + stream.size() * 4 + 4);
-        std::vector<uint8_t> host(total, 0);
-        memcpy(&host[o_prog], prog.data(), prog.size() * 4);
+        auto* p = new lurkhip_func_trace();
+        p->o_prog = 0;
+        p->o_args = al(p->o_prog + prog.size() * 4);
+        p->o_outs = al(p->o_args + args.size() * 4);
+        p->o_prov = al(p->o_outs + outs.size() * 4);
+        p->o_dep = al(p->o_prov + prov.size() * 4);
+        p->o_meta = al(p->o_dep + depths.size() * 4);
+        p->o_str = al(p->o_meta + meta.size() * sizeof(lair::RowMeta));
+        p->total = al(p->o_str + stream.size() * 4 + 4);
+        p->n = n;
+        p->height = height;
+        p->width = prog[lair::TH_WIDTH];
+        p->start = (uint32_t)start;
+        p->partial = f.partial;
+        p->stream_words = stream.size();
+        p->header.assign(prog.begin(), prog.begin() + lair::TH_WORDS);
+        std::vector<uint8_t> host(p->total, 0);
+        memcpy(&host[p->o_prog], prog.data(), prog.size() * 4);
         if (n) {
-            memcpy(&host[o_args], args.data(), args.size() * 4);
-            memcpy(&host[o_outs], outs.data(), outs.size() * 4);
-            memcpy(&host[o_prov], prov.data(), prov.size() * 4);
-            memcpy(&host[o_dep], depths.data(), depths.size() * 4);
-            memcpy(&host[o_meta], meta.data(), meta.size() * sizeof(lair::RowMeta));
-            if (!stream.empty()) memcpy(&host[o_str], stream.data(), stream.size() * 4);
+            memcpy(&host[p->o_args], args.data(), args.size() * 4);
+            memcpy(&host[p->o_outs], outs.data(), outs.size() * 4);
+            memcpy(&host[p->o_prov], prov.data(), prov.size() * 4);
+            memcpy(&host[p->o_dep], depths.data(), depths.size() * 4);
+            memcpy(&host[p->o_meta], meta.data(), meta.size() * sizeof(lair::RowMeta));
+            if (!stream.empty()) memcpy(&host[p->o_str], stream.data(), stream.size() * 4);
         }
-        void* dev = nullptr;
-        LH_TRY(lurkhip::arena_get(ctx, 3, total, &dev));
-        LH_HIP(ctx, hipMemcpyAsync(dev, host.data(), total, hipMemcpyHostToDevice, ctx->stream));
-        uint8_t* d = (uint8_t*)dev;
-        int32_t s = lurkhip_trace_func_dev(ctx, (const uint32_t*)(d + o_prog), prog.data(), n, height, (uint32_t)start,
-                                           (const uint32_t*)(d + o_args), (const uint32_t*)(d + o_outs), (const uint32_t*)(d + o_prov),
-                                           f.partial ? (const uint32_t*)(d + o_dep) : nullptr, d + o_meta, (const uint32_t*)(d + o_str),
-                                           out_dev, repr);
-        // `host` dies at scope exit: the pageable H2D copy has been staged by then, but be explicit
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        return s;
+        int32_t s = lurkhip::pool_alloc(ctx, p->total, &p->dev);
+        if (s != LURKHIP_OK) {
+            delete p;
+            return s;
+        }
+        hipError_t e = hipMemcpyAsync(p->dev, host.data(), p->total, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // `host` dies at scope exit
+        if (e != hipSuccess) {
+            lurkhip::pool_release(ctx, p->dev);
+            delete p;
+            return lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "row-stream upload failed: %s", hipGetErrorString(e));
+        }
+        *out = p;
+        return LURKHIP_OK;
     });
+}
+
+// shape[0..5) = n_real, height, width, bytes of device-resident inputs, stream words
+int32_t lurkhip_func_trace_shape_of(const lurkhip_func_trace* p, uint64_t* shape) {
+    if (!p || !shape) return LURKHIP_ERR_INVALID_ARG;
+    shape[0] = p->n;
+    shape[1] = p->height;
+    shape[2] = p->width;
+    shape[3] = p->total;
+    shape[4] = p->stream_words;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    if (!p || !out_dev) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    const uint8_t* d = (const uint8_t*)p->dev;
+    return lurkhip_trace_func_dev(ctx, (const uint32_t*)(d + p->o_prog), p->header.data(), p->n, p->height, p->start,
+                                  (const uint32_t*)(d + p->o_args), (const uint32_t*)(d + p->o_outs), (const uint32_t*)(d + p->o_prov),
+                                  p->partial ? (const uint32_t*)(d + p->o_dep) : nullptr, d + p->o_meta, (const uint32_t*)(d + p->o_str),
+                                  out_dev, repr);
+}
+
+int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p) {
+    LH_CHECK_CTX(ctx);
+    if (!p) return LURKHIP_OK;
+    lurkhip::pool_release(ctx, p->dev);
+    delete p;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
+                                        uint32_t shard_index, uint32_t max_shard_size, uint32_t* out_dev, int32_t repr) {
+    lurkhip_func_trace* p = nullptr;
+    LH_TRY(lurkhip_func_trace_prepare(ctx, top, r, func_idx, shard_index, max_shard_size, &p));
+    int32_t s = lurkhip_func_trace_run(ctx, p, out_dev, repr);
+    lurkhip_func_trace_free(ctx, p);
+    return s;
 }
 
 int32_t lurkhip_generate_trace_func(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,

@@ -62,7 +62,7 @@ class Toplevel:
         return cls(source, lurk_chips=False)
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and N is not None:
             N.lib.lurkhip_toplevel_free(self.handle)
             self.handle = None
 
@@ -105,7 +105,7 @@ class QueryRecord:
         self.handle = h
 
     def __del__(self):
-        if getattr(self, "handle", None):
+        if getattr(self, "handle", None) and N is not None:
             N.lib.lurkhip_record_free(self.handle)
             self.handle = None
 
@@ -182,6 +182,35 @@ class FuncChip:
         s = N.lib.lurkhip_generate_trace_func_dev(self.ctx.handle, self.toplevel.handle, shard.queries.handle, self.func_idx, shard.index, shard.shard_config.max_shard_size, _addr(out_dev), repr)
         if s != N.OK:
             raise LairError(s, N.last_error(self.ctx.handle))
+
+
+class PreparedFuncTrace:
+    """Device-resident inputs of one FuncChip trace (program + per-row arrays + row stream)."""
+
+    def __init__(self, chip: FuncChip, shard: Shard):
+        self.ctx = chip.ctx
+        h = C.c_void_p()
+        s = N.lib.lurkhip_func_trace_prepare(self.ctx.handle, chip.toplevel.handle, shard.queries.handle, chip.func_idx, shard.index, shard.shard_config.max_shard_size, C.byref(h))
+        if s != N.OK:
+            raise LairError(s, N.last_error(self.ctx.handle))
+        self.handle = h
+        shape = (C.c_uint64 * 5)()
+        _check(N.lib.lurkhip_func_trace_shape_of(h, shape))
+        self.n_real, self.height, self.width, self.input_bytes, self.stream_words = [int(x) for x in shape]
+
+    def run(self, out_dev, repr: int = N.REPR_CANONICAL):
+        self.ctx.check(N.lib.lurkhip_func_trace_run(self.ctx.handle, self.handle, _addr(out_dev), repr))
+
+    def close(self):
+        if self.handle:
+            N.lib.lurkhip_func_trace_free(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
 
 
 class MemChip:  # memory.rs:18-69
