@@ -217,10 +217,10 @@ struct QueryResult {
 
 struct VecHash {
     size_t operator()(const List& v) const {
-        uint64_t h = 1469598103934665603ull;
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ v.size();
         for (uint32_t x : v) {
-            h ^= x;
-            h *= 1099511628211ull;
+            h = (h ^ x) * 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
         }
         return (size_t)h;
     }
