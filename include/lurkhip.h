@@ -253,6 +253,50 @@ int32_t lurkhip_generate_trace_mem(lurkhip_ctx* ctx, const lurkhip_record* r, ui
 int32_t lurkhip_generate_trace_bytes(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index,
                                      uint32_t* out_host, int32_t repr);
 
+/* ---------------------------------------------------------------- AIR + prover stages */
+/* The constraints and lookup interactions of one chip, collected once on the host by a symbolic walk of the
+ * reference's AIR code and lowered to a register program the GPU evaluates per row.
+ * Replaces `Air::eval` of FuncChip (/root/reference/src/lair/air.rs:158-552), MemChip
+ * (/root/reference/src/lair/memory.rs:71-109), BytesChip (/root/reference/src/gadgets/bytes/trace.rs:117-143) and the
+ * Entrypoint chip (/root/reference/src/lair/lair_chip.rs:166-191) as sphinx-core's symbolic / debug / folding builders
+ * run them; provide / require follow /root/reference/src/air/builder.rs:42-104. */
+typedef struct lurkhip_air lurkhip_air;
+int32_t lurkhip_air_func(const lurkhip_toplevel* top, int32_t func_idx, lurkhip_air** out);
+int32_t lurkhip_air_mem(uint32_t len, lurkhip_air** out);
+int32_t lurkhip_air_bytes(lurkhip_air** out);
+int32_t lurkhip_air_entrypoint(uint32_t func_idx, uint32_t num_public_values, lurkhip_air** out);
+int32_t lurkhip_air_free(lurkhip_air* air);
+const char* lurkhip_air_name(const lurkhip_air* air);
+/* info[16]: 0 width, 1 preprocessed width, 2 #constraints, 3 #sends, 4 #receives, 5 max constraint degree,
+ * 6 log_quotient_degree, 7 permutation-trace width in extension-field columns, 8 words per row of the interaction
+ * dump (sum of 1 + tuple length), 9 #public values, 10/11 registers / instructions of the constraint program,
+ * 12/13 of the interaction program */
+int32_t lurkhip_air_info(const lurkhip_air* air, uint32_t* info);
+/* tuple length of each interaction, sends first then receives; returns their number */
+int32_t lurkhip_air_interaction_sizes(const lurkhip_air* air, uint32_t* sizes, uint32_t cap);
+/* Debug / parity entry: evaluates every constraint and every interaction on explicit (local, next) row pairs with
+ * explicit selector values [n][3] = (is_first_row, is_last_row, is_transition).  Host pointers, canonical values.
+ * constraints_out [n][#constraints] in assertion order; interactions_out [n][info[8]]: per interaction (sends
+ * first) the multiplicity followed by the tuple. */
+int32_t lurkhip_air_eval_rows(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t n_rows, const uint32_t* local,
+                              const uint32_t* next, const uint32_t* prep_local, const uint32_t* prep_next,
+                              const uint32_t* public_values, const uint32_t* selectors, uint32_t* constraints_out,
+                              uint32_t* interactions_out);
+/* Row-by-row constraint check of a whole trace on the device (the twin of sphinx's machine.debug_constraints /
+ * /root/reference/src/air/debug.rs:161-206): main_dev / prep_dev are height x width Montgomery matrices in natural
+ * row order; public_values host canonical.  first_bad_row = -1 when every constraint vanishes on every row. */
+int32_t lurkhip_air_check_trace_dev(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t height, const uint32_t* main_dev,
+                                    const uint32_t* prep_dev, const uint32_t* public_values, int64_t* first_bad_row,
+                                    int32_t* first_bad_constraint);
+/* LogUp permutation trace of one chip (sphinx generate_permutation_trace [UPSTREAM-RECALL]; spec twin
+ * /root/reference/src/logup/trace.rs:53-151).  main_dev / prep_dev: height x width Montgomery, natural order.
+ * challenges[8] = alpha, beta (canonical extension-field coefficients, host).  out_dev: height x (4 * info[7])
+ * Montgomery words (extension-field columns flattened to base), last column = running sum.  cumulative_sum[4]
+ * (host, canonical, may be NULL) receives the last row's running sum; passing it makes the call synchronous. */
+int32_t lurkhip_permutation_trace_dev(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t height, const uint32_t* main_dev,
+                                      const uint32_t* prep_dev, const uint32_t* challenges, uint32_t* out_dev,
+                                      uint32_t* cumulative_sum);
+
 #ifdef __cplusplus
 }
 #endif

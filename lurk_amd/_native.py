@@ -116,6 +116,17 @@ SIGNATURES = {
     "lurkhip_mem_trace_shape": (_i32, [_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "lurkhip_generate_trace_mem": (_i32, [_p, _p, C.c_uint32, _u32p, _i32]),
     "lurkhip_generate_trace_bytes": (_i32, [_p, _p, C.c_uint32, _u32p, _i32]),
+    "lurkhip_air_func": (_i32, [_p, _i32, C.POINTER(_p)]),
+    "lurkhip_air_mem": (_i32, [C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_air_bytes": (_i32, [C.POINTER(_p)]),
+    "lurkhip_air_entrypoint": (_i32, [C.c_uint32, C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_air_free": (_i32, [_p]),
+    "lurkhip_air_name": (C.c_char_p, [_p]),
+    "lurkhip_air_info": (_i32, [_p, _u32p]),
+    "lurkhip_air_interaction_sizes": (_i32, [_p, _u32p, C.c_uint32]),
+    "lurkhip_air_eval_rows": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
+    "lurkhip_air_check_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
+    "lurkhip_permutation_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p]),
 }
 
 

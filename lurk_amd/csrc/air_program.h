@@ -1,0 +1,56 @@
+// Register-program format of a chip's AIR, shared by the host lowering (lair/air.cpp) and the device VM
+// (air_vm.h).  All lanes of a launch run the same instruction stream (constraint evaluation has no
+// data-dependent control flow), so the program is read through the scalar cache and only operands and
+// results are per-lane.
+//
+// Words:
+//   header[H_WORDS] | code[2 * n_instr] | consts[n_consts] (Montgomery form)
+// Instruction = two words: w0 = op | dst << 8, w1 = a | b << 16, where a/b are 16-bit operands
+//   operand = source_type << 13 | index   (index < 8192)
+#pragma once
+#include <stdint.h>
+
+namespace airp {
+
+constexpr uint32_t MAGIC = 0x50524941u;  // "AIRP"
+
+enum Header : uint32_t {
+    H_MAGIC = 0,
+    H_N_INSTR,
+    H_N_REGS,
+    H_N_CONSTS,
+    H_N_ASSERTS,        // constraint program: number of ASSERT instructions
+    H_N_INTERACTIONS,   // interaction program: number of IBEGIN..IEND groups (sends first, then receives)
+    H_N_SENDS,
+    H_CODE_OFF,
+    H_CONST_OFF,
+    H_TOTAL_WORDS,
+    H_WORDS
+};
+
+enum Op : uint32_t {
+    OP_ADD = 1,  // regs[dst] = a + b
+    OP_SUB = 2,
+    OP_MUL = 3,
+    OP_ASSERT = 4,  // a must vanish on every row
+    OP_IBEGIN = 5,  // dst = interaction kind (argument index), a = is_send, b = number of values
+    OP_IVAL = 6,    // a = next value of the tuple
+    OP_IEND = 7     // a = multiplicity
+};
+
+enum Src : uint32_t {
+    S_REG = 0,
+    S_MAIN = 1,
+    S_MAIN_NEXT = 2,
+    S_PREP = 3,
+    S_PREP_NEXT = 4,
+    S_CONST = 5,
+    S_PUBLIC = 6,
+    S_SEL = 7  // index 0: is_first_row, 1: is_last_row, 2: is_transition
+};
+
+constexpr uint32_t SRC_SHIFT = 13;
+constexpr uint32_t SRC_MASK = (1u << SRC_SHIFT) - 1u;
+inline constexpr uint32_t operand(uint32_t type, uint32_t index) { return (type << SRC_SHIFT) | index; }
+
+}  // namespace airp

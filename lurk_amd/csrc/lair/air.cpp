@@ -1,0 +1,702 @@
+// Symbolic AIR builder for the Lair chips + lowering to the device register program.  See air.h.
+#include "air.h"
+
+#include <algorithm>
+#include <functional>
+#include <tuple>
+
+namespace lair {
+
+// ------------------------------------------------------------------ builder
+E Builder::intern(NodeKind k, uint32_t a, uint32_t b, uint8_t degree) {
+    auto key = std::make_tuple((uint8_t)k, a, b);
+    auto it = memo_.find(key);
+    if (it != memo_.end()) return it->second;
+    E id = (E)air_.nodes.size();
+    air_.nodes.push_back(Node{k, a, b, degree});
+    memo_.emplace(key, id);
+    return id;
+}
+E Builder::leaf(NodeKind k, uint32_t a, uint8_t degree) { return intern(k, a, 0, degree); }
+E Builder::cst(uint32_t canonical) { return intern(N_CONST, canonical % P, 0, 0); }
+
+bool Builder::is_const(E e, uint32_t* v) const {
+    const Node& n = air_.nodes[e];
+    if (n.kind != N_CONST) return false;
+    if (v) *v = n.a;
+    return true;
+}
+
+E Builder::add(E a, E b) {
+    uint32_t x, y;
+    const bool ca = is_const(a, &x), cb = is_const(b, &y);
+    if (ca && cb) return cst(fadd(x, y));
+    if (ca && x == 0) return b;
+    if (cb && y == 0) return a;
+    if (a > b) std::swap(a, b);  // commutative: one node per unordered pair
+    return intern(N_ADD, a, b, std::max(air_.nodes[a].degree, air_.nodes[b].degree));
+}
+E Builder::sub(E a, E b) {
+    uint32_t x, y;
+    const bool ca = is_const(a, &x), cb = is_const(b, &y);
+    if (ca && cb) return cst(fsub(x, y));
+    if (cb && y == 0) return a;
+    return intern(N_SUB, a, b, std::max(air_.nodes[a].degree, air_.nodes[b].degree));
+}
+E Builder::mul(E a, E b) {
+    uint32_t x, y;
+    const bool ca = is_const(a, &x), cb = is_const(b, &y);
+    if (ca && cb) return cst(fmul(x, y));
+    if ((ca && x == 0) || (cb && y == 0)) return cst(0);
+    if (ca && x == 1) return b;
+    if (cb && y == 1) return a;
+    if (a > b) std::swap(a, b);
+    return intern(N_MUL, a, b, (uint8_t)(air_.nodes[a].degree + air_.nodes[b].degree));
+}
+
+void Builder::assert_zero(E x, E cond) { air_.constraints.push_back(cond == NONE ? x : mul(cond, x)); }
+
+void Builder::receive(const std::vector<E>& values, E is_real) {
+    air_.receives.push_back(Interaction{false, INTERACTION_KIND_MEMORY, values, is_real});
+}
+void Builder::send(const std::vector<E>& values, E is_real) {
+    air_.sends.push_back(Interaction{true, INTERACTION_KIND_MEMORY, values, is_real});
+}
+
+// air/builder.rs:42-72
+void Builder::provide(const std::vector<E>& relation, E last_nonce, E last_count, E is_real) {
+    std::vector<E> r{last_nonce, last_count};
+    r.insert(r.end(), relation.begin(), relation.end());
+    receive(r, is_real);
+    std::vector<E> s{zero(), zero()};
+    s.insert(s.end(), relation.begin(), relation.end());
+    send(s, is_real);
+}
+
+// air/builder.rs:75-104
+void Builder::require(const std::vector<E>& relation, E nonce, E prev_nonce, E prev_count, E count_inv, E is_real) {
+    E count = add(prev_count, one());
+    assert_one(mul(count, count_inv), is_real);
+    std::vector<E> r{prev_nonce, prev_count};
+    r.insert(r.end(), relation.begin(), relation.end());
+    receive(r, is_real);
+    std::vector<E> s{nonce, count};
+    s.insert(s.end(), relation.begin(), relation.end());
+    send(s, is_real);
+}
+
+uint32_t ChipAir::max_constraint_degree() const {
+    uint32_t d = 0;
+    for (E c : constraints) d = std::max<uint32_t>(d, nodes[c].degree);
+    return d;
+}
+uint32_t ChipAir::log_quotient_degree() const {
+    uint32_t d = max_constraint_degree();
+    if (!sends.empty() || !receives.empty()) d = std::max(d, 3u);
+    if (d < 2) d = 2;  // log2_ceil(d - 1) with at least one quotient chunk
+    uint32_t l = 0;
+    while ((1u << l) < d - 1) l++;
+    return l;
+}
+uint32_t ChipAir::permutation_width() const {
+    const uint32_t batch = 1u << log_quotient_degree();
+    return (num_interactions() + batch - 1) / batch + 1;
+}
+
+// ------------------------------------------------------------------ byte-lookup records (gadgets/bytes/builder.rs)
+namespace {
+
+constexpr uint32_t CALL_TAG = 0, MEMORY_TAG = 1, BYTE_TAG = 3;
+
+struct ByteAirRecord {
+    struct Rec {
+        std::vector<E> relation;
+        E is_real;
+    };
+    std::vector<Rec> records;
+    Builder& b;
+    explicit ByteAirRecord(Builder& bb) : b(bb) {}
+    void range_check_u8_pair(E i1, E i2, E is_real) { records.push_back({{b.cst(BYTE_TAG), b.cst(1), i1, i2}, is_real}); }
+    void range_check_u8_iter(const std::vector<E>& xs, E is_real) {
+        for (size_t i = 0; i < xs.size(); i += 2) range_check_u8_pair(xs[i], i + 1 < xs.size() ? xs[i + 1] : b.zero(), is_real);
+    }
+    void range_check_u16(E i, E is_real) { records.push_back({{b.cst(BYTE_TAG), b.cst(2), i}, is_real}); }
+    void less_than(E i1, E i2, E r, E is_real) { records.push_back({{b.cst(BYTE_TAG), b.cst(3), i1, i2, r}, is_real}); }
+    // require_all (builder.rs:27-37): zip_eq with the row's RequireRecords
+    void require_all(E nonce, const std::vector<std::array<E, 3>>& requires_) {
+        if (requires_.size() != records.size()) throw ExecError("byte air record / require count mismatch");
+        for (size_t i = 0; i < records.size(); i++)
+            b.require(records[i].relation, nonce, requires_[i][0], requires_[i][1], requires_[i][2], records[i].is_real);
+    }
+};
+
+// ------------------------------------------------------------------ Func AIR (lair/air.rs:158-552)
+struct Val {
+    bool is_const;
+    uint32_t c;
+    E e;
+};
+
+struct FuncAirWalk {
+    const Toplevel& t;
+    const Func& f;
+    Builder& b;
+    LayoutSizes ls;
+    uint32_t in_cur = 0, aux_cur = 0, out_cur = 0;  // ColumnIndex
+    std::vector<Val> map;
+    E nonce;
+    std::vector<E> depth;  // own depth bytes (partial functions)
+
+    FuncAirWalk(const Toplevel& tl, const Func& fn, Builder& bb) : t(tl), f(fn), b(bb), ls(compute_layout_sizes(tl, fn)) {}
+
+    uint32_t col_input(uint32_t i) const { return 1 + i; }
+    uint32_t col_output(uint32_t i) const { return 1 + ls.input + i; }
+    uint32_t col_aux(uint32_t i) const { return 1 + ls.input + ls.output + i; }
+    uint32_t col_sel(uint32_t i) const { return 1 + ls.input + ls.output + ls.aux + i; }
+
+    E next_aux() {
+        if (aux_cur >= ls.aux) throw ExecError("AIR walk ran past the aux columns of " + f.name);
+        return b.main(col_aux(aux_cur++));
+    }
+    std::array<E, 3> next_require() {
+        E pn = next_aux(), pc = next_aux(), ci = next_aux();
+        return {pn, pc, ci};
+    }
+    E val_expr(const Val& v) { return v.is_const ? b.cst(v.c) : v.e; }
+    E var(uint32_t i) { return val_expr(map.at(i)); }
+    void push_expr(E e) { map.push_back(Val{false, 0, e}); }
+
+    E return_sel(const Block& blk) {
+        E s = b.zero();
+        for (uint32_t i : blk.return_idents) s = b.add(s, b.main(col_sel(i)));
+        return s;
+    }
+
+    // provenance.rs DepthLessThan = LessThanWitness<_, 4>; unsigned/less_than.rs:44-99
+    void assert_less_than(const std::array<E, 6>& wit, const std::vector<E>& lhs, const std::vector<E>& rhs, ByteAirRecord& rec,
+                          E is_real) {
+        const int W = DEPTH_W;
+        E is_equal = b.zero();
+        for (int i = 0; i < W; i++) {
+            if (i > 0) b.assert_eq(lhs[i], rhs[i], b.both(is_real, is_equal));
+            E is_comp = wit[i];
+            b.assert_bool(is_comp, is_real);
+            is_equal = b.add(is_equal, is_comp);
+        }
+        b.assert_one(is_equal, is_real);
+        auto select_limb = [&](const std::vector<E>& w) {
+            E s = b.zero();
+            for (int i = 0; i < W; i++) s = b.add(s, b.mul(w[i], wit[i]));
+            return s;
+        };
+        b.assert_eq(select_limb(lhs), wit[4], is_real);
+        b.assert_eq(select_limb(rhs), wit[5], is_real);
+        rec.less_than(wit[4], wit[5], b.one(), is_real);
+    }
+
+    // air.rs:103-133
+    void eval_depth(E sel, std::vector<E>& out) {
+        std::vector<E> dep_depth;
+        for (int i = 0; i < DEPTH_W; i++) dep_depth.push_back(next_aux());
+        std::array<E, 6> wit;
+        for (int i = 0; i < DEPTH_LESS_THAN_SIZE; i++) wit[i] = next_aux();
+        ByteAirRecord rec(b);
+        assert_less_than(wit, dep_depth, depth, rec, sel);
+        std::vector<std::array<E, 3>> reqs;
+        for (int i = 0; i < DEPTH_LT_REQUIRES; i++) reqs.push_back(next_require());
+        rec.require_all(nonce, reqs);
+        out.insert(out.end(), dep_depth.begin(), dep_depth.end());
+    }
+
+    void run() {
+        nonce = b.main(0);
+        E next_nonce = b.main_next(0);
+        // nonces are unique, even for dummy rows
+        b.assert_eq(next_nonce, b.add(nonce, b.one()), b.is_transition());
+        std::vector<E> call_inp;
+        for (uint32_t i = 0; i < f.input_size; i++) {
+            E v = b.main(col_input(in_cur++));
+            push_expr(v);
+            call_inp.push_back(v);
+        }
+        E toplevel_sel = return_sel(f.body);
+        b.assert_bool(toplevel_sel);
+        E last_nonce = next_aux(), last_count = next_aux();
+        std::vector<E> out;
+        for (uint32_t i = 0; i < f.output_size; i++) out.push_back(b.main(col_output(i)));
+        if (f.partial) {
+            for (int i = 0; i < DEPTH_W; i++) depth.push_back(next_aux());
+            const int num_requires = (DEPTH_W / 2) + (DEPTH_W % 2);
+            std::vector<std::array<E, 3>> reqs;
+            for (int i = 0; i < num_requires; i++) reqs.push_back(next_require());
+            ByteAirRecord rec(b);
+            rec.range_check_u8_iter(depth, toplevel_sel);
+            rec.require_all(nonce, reqs);
+            out.insert(out.end(), depth.begin(), depth.end());
+        }
+        std::vector<E> rel{b.cst(CALL_TAG), b.cst(f.index)};
+        rel.insert(rel.end(), call_inp.begin(), call_inp.end());
+        rel.insert(rel.end(), out.begin(), out.end());
+        b.provide(rel, last_nonce, last_count, toplevel_sel);
+        eval_block(f.body, toplevel_sel);
+    }
+
+    void eval_block(const Block& blk, E sel) {
+        for (const Op& op : blk.ops) eval_op(op, sel);
+        eval_ctrl(blk.ctrl);
+    }
+
+    void eval_ctrl(const Ctrl& c) {
+        if (c.kind == Ctrl::Return) {
+            E sel = b.main(col_sel(c.ident));
+            for (uint32_t v : c.ret) {
+                if (out_cur >= ls.output) throw ExecError("AIR walk ran past the output columns");
+                E out_var = b.main(col_output(out_cur++));
+                b.assert_eq(var(v), out_var, sel);
+            }
+            return;
+        }
+        const size_t map_len = map.size();
+        const uint32_t s_aux = aux_cur, s_out = out_cur;
+        auto process = [&](const Block& blk) {
+            E sel = return_sel(blk);
+            eval_block(blk, sel);
+            map.resize(map_len);
+            aux_cur = s_aux;
+            out_cur = s_out;
+        };
+        if (c.kind == Ctrl::Choose) {
+            for (const auto& blk : c.unique_branches) process(*blk);
+        } else {
+            for (const auto& kv : c.branches) process(*kv.second);
+        }
+        if (c.def) process(*c.def);
+    }
+
+    void eval_op(const Op& op, E sel) {
+        switch (op.kind) {
+            case OpKind::AssertNe: {
+                // constrain_inequality_witness (air.rs:540-552)
+                std::vector<E> coeffs;
+                for (size_t i = 0; i < op.a.size(); i++) coeffs.push_back(next_aux());
+                E acc = b.zero();
+                for (size_t i = 0; i < op.a.size(); i++) acc = b.add(acc, b.mul(coeffs[i], b.sub(var(op.a[i]), var(op.b[i]))));
+                b.assert_one(acc, sel);
+                break;
+            }
+            case OpKind::AssertEq:
+                for (size_t i = 0; i < op.a.size(); i++) b.assert_eq(var(op.a[i]), var(op.b[i]), sel);
+                break;
+            case OpKind::Contains: {
+                E y = var(op.y);
+                E acc = b.sub(var(op.a[0]), y);
+                for (size_t i = 1; i < op.a.size(); i++) {
+                    E diff = b.sub(var(op.a[i]), y);
+                    E aux = next_aux();
+                    b.assert_eq(b.mul(acc, diff), aux, sel);
+                    acc = aux;
+                }
+                b.assert_zero(acc, sel);
+                break;
+            }
+            case OpKind::Const:
+                map.push_back(Val{true, op.c % P, 0});
+                break;
+            case OpKind::Add:
+            case OpKind::Sub: {
+                const Val &x = map.at(op.x), &y = map.at(op.y);
+                const bool add = op.kind == OpKind::Add;
+                if (x.is_const && y.is_const) map.push_back(Val{true, add ? fadd(x.c, y.c) : fsub(x.c, y.c), 0});
+                else {
+                    E ex = val_expr(x), ey = val_expr(y);
+                    push_expr(add ? b.add(ex, ey) : b.sub(ex, ey));
+                }
+                break;
+            }
+            case OpKind::Mul: {
+                const Val x = map.at(op.x), y = map.at(op.y);
+                if (x.is_const && y.is_const) map.push_back(Val{true, fmul(x.c, y.c), 0});
+                else {
+                    // air.rs:345-358: an aux column whenever not both operands are constants (the layout
+                    // only allocates one when both have degree 1, func_chip.rs:202-211 -- upstream disagreement
+                    // preserved)
+                    E c = next_aux();
+                    b.assert_eq(b.mul(val_expr(x), val_expr(y)), c, sel);
+                    push_expr(c);
+                }
+                break;
+            }
+            case OpKind::Inv: {
+                const Val x = map.at(op.x);
+                if (x.is_const) map.push_back(Val{true, finv(x.c), 0});
+                else {
+                    E c = next_aux();
+                    b.assert_one(b.mul(val_expr(x), c), sel);
+                    push_expr(c);
+                }
+                break;
+            }
+            case OpKind::Not: {
+                const Val x = map.at(op.x);
+                if (x.is_const) map.push_back(Val{true, x.c == 0 ? 1u : 0u, 0});
+                else {
+                    E d = next_aux(), r = next_aux();
+                    E a = val_expr(x);
+                    b.assert_zero(b.mul(a, r), sel);
+                    b.assert_one(b.add(b.mul(a, d), r), sel);
+                    push_expr(r);
+                }
+                break;
+            }
+            case OpKind::Call: {
+                const Func& callee = t.funcs.at(op.x);
+                std::vector<E> out;
+                for (uint32_t i = 0; i < callee.output_size; i++) {
+                    E o = next_aux();
+                    push_expr(o);
+                    out.push_back(o);
+                }
+                std::vector<E> inp;
+                for (uint32_t v : op.a) inp.push_back(var(v));
+                auto rec = next_require();
+                if (callee.partial) eval_depth(sel, out);
+                std::vector<E> rel{b.cst(CALL_TAG), b.cst(op.x)};
+                rel.insert(rel.end(), inp.begin(), inp.end());
+                rel.insert(rel.end(), out.begin(), out.end());
+                b.require(rel, nonce, rec[0], rec[1], rec[2], sel);
+                break;
+            }
+            case OpKind::PreImg: {
+                const Func& callee = t.funcs.at(op.x);
+                std::vector<E> inp;
+                for (uint32_t i = 0; i < callee.input_size; i++) {
+                    E v = next_aux();
+                    push_expr(v);
+                    inp.push_back(v);
+                }
+                std::vector<E> out;
+                for (uint32_t v : op.a) out.push_back(var(v));
+                auto rec = next_require();
+                if (callee.partial) eval_depth(sel, out);
+                std::vector<E> rel{b.cst(CALL_TAG), b.cst(op.x)};
+                rel.insert(rel.end(), inp.begin(), inp.end());
+                rel.insert(rel.end(), out.begin(), out.end());
+                b.require(rel, nonce, rec[0], rec[1], rec[2], sel);
+                break;
+            }
+            case OpKind::Store: {
+                E ptr = next_aux();
+                push_expr(ptr);
+                std::vector<E> rel{b.cst(MEMORY_TAG), ptr};
+                for (uint32_t v : op.a) rel.push_back(var(v));
+                auto rec = next_require();
+                b.require(rel, nonce, rec[0], rec[1], rec[2], sel);
+                break;
+            }
+            case OpKind::Load: {
+                E ptr = var(op.y);
+                std::vector<E> rel{b.cst(MEMORY_TAG), ptr};
+                for (uint32_t i = 0; i < op.x; i++) {
+                    E o = next_aux();
+                    push_expr(o);
+                    rel.push_back(o);
+                }
+                auto rec = next_require();
+                b.require(rel, nonce, rec[0], rec[1], rec[2], sel);
+                break;
+            }
+            case OpKind::RangeU8: {
+                const size_t num_requires = (op.a.size() / 2) + (op.a.size() % 2);
+                std::vector<std::array<E, 3>> reqs;
+                for (size_t i = 0; i < num_requires; i++) reqs.push_back(next_require());
+                ByteAirRecord rec(b);
+                std::vector<E> xs;
+                for (uint32_t v : op.a) xs.push_back(var(v));
+                rec.range_check_u8_iter(xs, sel);
+                rec.require_all(nonce, reqs);
+                break;
+            }
+            case OpKind::ExternCall:
+                throw ExecError("AIR of extern chip " + t.chips.at(op.x).name + " is not available in this build");
+            case OpKind::Emit:
+            case OpKind::Breakpoint:
+            case OpKind::Debug:
+                break;
+        }
+    }
+};
+
+}  // namespace
+
+ChipAir build_func_air(const Toplevel& t, const Func& f) {
+    ChipAir air;
+    air.name = "Func[" + f.name + "]";
+    Builder b(air);
+    FuncAirWalk w(t, f, b);
+    air.width = w.ls.total();
+    w.run();
+    return air;
+}
+
+// lair/memory.rs:71-109
+ChipAir build_mem_air(uint32_t len) {
+    ChipAir air;
+    air.name = "Mem[" + std::to_string(len) + "-wide]";
+    air.width = 4 + len;
+    Builder b(air);
+    E is_real = b.main(0), ptr_local = b.main(1), last_nonce = b.main(2), last_count = b.main(3);
+    E is_real_next = b.main_next(0), ptr_next = b.main_next(1);
+    b.assert_bool(is_real);
+    E is_real_transition = b.mul(is_real_next, b.is_transition());
+    b.assert_one(is_real, is_real_transition);
+    b.assert_one(ptr_local, b.both(b.is_first_row(), is_real));
+    b.assert_eq(b.add(ptr_local, b.one()), ptr_next, is_real_transition);
+    std::vector<E> rel{b.cst(MEMORY_TAG), ptr_local};
+    for (uint32_t i = 0; i < len; i++) rel.push_back(b.main(4 + i));
+    b.provide(rel, last_nonce, last_count, is_real);
+    return air;
+}
+
+// gadgets/bytes/trace.rs:117-143; columns: preprocessed [i1, i2, less_than, and, xor, or],
+// main [is_real, 6 x (last_nonce, last_count)]
+ChipAir build_bytes_air() {
+    ChipAir air;
+    air.name = "CPU";  // the name sphinx requires of the byte chip (lair_chip.rs:90-92)
+    air.width = 13;
+    air.prep_width = 6;
+    Builder b(air);
+    E is_real = b.main(0);
+    b.assert_bool(is_real);
+    E i1 = b.prep(0), i2 = b.prep(1);
+    E input_u16 = b.add(i1, b.mul(i2, b.cst(256)));
+    std::vector<std::vector<E>> relations = {
+        {b.cst(BYTE_TAG), b.cst(1), i1, i2},        {b.cst(BYTE_TAG), b.cst(2), input_u16},
+        {b.cst(BYTE_TAG), b.cst(3), i1, i2, b.prep(2)}, {b.cst(BYTE_TAG), b.cst(4), i1, i2, b.prep(3)},
+        {b.cst(BYTE_TAG), b.cst(5), i1, i2, b.prep(4)}, {b.cst(BYTE_TAG), b.cst(6), i1, i2, b.prep(5)},
+    };
+    for (size_t k = 0; k < relations.size(); k++) b.provide(relations[k], b.main(1 + 2 * (uint32_t)k), b.main(2 + 2 * (uint32_t)k), is_real);
+    return air;
+}
+
+// lair/lair_chip.rs:166-191
+ChipAir build_entrypoint_air(uint32_t func_idx, uint32_t num_public_values) {
+    ChipAir air;
+    air.name = "Entrypoint[" + std::to_string(func_idx) + "]";
+    air.width = num_public_values;
+    air.num_public = num_public_values;
+    Builder b(air);
+    std::vector<E> rel{b.cst(CALL_TAG), b.cst(func_idx)};
+    for (uint32_t i = 0; i < num_public_values; i++) {
+        b.assert_eq(b.main(i), b.pub(i));
+        rel.push_back(b.main(i));
+    }
+    b.require(rel, b.zero(), b.zero(), b.zero(), b.one(), b.one());
+    return air;
+}
+
+// ------------------------------------------------------------------ lowering
+namespace {
+
+struct Lowerer {
+    const ChipAir& air;
+    std::vector<uint32_t> code;     // 2 words per instruction
+    std::vector<uint32_t> consts;   // Montgomery
+    std::map<uint32_t, uint32_t> const_index;
+    // scheduling
+    std::vector<E> order;                  // non-leaf nodes in emission order
+    std::vector<int> pos;                  // node -> index in `order` (-1: not emitted)
+    std::vector<int> last_use;             // node -> index of the last consuming step
+    std::vector<int> reg_of;
+    uint32_t n_regs = 0;
+
+    explicit Lowerer(const ChipAir& a) : air(a), pos(a.nodes.size(), -1), last_use(a.nodes.size(), -1), reg_of(a.nodes.size(), -1) {}
+
+    bool is_leaf(E e) const {
+        NodeKind k = air.nodes[e].kind;
+        return k != N_ADD && k != N_SUB && k != N_MUL;
+    }
+    static uint32_t to_monty(uint32_t x) { return (uint32_t)((((uint64_t)x) << 32) % P); }
+
+    uint32_t const_slot(uint32_t canonical) {
+        auto it = const_index.find(canonical);
+        if (it != const_index.end()) return it->second;
+        uint32_t i = (uint32_t)consts.size();
+        consts.push_back(to_monty(canonical));
+        const_index.emplace(canonical, i);
+        return i;
+    }
+
+    uint32_t operand_of(E e) {
+        const Node& n = air.nodes[e];
+        uint32_t idx = n.a, type;
+        switch (n.kind) {
+            case N_CONST: type = airp::S_CONST; idx = const_slot(n.a); break;
+            case N_MAIN: type = airp::S_MAIN; break;
+            case N_MAIN_NEXT: type = airp::S_MAIN_NEXT; break;
+            case N_PREP: type = airp::S_PREP; break;
+            case N_PREP_NEXT: type = airp::S_PREP_NEXT; break;
+            case N_PUBLIC: type = airp::S_PUBLIC; break;
+            case N_IS_FIRST: type = airp::S_SEL; idx = 0; break;
+            case N_IS_LAST: type = airp::S_SEL; idx = 1; break;
+            case N_IS_TRANS: type = airp::S_SEL; idx = 2; break;
+            default: type = airp::S_REG; idx = (uint32_t)reg_of[e]; break;
+        }
+        if (idx > airp::SRC_MASK) throw ExecError("AIR program operand index out of range");
+        return airp::operand(type, idx);
+    }
+
+    // iterative post-order scheduling of the non-leaf nodes under `root`
+    void schedule(E root) {
+        if (is_leaf(root) || pos[root] >= 0) return;
+        std::vector<std::pair<E, int>> st{{root, 0}};
+        while (!st.empty()) {
+            auto& [e, phase] = st.back();
+            const Node& n = air.nodes[e];
+            if (phase == 0) {
+                phase = 1;
+                if (!is_leaf(n.a) && pos[n.a] < 0) st.push_back({n.a, 0});
+            } else if (phase == 1) {
+                phase = 2;
+                if (!is_leaf(n.b) && pos[n.b] < 0) st.push_back({n.b, 0});
+            } else {
+                if (pos[e] < 0) {
+                    pos[e] = (int)order.size();
+                    order.push_back(e);
+                }
+                st.pop_back();
+            }
+        }
+    }
+
+    void emit(uint32_t op, uint32_t dst, uint32_t a, uint32_t b) {
+        code.push_back(op | (dst << 8));
+        code.push_back(a | (b << 16));
+    }
+
+    // `steps`: the root uses in program order; each step is (kind, node or immediate)
+    struct Step {
+        uint32_t op;
+        E node;            // ASSERT / IVAL / IEND operand
+        uint32_t dst = 0, a = 0, b = 0;  // IBEGIN immediates
+    };
+
+    std::vector<uint32_t> lower(const std::vector<Step>& steps, uint32_t n_asserts, uint32_t n_interactions, uint32_t n_sends) {
+        // 1. schedule every node needed by a step right before the step's position: emission order is
+        //    the concatenation over steps of the not-yet-emitted nodes
+        std::vector<size_t> step_after(steps.size());  // number of compute nodes emitted before step i
+        for (size_t i = 0; i < steps.size(); i++) {
+            if (steps[i].op != airp::OP_IBEGIN) schedule(steps[i].node);
+            step_after[i] = order.size();
+        }
+        // 2. last use, in a merged timeline: time of compute node k = 2 * ... simpler: walk the final stream
+        //    and record for each node the last stream position that reads it
+        struct Item { bool is_step; size_t idx; };
+        std::vector<Item> stream;
+        {
+            size_t k = 0;
+            for (size_t i = 0; i < steps.size(); i++) {
+                while (k < step_after[i]) stream.push_back({false, k++});
+                stream.push_back({true, i});
+            }
+        }
+        for (size_t s = 0; s < stream.size(); s++) {
+            if (stream[s].is_step) {
+                const Step& st = steps[stream[s].idx];
+                if (st.op != airp::OP_IBEGIN && !is_leaf(st.node)) last_use[st.node] = (int)s;
+            } else {
+                const Node& n = air.nodes[order[stream[s].idx]];
+                if (!is_leaf(n.a)) last_use[n.a] = (int)s;
+                if (!is_leaf(n.b)) last_use[n.b] = (int)s;
+            }
+        }
+        // 3. emit with a free list
+        std::vector<uint32_t> free_regs;
+        auto alloc = [&]() {
+            if (!free_regs.empty()) {
+                uint32_t r = free_regs.back();
+                free_regs.pop_back();
+                return r;
+            }
+            return n_regs++;
+        };
+        auto release_if_dead = [&](E e, int s) {
+            if (!is_leaf(e) && last_use[e] == s && reg_of[e] >= 0) {
+                free_regs.push_back((uint32_t)reg_of[e]);
+                reg_of[e] = -2;  // dead
+            }
+        };
+        uint32_t n_instr = 0;
+        for (size_t s = 0; s < stream.size(); s++) {
+            if (stream[s].is_step) {
+                const Step& st = steps[stream[s].idx];
+                if (st.op == airp::OP_IBEGIN) emit(st.op, st.dst, st.a, st.b);
+                else {
+                    emit(st.op, 0, operand_of(st.node), 0);
+                    release_if_dead(st.node, (int)s);
+                }
+            } else {
+                E e = order[stream[s].idx];
+                const Node& n = air.nodes[e];
+                uint32_t oa = operand_of(n.a), ob = operand_of(n.b);
+                // operands may die here: their registers can be reused for the result
+                release_if_dead(n.a, (int)s);
+                if (n.b != n.a) release_if_dead(n.b, (int)s);
+                uint32_t r = alloc();
+                reg_of[e] = (int)r;
+                uint32_t op = n.kind == N_ADD ? airp::OP_ADD : (n.kind == N_SUB ? airp::OP_SUB : airp::OP_MUL);
+                emit(op, r, oa, ob);
+                if (last_use[e] < 0) {  // never read (cannot happen for scheduled nodes, but keep the pool sound)
+                    free_regs.push_back(r);
+                    reg_of[e] = -2;
+                }
+            }
+            n_instr++;
+        }
+        if (n_regs > airp::SRC_MASK) throw ExecError("AIR program needs too many registers");
+        std::vector<uint32_t> out(airp::H_WORDS, 0);
+        out[airp::H_MAGIC] = airp::MAGIC;
+        out[airp::H_N_INSTR] = n_instr;
+        out[airp::H_N_REGS] = std::max<uint32_t>(n_regs, 1);
+        out[airp::H_N_CONSTS] = (uint32_t)consts.size();
+        out[airp::H_N_ASSERTS] = n_asserts;
+        out[airp::H_N_INTERACTIONS] = n_interactions;
+        out[airp::H_N_SENDS] = n_sends;
+        out[airp::H_CODE_OFF] = airp::H_WORDS;
+        out[airp::H_CONST_OFF] = airp::H_WORDS + (uint32_t)code.size();
+        out.insert(out.end(), code.begin(), code.end());
+        out.insert(out.end(), consts.begin(), consts.end());
+        out[airp::H_TOTAL_WORDS] = (uint32_t)out.size();
+        return out;
+    }
+};
+
+}  // namespace
+
+AirPrograms lower_air(const ChipAir& air) {
+    AirPrograms p;
+    {
+        Lowerer lw(air);
+        std::vector<Lowerer::Step> steps;
+        for (E c : air.constraints) steps.push_back({airp::OP_ASSERT, c});
+        p.constraints = lw.lower(steps, (uint32_t)air.constraints.size(), 0, 0);
+    }
+    {
+        Lowerer lw(air);
+        std::vector<Lowerer::Step> steps;
+        auto add = [&](const Interaction& it) {
+            Lowerer::Step s{airp::OP_IBEGIN, 0};
+            s.dst = it.kind;
+            s.a = it.is_send ? 1 : 0;
+            s.b = (uint32_t)it.values.size();
+            steps.push_back(s);
+            for (E v : it.values) steps.push_back({airp::OP_IVAL, v});
+            steps.push_back({airp::OP_IEND, it.mult});
+        };
+        for (const auto& it : air.sends) add(it);
+        for (const auto& it : air.receives) add(it);
+        p.interactions = lw.lower(steps, 0, air.num_interactions(), (uint32_t)air.sends.size());
+    }
+    return p;
+}
+
+}  // namespace lair

@@ -8,6 +8,8 @@
 #include <cstring>
 
 #include "../ctx.h"
+#include "../stark.h"
+#include "air.h"
 #include "lair.h"
 
 struct lurkhip_toplevel {
@@ -108,6 +110,13 @@ int32_t lurkhip_toplevel_func_info(const lurkhip_toplevel* top, int32_t func_idx
     uint32_t v[9] = {f.input_size, f.output_size, f.partial, f.invertible, l.nonce, l.input, l.output, l.aux, l.sel};
     memcpy(info, v, sizeof v);
     return LURKHIP_OK;
+}
+
+// AIR of one function's chip (lair/air.rs:158-552), lowered for the device VM
+int32_t lurkhip_air_func(const lurkhip_toplevel* top, int32_t func_idx, lurkhip_air** out) {
+    if (!top || !out || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size()) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "bad func index");
+    *out = nullptr;
+    return guarded(nullptr, [&]() -> int32_t { return lurkhip_air_from_chip(lair::build_func_air(top->t, top->t.funcs[func_idx]), out); });
 }
 
 int32_t lurkhip_record_new(const lurkhip_toplevel* top, lurkhip_record** out) {

@@ -1,0 +1,24 @@
+// Internal interfaces of the AIR-driven prover stages (stark.hip).
+#pragma once
+#include <stdint.h>
+
+#include "ctx.h"
+#include "lair/air.h"
+
+struct lurkhip_air;
+
+namespace lurkhip {
+
+// device copies (per HIP device) of the chip's two programs
+int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** constraints, const uint32_t** interactions);
+const lair::ChipAir& air_of(const lurkhip_air* a);
+const lair::AirPrograms& programs_of(const lurkhip_air* a);
+int vm_block(uint32_t n_regs, size_t* lds_bytes);
+// out[i] = base^i for i < count (extension field, Montgomery words)
+int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count);
+// in-place inclusive scan of the EF elements data[r * stride_words .. +4], r < n
+int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, size_t n);
+
+}  // namespace lurkhip
+
+extern "C" int32_t lurkhip_air_from_chip(lair::ChipAir&& air, lurkhip_air** out);

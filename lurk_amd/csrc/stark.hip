@@ -1,0 +1,571 @@
+// Prover stages that consume a chip's AIR program: debug constraint check, LogUp permutation trace,
+// quotient values.
+//
+// Replaces (third-party, source absent from /root/reference -> parity unpinned):
+//   sphinx-core `generate_permutation_trace` / `eval_permutation_constraints` / `quotient_values`
+//   / `debug_constraints`   [UPSTREAM-RECALL, sphinx @ 8a39b951 = SP1 v1 lineage]
+// driven by the in-tree AIRs (/root/reference/src/lair/air.rs:158-552, src/lair/memory.rs:71-109,
+// src/gadgets/bytes/trace.rs:117-143, src/lair/lair_chip.rs:166-191) and the in-tree lookup protocol
+// (/root/reference/src/air/builder.rs:34-133).  The dead in-tree LogUp (src/logup/trace.rs:53-151) has the
+// same shape (RLC denominators, batched inverses, running sum) and is covered by the same kernels.
+//
+// Permutation trace row i (sphinx `populate_permutation_row`):
+//   for interaction j (sends first, then receives), with tuple v_0..v_{k-1}, multiplicity m, kind K:
+//       d_j = alpha + K + sum_t beta^(t+1) v_t          (extension field)
+//   batch column c = sum_{j in batch c} (+-m_j) / d_j   (+ for sends, - for receives; batch = 2^log_quotient_degree)
+//   last column = inclusive running sum over rows of the row's batch columns.
+#include <map>
+#include <mutex>
+
+#include "air_vm.h"
+#include "babybear.h"
+#include "ctx.h"
+#include "lair/air.h"
+#include "stark.h"
+
+struct lurkhip_air {
+    lair::ChipAir air;
+    lair::AirPrograms prog;
+    std::mutex mu;
+    std::map<int, std::pair<uint32_t*, uint32_t*>> dev;  // device -> (constraint program, interaction program)
+    uint32_t tuple_words = 0;                              // sum over interactions of (1 + #values)
+    uint32_t max_tuple = 0;
+};
+
+namespace lurkhip {
+
+int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons, const uint32_t** inter) {
+    std::lock_guard<std::mutex> g(a->mu);
+    auto it = a->dev.find(ctx->device);
+    if (it == a->dev.end()) {
+        uint32_t *c = nullptr, *i = nullptr;
+        LH_HIP(ctx, hipMalloc(&c, a->prog.constraints.size() * 4));
+        LH_HIP(ctx, hipMalloc(&i, a->prog.interactions.size() * 4));
+        LH_HIP(ctx, hipMemcpy(c, a->prog.constraints.data(), a->prog.constraints.size() * 4, hipMemcpyHostToDevice));
+        LH_HIP(ctx, hipMemcpy(i, a->prog.interactions.data(), a->prog.interactions.size() * 4, hipMemcpyHostToDevice));
+        it = a->dev.emplace(ctx->device, std::make_pair(c, i)).first;
+    }
+    if (cons) *cons = it->second.first;
+    if (inter) *inter = it->second.second;
+    return LURKHIP_OK;
+}
+
+const lair::ChipAir& air_of(const lurkhip_air* a) { return a->air; }
+const lair::AirPrograms& programs_of(const lurkhip_air* a) { return a->prog; }
+
+// threads per block for a VM launch whose register file is regs[n_regs][block] in LDS
+int vm_block(uint32_t n_regs, size_t* lds_bytes) {
+    int block = 256;
+    while (block > 64 && (size_t)n_regs * block * 4 > 48 * 1024) block >>= 1;
+    *lds_bytes = (size_t)n_regs * block * 4;
+    return block;
+}
+
+namespace {
+
+using bb::ef;
+
+__device__ __forceinline__ ef ef_load(const uint32_t* p) { return ef{{p[0], p[1], p[2], p[3]}}; }
+
+// ---------------------------------------------------------------- explicit-row evaluation (debug / parity)
+struct DumpSink {
+    uint32_t* cons_out;   // [K] canonical
+    uint32_t* inter_out;  // per interaction: multiplicity, then the tuple (canonical)
+    uint32_t k = 0, t = 0;
+    __device__ __forceinline__ void assert_zero(uint32_t v) { cons_out[k++] = bb::from_monty(v); }
+    __device__ __forceinline__ void ibegin(uint32_t, bool, uint32_t) { t++; /* slot for the multiplicity */ base = t - 1; }
+    __device__ __forceinline__ void ival(uint32_t v) { inter_out[t++] = bb::from_monty(v); }
+    __device__ __forceinline__ void iend(uint32_t m) { inter_out[base] = bb::from_monty(m); }
+    uint32_t base = 0;
+};
+
+struct EvalRowsArgs {
+    const uint32_t* cons_prog;
+    const uint32_t* inter_prog;
+    const uint32_t* local;  // [n][w] Montgomery
+    const uint32_t* next;
+    const uint32_t* prep_local;
+    const uint32_t* prep_next;
+    const uint32_t* pub;
+    const uint32_t* sels;  // [n][3] Montgomery
+    uint32_t* cons_out;    // [n][K]
+    uint32_t* inter_out;   // [n][T]
+    uint32_t n, w, pw, K, T;
+};
+
+__global__ void k_air_eval_rows(EvalRowsArgs a) {
+    extern __shared__ uint32_t regs[];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= a.n) return;
+    airvm::Sources s{a.local + (size_t)i * a.w, a.next + (size_t)i * a.w, a.prep_local + (size_t)i * a.pw,
+                     a.prep_next + (size_t)i * a.pw, a.pub, {a.sels[3 * i], a.sels[3 * i + 1], a.sels[3 * i + 2]}};
+    DumpSink sink{a.cons_out + (size_t)i * a.K, a.inter_out + (size_t)i * a.T};
+    airvm::run(a.cons_prog, s, regs + threadIdx.x, blockDim.x, sink);
+    airvm::run(a.inter_prog, s, regs + threadIdx.x, blockDim.x, sink);
+}
+
+// ---------------------------------------------------------------- debug check of a whole trace
+struct CheckSink {
+    unsigned long long* first_bad;
+    uint32_t row;
+    uint32_t k = 0;
+    __device__ __forceinline__ void assert_zero(uint32_t v) {
+        if (v != 0) atomicMin(first_bad, ((unsigned long long)row << 32) | k);
+        k++;
+    }
+    __device__ __forceinline__ void ibegin(uint32_t, bool, uint32_t) {}
+    __device__ __forceinline__ void ival(uint32_t) {}
+    __device__ __forceinline__ void iend(uint32_t) {}
+};
+
+__global__ void k_air_check(const uint32_t* __restrict__ prog, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep,
+                            const uint32_t* __restrict__ pub, uint32_t n, uint32_t w, uint32_t pw, unsigned long long* first_bad) {
+    extern __shared__ uint32_t regs[];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nx = i + 1 == n ? 0 : i + 1;
+    // the selectors of a row-by-row checker (p3 check_constraints): indicator values on the trace domain
+    airvm::Sources s{main + (size_t)i * w, main + (size_t)nx * w, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub,
+                     {i == 0 ? bb::R1 : 0u, i + 1 == n ? bb::R1 : 0u, i + 1 == n ? 0u : bb::R1}};
+    CheckSink sink{first_bad, i};
+    airvm::run(prog, s, regs + threadIdx.x, blockDim.x, sink);
+}
+
+// ---------------------------------------------------------------- permutation trace rows
+// beta_pows[t] = beta^t (t = 0 .. max_tuple), Montgomery, 4 words each
+__global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t* __restrict__ out, uint32_t count) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    ef base{{b0, b1, b2, b3}}, r = bb::ef_one();
+    uint32_t e = i;
+    while (e) {
+        if (e & 1u) r = bb::ef_mul(r, base);
+        base = bb::ef_sqr(base);
+        e >>= 1;
+    }
+    out[4 * i] = r.c[0];
+    out[4 * i + 1] = r.c[1];
+    out[4 * i + 2] = r.c[2];
+    out[4 * i + 3] = r.c[3];
+}
+
+}  // namespace
+
+// Running (numerator, denominator) of the current batch of interactions; shared by the permutation trace
+// and the quotient kernel (where entry * den - num is the batch's constraint).
+struct LogupAccum {
+    const uint32_t* __restrict__ beta_pows;
+    ef alpha;
+    ef cur, num, den;
+    uint32_t t = 0, in_batch = 0;
+    bool is_send = false;
+    __device__ __forceinline__ void begin(uint32_t kind, bool send) {
+        cur = bb::ef_add_base(alpha, bb::to_monty(kind));  // alpha + beta^0 * argument_index
+        t = 1;
+        is_send = send;
+    }
+    __device__ __forceinline__ void value(uint32_t v) {
+        cur = bb::ef_add(cur, bb::ef_scale(ef_load(beta_pows + 4 * t), v));
+        t++;
+    }
+    // folds the finished interaction into the batch; returns true when the batch holds `batch` interactions
+    __device__ __forceinline__ bool end(uint32_t mult, uint32_t batch) {
+        const uint32_t m = is_send ? mult : bb::neg(mult);
+        if (in_batch == 0) {
+            num = bb::ef_from_base(m);
+            den = cur;
+        } else {
+            num = bb::ef_add(bb::ef_mul(num, cur), bb::ef_scale(den, m));
+            den = bb::ef_mul(den, cur);
+        }
+        in_batch++;
+        return in_batch == batch;
+    }
+};
+
+namespace {
+
+struct PermSink {
+    LogupAccum acc;
+    uint32_t batch;
+    uint32_t* out_row;  // [perm_width * 4]
+    uint32_t col = 0;
+    ef row_sum = bb::ef_zero();
+    __device__ __forceinline__ void assert_zero(uint32_t) {}
+    __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
+    __device__ __forceinline__ void ival(uint32_t v) { acc.value(v); }
+    __device__ __forceinline__ void flush() {
+        ef v = bb::ef_mul(acc.num, bb::ef_inv(acc.den));
+        uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
+        *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
+        row_sum = bb::ef_add(row_sum, v);
+        col++;
+        acc.in_batch = 0;
+    }
+    __device__ __forceinline__ void iend(uint32_t m) {
+        if (acc.end(m, batch)) flush();
+    }
+};
+
+__global__ void k_perm_rows(const uint32_t* __restrict__ prog, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep,
+                            const uint32_t* __restrict__ pub, const uint32_t* __restrict__ beta_pows, ef alpha, uint32_t n, uint32_t w,
+                            uint32_t pw, uint32_t perm_w, uint32_t batch, uint32_t* __restrict__ out) {
+    extern __shared__ uint32_t regs[];
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= n) return;
+    const uint32_t nx = i + 1 == n ? 0 : i + 1;
+    airvm::Sources s{main + (size_t)i * w, main + (size_t)nx * w, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub, {0u, 0u, 0u}};
+    PermSink sink{LogupAccum{beta_pows, alpha}, batch, out + (size_t)i * perm_w * 4};
+    airvm::run(prog, s, regs + threadIdx.x, blockDim.x, sink);
+    if (sink.acc.in_batch) sink.flush();
+    // the row's sum goes to the last column; the scan below turns it into the running sum
+    uint4* dst = reinterpret_cast<uint4*>(sink.out_row + 4 * (perm_w - 1));
+    *dst = make_uint4(sink.row_sum.c[0], sink.row_sum.c[1], sink.row_sum.c[2], sink.row_sum.c[3]);
+}
+
+// ---------------------------------------------------------------- inclusive scan of an EF column
+// (the sequential loop of /root/reference/src/logup/trace.rs:142-148 / sphinx's `scan`), three launches:
+// chunk-local scans, scan of the chunk totals, offset add.  EF addition is component-wise.
+constexpr int SCAN_BLOCK = 256;
+constexpr int SCAN_PER_THREAD = 4;
+constexpr int SCAN_CHUNK = SCAN_BLOCK * SCAN_PER_THREAD;
+
+__device__ __forceinline__ uint4 add4(uint4 a, uint4 b) {
+    return make_uint4(bb::add(a.x, b.x), bb::add(a.y, b.y), bb::add(a.z, b.z), bb::add(a.w, b.w));
+}
+
+// data: element r at data[r * stride_words .. +4]
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(uint32_t* __restrict__ data, size_t stride_words, size_t n,
+                                                            uint4* __restrict__ totals) {
+    __shared__ uint4 sh[SCAN_BLOCK];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+    uint4 v[SCAN_PER_THREAD];
+    uint4 run = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        size_t r = base + k;
+        uint4 x = r < n ? *reinterpret_cast<const uint4*>(data + r * stride_words) : make_uint4(0, 0, 0, 0);
+        run = add4(run, x);
+        v[k] = run;
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    // Hillis-Steele over the per-thread totals
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if ((int)threadIdx.x >= off) t = sh[threadIdx.x - off];
+        __syncthreads();
+        if ((int)threadIdx.x >= off) sh[threadIdx.x] = add4(sh[threadIdx.x], t);
+        __syncthreads();
+    }
+    uint4 prefix = threadIdx.x ? sh[threadIdx.x - 1] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        size_t r = base + k;
+        if (r < n) *reinterpret_cast<uint4*>(data + r * stride_words) = add4(v[k], prefix);
+    }
+    if (threadIdx.x == SCAN_BLOCK - 1) totals[blockIdx.x] = sh[SCAN_BLOCK - 1];
+}
+
+// exclusive scan of `count` totals in one workgroup (count <= 2^27 / 1024 fits a loop)
+__global__ __launch_bounds__(1024) void k_scan_totals(uint4* __restrict__ totals, size_t count) {
+    __shared__ uint4 sh[1024];
+    uint4 carry = make_uint4(0, 0, 0, 0);
+    for (size_t base = 0; base < count; base += 1024) {
+        size_t i = base + threadIdx.x;
+        uint4 x = i < count ? totals[i] : make_uint4(0, 0, 0, 0);
+        sh[threadIdx.x] = x;
+        __syncthreads();
+        for (int off = 1; off < 1024; off <<= 1) {
+            uint4 t = make_uint4(0, 0, 0, 0);
+            if ((int)threadIdx.x >= off) t = sh[threadIdx.x - off];
+            __syncthreads();
+            if ((int)threadIdx.x >= off) sh[threadIdx.x] = add4(sh[threadIdx.x], t);
+            __syncthreads();
+        }
+        uint4 incl = sh[threadIdx.x];
+        uint4 excl = threadIdx.x ? sh[threadIdx.x - 1] : make_uint4(0, 0, 0, 0);
+        if (i < count) totals[i] = add4(carry, excl);
+        uint4 last = sh[1023];
+        __syncthreads();
+        carry = add4(carry, last);
+        (void)incl;
+    }
+}
+
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ data, size_t stride_words, size_t n,
+                                                          const uint4* __restrict__ offsets) {
+    if (blockIdx.x == 0) return;
+    const uint4 off = offsets[blockIdx.x];
+    const size_t base = (size_t)blockIdx.x * SCAN_CHUNK + (size_t)threadIdx.x * SCAN_PER_THREAD;
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        size_t r = base + k;
+        if (r < n) {
+            uint4* p = reinterpret_cast<uint4*>(data + r * stride_words);
+            *p = add4(*p, off);
+        }
+    }
+}
+
+}  // namespace
+
+int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count) {
+    hipLaunchKernelGGL(k_ef_powers, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, base_m[0], base_m[1], base_m[2], base_m[3],
+                       out_dev, count);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, size_t n) {
+    if (n == 0) return LURKHIP_OK;
+    const size_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
+    void* totals = nullptr;
+    LH_TRY(pool_alloc(ctx, chunks * sizeof(uint4), &totals));
+    hipLaunchKernelGGL(k_scan_local, dim3((unsigned)chunks), dim3(SCAN_BLOCK), 0, ctx->stream, data, stride_words, n, (uint4*)totals);
+    if (chunks > 1) {
+        hipLaunchKernelGGL(k_scan_totals, dim3(1), dim3(1024), 0, ctx->stream, (uint4*)totals, chunks);
+        hipLaunchKernelGGL(k_scan_add, dim3((unsigned)chunks), dim3(SCAN_BLOCK), 0, ctx->stream, data, stride_words, n,
+                           (const uint4*)totals);
+    }
+    pool_release(ctx, totals);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+}  // namespace lurkhip
+
+using namespace lurkhip;
+
+namespace {
+
+thread_local std::string g_air_err;
+
+template <class F>
+int32_t air_guard(lurkhip_air** out, F&& f) {
+    if (!out) return LURKHIP_ERR_INVALID_ARG;
+    *out = nullptr;
+    try {
+        auto* a = new lurkhip_air();
+        try {
+            a->air = f();
+            a->prog = lair::lower_air(a->air);
+        } catch (...) {
+            delete a;
+            throw;
+        }
+        for (const auto* v : {&a->air.sends, &a->air.receives})
+            for (const auto& it : *v) {
+                a->tuple_words += 1 + (uint32_t)it.values.size();
+                a->max_tuple = std::max<uint32_t>(a->max_tuple, (uint32_t)it.values.size());
+            }
+        *out = a;
+        return LURKHIP_OK;
+    } catch (const std::exception& e) {
+        g_air_err = e.what();
+        return lurkhip::set_error(nullptr, LURKHIP_ERR_UNSUPPORTED, "%s", e.what());
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+int32_t lurkhip_air_mem(uint32_t len, lurkhip_air** out) {
+    return air_guard(out, [&] {
+        lair::mem_index_from_len(len);
+        return lair::build_mem_air(len);
+    });
+}
+int32_t lurkhip_air_bytes(lurkhip_air** out) {
+    return air_guard(out, [&] { return lair::build_bytes_air(); });
+}
+int32_t lurkhip_air_entrypoint(uint32_t func_idx, uint32_t num_public_values, lurkhip_air** out) {
+    return air_guard(out, [&] { return lair::build_entrypoint_air(func_idx, num_public_values); });
+}
+int32_t lurkhip_air_from_chip(lair::ChipAir&& air, lurkhip_air** out) {
+    return air_guard(out, [&] { return std::move(air); });
+}
+
+int32_t lurkhip_air_free(lurkhip_air* a) {
+    if (!a) return LURKHIP_OK;
+    for (auto& kv : a->dev) {
+        (void)hipFree(kv.second.first);
+        (void)hipFree(kv.second.second);
+    }
+    delete a;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_air_info(const lurkhip_air* a, uint32_t* info) {
+    if (!a || !info) return LURKHIP_ERR_INVALID_ARG;
+    info[0] = a->air.width;
+    info[1] = a->air.prep_width;
+    info[2] = (uint32_t)a->air.constraints.size();
+    info[3] = (uint32_t)a->air.sends.size();
+    info[4] = (uint32_t)a->air.receives.size();
+    info[5] = a->air.max_constraint_degree();
+    info[6] = a->air.log_quotient_degree();
+    info[7] = a->air.permutation_width();
+    info[8] = a->tuple_words;
+    info[9] = a->air.num_public;
+    info[10] = a->prog.constraints[airp::H_N_REGS];
+    info[11] = a->prog.constraints[airp::H_N_INSTR];
+    info[12] = a->prog.interactions[airp::H_N_REGS];
+    info[13] = a->prog.interactions[airp::H_N_INSTR];
+    return LURKHIP_OK;
+}
+
+const char* lurkhip_air_name(const lurkhip_air* a) { return a ? a->air.name.c_str() : ""; }
+
+// sizes of each interaction's tuple, sends first then receives; returns the number written
+int32_t lurkhip_air_interaction_sizes(const lurkhip_air* a, uint32_t* sizes, uint32_t cap) {
+    if (!a || !sizes) return LURKHIP_ERR_INVALID_ARG;
+    uint32_t k = 0;
+    for (const auto* v : {&a->air.sends, &a->air.receives})
+        for (const auto& it : *v) {
+            if (k < cap) sizes[k] = (uint32_t)it.values.size();
+            k++;
+        }
+    return (int32_t)k;
+}
+
+int32_t lurkhip_air_eval_rows(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t n_rows, const uint32_t* local, const uint32_t* next,
+                              const uint32_t* prep_local, const uint32_t* prep_next, const uint32_t* public_values,
+                              const uint32_t* selectors, uint32_t* constraints_out, uint32_t* interactions_out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, a && local && next && selectors && constraints_out && interactions_out, "null argument");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t w = a->air.width, pw = a->air.prep_width, K = (uint32_t)a->air.constraints.size(), T = a->tuple_words;
+    const uint32_t np = a->air.num_public;
+    LH_ARG(ctx, pw == 0 || (prep_local && prep_next), "chip has preprocessed columns: pass them");
+    LH_ARG(ctx, np == 0 || public_values, "chip reads public values: pass them");
+    const uint32_t *cp = nullptr, *ip = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, &cp, &ip));
+    auto words = [&](size_t x) { return std::max<size_t>(x, 4) * 4; };
+    size_t o_local = 0, o_next = o_local + words((size_t)n_rows * w), o_pl = o_next + words((size_t)n_rows * w),
+           o_pn = o_pl + words((size_t)n_rows * pw), o_pub = o_pn + words((size_t)n_rows * pw), o_sel = o_pub + words(np),
+           o_co = o_sel + words((size_t)n_rows * 3), o_io = o_co + words((size_t)n_rows * K), total = o_io + words((size_t)n_rows * T);
+    void* dev = nullptr;
+    LH_TRY(pool_alloc(ctx, total, &dev));
+    uint8_t* d = (uint8_t*)dev;
+    std::vector<uint32_t> host(total / 4, 0);
+    auto put = [&](size_t off, const uint32_t* src, size_t count) {
+        for (size_t i = 0; i < count; i++) host[off / 4 + i] = bb::to_monty(src[i] % bb::P);
+    };
+    put(o_local, local, (size_t)n_rows * w);
+    put(o_next, next, (size_t)n_rows * w);
+    if (pw) {
+        put(o_pl, prep_local, (size_t)n_rows * pw);
+        put(o_pn, prep_next, (size_t)n_rows * pw);
+    }
+    if (np) put(o_pub, public_values, np);
+    put(o_sel, selectors, (size_t)n_rows * 3);
+    int32_t s = LURKHIP_OK;
+    hipError_t e = hipMemcpyAsync(dev, host.data(), o_co, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && n_rows) {
+        EvalRowsArgs args{cp, ip, (const uint32_t*)(d + o_local), (const uint32_t*)(d + o_next), (const uint32_t*)(d + o_pl),
+                          (const uint32_t*)(d + o_pn), (const uint32_t*)(d + o_pub), (const uint32_t*)(d + o_sel), (uint32_t*)(d + o_co),
+                          (uint32_t*)(d + o_io), n_rows, w, pw, K, T};
+        const uint32_t n_regs = std::max(a->prog.constraints[airp::H_N_REGS], a->prog.interactions[airp::H_N_REGS]);
+        size_t lds = 0;
+        int block = vm_block(n_regs, &lds);
+        hipLaunchKernelGGL(k_air_eval_rows, dim3((n_rows + block - 1) / block), dim3(block), lds, ctx->stream, args);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(constraints_out, d + o_co, (size_t)n_rows * K * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(interactions_out, d + o_io, (size_t)n_rows * T * 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "air_eval_rows failed: %s", hipGetErrorString(e));
+    pool_release(ctx, dev);
+    return s;
+}
+
+int32_t lurkhip_air_check_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev,
+                                    const uint32_t* prep_dev, const uint32_t* public_values, int64_t* first_bad_row,
+                                    int32_t* first_bad_constraint) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, a && main_dev && first_bad_row && first_bad_constraint, "null argument");
+    LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
+    LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t* cp = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, &cp, nullptr));
+    const uint32_t np = a->air.num_public;
+    void* scratch = nullptr;
+    LH_TRY(pool_alloc(ctx, 16 + (size_t)np * 4, &scratch));
+    unsigned long long init = ~0ull;
+    std::vector<uint32_t> pubm(np);
+    for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
+    hipError_t e = hipMemcpyAsync(scratch, &init, 8, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess && np) e = hipMemcpyAsync((uint8_t*)scratch + 16, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess && height) {
+        size_t lds = 0;
+        int block = vm_block(a->prog.constraints[airp::H_N_REGS], &lds);
+        hipLaunchKernelGGL(k_air_check, dim3((height + block - 1) / block), dim3(block), lds, ctx->stream, cp, main_dev,
+                           prep_dev ? prep_dev : main_dev, (const uint32_t*)((uint8_t*)scratch + 16), height, a->air.width,
+                           a->air.prep_width, (unsigned long long*)scratch);
+        e = hipGetLastError();
+    }
+    unsigned long long res = ~0ull;
+    if (e == hipSuccess) e = hipMemcpyAsync(&res, scratch, 8, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    pool_release(ctx, scratch);
+    if (e != hipSuccess) return set_error(ctx, LURKHIP_ERR_HIP, "air_check_trace failed: %s", hipGetErrorString(e));
+    if (res == ~0ull) {
+        *first_bad_row = -1;
+        *first_bad_constraint = -1;
+    } else {
+        *first_bad_row = (int64_t)(res >> 32);
+        *first_bad_constraint = (int32_t)(res & 0xffffffffu);
+    }
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_permutation_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev,
+                                      const uint32_t* prep_dev, const uint32_t* challenges, uint32_t* out_dev,
+                                      uint32_t* cumulative_sum) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, a && main_dev && challenges && out_dev, "null argument");
+    LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
+    LH_ARG(ctx, height > 0, "empty trace");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t* ip = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, nullptr, &ip));
+    const uint32_t perm_w = a->air.permutation_width(), batch = 1u << a->air.log_quotient_degree();
+    uint32_t alpha_m[4], beta_m[4];
+    for (int i = 0; i < 4; i++) {
+        alpha_m[i] = bb::to_monty(challenges[i] % bb::P);
+        beta_m[i] = bb::to_monty(challenges[4 + i] % bb::P);
+    }
+    void* pows = nullptr;
+    const uint32_t n_pows = a->max_tuple + 2;
+    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 16, &pows));
+    span_begin(ctx, "perm_rows");
+    int32_t s = ef_powers(ctx, beta_m, (uint32_t*)pows, n_pows);
+    if (s == LURKHIP_OK) {
+        size_t lds = 0;
+        int block = vm_block(a->prog.interactions[airp::H_N_REGS], &lds);
+        bb::ef alpha{{alpha_m[0], alpha_m[1], alpha_m[2], alpha_m[3]}};
+        hipLaunchKernelGGL(k_perm_rows, dim3((height + block - 1) / block), dim3(block), lds, ctx->stream, ip, main_dev,
+                           prep_dev ? prep_dev : main_dev, (const uint32_t*)nullptr, (const uint32_t*)pows, alpha, height,
+                           a->air.width, a->air.prep_width, perm_w, batch, out_dev);
+        if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
+    }
+    span_end(ctx, "perm_rows");
+    span_begin(ctx, "perm_scan");
+    if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)perm_w * 4, height);
+    span_end(ctx, "perm_scan");
+    pool_release(ctx, pows);
+    if (s == LURKHIP_OK && cumulative_sum) {
+        uint32_t r[4];
+        LH_HIP(ctx, hipMemcpyAsync(r, out_dev + ((size_t)height * perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < 4; i++) cumulative_sum[i] = bb::from_monty(r[i]);
+    }
+    return s;
+}
+
+}  // extern "C"

@@ -1,0 +1,391 @@
+"""ORACLE (test infrastructure, not product code): numeric restatement of the Lair chips' AIR.
+
+Independent of lurk_amd/csrc/lair/air.cpp: it walks the oracle's own bytecode (oracle/lair.py) with a
+*numeric* builder, the way the reference's DebugConstraintBuilder does (/root/reference/src/air/debug.rs:209-406):
+every `assert_*` appends the value of the asserted polynomial on the given (local, next) row pair, every
+send / receive appends (multiplicity, tuple).  Used to check the product's symbolic walk + register program
+constraint by constraint and tuple by tuple on arbitrary rows, and -- like the reference's own tests
+(/root/reference/src/air/debug.rs:119-158) -- that valid traces satisfy every constraint and that the
+send / receive multisets balance.
+
+Follows:
+  Func chips      /root/reference/src/lair/air.rs:158-552
+  MemChip         /root/reference/src/lair/memory.rs:71-109
+  BytesChip       /root/reference/src/gadgets/bytes/trace.rs:117-143
+  Entrypoint      /root/reference/src/lair/lair_chip.rs:166-191
+  provide/require /root/reference/src/air/builder.rs:42-104; relations /root/reference/src/lair/relations.rs:6-59,
+                  /root/reference/src/gadgets/bytes/relation.rs:122-134
+  depth gadget    /root/reference/src/gadgets/unsigned/less_than.rs:44-99, /root/reference/src/lair/air.rs:103-133
+
+Only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg may import anything under oracle/.
+"""
+from __future__ import annotations
+
+from collections import Counter
+
+from .lair import DEPTH_LESS_THAN_SIZE, DEPTH_W, P, Toplevel, inv
+
+CALL_TAG, MEMORY_TAG, BYTE_TAG = 0, 1, 3
+INTERACTION_KIND_MEMORY = 1  # sphinx InteractionKind::Memory as usize [UPSTREAM-RECALL]
+
+
+class Builder:
+    """Numeric AirBuilder + LookupBuilder: records constraint values and interactions of one row pair."""
+
+    def __init__(self, local, nxt, prep_local=(), prep_next=(), public=(), sels=(0, 0, 0)):
+        self.local, self.next = list(local), list(nxt)
+        self.prep_local, self.prep_next = list(prep_local), list(prep_next)
+        self.public = list(public)
+        self.is_first_row, self.is_last_row, self.is_transition = sels
+        self.constraints: list[int] = []
+        self.sends: list[tuple[int, list[int]]] = []  # (multiplicity, tuple)
+        self.receives: list[tuple[int, list[int]]] = []
+
+    # p3 AirBuilder
+    def assert_zero(self, x, cond=None):
+        self.constraints.append((x if cond is None else cond * x) % P)
+
+    def assert_eq(self, a, b, cond=None):
+        self.assert_zero(a - b, cond)
+
+    def assert_one(self, x, cond=None):
+        self.assert_zero(x - 1, cond)
+
+    def assert_bool(self, x, cond=None):
+        self.assert_zero(x * (x - 1), cond)
+
+    # LookupBuilder (air/builder.rs)
+    def receive(self, values, is_real):
+        self.receives.append((is_real % P, [v % P for v in values]))
+
+    def send(self, values, is_real):
+        self.sends.append((is_real % P, [v % P for v in values]))
+
+    def provide(self, relation, last_nonce, last_count, is_real):
+        self.receive([last_nonce, last_count] + list(relation), is_real)
+        self.send([0, 0] + list(relation), is_real)
+
+    def require(self, relation, nonce, prev_nonce, prev_count, count_inv, is_real):
+        count = prev_count + 1
+        self.assert_one(count * count_inv, is_real)
+        self.receive([prev_nonce, prev_count] + list(relation), is_real)
+        self.send([nonce, count] + list(relation), is_real)
+
+    def dump(self):
+        """The flattening lurkhip_air_eval_rows uses: constraints; then per interaction (sends first)
+        multiplicity followed by the tuple."""
+        flat = []
+        for m, vals in self.sends + self.receives:
+            flat.append(m)
+            flat += vals
+        return list(self.constraints), flat
+
+
+class ByteAirRecord:  # gadgets/bytes/builder.rs
+    def __init__(self):
+        self.records = []
+
+    def range_check_u8_pair(self, i1, i2, is_real):
+        self.records.append(([BYTE_TAG, 1, i1, i2], is_real))
+
+    def range_check_u8_iter(self, xs, is_real):
+        xs = list(xs)
+        for i in range(0, len(xs), 2):
+            self.range_check_u8_pair(xs[i], xs[i + 1] if i + 1 < len(xs) else 0, is_real)
+
+    def less_than(self, i1, i2, r, is_real):
+        self.records.append(([BYTE_TAG, 3, i1, i2, r], is_real))
+
+    def require_all(self, b: Builder, nonce, requires):
+        assert len(requires) == len(self.records)
+        for (rel, is_real), (pn, pc, ci) in zip(self.records, requires):
+            b.require(rel, nonce, pn, pc, ci, is_real)
+
+
+def _return_idents(blk):
+    c = blk["ctrl"]
+    if c[0] == "return":
+        return [c[1]]
+    _, _, cases, uniq, d = c
+    out = []
+    for x in list(uniq) + ([d] if d is not None else []):
+        out += _return_idents(x)
+    return out
+
+
+class FuncAir:
+    def __init__(self, top: Toplevel, name: str):
+        self.top = top
+        self.f = top.funcs[top.index[name]]
+        self.fe = top.funcs_e[top.index[name]]
+        self.layout = top.layout(self.f)
+        self.width = sum(self.layout.values())
+
+    def eval(self, b: Builder):
+        f, ls = self.f, self.layout
+        loc = b.local
+        o_in, o_out = 1, 1 + ls["input"]
+        o_aux = o_out + ls["output"]
+        o_sel = o_aux + ls["aux"]
+        st = {"aux": 0, "out": 0}
+
+        def next_aux():
+            assert st["aux"] < ls["aux"], "walk ran past the aux columns"
+            v = loc[o_aux + st["aux"]]
+            st["aux"] += 1
+            return v
+
+        def next_require():
+            return (next_aux(), next_aux(), next_aux())
+
+        def return_sel(blk):
+            return sum(loc[o_sel + i] for i in _return_idents(blk)) % P
+
+        nonce = loc[0]
+        b.assert_eq(b.next[0], nonce + 1, b.is_transition)
+        vmap = []  # (is_const, value)
+        call_inp = []
+        for i in range(f["input_size"]):
+            vmap.append((False, loc[o_in + i]))
+            call_inp.append(loc[o_in + i])
+        toplevel_sel = return_sel(f["body"])
+        b.assert_bool(toplevel_sel)
+        last_nonce, last_count = next_aux(), next_aux()
+        out = [loc[o_out + i] for i in range(f["output_size"])]
+        depth = []
+        if f["partial"]:
+            depth = [next_aux() for _ in range(DEPTH_W)]
+            reqs = [next_require() for _ in range(DEPTH_W // 2 + DEPTH_W % 2)]
+            rec = ByteAirRecord()
+            rec.range_check_u8_iter(depth, toplevel_sel)
+            rec.require_all(b, nonce, reqs)
+            out = out + depth
+        b.provide([CALL_TAG, f["index"]] + call_inp + out, last_nonce, last_count, toplevel_sel)
+
+        def assert_less_than(wit, lhs, rhs, rec, is_real):
+            is_equal = 0
+            for i in range(DEPTH_W):
+                if i > 0:
+                    b.assert_eq(lhs[i], rhs[i], is_real * is_equal)
+                b.assert_bool(wit[i], is_real)
+                is_equal += wit[i]
+            b.assert_one(is_equal, is_real)
+            b.assert_eq(sum(l * w for l, w in zip(lhs, wit[:DEPTH_W])), wit[DEPTH_W], is_real)
+            b.assert_eq(sum(r * w for r, w in zip(rhs, wit[:DEPTH_W])), wit[DEPTH_W + 1], is_real)
+            rec.less_than(wit[DEPTH_W], wit[DEPTH_W + 1], 1, is_real)
+
+        def eval_depth(sel, out_list):
+            dep = [next_aux() for _ in range(DEPTH_W)]
+            wit = [next_aux() for _ in range(DEPTH_LESS_THAN_SIZE)]
+            rec = ByteAirRecord()
+            assert_less_than(wit, dep, depth, rec, sel)
+            rec.require_all(b, nonce, [next_require()])
+            out_list += dep
+
+        def eval_op(op, sel):
+            k = op[0]
+            if k == "assert_ne":
+                coeffs = [next_aux() for _ in op[1]]
+                acc = sum(c * (vmap[x][1] - vmap[y][1]) for c, x, y in zip(coeffs, op[1], op[2]))
+                b.assert_one(acc, sel)
+            elif k == "assert_eq":
+                for x, y in zip(op[1], op[2]):
+                    b.assert_eq(vmap[x][1], vmap[y][1], sel)
+            elif k == "contains":
+                y = vmap[op[2]][1]
+                acc = vmap[op[1][0]][1] - y
+                for x in op[1][1:]:
+                    aux = next_aux()
+                    b.assert_eq(acc * (vmap[x][1] - y), aux, sel)
+                    acc = aux
+                b.assert_zero(acc, sel)
+            elif k == "const":
+                vmap.append((True, op[1] % P))
+            elif k in ("add", "sub"):
+                (ca, a), (cb, c) = vmap[op[1]], vmap[op[2]]
+                vmap.append((ca and cb, (a + c if k == "add" else a - c) % P))
+            elif k == "mul":
+                (ca, a), (cb, c) = vmap[op[1]], vmap[op[2]]
+                if ca and cb:
+                    vmap.append((True, a * c % P))
+                else:  # air.rs:345-358: aux whenever not both operands are constants
+                    aux = next_aux()
+                    b.assert_eq(a * c, aux, sel)
+                    vmap.append((False, aux))
+            elif k == "inv":
+                ca, a = vmap[op[1]]
+                if ca:
+                    vmap.append((True, inv(a)))
+                else:
+                    aux = next_aux()
+                    b.assert_one(a * aux, sel)
+                    vmap.append((False, aux))
+            elif k == "not":
+                ca, a = vmap[op[1]]
+                if ca:
+                    vmap.append((True, 1 if a % P == 0 else 0))
+                else:
+                    d, x = next_aux(), next_aux()
+                    b.assert_zero(a * x, sel)
+                    b.assert_one(a * d + x, sel)
+                    vmap.append((False, x))
+            elif k == "call":
+                g = self.top.funcs[op[1]]
+                outs = []
+                for _ in range(g["output_size"]):
+                    o = next_aux()
+                    vmap.append((False, o))
+                    outs.append(o)
+                inp = [vmap[i][1] for i in op[2]]
+                rec = next_require()
+                if g["partial"]:
+                    eval_depth(sel, outs)
+                b.require([CALL_TAG, op[1]] + inp + outs, nonce, *rec, sel)
+            elif k == "preimg":
+                g = self.top.funcs[op[1]]
+                inp = []
+                for _ in range(g["input_size"]):
+                    v = next_aux()
+                    vmap.append((False, v))
+                    inp.append(v)
+                outs = [vmap[i][1] for i in op[2]]
+                rec = next_require()
+                if g["partial"]:
+                    eval_depth(sel, outs)
+                b.require([CALL_TAG, op[1]] + inp + outs, nonce, *rec, sel)
+            elif k == "store":
+                ptr = next_aux()
+                vmap.append((False, ptr))
+                vals = [vmap[i][1] for i in op[1]]
+                rec = next_require()
+                b.require([MEMORY_TAG, ptr] + vals, nonce, *rec, sel)
+            elif k == "load":
+                ptr = vmap[op[2]][1]
+                vals = []
+                for _ in range(op[1]):
+                    o = next_aux()
+                    vmap.append((False, o))
+                    vals.append(o)
+                rec = next_require()
+                b.require([MEMORY_TAG, ptr] + vals, nonce, *rec, sel)
+            elif k == "range_u8":
+                reqs = [next_require() for _ in range((len(op[1]) + 1) // 2)]
+                rec = ByteAirRecord()
+                rec.range_check_u8_iter([vmap[i][1] for i in op[1]], sel)
+                rec.require_all(b, nonce, reqs)
+            elif k == "extern":
+                raise NotImplementedError("extern chip AIR")
+            elif k == "emit":
+                pass
+            else:
+                raise AssertionError(k)
+
+        def eval_block(blk, sel):
+            for op in blk["ops"]:
+                eval_op(op, sel)
+            c = blk["ctrl"]
+            if c[0] == "return":
+                s = loc[o_sel + c[1]]
+                for v in c[2]:
+                    out_var = loc[o_out + st["out"]]
+                    st["out"] += 1
+                    b.assert_eq(vmap[v][1], out_var, s)
+                return
+            kind, _, cases, uniq, d = c
+            n_map, saved = len(vmap), dict(st)
+            if kind == "choose":
+                blocks = list(uniq)
+            else:  # Map iteration order: sorted by key (lair/map.rs:19-26)
+                blocks = [blk2 for _, blk2 in sorted(cases.items())]
+            if d is not None:
+                blocks.append(d)
+            for blk2 in blocks:
+                eval_block(blk2, return_sel(blk2))
+                del vmap[n_map:]
+                st.update(saved)
+
+        eval_block(f["body"], toplevel_sel)
+
+
+class MemAir:  # lair/memory.rs:71-109
+    def __init__(self, mem_len):
+        self.len = mem_len
+        self.width = 4 + mem_len
+
+    def eval(self, b: Builder):
+        loc, nxt = b.local, b.next
+        is_real, ptr_local, last_nonce, last_count = loc[0], loc[1], loc[2], loc[3]
+        is_real_next, ptr_next = nxt[0], nxt[1]
+        b.assert_bool(is_real)
+        is_real_transition = is_real_next * b.is_transition
+        b.assert_one(is_real, is_real_transition)
+        b.assert_one(ptr_local, b.is_first_row * is_real)
+        b.assert_eq(ptr_local + 1, ptr_next, is_real_transition)
+        b.provide([MEMORY_TAG, ptr_local] + loc[4:4 + self.len], last_nonce, last_count, is_real)
+
+
+class BytesAir:  # gadgets/bytes/trace.rs:117-143
+    width, prep_width = 13, 6
+
+    def eval(self, b: Builder):
+        main, prep = b.local, b.prep_local
+        is_real = main[0]
+        b.assert_bool(is_real)
+        i1, i2 = prep[0], prep[1]
+        relations = [
+            [BYTE_TAG, 1, i1, i2], [BYTE_TAG, 2, i1 + i2 * 256],
+            [BYTE_TAG, 3, i1, i2, prep[2]], [BYTE_TAG, 4, i1, i2, prep[3]],
+            [BYTE_TAG, 5, i1, i2, prep[4]], [BYTE_TAG, 6, i1, i2, prep[5]],
+        ]
+        for k, rel in enumerate(relations):
+            b.provide(rel, main[1 + 2 * k], main[2 + 2 * k], is_real)
+
+
+class EntrypointAir:  # lair/lair_chip.rs:166-191
+    def __init__(self, func_idx, num_public_values):
+        self.func_idx, self.width = func_idx, num_public_values
+
+    def eval(self, b: Builder):
+        pv = b.local[: self.width]
+        for a, c in zip(pv, b.public):
+            b.assert_eq(a, c)
+        b.require([CALL_TAG, self.func_idx] + pv, 0, 0, 0, 1, 1)
+
+
+def eval_rows(air, local, nxt, prep_local=None, prep_next=None, public=(), sels=None):
+    """Row-pair evaluation in the layout of lurkhip_air_eval_rows: (constraints[n][K], interactions[n][T])."""
+    cons, inter = [], []
+    for i in range(len(local)):
+        b = Builder(local[i], nxt[i], prep_local[i] if prep_local is not None else (), prep_next[i] if prep_next is not None else (),
+                    public, sels[i] if sels is not None else (0, 0, 0))
+        air.eval(b)
+        c, t = b.dump()
+        cons.append(c)
+        inter.append(t)
+    return cons, inter
+
+
+def debug_check(chips_and_traces, public=()):
+    """The reference's debug_chip_constraints_and_queries (air/debug.rs:119-206): every constraint vanishes on
+    every row (indicator selectors, next row wraps) and sends == receives as multisets.
+    chips_and_traces: iterable of (air, main rows, preprocessed rows or None)."""
+    sends, receives = Counter(), Counter()
+    for air, main, prep in chips_and_traces:
+        h = len(main)
+        for r in range(h):
+            n = (r + 1) % h
+            b = Builder(main[r], main[n], prep[r] if prep is not None else (), prep[n] if prep is not None else (), public,
+                        (1 if r == 0 else 0, 1 if r == h - 1 else 0, 0 if r == h - 1 else 1))
+            air.eval(b)
+            bad = [k for k, v in enumerate(b.constraints) if v]
+            assert not bad, f"{type(air).__name__}: row {r}: constraints {bad} do not vanish"
+            for m, vals in b.sends:
+                assert m in (0, 1)
+                if m:
+                    sends[tuple(vals)] += 1
+            for m, vals in b.receives:
+                assert m in (0, 1)
+                if m:
+                    receives[tuple(vals)] += 1
+    assert sends == receives, "send / receive multisets differ"
+    return sum(sends.values())

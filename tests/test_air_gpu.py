@@ -1,0 +1,108 @@
+"""GPU parity of the AIR programs (symbolic walk in C++ -> register program -> device VM) against the oracle's
+numeric AIR, constraint by constraint and tuple by tuple, on real trace rows and on random rows with random
+selector values (the constraint polynomials must agree everywhere, not just where they vanish); plus the
+device-side debug check of whole traces."""
+import numpy as np
+import pytest
+
+from lair_helpers import PARTIAL_SRC, load_cases
+from lurk_amd import air, field, lair, synth
+from lurk_amd.programs import synth_eval as se
+from oracle import air as oa
+from oracle import lair as ol
+
+pytestmark = pytest.mark.gpu
+P = field.P
+DEMO = load_cases()[0]["source"]
+
+
+def rows_for(width, real_rows, seed):
+    """real consecutive pairs + random pairs, random selectors"""
+    rnd = synth.field_elements((24, width), seed=seed)
+    local = [list(r) for r in real_rows[:-1]] + [list(map(int, r)) for r in rnd[:12]]
+    nxt = [list(r) for r in real_rows[1:]] + [list(map(int, r)) for r in rnd[12:]]
+    sels = synth.field_elements((len(local), 3), seed=seed + 1)
+    return np.array(local, dtype=np.uint32), np.array(nxt, dtype=np.uint32), sels
+
+
+def compare(ctx, chip_air, oracle_air, local, nxt, sels, prep_local=None, prep_next=None, public=()):
+    cons, inter = chip_air.eval_rows(ctx, local, nxt, prep_local, prep_next, public, sels)
+    ocons, ointer = oa.eval_rows(oracle_air, local.tolist(), nxt.tolist(), prep_local.tolist() if prep_local is not None else None,
+                                 prep_next.tolist() if prep_next is not None else None, list(public), [tuple(map(int, s)) for s in sels])
+    assert cons.shape[1] == len(ocons[0]) and inter.shape[1] == len(ointer[0])
+    assert cons.tolist() == ocons
+    assert inter.tolist() == ointer
+
+
+@pytest.mark.parametrize("src,calls", [(DEMO, [("fib", [9]), ("factorial", [6]), ("even", [7])]), (PARTIAL_SRC, [("top", [9])]),
+                                       (se.SOURCE, [("synth_eval", [1, 40, 0])])], ids=["demo", "partial", "synth_eval"])
+def test_func_air_matches_oracle(ctx, src, calls):
+    top, otop = lair.Toplevel(src), ol.Toplevel(src)
+    oq = ol.QueryRecord(otop)
+    for name, args in calls:
+        ol.execute(otop, name, args, oq)
+    for i, f in enumerate(otop.funcs):
+        rows, width = ol.generate_trace(otop, f["name"], oq)
+        if len(rows) < 2:
+            rows = [[0] * width, [0] * width]
+        a = air.ChipAir.for_func(top, i)
+        assert a.width == width
+        local, nxt, sels = rows_for(width, rows[:40], seed=100 + i)
+        compare(ctx, a, oa.FuncAir(otop, f["name"]), local, nxt, sels)
+
+
+def test_mem_bytes_entrypoint_air_match_oracle(ctx):
+    for ml in lair.MEM_TABLE_SIZES:
+        a = air.ChipAir.for_mem(ml)
+        local, nxt, sels = rows_for(4 + ml, [[1, 1, 0, 2] + [5] * ml, [1, 2, 3, 1] + [7] * ml, [0] * (4 + ml)], seed=7 + ml)
+        compare(ctx, a, oa.MemAir(ml), local, nxt, sels)
+    a = air.ChipAir.for_bytes()
+    local, nxt, sels = rows_for(13, [[1] + [3, 4] * 6, [0] * 13], seed=33)
+    prep = synth.field_elements((len(local), 6), seed=34)
+    compare(ctx, a, oa.BytesAir(), local, nxt, sels, prep, prep[::-1].copy())
+    a = air.ChipAir.for_entrypoint(2, 7)
+    local, nxt, sels = rows_for(7, [[1, 2, 3, 4, 5, 6, 7], [1, 2, 3, 4, 5, 6, 7]], seed=35)
+    compare(ctx, a, oa.EntrypointAir(2, 7), local, nxt, sels, public=[1, 2, 3, 9, 5, 6, 7])
+    assert a.num_public_values == 7
+
+
+def _dev_trace(ctx, chip, shard):
+    import torch
+
+    _, h, w = chip.trace_shape(shard)
+    t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+    chip.generate_trace_dev(shard, t, repr=1)
+    ctx.sync()
+    return t, h
+
+
+def test_check_trace_on_device(ctx):
+    import torch
+
+    top = lair.Toplevel(PARTIAL_SRC)
+    q = lair.QueryRecord(top)
+    top.execute_by_name("top", [11], q)
+    shard = lair.Shard.new(q)
+    for i in range(top.num_funcs()):
+        chip = lair.FuncChip(ctx, i, top)
+        t, h = _dev_trace(ctx, chip, shard)
+        a = air.ChipAir.for_func(top, i)
+        assert a.check_trace(ctx, h, t) == (-1, -1), a.name
+        if h >= 4:
+            bad = t.clone()
+            bad[2, 1] += 1  # an input column of row 2
+            row, k = a.check_trace(ctx, h, bad)
+            assert row in (1, 2) and k >= 0, (a.name, row, k)
+    # a big synthetic trace: 2^16 rows of the bench function
+    top = lair.Toplevel(se.SOURCE)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(se.FUNC, se.args_for_rows(1 << 16), q)
+    chip = lair.FuncChip(ctx, top.func_index(se.FUNC), top)
+    t, h = _dev_trace(ctx, chip, lair.Shard.new(q))
+    assert h == 1 << 16
+    a = air.ChipAir.for_func(top, top.func_index(se.FUNC))
+    assert a.check_trace(ctx, h, t) == (-1, -1)
+    t[40000, 30] += 1
+    row, _ = a.check_trace(ctx, h, t)
+    assert row == 40000
+    del torch

@@ -1,0 +1,63 @@
+"""The oracle's AIR restatement against the property the reference's own tests check
+(/root/reference/src/air/debug.rs:119-206, used by /root/reference/src/core/tests/mod.rs:28-74 and the
+lair tests): on traces of a real execution every constraint of every chip vanishes on every row and the
+send / receive multisets of the whole machine balance."""
+import pytest
+
+from lair_helpers import PARTIAL_SRC, load_cases
+from oracle import air as oa
+from oracle import lair as ol
+
+
+def machine(top, q, entry, with_bytes):
+    f = top.funcs[top.index[entry]]
+    pv = q.public_values
+    chips = [(oa.EntrypointAir(f["index"], len(pv)), [list(pv)], None)]
+    for g in top.funcs:
+        rows, _ = ol.generate_trace(top, g["name"], q)
+        if rows:
+            chips.append((oa.FuncAir(top, g["name"]), rows, None))
+    for ml in ol.MEM_TABLE_SIZES:
+        chips.append((oa.MemAir(ml), ol.mem_trace(q, ml), None))
+    if with_bytes:
+        prep = [[i & 0xFF, i >> 8, int((i & 0xFF) < (i >> 8)), (i & 0xFF) & (i >> 8), (i & 0xFF) ^ (i >> 8), (i & 0xFF) | (i >> 8)] for i in range(1 << 16)]
+        chips.append((oa.BytesAir(), ol.bytes_trace(q), prep))
+    return chips, pv
+
+
+@pytest.mark.parametrize("entry,args", [("factorial", [5]), ("fib", [7]), ("even", [6])])
+def test_demo_machine_constraints_and_lookups(entry, args):
+    top = ol.Toplevel(load_cases()[0]["source"])
+    q = ol.QueryRecord(top)
+    ol.execute(top, entry, args, q)
+    chips, pv = machine(top, q, entry, with_bytes=False)
+    assert oa.debug_check(chips, public=pv) > 0
+
+
+def test_memory_case_constraints_and_lookups():
+    case = next(c for c in load_cases() if c["mem"])
+    top = ol.Toplevel(case["source"])
+    q = ol.QueryRecord(top)
+    name, args = case["calls"][0]
+    ol.execute(top, name, args, q)
+    chips, pv = machine(top, q, name, with_bytes=False)
+    assert oa.debug_check(chips, public=pv) > 0
+
+
+def test_partial_machine_with_byte_lookups():
+    top = ol.Toplevel(PARTIAL_SRC)
+    q = ol.QueryRecord(top)
+    ol.execute(top, "top", [7], q)
+    chips, pv = machine(top, q, "top", with_bytes=True)
+    assert oa.debug_check(chips, public=pv) > 0
+
+
+def test_broken_trace_is_rejected():
+    top = ol.Toplevel(load_cases()[0]["source"])
+    q = ol.QueryRecord(top)
+    ol.execute(top, "factorial", [5], q)
+    chips, pv = machine(top, q, "factorial", with_bytes=False)
+    air, rows, prep = chips[1]
+    rows[2][3] = (rows[2][3] + 1) % ol.P
+    with pytest.raises(AssertionError):
+        oa.debug_check(chips, public=pv)
