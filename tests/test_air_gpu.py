@@ -106,3 +106,77 @@ def test_check_trace_on_device(ctx):
     row, _ = a.check_trace(ctx, h, t)
     assert row == 40000
     del torch
+
+
+def _machine_chips(ctx, src, entry, args):
+    """Product traces (device, Montgomery) + oracle traces of every chip of a small machine."""
+    import torch
+
+    top, otop = lair.Toplevel(src), ol.Toplevel(src)
+    q, oq = lair.QueryRecord(top), ol.QueryRecord(otop)
+    top.execute_by_name(entry, args, q)
+    ol.execute(otop, entry, args, oq)
+    shard = lair.Shard.new(q)
+    chips = []
+    pv = q.expect_public_values()
+    ep = np.array([pv], dtype=np.uint32)
+    chips.append((air.ChipAir.for_entrypoint(top.func_index(entry), len(pv)), oa.EntrypointAir(top.func_index(entry), len(pv)),
+                  torch.from_numpy(field.to_monty(ep).view(np.int32)).cuda(), ep.tolist()))
+    for i, f in enumerate(otop.funcs):
+        rows, _ = ol.generate_trace(otop, f["name"], oq)
+        if not rows:
+            continue
+        t, h = _dev_trace(ctx, lair.FuncChip(ctx, i, top), shard)
+        chips.append((air.ChipAir.for_func(top, i), oa.FuncAir(otop, f["name"]), t, rows))
+    for ml in lair.MEM_TABLE_SIZES:
+        rows = ol.mem_trace(oq, ml)
+        t = torch.from_numpy(field.to_monty(np.array(rows, dtype=np.uint32)).view(np.int32)).cuda()
+        chips.append((air.ChipAir.for_mem(ml), oa.MemAir(ml), t, rows))
+    return chips, pv
+
+
+def test_permutation_trace_matches_oracle_and_sums_to_zero(ctx):
+    import torch
+
+    from oracle import stark as os_
+
+    alpha, beta = (11, 22, 33, 44), (5, 6, 7, 2013265920)
+    for src, entry, args in [(DEMO, "fib", [10]), (se.SOURCE, "synth_eval", [1, 30, 0])]:
+        chips, pv = _machine_chips(ctx, src, entry, args)
+        total = os_.ZERO
+        for a, oair_, t, rows in chips:
+            h = len(rows)
+            out = torch.zeros((h, 4 * a.permutation_width), dtype=torch.int32, device="cuda")
+            cs = a.permutation_trace(ctx, h, t, None, alpha + beta, out)
+            got = field.from_monty(out.cpu().numpy().view(np.uint32)).reshape(h, a.permutation_width, 4)
+            want = os_.permutation_trace(oair_, rows, None, alpha, beta, 1 << a.log_quotient_degree, public=pv)
+            assert got.tolist() == [[list(c) for c in r] for r in want], a.name
+            assert tuple(int(x) for x in cs) == want[-1][-1]
+            total = os_.ef_add(total, tuple(int(x) for x in cs))
+        # the machine's lookups balance: the chips' cumulative sums cancel (what the verifier checks)
+        assert total == os_.ZERO
+
+
+def test_large_permutation_trace_cumulative_sums_cancel(ctx):
+    """2^16 rows of the bench function + its callee + the memory tables: scan over many chunks."""
+    import torch
+
+    top = lair.Toplevel(se.SOURCE)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(se.FUNC, se.args_for_rows(1 << 16), q)
+    shard = lair.Shard.new(q)
+    ch = [3, 1, 4, 1, 5, 9, 2, 6]
+    total = np.zeros(4, dtype=np.uint64)
+    pv = q.expect_public_values()
+    ep = torch.from_numpy(field.to_monty(np.array([pv], dtype=np.uint32)).view(np.int32)).cuda()
+    items = [(air.ChipAir.for_entrypoint(top.func_index(se.FUNC), len(pv)), ep, 1)]
+    for i in range(top.num_funcs()):
+        t, h = _dev_trace(ctx, lair.FuncChip(ctx, i, top), shard)
+        items.append((air.ChipAir.for_func(top, i), t, h))
+    for ml in lair.MEM_TABLE_SIZES:
+        m = lair.MemChip(ctx, ml).generate_trace(shard, repr=1)
+        items.append((air.ChipAir.for_mem(ml), torch.from_numpy(m.view(np.int32)).cuda(), m.shape[0]))
+    for a, t, h in items:
+        out = torch.zeros((h, 4 * a.permutation_width), dtype=torch.int32, device="cuda")
+        total += a.permutation_trace(ctx, h, t, None, ch, out).astype(np.uint64)
+    assert not (total % P).any()
