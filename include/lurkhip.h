@@ -155,6 +155,13 @@ int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* 
 int32_t lurkhip_commit_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev,
                            const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                            int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root);
+/* As lurkhip_commit_dev, for matrices given as evaluations over cosets: the LDE of matrix i is taken with p3's
+ * `shift` = shifts[i] (canonical) instead of the generator, i.e. shifts[i] = 31 / (coset shift of matrix i), so that
+ * every committed LDE holds the values of the underlying polynomial on 31 * <w> again.  This is how the quotient
+ * chunks (evaluations over 31 * w^c * H) are committed (p3 TwoAdicFriPcs::commit: shift = generator / domain.shift). */
+int32_t lurkhip_commit_cosets_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev,
+                                  const uint32_t* log_heights, const uint32_t* widths, const uint32_t* shifts,
+                                  int32_t log_blowup, int32_t repr, lurkhip_commitment** out, uint32_t* root);
 int32_t lurkhip_commitment_free(lurkhip_ctx* ctx, lurkhip_commitment* c);
 int32_t lurkhip_commitment_root(lurkhip_ctx* ctx, lurkhip_commitment* c, uint32_t* root, int32_t repr);
 /* Device pointer (Montgomery form) and shape of the LDE of matrix `index`. */
@@ -296,6 +303,19 @@ int32_t lurkhip_air_check_trace_dev(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t
 int32_t lurkhip_permutation_trace_dev(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t height, const uint32_t* main_dev,
                                       const uint32_t* prep_dev, const uint32_t* challenges, uint32_t* out_dev,
                                       uint32_t* cumulative_sum);
+
+/* Quotient values of one chip on the quotient domain 31 * <w_Q>, Q = 2^(log_n + info[6])
+ * (sphinx quotient_values [UPSTREAM-RECALL]): every constraint of the chip, the permutation constraints of its
+ * interactions and the three running-sum constraints folded with powers of `alpha`, divided by Z_H.
+ * main / prep / perm _lde_dev: the committed LDE matrices (lurkhip_commitment_matrix_dev: bit-reversed rows, Montgomery);
+ * their height must be at least Q.  perm_challenges[8] as in lurkhip_permutation_trace_dev; alpha[4],
+ * cumulative_sum[4], public_values: host, canonical.  out_dev: 2^info[6] chunk matrices back to back, each
+ * 2^log_n x 4 Montgomery words: chunk c row r = quotient at 31 * w_Q^(r * 2^info[6] + c), i.e. the evaluations of
+ * chunk c over the coset 31 * w_Q^c * H that lurkhip_commit_cosets_dev takes with shift w_Q^-c. */
+int32_t lurkhip_quotient_dev(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t log_n, const uint32_t* main_lde_dev,
+                             const uint32_t* prep_lde_dev, const uint32_t* perm_lde_dev, const uint32_t* perm_challenges,
+                             const uint32_t* alpha, const uint32_t* cumulative_sum, const uint32_t* public_values,
+                             uint32_t* out_dev);
 
 #ifdef __cplusplus
 }

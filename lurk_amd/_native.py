@@ -84,6 +84,7 @@ SIGNATURES = {
     "lurkhip_coset_lde_dev": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
     "lurkhip_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commit_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_commit_cosets_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _u32p, _i32, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commitment_free": (_i32, [_p, _p]),
     "lurkhip_commitment_root": (_i32, [_p, _p, _u32p, _i32]),
     "lurkhip_commitment_matrix_dev": (_i32, [_p, _p, _i32, C.POINTER(_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
@@ -127,6 +128,7 @@ SIGNATURES = {
     "lurkhip_air_eval_rows": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
     "lurkhip_air_check_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "lurkhip_permutation_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p]),
+    "lurkhip_quotient_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
 }
 
 

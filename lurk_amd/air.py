@@ -97,3 +97,12 @@ class ChipAir:
         ctx.check(N.lib.lurkhip_permutation_trace_dev(ctx.handle, self.handle, height, _addr(main_dev), _addr(prep_dev) if prep_dev is not None else None,
                                                       _addr(ch), _addr(out_dev), _addr(cs) if want_sum else None))
         return cs
+
+    def quotient(self, ctx: Context, log_n: int, main_lde_dev, prep_lde_dev, perm_lde_dev, perm_challenges, alpha, cumulative_sum, out_dev, public=None):
+        """Fills out_dev with 2^log_quotient_degree chunk matrices (2^log_n x 4 Montgomery words each)."""
+        ch = as_u32(perm_challenges).reshape(8)
+        al = as_u32(alpha).reshape(4)
+        cs = as_u32(cumulative_sum).reshape(4)
+        pub = as_u32(public) if public is not None and len(public) else None
+        ctx.check(N.lib.lurkhip_quotient_dev(ctx.handle, self.handle, log_n, _addr(main_lde_dev), _addr(prep_lde_dev) if prep_lde_dev is not None else None,
+                                             _addr(perm_lde_dev), _addr(ch), _addr(al), _addr(cs), _addr(pub) if pub is not None else None, _addr(out_dev)))

@@ -96,3 +96,16 @@ def commit(ctx: Context, mats, log_blowup: int = 1, repr: int = N.REPR_CANONICAL
 def commit_dev(ctx: Context, mats, log_heights, widths, log_blowup: int = 1, repr: int = N.REPR_CANONICAL, keep_coeffs: bool = False) -> Commitment:
     """mats: list of device buffers (torch tensors or raw pointers)."""
     return _commit(ctx, N.lib.lurkhip_commit_dev, mats, log_heights, widths, log_blowup, repr, keep_coeffs)
+
+
+def commit_cosets_dev(ctx: Context, mats, log_heights, widths, shifts, log_blowup: int = 1, repr: int = N.REPR_MONTY) -> Commitment:
+    """As commit_dev for matrices given over cosets: shifts[i] = 31 / (coset shift of matrix i) (canonical)."""
+    n = len(mats)
+    ptrs = (C.c_void_p * n)(*[_addr(m) for m in mats])
+    lh = np.asarray(log_heights, dtype=np.uint32)
+    ws = np.asarray(widths, dtype=np.uint32)
+    sh = np.asarray(shifts, dtype=np.uint32)
+    handle = C.c_void_p()
+    root = np.empty(8, dtype=np.uint32)
+    ctx.check(N.lib.lurkhip_commit_cosets_dev(ctx.handle, n, C.cast(ptrs, C.c_void_p), _addr(lh), _addr(ws), _addr(sh), log_blowup, repr, C.byref(handle), _addr(root)))
+    return Commitment(ctx, handle, root, [int(x) for x in lh], [int(x) for x in ws], log_blowup)

@@ -72,12 +72,12 @@ int32_t interpolate(lurkhip_ctx* ctx, int log_n, int w, const uint32_t* evals, b
 
 // coefficients -> LDE on the coset g * <w_{N << b}>, rows in bit-reversed order, Montgomery
 int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_t* coef, uint32_t* lde,
-               uint32_t* row_scale /* N words scratch */, bool out_canonical) {
+               uint32_t* row_scale /* N words scratch */, bool out_canonical, uint32_t shift_m) {
     const NttPlan* plan = nullptr;
     LH_TRY(get_ntt_plan(ctx, log_n, &plan));
     const size_t n = (size_t)1 << log_n;
     const uint32_t n_inv = hpow(bb::to_monty((uint32_t)(n % bb::P)), bb::P - 2);
-    const uint32_t g = bb::to_monty(bb::GEN);
+    const uint32_t g = shift_m;
     const uint32_t w_big = two_adic_generator_monty(log_n + log_blowup);
     for (uint32_t q = 0; q < (1u << log_blowup); q++) {
         uint32_t s_q = bb::mul(g, hpow(w_big, brev(q, log_blowup)));
@@ -167,7 +167,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
 
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
-                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root) {
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
     LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
@@ -227,7 +227,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         TRY_C(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
         span_begin(ctx, "lde");
         TRY_C(interpolate(ctx, log_n, w, src, repr == LURKHIP_REPR_CANONICAL, (uint32_t*)scratch, coef));
-        TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false));
+        TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false,
+                     bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN)));
         span_end(ctx, "lde");
         if (!keep_coeffs) {
             pool_release(ctx, coef);  // stream-ordered: only later work can reuse it
@@ -270,7 +271,7 @@ int32_t lurkhip_coset_lde_dev(lurkhip_ctx* ctx, int32_t log_n, int32_t width, in
     LH_TRY(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
     const bool canon = repr == LURKHIP_REPR_CANONICAL;
     LH_TRY(interpolate(ctx, log_n, width, in, canon, (uint32_t*)scratch, (uint32_t*)coef));
-    LH_TRY(extend(ctx, log_n, width, log_blowup, (const uint32_t*)coef, out, (uint32_t*)row_scale, canon));
+    LH_TRY(extend(ctx, log_n, width, log_blowup, (const uint32_t*)coef, out, (uint32_t*)row_scale, canon, bb::to_monty(bb::GEN)));
     return LURKHIP_OK;
 }
 
@@ -303,6 +304,14 @@ int32_t lurkhip_commit_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* con
                            const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t keep_coeffs,
                            lurkhip_commitment** out, uint32_t* root) {
     return commit_impl(ctx, n_mats, mats_dev, false, log_heights, widths, log_blowup, repr, keep_coeffs, out, root);
+}
+
+int32_t lurkhip_commit_cosets_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev, const uint32_t* log_heights,
+                                  const uint32_t* widths, const uint32_t* shifts, int32_t log_blowup, int32_t repr,
+                                  lurkhip_commitment** out, uint32_t* root) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, shifts != nullptr, "null shifts");
+    return commit_impl(ctx, n_mats, mats_dev, false, log_heights, widths, log_blowup, repr, 0, out, root, shifts);
 }
 
 int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, const uint32_t* log_heights,

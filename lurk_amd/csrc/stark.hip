@@ -19,6 +19,7 @@
 
 #include "air_vm.h"
 #include "babybear.h"
+#include "commit.h"
 #include "ctx.h"
 #include "lair/air.h"
 #include "stark.h"
@@ -310,6 +311,106 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_add(uint32_t* __restrict__ 
 
 }  // namespace
 
+namespace {
+
+// ---------------------------------------------------------------- quotient values
+// One row of the quotient domain g * <w_Q>, Q = N << log_quotient_degree, per lane.  The committed LDEs are
+// stored in bit-reversed row order, so lane s works on natural index i = bitrev(s): its "local" rows are
+// the contiguous storage rows of the launch, its "next" row (i + Q/N) is another storage row.
+// Constraint k of the chip (then one per permutation batch column, then the three running-sum constraints) is
+// folded as sum_k alpha^(K-1-k) C_k(x), which is sphinx's Horner accumulation `acc = acc * alpha + C_k`
+// [UPSTREAM-RECALL: ProverConstraintFolder], and multiplied by 1 / Z_H(x).
+struct QuotientArgs {
+    const uint32_t* cons_prog;
+    const uint32_t* inter_prog;
+    const uint32_t* main;   // LDE matrices, bit-reversed rows, Montgomery
+    const uint32_t* prep;
+    const uint32_t* perm;   // 4 * perm_w base columns
+    const uint32_t* pub;
+    const uint32_t* alpha_pows;  // alpha^j, j < k_total
+    const uint32_t* beta_pows;
+    ef perm_alpha;
+    ef cumulative_sum;
+    uint32_t log_n, log_q, w, pw, perm_w, batch, k_total;
+    uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
+    uint32_t zh[4];
+    uint32_t g_m, wq_m, wn_inv_m;
+    uint32_t* out;          // [2^lqd][N][4]
+};
+
+struct QuotientSink {
+    const uint32_t* __restrict__ alpha_pows;
+    uint32_t k_total;
+    LogupAccum acc;
+    uint32_t batch;
+    const uint32_t* perm_l;
+    uint32_t k = 0, col = 0;
+    ef folded = bb::ef_zero();
+    __device__ __forceinline__ ef weight() { return ef_load(alpha_pows + 4 * (k_total - 1 - k)); }
+    __device__ __forceinline__ void assert_zero(uint32_t v) {
+        folded = bb::ef_add(folded, bb::ef_scale(weight(), v));
+        k++;
+    }
+    __device__ __forceinline__ void assert_zero_ext(const ef& v) {
+        folded = bb::ef_add(folded, bb::ef_mul(weight(), v));
+        k++;
+    }
+    __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
+    __device__ __forceinline__ void ival(uint32_t v) { acc.value(v); }
+    __device__ __forceinline__ void flush() {
+        // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
+        ef entry = ef_load(perm_l + 4 * col);
+        assert_zero_ext(bb::ef_sub(bb::ef_mul(acc.den, entry), acc.num));
+        col++;
+        acc.in_batch = 0;
+    }
+    __device__ __forceinline__ void iend(uint32_t m) {
+        if (acc.end(m, batch)) flush();
+    }
+};
+
+__global__ void k_quotient(QuotientArgs a) {
+    extern __shared__ uint32_t regs[];
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t q = 1u << a.log_q;
+    if (s >= q) return;
+    const uint32_t lqd = a.log_q - a.log_n, qd = 1u << lqd;
+    const uint32_t i = a.log_q ? (__brev(s) >> (32 - a.log_q)) : 0u;
+    const uint32_t i_next = (i + qd) & (q - 1);
+    const uint32_t s_next = a.log_q ? (__brev(i_next) >> (32 - a.log_q)) : 0u;
+    // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset)
+    const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
+    const uint32_t zh = a.zh[i & (qd - 1)];
+    const uint32_t is_first = bb::mul(zh, bb::inv(bb::sub(x, bb::R1)));
+    const uint32_t x_minus_last = bb::sub(x, a.wn_inv_m);
+    const uint32_t is_last = bb::mul(zh, bb::inv(x_minus_last));
+    const uint32_t is_trans = x_minus_last;
+    airvm::Sources src{a.main + (size_t)s * a.w, a.main + (size_t)s_next * a.w, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw,
+                       a.pub, {is_first, is_last, is_trans}};
+    const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
+    const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
+    QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.perm_alpha}, a.batch, perm_l};
+    airvm::run(a.cons_prog, src, regs + threadIdx.x, blockDim.x, sink);
+    airvm::run(a.inter_prog, src, regs + threadIdx.x, blockDim.x, sink);
+    if (sink.acc.in_batch) sink.flush();
+    // running-sum constraints (sphinx eval_permutation_constraints)
+    ef sum_l = bb::ef_zero(), sum_n = bb::ef_zero();
+    for (uint32_t c = 0; c + 1 < a.perm_w; c++) {
+        sum_l = bb::ef_add(sum_l, ef_load(perm_l + 4 * c));
+        sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
+    }
+    const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1)), phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, a.cumulative_sum), is_last));
+    const ef quot = bb::ef_scale(sink.folded, a.zh_inv[i & (qd - 1)]);
+    const uint32_t chunk = i & (qd - 1), r = i >> lqd;
+    uint4* dst = reinterpret_cast<uint4*>(a.out + ((size_t)chunk * ((size_t)1 << a.log_n) + r) * 4);
+    *dst = make_uint4(quot.c[0], quot.c[1], quot.c[2], quot.c[3]);
+}
+
+}  // namespace
+
 int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count) {
     hipLaunchKernelGGL(k_ef_powers, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, base_m[0], base_m[1], base_m[2], base_m[3],
                        out_dev, count);
@@ -565,6 +666,92 @@ int32_t lurkhip_permutation_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         for (int i = 0; i < 4; i++) cumulative_sum[i] = bb::from_monty(r[i]);
     }
+    return s;
+}
+
+int32_t lurkhip_quotient_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev,
+                             const uint32_t* prep_lde_dev, const uint32_t* perm_lde_dev, const uint32_t* perm_challenges,
+                             const uint32_t* alpha, const uint32_t* cumulative_sum, const uint32_t* public_values,
+                             uint32_t* out_dev) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, a && main_lde_dev && perm_lde_dev && perm_challenges && alpha && cumulative_sum && out_dev, "null argument");
+    LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
+    LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
+    const uint32_t lqd = a->air.log_quotient_degree();
+    LH_ARG(ctx, lqd <= 2 && log_n + lqd <= (uint32_t)bb::TWO_ADICITY, "unsupported quotient degree / height");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t *cp = nullptr, *ip = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, &cp, &ip));
+    const uint32_t perm_w = a->air.permutation_width(), batch = 1u << lqd;
+    const uint32_t n_batches = perm_w - 1;
+    const uint32_t k_total = (uint32_t)a->air.constraints.size() + n_batches + 3;
+    const uint32_t np = a->air.num_public;
+    auto tm = [](const uint32_t* v, uint32_t* o) {
+        for (int i = 0; i < 4; i++) o[i] = bb::to_monty(v[i] % bb::P);
+    };
+    uint32_t pa[4], pb[4], al[4], cs[4];
+    tm(perm_challenges, pa);
+    tm(perm_challenges + 4, pb);
+    tm(alpha, al);
+    tm(cumulative_sum, cs);
+    const uint32_t n_bp = a->max_tuple + 2;
+    void* scratch = nullptr;  // alpha powers | beta powers | public values
+    const size_t o_bp = (size_t)k_total * 16, o_pub = o_bp + (size_t)n_bp * 16, total = o_pub + std::max<size_t>(np, 1) * 4;
+    LH_TRY(pool_alloc(ctx, total, &scratch));
+    uint8_t* d = (uint8_t*)scratch;
+    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total);
+    if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp);
+    std::vector<uint32_t> pubm(np);
+    if (s == LURKHIP_OK && np) {
+        for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
+        hipError_t e = hipMemcpyAsync(d + o_pub, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "public values upload failed: %s", hipGetErrorString(e));
+    }
+    if (s == LURKHIP_OK) {
+        QuotientArgs q{};
+        q.cons_prog = cp;
+        q.inter_prog = ip;
+        q.main = main_lde_dev;
+        q.prep = prep_lde_dev ? prep_lde_dev : main_lde_dev;
+        q.perm = perm_lde_dev;
+        q.pub = (const uint32_t*)(d + o_pub);
+        q.alpha_pows = (const uint32_t*)d;
+        q.beta_pows = (const uint32_t*)(d + o_bp);
+        q.perm_alpha = bb::ef{{pa[0], pa[1], pa[2], pa[3]}};
+        q.cumulative_sum = bb::ef{{cs[0], cs[1], cs[2], cs[3]}};
+        q.log_n = log_n;
+        q.log_q = log_n + lqd;
+        q.w = a->air.width;
+        q.pw = a->air.prep_width;
+        q.perm_w = perm_w;
+        q.batch = batch;
+        q.k_total = k_total;
+        q.g_m = bb::to_monty(bb::GEN);
+        q.wq_m = two_adic_generator_monty((int)q.log_q);
+        const uint32_t wn = two_adic_generator_monty((int)log_n);
+        q.wn_inv_m = bb::pow(wn, bb::P - 2);
+        // Z_H(x) = x^N - 1 on the coset: g^N * (w_Q^N)^i - 1, i mod 2^lqd
+        uint32_t gn = q.g_m;
+        for (uint32_t i = 0; i < log_n; i++) gn = bb::mul(gn, gn);
+        const uint32_t w_qd = two_adic_generator_monty((int)lqd);
+        uint32_t cur = bb::R1;
+        for (uint32_t c = 0; c < (1u << lqd); c++) {
+            q.zh[c] = bb::sub(bb::mul(gn, cur), bb::R1);
+            q.zh_inv[c] = bb::pow(q.zh[c], bb::P - 2);
+            cur = bb::mul(cur, w_qd);
+        }
+        q.out = out_dev;
+        const uint32_t n_regs = std::max(a->prog.constraints[airp::H_N_REGS], a->prog.interactions[airp::H_N_REGS]);
+        size_t lds = 0;
+        int block = vm_block(n_regs, &lds);
+        const uint32_t rows = 1u << q.log_q;
+        span_begin(ctx, "quotient");
+        hipLaunchKernelGGL(k_quotient, dim3((rows + block - 1) / block), dim3(block), lds, ctx->stream, q);
+        span_end(ctx, "quotient");
+        if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
+    }
+    pool_release(ctx, scratch);
     return s;
 }
 

@@ -142,3 +142,130 @@ def permutation_trace(air, main, prep, alpha, beta, batch, public=()):
         run = ef_add(run, ef_sum(cols))
         out.append(cols + [run])
     return out
+
+
+# ------------------------------------------------------------------ domains, LDE (pure Python, small sizes)
+def ntt(vals, root):
+    """Evaluations of the polynomial with coefficient list `vals` at root^0 .. root^(n-1) (natural order)."""
+    n = len(vals)
+    if n == 1:
+        return list(vals)
+    even = ntt(vals[0::2], root * root % P)
+    odd = ntt(vals[1::2], root * root % P)
+    out = [0] * n
+    w = 1
+    for i in range(n // 2):
+        t = w * odd[i] % P
+        out[i] = (even[i] + t) % P
+        out[i + n // 2] = (even[i] - t) % P
+        w = w * root % P
+    return out
+
+
+def interpolate(evals, log_n):
+    """Coefficients of the polynomial with the given evaluations over H = <w_N> (natural order)."""
+    n = 1 << log_n
+    root_inv = finv(two_adic_generator(log_n))
+    n_inv = finv(n)
+    return [c * n_inv % P for c in ntt(list(evals), root_inv)]
+
+
+def coset_lde_column(evals, log_n, log_blowup, shift=GEN):
+    """p3 coset_lde_batch(.., shift) on one column: evaluations on shift * <w_{N << b}>, NATURAL order."""
+    coef = interpolate(evals, log_n)
+    m = 1 << (log_n + log_blowup)
+    sp, scaled = 1, []
+    for c in coef:
+        scaled.append(c * sp % P)
+        sp = sp * shift % P
+    return ntt(scaled + [0] * (m - len(scaled)), two_adic_generator(log_n + log_blowup))
+
+
+def coset_lde(rows, log_blowup=1, shift=GEN):
+    """Row-major matrix -> LDE rows in natural order."""
+    n = len(rows)
+    log_n = n.bit_length() - 1
+    cols = [coset_lde_column([r[c] for r in rows], log_n, log_blowup, shift) for c in range(len(rows[0]))]
+    return [[col[i] for col in cols] for i in range(n << log_blowup)]
+
+
+def bit_reverse_rows(rows):
+    bits = len(rows).bit_length() - 1
+    return [rows[bitrev(i, bits)] for i in range(len(rows))]
+
+
+def flatten_ef_rows(rows):
+    return [[c for e in r for c in e] for r in rows]
+
+
+def selectors_at(x, log_n):
+    """(is_first_row, is_last_row, is_transition, inv_zeroifier) of the trace domain H of size 2^log_n at a point x
+    outside H (p3 TwoAdicMultiplicativeCoset::selectors_on_coset / selectors_at_point: unnormalised)."""
+    n = 1 << log_n
+    zh = (pow(x, n, P) - 1) % P
+    w_inv = finv(two_adic_generator(log_n))
+    return (zh * finv(x - 1) % P, zh * finv(x - w_inv) % P, (x - w_inv) % P, finv(zh))
+
+
+# ------------------------------------------------------------------ quotient
+def fold_constraints(b: "oair.Builder", perm_local, perm_next, perm_alpha, perm_beta, batch, alpha, cumulative_sum, sels):
+    """sphinx Chip::eval with the folding builder: the chip's constraints, then eval_permutation_constraints;
+    accumulator = accumulator * alpha + constraint.  perm rows are lists of EF tuples.  `sels` may hold base or
+    extension values (the verifier evaluates at an extension point); everything is lifted to EF."""
+
+    def lift(v):
+        return v if isinstance(v, tuple) else ef(v)
+
+    is_first, is_last, is_trans = (lift(s) for s in sels[:3])
+    acc = ZERO
+    for c in b.constraints:
+        acc = ef_add(ef_mul(acc, alpha), lift(c))
+    its = [(m, v, True) for m, v in b.sends] + [(m, v, False) for m, v in b.receives]
+    n_cols = len(perm_local)
+    for col, c0 in enumerate(range(0, len(its), batch)):
+        chunk = its[c0:c0 + batch]
+        rlcs = [fingerprint_ext(perm_alpha, perm_beta, [lift(x) for x in vals]) for _, vals, _ in chunk]
+        mults = [lift(m) if s else ef_neg(lift(m)) for m, _, s in chunk]
+        product, numerator = ONE, ZERO
+        for i, (m, rlc) in enumerate(zip(mults, rlcs)):
+            product = ef_mul(product, rlc)
+            others = ONE
+            for j, o in enumerate(rlcs):
+                if j != i:
+                    others = ef_mul(others, o)
+            numerator = ef_add(numerator, ef_mul(m, others))
+        acc = ef_add(ef_mul(acc, alpha), ef_sub(ef_mul(product, perm_local[col]), numerator))
+    sum_local, sum_next = ef_sum(perm_local[: n_cols - 1]), ef_sum(perm_next[: n_cols - 1])
+    phi_local, phi_next = perm_local[-1], perm_next[-1]
+    for c in (ef_mul(ef_sub(phi_local, sum_local), is_first), ef_mul(ef_sub(ef_sub(phi_next, phi_local), sum_next), is_trans),
+              ef_mul(ef_sub(phi_local, cumulative_sum), is_last)):
+        acc = ef_add(ef_mul(acc, alpha), c)
+    return acc
+
+
+def fingerprint_ext(alpha, beta, vals, kind=oair.INTERACTION_KIND_MEMORY):
+    d = ef_add(alpha, ef(kind))
+    bp = beta
+    for v in vals:
+        d = ef_add(d, ef_mul(bp, v))
+        bp = ef_mul(bp, beta)
+    return d
+
+
+def quotient_chunks(air, log_n, main_lde, prep_lde, perm_lde, perm_alpha, perm_beta, alpha, cumulative_sum, public=(), lqd=1):
+    """sphinx quotient_values + split_evals.  *_lde: NATURAL-order rows over the quotient domain 31 * <w_Q>
+    (perm_lde rows are lists of EF tuples).  Returns 2^lqd chunk matrices of EF tuples (chunk c row r = value at
+    31 * w_Q^(r * 2^lqd + c))."""
+    q, qd = 1 << (log_n + lqd), 1 << lqd
+    wq = two_adic_generator(log_n + lqd)
+    vals = []
+    for i in range(q):
+        x = GEN * pow(wq, i, P) % P
+        is_first, is_last, is_trans, inv_zh = selectors_at(x, log_n)
+        nx = (i + qd) % q
+        b = oair.Builder(main_lde[i], main_lde[nx], prep_lde[i] if prep_lde is not None else (), prep_lde[nx] if prep_lde is not None else (),
+                         public, (is_first, is_last, is_trans))
+        air.eval(b)
+        folded = fold_constraints(b, perm_lde[i], perm_lde[nx], perm_alpha, perm_beta, qd, alpha, cumulative_sum, (is_first, is_last, is_trans))
+        vals.append(ef_scale(folded, inv_zh))
+    return [[vals[r * qd + c] for r in range(1 << log_n)] for c in range(qd)]

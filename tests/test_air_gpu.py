@@ -180,3 +180,47 @@ def test_large_permutation_trace_cumulative_sums_cancel(ctx):
         out = torch.zeros((h, 4 * a.permutation_width), dtype=torch.int32, device="cuda")
         total += a.permutation_trace(ctx, h, t, None, ch, out).astype(np.uint64)
     assert not (total % P).any()
+
+
+def test_quotient_matches_oracle(ctx):
+    """main commit -> permutation trace -> commit -> quotient chunks, chip by chip, against the oracle's
+    quotient computed from its own LDEs and numeric AIR; then the chunks' commitment LDE against the
+    oracle's coset LDE (shift w_Q^-c)."""
+    import torch
+
+    from lurk_amd import commit as cm
+    from oracle import stark as os_
+
+    perm_alpha, perm_beta, alpha = (11, 22, 33, 44), (5, 6, 7, 2013265920), (1000, 2000, 3000, 4000)
+    for src, entry, args in [(DEMO, "fib", [10]), (se.SOURCE, "synth_eval", [1, 13, 0])]:
+        chips, pv = _machine_chips(ctx, src, entry, args)
+        for a, oair_, t, rows in chips:
+            h = len(rows)
+            log_n = h.bit_length() - 1
+            lqd = a.log_quotient_degree
+            assert lqd == 1
+            main_c = cm.commit_dev(ctx, [t], [log_n], [a.width], log_blowup=1, repr=1)
+            perm = torch.zeros((h, 4 * a.permutation_width), dtype=torch.int32, device="cuda")
+            cs = a.permutation_trace(ctx, h, t, None, perm_alpha + perm_beta, perm)
+            perm_c = cm.commit_dev(ctx, [perm], [log_n], [4 * a.permutation_width], log_blowup=1, repr=1)
+            out = torch.zeros((1 << lqd, h, 4), dtype=torch.int32, device="cuda")
+            a.quotient(ctx, log_n, main_c.matrix_dev(0)[0], None, perm_c.matrix_dev(0)[0], perm_alpha + perm_beta, alpha, cs, out, public=pv)
+            ctx.sync()
+            got = field.from_monty(out.cpu().numpy().view(np.uint32))
+            # oracle
+            operm = os_.permutation_trace(oair_, rows, None, perm_alpha, perm_beta, 1 << lqd, public=pv)
+            main_lde = os_.coset_lde(rows, 1)
+            perm_flat = os_.coset_lde(os_.flatten_ef_rows(operm), 1)
+            perm_lde = [[tuple(r[4 * j:4 * j + 4]) for j in range(a.permutation_width)] for r in perm_flat]
+            want = os_.quotient_chunks(oair_, log_n, main_lde, None, perm_lde, perm_alpha, perm_beta, alpha, operm[-1][-1], public=pv, lqd=lqd)
+            assert got.tolist() == [[list(v) for v in chunk] for chunk in want], a.name
+            # commit the chunks over their cosets: LDE == oracle coset LDE with shift g / (g w_Q^c) = w_Q^-c
+            wq = os_.two_adic_generator(log_n + lqd)
+            shifts = [pow(wq, (-c) % (P - 1), P) for c in range(1 << lqd)]
+            qc = cm.commit_cosets_dev(ctx, [out[c] for c in range(1 << lqd)], [log_n] * (1 << lqd), [4] * (1 << lqd), shifts, log_blowup=1)
+            for c in range(1 << lqd):
+                lde_c = qc.lde_host(c)
+                want_lde = os_.bit_reverse_rows(os_.coset_lde([list(v) for v in want[c]], 1, shift=shifts[c]))
+                assert lde_c.tolist() == want_lde, (a.name, c)
+            for c_ in (main_c, perm_c, qc):
+                c_.close()
