@@ -317,6 +317,47 @@ int32_t lurkhip_quotient_dev(lurkhip_ctx* ctx, lurkhip_air* air, uint32_t log_n,
                              const uint32_t* alpha, const uint32_t* cumulative_sum, const uint32_t* public_values,
                              uint32_t* out_dev);
 
+/* ---------------------------------------------------------------- transcript + shard prover */
+/* Fiat-Shamir transcript (p3 DuplexChallenger<BabyBear, Poseidon2-16, 16, 8> [UPSTREAM-RECALL]) over the same width-16
+ * permutation as the Merkle tree; host state.  Values are canonical. */
+typedef struct lurkhip_challenger lurkhip_challenger;
+int32_t lurkhip_challenger_new(lurkhip_ctx* ctx, lurkhip_challenger** out);
+int32_t lurkhip_challenger_clone(const lurkhip_challenger* src, lurkhip_challenger** out);
+int32_t lurkhip_challenger_free(lurkhip_challenger* c);
+int32_t lurkhip_challenger_observe(lurkhip_challenger* c, const uint32_t* values, uint32_t n);
+int32_t lurkhip_challenger_sample(lurkhip_challenger* c, uint32_t* out, uint32_t n);
+int32_t lurkhip_challenger_sample_bits(lurkhip_challenger* c, uint32_t bits, uint32_t* out);
+
+/* StarkMachine::setup: commits the preprocessed traces (height-sorted, tallest first; device, Montgomery, natural row
+ * order; they must outlive the key).  n_prep may be 0.  Replaces machine.setup(&LairMachineProgram),
+ * /root/reference/benches/fib.rs:120. */
+typedef struct lurkhip_pk lurkhip_pk;
+int32_t lurkhip_setup(lurkhip_ctx* ctx, int32_t n_prep, const uint32_t* const* prep_traces_dev, const uint32_t* log_heights,
+                      const uint32_t* widths, int32_t log_blowup, lurkhip_pk** out, uint32_t* root);
+int32_t lurkhip_pk_free(lurkhip_ctx* ctx, lurkhip_pk* pk);
+
+/* LocalProver::commit_shards for one shard: orders the chips by height (tallest first, stable) and commits their
+ * main traces (device, Montgomery, natural row order, 2^log_heights[i] x width(airs[i]); they must outlive the shard).
+ * prep_indices[i] = index of chip i's preprocessed trace in the key or -1 (may be NULL). */
+typedef struct lurkhip_shard lurkhip_shard;
+int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* const* airs, const uint32_t* log_heights,
+                             const uint32_t* const* main_traces_dev, const int32_t* prep_indices, int32_t log_blowup,
+                             lurkhip_shard** out, uint32_t* root);
+int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* shard);
+
+/* LocalProver::prove_shard: permutation traces, quotient, openings and FRI for a committed shard.  The challenger
+ * must already have observed what the machine observes before per-shard challenges are drawn (preprocessed root, 0,
+ * every shard's main root and public values); it is advanced exactly as the verifier's will be.  The proof is a flat
+ * array of canonical words (layout: lurk_amd/prover.py). Replaces machine.prove::<LocalProver>(..) per shard,
+ * /root/reference/benches/fib.rs:124, /root/reference/src/core/cli/repl.rs:196. */
+typedef struct lurkhip_proof lurkhip_proof;
+int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
+                            const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
+                            lurkhip_proof** out);
+int64_t lurkhip_proof_words(const lurkhip_proof* proof);
+int32_t lurkhip_proof_read(const lurkhip_proof* proof, uint32_t* out);
+int32_t lurkhip_proof_free(lurkhip_proof* proof);
+
 #ifdef __cplusplus
 }
 #endif

@@ -128,6 +128,20 @@ SIGNATURES = {
     "lurkhip_air_eval_rows": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
     "lurkhip_air_check_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "lurkhip_permutation_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p]),
+    "lurkhip_challenger_new": (_i32, [_p, C.POINTER(_p)]),
+    "lurkhip_challenger_clone": (_i32, [_p, C.POINTER(_p)]),
+    "lurkhip_challenger_free": (_i32, [_p]),
+    "lurkhip_challenger_observe": (_i32, [_p, _u32p, C.c_uint32]),
+    "lurkhip_challenger_sample": (_i32, [_p, _u32p, C.c_uint32]),
+    "lurkhip_challenger_sample_bits": (_i32, [_p, C.c_uint32, C.POINTER(C.c_uint32)]),
+    "lurkhip_setup": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_pk_free": (_i32, [_p, _p]),
+    "lurkhip_shard_commit": (_i32, [_p, _i32, _p, _u32p, _p, _p, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_shard_free": (_i32, [_p, _p]),
+    "lurkhip_shard_prove": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_proof_words": (_i64, [_p]),
+    "lurkhip_proof_read": (_i32, [_p, _u32p]),
+    "lurkhip_proof_free": (_i32, [_p]),
     "lurkhip_quotient_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
 }
 

@@ -7,6 +7,26 @@
 #include "ctx.h"
 
 namespace lurkhip {
+struct LeafCol;
+}
+
+// Device-resident result of a commit: the LDE matrices and every level of the Merkle tree.
+struct lurkhip_commitment {
+    int n_mats = 0;
+    int log_blowup = 0;
+    std::vector<uint32_t*> lde;       // device, Montgomery, (1 << log_h[i]) x width[i], bit-reversed rows
+    bool owns_lde = true;
+    std::vector<int> log_h;           // log2 of the LDE height
+    std::vector<uint32_t> width;
+    std::vector<uint32_t*> coeffs;    // device, Montgomery, natural-order coefficients (N x w), may be null
+    uint32_t* digests = nullptr;      // all levels back to back, level 0 first
+    std::vector<size_t> level_off;    // in digests (units of 8 words)
+    int log_max = 0;
+    std::vector<void*> owned;         // extra device allocations (column tables)
+    std::vector<std::vector<lurkhip::LeafCol>> host_cols;  // staging kept alive for the async copies
+};
+
+namespace lurkhip {
 
 // ---- NTT ---------------------------------------------------------------------
 struct NttPlan {
@@ -49,6 +69,15 @@ int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32
 int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n);
 
 int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev);
+
+// ---- commit pipeline entry points shared with the prover (commit.hip)
+int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
+                    const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr);
+int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const std::vector<int>& log_heights,
+                   const std::vector<uint32_t>& widths, lurkhip_commitment** out);
+int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m);
+void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c);
 int32_t get_ntt_plan(lurkhip_ctx* ctx, int log_n, const NttPlan** out);
 
 }  // namespace lurkhip

@@ -8,20 +8,6 @@
 #include "babybear.h"
 #include "commit.h"
 
-struct lurkhip_commitment {
-    int n_mats = 0;
-    int log_blowup = 0;
-    std::vector<uint32_t*> lde;       // device, Montgomery, (1 << log_h[i]) x width[i]
-    std::vector<int> log_h;           // log2 of the LDE height
-    std::vector<uint32_t> width;
-    std::vector<uint32_t*> coeffs;    // device, Montgomery, natural-order coefficients (N x w), may be null
-    uint32_t* digests = nullptr;      // all levels back to back, level 0 first
-    std::vector<size_t> level_off;    // in digests (units of 8 words)
-    int log_max = 0;
-    std::vector<void*> owned;         // extra device allocations (column tables)
-    std::vector<std::vector<lurkhip::LeafCol>> host_cols;  // staging kept alive for the async copies
-};
-
 namespace lurkhip {
 
 int32_t get_ntt_plan(lurkhip_ctx* ctx, int log_n, const NttPlan** out) {
@@ -88,14 +74,19 @@ int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_
     return LURKHIP_OK;
 }
 
+}  // namespace
+
 void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     if (!c) return;
-    for (auto p : c->lde) pool_release(ctx, p);
+    if (c->owns_lde)
+        for (auto p : c->lde) pool_release(ctx, p);
     for (auto p : c->coeffs) pool_release(ctx, p);
     for (auto p : c->owned) pool_release(ctx, p);
     pool_release(ctx, c->digests);
     delete c;
 }
+
+namespace {
 
 // Build (on device) the uniform column table for the matrices in `idx`
 int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int>& idx, LeafCol** out_dev,
@@ -165,9 +156,38 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     return LURKHIP_OK;
 }
 
+}  // namespace
+
+// Tree over matrices that are already on the device and are committed as they are (no LDE): FRI layers.
+// The commitment does not own the matrices.
+int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const std::vector<int>& log_heights,
+                   const std::vector<uint32_t>& widths, lurkhip_commitment** out) {
+    lurkhip_commitment* c = new lurkhip_commitment();
+    c->n_mats = (int)mats.size();
+    c->lde = mats;
+    c->owns_lde = false;
+    c->coeffs.assign(mats.size(), nullptr);
+    c->log_h = log_heights;
+    c->width = widths;
+    int32_t s = build_tree(ctx, c);
+    if (s != LURKHIP_OK) {
+        (void)hipStreamSynchronize(ctx->stream);
+        free_commitment(ctx, c);
+        return s;
+    }
+    *out = c;
+    return LURKHIP_OK;
+}
+
+int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m) {
+    LH_HIP(ctx, hipMemcpyAsync(root_m, c->digests + c->level_off[c->log_max] * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}
+
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
-                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr) {
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
     LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
@@ -249,7 +269,6 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     return LURKHIP_OK;
 }
 
-}  // namespace
 }  // namespace lurkhip
 
 using namespace lurkhip;

@@ -22,6 +22,7 @@ struct lurkhip_ctx {
     size_t arena_bytes[4] = {0, 0, 0, 0};
     // lazily created per-ctx device state owned by other translation units (commit.h)
     void* merkle_params_dev = nullptr;
+    void* merkle_params_host = nullptr;  // P16Params copy for the host-side challenger
     void* ntt_plans[32] = {};
     std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)

@@ -1,0 +1,40 @@
+// Internal interfaces of the opening-phase kernels (fri.hip).
+#pragma once
+#include <stdint.h>
+
+#include <vector>
+
+#include "babybear.h"
+#include "ctx.h"
+
+namespace lurkhip {
+
+// out[s] (EF, 4 Montgomery words), s < 2^log_m, for the point x_s = 31 * w_M^bitrev(s):
+//   mode 0: w_M^bitrev(s) / (z - x_s)   (barycentric weights of the coset 31 * <w_M>)
+//   mode 1: 1 / (x_s - z)
+int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev);
+// out_dev[p][c] = sum_{s < n_rows} mat[s][c] * u_p[s]  (p = 0, and 1 when u1 != null); out is [2][w][4] words
+int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
+                   uint32_t* out_dev);
+// ro[s] += apow0 * (rr_s - ys0) * d0[s] (+ apow1 * (rr_s - ys1) * d1[s]),  rr_s = sum_c alpha_pows[c] * mat[s][c]
+int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
+                        const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
+                        const bb::ef& apow1, uint32_t* ro);
+// p3 fold_even_odd on 2^log_len bit-reversed evaluations (+ add[j] when given); out has 2^(log_len-1) elements
+int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const bb::ef& beta, const uint32_t* add, uint32_t* out);
+// smallest canonical witness w such that a challenger whose permutation input is `state` (pending inputs already
+// written over lanes [0, n_pending)) samples `bits` zero bits after observing w
+int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, uint32_t* witness);
+
+struct OpenMat {
+    const uint32_t* base;
+    uint32_t width;
+    uint32_t log_h;
+};
+// MMCS open_batch for n_queries indices at once: record q = [row of every matrix at (indices[q] >> shift) >>
+// (log_max - log_h) | log_max sibling digests].  out_dev == null only computes record_words.
+int32_t gather_openings(lurkhip_ctx* ctx, const std::vector<OpenMat>& mats, const uint32_t* digests, const std::vector<size_t>& level_off,
+                        uint32_t log_max, const uint32_t* indices_dev, uint32_t n_queries, uint32_t shift, uint32_t* out_dev,
+                        uint32_t* record_words);
+
+}  // namespace lurkhip

@@ -1,0 +1,295 @@
+// Kernels of the opening phase: evaluation of committed matrices at out-of-domain points, the FRI input
+// ("reduced openings"), FRI folding, proof-of-work search and batched Merkle openings.
+//
+// Replaces (third-party, source absent from /root/reference; [UPSTREAM-RECALL] Plonky3 @ a0b92870, parity
+// unpinned): p3_fri::TwoAdicFriPcs::open (interpolate_coset, compute_inverse_denominators, the
+// "reduce rows" loop), p3_fri::prover::{commit_phase, fold_even_odd, answer_query},
+// DuplexChallenger::grind, FieldMerkleTreeMmcs::open_batch -- reached from the reference through
+// machine.prove::<LocalProver>, /root/reference/benches/fib.rs:124.
+//
+// All matrices are the committed LDEs: row-major, bit-reversed row order, Montgomery words; extension
+// elements are 4 consecutive words.  Storage row s of a height-M matrix is the point x_s = 31 * w_M^bitrev(s).
+#include "babybear.h"
+#include "commit.h"
+#include "ctx.h"
+#include "fri.h"
+#include "poseidon2_dev.h"
+
+namespace lurkhip {
+
+namespace {
+
+using bb::ef;
+
+__device__ __forceinline__ ef ef_load(const uint32_t* p) {
+    uint4 v = *reinterpret_cast<const uint4*>(p);
+    return ef{{v.x, v.y, v.z, v.w}};
+}
+__device__ __forceinline__ void ef_store(uint32_t* p, const ef& e) { *reinterpret_cast<uint4*>(p) = make_uint4(e.c[0], e.c[1], e.c[2], e.c[3]); }
+
+__device__ __forceinline__ uint32_t brev_bits(uint32_t x, int bits) { return bits ? (__brev(x) >> (32 - bits)) : 0u; }
+
+// ---------------------------------------------------------------- point-dependent row weights
+// mode 0: u[s] = w^i / (z - g w^i)      (barycentric weights on the low coset, p3 interpolate_coset)
+// mode 1: d[s] = 1 / (g w^i - z)        (p3 compute_inverse_denominators)
+// with i = bitrev(s) over log_m bits, w = w_M.
+__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, uint32_t w_m, ef z, uint32_t* __restrict__ out) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= (1u << log_m)) return;
+    const uint32_t i = brev_bits(s, log_m);
+    const uint32_t wi = bb::pow(w_m, i);
+    const uint32_t x = bb::mul(g_m, wi);
+    ef r;
+    if (mode == 0) {
+        ef diff = z;
+        diff.c[0] = bb::sub(diff.c[0], x);
+        r = bb::ef_scale(bb::ef_inv(diff), wi);
+    } else {
+        ef diff{{bb::sub(x, z.c[0]), bb::neg(z.c[1]), bb::neg(z.c[2]), bb::neg(z.c[3])}};
+        r = bb::ef_inv(diff);
+    }
+    ef_store(out + 4 * (size_t)s, r);
+}
+
+// ---------------------------------------------------------------- column-wise dot products with EF weights
+// partial[blk][p][c] = sum over the block's rows of mat[s][c] * u_p[s]; 256 threads = 4 row lanes x 64 column lanes
+constexpr int DOT_ROWS = 1024;
+
+__global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
+                                                     const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
+                                                     uint32_t* __restrict__ partial) {
+    __shared__ uint32_t sh[4][2][64][4];
+    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    const size_t row0 = (size_t)blockIdx.x * DOT_ROWS;
+    const size_t row_end = row0 + DOT_ROWS < n_rows ? row0 + DOT_ROWS : n_rows;
+    const int n_pts = u1 ? 2 : 1;
+    for (uint32_t cb = 0; cb < w; cb += 64) {
+        const uint32_t c = cb + lane;
+        ef a0 = bb::ef_zero(), a1 = bb::ef_zero();
+        if (c < w) {
+            for (size_t r = row0 + rl; r < row_end; r += 4) {
+                const uint32_t m = mat[r * w + c];
+                a0 = bb::ef_add(a0, bb::ef_scale(ef_load(u0 + 4 * r), m));
+                if (u1) a1 = bb::ef_add(a1, bb::ef_scale(ef_load(u1 + 4 * r), m));
+            }
+        }
+        for (int k = 0; k < 4; k++) {
+            sh[rl][0][lane][k] = a0.c[k];
+            sh[rl][1][lane][k] = a1.c[k];
+        }
+        __syncthreads();
+        if (rl == 0 && c < w) {
+            for (int p = 0; p < n_pts; p++) {
+                ef t = bb::ef_zero();
+                for (int q = 0; q < 4; q++) t = bb::ef_add(t, ef{{sh[q][p][lane][0], sh[q][p][lane][1], sh[q][p][lane][2], sh[q][p][lane][3]}});
+                ef_store(partial + (((size_t)blockIdx.x * 2 + p) * w + c) * 4, t);
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// out[p][c] = sum over blocks of partial[blk][p][c]; one workgroup per (p, c)
+__global__ __launch_bounds__(256) void k_dot_finish(const uint32_t* __restrict__ partial, uint32_t w, uint32_t n_blocks,
+                                                     uint32_t* __restrict__ out) {
+    __shared__ uint32_t sh[256][4];
+    const uint32_t c = blockIdx.x, p = blockIdx.y;
+    ef t = bb::ef_zero();
+    for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) t = bb::ef_add(t, ef_load(partial + (((size_t)b * 2 + p) * w + c) * 4));
+    for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = t.c[k];
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if ((int)threadIdx.x < off)
+            for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = bb::add(sh[threadIdx.x][k], sh[threadIdx.x + off][k]);
+        __syncthreads();
+    }
+    if (threadIdx.x == 0)
+        for (int k = 0; k < 4; k++) out[((size_t)p * w + c) * 4 + k] = sh[0][k];
+}
+
+// ---------------------------------------------------------------- reduced openings
+// ro[s] += apow0 * (rr - ys0) * d0[s] + apow1 * (rr - ys1) * d1[s],  rr = sum_c alpha^c mat[s][c]
+struct ReduceArgs {
+    const uint32_t* mat;
+    uint32_t w;
+    uint32_t m_rows;
+    const uint32_t* alpha_pows;  // alpha^c, c < w
+    const uint32_t* d0;
+    const uint32_t* d1;  // nullable
+    ef ys0, ys1, apow0, apow1;
+    uint32_t* ro;
+};
+
+__global__ __launch_bounds__(256) void k_reduce_openings(ReduceArgs a) {
+    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    if (s >= a.m_rows) return;
+    const uint32_t* __restrict__ row = a.mat + (size_t)s * a.w;
+    ef rr = bb::ef_zero();
+    for (uint32_t c = 0; c < a.w; c++) rr = bb::ef_add(rr, bb::ef_scale(ef_load(a.alpha_pows + 4 * c), row[c]));
+    ef acc = ef_load(a.ro + 4 * (size_t)s);
+    acc = bb::ef_add(acc, bb::ef_mul(a.apow0, bb::ef_mul(bb::ef_sub(rr, a.ys0), ef_load(a.d0 + 4 * (size_t)s))));
+    if (a.d1) acc = bb::ef_add(acc, bb::ef_mul(a.apow1, bb::ef_mul(bb::ef_sub(rr, a.ys1), ef_load(a.d1 + 4 * (size_t)s))));
+    ef_store(a.ro + 4 * (size_t)s, acc);
+}
+
+// ---------------------------------------------------------------- FRI fold (p3 fold_even_odd)
+// out[j] = (1/2 + beta/2 * ginv^bitrev(j)) e[2j] + (1/2 - beta/2 * ginv^bitrev(j)) e[2j+1]  (+ add[j]),
+// ginv = (generator of the size-len subgroup)^-1; len = 2^log_len
+__global__ __launch_bounds__(256) void k_fri_fold(const uint32_t* __restrict__ cur, int log_len, ef half_beta, uint32_t ginv_m,
+                                                   uint32_t half_m, const uint32_t* __restrict__ add, uint32_t* __restrict__ out) {
+    const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t half_len = 1u << (log_len - 1);
+    if (j >= half_len) return;
+    const ef power = bb::ef_scale(half_beta, bb::pow(ginv_m, brev_bits(j, log_len - 1)));
+    const ef e0 = ef_load(cur + 8 * (size_t)j), e1 = ef_load(cur + 8 * (size_t)j + 4);
+    ef r = bb::ef_add(bb::ef_mul(bb::ef_add_base(power, half_m), e0),
+                      bb::ef_mul(bb::ef_add_base(bb::ef_sub(bb::ef_zero(), power), half_m), e1));
+    if (add) r = bb::ef_add(r, ef_load(add + 4 * (size_t)j));
+    ef_store(out + 4 * (size_t)j, r);
+}
+
+// ---------------------------------------------------------------- proof of work (DuplexChallenger::grind)
+// witness w is accepted when, after observing it, the next sampled element has `bits` low zero bits: one
+// permutation of the state with the pending inputs and w written over its first lanes; the sample is lane 7.
+__global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__ p, const uint32_t* __restrict__ state_in,
+                                                    int n_pending, uint32_t base, uint32_t mask, uint32_t* __restrict__ best) {
+    const uint32_t wcan = base + blockIdx.x * blockDim.x + threadIdx.x;
+    if (wcan >= bb::P) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = state_in[i];  // pending inputs already written over lanes [0, n_pending)
+    const uint32_t wm = bb::to_monty(wcan);
+    // the witness lands in lane n_pending (compile-time indices only: select per lane)
+#pragma unroll
+    for (int i = 0; i < 8; i++)
+        if (i == n_pending) s[i] = wm;
+    p2::NoRecord rec;
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, rec);
+    if ((bb::from_monty(s[7]) & mask) == 0) atomicMin(best, wcan);
+}
+
+// ---------------------------------------------------------------- batched Merkle openings (MMCS open_batch)
+struct GatherMat {
+    const uint32_t* base;
+    uint32_t width;
+    uint32_t log_h;
+    uint32_t out_off;  // word offset of this matrix's row inside a query's record
+};
+
+// one workgroup per query: record = [rows of every matrix back to back | log_max sibling digests, leaf level first]
+__global__ __launch_bounds__(256) void k_gather_openings(const GatherMat* __restrict__ mats, uint32_t n_mats, const uint32_t* __restrict__ digests,
+                                                          const uint64_t* __restrict__ level_off, uint32_t log_max, uint32_t rows_words,
+                                                          const uint32_t* __restrict__ indices, uint32_t shift, uint32_t* __restrict__ out) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t index = indices[q] >> shift;
+    uint32_t* rec = out + (size_t)q * (rows_words + 8 * log_max);
+    for (uint32_t m = 0; m < n_mats; m++) {
+        const GatherMat g = mats[m];
+        const size_t r = index >> (log_max - g.log_h);
+        for (uint32_t c = threadIdx.x; c < g.width; c += blockDim.x) rec[g.out_off + c] = g.base[r * g.width + c];
+    }
+    for (uint32_t t = threadIdx.x; t < 8 * log_max; t += blockDim.x) {
+        const uint32_t l = t >> 3, k = t & 7;
+        const size_t sib = (index >> l) ^ 1u;
+        rec[rows_words + t] = digests[(level_off[l] + sib) * 8 + k];
+    }
+}
+
+}  // namespace
+
+int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev) {
+    const uint32_t m = 1u << log_m;
+    hipLaunchKernelGGL(k_point_weights, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, mode, log_m, bb::to_monty(bb::GEN),
+                       two_adic_generator_monty(log_m), z, out_dev);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
+                   uint32_t* out_dev) {
+    const uint32_t n_blocks = (uint32_t)((n_rows + DOT_ROWS - 1) / DOT_ROWS);
+    void* partial = nullptr;
+    LH_TRY(pool_alloc(ctx, (size_t)n_blocks * 2 * w * 16, &partial));
+    hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, (uint32_t*)partial);
+    hipLaunchKernelGGL(k_dot_finish, dim3(w, u1 ? 2 : 1), dim3(256), 0, ctx->stream, (const uint32_t*)partial, w, n_blocks, out_dev);
+    pool_release(ctx, partial);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
+                        const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
+                        const bb::ef& apow1, uint32_t* ro) {
+    ReduceArgs a{mat, w, m_rows, alpha_pows, d0, d1, ys0, ys1, apow0, apow1, ro};
+    hipLaunchKernelGGL(k_reduce_openings, dim3((m_rows + 255) / 256), dim3(256), 0, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const bb::ef& beta, const uint32_t* add, uint32_t* out) {
+    const uint32_t half_m = bb::pow(bb::to_monty(2), bb::P - 2);
+    const bb::ef half_beta = bb::ef_scale(beta, half_m);
+    const uint32_t ginv = bb::pow(two_adic_generator_monty(log_len), bb::P - 2);
+    const uint32_t half_len = 1u << (log_len - 1);
+    hipLaunchKernelGGL(k_fri_fold, dim3((half_len + 255) / 256), dim3(256), 0, ctx->stream, cur, log_len, half_beta, ginv, half_m, add, out);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, uint32_t* witness) {
+    const P16Params* params = nullptr;
+    LH_TRY(get_merkle_params(ctx, &params));
+    void* scratch = nullptr;
+    LH_TRY(pool_alloc(ctx, 80, &scratch));
+    uint32_t host[17];
+    for (int i = 0; i < 16; i++) host[i] = state_with_pending_m[i];
+    host[16] = 0xffffffffu;
+    int32_t s = LURKHIP_OK;
+    hipError_t e = hipMemcpyAsync(scratch, host, sizeof host, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    const uint32_t mask = bits >= 31 ? 0x7fffffffu : ((1u << bits) - 1u);
+    const uint32_t batch = 1u << 20;
+    uint32_t best = 0xffffffffu;
+    for (uint64_t base = 0; e == hipSuccess && base < bb::P && best == 0xffffffffu; base += batch) {
+        hipLaunchKernelGGL(k_pow_grind, dim3(batch / 256), dim3(256), 0, ctx->stream, params, (const uint32_t*)scratch, n_pending,
+                           (uint32_t)base, mask, (uint32_t*)scratch + 16);
+        e = hipGetLastError();
+        if (e == hipSuccess) e = hipMemcpyAsync(&best, (uint32_t*)scratch + 16, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    }
+    pool_release(ctx, scratch);
+    if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "pow_grind failed: %s", hipGetErrorString(e));
+    else if (best == 0xffffffffu) s = set_error(ctx, LURKHIP_ERR_EXEC, "no proof-of-work witness found");
+    *witness = best;
+    return s;
+}
+
+int32_t gather_openings(lurkhip_ctx* ctx, const std::vector<OpenMat>& mats, const uint32_t* digests, const std::vector<size_t>& level_off,
+                        uint32_t log_max, const uint32_t* indices_dev, uint32_t n_queries, uint32_t shift, uint32_t* out_dev,
+                        uint32_t* record_words) {
+    std::vector<GatherMat> g(mats.size());
+    uint32_t off = 0;
+    for (size_t i = 0; i < mats.size(); i++) {
+        g[i] = GatherMat{mats[i].base, mats[i].width, mats[i].log_h, off};
+        off += mats[i].width;
+    }
+    *record_words = off + 8 * log_max;
+    if (!out_dev) return LURKHIP_OK;  // size query
+    std::vector<uint64_t> lo(level_off.begin(), level_off.end());
+    void* scratch = nullptr;
+    const size_t b_g = g.size() * sizeof(GatherMat), b_lo = lo.size() * 8, o_lo = (b_g + 15) & ~(size_t)15;
+    LH_TRY(pool_alloc(ctx, o_lo + b_lo + 16, &scratch));
+    hipError_t e = hipMemcpyAsync(scratch, g.data(), b_g, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipMemcpyAsync((uint8_t*)scratch + o_lo, lo.data(), b_lo, hipMemcpyHostToDevice, ctx->stream);
+    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors die at scope exit
+    if (e == hipSuccess) {
+        hipLaunchKernelGGL(k_gather_openings, dim3(n_queries), dim3(256), 0, ctx->stream, (const GatherMat*)scratch, (uint32_t)g.size(), digests,
+                           (const uint64_t*)((uint8_t*)scratch + o_lo), log_max, off, indices_dev, shift, out_dev);
+        e = hipGetLastError();
+    }
+    pool_release(ctx, scratch);
+    if (e != hipSuccess) return set_error(ctx, LURKHIP_ERR_HIP, "gather_openings failed: %s", hipGetErrorString(e));
+    return LURKHIP_OK;
+}
+
+}  // namespace lurkhip

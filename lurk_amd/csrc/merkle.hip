@@ -157,7 +157,12 @@ int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev) {
         LH_HIP(ctx, hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
         ctx->merkle_params_dev = d;
-        ctx->cleanups.push_back([d]() { (void)hipFree(d); });
+        P16Params* hc = new P16Params(h);
+        ctx->merkle_params_host = hc;
+        ctx->cleanups.push_back([d, hc]() {
+            (void)hipFree(d);
+            delete hc;
+        });
     }
     *out_dev = (const P16Params*)ctx->merkle_params_dev;
     return LURKHIP_OK;
@@ -180,5 +185,6 @@ extern "C" int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds
     h.rounds_p = rounds_p;
     LH_HIP(ctx, hipMemcpyAsync(ctx->merkle_params_dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    *(P16Params*)ctx->merkle_params_host = h;
     return LURKHIP_OK;
 }

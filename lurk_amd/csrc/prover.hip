@@ -1,0 +1,616 @@
+// The shard prover: host orchestration of the device stages and of the Fiat-Shamir transcript.
+//
+// Replaces (third-party, source absent from /root/reference; [UPSTREAM-RECALL] sphinx-core @ 8a39b951 (SP1 v1
+// lineage) over Plonky3 @ a0b92870; parity unpinned):
+//   StarkMachine::setup            -> lurkhip_setup              (commit the preprocessed traces)
+//   LocalProver::commit_shards     -> lurkhip_shard_commit       (sort chips by height, commit main traces)
+//   LocalProver::prove_shard       -> lurkhip_shard_prove        (permutation traces, quotient, openings, FRI)
+// reached from the reference at /root/reference/benches/fib.rs:114-124 and /root/reference/src/core/cli/repl.rs:196.
+//
+// prove_shard, as restated here:
+//   sample 2 permutation challenges; per chip permutation trace; commit; observe; sample alpha;
+//   per chip quotient values on 31 * <w_{N << lqd}>, split into 2^lqd chunks over cosets; commit; observe;
+//   sample zeta; open {preprocessed, main, permutation} at zeta and zeta * w_N, quotient chunks at zeta:
+//     p3 TwoAdicFriPcs::open: alpha_fri = sample; per matrix and point y = p(z) by barycentric evaluation on the
+//     low coset; reduced_openings[log_height] += alpha_fri^k (p(x) - y) / (x - z) column by column;
+//     FRI commit phase (fold by beta per layer, layers committed as width-2 extension matrices), final constant,
+//     proof-of-work grind, query indices, Merkle openings of every round and every layer.
+// The transcript is host state (challenger.h); roots, sums and opened values cross the boundary once each.
+#include <algorithm>
+#include <cstring>
+#include <map>
+#include <numeric>
+
+#include "babybear.h"
+#include "challenger.h"
+#include "commit.h"
+#include "ctx.h"
+#include "fri.h"
+#include "stark.h"
+
+using namespace lurkhip;
+using bb::ef;
+
+struct lurkhip_challenger {
+    Challenger ch;
+};
+
+struct lurkhip_pk {
+    lurkhip_commitment* commit = nullptr;        // preprocessed traces (may be null when no chip has any)
+    std::vector<const uint32_t*> traces;         // natural order, Montgomery, caller-owned
+    std::vector<uint32_t> log_heights, widths;
+    uint32_t root_m[8] = {};
+    int log_blowup = 1;
+};
+
+struct lurkhip_shard {
+    std::vector<lurkhip_air*> airs;              // sorted by height, tallest first (stable)
+    std::vector<int> machine_index;              // position in the caller's chip list
+    std::vector<uint32_t> log_n;
+    std::vector<const uint32_t*> main;           // natural order, Montgomery, caller-owned
+    std::vector<int> prep_index;                 // index into the pk's matrices or -1
+    lurkhip_commitment* main_commit = nullptr;
+    uint32_t root_m[8] = {};
+    int log_blowup = 1;
+};
+
+struct lurkhip_proof {
+    std::vector<uint32_t> words;
+};
+
+namespace {
+
+constexpr uint32_t PROOF_MAGIC = 0x4652504cu;  // "LPRF"
+
+ef ef_pow_host(ef a, uint64_t e) {
+    ef r = bb::ef_one();
+    while (e) {
+        if (e & 1) r = bb::ef_mul(r, a);
+        a = bb::ef_sqr(a);
+        e >>= 1;
+    }
+    return r;
+}
+uint32_t pow_host(uint32_t a_m, uint64_t e) {
+    uint32_t r = bb::R1;
+    while (e) {
+        if (e & 1) r = bb::mul(r, a_m);
+        a_m = bb::mul(a_m, a_m);
+        e >>= 1;
+    }
+    return r;
+}
+
+struct Pooled {  // pooled device block released at scope exit (stream-ordered reuse)
+    lurkhip_ctx* ctx;
+    void* p = nullptr;
+    explicit Pooled(lurkhip_ctx* c) : ctx(c) {}
+    Pooled(const Pooled&) = delete;
+    Pooled& operator=(const Pooled&) = delete;
+    ~Pooled() { pool_release(ctx, p); }
+    int32_t alloc(size_t bytes) { return pool_alloc(ctx, bytes, &p); }
+    uint32_t* u32() const { return (uint32_t*)p; }
+};
+
+void push_ef(std::vector<uint32_t>& out, const ef& e) {
+    for (int i = 0; i < 4; i++) out.push_back(bb::from_monty(e.c[i]));
+}
+
+struct Round {
+    lurkhip_commitment* c;
+    // per matrix (committed order): the opening points (indices into the shard's point table)
+    std::vector<std::vector<int>> points;
+};
+
+}  // namespace
+
+extern "C" {
+
+// ------------------------------------------------------------------ transcript
+int32_t lurkhip_challenger_new(lurkhip_ctx* ctx, lurkhip_challenger** out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, out != nullptr, "null argument");
+    const P16Params* dev = nullptr;
+    LH_TRY(get_merkle_params(ctx, &dev));
+    auto* c = new lurkhip_challenger();
+    c->ch.params = (const P16Params*)ctx->merkle_params_host;
+    *out = c;
+    return LURKHIP_OK;
+}
+int32_t lurkhip_challenger_clone(const lurkhip_challenger* src, lurkhip_challenger** out) {
+    if (!src || !out) return LURKHIP_ERR_INVALID_ARG;
+    *out = new lurkhip_challenger(*src);
+    return LURKHIP_OK;
+}
+int32_t lurkhip_challenger_free(lurkhip_challenger* c) {
+    delete c;
+    return LURKHIP_OK;
+}
+int32_t lurkhip_challenger_observe(lurkhip_challenger* c, const uint32_t* values, uint32_t n) {
+    if (!c || (n && !values)) return LURKHIP_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; i++) c->ch.observe(values[i]);
+    return LURKHIP_OK;
+}
+int32_t lurkhip_challenger_sample(lurkhip_challenger* c, uint32_t* out, uint32_t n) {
+    if (!c || (n && !out)) return LURKHIP_ERR_INVALID_ARG;
+    for (uint32_t i = 0; i < n; i++) out[i] = bb::from_monty(c->ch.sample_m());
+    return LURKHIP_OK;
+}
+int32_t lurkhip_challenger_sample_bits(lurkhip_challenger* c, uint32_t bits, uint32_t* out) {
+    if (!c || !out || bits > 30) return LURKHIP_ERR_INVALID_ARG;
+    *out = c->ch.sample_bits((int)bits);
+    return LURKHIP_OK;
+}
+
+// ------------------------------------------------------------------ setup
+int32_t lurkhip_setup(lurkhip_ctx* ctx, int32_t n_prep, const uint32_t* const* prep_traces_dev, const uint32_t* log_heights,
+                      const uint32_t* widths, int32_t log_blowup, lurkhip_pk** out, uint32_t* root) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, out && n_prep >= 0 && (n_prep == 0 || (prep_traces_dev && log_heights && widths)), "bad setup arguments");
+    auto* pk = new lurkhip_pk();
+    pk->log_blowup = log_blowup;
+    if (n_prep > 0) {
+        // sphinx sorts the preprocessed traces by height, tallest first (stable)
+        std::vector<int> order(n_prep);
+        std::iota(order.begin(), order.end(), 0);
+        std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_heights[a] > log_heights[b]; });
+        for (int i : order) {
+            pk->traces.push_back(prep_traces_dev[i]);
+            pk->log_heights.push_back(log_heights[i]);
+            pk->widths.push_back(widths[i]);
+        }
+        bool identity = true;
+        for (int i = 0; i < n_prep; i++) identity = identity && order[i] == i;
+        if (!identity) {
+            delete pk;
+            return set_error(ctx, LURKHIP_ERR_INVALID_ARG, "pass the preprocessed traces sorted by height, tallest first");
+        }
+        uint32_t canon[8];
+        int32_t s = commit_impl(ctx, n_prep, pk->traces.data(), false, pk->log_heights.data(), pk->widths.data(), log_blowup,
+                                LURKHIP_REPR_MONTY, 0, &pk->commit, canon);
+        if (s != LURKHIP_OK) {
+            delete pk;
+            return s;
+        }
+        memcpy(pk->root_m, canon, sizeof canon);  // repr = MONTY: the root comes back in Montgomery form
+    }
+    if (root)
+        for (int i = 0; i < 8; i++) root[i] = bb::from_monty(pk->root_m[i]);
+    *out = pk;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_pk_free(lurkhip_ctx* ctx, lurkhip_pk* pk) {
+    LH_CHECK_CTX(ctx);
+    if (!pk) return LURKHIP_OK;
+    if (pk->commit) free_commitment(ctx, pk->commit);
+    delete pk;
+    return LURKHIP_OK;
+}
+
+// ------------------------------------------------------------------ main commitment of one shard
+int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* const* airs, const uint32_t* log_heights,
+                             const uint32_t* const* main_traces_dev, const int32_t* prep_indices, int32_t log_blowup,
+                             lurkhip_shard** out, uint32_t* root) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, n_chips > 0 && airs && log_heights && main_traces_dev && out, "bad shard arguments");
+    auto* sh = new lurkhip_shard();
+    sh->log_blowup = log_blowup;
+    std::vector<int> order(n_chips);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_heights[a] > log_heights[b]; });
+    std::vector<uint32_t> widths;
+    for (int i : order) {
+        sh->airs.push_back(airs[i]);
+        sh->machine_index.push_back(i);
+        sh->log_n.push_back(log_heights[i]);
+        sh->main.push_back(main_traces_dev[i]);
+        sh->prep_index.push_back(prep_indices ? prep_indices[i] : -1);
+        widths.push_back(air_of(airs[i]).width);
+    }
+    span_begin(ctx, "commit_main");
+    int32_t s = commit_impl(ctx, n_chips, sh->main.data(), false, sh->log_n.data(), widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
+                            &sh->main_commit, sh->root_m);
+    span_end(ctx, "commit_main");
+    if (s != LURKHIP_OK) {
+        delete sh;
+        return s;
+    }
+    if (root)
+        for (int i = 0; i < 8; i++) root[i] = bb::from_monty(sh->root_m[i]);
+    *out = sh;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* sh) {
+    LH_CHECK_CTX(ctx);
+    if (!sh) return LURKHIP_OK;
+    if (sh->main_commit) free_commitment(ctx, sh->main_commit);
+    delete sh;
+    return LURKHIP_OK;
+}
+
+// ------------------------------------------------------------------ prove_shard
+int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
+                            const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
+                            lurkhip_proof** out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, pk && sh && chal && out && (n_public == 0 || public_values), "null argument");
+    LH_ARG(ctx, num_queries >= 1 && num_queries <= 1024 && pow_bits <= 30, "bad FRI parameters");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    Challenger& ch = chal->ch;
+    const int n_chips = (int)sh->airs.size();
+    const int log_blowup = sh->log_blowup;
+    std::vector<lurkhip_commitment*> to_free;
+    std::vector<void*> pooled;
+    auto cleanup = [&]() {
+        (void)hipStreamSynchronize(ctx->stream);
+        for (auto* c : to_free) free_commitment(ctx, c);
+        for (void* p : pooled) pool_release(ctx, p);
+    };
+    auto palloc = [&](size_t bytes, uint32_t** p) -> int32_t {
+        void* v = nullptr;
+        int32_t s = pool_alloc(ctx, bytes, &v);
+        if (s == LURKHIP_OK) {
+            pooled.push_back(v);
+            *p = (uint32_t*)v;
+        }
+        return s;
+    };
+#define PTRY(expr)                  \
+    do {                            \
+        int32_t s__ = (expr);       \
+        if (s__ != LURKHIP_OK) {    \
+            cleanup();              \
+            return s__;             \
+        }                           \
+    } while (0)
+#define PHIP(expr)                                                                                  \
+    do {                                                                                            \
+        hipError_t e__ = (expr);                                                                    \
+        if (e__ != hipSuccess) {                                                                    \
+            cleanup();                                                                              \
+            return set_error(ctx, LURKHIP_ERR_HIP, "%s failed: %s", #expr, hipGetErrorString(e__)); \
+        }                                                                                           \
+    } while (0)
+
+    // ---- permutation traces
+    const ef perm_alpha = ch.sample_ef_m(), perm_beta = ch.sample_ef_m();
+    std::vector<uint32_t*> perm(n_chips, nullptr);
+    std::vector<ef> cumsum(n_chips);
+    std::vector<uint32_t> perm_widths(n_chips), lqds(n_chips);
+    span_begin(ctx, "permutation");
+    for (int i = 0; i < n_chips; i++) {
+        const lair::ChipAir& air = air_of(sh->airs[i]);
+        perm_widths[i] = 4 * air.permutation_width();
+        lqds[i] = air.log_quotient_degree();
+        if ((int)lqds[i] > log_blowup) {
+            cleanup();
+            return set_error(ctx, LURKHIP_ERR_UNSUPPORTED, "chip %s needs a quotient domain larger than the LDE", air.name.c_str());
+        }
+        const size_t h = (size_t)1 << sh->log_n[i];
+        PTRY(palloc(h * perm_widths[i] * 4, &perm[i]));
+        const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces.at(sh->prep_index[i]) : nullptr;
+        PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr));
+    }
+    // cumulative sums: last element of each trace, one batched read
+    {
+        std::vector<uint32_t> cs(n_chips * 4);
+        for (int i = 0; i < n_chips; i++) {
+            const size_t h = (size_t)1 << sh->log_n[i];
+            PHIP(hipMemcpyAsync(&cs[4 * i], perm[i] + h * perm_widths[i] - 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+        }
+        PHIP(hipStreamSynchronize(ctx->stream));
+        for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs[4 * i], cs[4 * i + 1], cs[4 * i + 2], cs[4 * i + 3]}};
+    }
+    span_end(ctx, "permutation");
+    lurkhip_commitment* perm_commit = nullptr;
+    uint32_t perm_root_m[8];
+    span_begin(ctx, "commit_perm");
+    PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
+                     perm_root_m));
+    span_end(ctx, "commit_perm");
+    to_free.push_back(perm_commit);
+    ch.observe_digest_m(perm_root_m);
+
+    // ---- quotient
+    const ef alpha = ch.sample_ef_m();
+    std::vector<uint32_t*> qmats;
+    std::vector<uint32_t> q_logn, q_widths, q_shifts;
+    std::vector<int> q_chip;  // chip of each quotient chunk
+    span_begin(ctx, "quotient_all");
+    for (int i = 0; i < n_chips; i++) {
+        const size_t h = (size_t)1 << sh->log_n[i];
+        const uint32_t qd = 1u << lqds[i];
+        uint32_t* chunks = nullptr;
+        PTRY(palloc(h * qd * 16, &chunks));
+        const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde.at(sh->prep_index[i]) : nullptr;
+        PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
+                           cumsum[i], public_values, chunks));
+        const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
+        const uint32_t wq_inv = pow_host(wq, bb::P - 2);
+        for (uint32_t c = 0; c < qd; c++) {
+            qmats.push_back(chunks + (size_t)c * h * 4);
+            q_logn.push_back(sh->log_n[i]);
+            q_widths.push_back(4);
+            q_shifts.push_back(bb::from_monty(pow_host(wq_inv, c)));  // generator / (generator * w_Q^c)
+            q_chip.push_back(i);
+        }
+    }
+    span_end(ctx, "quotient_all");
+    lurkhip_commitment* quot_commit = nullptr;
+    uint32_t quot_root_m[8];
+    span_begin(ctx, "commit_quotient");
+    PTRY(commit_impl(ctx, (int32_t)qmats.size(), qmats.data(), false, q_logn.data(), q_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
+                     &quot_commit, quot_root_m, q_shifts.data()));
+    span_end(ctx, "commit_quotient");
+    to_free.push_back(quot_commit);
+    ch.observe_digest_m(quot_root_m);
+
+    // ---- opening points
+    const ef zeta = ch.sample_ef_m();
+    // point table: per trace height, (zeta, zeta * w_N); quotient chunks only use zeta
+    struct Pt {
+        ef z;
+    };
+    std::vector<Pt> pts;
+    std::map<uint32_t, std::pair<int, int>> pts_of_logn;
+    auto points_for = [&](uint32_t log_n) {
+        auto it = pts_of_logn.find(log_n);
+        if (it != pts_of_logn.end()) return it->second;
+        // the zeta entry is shared by every height: index 0
+        if (pts.empty()) pts.push_back(Pt{zeta});
+        pts.push_back(Pt{bb::ef_scale(zeta, two_adic_generator_monty((int)log_n))});
+        auto pr = std::make_pair(0, (int)pts.size() - 1);
+        pts_of_logn.emplace(log_n, pr);
+        return pr;
+    };
+    std::vector<Round> rounds;
+    if (pk->commit) {
+        Round r{pk->commit, {}};
+        for (size_t m = 0; m < pk->traces.size(); m++) {
+            auto pr = points_for(pk->log_heights[m]);
+            r.points.push_back({pr.first, pr.second});
+        }
+        rounds.push_back(r);
+    }
+    for (lurkhip_commitment* c : {sh->main_commit, perm_commit}) {
+        Round r{c, {}};
+        for (int i = 0; i < n_chips; i++) {
+            auto pr = points_for(sh->log_n[i]);
+            r.points.push_back({pr.first, pr.second});
+        }
+        rounds.push_back(r);
+    }
+    {
+        if (pts.empty()) pts.push_back(Pt{zeta});
+        Round r{quot_commit, {}};
+        for (size_t m = 0; m < qmats.size(); m++) r.points.push_back({0});
+        rounds.push_back(r);
+    }
+
+    // ---- p3 TwoAdicFriPcs::open
+    span_begin(ctx, "open");
+    const ef alpha_fri = ch.sample_ef_m();
+    uint32_t max_w = 1;
+    int log_global_max = 0;
+    for (const Round& r : rounds)
+        for (int m = 0; m < r.c->n_mats; m++) {
+            max_w = std::max(max_w, r.c->width[m]);
+            log_global_max = std::max(log_global_max, r.c->log_h[m]);
+        }
+    uint32_t* alpha_pows = nullptr;  // alpha_fri^c for c < max_w
+    PTRY(palloc((size_t)max_w * 16, &alpha_pows));
+    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows, max_w));
+    std::vector<ef> alpha_pows_host(max_w);
+    {
+        ef p = bb::ef_one();
+        for (uint32_t c = 0; c < max_w; c++) {
+            alpha_pows_host[c] = p;
+            p = bb::ef_mul(p, alpha_fri);
+        }
+    }
+    // caches keyed by (log size, point index)
+    std::map<std::pair<int, int>, uint32_t*> bary, denoms;
+    auto get_weights = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt, uint32_t** outp) -> int32_t {
+        auto key = std::make_pair(log_m, pt);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            uint32_t* buf = nullptr;
+            LH_TRY(palloc(((size_t)16) << log_m, &buf));
+            LH_TRY(point_weights(ctx, mode, log_m, pts[pt].z, buf));
+            it = cache.emplace(key, buf).first;
+        }
+        *outp = it->second;
+        return LURKHIP_OK;
+    };
+    uint32_t* ro[32] = {};
+    uint64_t num_reduced[32] = {};
+    uint32_t* dot_out = nullptr;
+    PTRY(palloc((size_t)2 * max_w * 16, &dot_out));
+    std::vector<uint32_t> dot_host((size_t)2 * max_w * 4);
+    const uint32_t g_m = bb::to_monty(bb::GEN);
+    // opened values, per round, per matrix, per point: ys[c] (Montgomery)
+    std::vector<std::vector<std::vector<std::vector<ef>>>> opened(rounds.size());
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        const Round& r = rounds[ri];
+        opened[ri].resize(r.c->n_mats);
+        for (int m = 0; m < r.c->n_mats; m++) {
+            const int log_h = r.c->log_h[m], log_n = log_h - log_blowup;
+            const uint32_t w = r.c->width[m];
+            const size_t n = (size_t)1 << log_n;
+            const std::vector<int>& mp = r.points[m];
+            uint32_t *u0 = nullptr, *u1 = nullptr, *d0 = nullptr, *d1 = nullptr;
+            PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
+            if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
+            PTRY(column_dot(ctx, r.c->lde[m], w, n, u0, u1, dot_out));
+            PHIP(hipMemcpyAsync(dot_host.data(), dot_out, (size_t)2 * w * 16, hipMemcpyDeviceToHost, ctx->stream));
+            PHIP(hipStreamSynchronize(ctx->stream));
+            // y = (z^N - g^N) / (N g^(N-1)) * sum
+            const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
+            const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
+            ef reduced_ys[2] = {bb::ef_zero(), bb::ef_zero()};
+            opened[ri][m].resize(mp.size());
+            for (size_t p = 0; p < mp.size(); p++) {
+                ef zn = ef_pow_host(pts[mp[p]].z, n);
+                zn.c[0] = bb::sub(zn.c[0], gn);
+                const ef factor = bb::ef_scale(zn, denom_inv);
+                std::vector<ef>& ys = opened[ri][m][p];
+                ys.resize(w);
+                for (uint32_t c = 0; c < w; c++) {
+                    const uint32_t* sp = &dot_host[((size_t)p * w + c) * 4];
+                    ys[c] = bb::ef_mul(factor, ef{{sp[0], sp[1], sp[2], sp[3]}});
+                    reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
+                }
+            }
+            if (!ro[log_h]) {
+                PTRY(palloc(((size_t)16) << log_h, &ro[log_h]));
+                PHIP(hipMemsetAsync(ro[log_h], 0, ((size_t)16) << log_h, ctx->stream));
+            }
+            PTRY(get_weights(denoms, 1, log_h, mp[0], &d0));
+            if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
+            const ef apow0 = ef_pow_host(alpha_fri, num_reduced[log_h]);
+            const ef apow1 = ef_pow_host(alpha_fri, num_reduced[log_h] + w);
+            PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
+            num_reduced[log_h] += (uint64_t)mp.size() * w;
+        }
+    }
+    span_end(ctx, "open");
+
+    // ---- FRI commit phase
+    span_begin(ctx, "fri_commit");
+    const int log_max = log_global_max;
+    std::vector<lurkhip_commitment*> layers;
+    std::vector<uint32_t> layer_roots_m;
+    uint32_t* current = ro[log_max];
+    for (int log_folded = log_max - 1; log_folded >= log_blowup; log_folded--) {
+        lurkhip_commitment* lc = nullptr;
+        PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
+        to_free.push_back(lc);
+        layers.push_back(lc);
+        uint32_t root_m[8];
+        PTRY(commitment_root_m(ctx, lc, root_m));
+        layer_roots_m.insert(layer_roots_m.end(), root_m, root_m + 8);
+        ch.observe_digest_m(root_m);
+        const ef beta = ch.sample_ef_m();
+        uint32_t* next = nullptr;
+        PTRY(palloc(((size_t)16) << log_folded, &next));
+        PTRY(fri_fold(ctx, current, log_folded + 1, beta, ro[log_folded], next));
+        current = next;
+    }
+    std::vector<uint32_t> fin((size_t)4 << log_blowup);
+    PHIP(hipMemcpyAsync(fin.data(), current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHIP(hipStreamSynchronize(ctx->stream));
+    for (size_t i = 4; i < fin.size(); i++)
+        if (fin[i] != fin[i & 3]) {
+            cleanup();
+            return set_error(ctx, LURKHIP_ERR_EXEC, "internal error: the FRI commit phase did not end on a constant");
+        }
+    const ef final_poly{{fin[0], fin[1], fin[2], fin[3]}};
+    ch.observe_ef_m(final_poly);
+    span_end(ctx, "fri_commit");
+
+    // ---- proof of work, query indices
+    span_begin(ctx, "fri_query");
+    uint32_t pow_witness = 0;
+    if (pow_bits > 0) {
+        uint32_t st[16];
+        memcpy(st, ch.state, sizeof st);
+        for (size_t i = 0; i < ch.input.size(); i++) st[i] = ch.input[i];
+        PTRY(pow_grind(ctx, st, (int)ch.input.size(), (int)pow_bits, &pow_witness));
+    }
+    if (!ch.check_witness((int)pow_bits, pow_witness)) {
+        cleanup();
+        return set_error(ctx, LURKHIP_ERR_EXEC, "proof-of-work witness rejected by the host transcript");
+    }
+    std::vector<uint32_t> indices(num_queries);
+    for (auto& ix : indices) ix = ch.sample_bits(log_max);
+    uint32_t* indices_dev = nullptr;
+    PTRY(palloc((size_t)num_queries * 4, &indices_dev));
+    PHIP(hipMemcpyAsync(indices_dev, indices.data(), (size_t)num_queries * 4, hipMemcpyHostToDevice, ctx->stream));
+    PHIP(hipStreamSynchronize(ctx->stream));
+    // input rounds
+    std::vector<std::vector<uint32_t>> round_records(rounds.size());
+    std::vector<uint32_t> round_record_words(rounds.size());
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        const lurkhip_commitment* c = rounds[ri].c;
+        std::vector<OpenMat> om;
+        for (int m = 0; m < c->n_mats; m++) om.push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m]});
+        uint32_t rw = 0;
+        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &rw));
+        uint32_t* buf = nullptr;
+        PTRY(palloc((size_t)num_queries * rw * 4, &buf));
+        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)(log_max - c->log_max), buf, &rw));
+        round_records[ri].resize((size_t)num_queries * rw);
+        round_record_words[ri] = rw;
+        PHIP(hipMemcpyAsync(round_records[ri].data(), buf, round_records[ri].size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    std::vector<std::vector<uint32_t>> layer_records(layers.size());
+    std::vector<uint32_t> layer_record_words(layers.size());
+    for (size_t li = 0; li < layers.size(); li++) {
+        const lurkhip_commitment* c = layers[li];
+        std::vector<OpenMat> om{OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}};
+        uint32_t rw = 0;
+        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &rw));
+        uint32_t* buf = nullptr;
+        PTRY(palloc((size_t)num_queries * rw * 4, &buf));
+        // index_i = index >> li, pair = index_i >> 1
+        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)li + 1, buf, &rw));
+        layer_records[li].resize((size_t)num_queries * rw);
+        layer_record_words[li] = rw;
+        PHIP(hipMemcpyAsync(layer_records[li].data(), buf, layer_records[li].size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PHIP(hipStreamSynchronize(ctx->stream));
+    span_end(ctx, "fri_query");
+
+    // ---- serialise (canonical values); layout documented in lurk_amd/prover.py
+    auto* proof = new lurkhip_proof();
+    std::vector<uint32_t>& o = proof->words;
+    o.insert(o.end(), {PROOF_MAGIC, (uint32_t)n_chips, (uint32_t)log_blowup, num_queries, pow_bits, n_public, (uint32_t)layers.size(),
+                       (uint32_t)log_max, (uint32_t)(pk->commit ? pk->traces.size() : 0), (uint32_t)qmats.size()});
+    for (int i = 0; i < n_chips; i++) {
+        const lair::ChipAir& air = air_of(sh->airs[i]);
+        o.insert(o.end(), {(uint32_t)sh->machine_index[i], sh->log_n[i], air.width, air.prep_width, perm_widths[i], 1u << lqds[i],
+                           (uint32_t)(sh->prep_index[i] + 1)});
+        push_ef(o, cumsum[i]);
+    }
+    for (uint32_t i = 0; i < n_public; i++) o.push_back(public_values[i] % bb::P);
+    for (int i = 0; i < 8; i++) o.push_back(bb::from_monty(sh->root_m[i]));
+    for (int i = 0; i < 8; i++) o.push_back(bb::from_monty(perm_root_m[i]));
+    for (int i = 0; i < 8; i++) o.push_back(bb::from_monty(quot_root_m[i]));
+    // opened values: round by round, matrix by matrix, point by point, column by column
+    for (size_t ri = 0; ri < rounds.size(); ri++)
+        for (auto& mat : opened[ri])
+            for (auto& ys : mat)
+                for (const ef& y : ys) push_ef(o, y);
+    for (uint32_t v : layer_roots_m) o.push_back(bb::from_monty(v));
+    push_ef(o, final_poly);
+    o.push_back(pow_witness);
+    for (uint32_t ix : indices) o.push_back(ix);
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        o.push_back(round_record_words[ri]);
+        for (uint32_t v : round_records[ri]) o.push_back(bb::from_monty(v));
+    }
+    for (size_t li = 0; li < layers.size(); li++) {
+        o.push_back(layer_record_words[li]);
+        for (uint32_t v : layer_records[li]) o.push_back(bb::from_monty(v));
+    }
+    cleanup();
+#undef PTRY
+#undef PHIP
+    *out = proof;
+    return LURKHIP_OK;
+}
+
+int64_t lurkhip_proof_words(const lurkhip_proof* p) { return p ? (int64_t)p->words.size() : -1; }
+int32_t lurkhip_proof_read(const lurkhip_proof* p, uint32_t* out) {
+    if (!p || !out) return LURKHIP_ERR_INVALID_ARG;
+    memcpy(out, p->words.data(), p->words.size() * 4);
+    return LURKHIP_OK;
+}
+int32_t lurkhip_proof_free(lurkhip_proof* p) {
+    delete p;
+    return LURKHIP_OK;
+}
+
+}  // extern "C"

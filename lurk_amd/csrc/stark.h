@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include "babybear.h"
 #include "ctx.h"
 #include "lair/air.h"
 
@@ -18,6 +19,13 @@ int vm_block(uint32_t n_regs, size_t* lds_bytes);
 int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count);
 // in-place inclusive scan of the EF elements data[r * stride_words .. +4], r < n
 int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, size_t n);
+
+// Montgomery-form entry points shared by the C ABI wrappers and the shard prover
+int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
+                               const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m);
+int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
+                      const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
+                      const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev);
 
 }  // namespace lurkhip
 

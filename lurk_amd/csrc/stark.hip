@@ -434,6 +434,117 @@ int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, si
     return LURKHIP_OK;
 }
 
+
+int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
+                               const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m) {
+    LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
+    LH_ARG(ctx, height > 0, "empty trace");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t* ip = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, nullptr, &ip));
+    const uint32_t perm_w = a->air.permutation_width(), batch = 1u << a->air.log_quotient_degree();
+    void* pows = nullptr;
+    const uint32_t n_pows = a->max_tuple + 2;
+    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 16, &pows));
+    span_begin(ctx, "perm_rows");
+    int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows);
+    if (s == LURKHIP_OK) {
+        size_t lds = 0;
+        int block = vm_block(a->prog.interactions[airp::H_N_REGS], &lds);
+        hipLaunchKernelGGL(k_perm_rows, dim3((height + block - 1) / block), dim3(block), lds, ctx->stream, ip, main_dev,
+                           prep_dev ? prep_dev : main_dev, (const uint32_t*)nullptr, (const uint32_t*)pows, alpha, height,
+                           a->air.width, a->air.prep_width, perm_w, batch, out_dev);
+        if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
+    }
+    span_end(ctx, "perm_rows");
+    span_begin(ctx, "perm_scan");
+    if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)perm_w * 4, height);
+    span_end(ctx, "perm_scan");
+    pool_release(ctx, pows);
+    if (s == LURKHIP_OK && cumulative_sum_m) {
+        LH_HIP(ctx, hipMemcpyAsync(cumulative_sum_m->c, out_dev + ((size_t)height * perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    }
+    return s;
+}
+
+int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
+                      const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
+                      const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev) {
+    LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
+    LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
+    const uint32_t lqd = a->air.log_quotient_degree();
+    LH_ARG(ctx, lqd <= 2 && log_n + lqd <= (uint32_t)bb::TWO_ADICITY, "unsupported quotient degree / height");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    const uint32_t *cp = nullptr, *ip = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, &cp, &ip));
+    const uint32_t perm_w = a->air.permutation_width(), batch = 1u << lqd;
+    const uint32_t n_batches = perm_w - 1;
+    const uint32_t k_total = (uint32_t)a->air.constraints.size() + n_batches + 3;
+    const uint32_t np = a->air.num_public;
+    const uint32_t *pa = perm_alpha.c, *pb = perm_beta.c, *al = alpha_m.c, *cs = cumsum_m.c;
+    const uint32_t n_bp = a->max_tuple + 2;
+    void* scratch = nullptr;  // alpha powers | beta powers | public values
+    const size_t o_bp = (size_t)k_total * 16, o_pub = o_bp + (size_t)n_bp * 16, total = o_pub + std::max<size_t>(np, 1) * 4;
+    LH_TRY(pool_alloc(ctx, total, &scratch));
+    uint8_t* d = (uint8_t*)scratch;
+    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total);
+    if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp);
+    std::vector<uint32_t> pubm(np);
+    if (s == LURKHIP_OK && np) {
+        for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
+        hipError_t e = hipMemcpyAsync(d + o_pub, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "public values upload failed: %s", hipGetErrorString(e));
+    }
+    if (s == LURKHIP_OK) {
+        QuotientArgs q{};
+        q.cons_prog = cp;
+        q.inter_prog = ip;
+        q.main = main_lde_dev;
+        q.prep = prep_lde_dev ? prep_lde_dev : main_lde_dev;
+        q.perm = perm_lde_dev;
+        q.pub = (const uint32_t*)(d + o_pub);
+        q.alpha_pows = (const uint32_t*)d;
+        q.beta_pows = (const uint32_t*)(d + o_bp);
+        q.perm_alpha = bb::ef{{pa[0], pa[1], pa[2], pa[3]}};
+        q.cumulative_sum = bb::ef{{cs[0], cs[1], cs[2], cs[3]}};
+        q.log_n = log_n;
+        q.log_q = log_n + lqd;
+        q.w = a->air.width;
+        q.pw = a->air.prep_width;
+        q.perm_w = perm_w;
+        q.batch = batch;
+        q.k_total = k_total;
+        q.g_m = bb::to_monty(bb::GEN);
+        q.wq_m = two_adic_generator_monty((int)q.log_q);
+        const uint32_t wn = two_adic_generator_monty((int)log_n);
+        q.wn_inv_m = bb::pow(wn, bb::P - 2);
+        // Z_H(x) = x^N - 1 on the coset: g^N * (w_Q^N)^i - 1, i mod 2^lqd
+        uint32_t gn = q.g_m;
+        for (uint32_t i = 0; i < log_n; i++) gn = bb::mul(gn, gn);
+        const uint32_t w_qd = two_adic_generator_monty((int)lqd);
+        uint32_t cur = bb::R1;
+        for (uint32_t c = 0; c < (1u << lqd); c++) {
+            q.zh[c] = bb::sub(bb::mul(gn, cur), bb::R1);
+            q.zh_inv[c] = bb::pow(q.zh[c], bb::P - 2);
+            cur = bb::mul(cur, w_qd);
+        }
+        q.out = out_dev;
+        const uint32_t n_regs = std::max(a->prog.constraints[airp::H_N_REGS], a->prog.interactions[airp::H_N_REGS]);
+        size_t lds = 0;
+        int block = vm_block(n_regs, &lds);
+        const uint32_t rows = 1u << q.log_q;
+        span_begin(ctx, "quotient");
+        hipLaunchKernelGGL(k_quotient, dim3((rows + block - 1) / block), dim3(block), lds, ctx->stream, q);
+        span_end(ctx, "quotient");
+        if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
+    }
+    pool_release(ctx, scratch);
+    return s;
+}
+
+
 }  // namespace lurkhip
 
 using namespace lurkhip;
@@ -630,43 +741,15 @@ int32_t lurkhip_permutation_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t
                                       uint32_t* cumulative_sum) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, a && main_dev && challenges && out_dev, "null argument");
-    LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
-    LH_ARG(ctx, height > 0, "empty trace");
-    LH_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t* ip = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, nullptr, &ip));
-    const uint32_t perm_w = a->air.permutation_width(), batch = 1u << a->air.log_quotient_degree();
-    uint32_t alpha_m[4], beta_m[4];
+    bb::ef alpha, beta, cs;
     for (int i = 0; i < 4; i++) {
-        alpha_m[i] = bb::to_monty(challenges[i] % bb::P);
-        beta_m[i] = bb::to_monty(challenges[4 + i] % bb::P);
+        alpha.c[i] = bb::to_monty(challenges[i] % bb::P);
+        beta.c[i] = bb::to_monty(challenges[4 + i] % bb::P);
     }
-    void* pows = nullptr;
-    const uint32_t n_pows = a->max_tuple + 2;
-    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 16, &pows));
-    span_begin(ctx, "perm_rows");
-    int32_t s = ef_powers(ctx, beta_m, (uint32_t*)pows, n_pows);
-    if (s == LURKHIP_OK) {
-        size_t lds = 0;
-        int block = vm_block(a->prog.interactions[airp::H_N_REGS], &lds);
-        bb::ef alpha{{alpha_m[0], alpha_m[1], alpha_m[2], alpha_m[3]}};
-        hipLaunchKernelGGL(k_perm_rows, dim3((height + block - 1) / block), dim3(block), lds, ctx->stream, ip, main_dev,
-                           prep_dev ? prep_dev : main_dev, (const uint32_t*)nullptr, (const uint32_t*)pows, alpha, height,
-                           a->air.width, a->air.prep_width, perm_w, batch, out_dev);
-        if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
-    }
-    span_end(ctx, "perm_rows");
-    span_begin(ctx, "perm_scan");
-    if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)perm_w * 4, height);
-    span_end(ctx, "perm_scan");
-    pool_release(ctx, pows);
-    if (s == LURKHIP_OK && cumulative_sum) {
-        uint32_t r[4];
-        LH_HIP(ctx, hipMemcpyAsync(r, out_dev + ((size_t)height * perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (int i = 0; i < 4; i++) cumulative_sum[i] = bb::from_monty(r[i]);
-    }
-    return s;
+    LH_TRY(permutation_trace_impl(ctx, a, height, main_dev, prep_dev, alpha, beta, out_dev, cumulative_sum ? &cs : nullptr));
+    if (cumulative_sum)
+        for (int i = 0; i < 4; i++) cumulative_sum[i] = bb::from_monty(cs.c[i]);
+    return LURKHIP_OK;
 }
 
 int32_t lurkhip_quotient_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev,
@@ -675,84 +758,14 @@ int32_t lurkhip_quotient_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, c
                              uint32_t* out_dev) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, a && main_lde_dev && perm_lde_dev && perm_challenges && alpha && cumulative_sum && out_dev, "null argument");
-    LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
-    LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
-    const uint32_t lqd = a->air.log_quotient_degree();
-    LH_ARG(ctx, lqd <= 2 && log_n + lqd <= (uint32_t)bb::TWO_ADICITY, "unsupported quotient degree / height");
-    LH_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t *cp = nullptr, *ip = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, &cp, &ip));
-    const uint32_t perm_w = a->air.permutation_width(), batch = 1u << lqd;
-    const uint32_t n_batches = perm_w - 1;
-    const uint32_t k_total = (uint32_t)a->air.constraints.size() + n_batches + 3;
-    const uint32_t np = a->air.num_public;
-    auto tm = [](const uint32_t* v, uint32_t* o) {
-        for (int i = 0; i < 4; i++) o[i] = bb::to_monty(v[i] % bb::P);
-    };
-    uint32_t pa[4], pb[4], al[4], cs[4];
-    tm(perm_challenges, pa);
-    tm(perm_challenges + 4, pb);
-    tm(alpha, al);
-    tm(cumulative_sum, cs);
-    const uint32_t n_bp = a->max_tuple + 2;
-    void* scratch = nullptr;  // alpha powers | beta powers | public values
-    const size_t o_bp = (size_t)k_total * 16, o_pub = o_bp + (size_t)n_bp * 16, total = o_pub + std::max<size_t>(np, 1) * 4;
-    LH_TRY(pool_alloc(ctx, total, &scratch));
-    uint8_t* d = (uint8_t*)scratch;
-    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total);
-    if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp);
-    std::vector<uint32_t> pubm(np);
-    if (s == LURKHIP_OK && np) {
-        for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
-        hipError_t e = hipMemcpyAsync(d + o_pub, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
-        if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "public values upload failed: %s", hipGetErrorString(e));
+    bb::ef pa, pb, al, cs;
+    for (int i = 0; i < 4; i++) {
+        pa.c[i] = bb::to_monty(perm_challenges[i] % bb::P);
+        pb.c[i] = bb::to_monty(perm_challenges[4 + i] % bb::P);
+        al.c[i] = bb::to_monty(alpha[i] % bb::P);
+        cs.c[i] = bb::to_monty(cumulative_sum[i] % bb::P);
     }
-    if (s == LURKHIP_OK) {
-        QuotientArgs q{};
-        q.cons_prog = cp;
-        q.inter_prog = ip;
-        q.main = main_lde_dev;
-        q.prep = prep_lde_dev ? prep_lde_dev : main_lde_dev;
-        q.perm = perm_lde_dev;
-        q.pub = (const uint32_t*)(d + o_pub);
-        q.alpha_pows = (const uint32_t*)d;
-        q.beta_pows = (const uint32_t*)(d + o_bp);
-        q.perm_alpha = bb::ef{{pa[0], pa[1], pa[2], pa[3]}};
-        q.cumulative_sum = bb::ef{{cs[0], cs[1], cs[2], cs[3]}};
-        q.log_n = log_n;
-        q.log_q = log_n + lqd;
-        q.w = a->air.width;
-        q.pw = a->air.prep_width;
-        q.perm_w = perm_w;
-        q.batch = batch;
-        q.k_total = k_total;
-        q.g_m = bb::to_monty(bb::GEN);
-        q.wq_m = two_adic_generator_monty((int)q.log_q);
-        const uint32_t wn = two_adic_generator_monty((int)log_n);
-        q.wn_inv_m = bb::pow(wn, bb::P - 2);
-        // Z_H(x) = x^N - 1 on the coset: g^N * (w_Q^N)^i - 1, i mod 2^lqd
-        uint32_t gn = q.g_m;
-        for (uint32_t i = 0; i < log_n; i++) gn = bb::mul(gn, gn);
-        const uint32_t w_qd = two_adic_generator_monty((int)lqd);
-        uint32_t cur = bb::R1;
-        for (uint32_t c = 0; c < (1u << lqd); c++) {
-            q.zh[c] = bb::sub(bb::mul(gn, cur), bb::R1);
-            q.zh_inv[c] = bb::pow(q.zh[c], bb::P - 2);
-            cur = bb::mul(cur, w_qd);
-        }
-        q.out = out_dev;
-        const uint32_t n_regs = std::max(a->prog.constraints[airp::H_N_REGS], a->prog.interactions[airp::H_N_REGS]);
-        size_t lds = 0;
-        int block = vm_block(n_regs, &lds);
-        const uint32_t rows = 1u << q.log_q;
-        span_begin(ctx, "quotient");
-        hipLaunchKernelGGL(k_quotient, dim3((rows + block - 1) / block), dim3(block), lds, ctx->stream, q);
-        span_end(ctx, "quotient");
-        if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
-    }
-    pool_release(ctx, scratch);
-    return s;
+    return quotient_impl(ctx, a, log_n, main_lde_dev, prep_lde_dev, perm_lde_dev, pa, pb, al, cs, public_values, out_dev);
 }
 
 }  // extern "C"

@@ -1,0 +1,287 @@
+"""Host-side mirror of the reference's machine / prover objects over the lurkhip C ABI.
+
+`Machine` plays `StarkMachine<BabyBearPoseidon2, LairChip>` as the reference builds it
+(`new_machine`, /root/reference/src/core/stark_machine.rs:16-30; chip vector = Entrypoint + Func chips + 6 Mem chips
++ Bytes, /root/reference/src/lair/lair_chip.rs:196-211), `setup` / `prove` are `machine.setup` / `machine.prove::<P>`
+(/root/reference/benches/fib.rs:114-124).  Everything numeric happens behind the C ABI; this file only wires handles
+and parses the flat proof.
+
+Proof word layout (canonical values), written by lurk_amd/csrc/prover.hip:
+  header[10]: magic "LPRF", n_chips, log_blowup, num_queries, pow_bits, n_public, n_fri_layers, log_max_height,
+              n_preprocessed, n_quotient_chunks
+  per chip (prover order = height-sorted): machine index, log_n, width, prep width, permutation width (base columns),
+              quotient degree, prep index + 1, cumulative_sum[4]
+  public values[n_public]
+  roots: main[8], permutation[8], quotient[8]
+  opened values, round by round (preprocessed if any, main, permutation, quotient), matrix by matrix, point by point
+              (zeta, then zeta * w_N; quotient chunks: zeta only), one extension element (4 words) per base column
+  fri: commit-phase roots[n_layers][8], final_poly[4], pow_witness, query indices[num_queries]
+  per round: record_words, then num_queries records [rows of every matrix | log_max(round) sibling digests]
+  per fri layer: record_words, then num_queries records [8 words = the opened pair | sibling digests]
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field as dfield
+
+import numpy as np
+
+from . import _native as N
+from . import field
+from .air import ChipAir
+from .context import Context, _addr, as_u32
+from .lair import MEM_TABLE_SIZES, BytesChip, FuncChip, MemChip, QueryRecord, Shard, ShardingConfig, Toplevel, entrypoint_trace
+
+PROOF_MAGIC = 0x4652504C
+LOG_BLOWUP = 1          # sphinx BabyBearPoseidon2 [UPSTREAM-RECALL]
+NUM_QUERIES = 100       # env FRI_QUERIES upstream
+POW_BITS = 16
+
+
+class Challenger:
+    def __init__(self, ctx: Context, handle=None):
+        self.ctx = ctx
+        if handle is None:
+            handle = C.c_void_p()
+            ctx.check(N.lib.lurkhip_challenger_new(ctx.handle, C.byref(handle)))
+        self.handle = handle
+
+    def clone(self) -> "Challenger":
+        h = C.c_void_p()
+        N.check(N.lib.lurkhip_challenger_clone(self.handle, C.byref(h)))
+        return Challenger(self.ctx, h)
+
+    def observe(self, values):
+        v = as_u32(values).reshape(-1)
+        N.check(N.lib.lurkhip_challenger_observe(self.handle, _addr(v), len(v)))
+
+    def sample(self, n: int = 1):
+        out = np.zeros(n, dtype=np.uint32)
+        N.check(N.lib.lurkhip_challenger_sample(self.handle, _addr(out), n))
+        return [int(x) for x in out]
+
+    def sample_ext(self):
+        return tuple(self.sample(4))
+
+    def __del__(self):
+        if getattr(self, "handle", None) and N is not None:
+            N.lib.lurkhip_challenger_free(self.handle)
+            self.handle = None
+
+
+@dataclass
+class ChipProof:
+    machine_index: int
+    log_n: int
+    width: int
+    prep_width: int
+    perm_width: int  # base columns
+    quotient_degree: int
+    prep_index: int  # -1: none
+    cumulative_sum: tuple
+    opened: dict = dfield(default_factory=dict)  # "prep" / "main" / "perm": (local, next) lists of EF tuples; "quotient": [chunk][4]
+
+
+@dataclass
+class ShardProof:
+    log_blowup: int
+    num_queries: int
+    pow_bits: int
+    log_max_height: int
+    chips: list
+    public_values: list
+    main_root: list
+    perm_root: list
+    quot_root: list
+    fri_roots: list
+    final_poly: tuple
+    pow_witness: int
+    query_indices: list
+    round_openings: list  # per round: (record_words, [records])
+    layer_openings: list
+    n_preprocessed: int
+    words: np.ndarray = None
+
+
+def parse_proof(words: np.ndarray) -> ShardProof:
+    w = [int(x) for x in words]
+    pos = [0]
+
+    def take(n):
+        out = w[pos[0]:pos[0] + n]
+        assert len(out) == n, "truncated proof"
+        pos[0] += n
+        return out
+
+    def take_ef(n):
+        flat = take(4 * n)
+        return [tuple(flat[4 * i:4 * i + 4]) for i in range(n)]
+
+    magic, n_chips, log_blowup, nq, pow_bits, n_public, n_layers, log_max, n_prep, n_chunks = take(10)
+    assert magic == PROOF_MAGIC
+    chips = []
+    for _ in range(n_chips):
+        mi, log_n, width, pw, permw, qd, pidx = take(7)
+        chips.append(ChipProof(mi, log_n, width, pw, permw, qd, pidx - 1, tuple(take(4))))
+    public = take(n_public)
+    main_root, perm_root, quot_root = take(8), take(8), take(8)
+    if n_prep:
+        # preprocessed round: matrices in key order; map back to chips through prep_index
+        by_idx = {c.prep_index: c for c in chips if c.prep_index >= 0}
+        for m in range(n_prep):
+            c = by_idx[m]
+            c.opened["prep"] = (take_ef(c.prep_width), take_ef(c.prep_width))
+    for c in chips:
+        c.opened["main"] = (take_ef(c.width), take_ef(c.width))
+    for c in chips:
+        c.opened["perm"] = (take_ef(c.perm_width), take_ef(c.perm_width))
+    for c in chips:
+        c.opened["quotient"] = [take_ef(4) for _ in range(c.quotient_degree)]
+    assert sum(c.quotient_degree for c in chips) == n_chunks
+    fri_roots = [take(8) for _ in range(n_layers)]
+    final_poly = tuple(take(4))
+    pow_witness = take(1)[0]
+    indices = take(nq)
+    n_rounds = 3 + (1 if n_prep else 0)
+    rounds = []
+    for _ in range(n_rounds):
+        rw = take(1)[0]
+        rounds.append((rw, [take(rw) for _ in range(nq)]))
+    layers = []
+    for _ in range(n_layers):
+        rw = take(1)[0]
+        layers.append((rw, [take(rw) for _ in range(nq)]))
+    assert pos[0] == len(w), "trailing words in proof"
+    return ShardProof(log_blowup, nq, pow_bits, log_max, chips, public, main_root, perm_root, quot_root, fri_roots, final_poly,
+                      pow_witness, indices, rounds, layers, n_prep, words)
+
+
+class Machine:
+    """Chip vector of one Lair toplevel with `entry` as its entrypoint (lair_chip.rs:196-211)."""
+
+    def __init__(self, ctx: Context, toplevel: Toplevel, entry: str, num_public_values: int):
+        self.ctx, self.toplevel = ctx, toplevel
+        self.entry_idx = toplevel.func_index(entry)
+        self.num_public_values = num_public_values
+        self.chips = [("entrypoint", None, ChipAir.for_entrypoint(self.entry_idx, num_public_values))]
+        for i in range(toplevel.num_funcs()):
+            self.chips.append(("func", i, ChipAir.for_func(toplevel, i)))
+        for ml in MEM_TABLE_SIZES:
+            self.chips.append(("mem", ml, ChipAir.for_mem(ml)))
+        self.chips.append(("bytes", None, ChipAir.for_bytes()))
+        self.pk = None
+        self._prep = None
+
+    # machine.setup(&LairMachineProgram): only the byte chip has a preprocessed trace
+    def setup(self):
+        import torch
+
+        prep = BytesChip(self.ctx).generate_preprocessed_trace(repr=N.REPR_MONTY)
+        self._prep = torch.from_numpy(prep.view(np.int32)).cuda()
+        ptrs = (C.c_void_p * 1)(self._prep.data_ptr())
+        lh = np.array([16], dtype=np.uint32)
+        ws = np.array([6], dtype=np.uint32)
+        h = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_setup(self.ctx.handle, 1, C.cast(ptrs, C.c_void_p), _addr(lh), _addr(ws), LOG_BLOWUP, C.byref(h), _addr(root)))
+        self.pk = h
+        self.vk_root = [int(x) for x in root]
+        return self.vk_root
+
+    def close(self):
+        if self.pk:
+            N.lib.lurkhip_pk_free(self.ctx.handle, self.pk)
+            self.pk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def shard_traces(self, shard: Shard):
+        """[(machine index, air, log_height, device trace (Montgomery))] of the chips included in the shard
+        (LairChip::included, lair_chip.rs:124-139)."""
+        import torch
+
+        out = []
+        for mi, (kind, arg, air) in enumerate(self.chips):
+            if kind == "entrypoint":
+                if shard.index != 0:
+                    continue
+                t = torch.from_numpy(field.to_monty(entrypoint_trace(shard.queries)).view(np.int32)).cuda()
+            elif kind == "func":
+                chip = FuncChip(self.ctx, arg, self.toplevel)
+                n, h, w = chip.trace_shape(shard)
+                if n == 0:
+                    continue
+                t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+                chip.generate_trace_dev(shard, t, repr=N.REPR_MONTY)
+            elif kind == "mem":
+                if shard.index != 0:
+                    continue
+                t = torch.from_numpy(MemChip(self.ctx, arg).generate_trace(shard, repr=N.REPR_MONTY).view(np.int32)).cuda()
+            else:
+                t = torch.from_numpy(BytesChip(self.ctx).generate_trace(shard, repr=N.REPR_MONTY).view(np.int32)).cuda()
+            out.append((mi, air, t.shape[0].bit_length() - 1, t))
+        self.ctx.sync()
+        return out
+
+    def commit_shard(self, traces):
+        n = len(traces)
+        airs = (C.c_void_p * n)(*[a.handle.value for _, a, _, _ in traces])
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, _, _, t in traces])
+        lh = np.array([lg for _, _, lg, _ in traces], dtype=np.uint32)
+        prep_idx = np.array([0 if self.chips[mi][0] == "bytes" else -1 for mi, _, _, _ in traces], dtype=np.int32)
+        h = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_shard_commit(self.ctx.handle, n, C.cast(airs, C.c_void_p), _addr(lh), C.cast(ptrs, C.c_void_p), _addr(prep_idx),
+                                                  LOG_BLOWUP, C.byref(h), _addr(root)))
+        self._included = getattr(self, "_included", {})
+        self._included[h.value] = [mi for mi, _, _, _ in traces]
+        return h, [int(x) for x in root]
+
+    def prove_shard(self, shard_handle, challenger: Challenger, public_values, num_queries=NUM_QUERIES, pow_bits=POW_BITS) -> ShardProof:
+        pv = as_u32(public_values)
+        p = C.c_void_p()
+        self.ctx.check(N.lib.lurkhip_shard_prove(self.ctx.handle, self.pk, shard_handle, challenger.handle, _addr(pv), len(pv), num_queries, pow_bits,
+                                                 C.byref(p)))
+        n = int(N.lib.lurkhip_proof_words(p))
+        words = np.zeros(n, dtype=np.uint32)
+        N.check(N.lib.lurkhip_proof_read(p, _addr(words)))
+        N.lib.lurkhip_proof_free(p)
+        proof = parse_proof(words)
+        # the C ABI numbers chips by their position in the shard's chip list: map back to the machine's chip vector
+        included = self._included[shard_handle.value]
+        for c in proof.chips:
+            c.machine_index = included[c.machine_index]
+        return proof
+
+    def free_shard(self, shard_handle):
+        self._included.pop(shard_handle.value, None)
+        N.lib.lurkhip_shard_free(self.ctx.handle, shard_handle)
+
+    def prove(self, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS):
+        """machine.prove: commit every shard's main traces, observe (preprocessed root, pc_start = 0, then per shard
+        the main root and the public values), prove every shard with a clone of that transcript
+        [UPSTREAM-RECALL: sphinx LocalProver::prove_shards]."""
+        if self.pk is None:
+            self.setup()
+        full = Shard.new(queries)
+        shards = full.shard(config) if config is not None else [full]
+        pv = queries.expect_public_values()
+        ch = Challenger(self.ctx)
+        ch.observe(self.vk_root)
+        ch.observe([0])
+        committed = []
+        for sh in shards:
+            traces = self.shard_traces(sh)
+            handle, root = self.commit_shard(traces)
+            committed.append((handle, traces))
+            ch.observe(root)
+            ch.observe(pv)
+        proofs = []
+        for handle, traces in committed:
+            proofs.append(self.prove_shard(handle, ch.clone(), pv, num_queries, pow_bits))
+            self.free_shard(handle)
+        return proofs

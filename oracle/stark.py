@@ -269,3 +269,298 @@ def quotient_chunks(air, log_n, main_lde, prep_lde, perm_lde, perm_alpha, perm_b
         folded = fold_constraints(b, perm_lde[i], perm_lde[nx], perm_alpha, perm_beta, qd, alpha, cumulative_sum, (is_first, is_last, is_trans))
         vals.append(ef_scale(folded, inv_zh))
     return [[vals[r * qd + c] for r in range(1 << log_n)] for c in range(qd)]
+
+
+# ------------------------------------------------------------------ extension values with operators (verifier-side AIR evaluation)
+class EFv:
+    """Extension-field value with int-compatible operators so that oracle/air.py's numeric walk can run at an
+    out-of-domain extension point (what sphinx's VerifierConstraintFolder does)."""
+
+    __slots__ = ("v",)
+
+    def __init__(self, v):
+        self.v = v if isinstance(v, tuple) else ef(v)
+
+    @staticmethod
+    def lift(x):
+        return x if isinstance(x, EFv) else EFv(ef(x))
+
+    def __add__(self, o):
+        return EFv(ef_add(self.v, EFv.lift(o).v))
+
+    __radd__ = __add__
+
+    def __sub__(self, o):
+        return EFv(ef_sub(self.v, EFv.lift(o).v))
+
+    def __rsub__(self, o):
+        return EFv(ef_sub(EFv.lift(o).v, self.v))
+
+    def __mul__(self, o):
+        return EFv(ef_mul(self.v, EFv.lift(o).v))
+
+    __rmul__ = __mul__
+
+    def __neg__(self):
+        return EFv(ef_neg(self.v))
+
+    def __mod__(self, _):
+        return self
+
+    def __eq__(self, o):
+        return self.v == EFv.lift(o).v
+
+    def __hash__(self):
+        return hash(self.v)
+
+
+def _raw(x):
+    return x.v if isinstance(x, EFv) else ef(x)
+
+
+# ------------------------------------------------------------------ transcript (p3 DuplexChallenger<_, Perm16, 16, 8>)
+class Challenger:
+    def __init__(self, permute16):
+        self.perm = permute16  # list of 16 canonical ints -> list of 16
+        self.state = [0] * 16
+        self.input = []
+        self.output = []
+
+    def clone(self):
+        c = Challenger(self.perm)
+        c.state, c.input, c.output = list(self.state), list(self.input), list(self.output)
+        return c
+
+    def _duplexing(self):
+        for i, v in enumerate(self.input):
+            self.state[i] = v
+        self.input = []
+        self.state = self.perm(self.state)
+        self.output = list(self.state[:8])
+
+    def observe(self, v):
+        if isinstance(v, (list, tuple)):
+            for x in v:
+                self.observe(x)
+            return
+        self.output = []
+        self.input.append(int(v) % P)
+        if len(self.input) == 8:
+            self._duplexing()
+
+    def sample(self):
+        if self.input or not self.output:
+            self._duplexing()
+        return self.output.pop()
+
+    def sample_ext(self):
+        return tuple(self.sample() for _ in range(4))
+
+    def sample_bits(self, bits):
+        return self.sample() & ((1 << bits) - 1)
+
+    def check_witness(self, bits, witness):
+        self.observe(witness)
+        return self.sample_bits(bits) == 0
+
+
+def default_permute16():
+    from . import binding
+
+    def perm(state):
+        return [int(x) for x in binding.p2_permute(16, state)[0]]
+
+    return perm
+
+
+# ------------------------------------------------------------------ verifier
+class VerifyError(AssertionError):
+    pass
+
+
+def _need(cond, msg):
+    if not cond:
+        raise VerifyError(msg)
+
+
+def _unflatten(vals):
+    """4 opened base-column values (each EF) -> one EF: sum_e basis_e * v_e (basis_e = x^e)."""
+    out = []
+    for j in range(0, len(vals), 4):
+        acc = ZERO
+        for e in range(4):
+            mono = tuple(1 if k == e else 0 for k in range(4))
+            acc = ef_add(acc, ef_mul(mono, vals[j + e]))
+        out.append(acc)
+    return out
+
+
+def eval_constraints_at(air, chip, sels, alpha, perm_alpha, perm_beta, public):
+    """sphinx Verifier::eval_constraints: the chip's AIR on the opened values with a folding builder."""
+    o = chip.opened
+    prep_l, prep_n = o.get("prep", ([], []))
+    b = oair.Builder([EFv(v) for v in o["main"][0]], [EFv(v) for v in o["main"][1]], [EFv(v) for v in prep_l], [EFv(v) for v in prep_n],
+                     list(public), tuple(EFv(s) for s in sels[:3]))
+    # the numeric builder reduces with `% P`; EFv ignores it
+    b.assert_zero = lambda x, cond=None: b.constraints.append(x if cond is None else cond * x)
+    b.receive = lambda values, is_real: b.receives.append((is_real, list(values)))
+    b.send = lambda values, is_real: b.sends.append((is_real, list(values)))
+    air.eval(b)
+    b.constraints = [_raw(c) for c in b.constraints]
+    b.sends = [(_raw(m), [_raw(v) for v in vals]) for m, vals in b.sends]
+    b.receives = [(_raw(m), [_raw(v) for v in vals]) for m, vals in b.receives]
+    perm_local, perm_next = _unflatten(o["perm"][0]), _unflatten(o["perm"][1])
+    return fold_constraints(b, perm_local, perm_next, perm_alpha, perm_beta, chip.quotient_degree, alpha, chip.cumulative_sum, sels)
+
+
+def recompute_quotient(chip, zeta):
+    """sphinx Verifier::recompute_quotient: chunk c lives on the coset 31 * w_Q^c * H."""
+    log_n, qd = chip.log_n, chip.quotient_degree
+    lqd = qd.bit_length() - 1
+    n = 1 << log_n
+    wq = two_adic_generator(log_n + lqd)
+    shifts = [GEN * pow(wq, c, P) % P for c in range(qd)]
+
+    def zp_at(shift, x):  # (x / shift)^n - 1, x an EF tuple
+        return ef_sub(ef_scale(ef_pow(x, n), finv(pow(shift, n, P))), ONE)
+
+    total = ZERO
+    for i in range(qd):
+        zps = ONE
+        for j in range(qd):
+            if j != i:
+                num = zp_at(shifts[j], zeta)
+                den = zp_at(shifts[j], ef(shifts[i]))
+                zps = ef_mul(zps, ef_mul(num, ef_inv(den)))
+        chunk = chip.opened["quotient"][i]
+        acc = ZERO
+        for e in range(4):
+            mono = tuple(1 if k == e else 0 for k in range(4))
+            acc = ef_add(acc, ef_mul(mono, chunk[e]))
+        total = ef_add(total, ef_mul(zps, acc))
+    return total
+
+
+def selectors_at_point(zeta, log_n):
+    n = 1 << log_n
+    zh = ef_sub(ef_pow(zeta, n), ONE)
+    w_inv = finv(two_adic_generator(log_n))
+    return (ef_mul(zh, ef_inv(ef_sub(zeta, ONE))), ef_mul(zh, ef_inv(ef_sub(zeta, ef(w_inv)))), ef_sub(zeta, ef(w_inv)), ef_inv(zh))
+
+
+def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, proof, challenger, merkle_verify):
+    """sphinx Verifier::verify_shard + p3 TwoAdicFriPcs::verify + p3_fri::verifier.  `challenger` must be in the state
+    the prover's was when prove_shard started.  Returns the chips' cumulative sums."""
+    chips = proof.chips
+    log_blowup = proof.log_blowup
+    perm_alpha, perm_beta = challenger.sample_ext(), challenger.sample_ext()
+    challenger.observe(proof.perm_root)
+    alpha = challenger.sample_ext()
+    challenger.observe(proof.quot_root)
+    zeta = challenger.sample_ext()
+
+    # ---- rounds: (root, [(log_n, width, [(point, values)])]) in the prover's order
+    def next_point(log_n):
+        return ef_scale(zeta, two_adic_generator(log_n))
+
+    rounds = []
+    if proof.n_preprocessed:
+        by_idx = {c.prep_index: c for c in chips if c.prep_index >= 0}
+        mats = []
+        for m in range(proof.n_preprocessed):
+            c = by_idx[m]
+            _need(c.log_n == prep_log_heights[m] and c.prep_width == prep_widths[m], "preprocessed shape")
+            mats.append((c.log_n, c.prep_width, [(zeta, c.opened["prep"][0]), (next_point(c.log_n), c.opened["prep"][1])]))
+        rounds.append((vk_root, mats))
+    rounds.append((proof.main_root, [(c.log_n, c.width, [(zeta, c.opened["main"][0]), (next_point(c.log_n), c.opened["main"][1])]) for c in chips]))
+    rounds.append((proof.perm_root, [(c.log_n, c.perm_width, [(zeta, c.opened["perm"][0]), (next_point(c.log_n), c.opened["perm"][1])]) for c in chips]))
+    rounds.append((proof.quot_root, [(c.log_n, 4, [(zeta, chunk)]) for c in chips for chunk in c.opened["quotient"]]))
+
+    # ---- pcs.verify
+    alpha_fri = challenger.sample_ext()
+    betas = []
+    for root in proof.fri_roots:
+        challenger.observe(root)
+        betas.append(challenger.sample_ext())
+    challenger.observe(list(proof.final_poly))
+    _need(challenger.check_witness(proof.pow_bits, proof.pow_witness), "invalid proof-of-work witness")
+    log_max = len(proof.fri_roots) + log_blowup
+    _need(log_max == proof.log_max_height, "log_max_height")
+    indices = [challenger.sample_bits(log_max) for _ in range(proof.num_queries)]
+    _need(indices == proof.query_indices, "query indices differ from the transcript's")
+
+    for qi, index in enumerate(indices):
+        ro = {}
+        alpha_pow = {}
+        for (root, mats), (rw, records) in zip(rounds, proof.round_openings):
+            rec = records[qi]
+            log_hs = [lg + log_blowup for lg, _, _ in mats]
+            widths = [w for _, w, _ in mats]
+            log_batch_max = max(log_hs)
+            _need(rw == sum(widths) + 8 * log_batch_max, "round record size")
+            reduced_index = index >> (log_max - log_batch_max)
+            rows, path = rec[: sum(widths)], rec[sum(widths):]
+            _need(merkle_verify(log_hs, widths, reduced_index, rows, path, root), f"Merkle opening of query {qi} fails")
+            off = 0
+            for (log_n, w, pts), log_h in zip(mats, log_hs):
+                row = rows[off:off + w]
+                off += w
+                rev = bitrev(index >> (log_max - log_h), log_h)
+                x = GEN * pow(two_adic_generator(log_h), rev, P) % P
+                for z, ps_at_z in pts:
+                    _need(len(ps_at_z) == w, "opened values shape")
+                    inv_d = ef_inv(ef_sub(ef(x), z))
+                    for p_at_x, p_at_z in zip(row, ps_at_z):
+                        quotient = ef_mul(ef_sub(ef(p_at_x), p_at_z), inv_d)
+                        ap = alpha_pow.get(log_h, ONE)
+                        ro[log_h] = ef_add(ro.get(log_h, ZERO), ef_mul(ap, quotient))
+                        alpha_pow[log_h] = ef_mul(ap, alpha_fri)
+        # ---- fri verify_query
+        folded = ZERO
+        idx = index
+        x = pow(two_adic_generator(log_max), bitrev(index, log_max), P)
+        for li, (log_folded, root, beta) in enumerate(zip(range(log_max - 1, -1, -1), proof.fri_roots, betas)):
+            folded = ef_add(folded, ro.get(log_folded + 1, ZERO))
+            rw, records = proof.layer_openings[li]
+            rec = records[qi]
+            _need(rw == 8 + 8 * log_folded, "layer record size")
+            pair, path = rec[:8], rec[8:]
+            evals = [tuple(pair[0:4]), tuple(pair[4:8])]
+            _need(evals[idx % 2] == folded, f"query {qi}: layer {li} does not continue the fold")
+            _need(merkle_verify([log_folded], [8], idx >> 1, pair, path, root), f"query {qi}: FRI layer {li} opening fails")
+            xs = [x, x]
+            xs[(idx ^ 1) % 2] = xs[(idx ^ 1) % 2] * (P - 1) % P  # times the generator of the order-2 subgroup
+            # interpolate through (xs[0], evals[0]), (xs[1], evals[1]) and evaluate at beta
+            slope = ef_scale(ef_sub(evals[1], evals[0]), finv(xs[1] - xs[0]))
+            folded = ef_add(evals[0], ef_mul(ef_sub(beta, ef(xs[0])), slope))
+            idx >>= 1
+            x = x * x % P
+        _need(idx < (1 << log_blowup), "final index")
+        _need(folded == proof.final_poly, f"query {qi}: final polynomial mismatch")
+
+    # ---- constraints at zeta
+    for c in chips:
+        air = airs_by_machine_index[c.machine_index]
+        _need(air.width == c.width, "chip width")
+        sels = selectors_at_point(zeta, c.log_n)
+        folded = eval_constraints_at(air, c, sels, alpha, perm_alpha, perm_beta, proof.public_values)
+        quotient = recompute_quotient(c, zeta)
+        _need(ef_mul(folded, sels[3]) == quotient, f"constraints of chip {c.machine_index} do not match the quotient at zeta")
+    return [c.cumulative_sum for c in chips]
+
+
+def verify_machine(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, proofs, merkle_verify, permute16=None):
+    """sphinx StarkMachine::verify: rebuild the transcript, verify every shard, and check that the cumulative
+    sums of all chips of all shards cancel."""
+    ch = Challenger(permute16 or default_permute16())
+    ch.observe(vk_root)
+    ch.observe(0)
+    for pr in proofs:
+        ch.observe(pr.main_root)
+        ch.observe(pr.public_values)
+    total = ZERO
+    for pr in proofs:
+        for cs in verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, pr, ch.clone(), merkle_verify):
+            total = ef_add(total, cs)
+    _need(total == ZERO, "cumulative sums do not cancel")
+    return True

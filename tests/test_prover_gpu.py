@@ -1,0 +1,116 @@
+"""End to end: the GPU shard prover's proofs are accepted by the oracle's verifier (which recomputes the whole
+transcript, every Merkle opening, every FRI query and the constraint identity at zeta through the oracle's own
+numeric AIR), and tampered proofs are rejected."""
+import copy
+
+import numpy as np
+import pytest
+
+from lair_helpers import PARTIAL_SRC, load_cases
+from lurk_amd import lair, prover
+from lurk_amd.programs import synth_eval as se
+from oracle import air as oa
+from oracle import binding as ob
+from oracle import lair as ol
+from oracle import stark as os_
+
+pytestmark = pytest.mark.gpu
+DEMO = load_cases()[0]["source"]
+
+
+def oracle_airs(src, entry, n_public):
+    otop = ol.Toplevel(src)
+    airs = [oa.EntrypointAir(otop.index[entry], n_public)]
+    airs += [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
+    airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES]
+    airs.append(oa.BytesAir())
+    return airs
+
+
+def prove(ctx, src, entry, args, num_queries=8, pow_bits=6, shard_size=None):
+    top = lair.Toplevel(src)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(entry, args, q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, entry, len(pv))
+    root = m.setup()
+    proofs = m.prove(q, lair.ShardingConfig(shard_size) if shard_size else None, num_queries=num_queries, pow_bits=pow_bits)
+    return m, root, proofs, pv
+
+
+def verify(src, entry, root, proofs, n_public):
+    return os_.verify_machine(oracle_airs(src, entry, n_public), root, [16], [6], proofs, ob.merkle_verify)
+
+
+@pytest.mark.parametrize("src,entry,args", [(DEMO, "fib", [12]), (PARTIAL_SRC, "top", [8]), (se.SOURCE, "synth_eval", [1, 50, 0])],
+                         ids=["demo_fib", "partial_with_bytes", "synth_eval"])
+def test_gpu_proof_verifies(ctx, src, entry, args):
+    m, root, proofs, pv = prove(ctx, src, entry, args)
+    assert len(proofs) == 1
+    assert verify(src, entry, root, proofs, len(pv))
+
+
+def test_tampered_proofs_are_rejected(ctx):
+    m, root, proofs, pv = prove(ctx, DEMO, "fib", [9])
+    airs = oracle_airs(DEMO, "fib", len(pv))
+
+    def check(mutate):
+        bad = copy.deepcopy(proofs)
+        mutate(bad[0])
+        with pytest.raises(os_.VerifyError):
+            os_.verify_machine(airs, root, [16], [6], bad, ob.merkle_verify)
+
+    def bump_opened(p):
+        loc, nxt = p.chips[1].opened["main"]
+        loc[2] = ((loc[2][0] + 1) % os_.P,) + loc[2][1:]
+
+    def bump_final(p):
+        p.final_poly = ((p.final_poly[0] + 1) % os_.P,) + p.final_poly[1:]
+
+    def bump_cumsum(p):
+        cs = p.chips[0].cumulative_sum
+        p.chips[0].cumulative_sum = ((cs[0] + 1) % os_.P,) + cs[1:]
+
+    def bump_row(p):
+        rw, recs = p.round_openings[1]
+        recs[0][0] = (recs[0][0] + 1) % os_.P
+
+    def bump_pow(p):
+        p.pow_witness = (p.pow_witness + 1) % os_.P
+
+    for f in (bump_opened, bump_final, bump_cumsum, bump_row, bump_pow):
+        check(f)
+
+
+def test_proof_of_a_wrong_trace_is_rejected(ctx):
+    """A trace that violates a constraint still commits and opens consistently (every committed matrix is low degree by
+    construction), but C(zeta) / Z_H(zeta) no longer equals the quotient recomputed from the opened chunks: the verifier
+    rejects exactly there.  The device-side debug check finds the row."""
+    top = lair.Toplevel(DEMO)
+    q = lair.QueryRecord(top)
+    top.execute_by_name("fib", [9], q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, "fib", len(pv))
+    root = m.setup()
+    traces = m.shard_traces(lair.Shard.new(q))
+    mi, air, lg, t = traces[1]
+    t[1, 2] += 1
+    assert air.check_trace(ctx, 1 << lg, t)[0] in (0, 1)
+    handle, main_root = m.commit_shard(traces)
+    ch = prover.Challenger(ctx)
+    ch.observe(m.vk_root)
+    ch.observe([0])
+    ch.observe(main_root)
+    ch.observe(pv)
+    proof = m.prove_shard(handle, ch, pv, num_queries=4, pow_bits=2)
+    m.free_shard(handle)
+    with pytest.raises(os_.VerifyError, match="do not match the quotient"):
+        verify(DEMO, "fib", root, [proof], len(pv))
+
+
+def test_sharded_proof_verifies(ctx):
+    """max_shard_size 8: several independent shard proofs sharing one transcript prefix; the chips' cumulative
+    sums only cancel across all shards (the reference's sharding test uses size 4, src/core/tests/mod.rs:59-63)."""
+    m, root, proofs, pv = prove(ctx, DEMO, "fib", [20], shard_size=8)
+    assert len(proofs) >= 3
+    assert verify(DEMO, "fib", root, proofs, len(pv))
