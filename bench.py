@@ -1,18 +1,19 @@
 #!/usr/bin/env python3
 """Benchmark of the Lurk proving hot path on MI355X.
 
-Workload (BASELINE.json configs[2]): one shard = 2^20 queries of a width-78 `eval`
-chip (/root/reference/src/core/eval_direct.rs:2028; the synthetic Lair function of
-lurk_amd/programs/synth_eval.py stands in for the evaluator's program text), executed once on the host
-into a query record whose flattened row stream is resident in HBM before the timed region.  One *step*
-= one pass of the hot path over that shard: FuncChip trace generation (row kernel, 2^20 x 78) followed
-by the main-trace commitment of `machine.prove` (coset LDE with blow-up 2 + Poseidon2-16 Merkle root).
-Metric: eval-steps (rows of the eval chip) per second, whole job.
+Workload (BASELINE.json configs[2]): one shard whose `eval` chip (width 78,
+/root/reference/src/core/eval_direct.rs:2028; the synthetic Lair function of lurk_amd/programs/synth_eval.py stands in
+for the evaluator's program text) has 2^20 rows.  The host interpreter runs once before the timed region and the
+flattened inputs of every chip (row streams, memory tables, byte-lookup records) are resident in HBM.  One *step* = one
+pass of the proving hot path over that shard, i.e. what `machine.prove::<LocalProver>` does after `execute`
+(/root/reference/benches/fib.rs:88-124): trace generation of every chip of the machine (eval chip, its callee, the memory
+tables, the byte table), main-trace commitment, LogUp permutation traces + commitment, quotient + commitment, openings
+at zeta and FRI (100 queries, 16 proof-of-work bits).  Metric: eval-steps (rows of the eval chip) proved per second.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): shards are independent
-(`Shard::shard`, /root/reference/src/lair/execute.rs:186-216): rank r proves shard r (weak scaling) and
-the ranks exchange their 8-lane roots with one RCCL all-gather per step, which is the only
-cross-shard data the prover's transcript needs.
+Multi-GPU (--gpus N, launched by torch.distributed.run): shards are independent proofs
+(`Shard::shard`, /root/reference/src/lair/execute.rs:186-216): rank r proves shard r (weak scaling); per step the ranks
+all-gather their 8-lane main-trace roots (every shard's transcript observes every root before any challenge is drawn)
+and all-reduce the extension-field cumulative sums of their chips as 4 x uint64 (the verifier's grand-sum check).
 
 Prints ONE JSON line on rank 0.
 """
@@ -32,25 +33,8 @@ LOG_ROWS = 20
 WIDTH = 78
 LOG_BLOWUP = 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
-
-
-def build_shard(ctx, log_rows: int, rank: int):
-    """Executes the synthetic eval program into 2^log_rows queries and uploads the flattened row stream."""
-    from lurk_amd import lair
-    from lurk_amd.programs import synth_eval as se
-
-    top = lair.Toplevel(se.SOURCE)
-    idx = top.func_index(se.FUNC)
-    queries = lair.QueryRecord(top)
-    args = se.args_for_rows(1 << log_rows)
-    args[2] = rank  # a different environment per rank: every shard is a different trace
-    top.execute(idx, args, queries)
-    chip = lair.FuncChip(ctx, idx, top)
-    assert chip.width() == WIDTH, chip.width()
-    shard = lair.Shard.new(queries)
-    prepared = lair.PreparedFuncTrace(chip, shard)
-    assert prepared.n_real == prepared.height == 1 << log_rows, (prepared.n_real, prepared.height)
-    return top, queries, prepared
+SPANS = ("trace_func", "commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit", "fri_query",
+         "lde", "merkle_leaves", "merkle_levels")
 
 
 def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
@@ -63,7 +47,9 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
 
 
 def cpu_baseline(sample_log_rows: int):
-    """The oracle's commit (OpenMP FFT + Merkle) on a bounded sample of the same workload."""
+    """The oracle's commit (OpenMP FFT + Merkle) on a bounded sample of the same workload: the main-trace commitment of
+    the eval chip only (about 40 % of one step's hashing + NTT work; trace generation, permutation, quotient and FRI
+    have no compiled CPU port), so the CPU figure is an upper bound on what the port would reach on the full step."""
     from oracle import binding as ob
 
     ob.build()
@@ -78,16 +64,18 @@ def cpu_baseline(sample_log_rows: int):
         "unit": "eval-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"commit (LDE x2 + Poseidon2-16 Merkle) of a 2^{sample_log_rows} x {WIDTH} trace, OpenMP over {cores} threads, {dt:.2f} s",
+        "sample": f"main-trace commit only (LDE x2 + Poseidon2-16 Merkle) of a 2^{sample_log_rows} x {WIDTH} trace, OpenMP over {cores} threads, {dt:.2f} s; the GPU step also does trace generation, permutation + quotient commits and FRI",
     }
 
 
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=10)
-    ap.add_argument("--warmup", type=int, default=2)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--log-rows", type=int, default=LOG_ROWS)
+    ap.add_argument("--queries", type=int, default=100)
+    ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-sample-log-rows", type=int, default=20)
     args = ap.parse_args()
@@ -108,28 +96,60 @@ def main():
     torch.cuda.set_device(local_rank)
 
     import lurk_amd
-    from lurk_amd import commit as cm
-    from lurk_amd import field
+    from lurk_amd import lair, prover
+    from lurk_amd.programs import synth_eval as se
 
     ctx = lurk_amd.Context(local_rank)
     log_rows, n = args.log_rows, 1 << args.log_rows
+
+    # ---- host side, once: execute the program, flatten every chip's inputs into HBM
     t_host = time.perf_counter()
-    top, queries, prepared = build_shard(ctx, log_rows, rank)
+    top = lair.Toplevel(se.SOURCE)
+    queries = lair.QueryRecord(top)
+    prog_args = se.args_for_rows(n)
+    prog_args[2] = rank  # a different environment per rank: every shard is a different trace
+    top.execute(top.func_index(se.FUNC), prog_args, queries)
+    pv = queries.expect_public_values()
+    machine = prover.Machine(ctx, top, se.FUNC, len(pv))
+    vk_root = machine.setup()
+    prepared = machine.prepare_shard(lair.Shard.new(queries))
     t_host = time.perf_counter() - t_host
-    trace = torch.zeros((n, WIDTH), dtype=torch.int32, device="cuda")
-    roots = torch.zeros((world, 8), dtype=torch.int32, device="cuda")
-    my_root = torch.zeros(8, dtype=torch.int32, device="cuda")
-    torch.cuda.synchronize()
-    MONTY = 1  # the device-native encoding: no conversion between trace generation and commit
+    eval_rows = queries.num_func_queries(top.func_index(se.FUNC))
+    assert eval_rows == n, (eval_rows, n)
+    chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
+    input_bytes = sum(p.input_bytes for *_, p in prepared if p is not None)
+
+    roots = torch.zeros((world, 8), dtype=torch.int64, device="cuda")
+    my_root = torch.zeros(8, dtype=torch.int64, device="cuda")
+    sums = torch.zeros(4, dtype=torch.int64, device="cuda")
 
     def step():
-        prepared.run(trace, repr=MONTY)
-        c = cm.commit_dev(ctx, [trace], [log_rows], [WIDTH], log_blowup=LOG_BLOWUP, repr=MONTY)
+        traces = machine.run_prepared(prepared)
+        handle, root = machine.commit_shard(traces)
+        ch = prover.Challenger(ctx)
+        ch.observe(vk_root)
+        ch.observe([0])
         if distributed:
-            my_root.copy_(torch.from_numpy(c.root.view(np.int32)))
+            my_root.copy_(torch.tensor(root, dtype=torch.int64))
             dist.all_gather_into_tensor(roots.view(-1), my_root)
-        c.close()
-        return c.root
+            for r in roots.cpu().tolist():
+                ch.observe(r)
+                ch.observe(pv)
+        else:
+            ch.observe(root)
+            ch.observe(pv)
+        words = machine.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
+        machine.free_shard(handle)
+        if distributed:
+            # grand-sum check data: the chips' cumulative sums, reduced over all shards (RCCL has no modular sum:
+            # uint64 addends < 2^31 cannot overflow, reduce mod p locally)
+            n_chips = int(words[1])
+            cs = np.zeros(4, dtype=np.int64)
+            for i in range(n_chips):
+                cs += words[10 + 11 * i + 7:10 + 11 * i + 11].astype(np.int64)
+            sums.copy_(torch.from_numpy(cs))
+            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        return words
 
     def fence():
         ctx.sync()
@@ -144,9 +164,9 @@ def main():
     ctx.profile_reset()
     ctx.profile_enable(True)
     t0 = time.perf_counter()
-    root = None
+    words = None
     for _ in range(args.steps):
-        root = step()
+        words = step()
     fence()
     elapsed = time.perf_counter() - t0
     ctx.profile_enable(False)
@@ -155,16 +175,23 @@ def main():
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
 
-    spans = {name: ctx.profile_read(name) for name in ("trace_func", "lde", "merkle_leaves", "merkle_levels")}
+    spans = {name: ctx.profile_read(name) for name in SPANS}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
 
-    # dominant kernel: Merkle leaf hashing (k_leaves), one launch per step.
-    # algorithmic bytes per launch = LDE rows * (w*4 read + 32 written)   (DESIGN.md "Merkle leaves")
+    # dominant kernel: Merkle leaf hashing (k_leaves); launched once per committed round.
+    # algorithmic bytes of one launch = LDE rows x (sum of widths x 4 read + 32 written); the figure
+    # below is the total over the step's launches divided by their summed HIP-event time.
     leaf_ms, leaf_cnt = spans["merkle_leaves"]
-    leaf_avg_ms = leaf_ms / max(leaf_cnt, 1)
-    leaf_bytes = (n << LOG_BLOWUP) * (WIDTH * 4 + 32)
-    achieved = leaf_bytes / (leaf_avg_ms * 1e-3) / 1e9 if leaf_avg_ms > 0 else 0.0
+    cells = 0
+    for _, air, lg, _, _ in prepared:
+        lde_rows = 1 << (lg + LOG_BLOWUP)
+        cells += lde_rows * (air.width + 4 * air.permutation_width + 4 * (1 << air.log_quotient_degree))
+    max_lg = max(lg for _, _, lg, _, _ in prepared) + LOG_BLOWUP
+    # three trace rounds x one digest per leaf row of the tallest LDE, plus the FRI layers (64-byte leaves, 32-byte digests)
+    leaf_bytes_step = cells * 4 + 3 * (32 << max_lg) + (64 << max_lg)
+    leaf_ms_step = leaf_ms / args.steps
+    achieved = leaf_bytes_step / (leaf_ms_step * 1e-3) / 1e9 if leaf_ms_step > 0 else 0.0
 
     if rank == 0:
         out = {
@@ -181,24 +208,26 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"fib trace 2^{log_rows} rows x {WIDTH} cols per GPU (eval chip): lair trace-gen (row kernel over the HBM-resident row stream) + main-trace commit = coset LDE (blow-up 2) + Poseidon2-16 Merkle root"
-                + ("; RCCL all-gather of shard roots" if distributed else ""),
-                "stages_ms": {k: (v[0] / max(v[1], 1)) * (v[1] / args.steps) for k, v in spans.items()},
-                "parity": "Poseidon2/trace rows pinned by reference KATs; LDE/Merkle self-verified vs oracle (upstream parity unpinned)",
-                "root": [int(x) for x in field.from_monty(root)],
-                "row_stream_bytes": prepared.input_bytes,
-                "host_execute_s": t_host,
+                "workload": f"fib trace 2^{log_rows} rows x {WIDTH} cols per GPU (eval chip) + the rest of its machine: lair trace-gen, main / LogUp permutation / quotient commits (coset LDE blow-up 2 + Poseidon2-16 Merkle), openings + FRI ({args.queries} queries, {args.pow_bits} PoW bits)"
+                + ("; RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
+                "chips": chips_desc,
+                "stages_ms": {k: v[0] / args.steps for k, v in spans.items() if v[1]},
+                "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned)",
+                "proof_words": int(len(words)),
+                "hbm_resident_input_bytes": int(input_bytes),
+                "host_execute_and_upload_s": t_host,
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_leaves (Merkle leaf sponge)",
+                "kernel": "k_leaves (Merkle leaf sponge), all launches of a step",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": None,
-                "avg_launch_ms": leaf_avg_ms,
-                "note": "int32-VALU bound (10 width-16 permutations per 312-byte row), see DESIGN.md",
+                "launches_per_step": leaf_cnt / args.steps,
+                "ms_per_step": leaf_ms_step,
+                "note": "int32-VALU bound: ceil(w/8) width-16 permutations (~8.3 k int32 instructions each) per w*4-byte row, see DESIGN.md 3.4",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
@@ -209,6 +238,7 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+    machine.close()
     ctx.close()
 
 

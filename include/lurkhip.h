@@ -250,6 +250,9 @@ int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top,
 typedef struct lurkhip_func_trace lurkhip_func_trace;
 int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
                                    uint32_t shard_index, uint32_t max_shard_size, lurkhip_func_trace** out);
+/* the same for a MemChip table and for the BytesChip (run with lurkhip_func_trace_run) */
+int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t mem_len, lurkhip_func_trace** out);
+int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index, lurkhip_func_trace** out);
 int32_t lurkhip_func_trace_shape_of(const lurkhip_func_trace* p, uint64_t* shape);
 int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, int32_t repr);
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p);

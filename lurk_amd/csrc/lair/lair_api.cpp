@@ -206,6 +206,9 @@ struct lurkhip_func_trace {
     uint32_t n = 0, height = 0, width = 0, start = 0;
     bool partial = false;
     size_t stream_words = 0;
+    int kind = 0;        // 0: FuncChip, 1: MemChip, 2: BytesChip
+    uint32_t mem_len = 0;
+    bool is_real = false;
 };
 
 extern "C" {
@@ -309,9 +312,86 @@ int32_t lurkhip_func_trace_shape_of(const lurkhip_func_trace* p, uint64_t* shape
     return LURKHIP_OK;
 }
 
+// MemChip / BytesChip counterparts of lurkhip_func_trace_prepare: the chip's inputs (values + provide records, or the
+// 65536 x 6 byte-lookup records) resident on the device, run by lurkhip_func_trace_run.
+int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t mem_len, lurkhip_func_trace** out) {
+    LH_CHECK_CTX(ctx);
+    if (!r || !out) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    return guarded(ctx, [&]() -> int32_t {
+        const auto& mm = r->q.mem_queries[lair::mem_index_from_len(mem_len)];
+        const uint32_t n = (uint32_t)mm.size();
+        std::vector<uint32_t> host((size_t)n * (mem_len + 2) + 4, 0);
+        for (uint32_t i = 0; i < n; i++) {
+            memcpy(&host[(size_t)i * mem_len], mm.keys[i].data(), mem_len * 4);
+            host[(size_t)n * mem_len + 2 * i] = mm.vals[i].provide.nonce;
+            host[(size_t)n * mem_len + 2 * i + 1] = mm.vals[i].provide.count;
+        }
+        auto* p = new lurkhip_func_trace();
+        p->kind = 1;
+        p->mem_len = mem_len;
+        p->n = n;
+        p->height = std::max(4u, next_pow2(n));
+        p->width = 4 + mem_len;
+        p->total = host.size() * 4;
+        int32_t s = lurkhip::pool_alloc(ctx, p->total, &p->dev);
+        hipError_t e = hipSuccess;
+        if (s == LURKHIP_OK) e = hipMemcpyAsync(p->dev, host.data(), p->total, hipMemcpyHostToDevice, ctx->stream);
+        if (s == LURKHIP_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (s != LURKHIP_OK || e != hipSuccess) {
+            if (p->dev) lurkhip::pool_release(ctx, p->dev);
+            delete p;
+            return s != LURKHIP_OK ? s : lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "mem table upload failed: %s", hipGetErrorString(e));
+        }
+        *out = p;
+        return LURKHIP_OK;
+    });
+}
+
+int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index, lurkhip_func_trace** out) {
+    LH_CHECK_CTX(ctx);
+    if (!r || !out) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    return guarded(ctx, [&]() -> int32_t {
+        const bool is_real = shard_index == 0 && !r->q.bytes.records.empty();
+        std::vector<uint32_t> host((size_t)65536 * 12, 0);
+        if (is_real)
+            for (const auto& kv : r->q.bytes.records) {
+                const lair::Record recs[6] = {kv.second.range_u8, kv.second.range_u16, kv.second.less_than,
+                                              kv.second.and_,     kv.second.xor_,      kv.second.or_};
+                for (int k = 0; k < 6; k++) {
+                    host[(size_t)kv.first * 12 + 2 * k] = recs[k].nonce;
+                    host[(size_t)kv.first * 12 + 2 * k + 1] = recs[k].count;
+                }
+            }
+        auto* p = new lurkhip_func_trace();
+        p->kind = 2;
+        p->is_real = is_real;
+        p->n = is_real ? 65536 : 0;
+        p->height = 65536;
+        p->width = 13;
+        p->total = host.size() * 4;
+        int32_t s = lurkhip::pool_alloc(ctx, p->total, &p->dev);
+        hipError_t e = hipSuccess;
+        if (s == LURKHIP_OK) e = hipMemcpyAsync(p->dev, host.data(), p->total, hipMemcpyHostToDevice, ctx->stream);
+        if (s == LURKHIP_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (s != LURKHIP_OK || e != hipSuccess) {
+            if (p->dev) lurkhip::pool_release(ctx, p->dev);
+            delete p;
+            return s != LURKHIP_OK ? s : lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "byte record upload failed: %s", hipGetErrorString(e));
+        }
+        *out = p;
+        return LURKHIP_OK;
+    });
+}
+
 int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, int32_t repr) {
     LH_CHECK_CTX(ctx);
     if (!p || !out_dev) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    if (p->kind == 1)
+        return lurkhip_trace_mem_dev(ctx, p->mem_len, p->n, p->height, (const uint32_t*)p->dev,
+                                     (const uint32_t*)p->dev + (size_t)p->n * p->mem_len, out_dev, repr);
+    if (p->kind == 2) return lurkhip_trace_bytes_dev(ctx, (const uint32_t*)p->dev, p->is_real ? 1 : 0, out_dev, repr);
     const uint8_t* d = (const uint8_t*)p->dev;
     return lurkhip_trace_func_dev(ctx, (const uint32_t*)(d + p->o_prog), p->header.data(), p->n, p->height, p->start,
                                   (const uint32_t*)(d + p->o_args), (const uint32_t*)(d + p->o_outs), (const uint32_t*)(d + p->o_prov),

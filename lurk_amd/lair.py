@@ -185,12 +185,18 @@ class FuncChip:
 
 
 class PreparedFuncTrace:
-    """Device-resident inputs of one FuncChip trace (program + per-row arrays + row stream)."""
+    """Device-resident inputs of one chip's trace (FuncChip: program + per-row arrays + row stream; MemChip: values +
+    provide records; BytesChip: the 65536 x 6 lookup records)."""
 
-    def __init__(self, chip: FuncChip, shard: Shard):
+    def __init__(self, chip, shard: Shard):
         self.ctx = chip.ctx
         h = C.c_void_p()
-        s = N.lib.lurkhip_func_trace_prepare(self.ctx.handle, chip.toplevel.handle, shard.queries.handle, chip.func_idx, shard.index, shard.shard_config.max_shard_size, C.byref(h))
+        if isinstance(chip, FuncChip):
+            s = N.lib.lurkhip_func_trace_prepare(self.ctx.handle, chip.toplevel.handle, shard.queries.handle, chip.func_idx, shard.index, shard.shard_config.max_shard_size, C.byref(h))
+        elif isinstance(chip, MemChip):
+            s = N.lib.lurkhip_mem_trace_prepare(self.ctx.handle, shard.queries.handle, chip.len, C.byref(h))
+        else:
+            s = N.lib.lurkhip_bytes_trace_prepare(self.ctx.handle, shard.queries.handle, shard.index, C.byref(h))
         if s != N.OK:
             raise LairError(s, N.last_error(self.ctx.handle))
         self.handle = h

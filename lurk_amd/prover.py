@@ -227,6 +227,43 @@ class Machine:
         self.ctx.sync()
         return out
 
+    def prepare_shard(self, shard: Shard):
+        """Uploads every included chip's trace inputs once; returns [(machine index, air, log_height, out tensor,
+        prepared inputs or None)] -- `run_prepared` then regenerates all traces on the device without touching the host."""
+        import torch
+
+        from .lair import PreparedFuncTrace
+
+        out = []
+        for mi, (kind, arg, air) in enumerate(self.chips):
+            if kind == "entrypoint":
+                if shard.index != 0:
+                    continue
+                t = torch.from_numpy(field.to_monty(entrypoint_trace(shard.queries)).view(np.int32)).cuda()
+                out.append((mi, air, 0, t, None))
+                continue
+            if kind == "func":
+                chip = FuncChip(self.ctx, arg, self.toplevel)
+                if chip.trace_shape(shard)[0] == 0:
+                    continue
+            elif kind == "mem":
+                if shard.index != 0:
+                    continue
+                chip = MemChip(self.ctx, arg)
+            else:
+                chip = BytesChip(self.ctx)
+            p = PreparedFuncTrace(chip, shard)
+            t = torch.zeros((p.height, p.width), dtype=torch.int32, device="cuda")
+            out.append((mi, air, p.height.bit_length() - 1, t, p))
+        torch.cuda.synchronize()
+        return out
+
+    def run_prepared(self, prepared):
+        for _, _, _, t, p in prepared:
+            if p is not None:
+                p.run(t, repr=N.REPR_MONTY)
+        return [(mi, air, lg, t) for mi, air, lg, t, _ in prepared]
+
     def commit_shard(self, traces):
         n = len(traces)
         airs = (C.c_void_p * n)(*[a.handle.value for _, a, _, _ in traces])
@@ -241,7 +278,7 @@ class Machine:
         self._included[h.value] = [mi for mi, _, _, _ in traces]
         return h, [int(x) for x in root]
 
-    def prove_shard(self, shard_handle, challenger: Challenger, public_values, num_queries=NUM_QUERIES, pow_bits=POW_BITS) -> ShardProof:
+    def prove_shard(self, shard_handle, challenger: Challenger, public_values, num_queries=NUM_QUERIES, pow_bits=POW_BITS, parse=True):
         pv = as_u32(public_values)
         p = C.c_void_p()
         self.ctx.check(N.lib.lurkhip_shard_prove(self.ctx.handle, self.pk, shard_handle, challenger.handle, _addr(pv), len(pv), num_queries, pow_bits,
@@ -250,6 +287,8 @@ class Machine:
         words = np.zeros(n, dtype=np.uint32)
         N.check(N.lib.lurkhip_proof_read(p, _addr(words)))
         N.lib.lurkhip_proof_free(p)
+        if not parse:
+            return words
         proof = parse_proof(words)
         # the C ABI numbers chips by their position in the shard's chip list: map back to the machine's chip vector
         included = self._included[shard_handle.value]
