@@ -54,6 +54,32 @@ int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons
 const lair::ChipAir& air_of(const lurkhip_air* a) { return a->air; }
 const lair::AirPrograms& programs_of(const lurkhip_air* a) { return a->prog; }
 
+// Launch shape of a VM kernel that stages its rows in LDS: 64-lane workgroups whose LDS holds regs[n_regs][64], then
+// `tiles` row tiles of `tile_rows` x (w | 1) words (odd stride: a lane's row starts on its own bank), then 64 row
+// indices.  Falls back to unstaged global reads (staged = false) when that does not fit.
+struct VmShape {
+    int block;
+    size_t lds;
+    bool staged;
+    uint32_t wp;  // padded row stride of a tile
+};
+constexpr size_t VM_LDS_BUDGET = 64 * 1024;
+int vm_block(uint32_t n_regs, size_t* lds_bytes);
+VmShape vm_shape(uint32_t n_regs, uint32_t w, uint32_t tiles, uint32_t tile_rows) {
+    VmShape sh;
+    sh.wp = w | 1u;
+    size_t need = ((size_t)n_regs * 64 + (size_t)tiles * tile_rows * sh.wp + 80) * 4;  // + row indices (up to 65)
+    if (need <= VM_LDS_BUDGET) {
+        sh.block = 64;
+        sh.lds = need;
+        sh.staged = true;
+    } else {
+        sh.block = vm_block(n_regs, &sh.lds);
+        sh.staged = false;
+    }
+    return sh;
+}
+
 // threads per block for a VM launch whose register file is regs[n_regs][block] in LDS
 int vm_block(uint32_t n_regs, size_t* lds_bytes) {
     int block = 256;
@@ -67,6 +93,17 @@ namespace {
 using bb::ef;
 
 __device__ __forceinline__ ef ef_load(const uint32_t* p) { return ef{{p[0], p[1], p[2], p[3]}}; }
+
+// Copies rows idx[0..n_rows) of a row-major matrix into an LDS tile with row stride wp: lanes run along a row, so
+// every global access is one contiguous w*4-byte segment (the per-lane strided reads the VM would otherwise issue
+// thrash L1: a workgroup's rows are hundreds of KB apart from lane to lane).
+__device__ __forceinline__ void stage_rows(uint32_t* __restrict__ tile, uint32_t wp, const uint32_t* __restrict__ mat, uint32_t w,
+                                           const uint32_t* __restrict__ idx, uint32_t n_rows) {
+    for (uint32_t r = 0; r < n_rows; r++) {
+        const size_t g = idx[r];
+        for (uint32_t c = threadIdx.x; c < w; c += blockDim.x) tile[r * wp + c] = mat[g * w + c];
+    }
+}
 
 // ---------------------------------------------------------------- explicit-row evaluation (debug / parity)
 struct DumpSink {
@@ -120,16 +157,33 @@ struct CheckSink {
 };
 
 __global__ void k_air_check(const uint32_t* __restrict__ prog, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep,
-                            const uint32_t* __restrict__ pub, uint32_t n, uint32_t w, uint32_t pw, unsigned long long* first_bad) {
-    extern __shared__ uint32_t regs[];
+                            const uint32_t* __restrict__ pub, uint32_t n, uint32_t w, uint32_t pw, unsigned long long* first_bad,
+                            uint32_t n_regs, uint32_t wp, int staged) {
+    extern __shared__ uint32_t lds[];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nx = i + 1 >= n ? 0 : i + 1;
+    const uint32_t* main_l = main + (size_t)(i < n ? i : 0) * w;
+    const uint32_t* main_n = main + (size_t)nx * w;
+    if (staged) {
+        // rows i0 .. i0 + 64 (local of lane l = tile row l, next = tile row l + 1; the wrap row is staged last)
+        uint32_t* tile = lds + n_regs * blockDim.x;
+        uint32_t* idx = tile + (blockDim.x + 1) * wp;
+        idx[threadIdx.x] = i < n ? i : 0;
+        if (threadIdx.x == blockDim.x - 1) idx[blockDim.x] = nx;
+        __syncthreads();
+        stage_rows(tile, wp, main, w, idx, blockDim.x + 1);
+        __syncthreads();
+        main_l = tile + threadIdx.x * wp;
+        main_n = tile + (threadIdx.x + 1) * wp;
+        // a lane that is the last real row but not the last lane of the block needs row 0 as its next row
+        if (i + 1 == n && threadIdx.x + 1 < blockDim.x) main_n = main;
+    }
     if (i >= n) return;
-    const uint32_t nx = i + 1 == n ? 0 : i + 1;
     // the selectors of a row-by-row checker (p3 check_constraints): indicator values on the trace domain
-    airvm::Sources s{main + (size_t)i * w, main + (size_t)nx * w, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub,
+    airvm::Sources s{main_l, main_n, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub,
                      {i == 0 ? bb::R1 : 0u, i + 1 == n ? bb::R1 : 0u, i + 1 == n ? 0u : bb::R1}};
     CheckSink sink{first_bad, i};
-    airvm::run(prog, s, regs + threadIdx.x, blockDim.x, sink);
+    airvm::run(prog, s, lds + threadIdx.x, blockDim.x, sink);
 }
 
 // ---------------------------------------------------------------- permutation trace rows
@@ -158,7 +212,7 @@ struct LogupAccum {
     const uint32_t* __restrict__ beta_pows;
     ef alpha;
     ef cur, num, den;
-    uint32_t t = 0, in_batch = 0;
+    uint32_t t = 0, in_batch = 0, m_first = 0;
     bool is_send = false;
     __device__ __forceinline__ void begin(uint32_t kind, bool send) {
         cur = bb::ef_add_base(alpha, bb::to_monty(kind));  // alpha + beta^0 * argument_index
@@ -169,12 +223,17 @@ struct LogupAccum {
         cur = bb::ef_add(cur, bb::ef_scale(ef_load(beta_pows + 4 * t), v));
         t++;
     }
-    // folds the finished interaction into the batch; returns true when the batch holds `batch` interactions
+    // folds the finished interaction into the batch fraction num / den = sum_i m_i / d_i; returns true when the batch
+    // holds `batch` interactions.  Multiplicities are base-field: the first two interactions of a batch cost one
+    // extension product (d_1 d_2) and two scalings.
     __device__ __forceinline__ bool end(uint32_t mult, uint32_t batch) {
         const uint32_t m = is_send ? mult : bb::neg(mult);
         if (in_batch == 0) {
-            num = bb::ef_from_base(m);
+            m_first = m;
             den = cur;
+        } else if (in_batch == 1) {
+            num = bb::ef_add(bb::ef_scale(cur, m_first), bb::ef_scale(den, m));
+            den = bb::ef_mul(den, cur);
         } else {
             num = bb::ef_add(bb::ef_mul(num, cur), bb::ef_scale(den, m));
             den = bb::ef_mul(den, cur);
@@ -182,6 +241,8 @@ struct LogupAccum {
         in_batch++;
         return in_batch == batch;
     }
+    // numerator of the (possibly partial) batch
+    __device__ __forceinline__ ef numerator() const { return in_batch == 1 ? bb::ef_from_base(m_first) : num; }
 };
 
 namespace {
@@ -196,7 +257,7 @@ struct PermSink {
     __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
     __device__ __forceinline__ void ival(uint32_t v) { acc.value(v); }
     __device__ __forceinline__ void flush() {
-        ef v = bb::ef_mul(acc.num, bb::ef_inv(acc.den));
+        ef v = acc.in_batch == 1 ? bb::ef_scale(bb::ef_inv(acc.den), acc.m_first) : bb::ef_mul(acc.num, bb::ef_inv(acc.den));
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
         *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
         row_sum = bb::ef_add(row_sum, v);
@@ -210,14 +271,26 @@ struct PermSink {
 
 __global__ void k_perm_rows(const uint32_t* __restrict__ prog, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep,
                             const uint32_t* __restrict__ pub, const uint32_t* __restrict__ beta_pows, ef alpha, uint32_t n, uint32_t w,
-                            uint32_t pw, uint32_t perm_w, uint32_t batch, uint32_t* __restrict__ out) {
-    extern __shared__ uint32_t regs[];
+                            uint32_t pw, uint32_t perm_w, uint32_t batch, uint32_t* __restrict__ out, uint32_t n_regs, uint32_t wp,
+                            int staged) {
+    extern __shared__ uint32_t lds[];
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t nx = i + 1 >= n ? 0 : i + 1;
+    const uint32_t* main_l = main + (size_t)(i < n ? i : 0) * w;
+    if (staged) {
+        // interactions only read the local row
+        uint32_t* tile = lds + n_regs * blockDim.x;
+        uint32_t* idx = tile + blockDim.x * wp;
+        idx[threadIdx.x] = i < n ? i : 0;
+        __syncthreads();
+        stage_rows(tile, wp, main, w, idx, blockDim.x);
+        __syncthreads();
+        main_l = tile + threadIdx.x * wp;
+    }
     if (i >= n) return;
-    const uint32_t nx = i + 1 == n ? 0 : i + 1;
-    airvm::Sources s{main + (size_t)i * w, main + (size_t)nx * w, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub, {0u, 0u, 0u}};
+    airvm::Sources s{main_l, main + (size_t)nx * w, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub, {0u, 0u, 0u}};
     PermSink sink{LogupAccum{beta_pows, alpha}, batch, out + (size_t)i * perm_w * 4};
-    airvm::run(prog, s, regs + threadIdx.x, blockDim.x, sink);
+    airvm::run(prog, s, lds + threadIdx.x, blockDim.x, sink);
     if (sink.acc.in_batch) sink.flush();
     // the row's sum goes to the last column; the scan below turns it into the running sum
     uint4* dst = reinterpret_cast<uint4*>(sink.out_row + 4 * (perm_w - 1));
@@ -335,6 +408,8 @@ struct QuotientArgs {
     uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
     uint32_t zh[4];
     uint32_t g_m, wq_m, wn_inv_m;
+    uint32_t n_regs, wp;    // LDS layout (vm_shape)
+    int staged;
     uint32_t* out;          // [2^lqd][N][4]
 };
 
@@ -360,7 +435,7 @@ struct QuotientSink {
     __device__ __forceinline__ void flush() {
         // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
         ef entry = ef_load(perm_l + 4 * col);
-        assert_zero_ext(bb::ef_sub(bb::ef_mul(acc.den, entry), acc.num));
+        assert_zero_ext(bb::ef_sub(bb::ef_mul(acc.den, entry), acc.numerator()));
         col++;
         acc.in_batch = 0;
     }
@@ -371,13 +446,28 @@ struct QuotientSink {
 
 __global__ void k_quotient(QuotientArgs a) {
     extern __shared__ uint32_t regs[];
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t s_raw = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t q = 1u << a.log_q;
-    if (s >= q) return;
+    const bool live = s_raw < q;
+    const uint32_t s = live ? s_raw : 0u;
     const uint32_t lqd = a.log_q - a.log_n, qd = 1u << lqd;
     const uint32_t i = a.log_q ? (__brev(s) >> (32 - a.log_q)) : 0u;
     const uint32_t i_next = (i + qd) & (q - 1);
     const uint32_t s_next = a.log_q ? (__brev(i_next) >> (32 - a.log_q)) : 0u;
+    const uint32_t* main_l = a.main + (size_t)s * a.w;
+    const uint32_t* main_n = a.main + (size_t)s_next * a.w;
+    if (a.staged) {
+        // only the local rows are staged: the Lair AIRs read one or two columns of the next row (nonce, is_real, ptr),
+        // which stay in global memory, and a second tile would halve the waves an LDS-bound CU can hold
+        uint32_t* tile_l = regs + a.n_regs * blockDim.x;
+        uint32_t* idx = tile_l + blockDim.x * a.wp;
+        idx[threadIdx.x] = s;
+        __syncthreads();
+        stage_rows(tile_l, a.wp, a.main, a.w, idx, blockDim.x);
+        __syncthreads();
+        main_l = tile_l + threadIdx.x * a.wp;
+    }
+    if (!live) return;
     // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset)
     const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
     const uint32_t zh = a.zh[i & (qd - 1)];
@@ -385,8 +475,7 @@ __global__ void k_quotient(QuotientArgs a) {
     const uint32_t x_minus_last = bb::sub(x, a.wn_inv_m);
     const uint32_t is_last = bb::mul(zh, bb::inv(x_minus_last));
     const uint32_t is_trans = x_minus_last;
-    airvm::Sources src{a.main + (size_t)s * a.w, a.main + (size_t)s_next * a.w, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw,
-                       a.pub, {is_first, is_last, is_trans}};
+    airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw, a.pub, {is_first, is_last, is_trans}};
     const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
     const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.perm_alpha}, a.batch, perm_l};
@@ -449,11 +538,11 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     span_begin(ctx, "perm_rows");
     int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows);
     if (s == LURKHIP_OK) {
-        size_t lds = 0;
-        int block = vm_block(a->prog.interactions[airp::H_N_REGS], &lds);
-        hipLaunchKernelGGL(k_perm_rows, dim3((height + block - 1) / block), dim3(block), lds, ctx->stream, ip, main_dev,
+        const uint32_t n_regs = a->prog.interactions[airp::H_N_REGS];
+        const VmShape shp = vm_shape(n_regs, a->air.width, 1, 64);
+        hipLaunchKernelGGL(k_perm_rows, dim3((height + shp.block - 1) / shp.block), dim3(shp.block), shp.lds, ctx->stream, ip, main_dev,
                            prep_dev ? prep_dev : main_dev, (const uint32_t*)nullptr, (const uint32_t*)pows, alpha, height,
-                           a->air.width, a->air.prep_width, perm_w, batch, out_dev);
+                           a->air.width, a->air.prep_width, perm_w, batch, out_dev, n_regs, shp.wp, shp.staged ? 1 : 0);
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
     span_end(ctx, "perm_rows");
@@ -532,11 +621,13 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         }
         q.out = out_dev;
         const uint32_t n_regs = std::max(a->prog.constraints[airp::H_N_REGS], a->prog.interactions[airp::H_N_REGS]);
-        size_t lds = 0;
-        int block = vm_block(n_regs, &lds);
+        const VmShape shp = vm_shape(n_regs, q.w, 1, 64);
+        q.n_regs = n_regs;
+        q.wp = shp.wp;
+        q.staged = shp.staged ? 1 : 0;
         const uint32_t rows = 1u << q.log_q;
         span_begin(ctx, "quotient");
-        hipLaunchKernelGGL(k_quotient, dim3((rows + block - 1) / block), dim3(block), lds, ctx->stream, q);
+        hipLaunchKernelGGL(k_quotient, dim3((rows + shp.block - 1) / shp.block), dim3(shp.block), shp.lds, ctx->stream, q);
         span_end(ctx, "quotient");
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
     }
@@ -714,11 +805,11 @@ int32_t lurkhip_air_check_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t h
     if (e == hipSuccess && np) e = hipMemcpyAsync((uint8_t*)scratch + 16, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
     if (e == hipSuccess && height) {
-        size_t lds = 0;
-        int block = vm_block(a->prog.constraints[airp::H_N_REGS], &lds);
-        hipLaunchKernelGGL(k_air_check, dim3((height + block - 1) / block), dim3(block), lds, ctx->stream, cp, main_dev,
+        const uint32_t n_regs = a->prog.constraints[airp::H_N_REGS];
+        const VmShape shp = vm_shape(n_regs, a->air.width, 1, 65);
+        hipLaunchKernelGGL(k_air_check, dim3((height + shp.block - 1) / shp.block), dim3(shp.block), shp.lds, ctx->stream, cp, main_dev,
                            prep_dev ? prep_dev : main_dev, (const uint32_t*)((uint8_t*)scratch + 16), height, a->air.width,
-                           a->air.prep_width, (unsigned long long*)scratch);
+                           a->air.prep_width, (unsigned long long*)scratch, n_regs, shp.wp, shp.staged ? 1 : 0);
         e = hipGetLastError();
     }
     unsigned long long res = ~0ull;
