@@ -52,36 +52,45 @@ __global__ void k_point_weights(int mode, int log_m, uint32_t g_m, uint32_t w_m,
 }
 
 // ---------------------------------------------------------------- column-wise dot products with EF weights
-// partial[blk][p][c] = sum over the block's rows of mat[s][c] * u_p[s]; 256 threads = 4 row lanes x 64 column lanes
+// partial[blk][p][c] = sum over the block's rows of mat[s][c] * u_p[s].  A workgroup walks its rows R at a time, R =
+// floor(256 / w): thread t holds element (row t / w, column t % w) of the current R x w slab, so the 256 lanes read
+// consecutive words whatever the width (narrow matrices -- quotient chunks, memory tables -- fill the wave too);
+// wider matrices (w > 256) take one row per step in column chunks of 256.
 constexpr int DOT_ROWS = 1024;
 
 __global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
                                                      const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
                                                      uint32_t* __restrict__ partial) {
-    __shared__ uint32_t sh[4][2][64][4];
-    const int lane = threadIdx.x & 63, rl = threadIdx.x >> 6;
+    __shared__ uint32_t sh[2][256][4];
     const size_t row0 = (size_t)blockIdx.x * DOT_ROWS;
     const size_t row_end = row0 + DOT_ROWS < n_rows ? row0 + DOT_ROWS : n_rows;
     const int n_pts = u1 ? 2 : 1;
-    for (uint32_t cb = 0; cb < w; cb += 64) {
-        const uint32_t c = cb + lane;
+    const uint32_t R = w >= 256 ? 1u : 256u / w;
+    const uint32_t rl = w >= 256 ? 0u : threadIdx.x / w;
+    const uint32_t cl = w >= 256 ? threadIdx.x : threadIdx.x - rl * w;
+    const bool active = rl < R;
+    for (uint32_t cb = 0; cb < w; cb += 256) {
+        const uint32_t c = cb + cl;
         ef a0 = bb::ef_zero(), a1 = bb::ef_zero();
-        if (c < w) {
-            for (size_t r = row0 + rl; r < row_end; r += 4) {
+        if (active && c < w) {
+            for (size_t r = row0 + rl; r < row_end; r += R) {
                 const uint32_t m = mat[r * w + c];
                 a0 = bb::ef_add(a0, bb::ef_scale(ef_load(u0 + 4 * r), m));
                 if (u1) a1 = bb::ef_add(a1, bb::ef_scale(ef_load(u1 + 4 * r), m));
             }
         }
         for (int k = 0; k < 4; k++) {
-            sh[rl][0][lane][k] = a0.c[k];
-            sh[rl][1][lane][k] = a1.c[k];
+            sh[0][threadIdx.x][k] = a0.c[k];
+            sh[1][threadIdx.x][k] = a1.c[k];
         }
         __syncthreads();
         if (rl == 0 && c < w) {
             for (int p = 0; p < n_pts; p++) {
                 ef t = bb::ef_zero();
-                for (int q = 0; q < 4; q++) t = bb::ef_add(t, ef{{sh[q][p][lane][0], sh[q][p][lane][1], sh[q][p][lane][2], sh[q][p][lane][3]}});
+                for (uint32_t q = 0; q < R; q++) {
+                    const uint32_t* v = sh[p][q * (w >= 256 ? 0u : w) + cl];
+                    t = bb::ef_add(t, ef{{v[0], v[1], v[2], v[3]}});
+                }
                 ef_store(partial + (((size_t)blockIdx.x * 2 + p) * w + c) * 4, t);
             }
         }
@@ -118,12 +127,33 @@ struct ReduceArgs {
     const uint32_t* d1;  // nullable
     ef ys0, ys1, apow0, apow1;
     uint32_t* ro;
+    int staged;
 };
 
-__global__ __launch_bounds__(256) void k_reduce_openings(ReduceArgs a) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
+// 64 rows per workgroup; the rows are staged in LDS with coalesced loads (odd row stride) when they fit
+__global__ __launch_bounds__(64) void k_reduce_openings(ReduceArgs a) {
+    extern __shared__ uint32_t tile[];
+    const uint32_t s0 = blockIdx.x * 64u, s = s0 + threadIdx.x;
+    const uint32_t* row = a.mat + (size_t)s * a.w;
+    if (a.staged) {
+        const uint32_t wp = a.w | 1u;
+        const uint32_t rows = a.m_rows - s0 < 64u ? a.m_rows - s0 : 64u;
+        const uint32_t total = rows * a.w;  // the 64 rows are one contiguous run of words
+        const uint32_t* src = a.mat + (size_t)s0 * a.w;
+        if (a.w < 64) {
+            // narrow rows: flat copy, every lane busy (one division per element is cheaper than idle lanes)
+            for (uint32_t e = threadIdx.x; e < total; e += 64) {
+                const uint32_t r = e / a.w;
+                tile[r * wp + (e - r * a.w)] = src[e];
+            }
+        } else {
+            for (uint32_t r = 0; r < rows; r++)
+                for (uint32_t c = threadIdx.x; c < a.w; c += 64) tile[r * wp + c] = src[r * a.w + c];
+        }
+        __syncthreads();
+        row = tile + threadIdx.x * wp;
+    }
     if (s >= a.m_rows) return;
-    const uint32_t* __restrict__ row = a.mat + (size_t)s * a.w;
     ef rr = bb::ef_zero();
     for (uint32_t c = 0; c < a.w; c++) rr = bb::ef_add(rr, bb::ef_scale(ef_load(a.alpha_pows + 4 * c), row[c]));
     ef acc = ef_load(a.ro + 4 * (size_t)s);
@@ -220,8 +250,10 @@ int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_r
 int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
                         const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
                         const bb::ef& apow1, uint32_t* ro) {
-    ReduceArgs a{mat, w, m_rows, alpha_pows, d0, d1, ys0, ys1, apow0, apow1, ro};
-    hipLaunchKernelGGL(k_reduce_openings, dim3((m_rows + 255) / 256), dim3(256), 0, ctx->stream, a);
+    const size_t lds = (size_t)64 * (w | 1u) * 4;
+    const bool staged = lds <= 64 * 1024;
+    ReduceArgs a{mat, w, m_rows, alpha_pows, d0, d1, ys0, ys1, apow0, apow1, ro, staged ? 1 : 0};
+    hipLaunchKernelGGL(k_reduce_openings, dim3((m_rows + 63) / 64), dim3(64), staged ? lds : 0, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

@@ -426,26 +426,45 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     };
     uint32_t* ro[32] = {};
     uint64_t num_reduced[32] = {};
-    uint32_t* dot_out = nullptr;
-    PTRY(palloc((size_t)2 * max_w * 16, &dot_out));
-    std::vector<uint32_t> dot_host((size_t)2 * max_w * 4);
     const uint32_t g_m = bb::to_monty(bb::GEN);
+    // phase 1: barycentric sums of every matrix at its points, one read-back for all of them
+    std::vector<size_t> dot_off;  // word offset of each matrix's [2][w][4] block
+    size_t dot_words = 0;
+    for (const Round& r : rounds)
+        for (int m = 0; m < r.c->n_mats; m++) {
+            dot_off.push_back(dot_words);
+            dot_words += (size_t)2 * r.c->width[m] * 4;
+        }
+    uint32_t* dot_out = nullptr;
+    PTRY(palloc(dot_words * 4, &dot_out));
+    {
+        size_t k = 0;
+        for (const Round& r : rounds)
+            for (int m = 0; m < r.c->n_mats; m++, k++) {
+                const int log_n = r.c->log_h[m] - log_blowup;
+                const std::vector<int>& mp = r.points[m];
+                uint32_t *u0 = nullptr, *u1 = nullptr;
+                PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
+                if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
+                PTRY(column_dot(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, dot_out + dot_off[k]));
+            }
+    }
+    std::vector<uint32_t> dot_host(dot_words);
+    PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHIP(hipStreamSynchronize(ctx->stream));
+    // phase 2: opened values on the host, then the reduced openings of every matrix
     // opened values, per round, per matrix, per point: ys[c] (Montgomery)
     std::vector<std::vector<std::vector<std::vector<ef>>>> opened(rounds.size());
+    size_t mat_k = 0;
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const Round& r = rounds[ri];
         opened[ri].resize(r.c->n_mats);
-        for (int m = 0; m < r.c->n_mats; m++) {
+        for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
             const int log_h = r.c->log_h[m], log_n = log_h - log_blowup;
             const uint32_t w = r.c->width[m];
             const size_t n = (size_t)1 << log_n;
             const std::vector<int>& mp = r.points[m];
-            uint32_t *u0 = nullptr, *u1 = nullptr, *d0 = nullptr, *d1 = nullptr;
-            PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
-            if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
-            PTRY(column_dot(ctx, r.c->lde[m], w, n, u0, u1, dot_out));
-            PHIP(hipMemcpyAsync(dot_host.data(), dot_out, (size_t)2 * w * 16, hipMemcpyDeviceToHost, ctx->stream));
-            PHIP(hipStreamSynchronize(ctx->stream));
+            uint32_t *d0 = nullptr, *d1 = nullptr;
             // y = (z^N - g^N) / (N g^(N-1)) * sum
             const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
             const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
@@ -458,7 +477,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
                 std::vector<ef>& ys = opened[ri][m][p];
                 ys.resize(w);
                 for (uint32_t c = 0; c < w; c++) {
-                    const uint32_t* sp = &dot_host[((size_t)p * w + c) * 4];
+                    const uint32_t* sp = &dot_host[dot_off[mat_k] + ((size_t)p * w + c) * 4];
                     ys[c] = bb::ef_mul(factor, ef{{sp[0], sp[1], sp[2], sp[3]}});
                     reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
                 }
