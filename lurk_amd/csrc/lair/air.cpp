@@ -2,8 +2,11 @@
 #include "air.h"
 
 #include <algorithm>
+#include <array>
 #include <functional>
 #include <tuple>
+
+#include "../p2_params.h"
 
 namespace lair {
 
@@ -130,6 +133,110 @@ struct ByteAirRecord {
     }
 };
 
+
+// ------------------------------------------------------------------ extern chips (core/chipset.rs dispatch)
+struct P2Consts {
+    int w, rp;
+    const uint32_t *diag, *ext_rc, *int_rc;
+};
+P2Consts p2_consts(int w) {
+    switch (w) {
+        case 24: return {24, 21, LURK_P2_DIAG_24, LURK_P2_EXT_RC_24, LURK_P2_INT_RC_24};
+        case 32: return {32, 30, LURK_P2_DIAG_32, LURK_P2_EXT_RC_32, LURK_P2_INT_RC_32};
+        case 40: return {40, 38, LURK_P2_DIAG_40, LURK_P2_EXT_RC_40, LURK_P2_INT_RC_40};
+        default: throw ExecError("no Poseidon2 AIR for width " + std::to_string(w));
+    }
+}
+
+// p3 Poseidon2ExternalMatrixGeneral on expressions: M4 = circ(2,3,1,1) per 4-chunk, then add the column sums
+void external_linear_layer(Builder& b, std::vector<E>& s) {
+    const size_t w = s.size();
+    for (size_t i = 0; i < w; i += 4) {
+        E x0 = s[i], x1 = s[i + 1], x2 = s[i + 2], x3 = s[i + 3];
+        E t01 = b.add(x0, x1), t23 = b.add(x2, x3), t0123 = b.add(t01, t23);
+        E t01123 = b.add(t0123, x1), t01233 = b.add(t0123, x3);
+        s[i + 3] = b.add(t01233, b.add(x0, x0));
+        s[i + 1] = b.add(t01123, b.add(x2, x2));
+        s[i] = b.add(t01123, t01);
+        s[i + 2] = b.add(t01233, t23);
+    }
+    E sums[4];
+    for (size_t k = 0; k < 4; k++) {
+        E acc = s[k];
+        for (size_t j = k + 4; j < w; j += 4) acc = b.add(acc, s[j]);
+        sums[k] = acc;
+    }
+    for (size_t i = 0; i < w; i++) s[i] = b.add(s[i], sums[i & 3]);
+}
+
+// InternalDiffusion::permute_mut (poseidon/config.rs:109-118)
+void internal_linear_layer(Builder& b, std::vector<E>& s, const uint32_t* diag) {
+    E sum = b.zero();
+    for (E x : s) sum = b.add(sum, x);
+    for (size_t i = 0; i < s.size(); i++) s[i] = b.add(b.mul(s[i], b.cst(diag[i])), sum);
+}
+
+E cube(Builder& b, E x) { return b.mul(b.mul(x, x), x); }
+
+// Poseidon2Cols::eval (poseidon/wide/air.rs:15-124); cols = external_rounds_state[8][W], external_rounds_sbox[8][W],
+// internal_rounds_state_init[W], internal_rounds_state0[RP - 1], internal_rounds_sbox[RP] (wide/columns.rs:16-32)
+void poseidon2_wide_eval(Builder& b, int width, const std::vector<E>& input, const std::vector<E>& output, const std::vector<E>& cols,
+                         E is_real) {
+    const P2Consts pc = p2_consts(width);
+    const int W = pc.w, RP = pc.rp;
+    auto ext_state = [&](int r, int i) { return cols[(size_t)r * W + i]; };
+    auto ext_sbox = [&](int r, int i) { return cols[(size_t)8 * W + (size_t)r * W + i]; };
+    auto int_init = [&](int i) { return cols[(size_t)16 * W + i]; };
+    auto int_state0 = [&](int r) { return cols[(size_t)17 * W + r]; };
+    auto int_sbox = [&](int r) { return cols[(size_t)17 * W + (RP - 1) + r]; };
+    std::vector<E> state(W);
+    for (int i = 0; i < W; i++) state[i] = b.mul(is_real, input[i]);
+    external_linear_layer(b, state);
+    auto external_round = [&](int round) {
+        for (int i = 0; i < W; i++) {
+            b.assert_eq(state[i], ext_state(round, i));
+            state[i] = ext_state(round, i);
+        }
+        for (int i = 0; i < W; i++) state[i] = b.add(state[i], b.mul(is_real, b.cst(pc.ext_rc[round * W + i])));
+        for (int i = 0; i < W; i++) {
+            E s3 = ext_sbox(round, i);
+            b.assert_eq(cube(b, state[i]), s3);
+            state[i] = b.mul(state[i], b.mul(s3, s3));
+        }
+        external_linear_layer(b, state);
+    };
+    for (int r = 0; r < 4; r++) external_round(r);
+    for (int r = 0; r < RP; r++) {
+        if (r == 0) {
+            for (int i = 0; i < W; i++) {
+                b.assert_eq(state[i], int_init(i));
+                state[i] = int_init(i);
+            }
+        } else {
+            b.assert_eq(state[0], int_state0(r - 1));
+            state[0] = int_state0(r - 1);
+        }
+        state[0] = b.add(state[0], b.mul(is_real, b.cst(pc.int_rc[r])));
+        E s3 = int_sbox(r);
+        b.assert_eq(cube(b, state[0]), s3);
+        state[0] = b.mul(state[0], b.mul(s3, s3));
+        internal_linear_layer(b, state, pc.diag);
+    }
+    for (int r = 4; r < 8; r++) external_round(r);
+    for (size_t i = 0; i < output.size() && i < state.size(); i++) b.assert_eq(state[i], b.mul(is_real, output[i]));
+}
+
+// AddWitness::assert_add (gadgets/unsigned/add.rs:16-58): lhs + rhs = out limb-wise with boolean carries
+void assert_add(Builder& b, const std::vector<E>& lhs, const std::vector<E>& rhs, const std::vector<E>& out, E is_real) {
+    const E base_inv = b.cst(finv(256));
+    E carry = b.zero();
+    for (size_t i = 0; i < out.size(); i++) {
+        E sum = b.add(b.add(lhs[i], rhs[i]), carry);
+        carry = b.mul(b.sub(sum, out[i]), base_inv);
+        b.assert_bool(carry, is_real);
+    }
+}
+
 // ------------------------------------------------------------------ Func AIR (lair/air.rs:158-552)
 struct Val {
     bool is_const;
@@ -206,6 +313,93 @@ struct FuncAirWalk {
         for (int i = 0; i < DEPTH_LT_REQUIRES; i++) reqs.push_back(next_require());
         rec.require_all(nonce, reqs);
         out.insert(out.end(), dep_depth.begin(), dep_depth.end());
+    }
+
+    // LurkChip::eval (core/chipset.rs:122-171) -> PoseidonChipset::eval (core/poseidon.rs:74-93), U64::eval (core/u64.rs:173-229)
+    std::vector<E> eval_chip(const Chip& chip, E is_real, const std::vector<E>& ins, const std::vector<E>& wit,
+                             const std::vector<std::array<E, 3>>& reqs) {
+        ByteAirRecord rec(b);
+        std::vector<E> out;
+        auto word = [&](size_t from) { return std::vector<E>(ins.begin() + from, ins.begin() + from + 8); };
+        switch (chip.kind) {
+            case CHIP_HASHER3:
+            case CHIP_HASHER4:
+            case CHIP_HASHER5: {
+                std::vector<E> output(wit.begin(), wit.begin() + 8), cols(wit.begin() + 8, wit.end());
+                poseidon2_wide_eval(b, (int)chip.input_size, ins, output, cols, is_real);
+                out = output;
+                break;
+            }
+            case CHIP_U64_ADD:
+            case CHIP_U64_SUB: {
+                // Sum / Diff (gadgets/unsigned/add.rs:80-98,135-154): result bytes range-checked, then assert_add
+                std::vector<E> result(wit.begin(), wit.begin() + 8);
+                rec.range_check_u8_iter(result, is_real);
+                if (chip.kind == CHIP_U64_ADD) assert_add(b, word(0), word(8), result, is_real);
+                else assert_add(b, result, word(8), word(0), is_real);
+                out = result;
+                break;
+            }
+            case CHIP_U64_MUL: {
+                // Product { MulWitness { carry[8] }, result[8] } (gadgets/unsigned/mul.rs:66-108,141-164)
+                std::vector<E> carry(wit.begin(), wit.begin() + 8), result(wit.begin() + 8, wit.begin() + 16);
+                const std::vector<E> lhs = word(0), rhs = word(8);
+                std::vector<E> products(8, b.zero());
+                for (int i = 0; i < 8; i++)
+                    for (int j = 0; j + i < 8; j++) products[i + j] = b.add(products[i + j], b.mul(lhs[i], rhs[j]));
+                E carry_prev = b.zero();
+                for (int k = 0; k < 8; k++) {
+                    rec.range_check_u16(carry[k], is_real);
+                    E o = b.add(result[k], b.mul(carry[k], b.cst(256)));
+                    b.assert_eq(b.add(products[k], carry_prev), o, is_real);
+                    carry_prev = carry[k];
+                }
+                rec.range_check_u8_iter(result, is_real);
+                out = result;
+                break;
+            }
+            case CHIP_U64_LESSTHAN: {
+                // CompareWitness<_, 8> { is_comp[8], lhs_comp_limb, rhs_comp_limb, comp_diff_inv, is_less_than } (cmp.rs:48-118)
+                const std::vector<E> lhs = word(0), rhs = word(8);
+                E is_equal = b.one();
+                for (int i = 7; i >= 0; i--) {
+                    b.assert_bool(wit[i], is_real);
+                    is_equal = b.sub(is_equal, wit[i]);
+                    b.assert_eq(lhs[i], rhs[i], b.both(is_real, is_equal));
+                }
+                b.assert_bool(is_equal, is_real);
+                auto select_limb = [&](const std::vector<E>& w) {
+                    E s = b.zero();
+                    for (int i = 0; i < 8; i++) s = b.add(s, b.mul(w[i], wit[i]));
+                    return s;
+                };
+                b.assert_eq(select_limb(lhs), wit[8], is_real);
+                b.assert_eq(select_limb(rhs), wit[9], is_real);
+                E is_different = b.sub(b.one(), is_equal);
+                E comp_diff = b.sub(wit[8], wit[9]);
+                b.assert_eq(b.mul(comp_diff, wit[10]), is_different, is_real);
+                rec.less_than(wit[8], wit[9], wit[11], is_real);
+                out = {wit[11]};
+                break;
+            }
+            case CHIP_U64_ISZERO: {
+                // IsZeroOrEqual<_, 8> { IsZeroWitness { inverses[8] }, result } (is_zero.rs:69-92,142-157)
+                const E is_zero = wit[8];
+                b.assert_bool(is_zero, is_real);
+                E lc = b.zero();
+                for (int i = 0; i < 8; i++) {
+                    b.assert_zero(ins[i], b.both(is_real, is_zero));
+                    lc = b.add(lc, b.mul(ins[i], wit[i]));
+                }
+                b.assert_eq(lc, b.sub(b.one(), is_zero), is_real);
+                out = {is_zero};
+                break;
+            }
+            default:
+                throw ExecError("AIR of extern chip " + chip.name + " is not available in this build");
+        }
+        rec.require_all(nonce, reqs);
+        return out;
     }
 
     void run() {
@@ -416,8 +610,18 @@ struct FuncAirWalk {
                 rec.require_all(nonce, reqs);
                 break;
             }
-            case OpKind::ExternCall:
-                throw ExecError("AIR of extern chip " + t.chips.at(op.x).name + " is not available in this build");
+            case OpKind::ExternCall: {
+                // air.rs:453-472: witness columns, then the chip's requires, then Chipset::eval
+                const Chip& chip = t.chips.at(op.x);
+                std::vector<E> input;
+                for (uint32_t v : op.a) input.push_back(var(v));
+                std::vector<E> wit;
+                for (uint32_t i = 0; i < chip.witness_size; i++) wit.push_back(next_aux());
+                std::vector<std::array<E, 3>> reqs;
+                for (uint32_t i = 0; i < chip.require_size; i++) reqs.push_back(next_require());
+                for (E o : eval_chip(chip, sel, input, wit, reqs)) push_expr(o);
+                break;
+            }
             case OpKind::Emit:
             case OpKind::Breakpoint:
             case OpKind::Debug:

@@ -274,7 +274,12 @@ class FuncAir:
                 rec.range_check_u8_iter([vmap[i][1] for i in op[1]], sel)
                 rec.require_all(b, nonce, reqs)
             elif k == "extern":
-                raise NotImplementedError("extern chip AIR")
+                chip = self.top.chips[op[1]]
+                ins = [vmap[i][1] for i in op[2]]
+                wit = [next_aux() for _ in range(chip.witness_size)]
+                reqs = [next_require() for _ in range(chip.require_size)]
+                for o in eval_chip(b, chip, sel, ins, wit, nonce, reqs):
+                    vmap.append((False, o))
             elif k == "emit":
                 pass
             else:
@@ -305,6 +310,134 @@ class FuncAir:
                 st.update(saved)
 
         eval_block(f["body"], toplevel_sel)
+
+
+# ------------------------------------------------------------------ extern chips
+def _external_layer(s):
+    """p3 Poseidon2ExternalMatrixGeneral: M4 = [[2,3,1,1],[1,2,3,1],[1,1,2,3],[3,1,1,2]] per 4-chunk, then column sums."""
+    w = len(s)
+    for i in range(0, w, 4):
+        x0, x1, x2, x3 = s[i:i + 4]
+        s[i:i + 4] = [2 * x0 + 3 * x1 + x2 + x3, x0 + 2 * x1 + 3 * x2 + x3, x0 + x1 + 2 * x2 + 3 * x3, 3 * x0 + x1 + x2 + 2 * x3]
+    sums = [sum(s[j] for j in range(k, w, 4)) for k in range(4)]
+    for i in range(w):
+        s[i] = s[i] + sums[i % 4]
+
+
+def poseidon2_wide_eval(b: Builder, width, ins, output, cols, is_real):
+    """Poseidon2Cols::eval, /root/reference/src/poseidon/wide/air.rs:15-124 (column order wide/columns.rs:16-32)."""
+    from . import binding
+
+    rp, diag, ext_rc, int_rc = binding.p2_params(width)
+    W = width
+    ext_state = lambda r, i: cols[r * W + i]
+    ext_sbox = lambda r, i: cols[8 * W + r * W + i]
+    int_init = lambda i: cols[16 * W + i]
+    int_state0 = lambda r: cols[17 * W + r]
+    int_sbox = lambda r: cols[17 * W + (rp - 1) + r]
+    state = [is_real * x for x in ins]
+    _external_layer(state)
+
+    def external_round(r):
+        for i in range(W):
+            b.assert_eq(state[i], ext_state(r, i))
+            state[i] = ext_state(r, i)
+        for i in range(W):
+            state[i] = state[i] + is_real * ext_rc[r][i]
+        for i in range(W):
+            s3 = ext_sbox(r, i)
+            b.assert_eq(state[i] * state[i] * state[i], s3)
+            state[i] = state[i] * (s3 * s3)
+        _external_layer(state)
+
+    for r in range(4):
+        external_round(r)
+    for r in range(rp):
+        if r == 0:
+            for i in range(W):
+                b.assert_eq(state[i], int_init(i))
+                state[i] = int_init(i)
+        else:
+            b.assert_eq(state[0], int_state0(r - 1))
+            state[0] = int_state0(r - 1)
+        state[0] = state[0] + is_real * int_rc[r]
+        s3 = int_sbox(r)
+        b.assert_eq(state[0] * state[0] * state[0], s3)
+        state[0] = state[0] * (s3 * s3)
+        total = sum(state)
+        for i in range(W):
+            state[i] = state[i] * diag[i] + total
+    for r in range(4, 8):
+        external_round(r)
+    for st, o in zip(state, output):
+        b.assert_eq(st, is_real * o)
+
+
+def _assert_add(b, lhs, rhs, out, is_real):  # gadgets/unsigned/add.rs:16-58
+    base_inv = inv(256)
+    carry = 0
+    for o, x, y in zip(out, lhs, rhs):
+        carry = (x + y + carry - o) * base_inv
+        b.assert_bool(carry, is_real)
+
+
+def eval_chip(b: Builder, chip, is_real, ins, wit, nonce, reqs):
+    """LurkChip::eval (core/chipset.rs:122-171): PoseidonChipset::eval (core/poseidon.rs:74-93), U64::eval (core/u64.rs:173-229)."""
+    rec = ByteAirRecord()
+    name = chip.name
+    if name.startswith("hasher"):
+        output, cols = wit[:8], wit[8:]
+        poseidon2_wide_eval(b, chip.input_size, ins, output, cols, is_real)
+        out = list(output)
+    elif name in ("u64_add", "u64_sub"):
+        result = wit[:8]
+        rec.range_check_u8_iter(result, is_real)
+        if name == "u64_add":
+            _assert_add(b, ins[:8], ins[8:16], result, is_real)
+        else:
+            _assert_add(b, result, ins[8:16], ins[:8], is_real)
+        out = list(result)
+    elif name == "u64_mul":  # gadgets/unsigned/mul.rs:66-108,141-164
+        carry, result = wit[:8], wit[8:16]
+        lhs, rhs = ins[:8], ins[8:16]
+        products = [0] * 8
+        for i in range(8):
+            for j in range(8 - i):
+                products[i + j] += lhs[i] * rhs[j]
+        carry_prev = 0
+        for k in range(8):
+            rec.records.append(([BYTE_TAG, 2, carry[k]], is_real))
+            b.assert_eq(products[k] + carry_prev, result[k] + carry[k] * 256, is_real)
+            carry_prev = carry[k]
+        rec.range_check_u8_iter(result, is_real)
+        out = list(result)
+    elif name == "u64_lessthan":  # gadgets/unsigned/cmp.rs:48-118
+        lhs, rhs = ins[:8], ins[8:16]
+        is_comp, lhs_limb, rhs_limb, diff_inv, is_lt = wit[:8], wit[8], wit[9], wit[10], wit[11]
+        is_equal = 1
+        for i in reversed(range(8)):
+            b.assert_bool(is_comp[i], is_real)
+            is_equal = is_equal - is_comp[i]
+            b.assert_eq(lhs[i], rhs[i], is_real * is_equal)
+        b.assert_bool(is_equal, is_real)
+        b.assert_eq(sum(x * f for x, f in zip(lhs, is_comp)), lhs_limb, is_real)
+        b.assert_eq(sum(x * f for x, f in zip(rhs, is_comp)), rhs_limb, is_real)
+        b.assert_eq((lhs_limb - rhs_limb) * diff_inv, 1 - is_equal, is_real)
+        rec.less_than(lhs_limb, rhs_limb, is_lt, is_real)
+        out = [is_lt]
+    elif name == "u64_iszero":  # gadgets/unsigned/is_zero.rs:69-92,142-157
+        inverses, is_zero = wit[:8], wit[8]
+        b.assert_bool(is_zero, is_real)
+        lc = 0
+        for x, w_ in zip(ins[:8], inverses):
+            b.assert_zero(x, is_real * is_zero)
+            lc = lc + x * w_
+        b.assert_eq(lc, 1 - is_zero, is_real)
+        out = [is_zero]
+    else:
+        raise NotImplementedError(f"AIR of extern chip {name}")
+    rec.require_all(b, nonce, reqs)
+    return out
 
 
 class MemAir:  # lair/memory.rs:71-109

@@ -69,6 +69,25 @@ def p2_wide_witness(width: int, x) -> np.ndarray:
     return out
 
 
+class _P2Params(C.Structure):
+    _fields_ = [("width", C.c_int), ("rounds_p", C.c_int), ("diag", C.POINTER(C.c_uint32)), ("ext_rc", C.POINTER(C.c_uint32)),
+                ("int_rc", C.POINTER(C.c_uint32))]
+
+
+def p2_params(width: int):
+    """(rounds_p, diag[W], ext_rc[8][W], int_rc[rounds_p]) of the oracle's Poseidon2 tables (canonical ints)."""
+    L = lib()
+    L.or_p2_lookup.restype = C.c_int
+    L.or_p2_lookup.argtypes = [C.c_int, C.POINTER(_P2Params)]
+    p = _P2Params()
+    assert L.or_p2_lookup(width, C.byref(p)) == 0, f"no Poseidon2 parameters for width {width}"
+    rp = p.rounds_p
+    diag = [int(p.diag[i]) for i in range(width)]
+    ext = [[int(p.ext_rc[r * width + i]) for i in range(width)] for r in range(8)]
+    internal = [int(p.int_rc[i]) for i in range(rp)]
+    return rp, diag, ext, internal
+
+
 def f_inv(a: int) -> int:
     return int(lib().or_f_inv(a))
 

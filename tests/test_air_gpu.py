@@ -224,3 +224,26 @@ def test_quotient_matches_oracle(ctx):
                 assert lde_c.tolist() == want_lde, (a.name, c)
             for c_ in (main_c, perm_c, qc):
                 c_.close()
+
+
+def test_extern_chip_airs_match_oracle(ctx, oracle):
+    """Poseidon2 wide AIR (hasher3/4/5) and u64 gadget AIRs, constraint by constraint, on real and random rows."""
+    from lair_helpers import U64_SRC
+    from test_lair_gpu import oracle_chip_callbacks
+
+    poseidon, witness = oracle_chip_callbacks(oracle)
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    top, otop = lair.Toplevel(U64_SRC, lurk_chips=True), ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+    oq = ol.QueryRecord(otop)
+    for name, args in [("u64_ops", u64(5) + u64(7)), ("u64_ops", u64(2**64 - 1) + u64(1)), ("chain", [9, 8, 7, 6, 5, 4, 3, 2]),
+                       ("hash5", list(range(40)))]:
+        ol.execute(otop, name, args, oq, poseidon=poseidon)
+    for i, f in enumerate(otop.funcs):
+        rows, width = ol.generate_trace(otop, f["name"], oq, witness=witness)
+        a = air.ChipAir.for_func(top, i)
+        assert a.width == width and a.max_constraint_degree <= 3
+        local, nxt, sels = rows_for(width, rows[:4], seed=300 + i)
+        compare(ctx, a, oa.FuncAir(otop, f["name"]), local[:8], nxt[:8], sels[:8])

@@ -61,3 +61,33 @@ def test_broken_trace_is_rejected():
     rows[2][3] = (rows[2][3] + 1) % ol.P
     with pytest.raises(AssertionError):
         oa.debug_check(chips, public=pv)
+
+
+def test_extern_chip_machine_constraints_and_lookups(oracle):
+    """Poseidon2 wide AIR (hash3/4) and the u64 gadgets (add, sub, lessthan, iszero + byte lookups) on real traces:
+    the property the reference checks in its own chip tests (e.g. /root/reference/src/core/u64.rs:233-300)."""
+    from lair_helpers import U64_SRC
+    from test_lair_gpu import oracle_chip_callbacks
+
+    poseidon, witness = oracle_chip_callbacks(oracle)
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    for entry, args in (("u64_ops", u64(0x0102030405060708) + u64(0x01020304FF060708)), ("chain", [9, 8, 7, 6, 5, 4, 3, 2])):
+        top = ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+        q = ol.QueryRecord(top)
+        ol.execute(top, entry, args, q, poseidon=poseidon)
+        f = top.funcs[top.index[entry]]
+        pv = q.public_values
+        chips = [(oa.EntrypointAir(f["index"], len(pv)), [list(pv)], None)]
+        for g in top.funcs:
+            rows, _ = ol.generate_trace(top, g["name"], q, witness=witness)
+            if rows:
+                chips.append((oa.FuncAir(top, g["name"]), rows, None))
+        for ml in ol.MEM_TABLE_SIZES:
+            chips.append((oa.MemAir(ml), ol.mem_trace(q, ml), None))
+        if q.bytes:
+            prep = [[i & 0xFF, i >> 8, int((i & 0xFF) < (i >> 8)), (i & 0xFF) & (i >> 8), (i & 0xFF) ^ (i >> 8), (i & 0xFF) | (i >> 8)] for i in range(1 << 16)]
+            chips.append((oa.BytesAir(), ol.bytes_trace(q), prep))
+        assert oa.debug_check(chips, public=pv) > 0

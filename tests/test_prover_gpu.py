@@ -114,3 +114,40 @@ def test_sharded_proof_verifies(ctx):
     m, root, proofs, pv = prove(ctx, DEMO, "fib", [20], shard_size=8)
     assert len(proofs) >= 3
     assert verify(DEMO, "fib", root, proofs, len(pv))
+
+
+def test_machine_with_extern_chips_proves_and_verifies(ctx):
+    """hash3 / hash4 chips (Poseidon2 wide AIR, 493 / 655 columns) called through call / preimg, with the hash queries
+    injected the way the reference's setup does (inject_inv_queries, /root/reference/src/lair/execute.rs:299)."""
+    from lair_helpers import U64_SRC
+
+    top = lair.Toplevel(U64_SRC, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name("chain", [9, 8, 7, 6, 5, 4, 3, 2], q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, "chain", len(pv))
+    root = m.setup()
+    proofs = m.prove(q, num_queries=6, pow_bits=4)
+    otop = ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+    airs = [oa.EntrypointAir(otop.index["chain"], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
+    airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
+    assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+
+
+def test_u64_gadget_machine_proves_and_verifies(ctx):
+    from lair_helpers import U64_SRC
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    top = lair.Toplevel(U64_SRC, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name("u64_ops", u64(0x0102030405060708) + u64(0x01020304FF060708), q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, "u64_ops", len(pv))
+    root = m.setup()
+    proofs = m.prove(q, num_queries=6, pow_bits=4)
+    otop = ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+    airs = [oa.EntrypointAir(otop.index["u64_ops"], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
+    airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
+    assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
