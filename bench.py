@@ -34,7 +34,7 @@ WIDTH = 78
 LOG_BLOWUP = 1
 HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
 SPANS = ("trace_func", "commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit", "fri_query",
-         "lde", "merkle_leaves", "merkle_levels")
+         "lde", "merkle_leaves", "merkle_levels", "merkle_top")
 
 
 def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
@@ -179,19 +179,42 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
 
-    # dominant kernel: Merkle leaf hashing (k_leaves); launched once per committed round.
-    # algorithmic bytes of one launch = LDE rows x (sum of widths x 4 read + 32 written); the figure
-    # below is the total over the step's launches divided by their summed HIP-event time.
-    leaf_ms, leaf_cnt = spans["merkle_leaves"]
-    cells = 0
-    for _, air, lg, _, _ in prepared:
-        lde_rows = 1 << (lg + LOG_BLOWUP)
-        cells += lde_rows * (air.width + 4 * air.permutation_width + 4 * (1 << air.log_quotient_degree))
+    # dominant kernels: the Merkle hashing launches (k_leaves: leaf sponges; k_level: 2-to-1 compressions + the sponges of
+    # the shorter matrices injected at their level).  Algorithmic bytes: a leaf row reads its w*4 bytes and
+    # writes a 32-byte digest; a level node reads two digests (64 B) + the injected rows and writes 32 B.  `achieved` =
+    # bytes of all those launches in one step / their summed HIP-event time (launch-weighted average).
+    def merkle_hash_bytes(mats):
+        log_max = max(lg for lg, _ in mats)
+        total = (1 << log_max) * (4 * sum(w for lg, w in mats if lg == log_max) + 32)
+        launches = 1
+        for lvl in range(1, log_max + 1):
+            n_par = 1 << (log_max - lvl)
+            lh = log_max - lvl
+            if 2 * n_par <= 2048 and all(lg > lh for lg, _ in mats):
+                break  # k_top finishes the tree in one workgroup (latency-bound tail, reported separately)
+            total += n_par * (64 + 4 * sum(w for lg, w in mats if lg == lh) + 32)
+            launches += 1
+        return total, launches
+
+    rounds = [
+        [(lg + LOG_BLOWUP, air.width) for _, air, lg, _, _ in prepared],
+        [(lg + LOG_BLOWUP, 4 * air.permutation_width) for _, air, lg, _, _ in prepared],
+        [(lg + LOG_BLOWUP, 4) for _, air, lg, _, _ in prepared for _ in range(1 << air.log_quotient_degree)],
+    ]
     max_lg = max(lg for _, _, lg, _, _ in prepared) + LOG_BLOWUP
-    # three trace rounds x one digest per leaf row of the tallest LDE, plus the FRI layers (64-byte leaves, 32-byte digests)
-    leaf_bytes_step = cells * 4 + 3 * (32 << max_lg) + (64 << max_lg)
-    leaf_ms_step = leaf_ms / args.steps
-    achieved = leaf_bytes_step / (leaf_ms_step * 1e-3) / 1e9 if leaf_ms_step > 0 else 0.0
+    rounds += [[(lf, 8)] for lf in range(max_lg - 1, LOG_BLOWUP - 1, -1)]  # FRI layers
+    hash_bytes_step = sum(merkle_hash_bytes(r)[0] for r in rounds)
+    hash_launches_step = sum(merkle_hash_bytes(r)[1] for r in rounds)
+    hash_ms_step = (spans["merkle_leaves"][0] + spans["merkle_levels"][0]) / args.steps
+    achieved = hash_bytes_step / (hash_ms_step * 1e-3) / 1e9 if hash_ms_step > 0 else 0.0
+    traffic = None
+    try:  # HBM bytes per step of the same kernels from the rocprofv3 PMC passes (profiles/)
+        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+            pmc = json.load(f)
+        if pmc.get("log_rows") == log_rows:
+            traffic = pmc["merkle_hash_bytes_per_step"]
+    except Exception:
+        pass
 
     if rank == 0:
         out = {
@@ -219,15 +242,16 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "k_leaves (Merkle leaf sponge), all launches of a step",
+                "kernel": "Merkle hashing (k_leaves + k_level), all launches of a step",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
-                "traffic": None,
-                "launches_per_step": leaf_cnt / args.steps,
-                "ms_per_step": leaf_ms_step,
-                "note": "int32-VALU bound: ceil(w/8) width-16 permutations (~8.3 k int32 instructions each) per w*4-byte row, see DESIGN.md 3.4",
+                "traffic": traffic,
+                "algorithmic_bytes_per_step": hash_bytes_step,
+                "launches_per_step": hash_launches_step,
+                "ms_per_step": hash_ms_step,
+                "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (~8.3 k int32 instructions each) per w*4-byte row; at the 39 Tinstr/s int32 issue peak this kernel cannot exceed ~0.4 TB/s algorithmic (DESIGN.md 3.4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:

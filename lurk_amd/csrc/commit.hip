@@ -144,7 +144,11 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         const int min_log_h = *std::min_element(c->log_h.begin(), c->log_h.end());
         if (min_log_h > lh && (n_parents << 1) <= 2048) {
             // nothing left to inject: finish the tree in one workgroup
+            span_end(ctx, "merkle_levels");
+            span_begin(ctx, "merkle_top");
             LH_TRY(merkle_top(ctx, params, children, n_parents << 1));
+            span_end(ctx, "merkle_top");
+            span_begin(ctx, "merkle_levels");
             break;
         }
         LeafCol* icols = nullptr;
