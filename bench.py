@@ -119,9 +119,9 @@ def main():
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
     input_bytes = sum(p.input_bytes for *_, p in prepared if p is not None)
 
-    roots = torch.zeros((world, 8), dtype=torch.int64, device="cuda")
-    my_root = torch.zeros(8, dtype=torch.int64, device="cuda")
-    sums = torch.zeros(4, dtype=torch.int64, device="cuda")
+    from lurk_amd import shards
+
+    grand_sums = []
 
     def step():
         traces = machine.run_prepared(prepared)
@@ -129,26 +129,16 @@ def main():
         ch = prover.Challenger(ctx)
         ch.observe(vk_root)
         ch.observe([0])
-        if distributed:
-            my_root.copy_(torch.tensor(root, dtype=torch.int64))
-            dist.all_gather_into_tensor(roots.view(-1), my_root)
-            for r in roots.cpu().tolist():
-                ch.observe(r)
-                ch.observe(pv)
-        else:
-            ch.observe(root)
+        # every shard's transcript observes every shard's main root (RCCL all-gather of 8 lanes per rank)
+        for r in shards.exchange_roots([root], device="cuda" if distributed else "cpu"):
+            ch.observe(r)
             ch.observe(pv)
         words = machine.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
         machine.free_shard(handle)
-        if distributed:
-            # grand-sum check data: the chips' cumulative sums, reduced over all shards (RCCL has no modular sum:
-            # uint64 addends < 2^31 cannot overflow, reduce mod p locally)
-            n_chips = int(words[1])
-            cs = np.zeros(4, dtype=np.int64)
-            for i in range(n_chips):
-                cs += words[10 + 11 * i + 7:10 + 11 * i + 11].astype(np.int64)
-            sums.copy_(torch.from_numpy(cs))
-            dist.all_reduce(sums, op=dist.ReduceOp.SUM)
+        # grand-sum check data: the chips' cumulative sums, reduced over all shards (RCCL all-reduce of 4 x int64)
+        n_chips = int(words[1])
+        cs = [words[10 + 11 * i + 7:10 + 11 * i + 11] for i in range(n_chips)]
+        grand_sums.append(shards.reduce_cumulative_sums(cs, device="cuda" if distributed else "cpu"))
         return words
 
     def fence():
@@ -237,6 +227,7 @@ def main():
                 "stages_ms": {k: v[0] / args.steps for k, v in spans.items() if v[1]},
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned)",
                 "proof_words": int(len(words)),
+                "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
                 "hbm_resident_input_bytes": int(input_bytes),
                 "host_execute_and_upload_s": t_host,
             },

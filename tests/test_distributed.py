@@ -1,0 +1,83 @@
+"""The N > 1 path on CPU: two processes over gloo exchange shard roots and reduce cumulative sums exactly as
+bench.py does over RCCL, and end up with identical transcripts."""
+import os
+import socket
+import sys
+
+import numpy as np
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+P = 2013265921
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lurk_amd import shards
+    from oracle import stark as os_
+
+    n_shards = 6
+    mine = shards.assign_shards(n_shards, world, rank)
+    # a deterministic fake root / cumulative sum per shard; sums are built to cancel over all shards
+    def root_of(s):
+        return [(1000 * s + k) % P for k in range(8)]
+
+    sums = {s: (s + 1, 2 * s + 3, P - 5 * s - 1, 7) for s in range(n_shards - 1)}
+    total = np.zeros(4, dtype=np.int64)
+    for v in sums.values():
+        total = (total + np.array(v)) % P
+    sums[n_shards - 1] = tuple(int((P - x) % P) for x in total)
+    roots = shards.exchange_roots([root_of(s) for s in mine])
+    grand = shards.reduce_cumulative_sums([sums[s] for s in mine])
+    # the transcript every rank derives from the gathered roots
+    ch = os_.Challenger(os_.default_permute16())
+    ch.observe([1, 2, 3, 4, 5, 6, 7, 8])
+    ch.observe(0)
+    for r in roots:
+        ch.observe(r)
+    q.put((rank, mine, roots, grand, ch.sample_ext()))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_process_root_exchange_and_grand_sum():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=180) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    results.sort()
+    (r0, mine0, roots0, grand0, ch0), (r1, mine1, roots1, grand1, ch1) = results
+    assert mine0 == [0, 2, 4] and mine1 == [1, 3, 5]
+    assert roots0 == roots1 == [[(1000 * s + k) % P for k in range(8)] for s in range(6)]
+    assert grand0 == grand1 == (0, 0, 0, 0)
+    assert ch0 == ch1
+
+
+def test_single_process_paths_need_no_process_group():
+    sys.path.insert(0, ROOT)
+    from lurk_amd import shards
+
+    assert shards.assign_shards(5, 1, 0) == [0, 1, 2, 3, 4]
+    assert shards.exchange_roots([[1] * 8, [2] * 8]) == [[1] * 8, [2] * 8]
+    assert shards.reduce_cumulative_sums([(1, 2, 3, 4), (P - 1, P - 2, P - 3, P - 4)]) == (0, 0, 0, 0)
