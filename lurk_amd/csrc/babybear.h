@@ -66,6 +66,41 @@ BB_HD uint32_t mred(uint64_t t) {
 BB_HD uint32_t mul(uint32_t a, uint32_t b) { return mred((uint64_t)a * b); }
 BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 
+// Signed Montgomery product without the final correction: for int32 a, b returns r = a * b * 2^-32 (mod p) with
+// |r| < |a * b| / 2^32 + p / 2, so operands in (-p, p) give a result in (-p, p) again.  Four instructions on gfx950
+// (v_mad_i64_i32, v_mul_lo_u32, v_mul_hi_i32, v_sub) against six for the canonical-range product: used for the
+// x^7 chains of Poseidon2, whose intermediates never leave the chain.
+BB_HD int32_t smul(int32_t a, int32_t b) {
+    const int64_t t = (int64_t)a * b;
+    const int32_t m = (int32_t)((uint32_t)t * MU);
+#if defined(__HIP_DEVICE_COMPILE__)
+    const int32_t u = __mulhi(m, (int32_t)P);
+#else
+    const int32_t u = (int32_t)(((int64_t)m * (int32_t)P) >> 32);
+#endif
+    int32_t hi = (int32_t)(uint32_t)((uint64_t)t >> 32);
+#if defined(__HIP_DEVICE_COMPILE__)
+    // keep the subtraction 32-bit: without the barrier LLVM rewrites hi - u as the high word of a 64-bit
+    // subtraction (v_subrev_co + v_subb_co, two instructions instead of one v_sub)
+    asm("" : "+v"(hi));
+#endif
+    return hi - u;
+}
+// (s + rc)^7 for canonical-range s, rc, given rc_mp = rc - p (mod 2^32): the sum s + rc_mp lies in (-p, p), the chain
+// runs on signed values, one correction at the end
+BB_HD uint32_t add_pow7_mp(uint32_t s, uint32_t rc_mp) {
+    const int32_t x = (int32_t)(s + rc_mp);
+    const int32_t x2 = smul(x, x), x3 = smul(x2, x), x6 = smul(x3, x3), x7 = smul(x6, x);
+    const uint32_t r = (uint32_t)x7;
+    return umin(r, r + P);
+}
+BB_HD uint32_t add_pow7(uint32_t s, uint32_t rc) {
+    const int32_t x = (int32_t)(s + (rc - P));
+    const int32_t x2 = smul(x, x), x3 = smul(x2, x), x6 = smul(x3, x3), x7 = smul(x6, x);
+    const uint32_t r = (uint32_t)x7;
+    return umin(r, r + P);
+}
+
 BB_HD uint32_t to_monty(uint32_t x) { return mul(x, R2); }
 BB_HD uint32_t from_monty(uint32_t x) { return mred((uint64_t)x); }
 

@@ -50,6 +50,12 @@ struct P16Params {
     uint32_t int_rc[P16_MAX_RP];
     uint32_t diag[16];
     int32_t rounds_p;
+    uint32_t ext_rc_mp[8 * 16];  // rc - p (mod 2^32), for the signed S-box chain
+    uint32_t int_rc_mp[P16_MAX_RP];
+    void finish() {
+        for (int i = 0; i < 128; i++) ext_rc_mp[i] = ext_rc[i] - 2013265921u;
+        for (int i = 0; i < P16_MAX_RP; i++) int_rc_mp[i] = int_rc[i] - 2013265921u;
+    }
 };
 
 // One matrix column of the concatenated leaf row (uniform descriptor, read through the scalar cache)

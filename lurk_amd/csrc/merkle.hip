@@ -27,7 +27,7 @@ constexpr int MBLOCK = 256;
 
 __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
     p2::NoRecord rec;
-    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, rec);
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, rec);
 }
 
 // sponge over the uniform column table for row `row`; state must be zero on entry
@@ -152,6 +152,7 @@ int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev) {
         for (int i = 0; i < 13; i++) h.int_rc[i] = bb::c_to_monty(LURK_P2_INT_RC_16[i]);
         for (int i = 0; i < 16; i++) h.diag[i] = bb::c_to_monty(LURK_P2_DIAG_16[i]);
         h.rounds_p = 13;
+        h.finish();
         void* d = nullptr;
         LH_HIP(ctx, hipMalloc(&d, sizeof(P16Params)));
         LH_HIP(ctx, hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
@@ -183,6 +184,7 @@ extern "C" int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds
     for (int i = 0; i < rounds_p; i++) h.int_rc[i] = bb::to_monty(int_rc[i] % bb::P);
     for (int i = 0; i < 16; i++) h.diag[i] = bb::to_monty(diag[i] % bb::P);
     h.rounds_p = rounds_p;
+    h.finish();
     LH_HIP(ctx, hipMemcpyAsync(ctx->merkle_params_dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     *(P16Params*)ctx->merkle_params_host = h;

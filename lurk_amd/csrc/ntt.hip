@@ -62,6 +62,13 @@ struct PassArgs {
     int bitrev_store;  // store row r at bitrev(r, log_n)
     uint32_t magic_c;  // ceil(2^32 / col_chunk): e / C == umulhi(e, magic) for e < 2^17, C < 2^10
     uint32_t magic_c2; // same for C / 2 (two-column butterflies), 0 when C is odd
+    uint32_t magic_last;   // the same pair for the ragged last column chunk (w % col_chunk columns)
+    uint32_t magic_last2;
+    // Row grouping for narrow matrices: a tile takes 2^log_l ADJACENT rows (consecutive values of the low row bits)
+    // for each of its 2^log_r strided rows, so that every global access is a contiguous run of (w << log_l) words
+    // instead of w.  Then col_chunk = w << log_l (one chunk) and magic_w divides a tile column by w.
+    int log_l;
+    uint32_t magic_w;
 };
 
 __device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
@@ -70,52 +77,59 @@ __device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
 
 // One pass: tile = rows { hi << (bit_lo+log_r) | t << bit_lo | lo : t < 2^log_r } x col_chunk columns.
 // LDS: [R][C] tile followed by the pass's twiddles: tw_lds[(1 << s) + t_lo] for stage s.
-__global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
+__global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
+    const int NT = (int)blockDim.x;  // 256, or 1024 for large tiles: the stages are a latency chain per workgroup
     extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
     const int R = 1 << a.log_r;
-    const int n_col_chunks = (a.w + a.col_chunk - 1) / a.col_chunk;
+    const int n_col_chunks = a.log_l ? 1 : (a.w + a.col_chunk - 1) / a.col_chunk;
     const uint32_t tile_id = blockIdx.x / n_col_chunks;
     const int chunk = blockIdx.x - tile_id * n_col_chunks;
     const int col0 = chunk * a.col_chunk;
-    const int C = min(a.col_chunk, a.w - col0);
-    const bool full_chunk = C == a.col_chunk;
-    const uint32_t lo_mask = (1u << a.bit_lo) - 1u;
-    const uint32_t lo = tile_id & lo_mask;
-    const uint32_t hi = tile_id >> a.bit_lo;
+    const int C = a.log_l ? a.col_chunk : min(a.col_chunk, a.w - col0);
+    const bool is_full = C == a.col_chunk;
+    // every chunk takes the multiply-high division: the ragged last chunk has its own magic numbers
+    const bool full_chunk = true;
+    const uint32_t mg = is_full ? a.magic_c : a.magic_last, mg2 = is_full ? a.magic_c2 : a.magic_last2;
+    const int L = 1 << a.log_l;
+    const uint32_t lo_bits = (uint32_t)(a.bit_lo - a.log_l);
+    const uint32_t lo = (tile_id & ((1u << lo_bits) - 1u)) << a.log_l;  // first of the tile's L adjacent low-bit values
+    const uint32_t hi = tile_id >> lo_bits;
     const uint32_t row_base = (hi << (a.bit_lo + a.log_r)) | lo;
     uint32_t* tw_lds = tile + R * a.col_chunk;
 
     const int total = R * C;
-    // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | lo
-    for (int k = threadIdx.x + 1; k < R; k += NTT_BLOCK) {
+    // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l); stored at [k * L + l]
+    for (int idx = threadIdx.x + L; idx < R * L; idx += NT) {
+        int k = idx >> a.log_l, l = idx & (L - 1);
         int s = 31 - __clz(k);
         uint32_t t_lo = (uint32_t)k - (1u << s);
-        uint32_t j = (t_lo << a.bit_lo) | lo;
-        tw_lds[k] = a.tw[(size_t)j << (a.log_n - a.bit_lo - s - 1)];
+        uint32_t j = (t_lo << a.bit_lo) | (lo + (uint32_t)l);
+        tw_lds[idx] = a.tw[(size_t)j << (a.log_n - a.bit_lo - s - 1)];
     }
-    // load
-    for (int e = threadIdx.x; e < total; e += NTT_BLOCK) {
-        int t = full_chunk ? fast_div(e, a.magic_c, C) : e / C;
+    // load: tile row t = the L adjacent matrix rows row_base | t << bit_lo .. + L - 1, contiguous in memory
+    for (int e = threadIdx.x; e < total; e += NT) {
+        int t = fast_div(e, mg, C);
         int c = e - t * C;
         uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
         uint32_t v = a.in[(size_t)row * a.w + col0 + c];
         if (a.in_canonical) v = bb::to_monty(v);
-        if (a.row_scale) v = bb::mul(v, a.row_scale[row]);
+        if (a.row_scale) v = bb::mul(v, a.row_scale[row + (a.log_l ? (uint32_t)fast_div((uint32_t)c, a.magic_w, a.w) : 0u)]);
         tile[e] = v;
     }
     __syncthreads();
     // DIF stages: s = log_r-1 .. 0, pair distance 2^s tile rows
-    if (full_chunk && a.magic_c2) {
+    if (full_chunk && mg2) {
         // two adjacent columns per lane (8-byte LDS accesses; C is even so rows stay 8-byte aligned)
         const int C2 = C >> 1;
         const int half_total = (R >> 1) * C2;
         uint2* tile2 = reinterpret_cast<uint2*>(tile);
         for (int s = a.log_r - 1; s >= 0; s--) {
-            for (int e = threadIdx.x; e < half_total; e += NTT_BLOCK) {
-                int p = fast_div(e, a.magic_c2, C2), c = e - p * C2;
+            for (int e = threadIdx.x; e < half_total; e += NT) {
+                int p = fast_div(e, mg2, C2), c = e - p * C2;
                 int t_lo = p & ((1 << s) - 1);
                 int t = ((p >> s) << (s + 1)) | t_lo;
-                uint32_t twv = tw_lds[(1 << s) + t_lo];
+                int l = a.log_l ? fast_div((uint32_t)(2 * c), a.magic_w, a.w) : 0;
+                uint32_t twv = tw_lds[(((1 << s) + t_lo) << a.log_l) + l];
                 int i0 = t * C2 + c, i1 = i0 + (C2 << s);
                 uint2 x = tile2[i0], y = tile2[i1];
                 tile2[i0] = make_uint2(bb::add(x.x, y.x), bb::add(x.y, y.y));
@@ -127,12 +141,13 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
     } else {
         const int half_total = (R >> 1) * C;
         for (int s = a.log_r - 1; s >= 0; s--) {
-            for (int e = threadIdx.x; e < half_total; e += NTT_BLOCK) {
-                int p = full_chunk ? fast_div(e, a.magic_c, C) : e / C;
+            for (int e = threadIdx.x; e < half_total; e += NT) {
+                int p = fast_div(e, mg, C);
                 int c = e - p * C;
                 int t_lo = p & ((1 << s) - 1);
                 int t = ((p >> s) << (s + 1)) | t_lo;
-                uint32_t twv = tw_lds[(1 << s) + t_lo];
+                int l = a.log_l ? fast_div((uint32_t)c, a.magic_w, a.w) : 0;
+                uint32_t twv = tw_lds[(((1 << s) + t_lo) << a.log_l) + l];
                 int i0 = t * C + c, i1 = i0 + (C << s);
                 uint32_t x = tile[i0], y = tile[i1];
                 tile[i0] = bb::add(x, y);
@@ -142,8 +157,8 @@ __global__ __launch_bounds__(NTT_BLOCK) void k_ntt_pass(PassArgs a) {
         }
     }
     // store
-    for (int e = threadIdx.x; e < total; e += NTT_BLOCK) {
-        int t = full_chunk ? fast_div(e, a.magic_c, C) : e / C;
+    for (int e = threadIdx.x; e < total; e += NT) {
+        int t = fast_div(e, mg, C);
         int c = e - t * C;
         uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
         if (a.bitrev_store) row = bitrev32(row, a.log_n);
@@ -232,13 +247,26 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         // 1 x w: identity (times scale)
         PassArgs a{src, dst, plan.tw_fwd, row_scale, 0, w, 0, 0, w < 64 ? w : 64, in_canonical, out_canonical, 0, 0, 0};
         a.magic_c = magic_for(a.col_chunk);
+        a.magic_last = (w % a.col_chunk) ? magic_for(w % a.col_chunk) : 0;
+        a.magic_last2 = 0;
+        a.log_l = 0;
+        a.magic_w = 0;
         int chunks = (w + a.col_chunk - 1) / a.col_chunk;
         hipLaunchKernelGGL(k_ntt_pass, dim3(chunks), dim3(NTT_BLOCK), (size_t)(a.col_chunk + 1) * 4, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         return LURKHIP_OK;
     }
-    // tile budget: rows * cols * 4 B <= 64 KiB so two blocks fit a CU
-    int col_chunk = w < 96 ? w : 64;
+    // tile budget: rows * cols * 4 B <= 64 KiB so two blocks fit a CU.  Prefer a chunk width that divides w (no
+    // ragged chunk) and is even (two-column butterflies): the largest such divisor in [32, 112], else 64.
+    int col_chunk = w;
+    if (w > 112) {
+        col_chunk = 64;
+        for (int c = 112; c >= 32; c--)
+            if (w % c == 0 && c % 2 == 0) {
+                col_chunk = c;
+                break;
+            }
+    }
     int max_log_r = 7;
     while (((size_t)1 << max_log_r) * col_chunk * 4 > 64 * 1024 && max_log_r > 1) max_log_r--;
     std::vector<std::pair<int, int>> passes;
@@ -266,10 +294,29 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         a.bitrev_store = (last && bitrev_store) ? 1 : 0;
         a.magic_c = magic_for(col_chunk);
         a.magic_c2 = (col_chunk % 2 == 0 && col_chunk >= 4) ? magic_for(col_chunk / 2) : 0;
-        size_t tiles = ((size_t)1 << (log_n - a.log_r)) * n_chunks;
+        // narrow matrices: group adjacent rows in the strided passes so that global runs are >= ~256 bytes
+        int log_l = 0;
+        if (n_chunks == 1 && a.bit_lo > 0 && !a.bitrev_store) {
+            while (log_l < 4 && log_l < a.bit_lo && (w << (log_l + 1)) <= 128 &&
+                   ((size_t)1 << a.log_r) * ((size_t)(w << (log_l + 1)) + (1u << (log_l + 1))) * 4 <= 64 * 1024)
+                log_l++;
+        }
+        a.log_l = log_l;
+        a.magic_w = magic_for(w);
+        if (log_l > 0) {
+            a.col_chunk = w << log_l;
+            a.magic_c = magic_for(a.col_chunk);
+            a.magic_c2 = (w % 2 == 0 && a.col_chunk >= 4) ? magic_for(a.col_chunk / 2) : 0;
+        }
+        const int last_w = w % col_chunk;
+        a.magic_last = last_w ? magic_for(last_w) : 0;
+        a.magic_last2 = (last_w && last_w % 2 == 0 && last_w >= 4) ? magic_for(last_w / 2) : 0;
+        size_t tiles = ((size_t)1 << (log_n - a.log_r - a.log_l)) * n_chunks;
         LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
-        size_t lds = ((size_t)1 << a.log_r) * (col_chunk + 1) * 4;  // tile + per-pass twiddles
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(NTT_BLOCK), lds, ctx->stream, a);
+        size_t lds = ((size_t)1 << a.log_r) * ((size_t)a.col_chunk + ((size_t)1 << a.log_l)) * 4;  // tile + per-pass twiddles
+        const size_t tile_elems = ((size_t)1 << a.log_r) * a.col_chunk;
+        const int threads = tile_elems >= 4096 ? 1024 : (tile_elems >= 2048 ? 512 : NTT_BLOCK);
+        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(threads), lds, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         cur_in = cur_out;
     }

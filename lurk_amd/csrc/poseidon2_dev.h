@@ -35,6 +35,8 @@ struct Params {
     uint32_t ext_rc[8 * W];
     uint32_t int_rc[RP];
     uint32_t diag[W];
+    uint32_t ext_rc_mp[8 * W];  // rc - p (mod 2^32): operands of the signed S-box chain (bb::add_pow7_mp)
+    uint32_t int_rc_mp[RP];
 };
 template <int W, int RP>
 constexpr Params<W, RP> make_params(const uint32_t (&ext)[8 * W], const uint32_t (&in)[RP], const uint32_t (&d)[W]) {
@@ -42,6 +44,8 @@ constexpr Params<W, RP> make_params(const uint32_t (&ext)[8 * W], const uint32_t
     for (int i = 0; i < 8 * W; i++) p.ext_rc[i] = bb::c_to_monty(ext[i]);
     for (int i = 0; i < RP; i++) p.int_rc[i] = bb::c_to_monty(in[i]);
     for (int i = 0; i < W; i++) p.diag[i] = bb::c_to_monty(d[i]);
+    for (int i = 0; i < 8 * W; i++) p.ext_rc_mp[i] = p.ext_rc[i] - bb::P;
+    for (int i = 0; i < RP; i++) p.int_rc_mp[i] = p.int_rc[i] - bb::P;
     return p;
 }
 
@@ -112,6 +116,16 @@ __device__ __forceinline__ void internal_layer(uint32_t (&s)[W], const uint32_t*
     for (int i = 0; i < W; i++) s[i] = bb::add(bb::mul(s[i], diag[i]), sum);
 }
 
+struct NoRecord;
+template <class Rec>
+struct records_nothing {
+    static constexpr bool value = false;
+};
+template <>
+struct records_nothing<NoRecord> {
+    static constexpr bool value = true;
+};
+
 struct NoRecord {
     __device__ __forceinline__ void ext_state(int, int, uint32_t) {}
     __device__ __forceinline__ void end_ext_state(int) {}
@@ -125,16 +139,23 @@ struct NoRecord {
 };
 
 template <int W, class Rec>
-__device__ __forceinline__ void external_round(uint32_t (&s)[W], int r, const uint32_t* __restrict__ ext_rc, Rec& rec) {
+__device__ __forceinline__ void external_round(uint32_t (&s)[W], int r, const uint32_t* __restrict__ ext_rc,
+                                               const uint32_t* __restrict__ ext_rc_mp, Rec& rec) {
 #pragma unroll
     for (int i = 0; i < W; i++) rec.ext_state(r, i, s[i]);
     rec.end_ext_state(r);
+    if constexpr (records_nothing<Rec>::value) {
+        // nothing observes the intermediates: signed 4-instruction products, one correction per S-box
 #pragma unroll
-    for (int i = 0; i < W; i++) {
-        uint32_t x = bb::add(s[i], ext_rc[r * W + i]);
-        uint32_t x3 = bb::cube(x);
-        rec.ext_sbox(r, i, x3);
-        s[i] = bb::pow7_from_cube(x, x3);
+        for (int i = 0; i < W; i++) s[i] = bb::add_pow7_mp(s[i], ext_rc_mp[r * W + i]);
+    } else {
+#pragma unroll
+        for (int i = 0; i < W; i++) {
+            uint32_t x = bb::add(s[i], ext_rc[r * W + i]);
+            uint32_t x3 = bb::cube(x);
+            rec.ext_sbox(r, i, x3);
+            s[i] = bb::pow7_from_cube(x, x3);
+        }
     }
     rec.end_ext_sbox(r);
     external_layer<W>(s);
@@ -145,32 +166,37 @@ __device__ __forceinline__ void external_round(uint32_t (&s)[W], int r, const ui
 template <int W, class Rec>
 __device__ __forceinline__ void permute_core(uint32_t (&s)[W], int rounds_p, const uint32_t* __restrict__ ext_rc,
                                              const uint32_t* __restrict__ int_rc,
-                                             const uint32_t* __restrict__ diag, Rec& rec) {
+                                             const uint32_t* __restrict__ diag, const uint32_t* __restrict__ ext_rc_mp,
+                                             const uint32_t* __restrict__ int_rc_mp, Rec& rec) {
     external_layer<W>(s);
 #pragma unroll 1
-    for (int r = 0; r < 4; r++) external_round<W>(s, r, ext_rc, rec);
+    for (int r = 0; r < 4; r++) external_round<W>(s, r, ext_rc, ext_rc_mp, rec);
 #pragma unroll
     for (int i = 0; i < W; i++) rec.int_init(i, s[i]);
     rec.end_int_init();
 #pragma unroll 1
     for (int r = 0; r < rounds_p; r++) {
-        if (r > 0) rec.int_state0(r - 1, s[0]);
-        uint32_t x = bb::add(s[0], int_rc[r]);
-        uint32_t x3 = bb::cube(x);
-        rec.int_sbox(r, x3);
-        s[0] = bb::pow7_from_cube(x, x3);
+        if constexpr (records_nothing<Rec>::value) {
+            s[0] = bb::add_pow7_mp(s[0], int_rc_mp[r]);
+        } else {
+            if (r > 0) rec.int_state0(r - 1, s[0]);
+            uint32_t x = bb::add(s[0], int_rc[r]);
+            uint32_t x3 = bb::cube(x);
+            rec.int_sbox(r, x3);
+            s[0] = bb::pow7_from_cube(x, x3);
+        }
         internal_layer<W>(s, diag);
     }
     rec.end_internal();
 #pragma unroll 1
-    for (int r = 4; r < 8; r++) external_round<W>(s, r, ext_rc, rec);
+    for (int r = 4; r < 8; r++) external_round<W>(s, r, ext_rc, ext_rc_mp, rec);
 }
 
 template <int W>
 __device__ __forceinline__ void permute(uint32_t (&s)[W]) {
     NoRecord rec;
     const auto& p = Cfg<W>::params();
-    permute_core<W>(s, Cfg<W>::RP, p.ext_rc, p.int_rc, p.diag, rec);
+    permute_core<W>(s, Cfg<W>::RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, rec);
 }
 
 }  // namespace p2
