@@ -75,6 +75,52 @@ __device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
     return c == 1 ? (int)e : (int)__umulhi(e, magic);
 }
 
+
+// x <- x + y, y <- (x - y) * tw  (decimation in frequency); (x - y + P) < 2P is a valid Montgomery operand next to a
+// reduced twiddle
+__device__ __forceinline__ void dif_butterfly(uint32_t& x, uint32_t& y, uint32_t tw) {
+    const uint32_t sum = bb::add(x, y);
+    y = bb::mul(x + bb::P - y, tw);
+    x = sum;
+}
+__device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
+    dif_butterfly(x.x, y.x, tw);
+    dif_butterfly(x.y, y.y, tw);
+}
+
+// G consecutive DIF stages s_top .. s_top-G+1 of the LDS tile [R][Cv] (elements of type T = one or two columns).
+// Item (q, c): the 2^G rows t0 | b << s_bot, b < 2^G, of column c, where t0 is q with G zero bits inserted at s_bot.
+template <int G, class T>
+__device__ __forceinline__ void stage_group(T* __restrict__ tile, const uint32_t* __restrict__ tw_lds, int R, int Cv, int s_top, int log_l,
+                                            uint32_t magic_cv, uint32_t magic_w, int w, int cols_per_item, int NT) {
+    constexpr int M = 1 << G;
+    const int s_bot = s_top - G + 1;
+    const int items = (R >> G) * Cv;
+    for (int e = threadIdx.x; e < items; e += NT) {
+        const int q = fast_div(e, magic_cv, Cv), c = e - q * Cv;
+        const int low = q & ((1 << s_bot) - 1);
+        const int t0 = ((q >> s_bot) << (s_top + 1)) | low;
+        const int l = log_l ? fast_div((uint32_t)(cols_per_item * c), magic_w, w) : 0;
+        T x[M];
+#pragma unroll
+        for (int b = 0; b < M; b++) x[b] = tile[(t0 + (b << s_bot)) * Cv + c];
+#pragma unroll
+        for (int g = G - 1; g >= 0; g--) {
+            const int st = s_bot + g;  // stage: pair distance 2^g in b
+#pragma unroll
+            for (int b = 0; b < M; b++) {
+                if (b & (1 << g)) continue;
+                // twiddle index of the butterfly whose upper row is t0 | b << s_bot: its low `st` bits
+                const int t_lo = low | ((b & ((1 << g) - 1)) << s_bot);
+                const uint32_t tw = tw_lds[(((1 << st) + t_lo) << log_l) + l];
+                dif_butterfly(x[b], x[b | (1 << g)], tw);
+            }
+        }
+#pragma unroll
+        for (int b = 0; b < M; b++) tile[(t0 + (b << s_bot)) * Cv + c] = x[b];
+    }
+}
+
 // One pass: tile = rows { hi << (bit_lo+log_r) | t << bit_lo | lo : t < 2^log_r } x col_chunk columns.
 // LDS: [R][C] tile followed by the pass's twiddles: tw_lds[(1 << s) + t_lo] for stage s.
 __global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
@@ -88,7 +134,6 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
     const int C = a.log_l ? a.col_chunk : min(a.col_chunk, a.w - col0);
     const bool is_full = C == a.col_chunk;
     // every chunk takes the multiply-high division: the ragged last chunk has its own magic numbers
-    const bool full_chunk = true;
     const uint32_t mg = is_full ? a.magic_c : a.magic_last, mg2 = is_full ? a.magic_c2 : a.magic_last2;
     const int L = 1 << a.log_l;
     const uint32_t lo_bits = (uint32_t)(a.bit_lo - a.log_l);
@@ -97,7 +142,6 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
     const uint32_t row_base = (hi << (a.bit_lo + a.log_r)) | lo;
     uint32_t* tw_lds = tile + R * a.col_chunk;
 
-    const int total = R * C;
     // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l); stored at [k * L + l]
     for (int idx = threadIdx.x + L; idx < R * L; idx += NT) {
         int k = idx >> a.log_l, l = idx & (L - 1);
@@ -106,65 +150,56 @@ __global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
         uint32_t j = (t_lo << a.bit_lo) | (lo + (uint32_t)l);
         tw_lds[idx] = a.tw[(size_t)j << (a.log_n - a.bit_lo - s - 1)];
     }
-    // load: tile row t = the L adjacent matrix rows row_base | t << bit_lo .. + L - 1, contiguous in memory
-    for (int e = threadIdx.x; e < total; e += NT) {
-        int t = fast_div(e, mg, C);
-        int c = e - t * C;
-        uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
-        uint32_t v = a.in[(size_t)row * a.w + col0 + c];
-        if (a.in_canonical) v = bb::to_monty(v);
-        if (a.row_scale) v = bb::mul(v, a.row_scale[row + (a.log_l ? (uint32_t)fast_div((uint32_t)c, a.magic_w, a.w) : 0u)]);
-        tile[e] = v;
+    // load: tile row t = the L adjacent matrix rows row_base | t << bit_lo .. + L - 1, contiguous in memory.
+    // Thread (tr, tc) walks rows tr, tr + RS, ... of column tc: one division per thread, none per element.
+    const int RS = NT / C;                       // tile rows covered per sweep (C <= 128 <= NT)
+    const int tr = (int)threadIdx.x / C, tc = (int)threadIdx.x - tr * C;
+    const bool lane_on = tr < RS;
+    const uint32_t l_of_tc = a.log_l ? (uint32_t)fast_div((uint32_t)tc, a.magic_w, a.w) : 0u;
+    if (lane_on) {
+        const uint32_t* __restrict__ src = a.in + col0 + tc;
+        for (int t = tr; t < R; t += RS) {
+            const uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
+            uint32_t v = src[(size_t)row * a.w];
+            if (a.in_canonical) v = bb::to_monty(v);
+            if (a.row_scale) v = bb::mul(v, a.row_scale[row + l_of_tc]);
+            tile[t * C + tc] = v;
+        }
     }
     __syncthreads();
-    // DIF stages: s = log_r-1 .. 0, pair distance 2^s tile rows
-    if (full_chunk && mg2) {
-        // two adjacent columns per lane (8-byte LDS accesses; C is even so rows stay 8-byte aligned)
-        const int C2 = C >> 1;
-        const int half_total = (R >> 1) * C2;
-        uint2* tile2 = reinterpret_cast<uint2*>(tile);
-        for (int s = a.log_r - 1; s >= 0; s--) {
-            for (int e = threadIdx.x; e < half_total; e += NT) {
-                int p = fast_div(e, mg2, C2), c = e - p * C2;
-                int t_lo = p & ((1 << s) - 1);
-                int t = ((p >> s) << (s + 1)) | t_lo;
-                int l = a.log_l ? fast_div((uint32_t)(2 * c), a.magic_w, a.w) : 0;
-                uint32_t twv = tw_lds[(((1 << s) + t_lo) << a.log_l) + l];
-                int i0 = t * C2 + c, i1 = i0 + (C2 << s);
-                uint2 x = tile2[i0], y = tile2[i1];
-                tile2[i0] = make_uint2(bb::add(x.x, y.x), bb::add(x.y, y.y));
-                // (x - y + P) < 2P is a valid Montgomery operand next to a reduced twiddle
-                tile2[i1] = make_uint2(bb::mul(x.x + bb::P - y.x, twv), bb::mul(x.y + bb::P - y.y, twv));
-            }
-            __syncthreads();
+    // DIF stages s = log_r-1 .. 0 (pair distance 2^s tile rows), taken in groups of up to three: a thread holds the
+    // 2^g rows of one column (or column pair) in registers for g consecutive stages, so the tile makes one LDS round
+    // trip -- and one index computation -- per group instead of per stage (the passes are int32-issue bound).
+    const bool pairs = mg2 != 0;  // two adjacent columns per lane (8-byte LDS accesses; C even, rows 8-byte aligned)
+    const int Cv = pairs ? (C >> 1) : C;
+    const uint32_t mgv = pairs ? mg2 : mg;
+    int remaining = a.log_r, s_top = a.log_r - 1;
+    while (remaining > 0) {
+        const int g = remaining == 4 ? 2 : (remaining >= 3 ? 3 : remaining);
+        if (pairs) {
+            uint2* t2 = reinterpret_cast<uint2*>(tile);
+            if (g == 3) stage_group<3, uint2>(t2, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 2, NT);
+            else if (g == 2) stage_group<2, uint2>(t2, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 2, NT);
+            else stage_group<1, uint2>(t2, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 2, NT);
+        } else {
+            if (g == 3) stage_group<3, uint32_t>(tile, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 1, NT);
+            else if (g == 2) stage_group<2, uint32_t>(tile, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 1, NT);
+            else stage_group<1, uint32_t>(tile, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 1, NT);
         }
-    } else {
-        const int half_total = (R >> 1) * C;
-        for (int s = a.log_r - 1; s >= 0; s--) {
-            for (int e = threadIdx.x; e < half_total; e += NT) {
-                int p = fast_div(e, mg, C);
-                int c = e - p * C;
-                int t_lo = p & ((1 << s) - 1);
-                int t = ((p >> s) << (s + 1)) | t_lo;
-                int l = a.log_l ? fast_div((uint32_t)c, a.magic_w, a.w) : 0;
-                uint32_t twv = tw_lds[(((1 << s) + t_lo) << a.log_l) + l];
-                int i0 = t * C + c, i1 = i0 + (C << s);
-                uint32_t x = tile[i0], y = tile[i1];
-                tile[i0] = bb::add(x, y);
-                tile[i1] = bb::mul(x + bb::P - y, twv);
-            }
-            __syncthreads();
-        }
+        __syncthreads();
+        remaining -= g;
+        s_top -= g;
     }
-    // store
-    for (int e = threadIdx.x; e < total; e += NT) {
-        int t = fast_div(e, mg, C);
-        int c = e - t * C;
-        uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
-        if (a.bitrev_store) row = bitrev32(row, a.log_n);
-        uint32_t v = tile[e];
-        if (a.out_canonical) v = bb::from_monty(v);
-        a.out[(size_t)row * a.w + col0 + c] = v;
+    // store (same thread-to-element map as the load)
+    if (lane_on) {
+        uint32_t* __restrict__ dst = a.out + col0 + tc;
+        for (int t = tr; t < R; t += RS) {
+            uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
+            if (a.bitrev_store) row = bitrev32(row, a.log_n);
+            uint32_t v = tile[t * C + tc];
+            if (a.out_canonical) v = bb::from_monty(v);
+            dst[(size_t)row * a.w] = v;
+        }
     }
 }
 
@@ -315,7 +350,9 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
         size_t lds = ((size_t)1 << a.log_r) * ((size_t)a.col_chunk + ((size_t)1 << a.log_l)) * 4;  // tile + per-pass twiddles
         const size_t tile_elems = ((size_t)1 << a.log_r) * a.col_chunk;
-        const int threads = tile_elems >= 4096 ? 1024 : (tile_elems >= 2048 ? 512 : NTT_BLOCK);
+        // many tiles: 256-thread workgroups (several per CU overlap each other's load / stage / store phases);
+        // few tiles: the per-workgroup latency chain dominates, so spread each tile over up to 1024 threads
+        const int threads = tile_elems >= 4096 ? (tiles >= 4096 ? 512 : 1024) : (tile_elems >= 2048 ? 512 : NTT_BLOCK);
         hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(threads), lds, ctx->stream, a);
         LH_HIP(ctx, hipGetLastError());
         cur_in = cur_out;
