@@ -16,6 +16,7 @@ from oracle import stark as os_
 
 pytestmark = pytest.mark.gpu
 DEMO = load_cases()[0]["source"]
+LOG_ROWS_LARGE = 20  # BASELINE.json configs[2]
 
 
 def oracle_airs(src, entry, n_public):
@@ -151,3 +152,18 @@ def test_u64_gadget_machine_proves_and_verifies(ctx):
     airs = [oa.EntrypointAir(otop.index["u64_ops"], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
     airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
     assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+
+
+def test_large_shard_proof_verifies(ctx):
+    """The bench workload itself: a 2^20-row eval shard (LDE height 2^22 for the callee chip) with the bench FRI parameters: the verifier's work is
+    independent of the trace height except for the Merkle path lengths, so the full-size pipeline (multi-chunk scans,
+    3-pass NTTs, k_top tails, 18 FRI layers) is checked end to end."""
+    top = lair.Toplevel(se.SOURCE)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(se.FUNC, se.args_for_rows(1 << LOG_ROWS_LARGE), q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, se.FUNC, len(pv))
+    root = m.setup()
+    proofs = m.prove(q, num_queries=100, pow_bits=16)
+    assert proofs[0].log_max_height == LOG_ROWS_LARGE + 2
+    assert verify(se.SOURCE, se.FUNC, root, proofs, len(pv))
