@@ -197,16 +197,28 @@ std::vector<Chip> lurk_chip_map() {
 }
 
 // ------------------------------------------------------------------ query maps
-uint32_t QueryMap::insert_full(const List& k, QueryResult v) {
-    auto it = index.find(k);
-    if (it != index.end()) {
-        vals[it->second] = std::move(v);
-        return it->second;
+void QueryMap::grow() {
+    const size_t cap = slots.empty() ? 1024 : slots.size() * 2;
+    slots.assign(cap, 0);
+    const size_t mask = cap - 1;
+    for (size_t i = 0; i < vals.size(); i++) {
+        size_t s = hash(key(i), key_len) & mask;
+        while (slots[s]) s = (s + 1) & mask;
+        slots[s] = (uint32_t)i + 1;
     }
-    uint32_t i = (uint32_t)keys.size();
-    keys.push_back(k);
-    vals.push_back(std::move(v));
-    index.emplace(k, i);
+}
+
+uint32_t QueryMap::push(const uint32_t* k, uint32_t n, const QueryResult& v) {
+    if (vals.empty()) key_len = n;
+    if (n != key_len) throw ExecError("query table key length changed");
+    if ((vals.size() + 1) * 2 > slots.size()) grow();
+    const uint32_t i = (uint32_t)vals.size();
+    key_pool.insert(key_pool.end(), k, k + n);
+    vals.push_back(v);
+    const size_t mask = slots.size() - 1;
+    size_t s = hash(k, n) & mask;
+    while (slots[s]) s = (s + 1) & mask;
+    slots[s] = i + 1;
     return i;
 }
 
@@ -277,7 +289,7 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
     {
         QueryResult top;
         top.provide.count = 1;
-        q.func_queries[func_index].insert_full(args, std::move(top));
+        q.func_queries[func_index].insert_full(args, top);
     }
     uint32_t nonce = (uint32_t)q.func_queries[func_index].find(args);
     List map = args;
@@ -358,14 +370,19 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                     } else {
                         inp = key;
                     }
-                    int idx = q.func_queries[callee].find(inp);
+                    QueryMap& cqm = q.func_queries[callee];
+                    int idx = cqm.find(inp);
                     if (idx >= 0) {
-                        QueryResult& res = q.func_queries[callee].vals[idx];
+                        QueryResult& res = cqm.vals[idx];
                         if (!res.has_output) throw ExecError("Loop detected");
-                        if (pre && res.output != key) throw ExecError("memoized output differs from preimage key");
-                        const List& ext = pre ? inp : res.output;
-                        map.insert(map.end(), ext.begin(), ext.end());
-                        hints.insert(hints.end(), ext.begin(), ext.end());
+                        const uint32_t n_out = t.funcs[callee].output_size;
+                        const uint32_t* res_out = cqm.output(res);
+                        if (pre && (key.size() != n_out || memcmp(res_out, key.data(), (size_t)n_out * 4) != 0))
+                            throw ExecError("memoized output differs from preimage key");
+                        const uint32_t* ext = pre ? inp.data() : res_out;
+                        const size_t n_ext = pre ? inp.size() : n_out;
+                        map.insert(map.end(), ext, ext + n_ext);
+                        hints.insert(hints.end(), ext, ext + n_ext);
                         requires_.push_back(res.provide.new_lookup(nonce));
                         const bool callee_partial = t.funcs[callee].partial;
                         if (callee_partial) hints.push_back(res.depth);
@@ -409,9 +426,9 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                     uint32_t ptr = map[op.y];
                     QueryMap& mm = q.mem_queries[mem_index_from_len(op.x)];
                     if (ptr == 0 || ptr > mm.size()) throw ExecError("Unbound pointer");
-                    const List& vals = mm.keys[ptr - 1];
-                    map.insert(map.end(), vals.begin(), vals.end());
-                    hints.insert(hints.end(), vals.begin(), vals.end());
+                    const uint32_t* vals = mm.key(ptr - 1);
+                    map.insert(map.end(), vals, vals + op.x);
+                    hints.insert(hints.end(), vals, vals + op.x);
                     requires_.push_back(mm.vals[ptr - 1].provide.new_lookup(nonce));
                     break;
                 }
@@ -464,7 +481,7 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
         QueryMap& qm = q.func_queries[func_index];
         QueryResult& result = qm.vals[nonce];
         if (result.has_output) throw ExecError("query evaluated twice");
-        const List inp = qm.keys[nonce];
+        const List inp(qm.key(nonce), qm.key(nonce) + qm.key_len);
         if (q.inv_func_queries[func_index]) (*q.inv_func_queries[func_index])[out] = inp;
         if (partial) {
             uint32_t depth = 0;
@@ -474,11 +491,22 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
             for (uint32_t d : depths) depth_less_than_populate(d, depth, q.bytes, nonce, depth_requires);
             result.depth = depth;
         }
-        result.output = out;
+        // finalize: the frame's accumulators move into the table's pools
+        result.out_off = (uint32_t)qm.pool.size();
+        qm.pool.insert(qm.pool.end(), out.begin(), out.end());
+        result.hint_off = (uint32_t)qm.pool.size();
+        result.n_hints = (uint32_t)hints.size();
+        qm.pool.insert(qm.pool.end(), hints.begin(), hints.end());
+        result.req_off = (uint32_t)qm.rec_pool.size();
+        result.n_requires = (uint32_t)requires_.size();
+        result.n_depth_requires = (uint32_t)depth_requires.size();
+        qm.rec_pool.insert(qm.rec_pool.end(), requires_.begin(), requires_.end());
+        qm.rec_pool.insert(qm.rec_pool.end(), depth_requires.begin(), depth_requires.end());
+        if (qm.pool.size() > 0xfffffff0ull || qm.rec_pool.size() > 0xfffffff0ull) throw ExecError("query table pools exceed 2^32 words");
         result.has_output = true;
-        result.requires_ = std::move(requires_);
-        result.depth_requires = std::move(depth_requires);
-        result.hints = std::move(hints);
+        requires_.clear();
+        depth_requires.clear();
+        hints.clear();
         if (callers.empty()) {
             if (!stack.empty()) throw ExecError("exec stack not empty at exit");
             uint32_t depth = 0;

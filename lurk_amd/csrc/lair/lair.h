@@ -12,6 +12,8 @@
 #pragma once
 #include <stdint.h>
 
+#include <string.h>
+
 #include <map>
 #include <memory>
 #include <stdexcept>
@@ -203,16 +205,17 @@ constexpr int DEPTH_LESS_THAN_SIZE = 6;    // provenance.rs:121
 constexpr int DEPTH_LT_REQUIRES = 1;
 
 // ---------------------------------------------------------------- execution (execute.rs)
+// Result of one query.  Everything of variable length lives in the owning QueryMap's pools (one allocation per
+// table instead of four per query: the interpreter is memory-bound on multi-million-query executions).
 struct QueryResult {
     bool has_output = false;
-    List output;
-    Record provide;
-    std::vector<Record> requires_;
     uint32_t depth = 0;
-    std::vector<Record> depth_requires;
-    // values the row's trace needs that the reference re-derives by hash-map lookups at trace time
-    // (callee outputs, preimages, pointers, loaded values, callee depths), in bytecode order
-    List hints;
+    Record provide;
+    uint32_t out_off = 0;                 // QueryMap::pool: the output (length = the function's output size)
+    uint32_t hint_off = 0, n_hints = 0;   // QueryMap::pool: values the row's trace needs that the reference re-derives by
+                                          // hash-map lookups at trace time (callee outputs, preimages, pointers, loaded
+                                          // values, callee depths), in bytecode order
+    uint32_t req_off = 0, n_requires = 0, n_depth_requires = 0;  // QueryMap::rec_pool: requires, then depth requires
 };
 
 struct VecHash {
@@ -226,23 +229,59 @@ struct VecHash {
     }
 };
 
-// insertion-ordered map List -> QueryResult (indexmap::IndexMap)
+// Insertion-ordered map key -> QueryResult (indexmap::IndexMap): flat key pool (all keys of a table have the same
+// length: a function's inputs, a memory table's width), open-addressing index.
 struct QueryMap {
-    std::vector<List> keys;
+    uint32_t key_len = 0;
+    std::vector<uint32_t> key_pool;   // [n][key_len]
     std::vector<QueryResult> vals;
-    std::unordered_map<List, uint32_t, VecHash> index;
-    size_t size() const { return keys.size(); }
-    int find(const List& k) const {
-        auto it = index.find(k);
-        return it == index.end() ? -1 : (int)it->second;
+    std::vector<uint32_t> pool;       // outputs and hints
+    std::vector<Record> rec_pool;     // require records
+    std::vector<uint32_t> slots;      // entry index + 1, 0 = empty; power-of-two size
+    size_t size() const { return vals.size(); }
+    const uint32_t* key(size_t i) const { return key_pool.data() + i * key_len; }
+    static uint64_t hash(const uint32_t* k, uint32_t n) {
+        uint64_t h = 0x9e3779b97f4a7c15ull ^ n;
+        for (uint32_t i = 0; i < n; i++) {
+            h = (h ^ k[i]) * 0xff51afd7ed558ccdull;
+            h ^= h >> 29;
+        }
+        return h;
     }
-    // insert_full: replaces the value when the key exists (IndexMap semantics)
-    uint32_t insert_full(const List& k, QueryResult v);
+    int find(const uint32_t* k, uint32_t n) const {
+        if (slots.empty() || n != key_len) return -1;
+        const size_t mask = slots.size() - 1;
+        for (size_t s = hash(k, n) & mask;; s = (s + 1) & mask) {
+            const uint32_t e = slots[s];
+            if (!e) return -1;
+            if (memcmp(key(e - 1), k, (size_t)n * 4) == 0) return (int)(e - 1);
+        }
+    }
+    int find(const List& k) const { return find(k.data(), (uint32_t)k.size()); }
+    // appends a new entry (the key must be absent); returns its index
+    uint32_t push(const uint32_t* k, uint32_t n, const QueryResult& v);
+    // IndexMap::insert_full: replaces the value when the key exists
+    uint32_t insert_full(const List& k, const QueryResult& v) {
+        int i = find(k);
+        if (i >= 0) {
+            vals[i] = v;
+            return (uint32_t)i;
+        }
+        return push(k.data(), (uint32_t)k.size(), v);
+    }
+    const uint32_t* output(const QueryResult& r) const { return pool.data() + r.out_off; }
+    const uint32_t* hints(const QueryResult& r) const { return pool.data() + r.hint_off; }
+    const Record* requires_of(const QueryResult& r) const { return rec_pool.data() + r.req_off; }
     void clear() {
-        keys.clear();
+        key_pool.clear();
         vals.clear();
-        index.clear();
+        pool.clear();
+        rec_pool.clear();
+        slots.clear();
     }
+
+   private:
+    void grow();
 };
 
 constexpr int NUM_MEM_TABLES = 6;

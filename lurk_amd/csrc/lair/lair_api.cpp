@@ -232,28 +232,25 @@ int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, cons
         std::vector<lair::RowMeta> meta(n);
         std::vector<uint32_t> stream;
         for (uint32_t i = 0; i < n; i++) {
-            const lair::List& key = qm.keys[start + i];
+            const uint32_t* key = qm.key(start + i);
             const lair::QueryResult& res = qm.vals[start + i];
             if (!res.has_output) throw lair::ExecError("Result not computed");
-            memcpy(&args[(size_t)i * f.input_size], key.data(), f.input_size * 4);
-            memcpy(&outs[(size_t)i * f.output_size], res.output.data(), f.output_size * 4);
+            memcpy(&args[(size_t)i * f.input_size], key, f.input_size * 4);
+            memcpy(&outs[(size_t)i * f.output_size], qm.output(res), f.output_size * 4);
             prov[2 * (size_t)i] = res.provide.nonce;
             prov[2 * (size_t)i + 1] = res.provide.count;
             depths[i] = res.depth;
-            if (stream.size() + res.hints.size() + 2 * (res.requires_.size() + res.depth_requires.size()) > 0xffffff00ull)
+            if (stream.size() + res.n_hints + 2 * ((size_t)res.n_requires + res.n_depth_requires) > 0xffffff00ull)
                 throw lair::ExecError("row stream exceeds 2^32 words; use a smaller shard");
             meta[i].offset = (uint32_t)stream.size();
-            meta[i].n_hints = (uint32_t)res.hints.size();
-            meta[i].n_requires = (uint32_t)res.requires_.size();
-            meta[i].n_depth_requires = (uint32_t)res.depth_requires.size();
-            stream.insert(stream.end(), res.hints.begin(), res.hints.end());
-            for (const auto& q : res.requires_) {
-                stream.push_back(q.nonce);
-                stream.push_back(q.count);
-            }
-            for (const auto& q : res.depth_requires) {
-                stream.push_back(q.nonce);
-                stream.push_back(q.count);
+            meta[i].n_hints = res.n_hints;
+            meta[i].n_requires = res.n_requires;
+            meta[i].n_depth_requires = res.n_depth_requires;
+            stream.insert(stream.end(), qm.hints(res), qm.hints(res) + res.n_hints);
+            const lair::Record* recs = qm.requires_of(res);  // requires, then depth requires
+            for (uint32_t k = 0; k < res.n_requires + res.n_depth_requires; k++) {
+                stream.push_back(recs[k].nonce);
+                stream.push_back(recs[k].count);
             }
         }
         // ---- one staging buffer: program | args | outs | prov | depths | meta | stream
@@ -323,7 +320,7 @@ int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uin
         const uint32_t n = (uint32_t)mm.size();
         std::vector<uint32_t> host((size_t)n * (mem_len + 2) + 4, 0);
         for (uint32_t i = 0; i < n; i++) {
-            memcpy(&host[(size_t)i * mem_len], mm.keys[i].data(), mem_len * 4);
+            memcpy(&host[(size_t)i * mem_len], mm.key(i), mem_len * 4);
             host[(size_t)n * mem_len + 2 * i] = mm.vals[i].provide.nonce;
             host[(size_t)n * mem_len + 2 * i + 1] = mm.vals[i].provide.count;
         }
@@ -450,7 +447,7 @@ int32_t lurkhip_generate_trace_mem(lurkhip_ctx* ctx, const lurkhip_record* r, ui
         const uint32_t n = (uint32_t)mm.size(), height = std::max(4u, next_pow2(n)), width = 4 + mem_len;
         std::vector<uint32_t> host((size_t)n * (mem_len + 2) + 1);
         for (uint32_t i = 0; i < n; i++) {
-            memcpy(&host[(size_t)i * mem_len], mm.keys[i].data(), mem_len * 4);
+            memcpy(&host[(size_t)i * mem_len], mm.key(i), mem_len * 4);
             host[(size_t)n * mem_len + 2 * i] = mm.vals[i].provide.nonce;
             host[(size_t)n * mem_len + 2 * i + 1] = mm.vals[i].provide.count;
         }
