@@ -197,12 +197,15 @@ def main():
     hash_launches_step = sum(merkle_hash_bytes(r)[1] for r in rounds)
     hash_ms_step = (spans["merkle_leaves"][0] + spans["merkle_levels"][0]) / args.steps
     achieved = hash_bytes_step / (hash_ms_step * 1e-3) / 1e9 if hash_ms_step > 0 else 0.0
-    traffic = None
+    traffic, valu = None, None
     try:  # HBM bytes per step of the same kernels from the rocprofv3 PMC passes (profiles/)
         with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("log_rows") == log_rows:
             traffic = pmc["merkle_hash_bytes_per_step"]
+            valu = {"achieved": pmc["merkle_hash_valu_tinst_s"], "peak": pmc["int32_valu_peak_tinst_s"], "unit": "Tinstr/s",
+                    "frac": pmc["merkle_hash_valu_tinst_s"] / pmc["int32_valu_peak_tinst_s"],
+                    "source": "SQ_INSTS_VALU x 64 lanes / kernel time, profiles/r01_pmc_sq_per_kernel.csv"}
     except Exception:
         pass
 
@@ -239,10 +242,11 @@ def main():
                 "unit": "GB/s",
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
+                "int32_valu": valu,
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,
                 "ms_per_step": hash_ms_step,
-                "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (~8.3 k int32 instructions each) per w*4-byte row; at the 39 Tinstr/s int32 issue peak this kernel cannot exceed ~0.4 TB/s algorithmic (DESIGN.md 3.4)",
+                "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (~7.2 k int32 instructions each) per w*4-byte row; at the 39 Tinstr/s int32 issue peak this kernel cannot exceed ~0.4 TB/s algorithmic (DESIGN.md 3.4)",
             },
         }
         if world == 1 and not args.no_cpu_baseline:
