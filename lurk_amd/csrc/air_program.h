@@ -25,10 +25,13 @@ enum Header : uint32_t {
     H_CODE_OFF,
     H_CONST_OFF,
     H_TOTAL_WORDS,
-    H_WORDS
+    H_PAD0,
+    H_PAD1,
+    H_WORDS  // multiple of 4: the code starts 16-byte aligned
 };
 
 enum Op : uint32_t {
+    OP_NOP = 0,  // padding: programs are a multiple of four instructions long, 16-byte aligned
     OP_ADD = 1,  // regs[dst] = a + b
     OP_SUB = 2,
     OP_MUL = 3,

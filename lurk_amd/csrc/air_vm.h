@@ -42,8 +42,7 @@ __device__ __forceinline__ void run(const uint32_t* __restrict__ prog, const Sou
             default: return src.sel[idx];
         }
     };
-    for (uint32_t i = 0; i < n; i++) {
-        const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
+    auto step = [&](const uint32_t w0, const uint32_t w1) {
         const uint32_t op = w0 & 0xffu, dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
         switch (op) {
             case airp::OP_ADD: regs[dst * stride] = bb::add(fetch(a), fetch(b)); break;
@@ -52,8 +51,19 @@ __device__ __forceinline__ void run(const uint32_t* __restrict__ prog, const Sou
             case airp::OP_ASSERT: sink.assert_zero(fetch(a)); break;
             case airp::OP_IBEGIN: sink.ibegin(dst, a != 0, b); break;
             case airp::OP_IVAL: sink.ival(fetch(a)); break;
-            default: sink.iend(fetch(a)); break;
+            case airp::OP_IEND: sink.iend(fetch(a)); break;
+            default: break;  // OP_NOP padding
         }
+    };
+    // the program is padded to a multiple of four instructions: eight words (one s_load_dwordx8) per fetch, so the
+    // scalar-load latency is paid once per four instructions instead of once per instruction
+    const uint4* __restrict__ code4 = reinterpret_cast<const uint4*>(code);
+    for (uint32_t i = 0; i < n; i += 4) {
+        const uint4 c0 = code4[i >> 1], c1 = code4[(i >> 1) + 1];
+        step(c0.x, c0.y);
+        step(c0.z, c0.w);
+        step(c1.x, c1.y);
+        step(c1.z, c1.w);
     }
 }
 

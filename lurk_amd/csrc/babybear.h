@@ -170,28 +170,17 @@ BB_HD ef ef_scale(const ef& a, uint32_t s) {
 }
 BB_HD ef ef_add_base(const ef& a, uint32_t s) { return ef{{add(a.c[0], s), a.c[1], a.c[2], a.c[3]}}; }
 BB_HD ef ef_mul(const ef& a, const ef& b) {
-    // schoolbook with the x^4 = 11 fold; every partial product is < p so a sum of
-    // four of them fits 64 bits long before reduction: accumulate then reduce once.
-    uint64_t t0 = (uint64_t)a.c[0] * b.c[0];
-    uint64_t t1 = (uint64_t)a.c[0] * b.c[1] + (uint64_t)a.c[1] * b.c[0];
-    uint64_t t2 = (uint64_t)a.c[0] * b.c[2] + (uint64_t)a.c[1] * b.c[1] + (uint64_t)a.c[2] * b.c[0];
-    uint64_t t3 = (uint64_t)a.c[0] * b.c[3] + (uint64_t)a.c[1] * b.c[2] + (uint64_t)a.c[2] * b.c[1] +
-                  (uint64_t)a.c[3] * b.c[0];
-    uint64_t t4 = (uint64_t)a.c[1] * b.c[3] + (uint64_t)a.c[2] * b.c[2] + (uint64_t)a.c[3] * b.c[1];
-    uint64_t t5 = (uint64_t)a.c[2] * b.c[3] + (uint64_t)a.c[3] * b.c[2];
-    uint64_t t6 = (uint64_t)a.c[3] * b.c[3];
-    // each t < 4 * p^2 < 2^64 (p^2 < 2^62): reduce mod p * 2^32 domain via mred after a
-    // conditional subtraction so the mred precondition t < p * 2^32 holds.
-    const uint64_t PP = (uint64_t)P << 32;
-    auto red = [&](uint64_t t) -> uint32_t {
-        // t < 2^64; bring below p * 2^32 (= 0x78000001_00000000) by subtracting it at most twice
-        if (t >= PP) t -= PP;
-        if (t >= PP) t -= PP;
-        return mred(t);
+    // c_k = sum_{i+j=k} a_i b_j + 11 * sum_{i+j=k+4} a_i b_j.  With b'_j = 11 b_j every coefficient is a sum of four
+    // products of reduced operands; two of them are < 2 p^2 < p * 2^32, the Montgomery-reduction bound, so each
+    // coefficient costs four multiply-adds, two reductions and one modular add (no 64-bit comparisons).
+    const uint32_t w1 = mul(EXT_W_M, b.c[1]), w2 = mul(EXT_W_M, b.c[2]), w3 = mul(EXT_W_M, b.c[3]);
+    auto dot2 = [](uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) -> uint32_t {
+        return mred((uint64_t)x0 * y0 + (uint64_t)x1 * y1);
     };
-    uint32_t r0 = red(t0), r1 = red(t1), r2 = red(t2), r3 = red(t3);
-    uint32_t r4 = red(t4), r5 = red(t5), r6 = red(t6);
-    return ef{{add(r0, mul(EXT_W_M, r4)), add(r1, mul(EXT_W_M, r5)), add(r2, mul(EXT_W_M, r6)), r3}};
+    return ef{{add(dot2(a.c[0], b.c[0], a.c[1], w3), dot2(a.c[2], w2, a.c[3], w1)),
+               add(dot2(a.c[0], b.c[1], a.c[1], b.c[0]), dot2(a.c[2], w3, a.c[3], w2)),
+               add(dot2(a.c[0], b.c[2], a.c[1], b.c[1]), dot2(a.c[2], b.c[0], a.c[3], w3)),
+               add(dot2(a.c[0], b.c[3], a.c[1], b.c[2]), dot2(a.c[2], b.c[1], a.c[3], b.c[0]))}};
 }
 BB_HD ef ef_sqr(const ef& a) { return ef_mul(a, a); }
 BB_HD bool ef_is_zero(const ef& a) { return (a.c[0] | a.c[1] | a.c[2] | a.c[3]) == 0; }

@@ -857,6 +857,11 @@ struct Lowerer {
             n_instr++;
         }
         if (n_regs > airp::SRC_MASK) throw ExecError("AIR program needs too many registers");
+        while (n_instr % 4) {  // the VM fetches four instructions at a time
+            emit(airp::OP_NOP, 0, 0, 0);
+            n_instr++;
+        }
+        static_assert(airp::H_WORDS % 4 == 0, "code must start 16-byte aligned");
         std::vector<uint32_t> out(airp::H_WORDS, 0);
         out[airp::H_MAGIC] = airp::MAGIC;
         out[airp::H_N_INSTR] = n_instr;
