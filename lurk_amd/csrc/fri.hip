@@ -155,7 +155,19 @@ __global__ __launch_bounds__(64) void k_reduce_openings(ReduceArgs a) {
     }
     if (s >= a.m_rows) return;
     ef rr = bb::ef_zero();
-    for (uint32_t c = 0; c < a.w; c++) rr = bb::ef_add(rr, bb::ef_scale(ef_load(a.alpha_pows + 4 * c), row[c]));
+    {
+        // the alpha powers are wave-uniform (scalar loads): fetch four at a time so their latency is paid once per
+        // four columns
+        const uint32_t* __restrict__ ap = a.alpha_pows;
+        uint32_t c = 0;
+        for (; c + 4 <= a.w; c += 4) {
+            const ef p0 = ef_load(ap + 4 * c), p1 = ef_load(ap + 4 * c + 4), p2 = ef_load(ap + 4 * c + 8), p3 = ef_load(ap + 4 * c + 12);
+            const uint32_t v0 = row[c], v1 = row[c + 1], v2 = row[c + 2], v3 = row[c + 3];
+            rr = bb::ef_add(rr, bb::ef_add(bb::ef_add(bb::ef_scale(p0, v0), bb::ef_scale(p1, v1)),
+                                           bb::ef_add(bb::ef_scale(p2, v2), bb::ef_scale(p3, v3))));
+        }
+        for (; c < a.w; c++) rr = bb::ef_add(rr, bb::ef_scale(ef_load(ap + 4 * c), row[c]));
+    }
     ef acc = ef_load(a.ro + 4 * (size_t)s);
     acc = bb::ef_add(acc, bb::ef_mul(a.apow0, bb::ef_mul(bb::ef_sub(rr, a.ys0), ef_load(a.d0 + 4 * (size_t)s))));
     if (a.d1) acc = bb::ef_add(acc, bb::ef_mul(a.apow1, bb::ef_mul(bb::ef_sub(rr, a.ys1), ef_load(a.d1 + 4 * (size_t)s))));

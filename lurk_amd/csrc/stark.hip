@@ -212,16 +212,20 @@ struct LogupAccum {
     const uint32_t* __restrict__ beta_pows;
     ef alpha;
     ef cur, num, den;
+    ef next_pow;  // beta^t, loaded one value ahead: the (scalar) table load overlaps the previous value's arithmetic
     uint32_t t = 0, in_batch = 0, m_first = 0;
     bool is_send = false;
     __device__ __forceinline__ void begin(uint32_t kind, bool send) {
         cur = bb::ef_add_base(alpha, bb::to_monty(kind));  // alpha + beta^0 * argument_index
         t = 1;
+        next_pow = ef_load(beta_pows + 4);
         is_send = send;
     }
     __device__ __forceinline__ void value(uint32_t v) {
-        cur = bb::ef_add(cur, bb::ef_scale(ef_load(beta_pows + 4 * t), v));
+        const ef p = next_pow;
         t++;
+        next_pow = ef_load(beta_pows + 4 * t);  // the table has max_tuple + 2 entries: one past the last value is valid
+        cur = bb::ef_add(cur, bb::ef_scale(p, v));
     }
     // folds the finished interaction into the batch fraction num / den = sum_i m_i / d_i; returns true when the batch
     // holds `batch` interactions.  Multiplicities are base-field: the first two interactions of a batch cost one
@@ -421,7 +425,15 @@ struct QuotientSink {
     const uint32_t* perm_l;
     uint32_t k = 0, col = 0;
     ef folded = bb::ef_zero();
-    __device__ __forceinline__ ef weight() { return ef_load(alpha_pows + 4 * (k_total - 1 - k)); }
+    ef next_w;  // alpha^(K-1-k), loaded one constraint ahead (see LogupAccum::next_pow)
+    __device__ __forceinline__ void prime() { next_w = ef_load(alpha_pows + 4 * (k_total - 1)); }
+    __device__ __forceinline__ ef weight() {
+        const ef w = next_w;
+        // k + 1 <= k_total - 1 except after the last constraint, where index 0 is re-read (valid, unused)
+        const uint32_t nk = k + 1 < k_total ? k_total - 2 - k : 0u;
+        next_w = ef_load(alpha_pows + 4 * nk);
+        return w;
+    }
     __device__ __forceinline__ void assert_zero(uint32_t v) {
         folded = bb::ef_add(folded, bb::ef_scale(weight(), v));
         k++;
@@ -479,6 +491,7 @@ __global__ void k_quotient(QuotientArgs a) {
     const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
     const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.perm_alpha}, a.batch, perm_l};
+    sink.prime();
     airvm::run(a.cons_prog, src, regs + threadIdx.x, blockDim.x, sink);
     airvm::run(a.inter_prog, src, regs + threadIdx.x, blockDim.x, sink);
     if (sink.acc.in_batch) sink.flush();
