@@ -395,6 +395,134 @@ struct FuncAirWalk {
                 out = {is_zero};
                 break;
             }
+            case CHIP_U64_DIVREM: {
+                // DivRem::eval (gadgets/unsigned/div_rem.rs:65-110)
+                const std::vector<E> a = word(0), bw = word(8);
+                std::vector<E> inverses(wit.begin(), wit.begin() + 8), qv(wit.begin() + 8, wit.begin() + 16),
+                    carry(wit.begin() + 16, wit.begin() + 24), qb(wit.begin() + 24, wit.begin() + 32), r(wit.begin() + 32, wit.begin() + 40);
+                // b != 0: 1 = sum w_i * b_i (is_zero.rs:48-65)
+                {
+                    E lc = b.zero();
+                    for (int i = 0; i < 8; i++) lc = b.add(lc, b.mul(bw[i], inverses[i]));
+                    b.assert_one(lc, is_real);
+                }
+                rec.range_check_u8_iter(qv, is_real);
+                {  // qb = q * b (Product::eval)
+                    std::vector<E> products(8, b.zero());
+                    for (int i = 0; i < 8; i++)
+                        for (int j = 0; j + i < 8; j++) products[i + j] = b.add(products[i + j], b.mul(qv[i], bw[j]));
+                    E carry_prev = b.zero();
+                    for (int k = 0; k < 8; k++) {
+                        rec.range_check_u16(carry[k], is_real);
+                        b.assert_eq(b.add(products[k], carry_prev), b.add(qb[k], b.mul(carry[k], b.cst(256))), is_real);
+                        carry_prev = carry[k];
+                    }
+                    rec.range_check_u8_iter(qb, is_real);
+                }
+                // r = a - qb (Diff::eval): r + qb = a
+                rec.range_check_u8_iter(r, is_real);
+                assert_add(b, r, qb, a, is_real);
+                // r < b (LessThanWitness<_, 8>::assert_less_than, less_than.rs:44-99)
+                {
+                    const E* lw = &wit[40];
+                    E is_equal = b.zero();
+                    for (int i = 0; i < 8; i++) {
+                        if (i > 0) b.assert_eq(r[i], bw[i], b.both(is_real, is_equal));
+                        b.assert_bool(lw[i], is_real);
+                        is_equal = b.add(is_equal, lw[i]);
+                    }
+                    b.assert_one(is_equal, is_real);
+                    E sl = b.zero(), sr = b.zero();
+                    for (int i = 0; i < 8; i++) {
+                        sl = b.add(sl, b.mul(r[i], lw[i]));
+                        sr = b.add(sr, b.mul(bw[i], lw[i]));
+                    }
+                    b.assert_eq(sl, lw[8], is_real);
+                    b.assert_eq(sr, lw[9], is_real);
+                    rec.less_than(lw[8], lw[9], b.one(), is_real);
+                }
+                // qb <= a (CompareWitness<_, 8>::eval)
+                {
+                    const E* cw = &wit[50];
+                    E is_equal = b.one();
+                    for (int i = 7; i >= 0; i--) {
+                        b.assert_bool(cw[i], is_real);
+                        is_equal = b.sub(is_equal, cw[i]);
+                        b.assert_eq(qb[i], a[i], b.both(is_real, is_equal));
+                    }
+                    b.assert_bool(is_equal, is_real);
+                    E sl = b.zero(), sr = b.zero();
+                    for (int i = 0; i < 8; i++) {
+                        sl = b.add(sl, b.mul(qb[i], cw[i]));
+                        sr = b.add(sr, b.mul(a[i], cw[i]));
+                    }
+                    b.assert_eq(sl, cw[8], is_real);
+                    b.assert_eq(sr, cw[9], is_real);
+                    b.assert_eq(b.mul(b.sub(cw[8], cw[9]), cw[10]), b.sub(b.one(), is_equal), is_real);
+                    rec.less_than(cw[8], cw[9], cw[11], is_real);
+                    b.assert_one(b.add(cw[11], is_equal), is_real);  // is_less_than_or_equal
+                }
+                out = qv;
+                out.insert(out.end(), r.begin(), r.end());
+                break;
+            }
+            case CHIP_BIGNUM_LESSTHAN: {
+                // BigNumCompareWitness::eval (gadgets/big_num/cmp.rs:52-135)
+                const std::vector<E> lhs(ins.begin(), ins.begin() + 8), rhs(ins.begin() + 8, ins.begin() + 16);
+                E is_equal = b.one();
+                for (int i = 7; i >= 0; i--) {
+                    b.assert_bool(wit[i], is_real);
+                    is_equal = b.sub(is_equal, wit[i]);
+                    b.assert_eq(lhs[i], rhs[i], b.both(is_real, is_equal));
+                }
+                b.assert_bool(is_equal, is_real);
+                E sl = b.zero(), sr = b.zero();
+                for (int i = 0; i < 8; i++) {
+                    sl = b.add(sl, b.mul(lhs[i], wit[i]));
+                    sr = b.add(sr, b.mul(rhs[i], wit[i]));
+                }
+                b.assert_eq(sl, wit[8], is_real);
+                b.assert_eq(sr, wit[9], is_real);
+                // FieldToWord32::eval (gadgets/unsigned/field.rs:34-84,120-139): witness { is_msb_less_than, bytes[4] }
+                auto field_to_word = [&](E field, const E* fw) {
+                    const E is_msb_lt = fw[0];
+                    const E* wd = fw + 1;
+                    b.assert_bool(is_msb_lt, is_real);
+                    E recomposed = b.zero();
+                    for (int i = 3; i >= 0; i--) recomposed = b.add(b.mul(recomposed, b.cst(256)), wd[i]);
+                    b.assert_eq(field, recomposed, is_real);
+                    rec.less_than(wd[3], b.cst(0x78), is_msb_lt, is_real);
+                    const E when_eq = b.mul(is_real, b.sub(b.one(), is_msb_lt));
+                    b.assert_eq(wd[3], b.cst(0x78), when_eq);
+                    for (int i = 0; i < 3; i++) b.assert_eq(wd[i], b.zero(), when_eq);
+                    rec.range_check_u8_iter({wd[0], wd[1], wd[2], wd[3]}, is_real);
+                };
+                field_to_word(wit[8], &wit[10]);
+                field_to_word(wit[9], &wit[15]);
+                // CompareWitness<_, 4> on the two words
+                const E* lwd = &wit[11];
+                const E* rwd = &wit[16];
+                const E* cw = &wit[20];
+                E w_equal = b.one();
+                for (int i = 3; i >= 0; i--) {
+                    b.assert_bool(cw[i], is_real);
+                    w_equal = b.sub(w_equal, cw[i]);
+                    b.assert_eq(lwd[i], rwd[i], b.both(is_real, w_equal));
+                }
+                b.assert_bool(w_equal, is_real);
+                E wl = b.zero(), wr = b.zero();
+                for (int i = 0; i < 4; i++) {
+                    wl = b.add(wl, b.mul(lwd[i], cw[i]));
+                    wr = b.add(wr, b.mul(rwd[i], cw[i]));
+                }
+                b.assert_eq(wl, cw[4], is_real);
+                b.assert_eq(wr, cw[5], is_real);
+                b.assert_eq(b.mul(b.sub(cw[4], cw[5]), cw[6]), b.sub(b.one(), w_equal), is_real);
+                rec.less_than(cw[4], cw[5], cw[7], is_real);
+                b.assert_eq(is_equal, w_equal, is_real);
+                out = {cw[7]};
+                break;
+            }
             default:
                 throw ExecError("AIR of extern chip " + chip.name + " is not available in this build");
         }

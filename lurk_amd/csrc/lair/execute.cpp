@@ -153,6 +153,78 @@ List Chip::execute(const List& input, uint32_t nonce, BytesRecord& bytes, std::v
             uint64_t a = into_u64(&input[0]);
             return List{a == 0 ? 1u : 0u};
         }
+        case CHIP_U64_DIVREM: {
+            // DivRem::populate (unsigned/div_rem.rs:33-62): byte lookups in the order q bytes (4 pairs), q * b
+            // (8 u16 carries, 4 result pairs), r = a - q b (4 pairs), r < b (1 less_than), q b <= a (1 less_than)
+            uint64_t a = into_u64(&input[0]), b = into_u64(&input[8]);
+            if (b == 0) throw ExecError("expected input to be non-zero");
+            const uint64_t qv = a / b, qb = qv * b, r = a - qb;
+            auto bytes_of = [](uint64_t v, uint8_t* by) {
+                for (int i = 0; i < 8; i++) by[i] = (uint8_t)(v >> (8 * i));
+            };
+            uint8_t by[8];
+            bytes_of(qv, by);
+            bytes.range_check_u8_iter(by, 8, nonce, rq);
+            {
+                uint32_t products[8] = {0};
+                for (int i = 0; i < 8; i++)
+                    for (int j = 0; i + j < 8; j++) products[i + j] += ((qv >> (8 * i)) & 0xff) * ((b >> (8 * j)) & 0xff);
+                uint16_t carry = 0;
+                uint8_t res[8];
+                for (int k = 0; k < 8; k++) {
+                    uint32_t o = products[k] + carry;
+                    res[k] = (uint8_t)(o & 0xff);
+                    carry = (uint16_t)((o >> 8) & 0xffff);
+                    bytes.range_check_u16(carry, nonce, rq);
+                }
+                bytes.range_check_u8_iter(res, 8, nonce, rq);
+            }
+            bytes_of(r, by);
+            bytes.range_check_u8_iter(by, 8, nonce, rq);
+            auto msb_less_than = [&](uint64_t l, uint64_t rr, bool strict) {
+                for (int i = 7; i >= 0; i--) {
+                    uint8_t x = (uint8_t)(l >> (8 * i)), y = (uint8_t)(rr >> (8 * i));
+                    if (x != y) {
+                        bytes.less_than(x, y, nonce, rq);
+                        return;
+                    }
+                }
+                if (strict) throw ExecError("less-than witness on equal operands");
+                bytes.less_than(0, 0, nonce, rq);
+            };
+            msb_less_than(r, b, true);    // LessThanWitness::populate asserts r < b
+            msb_less_than(qb, a, false);  // CompareWitness::populate
+            List out = u64_bytes(qv), rem = u64_bytes(r);
+            out.insert(out.end(), rem.begin(), rem.end());
+            return out;
+        }
+        case CHIP_BIGNUM_LESSTHAN: {
+            // BigNumCompareWitness::populate (gadgets/big_num/cmp.rs:24-49): most significant differing field element,
+            // both as 4-byte words (FieldToWord32: less_than(msb, 0x78), then 2 byte pairs each), then CompareWitness<4>
+            uint32_t l = 0, r = 0;
+            for (int i = 7; i >= 0; i--)
+                if (input[i] != input[8 + i]) {
+                    l = input[i];
+                    r = input[8 + i];
+                    break;
+                }
+            auto field_to_word = [&](uint32_t v) {
+                uint8_t by[4] = {(uint8_t)v, (uint8_t)(v >> 8), (uint8_t)(v >> 16), (uint8_t)(v >> 24)};
+                bytes.less_than(by[3], 0x78, nonce, rq);
+                bytes.range_check_u8_iter(by, 4, nonce, rq);
+            };
+            field_to_word(l);
+            field_to_word(r);
+            for (int i = 3; i >= 0; i--) {
+                uint8_t x = (uint8_t)(l >> (8 * i)), y = (uint8_t)(r >> (8 * i));
+                if (x != y) {
+                    bool lt = bytes.less_than(x, y, nonce, rq);
+                    return List{lt ? 1u : 0u};
+                }
+            }
+            bytes.less_than(0, 0, nonce, rq);
+            return List{0u};
+        }
         default:
             throw ExecError("extern chip " + name + " is not supported by this build");
     }
@@ -189,10 +261,10 @@ std::vector<Chip> lurk_chip_map() {
         u64("u64_add", CHIP_U64_ADD, 16, 8, 8, 4),
         u64("u64_sub", CHIP_U64_SUB, 16, 8, 8, 4),
         u64("u64_mul", CHIP_U64_MUL, 16, 8, 16, 12),
-        u64("u64_divrem", CHIP_U64_DIVREM, 16, 16, 0, 0),  // sizes filled in when the gadget lands
+        u64("u64_divrem", CHIP_U64_DIVREM, 16, 16, 62, 22),  // DivRem<_, 8> (gadgets/unsigned/div_rem.rs:16-31,112-124)
         u64("u64_lessthan", CHIP_U64_LESSTHAN, 16, 1, 12, 1),
         u64("u64_iszero", CHIP_U64_ISZERO, 8, 1, 9, 0),
-        u64("big_num_lessthan", CHIP_BIGNUM_LESSTHAN, 16, 1, 0, 0),
+        u64("big_num_lessthan", CHIP_BIGNUM_LESSTHAN, 16, 1, 28, 7),  // BigNumCompareWitness (gadgets/big_num/cmp.rs:13-22)
     };
 }
 

@@ -300,6 +300,92 @@ __global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
                 uint32_t z = x == 0 ? 1u : 0u;
                 w.push_aux_int(z);
                 map[sp++] = bb::to_monty(z);
+            } else if (kind == CHIP_U64_DIVREM) {
+                // DivRem<_, 8> (unsigned/div_rem.rs:16-62): b_non_zero.inverses[8], q[8], qb { carry[8], result[8] },
+                // r[8], r_lt_b { is_comp[8], lhs, rhs }, qb_cmp_a { is_comp[8], lhs, rhs, diff_inv, is_less_than }
+                const uint64_t x = map_u64(map, ins_v), y = map_u64(map, ins_v + 8);
+                const uint64_t qv = y ? x / y : 0, qb = qv * y, rem = x - qb;
+                bool found = false;
+                for (int i = 0; i < 8; i++) {
+                    const uint32_t limb = (uint32_t)(y >> (8 * i)) & 0xff;
+                    if (!found && limb) {
+                        w.push_aux(bb::inv(bb::to_monty(limb)));
+                        found = true;
+                    } else {
+                        w.push_aux(0u);
+                    }
+                }
+                for (int i = 0; i < 8; i++) w.push_aux_int((uint32_t)(qv >> (8 * i)) & 0xff);
+                {
+                    uint32_t carry = 0, res[8];
+                    for (int k = 0; k < 8; k++) {
+                        uint32_t prod = 0;
+                        for (int i = 0; i <= k; i++) prod += (uint32_t)((qv >> (8 * i)) & 0xff) * (uint32_t)((y >> (8 * (k - i))) & 0xff);
+                        const uint32_t o = prod + carry;
+                        res[k] = o & 0xff;
+                        carry = (o >> 8) & 0xffff;
+                        w.push_aux_int(carry);
+                    }
+                    for (int k = 0; k < 8; k++) w.push_aux_int(res[k]);
+                }
+                for (int i = 0; i < 8; i++) w.push_aux_int((uint32_t)(rem >> (8 * i)) & 0xff);
+                auto msb_diff = [](uint64_t l, uint64_t r) {
+                    for (int i = 7; i >= 0; i--)
+                        if (((l >> (8 * i)) & 0xff) != ((r >> (8 * i)) & 0xff)) return i;
+                    return -1;
+                };
+                {  // LessThanWitness(rem, y)
+                    const int idx = msb_diff(rem, y);
+                    for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
+                    w.push_aux_int(idx >= 0 ? (uint32_t)(rem >> (8 * idx)) & 0xff : 0u);
+                    w.push_aux_int(idx >= 0 ? (uint32_t)(y >> (8 * idx)) & 0xff : 0u);
+                }
+                {  // CompareWitness(qb, x)
+                    const int idx = msb_diff(qb, x);
+                    const uint32_t l = idx >= 0 ? (uint32_t)(qb >> (8 * idx)) & 0xff : 0, rr = idx >= 0 ? (uint32_t)(x >> (8 * idx)) & 0xff : 0;
+                    for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
+                    w.push_aux_int(l);
+                    w.push_aux_int(rr);
+                    w.push_aux(idx >= 0 ? bb::inv(bb::sub(bb::to_monty(l), bb::to_monty(rr))) : 0u);
+                    w.push_aux_int((idx >= 0 && l < rr) ? 1u : 0u);
+                }
+                for (int i = 0; i < 8; i++) map[sp++] = bb::to_monty((uint32_t)(qv >> (8 * i)) & 0xff);
+                for (int i = 0; i < 8; i++) map[sp++] = bb::to_monty((uint32_t)(rem >> (8 * i)) & 0xff);
+            } else if (kind == CHIP_BIGNUM_LESSTHAN) {
+                // BigNumCompareWitness (big_num/cmp.rs:13-49): is_comp[8], lhs_limb, rhs_limb, lhs_word { is_msb_lt, bytes[4] },
+                // rhs_word { .. }, CompareWitness<_, 4> { is_comp[4], lhs, rhs, diff_inv, is_less_than }
+                int idx = -1;
+                uint32_t lm = 0, rm = 0;
+                for (int i = 7; i >= 0; i--)
+                    if (map[ins_v[i]] != map[ins_v[8 + i]]) {
+                        idx = i;
+                        lm = map[ins_v[i]];
+                        rm = map[ins_v[8 + i]];
+                        break;
+                    }
+                const uint32_t l = idx >= 0 ? bb::from_monty(lm) : 0u, r = idx >= 0 ? bb::from_monty(rm) : 0u;
+                for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
+                w.push_aux_int(l);
+                w.push_aux_int(r);
+                for (int side = 0; side < 2; side++) {
+                    const uint32_t v = side ? r : l;
+                    w.push_aux_int((v >> 24) < 0x78 ? 1u : 0u);
+                    for (int i = 0; i < 4; i++) w.push_aux_int((v >> (8 * i)) & 0xff);
+                }
+                int j = -1;
+                for (int i = 3; i >= 0; i--)
+                    if (((l >> (8 * i)) & 0xff) != ((r >> (8 * i)) & 0xff)) {
+                        j = i;
+                        break;
+                    }
+                const uint32_t lb = j >= 0 ? (l >> (8 * j)) & 0xff : 0, rb = j >= 0 ? (r >> (8 * j)) & 0xff : 0;
+                for (int i = 0; i < 4; i++) w.push_aux_int(i == j ? 1u : 0u);
+                w.push_aux_int(lb);
+                w.push_aux_int(rb);
+                w.push_aux(j >= 0 ? bb::inv(bb::sub(bb::to_monty(lb), bb::to_monty(rb))) : 0u);
+                const uint32_t lt = (j >= 0 && lb < rb) ? 1u : 0u;
+                w.push_aux_int(lt);
+                map[sp++] = bb::to_monty(lt);
             } else {
                 // unsupported chips are rejected on the host before launch
                 w.aux += wit;

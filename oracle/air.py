@@ -434,6 +434,87 @@ def eval_chip(b: Builder, chip, is_real, ins, wit, nonce, reqs):
             lc = lc + x * w_
         b.assert_eq(lc, 1 - is_zero, is_real)
         out = [is_zero]
+    elif name == "u64_divrem":  # gadgets/unsigned/div_rem.rs:65-110
+        a, bw = ins[:8], ins[8:16]
+        inverses, qv, carry, qb, r = wit[:8], wit[8:16], wit[16:24], wit[24:32], wit[32:40]
+        lw, cw = wit[40:50], wit[50:62]
+        b.assert_one(sum(x * w_ for x, w_ in zip(bw, inverses)), is_real)
+        rec.range_check_u8_iter(qv, is_real)
+        products = [0] * 8
+        for i in range(8):
+            for j in range(8 - i):
+                products[i + j] += qv[i] * bw[j]
+        carry_prev = 0
+        for k in range(8):
+            rec.records.append(([BYTE_TAG, 2, carry[k]], is_real))
+            b.assert_eq(products[k] + carry_prev, qb[k] + carry[k] * 256, is_real)
+            carry_prev = carry[k]
+        rec.range_check_u8_iter(qb, is_real)
+        rec.range_check_u8_iter(r, is_real)
+        _assert_add(b, r, qb, a, is_real)
+        is_equal = 0
+        for i in range(8):  # r < b: LessThanWitness<_, 8>
+            if i > 0:
+                b.assert_eq(r[i], bw[i], is_real * is_equal)
+            b.assert_bool(lw[i], is_real)
+            is_equal = is_equal + lw[i]
+        b.assert_one(is_equal, is_real)
+        b.assert_eq(sum(x * f for x, f in zip(r, lw[:8])), lw[8], is_real)
+        b.assert_eq(sum(x * f for x, f in zip(bw, lw[:8])), lw[9], is_real)
+        rec.less_than(lw[8], lw[9], 1, is_real)
+        is_equal = 1
+        for i in reversed(range(8)):  # qb <= a: CompareWitness<_, 8>
+            b.assert_bool(cw[i], is_real)
+            is_equal = is_equal - cw[i]
+            b.assert_eq(qb[i], a[i], is_real * is_equal)
+        b.assert_bool(is_equal, is_real)
+        b.assert_eq(sum(x * f for x, f in zip(qb, cw[:8])), cw[8], is_real)
+        b.assert_eq(sum(x * f for x, f in zip(a, cw[:8])), cw[9], is_real)
+        b.assert_eq((cw[8] - cw[9]) * cw[10], 1 - is_equal, is_real)
+        rec.less_than(cw[8], cw[9], cw[11], is_real)
+        b.assert_one(cw[11] + is_equal, is_real)
+        out = list(qv) + list(r)
+    elif name == "big_num_lessthan":  # gadgets/big_num/cmp.rs:52-135, gadgets/unsigned/field.rs:34-84,120-139
+        lhs, rhs = ins[:8], ins[8:16]
+        is_equal = 1
+        for i in reversed(range(8)):
+            b.assert_bool(wit[i], is_real)
+            is_equal = is_equal - wit[i]
+            b.assert_eq(lhs[i], rhs[i], is_real * is_equal)
+        b.assert_bool(is_equal, is_real)
+        b.assert_eq(sum(x * f for x, f in zip(lhs, wit[:8])), wit[8], is_real)
+        b.assert_eq(sum(x * f for x, f in zip(rhs, wit[:8])), wit[9], is_real)
+
+        def field_to_word(fld, fw):
+            is_msb_lt, wd = fw[0], fw[1:5]
+            b.assert_bool(is_msb_lt, is_real)
+            recomposed = 0
+            for i in reversed(range(4)):
+                recomposed = recomposed * 256 + wd[i]
+            b.assert_eq(fld, recomposed, is_real)
+            rec.less_than(wd[3], 0x78, is_msb_lt, is_real)
+            when_eq = is_real * (1 - is_msb_lt)
+            b.assert_eq(wd[3], 0x78, when_eq)
+            for i in range(3):
+                b.assert_eq(wd[i], 0, when_eq)
+            rec.range_check_u8_iter(wd, is_real)
+            return wd
+
+        lwd = field_to_word(wit[8], wit[10:15])
+        rwd = field_to_word(wit[9], wit[15:20])
+        cw = wit[20:28]
+        w_equal = 1
+        for i in reversed(range(4)):
+            b.assert_bool(cw[i], is_real)
+            w_equal = w_equal - cw[i]
+            b.assert_eq(lwd[i], rwd[i], is_real * w_equal)
+        b.assert_bool(w_equal, is_real)
+        b.assert_eq(sum(x * f for x, f in zip(lwd, cw[:4])), cw[4], is_real)
+        b.assert_eq(sum(x * f for x, f in zip(rwd, cw[:4])), cw[5], is_real)
+        b.assert_eq((cw[4] - cw[5]) * cw[6], 1 - w_equal, is_real)
+        rec.less_than(cw[4], cw[5], cw[7], is_real)
+        b.assert_eq(is_equal, w_equal, is_real)
+        out = [cw[7]]
     else:
         raise NotImplementedError(f"AIR of extern chip {name}")
     rec.require_all(b, nonce, reqs)

@@ -283,8 +283,8 @@ def lurk_chips():
     return [
         h("hasher3", 24, 21), h("hasher4", 32, 30), h("hasher5", 40, 38),
         Chip("u64_add", 16, 8, 8, 4, 8), Chip("u64_sub", 16, 8, 8, 4, 8), Chip("u64_mul", 16, 8, 16, 12, 8),
-        Chip("u64_divrem", 16, 16, 0, 0, 16), Chip("u64_lessthan", 16, 1, 12, 1, 1), Chip("u64_iszero", 8, 1, 9, 0, 1),
-        Chip("big_num_lessthan", 16, 1, 0, 0, 1),
+        Chip("u64_divrem", 16, 16, 62, 22, 16), Chip("u64_lessthan", 16, 1, 12, 1, 1), Chip("u64_iszero", 8, 1, 9, 0, 1),
+        Chip("big_num_lessthan", 16, 1, 28, 7, 1),
     ]
 
 
@@ -561,6 +561,9 @@ class QueryRecord:
         reqs.append(new_lookup(self.byte_rec(a, b)[2], nonce))
         return a < b
 
+    def range_u16(self, v, nonce, reqs):  # gadgets/bytes/record.rs: the row of the table whose (i1, i2) spell v
+        reqs.append(new_lookup(self.byte_rec(v & 0xFF, v >> 8)[1], nonce))
+
 
 def le_bytes(v, n):
     return [(v >> (8 * i)) & 0xFF for i in range(n)]
@@ -683,6 +686,59 @@ def chip_execute(chip, inp, nonce, q, reqs, poseidon):
         return [0]
     if chip.name == "u64_iszero":
         return [1 if a == 0 else 0]
+    if chip.name == "u64_mul":  # gadgets/unsigned/mul.rs:24-64,125-133
+        la, lb = le_bytes(a, 8), le_bytes(b, 8)
+        res, carry = [], 0
+        for k in range(8):
+            o = sum(la[i] * lb[k - i] for i in range(k + 1)) + carry
+            res.append(o & 0xFF)
+            carry = (o >> 8) & 0xFFFF
+            q.range_u16(carry, nonce, reqs)
+        q.range_u8_iter(res, nonce, reqs)
+        return res
+    if chip.name == "u64_divrem":  # gadgets/unsigned/div_rem.rs:33-62
+        assert b != 0, "expected input to be non-zero"
+        qv, r = divmod(a, b)
+        qb = qv * b
+        q.range_u8_iter(le_bytes(qv, 8), nonce, reqs)
+        lq, lb = le_bytes(qv, 8), le_bytes(b, 8)
+        res, carry = [], 0
+        for k in range(8):
+            o = sum(lq[i] * lb[k - i] for i in range(k + 1)) + carry
+            res.append(o & 0xFF)
+            carry = (o >> 8) & 0xFFFF
+            q.range_u16(carry, nonce, reqs)
+        q.range_u8_iter(res, nonce, reqs)
+        q.range_u8_iter(le_bytes(r, 8), nonce, reqs)
+
+        def msb(l, rr, strict):
+            ll, lr = le_bytes(l, 8), le_bytes(rr, 8)
+            for i in reversed(range(8)):
+                if ll[i] != lr[i]:
+                    q.less_than(ll[i], lr[i], nonce, reqs)
+                    return
+            assert not strict
+            q.less_than(0, 0, nonce, reqs)
+
+        msb(r, b, True)
+        msb(qb, a, False)
+        return le_bytes(qv, 8) + le_bytes(r, 8)
+    if chip.name == "big_num_lessthan":  # gadgets/big_num/cmp.rs:24-49
+        l = r = 0
+        for i in reversed(range(8)):
+            if inp[i] != inp[8 + i]:
+                l, r = inp[i], inp[8 + i]
+                break
+        for v in (l, r):
+            by = le_bytes(v, 4)
+            q.less_than(by[3], 0x78, nonce, reqs)
+            q.range_u8_iter(by, nonce, reqs)
+        bl, br = le_bytes(l, 4), le_bytes(r, 4)
+        for i in reversed(range(4)):
+            if bl[i] != br[i]:
+                return [1 if q.less_than(bl[i], br[i], nonce, reqs) else 0]
+        q.less_than(0, 0, nonce, reqs)
+        return [0]
     raise NotImplementedError(chip.name)
 
 

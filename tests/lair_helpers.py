@@ -68,6 +68,15 @@ invertible fn hash5(preimg: [40]): [8] {
     let img: [8] = extern_call(hasher5, preimg);
     return img
 }
+fn u64_more(a: [8], b: [8]): [24] {
+    let p: [8] = extern_call(u64_mul, a, b);
+    let (q: [8], r: [8]) = extern_call(u64_divrem, a, b);
+    return (p, q, r)
+}
+fn big_lt(a: [8], b: [8]): [1] {
+    let lt = extern_call(big_num_lessthan, a, b);
+    return lt
+}
 fn chain(x: [8]): [8] {
     let z = [0; 8];
     let one = [1; 8];

@@ -239,7 +239,8 @@ def test_extern_chip_airs_match_oracle(ctx, oracle):
     top, otop = lair.Toplevel(U64_SRC, lurk_chips=True), ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
     oq = ol.QueryRecord(otop)
     for name, args in [("u64_ops", u64(5) + u64(7)), ("u64_ops", u64(2**64 - 1) + u64(1)), ("chain", [9, 8, 7, 6, 5, 4, 3, 2]),
-                       ("hash5", list(range(40)))]:
+                       ("hash5", list(range(40))), ("u64_more", u64(0xFEDCBA9876543210) + u64(0x1234567)),
+                       ("big_lt", [1, 2, 3, 4, 5, 6, 7, 8] + [1, 2, 3, 4, 5, 6, 9, 8])]:
         ol.execute(otop, name, args, oq, poseidon=poseidon)
     for i, f in enumerate(otop.funcs):
         rows, width = ol.generate_trace(otop, f["name"], oq, witness=witness)

@@ -49,6 +49,60 @@ def oracle_chip_callbacks(oracle):
                     break
             wit[8] = 1 if a == 0 else 0
             return wit, [wit[8]]
+        if chip.name == "u64_mul":
+            la, lb = le(a, 8), le(b, 8)
+            carries, res, carry = [], [], 0
+            for k in range(8):
+                o = sum(la[i] * lb[k - i] for i in range(k + 1)) + carry
+                res.append(o & 0xFF)
+                carry = (o >> 8) & 0xFFFF
+                carries.append(carry)
+            return carries + res, res
+
+        def msb_diff(x, y, n):
+            lx, ly = le(x, n), le(y, n)
+            for i in reversed(range(n)):
+                if lx[i] != ly[i]:
+                    return i, lx[i], ly[i]
+            return -1, 0, 0
+
+        def compare_witness(x, y, n):  # CompareWitness<_, n>: is_comp[n], lhs, rhs, diff_inv, is_less_than
+            i, l, r = msb_diff(x, y, n)
+            return [1 if k == i else 0 for k in range(n)] + [l, r, pow((l - r) % P, P - 2, P) if i >= 0 else 0, 1 if (i >= 0 and l < r) else 0]
+
+        if chip.name == "u64_divrem":
+            qv, rem = divmod(a, b)
+            qb = qv * b
+            wit = [0] * 8
+            for i, limb in enumerate(le(b, 8)):
+                if limb:
+                    wit[i] = pow(limb, P - 2, P)
+                    break
+            wit += le(qv, 8)
+            lq, lb = le(qv, 8), le(b, 8)
+            carries, res, carry = [], [], 0
+            for k in range(8):
+                o = sum(lq[i] * lb[k - i] for i in range(k + 1)) + carry
+                res.append(o & 0xFF)
+                carry = (o >> 8) & 0xFFFF
+                carries.append(carry)
+            wit += carries + res + le(rem, 8)
+            i, l, r = msb_diff(rem, b, 8)
+            wit += [1 if k == i else 0 for k in range(8)] + [l, r]
+            wit += compare_witness(qb, a, 8)
+            return wit, le(qv, 8) + le(rem, 8)
+        if chip.name == "big_num_lessthan":
+            l = r = 0
+            idx = -1
+            for i in reversed(range(8)):
+                if inp[i] != inp[8 + i]:
+                    idx, l, r = i, inp[i], inp[8 + i]
+                    break
+            wit = [1 if k == idx else 0 for k in range(8)] + [l, r]
+            for v in (l, r):
+                wit += [1 if (v >> 24) < 0x78 else 0] + le(v, 4)
+            cw = compare_witness(l, r, 4)
+            return wit + cw, [cw[7]]
         raise NotImplementedError(chip.name)
 
     return poseidon, witness
@@ -118,6 +172,12 @@ def test_extern_chips_vs_oracle(ctx, oracle):
         ["chain", [9, 8, 7, 6, 5, 4, 3, 2]],
         ["chain", [1, 0, 0, 0, 0, 0, 0, 0]],
         ["hash5", list(range(40))],
+        ["u64_more", u64(0xFEDCBA9876543210) + u64(0x1234567)],
+        ["u64_more", u64(77) + u64(77)],
+        ["u64_more", u64(5) + u64(2**63)],
+        ["big_lt", [1, 2, 3, 4, 5, 6, 7, 8] + [1, 2, 3, 4, 5, 6, 9, 8]],
+        ["big_lt", [9] * 8 + [9] * 8],
+        ["big_lt", [0, 0, 0, 0, 0, 0, 0, 2013265920] + [0, 0, 0, 0, 0, 0, 0, 5]],
     ]
     top, q, oq = _compare_all_funcs(ctx, oracle, U64_SRC, calls, lurk_chips=True)
     # byte lookups were recorded and provided

@@ -91,3 +91,36 @@ def test_extern_chip_machine_constraints_and_lookups(oracle):
             prep = [[i & 0xFF, i >> 8, int((i & 0xFF) < (i >> 8)), (i & 0xFF) & (i >> 8), (i & 0xFF) ^ (i >> 8), (i & 0xFF) | (i >> 8)] for i in range(1 << 16)]
             chips.append((oa.BytesAir(), ol.bytes_trace(q), prep))
         assert oa.debug_check(chips, public=pv) > 0
+
+
+def test_mul_divrem_bignum_machine_constraints_and_lookups(oracle):
+    """u64 mul / divrem and the big-num comparison: witnesses from the oracle interpreter satisfy the oracle AIR and
+    the byte lookups balance (the reference's chip tests do the same, /root/reference/src/core/u64.rs:302-420,
+    /root/reference/src/core/big_num.rs:111-181)."""
+    from lair_helpers import U64_SRC
+    from test_lair_gpu import oracle_chip_callbacks
+
+    poseidon, witness = oracle_chip_callbacks(oracle)
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    cases = [("u64_more", u64(0xFEDCBA9876543210) + u64(0x1234567)), ("u64_more", u64(77) + u64(77)), ("u64_more", u64(5) + u64(2**63)),
+             ("big_lt", [1, 2, 3, 4, 5, 6, 7, 8] + [1, 2, 3, 4, 5, 6, 9, 8]), ("big_lt", [9] * 8 + [9] * 8),
+             ("big_lt", [0, 0, 0, 0, 0, 0, 0, 2013265920] + [0, 0, 0, 0, 0, 0, 0, 5])]
+    for entry, args in cases:
+        top = ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+        q = ol.QueryRecord(top)
+        ol.execute(top, entry, args, q, poseidon=poseidon)
+        f = top.funcs[top.index[entry]]
+        pv = q.public_values
+        chips = [(oa.EntrypointAir(f["index"], len(pv)), [list(pv)], None)]
+        for g in top.funcs:
+            rows, _ = ol.generate_trace(top, g["name"], q, witness=witness)
+            if rows:
+                chips.append((oa.FuncAir(top, g["name"]), rows, None))
+        for ml in ol.MEM_TABLE_SIZES:
+            chips.append((oa.MemAir(ml), ol.mem_trace(q, ml), None))
+        prep = [[i & 0xFF, i >> 8, int((i & 0xFF) < (i >> 8)), (i & 0xFF) & (i >> 8), (i & 0xFF) ^ (i >> 8), (i & 0xFF) | (i >> 8)] for i in range(1 << 16)]
+        chips.append((oa.BytesAir(), ol.bytes_trace(q), prep))
+        assert oa.debug_check(chips, public=pv) > 0, (entry, args)

@@ -167,3 +167,21 @@ def test_large_shard_proof_verifies(ctx):
     proofs = m.prove(q, num_queries=100, pow_bits=16)
     assert proofs[0].log_max_height == LOG_ROWS_LARGE + 2
     assert verify(se.SOURCE, se.FUNC, root, proofs, len(pv))
+
+
+@pytest.mark.parametrize("entry,args", [("u64_more", [0x10, 0x32, 0x54, 0x76, 0x98, 0xBA, 0xDC, 0xFE, 0x67, 0x45, 0x23, 0x01, 0, 0, 0, 0]),
+                                        ("big_lt", [1, 2, 3, 4, 5, 6, 7, 8, 1, 2, 3, 4, 5, 6, 9, 8])], ids=["mul_divrem", "bignum"])
+def test_mul_divrem_bignum_machines_prove_and_verify(ctx, entry, args):
+    from lair_helpers import U64_SRC
+
+    top = lair.Toplevel(U64_SRC, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(entry, args, q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, entry, len(pv))
+    root = m.setup()
+    proofs = m.prove(q, num_queries=6, pow_bits=4)
+    otop = ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+    airs = [oa.EntrypointAir(otop.index[entry], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
+    airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
+    assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
