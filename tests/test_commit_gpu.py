@@ -18,6 +18,16 @@ def test_lde_matches_oracle(ctx, oracle, log_n, w, b):
     assert np.array_equal(got, want)
 
 
+# widths and heights that exercise every tiling of the NTT passes: adjacent-row grouping for narrow matrices (w = 4 ... 13 at
+# heights with strided passes), single-chunk tiles up to 112 columns, evenly divided chunks (w = 224), ragged last chunks
+# (113, 130, 493, 655, 815 = the hash chips), odd widths (one-column butterflies), 256 / 512 / 1024-thread tiles
+@pytest.mark.parametrize("log_n,w", [(14, 4), (15, 8), (16, 9), (17, 6), (14, 13), (14, 96), (13, 112), (13, 113), (12, 224), (12, 493),
+                                     (11, 655), (11, 815), (9, 815), (16, 78)])
+def test_lde_tilings_match_oracle(ctx, oracle, log_n, w):
+    x = synth.field_elements((1 << log_n, w), seed=900 + log_n + w)
+    assert np.array_equal(cm.coset_lde(ctx, x, 1), oracle.lde(x, 1))
+
+
 def test_lde_montgomery_repr(ctx, oracle):
     x = synth.field_elements((256, 10), seed=8)
     got = cm.coset_lde(ctx, field.to_monty(x), 1, repr=lurk_amd.REPR_MONTY)
