@@ -142,8 +142,8 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         uint32_t* children = c->digests + c->level_off[l - 1] * 8;
         uint32_t* parents = c->digests + c->level_off[l] * 8;
         const int min_log_h = *std::min_element(c->log_h.begin(), c->log_h.end());
-        if (min_log_h > lh && (n_parents << 1) <= 2048) {
-            // nothing left to inject: finish the tree in one workgroup
+        if (min_log_h > lh && (n_parents << 1) <= 512) {
+            // nothing left to inject: finish the tree in one workgroup (wider levels are faster spread over the CUs)
             span_end(ctx, "merkle_levels");
             span_begin(ctx, "merkle_top");
             LH_TRY(merkle_top(ctx, params, children, n_parents << 1));
