@@ -81,17 +81,6 @@ uint32_t pow_host(uint32_t a_m, uint64_t e) {
     return r;
 }
 
-struct Pooled {  // pooled device block released at scope exit (stream-ordered reuse)
-    lurkhip_ctx* ctx;
-    void* p = nullptr;
-    explicit Pooled(lurkhip_ctx* c) : ctx(c) {}
-    Pooled(const Pooled&) = delete;
-    Pooled& operator=(const Pooled&) = delete;
-    ~Pooled() { pool_release(ctx, p); }
-    int32_t alloc(size_t bytes) { return pool_alloc(ctx, bytes, &p); }
-    uint32_t* u32() const { return (uint32_t*)p; }
-};
-
 void push_ef(std::vector<uint32_t>& out, const ef& e) {
     for (int i = 0; i < 4; i++) out.push_back(bb::from_monty(e.c[i]));
 }

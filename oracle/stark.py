@@ -113,11 +113,6 @@ def interactions_of_row(air, main, prep, r, public=()):
     return [(m, v, True) for m, v in b.sends] + [(m, v, False) for m, v in b.receives]
 
 
-def log_quotient_degree(air, sample_row_width=None):
-    """sphinx Chip::new: every Lair chip has degree-3 constraints and interactions -> log2_ceil(3 - 1) = 1."""
-    return 1
-
-
 def fingerprint(alpha, beta, vals, kind=oair.INTERACTION_KIND_MEMORY):
     d = ef_add(alpha, ef(kind))  # alpha + beta^0 * argument_index
     bp = beta

@@ -185,3 +185,25 @@ def test_mul_divrem_bignum_machines_prove_and_verify(ctx, entry, args):
     airs = [oa.EntrypointAir(otop.index[entry], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
     airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
     assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+
+
+def test_prover_edge_parameters_and_errors(ctx):
+    """One query / no proof of work; invalid arguments come back as status codes, not crashes."""
+    import ctypes as C
+
+    from lurk_amd import _native as N
+
+    m, root, proofs, pv = prove(ctx, DEMO, "factorial", [5], num_queries=1, pow_bits=0)
+    assert proofs[0].pow_witness == 0 and len(proofs[0].query_indices) == 1
+    assert verify(DEMO, "factorial", root, proofs, len(pv))
+    # null / out-of-range arguments
+    out = C.c_void_p()
+    assert N.lib.lurkhip_shard_prove(ctx.handle, None, None, None, None, 0, 1, 0, C.byref(out)) == N.ERR_INVALID_ARG
+    assert N.lib.lurkhip_shard_commit(ctx.handle, 0, None, None, None, None, 1, C.byref(out), None) == N.ERR_INVALID_ARG
+    assert N.lib.lurkhip_air_mem(7, C.byref(out)) != N.OK  # there is no 7-wide memory table (execute.rs:243-244)
+    top = lair.Toplevel(DEMO)
+    assert N.lib.lurkhip_air_func(top.handle, 99, C.byref(out)) == N.ERR_INVALID_ARG
+    ch = prover.Challenger(ctx)
+    ch.observe([1, 2, 3])
+    a = ch.clone()
+    assert a.sample_ext() == ch.sample_ext()  # clones continue identically
