@@ -109,6 +109,19 @@ class Hasher:
             raise ValueError("preimage length must be 24, 32 or 40")  # zstore.rs:241-248 `unreachable!()`
         return chip.hash(preimg)
 
+    def hash_many(self, preimgs) -> list[list[int]]:
+        """Digests of many preimages at once: one kernel launch per width present (24 / 32 / 40)."""
+        out = [None] * len(preimgs)
+        for width, chip in self.chips.items():
+            idx = [i for i, p in enumerate(preimgs) if len(p) == width]
+            if idx:
+                digests = chip.hash_batch(np.array([preimgs[i] for i in idx], dtype=np.uint32))
+                for i, d in zip(idx, digests):
+                    out[i] = [int(v) for v in d]
+        if any(o is None for o in out):
+            raise ValueError("preimage length must be 24, 32 or 40")
+        return out
+
     def hash3(self, preimg):
         assert len(preimg) == 24
         return self.hash(preimg)

@@ -55,6 +55,41 @@ class ZStore:
             self.hashes[key] = d
         return d
 
+    def hash_many(self, preimgs) -> list[tuple]:
+        """Memoised digests of many preimages; the misses go to the hasher in one batch per width (SURVEY.md 8f.1:
+        level-order hashing of independent nodes instead of one kernel round trip per node)."""
+        keys = [tuple(p) for p in preimgs]
+        missing = [k for k in dict.fromkeys(keys) if k not in self.hashes]
+        if missing:
+            if hasattr(self.hasher, "hash_many"):
+                digests = self.hasher.hash_many([list(k) for k in missing])
+            else:
+                digests = [self.hasher.hash(list(k)) for k in missing]
+            for k, d in zip(missing, digests):
+                self.hashes[k] = tuple(int(x) for x in d)
+        return [self.hashes[k] for k in keys]
+
+    def intern_strings(self, strings) -> list[ZPtr]:
+        """intern_string for many strings at once, level by level: strings are right-nested (char, tail) pairs
+        (zstore.rs:397-413), so the tails of length k of all strings form one independent batch."""
+        strings = list(strings)
+        todo = [s for s in dict.fromkeys(strings) if s not in self.str_cache]
+        # suffixes by length, shortest first; the empty suffix is the null string pointer
+        known = {"": self.null(TAG["Str"])}
+        known.update(self.str_cache)
+        level = 1
+        while True:
+            batch = sorted({s[len(s) - level:] for s in todo if len(s) >= level} - set(known))
+            if not batch and all(len(s) < level for s in todo):
+                break
+            digests = self.hash_many([self.char(suf[0]).flatten() + known[suf[1:]].flatten() for suf in batch])
+            for suf, d in zip(batch, digests):
+                known[suf] = ZPtr(TAG["Str"], d)
+            level += 1
+        for s in todo:
+            self.str_cache[s] = known[s]
+        return [self.str_cache[s] for s in strings]
+
     def intern_tuple11(self, tag: int, a: ZPtr, b: ZPtr) -> ZPtr:
         return ZPtr(tag, self.hash(a.flatten() + b.flatten()))
 

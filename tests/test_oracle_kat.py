@@ -49,3 +49,15 @@ def test_field_inverse_pins(oracle):
     assert oracle.f_inv(3) == 1342177281
     assert oracle.f_inv(7) == 862828252
     assert oracle.f_inv(6) == 1677721601
+
+
+def test_batched_string_interning_equals_sequential(oracle):
+    """ZStore.intern_strings (level-order batches) gives the digests of one-at-a-time interning and leaves the same memo."""
+    from lurk_amd.zstore import ZStore
+
+    words = ["lurk", "lurk-user", "builtin", "nil", "x", "", "cons", "lambda", "user", "lurk"]
+    a, b = ZStore(OracleHasher(oracle)), ZStore(OracleHasher(oracle))
+    seq = [a.intern_string(w) for w in words]
+    bat = b.intern_strings(words)
+    assert seq == bat
+    assert a.hashes == b.hashes

@@ -97,3 +97,16 @@ def test_device_pointer_path_large(ctx, oracle):
     assert np.array_equal(got[idx], oracle.p2_hash8(24, x[idx]))
     # determinism / no cross-row interference: same rows hashed alone give the same digests
     assert np.array_equal(chip.hash_batch(x[idx]), got[idx])
+
+
+def test_batched_zstore_hashing_on_gpu(ctx):
+    """Level-order batched interning through the HIP hash kernels == one-at-a-time interning."""
+    from lurk_amd.poseidon import Hasher
+    from lurk_amd.zstore import ZStore
+
+    words = ["lurk", "lurk-user", "builtin", "nil", "t", "cons", "lambda", "letrec", "fib", "quote", "a-rather-long-symbol-name"]
+    a, b = ZStore(Hasher(ctx)), ZStore(Hasher(ctx))
+    assert [a.intern_string(w) for w in words] == b.intern_strings(words)
+    assert a.hashes == b.hashes
+    mixed = [[1] * 24, list(range(32)), [7] * 40, [2] * 24]
+    assert b.hash_many(mixed) == [tuple(a.hash(p)) for p in mixed]
