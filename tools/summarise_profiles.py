@@ -1,0 +1,69 @@
+#!/usr/bin/env python3
+"""Turns the rocprofv3 outputs of one bench run (gpurun_out/<tag>...) into the summaries kept under profiles/.
+
+usage: python tools/summarise_profiles.py <tag>     e.g. r1j
+expects gpurun_out/prof_<tag>/bench_kernel_stats.csv, gpurun_out/pmc_<tag>_{FETCH_SIZE,WRITE_SIZE,sq}/bench_counter_collection.csv,
+gpurun_out/bench_<tag>.json
+"""
+import collections
+import csv
+import json
+import re
+import shutil
+import sys
+
+tag = sys.argv[1]
+
+
+def kname(s):
+    m = re.search(r"(k_[a-z_0-9]+)", s)
+    return m.group(1) if m else s[:40]
+
+
+res = {}
+for c in ("FETCH_SIZE", "WRITE_SIZE"):
+    tot, cnt = collections.Counter(), collections.Counter()
+    with open(f"gpurun_out/pmc_{tag}_{c}/bench_counter_collection.csv") as f:
+        for row in csv.DictReader(f):
+            if row["Counter_Name"] != c:
+                continue
+            n = kname(row["Kernel_Name"])
+            tot[n] += float(row["Counter_Value"])
+            cnt[n] += 1
+    res[c] = (tot, cnt)
+with open("profiles/r01_pmc_hbm_per_kernel.csv", "w") as f:
+    f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --steps 1 --warmup 0`\n")
+    f.write("# units: KB as reported; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, WRITE_SIZE uncalibrated\n")
+    f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
+    for k in sorted(res["FETCH_SIZE"][0], key=lambda k: -(res["FETCH_SIZE"][0][k] + res["WRITE_SIZE"][0][k])):
+        f.write(f"{k},{res['FETCH_SIZE'][1][k]},{res['FETCH_SIZE'][0][k]:.0f},{res['WRITE_SIZE'][0][k]:.0f}\n")
+F = (res["FETCH_SIZE"][0]["k_level"] + res["FETCH_SIZE"][0]["k_leaves"]) * 1024
+W = (res["WRITE_SIZE"][0]["k_level"] + res["WRITE_SIZE"][0]["k_leaves"]) * 1024
+
+tot, dur, cnt, seen = collections.defaultdict(collections.Counter), collections.Counter(), collections.Counter(), set()
+with open(f"gpurun_out/pmc_{tag}_sq/bench_counter_collection.csv") as f:
+    for row in csv.DictReader(f):
+        n = kname(row["Kernel_Name"])
+        tot[n][row["Counter_Name"]] += float(row["Counter_Value"])
+        if row["Dispatch_Id"] not in seen:
+            seen.add(row["Dispatch_Id"])
+            dur[n] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
+            cnt[n] += 1
+cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"]
+with open("profiles/r01_pmc_sq_per_kernel.csv", "w") as f:
+    f.write("# rocprofv3 --pmc " + " ".join(cols) + " --kernel-trace, `python bench.py --steps 1 --warmup 0`; valu_tinst_s = SQ_INSTS_VALU * 64 lanes / duration (int32 issue peak 39.3)\n")
+    f.write("kernel,launches,ms," + ",".join(cols) + ",valu_tinst_s\n")
+    for n in sorted(dur, key=lambda k: -dur[k]):
+        v = tot[n]
+        rate = v["SQ_INSTS_VALU"] * 64 / (dur[n] * 1e-9) / 1e12 if dur[n] else 0
+        f.write(f"{n},{cnt[n]},{dur[n] / 1e6:.3f}," + ",".join(f"{v[c]:.4g}" for c in cols) + f",{rate:.2f}\n")
+hv = (tot["k_level"]["SQ_INSTS_VALU"] + tot["k_leaves"]["SQ_INSTS_VALU"]) * 64 / ((dur["k_level"] + dur["k_leaves"]) * 1e-9) / 1e12
+json.dump({"log_rows": 20, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (profiles/r01_pmc_hbm_per_kernel.csv)",
+           "correction": "FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+           "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
+           "merkle_hash_valu_tinst_s": hv, "int32_valu_peak_tinst_s": 39.3}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
+shutil.copy(f"gpurun_out/prof_{tag}/bench_kernel_stats.csv", "profiles/r01_full_prove_kernel_stats.csv")
+shutil.copy(f"gpurun_out/bench_{tag}.json", "profiles/r01_bench_full_prove.json")
+with open("profiles/r01_full_prove_under_rocprof.log", "w") as f:
+    f.write("".join(l for l in open(f"gpurun_out/prof_{tag}_bench.log") if l.startswith("{") or "rocprofv3" in l)[:6000])
+print("merkle hash: traffic", 2 * F + W, "B/step; VALU", round(hv, 2), "Tinstr/s")
