@@ -120,6 +120,18 @@ int32_t lurkhip_poseidon2_wide_witness(lurkhip_ctx* ctx, int32_t width, size_t n
 int32_t lurkhip_poseidon2_wide_witness_dev(lurkhip_ctx* ctx, int32_t width, size_t n, const uint32_t* in,
                                            uint32_t* out, int32_t repr);
 
+/* The narrow Poseidon2 chip: one trace row per round, R_F + R_P + 1 rows per permutation, row =
+ * input[W] | is_init | rounds[R_F + R_P] | add_rc[W] | sbox_deg_3[W] | sbox_deg_7[W] | output[W].
+ * lurkhip_poseidon2_trace_shape: width of a row and the padded height (next power of two of n * (R_F + R_P + 1)).
+ * lurkhip_poseidon2_trace: in [n][width] -> out [height][row width], rows past the last permutation are zero.
+ * Replaces Poseidon2Chip::generate_trace, /root/reference/src/poseidon/trace.rs:14-46 (row contents
+ * /root/reference/src/poseidon/columns.rs:16-89; BaseAir::width /root/reference/src/poseidon/air.rs:15-19). */
+int32_t lurkhip_poseidon2_trace_shape(int32_t width, size_t n, uint32_t* row_width, uint64_t* height);
+int32_t lurkhip_poseidon2_trace(lurkhip_ctx* ctx, int32_t width, size_t n, const uint32_t* in, uint32_t* out,
+                                int32_t repr);
+int32_t lurkhip_poseidon2_trace_dev(lurkhip_ctx* ctx, int32_t width, size_t n, const uint32_t* in, uint32_t* out,
+                                    int32_t repr);
+
 /* ------------------------------------------------------------------- commit */
 /* The commit stage of the STARK prover: coset low-degree extension of each trace matrix followed by
  * one Poseidon2-width-16 Merkle tree over all of them.
@@ -275,6 +287,8 @@ int32_t lurkhip_air_func(const lurkhip_toplevel* top, int32_t func_idx, lurkhip_
 int32_t lurkhip_air_mem(uint32_t len, lurkhip_air** out);
 int32_t lurkhip_air_bytes(lurkhip_air** out);
 int32_t lurkhip_air_entrypoint(uint32_t func_idx, uint32_t num_public_values, lurkhip_air** out);
+/* Air::eval of the narrow Poseidon2 chip, /root/reference/src/poseidon/air.rs:21-165 (no lookups) */
+int32_t lurkhip_air_poseidon2(int32_t width, lurkhip_air** out);
 int32_t lurkhip_air_free(lurkhip_air* air);
 const char* lurkhip_air_name(const lurkhip_air* air);
 /* info[16]: 0 width, 1 preprocessed width, 2 #constraints, 3 #sends, 4 #receives, 5 max constraint degree,

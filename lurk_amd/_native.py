@@ -79,6 +79,9 @@ SIGNATURES = {
     "lurkhip_poseidon2_hash8_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_wide_witness": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_wide_witness_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_trace_shape": (_i32, [_i32, _sz, C.POINTER(C.c_uint32), C.POINTER(C.c_uint64)]),
+    "lurkhip_poseidon2_trace": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
+    "lurkhip_poseidon2_trace_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_set_merkle_poseidon2": (_i32, [_p, _i32, _u32p, _u32p, _u32p]),
     "lurkhip_coset_lde": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
     "lurkhip_coset_lde_dev": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
@@ -123,6 +126,7 @@ SIGNATURES = {
     "lurkhip_air_mem": (_i32, [C.c_uint32, C.POINTER(_p)]),
     "lurkhip_air_bytes": (_i32, [C.POINTER(_p)]),
     "lurkhip_air_entrypoint": (_i32, [C.c_uint32, C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_air_poseidon2": (_i32, [_i32, C.POINTER(_p)]),
     "lurkhip_air_free": (_i32, [_p]),
     "lurkhip_air_name": (C.c_char_p, [_p]),
     "lurkhip_air_info": (_i32, [_p, _u32p]),

@@ -52,8 +52,14 @@ class ChipAir:
         h = C.c_void_p()
         return cls(_new(N.lib.lurkhip_air_entrypoint(func_idx, num_public_values, C.byref(h)), h))
 
+    @classmethod
+    def for_poseidon2(cls, width: int) -> "ChipAir":
+        """The narrow (one row per round) Poseidon2 chip, /root/reference/src/poseidon/air.rs:21-165."""
+        h = C.c_void_p()
+        return cls(_new(N.lib.lurkhip_air_poseidon2(width, C.byref(h)), h))
+
     def __del__(self):
-        if getattr(self, "handle", None) and N is not None:
+        if getattr(self, "handle", None) and N is not None and getattr(N, "lib", None) is not None:
             N.lib.lurkhip_air_free(self.handle)
             self.handle = None
 
@@ -79,7 +85,8 @@ class ChipAir:
         ctx.check(N.lib.lurkhip_air_eval_rows(ctx.handle, self.handle, n, _addr(local), _addr(nxt), _addr(pl) if pl is not None else None,
                                               _addr(pn) if pn is not None else None, _addr(pub) if pub is not None else None, _addr(sel),
                                               _addr(cons_arg), _addr(inter_arg)))
-        return cons_arg, inter_arg
+        # chips without constraints / interactions: the dummy one-word buffers only keep the pointers valid
+        return (cons_arg if self.num_constraints else cons[:, :0]), (inter_arg if self.interaction_words else inter[:, :0])
 
     def check_trace(self, ctx: Context, height: int, main_dev, prep_dev=None, public=None):
         """(-1, -1) when every constraint vanishes on every row, else (row, constraint index) of the first failure.

@@ -140,12 +140,9 @@ struct P2Consts {
     const uint32_t *diag, *ext_rc, *int_rc;
 };
 P2Consts p2_consts(int w) {
-    switch (w) {
-        case 24: return {24, 21, LURK_P2_DIAG_24, LURK_P2_EXT_RC_24, LURK_P2_INT_RC_24};
-        case 32: return {32, 30, LURK_P2_DIAG_32, LURK_P2_EXT_RC_32, LURK_P2_INT_RC_32};
-        case 40: return {40, 38, LURK_P2_DIAG_40, LURK_P2_EXT_RC_40, LURK_P2_INT_RC_40};
-        default: throw ExecError("no Poseidon2 AIR for width " + std::to_string(w));
-    }
+    for (int i = 0; i < LURK_P2_NUM_WIDTHS; i++)
+        if (LURK_P2_PARAMS[i].width == w) return {w, LURK_P2_PARAMS[i].rounds_p, LURK_P2_PARAMS[i].diag, LURK_P2_PARAMS[i].ext_rc, LURK_P2_PARAMS[i].int_rc};
+    throw ExecError("no Poseidon2 AIR for width " + std::to_string(w));
 }
 
 // p3 Poseidon2ExternalMatrixGeneral on expressions: M4 = circ(2,3,1,1) per 4-chunk, then add the column sums
@@ -823,6 +820,68 @@ ChipAir build_entrypoint_air(uint32_t func_idx, uint32_t num_public_values) {
         rel.push_back(b.main(i));
     }
     b.require(rel, b.zero(), b.zero(), b.zero(), b.one(), b.one());
+    return air;
+}
+
+// Poseidon2Chip::eval, one row per round (poseidon/air.rs:21-165); columns input[W] | is_init | rounds[R] | add_rc[W] |
+// sbox_deg_3[W] | sbox_deg_7[W] | output[W] (poseidon/columns.rs:16-25); round constants in the order of
+// poseidon/config.rs:59-72.  No lookups.
+ChipAir build_poseidon2_air(uint32_t width) {
+    const P2Consts pc = p2_consts((int)width);
+    const uint32_t W = width, RP = (uint32_t)pc.rp, R = 8 + RP;
+    ChipAir air;
+    air.name = "Poseidon2[" + std::to_string(width) + "]";
+    air.width = 5 * W + 1 + R;
+    Builder b(air);
+    const uint32_t o_init = W, o_rounds = W + 1, o_rc = W + 1 + R, o_s3 = o_rc + W, o_s7 = o_s3 + W, o_out = o_s7 + W;
+    auto flag_sum = [&](uint32_t from, uint32_t to) {
+        E acc = b.zero();
+        for (uint32_t r = from; r < to; r++) acc = b.add(acc, b.main(o_rounds + r));
+        return acc;
+    };
+    const E is_init = b.main(o_init);
+    const E is_external_first = flag_sum(0, 4), is_internal = flag_sum(4, 4 + RP), is_external_second = flag_sum(4 + RP, R);
+    const E is_external = b.add(is_external_first, is_external_second);
+    const E is_linear = b.add(is_init, is_external);
+    b.assert_bool(is_init);
+    for (uint32_t r = 0; r < R; r++) b.assert_bool(b.main(o_rounds + r));
+    const E is_real = b.add(b.add(is_init, is_internal), is_external);
+    b.assert_bool(is_real);
+    std::vector<E> add_rc(W);
+    for (uint32_t i = 0; i < W; i++) add_rc[i] = b.main(i);
+    for (uint32_t r = 0; r < R; r++) {
+        const E flag = b.main(o_rounds + r);
+        if (r >= 4 && r < 4 + RP) {
+            add_rc[0] = b.add(add_rc[0], b.mul(flag, b.cst(pc.int_rc[r - 4])));
+        } else {
+            const uint32_t* rc = pc.ext_rc + (size_t)(r < 4 ? r : r - RP) * W;
+            for (uint32_t i = 0; i < W; i++) add_rc[i] = b.add(add_rc[i], b.mul(flag, b.cst(rc[i])));
+        }
+    }
+    for (uint32_t i = 0; i < W; i++) b.assert_eq(add_rc[i], b.main(o_rc + i), is_real);
+    for (uint32_t i = 0; i < W; i++) {
+        const E x = b.main(o_rc + i), s3 = b.main(o_s3 + i), s7 = b.main(o_s7 + i);
+        b.assert_eq(b.mul(b.mul(x, x), x), s3);
+        b.assert_eq(b.mul(b.mul(s3, s3), x), s7);
+    }
+    std::vector<E> sbox_result(W);
+    for (uint32_t i = 0; i < W; i++) {
+        const E x = b.main(o_rc + i), s7 = b.main(o_s7 + i);
+        sbox_result[i] = i == 0 ? b.add(b.mul(is_init, x), b.mul(b.add(is_internal, is_external), s7))
+                                : b.add(b.mul(b.add(is_init, is_internal), x), b.mul(is_external, s7));
+    }
+    {
+        std::vector<E> state = sbox_result;
+        external_linear_layer(b, state);
+        for (uint32_t i = 0; i < W; i++) b.assert_eq(state[i], b.main(o_out + i), is_linear);
+    }
+    {
+        std::vector<E> state = sbox_result;
+        internal_linear_layer(b, state, pc.diag);
+        for (uint32_t i = 0; i < W; i++) b.assert_eq(state[i], b.main(o_out + i), is_internal);
+    }
+    const E is_not_last_round = b.sub(is_real, b.main(o_rounds + R - 1));
+    for (uint32_t i = 0; i < W; i++) b.assert_eq(b.main(o_out + i), b.main_next(i), is_not_last_round);
     return air;
 }
 

@@ -120,6 +120,7 @@ ChipAir build_func_air(const Toplevel& t, const Func& f);
 ChipAir build_mem_air(uint32_t len);
 ChipAir build_bytes_air();
 ChipAir build_entrypoint_air(uint32_t func_idx, uint32_t num_public_values);
+ChipAir build_poseidon2_air(uint32_t width);  // the narrow (one row per round) Poseidon2 chip
 
 // Lowered programs (air_program.h): the constraint program asserts every constraint in order, the
 // interaction program emits sends (declaration order) then receives.

@@ -87,7 +87,9 @@ template <int W>
 __device__ __forceinline__ void external_layer(uint32_t (&s)[W]) {
 #pragma unroll
     for (int i = 0; i < W; i += 4) m4(s[i], s[i + 1], s[i + 2], s[i + 3]);
-    if constexpr (W > 4) {
+    // width 4 takes the same arm as the larger widths in p3's Poseidon2ExternalMatrixGeneral: the sums are added there
+    // too, i.e. the layer is 2*M4 [UPSTREAM-RECALL; no in-tree vector pins width 4]
+    {
         uint32_t sums[4];
 #pragma unroll
         for (int k = 0; k < 4; k++) {

@@ -699,6 +699,9 @@ int32_t lurkhip_air_bytes(lurkhip_air** out) {
 int32_t lurkhip_air_entrypoint(uint32_t func_idx, uint32_t num_public_values, lurkhip_air** out) {
     return air_guard(out, [&] { return lair::build_entrypoint_air(func_idx, num_public_values); });
 }
+int32_t lurkhip_air_poseidon2(int32_t width, lurkhip_air** out) {
+    return air_guard(out, [&] { return lair::build_poseidon2_air((uint32_t)width); });
+}
 int32_t lurkhip_air_from_chip(lair::ChipAir&& air, lurkhip_air** out) {
     return air_guard(out, [&] { return std::move(air); });
 }

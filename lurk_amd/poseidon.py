@@ -97,6 +97,44 @@ class PoseidonChipset:
         return [int(v) for v in self.permute_batch(x)[0]]
 
 
+class Poseidon2Chip:
+    """The narrow chip of /root/reference/src/poseidon/mod.rs:17-27: one trace row per round.  `generate_trace` keeps the
+    reference's meaning (/root/reference/src/poseidon/trace.rs:14-46): a list of W-lane states -> a row-major matrix of
+    next_power_of_two(len * (R_F + R_P + 1)) rows, zero rows after the last permutation."""
+
+    def __init__(self, ctx: Context, width: int):
+        if N.lib.lurkhip_poseidon2_num_cols(width) < 0:
+            raise ValueError(f"unsupported Poseidon2 width {width}")
+        self.ctx = ctx
+        self.input_width = width
+
+    def shape(self, n: int) -> tuple[int, int]:
+        """(height, width) of the trace of n permutations."""
+        import ctypes as C
+
+        w, h = C.c_uint32(), C.c_uint64()
+        N.check(N.lib.lurkhip_poseidon2_trace_shape(self.input_width, n, C.byref(w), C.byref(h)))
+        return int(h.value), int(w.value)
+
+    def width(self) -> int:  # BaseAir::width, poseidon/air.rs:15-19
+        return self.shape(0)[1]
+
+    def generate_trace(self, inputs, repr: int = N.REPR_CANONICAL) -> np.ndarray:
+        x = as_u32(np.asarray(inputs, dtype=np.uint32).reshape(-1, self.input_width))
+        out = np.empty(self.shape(x.shape[0]), dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_poseidon2_trace(self.ctx.handle, self.input_width, x.shape[0], _addr(x) if x.size else None, _addr(out), repr))
+        return out
+
+    def generate_trace_dev(self, x, out, n: int, repr: int = N.REPR_CANONICAL):
+        """x [n][W] -> out [shape(n)], device buffers, asynchronous on the context's stream."""
+        self.ctx.check(N.lib.lurkhip_poseidon2_trace_dev(self.ctx.handle, self.input_width, n, _addr(x), _addr(out), repr))
+
+    def air(self):
+        from .air import ChipAir
+
+        return ChipAir.for_poseidon2(self.input_width)
+
+
 class Hasher:
     """hash3 / hash4 / hash5 over widths 24 / 32 / 40 (core/chipset.rs:176-182)."""
 

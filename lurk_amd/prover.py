@@ -156,7 +156,99 @@ def parse_proof(words: np.ndarray) -> ShardProof:
                       pow_witness, indices, rounds, layers, n_prep, words)
 
 
-class Machine:
+class _ShardProver:
+    """commit / prove / free of one shard's chip list through the C ABI; shared by the Lair `Machine` and the generic
+    `StarkMachine`.  Subclasses provide `self.ctx`, `self.pk`, `self.chips` and `_prep_index(machine_index)`."""
+
+    def _prep_index(self, machine_index: int) -> int:
+        return -1
+
+    def close(self):
+        if self.pk:
+            N.lib.lurkhip_pk_free(self.ctx.handle, self.pk)
+            self.pk = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def commit_shard(self, traces):
+        n = len(traces)
+        airs = (C.c_void_p * n)(*[a.handle.value for _, a, _, _ in traces])
+        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, _, _, t in traces])
+        lh = np.array([lg for _, _, lg, _ in traces], dtype=np.uint32)
+        prep_idx = np.array([self._prep_index(mi) for mi, _, _, _ in traces], dtype=np.int32)
+        h = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_shard_commit(self.ctx.handle, n, C.cast(airs, C.c_void_p), _addr(lh), C.cast(ptrs, C.c_void_p), _addr(prep_idx),
+                                                  LOG_BLOWUP, C.byref(h), _addr(root)))
+        self._included = getattr(self, "_included", {})
+        self._included[h.value] = [mi for mi, _, _, _ in traces]
+        return h, [int(x) for x in root]
+
+    def prove_shard(self, shard_handle, challenger: Challenger, public_values, num_queries=NUM_QUERIES, pow_bits=POW_BITS, parse=True):
+        pv = as_u32(public_values)
+        p = C.c_void_p()
+        self.ctx.check(N.lib.lurkhip_shard_prove(self.ctx.handle, self.pk, shard_handle, challenger.handle, _addr(pv), len(pv), num_queries, pow_bits,
+                                                 C.byref(p)))
+        n = int(N.lib.lurkhip_proof_words(p))
+        words = np.zeros(n, dtype=np.uint32)
+        N.check(N.lib.lurkhip_proof_read(p, _addr(words)))
+        N.lib.lurkhip_proof_free(p)
+        if not parse:
+            return words
+        proof = parse_proof(words)
+        # the C ABI numbers chips by their position in the shard's chip list: map back to the machine's chip vector
+        included = self._included[shard_handle.value]
+        for c in proof.chips:
+            c.machine_index = included[c.machine_index]
+        return proof
+
+    def free_shard(self, shard_handle):
+        self._included.pop(shard_handle.value, None)
+        N.lib.lurkhip_shard_free(self.ctx.handle, shard_handle)
+
+
+class StarkMachine(_ShardProver):
+    """A machine over an explicit chip list without preprocessed traces (sphinx `StarkMachine::new(config, chips, n)`), for
+    chips that live outside a Lair toplevel -- e.g. the narrow Poseidon2 chip."""
+
+    def __init__(self, ctx: Context, airs):
+        self.ctx = ctx
+        self.chips = [("air", None, a) for a in airs]
+        self.pk = None
+
+    def setup(self):
+        h = C.c_void_p()
+        root = np.zeros(8, dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_setup(self.ctx.handle, 0, None, None, None, LOG_BLOWUP, C.byref(h), _addr(root)))
+        self.pk = h
+        self.vk_root = [int(x) for x in root]
+        return self.vk_root
+
+    def prove(self, traces, public_values=(), num_queries=NUM_QUERIES, pow_bits=POW_BITS):
+        """traces[i]: device matrix (Montgomery, power-of-two height) of chip i, or None when the chip is not included.
+        One shard; same transcript as Machine.prove."""
+        if self.pk is None:
+            self.setup()
+        pv = np.array(list(public_values), dtype=np.uint32)
+        included = [(mi, self.chips[mi][2], t.shape[0].bit_length() - 1, t) for mi, t in enumerate(traces) if t is not None]
+        ch = Challenger(self.ctx)
+        ch.observe(self.vk_root)
+        ch.observe([0])
+        handle, root = self.commit_shard(included)
+        ch.observe(root)
+        if len(pv):
+            ch.observe(pv)
+        try:
+            return self.prove_shard(handle, ch, pv, num_queries, pow_bits)
+        finally:
+            self.free_shard(handle)
+
+
+class Machine(_ShardProver):
     """Chip vector of one Lair toplevel with `entry` as its entrypoint (lair_chip.rs:196-211)."""
 
     def __init__(self, ctx: Context, toplevel: Toplevel, entry: str, num_public_values: int):
@@ -188,16 +280,8 @@ class Machine:
         self.vk_root = [int(x) for x in root]
         return self.vk_root
 
-    def close(self):
-        if self.pk:
-            N.lib.lurkhip_pk_free(self.ctx.handle, self.pk)
-            self.pk = None
-
-    def __del__(self):
-        try:
-            self.close()
-        except Exception:
-            pass
+    def _prep_index(self, machine_index: int) -> int:
+        return 0 if self.chips[machine_index][0] == "bytes" else -1
 
     def shard_traces(self, shard: Shard):
         """[(machine index, air, log_height, device trace (Montgomery))] of the chips included in the shard
@@ -263,42 +347,6 @@ class Machine:
             if p is not None:
                 p.run(t, repr=N.REPR_MONTY)
         return [(mi, air, lg, t) for mi, air, lg, t, _ in prepared]
-
-    def commit_shard(self, traces):
-        n = len(traces)
-        airs = (C.c_void_p * n)(*[a.handle.value for _, a, _, _ in traces])
-        ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, _, _, t in traces])
-        lh = np.array([lg for _, _, lg, _ in traces], dtype=np.uint32)
-        prep_idx = np.array([0 if self.chips[mi][0] == "bytes" else -1 for mi, _, _, _ in traces], dtype=np.int32)
-        h = C.c_void_p()
-        root = np.zeros(8, dtype=np.uint32)
-        self.ctx.check(N.lib.lurkhip_shard_commit(self.ctx.handle, n, C.cast(airs, C.c_void_p), _addr(lh), C.cast(ptrs, C.c_void_p), _addr(prep_idx),
-                                                  LOG_BLOWUP, C.byref(h), _addr(root)))
-        self._included = getattr(self, "_included", {})
-        self._included[h.value] = [mi for mi, _, _, _ in traces]
-        return h, [int(x) for x in root]
-
-    def prove_shard(self, shard_handle, challenger: Challenger, public_values, num_queries=NUM_QUERIES, pow_bits=POW_BITS, parse=True):
-        pv = as_u32(public_values)
-        p = C.c_void_p()
-        self.ctx.check(N.lib.lurkhip_shard_prove(self.ctx.handle, self.pk, shard_handle, challenger.handle, _addr(pv), len(pv), num_queries, pow_bits,
-                                                 C.byref(p)))
-        n = int(N.lib.lurkhip_proof_words(p))
-        words = np.zeros(n, dtype=np.uint32)
-        N.check(N.lib.lurkhip_proof_read(p, _addr(words)))
-        N.lib.lurkhip_proof_free(p)
-        if not parse:
-            return words
-        proof = parse_proof(words)
-        # the C ABI numbers chips by their position in the shard's chip list: map back to the machine's chip vector
-        included = self._included[shard_handle.value]
-        for c in proof.chips:
-            c.machine_index = included[c.machine_index]
-        return proof
-
-    def free_shard(self, shard_handle):
-        self._included.pop(shard_handle.value, None)
-        N.lib.lurkhip_shard_free(self.ctx.handle, shard_handle)
 
     def prove(self, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS):
         """machine.prove: commit every shard's main traces, observe (preprocessed root, pc_start = 0, then per shard

@@ -521,6 +521,61 @@ def eval_chip(b: Builder, chip, is_real, ins, wit, nonce, reqs):
     return out
 
 
+class Poseidon2NarrowAir:
+    """Poseidon2Chip (one row per round), /root/reference/src/poseidon/air.rs:21-165; columns poseidon/columns.rs:16-25."""
+
+    def __init__(self, width):
+        from . import binding
+
+        self.w = width
+        self.rp, self.diag, self.ext_rc, self.int_rc = binding.p2_params(width)
+        self.rounds = 8 + self.rp
+        self.width = 5 * width + 1 + self.rounds
+        self.name = f"Poseidon2[{width}]"
+
+    def round_constants(self):  # poseidon/config.rs:59-72
+        return [list(c) for c in self.ext_rc[:4]] + [[c] for c in self.int_rc] + [list(c) for c in self.ext_rc[4:]]
+
+    def eval(self, b: Builder):
+        W, R, rp = self.w, self.rounds, self.rp
+
+        def cols(row):
+            o = [0, W, W + 1, W + 1 + R, 2 * W + 1 + R, 3 * W + 1 + R, 4 * W + 1 + R, 5 * W + 1 + R]
+            return [row[o[i]:o[i + 1]] for i in range(7)]
+
+        inp, (is_init,), rounds, add_rc_c, s3_c, s7_c, out = cols(b.local)
+        nxt_in = cols(b.next)[0]
+        is_external_first, is_internal, is_external_second = sum(rounds[:4]), sum(rounds[4:4 + rp]), sum(rounds[4 + rp:])
+        is_external = is_external_first + is_external_second
+        is_linear = is_init + is_external
+        b.assert_bool(is_init)
+        for f in rounds:
+            b.assert_bool(f)
+        is_real = is_init + is_internal + is_external
+        b.assert_bool(is_real)
+        add_rc = list(inp)
+        for flag, consts in zip(rounds, self.round_constants()):
+            for i, c in enumerate(consts):
+                add_rc[i] = add_rc[i] + flag * c
+        for got, want in zip(add_rc, add_rc_c):
+            b.assert_eq(got, want, is_real)
+        for x, s3, s7 in zip(add_rc_c, s3_c, s7_c):
+            b.assert_eq(x * x * x, s3)
+            b.assert_eq(s3 * s3 * x, s7)
+        sbox_result = [is_init * add_rc_c[0] + (is_internal + is_external) * s7_c[0]]
+        sbox_result += [(is_init + is_internal) * add_rc_c[i] + is_external * s7_c[i] for i in range(1, W)]
+        state = list(sbox_result)
+        _external_layer(state)
+        for st, o in zip(state, out):
+            b.assert_eq(st, o, is_linear)
+        total = sum(sbox_result)
+        for i in range(W):
+            b.assert_eq(sbox_result[i] * self.diag[i] + total, out[i], is_internal)
+        is_not_last_round = is_real - rounds[-1]
+        for o, ni in zip(out, nxt_in):
+            b.assert_eq(o, ni, is_not_last_round)
+
+
 class MemAir:  # lair/memory.rs:71-109
     def __init__(self, mem_len):
         self.len = mem_len

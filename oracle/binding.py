@@ -69,6 +69,23 @@ def p2_wide_witness(width: int, x) -> np.ndarray:
     return out
 
 
+def p2_narrow_width(width: int) -> int:
+    return lib().or_p2_narrow_width(width)
+
+
+def p2_narrow_trace(width: int, x) -> np.ndarray:
+    """Trace of the narrow Poseidon2 chip (one row per round) for the given states, zero-padded to a power of two."""
+    x = _u32(x).reshape(-1, width)
+    rp = p2_params(width)[0]
+    rows = x.shape[0] * (8 + rp + 1)
+    height = 1 << max(rows - 1, 0).bit_length()
+    out = np.empty((height, p2_narrow_width(width)), dtype=np.uint32)
+    L = lib()
+    L.or_p2_narrow_trace.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_size_t, C.c_void_p]
+    assert L.or_p2_narrow_trace(width, x.shape[0], x.ctypes.data, height, out.ctypes.data) == 0
+    return out
+
+
 class _P2Params(C.Structure):
     _fields_ = [("width", C.c_int), ("rounds_p", C.c_int), ("diag", C.POINTER(C.c_uint32)), ("ext_rc", C.POINTER(C.c_uint32)),
                 ("int_rc", C.POINTER(C.c_uint32))]

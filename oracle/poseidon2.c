@@ -68,7 +68,8 @@ static void m4(uint32_t* x) {
 
 static void external_layer(int w, uint32_t* s) {
     for (int i = 0; i < w; i += 4) m4(s + i);
-    if (w == 4) return;
+    /* p3's Poseidon2ExternalMatrixGeneral runs width 4 through the same arm as the larger widths, i.e. the sums are added
+     * there too and the layer is 2*M4 [UPSTREAM-RECALL; no in-tree vector pins width 4] */
     uint32_t sums[4] = {0, 0, 0, 0};
     for (int i = 0; i < w; i++) sums[i & 3] = or_add(sums[i & 3], s[i]);
     for (int i = 0; i < w; i++) s[i] = or_add(s[i], sums[i & 3]);
@@ -170,6 +171,61 @@ int or_p2_wide_witness(int width, size_t n, const uint32_t* in, uint32_t* out) {
         memcpy(s, in + k * width, (size_t)width * 4);
         permute_rec(&p, s, out + k * stride + 8);
         memcpy(out + k * stride, s, 32);
+    }
+    return 0;
+}
+
+/* Narrow chip (P5): one row per round, R_F + R_P + 1 rows per permutation, padded with zero rows to a power of two.
+ * Row = input[W] | is_init | rounds[R] | add_rc[W] | sbox_deg_3[W] | sbox_deg_7[W] | output[W]
+ * (poseidon/columns.rs:16-25); row contents poseidon/columns.rs:28-89, row order and round constants
+ * poseidon/trace.rs:14-46 with poseidon/config.rs:59-72 (first external half, internal, second external half). */
+int or_p2_narrow_width(int width) {
+    or_p2_params p;
+    if (or_p2_lookup(width, &p)) return -1;
+    return 5 * width + 1 + 8 + p.rounds_p;
+}
+
+int or_p2_narrow_trace(int width, size_t n, const uint32_t* in, size_t height, uint32_t* out) {
+    or_p2_params p;
+    if (or_p2_lookup(width, &p)) return -1;
+    const int w = width, rounds = 8 + p.rounds_p;
+    const size_t nc = (size_t)or_p2_narrow_width(width);
+    if (height < n * (size_t)(rounds + 1)) return -2;
+    memset(out, 0, height * nc * 4);
+    for (size_t k = 0; k < n; k++) {
+        uint32_t s[OR_MAX_W];
+        memcpy(s, in + k * w, (size_t)w * 4);
+        for (int row = 0; row <= rounds; row++) {
+            uint32_t* c = out + (k * (size_t)(rounds + 1) + (size_t)row) * nc;
+            uint32_t *c_in = c, *c_flags = c + w, *c_rc = c + w + 1 + rounds, *c_s3 = c_rc + w, *c_s7 = c_s3 + w, *c_out = c_s7 + w;
+            memcpy(c_in, s, (size_t)w * 4);
+            memcpy(c_rc, s, (size_t)w * 4);
+            int external = 1;
+            if (row == 0) {
+                c_flags[0] = 1;
+            } else {
+                const int round = row - 1;
+                c_flags[1 + round] = 1;
+                if (round < 4) {
+                    for (int i = 0; i < w; i++) c_rc[i] = or_add(s[i], p.ext_rc[round * w + i]);
+                } else if (round < 4 + p.rounds_p) {
+                    external = 0;
+                    c_rc[0] = or_add(s[0], p.int_rc[round - 4]);
+                } else {
+                    for (int i = 0; i < w; i++) c_rc[i] = or_add(s[i], p.ext_rc[(round - p.rounds_p) * w + i]);
+                }
+            }
+            for (int i = 0; i < w; i++) {
+                c_s3[i] = cube(c_rc[i]);
+                c_s7[i] = or_mul(or_mul(c_s3[i], c_s3[i]), c_rc[i]);
+            }
+            if (row > 0) {
+                for (int i = 0; i < w; i++) s[i] = (i == 0 || external) ? c_s7[i] : c_rc[i];
+            }
+            if (external) external_layer(w, s);
+            else internal_layer(&p, s);
+            memcpy(c_out, s, (size_t)w * 4);
+        }
     }
     return 0;
 }

@@ -136,3 +136,71 @@ def test_lde_properties_at_bench_shape(ctx, oracle):
         assert np.array_equal(rows, la[index])
         assert oracle.merkle_verify([log_n + 1], [w], index, rows, path, c.root)
     c.close()
+
+
+# BASELINE config 5: the width mix of the full Lurk machine - 39 funcs in the order of `test_widths`
+# (src/core/tests/eval_direct.rs:2025-2063), six memory tables, the byte table, the entrypoint row.
+LURK_FUNC_WIDTHS = [97, 188, 10, 78, 148, 110, 81, 79, 97, 115, 78, 107, 70, 68, 72, 94, 66, 54, 66, 9, 50, 86, 58, 61, 114, 52, 104, 81,
+                    493, 655, 815, 53, 53, 85, 166, 44, 26, 38, 78]
+
+
+def lurk_machine_shapes(log_max):
+    """(log_height, width) per chip: eval / apply / env_lookup (widths 78, 114, 52) at the largest height, hash chips at most
+    2^(log_max - 4), the rest drawn from splitmix64 between 2^2 and 2^(log_max - 1)."""
+    draws = synth.splitmix64(len(LURK_FUNC_WIDTHS), synth.SEED + 5)
+    shapes = []
+    for i, w in enumerate(LURK_FUNC_WIDTHS):
+        if i in (3, 24, 25):
+            k = log_max
+        elif w in (493, 655, 815):
+            k = max(log_max - 4 - i % 3, 1)
+        else:
+            k = 2 + int(draws[i] % np.uint64(log_max - 2))
+        shapes.append((k, w))
+    shapes += [(log_max - 1 - i, w) for i, w in enumerate((6, 7, 8, 9, 10, 12))]
+    shapes += [(16 if log_max >= 16 else log_max, 13), (0, 44)]
+    return shapes
+
+
+def test_baseline_config5_lurk_machine_width_mix(ctx, oracle):
+    """One mixed-height commitment over all 47 matrices: root == oracle, openings at every height verify."""
+    log_max = 12
+    shapes = lurk_machine_shapes(log_max)
+    mats = [synth.field_elements((1 << k, w), seed=5000 + i) for i, (k, w) in enumerate(shapes)]
+    c = cm.commit(ctx, mats, log_blowup=1)
+    ldes = [oracle.lde(m, 1) for m in mats]
+    root, _ = oracle.merkle_commit(ldes)
+    assert np.array_equal(c.root, root)
+    lh = [k + 1 for k, _ in shapes]
+    ws = [w for _, w in shapes]
+    top = max(lh)
+    for index in (0, 1, 4097, (1 << top) - 1):
+        rows, path = c.open(index)
+        want = np.concatenate([ldes[i][index >> (top - lh[i])] for i in range(len(mats))])
+        assert np.array_equal(rows, want)
+        assert oracle.merkle_verify(lh, ws, index, rows, path, c.root)
+    c.close()
+
+
+def test_baseline_config5_at_full_height(ctx, oracle):
+    """The same mix with the big chips at 2^18 rows (≈ 1.6 GB of traces and LDEs): too slow for the oracle's tree on one core, so the root
+    is tied to the oracle through openings - every opened row must equal the oracle's LDE of that row's column (sampled
+    columns) and every path must verify against the root with the oracle's Merkle verifier."""
+    import torch
+
+    log_max = 18
+    shapes = lurk_machine_shapes(log_max)
+    mats = [synth.field_elements((1 << k, w), seed=6000 + i) for i, (k, w) in enumerate(shapes)]
+    dev = [torch.from_numpy(m.view(np.int32)).cuda() for m in mats]
+    c = cm.commit_dev(ctx, dev, [k for k, _ in shapes], [w for _, w in shapes], log_blowup=1)
+    lh = [k + 1 for k, _ in shapes]
+    ws = [w for _, w in shapes]
+    top = max(lh)
+    col_lde = {i: oracle.lde(np.ascontiguousarray(mats[i][:, 7:8]), 1)[:, 0] for i in (3, 24, 29, 30, 41)}
+    offs = np.concatenate([[0], np.cumsum(ws)])
+    for index in (0, 3, 99991, (1 << top) - 1):
+        rows, path = c.open(index)
+        assert oracle.merkle_verify(lh, ws, index, rows, path, c.root)
+        for i, col in col_lde.items():
+            assert rows[offs[i] + 7] == col[index >> (top - lh[i])]
+    c.close()
