@@ -28,7 +28,6 @@ namespace lurkhip {
 
 namespace {
 
-constexpr int NTT_BLOCK = 256;
 
 __host__ __device__ inline uint32_t bitrev32(uint32_t x, int bits) {
 #if defined(__HIP_DEVICE_COMPILE__)
@@ -55,15 +54,14 @@ struct PassArgs {
     int log_n;
     int w;
     int bit_lo;        // lowest row-index bit handled by this pass
-    int log_r;         // number of stages (tile rows = 1 << log_r)
-    int col_chunk;     // columns per tile
+    int col0;          // first column of this launch's first chunk
+    int col_chunk;     // columns per tile (every tile of a launch has the same shape)
+    int n_chunks;      // column chunks in this launch
     int in_canonical;  // convert on load
     int out_canonical; // convert on store
     int bitrev_store;  // store row r at bitrev(r, log_n)
-    uint32_t magic_c;  // ceil(2^32 / col_chunk): e / C == umulhi(e, magic) for e < 2^17, C < 2^10
-    uint32_t magic_c2; // same for C / 2 (two-column butterflies), 0 when C is odd
-    uint32_t magic_last;   // the same pair for the ragged last column chunk (w % col_chunk columns)
-    uint32_t magic_last2;
+    int slots;         // row slots per workgroup: thread = (slot, column item), slot < slots
+    uint32_t magic_cv; // ceil(2^32 / column items): tid / Cv == umulhi(tid, magic)
     // Row grouping for narrow matrices: a tile takes 2^log_l ADJACENT rows (consecutive values of the low row bits)
     // for each of its 2^log_r strided rows, so that every global access is a contiguous run of (w << log_l) words
     // instead of w.  Then col_chunk = w << log_l (one chunk) and magic_w divides a tile column by w.
@@ -75,12 +73,12 @@ __device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
     return c == 1 ? (int)e : (int)__umulhi(e, magic);
 }
 
-
-// x <- x + y, y <- (x - y) * tw  (decimation in frequency); (x - y + P) < 2P is a valid Montgomery operand next to a
-// reduced twiddle
+// x <- x + y, y <- (x - y) * tw  (decimation in frequency).  The difference is taken signed, in (-p, p), and goes
+// through the 4-instruction signed Montgomery product; one correction brings the result back to [0, p).
 __device__ __forceinline__ void dif_butterfly(uint32_t& x, uint32_t& y, uint32_t tw) {
     const uint32_t sum = bb::add(x, y);
-    y = bb::mul(x + bb::P - y, tw);
+    const uint32_t r = (uint32_t)bb::smul((int32_t)(x - y), (int32_t)tw);
+    y = bb::umin(r, r + bb::P);
     x = sum;
 }
 __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
@@ -88,118 +86,136 @@ __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
     dif_butterfly(x.y, y.y, tw);
 }
 
-// G consecutive DIF stages s_top .. s_top-G+1 of the LDS tile [R][Cv] (elements of type T = one or two columns).
-// Item (q, c): the 2^G rows t0 | b << s_bot, b < 2^G, of column c, where t0 is q with G zero bits inserted at s_bot.
-template <int G, class T>
-__device__ __forceinline__ void stage_group(T* __restrict__ tile, const uint32_t* __restrict__ tw_lds, int R, int Cv, int s_top, int log_l,
-                                            uint32_t magic_cv, uint32_t magic_w, int w, int cols_per_item, int NT) {
+// G consecutive DIF stages S_TOP .. S_TOP-G+1 of one column (T = one or two matrix columns) of the LDS tile.  The tile is
+// stored column-major, col[t] = tile row t, so the 2^G rows t0 | b << S_BOT of an item sit at compile-time offsets from
+// one address, and so do the item's twiddles tw[(1 << st) + t_lo]: no per-element index arithmetic.  The thread's slot
+// walks the items q = slot, slot + slots, ... of its own column: no division either.
+template <int LOG_R, int S_TOP, int G, class T>
+__device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, int slots) {
     constexpr int M = 1 << G;
-    const int s_bot = s_top - G + 1;
-    const int items = (R >> G) * Cv;
-    for (int e = threadIdx.x; e < items; e += NT) {
-        const int q = fast_div(e, magic_cv, Cv), c = e - q * Cv;
-        const int low = q & ((1 << s_bot) - 1);
-        const int t0 = ((q >> s_bot) << (s_top + 1)) | low;
-        const int l = log_l ? fast_div((uint32_t)(cols_per_item * c), magic_w, w) : 0;
+    constexpr int S_BOT = S_TOP - G + 1;
+    constexpr int ITEMS = (1 << LOG_R) >> G;
+    for (int q = slot; q < ITEMS; q += slots) {
+        const int low = q & ((1 << S_BOT) - 1);
+        const int t0 = ((q >> S_BOT) << (S_TOP + 1)) | low;
+        T* __restrict__ p = col + t0;
+        const uint32_t* __restrict__ twp = tw_l + low;
         T x[M];
 #pragma unroll
-        for (int b = 0; b < M; b++) x[b] = tile[(t0 + (b << s_bot)) * Cv + c];
+        for (int b = 0; b < M; b++) x[b] = p[b << S_BOT];
 #pragma unroll
         for (int g = G - 1; g >= 0; g--) {
-            const int st = s_bot + g;  // stage: pair distance 2^g in b
+            uint32_t tw[1 << (G - 1)];
+#pragma unroll
+            for (int j = 0; j < (1 << g); j++) tw[j] = twp[(1 << (S_BOT + g)) + (j << S_BOT)];
 #pragma unroll
             for (int b = 0; b < M; b++) {
                 if (b & (1 << g)) continue;
-                // twiddle index of the butterfly whose upper row is t0 | b << s_bot: its low `st` bits
-                const int t_lo = low | ((b & ((1 << g) - 1)) << s_bot);
-                const uint32_t tw = tw_lds[(((1 << st) + t_lo) << log_l) + l];
-                dif_butterfly(x[b], x[b | (1 << g)], tw);
+                dif_butterfly(x[b], x[b | (1 << g)], tw[b & ((1 << g) - 1)]);
             }
         }
 #pragma unroll
-        for (int b = 0; b < M; b++) tile[(t0 + (b << s_bot)) * Cv + c] = x[b];
+        for (int b = 0; b < M; b++) p[b << S_BOT] = x[b];
     }
 }
 
-// One pass: tile = rows { hi << (bit_lo+log_r) | t << bit_lo | lo : t < 2^log_r } x col_chunk columns.
-// LDS: [R][C] tile followed by the pass's twiddles: tw_lds[(1 << s) + t_lo] for stage s.
+// stage groups of a pass, top stage first: radix 8 while at least three stages remain (four are split 2 + 2)
+template <int LOG_R, int S_TOP, class T>
+__device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, int slots,
+                                           bool active) {
+    if constexpr (S_TOP >= 0) {
+        constexpr int REM = S_TOP + 1;
+        constexpr int G = REM == 4 ? 2 : (REM >= 3 ? 3 : REM);
+        if (active) stage_group<LOG_R, S_TOP, G, T>(col, tw_l, slot, slots);
+        __syncthreads();
+        run_stages<LOG_R, S_TOP - G, T>(col, tw_l, slot, slots, active);
+    }
+}
+
+__device__ __forceinline__ uint32_t to_monty_elem(uint32_t v) { return bb::to_monty(v); }
+__device__ __forceinline__ uint2 to_monty_elem(uint2 v) { return make_uint2(bb::to_monty(v.x), bb::to_monty(v.y)); }
+__device__ __forceinline__ uint32_t from_monty_elem(uint32_t v) { return bb::from_monty(v); }
+__device__ __forceinline__ uint2 from_monty_elem(uint2 v) { return make_uint2(bb::from_monty(v.x), bb::from_monty(v.y)); }
+__device__ __forceinline__ uint32_t scale_elem(uint32_t v, uint32_t s) { return bb::mul(v, s); }
+__device__ __forceinline__ uint2 scale_elem(uint2 v, uint32_t s) { return make_uint2(bb::mul(v.x, s), bb::mul(v.y, s)); }
+
+// One pass: tile = rows { hi << (bit_lo+LOG_R) | t << bit_lo | lo : t < 2^LOG_R } x col_chunk columns.
+// LDS: the tile column-major with one element of padding per column ([Cv][R + 1] elements of T: consecutive lanes hold
+// consecutive columns, the odd column stride keeps them on distinct banks), then the pass's twiddles
+// tw_lds[l][(1 << s) + t_lo] for stage s.
+template <int LOG_R, class T>
 __global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
-    const int NT = (int)blockDim.x;  // 256, or 1024 for large tiles: the stages are a latency chain per workgroup
-    extern __shared__ __attribute__((aligned(16))) uint32_t tile[];
-    const int R = 1 << a.log_r;
-    const int n_col_chunks = a.log_l ? 1 : (a.w + a.col_chunk - 1) / a.col_chunk;
-    const uint32_t tile_id = blockIdx.x / n_col_chunks;
-    const int chunk = blockIdx.x - tile_id * n_col_chunks;
-    const int col0 = chunk * a.col_chunk;
-    const int C = a.log_l ? a.col_chunk : min(a.col_chunk, a.w - col0);
-    const bool is_full = C == a.col_chunk;
-    // every chunk takes the multiply-high division: the ragged last chunk has its own magic numbers
-    const uint32_t mg = is_full ? a.magic_c : a.magic_last, mg2 = is_full ? a.magic_c2 : a.magic_last2;
+    constexpr int R = 1 << LOG_R;
+    constexpr int RP = R + 1;
+    constexpr int EW = (int)(sizeof(T) / 4);  // matrix columns per element
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    T* tile = reinterpret_cast<T*>(smem);
+    const int Cv = a.col_chunk / EW;
+    uint32_t* tw_lds = smem + (size_t)Cv * RP * EW;
+    const uint32_t tile_id = blockIdx.x / (uint32_t)a.n_chunks;
+    const int chunk = (int)(blockIdx.x - tile_id * (uint32_t)a.n_chunks);
     const int L = 1 << a.log_l;
     const uint32_t lo_bits = (uint32_t)(a.bit_lo - a.log_l);
     const uint32_t lo = (tile_id & ((1u << lo_bits) - 1u)) << a.log_l;  // first of the tile's L adjacent low-bit values
     const uint32_t hi = tile_id >> lo_bits;
-    const uint32_t row_base = (hi << (a.bit_lo + a.log_r)) | lo;
-    uint32_t* tw_lds = tile + R * a.col_chunk;
+    const uint32_t row_base = (hi << (a.bit_lo + LOG_R)) | lo;
 
-    // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l); stored at [k * L + l]
-    for (int idx = threadIdx.x + L; idx < R * L; idx += NT) {
-        int k = idx >> a.log_l, l = idx & (L - 1);
-        int s = 31 - __clz(k);
-        uint32_t t_lo = (uint32_t)k - (1u << s);
-        uint32_t j = (t_lo << a.bit_lo) | (lo + (uint32_t)l);
+    // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l); stored at [l][k], k = (1 << s) + t_lo
+    for (int idx = threadIdx.x; idx < R * L; idx += blockDim.x) {
+        const int l = idx >> LOG_R, k = idx & (R - 1);
+        if (k == 0) continue;
+        const int s = 31 - __clz(k);
+        const uint32_t t_lo = (uint32_t)k - (1u << s);
+        const uint32_t j = (t_lo << a.bit_lo) | (lo + (uint32_t)l);
         tw_lds[idx] = a.tw[(size_t)j << (a.log_n - a.bit_lo - s - 1)];
     }
-    // load: tile row t = the L adjacent matrix rows row_base | t << bit_lo .. + L - 1, contiguous in memory.
-    // Thread (tr, tc) walks rows tr, tr + RS, ... of column tc: one division per thread, none per element.
-    const int RS = NT / C;                       // tile rows covered per sweep (C <= 128 <= NT)
-    const int tr = (int)threadIdx.x / C, tc = (int)threadIdx.x - tr * C;
-    const bool lane_on = tr < RS;
-    const uint32_t l_of_tc = a.log_l ? (uint32_t)fast_div((uint32_t)tc, a.magic_w, a.w) : 0u;
-    if (lane_on) {
-        const uint32_t* __restrict__ src = a.in + col0 + tc;
-        for (int t = tr; t < R; t += RS) {
-            const uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
-            uint32_t v = src[(size_t)row * a.w];
-            if (a.in_canonical) v = bb::to_monty(v);
-            if (a.row_scale) v = bb::mul(v, a.row_scale[row + l_of_tc]);
-            tile[t * C + tc] = v;
+    // thread = (slot, cv): column item cv of the tile for the whole pass, tile rows / items slot, slot + slots, ...
+    const int slot = fast_div(threadIdx.x, a.magic_cv, Cv), cv = (int)threadIdx.x - slot * Cv;
+    const bool active = slot < a.slots;
+    const int tc = cv * EW;                                     // first tile column of the item
+    const int l_of = a.log_l ? fast_div((uint32_t)tc, a.magic_w, a.w) : 0;  // which of the L adjacent rows
+    const int col = a.col0 + chunk * a.col_chunk + tc - l_of * a.w;  // matrix column
+    T* __restrict__ my_col = tile + cv * RP;
+    const uint32_t row0 = row_base + (uint32_t)l_of;
+    if (active) {
+        const uint32_t* __restrict__ src = a.in + col;
+        if (a.in_canonical || a.row_scale) {
+            for (int t = slot; t < R; t += a.slots) {
+                const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
+                T v = *reinterpret_cast<const T*>(src + (size_t)row * a.w);
+                if (a.in_canonical) v = to_monty_elem(v);
+                if (a.row_scale) v = scale_elem(v, a.row_scale[row]);
+                my_col[t] = v;
+            }
+        } else {
+            for (int t = slot; t < R; t += a.slots) {
+                const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
+                my_col[t] = *reinterpret_cast<const T*>(src + (size_t)row * a.w);
+            }
         }
     }
     __syncthreads();
-    // DIF stages s = log_r-1 .. 0 (pair distance 2^s tile rows), taken in groups of up to three: a thread holds the
-    // 2^g rows of one column (or column pair) in registers for g consecutive stages, so the tile makes one LDS round
-    // trip -- and one index computation -- per group instead of per stage (the passes are int32-issue bound).
-    const bool pairs = mg2 != 0;  // two adjacent columns per lane (8-byte LDS accesses; C even, rows 8-byte aligned)
-    const int Cv = pairs ? (C >> 1) : C;
-    const uint32_t mgv = pairs ? mg2 : mg;
-    int remaining = a.log_r, s_top = a.log_r - 1;
-    while (remaining > 0) {
-        const int g = remaining == 4 ? 2 : (remaining >= 3 ? 3 : remaining);
-        if (pairs) {
-            uint2* t2 = reinterpret_cast<uint2*>(tile);
-            if (g == 3) stage_group<3, uint2>(t2, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 2, NT);
-            else if (g == 2) stage_group<2, uint2>(t2, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 2, NT);
-            else stage_group<1, uint2>(t2, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 2, NT);
-        } else {
-            if (g == 3) stage_group<3, uint32_t>(tile, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 1, NT);
-            else if (g == 2) stage_group<2, uint32_t>(tile, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 1, NT);
-            else stage_group<1, uint32_t>(tile, tw_lds, R, Cv, s_top, a.log_l, mgv, a.magic_w, a.w, 1, NT);
-        }
-        __syncthreads();
-        remaining -= g;
-        s_top -= g;
-    }
+    run_stages<LOG_R, LOG_R - 1, T>(my_col, tw_lds + (l_of << LOG_R), slot, a.slots, active);
     // store (same thread-to-element map as the load)
-    if (lane_on) {
-        uint32_t* __restrict__ dst = a.out + col0 + tc;
-        for (int t = tr; t < R; t += RS) {
-            uint32_t row = row_base | ((uint32_t)t << a.bit_lo);
+    if (active) {
+        uint32_t* __restrict__ dst = a.out + col;
+        for (int t = slot; t < R; t += a.slots) {
+            uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
             if (a.bitrev_store) row = bitrev32(row, a.log_n);
-            uint32_t v = tile[t * C + tc];
-            if (a.out_canonical) v = bb::from_monty(v);
-            dst[(size_t)row * a.w] = v;
+            T v = my_col[t];
+            if (a.out_canonical) v = from_monty_elem(v);
+            *reinterpret_cast<T*>(dst + (size_t)row * a.w) = v;
         }
+    }
+}
+
+template <class T>
+void launch_pass(int log_r, unsigned blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
+    switch (log_r) {
+#define LH_NTT_CASE(LR) \
+    case LR: hipLaunchKernelGGL((k_ntt_pass<LR, T>), dim3(blocks), dim3(threads), lds, stream, a); break;
+        LH_NTT_CASE(0) LH_NTT_CASE(1) LH_NTT_CASE(2) LH_NTT_CASE(3) LH_NTT_CASE(4) LH_NTT_CASE(5) LH_NTT_CASE(6) LH_NTT_CASE(7)
+#undef LH_NTT_CASE
     }
 }
 
@@ -278,21 +294,8 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
                 uint32_t* scratch, int w, const uint32_t* row_scale, bool in_canonical, bool out_canonical,
                 bool bitrev_store) {
     const int log_n = plan.log_n;
-    if (log_n == 0) {
-        // 1 x w: identity (times scale)
-        PassArgs a{src, dst, plan.tw_fwd, row_scale, 0, w, 0, 0, w < 64 ? w : 64, in_canonical, out_canonical, 0, 0, 0};
-        a.magic_c = magic_for(a.col_chunk);
-        a.magic_last = (w % a.col_chunk) ? magic_for(w % a.col_chunk) : 0;
-        a.magic_last2 = 0;
-        a.log_l = 0;
-        a.magic_w = 0;
-        int chunks = (w + a.col_chunk - 1) / a.col_chunk;
-        hipLaunchKernelGGL(k_ntt_pass, dim3(chunks), dim3(NTT_BLOCK), (size_t)(a.col_chunk + 1) * 4, ctx->stream, a);
-        LH_HIP(ctx, hipGetLastError());
-        return LURKHIP_OK;
-    }
-    // tile budget: rows * cols * 4 B <= 64 KiB so two blocks fit a CU.  Prefer a chunk width that divides w (no
-    // ragged chunk) and is even (two-column butterflies): the largest such divisor in [32, 112], else 64.
+    // Prefer a chunk width that divides w (no ragged chunk) and is even (two-column butterflies): the largest such
+    // divisor in [32, 112], else 64.
     int col_chunk = w;
     if (w > 112) {
         col_chunk = 64;
@@ -302,11 +305,15 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
                 break;
             }
     }
+    // tile budget: (rows + 1) * cols * 4 B + twiddles <= 64 KiB so two or three workgroups fit a CU
+    auto lds_bytes = [](int log_r, int cols, int log_l) {
+        return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
+    };
     int max_log_r = 7;
-    while (((size_t)1 << max_log_r) * col_chunk * 4 > 64 * 1024 && max_log_r > 1) max_log_r--;
+    while (lds_bytes(max_log_r, col_chunk, 0) > 64 * 1024 && max_log_r > 1) max_log_r--;
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
-    const int n_chunks = (w + col_chunk - 1) / col_chunk;
+    const int n_full = w / col_chunk, last_w = w % col_chunk;
     const uint32_t* cur_in = src;
     for (size_t p = 0; p < passes.size(); p++) {
         bool last = p + 1 == passes.size();
@@ -322,39 +329,43 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         a.log_n = log_n;
         a.w = w;
         a.bit_lo = passes[p].first;
-        a.log_r = passes[p].second;
-        a.col_chunk = col_chunk;
+        const int log_r = passes[p].second;
         a.in_canonical = (p == 0 && in_canonical) ? 1 : 0;
         a.out_canonical = (last && out_canonical) ? 1 : 0;
         a.bitrev_store = (last && bitrev_store) ? 1 : 0;
-        a.magic_c = magic_for(col_chunk);
-        a.magic_c2 = (col_chunk % 2 == 0 && col_chunk >= 4) ? magic_for(col_chunk / 2) : 0;
+        a.magic_w = magic_for(w);
         // narrow matrices: group adjacent rows in the strided passes so that global runs are >= ~256 bytes
         int log_l = 0;
-        if (n_chunks == 1 && a.bit_lo > 0 && !a.bitrev_store) {
+        if (n_full == 1 && last_w == 0 && a.bit_lo > 0 && !a.bitrev_store) {
             while (log_l < 4 && log_l < a.bit_lo && (w << (log_l + 1)) <= 128 &&
-                   ((size_t)1 << a.log_r) * ((size_t)(w << (log_l + 1)) + (1u << (log_l + 1))) * 4 <= 64 * 1024)
+                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= 64 * 1024)
                 log_l++;
         }
         a.log_l = log_l;
-        a.magic_w = magic_for(w);
-        if (log_l > 0) {
-            a.col_chunk = w << log_l;
-            a.magic_c = magic_for(a.col_chunk);
-            a.magic_c2 = (w % 2 == 0 && a.col_chunk >= 4) ? magic_for(a.col_chunk / 2) : 0;
+        const bool aligned8 = ((((uintptr_t)cur_in) | ((uintptr_t)cur_out)) & 7u) == 0;
+        // one launch for the full chunks, one more for a ragged last chunk: every tile of a launch has the same shape
+        for (int part = 0; part < 2; part++) {
+            if (part == 0 && n_full == 0) continue;
+            if (part == 1 && last_w == 0) continue;
+            a.col0 = part == 0 ? 0 : n_full * col_chunk;
+            a.col_chunk = part == 0 ? (col_chunk << log_l) : last_w;
+            a.n_chunks = part == 0 ? n_full : 1;
+            const bool pair = aligned8 && w % 2 == 0 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
+            const int cv = a.col_chunk / (pair ? 2 : 1);
+            // row slots: a power of two, at most one radix-8 item per slot and stage group, at most 1024 threads
+            int slots = 1;
+            const int slot_cap = std::max(1, (1 << log_r) >> (log_r == 4 ? 2 : 3));
+            while (slots * 2 <= slot_cap && slots * 2 * cv <= 1024) slots *= 2;
+            a.slots = slots;
+            a.magic_cv = magic_for(cv);
+            const int threads = std::min(1024, (slots * cv + 63) / 64 * 64);
+            const size_t tiles = ((size_t)1 << (log_n - log_r - log_l)) * a.n_chunks;
+            LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
+            const size_t lds = lds_bytes(log_r, a.col_chunk, log_l);
+            if (pair) launch_pass<uint2>(log_r, (unsigned)tiles, threads, lds, ctx->stream, a);
+            else launch_pass<uint32_t>(log_r, (unsigned)tiles, threads, lds, ctx->stream, a);
+            LH_HIP(ctx, hipGetLastError());
         }
-        const int last_w = w % col_chunk;
-        a.magic_last = last_w ? magic_for(last_w) : 0;
-        a.magic_last2 = (last_w && last_w % 2 == 0 && last_w >= 4) ? magic_for(last_w / 2) : 0;
-        size_t tiles = ((size_t)1 << (log_n - a.log_r - a.log_l)) * n_chunks;
-        LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
-        size_t lds = ((size_t)1 << a.log_r) * ((size_t)a.col_chunk + ((size_t)1 << a.log_l)) * 4;  // tile + per-pass twiddles
-        const size_t tile_elems = ((size_t)1 << a.log_r) * a.col_chunk;
-        // many tiles: 256-thread workgroups (several per CU overlap each other's load / stage / store phases);
-        // few tiles: the per-workgroup latency chain dominates, so spread each tile over up to 1024 threads
-        const int threads = tile_elems >= 4096 ? (tiles >= 4096 ? 512 : 1024) : (tile_elems >= 2048 ? 512 : NTT_BLOCK);
-        hipLaunchKernelGGL(k_ntt_pass, dim3((unsigned)tiles), dim3(threads), lds, ctx->stream, a);
-        LH_HIP(ctx, hipGetLastError());
         cur_in = cur_out;
     }
     return LURKHIP_OK;
