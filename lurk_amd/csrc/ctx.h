@@ -13,6 +13,7 @@
 
 struct lurkhip_ctx {
     int device = 0;
+    int num_cus = 256;  // compute units of the device (persistent-kernel grids)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
     std::string err;

@@ -144,6 +144,10 @@ static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkh
             return fail(e, "hipStreamCreateWithFlags");
         ctx->owns_stream = true;
     }
+    {
+        int cus = 0;
+        if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->num_cus = cus;
+    }
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
     *out = ctx;

@@ -18,6 +18,9 @@
 //
 // HBM traffic (algorithmic): iNTT 3 passes r+w over N*w*4 B, forward 2^b * 3 passes
 // r+w over N*w*4 B.
+#include <stdlib.h>
+
+#include <type_traits>
 #include <vector>
 
 #include "babybear.h"
@@ -60,13 +63,14 @@ struct PassArgs {
     int in_canonical;  // convert on load
     int out_canonical; // convert on store
     int bitrev_store;  // store row r at bitrev(r, log_n)
-    int slots;         // row slots per workgroup: thread = (slot, column item), slot < slots
     uint32_t magic_cv; // ceil(2^32 / column items): tid / Cv == umulhi(tid, magic)
     // Row grouping for narrow matrices: a tile takes 2^log_l ADJACENT rows (consecutive values of the low row bits)
     // for each of its 2^log_r strided rows, so that every global access is a contiguous run of (w << log_l) words
     // instead of w.  Then col_chunk = w << log_l (one chunk) and magic_w divides a tile column by w.
     int log_l;
     uint32_t magic_w;
+    uint32_t n_tiles;  // (row tile, column chunk) pairs of the launch; a workgroup takes several
+    uint32_t xcd_run;  // tiles per XCD when the tile count is a multiple of 8 (XCD-contiguous tile order), else 0
 };
 
 __device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
@@ -90,12 +94,14 @@ __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
 // stored column-major, col[t] = tile row t, so the 2^G rows t0 | b << S_BOT of an item sit at compile-time offsets from
 // one address, and so do the item's twiddles tw[(1 << st) + t_lo]: no per-element index arithmetic.  The thread's slot
 // walks the items q = slot, slot + slots, ... of its own column: no division either.
-template <int LOG_R, int S_TOP, int G, class T>
-__device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, int slots) {
+template <int LOG_R, int S_TOP, int G, int SLOTS, class T>
+__device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot) {
     constexpr int M = 1 << G;
     constexpr int S_BOT = S_TOP - G + 1;
     constexpr int ITEMS = (1 << LOG_R) >> G;
-    for (int q = slot; q < ITEMS; q += slots) {
+    static_assert(ITEMS % SLOTS == 0, "every slot takes the same number of items");
+#pragma unroll
+    for (int q = slot; q < ITEMS; q += SLOTS) {
         const int low = q & ((1 << S_BOT) - 1);
         const int t0 = ((q >> S_BOT) << (S_TOP + 1)) | low;
         T* __restrict__ p = col + t0;
@@ -120,15 +126,14 @@ __device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t*
 }
 
 // stage groups of a pass, top stage first: radix 8 while at least three stages remain (four are split 2 + 2)
-template <int LOG_R, int S_TOP, class T>
-__device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, int slots,
-                                           bool active) {
+template <int LOG_R, int S_TOP, int SLOTS, class T>
+__device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, bool active) {
     if constexpr (S_TOP >= 0) {
         constexpr int REM = S_TOP + 1;
         constexpr int G = REM == 4 ? 2 : (REM >= 3 ? 3 : REM);
-        if (active) stage_group<LOG_R, S_TOP, G, T>(col, tw_l, slot, slots);
+        if (active) stage_group<LOG_R, S_TOP, G, SLOTS, T>(col, tw_l, slot);
         __syncthreads();
-        run_stages<LOG_R, S_TOP - G, T>(col, tw_l, slot, slots, active);
+        run_stages<LOG_R, S_TOP - G, SLOTS, T>(col, tw_l, slot, active);
     }
 }
 
@@ -143,77 +148,141 @@ __device__ __forceinline__ uint2 scale_elem(uint2 v, uint32_t s) { return make_u
 // LDS: the tile column-major with one element of padding per column ([Cv][R + 1] elements of T: consecutive lanes hold
 // consecutive columns, the odd column stride keeps them on distinct banks), then the pass's twiddles
 // tw_lds[l][(1 << s) + t_lo] for stage s.
-template <int LOG_R, class T>
-__global__ __launch_bounds__(1024) void k_ntt_pass(PassArgs a) {
+//
+// Workgroups are persistent and software-pipelined: while the stages of one tile run out of LDS, the rows (and twiddles) of
+// the workgroup's next tile are already in flight into registers, so a workgroup overlaps its own HBM latency with its own
+// butterflies instead of relying on neighbours being in a different phase (they start in lockstep and stay there).
+// BIG: matrices of 4 GiB and more take 64-bit byte offsets; the others address rows as base (SGPR pair) + 32-bit offset.
+// SCALE: a per-row multiplier (the coset shift powers) is applied on load.
+template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_ntt_pass(PassArgs a) {
+    using boff_t = typename std::conditional<BIG, size_t, uint32_t>::type;
     constexpr int R = 1 << LOG_R;
     constexpr int RP = R + 1;
     constexpr int EW = (int)(sizeof(T) / 4);  // matrix columns per element
+    constexpr int U = R < 8 ? R : 8;          // rows a thread stages per tile
+    constexpr int SLOTS = R / U;              // row slots per workgroup: thread = (slot, column item), slot < SLOTS
+    constexpr int LOG_SLOTS = LOG_R < 3 ? 0 : LOG_R - 3;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     T* tile = reinterpret_cast<T*>(smem);
     const int Cv = a.col_chunk / EW;
     uint32_t* tw_lds = smem + (size_t)Cv * RP * EW;
-    const uint32_t tile_id = blockIdx.x / (uint32_t)a.n_chunks;
-    const int chunk = (int)(blockIdx.x - tile_id * (uint32_t)a.n_chunks);
-    const int L = 1 << a.log_l;
     const uint32_t lo_bits = (uint32_t)(a.bit_lo - a.log_l);
-    const uint32_t lo = (tile_id & ((1u << lo_bits) - 1u)) << a.log_l;  // first of the tile's L adjacent low-bit values
-    const uint32_t hi = tile_id >> lo_bits;
-    const uint32_t row_base = (hi << (a.bit_lo + LOG_R)) | lo;
-
-    // stage twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l); stored at [l][k], k = (1 << s) + t_lo
-    for (int idx = threadIdx.x; idx < R * L; idx += blockDim.x) {
-        const int l = idx >> LOG_R, k = idx & (R - 1);
-        if (k == 0) continue;
-        const int s = 31 - __clz(k);
-        const uint32_t t_lo = (uint32_t)k - (1u << s);
-        const uint32_t j = (t_lo << a.bit_lo) | (lo + (uint32_t)l);
-        tw_lds[idx] = a.tw[(size_t)j << (a.log_n - a.bit_lo - s - 1)];
-    }
-    // thread = (slot, cv): column item cv of the tile for the whole pass, tile rows / items slot, slot + slots, ...
-    const int slot = fast_div(threadIdx.x, a.magic_cv, Cv), cv = (int)threadIdx.x - slot * Cv;
-    const bool active = slot < a.slots;
+    // thread = (slot, cv): column item cv of the tile for the whole pass, tile rows / items slot, slot + SLOTS, ...
+    // Threads past the last slot shadow a real thread's loads (no branch around the loads) and write nothing.
+    const int slot_raw = fast_div(threadIdx.x, a.magic_cv, Cv), cv = (int)threadIdx.x - slot_raw * Cv;
+    const bool active = slot_raw < SLOTS;
+    const int slot = active ? slot_raw : SLOTS - 1;
     const int tc = cv * EW;                                     // first tile column of the item
     const int l_of = a.log_l ? fast_div((uint32_t)tc, a.magic_w, a.w) : 0;  // which of the L adjacent rows
-    const int col = a.col0 + chunk * a.col_chunk + tc - l_of * a.w;  // matrix column
+    const int col_in_chunk = tc - l_of * a.w;
     T* __restrict__ my_col = tile + cv * RP;
-    const uint32_t row0 = row_base + (uint32_t)l_of;
-    if (active) {
-        const uint32_t* __restrict__ src = a.in + col;
-        if (a.in_canonical || a.row_scale) {
-            for (int t = slot; t < R; t += a.slots) {
-                const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
-                T v = *reinterpret_cast<const T*>(src + (size_t)row * a.w);
-                if (a.in_canonical) v = to_monty_elem(v);
-                if (a.row_scale) v = scale_elem(v, a.row_scale[row]);
-                my_col[t] = v;
-            }
-        } else {
-            for (int t = slot; t < R; t += a.slots) {
-                const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
-                my_col[t] = *reinterpret_cast<const T*>(src + (size_t)row * a.w);
+    const int n_tw = R << a.log_l;
+
+    // Tiles of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and tiles with
+    // consecutive ids hold adjacent matrix rows (w * 4 bytes, not a multiple of the 128-byte line): every XCD takes a
+    // contiguous run of tiles and walks it with all its workgroups abreast, so shared lines meet in one L2.
+    const uint32_t wg = a.xcd_run ? (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t wgs = a.xcd_run ? (gridDim.x >> 3) : gridDim.x;
+    const uint32_t run = a.xcd_run ? a.xcd_run : a.n_tiles;
+    const uint32_t run0 = a.xcd_run ? (blockIdx.x & 7u) * a.xcd_run : 0u;
+    if (wg >= run) return;
+    const uint32_t my_tiles = (run - wg + wgs - 1) / wgs;
+    auto locate = [&](uint32_t it, uint32_t& row0, int& col, uint32_t& lo) {
+        const uint32_t bid = run0 + wg + it * wgs;
+        const uint32_t tile_id = bid / (uint32_t)a.n_chunks;
+        const int chunk = (int)(bid - tile_id * (uint32_t)a.n_chunks);
+        lo = (tile_id & ((1u << lo_bits) - 1u)) << a.log_l;  // first of the tile's L adjacent low-bit values
+        const uint32_t hi = tile_id >> lo_bits;
+        row0 = ((hi << (a.bit_lo + LOG_R)) | lo) + (uint32_t)l_of;
+        col = a.col0 + chunk * a.col_chunk + col_in_chunk;
+    };
+    // this thread's twiddle slots (TWN of them: 1, or 4 when grouped rows multiply the table): entry idx = [l][k] of the
+    // table, k = (1 << s) + t_lo; slots past the table (and k = 0) read entry 0 and are not written
+    auto tw_slot = [&](int i, uint32_t lo, size_t& src_idx) -> bool {
+        const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+        const int l = idx >> LOG_R, k = idx & (R - 1);
+        const bool ok = idx < n_tw && k != 0;
+        const int s_ = 31 - __clz(k | 1);
+        const uint32_t j = ((((uint32_t)k - (1u << s_)) << a.bit_lo) | (lo + (uint32_t)l));
+        src_idx = ok ? ((size_t)j << (a.log_n - a.bit_lo - s_ - 1)) : (size_t)0;
+        return ok;
+    };
+    T v[U];
+    uint32_t sc[U], twv[TWN];
+    const char* __restrict__ src = reinterpret_cast<const char*>(a.in);
+    char* __restrict__ dst = reinterpret_cast<char*>(a.out);
+    auto fetch = [&](uint32_t row0, int col, uint32_t lo) {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const int t = slot + (k << LOG_SLOTS);
+            const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
+            v[k] = *reinterpret_cast<const T*>(src + ((boff_t)row * (boff_t)a.w + (boff_t)col) * 4);
+            if constexpr (SCALE) sc[k] = a.row_scale[row];
+        }
+        // twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l)
+#pragma unroll
+        for (int i = 0; i < TWN; i++) {
+            size_t si;
+            tw_slot(i, lo, si);
+            twv[i] = a.tw[si];
+        }
+    };
+
+    uint32_t row0, lo;
+    int col;
+    locate(0, row0, col, lo);
+    fetch(row0, col, lo);
+    for (uint32_t it = 0; it < my_tiles; it++) {
+        // staged registers -> LDS
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                T x = v[k];
+                if (a.in_canonical) x = to_monty_elem(x);
+                if constexpr (SCALE) x = scale_elem(x, sc[k]);
+                my_col[slot + (k << LOG_SLOTS)] = x;
             }
         }
-    }
-    __syncthreads();
-    run_stages<LOG_R, LOG_R - 1, T>(my_col, tw_lds + (l_of << LOG_R), slot, a.slots, active);
-    // store (same thread-to-element map as the load)
-    if (active) {
-        uint32_t* __restrict__ dst = a.out + col;
-        for (int t = slot; t < R; t += a.slots) {
-            uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
-            if (a.bitrev_store) row = bitrev32(row, a.log_n);
-            T v = my_col[t];
-            if (a.out_canonical) v = from_monty_elem(v);
-            *reinterpret_cast<T*>(dst + (size_t)row * a.w) = v;
+#pragma unroll
+        for (int i = 0; i < TWN; i++) {
+            const int idx = (int)threadIdx.x + i * (int)blockDim.x;
+            if (idx < n_tw && (idx & (R - 1)) != 0) tw_lds[idx] = twv[i];
         }
+        const uint32_t cur_row0 = row0;
+        const int cur_col = col;
+        __syncthreads();
+        // the next tile's rows fly while this one's stages run (the last iteration re-reads its own tile: no branch)
+        locate(it + 1 < my_tiles ? it + 1 : it, row0, col, lo);
+        fetch(row0, col, lo);
+        run_stages<LOG_R, LOG_R - 1, SLOTS, T>(my_col, tw_lds + (l_of << LOG_R), slot, active);
+        if (active) {
+            constexpr int UB = U < 4 ? U : 4;  // rows per batch of the write-back (LDS reads first, then their global stores)
+#pragma unroll
+            for (int k0 = 0; k0 < U; k0 += UB) {
+                T o[UB];
+#pragma unroll
+                for (int k = 0; k < UB; k++) o[k] = my_col[slot + ((k0 + k) << LOG_SLOTS)];
+#pragma unroll
+                for (int k = 0; k < UB; k++) {
+                    const int t = slot + ((k0 + k) << LOG_SLOTS);
+                    uint32_t row = cur_row0 | ((uint32_t)t << a.bit_lo);
+                    if (a.bitrev_store) row = bitrev32(row, a.log_n);
+                    T x = o[k];
+                    if (a.out_canonical) x = from_monty_elem(x);
+                    *reinterpret_cast<T*>(dst + ((boff_t)row * (boff_t)a.w + (boff_t)cur_col) * 4) = x;
+                }
+            }
+        }
+        __syncthreads();  // the tile is free for the next one
     }
 }
 
-template <class T>
-void launch_pass(int log_r, unsigned blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
+template <class T, bool BIG, bool SCALE, int TWN>
+void launch_pass2(int log_r, unsigned blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
     switch (log_r) {
 #define LH_NTT_CASE(LR) \
-    case LR: hipLaunchKernelGGL((k_ntt_pass<LR, T>), dim3(blocks), dim3(threads), lds, stream, a); break;
+    case LR: hipLaunchKernelGGL((k_ntt_pass<LR, T, BIG, SCALE, TWN>), dim3(blocks), dim3(threads), lds, stream, a); break;
         LH_NTT_CASE(0) LH_NTT_CASE(1) LH_NTT_CASE(2) LH_NTT_CASE(3) LH_NTT_CASE(4) LH_NTT_CASE(5) LH_NTT_CASE(6) LH_NTT_CASE(7)
 #undef LH_NTT_CASE
     }
@@ -272,6 +341,15 @@ int32_t fill_powers(lurkhip_ctx* ctx, uint32_t* out, uint32_t root_m, uint32_t s
     return LURKHIP_OK;
 }
 
+template <class T, bool BIG>
+void launch_pass(int log_r, unsigned blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
+    const bool one = ((size_t)1 << (log_r + a.log_l)) <= (size_t)threads;  // one twiddle per thread covers the table
+    if (a.row_scale && one) launch_pass2<T, BIG, true, 1>(log_r, blocks, threads, lds, stream, a);
+    else if (a.row_scale) launch_pass2<T, BIG, true, 4>(log_r, blocks, threads, lds, stream, a);
+    else if (one) launch_pass2<T, BIG, false, 1>(log_r, blocks, threads, lds, stream, a);
+    else launch_pass2<T, BIG, false, 4>(log_r, blocks, threads, lds, stream, a);
+}
+
 // Pass schedule: split log_n stage bits (from the top) into chunks of at most max_log_r.
 static void schedule(int log_n, int max_log_r, std::vector<std::pair<int, int>>& passes /* (bit_lo, log_r) */) {
     passes.clear();
@@ -309,8 +387,13 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
     auto lds_bytes = [](int log_r, int cols, int log_l) {
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
     };
+    // two adjacent columns per lane (8-byte accesses) when rows and chunks start on 8-byte boundaries
+    const bool aligned8 = ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)scratch)) & 7u) == 0 && w % 2 == 0;
+    auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
+    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / 8) * items_of(cols); };
     int max_log_r = 7;
-    while (lds_bytes(max_log_r, col_chunk, 0) > 64 * 1024 && max_log_r > 1) max_log_r--;
+    while ((lds_bytes(max_log_r, col_chunk, 0) > 64 * 1024 || threads_of(max_log_r, col_chunk) > 1024) && max_log_r > 1)
+        max_log_r--;
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
     const int n_full = w / col_chunk, last_w = w % col_chunk;
@@ -338,11 +421,10 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         int log_l = 0;
         if (n_full == 1 && last_w == 0 && a.bit_lo > 0 && !a.bitrev_store) {
             while (log_l < 4 && log_l < a.bit_lo && (w << (log_l + 1)) <= 128 &&
-                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= 64 * 1024)
+                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= 64 * 1024 && threads_of(log_r, w << (log_l + 1)) <= 1024)
                 log_l++;
         }
         a.log_l = log_l;
-        const bool aligned8 = ((((uintptr_t)cur_in) | ((uintptr_t)cur_out)) & 7u) == 0;
         // one launch for the full chunks, one more for a ragged last chunk: every tile of a launch has the same shape
         for (int part = 0; part < 2; part++) {
             if (part == 0 && n_full == 0) continue;
@@ -350,20 +432,29 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
             a.col0 = part == 0 ? 0 : n_full * col_chunk;
             a.col_chunk = part == 0 ? (col_chunk << log_l) : last_w;
             a.n_chunks = part == 0 ? n_full : 1;
-            const bool pair = aligned8 && w % 2 == 0 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
+            const bool pair = aligned8 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
             const int cv = a.col_chunk / (pair ? 2 : 1);
-            // row slots: a power of two, at most one radix-8 item per slot and stage group, at most 1024 threads
-            int slots = 1;
-            const int slot_cap = std::max(1, (1 << log_r) >> (log_r == 4 ? 2 : 3));
-            while (slots * 2 <= slot_cap && slots * 2 * cv <= 1024) slots *= 2;
-            a.slots = slots;
+            const int slots = std::max(1, (1 << log_r) / 8);  // the kernel's SLOTS: eight tile rows per thread
+            LH_ARG(ctx, slots * cv <= 1024, "NTT tile shape");
             a.magic_cv = magic_for(cv);
             const int threads = std::min(1024, (slots * cv + 63) / 64 * 64);
             const size_t tiles = ((size_t)1 << (log_n - log_r - log_l)) * a.n_chunks;
             LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
+            LH_ARG(ctx, ((size_t)1 << (log_r + log_l)) <= (size_t)4 * threads, "NTT twiddle staging");
+            static const bool xcd_order = !getenv("LURKHIP_NTT_NO_XCD");
+            a.n_tiles = (uint32_t)tiles;
+            a.xcd_run = (xcd_order && tiles % 8 == 0 && tiles >= 64) ? (uint32_t)(tiles / 8) : 0u;
+            // persistent workgroups: as many per CU as its registers (5 waves per SIMD at <= 96 VGPRs) and LDS hold, all
+            // resident at once; a multiple of 8 so that every XCD gets the same number
             const size_t lds = lds_bytes(log_r, a.col_chunk, log_l);
-            if (pair) launch_pass<uint2>(log_r, (unsigned)tiles, threads, lds, ctx->stream, a);
-            else launch_pass<uint32_t>(log_r, (unsigned)tiles, threads, lds, ctx->stream, a);
+            const int per_cu = std::max(1, std::min(20 / (threads / 64), (int)((160 * 1024) / (lds + 256))));
+            size_t blocks = std::min<size_t>(tiles, (size_t)per_cu * ctx->num_cus);
+            if (a.xcd_run) blocks = blocks / 8 * 8;
+            const bool big = (((size_t)w) << (log_n + 2)) >= ((size_t)1 << 32);
+            if (pair && big) launch_pass<uint2, true>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
+            else if (pair) launch_pass<uint2, false>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
+            else if (big) launch_pass<uint32_t, true>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
+            else launch_pass<uint32_t, false>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
             LH_HIP(ctx, hipGetLastError());
         }
         cur_in = cur_out;
