@@ -66,26 +66,41 @@ BB_HD uint32_t mred(uint64_t t) {
 BB_HD uint32_t mul(uint32_t a, uint32_t b) { return mred((uint64_t)a * b); }
 BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 
-// Signed Montgomery product without the final correction: for int32 a, b returns r = a * b * 2^-32 (mod p) with
-// |r| < |a * b| / 2^32 + p / 2, so operands in (-p, p) give a result in (-p, p) again.  Four instructions on gfx950
-// (v_mad_i64_i32, v_mul_lo_u32, v_mul_hi_i32, v_sub) against six for the canonical-range product: used for the
-// x^7 chains of Poseidon2, whose intermediates never leave the chain.
-BB_HD int32_t smul(int32_t a, int32_t b) {
-    const int64_t t = (int64_t)a * b;
-    const int32_t m = (int32_t)((uint32_t)t * MU);
+// a * b + c on signed 32-bit factors with a 64-bit addend: one v_mad_i64_i32.  Spelled as inline assembly on the device:
+// left to itself the compiler expands a product with a wave-uniform factor into an unsigned multiply-add plus sign fix-ups
+// (five instructions instead of one).  mad_i64_u takes the uniform factor straight from a scalar register.
+BB_HD int64_t mad_i64(int32_t a, int32_t b, int64_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
-    const int32_t u = __mulhi(m, (int32_t)P);
+    int64_t d;
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+    return d;
 #else
-    const int32_t u = (int32_t)(((int64_t)m * (int32_t)P) >> 32);
+    return (int64_t)a * b + c;
 #endif
-    int32_t hi = (int32_t)(uint32_t)((uint64_t)t >> 32);
-#if defined(__HIP_DEVICE_COMPILE__)
-    // keep the subtraction 32-bit: without the barrier LLVM rewrites hi - u as the high word of a 64-bit
-    // subtraction (v_subrev_co + v_subb_co, two instructions instead of one v_sub)
-    asm("" : "+v"(hi));
-#endif
-    return hi - u;
 }
+BB_HD int64_t mad_i64_u(int32_t a, int32_t b_uniform, int64_t c) {
+#if defined(__HIP_DEVICE_COMPILE__)
+    int64_t d;
+    uint64_t carry;
+    asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+    return d;
+#else
+    return (int64_t)a * b_uniform + c;
+#endif
+}
+// Signed Montgomery reduction without the final correction: for |t| < 2^62.9 returns r = t * 2^-32 (mod p) with
+// |r| <= |t| / 2^32 + p / 2.  m = t * p^-1 mod 2^32 (signed), and t - m * p has a zero low word, so the high word of one
+// 64-bit multiply-add is the result: v_mul_lo_u32 + v_mad_i64_i32, no separate high product and subtraction.
+BB_HD int32_t sred(int64_t t) {
+    const int32_t m = (int32_t)((uint32_t)t * MU);
+    const int64_t t2 = mad_i64(m, -(int32_t)P, t);
+    return (int32_t)(t2 >> 32);
+}
+// Signed Montgomery product: operands in (-p, p) give a result in (-p, p) again; three instructions on gfx950
+// (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32) against six for the canonical-range product.  Used for the x^7 chains of
+// Poseidon2 and the NTT butterflies, whose intermediates never leave the chain.
+BB_HD int32_t smul(int32_t a, int32_t b) { return sred(mad_i64(a, b, 0)); }
 // (s + rc)^7 for canonical-range s, rc, given rc_mp = rc - p (mod 2^32): the sum s + rc_mp lies in (-p, p), the chain
 // runs on signed values, one correction at the end
 BB_HD uint32_t add_pow7_mp(uint32_t s, uint32_t rc_mp) {

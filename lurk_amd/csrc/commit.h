@@ -52,9 +52,11 @@ struct P16Params {
     int32_t rounds_p;
     uint32_t ext_rc_mp[8 * 16];  // rc - p (mod 2^32), for the signed S-box chain
     uint32_t int_rc_mp[P16_MAX_RP];
+    int32_t diag_c[16];          // diag, centred in (-p/2, p/2]: multiplier of the lazy internal rounds
     void finish() {
         for (int i = 0; i < 128; i++) ext_rc_mp[i] = ext_rc[i] - 2013265921u;
         for (int i = 0; i < P16_MAX_RP; i++) int_rc_mp[i] = int_rc[i] - 2013265921u;
+        for (int i = 0; i < 16; i++) diag_c[i] = diag[i] > 2013265921u / 2 ? (int32_t)(diag[i] - 2013265921u) : (int32_t)diag[i];
     }
 };
 

@@ -206,7 +206,7 @@ __global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__
     for (int i = 0; i < 8; i++)
         if (i == n_pending) s[i] = wm;
     p2::NoRecord rec;
-    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, rec);
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec);
     if ((bb::from_monty(s[7]) & mask) == 0) atomicMin(best, wcan);
 }
 

@@ -27,7 +27,7 @@ constexpr int MBLOCK = 256;
 
 __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
     p2::NoRecord rec;
-    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, rec);
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec);
 }
 
 // sponge over the uniform column table for row `row`; state must be zero on entry

@@ -113,7 +113,7 @@ __global__ __launch_bounds__(BLOCK) void k_wide_witness(const uint32_t* __restri
     rec.lane = lane;
     rec.canonical = canonical != 0;
     const auto& p = Cfg<W>::params();
-    permute_core<W>(s, RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, rec);
+    permute_core<W>(s, RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, p.diag_c, rec);
     // the 8 output lanes lead the row (core/poseidon.rs:66-71)
 #pragma unroll
     for (int i = 0; i < 8; i++) rec.put(i, s[i]);

@@ -37,6 +37,7 @@ struct Params {
     uint32_t diag[W];
     uint32_t ext_rc_mp[8 * W];  // rc - p (mod 2^32): operands of the signed S-box chain (bb::add_pow7_mp)
     uint32_t int_rc_mp[RP];
+    int32_t diag_c[W];          // diag, centred representative in (-p/2, p/2]: multiplier of the lazy internal rounds
 };
 template <int W, int RP>
 constexpr Params<W, RP> make_params(const uint32_t (&ext)[8 * W], const uint32_t (&in)[RP], const uint32_t (&d)[W]) {
@@ -46,6 +47,7 @@ constexpr Params<W, RP> make_params(const uint32_t (&ext)[8 * W], const uint32_t
     for (int i = 0; i < W; i++) p.diag[i] = bb::c_to_monty(d[i]);
     for (int i = 0; i < 8 * W; i++) p.ext_rc_mp[i] = p.ext_rc[i] - bb::P;
     for (int i = 0; i < RP; i++) p.int_rc_mp[i] = p.int_rc[i] - bb::P;
+    for (int i = 0; i < W; i++) p.diag_c[i] = p.diag[i] > bb::P / 2 ? (int32_t)(p.diag[i] - bb::P) : (int32_t)p.diag[i];
     return p;
 }
 
@@ -118,6 +120,45 @@ __device__ __forceinline__ void internal_layer(uint32_t (&s)[W], const uint32_t*
     for (int i = 0; i < W; i++) s[i] = bb::add(bb::mul(s[i], diag[i]), sum);
 }
 
+// All internal rounds on lazily reduced signed lanes (no witness is recorded, W <= 40).
+//
+// A lane is an int32 x with |x| < 2^31 standing for x mod p.  With V = R * sum_j x_j held as one 64-bit value, lane i of the
+// layer is sred(x_i * d_i + V): one multiply-add, one low product, one multiply-add -- three instructions against nine for
+// the canonical mul + add -- and nothing is corrected between rounds.  V is built from groups of at most eight lanes:
+// U_g = sum_j x_j * R (64-bit multiply-adds, |U_g| < 8 * 1.05 p * 0.134 p < 2^63), u_g = sred(U_g) = sum_j x_j (mod p),
+// V = sum_g u_g * R.  Bounds (R mod p = 0.134 p, |d_i| <= p / 2): |V| < 0.14 p^2 * ceil(W / 8), so for W <= 40
+// |x_i * d_i + V| < 1.2 p^2 and the lanes stay below 1.06 p < 2^31 round after round.  Lane 0 is brought to [0, p) before
+// its round constant is added; its x^7 stays signed.
+template <int W>
+__device__ __forceinline__ void internal_rounds_lazy(uint32_t (&s)[W], int rounds_p, const uint32_t* __restrict__ int_rc_mp,
+                                                     const int32_t* __restrict__ diag_c) {
+    static_assert(W <= 40, "lane bound of the lazy internal rounds");
+    int32_t x[W];
+#pragma unroll
+    for (int i = 0; i < W; i++) x[i] = (int32_t)s[i];
+#pragma unroll 1
+    for (int r = 0; r < rounds_p; r++) {
+        {
+            const uint32_t c0 = bb::umin((uint32_t)x[0], (uint32_t)x[0] + bb::P);
+            const int32_t y = (int32_t)(c0 + int_rc_mp[r]);
+            const int32_t y2 = bb::smul(y, y), y3 = bb::smul(y2, y), y6 = bb::smul(y3, y3);
+            x[0] = bb::smul(y6, y);
+        }
+        int64_t v = 0;
+#pragma unroll
+        for (int g = 0; g < W; g += 8) {
+            int64_t u = 0;
+#pragma unroll
+            for (int j = g; j < g + 8 && j < W; j++) u = bb::mad_i64(x[j], (int32_t)bb::R1, u);
+            v = bb::mad_i64(bb::sred(u), (int32_t)bb::R1, v);
+        }
+#pragma unroll
+        for (int i = 0; i < W; i++) x[i] = bb::sred(bb::mad_i64_u(x[i], diag_c[i], v));
+    }
+#pragma unroll
+    for (int i = 0; i < W; i++) s[i] = bb::umin((uint32_t)x[i], (uint32_t)x[i] + bb::P);
+}
+
 struct NoRecord;
 template <class Rec>
 struct records_nothing {
@@ -169,25 +210,30 @@ template <int W, class Rec>
 __device__ __forceinline__ void permute_core(uint32_t (&s)[W], int rounds_p, const uint32_t* __restrict__ ext_rc,
                                              const uint32_t* __restrict__ int_rc,
                                              const uint32_t* __restrict__ diag, const uint32_t* __restrict__ ext_rc_mp,
-                                             const uint32_t* __restrict__ int_rc_mp, Rec& rec) {
+                                             const uint32_t* __restrict__ int_rc_mp, const int32_t* __restrict__ diag_c,
+                                             Rec& rec) {
     external_layer<W>(s);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) external_round<W>(s, r, ext_rc, ext_rc_mp, rec);
 #pragma unroll
     for (int i = 0; i < W; i++) rec.int_init(i, s[i]);
     rec.end_int_init();
+    if constexpr (records_nothing<Rec>::value && W <= 40) {
+        internal_rounds_lazy<W>(s, rounds_p, int_rc_mp, diag_c);
+    } else {
 #pragma unroll 1
-    for (int r = 0; r < rounds_p; r++) {
-        if constexpr (records_nothing<Rec>::value) {
-            s[0] = bb::add_pow7_mp(s[0], int_rc_mp[r]);
-        } else {
-            if (r > 0) rec.int_state0(r - 1, s[0]);
-            uint32_t x = bb::add(s[0], int_rc[r]);
-            uint32_t x3 = bb::cube(x);
-            rec.int_sbox(r, x3);
-            s[0] = bb::pow7_from_cube(x, x3);
+        for (int r = 0; r < rounds_p; r++) {
+            if constexpr (records_nothing<Rec>::value) {
+                s[0] = bb::add_pow7_mp(s[0], int_rc_mp[r]);
+            } else {
+                if (r > 0) rec.int_state0(r - 1, s[0]);
+                uint32_t x = bb::add(s[0], int_rc[r]);
+                uint32_t x3 = bb::cube(x);
+                rec.int_sbox(r, x3);
+                s[0] = bb::pow7_from_cube(x, x3);
+            }
+            internal_layer<W>(s, diag);
         }
-        internal_layer<W>(s, diag);
     }
     rec.end_internal();
 #pragma unroll 1
@@ -198,7 +244,7 @@ template <int W>
 __device__ __forceinline__ void permute(uint32_t (&s)[W]) {
     NoRecord rec;
     const auto& p = Cfg<W>::params();
-    permute_core<W>(s, Cfg<W>::RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, rec);
+    permute_core<W>(s, Cfg<W>::RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, p.diag_c, rec);
 }
 
 }  // namespace p2

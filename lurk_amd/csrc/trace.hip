@@ -85,7 +85,7 @@ __device__ __noinline__ void extern_hasher(RowWriter& w, MapT& map, uint32_t& sp
     for (int i = 0; i < W; i++) s[i] = map[ins[i]];
     RowRec<W, RP> rec{&w, w.aux0 + w.aux};
     const auto& p = p2::Cfg<W>::params();
-    p2::permute_core<W>(s, RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, rec);
+    p2::permute_core<W>(s, RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, p.diag_c, rec);
 #pragma unroll
     for (int i = 0; i < 8; i++) w.put(rec.base + i, s[i]);
     w.aux += 8 + p2::Cfg<W>::NUM_COLS;
