@@ -187,8 +187,11 @@ __global__ void k_air_check(const uint32_t* __restrict__ prog, const uint32_t* _
 }
 
 // ---------------------------------------------------------------- permutation trace rows
-// beta_pows[t] = beta^t (t = 0 .. max_tuple), Montgomery, 4 words each
-__global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t* __restrict__ out, uint32_t count) {
+// out[i] = base^i, Montgomery.  centred == 0: 4 canonical words per power.  centred == 1: 8 words per power for the lazy
+// 64-bit accumulators below: the coefficients c0..c3 and 11*c1, 11*c2, 11*c3 (the wrap-around factors of x^4 = 11) as
+// signed representatives in (-p/2, p/2], then a zero.
+__global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t* __restrict__ out, uint32_t count,
+                            int centred) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
     ef base{{b0, b1, b2, b3}}, r = bb::ef_one();
@@ -198,39 +201,111 @@ __global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
         base = bb::ef_sqr(base);
         e >>= 1;
     }
-    out[4 * i] = r.c[0];
-    out[4 * i + 1] = r.c[1];
-    out[4 * i + 2] = r.c[2];
-    out[4 * i + 3] = r.c[3];
+    if (!centred) {
+        out[4 * i] = r.c[0];
+        out[4 * i + 1] = r.c[1];
+        out[4 * i + 2] = r.c[2];
+        out[4 * i + 3] = r.c[3];
+        return;
+    }
+    auto centre = [](uint32_t x) -> uint32_t { return x > bb::P / 2 ? x - bb::P : x; };
+    for (int c = 0; c < 4; c++) out[8 * i + c] = centre(r.c[c]);
+    for (int c = 1; c < 4; c++) out[8 * i + 3 + c] = centre(bb::mul(bb::EXT_W_M, r.c[c]));
+    out[8 * i + 7] = 0;
 }
 
 }  // namespace
 
+// Extension-field accumulator for sums of (lane value) x (wave-uniform extension constant): four 64-bit lanes holding
+// R * value, fed by one v_mad_i64_i32 per coefficient and term and reduced only when the next term would not fit.
+// A term is (|v| <= p) x (|w_c| <= p/2) <= p^2 / 2; a freshly folded lane is below 0.15 p^2 and sred needs |t| < 1.2 p^2,
+// so two terms fit between folds: 4 multiply-adds + 6 fold instructions per term against 36 for scale + add in
+// canonical form.
+struct LazyEf {
+    int64_t a[4];
+    uint32_t room;  // terms that still fit (wave-uniform)
+    __device__ __forceinline__ void fold() {
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[c] = bb::mad_i64(bb::sred(a[c]), (int32_t)bb::R1, 0);
+        room = 2;
+    }
+    __device__ __forceinline__ void set(const ef& x) {  // canonical x
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[c] = bb::mad_i64((int32_t)x.c[c], (int32_t)bb::R1, 0);
+        room = 2;
+    }
+    __device__ __forceinline__ void zero() {
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[c] = 0;
+        room = 2;
+    }
+    // += v * w, v a canonical lane value, w[0..3] the centred coefficients of a uniform constant
+    __device__ __forceinline__ void add_base(uint32_t v, const int32_t (&w)[8]) {
+        if (room == 0) fold();
+#pragma unroll
+        for (int c = 0; c < 4; c++) a[c] = bb::mad_i64_u((int32_t)v, w[c], a[c]);
+        room--;
+    }
+    // += v * w for a canonical lane extension element v; w[4..6] = 11 * w[1..3]
+    __device__ __forceinline__ void add_ext(const ef& v, const int32_t (&w)[8]) {
+        if (room < 2) fold();
+        const int32_t v0 = (int32_t)v.c[0], v1 = (int32_t)v.c[1], v2 = (int32_t)v.c[2], v3 = (int32_t)v.c[3];
+        a[0] = bb::mad_i64_u(v1, w[6], bb::mad_i64_u(v0, w[0], a[0]));
+        a[1] = bb::mad_i64_u(v1, w[0], bb::mad_i64_u(v0, w[1], a[1]));
+        a[2] = bb::mad_i64_u(v1, w[1], bb::mad_i64_u(v0, w[2], a[2]));
+        a[3] = bb::mad_i64_u(v1, w[2], bb::mad_i64_u(v0, w[3], a[3]));
+        fold();
+        a[0] = bb::mad_i64_u(v3, w[4], bb::mad_i64_u(v2, w[5], a[0]));
+        a[1] = bb::mad_i64_u(v3, w[5], bb::mad_i64_u(v2, w[6], a[1]));
+        a[2] = bb::mad_i64_u(v3, w[6], bb::mad_i64_u(v2, w[0], a[2]));
+        a[3] = bb::mad_i64_u(v3, w[0], bb::mad_i64_u(v2, w[1], a[3]));
+        room = 0;
+    }
+    __device__ __forceinline__ ef value() const {  // canonical
+        ef r;
+#pragma unroll
+        for (int c = 0; c < 4; c++) {
+            const uint32_t x = (uint32_t)bb::sred(a[c]);
+            r.c[c] = bb::umin(x, x + bb::P);
+        }
+        return r;
+    }
+};
+
+__device__ __forceinline__ void load_w8(int32_t (&w)[8], const uint32_t* __restrict__ p) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) w[c] = (int32_t)p[c];
+}
+
 // Running (numerator, denominator) of the current batch of interactions; shared by the permutation trace
 // and the quotient kernel (where entry * den - num is the batch's constraint).
 struct LogupAccum {
-    const uint32_t* __restrict__ beta_pows;
+    const uint32_t* __restrict__ beta_pows;  // centred, 8 words per power (k_ef_powers)
     ef alpha;
+    LazyEf cur64;
     ef cur, num, den;
-    ef next_pow;  // beta^t, loaded one value ahead: the (scalar) table load overlaps the previous value's arithmetic
+    int32_t next_pow[8];  // beta^t, loaded one value ahead: the (scalar) table load overlaps the previous value's arithmetic
     uint32_t t = 0, in_batch = 0, m_first = 0;
     bool is_send = false;
     __device__ __forceinline__ void begin(uint32_t kind, bool send) {
-        cur = bb::ef_add_base(alpha, bb::to_monty(kind));  // alpha + beta^0 * argument_index
+        cur64.set(bb::ef_add_base(alpha, bb::to_monty(kind)));  // alpha + beta^0 * argument_index
         t = 1;
-        next_pow = ef_load(beta_pows + 4);
+        load_w8(next_pow, beta_pows + 8);
         is_send = send;
     }
     __device__ __forceinline__ void value(uint32_t v) {
-        const ef p = next_pow;
+        int32_t p[8];
+#pragma unroll
+        for (int c = 0; c < 8; c++) p[c] = next_pow[c];
         t++;
-        next_pow = ef_load(beta_pows + 4 * t);  // the table has max_tuple + 2 entries: one past the last value is valid
-        cur = bb::ef_add(cur, bb::ef_scale(p, v));
+        load_w8(next_pow, beta_pows + 8 * t);  // the table has max_tuple + 2 entries: one past the last value is valid
+        cur64.add_base(v, p);
     }
     // folds the finished interaction into the batch fraction num / den = sum_i m_i / d_i; returns true when the batch
     // holds `batch` interactions.  Multiplicities are base-field: the first two interactions of a batch cost one
     // extension product (d_1 d_2) and two scalings.
     __device__ __forceinline__ bool end(uint32_t mult, uint32_t batch) {
+        cur = cur64.value();
         const uint32_t m = is_send ? mult : bb::neg(mult);
         if (in_batch == 0) {
             m_first = m;
@@ -418,28 +493,35 @@ struct QuotientArgs {
 };
 
 struct QuotientSink {
-    const uint32_t* __restrict__ alpha_pows;
+    const uint32_t* __restrict__ alpha_pows;  // centred, 8 words per power
     uint32_t k_total;
     LogupAccum acc;
     uint32_t batch;
     const uint32_t* perm_l;
     uint32_t k = 0, col = 0;
-    ef folded = bb::ef_zero();
-    ef next_w;  // alpha^(K-1-k), loaded one constraint ahead (see LogupAccum::next_pow)
-    __device__ __forceinline__ void prime() { next_w = ef_load(alpha_pows + 4 * (k_total - 1)); }
-    __device__ __forceinline__ ef weight() {
-        const ef w = next_w;
+    LazyEf folded;
+    int32_t next_w[8];  // alpha^(K-1-k), loaded one constraint ahead (see LogupAccum::next_pow)
+    __device__ __forceinline__ void prime() {
+        folded.zero();
+        load_w8(next_w, alpha_pows + 8 * (k_total - 1));
+    }
+    __device__ __forceinline__ void weight(int32_t (&w)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) w[c] = next_w[c];
         // k + 1 <= k_total - 1 except after the last constraint, where index 0 is re-read (valid, unused)
         const uint32_t nk = k + 1 < k_total ? k_total - 2 - k : 0u;
-        next_w = ef_load(alpha_pows + 4 * nk);
-        return w;
+        load_w8(next_w, alpha_pows + 8 * nk);
     }
     __device__ __forceinline__ void assert_zero(uint32_t v) {
-        folded = bb::ef_add(folded, bb::ef_scale(weight(), v));
+        int32_t w[8];
+        weight(w);
+        folded.add_base(v, w);
         k++;
     }
     __device__ __forceinline__ void assert_zero_ext(const ef& v) {
-        folded = bb::ef_add(folded, bb::ef_mul(weight(), v));
+        int32_t w[8];
+        weight(w);
+        folded.add_ext(v, w);
         k++;
     }
     __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
@@ -505,7 +587,7 @@ __global__ void k_quotient(QuotientArgs a) {
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, a.cumulative_sum), is_last));
-    const ef quot = bb::ef_scale(sink.folded, a.zh_inv[i & (qd - 1)]);
+    const ef quot = bb::ef_scale(sink.folded.value(), a.zh_inv[i & (qd - 1)]);
     const uint32_t chunk = i & (qd - 1), r = i >> lqd;
     uint4* dst = reinterpret_cast<uint4*>(a.out + ((size_t)chunk * ((size_t)1 << a.log_n) + r) * 4);
     *dst = make_uint4(quot.c[0], quot.c[1], quot.c[2], quot.c[3]);
@@ -513,9 +595,9 @@ __global__ void k_quotient(QuotientArgs a) {
 
 }  // namespace
 
-int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count) {
+int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count, bool centred) {
     hipLaunchKernelGGL(k_ef_powers, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, base_m[0], base_m[1], base_m[2], base_m[3],
-                       out_dev, count);
+                       out_dev, count, centred ? 1 : 0);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
@@ -547,9 +629,9 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     const uint32_t perm_w = a->air.permutation_width(), batch = 1u << a->air.log_quotient_degree();
     void* pows = nullptr;
     const uint32_t n_pows = a->max_tuple + 2;
-    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 16, &pows));
+    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 32, &pows));
     span_begin(ctx, "perm_rows");
-    int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows);
+    int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
     if (s == LURKHIP_OK) {
         const uint32_t n_regs = a->prog.interactions[airp::H_N_REGS];
         const VmShape shp = vm_shape(n_regs, a->air.width, 1, 64);
@@ -587,11 +669,11 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     const uint32_t *pa = perm_alpha.c, *pb = perm_beta.c, *al = alpha_m.c, *cs = cumsum_m.c;
     const uint32_t n_bp = a->max_tuple + 2;
     void* scratch = nullptr;  // alpha powers | beta powers | public values
-    const size_t o_bp = (size_t)k_total * 16, o_pub = o_bp + (size_t)n_bp * 16, total = o_pub + std::max<size_t>(np, 1) * 4;
+    const size_t o_bp = (size_t)k_total * 32, o_pub = o_bp + (size_t)n_bp * 32, total = o_pub + std::max<size_t>(np, 1) * 4;
     LH_TRY(pool_alloc(ctx, total, &scratch));
     uint8_t* d = (uint8_t*)scratch;
-    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total);
-    if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp);
+    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total, true);
+    if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp, true);
     std::vector<uint32_t> pubm(np);
     if (s == LURKHIP_OK && np) {
         for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);

@@ -178,6 +178,108 @@ struct OpMulHiSgpr {
     __device__ static void f(T& x, T) { asm volatile("v_mul_hi_i32 %0, %1, s4" : "=v"(x) : "v"(x)); }
     __device__ static uint32_t fin(T x) { return x; }
 };
+struct OpAshr {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_ashrrev_i32 %0, 3, %1" : "=v"(x) : "v"(x)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpAnd {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_and_b32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpXor {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_xor_b32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpMaxI {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_max_i32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpMinI {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_min_i32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpMaxU {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_max_u32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpLshl {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_lshlrev_b32 %0, 1, %1" : "=v"(x) : "v"(x)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpSubrev {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_subrev_u32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpAddF32 {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_add_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpMinF32 {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_min_f32 %0, %1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpMed3 {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_med3_i32 %0, %1, %2, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpAndOr {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_and_or_b32 %0, %1, %2, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpLshlAdd {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_lshl_add_u32 %0, %1, 1, %2" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpMov {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_mov_b32 %0, %1" : "=v"(x) : "v"(x)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpBfe {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_bfe_i32 %0, %1, 31, 1" : "=v"(x) : "v"(x)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpCndmask {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_cndmask_b32 %0, %1, %2, vcc" : "=v"(x) : "v"(x), "v"(y)); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
+struct OpSubCo {
+    using T = uint32_t;
+    __device__ static T init(uint32_t s) { return s; }
+    __device__ static void f(T& x, T y) { asm volatile("v_sub_co_u32 %0, vcc, %1, %2" : "=v"(x) : "v"(x), "v"(y) : "vcc"); }
+    __device__ static uint32_t fin(T x) { return x; }
+};
 
 template <class Op>
 __global__ __launch_bounds__(256) void k(uint32_t* out, uint32_t seed) {
@@ -221,6 +323,23 @@ int main() {
     uint32_t* dout;
     CK(hipMalloc(&dout, 256 * 8 * 256 * 4));
     run<OpAddU32>("v_add_u32", 1, dout);
+    run<OpAshr>("v_ashrrev_i32", 1, dout);
+    run<OpAnd>("v_and_b32", 1, dout);
+    run<OpXor>("v_xor_b32", 1, dout);
+    run<OpMaxI>("v_max_i32", 1, dout);
+    run<OpMinI>("v_min_i32", 1, dout);
+    run<OpMaxU>("v_max_u32", 1, dout);
+    run<OpLshl>("v_lshlrev_b32", 1, dout);
+    run<OpSubrev>("v_subrev_u32", 1, dout);
+    run<OpAddF32>("v_add_f32", 1, dout);
+    run<OpMinF32>("v_min_f32", 1, dout);
+    run<OpMed3>("v_med3_i32", 1, dout);
+    run<OpAndOr>("v_and_or_b32", 1, dout);
+    run<OpLshlAdd>("v_lshl_add_u32", 1, dout);
+    run<OpMov>("v_mov_b32", 1, dout);
+    run<OpBfe>("v_bfe_i32", 1, dout);
+    run<OpCndmask>("v_cndmask_b32", 1, dout);
+    run<OpSubCo>("v_sub_co_u32", 1, dout);
     run<OpMinU32>("v_min_u32", 1, dout);
     run<OpSubU32>("v_sub_u32", 1, dout);
     run<OpAdd3U32>("v_add3_u32", 1, dout);
