@@ -25,7 +25,7 @@ enum Header : uint32_t {
     H_CODE_OFF,
     H_CONST_OFF,
     H_TOTAL_WORDS,
-    H_PAD0,
+    H_FIRST_COLUMN,     // interaction program piece: permutation column of its first batch (0 for a whole program)
     H_PAD1,
     H_WORDS  // multiple of 4: the code starts 16-byte aligned
 };

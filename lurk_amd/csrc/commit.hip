@@ -67,8 +67,23 @@ int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_
     const uint32_t w_big = two_adic_generator_monty(log_n + log_blowup);
     for (uint32_t q = 0; q < (1u << log_blowup); q++) {
         uint32_t s_q = bb::mul(g, hpow(w_big, brev(q, log_blowup)));
-        LH_TRY(fill_powers(ctx, row_scale, s_q, n_inv, n));
-        LH_TRY(ntt_dif(ctx, *plan, /*inverse=*/false, coef, lde + q * n * w, nullptr, w, row_scale, false, out_canonical,
+        // s_q^i / N, i < N: cached per (log_n, s_q) while the cache stays under 1 GiB, else built in the caller's scratch
+        const uint32_t* scale = row_scale;
+        auto key = std::make_pair(log_n, s_q);
+        auto it = ctx->lde_scale_tables.find(key);
+        if (it != ctx->lde_scale_tables.end()) {
+            scale = it->second;
+        } else if (ctx->lde_scale_bytes + n * 4 <= ((size_t)1 << 30)) {
+            uint32_t* tbl = nullptr;
+            LH_HIP(ctx, hipMalloc(&tbl, n * 4));
+            LH_TRY(fill_powers(ctx, tbl, s_q, n_inv, n));
+            ctx->lde_scale_tables[key] = tbl;
+            ctx->lde_scale_bytes += n * 4;
+            scale = tbl;
+        } else {
+            LH_TRY(fill_powers(ctx, row_scale, s_q, n_inv, n));
+        }
+        LH_TRY(ntt_dif(ctx, *plan, /*inverse=*/false, coef, lde + q * n * w, nullptr, w, scale, false, out_canonical,
                        /*bitrev_store=*/false));
     }
     return LURKHIP_OK;

@@ -25,6 +25,10 @@ struct lurkhip_ctx {
     void* merkle_params_dev = nullptr;
     void* merkle_params_host = nullptr;  // P16Params copy for the host-side challenger
     void* ntt_plans[32] = {};
+    // coset-shift power tables of the LDE, s^i / N for i < N, keyed by (log_n, s): immutable once filled, so a table is
+    // computed once per context instead of once per matrix (commit.hip: extend)
+    std::map<std::pair<int, uint32_t>, uint32_t*> lde_scale_tables;
+    size_t lde_scale_bytes = 0;
     std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)
     std::multimap<size_t, void*> pool_free;

@@ -52,7 +52,8 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (e != hipSuccess && !ctx->pool_free.empty()) {
         // give cached blocks back to the driver and retry once
         (void)hipStreamSynchronize(ctx->stream);
-        for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+        for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
+    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
         ctx->pool_free.clear();
         e = hipMalloc(out, bytes);
     }

@@ -1,4 +1,5 @@
 // Symbolic AIR builder for the Lair chips + lowering to the device register program.  See air.h.
+#include <cstdlib>
 #include "air.h"
 
 #include <algorithm>
@@ -1076,10 +1077,15 @@ AirPrograms lower_air(const ChipAir& air) {
         for (E c : air.constraints) steps.push_back({airp::OP_ASSERT, c});
         p.constraints = lw.lower(steps, (uint32_t)air.constraints.size(), 0, 0);
     }
-    {
+    std::vector<const Interaction*> all;
+    for (const auto& it : air.sends) all.push_back(&it);
+    for (const auto& it : air.receives) all.push_back(&it);
+    auto lower_range = [&](size_t i0, size_t i1, uint32_t first_column) {
         Lowerer lw(air);
         std::vector<Lowerer::Step> steps;
-        auto add = [&](const Interaction& it) {
+        uint32_t n_sends = 0;
+        for (size_t i = i0; i < i1; i++) {
+            const Interaction& it = *all[i];
             Lowerer::Step s{airp::OP_IBEGIN, 0};
             s.dst = it.kind;
             s.a = it.is_send ? 1 : 0;
@@ -1087,11 +1093,26 @@ AirPrograms lower_air(const ChipAir& air) {
             steps.push_back(s);
             for (E v : it.values) steps.push_back({airp::OP_IVAL, v});
             steps.push_back({airp::OP_IEND, it.mult});
-        };
-        for (const auto& it : air.sends) add(it);
-        for (const auto& it : air.receives) add(it);
-        p.interactions = lw.lower(steps, 0, air.num_interactions(), (uint32_t)air.sends.size());
-    }
+            if (it.is_send) n_sends++;
+        }
+        std::vector<uint32_t> prog = lw.lower(steps, 0, (uint32_t)(i1 - i0), n_sends);
+        prog[airp::H_FIRST_COLUMN] = first_column;
+        return prog;
+    };
+    p.interactions = lower_range(0, all.size(), 0);
+    // pieces of about `per_part` interactions, at most six, each a whole number of batches
+    const size_t batch = (size_t)1 << air.log_quotient_degree();
+    const size_t n_batches = (all.size() + batch - 1) / batch;
+    auto cut = [&](size_t per_part, std::vector<std::vector<uint32_t>>& out) {
+        size_t n_parts = std::min<size_t>(6, std::max<size_t>(1, (all.size() + per_part - 1) / per_part));
+        n_parts = std::min(n_parts, std::max<size_t>(n_batches, 1));
+        for (size_t j = 0; j < n_parts; j++) {
+            const size_t b0 = n_batches * j / n_parts, b1 = n_batches * (j + 1) / n_parts;
+            out.push_back(lower_range(std::min(b0 * batch, all.size()), std::min(b1 * batch, all.size()), (uint32_t)b0));
+        }
+    };
+    cut(12, p.interaction_parts);
+    cut(24, p.interaction_parts_coarse);
     return p;
 }
 

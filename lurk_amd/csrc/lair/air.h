@@ -127,6 +127,13 @@ ChipAir build_poseidon2_air(uint32_t width);  // the narrow (one row per round) 
 struct AirPrograms {
     std::vector<uint32_t> constraints;
     std::vector<uint32_t> interactions;
+    // The interaction program cut into independent pieces at batch boundaries (batch = 2^log_quotient_degree interactions
+    // per permutation column): piece j covers whole columns, its header's H_FIRST_COLUMN says where it starts.  The prover
+    // kernels give every piece its own wave over one staged tile of rows, which multiplies the waves a CU can hold.
+    std::vector<std::vector<uint32_t>> interaction_parts;
+    // the same, cut coarser, for the quotient kernel (measured: it does best with two dozen interactions per wave, the
+    // permutation-trace kernel with one dozen)
+    std::vector<std::vector<uint32_t>> interaction_parts_coarse;
 };
 AirPrograms lower_air(const ChipAir& air);
 

@@ -28,26 +28,47 @@ struct lurkhip_air {
     lair::ChipAir air;
     lair::AirPrograms prog;
     std::mutex mu;
-    std::map<int, std::pair<uint32_t*, uint32_t*>> dev;  // device -> (constraint program, interaction program)
+    struct DevPrograms {
+        uint32_t* cons = nullptr;
+        uint32_t* inter = nullptr;
+        std::vector<uint32_t*> parts;         // interaction program pieces (AirPrograms::interaction_parts)
+        std::vector<uint32_t*> parts_coarse;  // AirPrograms::interaction_parts_coarse
+    };
+    std::map<int, DevPrograms> dev;  // device -> programs
     uint32_t tuple_words = 0;                              // sum over interactions of (1 + #values)
     uint32_t max_tuple = 0;
 };
 
 namespace lurkhip {
 
-int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons, const uint32_t** inter) {
+int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons, const uint32_t** inter,
+                         const std::vector<uint32_t*>** parts, bool coarse) {
     std::lock_guard<std::mutex> g(a->mu);
     auto it = a->dev.find(ctx->device);
     if (it == a->dev.end()) {
-        uint32_t *c = nullptr, *i = nullptr;
-        LH_HIP(ctx, hipMalloc(&c, a->prog.constraints.size() * 4));
-        LH_HIP(ctx, hipMalloc(&i, a->prog.interactions.size() * 4));
-        LH_HIP(ctx, hipMemcpy(c, a->prog.constraints.data(), a->prog.constraints.size() * 4, hipMemcpyHostToDevice));
-        LH_HIP(ctx, hipMemcpy(i, a->prog.interactions.data(), a->prog.interactions.size() * 4, hipMemcpyHostToDevice));
-        it = a->dev.emplace(ctx->device, std::make_pair(c, i)).first;
+        lurkhip_air::DevPrograms d;
+        auto upload = [&](const std::vector<uint32_t>& words, uint32_t** out) -> int32_t {
+            LH_HIP(ctx, hipMalloc(out, words.size() * 4));
+            LH_HIP(ctx, hipMemcpy(*out, words.data(), words.size() * 4, hipMemcpyHostToDevice));
+            return LURKHIP_OK;
+        };
+        LH_TRY(upload(a->prog.constraints, &d.cons));
+        LH_TRY(upload(a->prog.interactions, &d.inter));
+        for (const auto& part : a->prog.interaction_parts) {
+            uint32_t* dp = nullptr;
+            LH_TRY(upload(part, &dp));
+            d.parts.push_back(dp);
+        }
+        for (const auto& part : a->prog.interaction_parts_coarse) {
+            uint32_t* dp = nullptr;
+            LH_TRY(upload(part, &dp));
+            d.parts_coarse.push_back(dp);
+        }
+        it = a->dev.emplace(ctx->device, std::move(d)).first;
     }
-    if (cons) *cons = it->second.first;
-    if (inter) *inter = it->second.second;
+    if (cons) *cons = it->second.cons;
+    if (inter) *inter = it->second.inter;
+    if (parts) *parts = coarse ? &it->second.parts_coarse : &it->second.parts;
     return LURKHIP_OK;
 }
 
@@ -65,10 +86,10 @@ struct VmShape {
 };
 constexpr size_t VM_LDS_BUDGET = 64 * 1024;
 int vm_block(uint32_t n_regs, size_t* lds_bytes);
-VmShape vm_shape(uint32_t n_regs, uint32_t w, uint32_t tiles, uint32_t tile_rows) {
+VmShape vm_shape(uint32_t n_regs, uint32_t w, uint32_t tiles, uint32_t tile_rows, uint32_t extra_words = 0) {
     VmShape sh;
     sh.wp = w | 1u;
-    size_t need = ((size_t)n_regs * 64 + (size_t)tiles * tile_rows * sh.wp + 80) * 4;  // + row indices (up to 65)
+    size_t need = ((size_t)n_regs * 64 + (size_t)tiles * tile_rows * sh.wp + 80 + extra_words) * 4;  // + row indices (up to 65)
     if (need <= VM_LDS_BUDGET) {
         sh.block = 64;
         sh.lds = need;
@@ -332,13 +353,14 @@ struct PermSink {
     uint32_t* out_row;  // [perm_width * 4]
     uint32_t col = 0;
     ef row_sum = bb::ef_zero();
+    bool live = true;  // lanes past the last row run along (workgroup barriers) and store nothing
     __device__ __forceinline__ void assert_zero(uint32_t) {}
     __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
     __device__ __forceinline__ void ival(uint32_t v) { acc.value(v); }
     __device__ __forceinline__ void flush() {
         ef v = acc.in_batch == 1 ? bb::ef_scale(bb::ef_inv(acc.den), acc.m_first) : bb::ef_mul(acc.num, bb::ef_inv(acc.den));
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
-        *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
+        if (live) *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
         row_sum = bb::ef_add(row_sum, v);
         col++;
         acc.in_batch = 0;
@@ -348,31 +370,65 @@ struct PermSink {
     }
 };
 
-__global__ void k_perm_rows(const uint32_t* __restrict__ prog, const uint32_t* __restrict__ main, const uint32_t* __restrict__ prep,
-                            const uint32_t* __restrict__ pub, const uint32_t* __restrict__ beta_pows, ef alpha, uint32_t n, uint32_t w,
-                            uint32_t pw, uint32_t perm_w, uint32_t batch, uint32_t* __restrict__ out, uint32_t n_regs, uint32_t wp,
-                            int staged) {
+// Program pieces of a launch: one wave of every workgroup per piece, all over the same 64 staged rows.
+constexpr int MAX_VM_PARTS = 8;
+struct VmParts {
+    const uint32_t* prog[MAX_VM_PARTS];
+    uint32_t reg_off[MAX_VM_PARTS];  // word offset of the piece's register file regs[n_regs][64] in LDS
+    uint32_t n_parts;
+};
+
+struct PermArgs {
+    VmParts parts;
+    const uint32_t* main;
+    const uint32_t* prep;
+    const uint32_t* beta_pows;
+    ef alpha;
+    uint32_t n, w, pw, perm_w, batch;
+    uint32_t* out;
+    uint32_t regs_words;  // all register files
+    uint32_t wp;
+    int staged;
+};
+
+// Workgroup = 64 rows x n_parts waves: wave j runs interaction piece j (its own permutation columns) on the shared tile;
+// the pieces' row sums meet in LDS and wave 0 writes the last column.
+__global__ void k_perm_rows(PermArgs a) {
     extern __shared__ uint32_t lds[];
-    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t nx = i + 1 >= n ? 0 : i + 1;
-    const uint32_t* main_l = main + (size_t)(i < n ? i : 0) * w;
-    if (staged) {
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 64u + lane;
+    const bool live = i < a.n;
+    const uint32_t ic = live ? i : 0u;
+    const uint32_t nx = ic + 1 >= a.n ? 0 : ic + 1;
+    const uint32_t* main_l = a.main + (size_t)ic * a.w;
+    uint32_t* tile = lds + a.regs_words;
+    uint32_t* idx = tile + (a.staged ? 64u * a.wp : 0u);
+    uint32_t* sums = idx + 64;  // [n_parts][64][4]
+    if (a.staged) {
         // interactions only read the local row
-        uint32_t* tile = lds + n_regs * blockDim.x;
-        uint32_t* idx = tile + blockDim.x * wp;
-        idx[threadIdx.x] = i < n ? i : 0;
+        if (wave == 0) idx[lane] = ic;
         __syncthreads();
-        stage_rows(tile, wp, main, w, idx, blockDim.x);
+        stage_rows(tile, a.wp, a.main, a.w, idx, 64u);
         __syncthreads();
-        main_l = tile + threadIdx.x * wp;
+        main_l = tile + lane * a.wp;
     }
-    if (i >= n) return;
-    airvm::Sources s{main_l, main + (size_t)nx * w, prep + (size_t)i * pw, prep + (size_t)nx * pw, pub, {0u, 0u, 0u}};
-    PermSink sink{LogupAccum{beta_pows, alpha}, batch, out + (size_t)i * perm_w * 4};
-    airvm::run(prog, s, lds + threadIdx.x, blockDim.x, sink);
+    const uint32_t* prog = a.parts.prog[wave];
+    airvm::Sources src{main_l, a.main + (size_t)nx * a.w, a.prep + (size_t)ic * a.pw, a.prep + (size_t)nx * a.pw, nullptr, {0u, 0u, 0u}};
+    PermSink sink{LogupAccum{a.beta_pows, a.alpha}, a.batch, a.out + (size_t)ic * a.perm_w * 4};
+    sink.col = prog[airp::H_FIRST_COLUMN];
+    sink.live = live;
+    airvm::run(prog, src, lds + a.parts.reg_off[wave] + lane, 64u, sink);
     if (sink.acc.in_batch) sink.flush();
+    if (a.parts.n_parts > 1) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) sums[(wave * 64u + lane) * 4 + c] = sink.row_sum.c[c];
+        __syncthreads();
+        if (wave != 0) return;
+        for (uint32_t j = 1; j < a.parts.n_parts; j++) sink.row_sum = bb::ef_add(sink.row_sum, ef_load(sums + (j * 64u + lane) * 4));
+    }
+    if (!live) return;
     // the row's sum goes to the last column; the scan below turns it into the running sum
-    uint4* dst = reinterpret_cast<uint4*>(sink.out_row + 4 * (perm_w - 1));
+    uint4* dst = reinterpret_cast<uint4*>(sink.out_row + 4 * (a.perm_w - 1));
     *dst = make_uint4(sink.row_sum.c[0], sink.row_sum.c[1], sink.row_sum.c[2], sink.row_sum.c[3]);
 }
 
@@ -473,8 +529,8 @@ namespace {
 // folded as sum_k alpha^(K-1-k) C_k(x), which is sphinx's Horner accumulation `acc = acc * alpha + C_k`
 // [UPSTREAM-RECALL: ProverConstraintFolder], and multiplied by 1 / Z_H(x).
 struct QuotientArgs {
-    const uint32_t* cons_prog;
-    const uint32_t* inter_prog;
+    VmParts parts;          // piece 0: the constraint program, pieces 1..: the interaction program pieces
+    uint32_t n_cons;        // constraints of the chip (the interaction batches' constraints follow them)
     const uint32_t* main;   // LDE matrices, bit-reversed rows, Montgomery
     const uint32_t* prep;
     const uint32_t* perm;   // 4 * perm_w base columns
@@ -487,7 +543,7 @@ struct QuotientArgs {
     uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
     uint32_t zh[4];
     uint32_t g_m, wq_m, wn_inv_m;
-    uint32_t n_regs, wp;    // LDS layout (vm_shape)
+    uint32_t regs_words, wp;    // LDS layout (layout_parts)
     int staged;
     uint32_t* out;          // [2^lqd][N][4]
 };
@@ -501,9 +557,13 @@ struct QuotientSink {
     uint32_t k = 0, col = 0;
     LazyEf folded;
     int32_t next_w[8];  // alpha^(K-1-k), loaded one constraint ahead (see LogupAccum::next_pow)
-    __device__ __forceinline__ void prime() {
+    __device__ __forceinline__ void prime(uint32_t k_start) {
         folded.zero();
-        load_w8(next_w, alpha_pows + 8 * (k_total - 1));
+        seek(k_start);
+    }
+    __device__ __forceinline__ void seek(uint32_t k_next) {
+        k = k_next;
+        load_w8(next_w, alpha_pows + 8 * (k_total - 1 - k));
     }
     __device__ __forceinline__ void weight(int32_t (&w)[8]) {
 #pragma unroll
@@ -538,9 +598,13 @@ struct QuotientSink {
     }
 };
 
+// Workgroup = 64 quotient-domain rows x n_parts waves over one staged tile: wave 0 folds the chip's constraints, wave j >= 1
+// the batch constraints of interaction piece j - 1 (weights alpha^(K-1-k) at their own k); the partial folds meet in LDS and
+// wave 0 adds the running-sum constraints and stores the quotient value.
 __global__ void k_quotient(QuotientArgs a) {
     extern __shared__ uint32_t regs[];
-    const uint32_t s_raw = blockIdx.x * blockDim.x + threadIdx.x;
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t s_raw = blockIdx.x * 64u + lane;
     const uint32_t q = 1u << a.log_q;
     const bool live = s_raw < q;
     const uint32_t s = live ? s_raw : 0u;
@@ -550,33 +614,45 @@ __global__ void k_quotient(QuotientArgs a) {
     const uint32_t s_next = a.log_q ? (__brev(i_next) >> (32 - a.log_q)) : 0u;
     const uint32_t* main_l = a.main + (size_t)s * a.w;
     const uint32_t* main_n = a.main + (size_t)s_next * a.w;
+    uint32_t* tile_l = regs + a.regs_words;
+    uint32_t* idx = tile_l + (a.staged ? 64u * a.wp : 0u);
+    uint32_t* folds = idx + 64;  // [n_parts][64][4]
     if (a.staged) {
         // only the local rows are staged: the Lair AIRs read one or two columns of the next row (nonce, is_real, ptr),
         // which stay in global memory, and a second tile would halve the waves an LDS-bound CU can hold
-        uint32_t* tile_l = regs + a.n_regs * blockDim.x;
-        uint32_t* idx = tile_l + blockDim.x * a.wp;
-        idx[threadIdx.x] = s;
+        if (wave == 0) idx[lane] = s;
         __syncthreads();
-        stage_rows(tile_l, a.wp, a.main, a.w, idx, blockDim.x);
+        stage_rows(tile_l, a.wp, a.main, a.w, idx, 64u);
         __syncthreads();
-        main_l = tile_l + threadIdx.x * a.wp;
+        main_l = tile_l + lane * a.wp;
     }
-    if (!live) return;
-    // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset)
-    const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
-    const uint32_t zh = a.zh[i & (qd - 1)];
-    const uint32_t is_first = bb::mul(zh, bb::inv(bb::sub(x, bb::R1)));
-    const uint32_t x_minus_last = bb::sub(x, a.wn_inv_m);
-    const uint32_t is_last = bb::mul(zh, bb::inv(x_minus_last));
-    const uint32_t is_trans = x_minus_last;
+    // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset): the constraint wave needs them
+    uint32_t is_first = 0, is_last = 0, is_trans = 0;
+    if (wave == 0) {
+        const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
+        const uint32_t zh = a.zh[i & (qd - 1)];
+        is_first = bb::mul(zh, bb::inv(bb::sub(x, bb::R1)));
+        const uint32_t x_minus_last = bb::sub(x, a.wn_inv_m);
+        is_last = bb::mul(zh, bb::inv(x_minus_last));
+        is_trans = x_minus_last;
+    }
     airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw, a.pub, {is_first, is_last, is_trans}};
     const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
     const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.perm_alpha}, a.batch, perm_l};
-    sink.prime();
-    airvm::run(a.cons_prog, src, regs + threadIdx.x, blockDim.x, sink);
-    airvm::run(a.inter_prog, src, regs + threadIdx.x, blockDim.x, sink);
+    const uint32_t* prog = a.parts.prog[wave];
+    const uint32_t first_col = wave == 0 ? 0u : prog[airp::H_FIRST_COLUMN];
+    sink.col = first_col;
+    sink.prime(wave == 0 ? 0u : a.n_cons + first_col);
+    airvm::run(prog, src, regs + a.parts.reg_off[wave] + lane, 64u, sink);
     if (sink.acc.in_batch) sink.flush();
+    if (wave != 0) {
+        const ef f = sink.folded.value();
+#pragma unroll
+        for (int c = 0; c < 4; c++) folds[(wave * 64u + lane) * 4 + c] = f.c[c];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
     // running-sum constraints (sphinx eval_permutation_constraints)
     ef sum_l = bb::ef_zero(), sum_n = bb::ef_zero();
     for (uint32_t c = 0; c + 1 < a.perm_w; c++) {
@@ -584,16 +660,45 @@ __global__ void k_quotient(QuotientArgs a) {
         sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
     }
     const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1)), phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
+    sink.seek(a.k_total - 3);
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, a.cumulative_sum), is_last));
-    const ef quot = bb::ef_scale(sink.folded.value(), a.zh_inv[i & (qd - 1)]);
+    ef folded = sink.folded.value();
+    for (uint32_t j = 1; j < a.parts.n_parts; j++) folded = bb::ef_add(folded, ef_load(folds + (j * 64u + lane) * 4));
+    const ef quot = bb::ef_scale(folded, a.zh_inv[i & (qd - 1)]);
     const uint32_t chunk = i & (qd - 1), r = i >> lqd;
     uint4* dst = reinterpret_cast<uint4*>(a.out + ((size_t)chunk * ((size_t)1 << a.log_n) + r) * 4);
     *dst = make_uint4(quot.c[0], quot.c[1], quot.c[2], quot.c[3]);
 }
 
 }  // namespace
+
+// LDS layout of a multi-piece VM launch: the pieces' register files, the staged tile of 64 rows (when it fits), 64 row
+// indices, one extension element per piece and lane for the final combination.
+struct PartLayout {
+    VmParts parts;
+    uint32_t regs_words;
+    uint32_t wp;
+    bool staged;
+    size_t lds_bytes;
+};
+static PartLayout layout_parts(const std::vector<const std::vector<uint32_t>*>& host, const std::vector<uint32_t*>& dev, uint32_t w) {
+    PartLayout l{};
+    l.parts.n_parts = (uint32_t)host.size();
+    uint32_t off = 0;
+    for (size_t j = 0; j < host.size(); j++) {
+        l.parts.prog[j] = dev[j];
+        l.parts.reg_off[j] = off;
+        off += (*host[j])[airp::H_N_REGS] * 64u;
+    }
+    l.regs_words = off;
+    l.wp = w | 1u;
+    const size_t fixed = (size_t)off + 64 + (size_t)host.size() * 256;
+    l.staged = (fixed + 64u * l.wp) * 4 <= VM_LDS_BUDGET;
+    l.lds_bytes = (fixed + (l.staged ? 64u * l.wp : 0u)) * 4;
+    return l;
+}
 
 int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count, bool centred) {
     hipLaunchKernelGGL(k_ef_powers, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, base_m[0], base_m[1], base_m[2], base_m[3],
@@ -624,8 +729,8 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
     LH_ARG(ctx, height > 0, "empty trace");
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t* ip = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, nullptr, &ip));
+    const std::vector<uint32_t*>* dparts = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, nullptr, nullptr, &dparts));
     const uint32_t perm_w = a->air.permutation_width(), batch = 1u << a->air.log_quotient_degree();
     void* pows = nullptr;
     const uint32_t n_pows = a->max_tuple + 2;
@@ -633,11 +738,25 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     span_begin(ctx, "perm_rows");
     int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
     if (s == LURKHIP_OK) {
-        const uint32_t n_regs = a->prog.interactions[airp::H_N_REGS];
-        const VmShape shp = vm_shape(n_regs, a->air.width, 1, 64);
-        hipLaunchKernelGGL(k_perm_rows, dim3((height + shp.block - 1) / shp.block), dim3(shp.block), shp.lds, ctx->stream, ip, main_dev,
-                           prep_dev ? prep_dev : main_dev, (const uint32_t*)nullptr, (const uint32_t*)pows, alpha, height,
-                           a->air.width, a->air.prep_width, perm_w, batch, out_dev, n_regs, shp.wp, shp.staged ? 1 : 0);
+        PermArgs pa{};
+        std::vector<const std::vector<uint32_t>*> host_parts;
+        for (const auto& part : a->prog.interaction_parts) host_parts.push_back(&part);
+        const PartLayout lay = layout_parts(host_parts, *dparts, a->air.width);
+        pa.parts = lay.parts;
+        pa.main = main_dev;
+        pa.prep = prep_dev ? prep_dev : main_dev;
+        pa.beta_pows = (const uint32_t*)pows;
+        pa.alpha = alpha;
+        pa.n = height;
+        pa.w = a->air.width;
+        pa.pw = a->air.prep_width;
+        pa.perm_w = perm_w;
+        pa.batch = batch;
+        pa.out = out_dev;
+        pa.regs_words = lay.regs_words;
+        pa.wp = lay.wp;
+        pa.staged = lay.staged ? 1 : 0;
+        hipLaunchKernelGGL(k_perm_rows, dim3((height + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, pa);
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
     span_end(ctx, "perm_rows");
@@ -660,8 +779,9 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     const uint32_t lqd = a->air.log_quotient_degree();
     LH_ARG(ctx, lqd <= 2 && log_n + lqd <= (uint32_t)bb::TWO_ADICITY, "unsupported quotient degree / height");
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t *cp = nullptr, *ip = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, &cp, &ip));
+    const uint32_t* cp = nullptr;
+    const std::vector<uint32_t*>* dparts = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, &cp, nullptr, &dparts, /*coarse=*/true));
     const uint32_t perm_w = a->air.permutation_width(), batch = 1u << lqd;
     const uint32_t n_batches = perm_w - 1;
     const uint32_t k_total = (uint32_t)a->air.constraints.size() + n_batches + 3;
@@ -683,8 +803,15 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     }
     if (s == LURKHIP_OK) {
         QuotientArgs q{};
-        q.cons_prog = cp;
-        q.inter_prog = ip;
+        std::vector<const std::vector<uint32_t>*> host_parts{&a->prog.constraints};
+        std::vector<uint32_t*> dev_parts{const_cast<uint32_t*>(cp)};
+        for (size_t j = 0; j < a->prog.interaction_parts_coarse.size(); j++) {
+            host_parts.push_back(&a->prog.interaction_parts_coarse[j]);
+            dev_parts.push_back((*dparts)[j]);
+        }
+        const PartLayout lay = layout_parts(host_parts, dev_parts, a->air.width);
+        q.parts = lay.parts;
+        q.n_cons = (uint32_t)a->air.constraints.size();
         q.main = main_lde_dev;
         q.prep = prep_lde_dev ? prep_lde_dev : main_lde_dev;
         q.perm = perm_lde_dev;
@@ -715,14 +842,12 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             cur = bb::mul(cur, w_qd);
         }
         q.out = out_dev;
-        const uint32_t n_regs = std::max(a->prog.constraints[airp::H_N_REGS], a->prog.interactions[airp::H_N_REGS]);
-        const VmShape shp = vm_shape(n_regs, q.w, 1, 64);
-        q.n_regs = n_regs;
-        q.wp = shp.wp;
-        q.staged = shp.staged ? 1 : 0;
+        q.regs_words = lay.regs_words;
+        q.wp = lay.wp;
+        q.staged = lay.staged ? 1 : 0;
         const uint32_t rows = 1u << q.log_q;
         span_begin(ctx, "quotient");
-        hipLaunchKernelGGL(k_quotient, dim3((rows + shp.block - 1) / shp.block), dim3(shp.block), shp.lds, ctx->stream, q);
+        hipLaunchKernelGGL(k_quotient, dim3((rows + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, q);
         span_end(ctx, "quotient");
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
     }
@@ -791,8 +916,10 @@ int32_t lurkhip_air_from_chip(lair::ChipAir&& air, lurkhip_air** out) {
 int32_t lurkhip_air_free(lurkhip_air* a) {
     if (!a) return LURKHIP_OK;
     for (auto& kv : a->dev) {
-        (void)hipFree(kv.second.first);
-        (void)hipFree(kv.second.second);
+        (void)hipFree(kv.second.cons);
+        (void)hipFree(kv.second.inter);
+        for (auto* part : kv.second.parts) (void)hipFree(part);
+        for (auto* part : kv.second.parts_coarse) (void)hipFree(part);
     }
     delete a;
     return LURKHIP_OK;
@@ -814,6 +941,12 @@ int32_t lurkhip_air_info(const lurkhip_air* a, uint32_t* info) {
     info[11] = a->prog.constraints[airp::H_N_INSTR];
     info[12] = a->prog.interactions[airp::H_N_REGS];
     info[13] = a->prog.interactions[airp::H_N_INSTR];
+    info[14] = (uint32_t)a->prog.interaction_parts.size();
+    {
+        uint32_t sum = 0;
+        for (const auto& part : a->prog.interaction_parts) sum += part[airp::H_N_INSTR];
+        info[15] = sum;  // instructions over all pieces (common subexpressions are recomputed per piece)
+    }
     return LURKHIP_OK;
 }
 
