@@ -18,7 +18,7 @@ int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_r
                    uint32_t* out_dev);
 // ro[s] += apow0 * (rr_s - ys0) * d0[s] (+ apow1 * (rr_s - ys1) * d1[s]),  rr_s = sum_c alpha_pows[c] * mat[s][c]
 int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
-                        const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
+                        const uint32_t* alpha_pows_centred /* 8 words per power (ef_powers centred), or null */, const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
                         const bb::ef& apow1, uint32_t* ro);
 // p3 fold_even_odd on 2^log_len bit-reversed evaluations (+ add[j] when given); out has 2^(log_len-1) elements
 int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const bb::ef& beta, const uint32_t* add, uint32_t* out);

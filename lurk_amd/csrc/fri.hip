@@ -9,10 +9,13 @@
 //
 // All matrices are the committed LDEs: row-major, bit-reversed row order, Montgomery words; extension
 // elements are 4 consecutive words.  Storage row s of a height-M matrix is the point x_s = 31 * w_M^bitrev(s).
+#include <algorithm>
+
 #include "babybear.h"
 #include "commit.h"
 #include "ctx.h"
 #include "fri.h"
+#include "lazy_ef.h"
 #include "poseidon2_dev.h"
 
 namespace lurkhip {
@@ -33,7 +36,8 @@ __device__ __forceinline__ uint32_t brev_bits(uint32_t x, int bits) { return bit
 // mode 0: u[s] = w^i / (z - g w^i)      (barycentric weights on the low coset, p3 interpolate_coset)
 // mode 1: d[s] = 1 / (g w^i - z)        (p3 compute_inverse_denominators)
 // with i = bitrev(s) over log_m bits, w = w_M.
-__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, uint32_t w_m, ef z, uint32_t* __restrict__ out) {
+// centred: store the coefficients as signed representatives in (-p/2, p/2] (operands of the lazy accumulators)
+__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, uint32_t w_m, ef z, uint32_t* __restrict__ out, int centred) {
     const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
     if (s >= (1u << log_m)) return;
     const uint32_t i = brev_bits(s, log_m);
@@ -48,6 +52,8 @@ __global__ void k_point_weights(int mode, int log_m, uint32_t g_m, uint32_t w_m,
         ef diff{{bb::sub(x, z.c[0]), bb::neg(z.c[1]), bb::neg(z.c[2]), bb::neg(z.c[3])}};
         r = bb::ef_inv(diff);
     }
+    if (centred)
+        for (int c = 0; c < 4; c++) r.c[c] = r.c[c] > bb::P / 2 ? r.c[c] - bb::P : r.c[c];
     ef_store(out + 4 * (size_t)s, r);
 }
 
@@ -71,14 +77,25 @@ __global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__
     const bool active = rl < R;
     for (uint32_t cb = 0; cb < w; cb += 256) {
         const uint32_t c = cb + cl;
-        ef a0 = bb::ef_zero(), a1 = bb::ef_zero();
+        // the weights are centred (k_point_weights): one multiply-add per coefficient into 64-bit lanes, folded every
+        // second row
+        LazyEf l0, l1;
+        l0.zero();
+        l1.zero();
         if (active && c < w) {
             for (size_t r = row0 + rl; r < row_end; r += R) {
                 const uint32_t m = mat[r * w + c];
-                a0 = bb::ef_add(a0, bb::ef_scale(ef_load(u0 + 4 * r), m));
-                if (u1) a1 = bb::ef_add(a1, bb::ef_scale(ef_load(u1 + 4 * r), m));
+                const uint4 p0 = *reinterpret_cast<const uint4*>(u0 + 4 * r);
+                const int32_t w0[4] = {(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w};
+                l0.add_base_v(m, w0);
+                if (u1) {
+                    const uint4 p1 = *reinterpret_cast<const uint4*>(u1 + 4 * r);
+                    const int32_t w1[4] = {(int32_t)p1.x, (int32_t)p1.y, (int32_t)p1.z, (int32_t)p1.w};
+                    l1.add_base_v(m, w1);
+                }
             }
         }
+        const ef a0 = l0.value(), a1 = l1.value();
         for (int k = 0; k < 4; k++) {
             sh[0][threadIdx.x][k] = a0.c[k];
             sh[1][threadIdx.x][k] = a1.c[k];
@@ -174,6 +191,61 @@ __global__ __launch_bounds__(64) void k_reduce_openings(ReduceArgs a) {
     ef_store(a.ro + 4 * (size_t)s, acc);
 }
 
+// Streaming version for w <= 128: one wave per workgroup, persistent over 64-row tiles.  A tile is 64 * w contiguous
+// words: lane l loads words l, l + 64, ... (coalesced) into registers while the previous tile is being reduced, drops them
+// into LDS in the same flat order (position e + (e >> 5): one pad word per 32 keeps the row-wise reads of every width off a
+// single bank) and then takes row l: sum_c alpha^c * row[c] in lazily reduced 64-bit lanes (lazy_ef.h; alpha powers
+// centred, 8 words each).  NV = words per lane, >= w.
+template <int NV>
+__global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
+    extern __shared__ uint32_t tile[];
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_tiles = (a.m_rows + 63u) / 64u;
+    const size_t total = (size_t)a.m_rows * a.w;  // words in the matrix
+    uint32_t v[NV];
+    auto fetch = [&](uint32_t t) {
+        const size_t base = (size_t)t * 64u * a.w;
+        const size_t lim = total - 1;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            // words past the tile (k >= w) or past the matrix re-read a valid word: no branch around a load
+            const uint32_t kk = (uint32_t)k < a.w ? (uint32_t)k : a.w - 1u;
+            size_t e = base + (size_t)kk * 64u + lane;
+            e = e < lim ? e : lim;
+            v[k] = a.mat[e];
+        }
+    };
+    uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    fetch(t);
+    const uint32_t wbase = lane + (lane >> 5);  // position of flat word e = k * 64 + lane: e + (e >> 5) = k * 66 + wbase
+    for (; t < n_tiles; t += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) tile[wbase + (uint32_t)k * 66u] = v[k];
+        __syncthreads();
+        const uint32_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
+        fetch(t_next);
+        const uint32_t s = t * 64u + lane;
+        LazyEf rr;
+        rr.zero();
+        uint32_t e = lane * a.w;
+        const uint32_t* __restrict__ ap = a.alpha_pows;
+        for (uint32_t c = 0; c < a.w; c++, e++) {
+            int32_t pw[8];
+            load_w8(pw, ap + 8 * c);
+            rr.add_base(tile[e + (e >> 5)], pw);
+        }
+        if (s < a.m_rows) {
+            const ef r = rr.value();
+            ef acc = ef_load(a.ro + 4 * (size_t)s);
+            acc = bb::ef_add(acc, bb::ef_mul(a.apow0, bb::ef_mul(bb::ef_sub(r, a.ys0), ef_load(a.d0 + 4 * (size_t)s))));
+            if (a.d1) acc = bb::ef_add(acc, bb::ef_mul(a.apow1, bb::ef_mul(bb::ef_sub(r, a.ys1), ef_load(a.d1 + 4 * (size_t)s))));
+            ef_store(a.ro + 4 * (size_t)s, acc);
+        }
+        __syncthreads();  // the tile is free for the next one
+    }
+}
+
 // ---------------------------------------------------------------- FRI fold (p3 fold_even_odd)
 // out[j] = (1/2 + beta/2 * ginv^bitrev(j)) e[2j] + (1/2 - beta/2 * ginv^bitrev(j)) e[2j+1]  (+ add[j]),
 // ginv = (generator of the size-len subgroup)^-1; len = 2^log_len
@@ -241,8 +313,9 @@ __global__ __launch_bounds__(256) void k_gather_openings(const GatherMat* __rest
 
 int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev) {
     const uint32_t m = 1u << log_m;
+    // the barycentric weights (mode 0) only feed k_column_dot's lazy accumulators: centred
     hipLaunchKernelGGL(k_point_weights, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, mode, log_m, bb::to_monty(bb::GEN),
-                       two_adic_generator_monty(log_m), z, out_dev);
+                       two_adic_generator_monty(log_m), z, out_dev, mode == 0 ? 1 : 0);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
@@ -260,8 +333,30 @@ int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_r
 }
 
 int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
-                        const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
-                        const bb::ef& apow1, uint32_t* ro) {
+                        const uint32_t* alpha_pows_centred, const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0,
+                        const bb::ef& ys1, const bb::ef& apow0, const bb::ef& apow1, uint32_t* ro) {
+    if (w <= 128 && alpha_pows_centred) {
+        ReduceArgs a{mat, w, m_rows, alpha_pows_centred, d0, d1, ys0, ys1, apow0, apow1, ro, 1};
+        const uint32_t n_tiles = (m_rows + 63) / 64;
+        auto launch = [&](auto kernel, int nv) {
+            const size_t lds = ((size_t)nv * 66 + 64 + 8) * 4;
+            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
+            const unsigned blocks = (unsigned)std::min<size_t>(n_tiles, (size_t)per_cu * ctx->num_cus);
+            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, ctx->stream, a);
+        };
+        if (w <= 8) launch(k_reduce_openings_stream<8>, 8);
+        else if (w <= 16) launch(k_reduce_openings_stream<16>, 16);
+        else if (w <= 24) launch(k_reduce_openings_stream<24>, 24);
+        else if (w <= 32) launch(k_reduce_openings_stream<32>, 32);
+        else if (w <= 48) launch(k_reduce_openings_stream<48>, 48);
+        else if (w <= 64) launch(k_reduce_openings_stream<64>, 64);
+        else if (w <= 80) launch(k_reduce_openings_stream<80>, 80);
+        else if (w <= 96) launch(k_reduce_openings_stream<96>, 96);
+        else if (w <= 112) launch(k_reduce_openings_stream<112>, 112);
+        else launch(k_reduce_openings_stream<128>, 128);
+        LH_HIP(ctx, hipGetLastError());
+        return LURKHIP_OK;
+    }
     const size_t lds = (size_t)64 * (w | 1u) * 4;
     const bool staged = lds <= 64 * 1024;
     ReduceArgs a{mat, w, m_rows, alpha_pows, d0, d1, ys0, ys1, apow0, apow1, ro, staged ? 1 : 0};

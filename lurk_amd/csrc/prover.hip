@@ -391,6 +391,9 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     uint32_t* alpha_pows = nullptr;  // alpha_fri^c for c < max_w
     PTRY(palloc((size_t)max_w * 16, &alpha_pows));
     PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows, max_w));
+    uint32_t* alpha_pows_c = nullptr;  // the same powers, centred, 8 words each (lazy accumulators)
+    PTRY(palloc((size_t)max_w * 32, &alpha_pows_c));
+    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows_c, max_w, true));
     std::vector<ef> alpha_pows_host(max_w);
     {
         ef p = bb::ef_one();
@@ -479,7 +482,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
             if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
             const ef apow0 = ef_pow_host(alpha_fri, num_reduced[log_h]);
             const ef apow1 = ef_pow_host(alpha_fri, num_reduced[log_h] + w);
-            PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
+            PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
             num_reduced[log_h] += (uint64_t)mp.size() * w;
         }
     }
