@@ -83,7 +83,31 @@ __global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__
         l0.zero();
         l1.zero();
         if (active && c < w) {
-            for (size_t r = row0 + rl; r < row_end; r += R) {
+            // eight rows per trip: the matrix words go out as one batch of loads (one word in flight per lane leaves the
+            // HBM latency uncovered), then the accumulation
+            constexpr int UR = 8;
+            size_t r = row0 + rl;
+            for (; r + (size_t)(UR - 1) * R < row_end; r += (size_t)UR * R) {
+                uint32_t m[UR];
+                uint4 p0[UR], p1[UR];
+#pragma unroll
+                for (int k = 0; k < UR; k++) {
+                    const size_t rr = r + (size_t)k * R;
+                    m[k] = mat[rr * w + c];
+                    p0[k] = *reinterpret_cast<const uint4*>(u0 + 4 * rr);
+                    p1[k] = *reinterpret_cast<const uint4*>((u1 ? u1 : u0) + 4 * rr);
+                }
+#pragma unroll
+                for (int k = 0; k < UR; k++) {
+                    const int32_t w0[4] = {(int32_t)p0[k].x, (int32_t)p0[k].y, (int32_t)p0[k].z, (int32_t)p0[k].w};
+                    l0.add_base_v(m[k], w0);
+                    if (u1) {
+                        const int32_t w1[4] = {(int32_t)p1[k].x, (int32_t)p1[k].y, (int32_t)p1[k].z, (int32_t)p1[k].w};
+                        l1.add_base_v(m[k], w1);
+                    }
+                }
+            }
+            for (; r < row_end; r += R) {
                 const uint32_t m = mat[r * w + c];
                 const uint4 p0 = *reinterpret_cast<const uint4*>(u0 + 4 * r);
                 const int32_t w0[4] = {(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w};

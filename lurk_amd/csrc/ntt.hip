@@ -126,13 +126,21 @@ __device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t*
 }
 
 // stage groups of a pass, top stage first: radix 8 while at least three stages remain (four are split 2 + 2)
+// During the stages a column belongs to one wave (all its row slots are lanes of that wave), and a wave's LDS operations
+// execute in order: between stage groups only the compiler has to be kept from reordering them -- no workgroup barrier.
 template <int LOG_R, int S_TOP, int SLOTS, class T>
 __device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, bool active) {
     if constexpr (S_TOP >= 0) {
         constexpr int REM = S_TOP + 1;
         constexpr int G = REM == 4 ? 2 : (REM >= 3 ? 3 : REM);
         if (active) stage_group<LOG_R, S_TOP, G, SLOTS, T>(col, tw_l, slot);
-        __syncthreads();
+        if constexpr (SLOTS <= 64) {
+            __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
+            __builtin_amdgcn_wave_barrier();
+            __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "wavefront");
+        } else {
+            __syncthreads();
+        }
         run_stages<LOG_R, S_TOP - G, SLOTS, T>(col, tw_l, slot, active);
     }
 }
@@ -177,6 +185,12 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
     const int l_of = a.log_l ? fast_div((uint32_t)tc, a.magic_w, a.w) : 0;  // which of the L adjacent rows
     const int col_in_chunk = tc - l_of * a.w;
     T* __restrict__ my_col = tile + cv * RP;
+    // the stages' map: slot fastest, so the SLOTS row slots of a column item are lanes of one wave
+    const int st_cv = (int)threadIdx.x >> LOG_SLOTS, st_slot = (int)threadIdx.x & (SLOTS - 1);
+    const bool st_active = st_cv < Cv;
+    const int st_cvc = st_active ? st_cv : 0;
+    const int st_l = a.log_l ? fast_div((uint32_t)(st_cvc * EW), a.magic_w, a.w) : 0;
+    T* __restrict__ st_col = tile + st_cvc * RP;
     const int n_tw = R << a.log_l;
 
     // Tiles of this workgroup.  Workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and tiles with
@@ -255,7 +269,8 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
         // the next tile's rows fly while this one's stages run (the last iteration re-reads its own tile: no branch)
         locate(it + 1 < my_tiles ? it + 1 : it, row0, col, lo);
         fetch(row0, col, lo);
-        run_stages<LOG_R, LOG_R - 1, SLOTS, T>(my_col, tw_lds + (l_of << LOG_R), slot, active);
+        run_stages<LOG_R, LOG_R - 1, SLOTS, T>(st_col, tw_lds + (st_l << LOG_R), st_slot, st_active);
+        __syncthreads();  // the stages ran under the column-per-wave map, the write-back uses the row-contiguous one
         if (active) {
             constexpr int UB = U < 4 ? U : 4;  // rows per batch of the write-back (LDS reads first, then their global stores)
 #pragma unroll
