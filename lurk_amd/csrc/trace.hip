@@ -41,24 +41,57 @@ struct TraceArgs {
     int canonical_out;
 };
 
+// Column col of the lane's row lives at base[e + (e >> sh)], e = e0 + col.  Staged (the workgroup's rows go through LDS and
+// leave with coalesced stores): base = the LDS tile, e0 = lane * width, sh = 5 (one pad word per 32 keeps a column of 64
+// rows off a single bank whatever the width).  Unstaged (rows wider than the tile budget): base = the row in global
+// memory, e0 = 0, sh = 31.
 struct RowWriter {
-    uint32_t* row;   // start of this row
+    uint32_t* row;
     uint32_t aux0;   // column of aux[0]
     uint32_t aux;    // aux cursor
     bool canonical;
-    __device__ __forceinline__ void put(uint32_t col, uint32_t v_m) { row[col] = canonical ? bb::from_monty(v_m) : v_m; }
+    uint32_t e0 = 0, sh = 31;
+    __device__ __forceinline__ uint32_t& at(uint32_t col) {
+        const uint32_t e = e0 + col;
+        return row[e + (e >> sh)];
+    }
+    __device__ __forceinline__ void put(uint32_t col, uint32_t v_m) { at(col) = canonical ? bb::from_monty(v_m) : v_m; }
     __device__ __forceinline__ void push_aux(uint32_t v_m) { put(aux0 + aux++, v_m); }
     // small non-negative integers (bytes, nonces, counts) given as plain integers
-    __device__ __forceinline__ void put_int(uint32_t col, uint32_t v) { row[col] = canonical ? v : bb::to_monty(v); }
+    __device__ __forceinline__ void put_int(uint32_t col, uint32_t v) { at(col) = canonical ? v : bb::to_monty(v); }
     __device__ __forceinline__ void push_aux_int(uint32_t v) { put_int(aux0 + aux++, v); }
 };
+
+// Inverses of the small integers (Montgomery form), built at compile time: the lookup counts whose successors a require
+// record inverts (air/builder.rs:162) are almost always a handful, and a Fermat ladder is 40 products per record.
+constexpr int INV_TABLE = 1024;
+struct InvTable {
+    uint32_t v[INV_TABLE];
+};
+constexpr uint32_t c_pow(uint32_t a, uint32_t e) {
+    uint32_t r = 1;
+    while (e) {
+        if (e & 1u) r = bb::cmulmod(r, a);
+        a = bb::cmulmod(a, a);
+        e >>= 1;
+    }
+    return r;
+}
+constexpr InvTable make_inv_table() {
+    InvTable t{};
+    t.v[0] = 0;
+    for (int i = 1; i < INV_TABLE; i++) t.v[i] = bb::c_to_monty(c_pow((uint32_t)i, bb::P - 2));
+    return t;
+}
+__constant__ const InvTable kInvSmall = make_inv_table();
 
 // RequireRecord: prev_nonce, prev_count, (prev_count + 1)^-1   (air/builder.rs:159-168)
 __device__ __forceinline__ void push_require(RowWriter& w, const uint32_t* rec) {
     uint32_t nonce = rec[0], count = rec[1];
     w.push_aux_int(nonce);
     w.push_aux_int(count);
-    w.push_aux(bb::inv(bb::to_monty(count + 1)));
+    const uint32_t c1 = count + 1;
+    w.push_aux(c1 < (uint32_t)INV_TABLE ? kInvSmall.v[c1] : bb::inv(bb::to_monty(c1)));
 }
 
 // Poseidon2Cols recorder writing straight into the row (core/poseidon.rs:65-72: 8 outputs first)
@@ -116,13 +149,9 @@ __device__ __forceinline__ void push_depth_less_than(RowWriter& w, uint32_t lhs,
 }
 
 template <int CAP>
-__global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
-    const uint32_t row_i = blockIdx.x * TBLOCK + threadIdx.x;
-    if (row_i >= a.height) return;
+__device__ __forceinline__ void trace_row(const TraceArgs& a, const uint32_t row_i, RowWriter& w) {
     const uint32_t* __restrict__ prog = a.prog;
-    const uint32_t width = prog[TH_WIDTH], n_in = prog[TH_INPUT], n_out = prog[TH_OUTPUT], n_aux = prog[TH_AUX];
-    uint32_t* row = a.out + (size_t)row_i * width;
-    RowWriter w{row, 1 + n_in + n_out, 0, a.canonical_out != 0};
+    const uint32_t n_in = prog[TH_INPUT], n_out = prog[TH_OUTPUT], n_aux = prog[TH_AUX];
     // nonce for every row, padding included (trace.rs:82-84); the rest of a padding row stays zero
     w.put_int(0, a.nonce_start + row_i);
     if (row_i >= a.n_real) return;
@@ -429,6 +458,33 @@ __global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
     }
 }
 
+// One row per lane.  STAGED: the workgroup's 64 rows are built in a zero-filled LDS tile and leave as one contiguous run
+// of 64 * width words with coalesced stores (a lane writing its own row straight to HBM touches 64 lines per store
+// instruction: 4x write amplification measured); the output needs no memset then.
+template <int CAP, bool STAGED>
+__global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
+    extern __shared__ uint32_t tile[];
+    const uint32_t row0 = blockIdx.x * TBLOCK, row_i = row0 + threadIdx.x;
+    const uint32_t width = a.prog[TH_WIDTH], n_in = a.prog[TH_INPUT], n_out = a.prog[TH_OUTPUT];
+    if constexpr (STAGED) {
+        const uint32_t rows = a.height - row0 < (uint32_t)TBLOCK ? a.height - row0 : (uint32_t)TBLOCK;
+        const uint32_t words = rows * width, padded = TBLOCK * width + ((TBLOCK * width) >> 5) + 1;
+        for (uint32_t e = threadIdx.x; e < padded; e += TBLOCK) tile[e] = 0;
+        __syncthreads();
+        if (row_i < a.height) {
+            RowWriter w{tile, 1 + n_in + n_out, 0, a.canonical_out != 0, threadIdx.x * width, 5};
+            trace_row<CAP>(a, row_i, w);
+        }
+        __syncthreads();
+        uint32_t* __restrict__ dst = a.out + (size_t)row0 * width;
+        for (uint32_t e = threadIdx.x; e < words; e += TBLOCK) dst[e] = tile[e + (e >> 5)];
+    } else {
+        if (row_i >= a.height) return;
+        RowWriter w{a.out + (size_t)row_i * width, 1 + n_in + n_out, 0, a.canonical_out != 0};
+        trace_row<CAP>(a, row_i, w);
+    }
+}
+
 // ---- MemChip (memory.rs:30-69): [is_real = 1, ptr = i + 1, last_nonce, last_count, values...] -----------
 __global__ void k_trace_mem(const uint32_t* __restrict__ values, const uint32_t* __restrict__ provides, uint32_t len,
                             uint32_t n_real, uint32_t height, uint32_t* __restrict__ out, int canonical) {
@@ -483,16 +539,25 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     const uint32_t width = program_host_header[TH_WIDTH];
     const uint32_t max_vars = program_host_header[TH_MAX_VARS];
     LH_ARG(ctx, max_vars <= 4096, "function needs %u variables, more than the kernel's map capacity", max_vars);
-    LH_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)height * width * sizeof(uint32_t), ctx->stream));
     if (height == 0) return LURKHIP_OK;
+    const size_t tile_words = (size_t)TBLOCK * width + (((size_t)TBLOCK * width) >> 5) + 1;
+    const bool staged = tile_words * 4 <= 64 * 1024;
+    if (!staged) LH_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)height * width * sizeof(uint32_t), ctx->stream));
     TraceArgs a{program_dev, args_dev, outputs_dev, provides_dev, depths_dev, (const RowMeta*)meta_dev, stream_dev, out_dev,
                 n_real, height, nonce_start, repr == LURKHIP_REPR_CANONICAL};
     dim3 grid((height + TBLOCK - 1) / TBLOCK), block(TBLOCK);
     lurkhip::span_begin(ctx, "trace_func");
-    if (max_vars <= 64) hipLaunchKernelGGL(k_trace_func<64>, grid, block, 0, ctx->stream, a);
-    else if (max_vars <= 256) hipLaunchKernelGGL(k_trace_func<256>, grid, block, 0, ctx->stream, a);
-    else if (max_vars <= 1024) hipLaunchKernelGGL(k_trace_func<1024>, grid, block, 0, ctx->stream, a);
-    else hipLaunchKernelGGL(k_trace_func<4096>, grid, block, 0, ctx->stream, a);
+    const size_t lds = staged ? tile_words * 4 : 0;
+#define LH_TRACE_LAUNCH(CAP)                                                                             \
+    do {                                                                                                 \
+        if (staged) hipLaunchKernelGGL((k_trace_func<CAP, true>), grid, block, lds, ctx->stream, a);     \
+        else hipLaunchKernelGGL((k_trace_func<CAP, false>), grid, block, 0, ctx->stream, a);             \
+    } while (0)
+    if (max_vars <= 64) LH_TRACE_LAUNCH(64);
+    else if (max_vars <= 256) LH_TRACE_LAUNCH(256);
+    else if (max_vars <= 1024) LH_TRACE_LAUNCH(1024);
+    else LH_TRACE_LAUNCH(4096);
+#undef LH_TRACE_LAUNCH
     lurkhip::span_end(ctx, "trace_func");
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
