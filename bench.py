@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra two-shards-in-flight measurement")
     args = ap.parse_args()
 
     import torch
@@ -215,6 +216,57 @@ def main():
     except Exception:
         pass
 
+    # Extra (N = 1 only, never `value`): two shards proved concurrently on two HIP streams of the one GPU, the way a multi-shard
+    # proof keeps the device busy through each shard's latency chains (tree tails, FRI layers, host transcript round trips).
+    two_in_flight = None
+    if world == 1 and not args.no_two_in_flight:
+        try:
+            import threading
+
+            ctx2 = lurk_amd.Context(local_rank)
+            q2 = lair.QueryRecord(top)
+            a2 = se.args_for_rows(n)
+            a2[2] = 1
+            top.execute(top.func_index(se.FUNC), a2, q2)
+            pv2 = q2.expect_public_values()
+            m2 = prover.Machine(ctx2, top, se.FUNC, len(pv2))
+            vk2 = m2.setup()
+            prep2 = m2.prepare_shard(lair.Shard.new(q2))
+
+            def one(mach, cx, prep, vk, pvs):
+                traces = mach.run_prepared(prep)
+                handle, root = mach.commit_shard(traces)
+                ch = prover.Challenger(cx)
+                ch.observe(vk)
+                ch.observe([0])
+                ch.observe(root)
+                ch.observe(pvs)
+                mach.prove_shard(handle, ch, pvs, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
+                mach.free_shard(handle)
+
+            def worker(mach, cx, prep, vk, pvs, k):
+                for _ in range(k):
+                    one(mach, cx, prep, vk, pvs)
+                cx.sync()
+
+            for k in (1, args.steps):  # warm-up pass, then the timed one
+                ths = [threading.Thread(target=worker, args=(machine, ctx, prepared, vk_root, pv, k)),
+                       threading.Thread(target=worker, args=(m2, ctx2, prep2, vk2, pv2, k))]
+                torch.cuda.synchronize()
+                t1 = time.perf_counter()
+                for th in ths:
+                    th.start()
+                for th in ths:
+                    th.join()
+                torch.cuda.synchronize()
+                dt2 = time.perf_counter() - t1
+            two_in_flight = {"shards": 2 * args.steps, "ms_per_shard": dt2 / (2 * args.steps) * 1e3, "eval_steps_per_s": 2 * n * args.steps / dt2,
+                             "note": "two independent shards on two HIP streams of the same GPU; not the headline value"}
+            m2.close()
+            ctx2.close()
+        except Exception as e:
+            two_in_flight = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "Lurk eval-steps proved/sec (fib trace)",
@@ -239,6 +291,7 @@ def main():
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
                 "hbm_resident_input_bytes": int(input_bytes),
                 "host_execute_and_upload_s": t_host,
+                "two_shards_in_flight": two_in_flight,
             },
             "roofline": {
                 "bound": "hbm",
