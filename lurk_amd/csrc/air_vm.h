@@ -29,31 +29,29 @@ __device__ __forceinline__ void run(const uint32_t* __restrict__ prog, const Sou
     const uint32_t n = prog[airp::H_N_INSTR];
     const uint32_t* __restrict__ code = prog + prog[airp::H_CODE_OFF];
     const uint32_t* __restrict__ consts = prog + prog[airp::H_CONST_OFF];
+    // if-chains in order of frequency (registers, the row, constants; then ALU ops and tuple values): with one or two waves
+    // per SIMD every scalar compare-and-branch level of a balanced switch is exposed latency
     auto fetch = [&](uint32_t o) -> uint32_t {
-        const uint32_t idx = o & airp::SRC_MASK;
-        switch (o >> airp::SRC_SHIFT) {
-            case airp::S_REG: return regs[idx * stride];
-            case airp::S_MAIN: return src.main_l[idx];
-            case airp::S_MAIN_NEXT: return src.main_n[idx];
-            case airp::S_PREP: return src.prep_l[idx];
-            case airp::S_PREP_NEXT: return src.prep_n[idx];
-            case airp::S_CONST: return consts[idx];
-            case airp::S_PUBLIC: return src.pub[idx];
-            default: return src.sel[idx];
-        }
+        const uint32_t idx = o & airp::SRC_MASK, ty = o >> airp::SRC_SHIFT;
+        if (ty == airp::S_REG) return regs[idx * stride];
+        if (ty == airp::S_MAIN) return src.main_l[idx];
+        if (ty == airp::S_CONST) return consts[idx];
+        if (ty == airp::S_MAIN_NEXT) return src.main_n[idx];
+        if (ty == airp::S_PUBLIC) return src.pub[idx];
+        if (ty == airp::S_PREP) return src.prep_l[idx];
+        if (ty == airp::S_PREP_NEXT) return src.prep_n[idx];
+        return src.sel[idx];
     };
     auto step = [&](const uint32_t w0, const uint32_t w1) {
         const uint32_t op = w0 & 0xffu, dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
-        switch (op) {
-            case airp::OP_ADD: regs[dst * stride] = bb::add(fetch(a), fetch(b)); break;
-            case airp::OP_SUB: regs[dst * stride] = bb::sub(fetch(a), fetch(b)); break;
-            case airp::OP_MUL: regs[dst * stride] = bb::mul(fetch(a), fetch(b)); break;
-            case airp::OP_ASSERT: sink.assert_zero(fetch(a)); break;
-            case airp::OP_IBEGIN: sink.ibegin(dst, a != 0, b); break;
-            case airp::OP_IVAL: sink.ival(fetch(a)); break;
-            case airp::OP_IEND: sink.iend(fetch(a)); break;
-            default: break;  // OP_NOP padding
-        }
+        if (op == airp::OP_MUL) regs[dst * stride] = bb::mul(fetch(a), fetch(b));
+        else if (op == airp::OP_IVAL) sink.ival(fetch(a));
+        else if (op == airp::OP_SUB) regs[dst * stride] = bb::sub(fetch(a), fetch(b));
+        else if (op == airp::OP_ADD) regs[dst * stride] = bb::add(fetch(a), fetch(b));
+        else if (op == airp::OP_IBEGIN) sink.ibegin(dst, a != 0, b);
+        else if (op == airp::OP_IEND) sink.iend(fetch(a));
+        else if (op == airp::OP_ASSERT) sink.assert_zero(fetch(a));
+        // else OP_NOP padding
     };
     // the program is padded to a multiple of four instructions: eight words (one s_load_dwordx8) per fetch, so the
     // scalar-load latency is paid once per four instructions instead of once per instruction

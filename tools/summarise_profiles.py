@@ -65,5 +65,5 @@ json.dump({"log_rows": 20, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE
 shutil.copy(f"gpurun_out/prof_{tag}/bench_kernel_stats.csv", "profiles/r01_full_prove_kernel_stats.csv")
 shutil.copy(f"gpurun_out/bench_{tag}.json", "profiles/r01_bench_full_prove.json")
 with open("profiles/r01_full_prove_under_rocprof.log", "w") as f:
-    f.write("".join(l for l in open(f"gpurun_out/prof_{tag}_bench.log") if l.startswith("{") or "rocprofv3" in l)[:6000])
+    f.write("".join(l for l in open(f"gpurun_out/prof_{tag}/bench.log") if l.startswith("{") or "rocprofv3" in l)[:6000])
 print("merkle hash: traffic", 2 * F + W, "B/step; VALU", round(hv, 2), "Tinstr/s")
