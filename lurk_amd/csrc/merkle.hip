@@ -15,7 +15,7 @@
 // One row (or one tree node) per lane; the 16-lane sponge state stays in VGPRs; the concatenated
 // row is described by a uniform LeafCol table read through the scalar cache, so the absorb loop
 // indexes the state with compile-time lane numbers (no scratch).  VALU-bound: ceil(w/8)
-// permutations (~9.2 k int32 instructions each) per w*4 bytes read.
+// permutations (~5.0 k int32 instructions each) per w*4 bytes read.
 #include "commit.h"
 #include "poseidon2_dev.h"
 
@@ -94,7 +94,7 @@ __global__ __launch_bounds__(MBLOCK) void k_level(const P16Params* __restrict__ 
 
 // ---- lane-cooperative permutation: 16 lanes hold one width-16 state (lane j = element j).
 // The tail of a tree is a latency chain (one permutation per level with nothing else to run): spreading a
-// permutation over 16 lanes cuts its dependent-instruction count from ~7.2 k to ~1 k.  Data moves with DPP inside
+// permutation over 16 lanes cuts its dependent-instruction count from ~5 k to ~1 k.  Data moves with DPP inside
 // the 16-lane rows of the wave (quad permutes for M4, row rotations for the column / full sums).
 template <int CTRL>
 __device__ __forceinline__ uint32_t dpp(uint32_t x) {
