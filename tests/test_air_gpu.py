@@ -157,6 +157,34 @@ def test_permutation_trace_matches_oracle_and_sums_to_zero(ctx):
         assert total == os_.ZERO
 
 
+def test_permutation_trace_on_extreme_rows(ctx):
+    """The LogUp sums are accumulated in 64-bit lanes with deferred reduction (lazy_ef.h): rows filled with p - 1, with uniform
+    field elements and with zeros, under challenges whose coefficients sit at the edges of the centred range, must still match
+    the oracle's canonical arithmetic bit for bit."""
+    import torch
+
+    from oracle import stark as os_
+
+    half = (P - 1) // 2
+    challenges = [((half, half + 1, P - 1, 1), (half + 1, half, P - 1, half)), ((11, 22, 33, 44), (5, 6, 7, 2013265920))]
+    top, otop = lair.Toplevel(se.SOURCE), ol.Toplevel(se.SOURCE)
+    for name in ("synth_eval", "aux"):
+        a, oair_ = air.ChipAir.for_func(top, top.func_index(name)), oa.FuncAir(otop, name)
+        h = 64
+        fills = [np.full((h, a.width), P - 1, dtype=np.uint32), synth.field_elements((h, a.width), seed=77), np.zeros((h, a.width), dtype=np.uint32)]
+        for rows in fills:
+            t = torch.from_numpy(field.to_monty(rows).view(np.int32)).cuda()
+            for alpha, beta in challenges:
+                out = torch.zeros((h, 4 * a.permutation_width), dtype=torch.int32, device="cuda")
+                try:
+                    want = os_.permutation_trace(oair_, rows.tolist(), None, alpha, beta, 1 << a.log_quotient_degree, public=[0] * 64)
+                except ZeroDivisionError:
+                    continue  # a denominator vanished on this synthetic row: nothing to compare
+                a.permutation_trace(ctx, h, t, None, alpha + beta, out)
+                got = field.from_monty(out.cpu().numpy().view(np.uint32)).reshape(h, a.permutation_width, 4)
+                assert got.tolist() == [[list(c) for c in r] for r in want], (name, alpha)
+
+
 def test_large_permutation_trace_cumulative_sums_cancel(ctx):
     """2^16 rows of the bench function + its callee + the memory tables: scan over many chunks."""
     import torch

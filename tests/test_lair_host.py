@@ -106,3 +106,33 @@ def test_errors_are_reported_not_thrown():
     with pytest.raises(lair.LairError) as e:
         loop.execute_by_name("f", [1], lair.QueryRecord(loop))
     assert "Loop detected" in e.value.message  # execute.rs:505-507
+
+
+def test_air_programs_are_cut_into_interaction_pieces():
+    """Host lowering (no GPU): the interaction program of a chip is also emitted as independent pieces at batch boundaries
+    (one wave per piece in the prover kernels).  The pieces together hold every interaction, recompute at most a few common
+    subexpressions, and small chips stay in one piece."""
+    import numpy as np
+
+    from lurk_amd import _native as N
+    from lurk_amd import air
+    from lurk_amd.context import _addr
+    from lurk_amd.programs import synth_eval as se
+
+    top = lair.Toplevel(se.SOURCE)
+
+    def info(a):
+        v = np.zeros(16, dtype=np.uint32)
+        N.check(N.lib.lurkhip_air_info(a.handle, _addr(v)))
+        return [int(x) for x in v]
+
+    big = air.ChipAir.for_func(top, top.func_index(se.FUNC))
+    i = info(big)
+    n_inter = big.num_sends + big.num_receives
+    assert n_inter == 46 and big.permutation_width == 24
+    assert i[14] == 4  # a dozen interactions per piece
+    assert i[13] <= i[15] <= i[13] * 1.1  # instructions over the pieces vs the whole program
+    small = air.ChipAir.for_mem(4)
+    assert info(small)[14] == 1
+    none = air.ChipAir.for_poseidon2(16)  # no lookups at all: one empty piece
+    assert none.num_sends + none.num_receives == 0 and info(none)[14] == 1
