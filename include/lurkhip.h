@@ -294,7 +294,8 @@ const char* lurkhip_air_name(const lurkhip_air* air);
 /* info[16]: 0 width, 1 preprocessed width, 2 #constraints, 3 #sends, 4 #receives, 5 max constraint degree,
  * 6 log_quotient_degree, 7 permutation-trace width in extension-field columns, 8 words per row of the interaction
  * dump (sum of 1 + tuple length), 9 #public values, 10/11 registers / instructions of the constraint program,
- * 12/13 of the interaction program */
+ * 12/13 of the interaction program, 14 number of pieces the interaction program is cut into for the prover kernels (one
+ * wave per piece), 15 instructions summed over the pieces */
 int32_t lurkhip_air_info(const lurkhip_air* air, uint32_t* info);
 /* tuple length of each interaction, sends first then receives; returns their number */
 int32_t lurkhip_air_interaction_sizes(const lurkhip_air* air, uint32_t* sizes, uint32_t cap);

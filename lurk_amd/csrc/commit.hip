@@ -106,16 +106,31 @@ namespace {
 // Build (on device) the uniform column table for the matrices in `idx`
 int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int>& idx, LeafCol** out_dev,
                   uint32_t* total_w) {
-    c->host_cols.emplace_back();
-    std::vector<LeafCol>& cols = c->host_cols.back();  // lives as long as the commitment
+    std::vector<std::pair<const void*, uint32_t>> key;
+    uint32_t n_cols = 0;
+    for (int m : idx) {
+        key.emplace_back(c->lde[m], c->width[m]);
+        n_cols += c->width[m];
+    }
+    *total_w = n_cols;
+    auto it = ctx->leafcol_tables.find(key);
+    if (it != ctx->leafcol_tables.end()) {
+        *out_dev = (LeafCol*)it->second;
+        return LURKHIP_OK;
+    }
+    std::vector<LeafCol> cols;
     for (int m : idx)
         for (uint32_t k = 0; k < c->width[m]; k++) cols.push_back(LeafCol{c->lde[m], c->width[m], k});
-    *total_w = (uint32_t)cols.size();
+    if (ctx->leafcol_tables.size() >= 1024) {  // bound the cache: tables of past shapes are dropped wholesale
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second);
+        ctx->leafcol_tables.clear();
+    }
     void* d = nullptr;
-    LH_TRY(pool_alloc(ctx, std::max<size_t>(cols.size(), 1) * sizeof(LeafCol), &d));
-    c->owned.push_back(d);
-    if (!cols.empty())
-        LH_HIP(ctx, hipMemcpyAsync(d, cols.data(), cols.size() * sizeof(LeafCol), hipMemcpyHostToDevice, ctx->stream));
+    LH_HIP(ctx, hipMalloc(&d, std::max<size_t>(cols.size(), 1) * sizeof(LeafCol)));
+    // synchronous copy: a miss happens once per distinct set of buffers
+    if (!cols.empty()) LH_HIP(ctx, hipMemcpy(d, cols.data(), cols.size() * sizeof(LeafCol), hipMemcpyHostToDevice));
+    ctx->leafcol_tables.emplace(std::move(key), d);
     *out_dev = (LeafCol*)d;
     return LURKHIP_OK;
 }

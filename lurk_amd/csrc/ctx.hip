@@ -53,6 +53,7 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
         // give cached blocks back to the driver and retry once
         (void)hipStreamSynchronize(ctx->stream);
         for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
+    for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
         ctx->pool_free.clear();
         e = hipMalloc(out, bytes);
