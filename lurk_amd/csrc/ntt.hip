@@ -27,6 +27,10 @@
 #include "commit.h"
 #include "ctx.h"
 
+#ifndef LURK_NTT_WAVES
+#define LURK_NTT_WAVES 5
+#endif
+
 namespace lurkhip {
 
 namespace {
@@ -128,12 +132,17 @@ __device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t*
 // stage groups of a pass, top stage first: radix 8 while at least three stages remain (four are split 2 + 2)
 // During the stages a column belongs to one wave (all its row slots are lanes of that wave), and a wave's LDS operations
 // execute in order: between stage groups only the compiler has to be kept from reordering them -- no workgroup barrier.
-template <int LOG_R, int S_TOP, int SLOTS, class T>
-__device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, bool active) {
-    if constexpr (S_TOP >= 0) {
+// `after_first` runs once, after the first group -- the radix-8 one, which needs the most registers: the prefetch of the next
+// tile is issued there, so its staging registers are not live while sixteen data registers and seven twiddles are.
+template <int LOG_R, int S_TOP, int SLOTS, class T, class F>
+__device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* __restrict__ tw_l, int slot, bool active, F&& after_first) {
+    if constexpr (S_TOP < 0) {
+        if constexpr (LOG_R == 0) after_first();
+    } else {
         constexpr int REM = S_TOP + 1;
         constexpr int G = REM == 4 ? 2 : (REM >= 3 ? 3 : REM);
         if (active) stage_group<LOG_R, S_TOP, G, SLOTS, T>(col, tw_l, slot);
+        if constexpr (S_TOP == LOG_R - 1) after_first();
         if constexpr (SLOTS <= 64) {
             __builtin_amdgcn_fence(__ATOMIC_RELEASE, "wavefront");
             __builtin_amdgcn_wave_barrier();
@@ -141,7 +150,7 @@ __device__ __forceinline__ void run_stages(T* __restrict__ col, const uint32_t* 
         } else {
             __syncthreads();
         }
-        run_stages<LOG_R, S_TOP - G, SLOTS, T>(col, tw_l, slot, active);
+        run_stages<LOG_R, S_TOP - G, SLOTS, T>(col, tw_l, slot, active, after_first);
     }
 }
 
@@ -163,7 +172,7 @@ __device__ __forceinline__ uint2 scale_elem(uint2 v, uint32_t s) { return make_u
 // BIG: matrices of 4 GiB and more take 64-bit byte offsets; the others address rows as base (SGPR pair) + 32-bit offset.
 // SCALE: a per-row multiplier (the coset shift powers) is applied on load.
 template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) void k_ntt_pass(PassArgs a) {
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_WAVES, 8))) void k_ntt_pass(PassArgs a) {
     using boff_t = typename std::conditional<BIG, size_t, uint32_t>::type;
     constexpr int R = 1 << LOG_R;
     constexpr int RP = R + 1;
@@ -266,10 +275,11 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(5, 8))) vo
         const uint32_t cur_row0 = row0;
         const int cur_col = col;
         __syncthreads();
-        // the next tile's rows fly while this one's stages run (the last iteration re-reads its own tile: no branch)
-        locate(it + 1 < my_tiles ? it + 1 : it, row0, col, lo);
-        fetch(row0, col, lo);
-        run_stages<LOG_R, LOG_R - 1, SLOTS, T>(st_col, tw_lds + (st_l << LOG_R), st_slot, st_active);
+        // the next tile's rows fly while this one's remaining stages run (the last iteration re-reads its own tile: no branch)
+        run_stages<LOG_R, LOG_R - 1, SLOTS, T>(st_col, tw_lds + (st_l << LOG_R), st_slot, st_active, [&]() {
+            locate(it + 1 < my_tiles ? it + 1 : it, row0, col, lo);
+            fetch(row0, col, lo);
+        });
         __syncthreads();  // the stages ran under the column-per-wave map, the write-back uses the row-contiguous one
         if (active) {
             constexpr int UB = U < 4 ? U : 4;  // rows per batch of the write-back (LDS reads first, then their global stores)
