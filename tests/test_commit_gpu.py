@@ -66,6 +66,28 @@ def test_commit_mixed_heights(ctx, oracle):
     c.close()
 
 
+def test_commit_buffer_reuse_across_shapes(ctx, oracle):
+    """The pooled allocator hands a released LDE buffer to the next commit of the same byte size, and the context caches the
+    Merkle leaf-column tables and the coset-shift power tables by (pointer, width) / (height, shift): commits of different
+    shapes that land in the same buffers, and repeats of one shape, must each give the oracle's root."""
+    shapes = [(10, 8), (9, 16), (8, 32), (10, 8), (9, 16), (11, 4), (10, 8)]  # all 2^13 words: one pool bucket
+    for i, (k, w) in enumerate(shapes):
+        x = synth.field_elements((1 << k, w), seed=900 + i)
+        c = cm.commit(ctx, [x], log_blowup=1)
+        lde = oracle.lde(x, 1)
+        root, _ = oracle.merkle_commit([lde])
+        assert np.array_equal(c.root, root), (i, k, w)
+        assert np.array_equal(c.lde_host(0), lde)
+        c.close()
+    # two live commitments of the same shape at once: distinct buffers, distinct tables
+    xs = [synth.field_elements((1 << 9, 16), seed=950 + i) for i in range(2)]
+    cs = [cm.commit(ctx, [x], log_blowup=1) for x in xs]
+    for x, c in zip(xs, cs):
+        root, _ = oracle.merkle_commit([oracle.lde(x, 1)])
+        assert np.array_equal(c.root, root)
+        c.close()
+
+
 def test_commit_height_one_and_two(ctx, oracle):
     for k in (0, 1):
         x = synth.field_elements((1 << k, 44), seed=70 + k)
