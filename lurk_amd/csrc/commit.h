@@ -23,7 +23,6 @@ struct lurkhip_commitment {
     std::vector<size_t> level_off;    // in digests (units of 8 words)
     int log_max = 0;
     std::vector<void*> owned;         // extra device allocations (column tables)
-    std::vector<std::vector<lurkhip::LeafCol>> host_cols;  // staging kept alive for the async copies
 };
 
 namespace lurkhip {

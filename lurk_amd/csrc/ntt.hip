@@ -18,8 +18,6 @@
 //
 // HBM traffic (algorithmic): iNTT 3 passes r+w over N*w*4 B, forward 2^b * 3 passes
 // r+w over N*w*4 B.
-#include <stdlib.h>
-
 #include <type_traits>
 #include <vector>
 
@@ -466,9 +464,8 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
             const size_t tiles = ((size_t)1 << (log_n - log_r - log_l)) * a.n_chunks;
             LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
             LH_ARG(ctx, ((size_t)1 << (log_r + log_l)) <= (size_t)4 * threads, "NTT twiddle staging");
-            static const bool xcd_order = !getenv("LURKHIP_NTT_NO_XCD");
             a.n_tiles = (uint32_t)tiles;
-            a.xcd_run = (xcd_order && tiles % 8 == 0 && tiles >= 64) ? (uint32_t)(tiles / 8) : 0u;
+            a.xcd_run = (tiles % 8 == 0 && tiles >= 64) ? (uint32_t)(tiles / 8) : 0u;
             // persistent workgroups: as many per CU as its registers (5 waves per SIMD at <= 96 VGPRs) and LDS hold, all
             // resident at once; a multiple of 8 so that every XCD gets the same number
             const size_t lds = lds_bytes(log_r, a.col_chunk, log_l);
