@@ -36,25 +36,56 @@ __device__ __forceinline__ uint32_t brev_bits(uint32_t x, int bits) { return bit
 // mode 0: u[s] = w^i / (z - g w^i)      (barycentric weights on the low coset, p3 interpolate_coset)
 // mode 1: d[s] = 1 / (g w^i - z)        (p3 compute_inverse_denominators)
 // with i = bitrev(s) over log_m bits, w = w_M.
-// centred: store the coefficients as signed representatives in (-p/2, p/2] (operands of the lazy accumulators)
-__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, uint32_t w_m, ef z, uint32_t* __restrict__ out, int centred) {
-    const uint32_t s = blockIdx.x * blockDim.x + threadIdx.x;
-    if (s >= (1u << log_m)) return;
-    const uint32_t i = brev_bits(s, log_m);
-    const uint32_t wi = bb::pow(w_m, i);
-    const uint32_t x = bb::mul(g_m, wi);
-    ef r;
-    if (mode == 0) {
-        ef diff = z;
-        diff.c[0] = bb::sub(diff.c[0], x);
-        r = bb::ef_scale(bb::ef_inv(diff), wi);
-    } else {
-        ef diff{{bb::sub(x, z.c[0]), bb::neg(z.c[1]), bb::neg(z.c[2]), bb::neg(z.c[3])}};
-        r = bb::ef_inv(diff);
+// centred: store the coefficients as signed representatives in (-p/2, p/2] (operands of the lazy accumulators).
+// tw[i] = w^i for i < M/2 is the NTT plan's twiddle table (w^(M/2) = -1), so no power ladder; a thread takes four
+// consecutive rows and inverts their four extension elements with ONE base-field inversion: 1 / a = conj(a) / N(a) with the
+// norm N(a) = a * a' * (a a')'' in the base field (two conjugations), and the four norms are inverted together
+// (Montgomery's trick: 9 products + 1 Fermat ladder instead of 4 ladders).
+constexpr int PW_BATCH = 4;
+__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, const uint32_t* __restrict__ tw, ef z, uint32_t* __restrict__ out,
+                                int centred) {
+    const uint32_t m = 1u << log_m, half = m >> 1;
+    const uint32_t s0 = (blockIdx.x * blockDim.x + threadIdx.x) * PW_BATCH;
+    if (s0 >= m) return;
+    ef c[PW_BATCH];       // conj-product a' * (a a')'' of each element: inverse = c / norm
+    uint32_t nrm[PW_BATCH], wi[PW_BATCH];
+#pragma unroll
+    for (int k = 0; k < PW_BATCH; k++) {
+        const uint32_t s = s0 + k < m ? s0 + k : m - 1;  // m < PW_BATCH: the tail lanes repeat the last row
+        const uint32_t i = brev_bits(s, log_m);
+        wi[k] = half == 0 ? bb::R1 : (i < half ? tw[i] : bb::neg(tw[i - half]));
+        const uint32_t x = bb::mul(g_m, wi[k]);
+        ef a;
+        if (mode == 0) {
+            a = z;
+            a.c[0] = bb::sub(a.c[0], x);
+        } else {
+            a = ef{{bb::sub(x, z.c[0]), bb::neg(z.c[1]), bb::neg(z.c[2]), bb::neg(z.c[3])}};
+        }
+        const ef a1{{a.c[0], bb::neg(a.c[1]), a.c[2], bb::neg(a.c[3])}};
+        const ef b = bb::ef_mul(a, a1);  // in span{1, x^2}
+        const ef b1{{b.c[0], 0, bb::neg(b.c[2]), 0}};
+        nrm[k] = bb::sub(bb::sqr(b.c[0]), bb::mul(bb::EXT_W_M, bb::sqr(b.c[2])));  // b * b1 = b0^2 - 11 b2^2
+        c[k] = bb::ef_mul(a1, b1);
     }
-    if (centred)
-        for (int c = 0; c < 4; c++) r.c[c] = r.c[c] > bb::P / 2 ? r.c[c] - bb::P : r.c[c];
-    ef_store(out + 4 * (size_t)s, r);
+    // batch inversion; a zero norm (z on the domain: cannot happen for a sampled challenge) inverts to zero like bb::inv
+    uint32_t pre[PW_BATCH];
+    uint32_t acc = bb::R1;
+#pragma unroll
+    for (int k = 0; k < PW_BATCH; k++) {
+        pre[k] = acc;
+        acc = bb::mul(acc, nrm[k] ? nrm[k] : bb::R1);
+    }
+    uint32_t inv = bb::inv(acc);
+#pragma unroll
+    for (int k = PW_BATCH - 1; k >= 0; k--) {
+        const uint32_t ninv = nrm[k] ? bb::mul(inv, pre[k]) : 0u;
+        inv = bb::mul(inv, nrm[k] ? nrm[k] : bb::R1);
+        ef r = bb::ef_scale(c[k], mode == 0 ? bb::mul(ninv, wi[k]) : ninv);
+        if (centred)
+            for (int j = 0; j < 4; j++) r.c[j] = r.c[j] > bb::P / 2 ? r.c[j] - bb::P : r.c[j];
+        if (s0 + k < m) ef_store(out + 4 * (size_t)(s0 + k), r);
+    }
 }
 
 // ---------------------------------------------------------------- column-wise dot products with EF weights
@@ -336,10 +367,12 @@ __global__ __launch_bounds__(256) void k_gather_openings(const GatherMat* __rest
 }  // namespace
 
 int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev) {
-    const uint32_t m = 1u << log_m;
+    const uint32_t m = 1u << log_m, threads = (m + PW_BATCH - 1) / PW_BATCH;
+    const NttPlan* plan = nullptr;
+    LH_TRY(get_ntt_plan(ctx, log_m, &plan));
     // the barycentric weights (mode 0) only feed k_column_dot's lazy accumulators: centred
-    hipLaunchKernelGGL(k_point_weights, dim3((m + 255) / 256), dim3(256), 0, ctx->stream, mode, log_m, bb::to_monty(bb::GEN),
-                       two_adic_generator_monty(log_m), z, out_dev, mode == 0 ? 1 : 0);
+    hipLaunchKernelGGL(k_point_weights, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, mode, log_m, bb::to_monty(bb::GEN),
+                       (const uint32_t*)plan->tw_fwd, z, out_dev, mode == 0 ? 1 : 0);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
