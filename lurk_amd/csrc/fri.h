@@ -21,7 +21,17 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
                         const uint32_t* alpha_pows_centred /* 8 words per power (ef_powers centred), or null */, const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,
                         const bb::ef& apow1, uint32_t* ro);
 // p3 fold_even_odd on 2^log_len bit-reversed evaluations (+ add[j] when given); out has 2^(log_len-1) elements
-int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const bb::ef& beta, const uint32_t* add, uint32_t* out);
+int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint32_t* beta_dev /* 4 words, device */, const uint32_t* add,
+                 uint32_t* out);
+// Transcript state as the device keeps it during the FRI commit phase (challenger.h: Challenger, same semantics)
+struct DevChallenger {
+    uint32_t state[16];
+    uint32_t input[8];
+    uint32_t output[8];
+    uint32_t n_in, n_out;
+};
+// observes the 8-word digest at root_dev and samples one extension element into beta_dev, all on the context's stream
+int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev);
 // smallest canonical witness w such that a challenger whose permutation input is `state` (pending inputs already
 // written over lanes [0, n_pending)) samples `bits` zero bits after observing w
 int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, uint32_t* witness);

@@ -16,6 +16,7 @@
 #include "ctx.h"
 #include "fri.h"
 #include "lazy_ef.h"
+#include "p16_coop.h"
 #include "poseidon2_dev.h"
 
 namespace lurkhip {
@@ -304,17 +305,63 @@ __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
 // ---------------------------------------------------------------- FRI fold (p3 fold_even_odd)
 // out[j] = (1/2 + beta/2 * ginv^bitrev(j)) e[2j] + (1/2 - beta/2 * ginv^bitrev(j)) e[2j+1]  (+ add[j]),
 // ginv = (generator of the size-len subgroup)^-1; len = 2^log_len
-__global__ __launch_bounds__(256) void k_fri_fold(const uint32_t* __restrict__ cur, int log_len, ef half_beta, uint32_t ginv_m,
-                                                   uint32_t half_m, const uint32_t* __restrict__ add, uint32_t* __restrict__ out) {
+__global__ __launch_bounds__(256) void k_fri_fold(const uint32_t* __restrict__ cur, int log_len, const uint32_t* __restrict__ beta_dev,
+                                                   uint32_t ginv_m, uint32_t half_m, const uint32_t* __restrict__ add,
+                                                   uint32_t* __restrict__ out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
     const uint32_t half_len = 1u << (log_len - 1);
     if (j >= half_len) return;
+    // the layer's challenge was sampled on the device (k_fri_challenge): beta / 2
+    const ef half_beta = bb::ef_scale(ef{{beta_dev[0], beta_dev[1], beta_dev[2], beta_dev[3]}}, half_m);
     const ef power = bb::ef_scale(half_beta, bb::pow(ginv_m, brev_bits(j, log_len - 1)));
     const ef e0 = ef_load(cur + 8 * (size_t)j), e1 = ef_load(cur + 8 * (size_t)j + 4);
     ef r = bb::ef_add(bb::ef_mul(bb::ef_add_base(power, half_m), e0),
                       bb::ef_mul(bb::ef_add_base(bb::ef_sub(bb::ef_zero(), power), half_m), e1));
     if (add) r = bb::ef_add(r, ef_load(add + 4 * (size_t)j));
     ef_store(out + 4 * (size_t)j, r);
+}
+
+// ---------------------------------------------------------------- device side of the transcript (FRI commit phase)
+// p3's DuplexChallenger (challenger.h) on the device for the one stretch of the proof where the transcript sits on the
+// critical path of a latency chain: per FRI layer "observe the layer root, sample beta".  One wave; the width-16 state is held
+// by 16 lanes and permuted cooperatively (p16_coop.h).  The host uploads its transcript state before the first layer and
+// reads it back after the last one, so the 21 root read-backs and host permutations of a proof leave the chain.
+__global__ __launch_bounds__(64) void k_fri_challenge(const P16Params* __restrict__ p, DevChallenger* __restrict__ ch,
+                                                      const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out) {
+    __shared__ DevChallenger c;
+    const int lane = threadIdx.x, j = lane & 15;
+    if (lane == 0) c = *ch;
+    __syncthreads();
+    auto duplex = [&]() {
+        uint32_t x = (uint32_t)j < c.n_in ? c.input[j & 7] : c.state[j];
+        x = coop_perm16(x, p, j);
+        __syncthreads();
+        if (lane < 16) c.state[lane] = x;
+        if (lane < 8) c.output[lane] = x;
+        if (lane == 0) {
+            c.n_in = 0;
+            c.n_out = 8;
+        }
+        __syncthreads();
+    };
+    for (int i = 0; i < 8; i++) {  // observe the digest, one lane value at a time
+        if (lane == 0) {
+            c.n_out = 0;
+            c.input[c.n_in] = root[i];
+            c.n_in += 1;
+        }
+        __syncthreads();
+        if (c.n_in == 8) duplex();
+    }
+    for (int i = 0; i < 4; i++) {  // sample an extension element: pops from the end of the output buffer
+        if (c.n_in != 0 || c.n_out == 0) duplex();
+        if (lane == 0) {
+            c.n_out -= 1;
+            beta_out[i] = c.output[c.n_out];
+        }
+        __syncthreads();
+    }
+    if (lane == 0) *ch = c;
 }
 
 // ---------------------------------------------------------------- proof of work (DuplexChallenger::grind)
@@ -422,12 +469,19 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
     return LURKHIP_OK;
 }
 
-int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const bb::ef& beta, const uint32_t* add, uint32_t* out) {
+int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint32_t* beta_dev, const uint32_t* add, uint32_t* out) {
     const uint32_t half_m = bb::pow(bb::to_monty(2), bb::P - 2);
-    const bb::ef half_beta = bb::ef_scale(beta, half_m);
     const uint32_t ginv = bb::pow(two_adic_generator_monty(log_len), bb::P - 2);
     const uint32_t half_len = 1u << (log_len - 1);
-    hipLaunchKernelGGL(k_fri_fold, dim3((half_len + 255) / 256), dim3(256), 0, ctx->stream, cur, log_len, half_beta, ginv, half_m, add, out);
+    hipLaunchKernelGGL(k_fri_fold, dim3((half_len + 255) / 256), dim3(256), 0, ctx->stream, cur, log_len, beta_dev, ginv, half_m, add, out);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev) {
+    const P16Params* params = nullptr;
+    LH_TRY(get_merkle_params(ctx, &params));
+    hipLaunchKernelGGL(k_fri_challenge, dim3(1), dim3(64), 0, ctx->stream, params, ch_dev, root_dev, beta_dev);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

@@ -494,24 +494,45 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     std::vector<lurkhip_commitment*> layers;
     std::vector<uint32_t> layer_roots_m;
     uint32_t* current = ro[log_max];
-    for (int log_folded = log_max - 1; log_folded >= log_blowup; log_folded--) {
+    // The transcript moves to the device for this phase (fri.hip: k_fri_challenge): per layer "commit, observe the root,
+    // sample beta, fold" is a chain of launches with no host round trip; the state comes back with the final polynomial.
+    const int n_layers = log_max > log_blowup ? log_max - log_blowup : 0;
+    DevChallenger hc{};
+    memcpy(hc.state, ch.state, sizeof hc.state);
+    hc.n_in = (uint32_t)ch.input.size();
+    hc.n_out = (uint32_t)ch.output.size();
+    for (size_t i = 0; i < ch.input.size(); i++) hc.input[i] = ch.input[i];
+    for (size_t i = 0; i < ch.output.size(); i++) hc.output[i] = ch.output[i];
+    DevChallenger* ch_dev = nullptr;
+    uint32_t* betas_dev = nullptr;
+    PTRY(palloc(sizeof(DevChallenger), (uint32_t**)&ch_dev));
+    PTRY(palloc((size_t)std::max(n_layers, 1) * 16, &betas_dev));
+    PHIP(hipMemcpyAsync(ch_dev, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
+    PHIP(hipStreamSynchronize(ctx->stream));  // hc is a stack object
+    for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
         lurkhip_commitment* lc = nullptr;
         PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
         to_free.push_back(lc);
         layers.push_back(lc);
-        uint32_t root_m[8];
-        PTRY(commitment_root_m(ctx, lc, root_m));
-        layer_roots_m.insert(layer_roots_m.end(), root_m, root_m + 8);
-        ch.observe_digest_m(root_m);
-        const ef beta = ch.sample_ef_m();
+        const uint32_t* root_dev = lc->digests + lc->level_off[lc->log_max] * 8;
+        PTRY(fri_challenge(ctx, ch_dev, root_dev, betas_dev + 4 * li));
         uint32_t* next = nullptr;
         PTRY(palloc(((size_t)16) << log_folded, &next));
-        PTRY(fri_fold(ctx, current, log_folded + 1, beta, ro[log_folded], next));
+        PTRY(fri_fold(ctx, current, log_folded + 1, betas_dev + 4 * li, ro[log_folded], next));
         current = next;
     }
     std::vector<uint32_t> fin((size_t)4 << log_blowup);
+    layer_roots_m.resize((size_t)layers.size() * 8);
+    for (size_t li = 0; li < layers.size(); li++) {
+        const lurkhip_commitment* lc = layers[li];
+        PHIP(hipMemcpyAsync(&layer_roots_m[8 * li], lc->digests + lc->level_off[lc->log_max] * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    }
+    PHIP(hipMemcpyAsync(&hc, ch_dev, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
     PHIP(hipMemcpyAsync(fin.data(), current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHIP(hipStreamSynchronize(ctx->stream));
+    memcpy(ch.state, hc.state, sizeof hc.state);
+    ch.input.assign(hc.input, hc.input + hc.n_in);
+    ch.output.assign(hc.output, hc.output + hc.n_out);
     for (size_t i = 4; i < fin.size(); i++)
         if (fin[i] != fin[i & 3]) {
             cleanup();
