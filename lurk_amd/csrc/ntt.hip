@@ -18,6 +18,8 @@
 //
 // HBM traffic (algorithmic): iNTT 3 passes r+w over N*w*4 B, forward 2^b * 3 passes
 // r+w over N*w*4 B.
+#include <stdlib.h>
+
 #include <type_traits>
 #include <vector>
 
@@ -472,7 +474,8 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
             const int per_cu = std::max(1, std::min(20 / (threads / 64), (int)((160 * 1024) / (lds + 256))));
             size_t blocks = std::min<size_t>(tiles, (size_t)per_cu * ctx->num_cus);
             if (a.xcd_run) blocks = blocks / 8 * 8;
-            const bool big = (((size_t)w) << (log_n + 2)) >= ((size_t)1 << 32);
+            // matrices of 4 GiB and more need 64-bit offsets; LURKHIP_NTT_FORCE_64BIT (test hook) takes that path at any size
+            const bool big = (((size_t)w) << (log_n + 2)) >= ((size_t)1 << 32) || getenv("LURKHIP_NTT_FORCE_64BIT") != nullptr;
             if (pair && big) launch_pass<uint2, true>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
             else if (pair) launch_pass<uint2, false>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
             else if (big) launch_pass<uint32_t, true>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);

@@ -28,6 +28,14 @@ def test_lde_tilings_match_oracle(ctx, oracle, log_n, w):
     assert np.array_equal(cm.coset_lde(ctx, x, 1), oracle.lde(x, 1))
 
 
+def test_lde_64bit_offset_kernels(ctx, oracle, monkeypatch):
+    """Matrices of 4 GiB and more run kernel variants with 64-bit row offsets; the test hook forces them at small sizes."""
+    monkeypatch.setenv("LURKHIP_NTT_FORCE_64BIT", "1")
+    for log_n, w in [(12, 78), (14, 9), (10, 113), (15, 96)]:
+        x = synth.field_elements((1 << log_n, w), seed=1200 + log_n + w)
+        assert np.array_equal(cm.coset_lde(ctx, x, 1), oracle.lde(x, 1)), (log_n, w)
+
+
 def test_lde_montgomery_repr(ctx, oracle):
     x = synth.field_elements((256, 10), seed=8)
     got = cm.coset_lde(ctx, field.to_monty(x), 1, repr=lurk_amd.REPR_MONTY)
