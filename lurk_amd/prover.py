@@ -372,3 +372,68 @@ class Machine(_ShardProver):
             proofs.append(self.prove_shard(handle, ch.clone(), pv, num_queries, pow_bits))
             self.free_shard(handle)
         return proofs
+
+
+def prove_pipelined(machines, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS):
+    """`Machine.prove` with the shards dealt round-robin to several machines of the same toplevel, each on its own context
+    (= its own HIP stream) of one GPU, and one host thread per machine: while one shard sits in a latency chain (FRI layers,
+    tree tails, transcript round trips) the other's big kernels keep the device busy (bench.py: +18 % shards per second with
+    two).  The proofs are the ones `Machine.prove` returns, in shard order: the transcript prefix (every shard's main root)
+    is assembled before any shard is proved, exactly as there."""
+    import threading
+
+    for m in machines:
+        if m.pk is None:
+            m.setup()
+    full = Shard.new(queries)
+    shards = full.shard(config) if config is not None else [full]
+    pv = queries.expect_public_values()
+    k = len(machines)
+    committed = [None] * len(shards)
+    errors = []
+
+    def run(target, *args):
+        def wrapped():
+            try:
+                target(*args)
+            except BaseException as e:  # surfaced after the join
+                errors.append(e)
+        return threading.Thread(target=wrapped)
+
+    def commit_lane(j):
+        m = machines[j]
+        for i in range(j, len(shards), k):
+            traces = m.shard_traces(shards[i])
+            committed[i] = m.commit_shard(traces) + (traces,)  # the shard handle points into the trace buffers: keep them
+
+    ths = [run(commit_lane, j) for j in range(k)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errors:
+        raise errors[0]
+    proofs = [None] * len(shards)
+
+    def prove_lane(j):
+        m = machines[j]
+        for i in range(j, len(shards), k):
+            handle = committed[i][0]
+            c = Challenger(m.ctx)
+            c.observe(m.vk_root)
+            c.observe([0])
+            for _, root, _ in committed:
+                c.observe(root)
+                c.observe(pv)
+            proofs[i] = m.prove_shard(handle, c, pv, num_queries, pow_bits)
+            m.free_shard(handle)
+            committed[i] = (None, committed[i][1], None)
+
+    ths = [run(prove_lane, j) for j in range(k)]
+    for t in ths:
+        t.start()
+    for t in ths:
+        t.join()
+    if errors:
+        raise errors[0]
+    return proofs

@@ -6,6 +6,7 @@ import copy
 import numpy as np
 import pytest
 
+import lurk_amd
 from lair_helpers import PARTIAL_SRC, load_cases
 from lurk_amd import lair, prover
 from lurk_amd.programs import synth_eval as se
@@ -115,6 +116,28 @@ def test_sharded_proof_verifies(ctx):
     m, root, proofs, pv = prove(ctx, DEMO, "fib", [20], shard_size=8)
     assert len(proofs) >= 3
     assert verify(DEMO, "fib", root, proofs, len(pv))
+
+
+def test_pipelined_sharded_proof_equals_sequential(ctx):
+    """Two machines on two contexts (two HIP streams) of the one GPU prove the shards of an execution concurrently
+    (prover.prove_pipelined): the proofs are those of Machine.prove, shard by shard, and verify."""
+    top = lair.Toplevel(DEMO)
+    q = lair.QueryRecord(top)
+    top.execute_by_name("fib", [20], q)
+    pv = q.expect_public_values()
+    cfg = lair.ShardingConfig(8)
+    m1 = prover.Machine(ctx, top, "fib", len(pv))
+    root = m1.setup()
+    want = m1.prove(q, cfg, num_queries=4, pow_bits=2)
+    with lurk_amd.Context(0) as ctx2:
+        m2 = prover.Machine(ctx2, top, "fib", len(pv))
+        got = prover.prove_pipelined([m1, m2], q, cfg, num_queries=4, pow_bits=2)
+        m2.close()
+    m1.close()
+    assert len(got) == len(want) >= 3
+    for a, b in zip(got, want):
+        assert np.array_equal(a.words, b.words)
+    assert verify(DEMO, "fib", root, got, len(pv))
 
 
 def test_machine_with_extern_chips_proves_and_verifies(ctx):
