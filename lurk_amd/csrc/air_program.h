@@ -38,7 +38,12 @@ enum Op : uint32_t {
     OP_ASSERT = 4,  // a must vanish on every row
     OP_IBEGIN = 5,  // dst = interaction kind (argument index), a = is_send, b = number of values
     OP_IVAL = 6,    // a = next value of the tuple
-    OP_IEND = 7     // a = multiplicity
+    OP_IEND = 7,    // a = multiplicity
+    // compact interaction pieces (the prover kernels): constant tuple elements are folded into a per-interaction start value
+    // (alpha + kind + sum of beta^t * constant, computed once per proof), so IBEGIN's b is the interaction's index in the
+    // chip's send-then-receive list and every remaining value names its own position t (power of beta)
+    OP_IVALS = 8,   // dst = count, a = first main column, b = t of the first value: `count` consecutive columns, t ascending
+    OP_IVALT = 9    // dst = t, a = the value
 };
 
 enum Src : uint32_t {

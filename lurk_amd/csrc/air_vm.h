@@ -51,6 +51,8 @@ __device__ __forceinline__ void run(const uint32_t* __restrict__ prog, const Sou
         else if (op == airp::OP_IBEGIN) sink.ibegin(dst, a != 0, b);
         else if (op == airp::OP_IEND) sink.iend(fetch(a));
         else if (op == airp::OP_ASSERT) sink.assert_zero(fetch(a));
+        else if (op == airp::OP_IVALS) sink.ival_run(src.main_l + a, b, dst);  // dst consecutive main columns from a, positions b..
+        else if (op == airp::OP_IVALT) sink.ival_at(fetch(a), dst);
         // else OP_NOP padding
     };
     // the program is padded to a multiple of four instructions: eight words (one s_load_dwordx8) per fetch, so the

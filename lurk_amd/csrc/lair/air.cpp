@@ -965,11 +965,13 @@ struct Lowerer {
         code.push_back(a | (b << 16));
     }
 
+    static bool immediate_only(uint32_t op) { return op == airp::OP_IBEGIN || op == airp::OP_IVALS; }
+
     // `steps`: the root uses in program order; each step is (kind, node or immediate)
     struct Step {
         uint32_t op;
-        E node;            // ASSERT / IVAL / IEND operand
-        uint32_t dst = 0, a = 0, b = 0;  // IBEGIN immediates
+        E node;            // ASSERT / IVAL / IVALT / IEND operand
+        uint32_t dst = 0, a = 0, b = 0;  // IBEGIN / IVALS immediates, IVALT position
     };
 
     std::vector<uint32_t> lower(const std::vector<Step>& steps, uint32_t n_asserts, uint32_t n_interactions, uint32_t n_sends) {
@@ -977,7 +979,7 @@ struct Lowerer {
         //    the concatenation over steps of the not-yet-emitted nodes
         std::vector<size_t> step_after(steps.size());  // number of compute nodes emitted before step i
         for (size_t i = 0; i < steps.size(); i++) {
-            if (steps[i].op != airp::OP_IBEGIN) schedule(steps[i].node);
+            if (!immediate_only(steps[i].op)) schedule(steps[i].node);
             step_after[i] = order.size();
         }
         // 2. last use, in a merged timeline: time of compute node k = 2 * ... simpler: walk the final stream
@@ -994,7 +996,7 @@ struct Lowerer {
         for (size_t s = 0; s < stream.size(); s++) {
             if (stream[s].is_step) {
                 const Step& st = steps[stream[s].idx];
-                if (st.op != airp::OP_IBEGIN && !is_leaf(st.node)) last_use[st.node] = (int)s;
+                if (!immediate_only(st.op) && !is_leaf(st.node)) last_use[st.node] = (int)s;
             } else {
                 const Node& n = air.nodes[order[stream[s].idx]];
                 if (!is_leaf(n.a)) last_use[n.a] = (int)s;
@@ -1021,9 +1023,9 @@ struct Lowerer {
         for (size_t s = 0; s < stream.size(); s++) {
             if (stream[s].is_step) {
                 const Step& st = steps[stream[s].idx];
-                if (st.op == airp::OP_IBEGIN) emit(st.op, st.dst, st.a, st.b);
+                if (immediate_only(st.op)) emit(st.op, st.dst, st.a, st.b);
                 else {
-                    emit(st.op, 0, operand_of(st.node), 0);
+                    emit(st.op, st.op == airp::OP_IVALT ? st.dst : 0, operand_of(st.node), 0);
                     release_if_dead(st.node, (int)s);
                 }
             } else {
@@ -1080,7 +1082,7 @@ AirPrograms lower_air(const ChipAir& air) {
     std::vector<const Interaction*> all;
     for (const auto& it : air.sends) all.push_back(&it);
     for (const auto& it : air.receives) all.push_back(&it);
-    auto lower_range = [&](size_t i0, size_t i1, uint32_t first_column) {
+    auto lower_range = [&](size_t i0, size_t i1, uint32_t first_column, bool compact) {
         Lowerer lw(air);
         std::vector<Lowerer::Step> steps;
         uint32_t n_sends = 0;
@@ -1089,9 +1091,39 @@ AirPrograms lower_air(const ChipAir& air) {
             Lowerer::Step s{airp::OP_IBEGIN, 0};
             s.dst = it.kind;
             s.a = it.is_send ? 1 : 0;
-            s.b = (uint32_t)it.values.size();
+            s.b = compact ? (uint32_t)i : (uint32_t)it.values.size();
             steps.push_back(s);
-            for (E v : it.values) steps.push_back({airp::OP_IVAL, v});
+            if (!compact) {
+                for (E v : it.values) steps.push_back({airp::OP_IVAL, v});
+            } else {
+                // constants are folded into the start value; runs of consecutive main columns become one instruction
+                for (size_t k = 0; k < it.values.size();) {
+                    const Node& n = air.nodes[it.values[k]];
+                    if (n.kind == N_CONST) {
+                        k++;
+                        continue;
+                    }
+                    if (n.kind == N_MAIN) {
+                        size_t run = 1;
+                        while (k + run < it.values.size() && run < 255) {
+                            const Node& m = air.nodes[it.values[k + run]];
+                            if (m.kind != N_MAIN || m.a != n.a + run) break;
+                            run++;
+                        }
+                        Lowerer::Step r{airp::OP_IVALS, 0};
+                        r.dst = (uint32_t)run;
+                        r.a = n.a;
+                        r.b = (uint32_t)k + 1;
+                        steps.push_back(r);
+                        k += run;
+                        continue;
+                    }
+                    Lowerer::Step v{airp::OP_IVALT, it.values[k]};
+                    v.dst = (uint32_t)k + 1;
+                    steps.push_back(v);
+                    k++;
+                }
+            }
             steps.push_back({airp::OP_IEND, it.mult});
             if (it.is_send) n_sends++;
         }
@@ -1099,7 +1131,14 @@ AirPrograms lower_air(const ChipAir& air) {
         prog[airp::H_FIRST_COLUMN] = first_column;
         return prog;
     };
-    p.interactions = lower_range(0, all.size(), 0);
+    p.interactions = lower_range(0, all.size(), 0, false);
+    for (size_t i = 0; i < all.size(); i++) {
+        p.interaction_kinds.push_back(all[i]->kind);
+        for (size_t k = 0; k < all[i]->values.size(); k++) {
+            const Node& n = air.nodes[all[i]->values[k]];
+            if (n.kind == N_CONST && n.a != 0) p.const_terms.push_back({(uint32_t)i, (uint32_t)k + 1, n.a});
+        }
+    }
     // pieces of about `per_part` interactions, at most six, each a whole number of batches
     const size_t batch = (size_t)1 << air.log_quotient_degree();
     const size_t n_batches = (all.size() + batch - 1) / batch;
@@ -1108,7 +1147,7 @@ AirPrograms lower_air(const ChipAir& air) {
         n_parts = std::min(n_parts, std::max<size_t>(n_batches, 1));
         for (size_t j = 0; j < n_parts; j++) {
             const size_t b0 = n_batches * j / n_parts, b1 = n_batches * (j + 1) / n_parts;
-            out.push_back(lower_range(std::min(b0 * batch, all.size()), std::min(b1 * batch, all.size()), (uint32_t)b0));
+            out.push_back(lower_range(std::min(b0 * batch, all.size()), std::min(b1 * batch, all.size()), (uint32_t)b0, true));
         }
     };
     cut(12, p.interaction_parts);

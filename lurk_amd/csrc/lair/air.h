@@ -134,6 +134,14 @@ struct AirPrograms {
     // the same, cut coarser, for the quotient kernel (measured: it does best with two dozen interactions per wave, the
     // permutation-trace kernel with one dozen)
     std::vector<std::vector<uint32_t>> interaction_parts_coarse;
+    // The pieces are *compact* (air_program.h: OP_IVALS / OP_IVALT): constant tuple elements are left out of the programs.
+    // const_terms lists them -- (interaction index, position t = 1 + index in the tuple, canonical constant) -- and
+    // interaction_kinds the kind of every interaction, so the prover can build the start values alpha + kind + sum beta^t c.
+    struct ConstTerm {
+        uint32_t interaction, t, value;
+    };
+    std::vector<ConstTerm> const_terms;
+    std::vector<uint32_t> interaction_kinds;
 };
 AirPrograms lower_air(const ChipAir& air);
 

@@ -32,6 +32,7 @@ struct lurkhip_air {
     struct DevPrograms {
         uint32_t* cons = nullptr;
         uint32_t* inter = nullptr;
+        uint32_t* inter_static = nullptr;  // k_interaction_starts: kinds, offsets, constant terms
         std::vector<uint32_t*> parts;         // interaction program pieces (AirPrograms::interaction_parts)
         std::vector<uint32_t*> parts_coarse;  // AirPrograms::interaction_parts_coarse
     };
@@ -43,7 +44,7 @@ struct lurkhip_air {
 namespace lurkhip {
 
 int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons, const uint32_t** inter,
-                         const std::vector<uint32_t*>** parts, bool coarse) {
+                         const std::vector<uint32_t*>** parts, bool coarse, const uint32_t** inter_static) {
     std::lock_guard<std::mutex> g(a->mu);
     auto it = a->dev.find(ctx->device);
     if (it == a->dev.end()) {
@@ -55,6 +56,21 @@ int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons
         };
         LH_TRY(upload(a->prog.constraints, &d.cons));
         LH_TRY(upload(a->prog.interactions, &d.inter));
+        {
+            const auto& pr = a->prog;
+            const uint32_t n = (uint32_t)pr.interaction_kinds.size();
+            std::vector<uint32_t> st{n};
+            st.insert(st.end(), pr.interaction_kinds.begin(), pr.interaction_kinds.end());
+            std::vector<uint32_t> offs(n + 1, 0);
+            for (const auto& t : pr.const_terms) offs[t.interaction + 1]++;
+            for (uint32_t j = 0; j < n; j++) offs[j + 1] += offs[j];
+            st.insert(st.end(), offs.begin(), offs.end());
+            for (const auto& t : pr.const_terms) {  // const_terms are in interaction order
+                st.push_back(t.t);
+                st.push_back(bb::to_monty(t.value % bb::P));
+            }
+            LH_TRY(upload(st, &d.inter_static));
+        }
         for (const auto& part : a->prog.interaction_parts) {
             uint32_t* dp = nullptr;
             LH_TRY(upload(part, &dp));
@@ -68,6 +84,7 @@ int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons
         it = a->dev.emplace(ctx->device, std::move(d)).first;
     }
     if (cons) *cons = it->second.cons;
+    if (inter_static) *inter_static = it->second.inter_static;
     if (inter) *inter = it->second.inter;
     if (parts) *parts = coarse ? &it->second.parts_coarse : &it->second.parts;
     return LURKHIP_OK;
@@ -135,6 +152,8 @@ struct DumpSink {
     __device__ __forceinline__ void assert_zero(uint32_t v) { cons_out[k++] = bb::from_monty(v); }
     __device__ __forceinline__ void ibegin(uint32_t, bool, uint32_t) { t++; /* slot for the multiplicity */ base = t - 1; }
     __device__ __forceinline__ void ival(uint32_t v) { inter_out[t++] = bb::from_monty(v); }
+    __device__ __forceinline__ void ival_at(uint32_t, uint32_t) {}  // compact pieces only (prover kernels)
+    __device__ __forceinline__ void ival_run(const uint32_t*, uint32_t, uint32_t) {}
     __device__ __forceinline__ void iend(uint32_t m) { inter_out[base] = bb::from_monty(m); }
     uint32_t base = 0;
 };
@@ -175,6 +194,8 @@ struct CheckSink {
     }
     __device__ __forceinline__ void ibegin(uint32_t, bool, uint32_t) {}
     __device__ __forceinline__ void ival(uint32_t) {}
+    __device__ __forceinline__ void ival_at(uint32_t, uint32_t) {}
+    __device__ __forceinline__ void ival_run(const uint32_t*, uint32_t, uint32_t) {}
     __device__ __forceinline__ void iend(uint32_t) {}
 };
 
@@ -242,25 +263,33 @@ __global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
 // and the quotient kernel (where entry * den - num is the batch's constraint).
 struct LogupAccum {
     const uint32_t* __restrict__ beta_pows;  // centred, 8 words per power (k_ef_powers)
-    ef alpha;
+    const uint32_t* __restrict__ starts;     // per interaction: alpha + kind + sum of beta^t * (constant tuple elements)
     LazyEf cur64;
     ef cur, num, den;
-    int32_t next_pow[8];  // beta^t, loaded one value ahead: the (scalar) table load overlaps the previous value's arithmetic
-    uint32_t t = 0, in_batch = 0, m_first = 0;
+    uint32_t in_batch = 0, m_first = 0;
     bool is_send = false;
-    __device__ __forceinline__ void begin(uint32_t kind, bool send) {
-        cur64.set(bb::ef_add_base(alpha, bb::to_monty(kind)));  // alpha + beta^0 * argument_index
-        t = 1;
-        load_w8(next_pow, beta_pows + 8);
+    __device__ __forceinline__ void begin(uint32_t interaction, bool send) {
+        cur64.set(ef{{starts[4 * interaction], starts[4 * interaction + 1], starts[4 * interaction + 2], starts[4 * interaction + 3]}});
         is_send = send;
     }
-    __device__ __forceinline__ void value(uint32_t v) {
+    // the tuple element at position t (t = 1 + index in the tuple): += beta^t * v
+    __device__ __forceinline__ void value_at(uint32_t v, uint32_t t) {
         int32_t p[8];
-#pragma unroll
-        for (int c = 0; c < 8; c++) p[c] = next_pow[c];
-        t++;
-        load_w8(next_pow, beta_pows + 8 * t);  // the table has max_tuple + 2 entries: one past the last value is valid
+        load_w8(p, beta_pows + 8 * t);
         cur64.add_base(v, p);
+    }
+    // `count` elements from consecutive words at positions t, t + 1, ...; the (scalar) table load of the next power overlaps
+    // the current element's arithmetic (the table has max_tuple + 2 entries: one past the last position is valid)
+    __device__ __forceinline__ void value_run(const uint32_t* __restrict__ vals, uint32_t t, uint32_t count) {
+        int32_t p[8];
+        load_w8(p, beta_pows + 8 * t);
+        for (uint32_t k = 0; k < count; k++) {
+            int32_t q[8];
+            load_w8(q, beta_pows + 8 * (t + k + 1));
+            cur64.add_base(vals[k], p);
+#pragma unroll
+            for (int c = 0; c < 8; c++) p[c] = q[c];
+        }
     }
     // folds the finished interaction into the batch fraction num / den = sum_i m_i / d_i; returns true when the batch
     // holds `batch` interactions.  Multiplicities are base-field: the first two interactions of a batch cost one
@@ -295,8 +324,10 @@ struct PermSink {
     ef row_sum = bb::ef_zero();
     bool live = true;  // lanes past the last row run along (workgroup barriers) and store nothing
     __device__ __forceinline__ void assert_zero(uint32_t) {}
-    __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
-    __device__ __forceinline__ void ival(uint32_t v) { acc.value(v); }
+    __device__ __forceinline__ void ibegin(uint32_t, bool send, uint32_t interaction) { acc.begin(interaction, send); }
+    __device__ __forceinline__ void ival(uint32_t) {}  // compact pieces carry no plain IVAL
+    __device__ __forceinline__ void ival_at(uint32_t v, uint32_t t) { acc.value_at(v, t); }
+    __device__ __forceinline__ void ival_run(const uint32_t* vals, uint32_t t, uint32_t count) { acc.value_run(vals, t, count); }
     __device__ __forceinline__ void flush() {
         ef v = acc.in_batch == 1 ? bb::ef_scale(bb::ef_inv(acc.den), acc.m_first) : bb::ef_mul(acc.num, bb::ef_inv(acc.den));
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
@@ -309,6 +340,29 @@ struct PermSink {
         if (acc.end(m, batch)) flush();
     }
 };
+
+// Start value of every interaction's denominator: alpha + kind + sum over its constant tuple elements of beta^t * c.
+// stat = [n | kinds[n] | offsets[n + 1] | (t, constant in Montgomery form) pairs], uploaded once per chip; beta_pows is the
+// centred 8-word table.  One thread per interaction, once per proof and chip.
+__global__ void k_interaction_starts(const uint32_t* __restrict__ stat, const uint32_t* __restrict__ beta_pows, ef alpha,
+                                     uint32_t* __restrict__ starts) {
+    const uint32_t n = stat[0], j = blockIdx.x * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t* kinds = stat + 1;
+    const uint32_t* offs = kinds + n;
+    const uint32_t* terms = offs + n + 1;
+    ef s_ = bb::ef_add_base(alpha, bb::to_monty(kinds[j]));
+    for (uint32_t e = offs[j]; e < offs[j + 1]; e++) {
+        const uint32_t t = terms[2 * e], c = terms[2 * e + 1];
+        ef pw;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = beta_pows[8 * t + k];  // centred -> canonical
+            pw.c[k] = (int32_t)x < 0 ? x + bb::P : x;
+        }
+        s_ = bb::ef_add(s_, bb::ef_scale(pw, c));
+    }
+    for (int k = 0; k < 4; k++) starts[4 * j + k] = s_.c[k];
+}
 
 // Program pieces of a launch: one wave of every workgroup per piece, all over the same 64 staged rows.
 constexpr int MAX_VM_PARTS = 8;
@@ -323,7 +377,7 @@ struct PermArgs {
     const uint32_t* main;
     const uint32_t* prep;
     const uint32_t* beta_pows;
-    ef alpha;
+    const uint32_t* starts;  // per interaction: alpha + kind + sum beta^t * constants (k_interaction_starts)
     uint32_t n, w, pw, perm_w, batch;
     uint32_t* out;
     uint32_t regs_words;  // all register files
@@ -354,7 +408,7 @@ __global__ void k_perm_rows(PermArgs a) {
     }
     const uint32_t* prog = a.parts.prog[wave];
     airvm::Sources src{main_l, a.main + (size_t)nx * a.w, a.prep + (size_t)ic * a.pw, a.prep + (size_t)nx * a.pw, nullptr, {0u, 0u, 0u}};
-    PermSink sink{LogupAccum{a.beta_pows, a.alpha}, a.batch, a.out + (size_t)ic * a.perm_w * 4};
+    PermSink sink{LogupAccum{a.beta_pows, a.starts}, a.batch, a.out + (size_t)ic * a.perm_w * 4};
     sink.col = prog[airp::H_FIRST_COLUMN];
     sink.live = live;
     airvm::run(prog, src, lds + a.parts.reg_off[wave] + lane, 64u, sink);
@@ -477,7 +531,7 @@ struct QuotientArgs {
     const uint32_t* pub;
     const uint32_t* alpha_pows;  // alpha^j, j < k_total
     const uint32_t* beta_pows;
-    ef perm_alpha;
+    const uint32_t* starts;  // per interaction: alpha + kind + sum beta^t * constants (k_interaction_starts)
     ef cumulative_sum;
     uint32_t log_n, log_q, w, pw, perm_w, batch, k_total;
     uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
@@ -524,8 +578,10 @@ struct QuotientSink {
         folded.add_ext(v, w);
         k++;
     }
-    __device__ __forceinline__ void ibegin(uint32_t kind, bool send, uint32_t) { acc.begin(kind, send); }
-    __device__ __forceinline__ void ival(uint32_t v) { acc.value(v); }
+    __device__ __forceinline__ void ibegin(uint32_t, bool send, uint32_t interaction) { acc.begin(interaction, send); }
+    __device__ __forceinline__ void ival(uint32_t) {}  // compact pieces carry no plain IVAL
+    __device__ __forceinline__ void ival_at(uint32_t v, uint32_t t) { acc.value_at(v, t); }
+    __device__ __forceinline__ void ival_run(const uint32_t* vals, uint32_t t, uint32_t count) { acc.value_run(vals, t, count); }
     __device__ __forceinline__ void flush() {
         // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
         ef entry = ef_load(perm_l + 4 * col);
@@ -579,7 +635,7 @@ __global__ void k_quotient(QuotientArgs a) {
     airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw, a.pub, {is_first, is_last, is_trans}};
     const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
     const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
-    QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.perm_alpha}, a.batch, perm_l};
+    QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.starts}, a.batch, perm_l};
     const uint32_t* prog = a.parts.prog[wave];
     const uint32_t first_col = wave == 0 ? 0u : prog[airp::H_FIRST_COLUMN];
     sink.col = first_col;
@@ -670,13 +726,17 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     LH_ARG(ctx, height > 0, "empty trace");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     const std::vector<uint32_t*>* dparts = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, nullptr, nullptr, &dparts));
+    const uint32_t* istat = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, nullptr, nullptr, &dparts, false, &istat));
     const uint32_t perm_w = a->air.permutation_width(), batch = 1u << a->air.log_quotient_degree();
-    void* pows = nullptr;
-    const uint32_t n_pows = a->max_tuple + 2;
-    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 32, &pows));
+    void* pows = nullptr;  // beta powers | interaction start values
+    const uint32_t n_pows = a->max_tuple + 2, n_inter = a->air.num_interactions();
+    LH_TRY(pool_alloc(ctx, (size_t)n_pows * 32 + (size_t)std::max(n_inter, 1u) * 16, &pows));
+    uint32_t* starts = (uint32_t*)pows + (size_t)n_pows * 8;
     span_begin(ctx, "perm_rows");
     int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
+    if (s == LURKHIP_OK && n_inter)
+        hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, (const uint32_t*)pows, alpha, starts);
     if (s == LURKHIP_OK) {
         PermArgs pa{};
         std::vector<const std::vector<uint32_t>*> host_parts;
@@ -686,7 +746,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         pa.main = main_dev;
         pa.prep = prep_dev ? prep_dev : main_dev;
         pa.beta_pows = (const uint32_t*)pows;
-        pa.alpha = alpha;
+        pa.starts = starts;
         pa.n = height;
         pa.w = a->air.width;
         pa.pw = a->air.prep_width;
@@ -721,19 +781,25 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     LH_HIP(ctx, hipSetDevice(ctx->device));
     const uint32_t* cp = nullptr;
     const std::vector<uint32_t*>* dparts = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, &cp, nullptr, &dparts, /*coarse=*/true));
+    const uint32_t* istat = nullptr;
+    LH_TRY(air_programs_dev(ctx, a, &cp, nullptr, &dparts, /*coarse=*/true, &istat));
     const uint32_t perm_w = a->air.permutation_width(), batch = 1u << lqd;
     const uint32_t n_batches = perm_w - 1;
     const uint32_t k_total = (uint32_t)a->air.constraints.size() + n_batches + 3;
     const uint32_t np = a->air.num_public;
     const uint32_t *pa = perm_alpha.c, *pb = perm_beta.c, *al = alpha_m.c, *cs = cumsum_m.c;
     const uint32_t n_bp = a->max_tuple + 2;
-    void* scratch = nullptr;  // alpha powers | beta powers | public values
-    const size_t o_bp = (size_t)k_total * 32, o_pub = o_bp + (size_t)n_bp * 32, total = o_pub + std::max<size_t>(np, 1) * 4;
+    void* scratch = nullptr;  // alpha powers | beta powers | interaction start values | public values
+    const uint32_t n_inter = a->air.num_interactions();
+    const size_t o_bp = (size_t)k_total * 32, o_st = o_bp + (size_t)n_bp * 32, o_pub = o_st + (size_t)std::max(n_inter, 1u) * 16,
+                 total = o_pub + std::max<size_t>(np, 1) * 4;
     LH_TRY(pool_alloc(ctx, total, &scratch));
     uint8_t* d = (uint8_t*)scratch;
     int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total, true);
     if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp, true);
+    if (s == LURKHIP_OK && n_inter)
+        hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, (const uint32_t*)(d + o_bp),
+                           bb::ef{{pa[0], pa[1], pa[2], pa[3]}}, (uint32_t*)(d + o_st));
     std::vector<uint32_t> pubm(np);
     if (s == LURKHIP_OK && np) {
         for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
@@ -758,7 +824,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.pub = (const uint32_t*)(d + o_pub);
         q.alpha_pows = (const uint32_t*)d;
         q.beta_pows = (const uint32_t*)(d + o_bp);
-        q.perm_alpha = bb::ef{{pa[0], pa[1], pa[2], pa[3]}};
+        q.starts = (const uint32_t*)(d + o_st);
         q.cumulative_sum = bb::ef{{cs[0], cs[1], cs[2], cs[3]}};
         q.log_n = log_n;
         q.log_q = log_n + lqd;
@@ -857,6 +923,7 @@ int32_t lurkhip_air_free(lurkhip_air* a) {
     if (!a) return LURKHIP_OK;
     for (auto& kv : a->dev) {
         (void)hipFree(kv.second.cons);
+        (void)hipFree(kv.second.inter_static);
         (void)hipFree(kv.second.inter);
         for (auto* part : kv.second.parts) (void)hipFree(part);
         for (auto* part : kv.second.parts_coarse) (void)hipFree(part);
