@@ -115,23 +115,24 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
     *total_w = n_cols;
     auto it = ctx->leafcol_tables.find(key);
     if (it != ctx->leafcol_tables.end()) {
-        *out_dev = (LeafCol*)it->second;
+        *out_dev = (LeafCol*)it->second.dev;
         return LURKHIP_OK;
     }
-    std::vector<LeafCol> cols;
-    for (int m : idx)
-        for (uint32_t k = 0; k < c->width[m]; k++) cols.push_back(LeafCol{c->lde[m], c->width[m], k});
     if (ctx->leafcol_tables.size() >= 1024) {  // bound the cache: tables of past shapes are dropped wholesale
         LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second);
+        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
         ctx->leafcol_tables.clear();
     }
-    void* d = nullptr;
-    LH_HIP(ctx, hipMalloc(&d, std::max<size_t>(cols.size(), 1) * sizeof(LeafCol)));
-    // synchronous copy: a miss happens once per distinct set of buffers
-    if (!cols.empty()) LH_HIP(ctx, hipMemcpy(d, cols.data(), cols.size() * sizeof(LeafCol), hipMemcpyHostToDevice));
-    ctx->leafcol_tables.emplace(std::move(key), d);
-    *out_dev = (LeafCol*)d;
+    lurkhip_ctx::LeafColTable& t = ctx->leafcol_tables[key];
+    t.host.resize(std::max<size_t>(n_cols, 1) * sizeof(LeafCol));
+    LeafCol* cols = reinterpret_cast<LeafCol*>(t.host.data());
+    size_t k = 0;
+    for (int m : idx)
+        for (uint32_t j = 0; j < c->width[m]; j++) cols[k++] = LeafCol{c->lde[m], c->width[m], j};
+    LH_HIP(ctx, hipMalloc(&t.dev, t.host.size()));
+    // stream-ordered upload from the entry's own staging buffer: no host wait
+    if (n_cols) LH_HIP(ctx, hipMemcpyAsync(t.dev, t.host.data(), (size_t)n_cols * sizeof(LeafCol), hipMemcpyHostToDevice, ctx->stream));
+    *out_dev = (LeafCol*)t.dev;
     return LURKHIP_OK;
 }
 

@@ -30,7 +30,11 @@ struct lurkhip_ctx {
     std::map<std::pair<int, uint32_t>, uint32_t*> lde_scale_tables;
     // Merkle leaf-column tables (commit.hip: make_cols) keyed by their (matrix pointer, width) lists: the pooled allocator
     // hands the same buffers to every proof, so after the first one a commit uploads nothing
-    std::map<std::vector<std::pair<const void*, uint32_t>>, void*> leafcol_tables;
+    struct LeafColTable {
+        void* dev = nullptr;
+        std::vector<unsigned char> host;  // staging of the asynchronous upload, kept as long as the entry
+    };
+    std::map<std::vector<std::pair<const void*, uint32_t>>, LeafColTable> leafcol_tables;
     size_t lde_scale_bytes = 0;
     std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)

@@ -1,4 +1,6 @@
 // Context, memory helpers and the HIP-event stopwatch of the lurkhip C ABI.
+#include <iterator>
+
 #include "ctx.h"
 
 #include <cstring>
@@ -41,8 +43,11 @@ int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out) {
 
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
-    auto it = ctx->pool_free.find(bytes);
-    if (it != ctx->pool_free.end()) {
+    // most recently released block of this size first (LIFO): a proof's sequence of allocations then lands in the same buffers
+    // as the previous proof's, which is what the pointer-keyed table caches (Merkle leaf columns) rely on
+    auto range = ctx->pool_free.equal_range(bytes);
+    if (range.first != range.second) {
+        auto it = std::prev(range.second);
         *out = it->second;
         ctx->pool_free.erase(it);
         ctx->pool_live[*out] = bytes;
@@ -52,10 +57,14 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (e != hipSuccess && !ctx->pool_free.empty()) {
         // give cached blocks back to the driver and retry once
         (void)hipStreamSynchronize(ctx->stream);
-        for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
-    for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second);
-    for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
+        for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
         ctx->pool_free.clear();
+        // the table caches are rebuilt on demand
+        for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
+        ctx->lde_scale_tables.clear();
+        ctx->lde_scale_bytes = 0;
+        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
+        ctx->leafcol_tables.clear();
         e = hipMalloc(out, bytes);
     }
     if (e != hipSuccess)
@@ -179,6 +188,8 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     for (auto it = ctx->cleanups.rbegin(); it != ctx->cleanups.rend(); ++it) (*it)();
     spans_resolve(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
+    for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
+    for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
     for (int i = 0; i < 4; i++)
