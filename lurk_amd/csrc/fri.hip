@@ -411,6 +411,31 @@ __global__ __launch_bounds__(256) void k_gather_openings(const GatherMat* __rest
     }
 }
 
+// The same with the matrix table and the level offsets passed by value in the kernel arguments (up to GATHER_INLINE matrices):
+// no upload, no host wait for staging buffers -- a proof opens two dozen commitments back to back.
+constexpr int GATHER_INLINE = 96;
+struct GatherInline {
+    GatherMat mats[GATHER_INLINE];
+    uint64_t level_off[32];
+};
+__global__ __launch_bounds__(256) void k_gather_openings_inline(GatherInline t, uint32_t n_mats, const uint32_t* __restrict__ digests,
+                                                                 uint32_t log_max, uint32_t rows_words, const uint32_t* __restrict__ indices,
+                                                                 uint32_t shift, uint32_t* __restrict__ out) {
+    const uint32_t q = blockIdx.x;
+    const uint32_t index = indices[q] >> shift;
+    uint32_t* rec = out + (size_t)q * (rows_words + 8 * log_max);
+    for (uint32_t m = 0; m < n_mats; m++) {
+        const GatherMat g = t.mats[m];
+        const size_t r = index >> (log_max - g.log_h);
+        for (uint32_t c = threadIdx.x; c < g.width; c += blockDim.x) rec[g.out_off + c] = g.base[r * g.width + c];
+    }
+    for (uint32_t e = threadIdx.x; e < 8 * log_max; e += blockDim.x) {
+        const uint32_t l = e >> 3, k = e & 7;
+        const size_t sib = (index >> l) ^ 1u;
+        rec[rows_words + e] = digests[(t.level_off[l] + sib) * 8 + k];
+    }
+}
+
 }  // namespace
 
 int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev) {
@@ -525,6 +550,15 @@ int32_t gather_openings(lurkhip_ctx* ctx, const std::vector<OpenMat>& mats, cons
     }
     *record_words = off + 8 * log_max;
     if (!out_dev) return LURKHIP_OK;  // size query
+    if (mats.size() <= (size_t)GATHER_INLINE && level_off.size() <= 32) {
+        GatherInline t{};
+        for (size_t i = 0; i < g.size(); i++) t.mats[i] = g[i];
+        for (size_t i = 0; i < level_off.size(); i++) t.level_off[i] = level_off[i];
+        hipLaunchKernelGGL(k_gather_openings_inline, dim3(n_queries), dim3(256), 0, ctx->stream, t, (uint32_t)g.size(), digests, log_max, off,
+                           indices_dev, shift, out_dev);
+        LH_HIP(ctx, hipGetLastError());
+        return LURKHIP_OK;
+    }
     std::vector<uint64_t> lo(level_off.begin(), level_off.end());
     void* scratch = nullptr;
     const size_t b_g = g.size() * sizeof(GatherMat), b_lo = lo.size() * 8, o_lo = (b_g + 15) & ~(size_t)15;
