@@ -297,6 +297,10 @@ const char* lurkhip_air_name(const lurkhip_air* air);
  * 12/13 of the interaction program, 14 number of pieces the interaction program is cut into for the prover kernels (one
  * wave per piece), 15 instructions summed over the pieces */
 int32_t lurkhip_air_info(const lurkhip_air* air, uint32_t* info);
+/* The lowered register programs (csrc/air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),
+ * 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel.  Returns the word count (copies at
+ * most cap words), negative for an unknown program. */
+int32_t lurkhip_air_program(const lurkhip_air* air, int32_t which, uint32_t index, uint32_t* out, uint32_t cap);
 /* tuple length of each interaction, sends first then receives; returns their number */
 int32_t lurkhip_air_interaction_sizes(const lurkhip_air* air, uint32_t* sizes, uint32_t cap);
 /* Debug / parity entry: evaluates every constraint and every interaction on explicit (local, next) row pairs with

@@ -971,6 +971,21 @@ int32_t lurkhip_air_interaction_sizes(const lurkhip_air* a, uint32_t* sizes, uin
     return (int32_t)k;
 }
 
+// The lowered register programs (air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),
+// 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel.  Returns the program's word count
+// (copying at most `cap` words), or a negative error for an unknown program.
+int32_t lurkhip_air_program(const lurkhip_air* a, int32_t which, uint32_t index, uint32_t* out, uint32_t cap) {
+    if (!a) return LURKHIP_ERR_INVALID_ARG;
+    const std::vector<uint32_t>* p = nullptr;
+    if (which == 0) p = &a->prog.constraints;
+    else if (which == 1) p = &a->prog.interactions;
+    else if (which == 2 && index < a->prog.interaction_parts.size()) p = &a->prog.interaction_parts[index];
+    else if (which == 3 && index < a->prog.interaction_parts_coarse.size()) p = &a->prog.interaction_parts_coarse[index];
+    if (!p) return LURKHIP_ERR_INVALID_ARG;
+    for (size_t i = 0; i < p->size() && i < cap && out; i++) out[i] = (*p)[i];
+    return (int32_t)p->size();
+}
+
 int32_t lurkhip_air_eval_rows(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t n_rows, const uint32_t* local, const uint32_t* next,
                               const uint32_t* prep_local, const uint32_t* prep_next, const uint32_t* public_values,
                               const uint32_t* selectors, uint32_t* constraints_out, uint32_t* interactions_out) {
