@@ -1,0 +1,332 @@
+// Device side of the prover's AIR kernels: LogUp / folding sinks and the bodies of the permutation-trace and quotient kernels,
+// templated on the *runner* that executes a chip's program pieces -- the interpreter (air_vm.h) in the library build, straight-
+// line code generated from the same programs when a chip is compiled at run time (jit.cpp).  Device code only.
+#pragma once
+#include "air_program.h"
+#include "air_vm.h"
+#include "babybear.h"
+#include "lazy_ef.h"
+
+namespace lurkhip {
+
+using bb::ef;
+
+__device__ __forceinline__ ef ef_load(const uint32_t* p) { return ef{{p[0], p[1], p[2], p[3]}}; }
+
+// Copies rows idx[0..n_rows) of a row-major matrix into an LDS tile with row stride wp: lanes run along a row, so
+// every global access is one contiguous w*4-byte segment (the per-lane strided reads the VM would otherwise issue
+// thrash L1: a workgroup's rows are hundreds of KB apart from lane to lane).
+__device__ __forceinline__ void stage_rows(uint32_t* __restrict__ tile, uint32_t wp, const uint32_t* __restrict__ mat, uint32_t w,
+                                           const uint32_t* __restrict__ idx, uint32_t n_rows) {
+    for (uint32_t r = 0; r < n_rows; r++) {
+        const size_t g = idx[r];
+        for (uint32_t c = threadIdx.x; c < w; c += blockDim.x) tile[r * wp + c] = mat[g * w + c];
+    }
+}
+
+// Running (numerator, denominator) of the current batch of interactions; shared by the permutation trace
+// and the quotient kernel (where entry * den - num is the batch's constraint).
+struct LogupAccum {
+    const uint32_t* __restrict__ beta_pows;  // centred, 8 words per power (k_ef_powers)
+    const uint32_t* __restrict__ starts;     // per interaction: alpha + kind + sum of beta^t * (constant tuple elements)
+    LazyEf cur64;
+    ef cur, num, den;
+    uint32_t in_batch = 0, m_first = 0;
+    bool is_send = false;
+    __device__ __forceinline__ void begin(uint32_t interaction, bool send) {
+        cur64.set(ef{{starts[4 * interaction], starts[4 * interaction + 1], starts[4 * interaction + 2], starts[4 * interaction + 3]}});
+        is_send = send;
+    }
+    // the tuple element at position t (t = 1 + index in the tuple): += beta^t * v
+    __device__ __forceinline__ void value_at(uint32_t v, uint32_t t) {
+        int32_t p[8];
+        load_w8(p, beta_pows + 8 * t);
+        cur64.add_base(v, p);
+    }
+    // `count` elements from consecutive words at positions t, t + 1, ...; the (scalar) table load of the next power overlaps
+    // the current element's arithmetic (the table has max_tuple + 2 entries: one past the last position is valid)
+    __device__ __forceinline__ void value_run(const uint32_t* __restrict__ vals, uint32_t t, uint32_t count) {
+        int32_t p[8];
+        load_w8(p, beta_pows + 8 * t);
+        for (uint32_t k = 0; k < count; k++) {
+            int32_t q[8];
+            load_w8(q, beta_pows + 8 * (t + k + 1));
+            cur64.add_base(vals[k], p);
+#pragma unroll
+            for (int c = 0; c < 8; c++) p[c] = q[c];
+        }
+    }
+    // folds the finished interaction into the batch fraction num / den = sum_i m_i / d_i; returns true when the batch
+    // holds `batch` interactions.  Multiplicities are base-field: the first two interactions of a batch cost one
+    // extension product (d_1 d_2) and two scalings.
+    __device__ __forceinline__ bool end(uint32_t mult, uint32_t batch) {
+        cur = cur64.value();
+        const uint32_t m = is_send ? mult : bb::neg(mult);
+        if (in_batch == 0) {
+            m_first = m;
+            den = cur;
+        } else if (in_batch == 1) {
+            num = bb::ef_add(bb::ef_scale(cur, m_first), bb::ef_scale(den, m));
+            den = bb::ef_mul(den, cur);
+        } else {
+            num = bb::ef_add(bb::ef_mul(num, cur), bb::ef_scale(den, m));
+            den = bb::ef_mul(den, cur);
+        }
+        in_batch++;
+        return in_batch == batch;
+    }
+    // numerator of the (possibly partial) batch
+    __device__ __forceinline__ ef numerator() const { return in_batch == 1 ? bb::ef_from_base(m_first) : num; }
+};
+
+struct PermSink {
+    LogupAccum acc;
+    uint32_t batch;
+    uint32_t* out_row;  // [perm_width * 4]
+    uint32_t col = 0;
+    ef row_sum = bb::ef_zero();
+    bool live = true;  // lanes past the last row run along (workgroup barriers) and store nothing
+    __device__ __forceinline__ void assert_zero(uint32_t) {}
+    __device__ __forceinline__ void ibegin(uint32_t, bool send, uint32_t interaction) { acc.begin(interaction, send); }
+    __device__ __forceinline__ void ival(uint32_t) {}  // compact pieces carry no plain IVAL
+    __device__ __forceinline__ void ival_at(uint32_t v, uint32_t t) { acc.value_at(v, t); }
+    __device__ __forceinline__ void ival_run(const uint32_t* vals, uint32_t t, uint32_t count) { acc.value_run(vals, t, count); }
+    __device__ __forceinline__ void flush() {
+        ef v = acc.in_batch == 1 ? bb::ef_scale(bb::ef_inv(acc.den), acc.m_first) : bb::ef_mul(acc.num, bb::ef_inv(acc.den));
+        uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
+        if (live) *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
+        row_sum = bb::ef_add(row_sum, v);
+        col++;
+        acc.in_batch = 0;
+    }
+    __device__ __forceinline__ void iend(uint32_t m) {
+        if (acc.end(m, batch)) flush();
+    }
+};
+
+// Program pieces of a launch: one wave of every workgroup per piece, all over the same 64 staged rows.
+constexpr int MAX_VM_PARTS = 8;
+struct VmParts {
+    const uint32_t* prog[MAX_VM_PARTS];
+    uint32_t reg_off[MAX_VM_PARTS];  // word offset of the piece's register file regs[n_regs][64] in LDS
+    uint32_t n_parts;
+};
+
+struct PermArgs {
+    VmParts parts;
+    const uint32_t* main;
+    const uint32_t* prep;
+    const uint32_t* beta_pows;
+    const uint32_t* starts;  // per interaction: alpha + kind + sum beta^t * constants (k_interaction_starts)
+    uint32_t n, w, pw, perm_w, batch;
+    uint32_t* out;
+    uint32_t regs_words;  // all register files
+    uint32_t wp;
+    int staged;
+};
+
+// Workgroup = 64 rows x n_parts waves: wave j runs interaction piece j (its own permutation columns) on the shared tile;
+// the pieces' row sums meet in LDS and wave 0 writes the last column.
+template <class Runner>
+__device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
+    extern __shared__ uint32_t lds[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t i = blockIdx.x * 64u + lane;
+    const bool live = i < a.n;
+    const uint32_t ic = live ? i : 0u;
+    const uint32_t nx = ic + 1 >= a.n ? 0 : ic + 1;
+    const uint32_t* main_l = a.main + (size_t)ic * a.w;
+    uint32_t* tile = lds + a.regs_words;
+    uint32_t* idx = tile + (a.staged ? 64u * a.wp : 0u);
+    uint32_t* sums = idx + 64;  // [n_parts][64][4]
+    if (a.staged) {
+        // interactions only read the local row
+        if (wave == 0) idx[lane] = ic;
+        __syncthreads();
+        stage_rows(tile, a.wp, a.main, a.w, idx, 64u);
+        __syncthreads();
+        main_l = tile + lane * a.wp;
+    }
+    const uint32_t* prog = a.parts.prog[wave];
+    airvm::Sources src{main_l, a.main + (size_t)nx * a.w, a.prep + (size_t)ic * a.pw, a.prep + (size_t)nx * a.pw, nullptr, {0u, 0u, 0u}};
+    PermSink sink{LogupAccum{a.beta_pows, a.starts}, a.batch, a.out + (size_t)ic * a.perm_w * 4};
+    sink.col = prog[airp::H_FIRST_COLUMN];
+    sink.live = live;
+    Runner::run(prog, wave, src, lds + a.parts.reg_off[wave] + lane, sink);
+    if (sink.acc.in_batch) sink.flush();
+    if (a.parts.n_parts > 1) {
+#pragma unroll
+        for (int c = 0; c < 4; c++) sums[(wave * 64u + lane) * 4 + c] = sink.row_sum.c[c];
+        __syncthreads();
+        if (wave != 0) return;
+        for (uint32_t j = 1; j < a.parts.n_parts; j++) sink.row_sum = bb::ef_add(sink.row_sum, ef_load(sums + (j * 64u + lane) * 4));
+    }
+    if (!live) return;
+    // the row's sum goes to the last column; the scan below turns it into the running sum
+    uint4* dst = reinterpret_cast<uint4*>(sink.out_row + 4 * (a.perm_w - 1));
+    *dst = make_uint4(sink.row_sum.c[0], sink.row_sum.c[1], sink.row_sum.c[2], sink.row_sum.c[3]);
+}
+
+// ---------------------------------------------------------------- quotient values
+// One row of the quotient domain g * <w_Q>, Q = N << log_quotient_degree, per lane.  The committed LDEs are
+// stored in bit-reversed row order, so lane s works on natural index i = bitrev(s): its "local" rows are
+// the contiguous storage rows of the launch, its "next" row (i + Q/N) is another storage row.
+// Constraint k of the chip (then one per permutation batch column, then the three running-sum constraints) is
+// folded as sum_k alpha^(K-1-k) C_k(x), which is sphinx's Horner accumulation `acc = acc * alpha + C_k`
+// [UPSTREAM-RECALL: ProverConstraintFolder], and multiplied by 1 / Z_H(x).
+struct QuotientArgs {
+    VmParts parts;          // piece 0: the constraint program, pieces 1..: the interaction program pieces
+    uint32_t n_cons;        // constraints of the chip (the interaction batches' constraints follow them)
+    const uint32_t* main;   // LDE matrices, bit-reversed rows, Montgomery
+    const uint32_t* prep;
+    const uint32_t* perm;   // 4 * perm_w base columns
+    const uint32_t* pub;
+    const uint32_t* alpha_pows;  // alpha^j, j < k_total
+    const uint32_t* beta_pows;
+    const uint32_t* starts;  // per interaction: alpha + kind + sum beta^t * constants (k_interaction_starts)
+    ef cumulative_sum;
+    uint32_t log_n, log_q, w, pw, perm_w, batch, k_total;
+    uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
+    uint32_t zh[4];
+    uint32_t g_m, wq_m, wn_inv_m;
+    uint32_t regs_words, wp;    // LDS layout (layout_parts)
+    int staged;
+    uint32_t* out;          // [2^lqd][N][4]
+};
+
+struct QuotientSink {
+    const uint32_t* __restrict__ alpha_pows;  // centred, 8 words per power
+    uint32_t k_total;
+    LogupAccum acc;
+    uint32_t batch;
+    const uint32_t* perm_l;
+    uint32_t k = 0, col = 0;
+    LazyEf folded;
+    int32_t next_w[8];  // alpha^(K-1-k), loaded one constraint ahead (see LogupAccum::next_pow)
+    __device__ __forceinline__ void prime(uint32_t k_start) {
+        folded.zero();
+        seek(k_start);
+    }
+    __device__ __forceinline__ void seek(uint32_t k_next) {
+        k = k_next;
+        load_w8(next_w, alpha_pows + 8 * (k_total - 1 - k));
+    }
+    __device__ __forceinline__ void weight(int32_t (&w)[8]) {
+#pragma unroll
+        for (int c = 0; c < 8; c++) w[c] = next_w[c];
+        // k + 1 <= k_total - 1 except after the last constraint, where index 0 is re-read (valid, unused)
+        const uint32_t nk = k + 1 < k_total ? k_total - 2 - k : 0u;
+        load_w8(next_w, alpha_pows + 8 * nk);
+    }
+    __device__ __forceinline__ void assert_zero(uint32_t v) {
+        int32_t w[8];
+        weight(w);
+        folded.add_base(v, w);
+        k++;
+    }
+    __device__ __forceinline__ void assert_zero_ext(const ef& v) {
+        int32_t w[8];
+        weight(w);
+        folded.add_ext(v, w);
+        k++;
+    }
+    __device__ __forceinline__ void ibegin(uint32_t, bool send, uint32_t interaction) { acc.begin(interaction, send); }
+    __device__ __forceinline__ void ival(uint32_t) {}  // compact pieces carry no plain IVAL
+    __device__ __forceinline__ void ival_at(uint32_t v, uint32_t t) { acc.value_at(v, t); }
+    __device__ __forceinline__ void ival_run(const uint32_t* vals, uint32_t t, uint32_t count) { acc.value_run(vals, t, count); }
+    __device__ __forceinline__ void flush() {
+        // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
+        ef entry = ef_load(perm_l + 4 * col);
+        assert_zero_ext(bb::ef_sub(bb::ef_mul(acc.den, entry), acc.numerator()));
+        col++;
+        acc.in_batch = 0;
+    }
+    __device__ __forceinline__ void iend(uint32_t m) {
+        if (acc.end(m, batch)) flush();
+    }
+};
+
+// Workgroup = 64 quotient-domain rows x n_parts waves over one staged tile: wave 0 folds the chip's constraints, wave j >= 1
+// the batch constraints of interaction piece j - 1 (weights alpha^(K-1-k) at their own k); the partial folds meet in LDS and
+// wave 0 adds the running-sum constraints and stores the quotient value.
+template <class Runner>
+__device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
+    extern __shared__ uint32_t regs[];
+    const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
+    const uint32_t s_raw = blockIdx.x * 64u + lane;
+    const uint32_t q = 1u << a.log_q;
+    const bool live = s_raw < q;
+    const uint32_t s = live ? s_raw : 0u;
+    const uint32_t lqd = a.log_q - a.log_n, qd = 1u << lqd;
+    const uint32_t i = a.log_q ? (__brev(s) >> (32 - a.log_q)) : 0u;
+    const uint32_t i_next = (i + qd) & (q - 1);
+    const uint32_t s_next = a.log_q ? (__brev(i_next) >> (32 - a.log_q)) : 0u;
+    const uint32_t* main_l = a.main + (size_t)s * a.w;
+    const uint32_t* main_n = a.main + (size_t)s_next * a.w;
+    uint32_t* tile_l = regs + a.regs_words;
+    uint32_t* idx = tile_l + (a.staged ? 64u * a.wp : 0u);
+    uint32_t* folds = idx + 64;  // [n_parts][64][4]
+    if (a.staged) {
+        // only the local rows are staged: the Lair AIRs read one or two columns of the next row (nonce, is_real, ptr),
+        // which stay in global memory, and a second tile would halve the waves an LDS-bound CU can hold
+        if (wave == 0) idx[lane] = s;
+        __syncthreads();
+        stage_rows(tile_l, a.wp, a.main, a.w, idx, 64u);
+        __syncthreads();
+        main_l = tile_l + lane * a.wp;
+    }
+    // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset): the constraint wave needs them
+    uint32_t is_first = 0, is_last = 0, is_trans = 0;
+    if (wave == 0) {
+        const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
+        const uint32_t zh = a.zh[i & (qd - 1)];
+        is_first = bb::mul(zh, bb::inv(bb::sub(x, bb::R1)));
+        const uint32_t x_minus_last = bb::sub(x, a.wn_inv_m);
+        is_last = bb::mul(zh, bb::inv(x_minus_last));
+        is_trans = x_minus_last;
+    }
+    airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw, a.pub, {is_first, is_last, is_trans}};
+    const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
+    const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
+    QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.starts}, a.batch, perm_l};
+    const uint32_t* prog = a.parts.prog[wave];
+    const uint32_t first_col = wave == 0 ? 0u : prog[airp::H_FIRST_COLUMN];
+    sink.col = first_col;
+    sink.prime(wave == 0 ? 0u : a.n_cons + first_col);
+    Runner::run(prog, wave, src, regs + a.parts.reg_off[wave] + lane, sink);
+    if (sink.acc.in_batch) sink.flush();
+    if (wave != 0) {
+        const ef f = sink.folded.value();
+#pragma unroll
+        for (int c = 0; c < 4; c++) folds[(wave * 64u + lane) * 4 + c] = f.c[c];
+    }
+    __syncthreads();
+    if (wave != 0 || !live) return;
+    // running-sum constraints (sphinx eval_permutation_constraints)
+    ef sum_l = bb::ef_zero(), sum_n = bb::ef_zero();
+    for (uint32_t c = 0; c + 1 < a.perm_w; c++) {
+        sum_l = bb::ef_add(sum_l, ef_load(perm_l + 4 * c));
+        sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
+    }
+    const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1)), phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
+    sink.seek(a.k_total - 3);
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, a.cumulative_sum), is_last));
+    ef folded = sink.folded.value();
+    for (uint32_t j = 1; j < a.parts.n_parts; j++) folded = bb::ef_add(folded, ef_load(folds + (j * 64u + lane) * 4));
+    const ef quot = bb::ef_scale(folded, a.zh_inv[i & (qd - 1)]);
+    const uint32_t chunk = i & (qd - 1), r = i >> lqd;
+    uint4* dst = reinterpret_cast<uint4*>(a.out + ((size_t)chunk * ((size_t)1 << a.log_n) + r) * 4);
+    *dst = make_uint4(quot.c[0], quot.c[1], quot.c[2], quot.c[3]);
+}
+
+// the library's runner: the interpreter
+struct InterpreterRunner {
+    template <class Sink>
+    static __device__ __forceinline__ void run(const uint32_t* prog, uint32_t /*wave*/, const airvm::Sources& src, uint32_t* regs, Sink& sink) {
+        airvm::run(prog, src, regs, 64u, sink);
+    }
+};
+
+}  // namespace lurkhip
