@@ -297,6 +297,10 @@ const char* lurkhip_air_name(const lurkhip_air* air);
  * 12/13 of the interaction program, 14 number of pieces the interaction program is cut into for the prover kernels (one
  * wave per piece), 15 instructions summed over the pieces */
 int32_t lurkhip_air_info(const lurkhip_air* air, uint32_t* info);
+/* Compiles the chip's AIR program pieces to straight-line device code (hiprtc) and uses the compiled kernels for its permutation
+ * traces and quotients on this context's device from then on (the interpreter otherwise).  Costs seconds to tens of seconds of
+ * host time per chip: for traces of 2^17 rows and more.  No reference counterpart (sphinx evaluates `Air::eval` natively). */
+int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* air);
 /* The lowered register programs (csrc/air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),
  * 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel.  Returns the word count (copies at
  * most cap words), negative for an unknown program. */

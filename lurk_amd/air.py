@@ -63,6 +63,11 @@ class ChipAir:
             N.lib.lurkhip_air_free(self.handle)
             self.handle = None
 
+    def compile(self, ctx: Context) -> None:
+        """Compile this chip's program pieces to straight-line device code (hiprtc); its permutation traces and quotients on
+        `ctx`'s device then run the compiled kernels.  Seconds to tens of seconds per chip: for big traces."""
+        ctx.check(N.lib.lurkhip_air_compile(ctx.handle, self.handle))
+
     def interaction_sizes(self) -> list[int]:
         n = self.num_sends + self.num_receives
         out = np.zeros(max(n, 1), dtype=np.uint32)

@@ -1,0 +1,151 @@
+// Run-time compilation of a chip's AIR program pieces.  See jit.h and DESIGN.md (AIR programs).
+//
+// The interpreter (air_vm.h) pays scalar decode, branches and LDS register traffic per instruction; for a chip with millions
+// of rows it is worth compiling its programs once: every piece becomes one straight-line device function over the same sinks
+// (stark_kernels.h), every interpreter register an SSA value the compiler keeps in a VGPR.  The generated kernels take the
+// arguments, grid and LDS layout of k_perm_rows / k_quotient, so the host side only swaps the function it launches.
+#include "jit.h"
+
+#include <hip/hiprtc.h>
+
+#include <map>
+#include <mutex>
+#include <sstream>
+
+#include "air_program.h"
+#include "jit_headers.inc"
+
+namespace lurkhip {
+
+namespace {
+
+// one program (classic 2-word encoding, compact interaction ops included) -> a function template over the sink
+void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, const std::string& name) {
+    const uint32_t n = prog[airp::H_N_INSTR];
+    const uint32_t* code = prog.data() + prog[airp::H_CODE_OFF];
+    const uint32_t* consts = prog.data() + prog[airp::H_CONST_OFF];
+    std::map<uint32_t, std::string> reg;  // interpreter register -> the SSA value that currently lives in it
+    auto operand = [&](uint32_t op) -> std::string {
+        const uint32_t idx = op & airp::SRC_MASK;
+        switch (op >> airp::SRC_SHIFT) {
+            case airp::S_REG: return reg.at(idx);
+            case airp::S_MAIN: return "s.main_l[" + std::to_string(idx) + "]";
+            case airp::S_MAIN_NEXT: return "s.main_n[" + std::to_string(idx) + "]";
+            case airp::S_PREP: return "s.prep_l[" + std::to_string(idx) + "]";
+            case airp::S_PREP_NEXT: return "s.prep_n[" + std::to_string(idx) + "]";
+            case airp::S_CONST: return std::to_string(consts[idx]) + "u";
+            case airp::S_PUBLIC: return "s.pub[" + std::to_string(idx) + "]";
+            default: return "s.sel[" + std::to_string(idx) + "]";
+        }
+    };
+    o << "template <class Sink> __device__ __forceinline__ void " << name << "(const airvm::Sources& s, Sink& sink) {\n";
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
+        const uint32_t op = w0 & 0xffu, dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
+        const std::string t = "t" + std::to_string(i);
+        switch (op) {
+            case airp::OP_ADD: o << "    const uint32_t " << t << " = bb::add(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
+            case airp::OP_SUB: o << "    const uint32_t " << t << " = bb::sub(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
+            case airp::OP_MUL: o << "    const uint32_t " << t << " = bb::mul(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
+            case airp::OP_ASSERT: o << "    sink.assert_zero(" << operand(a) << ");\n"; break;
+            case airp::OP_IBEGIN: o << "    sink.ibegin(" << dst << "u, " << (a ? "true" : "false") << ", " << b << "u);\n"; break;
+            case airp::OP_IVAL: o << "    sink.ival(" << operand(a) << ");\n"; break;
+            case airp::OP_IEND: o << "    sink.iend(" << operand(a) << ");\n"; break;
+            case airp::OP_IVALS: o << "    sink.ival_run(s.main_l + " << a << ", " << b << "u, " << dst << "u);\n"; break;
+            case airp::OP_IVALT: o << "    sink.ival_at(" << operand(a) << ", " << dst << "u);\n"; break;
+            default: break;  // OP_NOP padding
+        }
+    }
+    o << "}\n";
+}
+
+void emit_runner(std::ostringstream& o, const std::string& name, const std::vector<std::string>& funcs) {
+    o << "struct " << name << " {\n    template <class Sink>\n"
+      << "    static __device__ __forceinline__ void run(const uint32_t*, uint32_t wave, const airvm::Sources& src, uint32_t*, Sink& sink) {\n"
+      << "        switch (wave) {\n";
+    for (size_t j = 0; j < funcs.size(); j++) o << "            case " << j << ": " << funcs[j] << "(src, sink); break;\n";
+    o << "            default: break;\n        }\n    }\n};\n";
+}
+
+}  // namespace
+
+std::string jit_source(const lair::AirPrograms& prog) {
+    std::ostringstream o;
+    o << "#include \"stark_kernels.h\"\nnamespace lurkhip {\n";
+    std::vector<std::string> perm, quot{"quot_cons"};
+    for (size_t j = 0; j < prog.interaction_parts.size(); j++) {
+        perm.push_back("perm_piece" + std::to_string(j));
+        emit_function(o, prog.interaction_parts[j], perm.back());
+    }
+    emit_function(o, prog.constraints, "quot_cons");
+    for (size_t j = 0; j < prog.interaction_parts_coarse.size(); j++) {
+        quot.push_back("quot_piece" + std::to_string(j));
+        emit_function(o, prog.interaction_parts_coarse[j], quot.back());
+    }
+    emit_runner(o, "JitPermRunner", perm);
+    emit_runner(o, "JitQuotRunner", quot);
+    o << "}  // namespace lurkhip\n"
+      << "extern \"C\" __global__ void jit_perm_rows(lurkhip::PermArgs a) { lurkhip::perm_rows_body<lurkhip::JitPermRunner>(a); }\n"
+      << "extern \"C\" __global__ void jit_quotient(lurkhip::QuotientArgs a) { lurkhip::quotient_body<lurkhip::JitQuotRunner>(a); }\n";
+    return o.str();
+}
+
+namespace {
+// compiled code objects by source text: a second context / machine of the same toplevel compiles nothing
+std::mutex g_cache_mu;
+std::map<std::string, std::vector<char>> g_code_cache;
+
+bool load_module(const std::vector<char>& code, JitKernels* out, std::string* log) {
+    JitKernels k;
+    if (hipModuleLoadData(&k.module, code.data()) != hipSuccess || hipModuleGetFunction(&k.perm_rows, k.module, "jit_perm_rows") != hipSuccess ||
+        hipModuleGetFunction(&k.quotient, k.module, "jit_quotient") != hipSuccess) {
+        if (k.module) (void)hipModuleUnload(k.module);
+        if (log) *log = "loading the compiled module failed";
+        return false;
+    }
+    *out = k;
+    return true;
+}
+}  // namespace
+
+bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log) {
+    const std::string src = jit_source(prog);
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        auto it = g_code_cache.find(src);
+        if (it != g_code_cache.end()) return load_module(it->second, out, log);
+    }
+    hiprtcProgram p = nullptr;
+    if (hiprtcCreateProgram(&p, src.c_str(), "lurkhip_air_jit.hip", kJitHeaderCount, kJitHeaderBodies, kJitHeaderNames) != HIPRTC_SUCCESS) {
+        if (log) *log = "hiprtcCreateProgram failed";
+        return false;
+    }
+    // the ROCm include directory provides <hip/hip_runtime.h> for the embedded headers
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I/opt/rocm/include"};
+    const hiprtcResult r = hiprtcCompileProgram(p, 5, opts);
+    if (r != HIPRTC_SUCCESS) {
+        size_t n = 0;
+        (void)hiprtcGetProgramLogSize(p, &n);
+        std::string l(n, '\0');
+        if (n) (void)hiprtcGetProgramLog(p, &l[0]);
+        if (log) *log = std::string(hiprtcGetErrorString(r)) + ": " + l.substr(0, 4000);
+        (void)hiprtcDestroyProgram(&p);
+        return false;
+    }
+    size_t n = 0;
+    (void)hiprtcGetCodeSize(p, &n);
+    std::vector<char> code(n);
+    (void)hiprtcGetCode(p, code.data());
+    (void)hiprtcDestroyProgram(&p);
+    if (!load_module(code, out, log)) return false;
+    std::lock_guard<std::mutex> g(g_cache_mu);
+    g_code_cache.emplace(src, std::move(code));
+    return true;
+}
+
+void jit_release(JitKernels* k) {
+    if (k && k->module) (void)hipModuleUnload(k->module);
+    if (k) *k = JitKernels{};
+}
+
+}  // namespace lurkhip

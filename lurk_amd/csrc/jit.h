@@ -1,0 +1,24 @@
+// Run-time compilation of a chip's AIR program pieces (hiprtc): straight-line device code instead of the interpreter.
+#pragma once
+#include <hip/hip_runtime.h>
+
+#include <string>
+#include <vector>
+
+#include "lair/air.h"
+
+namespace lurkhip {
+
+struct JitKernels {
+    hipModule_t module = nullptr;
+    hipFunction_t perm_rows = nullptr;  // same arguments, grid and LDS as k_perm_rows
+    hipFunction_t quotient = nullptr;   // same as k_quotient
+};
+
+// C++ source of the two kernels for these programs (stark_kernels.h bodies with a generated runner)
+std::string jit_source(const lair::AirPrograms& prog);
+// compiles for gfx950 and loads the module on the current device; on failure returns false and leaves the log in *log
+bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log);
+void jit_release(JitKernels* k);
+
+}  // namespace lurkhip

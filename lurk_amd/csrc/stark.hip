@@ -22,6 +22,7 @@
 #include "commit.h"
 #include "ctx.h"
 #include "lair/air.h"
+#include "jit.h"
 #include "lazy_ef.h"
 #include "stark_kernels.h"
 #include "stark.h"
@@ -36,6 +37,7 @@ struct lurkhip_air {
         uint32_t* inter_static = nullptr;  // k_interaction_starts: kinds, offsets, constant terms
         std::vector<uint32_t*> parts;         // interaction program pieces (AirPrograms::interaction_parts)
         std::vector<uint32_t*> parts_coarse;  // AirPrograms::interaction_parts_coarse
+        lurkhip::JitKernels jit;              // run-time compiled kernels of this chip (lurkhip_air_compile), or empty
     };
     std::map<int, DevPrograms> dev;  // device -> programs
     uint32_t tuple_words = 0;                              // sum over interactions of (1 + #values)
@@ -89,6 +91,13 @@ int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons
     if (inter) *inter = it->second.inter;
     if (parts) *parts = coarse ? &it->second.parts_coarse : &it->second.parts;
     return LURKHIP_OK;
+}
+
+// the chip's compiled kernels on this context's device, if lurkhip_air_compile was called for it
+static JitKernels jit_of(lurkhip_ctx* ctx, lurkhip_air* a) {
+    std::lock_guard<std::mutex> g(a->mu);
+    auto it = a->dev.find(ctx->device);
+    return it == a->dev.end() ? JitKernels{} : it->second.jit;
 }
 
 const lair::ChipAir& air_of(const lurkhip_air* a) { return a->air; }
@@ -454,7 +463,15 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         pa.regs_words = lay.regs_words;
         pa.wp = lay.wp;
         pa.staged = lay.staged ? 1 : 0;
-        hipLaunchKernelGGL(k_perm_rows, dim3((height + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, pa);
+        const JitKernels jit = jit_of(ctx, a);
+        if (jit.perm_rows) {
+            void* params[] = {&pa};
+            if (hipModuleLaunchKernel(jit.perm_rows, (height + 63) / 64, 1, 1, 64 * lay.parts.n_parts, 1, 1, (unsigned)lay.lds_bytes, ctx->stream,
+                                      params, nullptr) != hipSuccess)
+                s = set_error(ctx, LURKHIP_ERR_HIP, "launch of the compiled permutation kernel failed");
+        } else {
+            hipLaunchKernelGGL(k_perm_rows, dim3((height + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, pa);
+        }
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
     span_end(ctx, "perm_rows");
@@ -551,7 +568,15 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.staged = lay.staged ? 1 : 0;
         const uint32_t rows = 1u << q.log_q;
         span_begin(ctx, "quotient");
-        hipLaunchKernelGGL(k_quotient, dim3((rows + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, q);
+        const JitKernels jit = jit_of(ctx, a);
+        if (jit.quotient) {
+            void* params[] = {&q};
+            if (hipModuleLaunchKernel(jit.quotient, (rows + 63) / 64, 1, 1, 64 * lay.parts.n_parts, 1, 1, (unsigned)lay.lds_bytes, ctx->stream, params,
+                                      nullptr) != hipSuccess)
+                s = set_error(ctx, LURKHIP_ERR_HIP, "launch of the compiled quotient kernel failed");
+        } else {
+            hipLaunchKernelGGL(k_quotient, dim3((rows + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, q);
+        }
         span_end(ctx, "quotient");
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
     }
@@ -625,6 +650,7 @@ int32_t lurkhip_air_free(lurkhip_air* a) {
         (void)hipFree(kv.second.inter);
         for (auto* part : kv.second.parts) (void)hipFree(part);
         for (auto* part : kv.second.parts_coarse) (void)hipFree(part);
+        jit_release(&kv.second.jit);
     }
     delete a;
     return LURKHIP_OK;
@@ -667,6 +693,26 @@ int32_t lurkhip_air_interaction_sizes(const lurkhip_air* a, uint32_t* sizes, uin
             k++;
         }
     return (int32_t)k;
+}
+
+// Compiles the chip's program pieces to straight-line device code (hiprtc, gfx950) and uses the compiled kernels for its
+// permutation traces and quotients on this context's device from now on.  Seconds to tens of seconds of host time for a big
+// chip: worth it for traces of 2^17 rows and more.  On failure the chip keeps running on the interpreter and the error says why.
+int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* a) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, a != nullptr, "null air");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_TRY(air_programs_dev(ctx, a, nullptr, nullptr));  // creates the per-device entry
+    {
+        std::lock_guard<std::mutex> g(a->mu);
+        if (a->dev.at(ctx->device).jit.module) return LURKHIP_OK;
+    }
+    JitKernels k;
+    std::string log;
+    if (!jit_compile(a->prog, &k, &log)) return set_error(ctx, LURKHIP_ERR_EXEC, "compiling %s failed: %s", a->air.name.c_str(), log.c_str());
+    std::lock_guard<std::mutex> g(a->mu);
+    a->dev.at(ctx->device).jit = k;
+    return LURKHIP_OK;
 }
 
 // The lowered register programs (air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),

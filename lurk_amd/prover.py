@@ -342,6 +342,20 @@ class Machine(_ShardProver):
         torch.cuda.synchronize()
         return out
 
+    def compile_airs(self, prepared, min_log_rows: int = 17):
+        """Compile (hiprtc) the AIR programs of the chips whose traces in `prepared` have at least 2^min_log_rows rows: their
+        permutation traces and quotients then run straight-line device code instead of the interpreter.  A chip that fails
+        to compile keeps the interpreter; returns the names of the compiled chips."""
+        done = []
+        for _, chip_air, lg, _, _ in prepared:
+            if lg >= min_log_rows:
+                try:
+                    chip_air.compile(self.ctx)
+                    done.append(chip_air.name)
+                except Exception:  # hiprtc unavailable / compilation error: the interpreter stays in place
+                    pass
+        return done
+
     def run_prepared(self, prepared):
         for _, _, _, t, p in prepared:
             if p is not None:

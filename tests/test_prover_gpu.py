@@ -140,6 +140,45 @@ def test_pipelined_sharded_proof_equals_sequential(ctx):
     assert verify(DEMO, "fib", root, got, len(pv))
 
 
+def test_compiled_air_kernels(ctx):
+    """ChipAir.compile: the chip's program pieces as straight-line device code (hiprtc) instead of the interpreter.  The
+    permutation traces must be bit-identical, and a proof made with every chip compiled is the interpreter's proof."""
+    import torch
+
+    from lurk_amd import air, field
+
+    top = lair.Toplevel(DEMO)
+    q = lair.QueryRecord(top)
+    top.execute_by_name("fib", [12], q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, "fib", len(pv))
+    root = m.setup()
+    want = m.prove(q, num_queries=4, pow_bits=2)
+    # permutation trace of one chip, before and after compiling it
+    shard = lair.Shard.new(q)
+    idx = top.func_index("fib")
+    chip = lair.FuncChip(ctx, idx, top)
+    t = chip.generate_trace(shard, repr=1)
+    td = torch.from_numpy(t.view(np.int32)).cuda()
+    a = air.ChipAir.for_func(top, idx)
+    ch = [3, 1, 4, 1, 5, 9, 2, 6]
+    out0 = torch.zeros((t.shape[0], 4 * a.permutation_width), dtype=torch.int32, device="cuda")
+    a.permutation_trace(ctx, t.shape[0], td, None, ch, out0)
+    a.compile(ctx)
+    out1 = torch.zeros_like(out0)
+    a.permutation_trace(ctx, t.shape[0], td, None, ch, out1)
+    assert torch.equal(out0, out1)
+    # the whole machine compiled
+    for _, _, chip_air in m.chips:
+        chip_air.compile(ctx)
+    got = m.prove(q, num_queries=4, pow_bits=2)
+    m.close()
+    assert len(got) == len(want)
+    for x, y in zip(got, want):
+        assert np.array_equal(x.words, y.words)
+    assert verify(DEMO, "fib", root, got, len(pv))
+
+
 def test_machine_with_extern_chips_proves_and_verifies(ctx):
     """hash3 / hash4 chips (Poseidon2 wide AIR, 493 / 655 columns) called through call / preimg, with the hash queries
     injected the way the reference's setup does (inject_inv_queries, /root/reference/src/lair/execute.rs:299)."""
