@@ -8,6 +8,8 @@
 
 #include <hip/hiprtc.h>
 
+#include <stdlib.h>
+
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -121,7 +123,9 @@ bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* lo
         return false;
     }
     // the ROCm include directory provides <hip/hip_runtime.h> for the embedded headers
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", "-I/opt/rocm/include"};
+    const char* rocm = getenv("ROCM_PATH");
+    const std::string inc = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
+    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
     const hiprtcResult r = hiprtcCompileProgram(p, 5, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;

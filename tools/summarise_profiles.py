@@ -16,7 +16,7 @@ tag = sys.argv[1]
 
 
 def kname(s):
-    m = re.search(r"(k_[a-z_0-9]+)", s)
+    m = re.search(r"(k_[a-z_0-9]+|jit_[a-z_]+)", s)
     return m.group(1) if m else s[:40]
 
 
