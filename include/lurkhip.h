@@ -301,6 +301,9 @@ int32_t lurkhip_air_info(const lurkhip_air* air, uint32_t* info);
  * traces and quotients on this context's device from then on (the interpreter otherwise).  Costs seconds to tens of seconds of
  * host time per chip: for traces of 2^17 rows and more.  No reference counterpart (sphinx evaluates `Air::eval` natively). */
 int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* air);
+/* Generates and compiles the chip's kernels without loading them (no device needed): code object size in bytes, or a negative
+ * error with the compiler's message in log. */
+int32_t lurkhip_air_compile_check(const lurkhip_air* air, char* log, uint32_t log_cap);
 /* The lowered register programs (csrc/air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),
  * 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel.  Returns the word count (copies at
  * most cap words), negative for an unknown program. */

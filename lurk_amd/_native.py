@@ -133,6 +133,7 @@ SIGNATURES = {
     "lurkhip_air_interaction_sizes": (_i32, [_p, _u32p, C.c_uint32]),
     "lurkhip_air_program": (_i32, [_p, _i32, C.c_uint32, _u32p, C.c_uint32]),
     "lurkhip_air_compile": (_i32, [_p, _p]),
+    "lurkhip_air_compile_check": (_i32, [_p, _p, C.c_uint32]),
     "lurkhip_air_eval_rows": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
     "lurkhip_air_check_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.POINTER(C.c_int64), C.POINTER(C.c_int32)]),
     "lurkhip_permutation_trace_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p]),

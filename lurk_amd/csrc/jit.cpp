@@ -110,13 +110,8 @@ bool load_module(const std::vector<char>& code, JitKernels* out, std::string* lo
 }
 }  // namespace
 
-bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log) {
-    const std::string src = jit_source(prog);
-    {
-        std::lock_guard<std::mutex> g(g_cache_mu);
-        auto it = g_code_cache.find(src);
-        if (it != g_code_cache.end()) return load_module(it->second, out, log);
-    }
+namespace {
+bool compile_source(const std::string& src, std::vector<char>* code, std::string* log) {
     hiprtcProgram p = nullptr;
     if (hiprtcCreateProgram(&p, src.c_str(), "lurkhip_air_jit.hip", kJitHeaderCount, kJitHeaderBodies, kJitHeaderNames) != HIPRTC_SUCCESS) {
         if (log) *log = "hiprtcCreateProgram failed";
@@ -138,9 +133,27 @@ bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* lo
     }
     size_t n = 0;
     (void)hiprtcGetCodeSize(p, &n);
-    std::vector<char> code(n);
-    (void)hiprtcGetCode(p, code.data());
+    code->resize(n);
+    (void)hiprtcGetCode(p, code->data());
     (void)hiprtcDestroyProgram(&p);
+    return true;
+}
+}  // namespace
+
+size_t jit_compile_only(const lair::AirPrograms& prog, std::string* log) {
+    std::vector<char> code;
+    return compile_source(jit_source(prog), &code, log) ? code.size() : 0;
+}
+
+bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log) {
+    const std::string src = jit_source(prog);
+    {
+        std::lock_guard<std::mutex> g(g_cache_mu);
+        auto it = g_code_cache.find(src);
+        if (it != g_code_cache.end()) return load_module(it->second, out, log);
+    }
+    std::vector<char> code;
+    if (!compile_source(src, &code, log)) return false;
     if (!load_module(code, out, log)) return false;
     std::lock_guard<std::mutex> g(g_cache_mu);
     g_code_cache.emplace(src, std::move(code));

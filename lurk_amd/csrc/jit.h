@@ -20,5 +20,7 @@ std::string jit_source(const lair::AirPrograms& prog);
 // compiles for gfx950 and loads the module on the current device; on failure returns false and leaves the log in *log
 bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log);
 void jit_release(JitKernels* k);
+// compiles without loading (no device needed): code object size in bytes, 0 on failure (reason in *log)
+size_t jit_compile_only(const lair::AirPrograms& prog, std::string* log);
 
 }  // namespace lurkhip

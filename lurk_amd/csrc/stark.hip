@@ -22,6 +22,8 @@
 #include "commit.h"
 #include "ctx.h"
 #include "lair/air.h"
+#include <string.h>
+
 #include "jit.h"
 #include "lazy_ef.h"
 #include "stark_kernels.h"
@@ -713,6 +715,20 @@ int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* a) {
     std::lock_guard<std::mutex> g(a->mu);
     a->dev.at(ctx->device).jit = k;
     return LURKHIP_OK;
+}
+
+// Generates and compiles the chip's kernels without loading them: no device needed (build / CPU test of the run-time compiler).
+// Returns the code object size in bytes, or a negative error with the compiler's message in `log`.
+int32_t lurkhip_air_compile_check(const lurkhip_air* a, char* log, uint32_t log_cap) {
+    if (!a) return LURKHIP_ERR_INVALID_ARG;
+    std::string l;
+    const size_t n = jit_compile_only(a->prog, &l);
+    if (log && log_cap) {
+        const size_t k = std::min<size_t>(l.size(), log_cap - 1);
+        memcpy(log, l.data(), k);
+        log[k] = 0;
+    }
+    return n ? (int32_t)std::min<size_t>(n, 0x7fffffff) : LURKHIP_ERR_EXEC;
 }
 
 // The lowered register programs (air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),

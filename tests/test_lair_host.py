@@ -137,3 +137,18 @@ def test_air_programs_are_cut_into_interaction_pieces():
     assert info(small)[14] == 1
     none = air.ChipAir.for_poseidon2(16)  # no lookups at all: one empty piece
     assert none.num_sends + none.num_receives == 0 and info(none)[14] == 1
+
+
+def test_air_run_time_compiler_builds_without_a_device():
+    """The run-time compiler of the AIR kernels (csrc/jit.cpp): source generation from the lowered program pieces + hiprtc against
+    the embedded device headers needs no GPU -- a chip with lookups and one without compile to gfx950 code objects here."""
+    import ctypes as C
+
+    from lurk_amd import _native as N
+    from lurk_amd import air
+
+    top = lair.Toplevel(load_cases()[0]["source"])
+    for a in (air.ChipAir.for_func(top, top.func_index("fib")), air.ChipAir.for_mem(4), air.ChipAir.for_poseidon2(16)):
+        log = C.create_string_buffer(8192)
+        size = N.lib.lurkhip_air_compile_check(a.handle, log, 8192)
+        assert size > 1000, (a.name, log.value.decode(errors="replace"))
