@@ -9,7 +9,10 @@
 //
 // All matrices are the committed LDEs: row-major, bit-reversed row order, Montgomery words; extension
 // elements are 4 consecutive words.  Storage row s of a height-M matrix is the point x_s = 31 * w_M^bitrev(s).
+#include <stdlib.h>
+
 #include <algorithm>
+#include <type_traits>
 
 #include "babybear.h"
 #include "commit.h"
@@ -252,21 +255,23 @@ __global__ __launch_bounds__(64) void k_reduce_openings(ReduceArgs a) {
 // into LDS in the same flat order (position e + (e >> 5): one pad word per 32 keeps the row-wise reads of every width off a
 // single bank) and then takes row l: sum_c alpha^c * row[c] in lazily reduced 64-bit lanes (lazy_ef.h; alpha powers
 // centred, 8 words each).  NV = words per lane, >= w.
-template <int NV>
+// BIG: matrices of 4 GiB and more index their words with 64 bits; the others with one 32-bit add and one min per load.
+template <int NV, bool BIG>
 __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
     extern __shared__ uint32_t tile[];
+    using idx_t = typename std::conditional<BIG, size_t, uint32_t>::type;
     const uint32_t lane = threadIdx.x;
     const uint32_t n_tiles = (a.m_rows + 63u) / 64u;
-    const size_t total = (size_t)a.m_rows * a.w;  // words in the matrix
+    const idx_t total = (idx_t)a.m_rows * (idx_t)a.w;  // words in the matrix
     uint32_t v[NV];
     auto fetch = [&](uint32_t t) {
-        const size_t base = (size_t)t * 64u * a.w;
-        const size_t lim = total - 1;
+        const idx_t base = (idx_t)t * 64u * a.w + lane;
+        const idx_t lim = total - 1;
 #pragma unroll
         for (int k = 0; k < NV; k++) {
             // words past the tile (k >= w) or past the matrix re-read a valid word: no branch around a load
             const uint32_t kk = (uint32_t)k < a.w ? (uint32_t)k : a.w - 1u;
-            size_t e = base + (size_t)kk * 64u + lane;
+            idx_t e = base + (idx_t)(kk * 64u);
             e = e < lim ? e : lim;
             v[k] = a.mat[e];
         }
@@ -467,22 +472,27 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
     if (w <= 128 && alpha_pows_centred) {
         ReduceArgs a{mat, w, m_rows, alpha_pows_centred, d0, d1, ys0, ys1, apow0, apow1, ro, 1};
         const uint32_t n_tiles = (m_rows + 63) / 64;
-        auto launch = [&](auto kernel, int nv) {
+        // 4 GiB of words and more: 64-bit word indices; LURKHIP_OPENINGS_FORCE_64BIT (test hook) takes that path at any size
+        const bool big = (size_t)m_rows * w >= ((size_t)1 << 30) || getenv("LURKHIP_OPENINGS_FORCE_64BIT") != nullptr;
+        auto launch = [&](auto kernel, auto kernel_big, int nv) {
             const size_t lds = ((size_t)nv * 66 + 64 + 8) * 4;
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
             const unsigned blocks = (unsigned)std::min<size_t>(n_tiles, (size_t)per_cu * ctx->num_cus);
-            hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, ctx->stream, a);
+            if (big) hipLaunchKernelGGL(kernel_big, dim3(blocks), dim3(64), lds, ctx->stream, a);
+            else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, ctx->stream, a);
         };
-        if (w <= 8) launch(k_reduce_openings_stream<8>, 8);
-        else if (w <= 16) launch(k_reduce_openings_stream<16>, 16);
-        else if (w <= 24) launch(k_reduce_openings_stream<24>, 24);
-        else if (w <= 32) launch(k_reduce_openings_stream<32>, 32);
-        else if (w <= 48) launch(k_reduce_openings_stream<48>, 48);
-        else if (w <= 64) launch(k_reduce_openings_stream<64>, 64);
-        else if (w <= 80) launch(k_reduce_openings_stream<80>, 80);
-        else if (w <= 96) launch(k_reduce_openings_stream<96>, 96);
-        else if (w <= 112) launch(k_reduce_openings_stream<112>, 112);
-        else launch(k_reduce_openings_stream<128>, 128);
+#define LH_RO(NV) launch(k_reduce_openings_stream<NV, false>, k_reduce_openings_stream<NV, true>, NV)
+        if (w <= 8) LH_RO(8);
+        else if (w <= 16) LH_RO(16);
+        else if (w <= 24) LH_RO(24);
+        else if (w <= 32) LH_RO(32);
+        else if (w <= 48) LH_RO(48);
+        else if (w <= 64) LH_RO(64);
+        else if (w <= 80) LH_RO(80);
+        else if (w <= 96) LH_RO(96);
+        else if (w <= 112) LH_RO(112);
+        else LH_RO(128);
+#undef LH_RO
         LH_HIP(ctx, hipGetLastError());
         return LURKHIP_OK;
     }

@@ -118,6 +118,18 @@ def test_sharded_proof_verifies(ctx):
     assert verify(DEMO, "fib", root, proofs, len(pv))
 
 
+def test_openings_64bit_index_kernels(ctx, monkeypatch):
+    """Committed matrices of 4 GiB and more reduce their openings with 64-bit word indices; the test hook takes those
+    kernels at small sizes and the proof must not change."""
+    _, root, want, pv = prove(ctx, DEMO, "fib", [20])
+    monkeypatch.setenv("LURKHIP_OPENINGS_FORCE_64BIT", "1")
+    _, _, got, _ = prove(ctx, DEMO, "fib", [20])
+    assert len(got) == len(want)
+    for a, b in zip(got, want):
+        assert np.array_equal(a.words, b.words)
+    assert verify(DEMO, "fib", root, got, len(pv))
+
+
 def test_pipelined_sharded_proof_equals_sequential(ctx):
     """Two machines on two contexts (two HIP streams) of the one GPU prove the shards of an execution concurrently
     (prover.prove_pipelined): the proofs are those of Machine.prove, shard by shard, and verify."""
