@@ -72,8 +72,14 @@ int32_t merkle_leaves(lurkhip_ctx* ctx, const P16Params* params_dev, const LeafC
 // parents[i] = compress(children[2i], children[2i+1]); if inject_cols: then compress(that, hash(row i))
 int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
                      const LeafCol* inject_cols_dev, uint32_t inject_w, uint32_t* parents);
-// collapses the levels below `n` nodes down to the root inside one workgroup (n <= 2048, no injection)
-int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n);
+// collapses the levels below `n` nodes down to the root inside one workgroup (n <= 2048)
+// matrices injected at the levels merkle_top collapses: entry t describes the rows absorbed into the parents of step t
+// (n >> (t + 1) of them); cols[t] == nullptr where nothing is injected
+struct TopInject {
+    const LeafCol* cols[11];
+    uint32_t w[11];
+};
+int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n, const TopInject& inject);
 
 int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev);
 

@@ -172,12 +172,21 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             if (c->log_h[m] == lh) inject.push_back(m);
         uint32_t* children = c->digests + c->level_off[l - 1] * 8;
         uint32_t* parents = c->digests + c->level_off[l] * 8;
-        const int min_log_h = *std::min_element(c->log_h.begin(), c->log_h.end());
-        if (min_log_h > lh && (n_parents << 1) <= 512) {
-            // nothing left to inject: finish the tree in one workgroup (wider levels are faster spread over the CUs)
+        if ((n_parents << 1) <= 512) {
+            // finish the tree in one workgroup (wider levels are faster spread over the CUs)
+            TopInject ti{};
+            for (int t = 0; l + t <= c->log_max; t++) {
+                std::vector<int> inj;
+                for (int m : order)
+                    if (c->log_h[m] == lh - t) inj.push_back(m);
+                if (inj.empty()) continue;
+                LeafCol* tc = nullptr;
+                LH_TRY(make_cols(ctx, c, inj, &tc, &ti.w[t]));
+                ti.cols[t] = tc;
+            }
             span_end(ctx, "merkle_levels");
             span_begin(ctx, "merkle_top");
-            LH_TRY(merkle_top(ctx, params, children, n_parents << 1));
+            LH_TRY(merkle_top(ctx, params, children, n_parents << 1, ti));
             span_end(ctx, "merkle_top");
             span_begin(ctx, "merkle_levels");
             break;

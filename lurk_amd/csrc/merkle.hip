@@ -25,6 +25,8 @@ namespace lurkhip {
 namespace {
 
 constexpr int MBLOCK = 256;
+// levels of at most this many parents run lane-cooperatively (above it one permutation per lane already fills the SIMDs)
+constexpr size_t COOP_MAX_PARENTS = 16384;
 
 __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
     p2::NoRecord rec;
@@ -93,16 +95,50 @@ __global__ __launch_bounds__(MBLOCK) void k_level(const P16Params* __restrict__ 
     dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// ---- lane-cooperative levels: 16 lanes per parent (p16_coop.h).  A level of a few thousand parents run one per lane is a
+// handful of waves, each a ~5 k-instruction dependent chain (~13 us whatever the level's size); spread over 16 lanes the chain
+// is ~1 k instructions and the level fills the CUs.
+
+// sponge of row `row` of the injected matrices, then compress(node, sponge): lanes 0..7 of the group hold the node on entry
+__device__ __forceinline__ uint32_t coop_inject(uint32_t x, const P16Params* __restrict__ p, const LeafCol* __restrict__ cols,
+                                                uint32_t w, size_t row, int j) {
+    uint32_t t = 0;
+    for (uint32_t c0 = 0; c0 < w; c0 += 8) {
+        if (j < 8 && c0 + j < w) {
+            const LeafCol d = cols[c0 + j];
+            t = d.base[row * d.width + d.col];
+        }
+        t = coop_perm16(t, p, j);
+    }
+    const uint32_t up = dpp<DPP_ROW_ROR8>(t);  // lane j >= 8 reads lane j - 8
+    return coop_perm16(j < 8 ? x : up, p, j);
+}
+
+__global__ __launch_bounds__(MBLOCK) void k_level_coop(const P16Params* __restrict__ p, const uint32_t* __restrict__ children,
+                                                        size_t n_parents, const LeafCol* __restrict__ inject_cols,
+                                                        uint32_t inject_w, uint32_t* __restrict__ parents) {
+    const int j = threadIdx.x & 15;
+    const size_t g = ((size_t)blockIdx.x * MBLOCK + threadIdx.x) >> 4;
+    // every lane of a group runs the permutation (DPP reads need all 16 active): groups past the end redo parent 0
+    const size_t gg = g < n_parents ? g : 0;
+    uint32_t x = coop_perm16(children[gg * 16 + j], p, j);
+    if (inject_cols) x = coop_inject(x, p, inject_cols, inject_w, gg, j);
+    if (g < n_parents && j < 8) parents[g * 8 + j] = x;
+}
+
 // Collapse n (<= 2048, power of two) nodes to the root in one workgroup.  The levels are stored back
-// to back after `level_base` exactly as the multi-launch path would store them.  Wide levels run one
-// permutation per lane; from 128 parents down the permutations are lane-cooperative.
-__global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, uint32_t* __restrict__ level_base, size_t n) {
+// to back after `level_base` exactly as the multi-launch path would store them.  Wide levels without injected matrices
+// run one permutation per lane; from 128 parents down, and wherever rows are injected, the permutations are lane-cooperative.
+__global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, uint32_t* __restrict__ level_base, size_t n,
+                                              TopInject inj) {
     uint32_t* cur = level_base;
     size_t len = n;
+    int lvl = 0;
     while (len > 1) {
         size_t half = len >> 1;
         uint32_t* next = cur + len * 8;
-        if (half > 128) {
+        const LeafCol* icols = inj.cols[lvl];
+        if (half > 128 && !icols) {
             for (size_t i = threadIdx.x; i < half; i += blockDim.x) {
                 uint32_t s[16];
                 load_pair(cur, i, s);
@@ -112,14 +148,12 @@ __global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, u
                 dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
             }
         } else {
-            // parent g = (left || right)[j] over lanes j = 0..15 of a 16-lane group; every lane of the group runs the
-            // permutation (DPP reads need all 16 lanes active), groups beyond `half` work on parent 0 and do not store
             const int j = threadIdx.x & 15;
             for (size_t g0 = 0; g0 < half; g0 += blockDim.x / 16) {
                 const size_t g = g0 + (threadIdx.x >> 4);
                 const size_t gg = g < half ? g : 0;
-                uint32_t x = cur[gg * 16 + j];
-                x = coop_perm16(x, p, j);
+                uint32_t x = coop_perm16(cur[gg * 16 + j], p, j);
+                if (icols) x = coop_inject(x, p, icols, inj.w[lvl], gg, j);
                 if (g < half && j < 8) next[g * 8 + j] = x;
             }
         }
@@ -128,6 +162,7 @@ __global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, u
         __syncthreads();
         cur = next;
         len = half;
+        lvl++;
     }
 }
 
@@ -145,17 +180,23 @@ int32_t merkle_leaves(lurkhip_ctx* ctx, const P16Params* params_dev, const LeafC
 
 int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
                      const LeafCol* inject_cols_dev, uint32_t inject_w, uint32_t* parents) {
-    size_t blocks = (n_parents + MBLOCK - 1) / MBLOCK;
-    hipLaunchKernelGGL(k_level, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents,
-                       inject_cols_dev, inject_w, parents);
+    if (n_parents <= COOP_MAX_PARENTS) {
+        const size_t blocks = (n_parents * 16 + MBLOCK - 1) / MBLOCK;
+        hipLaunchKernelGGL(k_level_coop, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents,
+                           inject_cols_dev, inject_w, parents);
+    } else {
+        const size_t blocks = (n_parents + MBLOCK - 1) / MBLOCK;
+        hipLaunchKernelGGL(k_level, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents,
+                           inject_cols_dev, inject_w, parents);
+    }
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
 
-int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n) {
+int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n, const TopInject& inject) {
     LH_ARG(ctx, n <= 2048 && (n & (n - 1)) == 0, "merkle_top needs a power of two <= 2048");
     if (n <= 1) return LURKHIP_OK;
-    hipLaunchKernelGGL(k_top, dim3(1), dim3(1024), 0, ctx->stream, params_dev, level_base, n);
+    hipLaunchKernelGGL(k_top, dim3(1), dim3(1024), 0, ctx->stream, params_dev, level_base, n, inject);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
