@@ -74,6 +74,24 @@ def test_commit_mixed_heights(ctx, oracle):
     c.close()
 
 
+def test_commit_injection_at_cooperative_levels(ctx, oracle):
+    """Levels of at most 16384 parents hash lane-cooperatively (16 lanes per node), the last 512 nodes inside one workgroup:
+    matrices injected at such levels -- narrow, wider than one sponge block, and as wide as the hash chips -- and at the
+    one-lane-per-node levels above them must give the oracle's tree."""
+    shapes = [(15, 8), (14, 5), (13, 20), (12, 9), (10, 493), (9, 5), (8, 17), (3, 7), (0, 3)]
+    mats = [synth.field_elements((1 << k, w), seed=1500 + i) for i, (k, w) in enumerate(shapes)]
+    c = cm.commit(ctx, mats, log_blowup=1)
+    ldes = [oracle.lde(m, 1) for m in mats]
+    root, _ = oracle.merkle_commit(ldes)
+    assert np.array_equal(c.root, root)
+    lh = [k + 1 for k, _ in shapes]
+    ws = [w for _, w in shapes]
+    for index in (0, 4097, 65535):
+        rows, path = c.open(index)
+        assert oracle.merkle_verify(lh, ws, index, rows, path, c.root)
+    c.close()
+
+
 def test_commit_buffer_reuse_across_shapes(ctx, oracle):
     """The pooled allocator hands a released LDE buffer to the next commit of the same byte size, and the context caches the
     Merkle leaf-column tables and the coset-shift power tables by (pointer, width) / (height, shift): commits of different
