@@ -21,6 +21,10 @@ struct lurkhip_ctx {
     // grow-only scratch arenas for the host-pointer entry points
     void* arena[4] = {nullptr, nullptr, nullptr, nullptr};
     size_t arena_bytes[4] = {0, 0, 0, 0};
+    // grow-only page-locked host buffer for the prover's read-backs (host_staging): copies into it are stream-ordered and
+    // do not bounce through the runtime's own staging
+    void* host_stage = nullptr;
+    size_t host_stage_bytes = 0;
     // lazily created per-ctx device state owned by other translation units (commit.h)
     void* merkle_params_dev = nullptr;
     void* merkle_params_host = nullptr;  // P16Params copy for the host-side challenger
@@ -56,6 +60,8 @@ namespace lurkhip {
 int32_t set_error(lurkhip_ctx* ctx, int32_t code, const char* fmt, ...);
 // returns a device buffer of at least `bytes` from scratch slot `slot` (grown on demand)
 int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out);
+// page-locked host buffer of at least `bytes` (grown on demand; the previous contents are dropped, the stream is drained first)
+int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out);
 // pooled device allocations: released blocks are kept and reused for later requests of the same size
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
 void pool_release(lurkhip_ctx* ctx, void* ptr);

@@ -41,6 +41,23 @@ int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out) {
     return LURKHIP_OK;
 }
 
+int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out) {
+    if (bytes == 0) bytes = 16;
+    if (ctx->host_stage_bytes < bytes) {
+        if (ctx->host_stage) {
+            LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+            LH_HIP(ctx, hipHostFree(ctx->host_stage));
+            ctx->host_stage = nullptr;
+            ctx->host_stage_bytes = 0;
+        }
+        const size_t want = bytes + bytes / 4;
+        LH_HIP(ctx, hipHostMalloc(&ctx->host_stage, want, hipHostMallocDefault));
+        ctx->host_stage_bytes = want;
+    }
+    *out = ctx->host_stage;
+    return LURKHIP_OK;
+}
+
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
     // most recently released block of this size first (LIFO): a proof's sequence of allocations then lands in the same buffers
@@ -194,6 +211,7 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
     for (int i = 0; i < 4; i++)
         if (ctx->arena[i]) (void)hipFree(ctx->arena[i]);
+    if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);

@@ -31,7 +31,7 @@ struct DevChallenger {
     uint32_t n_in, n_out;
 };
 // observes the 8-word digest at root_dev and samples one extension element into beta_dev, all on the context's stream
-int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev);
+int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev, uint32_t* root_copy_dev);
 // smallest canonical witness w such that a challenger whose permutation input is `state` (pending inputs already
 // written over lanes [0, n_pending)) samples `bits` zero bits after observing w
 int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, uint32_t* witness);

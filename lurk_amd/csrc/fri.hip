@@ -332,10 +332,12 @@ __global__ __launch_bounds__(256) void k_fri_fold(const uint32_t* __restrict__ c
 // by 16 lanes and permuted cooperatively (p16_coop.h).  The host uploads its transcript state before the first layer and
 // reads it back after the last one, so the 21 root read-backs and host permutations of a proof leave the chain.
 __global__ __launch_bounds__(64) void k_fri_challenge(const P16Params* __restrict__ p, DevChallenger* __restrict__ ch,
-                                                      const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out) {
+                                                      const uint32_t* __restrict__ root, uint32_t* __restrict__ beta_out,
+                                                      uint32_t* __restrict__ root_copy) {
     __shared__ DevChallenger c;
     const int lane = threadIdx.x, j = lane & 15;
     if (lane == 0) c = *ch;
+    if (root_copy && lane < 8) root_copy[lane] = root[lane];  // the proof's copy of the root, read back once for all layers
     __syncthreads();
     auto duplex = [&]() {
         uint32_t x = (uint32_t)j < c.n_in ? c.input[j & 7] : c.state[j];
@@ -513,10 +515,10 @@ int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint3
     return LURKHIP_OK;
 }
 
-int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev) {
+int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev, uint32_t* root_copy_dev) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
-    hipLaunchKernelGGL(k_fri_challenge, dim3(1), dim3(64), 0, ctx->stream, params, ch_dev, root_dev, beta_dev);
+    hipLaunchKernelGGL(k_fri_challenge, dim3(1), dim3(64), 0, ctx->stream, params, ch_dev, root_dev, beta_dev, root_copy_dev);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

@@ -284,7 +284,8 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     }
     // cumulative sums: last element of each trace, one batched read
     {
-        std::vector<uint32_t> cs(n_chips * 4);
+        uint32_t* cs = nullptr;  // page-locked: the copies queue up behind the kernels without a host round trip each
+        PTRY(host_staging(ctx, (size_t)n_chips * 16, (void**)&cs));
         for (int i = 0; i < n_chips; i++) {
             const size_t h = (size_t)1 << sh->log_n[i];
             PHIP(hipMemcpyAsync(&cs[4 * i], perm[i] + h * perm_widths[i] - 4, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -507,6 +508,8 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     uint32_t* betas_dev = nullptr;
     PTRY(palloc(sizeof(DevChallenger), (uint32_t**)&ch_dev));
     PTRY(palloc((size_t)std::max(n_layers, 1) * 16, &betas_dev));
+    uint32_t* roots_dev = nullptr;  // the layer roots, copied by k_fri_challenge as it observes them
+    PTRY(palloc((size_t)std::max(n_layers, 1) * 32, &roots_dev));
     PHIP(hipMemcpyAsync(ch_dev, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
     PHIP(hipStreamSynchronize(ctx->stream));  // hc is a stack object
     for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
@@ -515,7 +518,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
         to_free.push_back(lc);
         layers.push_back(lc);
         const uint32_t* root_dev = lc->digests + lc->level_off[lc->log_max] * 8;
-        PTRY(fri_challenge(ctx, ch_dev, root_dev, betas_dev + 4 * li));
+        PTRY(fri_challenge(ctx, ch_dev, root_dev, betas_dev + 4 * li, roots_dev + 8 * li));
         uint32_t* next = nullptr;
         PTRY(palloc(((size_t)16) << log_folded, &next));
         PTRY(fri_fold(ctx, current, log_folded + 1, betas_dev + 4 * li, ro[log_folded], next));
@@ -523,13 +526,19 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     }
     std::vector<uint32_t> fin((size_t)4 << log_blowup);
     layer_roots_m.resize((size_t)layers.size() * 8);
-    for (size_t li = 0; li < layers.size(); li++) {
-        const lurkhip_commitment* lc = layers[li];
-        PHIP(hipMemcpyAsync(&layer_roots_m[8 * li], lc->digests + lc->level_off[lc->log_max] * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    {
+        // one page-locked block: [roots | transcript state | final polynomial]
+        const size_t b_roots = layer_roots_m.size() * 4, o_hc = (b_roots + 15) & ~(size_t)15, o_fin = o_hc + ((sizeof hc + 15) & ~(size_t)15);
+        uint8_t* st = nullptr;
+        PTRY(host_staging(ctx, o_fin + fin.size() * 4, (void**)&st));
+        if (b_roots) PHIP(hipMemcpyAsync(st, roots_dev, b_roots, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(hipMemcpyAsync(st + o_hc, ch_dev, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(hipMemcpyAsync(st + o_fin, current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(hipStreamSynchronize(ctx->stream));
+        memcpy(layer_roots_m.data(), st, b_roots);
+        memcpy(&hc, st + o_hc, sizeof hc);
+        memcpy(fin.data(), st + o_fin, fin.size() * 4);
     }
-    PHIP(hipMemcpyAsync(&hc, ch_dev, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
-    PHIP(hipMemcpyAsync(fin.data(), current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PHIP(hipStreamSynchronize(ctx->stream));
     memcpy(ch.state, hc.state, sizeof hc.state);
     ch.input.assign(hc.input, hc.input + hc.n_in);
     ch.output.assign(hc.output, hc.output + hc.n_out);
@@ -561,37 +570,46 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     PTRY(palloc((size_t)num_queries * 4, &indices_dev));
     PHIP(hipMemcpyAsync(indices_dev, indices.data(), (size_t)num_queries * 4, hipMemcpyHostToDevice, ctx->stream));
     PHIP(hipStreamSynchronize(ctx->stream));
-    // input rounds
-    std::vector<std::vector<uint32_t>> round_records(rounds.size());
-    std::vector<uint32_t> round_record_words(rounds.size());
+    // every record of every round and layer goes to one device buffer and comes back in one copy
+    std::vector<uint32_t> round_record_words(rounds.size()), layer_record_words(layers.size());
+    std::vector<std::vector<OpenMat>> round_mats(rounds.size());
+    size_t rec_words = 0;
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const lurkhip_commitment* c = rounds[ri].c;
-        std::vector<OpenMat> om;
-        for (int m = 0; m < c->n_mats; m++) om.push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m]});
-        uint32_t rw = 0;
-        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &rw));
-        uint32_t* buf = nullptr;
-        PTRY(palloc((size_t)num_queries * rw * 4, &buf));
-        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)(log_max - c->log_max), buf, &rw));
-        round_records[ri].resize((size_t)num_queries * rw);
-        round_record_words[ri] = rw;
-        PHIP(hipMemcpyAsync(round_records[ri].data(), buf, round_records[ri].size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        for (int m = 0; m < c->n_mats; m++) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m]});
+        PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &round_record_words[ri]));
+        rec_words += (size_t)num_queries * round_record_words[ri];
     }
-    std::vector<std::vector<uint32_t>> layer_records(layers.size());
-    std::vector<uint32_t> layer_record_words(layers.size());
     for (size_t li = 0; li < layers.size(); li++) {
         const lurkhip_commitment* c = layers[li];
-        std::vector<OpenMat> om{OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}};
-        uint32_t rw = 0;
-        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &rw));
-        uint32_t* buf = nullptr;
-        PTRY(palloc((size_t)num_queries * rw * 4, &buf));
-        // index_i = index >> li, pair = index_i >> 1
-        PTRY(gather_openings(ctx, om, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)li + 1, buf, &rw));
-        layer_records[li].resize((size_t)num_queries * rw);
-        layer_record_words[li] = rw;
-        PHIP(hipMemcpyAsync(layer_records[li].data(), buf, layer_records[li].size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0,
+                             nullptr, &layer_record_words[li]));
+        rec_words += (size_t)num_queries * layer_record_words[li];
     }
+    uint32_t* rec_dev = nullptr;
+    PTRY(palloc(std::max<size_t>(rec_words, 4) * 4, &rec_dev));
+    std::vector<size_t> round_off(rounds.size()), layer_off(layers.size());
+    size_t rec_at = 0;
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        const lurkhip_commitment* c = rounds[ri].c;
+        uint32_t rw = 0;
+        round_off[ri] = rec_at;
+        PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)(log_max - c->log_max),
+                             rec_dev + rec_at, &rw));
+        rec_at += (size_t)num_queries * rw;
+    }
+    for (size_t li = 0; li < layers.size(); li++) {
+        const lurkhip_commitment* c = layers[li];
+        uint32_t rw = 0;
+        layer_off[li] = rec_at;
+        // index_i = index >> li, pair = index_i >> 1
+        PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries,
+                             (uint32_t)li + 1, rec_dev + rec_at, &rw));
+        rec_at += (size_t)num_queries * rw;
+    }
+    const uint32_t* rec_host = nullptr;
+    PTRY(host_staging(ctx, std::max<size_t>(rec_words, 4) * 4, (void**)&rec_host));
+    if (rec_words) PHIP(hipMemcpyAsync((void*)rec_host, rec_dev, rec_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHIP(hipStreamSynchronize(ctx->stream));
     span_end(ctx, "fri_query");
 
@@ -619,13 +637,16 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     push_ef(o, final_poly);
     o.push_back(pow_witness);
     for (uint32_t ix : indices) o.push_back(ix);
+    o.reserve(o.size() + rec_words + rounds.size() + layers.size());
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         o.push_back(round_record_words[ri]);
-        for (uint32_t v : round_records[ri]) o.push_back(bb::from_monty(v));
+        const size_t n = (size_t)num_queries * round_record_words[ri];
+        for (size_t k = 0; k < n; k++) o.push_back(bb::from_monty(rec_host[round_off[ri] + k]));
     }
     for (size_t li = 0; li < layers.size(); li++) {
         o.push_back(layer_record_words[li]);
-        for (uint32_t v : layer_records[li]) o.push_back(bb::from_monty(v));
+        const size_t n = (size_t)num_queries * layer_record_words[li];
+        for (size_t k = 0; k < n; k++) o.push_back(bb::from_monty(rec_host[layer_off[li] + k]));
     }
     cleanup();
 #undef PTRY
