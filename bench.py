@@ -84,6 +84,7 @@ def main():
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-spans", action="store_true", help="diagnostic: no per-stage HIP events in the timed region (stages_ms and roofline read 0)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra two-shards-in-flight measurement")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
     args = ap.parse_args()
@@ -164,7 +165,7 @@ def main():
         step()
     fence()
     ctx.profile_reset()
-    ctx.profile_enable(True)
+    ctx.profile_enable(not args.no_spans)
     t0 = time.perf_counter()
     words = None
     for _ in range(args.steps):

@@ -161,8 +161,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     LH_TRY(make_cols(ctx, c, tallest, &cols, &tw));
     span_begin(ctx, "merkle_leaves");
     LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
-    span_end(ctx, "merkle_leaves");
-    span_begin(ctx, "merkle_levels");
+    const char* stage = "merkle_leaves";  // the span that is open
     // inner levels
     for (int l = 1; l <= c->log_max; l++) {
         const size_t n_parents = n_leaves >> l;
@@ -184,19 +183,21 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
                 LH_TRY(make_cols(ctx, c, inj, &tc, &ti.w[t]));
                 ti.cols[t] = tc;
             }
-            span_end(ctx, "merkle_levels");
-            span_begin(ctx, "merkle_top");
+            span_switch(ctx, stage, "merkle_top");
+            stage = "merkle_top";
             LH_TRY(merkle_top(ctx, params, children, n_parents << 1, ti));
-            span_end(ctx, "merkle_top");
-            span_begin(ctx, "merkle_levels");
             break;
         }
         LeafCol* icols = nullptr;
         uint32_t iw = 0;
         if (!inject.empty()) LH_TRY(make_cols(ctx, c, inject, &icols, &iw));
+        if (l == 1) {
+            span_switch(ctx, stage, "merkle_levels");
+            stage = "merkle_levels";
+        }
         LH_TRY(merkle_level(ctx, params, children, n_parents, icols, iw, parents));
     }
-    span_end(ctx, "merkle_levels");
+    span_end(ctx, stage);
     return LURKHIP_OK;
 }
 
@@ -266,6 +267,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                                   "%s failed: %s", #expr, hipGetErrorString(e__)));                     \
     } while (0)
 
+    span_begin(ctx, "lde");  // one span for the matrices of the commitment (with host inputs it includes their uploads)
     for (int i = 0; i < n_mats; i++) {
         const int log_n = (int)log_heights[i];
         const int w = (int)widths[i];
@@ -289,16 +291,15 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         if (log_blowup >= 1) scratch = c->lde[i];
         else TRY_C(arena_get(ctx, 1, bytes, &scratch));
         TRY_C(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
-        span_begin(ctx, "lde");
         TRY_C(interpolate(ctx, log_n, w, src, repr == LURKHIP_REPR_CANONICAL, (uint32_t*)scratch, coef));
         TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false,
                      bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN)));
-        span_end(ctx, "lde");
         if (!keep_coeffs) {
             pool_release(ctx, coef);  // stream-ordered: only later work can reuse it
             c->coeffs[i] = nullptr;
         }
     }
+    span_end(ctx, "lde");
     TRY_C(build_tree(ctx, c));
     if (root) {
         uint32_t r[8];

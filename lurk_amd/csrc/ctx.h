@@ -68,6 +68,7 @@ void pool_release(lurkhip_ctx* ctx, void* ptr);
 // span timing (no-ops unless profiling is enabled)
 void span_begin(lurkhip_ctx* ctx, const char* name);
 void span_end(lurkhip_ctx* ctx, const char* name);
+void span_switch(lurkhip_ctx* ctx, const char* from, const char* to);  // span_end(from) + span_begin(to) on one event
 
 }  // namespace lurkhip
 

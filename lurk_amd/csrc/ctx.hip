@@ -3,6 +3,8 @@
 
 #include "ctx.h"
 
+#include <set>
+
 #include <cstring>
 
 namespace lurkhip {
@@ -129,8 +131,24 @@ void span_end(lurkhip_ctx* ctx, const char* name) {
     (void)hipEventRecord(sp.pending.back().second, ctx->stream);
 }
 
+// ends `from` and begins `to` on one event: back-to-back spans (the stages of a Merkle tree) cost one record, not two --
+// every record is a marker packet the next kernel waits behind
+void span_switch(lurkhip_ctx* ctx, const char* from, const char* to) {
+    if (!ctx->profiling) return;
+    auto& f = ctx->spans[from];
+    if (f.pending.empty()) {
+        span_begin(ctx, to);
+        return;
+    }
+    hipEvent_t e = f.pending.back().second;
+    (void)hipEventRecord(e, ctx->stream);
+    hipEvent_t b = get_event(ctx);
+    ctx->spans[to].pending.push_back({e, b});
+}
+
 static void spans_resolve(lurkhip_ctx* ctx) {
     (void)hipStreamSynchronize(ctx->stream);
+    std::set<hipEvent_t> used;  // an event shared by two spans (span_switch) returns to the pool once
     for (auto& kv : ctx->spans) {
         for (auto& pr : kv.second.pending) {
             float ms = 0;
@@ -138,11 +156,12 @@ static void spans_resolve(lurkhip_ctx* ctx) {
                 kv.second.total_ms += ms;
                 kv.second.count += 1;
             }
-            ctx->event_pool.push_back(pr.first);
-            ctx->event_pool.push_back(pr.second);
+            used.insert(pr.first);
+            used.insert(pr.second);
         }
         kv.second.pending.clear();
     }
+    for (hipEvent_t e : used) ctx->event_pool.push_back(e);
 }
 
 static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkhip_ctx** out) {

@@ -476,8 +476,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         }
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
-    span_end(ctx, "perm_rows");
-    span_begin(ctx, "perm_scan");
+    span_switch(ctx, "perm_rows", "perm_scan");
     if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)perm_w * 4, height);
     span_end(ctx, "perm_scan");
     pool_release(ctx, pows);
