@@ -37,8 +37,9 @@ with open("profiles/r01_pmc_hbm_per_kernel.csv", "w") as f:
     f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
     for k in sorted(res["FETCH_SIZE"][0], key=lambda k: -(res["FETCH_SIZE"][0][k] + res["WRITE_SIZE"][0][k])):
         f.write(f"{k},{res['FETCH_SIZE'][1][k]},{res['FETCH_SIZE'][0][k]:.0f},{res['WRITE_SIZE'][0][k]:.0f}\n")
-F = (res["FETCH_SIZE"][0]["k_level"] + res["FETCH_SIZE"][0]["k_leaves"]) * 1024
-W = (res["WRITE_SIZE"][0]["k_level"] + res["WRITE_SIZE"][0]["k_leaves"]) * 1024
+HASH = ("k_level", "k_level_coop", "k_leaves")  # the launches inside bench.py's merkle_leaves + merkle_levels spans
+F = sum(res["FETCH_SIZE"][0][k] for k in HASH) * 1024
+W = sum(res["WRITE_SIZE"][0][k] for k in HASH) * 1024
 
 tot, dur, cnt, seen = collections.defaultdict(collections.Counter), collections.Counter(), collections.Counter(), set()
 with open(f"gpurun_out/pmc_{tag}_sq/bench_counter_collection.csv") as f:
@@ -57,7 +58,7 @@ with open("profiles/r01_pmc_sq_per_kernel.csv", "w") as f:
         v = tot[n]
         rate = v["SQ_INSTS_VALU"] * 64 / (dur[n] * 1e-9) / 1e12 if dur[n] else 0
         f.write(f"{n},{cnt[n]},{dur[n] / 1e6:.3f}," + ",".join(f"{v[c]:.4g}" for c in cols) + f",{rate:.2f}\n")
-hv = (tot["k_level"]["SQ_INSTS_VALU"] + tot["k_leaves"]["SQ_INSTS_VALU"]) * 64 / ((dur["k_level"] + dur["k_leaves"]) * 1e-9) / 1e12
+hv = sum(tot[k]["SQ_INSTS_VALU"] for k in HASH) * 64 / (sum(dur[k] for k in HASH) * 1e-9) / 1e12
 json.dump({"log_rows": 20, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (profiles/r01_pmc_hbm_per_kernel.csv)",
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
            "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
