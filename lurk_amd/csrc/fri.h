@@ -16,6 +16,24 @@ int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, ui
 // out_dev[p][c] = sum_{s < n_rows} mat[s][c] * u_p[s]  (p = 0, and 1 when u1 != null); out is [2][w][4] words
 int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
                    uint32_t* out_dev);
+// reduced openings of the narrow matrices of one height in one launch (fri.hip: k_reduce_openings_narrow)
+constexpr uint32_t NARROW_MAX_W = 16, NARROW_MAX_MATS = 16;
+struct NarrowMat {
+    const uint32_t* mat;
+    uint32_t w;
+    uint32_t two;  // opened at both points (else only at the first)
+    bb::ef ys0, ys1, apow0, apow1;
+};
+struct NarrowArgs {
+    NarrowMat m[NARROW_MAX_MATS];
+    uint32_t n_mats;
+    uint32_t m_rows;
+    const uint32_t* alpha_pows;  // centred table (k_ef_powers)
+    const uint32_t* d0;
+    const uint32_t* d1;  // nullable: no matrix of the group is opened at a second point
+    uint32_t* ro;
+};
+int32_t reduce_openings_narrow(lurkhip_ctx* ctx, const NarrowArgs& args);
 // ro[s] += apow0 * (rr_s - ys0) * d0[s] (+ apow1 * (rr_s - ys1) * d1[s]),  rr_s = sum_c alpha_pows[c] * mat[s][c]
 int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
                         const uint32_t* alpha_pows_centred /* 8 words per power (ef_powers centred), or null */, const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,

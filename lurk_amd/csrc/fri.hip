@@ -307,6 +307,45 @@ __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
     }
 }
 
+// Narrow matrices (w <= NARROW_MAX_W: memory tables, quotient chunks, the callee chip's permutation trace) of one height in one
+// launch.  Per row their own words are a few bytes next to the 64 bytes of d0 / d1 / ro traffic and the four extension products of
+// the tail, so one launch per matrix is bound by the tail: here a lane owns a row, walks the matrices
+//   G_p += apow_p[m] * (sum_c alpha^c mat_m[s][c] - ys_p[m])
+// and touches d0, d1, ro once: ro[s] += G_0 d0[s] + G_1 d1[s].
+__global__ __launch_bounds__(256) void k_reduce_openings_narrow(NarrowArgs a) {
+    const uint32_t s = blockIdx.x * 256u + threadIdx.x;
+    if (s >= a.m_rows) return;
+    const uint32_t* __restrict__ ap = a.alpha_pows;
+    ef g0 = bb::ef_zero(), g1 = bb::ef_zero();
+    for (uint32_t m = 0; m < a.n_mats; m++) {
+        const NarrowMat& nm = a.m[m];
+        const uint32_t w = nm.w;
+        const uint32_t* __restrict__ row = nm.mat + (size_t)s * w;
+        LazyEf rr;
+        rr.zero();
+        for (uint32_t c0 = 0; c0 < w; c0 += 4) {
+            // four words per trip go out together; words past the row re-read its last one and are not accumulated
+            uint32_t v[4];
+#pragma unroll
+            for (int k = 0; k < 4; k++) v[k] = row[c0 + k < w ? c0 + k : w - 1];
+#pragma unroll
+            for (int k = 0; k < 4; k++)
+                if (c0 + k < w) {
+                    int32_t pw[8];
+                    load_w8(pw, ap + 8 * (c0 + k));
+                    rr.add_base(v[k], pw);
+                }
+        }
+        const ef r = rr.value();
+        g0 = bb::ef_add(g0, bb::ef_mul(nm.apow0, bb::ef_sub(r, nm.ys0)));
+        if (nm.two) g1 = bb::ef_add(g1, bb::ef_mul(nm.apow1, bb::ef_sub(r, nm.ys1)));
+    }
+    ef acc = ef_load(a.ro + 4 * (size_t)s);
+    acc = bb::ef_add(acc, bb::ef_mul(g0, ef_load(a.d0 + 4 * (size_t)s)));
+    if (a.d1) acc = bb::ef_add(acc, bb::ef_mul(g1, ef_load(a.d1 + 4 * (size_t)s)));
+    ef_store(a.ro + 4 * (size_t)s, acc);
+}
+
 // ---------------------------------------------------------------- FRI fold (p3 fold_even_odd)
 // out[j] = (1/2 + beta/2 * ginv^bitrev(j)) e[2j] + (1/2 - beta/2 * ginv^bitrev(j)) e[2j+1]  (+ add[j]),
 // ginv = (generator of the size-len subgroup)^-1; len = 2^log_len
@@ -502,6 +541,13 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
     const bool staged = lds <= 64 * 1024;
     ReduceArgs a{mat, w, m_rows, alpha_pows, d0, d1, ys0, ys1, apow0, apow1, ro, staged ? 1 : 0};
     hipLaunchKernelGGL(k_reduce_openings, dim3((m_rows + 63) / 64), dim3(64), staged ? lds : 0, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t reduce_openings_narrow(lurkhip_ctx* ctx, const NarrowArgs& a) {
+    if (a.n_mats == 0) return LURKHIP_OK;
+    hipLaunchKernelGGL(k_reduce_openings_narrow, dim3((a.m_rows + 255) / 256), dim3(256), 0, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

@@ -448,6 +448,13 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     // phase 2: opened values on the host, then the reduced openings of every matrix
     // opened values, per round, per matrix, per point: ys[c] (Montgomery)
     std::vector<std::vector<std::vector<std::vector<ef>>>> opened(rounds.size());
+    // narrow matrices wait per (height, first point) and go out together (fri.hip: k_reduce_openings_narrow)
+    std::map<std::pair<int, int>, NarrowArgs> narrow;
+    auto flush_narrow = [&](NarrowArgs& g) -> int32_t {
+        const int32_t st = reduce_openings_narrow(ctx, g);
+        g.n_mats = 0;
+        return st;
+    };
     size_t mat_k = 0;
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const Round& r = rounds[ri];
@@ -483,10 +490,20 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
             if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
             const ef apow0 = ef_pow_host(alpha_fri, num_reduced[log_h]);
             const ef apow1 = ef_pow_host(alpha_fri, num_reduced[log_h] + w);
-            PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
+            if (w <= NARROW_MAX_W && alpha_pows_c) {
+                NarrowArgs& g = narrow[{log_h, mp[0]}];
+                if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
+                if (g.n_mats == 0) g = NarrowArgs{{}, 0, 1u << log_h, alpha_pows_c, d0, nullptr, ro[log_h]};
+                if (d1) g.d1 = d1;  // one second point per height (the first point's successor on that domain)
+                g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1};
+                if (g.n_mats == NARROW_MAX_MATS) PTRY(flush_narrow(g));
+            } else {
+                PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
+            }
             num_reduced[log_h] += (uint64_t)mp.size() * w;
         }
     }
+    for (auto& kv : narrow) PTRY(flush_narrow(kv.second));
     span_end(ctx, "open");
 
     // ---- FRI commit phase
