@@ -8,6 +8,7 @@
 
 #include <hip/hiprtc.h>
 
+#include <stdio.h>
 #include <stdlib.h>
 
 #include <map>
@@ -22,7 +23,9 @@ namespace lurkhip {
 namespace {
 
 // one program (classic 2-word encoding, compact interaction ops included) -> a function template over the sink
-void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, const std::string& name) {
+// `batch` > 0: the program is an interaction piece that starts at a batch boundary; every IEND then names its position in the
+// batch and whether it closes it (sink.iend_at<POS, LAST>), so the sink's batch bookkeeping folds away at compile time
+void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, const std::string& name, uint32_t batch) {
     const uint32_t n = prog[airp::H_N_INSTR];
     const uint32_t* code = prog.data() + prog[airp::H_CODE_OFF];
     const uint32_t* consts = prog.data() + prog[airp::H_CONST_OFF];
@@ -41,6 +44,8 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
         }
     };
     o << "template <class Sink> __device__ __forceinline__ void " << name << "(const airvm::Sources& s, Sink& sink) {\n";
+    uint32_t n_ends = 0, seen_ends = 0;
+    for (uint32_t i = 0; i < n; i++) n_ends += (code[2 * i] & 0xffu) == airp::OP_IEND;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
         const uint32_t op = w0 & 0xffu, dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
@@ -52,7 +57,17 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
             case airp::OP_ASSERT: o << "    sink.assert_zero(" << operand(a) << ");\n"; break;
             case airp::OP_IBEGIN: o << "    sink.ibegin(" << dst << "u, " << (a ? "true" : "false") << ", " << b << "u);\n"; break;
             case airp::OP_IVAL: o << "    sink.ival(" << operand(a) << ");\n"; break;
-            case airp::OP_IEND: o << "    sink.iend(" << operand(a) << ");\n"; break;
+            case airp::OP_IEND:
+                if (batch) {
+                    // the last batch of the chip may be partial: the kernel body flushes it after the piece
+                    const uint32_t pos = seen_ends % batch;
+                    const bool last = pos + 1 == batch;
+                    o << "    sink.template iend_at<" << (pos < 2 ? pos : 2u) << ", " << (last ? "true" : "false") << ">(" << operand(a) << ");\n";
+                    seen_ends++;
+                } else {
+                    o << "    sink.iend(" << operand(a) << ");\n";
+                }
+                break;
             case airp::OP_IVALS: o << "    sink.ival_run(s.main_l + " << a << ", " << b << "u, " << dst << "u);\n"; break;
             case airp::OP_IVALT: o << "    sink.ival_at(" << operand(a) << ", " << dst << "u);\n"; break;
             default: break;  // OP_NOP padding
@@ -71,18 +86,18 @@ void emit_runner(std::ostringstream& o, const std::string& name, const std::vect
 
 }  // namespace
 
-std::string jit_source(const lair::AirPrograms& prog) {
+std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     std::ostringstream o;
-    o << "#include \"stark_kernels.h\"\nnamespace lurkhip {\n";
+    o << "#define LURKHIP_COMPILED_AIR 1\n#include \"stark_kernels.h\"\nnamespace lurkhip {\n";
     std::vector<std::string> perm, quot{"quot_cons"};
     for (size_t j = 0; j < prog.interaction_parts.size(); j++) {
         perm.push_back("perm_piece" + std::to_string(j));
-        emit_function(o, prog.interaction_parts[j], perm.back());
+        emit_function(o, prog.interaction_parts[j], perm.back(), batch);
     }
-    emit_function(o, prog.constraints, "quot_cons");
+    emit_function(o, prog.constraints, "quot_cons", 0);
     for (size_t j = 0; j < prog.interaction_parts_coarse.size(); j++) {
         quot.push_back("quot_piece" + std::to_string(j));
-        emit_function(o, prog.interaction_parts_coarse[j], quot.back());
+        emit_function(o, prog.interaction_parts_coarse[j], quot.back(), batch);
     }
     emit_runner(o, "JitPermRunner", perm);
     emit_runner(o, "JitQuotRunner", quot);
@@ -136,17 +151,28 @@ bool compile_source(const std::string& src, std::vector<char>* code, std::string
     code->resize(n);
     (void)hiprtcGetCode(p, code->data());
     (void)hiprtcDestroyProgram(&p);
+    // debugging aid: LURKHIP_JIT_DUMP=<prefix> keeps the last generated source and code object (<prefix>.hip / <prefix>.co)
+    if (const char* dump = getenv("LURKHIP_JIT_DUMP")) {
+        if (FILE* f = fopen((std::string(dump) + ".hip").c_str(), "w")) {
+            fwrite(src.data(), 1, src.size(), f);
+            fclose(f);
+        }
+        if (FILE* f = fopen((std::string(dump) + ".co").c_str(), "wb")) {
+            fwrite(code->data(), 1, code->size(), f);
+            fclose(f);
+        }
+    }
     return true;
 }
 }  // namespace
 
-size_t jit_compile_only(const lair::AirPrograms& prog, std::string* log) {
+size_t jit_compile_only(const lair::AirPrograms& prog, uint32_t batch, std::string* log) {
     std::vector<char> code;
-    return compile_source(jit_source(prog), &code, log) ? code.size() : 0;
+    return compile_source(jit_source(prog, batch), &code, log) ? code.size() : 0;
 }
 
-bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log) {
-    const std::string src = jit_source(prog);
+bool jit_compile(const lair::AirPrograms& prog, uint32_t batch, JitKernels* out, std::string* log) {
+    const std::string src = jit_source(prog, batch);
     {
         std::lock_guard<std::mutex> g(g_cache_mu);
         auto it = g_code_cache.find(src);

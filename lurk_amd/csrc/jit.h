@@ -16,11 +16,11 @@ struct JitKernels {
 };
 
 // C++ source of the two kernels for these programs (stark_kernels.h bodies with a generated runner)
-std::string jit_source(const lair::AirPrograms& prog);
+std::string jit_source(const lair::AirPrograms& prog, uint32_t batch);
 // compiles for gfx950 and loads the module on the current device; on failure returns false and leaves the log in *log
-bool jit_compile(const lair::AirPrograms& prog, JitKernels* out, std::string* log);
+bool jit_compile(const lair::AirPrograms& prog, uint32_t batch, JitKernels* out, std::string* log);
 void jit_release(JitKernels* k);
 // compiles without loading (no device needed): code object size in bytes, 0 on failure (reason in *log)
-size_t jit_compile_only(const lair::AirPrograms& prog, std::string* log);
+size_t jit_compile_only(const lair::AirPrograms& prog, uint32_t batch, std::string* log);
 
 }  // namespace lurkhip

@@ -710,7 +710,7 @@ int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* a) {
     }
     JitKernels k;
     std::string log;
-    if (!jit_compile(a->prog, &k, &log)) return set_error(ctx, LURKHIP_ERR_EXEC, "compiling %s failed: %s", a->air.name.c_str(), log.c_str());
+    if (!jit_compile(a->prog, 1u << a->air.log_quotient_degree(), &k, &log)) return set_error(ctx, LURKHIP_ERR_EXEC, "compiling %s failed: %s", a->air.name.c_str(), log.c_str());
     std::lock_guard<std::mutex> g(a->mu);
     a->dev.at(ctx->device).jit = k;
     return LURKHIP_OK;
@@ -721,7 +721,7 @@ int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* a) {
 int32_t lurkhip_air_compile_check(const lurkhip_air* a, char* log, uint32_t log_cap) {
     if (!a) return LURKHIP_ERR_INVALID_ARG;
     std::string l;
-    const size_t n = jit_compile_only(a->prog, &l);
+    const size_t n = jit_compile_only(a->prog, 1u << a->air.log_quotient_degree(), &l);
     if (log && log_cap) {
         const size_t k = std::min<size_t>(l.size(), log_cap - 1);
         memcpy(log, l.data(), k);

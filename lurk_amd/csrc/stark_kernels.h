@@ -13,6 +13,16 @@ using bb::ef;
 
 __device__ __forceinline__ ef ef_load(const uint32_t* p) { return ef{{p[0], p[1], p[2], p[3]}}; }
 
+// A compiled chip (jit.cpp) repeats the sinks' code once per interaction: there the long extension-field operations are
+// calls, so that a piece stays within reach of the instruction cache; the interpreter has one copy and inlines them.
+#ifdef LURKHIP_COMPILED_AIR
+#define LURKHIP_SINK_OP __attribute__((noinline))
+#else
+#define LURKHIP_SINK_OP __forceinline__
+#endif
+__device__ LURKHIP_SINK_OP ef sink_ef_inv(ef a) { return bb::ef_inv(a); }
+__device__ LURKHIP_SINK_OP ef sink_ef_mul(ef a, ef b) { return bb::ef_mul(a, b); }
+
 // Copies rows idx[0..n_rows) of a row-major matrix into an LDS tile with row stride wp: lanes run along a row, so
 // every global access is one contiguous w*4-byte segment (the per-lane strided reads the VM would otherwise issue
 // thrash L1: a workgroup's rows are hundreds of KB apart from lane to lane).
@@ -67,13 +77,30 @@ struct LogupAccum {
             den = cur;
         } else if (in_batch == 1) {
             num = bb::ef_add(bb::ef_scale(cur, m_first), bb::ef_scale(den, m));
-            den = bb::ef_mul(den, cur);
+            den = sink_ef_mul(den, cur);
         } else {
-            num = bb::ef_add(bb::ef_mul(num, cur), bb::ef_scale(den, m));
-            den = bb::ef_mul(den, cur);
+            num = bb::ef_add(sink_ef_mul(num, cur), bb::ef_scale(den, m));
+            den = sink_ef_mul(den, cur);
         }
         in_batch++;
         return in_batch == batch;
+    }
+    // the same with the position in the batch known when the code is generated (jit.cpp): the two dead arms are not emitted
+    template <int POS>
+    __device__ __forceinline__ void end_at(uint32_t mult) {
+        cur = cur64.value();
+        const uint32_t m = is_send ? mult : bb::neg(mult);
+        if (POS == 0) {
+            m_first = m;
+            den = cur;
+        } else if (POS == 1) {
+            num = bb::ef_add(bb::ef_scale(cur, m_first), bb::ef_scale(den, m));
+            den = sink_ef_mul(den, cur);
+        } else {
+            num = bb::ef_add(sink_ef_mul(num, cur), bb::ef_scale(den, m));
+            den = sink_ef_mul(den, cur);
+        }
+        in_batch = POS + 1;
     }
     // numerator of the (possibly partial) batch
     __device__ __forceinline__ ef numerator() const { return in_batch == 1 ? bb::ef_from_base(m_first) : num; }
@@ -92,7 +119,7 @@ struct PermSink {
     __device__ __forceinline__ void ival_at(uint32_t v, uint32_t t) { acc.value_at(v, t); }
     __device__ __forceinline__ void ival_run(const uint32_t* vals, uint32_t t, uint32_t count) { acc.value_run(vals, t, count); }
     __device__ __forceinline__ void flush() {
-        ef v = acc.in_batch == 1 ? bb::ef_scale(bb::ef_inv(acc.den), acc.m_first) : bb::ef_mul(acc.num, bb::ef_inv(acc.den));
+        ef v = acc.in_batch == 1 ? bb::ef_scale(sink_ef_inv(acc.den), acc.m_first) : sink_ef_mul(acc.num, sink_ef_inv(acc.den));
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
         if (live) *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
         row_sum = bb::ef_add(row_sum, v);
@@ -101,6 +128,12 @@ struct PermSink {
     }
     __device__ __forceinline__ void iend(uint32_t m) {
         if (acc.end(m, batch)) flush();
+    }
+    // compiled pieces: position in the batch (0, 1, 2 = later) and whether the batch ends here are literals
+    template <int POS, bool LAST>
+    __device__ __forceinline__ void iend_at(uint32_t m) {
+        acc.end_at<POS>(m);
+        if (LAST) flush();
     }
 };
 
@@ -237,12 +270,17 @@ struct QuotientSink {
     __device__ __forceinline__ void flush() {
         // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
         ef entry = ef_load(perm_l + 4 * col);
-        assert_zero_ext(bb::ef_sub(bb::ef_mul(acc.den, entry), acc.numerator()));
+        assert_zero_ext(bb::ef_sub(sink_ef_mul(acc.den, entry), acc.numerator()));
         col++;
         acc.in_batch = 0;
     }
     __device__ __forceinline__ void iend(uint32_t m) {
         if (acc.end(m, batch)) flush();
+    }
+    template <int POS, bool LAST>
+    __device__ __forceinline__ void iend_at(uint32_t m) {
+        acc.end_at<POS>(m);
+        if (LAST) flush();
     }
 };
 
