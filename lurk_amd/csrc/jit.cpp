@@ -44,8 +44,7 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
         }
     };
     o << "template <class Sink> __device__ __forceinline__ void " << name << "(const airvm::Sources& s, Sink& sink) {\n";
-    uint32_t n_ends = 0, seen_ends = 0;
-    for (uint32_t i = 0; i < n; i++) n_ends += (code[2 * i] & 0xffu) == airp::OP_IEND;
+    uint32_t seen_ends = 0;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
         const uint32_t op = w0 & 0xffu, dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
