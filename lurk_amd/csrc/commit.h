@@ -41,6 +41,17 @@ int32_t fill_powers(lurkhip_ctx* ctx, uint32_t* out, uint32_t root_m, uint32_t s
 int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* dst,
                 uint32_t* scratch, int w, const uint32_t* row_scale, bool in_canonical, bool out_canonical,
                 bool bitrev_store);
+// several matrices of one shape (height, width), one launch per pass
+constexpr int NTT_MAX_BATCH = 8;
+struct NttBatch {
+    int n;
+    const uint32_t* src[NTT_MAX_BATCH];
+    uint32_t* dst[NTT_MAX_BATCH];
+    uint32_t* scratch[NTT_MAX_BATCH];
+    const uint32_t* row_scale[NTT_MAX_BATCH];
+};
+int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const NttBatch& b, int w, bool in_canonical,
+                      bool out_canonical, bool bitrev_store);
 
 // ---- Poseidon2 width-16 parameters for the Merkle hash (device resident, Montgomery) ----
 constexpr int P16_MAX_RP = 32;

@@ -3,6 +3,7 @@
 // Replaces (S1 in SURVEY.md 8a; third-party): p3 TwoAdicFriPcs::commit(Vec<(domain, RowMajorMatrix)>)
 // as called by sphinx's prover for the main, permutation and quotient traces [UPSTREAM-RECALL].
 #include <algorithm>
+#include <map>
 #include <numeric>
 
 #include "babybear.h"
@@ -56,6 +57,28 @@ int32_t interpolate(lurkhip_ctx* ctx, int log_n, int w, const uint32_t* evals, b
     return ntt_dif(ctx, *plan, /*inverse=*/true, evals, coef, scratch, w, nullptr, canonical, false, /*bitrev_store=*/true);
 }
 
+// s^i / N, i < N, for the coset shift s: immutable, so cached per (log_n, s) while the cache stays under 1 GiB (nullptr
+// beyond that: the caller builds the table in its own scratch)
+int32_t cached_scale_table(lurkhip_ctx* ctx, int log_n, uint32_t s_m, const uint32_t** out) {
+    const size_t n = (size_t)1 << log_n;
+    *out = nullptr;
+    auto key = std::make_pair(log_n, s_m);
+    auto it = ctx->lde_scale_tables.find(key);
+    if (it != ctx->lde_scale_tables.end()) {
+        *out = it->second;
+        return LURKHIP_OK;
+    }
+    if (ctx->lde_scale_bytes + n * 4 > ((size_t)1 << 30)) return LURKHIP_OK;
+    const uint32_t n_inv = hpow(bb::to_monty((uint32_t)(n % bb::P)), bb::P - 2);
+    uint32_t* tbl = nullptr;
+    LH_HIP(ctx, hipMalloc(&tbl, n * 4));
+    LH_TRY(fill_powers(ctx, tbl, s_m, n_inv, n));
+    ctx->lde_scale_tables[key] = tbl;
+    ctx->lde_scale_bytes += n * 4;
+    *out = tbl;
+    return LURKHIP_OK;
+}
+
 // coefficients -> LDE on the coset g * <w_{N << b}>, rows in bit-reversed order, Montgomery
 int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_t* coef, uint32_t* lde,
                uint32_t* row_scale /* N words scratch */, bool out_canonical, uint32_t shift_m) {
@@ -63,29 +86,54 @@ int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_
     LH_TRY(get_ntt_plan(ctx, log_n, &plan));
     const size_t n = (size_t)1 << log_n;
     const uint32_t n_inv = hpow(bb::to_monty((uint32_t)(n % bb::P)), bb::P - 2);
-    const uint32_t g = shift_m;
     const uint32_t w_big = two_adic_generator_monty(log_n + log_blowup);
     for (uint32_t q = 0; q < (1u << log_blowup); q++) {
-        uint32_t s_q = bb::mul(g, hpow(w_big, brev(q, log_blowup)));
-        // s_q^i / N, i < N: cached per (log_n, s_q) while the cache stays under 1 GiB, else built in the caller's scratch
-        const uint32_t* scale = row_scale;
-        auto key = std::make_pair(log_n, s_q);
-        auto it = ctx->lde_scale_tables.find(key);
-        if (it != ctx->lde_scale_tables.end()) {
-            scale = it->second;
-        } else if (ctx->lde_scale_bytes + n * 4 <= ((size_t)1 << 30)) {
-            uint32_t* tbl = nullptr;
-            LH_HIP(ctx, hipMalloc(&tbl, n * 4));
-            LH_TRY(fill_powers(ctx, tbl, s_q, n_inv, n));
-            ctx->lde_scale_tables[key] = tbl;
-            ctx->lde_scale_bytes += n * 4;
-            scale = tbl;
-        } else {
+        const uint32_t s_q = bb::mul(shift_m, hpow(w_big, brev(q, log_blowup)));
+        const uint32_t* scale = nullptr;
+        LH_TRY(cached_scale_table(ctx, log_n, s_q, &scale));
+        if (!scale) {
             LH_TRY(fill_powers(ctx, row_scale, s_q, n_inv, n));
+            scale = row_scale;
         }
         LH_TRY(ntt_dif(ctx, *plan, /*inverse=*/false, coef, lde + q * n * w, nullptr, w, scale, false, out_canonical,
                        /*bitrev_store=*/false));
     }
+    return LURKHIP_OK;
+}
+
+// interpolate + extend for up to NTT_MAX_BATCH device-resident matrices of one shape (blow-up >= 1: the LDE buffer is the
+// interpolation scratch): one launch per pass for all of them.  *done = false (nothing launched for the extension) when a
+// coset's scale table is not cacheable; the caller then extends the matrices one by one.
+int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batch, const uint32_t* const* evals, bool canonical,
+                  uint32_t* const* coefs, uint32_t* const* ldes, const uint32_t* shifts_m, bool* done) {
+    const NttPlan* plan = nullptr;
+    LH_TRY(get_ntt_plan(ctx, log_n, &plan));
+    const size_t n = (size_t)1 << log_n;
+    *done = false;
+    const uint32_t w_big = two_adic_generator_monty(log_n + log_blowup);
+    std::vector<NttBatch> cosets((size_t)1 << log_blowup);
+    for (uint32_t q = 0; q < (1u << log_blowup); q++) {
+        NttBatch& e = cosets[q];
+        e = NttBatch{};
+        e.n = n_batch;
+        for (int m = 0; m < n_batch; m++) {
+            const uint32_t s_q = bb::mul(shifts_m[m], hpow(w_big, brev(q, log_blowup)));
+            LH_TRY(cached_scale_table(ctx, log_n, s_q, &e.row_scale[m]));
+            if (!e.row_scale[m]) return LURKHIP_OK;
+            e.src[m] = coefs[m];
+            e.dst[m] = ldes[m] + q * n * w;
+        }
+    }
+    NttBatch b{};
+    b.n = n_batch;
+    for (int m = 0; m < n_batch; m++) {
+        b.src[m] = evals[m];
+        b.dst[m] = coefs[m];
+        b.scratch[m] = ldes[m];
+    }
+    LH_TRY(ntt_dif_batch(ctx, *plan, /*inverse=*/true, b, w, canonical, false, /*bitrev_store=*/true));
+    for (const NttBatch& e : cosets) LH_TRY(ntt_dif_batch(ctx, *plan, /*inverse=*/false, e, w, false, false, /*bitrev_store=*/false));
+    *done = true;
     return LURKHIP_OK;
 }
 
@@ -268,32 +316,63 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     } while (0)
 
     span_begin(ctx, "lde");  // one span for the matrices of the commitment (with host inputs it includes their uploads)
+    std::vector<char> extended(n_mats, 0);
+    for (int i = 0; i < n_mats; i++) {
+        const size_t bytes = ((size_t)widths[i] << log_heights[i]) * sizeof(uint32_t);
+        c->log_h[i] = (int)log_heights[i] + log_blowup;
+        TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
+        TRY_C(pool_alloc(ctx, bytes, (void**)&c->coeffs[i]));
+    }
+    if (!mats_on_host && log_blowup >= 1) {
+        // device-resident matrices of one shape go through the passes together
+        std::map<std::pair<uint32_t, uint32_t>, std::vector<int>> shapes;
+        for (int i = 0; i < n_mats; i++) shapes[{log_heights[i], widths[i]}].push_back(i);
+        for (const auto& kv : shapes) {
+            const std::vector<int>& idx = kv.second;
+            for (size_t at = 0; at < idx.size(); at += NTT_MAX_BATCH) {
+                const int nb = (int)std::min<size_t>(NTT_MAX_BATCH, idx.size() - at);
+                if (nb < 2) continue;
+                const uint32_t* ev[NTT_MAX_BATCH];
+                uint32_t *co[NTT_MAX_BATCH], *ld[NTT_MAX_BATCH];
+                uint32_t sh[NTT_MAX_BATCH];
+                for (int m = 0; m < nb; m++) {
+                    const int i = idx[at + m];
+                    ev[m] = mats[i];
+                    co[m] = c->coeffs[i];
+                    ld[m] = c->lde[i];
+                    sh[m] = bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN);
+                }
+                bool done = false;
+                TRY_C(lde_batch(ctx, (int)kv.first.first, (int)kv.first.second, log_blowup, nb, ev, repr == LURKHIP_REPR_CANONICAL, co, ld, sh, &done));
+                if (done)
+                    for (int m = 0; m < nb; m++) extended[idx[at + m]] = 1;
+            }
+        }
+    }
     for (int i = 0; i < n_mats; i++) {
         const int log_n = (int)log_heights[i];
         const int w = (int)widths[i];
         const size_t n = (size_t)1 << log_n;
         const size_t bytes = n * w * sizeof(uint32_t);
-        c->log_h[i] = log_n + log_blowup;
-        TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
-        uint32_t* coef = nullptr;
-        TRY_C(pool_alloc(ctx, bytes, (void**)&coef));
-        c->coeffs[i] = coef;
-        const uint32_t* src = mats[i];
-        void* staged = nullptr;
-        if (mats_on_host) {
-            TRY_C(arena_get(ctx, 0, bytes, &staged));
-            HIP_C(hipMemcpyAsync(staged, mats[i], bytes, hipMemcpyHostToDevice, ctx->stream));
-            src = (const uint32_t*)staged;
+        uint32_t* coef = c->coeffs[i];
+        if (!extended[i]) {
+            const uint32_t* src = mats[i];
+            void* staged = nullptr;
+            if (mats_on_host) {
+                TRY_C(arena_get(ctx, 0, bytes, &staged));
+                HIP_C(hipMemcpyAsync(staged, mats[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+                src = (const uint32_t*)staged;
+            }
+            void* scratch = nullptr;
+            void* row_scale = nullptr;
+            // the LDE buffer doubles as interpolation scratch when it is big enough (blow-up >= 1)
+            if (log_blowup >= 1) scratch = c->lde[i];
+            else TRY_C(arena_get(ctx, 1, bytes, &scratch));
+            TRY_C(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
+            TRY_C(interpolate(ctx, log_n, w, src, repr == LURKHIP_REPR_CANONICAL, (uint32_t*)scratch, coef));
+            TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false,
+                         bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN)));
         }
-        void* scratch = nullptr;
-        void* row_scale = nullptr;
-        // the LDE buffer doubles as interpolation scratch when it is big enough (blow-up >= 1)
-        if (log_blowup >= 1) scratch = c->lde[i];
-        else TRY_C(arena_get(ctx, 1, bytes, &scratch));
-        TRY_C(arena_get(ctx, 2, n * sizeof(uint32_t), &row_scale));
-        TRY_C(interpolate(ctx, log_n, w, src, repr == LURKHIP_REPR_CANONICAL, (uint32_t*)scratch, coef));
-        TRY_C(extend(ctx, log_n, w, log_blowup, coef, c->lde[i], (uint32_t*)row_scale, false,
-                     bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN)));
         if (!keep_coeffs) {
             pool_release(ctx, coef);  // stream-ordered: only later work can reuse it
             c->coeffs[i] = nullptr;

@@ -54,10 +54,13 @@ __global__ void k_powers(uint32_t* __restrict__ out, uint32_t root_m, uint32_t s
 }
 
 struct PassArgs {
-    const uint32_t* in;    // N x w
-    uint32_t* out;         // N x w (may alias in when !bitrev_store and in-place is wanted)
+    // A launch transforms up to NTT_MAX_BATCH matrices of one shape: blockIdx.y picks the matrix, the x dimension is the
+    // persistent grid of one matrix.  (The narrow matrices of a commitment -- quotient chunks, memory tables -- are a few
+    // tens of microseconds per pass each: one launch per matrix leaves the launch boundaries and ramps to dominate.)
+    const uint32_t* in[NTT_MAX_BATCH];    // N x w
+    uint32_t* out[NTT_MAX_BATCH];         // N x w (may alias in when !bitrev_store and in-place is wanted)
     const uint32_t* tw;    // powers of the size-N root (or inverse root), N/2 entries, Montgomery
-    const uint32_t* row_scale;  // optional per-row multiplier applied on load (N entries) or nullptr
+    const uint32_t* row_scale[NTT_MAX_BATCH];  // optional per-row multiplier applied on load (N entries) or nullptr
     int log_n;
     int w;
     int bit_lo;        // lowest row-index bit handled by this pass
@@ -233,15 +236,16 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_W
     };
     T v[U];
     uint32_t sc[U], twv[TWN];
-    const char* __restrict__ src = reinterpret_cast<const char*>(a.in);
-    char* __restrict__ dst = reinterpret_cast<char*>(a.out);
+    const char* __restrict__ src = reinterpret_cast<const char*>(a.in[blockIdx.y]);
+    char* __restrict__ dst = reinterpret_cast<char*>(a.out[blockIdx.y]);
+    const uint32_t* __restrict__ row_scale = a.row_scale[blockIdx.y];
     auto fetch = [&](uint32_t row0, int col, uint32_t lo) {
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int t = slot + (k << LOG_SLOTS);
             const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
             v[k] = *reinterpret_cast<const T*>(src + ((boff_t)row * (boff_t)a.w + (boff_t)col) * 4);
-            if constexpr (SCALE) sc[k] = a.row_scale[row];
+            if constexpr (SCALE) sc[k] = row_scale[row];
         }
         // twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l)
 #pragma unroll
@@ -304,10 +308,10 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_W
 }
 
 template <class T, bool BIG, bool SCALE, int TWN>
-void launch_pass2(int log_r, unsigned blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
+void launch_pass2(int log_r, dim3 blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
     switch (log_r) {
 #define LH_NTT_CASE(LR) \
-    case LR: hipLaunchKernelGGL((k_ntt_pass<LR, T, BIG, SCALE, TWN>), dim3(blocks), dim3(threads), lds, stream, a); break;
+    case LR: hipLaunchKernelGGL((k_ntt_pass<LR, T, BIG, SCALE, TWN>), blocks, dim3(threads), lds, stream, a); break;
         LH_NTT_CASE(0) LH_NTT_CASE(1) LH_NTT_CASE(2) LH_NTT_CASE(3) LH_NTT_CASE(4) LH_NTT_CASE(5) LH_NTT_CASE(6) LH_NTT_CASE(7)
 #undef LH_NTT_CASE
     }
@@ -367,10 +371,10 @@ int32_t fill_powers(lurkhip_ctx* ctx, uint32_t* out, uint32_t root_m, uint32_t s
 }
 
 template <class T, bool BIG>
-void launch_pass(int log_r, unsigned blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
+void launch_pass(int log_r, dim3 blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
     const bool one = ((size_t)1 << (log_r + a.log_l)) <= (size_t)threads;  // one twiddle per thread covers the table
-    if (a.row_scale && one) launch_pass2<T, BIG, true, 1>(log_r, blocks, threads, lds, stream, a);
-    else if (a.row_scale) launch_pass2<T, BIG, true, 4>(log_r, blocks, threads, lds, stream, a);
+    if (a.row_scale[0] && one) launch_pass2<T, BIG, true, 1>(log_r, blocks, threads, lds, stream, a);
+    else if (a.row_scale[0]) launch_pass2<T, BIG, true, 4>(log_r, blocks, threads, lds, stream, a);
     else if (one) launch_pass2<T, BIG, false, 1>(log_r, blocks, threads, lds, stream, a);
     else launch_pass2<T, BIG, false, 4>(log_r, blocks, threads, lds, stream, a);
 }
@@ -396,6 +400,19 @@ static void schedule(int log_n, int max_log_r, std::vector<std::pair<int, int>>&
 int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint32_t* src, uint32_t* dst,
                 uint32_t* scratch, int w, const uint32_t* row_scale, bool in_canonical, bool out_canonical,
                 bool bitrev_store) {
+    NttBatch b{};
+    b.n = 1;
+    b.src[0] = src;
+    b.dst[0] = dst;
+    b.scratch[0] = scratch;
+    b.row_scale[0] = row_scale;
+    return ntt_dif_batch(ctx, plan, inverse, b, w, in_canonical, out_canonical, bitrev_store);
+}
+
+// The same transform for b.n matrices of one shape, one launch per pass.  Either every matrix has a row_scale or none.
+int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const NttBatch& b, int w, bool in_canonical,
+                      bool out_canonical, bool bitrev_store) {
+    LH_ARG(ctx, b.n >= 1 && b.n <= NTT_MAX_BATCH, "NTT batch size");
     const int log_n = plan.log_n;
     // Prefer a chunk width that divides w (no ragged chunk) and is even (two-column butterflies): the largest such
     // divisor in [32, 112], else 64.
@@ -413,7 +430,12 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
     };
     // two adjacent columns per lane (8-byte accesses) when rows and chunks start on 8-byte boundaries
-    const bool aligned8 = ((((uintptr_t)src) | ((uintptr_t)dst) | ((uintptr_t)scratch)) & 7u) == 0 && w % 2 == 0;
+    uintptr_t all_ptrs = 0;
+    for (int m = 0; m < b.n; m++) {
+        all_ptrs |= (uintptr_t)b.src[m] | (uintptr_t)b.dst[m] | (uintptr_t)b.scratch[m];
+        LH_ARG(ctx, (b.row_scale[m] != nullptr) == (b.row_scale[0] != nullptr), "NTT batch mixes scaled and unscaled matrices");
+    }
+    const bool aligned8 = (all_ptrs & 7u) == 0 && w % 2 == 0;
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
     auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / 8) * items_of(cols); };
     int max_log_r = 7;
@@ -422,18 +444,21 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
     const int n_full = w / col_chunk, last_w = w % col_chunk;
-    const uint32_t* cur_in = src;
+    const uint32_t* cur_in[NTT_MAX_BATCH] = {};
+    for (int m = 0; m < b.n; m++) cur_in[m] = b.src[m];
     for (size_t p = 0; p < passes.size(); p++) {
         bool last = p + 1 == passes.size();
-        uint32_t* cur_out;
-        if (last) cur_out = dst;
-        else if (bitrev_store) cur_out = scratch;   // keep dst free for the final scatter
-        else cur_out = dst;                          // in-place chain inside dst
-        PassArgs a;
-        a.in = cur_in;
-        a.out = cur_out;
+        PassArgs a{};
+        for (int m = 0; m < b.n; m++) {
+            uint32_t* cur_out;
+            if (last) cur_out = b.dst[m];
+            else if (bitrev_store) cur_out = b.scratch[m];  // keep dst free for the final scatter
+            else cur_out = b.dst[m];                         // in-place chain inside dst
+            a.in[m] = cur_in[m];
+            a.out[m] = cur_out;
+            a.row_scale[m] = p == 0 ? b.row_scale[m] : nullptr;
+        }
         a.tw = inverse ? plan.tw_inv : plan.tw_fwd;
-        a.row_scale = p == 0 ? row_scale : nullptr;
         a.log_n = log_n;
         a.w = w;
         a.bit_lo = passes[p].first;
@@ -472,17 +497,19 @@ int32_t ntt_dif(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const uint3
             // resident at once; a multiple of 8 so that every XCD gets the same number
             const size_t lds = lds_bytes(log_r, a.col_chunk, log_l);
             const int per_cu = std::max(1, std::min(20 / (threads / 64), (int)((160 * 1024) / (lds + 256))));
-            size_t blocks = std::min<size_t>(tiles, (size_t)per_cu * ctx->num_cus);
+            // (a batch shares the CUs: every matrix gets its part of the resident grid)
+            size_t blocks = std::min<size_t>(tiles, std::max<size_t>(8, (size_t)per_cu * ctx->num_cus / b.n));
             if (a.xcd_run) blocks = blocks / 8 * 8;
             // matrices of 4 GiB and more need 64-bit offsets; LURKHIP_NTT_FORCE_64BIT (test hook) takes that path at any size
             const bool big = (((size_t)w) << (log_n + 2)) >= ((size_t)1 << 32) || getenv("LURKHIP_NTT_FORCE_64BIT") != nullptr;
-            if (pair && big) launch_pass<uint2, true>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
-            else if (pair) launch_pass<uint2, false>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
-            else if (big) launch_pass<uint32_t, true>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
-            else launch_pass<uint32_t, false>(log_r, (unsigned)blocks, threads, lds, ctx->stream, a);
+            const dim3 grid((unsigned)blocks, (unsigned)b.n);
+            if (pair && big) launch_pass<uint2, true>(log_r, grid, threads, lds, ctx->stream, a);
+            else if (pair) launch_pass<uint2, false>(log_r, grid, threads, lds, ctx->stream, a);
+            else if (big) launch_pass<uint32_t, true>(log_r, grid, threads, lds, ctx->stream, a);
+            else launch_pass<uint32_t, false>(log_r, grid, threads, lds, ctx->stream, a);
             LH_HIP(ctx, hipGetLastError());
         }
-        cur_in = cur_out;
+        for (int m = 0; m < b.n; m++) cur_in[m] = a.out[m];
     }
     return LURKHIP_OK;
 }

@@ -92,6 +92,23 @@ def test_commit_injection_at_cooperative_levels(ctx, oracle):
     c.close()
 
 
+def test_commit_same_shape_matrices_share_their_passes(ctx, oracle):
+    """Device-resident matrices of one (height, width) go through the NTT passes in one launch per pass (up to 8 per launch):
+    eleven 2^10 x 4 matrices (a batch of 8 and one of 3), three 2^9 x 12, pairs with an odd width and a single one."""
+    import torch
+
+    shapes = [(10, 4)] * 11 + [(9, 12)] * 3 + [(8, 7)] * 2 + [(11, 5)]
+    mats = [synth.field_elements((1 << k, w), seed=1700 + i) for i, (k, w) in enumerate(shapes)]
+    dev = [torch.from_numpy(m.view(np.int32)).cuda() for m in mats]
+    c = cm.commit_dev(ctx, dev, [k for k, _ in shapes], [w for _, w in shapes], log_blowup=1)
+    ldes = [oracle.lde(m, 1) for m in mats]
+    root, _ = oracle.merkle_commit(ldes)
+    assert np.array_equal(c.root, root)
+    for i in (0, 7, 8, 10, 11, 13, 14, 15, 16):
+        assert np.array_equal(c.lde_host(i), ldes[i]), i
+    c.close()
+
+
 def test_commit_buffer_reuse_across_shapes(ctx, oracle):
     """The pooled allocator hands a released LDE buffer to the next commit of the same byte size, and the context caches the
     Merkle leaf-column tables and the coset-shift power tables by (pointer, width) / (height, shift): commits of different
