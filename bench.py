@@ -193,7 +193,7 @@ def main():
         for lvl in range(1, log_max + 1):
             n_par = 1 << (log_max - lvl)
             lh = log_max - lvl
-            if 2 * n_par <= 512:
+            if 2 * n_par <= 64:
                 break  # k_top finishes the tree in one workgroup (latency-bound tail, reported separately)
             total += n_par * (64 + 4 * sum(w for lg, w in mats if lg == lh) + 32)
             launches += 1

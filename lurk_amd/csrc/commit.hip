@@ -184,6 +184,11 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
     return LURKHIP_OK;
 }
 
+// The last TOP_NODES nodes of a tree collapse inside one workgroup (merkle_top).  A level costs about one cooperative
+// permutation (~6 us) either way; measured on the bench shard 64 is 0.2 ms per proof better than 512 (the wider levels gain
+// from being spread over the CUs) and no different from 16 or 2.
+constexpr size_t TOP_NODES = 64;
+
 int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
@@ -219,7 +224,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             if (c->log_h[m] == lh) inject.push_back(m);
         uint32_t* children = c->digests + c->level_off[l - 1] * 8;
         uint32_t* parents = c->digests + c->level_off[l] * 8;
-        if ((n_parents << 1) <= 512) {
+        if ((n_parents << 1) <= TOP_NODES) {
             // finish the tree in one workgroup (wider levels are faster spread over the CUs)
             TopInject ti{};
             for (int t = 0; l + t <= c->log_max; t++) {

@@ -75,10 +75,10 @@ def test_commit_mixed_heights(ctx, oracle):
 
 
 def test_commit_injection_at_cooperative_levels(ctx, oracle):
-    """Levels of at most 16384 parents hash lane-cooperatively (16 lanes per node), the last 512 nodes inside one workgroup:
+    """Levels of at most 16384 parents hash lane-cooperatively (16 lanes per node), the last 64 nodes inside one workgroup:
     matrices injected at such levels -- narrow, wider than one sponge block, and as wide as the hash chips -- and at the
     one-lane-per-node levels above them must give the oracle's tree."""
-    shapes = [(15, 8), (14, 5), (13, 20), (12, 9), (10, 493), (9, 5), (8, 17), (3, 7), (0, 3)]
+    shapes = [(15, 8), (14, 5), (13, 20), (12, 9), (10, 493), (9, 5), (8, 17), (4, 11), (3, 7), (0, 3)]
     mats = [synth.field_elements((1 << k, w), seed=1500 + i) for i, (k, w) in enumerate(shapes)]
     c = cm.commit(ctx, mats, log_blowup=1)
     ldes = [oracle.lde(m, 1) for m in mats]
