@@ -167,7 +167,7 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
         return LURKHIP_OK;
     }
     if (ctx->leafcol_tables.size() >= 1024) {  // bound the cache: tables of past shapes are dropped wholesale
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LH_HIP(ctx, stream_wait(ctx));
         for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
         ctx->leafcol_tables.clear();
     }
@@ -269,7 +269,7 @@ int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const s
     c->width = widths;
     int32_t s = build_tree(ctx, c);
     if (s != LURKHIP_OK) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)stream_wait(ctx);
         free_commitment(ctx, c);
         return s;
     }
@@ -279,7 +279,7 @@ int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const s
 
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m) {
     LH_HIP(ctx, hipMemcpyAsync(root_m, c->digests + c->level_off[c->log_max] * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, stream_wait(ctx));
     return LURKHIP_OK;
 }
 
@@ -303,7 +303,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     c->log_h.resize(n_mats);
     c->width.assign(widths, widths + n_mats);
     auto fail = [&](int32_t s) {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)stream_wait(ctx);
         free_commitment(ctx, c);
         return s;
     };
@@ -389,7 +389,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         uint32_t r[8];
         const uint32_t* droot = c->digests + c->level_off[c->log_max] * 8;
         HIP_C(hipMemcpyAsync(r, droot, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
-        HIP_C(hipStreamSynchronize(ctx->stream));
+        HIP_C(stream_wait(ctx));
         for (int k = 0; k < 8; k++) root[k] = repr == LURKHIP_REPR_CANONICAL ? bb::from_monty(r[k]) : r[k];
     }
 #undef TRY_C
@@ -442,7 +442,7 @@ int32_t lurkhip_coset_lde(lurkhip_ctx* ctx, int32_t log_n, int32_t width, int32_
     if (s == LURKHIP_OK) s = lurkhip_coset_lde_dev(ctx, log_n, width, log_blowup, (const uint32_t*)din, (uint32_t*)dout, repr);
     if (s == LURKHIP_OK && hipMemcpyAsync(out, dout, bytes << log_blowup, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
         s = set_error(ctx, LURKHIP_ERR_HIP, "D2H copy failed");
-    (void)hipStreamSynchronize(ctx->stream);
+    (void)stream_wait(ctx);
     (void)hipFree(din);
     (void)hipFree(dout);
     return s;
@@ -490,7 +490,7 @@ int32_t lurkhip_commitment_root(lurkhip_ctx* ctx, lurkhip_commitment* c, uint32_
     LH_ARG(ctx, c && root, "null argument");
     uint32_t r[8];
     LH_HIP(ctx, hipMemcpyAsync(r, c->digests + c->level_off[c->log_max] * 8, sizeof r, hipMemcpyDeviceToHost, ctx->stream));
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, stream_wait(ctx));
     for (int k = 0; k < 8; k++) root[k] = repr == LURKHIP_REPR_CANONICAL ? bb::from_monty(r[k]) : r[k];
     return LURKHIP_OK;
 }
@@ -513,7 +513,7 @@ int32_t lurkhip_commitment_open(lurkhip_ctx* ctx, lurkhip_commitment* c, uint64_
         uint64_t sib = (index >> l) ^ 1;
         LH_HIP(ctx, hipMemcpyAsync(path + l * 8, c->digests + (c->level_off[l] + sib) * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
     }
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, stream_wait(ctx));
     if (repr == LURKHIP_REPR_CANONICAL) {
         for (size_t i = 0; i < off; i++) rows[i] = bb::from_monty(rows[i]);
         for (int i = 0; i < c->log_max * 8; i++) path[i] = bb::from_monty(path[i]);

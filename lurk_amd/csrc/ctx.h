@@ -60,6 +60,9 @@ namespace lurkhip {
 int32_t set_error(lurkhip_ctx* ctx, int32_t code, const char* fmt, ...);
 // returns a device buffer of at least `bytes` from scratch slot `slot` (grown on demand)
 int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out);
+// waits for the stream like hipStreamSynchronize, polling first: the prover's read-backs come back within tens of
+// microseconds and a blocking wait adds its wake-up latency to every transcript round trip
+hipError_t stream_wait(lurkhip_ctx* ctx);
 // page-locked host buffer of at least `bytes` (grown on demand; the previous contents are dropped, the stream is drained first)
 int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out);
 // pooled device allocations: released blocks are kept and reused for later requests of the same size

@@ -3,6 +3,7 @@
 
 #include "ctx.h"
 
+#include <chrono>
 #include <set>
 
 #include <cstring>
@@ -41,6 +42,16 @@ int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out) {
     }
     *out = ctx->arena[slot];
     return LURKHIP_OK;
+}
+
+hipError_t stream_wait(lurkhip_ctx* ctx) {
+    const auto t0 = std::chrono::steady_clock::now();
+    for (;;) {
+        const hipError_t e = hipStreamQuery(ctx->stream);
+        if (e != hipErrorNotReady) return e;
+        if (std::chrono::steady_clock::now() - t0 > std::chrono::milliseconds(2)) break;  // long waits block
+    }
+    return hipStreamSynchronize(ctx->stream);
 }
 
 int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out) {

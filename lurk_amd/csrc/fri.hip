@@ -579,7 +579,7 @@ int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int
     host[16] = 0xffffffffu;
     int32_t s = LURKHIP_OK;
     hipError_t e = hipMemcpyAsync(scratch, host, sizeof host, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx);
     const uint32_t mask = bits >= 31 ? 0x7fffffffu : ((1u << bits) - 1u);
     const uint32_t batch = 1u << 20;
     uint32_t best = 0xffffffffu;
@@ -588,7 +588,7 @@ int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int
                            (uint32_t)base, mask, (uint32_t*)scratch + 16);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&best, (uint32_t*)scratch + 16, 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = stream_wait(ctx);
     }
     pool_release(ctx, scratch);
     if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "pow_grind failed: %s", hipGetErrorString(e));
@@ -623,7 +623,7 @@ int32_t gather_openings(lurkhip_ctx* ctx, const std::vector<OpenMat>& mats, cons
     LH_TRY(pool_alloc(ctx, o_lo + b_lo + 16, &scratch));
     hipError_t e = hipMemcpyAsync(scratch, g.data(), b_g, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess) e = hipMemcpyAsync((uint8_t*)scratch + o_lo, lo.data(), b_lo, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);  // the staging vectors die at scope exit
+    if (e == hipSuccess) e = stream_wait(ctx);  // the staging vectors die at scope exit
     if (e == hipSuccess) {
         hipLaunchKernelGGL(k_gather_openings, dim3(n_queries), dim3(256), 0, ctx->stream, (const GatherMat*)scratch, (uint32_t)g.size(), digests,
                            (const uint64_t*)((uint8_t*)scratch + o_lo), log_max, off, indices_dev, shift, out_dev);

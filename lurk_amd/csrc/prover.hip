@@ -233,7 +233,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     std::vector<lurkhip_commitment*> to_free;
     std::vector<void*> pooled;
     auto cleanup = [&]() {
-        (void)hipStreamSynchronize(ctx->stream);
+        (void)stream_wait(ctx);
         for (auto* c : to_free) free_commitment(ctx, c);
         for (void* p : pooled) pool_release(ctx, p);
     };
@@ -290,7 +290,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
             const size_t h = (size_t)1 << sh->log_n[i];
             PHIP(hipMemcpyAsync(&cs[4 * i], perm[i] + h * perm_widths[i] - 4, 16, hipMemcpyDeviceToHost, ctx->stream));
         }
-        PHIP(hipStreamSynchronize(ctx->stream));
+        PHIP(stream_wait(ctx));
         for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs[4 * i], cs[4 * i + 1], cs[4 * i + 2], cs[4 * i + 3]}};
     }
     span_end(ctx, "permutation");
@@ -444,7 +444,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     }
     std::vector<uint32_t> dot_host(dot_words);
     PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PHIP(hipStreamSynchronize(ctx->stream));
+    PHIP(stream_wait(ctx));
     // phase 2: opened values on the host, then the reduced openings of every matrix
     // opened values, per round, per matrix, per point: ys[c] (Montgomery)
     std::vector<std::vector<std::vector<std::vector<ef>>>> opened(rounds.size());
@@ -528,7 +528,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     uint32_t* roots_dev = nullptr;  // the layer roots, copied by k_fri_challenge as it observes them
     PTRY(palloc((size_t)std::max(n_layers, 1) * 32, &roots_dev));
     PHIP(hipMemcpyAsync(ch_dev, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
-    PHIP(hipStreamSynchronize(ctx->stream));  // hc is a stack object
+    PHIP(stream_wait(ctx));  // hc is a stack object
     for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
         lurkhip_commitment* lc = nullptr;
         PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
@@ -551,7 +551,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
         if (b_roots) PHIP(hipMemcpyAsync(st, roots_dev, b_roots, hipMemcpyDeviceToHost, ctx->stream));
         PHIP(hipMemcpyAsync(st + o_hc, ch_dev, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
         PHIP(hipMemcpyAsync(st + o_fin, current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PHIP(hipStreamSynchronize(ctx->stream));
+        PHIP(stream_wait(ctx));
         memcpy(layer_roots_m.data(), st, b_roots);
         memcpy(&hc, st + o_hc, sizeof hc);
         memcpy(fin.data(), st + o_fin, fin.size() * 4);
@@ -586,7 +586,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     uint32_t* indices_dev = nullptr;
     PTRY(palloc((size_t)num_queries * 4, &indices_dev));
     PHIP(hipMemcpyAsync(indices_dev, indices.data(), (size_t)num_queries * 4, hipMemcpyHostToDevice, ctx->stream));
-    PHIP(hipStreamSynchronize(ctx->stream));
+    PHIP(stream_wait(ctx));
     // every record of every round and layer goes to one device buffer and comes back in one copy
     std::vector<uint32_t> round_record_words(rounds.size()), layer_record_words(layers.size());
     std::vector<std::vector<OpenMat>> round_mats(rounds.size());
@@ -627,7 +627,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     const uint32_t* rec_host = nullptr;
     PTRY(host_staging(ctx, std::max<size_t>(rec_words, 4) * 4, (void**)&rec_host));
     if (rec_words) PHIP(hipMemcpyAsync((void*)rec_host, rec_dev, rec_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PHIP(hipStreamSynchronize(ctx->stream));
+    PHIP(stream_wait(ctx));
     span_end(ctx, "fri_query");
 
     // ---- serialise (canonical values); layout documented in lurk_amd/prover.py

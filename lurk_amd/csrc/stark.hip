@@ -482,7 +482,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     pool_release(ctx, pows);
     if (s == LURKHIP_OK && cumulative_sum_m) {
         LH_HIP(ctx, hipMemcpyAsync(cumulative_sum_m->c, out_dev + ((size_t)height * perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
-        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LH_HIP(ctx, stream_wait(ctx));
     }
     return s;
 }
@@ -520,7 +520,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     if (s == LURKHIP_OK && np) {
         for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
         hipError_t e = hipMemcpyAsync(d + o_pub, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = stream_wait(ctx);
         if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "public values upload failed: %s", hipGetErrorString(e));
     }
     if (s == LURKHIP_OK) {
@@ -778,7 +778,7 @@ int32_t lurkhip_air_eval_rows(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t n_rows,
     put(o_sel, selectors, (size_t)n_rows * 3);
     int32_t s = LURKHIP_OK;
     hipError_t e = hipMemcpyAsync(dev, host.data(), o_co, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx);
     if (e == hipSuccess && n_rows) {
         EvalRowsArgs args{cp, ip, (const uint32_t*)(d + o_local), (const uint32_t*)(d + o_next), (const uint32_t*)(d + o_pl),
                           (const uint32_t*)(d + o_pn), (const uint32_t*)(d + o_pub), (const uint32_t*)(d + o_sel), (uint32_t*)(d + o_co),
@@ -790,7 +790,7 @@ int32_t lurkhip_air_eval_rows(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t n_rows,
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(constraints_out, d + o_co, (size_t)n_rows * K * 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = hipMemcpyAsync(interactions_out, d + o_io, (size_t)n_rows * T * 4, hipMemcpyDeviceToHost, ctx->stream);
-        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e == hipSuccess) e = stream_wait(ctx);
     }
     if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "air_eval_rows failed: %s", hipGetErrorString(e));
     pool_release(ctx, dev);
@@ -815,7 +815,7 @@ int32_t lurkhip_air_check_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t h
     for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
     hipError_t e = hipMemcpyAsync(scratch, &init, 8, hipMemcpyHostToDevice, ctx->stream);
     if (e == hipSuccess && np) e = hipMemcpyAsync((uint8_t*)scratch + 16, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx);
     if (e == hipSuccess && height) {
         const uint32_t n_regs = a->prog.constraints[airp::H_N_REGS];
         const VmShape shp = vm_shape(n_regs, a->air.width, 1, 65);
@@ -826,7 +826,7 @@ int32_t lurkhip_air_check_trace_dev(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t h
     }
     unsigned long long res = ~0ull;
     if (e == hipSuccess) e = hipMemcpyAsync(&res, scratch, 8, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx);
     pool_release(ctx, scratch);
     if (e != hipSuccess) return set_error(ctx, LURKHIP_ERR_HIP, "air_check_trace failed: %s", hipGetErrorString(e));
     if (res == ~0ull) {
