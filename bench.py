@@ -168,10 +168,14 @@ def main():
     ctx.profile_enable(not args.no_spans)
     t0 = time.perf_counter()
     words = None
+    step_words = []
     for _ in range(args.steps):
         words = step()
+        step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
     fence()
     elapsed = time.perf_counter() - t0
+    proofs_identical = all(len(w) == len(step_words[0]) and bool((w == step_words[0]).all()) for w in step_words[1:])
+    del step_words
     ctx.profile_enable(False)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
@@ -306,6 +310,7 @@ def main():
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned)",
                 "proof_words": int(len(words)),
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
+                "proofs_identical_across_steps": proofs_identical,
                 "hbm_resident_input_bytes": int(input_bytes),
                 "host_execute_and_upload_s": t_host,
                 "compiled_air_chips": compiled,

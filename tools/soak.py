@@ -1,0 +1,46 @@
+#!/usr/bin/env python3
+"""GPU box only: determinism soak.  The same execution is proved over and over -- sequentially, with compiled chips, and with
+two shards in flight on two contexts -- and every proof must be word-for-word the first one (the transcript is deterministic):
+a race between streams, a stale cached table or a buffer handed out while still in use would show up as a differing proof.
+usage: python tools/soak.py [rounds=30] [fib argument=60]"""
+import os
+import sys
+import time
+
+import numpy as np
+
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
+import lurk_amd  # noqa: E402
+from lair_helpers import load_cases  # noqa: E402
+from lurk_amd import lair, prover  # noqa: E402
+
+rounds = int(sys.argv[1]) if len(sys.argv) > 1 else 30
+arg = int(sys.argv[2]) if len(sys.argv) > 2 else 60
+src = load_cases()[0]["source"]
+top = lair.Toplevel(src)
+q = lair.QueryRecord(top)
+top.execute_by_name("fib", [arg], q)
+pv = q.expect_public_values()
+cfg = lair.ShardingConfig(16)
+t0 = time.time()
+with lurk_amd.Context(0) as ctx, lurk_amd.Context(0) as ctx2:
+    m1 = prover.Machine(ctx, top, "fib", len(pv))
+    m2 = prover.Machine(ctx2, top, "fib", len(pv))
+    m1.setup()
+    m2.setup()
+    want = [p.words.copy() for p in m1.prove(q, cfg, num_queries=8, pow_bits=4)]
+    print(f"{len(want)} shards per round, {sum(len(w) for w in want)} proof words")
+    bad = 0
+    for r in range(rounds):
+        for name, got in (("sequential", m1.prove(q, cfg, num_queries=8, pow_bits=4)),
+                          ("second context", m2.prove(q, cfg, num_queries=8, pow_bits=4)),
+                          ("two in flight", prover.prove_pipelined([m1, m2], q, cfg, num_queries=8, pow_bits=4))):
+            for i, (a, b) in enumerate(zip(got, want)):
+                if not np.array_equal(a.words, b):
+                    bad += 1
+                    print(f"round {r}: {name}: shard {i} differs")
+    m1.close()
+    m2.close()
+print(f"{rounds} rounds, {bad} differing proofs, {time.time() - t0:.1f} s")
+sys.exit(1 if bad else 0)
