@@ -262,12 +262,17 @@ def main():
                 ch.observe([0])
                 ch.observe(root)
                 ch.observe(pvs)
-                mach.prove_shard(handle, ch, pvs, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
+                w = mach.prove_shard(handle, ch, pvs, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
                 mach.free_shard(handle)
+                return w
+
+            in_flight_ok = []  # the first lane proves the timed region's shard: its proofs must be that proof
 
             def worker(mach, cx, prep, vk, pvs, k):
                 for _ in range(k):
-                    one(mach, cx, prep, vk, pvs)
+                    w = one(mach, cx, prep, vk, pvs)
+                    if mach is machine:
+                        in_flight_ok.append(len(w) == len(words) and bool((w == words).all()))
                 cx.sync()
 
             for k in (1, args.steps):  # warm-up pass, then the timed one
@@ -282,6 +287,7 @@ def main():
                 torch.cuda.synchronize()
                 dt2 = time.perf_counter() - t1
             two_in_flight = {"shards": 2 * args.steps, "ms_per_shard": dt2 / (2 * args.steps) * 1e3, "eval_steps_per_s": 2 * n * args.steps / dt2,
+                             "proofs_match_sequential": bool(in_flight_ok) and all(in_flight_ok),
                              "note": "two independent shards on two HIP streams of the same GPU; not the headline value"}
             m2.close()
             ctx2.close()
