@@ -114,6 +114,23 @@ __device__ __forceinline__ uint32_t coop_inject(uint32_t x, const P16Params* __r
     return coop_perm16(j < 8 ? x : up, p, j);
 }
 
+// leaves of a short tree (the later FRI layers, small commitments): one row per 16-lane group, lanes 0..7 absorb
+__global__ __launch_bounds__(MBLOCK) void k_leaves_coop(const P16Params* __restrict__ p, const LeafCol* __restrict__ cols, uint32_t total_w,
+                                                         size_t n_rows, uint32_t* __restrict__ out) {
+    const int j = threadIdx.x & 15;
+    const size_t g = ((size_t)blockIdx.x * MBLOCK + threadIdx.x) >> 4;
+    const size_t row = g < n_rows ? g : 0;
+    uint32_t t = 0;
+    for (uint32_t c0 = 0; c0 < total_w; c0 += 8) {
+        if (j < 8 && c0 + j < total_w) {
+            const LeafCol d = cols[c0 + j];
+            t = d.base[row * d.width + d.col];
+        }
+        t = coop_perm16(t, p, j);
+    }
+    if (g < n_rows && j < 8) out[g * 8 + j] = t;
+}
+
 __global__ __launch_bounds__(MBLOCK) void k_level_coop(const P16Params* __restrict__ p, const uint32_t* __restrict__ children,
                                                         size_t n_parents, const LeafCol* __restrict__ inject_cols,
                                                         uint32_t inject_w, uint32_t* __restrict__ parents) {
@@ -170,6 +187,14 @@ __global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, u
 
 int32_t merkle_leaves(lurkhip_ctx* ctx, const P16Params* params_dev, const LeafCol* cols_dev, uint32_t total_w,
                       size_t n_rows, uint32_t* digests_out) {
+    if (n_rows <= COOP_MAX_PARENTS && total_w <= 64) {
+        // few rows: a handful of one-row-per-lane waves would each run ceil(w / 8) full-latency permutations
+        const size_t blocks = (n_rows * 16 + MBLOCK - 1) / MBLOCK;
+        hipLaunchKernelGGL(k_leaves_coop, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, cols_dev, total_w, n_rows,
+                           digests_out);
+        LH_HIP(ctx, hipGetLastError());
+        return LURKHIP_OK;
+    }
     size_t blocks = (n_rows + MBLOCK - 1) / MBLOCK;
     LH_ARG(ctx, blocks <= 0x7fffffffu, "too many Merkle leaves for one launch");
     hipLaunchKernelGGL(k_leaves, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, cols_dev, total_w,
