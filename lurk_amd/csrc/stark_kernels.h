@@ -25,12 +25,30 @@ __device__ LURKHIP_SINK_OP ef sink_ef_mul(ef a, ef b) { return bb::ef_mul(a, b);
 
 // Copies rows idx[0..n_rows) of a row-major matrix into an LDS tile with row stride wp: lanes run along a row, so
 // every global access is one contiguous w*4-byte segment (the per-lane strided reads the VM would otherwise issue
-// thrash L1: a workgroup's rows are hundreds of KB apart from lane to lane).
+// thrash L1: a workgroup's rows are hundreds of KB apart from lane to lane).  The (row, column) pairs are dealt to all the
+// threads of the workgroup and eight loads go out before the first is awaited: one load per trip, awaited on the spot, made
+// the staging a chain of n_rows memory round trips -- the longest phase of the permutation and quotient kernels.
 __device__ __forceinline__ void stage_rows(uint32_t* __restrict__ tile, uint32_t wp, const uint32_t* __restrict__ mat, uint32_t w,
                                            const uint32_t* __restrict__ idx, uint32_t n_rows) {
-    for (uint32_t r = 0; r < n_rows; r++) {
-        const size_t g = idx[r];
-        for (uint32_t c = threadIdx.x; c < w; c += blockDim.x) tile[r * wp + c] = mat[g * w + c];
+    constexpr int UR = 8;
+    const uint32_t total = n_rows * w;  // < 2^24: the quotient e / w below is exact after one correction step
+    const float inv_w = 1.0f / (float)w;
+    for (uint32_t e0 = threadIdx.x; e0 < total; e0 += blockDim.x * UR) {
+        uint32_t v[UR], at[UR];
+#pragma unroll
+        for (int k = 0; k < UR; k++) {
+            const uint32_t e = e0 + (uint32_t)k * blockDim.x;
+            const uint32_t ec = e < total ? e : total - 1u;  // past the end: re-read the last word, not stored
+            uint32_t r = (uint32_t)((float)ec * inv_w);
+            r += (r + 1u) * w <= ec ? 1u : 0u;
+            r -= r * w > ec ? 1u : 0u;
+            const uint32_t c = ec - r * w;
+            at[k] = r * wp + c;
+            v[k] = mat[(size_t)idx[r] * w + c];
+        }
+#pragma unroll
+        for (int k = 0; k < UR; k++)
+            if (e0 + (uint32_t)k * blockDim.x < total) tile[at[k]] = v[k];
     }
 }
 
