@@ -13,9 +13,28 @@ namespace lurkhip {
 //   mode 0: w_M^bitrev(s) / (z - x_s)   (barycentric weights of the coset 31 * <w_M>)
 //   mode 1: 1 / (x_s - z)
 int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev);
-// out_dev[p][c] = sum_{s < n_rows} mat[s][c] * u_p[s]  (p = 0, and 1 when u1 != null); out is [2][w][4] words
-int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
-                   uint32_t* out_dev);
+// Opened values.  partial[blk][p][c] = sum over the block's rows of mat[s][c] * u_p[s] (p = 0, and 1 when u1 != null) for
+// one matrix; column_dot_finish then sums the blocks of every matrix of the proof in one launch:
+// out_dev[out_off + (p * w + c) * 4 ..] = sum_{s < n_rows} mat[s][c] * u_p[s].
+size_t column_dot_partial_words(uint32_t w, size_t n_rows);
+int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
+                           uint32_t* partial_dev);
+struct DotJob {
+    const uint32_t* partial;
+    uint32_t w;
+    size_t n_rows;
+    uint32_t out_off;  // word offset of the matrix's [2][w][4] block in out_dev
+    bool two_points;
+};
+constexpr uint32_t DOT_FINISH_MAX = 64;
+struct DotFinishArgs {
+    uint32_t n;
+    uint32_t col_start[DOT_FINISH_MAX + 1];
+    const uint32_t* partial[DOT_FINISH_MAX];
+    uint32_t w[DOT_FINISH_MAX], n_blocks[DOT_FINISH_MAX], out_off[DOT_FINISH_MAX];
+    uint32_t* out;
+};
+int32_t column_dot_finish(lurkhip_ctx* ctx, const std::vector<DotJob>& jobs, uint32_t* out_dev);
 // reduced openings of the narrow matrices of one height in one launch (fri.hip: k_reduce_openings_narrow)
 constexpr uint32_t NARROW_MAX_W = 16, NARROW_MAX_MATS = 16;
 struct NarrowMat {

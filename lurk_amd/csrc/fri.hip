@@ -174,11 +174,15 @@ __global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__
     }
 }
 
-// out[p][c] = sum over blocks of partial[blk][p][c]; one workgroup per (p, c)
-__global__ __launch_bounds__(256) void k_dot_finish(const uint32_t* __restrict__ partial, uint32_t w, uint32_t n_blocks,
-                                                     uint32_t* __restrict__ out) {
+// out[p][c] = sum over blocks of partial[blk][p][c]; one workgroup per (p, c),
+// every matrix of a proof in one launch: block -> (matrix, point, column) through the prefix sums in the arguments
+__global__ __launch_bounds__(256) void k_dot_finish_all(DotFinishArgs a) {
     __shared__ uint32_t sh[256][4];
-    const uint32_t c = blockIdx.x, p = blockIdx.y;
+    uint32_t m = 0;
+    while (m + 1 < a.n && blockIdx.x >= a.col_start[m + 1]) m++;
+    const uint32_t local = blockIdx.x - a.col_start[m], w = a.w[m], n_blocks = a.n_blocks[m];
+    const uint32_t p = local >= w ? 1u : 0u, c = local - p * w;
+    const uint32_t* __restrict__ partial = a.partial[m];
     ef t = bb::ef_zero();
     for (uint32_t b = threadIdx.x; b < n_blocks; b += 256) t = bb::ef_add(t, ef_load(partial + (((size_t)b * 2 + p) * w + c) * 4));
     for (int k = 0; k < 4; k++) sh[threadIdx.x][k] = t.c[k];
@@ -189,7 +193,7 @@ __global__ __launch_bounds__(256) void k_dot_finish(const uint32_t* __restrict__
         __syncthreads();
     }
     if (threadIdx.x == 0)
-        for (int k = 0; k < 4; k++) out[((size_t)p * w + c) * 4 + k] = sh[0][k];
+        for (int k = 0; k < 4; k++) a.out[a.out_off[m] + ((size_t)p * w + c) * 4 + k] = sh[0][k];
 }
 
 // ---------------------------------------------------------------- reduced openings
@@ -495,14 +499,34 @@ int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, ui
     return LURKHIP_OK;
 }
 
-int32_t column_dot(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
-                   uint32_t* out_dev) {
+size_t column_dot_partial_words(uint32_t w, size_t n_rows) { return ((n_rows + DOT_ROWS - 1) / DOT_ROWS) * 2 * w * 4; }
+
+int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
+                           uint32_t* partial_dev) {
     const uint32_t n_blocks = (uint32_t)((n_rows + DOT_ROWS - 1) / DOT_ROWS);
-    void* partial = nullptr;
-    LH_TRY(pool_alloc(ctx, (size_t)n_blocks * 2 * w * 16, &partial));
-    hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, (uint32_t*)partial);
-    hipLaunchKernelGGL(k_dot_finish, dim3(w, u1 ? 2 : 1), dim3(256), 0, ctx->stream, (const uint32_t*)partial, w, n_blocks, out_dev);
-    pool_release(ctx, partial);
+    hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, partial_dev);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t column_dot_finish(lurkhip_ctx* ctx, const std::vector<DotJob>& jobs, uint32_t* out_dev) {
+    for (size_t at = 0; at < jobs.size(); at += DOT_FINISH_MAX) {
+        DotFinishArgs a{};
+        a.n = (uint32_t)std::min<size_t>(DOT_FINISH_MAX, jobs.size() - at);
+        a.out = out_dev;
+        uint32_t cols = 0;
+        for (uint32_t m = 0; m < a.n; m++) {
+            const DotJob& j = jobs[at + m];
+            a.col_start[m] = cols;
+            a.partial[m] = j.partial;
+            a.w[m] = j.w;
+            a.n_blocks[m] = (uint32_t)((j.n_rows + DOT_ROWS - 1) / DOT_ROWS);
+            a.out_off[m] = j.out_off;
+            cols += j.w * (j.two_points ? 2u : 1u);
+        }
+        a.col_start[a.n] = cols;
+        if (cols) hipLaunchKernelGGL(k_dot_finish_all, dim3(cols), dim3(256), 0, ctx->stream, a);
+    }
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

@@ -431,7 +431,14 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     uint32_t* dot_out = nullptr;
     PTRY(palloc(dot_words * 4, &dot_out));
     {
-        size_t k = 0;
+        // per-block partial sums of every matrix in one buffer, summed by one launch at the end
+        size_t partial_words = 0;
+        for (const Round& r : rounds)
+            for (int m = 0; m < r.c->n_mats; m++) partial_words += column_dot_partial_words(r.c->width[m], (size_t)1 << (r.c->log_h[m] - log_blowup));
+        uint32_t* partials = nullptr;
+        PTRY(palloc(std::max<size_t>(partial_words, 4) * 4, &partials));
+        std::vector<DotJob> jobs;
+        size_t k = 0, at = 0;
         for (const Round& r : rounds)
             for (int m = 0; m < r.c->n_mats; m++, k++) {
                 const int log_n = r.c->log_h[m] - log_blowup;
@@ -439,8 +446,11 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
                 uint32_t *u0 = nullptr, *u1 = nullptr;
                 PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
                 if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
-                PTRY(column_dot(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, dot_out + dot_off[k]));
+                PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
+                jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
+                at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
             }
+        PTRY(column_dot_finish(ctx, jobs, dot_out));
     }
     std::vector<uint32_t> dot_host(dot_words);
     PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
