@@ -283,6 +283,10 @@ __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
     uint32_t t = blockIdx.x;
     if (t >= n_tiles) return;
     fetch(t);
+    // The alpha powers (first four words of each centred entry) sit in LDS behind the tile: read from global memory inside the
+    // column loop they were vector loads, and waiting for one also waited for the next tile's rows in flight.
+    uint32_t* __restrict__ apw = tile + (NV * 66 + 64 + 8);
+    for (uint32_t e = lane; e < 4u * a.w; e += 64u) apw[e] = a.alpha_pows[8u * (e >> 2) + (e & 3u)];
     const uint32_t wbase = lane + (lane >> 5);  // position of flat word e = k * 64 + lane: e + (e >> 5) = k * 66 + wbase
     for (; t < n_tiles; t += gridDim.x) {
 #pragma unroll
@@ -294,11 +298,10 @@ __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
         LazyEf rr;
         rr.zero();
         uint32_t e = lane * a.w;
-        const uint32_t* __restrict__ ap = a.alpha_pows;
         for (uint32_t c = 0; c < a.w; c++, e++) {
-            int32_t pw[8];
-            load_w8(pw, ap + 8 * c);
-            rr.add_base(tile[e + (e >> 5)], pw);
+            const uint4 q = *reinterpret_cast<const uint4*>(apw + 4 * c);
+            const int32_t pw[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+            rr.add_base_v(tile[e + (e >> 5)], pw);
         }
         if (s < a.m_rows) {
             const ef r = rr.value();
@@ -540,7 +543,7 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
         // 4 GiB of words and more: 64-bit word indices; LURKHIP_OPENINGS_FORCE_64BIT (test hook) takes that path at any size
         const bool big = (size_t)m_rows * w >= ((size_t)1 << 30) || getenv("LURKHIP_OPENINGS_FORCE_64BIT") != nullptr;
         auto launch = [&](auto kernel, auto kernel_big, int nv) {
-            const size_t lds = ((size_t)nv * 66 + 64 + 8) * 4;
+            const size_t lds = ((size_t)nv * 66 + 64 + 8 + 4 * (size_t)nv) * 4;  // tile + the alpha powers of its columns
             const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
             const unsigned blocks = (unsigned)std::min<size_t>(n_tiles, (size_t)per_cu * ctx->num_cus);
             if (big) hipLaunchKernelGGL(kernel_big, dim3(blocks), dim3(64), lds, ctx->stream, a);
