@@ -166,11 +166,6 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
         *out_dev = (LeafCol*)it->second.dev;
         return LURKHIP_OK;
     }
-    if (ctx->leafcol_tables.size() >= 1024) {  // bound the cache: tables of past shapes are dropped wholesale
-        LH_HIP(ctx, stream_wait(ctx));
-        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
-        ctx->leafcol_tables.clear();
-    }
     lurkhip_ctx::LeafColTable& t = ctx->leafcol_tables[key];
     t.host.resize(std::max<size_t>(n_cols, 1) * sizeof(LeafCol));
     LeafCol* cols = reinterpret_cast<LeafCol*>(t.host.data());
@@ -192,6 +187,15 @@ constexpr size_t TOP_NODES = 64;
 int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
+    // Bound the column-table cache HERE, before this tree hands out any table: make_cols results are kept (TopInject) until the
+    // launch that reads them is enqueued, so nothing may be evicted between the first make_cols of a tree and its last launch.
+    // The same invariant covers pool_alloc's out-of-memory path (ctx.hip), which also drops the tables: the only pool_alloc of
+    // a tree (the digests) comes before its first make_cols.
+    if (ctx->leafcol_tables.size() >= 1024) {
+        LH_HIP(ctx, stream_wait(ctx));
+        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
+        ctx->leafcol_tables.clear();
+    }
     c->log_max = *std::max_element(c->log_h.begin(), c->log_h.end());
     // stable order by height, tallest first (p3 sorts matrices by height descending)
     std::vector<int> order(c->n_mats);

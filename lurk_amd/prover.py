@@ -299,7 +299,9 @@ class Machine(_ShardProver):
                 n, h, w = chip.trace_shape(shard)
                 if n == 0:
                     continue
-                t = torch.zeros((h, w), dtype=torch.int32, device="cuda")
+                # torch.empty, not zeros: a fill would be enqueued on torch's stream, which is not ordered with the
+                # context's (non-blocking) stream, and could land after the trace kernel; the kernel writes every word
+                t = torch.empty((h, w), dtype=torch.int32, device="cuda")
                 chip.generate_trace_dev(shard, t, repr=N.REPR_MONTY)
             elif kind == "mem":
                 if shard.index != 0:
@@ -337,7 +339,7 @@ class Machine(_ShardProver):
             else:
                 chip = BytesChip(self.ctx)
             p = PreparedFuncTrace(chip, shard)
-            t = torch.zeros((p.height, p.width), dtype=torch.int32, device="cuda")
+            t = torch.empty((p.height, p.width), dtype=torch.int32, device="cuda")  # every word is written by the trace kernel
             out.append((mi, air, p.height.bit_length() - 1, t, p))
         torch.cuda.synchronize()
         return out
