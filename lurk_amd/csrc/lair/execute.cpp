@@ -10,6 +10,10 @@
 // kernel then needs no lookups at all (DESIGN.md "row stream").
 #include <algorithm>
 #include <cstring>
+#include <deque>
+#include <new>
+
+#include <sys/mman.h>
 
 #include "../babybear.h"
 #include "../p2_params.h"
@@ -17,21 +21,46 @@
 
 namespace lair {
 
+// ------------------------------------------------------------------ huge-page allocator (lair.h: HugeAlloc)
+namespace {
+constexpr size_t HUGE_MIN = (size_t)4 << 20, HUGE_PAGE = (size_t)2 << 20;
+}
+void* huge_alloc(size_t bytes) {
+    if (bytes < HUGE_MIN) return ::operator new(bytes);
+    const size_t len = (bytes + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1);
+    // over-map by one huge page, keep the aligned part
+    char* base = (char*)mmap(nullptr, len + HUGE_PAGE, PROT_READ | PROT_WRITE, MAP_PRIVATE | MAP_ANONYMOUS, -1, 0);
+    if (base == MAP_FAILED) throw std::bad_alloc();
+    char* p = (char*)(((uintptr_t)base + HUGE_PAGE - 1) & ~(uintptr_t)(HUGE_PAGE - 1));
+    if (p > base) munmap(base, (size_t)(p - base));
+    const size_t tail = (size_t)(base + len + HUGE_PAGE - (p + len));
+    if (tail) munmap(p + len, tail);
+    (void)madvise(p, len, MADV_HUGEPAGE);  // advisory: small pages if the kernel declines
+    return p;
+}
+void huge_free(void* p, size_t bytes) {
+    if (bytes < HUGE_MIN) {
+        ::operator delete(p);
+        return;
+    }
+    munmap(p, (bytes + HUGE_PAGE - 1) & ~(HUGE_PAGE - 1));
+}
+
 // ------------------------------------------------------------------ byte records (gadgets/bytes/record.rs:112-158)
 void BytesRecord::range_check_u8_pair(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& rq) {
     uint16_t key = (uint16_t)(i1 | (i2 << 8));
-    rq.push_back(records[key].range_u8.new_lookup(nonce));
+    rq.push_back(at(key).range_u8.new_lookup(nonce));
 }
 void BytesRecord::range_check_u8_iter(const uint8_t* b, size_t n, uint32_t nonce, std::vector<Record>& rq) {
     for (size_t i = 0; i < n; i += 2) range_check_u8_pair(b[i], i + 1 < n ? b[i + 1] : 0, nonce, rq);
 }
 bool BytesRecord::less_than(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& rq) {
     uint16_t key = (uint16_t)(i1 | (i2 << 8));
-    rq.push_back(records[key].less_than.new_lookup(nonce));
+    rq.push_back(at(key).less_than.new_lookup(nonce));
     return i1 < i2;
 }
 void BytesRecord::range_check_u16(uint16_t v, uint32_t nonce, std::vector<Record>& rq) {
-    rq.push_back(records[v].range_u16.new_lookup(nonce));
+    rq.push_back(at(v).range_u16.new_lookup(nonce));
 }
 
 // ------------------------------------------------------------------ host Poseidon2 (for `execute` only)
@@ -306,7 +335,7 @@ QueryRecord::QueryRecord(const Toplevel& t) {
 void QueryRecord::clean() {
     for (auto& q : func_queries) q.clear();
     for (auto& q : mem_queries) q.clear();
-    bytes.records.clear();
+    bytes.clear();
     emitted.clear();
 }
 
@@ -324,21 +353,27 @@ size_t num_shards(const QueryRecord& r, uint32_t max_shard_size) {
 // ------------------------------------------------------------------ the interpreter (execute.rs:436-784)
 namespace {
 
-struct ExecEntry {
-    const Op* op;      // non-null: an op
-    const Ctrl* ctrl;  // non-null: a ctrl
+// One activation of a Func.  The reference keeps an exec-entry stack plus a caller stack (execute.rs:436-470); a block's
+// control node is always its last entry, so a (block, next op) cursor per activation is the same traversal.  Activations
+// live in a grow-only pool and are reused (their vectors keep their capacity): multi-million-query executions recurse
+// millions of frames deep, and allocating five vectors per call was most of the interpreter's time.
+struct Frame {
+    const Block* blk = nullptr;
+    size_t ip = 0;
+    bool preimg = false;
+    bool partial = false;
+    uint32_t func_index = 0;
+    uint32_t nonce = 0;
+    // where this activation's slices start in the five arenas (Arenas below)
+    size_t map0 = 0, req0 = 0, dep0 = 0, dreq0 = 0, hint0 = 0;
 };
 
-struct CallerState {
-    bool preimg;
-    uint32_t func_index;
-    uint32_t nonce;
-    List map;
-    std::vector<Record> requires_;
-    bool partial;
-    std::vector<uint32_t> depths;
-    std::vector<Record> depth_requires;
-    List hints;
+// The variable map, requires, callee depths, depth requires and hints of every live activation, each kind in one
+// contiguous stack: only the innermost activation grows, and a return truncates the stacks to its start offsets, so live
+// memory is exactly the live data (no per-frame capacity slack, no allocation per call).
+struct Arenas {
+    BigVec<uint32_t> map, depths, hints;
+    BigVec<Record> requires_, depth_requires;
 };
 
 void depth_less_than_populate(uint32_t lhs, uint32_t rhs, BytesRecord& bytes, uint32_t nonce, std::vector<Record>& rq) {
@@ -357,58 +392,56 @@ void depth_less_than_populate(uint32_t lhs, uint32_t rhs, BytesRecord& bytes, ui
 }  // namespace
 
 static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& self, const List& args, QueryRecord& q) {
-    uint32_t func_index = self.index;
     {
         QueryResult top;
         top.provide.count = 1;
-        q.func_queries[func_index].insert_full(args, top);
+        q.func_queries[self.index].insert_full(args, top);
     }
-    uint32_t nonce = (uint32_t)q.func_queries[func_index].find(args);
-    List map = args;
-    std::vector<Record> requires_;
-    bool partial = self.partial;
-    std::vector<uint32_t> depths;
-    std::vector<Record> depth_requires;
-    List hints;
+    std::deque<Frame> frames;  // stable addresses; frames[0 .. depth] are live
+    Arenas A;
+    size_t depth = 0;
+    frames.emplace_back();
+    Frame* f = &frames[0];
+    f->blk = &self.body;
+    f->func_index = self.index;
+    f->nonce = (uint32_t)q.func_queries[self.index].find(args);
+    f->partial = self.partial;
+    A.map.insert(A.map.end(), args.begin(), args.end());
+    List key, inp, out;  // scratch, reused
+    std::vector<Record> chip_requires;
 
-    std::vector<ExecEntry> stack;
-    std::vector<CallerState> callers;
-    auto push_block = [&](const Block& b) {
-        stack.push_back(ExecEntry{nullptr, &b.ctrl});
-        for (auto it = b.ops.rbegin(); it != b.ops.rend(); ++it) stack.push_back(ExecEntry{&*it, nullptr});
-    };
-    push_block(self.body);
-
-    auto enter = [&](bool preimg, uint32_t callee_index, List inp) {
-        uint32_t callee_nonce = q.func_queries[callee_index].insert_full(inp, QueryResult());
-        CallerState cs;
-        cs.preimg = preimg;
-        cs.func_index = func_index;
-        cs.nonce = nonce;
-        cs.map.swap(map);
-        cs.requires_.swap(requires_);
-        cs.partial = partial;
-        cs.depths.swap(depths);
-        cs.depth_requires.swap(depth_requires);
-        cs.hints.swap(hints);
-        callers.push_back(std::move(cs));
-        map = std::move(inp);
-        func_index = callee_index;
-        nonce = callee_nonce;
-        const Func& f = t.funcs[func_index];
-        partial = f.partial;
-        push_block(f.body);
+    auto enter = [&](bool preimg, uint32_t callee_index, const List& input) {
+        const uint32_t callee_nonce = q.func_queries[callee_index].insert_full(input, QueryResult());
+        depth++;
+        if (depth == frames.size()) frames.emplace_back();
+        Frame* n = &frames[depth];
+        const Func& cf = t.funcs[callee_index];
+        n->blk = &cf.body;
+        n->ip = 0;
+        n->preimg = preimg;
+        n->partial = cf.partial;
+        n->func_index = callee_index;
+        n->nonce = callee_nonce;
+        n->map0 = A.map.size();
+        n->req0 = A.requires_.size();
+        n->dep0 = A.depths.size();
+        n->dreq0 = A.depth_requires.size();
+        n->hint0 = A.hints.size();
+        A.map.insert(A.map.end(), input.begin(), input.end());
+        f = n;
     };
 
-    while (!stack.empty()) {
-        ExecEntry e = stack.back();
-        stack.pop_back();
-        if (e.op) {
-            const Op& op = *e.op;
+    for (;;) {
+        if (f->ip < f->blk->ops.size()) {
+            const Op& op = f->blk->ops[f->ip++];
+            // the innermost activation's variable map is the top slice of A.map; `map` is re-read per op because a push may
+            // move the arena (values are fetched before they are pushed)
+            const uint32_t* map = A.map.data() + f->map0;
+            const uint32_t nonce = f->nonce;
             switch (op.kind) {
                 case OpKind::AssertEq:
                     for (size_t i = 0; i < op.a.size(); i++)
-                        if (map[op.a[i]] != map[op.b[i]]) throw ExecError("assert_eq! failed in " + t.funcs[func_index].name);
+                        if (map[op.a[i]] != map[op.b[i]]) throw ExecError("assert_eq! failed in " + t.funcs[f->func_index].name);
                     break;
                 case OpKind::AssertNe: {
                     bool unequal = false;
@@ -417,22 +450,21 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                             unequal = true;
                             break;
                         }
-                    if (!unequal) throw ExecError("assert_ne! failed in " + t.funcs[func_index].name);
+                    if (!unequal) throw ExecError("assert_ne! failed in " + t.funcs[f->func_index].name);
                     break;
                 }
                 case OpKind::Contains: {
                     bool found = false;
                     for (uint32_t a : op.a) found = found || map[a] == map[op.y];
-                    if (!found) throw ExecError("contains! failed in " + t.funcs[func_index].name);
+                    if (!found) throw ExecError("contains! failed in " + t.funcs[f->func_index].name);
                     break;
                 }
                 case OpKind::Call:
                 case OpKind::PreImg: {
                     const bool pre = op.kind == OpKind::PreImg;
                     const uint32_t callee = op.x;
-                    List key;
+                    key.clear();
                     for (uint32_t v : op.a) key.push_back(map[v]);
-                    List inp;
                     if (pre) {
                         auto& inv = q.inv_func_queries[callee];
                         if (!inv) throw ExecError("Missing inverse map");
@@ -453,45 +485,45 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                             throw ExecError("memoized output differs from preimage key");
                         const uint32_t* ext = pre ? inp.data() : res_out;
                         const size_t n_ext = pre ? inp.size() : n_out;
-                        map.insert(map.end(), ext, ext + n_ext);
-                        hints.insert(hints.end(), ext, ext + n_ext);
-                        requires_.push_back(res.provide.new_lookup(nonce));
+                        A.map.insert(A.map.end(), ext, ext + n_ext);
+                        A.hints.insert(A.hints.end(), ext, ext + n_ext);
+                        A.requires_.push_back(res.provide.new_lookup(nonce));
                         const bool callee_partial = t.funcs[callee].partial;
-                        if (callee_partial) hints.push_back(res.depth);
-                        if (partial && callee_partial) depths.push_back(res.depth);
+                        if (callee_partial) A.hints.push_back(res.depth);
+                        if (f->partial && callee_partial) A.depths.push_back(res.depth);
                     } else {
-                        enter(pre, callee, std::move(inp));
+                        enter(pre, callee, inp);
                     }
                     break;
                 }
                 case OpKind::Const:
-                    map.push_back(op.c);
+                    A.map.push_back(op.c);
                     break;
                 case OpKind::Add:
-                    map.push_back(fadd(map[op.x], map[op.y]));
+                    A.map.push_back(fadd(map[op.x], map[op.y]));
                     break;
                 case OpKind::Sub:
-                    map.push_back(fsub(map[op.x], map[op.y]));
+                    A.map.push_back(fsub(map[op.x], map[op.y]));
                     break;
                 case OpKind::Mul:
-                    map.push_back(fmul(map[op.x], map[op.y]));
+                    A.map.push_back(fmul(map[op.x], map[op.y]));
                     break;
                 case OpKind::Inv:
-                    map.push_back(finv(map[op.x]));
+                    A.map.push_back(finv(map[op.x]));
                     break;
                 case OpKind::Not:
-                    map.push_back(map[op.x] == 0 ? 1u : 0u);
+                    A.map.push_back(map[op.x] == 0 ? 1u : 0u);
                     break;
                 case OpKind::Store: {
-                    List vals;
-                    for (uint32_t v : op.a) vals.push_back(map[v]);
-                    QueryMap& mm = q.mem_queries[mem_index_from_len((uint32_t)vals.size())];
-                    int i = mm.find(vals);
-                    if (i < 0) i = (int)mm.insert_full(vals, QueryResult());
+                    key.clear();
+                    for (uint32_t v : op.a) key.push_back(map[v]);
+                    QueryMap& mm = q.mem_queries[mem_index_from_len((uint32_t)key.size())];
+                    int i = mm.find(key);
+                    if (i < 0) i = (int)mm.insert_full(key, QueryResult());
                     uint32_t ptr = (uint32_t)(i + 1);
-                    map.push_back(ptr);
-                    hints.push_back(ptr);
-                    requires_.push_back(mm.vals[i].provide.new_lookup(nonce));
+                    A.map.push_back(ptr);
+                    A.hints.push_back(ptr);
+                    A.requires_.push_back(mm.vals[i].provide.new_lookup(nonce));
                     break;
                 }
                 case OpKind::Load: {
@@ -499,16 +531,18 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                     QueryMap& mm = q.mem_queries[mem_index_from_len(op.x)];
                     if (ptr == 0 || ptr > mm.size()) throw ExecError("Unbound pointer");
                     const uint32_t* vals = mm.key(ptr - 1);
-                    map.insert(map.end(), vals, vals + op.x);
-                    hints.insert(hints.end(), vals, vals + op.x);
-                    requires_.push_back(mm.vals[ptr - 1].provide.new_lookup(nonce));
+                    A.map.insert(A.map.end(), vals, vals + op.x);
+                    A.hints.insert(A.hints.end(), vals, vals + op.x);
+                    A.requires_.push_back(mm.vals[ptr - 1].provide.new_lookup(nonce));
                     break;
                 }
                 case OpKind::ExternCall: {
-                    List in;
-                    for (uint32_t v : op.a) in.push_back(map[v]);
-                    List out = t.chips[op.x].execute(in, nonce, q.bytes, requires_);
-                    map.insert(map.end(), out.begin(), out.end());
+                    key.clear();
+                    for (uint32_t v : op.a) key.push_back(map[v]);
+                    chip_requires.clear();
+                    List res = t.chips[op.x].execute(key, nonce, q.bytes, chip_requires);
+                    A.requires_.insert(A.requires_.end(), chip_requires.begin(), chip_requires.end());
+                    A.map.insert(A.map.end(), res.begin(), res.end());
                     break;
                 }
                 case OpKind::Emit: {
@@ -523,7 +557,9 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                         if (map[a] > 255) throw ExecError("Variable not in u8 range");
                         by.push_back((uint8_t)map[a]);
                     }
-                    q.bytes.range_check_u8_iter(by.data(), by.size(), nonce, requires_);
+                    chip_requires.clear();
+                    q.bytes.range_check_u8_iter(by.data(), by.size(), nonce, chip_requires);
+                    A.requires_.insert(A.requires_.end(), chip_requires.begin(), chip_requires.end());
                     break;
                 }
                 case OpKind::Breakpoint:
@@ -532,81 +568,79 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
             }
             continue;
         }
-        const Ctrl& c = *e.ctrl;
+        const Ctrl& c = f->blk->ctrl;
         if (c.kind == Ctrl::Choose) {
-            const Block* b = c.match_case(List{map[c.var]});
+            key.assign(1, A.map[f->map0 + c.var]);
+            const Block* b = c.match_case(key);
             if (!b) throw ExecError("No match");
-            push_block(*b);
+            f->blk = b;
+            f->ip = 0;
             continue;
         }
         if (c.kind == Ctrl::ChooseMany) {
-            List k;
-            for (uint32_t v : c.vars) k.push_back(map[v]);
-            const Block* b = c.match_case(k);
+            key.clear();
+            for (uint32_t v : c.vars) key.push_back(A.map[f->map0 + v]);
+            const Block* b = c.match_case(key);
             if (!b) throw ExecError("No match");
-            push_block(*b);
+            f->blk = b;
+            f->ip = 0;
             continue;
         }
         // Return
-        List out;
-        for (uint32_t v : c.ret) out.push_back(map[v]);
+        out.clear();
+        for (uint32_t v : c.ret) out.push_back(A.map[f->map0 + v]);
+        const uint32_t func_index = f->func_index, nonce = f->nonce;
         QueryMap& qm = q.func_queries[func_index];
         QueryResult& result = qm.vals[nonce];
         if (result.has_output) throw ExecError("query evaluated twice");
-        const List inp(qm.key(nonce), qm.key(nonce) + qm.key_len);
+        inp.assign(qm.key(nonce), qm.key(nonce) + qm.key_len);
         if (q.inv_func_queries[func_index]) (*q.inv_func_queries[func_index])[out] = inp;
-        if (partial) {
-            uint32_t depth = 0;
-            for (uint32_t d : depths) depth = std::max(depth, d + 1);
-            uint8_t by[4] = {(uint8_t)depth, (uint8_t)(depth >> 8), (uint8_t)(depth >> 16), (uint8_t)(depth >> 24)};
-            q.bytes.range_check_u8_iter(by, 4, nonce, depth_requires);
-            for (uint32_t d : depths) depth_less_than_populate(d, depth, q.bytes, nonce, depth_requires);
-            result.depth = depth;
+        if (f->partial) {
+            uint32_t d_self = 0;
+            for (size_t i = f->dep0; i < A.depths.size(); i++) d_self = std::max(d_self, A.depths[i] + 1);
+            uint8_t by[4] = {(uint8_t)d_self, (uint8_t)(d_self >> 8), (uint8_t)(d_self >> 16), (uint8_t)(d_self >> 24)};
+            chip_requires.clear();
+            q.bytes.range_check_u8_iter(by, 4, nonce, chip_requires);
+            for (size_t i = f->dep0; i < A.depths.size(); i++) depth_less_than_populate(A.depths[i], d_self, q.bytes, nonce, chip_requires);
+            A.depth_requires.insert(A.depth_requires.end(), chip_requires.begin(), chip_requires.end());
+            result.depth = d_self;
         }
-        // finalize: the frame's accumulators move into the table's pools
+        // finalize: the activation's slices move into the table's pools
         result.out_off = (uint32_t)qm.pool.size();
         qm.pool.insert(qm.pool.end(), out.begin(), out.end());
         result.hint_off = (uint32_t)qm.pool.size();
-        result.n_hints = (uint32_t)hints.size();
-        qm.pool.insert(qm.pool.end(), hints.begin(), hints.end());
+        result.n_hints = (uint32_t)(A.hints.size() - f->hint0);
+        qm.pool.insert(qm.pool.end(), A.hints.begin() + f->hint0, A.hints.end());
         result.req_off = (uint32_t)qm.rec_pool.size();
-        result.n_requires = (uint32_t)requires_.size();
-        result.n_depth_requires = (uint32_t)depth_requires.size();
-        qm.rec_pool.insert(qm.rec_pool.end(), requires_.begin(), requires_.end());
-        qm.rec_pool.insert(qm.rec_pool.end(), depth_requires.begin(), depth_requires.end());
+        result.n_requires = (uint32_t)(A.requires_.size() - f->req0);
+        result.n_depth_requires = (uint32_t)(A.depth_requires.size() - f->dreq0);
+        qm.rec_pool.insert(qm.rec_pool.end(), A.requires_.begin() + f->req0, A.requires_.end());
+        qm.rec_pool.insert(qm.rec_pool.end(), A.depth_requires.begin() + f->dreq0, A.depth_requires.end());
         if (qm.pool.size() > 0xfffffff0ull || qm.rec_pool.size() > 0xfffffff0ull) throw ExecError("query table pools exceed 2^32 words");
         result.has_output = true;
-        requires_.clear();
-        depth_requires.clear();
-        hints.clear();
-        if (callers.empty()) {
-            if (!stack.empty()) throw ExecError("exec stack not empty at exit");
-            uint32_t depth = 0;
-            for (uint32_t d : depths) depth = std::max(depth, d + 1);
-            return {out, depth};
+        if (depth == 0) {
+            uint32_t d_top = 0;
+            for (size_t i = f->dep0; i < A.depths.size(); i++) d_top = std::max(d_top, A.depths[i] + 1);
+            return {out, d_top};
         }
-        CallerState cs = std::move(callers.back());
-        callers.pop_back();
-        const bool callee_partial = partial;
+        // pop: the caller's slices are the arenas' tops again
+        A.map.resize(f->map0);
+        A.requires_.resize(f->req0);
+        A.depths.resize(f->dep0);
+        A.depth_requires.resize(f->dreq0);
+        A.hints.resize(f->hint0);
+        const bool callee_partial = f->partial, callee_preimg = f->preimg;
         const uint32_t callee_depth = result.depth;
-        func_index = cs.func_index;
-        nonce = cs.nonce;
-        map = std::move(cs.map);
-        requires_ = std::move(cs.requires_);
-        partial = cs.partial;
-        depths = std::move(cs.depths);
-        depth_requires = std::move(cs.depth_requires);
-        hints = std::move(cs.hints);
-        const List& ext = cs.preimg ? inp : out;
-        map.insert(map.end(), ext.begin(), ext.end());
-        hints.insert(hints.end(), ext.begin(), ext.end());
-        // `result` may have moved if the callee's table grew: it cannot have (same table slot, no
-        // insertion between the Return and here), so the reference stays valid
-        requires_.push_back(result.provide.new_lookup(nonce));
-        if (callee_partial) hints.push_back(callee_depth);
-        if (partial && callee_partial) depths.push_back(callee_depth);
+        depth--;
+        f = &frames[depth];
+        const List& ext = callee_preimg ? inp : out;
+        A.map.insert(A.map.end(), ext.begin(), ext.end());
+        A.hints.insert(A.hints.end(), ext.begin(), ext.end());
+        // `result` still refers to the callee's table slot: nothing was inserted between the Return and here
+        A.requires_.push_back(result.provide.new_lookup(f->nonce));
+        if (callee_partial) A.hints.push_back(callee_depth);
+        if (f->partial && callee_partial) A.depths.push_back(callee_depth);
     }
-    throw ExecError("exec stack exhausted without a return");
 }
 
 List execute(const Toplevel& t, const Func& func, const List& args, QueryRecord& record) {

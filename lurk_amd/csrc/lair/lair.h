@@ -45,6 +45,27 @@ struct ParseError : std::runtime_error {
 
 using List = std::vector<uint32_t>;
 
+// Allocator of the multi-gigabyte tables of a big execution (query pools, interpreter arenas).  Blocks of 4 MiB and more are
+// mapped directly, 2 MiB aligned and advised as transparent huge pages: first-touch page faults of 4 KiB pages cost more than
+// the interpreter's own work (measured: 3.5 s of system time in a 5.5 s execution of 0.8 M queries).
+void* huge_alloc(size_t bytes);
+void huge_free(void* p, size_t bytes);
+template <class T>
+struct HugeAlloc {
+    using value_type = T;
+    HugeAlloc() = default;
+    template <class U>
+    HugeAlloc(const HugeAlloc<U>&) {}
+    T* allocate(size_t n) { return static_cast<T*>(huge_alloc(n * sizeof(T))); }
+    void deallocate(T* p, size_t n) { huge_free(p, n * sizeof(T)); }
+    template <class U>
+    bool operator==(const HugeAlloc<U>&) const { return true; }
+    template <class U>
+    bool operator!=(const HugeAlloc<U>&) const { return false; }
+};
+template <class T>
+using BigVec = std::vector<T, HugeAlloc<T>>;
+
 // ---------------------------------------------------------------- IR (expr.rs)
 struct Var {
     std::string name;  // user names as written; internal names start with '$'
@@ -162,7 +183,25 @@ struct BytesInputRecord {  // gadgets/bytes/record.rs:50-71, order fixed by iter
 };
 
 struct BytesRecord {  // gadgets/bytes/record.rs:14-17
-    std::map<uint16_t, BytesInputRecord> records;
+    std::map<uint16_t, BytesInputRecord> records;   // ordered: the trace rows are emitted in key order
+    std::vector<BytesInputRecord*> slot;            // direct index into `records` (map nodes never move)
+    BytesRecord() = default;
+    BytesRecord(const BytesRecord& o) : records(o.records) {}  // the index points into the source's nodes: rebuilt on demand
+    BytesRecord& operator=(const BytesRecord& o) {
+        records = o.records;
+        slot.clear();
+        return *this;
+    }
+    BytesInputRecord& at(uint16_t key) {
+        if (slot.empty()) slot.assign(65536, nullptr);
+        BytesInputRecord*& p = slot[key];
+        if (!p) p = &records[key];
+        return *p;
+    }
+    void clear() {
+        records.clear();
+        slot.clear();
+    }
     void range_check_u8_pair(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& requires_);
     void range_check_u8_iter(const uint8_t* bytes, size_t n, uint32_t nonce, std::vector<Record>& requires_);
     bool less_than(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& requires_);
@@ -233,11 +272,11 @@ struct VecHash {
 // length: a function's inputs, a memory table's width), open-addressing index.
 struct QueryMap {
     uint32_t key_len = 0;
-    std::vector<uint32_t> key_pool;   // [n][key_len]
-    std::vector<QueryResult> vals;
-    std::vector<uint32_t> pool;       // outputs and hints
-    std::vector<Record> rec_pool;     // require records
-    std::vector<uint32_t> slots;      // entry index + 1, 0 = empty; power-of-two size
+    BigVec<uint32_t> key_pool;        // [n][key_len]
+    BigVec<QueryResult> vals;
+    BigVec<uint32_t> pool;            // outputs and hints
+    BigVec<Record> rec_pool;          // require records
+    BigVec<uint32_t> slots;           // entry index + 1, 0 = empty; power-of-two size
     size_t size() const { return vals.size(); }
     const uint32_t* key(size_t i) const { return key_pool.data() + i * key_len; }
     static uint64_t hash(const uint32_t* k, uint32_t n) {
