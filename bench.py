@@ -1,19 +1,27 @@
 #!/usr/bin/env python3
 """Benchmark of the Lurk proving hot path on MI355X.
 
-Workload (BASELINE.json configs[2]): one shard whose `eval` chip (width 78,
-/root/reference/src/core/eval_direct.rs:2028; the synthetic Lair function of lurk_amd/programs/synth_eval.py stands in
-for the evaluator's program text) has 2^20 rows.  The host interpreter runs once before the timed region and the
-flattened inputs of every chip (row streams, memory tables, byte-lookup records) are resident in HBM.  One *step* = one
-pass of the proving hot path over that shard, i.e. what `machine.prove::<LocalProver>` does after `execute`
-(/root/reference/benches/fib.rs:88-124): trace generation of every chip of the machine (eval chip, its callee, the memory
-tables, the byte table), main-trace commitment, LogUp permutation traces + commitment, quotient + commitment, openings
-at zeta and FRI (100 queries, 16 proof-of-work bits).  Metric: eval-steps (rows of the eval chip) proved per second.
+Workload (BASELINE.json configs[2]): a `fib`-shaped Lair machine whose `eval` chip (width 78,
+/root/reference/src/core/eval_direct.rs:2028) has 2^20 rows per GPU.  The evaluator's program text cannot be shipped, so
+the machine is the width-matched `fib-mix` of lurk_amd/programs/lurk_mix.py: the 14 chips a fib run touches with the
+reference's names, widths (eval 78 partial, eval_builtin_expr 148, eval_binop_num 107, apply 114, env_lookup 52,
+u64_add/sub 53, u64_lessthan 44, ingress 104, egress 81, hash3/4/5 493/655/815, lurk_main 97), `partial` depth columns,
+extern chips and the row ratios of SURVEY.md appendix C.  `--workload eval-only` is round 1's thinner single-function
+machine, `--workload lurk-mix` all 39 functions (BASELINE config 5, irregular widths 9 ... 815).
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): shards are independent proofs
-(`Shard::shard`, /root/reference/src/lair/execute.rs:186-216): rank r proves shard r (weak scaling); per step the ranks
-all-gather their 8-lane main-trace roots (every shard's transcript observes every root before any challenge is drawn)
-and all-reduce the extension-field cumulative sums of their chips as 4 x uint64 (the verifier's grand-sum check).
+The host interpreter runs once before the timed region and the flattened inputs of every chip (row streams, memory
+tables, byte-lookup records) are resident in HBM.  One *step* = one pass of the proving hot path over one shard per GPU,
+i.e. what `machine.prove::<LocalProver>` does after `execute` (/root/reference/benches/fib.rs:88-124): trace generation of
+every chip, main-trace commitment, LogUp permutation traces + commitment, quotient + commitment, openings at zeta and FRI
+(100 queries, 16 proof-of-work bits).  Metric: eval-steps (rows of the eval chip) proved per second.
+
+Multi-GPU (--gpus N, launched by torch.distributed.run): ONE execution with N * 2^log_rows eval rows on every rank (the
+same program, so the same query record), `ShardingConfig(2^log_rows)` -> N shards (`Shard::shard`,
+/root/reference/src/lair/execute.rs:186-216; Entrypoint / memory chips only in shard 0, lair_chip.rs:124-139), rank r
+proves shard r (`shards.assign_shards`).  Per step: every rank commits its shard's main traces, the ranks all-gather the
+8-lane roots (RCCL; every shard's transcript observes every root before any challenge is drawn), every rank proves its
+shard, and the extension-field cumulative sums are all-reduced as 4 x int64: each rank's sum is non-zero, the total is
+zero.  BASELINE config 4 literally is `--gpus 8 --log-rows 19` (2^22 rows as 8 x 2^19).
 
 Prints ONE JSON line on rank 0.
 """
@@ -30,9 +38,10 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 LOG_ROWS = 20
-WIDTH = 78
 LOG_BLOWUP = 1
-HBM_PEAK_GBS = 8000.0  # MI355X_MICROARCH.md: 8 TB/s spec
+HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
+VALU_FULL_RATE = 78.6   # T lane-instr/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md "Wave scheduling"); = 157.3 TFLOPS fp32 / 2
+VALU_HALF_RATE = 39.3   # mul-class instructions (v_mul_lo/hi, v_mad_u64_u32, VOP3 adds, ...) issue at half rate (measured)
 SPANS = ("trace_func", "commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit", "fri_query",
          "lde", "merkle_leaves", "merkle_levels", "merkle_top")
 
@@ -47,11 +56,12 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
 
 
 def cpu_baseline(round_shapes, eval_rows: int):
-    """The oracle's commit (OpenMP FFT + Poseidon2-16 Merkle) of the step's three commitment rounds -- main traces, LogUp
-    permutation traces, quotient chunks -- on synthetic matrices of exactly the shapes the GPU step commits (the CPU time of
-    an LDE + Merkle commit does not depend on the values).  Trace generation, the permutation / quotient arithmetic,
-    openings and FRI have no compiled CPU port (the oracle does them in Python), so the CPU figure is an upper bound on what
-    the port would reach on the full step; the commits are about two thirds of the GPU step."""
+    """The CPU port (oracle/commit.c: row-major Montgomery FFT + Poseidon2-16 Merkle, OpenMP) of the step's three commitment
+    rounds -- main traces, LogUp permutation traces, quotient chunks -- on synthetic matrices of exactly the shapes the GPU
+    step commits (the CPU time of an LDE + Merkle commit does not depend on the values).  Trace generation, the
+    permutation / quotient arithmetic, openings and FRI have no compiled CPU port (the oracle does them in Python), so
+    the CPU figure is an upper bound on what the port would reach on the full step; the commits are about two thirds of
+    the GPU step.  kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be built here."""
     from oracle import binding as ob
 
     ob.build()
@@ -71,8 +81,26 @@ def cpu_baseline(round_shapes, eval_rows: int):
         "cores": cores,
         "kind": "port",
         "sample": f"the three commitment rounds of one step (coset LDE x2 + Poseidon2-16 Merkle over {cols / eval_rows:.0f} columns per eval row: main, permutation, quotient), "
-                  f"OpenMP over {cores} threads, {dt:.2f} s; the GPU step also does trace generation, the permutation / quotient arithmetic, openings and FRI",
+                  f"OpenMP over {cores} threads, {dt:.2f} s; the GPU step also does trace generation, the permutation / quotient arithmetic, openings and FRI; "
+                  "not the reference binary (no Rust toolchain): never quote the ratio as 'vs the reference'",
     }
+
+
+def build_workload(name: str, world: int, log_rows: int):
+    """(source, lurk_chips, entry, main args, eval function name, description)."""
+    n = 1 << log_rows
+    if name == "eval-only":
+        from lurk_amd.programs import synth_eval as se
+
+        if world != 1:
+            raise SystemExit("--workload eval-only is single-GPU (its callee chip is taller than its eval chip, so it does not shard by eval rows)")
+        return se.SOURCE, False, se.FUNC, se.args_for_rows(n), se.FUNC, "eval-only: one width-78 non-partial function + a 9-column callee (round 1's workload)"
+    from lurk_amd.programs import lurk_mix as lm
+
+    mix = lm.fib_mix(world * n) if name == "fib-mix" else lm.lurk_mix(world * n)
+    desc = ("fib-mix: the 14 chips of a fib run with the reference's widths, partial eval, u64 extern chips, appendix-C row ratios"
+            if name == "fib-mix" else "lurk-mix: all 39 Lurk functions (widths 9 ... 815), 6 memory tables, byte table, entrypoint")
+    return mix.source, True, mix.entry, mix.main_args, "eval", desc
 
 
 def main():
@@ -80,7 +108,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--log-rows", type=int, default=LOG_ROWS)
+    ap.add_argument("--workload", choices=("fib-mix", "eval-only", "lurk-mix"), default="fib-mix")
+    ap.add_argument("--log-rows", type=int, default=None, help="log2 of the eval rows per GPU (default 20; 18 for lurk-mix)")
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -105,53 +134,68 @@ def main():
     torch.cuda.set_device(local_rank)
 
     import lurk_amd
-    from lurk_amd import lair, prover
-    from lurk_amd.programs import synth_eval as se
+    from lurk_amd import lair, prover, shards
 
     ctx = lurk_amd.Context(local_rank)
-    log_rows, n = args.log_rows, 1 << args.log_rows
+    log_rows = args.log_rows if args.log_rows is not None else (18 if args.workload == "lurk-mix" else LOG_ROWS)
+    n = 1 << log_rows
+    dev = "cuda" if distributed else "cpu"
 
-    # ---- host side, once: execute the program, flatten every chip's inputs into HBM
-    t_host = time.perf_counter()
-    top = lair.Toplevel(se.SOURCE)
+    # ---- host side, once: execute the ONE program on every rank, flatten this rank's shard into HBM
+    source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, world, log_rows)
+    t0 = time.perf_counter()
+    top = lair.Toplevel(source, lurk_chips=lurk_chips)
     queries = lair.QueryRecord(top)
-    prog_args = se.args_for_rows(n)
-    prog_args[2] = rank  # a different environment per rank: every shard is a different trace
-    top.execute(top.func_index(se.FUNC), prog_args, queries)
+    top.execute(top.func_index(entry), main_args, queries)
+    t_execute = time.perf_counter() - t0
     pv = queries.expect_public_values()
-    machine = prover.Machine(ctx, top, se.FUNC, len(pv))
+    eval_idx = top.func_index(eval_name)
+    eval_rows_total = queries.num_func_queries(eval_idx)
+    assert eval_rows_total == world * n, (eval_rows_total, world, n)
+    machine = prover.Machine(ctx, top, entry, len(pv))
     vk_root = machine.setup()
-    prepared = machine.prepare_shard(lair.Shard.new(queries))
-    t_host = time.perf_counter() - t_host
+    if world > 1 or args.workload != "eval-only":
+        all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(n))
+    else:
+        all_shards = [lair.Shard.new(queries)]
+    assert len(all_shards) == world, f"{len(all_shards)} shards for {world} ranks: the eval chip must be the tallest"
+    mine = shards.assign_shards(len(all_shards), world, rank)
+    assert mine == [rank]
+    t0 = time.perf_counter()
+    prepared = machine.prepare_shard(all_shards[rank])
+    t_flatten = time.perf_counter() - t0
     # once per machine, before the timed region: the big chips' AIR programs compiled to straight-line device code
     t_jit = time.perf_counter()
     compiled = [] if args.no_compile else machine.compile_airs(prepared)
     t_jit = time.perf_counter() - t_jit
-    eval_rows = queries.num_func_queries(top.func_index(se.FUNC))
-    assert eval_rows == n, (eval_rows, n)
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
     input_bytes = sum(p.input_bytes for *_, p in prepared if p is not None)
+    main_cols_per_eval_row = sum(air.width << lg for _, air, lg, _, _ in prepared) / n
 
-    from lurk_amd import shards
-
-    grand_sums = []
+    grand_sums, rank_sums = [], []
 
     def step():
+        # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shard
         traces = machine.run_prepared(prepared)
         handle, root = machine.commit_shard(traces)
+        # the transcript prefix: every shard's main root (RCCL all-gather of 8 lanes per rank) and the public values
         ch = prover.Challenger(ctx)
         ch.observe(vk_root)
         ch.observe([0])
-        # every shard's transcript observes every shard's main root (RCCL all-gather of 8 lanes per rank)
-        for r in shards.exchange_roots([root], device="cuda" if distributed else "cpu"):
+        for r in shards.exchange_roots([root], device=dev):
             ch.observe(r)
             ch.observe(pv)
+        # phase 2 (prove_shard)
         words = machine.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
         machine.free_shard(handle)
-        # grand-sum check data: the chips' cumulative sums, reduced over all shards (RCCL all-reduce of 4 x int64)
+        # grand-sum check: the chips' cumulative sums, reduced over all shards (RCCL all-reduce of 4 x int64)
         n_chips = int(words[1])
         cs = [words[10 + 11 * i + 7:10 + 11 * i + 11] for i in range(n_chips)]
-        grand_sums.append(shards.reduce_cumulative_sums(cs, device="cuda" if distributed else "cpu"))
+        mine_sum = np.zeros(4, dtype=np.int64)
+        for c in cs:
+            mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % 2013265921
+        rank_sums.append(tuple(int(x) for x in mine_sum))
+        grand_sums.append(shards.reduce_cumulative_sums(cs, device=dev))
         return words
 
     def fence():
@@ -177,10 +221,18 @@ def main():
     proofs_identical = all(len(w) == len(step_words[0]) and bool((w == step_words[0]).all()) for w in step_words[1:])
     del step_words
     ctx.profile_enable(False)
+    rank_ms = elapsed / args.steps * 1e3
+    per_rank_ms = [rank_ms]
+    all_rank_sums_nonzero = all(s != (0, 0, 0, 0) for s in rank_sums)
     if distributed:
         t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
+        gathered = [torch.zeros_like(t) for _ in range(world)]
+        dist.all_gather(gathered, t)
+        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
+        elapsed = max(float(g.item()) for g in gathered)
+        flag = torch.tensor([1 if all_rank_sums_nonzero else 0], dtype=torch.int64, device="cuda")
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        all_rank_sums_nonzero = bool(flag.item())
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
     ms_per_step = elapsed / args.steps * 1e3
@@ -214,24 +266,33 @@ def main():
     hash_launches_step = sum(merkle_hash_bytes(r)[1] for r in rounds)
     hash_ms_step = (spans["merkle_leaves"][0] + spans["merkle_levels"][0]) / args.steps
     achieved = hash_bytes_step / (hash_ms_step * 1e-3) / 1e9 if hash_ms_step > 0 else 0.0
-    # second-largest kernel family, the coset LDE passes (k_ntt_pass): every pass reads and writes its matrix once; a size-N
-    # transform takes ceil(log N / 7) passes, an LDE with blow-up 2 is three transforms
-    lde_bytes_step = 0
+    # second-largest kernel family, the coset LDE passes (k_ntt_pass).  SURVEY.md 8(d) prices an LDE (blow-up 2) at read 4w +
+    # write 8w bytes per trace row = 12 w B/row: that is `algorithmic`.  `pass_traffic` is what the implementation moves:
+    # every pass reads and writes its matrix once, a size-N transform takes ceil(log N / NTT_LOG_TILE) passes, an LDE is three
+    # transforms.
+    lde_alg_bytes, lde_pass_bytes = 0, 0
+    ntt_log_tile = int(os.environ.get("LURKHIP_NTT_LOG_TILE_REPORTED", "7"))
     for r in rounds[:3]:
         for lg, w in r:
             log_n = lg - LOG_BLOWUP
-            lde_bytes_step += 3 * max(1, -(-log_n // 7)) * 2 * (1 << log_n) * w * 4
+            lde_alg_bytes += 12 * w * (1 << log_n)
+            lde_pass_bytes += 3 * max(1, -(-log_n // ntt_log_tile)) * 2 * (1 << log_n) * w * 4
     lde_ms_step = spans["lde"][0] / args.steps
-    lde_achieved = lde_bytes_step / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
+    lde_alg = lde_alg_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
+    lde_pass = lde_pass_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     traffic, valu = None, None
-    try:  # HBM bytes per step of the same kernels from the rocprofv3 PMC passes (profiles/)
-        with open(os.path.join(ROOT, "profiles", "r01_pmc_traffic.json")) as f:
+    try:  # HBM bytes / instruction counts of the same kernels from committed rocprofv3 PMC passes (NOT measured in this run)
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
-        if pmc.get("log_rows") == log_rows:
-            traffic = pmc["merkle_hash_bytes_per_step"]
-            valu = {"achieved": pmc["merkle_hash_valu_tinst_s"], "peak": pmc["int32_valu_peak_tinst_s"], "unit": "Tinstr/s",
-                    "frac": pmc["merkle_hash_valu_tinst_s"] / pmc["int32_valu_peak_tinst_s"],
-                    "source": "SQ_INSTS_VALU x 64 lanes / kernel time, profiles/r01_pmc_sq_per_kernel.csv"}
+        if pmc.get("log_rows") == log_rows and pmc.get("workload") == args.workload:
+            traffic = {"bytes_per_step": pmc["merkle_hash_bytes_per_step"], "source": f"profiles (static): {pmc.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}"}
+            mul_frac = pmc.get("merkle_hash_mul_class_frac", 0.6)
+            # instruction-mix ceiling: add-class at the full rate, mul-class at half rate, no overlap between the classes
+            ceiling = 1.0 / ((1 - mul_frac) / VALU_FULL_RATE + mul_frac / VALU_HALF_RATE)
+            valu = {"achieved": pmc["merkle_hash_valu_tinst_s"], "unit": "T lane-instr/s", "peak_full_rate": VALU_FULL_RATE, "peak_half_rate": VALU_HALF_RATE,
+                    "mul_class_frac": mul_frac, "mix_ceiling": ceiling, "frac_of_mix_ceiling": pmc["merkle_hash_valu_tinst_s"] / ceiling,
+                    "frac_of_full_rate": pmc["merkle_hash_valu_tinst_s"] / VALU_FULL_RATE,
+                    "source": "profiles (static): SQ_INSTS_VALU x 64 lanes / kernel time"}
     except Exception:
         pass
 
@@ -243,41 +304,35 @@ def main():
             import threading
 
             ctx2 = lurk_amd.Context(local_rank)
-            q2 = lair.QueryRecord(top)
-            a2 = se.args_for_rows(n)
-            a2[2] = 1
-            top.execute(top.func_index(se.FUNC), a2, q2)
-            pv2 = q2.expect_public_values()
-            m2 = prover.Machine(ctx2, top, se.FUNC, len(pv2))
+            m2 = prover.Machine(ctx2, top, entry, len(pv))
             vk2 = m2.setup()
-            prep2 = m2.prepare_shard(lair.Shard.new(q2))
+            prep2 = m2.prepare_shard(all_shards[0])
             if not args.no_compile:
                 m2.compile_airs(prep2)  # same programs: served from the in-process code cache
 
-            def one(mach, cx, prep, vk, pvs):
+            def one(mach, cx, prep, vk):
                 traces = mach.run_prepared(prep)
                 handle, root = mach.commit_shard(traces)
                 ch = prover.Challenger(cx)
                 ch.observe(vk)
                 ch.observe([0])
                 ch.observe(root)
-                ch.observe(pvs)
-                w = mach.prove_shard(handle, ch, pvs, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
+                ch.observe(pv)
+                w = mach.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
                 mach.free_shard(handle)
                 return w
 
-            in_flight_ok = []  # the first lane proves the timed region's shard: its proofs must be that proof
+            in_flight_ok = []  # both lanes prove the timed region's shard: every proof must be that proof
 
-            def worker(mach, cx, prep, vk, pvs, k):
+            def worker(mach, cx, prep, vk, k):
                 for _ in range(k):
-                    w = one(mach, cx, prep, vk, pvs)
-                    if mach is machine:
-                        in_flight_ok.append(len(w) == len(words) and bool((w == words).all()))
+                    w = one(mach, cx, prep, vk)
+                    in_flight_ok.append(len(w) == len(words) and bool((w == words).all()))
                 cx.sync()
 
             for k in (1, args.steps):  # warm-up pass, then the timed one
-                ths = [threading.Thread(target=worker, args=(machine, ctx, prepared, vk_root, pv, k)),
-                       threading.Thread(target=worker, args=(m2, ctx2, prep2, vk2, pv2, k))]
+                ths = [threading.Thread(target=worker, args=(machine, ctx, prepared, vk_root, k)),
+                       threading.Thread(target=worker, args=(m2, ctx2, prep2, vk2, k))]
                 torch.cuda.synchronize()
                 t1 = time.perf_counter()
                 for th in ths:
@@ -288,7 +343,8 @@ def main():
                 dt2 = time.perf_counter() - t1
             two_in_flight = {"shards": 2 * args.steps, "ms_per_shard": dt2 / (2 * args.steps) * 1e3, "eval_steps_per_s": 2 * n * args.steps / dt2,
                              "proofs_match_sequential": bool(in_flight_ok) and all(in_flight_ok),
-                             "note": "two independent shards on two HIP streams of the same GPU; not the headline value"}
+                             "note": "the same shard proved on two HIP streams of the one GPU concurrently; not the headline value"}
+            del prep2
             m2.close()
             ctx2.close()
         except Exception as e:
@@ -309,16 +365,22 @@ def main():
             "dtype": "u32",
             "data": "synthetic",
             "config": {
-                "workload": f"fib trace 2^{log_rows} rows x {WIDTH} cols per GPU (eval chip) + the rest of its machine: lair trace-gen, main / LogUp permutation / quotient commits (coset LDE blow-up 2 + Poseidon2-16 Merkle), openings + FRI ({args.queries} queries, {args.pow_bits} PoW bits)"
-                + ("; RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
+                "workload": f"fib trace 2^{log_rows} eval rows x 78 cols per GPU ({args.workload}) + the rest of its machine: lair trace-gen, main / LogUp permutation / quotient commits (coset LDE blow-up 2 + Poseidon2-16 Merkle), openings + FRI ({args.queries} queries, {args.pow_bits} PoW bits)"
+                + (f"; one execution of {world} x 2^{log_rows} eval rows sharded over {world} ranks, RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
+                "workload_detail": workload_desc,
                 "chips": chips_desc,
+                "main_columns_per_eval_row": main_cols_per_eval_row,
                 "stages_ms": {k: v[0] / args.steps for k, v in spans.items() if v[1]},
-                "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned)",
+                "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),
+                "shards": len(all_shards),
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
+                "per_rank_sum_nonzero": all_rank_sums_nonzero if world > 1 else None,  # one shard: its own sum is the (zero) total
+                "per_rank_ms_per_step": per_rank_ms,
                 "proofs_identical_across_steps": proofs_identical,
                 "hbm_resident_input_bytes": int(input_bytes),
-                "host_execute_and_upload_s": t_host,
+                "host_execute_s": t_execute,
+                "host_flatten_upload_s": t_flatten,
                 "compiled_air_chips": compiled,
                 "air_compile_s": t_jit,
                 "two_shards_in_flight": two_in_flight,
@@ -332,9 +394,10 @@ def main():
                 "frac": achieved / HBM_PEAK_GBS,
                 "traffic": traffic,
                 "int32_valu": valu,
-                "also": {"kernel": "coset LDE passes (k_ntt_pass), all launches of a step", "bound": "hbm", "achieved": lde_achieved,
-                         "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_achieved / HBM_PEAK_GBS,
-                         "algorithmic_bytes_per_step": lde_bytes_step, "ms_per_step": lde_ms_step},
+                "also": {"kernel": "coset LDE passes (k_ntt_pass), all launches of a step", "bound": "hbm",
+                         "achieved": lde_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_alg / HBM_PEAK_GBS,
+                         "algorithmic_bytes_per_step": lde_alg_bytes, "algorithmic_bytes_rule": "SURVEY 8(d): 12 w B per trace row (read 4w, write 8w)",
+                         "pass_traffic_bytes_per_step": lde_pass_bytes, "pass_traffic_GBs": lde_pass, "ms_per_step": lde_ms_step},
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,
                 "ms_per_step": hash_ms_step,
@@ -349,6 +412,7 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
+    del prepared
     machine.close()
     ctx.close()
 

@@ -100,6 +100,7 @@ FIXED["eval_coroutine_expr"] = "fn eval_coroutine_expr(a0, a1, a2, a3): [2] {\n 
 # walker -> leaf calls made on every step, before the recursive call.  `@j` is the step counter (distinct per row), `@acc`
 # the u64 accumulator pointer threaded through the recursion (the parameter named in THREAD).
 U64_OWNER_PARAM = {"eval_binop_num": "a4", "apply": "a3"}
+U64_PHASE_PARAM = {"eval_binop_num": "a5", "apply": "a1"}
 LEAF_CALLS = {
     "hash4": ("ingress", ["let pre4: [32] = (a0, @arr, a0, @arr);", "let h4: [8] = call(hash4, pre4);"]),
     "hash3": ("ingress", ["let pre3: [24] = (a0, @arr, a0);", "let h3: [8] = call(hash3, pre3);"]),
@@ -131,7 +132,7 @@ def _sig(name):
 def _counter(name):
     """(counter variable, array parameter it is lane 0 of or None)."""
     for p, s in _sig(name):
-        if s == 1 and p != U64_OWNER_PARAM.get(name):
+        if s == 1 and p != U64_OWNER_PARAM.get(name) and p != U64_PHASE_PARAM.get(name):
             return p, None
     arr, _ = _sig(name)[-1]
     return "j", arr
@@ -191,8 +192,12 @@ def emit_walker(name, pre, base, cells, muls, start):
         elif p == arr:
             L.append(f"let nxt: [{s}] = ({', '.join(['jn'] + [f'{arr}_{k}' for k in range(1, s)])});")
             args.append("nxt")
+        elif p == acc and any("nacc" in x for x in pre):
+            args.append("nacc")
         elif p == acc and any("acc2" in x for x in pre):
             args.append("acc2")
+        elif p == U64_PHASE_PARAM.get(name) and any("nph" in x for x in pre):
+            args.append("nph")
         else:
             args.append(p)
     rets = [f"r{k}" for k in range(out)]
@@ -250,6 +255,8 @@ def _start_call(name, count, tag):
         elif p == acc:
             L += [x.replace("b1", f"b1_{tag}").replace("b2", f"b2_{tag}").replace("c8", f"c8_{tag}") for x in C8]
             args.append(f"c8_{tag}")
+        elif p == U64_PHASE_PARAM.get(name):
+            args.append("one")
         elif s == 1:
             args.append("zero")
         else:
@@ -271,7 +278,7 @@ class Mix:
     main_args: list
 
 
-def build_mix(name, funcs, counts):
+def build_mix(name, funcs, counts, u64_owner=None, u64_every_other_step=False):
     """funcs: function names in machine order (a subset of LURK_FUNC_ORDER, `lurk_main` first); counts: walker name -> rows.
     Walkers are chained: `lurk_main` starts the first one, each walker's bottom frame starts the next."""
     from .. import lair
@@ -284,7 +291,7 @@ def build_mix(name, funcs, counts):
         assert counts.get(w, 0) >= 1, f"no row count for {w}"
     pre = {w: [] for w in walkers}
     rows = {w: counts[w] for w in walkers}
-    u64_owner = next((w for w in ("eval_binop_num", "apply") if w in have), None)
+    u64_owner = u64_owner or next((w for w in ("eval_binop_num", "apply") if w in have), None)
     for leafname, (owner, lines) in LEAF_CALLS.items():
         if leafname in have:
             assert owner in have, f"{leafname} needs its caller {owner}"
@@ -294,8 +301,15 @@ def build_mix(name, funcs, counts):
     if u64_ops:
         assert u64_owner, "u64 gadgets need eval_binop_num or apply in the machine"
         pre[u64_owner] += C8 + [U64_CALLS[op] for op in u64_ops]
+        steps = counts[u64_owner] - 1
+        if u64_every_other_step:
+            # the accumulator pointer advances only when the phase parameter is 1, and the phase flips every step: on the
+            # other steps the u64 calls repeat the previous step's queries (memoised: no new rows)
+            ph = U64_PHASE_PARAM[u64_owner]
+            pre[u64_owner] += ["let dacc = sub(acc2, @acc);", f"let pd = mul({ph}, dacc);", "let nacc = add(@acc, pd);", f"let nph = sub(one, {ph});"]
+            steps = (steps + 1) // 2
         for op in u64_ops:
-            rows[op] = counts[u64_owner] - 1
+            rows[op] = steps
     # every walker: base case starts the next one
     base = {}
     for i, w in enumerate(walkers):
@@ -361,14 +375,14 @@ FIB_FUNCS = ["lurk_main", "eval", "eval_builtin_expr", "eval_binop_num", "apply"
 
 def fib_mix(eval_rows: int) -> Mix:
     """The chips of a `fib` run (SURVEY.md 8a T1 widths) at appendix C's row ratios: per 13 eval rows 5 eval_builtin_expr,
-    4 eval_binop_num (which owns the u64 add / sub / lessthan calls here: 4 of each per 13 eval rows where appendix C estimates
-    ~1; the u64 chips are 44-53 columns wide), 2 apply, 5 env_lookup (one fresh memory cell per row); ingress / egress / hash
-    chips: a few hundred rows whatever the run length."""
+    4 eval_binop_num, 2 apply, 5 env_lookup (one fresh memory cell per row), 1 each of u64_add / u64_sub / u64_lessthan (`apply`
+    owns them and advances its u64 accumulator every other step; each u64_add / u64_sub row stores one 8-lane cell); ingress /
+    egress / hash chips: a few hundred rows whatever the run length."""
     e = eval_rows
     small = max(2, min(256, e // 16))
-    counts = {"eval": e, "eval_builtin_expr": max(2, 5 * e // 13), "eval_binop_num": max(2, 4 * e // 13), "apply": max(2, 2 * e // 13),
+    counts = {"eval": e, "eval_builtin_expr": max(2, 5 * e // 13), "eval_binop_num": max(2, 4 * e // 13), "apply": max(3, 2 * e // 13),
               "env_lookup": max(2, 5 * e // 13), "ingress": small, "egress": max(2, small // 4)}
-    return build_mix("fib-mix", FIB_FUNCS, counts)
+    return build_mix("fib-mix", FIB_FUNCS, counts, u64_owner="apply", u64_every_other_step=True)
 
 
 # lurk-mix: every function of the Lurk toplevel; heights as fractions of the eval chip (hand-set: eval / apply / env_lookup /

@@ -109,7 +109,8 @@ def parse_proof(words: np.ndarray) -> ShardProof:
 
     def take(n):
         out = w[pos[0]:pos[0] + n]
-        assert len(out) == n, "truncated proof"
+        if len(out) != n:
+            raise ValueError("truncated proof")
         pos[0] += n
         return out
 
@@ -118,7 +119,8 @@ def parse_proof(words: np.ndarray) -> ShardProof:
         return [tuple(flat[4 * i:4 * i + 4]) for i in range(n)]
 
     magic, n_chips, log_blowup, nq, pow_bits, n_public, n_layers, log_max, n_prep, n_chunks = take(10)
-    assert magic == PROOF_MAGIC
+    if magic != PROOF_MAGIC:
+        raise ValueError("not a lurkhip proof (bad magic)")
     chips = []
     for _ in range(n_chips):
         mi, log_n, width, pw, permw, qd, pidx = take(7)
@@ -137,7 +139,8 @@ def parse_proof(words: np.ndarray) -> ShardProof:
         c.opened["perm"] = (take_ef(c.perm_width), take_ef(c.perm_width))
     for c in chips:
         c.opened["quotient"] = [take_ef(4) for _ in range(c.quotient_degree)]
-    assert sum(c.quotient_degree for c in chips) == n_chunks
+    if sum(c.quotient_degree for c in chips) != n_chunks:
+        raise ValueError("quotient chunk count mismatch")
     fri_roots = [take(8) for _ in range(n_layers)]
     final_poly = tuple(take(4))
     pow_witness = take(1)[0]
@@ -151,7 +154,8 @@ def parse_proof(words: np.ndarray) -> ShardProof:
     for _ in range(n_layers):
         rw = take(1)[0]
         layers.append((rw, [take(rw) for _ in range(nq)]))
-    assert pos[0] == len(w), "trailing words in proof"
+    if pos[0] != len(w):
+        raise ValueError("trailing words in proof")
     return ShardProof(log_blowup, nq, pow_bits, log_max, chips, public, main_root, perm_root, quot_root, fri_roots, final_poly,
                       pow_witness, indices, rounds, layers, n_prep, words)
 
@@ -364,10 +368,16 @@ class Machine(_ShardProver):
                 p.run(t, repr=N.REPR_MONTY)
         return [(mi, air, lg, t) for mi, air, lg, t, _ in prepared]
 
-    def prove(self, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS):
+    def prove(self, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS, resident_shards: int = 1,
+              parse=True):
         """machine.prove: commit every shard's main traces, observe (preprocessed root, pc_start = 0, then per shard
         the main root and the public values), prove every shard with a clone of that transcript
-        [UPSTREAM-RECALL: sphinx LocalProver::prove_shards]."""
+        [UPSTREAM-RECALL: sphinx LocalProver::prove_shards].
+
+        Like sphinx, phase 1 keeps only the main roots: a shard's traces and main commitment (about 15 GB for a 2^22-row
+        shard) are dropped once its root is known and regenerated in phase 2 (trace generation + main commit are under a
+        third of a shard's proving time), so HBM holds `resident_shards` shards at a time instead of all of them; the last
+        `resident_shards` shards of phase 1 stay resident.  The proofs do not depend on that schedule."""
         if self.pk is None:
             self.setup()
         full = Shard.new(queries)
@@ -376,18 +386,47 @@ class Machine(_ShardProver):
         ch = Challenger(self.ctx)
         ch.observe(self.vk_root)
         ch.observe([0])
-        committed = []
-        for sh in shards:
+        keep_from = max(0, len(shards) - max(1, resident_shards))
+        committed, roots = {}, []
+        for i, sh in enumerate(shards):
             traces = self.shard_traces(sh)
             handle, root = self.commit_shard(traces)
-            committed.append((handle, traces))
+            roots.append(root)
+            if i >= keep_from:
+                committed[i] = (handle, traces)
+            else:
+                self.free_shard(handle)
+                del traces
             ch.observe(root)
             ch.observe(pv)
         proofs = []
-        for handle, traces in committed:
-            proofs.append(self.prove_shard(handle, ch.clone(), pv, num_queries, pow_bits))
+        for i, sh in enumerate(shards):
+            if i in committed:
+                handle, traces = committed.pop(i)
+            else:
+                traces = self.shard_traces(sh)
+                handle, root = self.commit_shard(traces)
+                if root != roots[i]:
+                    raise RuntimeError(f"shard {i}: regenerated main commitment differs from phase 1")
+            proofs.append(self.prove_shard(handle, ch.clone(), pv, num_queries, pow_bits, parse=parse))
             self.free_shard(handle)
+            del traces
         return proofs
+
+
+def grand_sum(proofs):
+    """Sum of the cumulative sums of every chip of every shard proof (extension field, canonical lanes): zero for a
+    consistent machine proof (the verifier's global LogUp check)."""
+    acc = [0, 0, 0, 0]
+    for p in proofs:
+        for c in p.chips:
+            for k in range(4):
+                acc[k] = (acc[k] + int(c.cumulative_sum[k])) % field.P
+    return tuple(acc)
+
+
+def shard_sum(proof):
+    return grand_sum([proof])
 
 
 def prove_pipelined(machines, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS):
