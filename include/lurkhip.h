@@ -305,8 +305,9 @@ int32_t lurkhip_air_compile(lurkhip_ctx* ctx, lurkhip_air* air);
  * error with the compiler's message in log. */
 int32_t lurkhip_air_compile_check(const lurkhip_air* air, char* log, uint32_t log_cap);
 /* The lowered register programs (csrc/air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),
- * 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel.  Returns the word count (copies at
- * most cap words), negative for an unknown program. */
+ * 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel, 4 constraint pieces of the quotient kernel
+ * (header word 10 = index of the piece's first constraint).  Returns the word count (copies at most cap words), negative for an
+ * unknown program. */
 int32_t lurkhip_air_program(const lurkhip_air* air, int32_t which, uint32_t index, uint32_t* out, uint32_t cap);
 /* tuple length of each interaction, sends first then receives; returns their number */
 int32_t lurkhip_air_interaction_sizes(const lurkhip_air* air, uint32_t* sizes, uint32_t cap);

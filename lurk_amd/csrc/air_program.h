@@ -25,7 +25,8 @@ enum Header : uint32_t {
     H_CODE_OFF,
     H_CONST_OFF,
     H_TOTAL_WORDS,
-    H_FIRST_COLUMN,     // interaction program piece: permutation column of its first batch (0 for a whole program)
+    H_FIRST_COLUMN,     // interaction program piece: permutation column of its first batch (0 for a whole program);
+                        // constraint program piece: index of its first constraint
     H_PAD1,
     H_WORDS  // multiple of 4: the code starts 16-byte aligned
 };
@@ -56,6 +57,8 @@ enum Src : uint32_t {
     S_PUBLIC = 6,
     S_SEL = 7  // index 0: is_first_row, 1: is_last_row, 2: is_transition
 };
+
+constexpr uint32_t MAX_CONSTRAINT_PARTS = 8;  // pieces the constraint program is cut into (one wave each in the quotient kernel)
 
 constexpr uint32_t SRC_SHIFT = 13;
 constexpr uint32_t SRC_MASK = (1u << SRC_SHIFT) - 1u;

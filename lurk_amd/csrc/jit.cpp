@@ -8,8 +8,13 @@
 
 #include <hip/hiprtc.h>
 
+#include <dlfcn.h>
 #include <stdio.h>
 #include <stdlib.h>
+#include <sys/stat.h>
+#include <unistd.h>
+
+#include <string.h>
 
 #include <map>
 #include <mutex>
@@ -88,12 +93,15 @@ void emit_runner(std::ostringstream& o, const std::string& name, const std::vect
 std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     std::ostringstream o;
     o << "#define LURKHIP_COMPILED_AIR 1\n#include \"stark_kernels.h\"\nnamespace lurkhip {\n";
-    std::vector<std::string> perm, quot{"quot_cons"};
+    std::vector<std::string> perm, quot;
     for (size_t j = 0; j < prog.interaction_parts.size(); j++) {
         perm.push_back("perm_piece" + std::to_string(j));
         emit_function(o, prog.interaction_parts[j], perm.back(), batch);
     }
-    emit_function(o, prog.constraints, "quot_cons", 0);
+    for (size_t j = 0; j < prog.constraint_parts.size(); j++) {
+        quot.push_back("quot_cons" + std::to_string(j));
+        emit_function(o, prog.constraint_parts[j], quot.back(), 0);
+    }
     for (size_t j = 0; j < prog.interaction_parts_coarse.size(); j++) {
         quot.push_back("quot_piece" + std::to_string(j));
         emit_function(o, prog.interaction_parts_coarse[j], quot.back(), batch);
@@ -134,7 +142,8 @@ bool compile_source(const std::string& src, std::vector<char>* code, std::string
     // the ROCm include directory provides <hip/hip_runtime.h> for the embedded headers
     const char* rocm = getenv("ROCM_PATH");
     const std::string inc = std::string("-I") + (rocm && *rocm ? rocm : "/opt/rocm") + "/include";
-    const char* opts[] = {"--offload-arch=gfx950", "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
+    const char* olevel = getenv("LURKHIP_JIT_OPT");
+    const char* opts[] = {"--offload-arch=gfx950", olevel && *olevel ? olevel : "-O3", "-std=c++17", "-ffp-contract=off", inc.c_str()};
     const hiprtcResult r = hiprtcCompileProgram(p, 5, opts);
     if (r != HIPRTC_SUCCESS) {
         size_t n = 0;
@@ -165,24 +174,102 @@ bool compile_source(const std::string& src, std::vector<char>* code, std::string
 }
 }  // namespace
 
-size_t jit_compile_only(const lair::AirPrograms& prog, uint32_t batch, std::string* log) {
-    std::vector<char> code;
-    return compile_source(jit_source(prog, batch), &code, log) ? code.size() : 0;
+// ---- persistent code-object cache.  A machine's AIR programs are fixed by its toplevel, and compiling a Poseidon2 chip takes
+// a minute: compiled code objects are kept on disk keyed by everything that determines them (generated source, the embedded
+// headers, compiler options, hiprtc version).  Directory: $LURKHIP_JIT_CACHE (empty = no disk cache), else jit_cache/ next to
+// liblurkhip.so -- in-tree, so a cache warmed by the build travels with the library.
+namespace {
+std::string cache_dir() {
+    if (const char* e = getenv("LURKHIP_JIT_CACHE")) return e;
+    Dl_info info;
+    if (dladdr((const void*)&cache_dir, &info) && info.dli_fname) {
+        std::string path = info.dli_fname;
+        const size_t slash = path.rfind('/');
+        return (slash == std::string::npos ? std::string(".") : path.substr(0, slash)) + "/jit_cache";
+    }
+    return "";
 }
-
-bool jit_compile(const lair::AirPrograms& prog, uint32_t batch, JitKernels* out, std::string* log) {
-    const std::string src = jit_source(prog, batch);
+uint64_t fnv1a(const char* p, size_t n, uint64_t h) {
+    for (size_t i = 0; i < n; i++) h = (h ^ (unsigned char)p[i]) * 0x100000001b3ull;
+    return h;
+}
+std::string cache_key(const std::string& src) {
+    uint64_t h1 = 0xcbf29ce484222325ull, h2 = 0x84222325cbf29ce4ull;
+    auto mix = [&](const char* p, size_t n) {
+        h1 = fnv1a(p, n, h1);
+        h2 = fnv1a(p, n, h2 ^ 0x9e3779b97f4a7c15ull);
+    };
+    mix(src.data(), src.size());
+    for (int i = 0; i < kJitHeaderCount; i++) mix(kJitHeaderBodies[i], strlen(kJitHeaderBodies[i]));
+    int maj = 0, min = 0;
+    (void)hiprtcVersion(&maj, &min);
+    const char* olevel = getenv("LURKHIP_JIT_OPT");
+    const std::string tag = "gfx950|" + std::string(olevel && *olevel ? olevel : "-O3") + "|" + std::to_string(maj) + "." + std::to_string(min);
+    mix(tag.data(), tag.size());
+    char buf[40];
+    snprintf(buf, sizeof buf, "%016llx%016llx", (unsigned long long)h1, (unsigned long long)h2);
+    return buf;
+}
+bool disk_load(const std::string& key, std::vector<char>* code) {
+    const std::string dir = cache_dir();
+    if (dir.empty()) return false;
+    FILE* f = fopen((dir + "/" + key + ".hsaco").c_str(), "rb");
+    if (!f) return false;
+    fseek(f, 0, SEEK_END);
+    const long n = ftell(f);
+    fseek(f, 0, SEEK_SET);
+    bool ok = n > 0;
+    if (ok) {
+        code->resize((size_t)n);
+        ok = fread(code->data(), 1, (size_t)n, f) == (size_t)n;
+    }
+    fclose(f);
+    return ok;
+}
+void disk_store(const std::string& key, const std::vector<char>& code) {
+    const std::string dir = cache_dir();
+    if (dir.empty()) return;
+    (void)mkdir(dir.c_str(), 0755);
+    const std::string final_path = dir + "/" + key + ".hsaco", tmp = final_path + ".tmp" + std::to_string((long)getpid());
+    FILE* f = fopen(tmp.c_str(), "wb");
+    if (!f) return;  // read-only tree: the in-process cache still serves this process
+    const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();
+    fclose(f);
+    if (!ok || rename(tmp.c_str(), final_path.c_str()) != 0) (void)remove(tmp.c_str());
+}
+// code object for `src`: in-process cache, then disk, then the compiler
+bool get_code(const std::string& src, std::vector<char>* code, std::string* log, bool* from_cache) {
     {
         std::lock_guard<std::mutex> g(g_cache_mu);
         auto it = g_code_cache.find(src);
-        if (it != g_code_cache.end()) return load_module(it->second, out, log);
+        if (it != g_code_cache.end()) {
+            *code = it->second;
+            if (from_cache) *from_cache = true;
+            return true;
+        }
     }
-    std::vector<char> code;
-    if (!compile_source(src, &code, log)) return false;
-    if (!load_module(code, out, log)) return false;
+    const std::string key = cache_key(src);
+    bool cached = disk_load(key, code);
+    if (!cached) {
+        if (!compile_source(src, code, log)) return false;
+        disk_store(key, *code);
+    }
+    if (from_cache) *from_cache = cached;
     std::lock_guard<std::mutex> g(g_cache_mu);
-    g_code_cache.emplace(src, std::move(code));
+    g_code_cache.emplace(src, *code);
     return true;
+}
+}  // namespace
+
+size_t jit_compile_only(const lair::AirPrograms& prog, uint32_t batch, std::string* log) {
+    std::vector<char> code;
+    return get_code(jit_source(prog, batch), &code, log, nullptr) ? code.size() : 0;
+}
+
+bool jit_compile(const lair::AirPrograms& prog, uint32_t batch, JitKernels* out, std::string* log) {
+    std::vector<char> code;
+    if (!get_code(jit_source(prog, batch), &code, log, nullptr)) return false;
+    return load_module(code, out, log);
 }
 
 void jit_release(JitKernels* k) {

@@ -1079,6 +1079,27 @@ AirPrograms lower_air(const ChipAir& air) {
         for (E c : air.constraints) steps.push_back({airp::OP_ASSERT, c});
         p.constraints = lw.lower(steps, (uint32_t)air.constraints.size(), 0, 0);
     }
+    {
+        const size_t n_cons = air.constraints.size();
+        const size_t n_instr = p.constraints[airp::H_N_INSTR];
+        size_t n_parts = std::min<size_t>({(size_t)airp::MAX_CONSTRAINT_PARTS, std::max<size_t>(1, (n_instr + 1023) / 1024), std::max<size_t>(n_cons, 1)});
+        // every piece keeps its register file regs[n_regs][64] in LDS next to the other pieces': stay within 128 KiB of the CU's 160
+        for (;; n_parts--) {
+            p.constraint_parts.clear();
+            size_t reg_words = 0;
+            for (size_t j = 0; j < n_parts; j++) {
+                const size_t k0 = n_cons * j / n_parts, k1 = n_cons * (j + 1) / n_parts;
+                Lowerer lw(air);
+                std::vector<Lowerer::Step> steps;
+                for (size_t k = k0; k < k1; k++) steps.push_back({airp::OP_ASSERT, air.constraints[k]});
+                std::vector<uint32_t> prog = lw.lower(steps, (uint32_t)(k1 - k0), 0, 0);
+                prog[airp::H_FIRST_COLUMN] = (uint32_t)k0;
+                reg_words += (size_t)prog[airp::H_N_REGS] * 64;
+                p.constraint_parts.push_back(std::move(prog));
+            }
+            if (n_parts == 1 || reg_words * 4 <= (size_t)96 * 1024) break;
+        }
+    }
     std::vector<const Interaction*> all;
     for (const auto& it : air.sends) all.push_back(&it);
     for (const auto& it : air.receives) all.push_back(&it);

@@ -130,6 +130,11 @@ struct AirPrograms {
     // The interaction program cut into independent pieces at batch boundaries (batch = 2^log_quotient_degree interactions
     // per permutation column): piece j covers whole columns, its header's H_FIRST_COLUMN says where it starts.  The prover
     // kernels give every piece its own wave over one staged tile of rows, which multiplies the waves a CU can hold.
+    // The constraint program cut into independent pieces of consecutive constraints (each piece recomputes the shared
+    // subexpressions it needs; header word H_FIRST_COLUMN = index of its first constraint).  One piece for ordinary chips; the
+    // Poseidon2 chips' 5-10 k instructions become up to 8 pieces = 8 waves per 64 rows of the quotient kernel (a 2^8-row hash
+    // chip is 8 workgroups: with one constraint wave each the launch was a 600 us dependent chain).
+    std::vector<std::vector<uint32_t>> constraint_parts;
     std::vector<std::vector<uint32_t>> interaction_parts;
     // the same, cut coarser, for the quotient kernel (measured: it does best with two dozen interactions per wave, the
     // permutation-trace kernel with one dozen)

@@ -15,7 +15,7 @@ namespace lurkhip {
 // device copies (per HIP device) of the chip's two programs
 int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** constraints, const uint32_t** interactions,
                          const std::vector<uint32_t*>** interaction_parts = nullptr, bool coarse = false,
-                         const uint32_t** interaction_static = nullptr);
+                         const uint32_t** interaction_static = nullptr, const std::vector<uint32_t*>** constraint_parts = nullptr);
 const lair::ChipAir& air_of(const lurkhip_air* a);
 const lair::AirPrograms& programs_of(const lurkhip_air* a);
 int vm_block(uint32_t n_regs, size_t* lds_bytes);

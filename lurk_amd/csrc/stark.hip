@@ -37,6 +37,7 @@ struct lurkhip_air {
         uint32_t* cons = nullptr;
         uint32_t* inter = nullptr;
         uint32_t* inter_static = nullptr;  // k_interaction_starts: kinds, offsets, constant terms
+        std::vector<uint32_t*> cons_parts;    // constraint program pieces (AirPrograms::constraint_parts)
         std::vector<uint32_t*> parts;         // interaction program pieces (AirPrograms::interaction_parts)
         std::vector<uint32_t*> parts_coarse;  // AirPrograms::interaction_parts_coarse
         lurkhip::JitKernels jit;              // run-time compiled kernels of this chip (lurkhip_air_compile), or empty
@@ -49,7 +50,8 @@ struct lurkhip_air {
 namespace lurkhip {
 
 int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons, const uint32_t** inter,
-                         const std::vector<uint32_t*>** parts, bool coarse, const uint32_t** inter_static) {
+                         const std::vector<uint32_t*>** parts, bool coarse, const uint32_t** inter_static,
+                         const std::vector<uint32_t*>** cons_parts) {
     std::lock_guard<std::mutex> g(a->mu);
     auto it = a->dev.find(ctx->device);
     if (it == a->dev.end()) {
@@ -76,6 +78,11 @@ int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons
             }
             LH_TRY(upload(st, &d.inter_static));
         }
+        for (const auto& part : a->prog.constraint_parts) {
+            uint32_t* dp = nullptr;
+            LH_TRY(upload(part, &dp));
+            d.cons_parts.push_back(dp);
+        }
         for (const auto& part : a->prog.interaction_parts) {
             uint32_t* dp = nullptr;
             LH_TRY(upload(part, &dp));
@@ -92,6 +99,7 @@ int32_t air_programs_dev(lurkhip_ctx* ctx, lurkhip_air* a, const uint32_t** cons
     if (inter_static) *inter_static = it->second.inter_static;
     if (inter) *inter = it->second.inter;
     if (parts) *parts = coarse ? &it->second.parts_coarse : &it->second.parts;
+    if (cons_parts) *cons_parts = &it->second.cons_parts;
     return LURKHIP_OK;
 }
 
@@ -495,10 +503,10 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     const uint32_t lqd = a->air.log_quotient_degree();
     LH_ARG(ctx, lqd <= 2 && log_n + lqd <= (uint32_t)bb::TWO_ADICITY, "unsupported quotient degree / height");
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    const uint32_t* cp = nullptr;
     const std::vector<uint32_t*>* dparts = nullptr;
+    const std::vector<uint32_t*>* dcons = nullptr;
     const uint32_t* istat = nullptr;
-    LH_TRY(air_programs_dev(ctx, a, &cp, nullptr, &dparts, /*coarse=*/true, &istat));
+    LH_TRY(air_programs_dev(ctx, a, nullptr, nullptr, &dparts, /*coarse=*/true, &istat, &dcons));
     const uint32_t perm_w = a->air.permutation_width(), batch = 1u << lqd;
     const uint32_t n_batches = perm_w - 1;
     const uint32_t k_total = (uint32_t)a->air.constraints.size() + n_batches + 3;
@@ -525,14 +533,19 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     }
     if (s == LURKHIP_OK) {
         QuotientArgs q{};
-        std::vector<const std::vector<uint32_t>*> host_parts{&a->prog.constraints};
-        std::vector<uint32_t*> dev_parts{const_cast<uint32_t*>(cp)};
+        std::vector<const std::vector<uint32_t>*> host_parts;
+        std::vector<uint32_t*> dev_parts;
+        for (size_t j = 0; j < a->prog.constraint_parts.size(); j++) {
+            host_parts.push_back(&a->prog.constraint_parts[j]);
+            dev_parts.push_back((*dcons)[j]);
+        }
         for (size_t j = 0; j < a->prog.interaction_parts_coarse.size(); j++) {
             host_parts.push_back(&a->prog.interaction_parts_coarse[j]);
             dev_parts.push_back((*dparts)[j]);
         }
         const PartLayout lay = layout_parts(host_parts, dev_parts, a->air.width);
         q.parts = lay.parts;
+        q.n_cons_parts = (uint32_t)a->prog.constraint_parts.size();
         q.n_cons = (uint32_t)a->air.constraints.size();
         q.main = main_lde_dev;
         q.prep = prep_lde_dev ? prep_lde_dev : main_lde_dev;
@@ -731,7 +744,8 @@ int32_t lurkhip_air_compile_check(const lurkhip_air* a, char* log, uint32_t log_
 }
 
 // The lowered register programs (air_program.h), for inspection and tests.  which: 0 constraints, 1 interactions (whole),
-// 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel.  Returns the program's word count
+// 2 interaction pieces of the permutation-trace kernel, 3 pieces of the quotient kernel, 4 constraint pieces of the quotient
+// kernel.  Returns the program's word count
 // (copying at most `cap` words), or a negative error for an unknown program.
 int32_t lurkhip_air_program(const lurkhip_air* a, int32_t which, uint32_t index, uint32_t* out, uint32_t cap) {
     if (!a) return LURKHIP_ERR_INVALID_ARG;
@@ -740,6 +754,7 @@ int32_t lurkhip_air_program(const lurkhip_air* a, int32_t which, uint32_t index,
     else if (which == 1) p = &a->prog.interactions;
     else if (which == 2 && index < a->prog.interaction_parts.size()) p = &a->prog.interaction_parts[index];
     else if (which == 3 && index < a->prog.interaction_parts_coarse.size()) p = &a->prog.interaction_parts_coarse[index];
+    else if (which == 4 && index < a->prog.constraint_parts.size()) p = &a->prog.constraint_parts[index];
     if (!p) return LURKHIP_ERR_INVALID_ARG;
     for (size_t i = 0; i < p->size() && i < cap && out; i++) out[i] = (*p)[i];
     return (int32_t)p->size();

@@ -156,7 +156,7 @@ struct PermSink {
 };
 
 // Program pieces of a launch: one wave of every workgroup per piece, all over the same 64 staged rows.
-constexpr int MAX_VM_PARTS = 8;
+constexpr int MAX_VM_PARTS = 16;  // up to 8 constraint pieces + 6 interaction pieces: 1024-thread workgroups at most
 struct VmParts {
     const uint32_t* prog[MAX_VM_PARTS];
     uint32_t reg_off[MAX_VM_PARTS];  // word offset of the piece's register file regs[n_regs][64] in LDS
@@ -226,7 +226,8 @@ __device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
 // folded as sum_k alpha^(K-1-k) C_k(x), which is sphinx's Horner accumulation `acc = acc * alpha + C_k`
 // [UPSTREAM-RECALL: ProverConstraintFolder], and multiplied by 1 / Z_H(x).
 struct QuotientArgs {
-    VmParts parts;          // piece 0: the constraint program, pieces 1..: the interaction program pieces
+    VmParts parts;          // pieces [0, n_cons_parts): the constraint program pieces, then the interaction program pieces
+    uint32_t n_cons_parts;
     uint32_t n_cons;        // constraints of the chip (the interaction batches' constraints follow them)
     const uint32_t* main;   // LDE matrices, bit-reversed rows, Montgomery
     const uint32_t* prep;
@@ -302,9 +303,10 @@ struct QuotientSink {
     }
 };
 
-// Workgroup = 64 quotient-domain rows x n_parts waves over one staged tile: wave 0 folds the chip's constraints, wave j >= 1
-// the batch constraints of interaction piece j - 1 (weights alpha^(K-1-k) at their own k); the partial folds meet in LDS and
-// wave 0 adds the running-sum constraints and stores the quotient value.
+// Workgroup = 64 quotient-domain rows x n_parts waves over one staged tile: waves [0, n_cons_parts) fold the pieces of the chip's
+// constraints (piece j from its first constraint's index on), the waves after them the batch constraints of the interaction
+// pieces (weights alpha^(K-1-k) at their own k); the partial folds meet in LDS and wave 0 adds the running-sum constraints
+// and stores the quotient value.
 template <class Runner>
 __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     extern __shared__ uint32_t regs[];
@@ -333,7 +335,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     }
     // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset): the constraint wave needs them
     uint32_t is_first = 0, is_last = 0, is_trans = 0;
-    if (wave == 0) {
+    const bool cons_wave = wave < a.n_cons_parts;
+    if (cons_wave) {
         const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
         const uint32_t zh = a.zh[i & (qd - 1)];
         is_first = bb::mul(zh, bb::inv(bb::sub(x, bb::R1)));
@@ -346,9 +349,9 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.starts}, a.batch, perm_l};
     const uint32_t* prog = a.parts.prog[wave];
-    const uint32_t first_col = wave == 0 ? 0u : prog[airp::H_FIRST_COLUMN];
-    sink.col = first_col;
-    sink.prime(wave == 0 ? 0u : a.n_cons + first_col);
+    const uint32_t first = prog[airp::H_FIRST_COLUMN];  // constraint piece: its first constraint; interaction piece: its first column
+    sink.col = cons_wave ? 0u : first;
+    sink.prime(cons_wave ? first : a.n_cons + first);
     Runner::run(prog, wave, src, regs + a.parts.reg_off[wave] + lane, sink);
     if (sink.acc.in_batch) sink.flush();
     if (wave != 0) {

@@ -348,13 +348,19 @@ class Machine(_ShardProver):
         torch.cuda.synchronize()
         return out
 
-    def compile_airs(self, prepared, min_log_rows: int = 17):
-        """Compile (hiprtc) the AIR programs of the chips whose traces in `prepared` have at least 2^min_log_rows rows: their
-        permutation traces and quotients then run straight-line device code instead of the interpreter.  A chip that fails
-        to compile keeps the interpreter; returns the names of the compiled chips."""
+    def compile_airs(self, prepared, min_log_rows: int | None = None, min_instrs: int | None = None):
+        """Compile (hiprtc, or the on-disk code-object cache) the AIR programs of the chips whose traces in `prepared` have at
+        least 2^min_log_rows rows or whose constraint program has at least min_instrs instructions (the Poseidon2 chips: on
+        the interpreter their quotient is a millisecond-long dependent chain whatever their height): their permutation traces
+        and quotients then run straight-line device code.  A chip that fails to compile keeps the interpreter; returns the
+        names of the compiled chips."""
+        from . import jit_warm
+
+        lo = jit_warm.COMPILE_MIN_LOG_ROWS if min_log_rows is None else min_log_rows
+        ni = jit_warm.COMPILE_MIN_INSTRS if min_instrs is None else min_instrs
         done = []
         for _, chip_air, lg, _, _ in prepared:
-            if lg >= min_log_rows:
+            if lg >= lo or chip_air.constraint_instrs >= ni:
                 try:
                     chip_air.compile(self.ctx)
                     done.append(chip_air.name)
