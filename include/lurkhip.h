@@ -149,6 +149,47 @@ typedef struct lurkhip_commitment lurkhip_commitment;
 int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds_p, const uint32_t* ext_rc,
                                      const uint32_t* int_rc, const uint32_t* diag);
 
+/* ------------------------------------------------------------- protocol profile */
+/* EVERY choice of the commit / transcript / FRI layer that is restated from memory of the absent third-party sources
+ * (sphinx-core @ 8a39b951 over Plonky3 @ a0b92870, /root/reference/Cargo.lock:1626-1852,2528-2592) [UPSTREAM-RECALL] lives in
+ * this one structure, per context; the oracle mirrors it field by field (oracle/stark.py: Profile).  A maintainer with the
+ * Rust toolchain dumps vectors from sphinx ("Pinning S1"), drops them into tests/golden/upstream/ and flips
+ * fields here until the loader tests pass: nothing else in the library encodes a recalled choice.
+ * Values are canonical field elements.  struct_bytes must be sizeof(lurkhip_protocol_profile) (ABI check). */
+typedef struct lurkhip_protocol_profile {
+    uint32_t struct_bytes;
+    /* Poseidon2 width 16 (x^7, 8 external rounds) of the Merkle tree, the sponge and the transcript */
+    uint32_t p16_rounds_p;            /* internal rounds, <= 32 */
+    uint32_t p16_ext_rc[8 * 16];      /* external round constants, round-major */
+    uint32_t p16_int_rc[32];          /* internal round constants (lane 0) */
+    uint32_t p16_diag[16];            /* internal layer: y_i = scale * (sum_j x_j + diag_i * x_i) */
+    uint32_t p16_internal_scale;      /* 1 = the paper's 1 + diag; p3's Montgomery-shift diffusion layer computes 2^-32 (1 + diag) */
+    /* p3 DuplexChallenger<_, _, 16, 8>: absorbs 8 lanes by overwrite */
+    uint32_t challenger_squeeze;      /* lanes of the state offered as output after a permutation: 16 (whole state) or 8 (rate) */
+    uint32_t challenger_pop_front;    /* 0: sample() pops the END of the output buffer (p3 Vec::pop), 1: the front */
+    /* what the shard transcript observes */
+    uint32_t observe_openings;        /* 0: alpha_fri is sampled right after zeta (the pinned revision); 1: every opened value is
+                                         observed first (the later upstream soundness fix) */
+    uint32_t observe_chip_meta;       /* 1: each chip's (machine index, log height) is observed before the permutation challenges
+                                         and its cumulative sum before alpha; 0: neither (the pinned revision) */
+    /* folding orders */
+    uint32_t constraint_alpha_ascending;  /* 0: Horner, first constraint gets the highest power (sphinx folders); 1: constraint k gets alpha^k */
+    uint32_t fri_alpha_global;        /* 0: the alpha_fri power offset restarts per LDE height (p3 num_reduced[log_height]); 1: one running offset */
+    uint32_t fri_log_arity;           /* 1 (fold by 2); other arities are refused */
+    /* machine defaults (sphinx BabyBearPoseidon2: blow-up 2, 100 queries from FRI_QUERIES, 16 proof-of-work bits) */
+    uint32_t fri_log_blowup, fri_num_queries, fri_pow_bits;
+    /* wire format of field elements in serialized proofs (lurkhip_proof_serialize): 0 canonical u32, 1 Montgomery u32 */
+    uint32_t serialize_montgomery;
+} lurkhip_protocol_profile;
+
+/* Fills `out` with a named preset: "default" (this build's best recall of the pinned revision, with the reference's in-tree
+ * BabyBearConfig16 constants because sphinx's RC_16_30 are not in /root/reference), "hardened" (default + observe_openings +
+ * observe_chip_meta + squeeze 8), "p3-monty-diffusion" (default with diag = [-2, 1, 2, 4, ..., 2^13, 2^15] and scale 2^-32). */
+int32_t lurkhip_protocol_profile_preset(const char* name, lurkhip_protocol_profile* out);
+/* Installs / reads the context's profile.  Set it before anything is committed or any challenger is created on the ctx. */
+int32_t lurkhip_set_protocol_profile(lurkhip_ctx* ctx, const lurkhip_protocol_profile* profile);
+int32_t lurkhip_get_protocol_profile(lurkhip_ctx* ctx, lurkhip_protocol_profile* out);
+
 /* out = LDE of the (1 << log_n) x width matrix `in` (evaluations over the size-2^log_n subgroup, natural
  * order) onto the coset 31 * <w_{2^(log_n+log_blowup)}>, rows in bit-reversed order;
  * out is (1 << (log_n + log_blowup)) x width. */
@@ -385,7 +426,8 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
                             const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                             lurkhip_proof** out);
 int64_t lurkhip_proof_words(const lurkhip_proof* proof);
-int32_t lurkhip_proof_read(const lurkhip_proof* proof, uint32_t* out);
+/* copies the proof's words; capacity_words (the size of `out`) must be at least lurkhip_proof_words(proof) */
+int32_t lurkhip_proof_read(const lurkhip_proof* proof, uint32_t* out, uint64_t capacity_words);
 int32_t lurkhip_proof_free(lurkhip_proof* proof);
 
 #ifdef __cplusplus

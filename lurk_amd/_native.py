@@ -83,6 +83,9 @@ SIGNATURES = {
     "lurkhip_poseidon2_trace": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_trace_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_set_merkle_poseidon2": (_i32, [_p, _i32, _u32p, _u32p, _u32p]),
+    "lurkhip_protocol_profile_preset": (_i32, [C.c_char_p, _p]),
+    "lurkhip_set_protocol_profile": (_i32, [_p, _p]),
+    "lurkhip_get_protocol_profile": (_i32, [_p, _p]),
     "lurkhip_coset_lde": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
     "lurkhip_coset_lde_dev": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
     "lurkhip_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
@@ -149,7 +152,7 @@ SIGNATURES = {
     "lurkhip_shard_free": (_i32, [_p, _p]),
     "lurkhip_shard_prove": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_proof_words": (_i64, [_p]),
-    "lurkhip_proof_read": (_i32, [_p, _u32p]),
+    "lurkhip_proof_read": (_i32, [_p, _u32p, C.c_uint64]),
     "lurkhip_proof_free": (_i32, [_p]),
     "lurkhip_quotient_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
 }

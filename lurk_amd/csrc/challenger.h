@@ -9,7 +9,8 @@
 //   observe:  clears the output buffer, buffers the value, duplexes when 8 values are buffered
 //   sample:   duplexes first if inputs are pending or the output buffer is empty; pops from the END of the
 //             output buffer (state[7] first)
-//   duplexing: overwrite state[0..k) with the k buffered inputs, permute, output = state[0..8)
+//   duplexing: overwrite state[0..k) with the k buffered inputs, permute, output = state[0..squeeze), squeeze = 16 or 8
+// (lurkhip_protocol_profile::challenger_squeeze / challenger_pop_front)
 #pragma once
 #include <stdint.h>
 
@@ -49,7 +50,8 @@ inline void host_perm16(const P16Params& p, uint32_t (&s)[16]) {
         s[0] = bb::pow7_from_cube(x, bb::cube(x));
         uint32_t sum = 0;
         for (int i = 0; i < 16; i++) sum = bb::add(sum, s[i]);
-        for (int i = 0; i < 16; i++) s[i] = bb::add(bb::mul(s[i], p.diag[i]), sum);
+        const uint32_t scaled_sum = bb::mul(sum, p.sum_mult);  // diag already carries the layer's scale (commit.h: P16Params)
+        for (int i = 0; i < 16; i++) s[i] = bb::add(bb::mul(s[i], p.diag[i]), scaled_sum);
     }
     for (int r = 4; r < 8; r++) ext_round(r);
 }
@@ -59,12 +61,15 @@ struct Challenger {
     uint32_t state[16] = {};       // Montgomery
     std::vector<uint32_t> input;   // Montgomery
     std::vector<uint32_t> output;  // Montgomery
+    // lurkhip_protocol_profile: lanes offered after a permutation (8 or 16), and which end sample() pops
+    int squeeze = 16;
+    bool pop_front = false;
 
     void duplexing() {
         for (size_t i = 0; i < input.size(); i++) state[i] = input[i];
         input.clear();
         host_perm16(*params, state);
-        output.assign(state, state + 8);
+        output.assign(state, state + squeeze);
     }
     void observe_m(uint32_t v_m) {
         output.clear();
@@ -80,10 +85,18 @@ struct Challenger {
     }
     uint32_t sample_m() {
         if (!input.empty() || output.empty()) duplexing();
-        uint32_t v = output.back();
-        output.pop_back();
+        uint32_t v;
+        if (pop_front) {
+            v = output.front();
+            output.erase(output.begin());
+        } else {
+            v = output.back();
+            output.pop_back();
+        }
         return v;
     }
+    // lane of the freshly permuted state the next sample() returns when a permutation is due
+    int first_sample_lane() const { return pop_front ? 0 : squeeze - 1; }
     bb::ef sample_ef_m() {
         bb::ef e;
         for (int i = 0; i < 4; i++) e.c[i] = sample_m();

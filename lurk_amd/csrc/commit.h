@@ -58,15 +58,18 @@ constexpr int P16_MAX_RP = 32;
 struct P16Params {
     uint32_t ext_rc[8 * 16];
     uint32_t int_rc[P16_MAX_RP];
-    uint32_t diag[16];
+    uint32_t diag[16];           // Montgomery form of scale * diag_i: the internal layer is y_i = diag[i] x_i + sum_mult * sum_j x_j
     int32_t rounds_p;
     uint32_t ext_rc_mp[8 * 16];  // rc - p (mod 2^32), for the signed S-box chain
     uint32_t int_rc_mp[P16_MAX_RP];
     int32_t diag_c[16];          // diag, centred in (-p/2, p/2]: multiplier of the lazy internal rounds
+    uint32_t sum_mult;           // Montgomery form of the internal layer's scale (lurkhip_protocol_profile::p16_internal_scale): R mod p for scale 1
+    int32_t sum_mult_c;          // the same, centred: integer multiplier of the lazily reduced lane sum
     void finish() {
         for (int i = 0; i < 128; i++) ext_rc_mp[i] = ext_rc[i] - 2013265921u;
         for (int i = 0; i < P16_MAX_RP; i++) int_rc_mp[i] = int_rc[i] - 2013265921u;
         for (int i = 0; i < 16; i++) diag_c[i] = diag[i] > 2013265921u / 2 ? (int32_t)(diag[i] - 2013265921u) : (int32_t)diag[i];
+        sum_mult_c = sum_mult > 2013265921u / 2 ? (int32_t)(sum_mult - 2013265921u) : (int32_t)sum_mult;
     }
 };
 
@@ -93,6 +96,8 @@ struct TopInject {
 int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n, const TopInject& inject);
 
 int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev);
+// the context's protocol profile (created with the "default" preset on first use)
+const lurkhip_protocol_profile& profile_of(lurkhip_ctx* ctx);
 
 // ---- commit pipeline entry points shared with the prover (commit.hip)
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,

@@ -28,6 +28,7 @@ struct lurkhip_ctx {
     // lazily created per-ctx device state owned by other translation units (commit.h)
     void* merkle_params_dev = nullptr;
     void* merkle_params_host = nullptr;  // P16Params copy for the host-side challenger
+    lurkhip_protocol_profile* profile = nullptr;  // every recalled protocol choice (lurkhip.h); default preset until set
     void* ntt_plans[32] = {};
     // coset-shift power tables of the LDE, s^i / N for i < N, keyed by (log_n, s): immutable once filled, so a table is
     // computed once per context instead of once per matrix (commit.hip: extend)

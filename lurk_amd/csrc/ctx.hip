@@ -218,7 +218,7 @@ using namespace lurkhip;
 
 extern "C" {
 
-int32_t lurkhip_abi_version(void) { return 1; }
+int32_t lurkhip_abi_version(void) { return 2; }  // 2: protocol profile, lurkhip_proof_read capacity, bytecode import, lurkhip_open
 
 int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out) {
     return create_common(device_id, nullptr, false, out);

@@ -64,14 +64,17 @@ int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint3
 struct DevChallenger {
     uint32_t state[16];
     uint32_t input[8];
-    uint32_t output[8];
-    uint32_t n_in, n_out;
+    uint32_t output[16];  // the not yet sampled outputs are output[out_head .. out_head + n_out)
+    uint32_t n_in, n_out, out_head;
+    uint32_t squeeze;     // lanes offered after a permutation: 8 or 16 (lurkhip_protocol_profile::challenger_squeeze)
+    uint32_t pop_front;   // sample from the front instead of the end
 };
 // observes the 8-word digest at root_dev and samples one extension element into beta_dev, all on the context's stream
 int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* root_dev, uint32_t* beta_dev, uint32_t* root_copy_dev);
 // smallest canonical witness w such that a challenger whose permutation input is `state` (pending inputs already
-// written over lanes [0, n_pending)) samples `bits` zero bits after observing w
-int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, uint32_t* witness);
+// written over lanes [0, n_pending)) samples `bits` zero bits after observing w; sample_lane = the lane of the permuted state
+// that the first sample() returns (challenger.h: Challenger::first_sample_lane)
+int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, int sample_lane, uint32_t* witness);
 
 struct OpenMat {
     const uint32_t* base;

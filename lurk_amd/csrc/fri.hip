@@ -389,11 +389,14 @@ __global__ __launch_bounds__(64) void k_fri_challenge(const P16Params* __restric
         uint32_t x = (uint32_t)j < c.n_in ? c.input[j & 7] : c.state[j];
         x = coop_perm16(x, p, j);
         __syncthreads();
-        if (lane < 16) c.state[lane] = x;
-        if (lane < 8) c.output[lane] = x;
+        if (lane < 16) {
+            c.state[lane] = x;
+            c.output[lane] = x;
+        }
         if (lane == 0) {
             c.n_in = 0;
-            c.n_out = 8;
+            c.n_out = c.squeeze;
+            c.out_head = 0;
         }
         __syncthreads();
     };
@@ -406,11 +409,16 @@ __global__ __launch_bounds__(64) void k_fri_challenge(const P16Params* __restric
         __syncthreads();
         if (c.n_in == 8) duplex();
     }
-    for (int i = 0; i < 4; i++) {  // sample an extension element: pops from the end of the output buffer
+    for (int i = 0; i < 4; i++) {  // sample an extension element: pops from the end of the output buffer (or its front)
         if (c.n_in != 0 || c.n_out == 0) duplex();
         if (lane == 0) {
             c.n_out -= 1;
-            beta_out[i] = c.output[c.n_out];
+            if (c.pop_front) {
+                beta_out[i] = c.output[c.out_head];
+                c.out_head += 1;
+            } else {
+                beta_out[i] = c.output[c.out_head + c.n_out];
+            }
         }
         __syncthreads();
     }
@@ -419,9 +427,9 @@ __global__ __launch_bounds__(64) void k_fri_challenge(const P16Params* __restric
 
 // ---------------------------------------------------------------- proof of work (DuplexChallenger::grind)
 // witness w is accepted when, after observing it, the next sampled element has `bits` low zero bits: one
-// permutation of the state with the pending inputs and w written over its first lanes; the sample is lane 7.
+// permutation of the state with the pending inputs and w written over its first lanes; the sample is lane squeeze - 1 (7 or 15), or lane 0 when samples pop from the front.
 __global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__ p, const uint32_t* __restrict__ state_in,
-                                                    int n_pending, uint32_t base, uint32_t mask, uint32_t* __restrict__ best) {
+                                                    int n_pending, int sample_lane, uint32_t base, uint32_t mask, uint32_t* __restrict__ best) {
     const uint32_t wcan = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (wcan >= bb::P) return;
     uint32_t s[16];
@@ -433,8 +441,13 @@ __global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__
     for (int i = 0; i < 8; i++)
         if (i == n_pending) s[i] = wm;
     p2::NoRecord rec;
-    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec);
-    if ((bb::from_monty(s[7]) & mask) == 0) atomicMin(best, wcan);
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec, p->sum_mult_c);
+    // the first sample after the permutation: lane squeeze - 1 (pop from the end) or lane 0 (pop from the front)
+    uint32_t v = s[0];
+#pragma unroll
+    for (int i = 1; i < 16; i++)
+        if (i == sample_lane) v = s[i];
+    if ((bb::from_monty(v) & mask) == 0) atomicMin(best, wcan);
 }
 
 // ---------------------------------------------------------------- batched Merkle openings (MMCS open_batch)
@@ -596,7 +609,7 @@ int32_t fri_challenge(lurkhip_ctx* ctx, DevChallenger* ch_dev, const uint32_t* r
     return LURKHIP_OK;
 }
 
-int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, uint32_t* witness) {
+int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int n_pending, int bits, int sample_lane, uint32_t* witness) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
     void* scratch = nullptr;
@@ -611,7 +624,7 @@ int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int
     const uint32_t batch = 1u << 20;
     uint32_t best = 0xffffffffu;
     for (uint64_t base = 0; e == hipSuccess && base < bb::P && best == 0xffffffffu; base += batch) {
-        hipLaunchKernelGGL(k_pow_grind, dim3(batch / 256), dim3(256), 0, ctx->stream, params, (const uint32_t*)scratch, n_pending,
+        hipLaunchKernelGGL(k_pow_grind, dim3(batch / 256), dim3(256), 0, ctx->stream, params, (const uint32_t*)scratch, n_pending, sample_lane,
                            (uint32_t)base, mask, (uint32_t*)scratch + 16);
         e = hipGetLastError();
         if (e == hipSuccess) e = hipMemcpyAsync(&best, (uint32_t*)scratch + 16, 4, hipMemcpyDeviceToHost, ctx->stream);

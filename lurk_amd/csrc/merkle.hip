@@ -16,6 +16,10 @@
 // row is described by a uniform LeafCol table read through the scalar cache, so the absorb loop
 // indexes the state with compile-time lane numbers (no scratch).  VALU-bound: ceil(w/8)
 // permutations (~5.0 k int32 instructions each) per w*4 bytes read.
+#include <string.h>
+
+#include <string>
+
 #include "commit.h"
 #include "p16_coop.h"
 #include "poseidon2_dev.h"
@@ -30,7 +34,7 @@ constexpr size_t COOP_MAX_PARENTS = 16384;
 
 __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
     p2::NoRecord rec;
-    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec);
+    p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec, p->sum_mult_c);
 }
 
 // sponge over the uniform column table for row `row`; state must be zero on entry
@@ -226,14 +230,83 @@ int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* leve
     return LURKHIP_OK;
 }
 
+// ---- protocol profile (lurkhip.h): presets, the context's copy, and the width-16 permutation tables derived from it
+namespace {
+
+void preset_default(lurkhip_protocol_profile* p) {
+    memset(p, 0, sizeof *p);
+    p->struct_bytes = (uint32_t)sizeof *p;
+    p->p16_rounds_p = 13;
+    // the reference's own BabyBearConfig16 (/root/reference/src/poseidon/config.rs:190-199): sphinx's RC_16_30 are not in the tree
+    for (int i = 0; i < 128; i++) p->p16_ext_rc[i] = LURK_P2_EXT_RC_16[i];
+    for (int i = 0; i < 13; i++) p->p16_int_rc[i] = LURK_P2_INT_RC_16[i];
+    for (int i = 0; i < 16; i++) p->p16_diag[i] = LURK_P2_DIAG_16[i];
+    p->p16_internal_scale = 1;
+    p->challenger_squeeze = 16;  // p3 at the pinned revision offered the whole state after a permutation [UPSTREAM-RECALL]
+    p->challenger_pop_front = 0;
+    p->observe_openings = 0;
+    p->observe_chip_meta = 0;
+    p->constraint_alpha_ascending = 0;
+    p->fri_alpha_global = 0;
+    p->fri_log_arity = 1;
+    p->fri_log_blowup = 1;
+    p->fri_num_queries = 100;
+    p->fri_pow_bits = 16;
+    p->serialize_montgomery = 0;
+}
+
+uint32_t pow_canonical(uint32_t a, uint64_t e) {
+    uint64_t r = 1, b = a % bb::P;
+    while (e) {
+        if (e & 1) r = r * b % bb::P;
+        b = b * b % bb::P;
+        e >>= 1;
+    }
+    return (uint32_t)r;
+}
+
+int32_t validate_profile(lurkhip_ctx* ctx, const lurkhip_protocol_profile* p) {
+    LH_ARG(ctx, p != nullptr, "null profile");
+    LH_ARG(ctx, p->struct_bytes == sizeof *p, "profile struct_bytes %u, this library expects %zu", p->struct_bytes, sizeof *p);
+    LH_ARG(ctx, p->p16_rounds_p >= 1 && p->p16_rounds_p <= (uint32_t)P16_MAX_RP, "p16_rounds_p must be in 1..%d", P16_MAX_RP);
+    LH_ARG(ctx, p->p16_internal_scale % bb::P != 0, "p16_internal_scale must be non-zero");
+    LH_ARG(ctx, p->challenger_squeeze == 8 || p->challenger_squeeze == 16, "challenger_squeeze must be 8 or 16");
+    LH_ARG(ctx, p->challenger_pop_front <= 1 && p->observe_openings <= 1 && p->observe_chip_meta <= 1 && p->constraint_alpha_ascending <= 1 &&
+                    p->fri_alpha_global <= 1 && p->serialize_montgomery <= 1,
+           "profile flags must be 0 or 1");
+    if (p->fri_log_arity != 1) return set_error(ctx, LURKHIP_ERR_UNSUPPORTED, "FRI folding arity 2^%u is not implemented (only 2)", p->fri_log_arity);
+    LH_ARG(ctx, p->fri_log_blowup >= 1 && p->fri_log_blowup <= 4 && p->fri_num_queries >= 1 && p->fri_num_queries <= 1024 && p->fri_pow_bits <= 30,
+           "FRI defaults out of range");
+    return LURKHIP_OK;
+}
+
+P16Params tables_of(const lurkhip_protocol_profile& p) {
+    P16Params h{};
+    const uint32_t scale = p.p16_internal_scale % bb::P;
+    for (int i = 0; i < 128; i++) h.ext_rc[i] = bb::to_monty(p.p16_ext_rc[i] % bb::P);
+    for (uint32_t i = 0; i < p.p16_rounds_p; i++) h.int_rc[i] = bb::to_monty(p.p16_int_rc[i] % bb::P);
+    for (int i = 0; i < 16; i++) h.diag[i] = bb::to_monty((uint32_t)((uint64_t)(p.p16_diag[i] % bb::P) * scale % bb::P));
+    h.sum_mult = bb::to_monty(scale);
+    h.rounds_p = (int32_t)p.p16_rounds_p;
+    h.finish();
+    return h;
+}
+
+}  // namespace
+
+const lurkhip_protocol_profile& profile_of(lurkhip_ctx* ctx) {
+    if (!ctx->profile) {
+        auto* p = new lurkhip_protocol_profile();
+        preset_default(p);
+        ctx->profile = p;
+        ctx->cleanups.push_back([p]() { delete p; });
+    }
+    return *ctx->profile;
+}
+
 int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev) {
     if (!ctx->merkle_params_dev) {
-        P16Params h{};
-        for (int i = 0; i < 128; i++) h.ext_rc[i] = bb::c_to_monty(LURK_P2_EXT_RC_16[i]);
-        for (int i = 0; i < 13; i++) h.int_rc[i] = bb::c_to_monty(LURK_P2_INT_RC_16[i]);
-        for (int i = 0; i < 16; i++) h.diag[i] = bb::c_to_monty(LURK_P2_DIAG_16[i]);
-        h.rounds_p = 13;
-        h.finish();
+        const P16Params h = tables_of(profile_of(ctx));
         void* d = nullptr;
         LH_HIP(ctx, hipMalloc(&d, sizeof(P16Params)));
         LH_HIP(ctx, hipMemcpyAsync(d, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
@@ -252,22 +325,69 @@ int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev) {
 
 }  // namespace lurkhip
 
-extern "C" int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds_p, const uint32_t* ext_rc,
-                                                const uint32_t* int_rc, const uint32_t* diag) {
-    using namespace lurkhip;
+extern "C" {
+
+using namespace lurkhip;
+
+int32_t lurkhip_protocol_profile_preset(const char* name, lurkhip_protocol_profile* out) {
+    if (!name || !out) return LURKHIP_ERR_INVALID_ARG;
+    preset_default(out);
+    const std::string n = name;
+    if (n == "default") return LURKHIP_OK;
+    if (n == "hardened") {
+        out->observe_openings = 1;
+        out->observe_chip_meta = 1;
+        out->challenger_squeeze = 8;
+        return LURKHIP_OK;
+    }
+    if (n == "p3-monty-diffusion") {
+        // DiffusionMatrixBabyBear as recalled: monty_reduce(sum + (x_i << shift_i)) on Montgomery words, i.e. 2^-32 (1 + diag)
+        // with diag = [-2, 1, 2, 4, ..., 2^13, 2^15] [UPSTREAM-RECALL]
+        static const int shifts[15] = {0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15};
+        out->p16_diag[0] = bb::P - 2;
+        for (int i = 1; i < 16; i++) out->p16_diag[i] = 1u << shifts[i - 1];
+        out->p16_internal_scale = pow_canonical(pow_canonical(2, 32), bb::P - 2);
+        return LURKHIP_OK;
+    }
+    return LURKHIP_ERR_INVALID_ARG;
+}
+
+int32_t lurkhip_set_protocol_profile(lurkhip_ctx* ctx, const lurkhip_protocol_profile* profile) {
+    LH_CHECK_CTX(ctx);
+    LH_TRY(validate_profile(ctx, profile));
+    (void)profile_of(ctx);
+    *ctx->profile = *profile;
+    if (ctx->merkle_params_dev) {  // the tables are already on the device: refresh them
+        const P16Params h = tables_of(*profile);
+        LH_HIP(ctx, hipSetDevice(ctx->device));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        LH_HIP(ctx, hipMemcpyAsync(ctx->merkle_params_dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
+        LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+        *(P16Params*)ctx->merkle_params_host = h;
+    }
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_get_protocol_profile(lurkhip_ctx* ctx, lurkhip_protocol_profile* out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, out != nullptr, "null argument");
+    *out = profile_of(ctx);
+    return LURKHIP_OK;
+}
+
+/* older entry point: only the permutation tables (internal scale 1); kept for callers of ABI 1 */
+int32_t lurkhip_set_merkle_poseidon2(lurkhip_ctx* ctx, int32_t rounds_p, const uint32_t* ext_rc, const uint32_t* int_rc,
+                                     const uint32_t* diag) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, rounds_p > 0 && rounds_p <= P16_MAX_RP, "rounds_p must be in 1..%d", P16_MAX_RP);
     LH_ARG(ctx, ext_rc && int_rc && diag, "null parameter table");
-    const P16Params* cur = nullptr;
-    LH_TRY(get_merkle_params(ctx, &cur));
-    P16Params h{};
-    for (int i = 0; i < 128; i++) h.ext_rc[i] = bb::to_monty(ext_rc[i] % bb::P);
-    for (int i = 0; i < rounds_p; i++) h.int_rc[i] = bb::to_monty(int_rc[i] % bb::P);
-    for (int i = 0; i < 16; i++) h.diag[i] = bb::to_monty(diag[i] % bb::P);
-    h.rounds_p = rounds_p;
-    h.finish();
-    LH_HIP(ctx, hipMemcpyAsync(ctx->merkle_params_dev, &h, sizeof h, hipMemcpyHostToDevice, ctx->stream));
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
-    *(P16Params*)ctx->merkle_params_host = h;
-    return LURKHIP_OK;
+    lurkhip_protocol_profile p = profile_of(ctx);
+    p.p16_rounds_p = (uint32_t)rounds_p;
+    for (int i = 0; i < 128; i++) p.p16_ext_rc[i] = ext_rc[i] % bb::P;
+    for (int i = 0; i < 32; i++) p.p16_int_rc[i] = i < rounds_p ? int_rc[i] % bb::P : 0;
+    for (int i = 0; i < 16; i++) p.p16_diag[i] = diag[i] % bb::P;
+    p.p16_internal_scale = 1;
+    return lurkhip_set_protocol_profile(ctx, &p);
 }
+
+}  // extern "C"

@@ -44,7 +44,7 @@ __device__ __forceinline__ int32_t coop_sbox(int32_t x, uint32_t rc_mp) {
 }
 
 __device__ __forceinline__ uint32_t coop_perm16(uint32_t x_in, const P16Params* __restrict__ p, int j) {
-    constexpr int32_t R1 = (int32_t)bb::R1;
+    const int32_t sum_mult = p->sum_mult_c;  // R mod p for the plain layer (commit.h: P16Params)
     const int32_t diag = p->diag_c[j];
     int32_t x = coop_external_layer((int32_t)x_in);
 #pragma unroll 1
@@ -53,14 +53,14 @@ __device__ __forceinline__ uint32_t coop_perm16(uint32_t x_in, const P16Params* 
     for (int r = 0; r < p->rounds_p; r++) {
         const int32_t sb = coop_sbox(x, p->int_rc_mp[r]);
         x = j == 0 ? sb : x;
-        // the sum of the lanes on canonical values (four modular adds), then x <- sred(x d + R1 sum):
-        // |x d + R1 sum| < 0.94 p * p / 2 + 0.134 p^2 = 0.61 p^2, |x| < 0.79 p
+        // the sum of the lanes on canonical values (four modular adds), then x <- sred(x d + m sum), m = sum_mult (R mod p for
+        // the plain layer): |x d + m sum| < 0.94 p * p / 2 + p / 2 * p = 0.97 p^2 < 1.2 p^2 for any centred m, |x| < 0.99 p
         const uint32_t c = bb::umin((uint32_t)x, (uint32_t)x + bb::P);
         uint32_t sum = bb::add(c, dpp<DPP_ROW_ROR8>(c));
         sum = bb::add(sum, dpp<DPP_ROW_ROR4>(sum));
         sum = bb::add(sum, dpp<DPP_ROW_ROR2>(sum));
         sum = bb::add(sum, dpp<DPP_ROW_ROR1>(sum));
-        x = bb::sred(bb::mad_i64(x, diag, bb::mad_i64_u((int32_t)sum, R1, 0)));
+        x = bb::sred(bb::mad_i64(x, diag, bb::mad_i64_u((int32_t)sum, sum_mult, 0)));
     }
 #pragma unroll 1
     for (int r = 4; r < 8; r++) x = coop_external_layer(coop_sbox(x, p->ext_rc_mp[r * 16 + j]));

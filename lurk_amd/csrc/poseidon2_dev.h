@@ -129,9 +129,13 @@ __device__ __forceinline__ void internal_layer(uint32_t (&s)[W], const uint32_t*
 // V = sum_g u_g * R.  Bounds (R mod p = 0.134 p, |d_i| <= p / 2): |V| < 0.14 p^2 * ceil(W / 8), so for W <= 40
 // |x_i * d_i + V| < 1.2 p^2 and the lanes stay below 1.06 p < 2^31 round after round.  Lane 0 is brought to [0, p) before
 // its round constant is added; its x^7 stays signed.
+// `sum_mult_c`: centred integer multiplier of the lane sum, R mod p for the paper's layer (sum + d_i x_i); a scaled layer
+// s (sum + d_i x_i) -- p3's Montgomery-shift diffusion matrix, scale 2^-32 -- passes s R mod p and scaled d_i.  A multiplier
+// other than R mod p can be as large as p / 2, so the group sums are combined and reduced once more before it is applied
+// (uniform branch: the common case keeps its instruction count).
 template <int W>
 __device__ __forceinline__ void internal_rounds_lazy(uint32_t (&s)[W], int rounds_p, const uint32_t* __restrict__ int_rc_mp,
-                                                     const int32_t* __restrict__ diag_c) {
+                                                     const int32_t* __restrict__ diag_c, int32_t sum_mult_c = (int32_t)bb::R1) {
     static_assert(W <= 40, "lane bound of the lazy internal rounds");
     int32_t x[W];
 #pragma unroll
@@ -152,6 +156,7 @@ __device__ __forceinline__ void internal_rounds_lazy(uint32_t (&s)[W], int round
             for (int j = g; j < g + 8 && j < W; j++) u = bb::mad_i64(x[j], (int32_t)bb::R1, u);
             v = bb::mad_i64(bb::sred(u), (int32_t)bb::R1, v);
         }
+        if (sum_mult_c != (int32_t)bb::R1) v = bb::mad_i64(bb::sred(v), sum_mult_c, 0);  // |sred(v)| < 0.7 p, |v| < 0.35 p^2
 #pragma unroll
         for (int i = 0; i < W; i++) x[i] = bb::sred(bb::mad_i64_u(x[i], diag_c[i], v));
     }
@@ -211,7 +216,7 @@ __device__ __forceinline__ void permute_core(uint32_t (&s)[W], int rounds_p, con
                                              const uint32_t* __restrict__ int_rc,
                                              const uint32_t* __restrict__ diag, const uint32_t* __restrict__ ext_rc_mp,
                                              const uint32_t* __restrict__ int_rc_mp, const int32_t* __restrict__ diag_c,
-                                             Rec& rec) {
+                                             Rec& rec, int32_t sum_mult_c = (int32_t)bb::R1) {
     external_layer<W>(s);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) external_round<W>(s, r, ext_rc, ext_rc_mp, rec);
@@ -219,7 +224,7 @@ __device__ __forceinline__ void permute_core(uint32_t (&s)[W], int rounds_p, con
     for (int i = 0; i < W; i++) rec.int_init(i, s[i]);
     rec.end_int_init();
     if constexpr (records_nothing<Rec>::value && W <= 40) {
-        internal_rounds_lazy<W>(s, rounds_p, int_rc_mp, diag_c);
+        internal_rounds_lazy<W>(s, rounds_p, int_rc_mp, diag_c, sum_mult_c);
     } else {
 #pragma unroll 1
         for (int r = 0; r < rounds_p; r++) {

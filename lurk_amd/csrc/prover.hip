@@ -19,7 +19,9 @@
 #include <algorithm>
 #include <cstring>
 #include <map>
+#include <new>
 #include <numeric>
+#include <stdexcept>
 
 #include "babybear.h"
 #include "challenger.h"
@@ -103,6 +105,9 @@ int32_t lurkhip_challenger_new(lurkhip_ctx* ctx, lurkhip_challenger** out) {
     LH_TRY(get_merkle_params(ctx, &dev));
     auto* c = new lurkhip_challenger();
     c->ch.params = (const P16Params*)ctx->merkle_params_host;
+    const lurkhip_protocol_profile& prof = profile_of(ctx);
+    c->ch.squeeze = (int)prof.challenger_squeeze;
+    c->ch.pop_front = prof.challenger_pop_front != 0;
     *out = c;
     return LURKHIP_OK;
 }
@@ -220,13 +225,41 @@ int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* sh) {
 }
 
 // ------------------------------------------------------------------ prove_shard
+static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
+                                const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
+                                lurkhip_proof** out);
+
 int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
                             const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                             lurkhip_proof** out) {
     LH_CHECK_CTX(ctx);
+    try {  // nothing unwinds across the C boundary
+        return shard_prove_impl(ctx, pk, sh, chal, public_values, n_public, num_queries, pow_bits, out);
+    } catch (const std::bad_alloc&) {
+        return set_error(ctx, LURKHIP_ERR_OOM, "host allocation failed while proving");
+    } catch (const std::exception& e) {
+        return set_error(ctx, LURKHIP_ERR_EXEC, "internal error while proving: %s", e.what());
+    }
+}
+
+static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
+                                const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
+                                lurkhip_proof** out) {
     LH_ARG(ctx, pk && sh && chal && out && (n_public == 0 || public_values), "null argument");
     LH_ARG(ctx, num_queries >= 1 && num_queries <= 1024 && pow_bits <= 30, "bad FRI parameters");
+    LH_ARG(ctx, pk->log_blowup == sh->log_blowup, "the key was set up with blow-up 2^%d, the shard committed with 2^%d", pk->log_blowup, sh->log_blowup);
+    for (size_t i = 0; i < sh->airs.size(); i++) {
+        const lair::ChipAir& air = air_of(sh->airs[i]);
+        LH_ARG(ctx, n_public >= air.num_public, "chip %s reads %u public values, %u given", air.name.c_str(), air.num_public, n_public);
+        const int pi = sh->prep_index[i];
+        LH_ARG(ctx, pi < 0 ? air.prep_width == 0 : (pk->commit != nullptr && (size_t)pi < pk->traces.size()),
+               "chip %s: preprocessed trace index %d does not exist in the key", air.name.c_str(), pi);
+        if (pi >= 0)
+            LH_ARG(ctx, pk->log_heights[pi] == sh->log_n[i] && pk->widths[pi] == air.prep_width,
+                   "chip %s: its preprocessed trace in the key has another shape", air.name.c_str());
+    }
     LH_HIP(ctx, hipSetDevice(ctx->device));
+    const lurkhip_protocol_profile prof = profile_of(ctx);
     Challenger& ch = chal->ch;
     const int n_chips = (int)sh->airs.size();
     const int log_blowup = sh->log_blowup;
@@ -264,6 +297,12 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     } while (0)
 
     // ---- permutation traces
+    if (prof.observe_chip_meta)  // hardened transcript: bind every chip's shape before any per-shard challenge is drawn
+        for (int i = 0; i < n_chips; i++) {
+            ch.observe(sh->log_n[i]);
+            ch.observe(air_of(sh->airs[i]).width);
+            ch.observe((uint32_t)(sh->prep_index[i] + 1));
+        }
     const ef perm_alpha = ch.sample_ef_m(), perm_beta = ch.sample_ef_m();
     std::vector<uint32_t*> perm(n_chips, nullptr);
     std::vector<ef> cumsum(n_chips);
@@ -279,7 +318,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
         }
         const size_t h = (size_t)1 << sh->log_n[i];
         PTRY(palloc(h * perm_widths[i] * 4, &perm[i]));
-        const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces.at(sh->prep_index[i]) : nullptr;
+        const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
         PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr));
     }
     // cumulative sums: last element of each trace, one batched read
@@ -302,6 +341,8 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     span_end(ctx, "commit_perm");
     to_free.push_back(perm_commit);
     ch.observe_digest_m(perm_root_m);
+    if (prof.observe_chip_meta)  // ... and the cumulative sums before the constraint-folding challenge
+        for (int i = 0; i < n_chips; i++) ch.observe_ef_m(cumsum[i]);
 
     // ---- quotient
     const ef alpha = ch.sample_ef_m();
@@ -314,7 +355,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
         const uint32_t qd = 1u << lqds[i];
         uint32_t* chunks = nullptr;
         PTRY(palloc(h * qd * 16, &chunks));
-        const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde.at(sh->prep_index[i]) : nullptr;
+        const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde[sh->prep_index[i]] : nullptr;
         PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
                            cumsum[i], public_values, chunks));
         const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
@@ -381,7 +422,6 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
 
     // ---- p3 TwoAdicFriPcs::open
     span_begin(ctx, "open");
-    const ef alpha_fri = ch.sample_ef_m();
     uint32_t max_w = 1;
     int log_global_max = 0;
     for (const Round& r : rounds)
@@ -389,20 +429,6 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
             max_w = std::max(max_w, r.c->width[m]);
             log_global_max = std::max(log_global_max, r.c->log_h[m]);
         }
-    uint32_t* alpha_pows = nullptr;  // alpha_fri^c for c < max_w
-    PTRY(palloc((size_t)max_w * 16, &alpha_pows));
-    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows, max_w));
-    uint32_t* alpha_pows_c = nullptr;  // the same powers, centred, 8 words each (lazy accumulators)
-    PTRY(palloc((size_t)max_w * 32, &alpha_pows_c));
-    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows_c, max_w, true));
-    std::vector<ef> alpha_pows_host(max_w);
-    {
-        ef p = bb::ef_one();
-        for (uint32_t c = 0; c < max_w; c++) {
-            alpha_pows_host[c] = p;
-            p = bb::ef_mul(p, alpha_fri);
-        }
-    }
     // caches keyed by (log size, point index)
     std::map<std::pair<int, int>, uint32_t*> bary, denoms;
     auto get_weights = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt, uint32_t** outp) -> int32_t {
@@ -447,6 +473,9 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
                 PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
                 if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
                 PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
+                // the inverse denominators of the reduced openings do not depend on alpha_fri: queued here, ahead of the host wait
+                uint32_t* dn = nullptr;
+                for (int pt : mp) PTRY(get_weights(denoms, 1, r.c->log_h[m], pt, &dn));
                 jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
                 at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
             }
@@ -455,9 +484,57 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     std::vector<uint32_t> dot_host(dot_words);
     PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHIP(stream_wait(ctx));
-    // phase 2: opened values on the host, then the reduced openings of every matrix
-    // opened values, per round, per matrix, per point: ys[c] (Montgomery)
+    // phase 2: opened values on the host: y = (z^N - g^N) / (N g^(N-1)) * sum
+    // per round, per matrix, per point: ys[c] (Montgomery)
     std::vector<std::vector<std::vector<std::vector<ef>>>> opened(rounds.size());
+    {
+        size_t k = 0;
+        for (size_t ri = 0; ri < rounds.size(); ri++) {
+            const Round& r = rounds[ri];
+            opened[ri].resize(r.c->n_mats);
+            for (int m = 0; m < r.c->n_mats; m++, k++) {
+                const uint32_t w = r.c->width[m];
+                const size_t n = (size_t)1 << (r.c->log_h[m] - log_blowup);
+                const std::vector<int>& mp = r.points[m];
+                const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
+                const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
+                opened[ri][m].resize(mp.size());
+                for (size_t p = 0; p < mp.size(); p++) {
+                    ef zn = ef_pow_host(pts[mp[p]].z, n);
+                    zn.c[0] = bb::sub(zn.c[0], gn);
+                    const ef factor = bb::ef_scale(zn, denom_inv);
+                    std::vector<ef>& ys = opened[ri][m][p];
+                    ys.resize(w);
+                    for (uint32_t c = 0; c < w; c++) {
+                        const uint32_t* sp = &dot_host[dot_off[k] + ((size_t)p * w + c) * 4];
+                        ys[c] = bb::ef_mul(factor, ef{{sp[0], sp[1], sp[2], sp[3]}});
+                    }
+                }
+            }
+        }
+    }
+    // the batching challenge: right after zeta at the pinned revision; the later upstream fix observes every opened value first
+    if (prof.observe_openings)
+        for (size_t ri = 0; ri < rounds.size(); ri++)
+            for (auto& mat : opened[ri])
+                for (auto& ys : mat)
+                    for (const ef& y : ys) ch.observe_ef_m(y);
+    const ef alpha_fri = ch.sample_ef_m();
+    uint32_t* alpha_pows = nullptr;  // alpha_fri^c for c < max_w
+    PTRY(palloc((size_t)max_w * 16, &alpha_pows));
+    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows, max_w));
+    uint32_t* alpha_pows_c = nullptr;  // the same powers, centred, 8 words each (lazy accumulators)
+    PTRY(palloc((size_t)max_w * 32, &alpha_pows_c));
+    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows_c, max_w, true));
+    std::vector<ef> alpha_pows_host(max_w);
+    {
+        ef p = bb::ef_one();
+        for (uint32_t c = 0; c < max_w; c++) {
+            alpha_pows_host[c] = p;
+            p = bb::ef_mul(p, alpha_fri);
+        }
+    }
+    // phase 3: the reduced openings of every matrix
     // narrow matrices wait per (height, first point) and go out together (fri.hip: k_reduce_openings_narrow)
     std::map<std::pair<int, int>, NarrowArgs> narrow;
     auto flush_narrow = [&](NarrowArgs& g) -> int32_t {
@@ -468,29 +545,15 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     size_t mat_k = 0;
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const Round& r = rounds[ri];
-        opened[ri].resize(r.c->n_mats);
         for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
-            const int log_h = r.c->log_h[m], log_n = log_h - log_blowup;
+            const int log_h = r.c->log_h[m];
             const uint32_t w = r.c->width[m];
-            const size_t n = (size_t)1 << log_n;
             const std::vector<int>& mp = r.points[m];
             uint32_t *d0 = nullptr, *d1 = nullptr;
-            // y = (z^N - g^N) / (N g^(N-1)) * sum
-            const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
-            const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
             ef reduced_ys[2] = {bb::ef_zero(), bb::ef_zero()};
-            opened[ri][m].resize(mp.size());
             for (size_t p = 0; p < mp.size(); p++) {
-                ef zn = ef_pow_host(pts[mp[p]].z, n);
-                zn.c[0] = bb::sub(zn.c[0], gn);
-                const ef factor = bb::ef_scale(zn, denom_inv);
-                std::vector<ef>& ys = opened[ri][m][p];
-                ys.resize(w);
-                for (uint32_t c = 0; c < w; c++) {
-                    const uint32_t* sp = &dot_host[dot_off[mat_k] + ((size_t)p * w + c) * 4];
-                    ys[c] = bb::ef_mul(factor, ef{{sp[0], sp[1], sp[2], sp[3]}});
-                    reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
-                }
+                const std::vector<ef>& ys = opened[ri][m][p];
+                for (uint32_t c = 0; c < w; c++) reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
             }
             if (!ro[log_h]) {
                 PTRY(palloc(((size_t)16) << log_h, &ro[log_h]));
@@ -498,8 +561,10 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
             }
             PTRY(get_weights(denoms, 1, log_h, mp[0], &d0));
             if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
-            const ef apow0 = ef_pow_host(alpha_fri, num_reduced[log_h]);
-            const ef apow1 = ef_pow_host(alpha_fri, num_reduced[log_h] + w);
+            // p3 keeps one alpha-power offset per LDE height (num_reduced[log_height]); fri_alpha_global: one for all heights
+            uint64_t& offset = num_reduced[prof.fri_alpha_global ? 0 : log_h];
+            const ef apow0 = ef_pow_host(alpha_fri, offset);
+            const ef apow1 = ef_pow_host(alpha_fri, offset + w);
             if (w <= NARROW_MAX_W && alpha_pows_c) {
                 NarrowArgs& g = narrow[{log_h, mp[0]}];
                 if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
@@ -510,7 +575,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
             } else {
                 PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
             }
-            num_reduced[log_h] += (uint64_t)mp.size() * w;
+            offset += (uint64_t)mp.size() * w;
         }
     }
     for (auto& kv : narrow) PTRY(flush_narrow(kv.second));
@@ -529,6 +594,9 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     memcpy(hc.state, ch.state, sizeof hc.state);
     hc.n_in = (uint32_t)ch.input.size();
     hc.n_out = (uint32_t)ch.output.size();
+    hc.out_head = 0;
+    hc.squeeze = (uint32_t)ch.squeeze;
+    hc.pop_front = ch.pop_front ? 1u : 0u;
     for (size_t i = 0; i < ch.input.size(); i++) hc.input[i] = ch.input[i];
     for (size_t i = 0; i < ch.output.size(); i++) hc.output[i] = ch.output[i];
     DevChallenger* ch_dev = nullptr;
@@ -568,7 +636,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     }
     memcpy(ch.state, hc.state, sizeof hc.state);
     ch.input.assign(hc.input, hc.input + hc.n_in);
-    ch.output.assign(hc.output, hc.output + hc.n_out);
+    ch.output.assign(hc.output + hc.out_head, hc.output + hc.out_head + hc.n_out);
     for (size_t i = 4; i < fin.size(); i++)
         if (fin[i] != fin[i & 3]) {
             cleanup();
@@ -585,7 +653,7 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
         uint32_t st[16];
         memcpy(st, ch.state, sizeof st);
         for (size_t i = 0; i < ch.input.size(); i++) st[i] = ch.input[i];
-        PTRY(pow_grind(ctx, st, (int)ch.input.size(), (int)pow_bits, &pow_witness));
+        PTRY(pow_grind(ctx, st, (int)ch.input.size(), (int)pow_bits, ch.first_sample_lane(), &pow_witness));
     }
     if (!ch.check_witness((int)pow_bits, pow_witness)) {
         cleanup();
@@ -683,8 +751,8 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
 }
 
 int64_t lurkhip_proof_words(const lurkhip_proof* p) { return p ? (int64_t)p->words.size() : -1; }
-int32_t lurkhip_proof_read(const lurkhip_proof* p, uint32_t* out) {
-    if (!p || !out) return LURKHIP_ERR_INVALID_ARG;
+int32_t lurkhip_proof_read(const lurkhip_proof* p, uint32_t* out, uint64_t capacity_words) {
+    if (!p || !out || capacity_words < p->words.size()) return LURKHIP_ERR_INVALID_ARG;
     memcpy(out, p->words.data(), p->words.size() * 4);
     return LURKHIP_OK;
 }

@@ -20,7 +20,7 @@ const lair::ChipAir& air_of(const lurkhip_air* a);
 const lair::AirPrograms& programs_of(const lurkhip_air* a);
 int vm_block(uint32_t n_regs, size_t* lds_bytes);
 // out[i] = base^i for i < count (extension field, Montgomery words)
-int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count, bool centred = false);
+int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count, bool centred = false, bool reversed = false);
 // in-place inclusive scan of the EF elements data[r * stride_words .. +4], r < n
 int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, size_t n);
 

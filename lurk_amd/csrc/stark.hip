@@ -241,10 +241,13 @@ __global__ void k_air_check(const uint32_t* __restrict__ prog, const uint32_t* _
 // out[i] = base^i, Montgomery.  centred == 0: 4 canonical words per power.  centred == 1: 8 words per power for the lazy
 // 64-bit accumulators below: the coefficients c0..c3 and 11*c1, 11*c2, 11*c3 (the wrap-around factors of x^4 = 11) as
 // signed representatives in (-p/2, p/2], then a zero.
-__global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t* __restrict__ out, uint32_t count,
-                            int centred) {
+// reversed != 0: power i is stored at slot count - 1 - i.
+__global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, uint32_t* __restrict__ out_base, uint32_t count,
+                            int centred, int reversed) {
     const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
     if (i >= count) return;
+    uint32_t* out = out_base;
+    const uint32_t slot = reversed ? count - 1 - i : i;
     ef base{{b0, b1, b2, b3}}, r = bb::ef_one();
     uint32_t e = i;
     while (e) {
@@ -253,16 +256,16 @@ __global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
         e >>= 1;
     }
     if (!centred) {
-        out[4 * i] = r.c[0];
-        out[4 * i + 1] = r.c[1];
-        out[4 * i + 2] = r.c[2];
-        out[4 * i + 3] = r.c[3];
+        out[4 * slot] = r.c[0];
+        out[4 * slot + 1] = r.c[1];
+        out[4 * slot + 2] = r.c[2];
+        out[4 * slot + 3] = r.c[3];
         return;
     }
     auto centre = [](uint32_t x) -> uint32_t { return x > bb::P / 2 ? x - bb::P : x; };
-    for (int c = 0; c < 4; c++) out[8 * i + c] = centre(r.c[c]);
-    for (int c = 1; c < 4; c++) out[8 * i + 3 + c] = centre(bb::mul(bb::EXT_W_M, r.c[c]));
-    out[8 * i + 7] = 0;
+    for (int c = 0; c < 4; c++) out[8 * slot + c] = centre(r.c[c]);
+    for (int c = 1; c < 4; c++) out[8 * slot + 3 + c] = centre(bb::mul(bb::EXT_W_M, r.c[c]));
+    out[8 * slot + 7] = 0;
 }
 
 }  // namespace
@@ -413,9 +416,9 @@ static PartLayout layout_parts(const std::vector<const std::vector<uint32_t>*>& 
     return l;
 }
 
-int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count, bool centred) {
+int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev, uint32_t count, bool centred, bool reversed) {
     hipLaunchKernelGGL(k_ef_powers, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, base_m[0], base_m[1], base_m[2], base_m[3],
-                       out_dev, count, centred ? 1 : 0);
+                       out_dev, count, centred ? 1 : 0, reversed ? 1 : 0);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
@@ -519,7 +522,9 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
                  total = o_pub + std::max<size_t>(np, 1) * 4;
     LH_TRY(pool_alloc(ctx, total, &scratch));
     uint8_t* d = (uint8_t*)scratch;
-    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total, true);
+    // the sinks weigh constraint k with table[K - 1 - k]: powers in natural order give sphinx's Horner folding (first constraint,
+    // highest power); the table reversed gives constraint k the power alpha^k (lurkhip_protocol_profile::constraint_alpha_ascending)
+    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total, true, profile_of(ctx).constraint_alpha_ascending != 0);
     if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp, true);
     if (s == LURKHIP_OK && n_inter)
         hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, (const uint32_t*)(d + o_bp),

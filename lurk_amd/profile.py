@@ -1,0 +1,77 @@
+"""The protocol profile (include/lurkhip.h: lurkhip_protocol_profile): every choice of the commit / transcript / FRI layer
+that is restated from memory of the absent third-party sources (sphinx-core @ 8a39b951, Plonky3 @ a0b92870) in ONE
+structure per context.  `oracle/stark.py: Profile` mirrors it field by field; tests/golden/upstream/ pins it once vectors
+dumped from the real crates are available ("Pinning S1")."""
+from __future__ import annotations
+
+import ctypes as C
+
+from . import _native as N
+
+
+class ProtocolProfile(C.Structure):
+    _fields_ = [
+        ("struct_bytes", C.c_uint32),
+        ("p16_rounds_p", C.c_uint32),
+        ("p16_ext_rc", C.c_uint32 * 128),
+        ("p16_int_rc", C.c_uint32 * 32),
+        ("p16_diag", C.c_uint32 * 16),
+        ("p16_internal_scale", C.c_uint32),
+        ("challenger_squeeze", C.c_uint32),
+        ("challenger_pop_front", C.c_uint32),
+        ("observe_openings", C.c_uint32),
+        ("observe_chip_meta", C.c_uint32),
+        ("constraint_alpha_ascending", C.c_uint32),
+        ("fri_alpha_global", C.c_uint32),
+        ("fri_log_arity", C.c_uint32),
+        ("fri_log_blowup", C.c_uint32),
+        ("fri_num_queries", C.c_uint32),
+        ("fri_pow_bits", C.c_uint32),
+        ("serialize_montgomery", C.c_uint32),
+    ]
+
+    SCALARS = ("p16_rounds_p", "p16_internal_scale", "challenger_squeeze", "challenger_pop_front", "observe_openings", "observe_chip_meta",
+               "constraint_alpha_ascending", "fri_alpha_global", "fri_log_arity", "fri_log_blowup", "fri_num_queries", "fri_pow_bits",
+               "serialize_montgomery")
+
+    @classmethod
+    def preset(cls, name: str = "default") -> "ProtocolProfile":
+        p = cls()
+        N.check(N.lib.lurkhip_protocol_profile_preset(name.encode(), C.byref(p)))
+        return p
+
+    def to_dict(self) -> dict:
+        """Plain-Python form: what oracle.stark.Profile.from_dict and the upstream vector files use."""
+        d = {k: int(getattr(self, k)) for k in self.SCALARS}
+        d["p16_ext_rc"] = [int(x) for x in self.p16_ext_rc]
+        d["p16_int_rc"] = [int(x) for x in self.p16_int_rc][: d["p16_rounds_p"]]
+        d["p16_diag"] = [int(x) for x in self.p16_diag]
+        return d
+
+    @classmethod
+    def from_dict(cls, d: dict, base: str = "default") -> "ProtocolProfile":
+        p = cls.preset(base)
+        for k in cls.SCALARS:
+            if k in d:
+                setattr(p, k, int(d[k]))
+        if "p16_ext_rc" in d:
+            flat = [int(x) for row in d["p16_ext_rc"] for x in (row if isinstance(row, (list, tuple)) else [row])]
+            assert len(flat) == 128, "p16_ext_rc needs 8 x 16 values"
+            p.p16_ext_rc[:] = flat
+        if "p16_int_rc" in d:
+            rc = [int(x) for x in d["p16_int_rc"]]
+            assert len(rc) <= 32
+            p.p16_int_rc[:] = rc + [0] * (32 - len(rc))
+            p.p16_rounds_p = len(rc)
+        if "p16_diag" in d:
+            p.p16_diag[:] = [int(x) for x in d["p16_diag"]]
+        return p
+
+    def install(self, ctx) -> None:
+        ctx.check(N.lib.lurkhip_set_protocol_profile(ctx.handle, C.byref(self)))
+
+    @classmethod
+    def of(cls, ctx) -> "ProtocolProfile":
+        p = cls()
+        ctx.check(N.lib.lurkhip_get_protocol_profile(ctx.handle, C.byref(p)))
+        return p

@@ -63,6 +63,11 @@ class Challenger:
     def sample_ext(self):
         return tuple(self.sample(4))
 
+    def sample_bits(self, bits: int) -> int:
+        out = C.c_uint32()
+        N.check(N.lib.lurkhip_challenger_sample_bits(self.handle, bits, C.byref(out)))
+        return int(out.value)
+
     def __del__(self):
         if getattr(self, "handle", None) and N is not None:
             N.lib.lurkhip_challenger_free(self.handle)
@@ -199,7 +204,7 @@ class _ShardProver:
                                                  C.byref(p)))
         n = int(N.lib.lurkhip_proof_words(p))
         words = np.zeros(n, dtype=np.uint32)
-        N.check(N.lib.lurkhip_proof_read(p, _addr(words)))
+        N.check(N.lib.lurkhip_proof_read(p, _addr(words), n))
         N.lib.lurkhip_proof_free(p)
         if not parse:
             return words

@@ -161,3 +161,27 @@ def merkle_verify(log_heights, widths, index, rows, path, root) -> bool:
     path = _u32(path)
     root = _u32(root)
     return bool(L.or_merkle_verify(len(lh), lh.ctypes.data, ws.ctypes.data, index, rows.ctypes.data, path.ctypes.data, root.ctypes.data))
+
+
+def set_p16(rounds_p=None, ext_rc=None, int_rc=None, diag=None, scale=1) -> None:
+    """Installs the width-16 permutation tables of a protocol profile in the oracle (Merkle tree, sponge, transcript);
+    set_p16() with no arguments restores the default (the reference's BabyBearConfig16)."""
+    L = _setup_commit()
+    L.or_set_p16.restype = C.c_int
+    L.or_set_p16.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_uint32]
+    if ext_rc is None:
+        assert L.or_set_p16(0, None, None, None, 1) == 0
+        return
+    e, i, d = _u32(ext_rc).reshape(-1), _u32(int_rc).reshape(-1), _u32(diag).reshape(-1)
+    assert e.size == 128 and d.size == 16 and i.size >= rounds_p
+    assert L.or_set_p16(rounds_p, e.ctypes.data, i.ctypes.data, d.ctypes.data, scale) == 0
+
+
+def perm16(state):
+    """The width-16 permutation currently installed (canonical ints in, canonical ints out)."""
+    L = _setup_commit()
+    L.or_perm16.restype = None
+    L.or_perm16.argtypes = [C.c_void_p]
+    s = _u32(state).copy()
+    L.or_perm16(s.ctypes.data)
+    return [int(x) for x in s]

@@ -135,11 +135,79 @@ int or_lde_fft(int log_n, int w, int log_blowup, const uint32_t* in, uint32_t* o
 }
 
 /* ---- Merkle -------------------------------------------------------------------------------- */
+/* The width-16 permutation of the tree, the sponge and the transcript.  Default: the reference's BabyBearConfig16 tables.
+ * or_set_p16 installs the tables of a protocol profile (oracle/stark.py: Profile; include/lurkhip.h:
+ * lurkhip_protocol_profile), including the internal layer's scale: y_i = scale * (sum_j x_j + diag_i x_i).  Restated here on
+ * its own (canonical arithmetic, one statement per step of the paper's round structure) rather than through the product's
+ * tables. */
+static int g_p16_custom = 0, g_p16_rounds_p = 13;
+static uint32_t g_p16_ext[128], g_p16_int[32], g_p16_diag[16], g_p16_scale = 1;
+
+int or_set_p16(int rounds_p, const uint32_t* ext_rc, const uint32_t* int_rc, const uint32_t* diag, uint32_t scale) {
+    if (!ext_rc) {
+        g_p16_custom = 0;
+        return 0;
+    }
+    if (rounds_p < 1 || rounds_p > 32 || scale % OR_P == 0) return -1;
+    for (int i = 0; i < 128; i++) g_p16_ext[i] = ext_rc[i] % OR_P;
+    for (int i = 0; i < rounds_p; i++) g_p16_int[i] = int_rc[i] % OR_P;
+    for (int i = 0; i < 16; i++) g_p16_diag[i] = diag[i] % OR_P;
+    g_p16_rounds_p = rounds_p;
+    g_p16_scale = scale % OR_P;
+    g_p16_custom = 1;
+    return 0;
+}
+
+static uint32_t pow7(uint32_t x) {
+    uint32_t x2 = or_mul(x, x), x3 = or_mul(x2, x), x6 = or_mul(x3, x3);
+    return or_mul(x6, x);
+}
+
+static void p16_external_layer(uint32_t* s) {
+    /* M4 = circ(2, 3, 1, 1) on each block of four, then every lane gains the sum of the lanes at its position mod 4 */
+    for (int b = 0; b < 16; b += 4) {
+        uint32_t x[4] = {s[b], s[b + 1], s[b + 2], s[b + 3]};
+        for (int r = 0; r < 4; r++) {
+            uint32_t acc = or_add(or_add(x[r], x[r]), or_add(or_add(x[(r + 1) & 3], x[(r + 1) & 3]), x[(r + 1) & 3]));
+            acc = or_add(acc, or_add(x[(r + 2) & 3], x[(r + 3) & 3]));
+            s[b + r] = acc;
+        }
+    }
+    uint32_t sums[4] = {0, 0, 0, 0};
+    for (int i = 0; i < 16; i++) sums[i & 3] = or_add(sums[i & 3], s[i]);
+    for (int i = 0; i < 16; i++) s[i] = or_add(s[i], sums[i & 3]);
+}
+
+static void perm16_custom(uint32_t* s) {
+    p16_external_layer(s);
+    for (int r = 0; r < 4; r++) {
+        for (int i = 0; i < 16; i++) s[i] = pow7(or_add(s[i], g_p16_ext[r * 16 + i]));
+        p16_external_layer(s);
+    }
+    for (int r = 0; r < g_p16_rounds_p; r++) {
+        s[0] = pow7(or_add(s[0], g_p16_int[r]));
+        uint32_t sum = 0;
+        for (int i = 0; i < 16; i++) sum = or_add(sum, s[i]);
+        for (int i = 0; i < 16; i++) s[i] = or_mul(g_p16_scale, or_add(sum, or_mul(g_p16_diag[i], s[i])));
+    }
+    for (int r = 4; r < 8; r++) {
+        for (int i = 0; i < 16; i++) s[i] = pow7(or_add(s[i], g_p16_ext[r * 16 + i]));
+        p16_external_layer(s);
+    }
+}
+
 static void perm16(uint32_t* s) {
+    if (g_p16_custom) {
+        perm16_custom(s);
+        return;
+    }
     or_p2_params p;
     or_p2_lookup(16, &p);
     or_p2_permute_with(16, p.rounds_p, p.diag, p.ext_rc, p.int_rc, s);
 }
+
+/* the transcript's permutation: the same one as the tree's */
+void or_perm16(uint32_t* state) { perm16(state); }
 
 /* sponge over `count` values produced by get(i) */
 typedef struct {

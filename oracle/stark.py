@@ -24,6 +24,43 @@ GEN = 31
 ROOT27 = 0x1A427A41
 
 
+# ------------------------------------------------------------------ protocol profile
+class Profile:
+    """Mirror of include/lurkhip.h: lurkhip_protocol_profile -- every recalled choice of the commit / transcript / FRI layer,
+    field by field.  `install()` hands the permutation tables to the oracle's C side (Merkle tree, sponge, transcript)."""
+
+    FIELDS = {"p16_rounds_p": 13, "p16_ext_rc": None, "p16_int_rc": None, "p16_diag": None, "p16_internal_scale": 1,
+              "challenger_squeeze": 16, "challenger_pop_front": 0, "observe_openings": 0, "observe_chip_meta": 0,
+              "constraint_alpha_ascending": 0, "fri_alpha_global": 0, "fri_log_arity": 1, "fri_log_blowup": 1, "fri_num_queries": 100,
+              "fri_pow_bits": 16, "serialize_montgomery": 0}
+
+    def __init__(self, **kw):
+        for k, v in self.FIELDS.items():
+            setattr(self, k, v)
+        for k, v in kw.items():
+            assert k in self.FIELDS, f"unknown profile field {k}"
+            setattr(self, k, v)
+
+    @classmethod
+    def from_dict(cls, d):
+        return cls(**{k: v for k, v in d.items() if k in cls.FIELDS})
+
+    def install(self):
+        from . import binding
+
+        assert self.fri_log_arity == 1, "only FRI folding by 2 is restated"
+        if self.p16_ext_rc is None:
+            assert self.p16_internal_scale == 1
+            binding.set_p16()
+        else:
+            flat = [x for row in self.p16_ext_rc for x in (row if isinstance(row, (list, tuple)) else [row])]
+            binding.set_p16(self.p16_rounds_p, flat, list(self.p16_int_rc) + [0] * (32 - len(self.p16_int_rc)), self.p16_diag, self.p16_internal_scale)
+        return self
+
+
+DEFAULT_PROFILE = Profile()
+
+
 # ------------------------------------------------------------------ base field helpers
 def finv(a):
     a %= P
@@ -203,7 +240,7 @@ def selectors_at(x, log_n):
 
 
 # ------------------------------------------------------------------ quotient
-def fold_constraints(b: "oair.Builder", perm_local, perm_next, perm_alpha, perm_beta, batch, alpha, cumulative_sum, sels):
+def fold_constraints(b: "oair.Builder", perm_local, perm_next, perm_alpha, perm_beta, batch, alpha, cumulative_sum, sels, ascending=False):
     """sphinx Chip::eval with the folding builder: the chip's constraints, then eval_permutation_constraints;
     accumulator = accumulator * alpha + constraint.  perm rows are lists of EF tuples.  `sels` may hold base or
     extension values (the verifier evaluates at an extension point); everything is lifted to EF."""
@@ -212,9 +249,10 @@ def fold_constraints(b: "oair.Builder", perm_local, perm_next, perm_alpha, perm_
         return v if isinstance(v, tuple) else ef(v)
 
     is_first, is_last, is_trans = (lift(s) for s in sels[:3])
+    folded_terms = []  # every constraint in folding order; combined at the end (Horner, or ascending powers)
     acc = ZERO
     for c in b.constraints:
-        acc = ef_add(ef_mul(acc, alpha), lift(c))
+        folded_terms.append(lift(c))
     its = [(m, v, True) for m, v in b.sends] + [(m, v, False) for m, v in b.receives]
     n_cols = len(perm_local)
     for col, c0 in enumerate(range(0, len(its), batch)):
@@ -229,12 +267,20 @@ def fold_constraints(b: "oair.Builder", perm_local, perm_next, perm_alpha, perm_
                 if j != i:
                     others = ef_mul(others, o)
             numerator = ef_add(numerator, ef_mul(m, others))
-        acc = ef_add(ef_mul(acc, alpha), ef_sub(ef_mul(product, perm_local[col]), numerator))
+        folded_terms.append(ef_sub(ef_mul(product, perm_local[col]), numerator))
     sum_local, sum_next = ef_sum(perm_local[: n_cols - 1]), ef_sum(perm_next[: n_cols - 1])
     phi_local, phi_next = perm_local[-1], perm_next[-1]
     for c in (ef_mul(ef_sub(phi_local, sum_local), is_first), ef_mul(ef_sub(ef_sub(phi_next, phi_local), sum_next), is_trans),
               ef_mul(ef_sub(phi_local, cumulative_sum), is_last)):
-        acc = ef_add(ef_mul(acc, alpha), c)
+        folded_terms.append(c)
+    if ascending:  # constraint k weighs alpha^k
+        pw = ONE
+        for c in folded_terms:
+            acc = ef_add(acc, ef_mul(pw, c))
+            pw = ef_mul(pw, alpha)
+    else:  # sphinx's folders: accumulator = accumulator * alpha + constraint
+        for c in folded_terms:
+            acc = ef_add(ef_mul(acc, alpha), c)
     return acc
 
 
@@ -247,7 +293,7 @@ def fingerprint_ext(alpha, beta, vals, kind=oair.INTERACTION_KIND_MEMORY):
     return d
 
 
-def quotient_chunks(air, log_n, main_lde, prep_lde, perm_lde, perm_alpha, perm_beta, alpha, cumulative_sum, public=(), lqd=1):
+def quotient_chunks(air, log_n, main_lde, prep_lde, perm_lde, perm_alpha, perm_beta, alpha, cumulative_sum, public=(), lqd=1, ascending=False):
     """sphinx quotient_values + split_evals.  *_lde: NATURAL-order rows over the quotient domain 31 * <w_Q>
     (perm_lde rows are lists of EF tuples).  Returns 2^lqd chunk matrices of EF tuples (chunk c row r = value at
     31 * w_Q^(r * 2^lqd + c))."""
@@ -261,7 +307,7 @@ def quotient_chunks(air, log_n, main_lde, prep_lde, perm_lde, perm_alpha, perm_b
         b = oair.Builder(main_lde[i], main_lde[nx], prep_lde[i] if prep_lde is not None else (), prep_lde[nx] if prep_lde is not None else (),
                          public, (is_first, is_last, is_trans))
         air.eval(b)
-        folded = fold_constraints(b, perm_lde[i], perm_lde[nx], perm_alpha, perm_beta, qd, alpha, cumulative_sum, (is_first, is_last, is_trans))
+        folded = fold_constraints(b, perm_lde[i], perm_lde[nx], perm_alpha, perm_beta, qd, alpha, cumulative_sum, (is_first, is_last, is_trans), ascending)
         vals.append(ef_scale(folded, inv_zh))
     return [[vals[r * qd + c] for r in range(1 << log_n)] for c in range(qd)]
 
@@ -315,14 +361,15 @@ def _raw(x):
 
 # ------------------------------------------------------------------ transcript (p3 DuplexChallenger<_, Perm16, 16, 8>)
 class Challenger:
-    def __init__(self, permute16):
+    def __init__(self, permute16, profile=None):
         self.perm = permute16  # list of 16 canonical ints -> list of 16
+        self.profile = profile or DEFAULT_PROFILE
         self.state = [0] * 16
         self.input = []
         self.output = []
 
     def clone(self):
-        c = Challenger(self.perm)
+        c = Challenger(self.perm, self.profile)
         c.state, c.input, c.output = list(self.state), list(self.input), list(self.output)
         return c
 
@@ -331,7 +378,7 @@ class Challenger:
             self.state[i] = v
         self.input = []
         self.state = self.perm(self.state)
-        self.output = list(self.state[:8])
+        self.output = list(self.state[: self.profile.challenger_squeeze])
 
     def observe(self, v):
         if isinstance(v, (list, tuple)):
@@ -346,7 +393,7 @@ class Challenger:
     def sample(self):
         if self.input or not self.output:
             self._duplexing()
-        return self.output.pop()
+        return self.output.pop(0) if self.profile.challenger_pop_front else self.output.pop()
 
     def sample_ext(self):
         return tuple(self.sample() for _ in range(4))
@@ -360,12 +407,10 @@ class Challenger:
 
 
 def default_permute16():
+    """The width-16 permutation installed in the oracle's C side (Profile.install; default: the reference's BabyBearConfig16)."""
     from . import binding
 
-    def perm(state):
-        return [int(x) for x in binding.p2_permute(16, state)[0]]
-
-    return perm
+    return binding.perm16
 
 
 # ------------------------------------------------------------------ verifier
@@ -390,7 +435,7 @@ def _unflatten(vals):
     return out
 
 
-def eval_constraints_at(air, chip, sels, alpha, perm_alpha, perm_beta, public):
+def eval_constraints_at(air, chip, sels, alpha, perm_alpha, perm_beta, public, ascending=False):
     """sphinx Verifier::eval_constraints: the chip's AIR on the opened values with a folding builder."""
     o = chip.opened
     prep_l, prep_n = o.get("prep", ([], []))
@@ -405,7 +450,7 @@ def eval_constraints_at(air, chip, sels, alpha, perm_alpha, perm_beta, public):
     b.sends = [(_raw(m), [_raw(v) for v in vals]) for m, vals in b.sends]
     b.receives = [(_raw(m), [_raw(v) for v in vals]) for m, vals in b.receives]
     perm_local, perm_next = _unflatten(o["perm"][0]), _unflatten(o["perm"][1])
-    return fold_constraints(b, perm_local, perm_next, perm_alpha, perm_beta, chip.quotient_degree, alpha, chip.cumulative_sum, sels)
+    return fold_constraints(b, perm_local, perm_next, perm_alpha, perm_beta, chip.quotient_degree, alpha, chip.cumulative_sum, sels, ascending)
 
 
 def recompute_quotient(chip, zeta):
@@ -448,8 +493,15 @@ def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, 
     the prover's was when prove_shard started.  Returns the chips' cumulative sums."""
     chips = proof.chips
     log_blowup = proof.log_blowup
+    prof = challenger.profile
+    if prof.observe_chip_meta:
+        for c in chips:
+            challenger.observe([c.log_n, c.width, c.prep_index + 1])
     perm_alpha, perm_beta = challenger.sample_ext(), challenger.sample_ext()
     challenger.observe(proof.perm_root)
+    if prof.observe_chip_meta:
+        for c in chips:
+            challenger.observe(list(c.cumulative_sum))
     alpha = challenger.sample_ext()
     challenger.observe(proof.quot_root)
     zeta = challenger.sample_ext()
@@ -472,6 +524,12 @@ def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, 
     rounds.append((proof.quot_root, [(c.log_n, 4, [(zeta, chunk)]) for c in chips for chunk in c.opened["quotient"]]))
 
     # ---- pcs.verify
+    if prof.observe_openings:
+        for _, mats in rounds:
+            for _, _, pts in mats:
+                for _, values in pts:
+                    for v in values:
+                        challenger.observe(list(v))
     alpha_fri = challenger.sample_ext()
     betas = []
     for root in proof.fri_roots:
@@ -507,9 +565,10 @@ def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, 
                     inv_d = ef_inv(ef_sub(ef(x), z))
                     for p_at_x, p_at_z in zip(row, ps_at_z):
                         quotient = ef_mul(ef_sub(ef(p_at_x), p_at_z), inv_d)
-                        ap = alpha_pow.get(log_h, ONE)
+                        key = 0 if prof.fri_alpha_global else log_h  # p3: one power offset per LDE height
+                        ap = alpha_pow.get(key, ONE)
                         ro[log_h] = ef_add(ro.get(log_h, ZERO), ef_mul(ap, quotient))
-                        alpha_pow[log_h] = ef_mul(ap, alpha_fri)
+                        alpha_pow[key] = ef_mul(ap, alpha_fri)
         # ---- fri verify_query
         folded = ZERO
         idx = index
@@ -538,16 +597,17 @@ def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, 
         air = airs_by_machine_index[c.machine_index]
         _need(air.width == c.width, "chip width")
         sels = selectors_at_point(zeta, c.log_n)
-        folded = eval_constraints_at(air, c, sels, alpha, perm_alpha, perm_beta, proof.public_values)
+        folded = eval_constraints_at(air, c, sels, alpha, perm_alpha, perm_beta, proof.public_values, bool(prof.constraint_alpha_ascending))
         quotient = recompute_quotient(c, zeta)
         _need(ef_mul(folded, sels[3]) == quotient, f"constraints of chip {c.machine_index} do not match the quotient at zeta")
     return [c.cumulative_sum for c in chips]
 
 
-def verify_machine(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, proofs, merkle_verify, permute16=None):
+def verify_machine(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, proofs, merkle_verify, permute16=None, profile=None):
     """sphinx StarkMachine::verify: rebuild the transcript, verify every shard, and check that the cumulative
-    sums of all chips of all shards cancel."""
-    ch = Challenger(permute16 or default_permute16())
+    sums of all chips of all shards cancel.  `profile` (default DEFAULT_PROFILE) must have been install()ed when it carries
+    its own permutation tables."""
+    ch = Challenger(permute16 or default_permute16(), profile)
     ch.observe(vk_root)
     ch.observe(0)
     for pr in proofs:

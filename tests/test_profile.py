@@ -1,0 +1,111 @@
+"""The protocol profile on the CPU: the C structure and its ctypes / oracle mirrors agree, presets are what they say, the
+oracle's restated width-16 permutation matches the table-driven one, and the transcript reacts to every challenger field."""
+import ctypes as C
+
+import pytest
+
+from lurk_amd import _native as N
+from lurk_amd.profile import ProtocolProfile
+from oracle import binding as ob
+from oracle import stark as os_
+
+P = 2013265921
+
+
+def test_struct_layout_and_presets():
+    p = ProtocolProfile.preset("default")
+    assert p.struct_bytes == C.sizeof(ProtocolProfile)  # the C side wrote its own sizeof
+    d = p.to_dict()
+    # the oracle mirrors every scalar field with the same default
+    for k, v in os_.Profile.FIELDS.items():
+        if v is not None:
+            assert d[k] == v, k
+    assert set(d) == set(os_.Profile.FIELDS)
+    assert d["challenger_squeeze"] == 16 and d["p16_internal_scale"] == 1 and d["fri_log_arity"] == 1
+    h = ProtocolProfile.preset("hardened").to_dict()
+    assert (h["observe_openings"], h["observe_chip_meta"], h["challenger_squeeze"]) == (1, 1, 8)
+    m = ProtocolProfile.preset("p3-monty-diffusion").to_dict()
+    assert m["p16_diag"] == [P - 2] + [1 << s for s in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15)]
+    assert m["p16_internal_scale"] * pow(2, 32, P) % P == 1
+    bad = ProtocolProfile()
+    assert N.lib.lurkhip_protocol_profile_preset(b"no-such-preset", C.byref(bad)) == N.ERR_INVALID_ARG
+    # round trip through the dict form
+    assert ProtocolProfile.from_dict(m).to_dict() == m
+
+
+def test_oracle_custom_perm16_equals_table_driven_one(oracle):
+    """oracle/commit.c restates the width-16 permutation on its own for profile tables: with the default tables and scale 1 it
+    must be the permutation pinned (through widths 24/32/40 of the same code) by the reference's KATs."""
+    d = ProtocolProfile.preset("default").to_dict()
+    states = [[(7 * i + 3 * k * k + 1) % P for i in range(16)] for k in range(5)]
+    want = [[int(x) for x in ob.p2_permute(16, s)[0]] for s in states]
+    try:
+        ob.set_p16(d["p16_rounds_p"], d["p16_ext_rc"], d["p16_int_rc"] + [0] * (32 - len(d["p16_int_rc"])), d["p16_diag"], 1)
+        assert [ob.perm16(s) for s in states] == want
+        # a scale s multiplies every internal layer: different permutation
+        ob.set_p16(d["p16_rounds_p"], d["p16_ext_rc"], d["p16_int_rc"] + [0] * 19, d["p16_diag"], 5)
+        assert ob.perm16(states[0]) != want[0]
+    finally:
+        ob.set_p16()
+    assert ob.perm16(states[1]) == want[1]
+
+
+@pytest.mark.parametrize("field,value", [("challenger_squeeze", 8), ("challenger_pop_front", 1)])
+def test_oracle_transcript_reacts_to_challenger_fields(oracle, field, value):
+    def run(profile):
+        ch = os_.Challenger(os_.default_permute16(), profile)
+        ch.observe(list(range(1, 12)))
+        out = [ch.sample() for _ in range(20)]
+        ch.observe(5)
+        return out + [ch.sample_bits(10)]
+
+    base, other = run(os_.Profile()), run(os_.Profile(**{field: value}))
+    assert base != other
+    if field == "challenger_squeeze":
+        # 16 outputs per permutation instead of 8: the first 8 samples of the rate-8 transcript are lanes 7..0, of the whole-
+        # state one lanes 15..8
+        assert base[:8] != other[:8]
+
+
+def test_upstream_loader_mechanics(oracle, tmp_path, monkeypatch):
+    """The vector loader itself (not parity): a file written from the ORACLE's own outputs under a non-default profile must
+    pass every check, and fail once a value in it is altered.  Real pins come from files dumped from sphinx (README.md in
+    tests/golden/upstream/)."""
+    import json
+
+    import numpy as np
+
+    import test_upstream_vectors as tv
+    import upstream_helpers as uh
+
+    doc = {"source": "oracle self-check", "profile": {"preset": "p3-monty-diffusion", "challenger_squeeze": 8}}
+    prof = tv.oracle_profile_of(doc).install()
+    try:
+        st = [(i * i + 5) % P for i in range(16)]
+        doc["poseidon2_16"] = [{"input": st, "output": ob.perm16(st)}]
+        ch = os_.Challenger(os_.default_permute16(), prof)
+        ch.observe([1, 2, 3])
+        outs = [ch.sample() for _ in range(9)] + [ch.sample_bits(7)]
+        doc["challenger"] = [{"ops": [["observe", [1, 2, 3]], ["sample", 9], ["sample_bits", 7]], "outputs": outs}]
+        m = (np.arange(8 * 3, dtype=np.uint32).reshape(8, 3) * 77 + 1) % P
+        lde = ob.lde(m, 1)
+        root, _ = ob.merkle_commit([lde])
+        doc["coset_lde"] = [{"log_n": 3, "width": 3, "values": m.reshape(-1).tolist(), "log_blowup": 1, "lde_bit_reversed": lde.reshape(-1).tolist()}]
+        doc["pcs_commit"] = [{"matrices": [{"log_height": 3, "width": 3, "values": m.reshape(-1).tolist()}], "log_blowup": 1, "root": root.tolist()}]
+        doc["mmcs_commit"] = [{"matrices": [{"log_height": 4, "width": 3, "values": lde.reshape(-1).tolist()}], "root": root.tolist()}]
+    finally:
+        os_.Profile().install()
+    (tmp_path / "selfcheck.json").write_text(json.dumps(doc))
+    monkeypatch.setattr(uh, "DIR", str(tmp_path))
+    docs = uh.load_all()
+    assert [n for n, _ in docs] == ["selfcheck.json"]
+    for _, d in docs:
+        pr = tv.oracle_profile_of(d).install()
+        try:
+            for chk in tv.CHECKS:
+                chk((d, pr))
+            d["mmcs_commit"][0]["root"][0] ^= 1
+            with pytest.raises(AssertionError):
+                tv.test_mmcs_commit((d, pr))
+        finally:
+            os_.Profile().install()
