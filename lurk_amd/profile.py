@@ -1,6 +1,6 @@
 """The protocol profile (include/lurkhip.h: lurkhip_protocol_profile): every choice of the commit / transcript / FRI layer
 that is restated from memory of the absent third-party sources (sphinx-core @ 8a39b951, Plonky3 @ a0b92870) in ONE
-structure per context.  `oracle/stark.py: Profile` mirrors it field by field; tests/golden/upstream/ pins it once vectors
+structure per context.  The test oracle keeps a field-by-field mirror (class Profile of its stark module); tests/golden/upstream/ pins it once vectors
 dumped from the real crates are available ("Pinning S1")."""
 from __future__ import annotations
 
@@ -41,7 +41,7 @@ class ProtocolProfile(C.Structure):
         return p
 
     def to_dict(self) -> dict:
-        """Plain-Python form: what oracle.stark.Profile.from_dict and the upstream vector files use."""
+        """Plain-Python form: what the checker's mirror class and the upstream vector files use."""
         d = {k: int(getattr(self, k)) for k in self.SCALARS}
         d["p16_ext_rc"] = [int(x) for x in self.p16_ext_rc]
         d["p16_int_rc"] = [int(x) for x in self.p16_int_rc][: d["p16_rounds_p"]]
