@@ -175,14 +175,18 @@ __device__ __forceinline__ uint2 scale_elem(uint2 v, uint32_t s) { return make_u
 // BIG: matrices of 4 GiB and more take 64-bit byte offsets; the others address rows as base (SGPR pair) + 32-bit offset.
 // SCALE: a per-row multiplier (the coset shift powers) is applied on load.
 template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
-__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_WAVES, 8))) void k_ntt_pass(PassArgs a) {
+__device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     using boff_t = typename std::conditional<BIG, size_t, uint32_t>::type;
     constexpr int R = 1 << LOG_R;
     constexpr int RP = R + 1;
     constexpr int EW = (int)(sizeof(T) / 4);  // matrix columns per element
-    constexpr int U = R < 8 ? R : 8;          // rows a thread stages per tile
+    // rows a thread stages per tile: 8, and 16 for the 1024-row tiles so that the row slots of a column stay the 64 lanes of
+    // one wave (the stage groups rely on it: wave-local ordering instead of workgroup barriers)
+    constexpr int U = R < 8 ? R : (LOG_R > 9 ? R / 64 : 8);
     constexpr int SLOTS = R / U;              // row slots per workgroup: thread = (slot, column item), slot < SLOTS
-    constexpr int LOG_SLOTS = LOG_R < 3 ? 0 : LOG_R - 3;
+    constexpr int LOG_U = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - 6 : 3);
+    constexpr int LOG_SLOTS = LOG_R - LOG_U;
+    static_assert(SLOTS <= 64, "a column's row slots are lanes of one wave");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     T* tile = reinterpret_cast<T*>(smem);
     const int Cv = a.col_chunk / EW;
@@ -307,12 +311,37 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_W
     }
 }
 
+// tiles of up to 128 rows: two or three workgroups per CU, registers capped for five waves per SIMD
+template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
+__global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_WAVES, 8))) void k_ntt_pass(PassArgs a) {
+    ntt_pass_body<LOG_R, T, BIG, SCALE, TWN>(a);
+}
+// tiles of 256 .. 1024 rows: one workgroup of up to 16 waves per CU (its LDS tile is most of the CU's 160 KiB), so each wave may
+// use the 128 VGPRs of a 4-waves-per-SIMD kernel -- the 1024-row tiles stage sixteen rows per thread
+template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
+__global__ __launch_bounds__(1024) void k_ntt_pass_tall(PassArgs a) {
+    ntt_pass_body<LOG_R, T, BIG, SCALE, TWN>(a);
+}
+
 template <class T, bool BIG, bool SCALE, int TWN>
 void launch_pass2(int log_r, dim3 blocks, int threads, size_t lds, hipStream_t stream, const PassArgs& a) {
     switch (log_r) {
-#define LH_NTT_CASE(LR) \
-    case LR: hipLaunchKernelGGL((k_ntt_pass<LR, T, BIG, SCALE, TWN>), blocks, dim3(threads), lds, stream, a); break;
-        LH_NTT_CASE(0) LH_NTT_CASE(1) LH_NTT_CASE(2) LH_NTT_CASE(3) LH_NTT_CASE(4) LH_NTT_CASE(5) LH_NTT_CASE(6) LH_NTT_CASE(7)
+#define LH_NTT_CASE(LR, KERNEL)                                                                                              \
+    case LR: {                                                                                                               \
+        auto kern = KERNEL<LR, T, BIG, SCALE, TWN>;                                                                          \
+        if (lds > 64 * 1024) {                                                                                               \
+            static bool big_lds_ok = false; /* per instantiation: tiles above 64 KiB need the opt-in once */               \
+            if (!big_lds_ok) {                                                                                               \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+                big_lds_ok = true;                                                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, blocks, dim3(threads), lds, stream, a);                                                     \
+        break;                                                                                                               \
+    }
+        LH_NTT_CASE(0, k_ntt_pass) LH_NTT_CASE(1, k_ntt_pass) LH_NTT_CASE(2, k_ntt_pass) LH_NTT_CASE(3, k_ntt_pass)
+        LH_NTT_CASE(4, k_ntt_pass) LH_NTT_CASE(5, k_ntt_pass) LH_NTT_CASE(6, k_ntt_pass) LH_NTT_CASE(7, k_ntt_pass)
+        LH_NTT_CASE(8, k_ntt_pass_tall) LH_NTT_CASE(9, k_ntt_pass_tall) LH_NTT_CASE(10, k_ntt_pass_tall)
 #undef LH_NTT_CASE
     }
 }
@@ -414,21 +443,6 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
                       bool out_canonical, bool bitrev_store) {
     LH_ARG(ctx, b.n >= 1 && b.n <= NTT_MAX_BATCH, "NTT batch size");
     const int log_n = plan.log_n;
-    // Prefer a chunk width that divides w (no ragged chunk) and is even (two-column butterflies): the largest such
-    // divisor in [32, 112], else 64.
-    int col_chunk = w;
-    if (w > 112) {
-        col_chunk = 64;
-        for (int c = 112; c >= 32; c--)
-            if (w % c == 0 && c % 2 == 0) {
-                col_chunk = c;
-                break;
-            }
-    }
-    // tile budget: (rows + 1) * cols * 4 B + twiddles <= 64 KiB so two or three workgroups fit a CU
-    auto lds_bytes = [](int log_r, int cols, int log_l) {
-        return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
-    };
     // two adjacent columns per lane (8-byte accesses) when rows and chunks start on 8-byte boundaries
     uintptr_t all_ptrs = 0;
     for (int m = 0; m < b.n; m++) {
@@ -437,10 +451,45 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     }
     const bool aligned8 = (all_ptrs & 7u) == 0 && w % 2 == 0;
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
-    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / 8) * items_of(cols); };
-    int max_log_r = 7;
-    while ((lds_bytes(max_log_r, col_chunk, 0) > 64 * 1024 || threads_of(max_log_r, col_chunk) > 1024) && max_log_r > 1)
+    auto rows_per_thread = [](int log_r) { return log_r > 9 ? (1 << log_r) / 64 : 8; };  // the kernel's U
+    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r)) * items_of(cols); };
+    auto lds_bytes = [](int log_r, int cols, int log_l) {
+        return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
+    };
+    // Every pass reads and writes the whole matrix, so the number of passes is what the LDE costs in HBM traffic: tiles of up to
+    // 2^10 rows (132 KiB of the CU's 160 KiB of LDS at 32 columns) take a 2^20-row transform in two passes instead of three.
+    // LURKHIP_NTT_MAX_LOG_R caps the tile height (7 = the 64 KiB tiles of round 1; for A/B measurements).
+    int cap_log_r = 10;
+    if (const char* e = getenv("LURKHIP_NTT_MAX_LOG_R")) cap_log_r = std::max(1, std::min(10, atoi(e)));
+    const int n_pass = std::max(1, (log_n + cap_log_r - 1) / cap_log_r);
+    int max_log_r = std::max(1, (log_n + n_pass - 1) / n_pass);  // tallest tile of the schedule
+    const size_t lds_cap = max_log_r > 7 ? (size_t)140 * 1024 : (size_t)64 * 1024;
+    // column chunk: the widest even divisor of w that fits (no ragged chunk), else the widest even width that fits (the ragged
+    // remainder gets its own launch); narrow matrices are one chunk
+    auto fits = [&](int cols) { return lds_bytes(max_log_r, cols, 0) <= lds_cap && threads_of(max_log_r, cols) <= 1024; };
+    int col_chunk = w;
+    if (!fits(w)) {
+        int widest = 2;
+        for (int c = std::min(w, 112); c >= 2; c--)
+            if (c % 2 == 0 && fits(c)) {
+                widest = c;
+                break;
+            }
+        col_chunk = widest;
+        for (int c = widest; c >= std::max(2, widest * 3 / 4); c--)
+            if (c % 2 == 0 && w % c == 0) {
+                col_chunk = c;
+                break;
+            }
+    }
+    while ((lds_bytes(max_log_r, col_chunk, 0) > lds_cap || threads_of(max_log_r, col_chunk) > 1024) && max_log_r > 1)
         max_log_r--;
+    // The tile's twiddles are staged by at most four loads per thread, so a launch has at least 2^(log_r + log_l) / 4 threads:
+    // a narrow (ragged) chunk of a tall tile gets idle threads -- they shadow a real thread's loads and write nothing.
+    auto launch_threads = [&](int log_r, int cols, int log_l) {
+        const int need = (int)((((size_t)1 << (log_r + log_l)) + 3) / 4);
+        return std::min(1024, (std::max(threads_of(log_r, cols), need) + 63) / 64 * 64);
+    };
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
     const int n_full = w / col_chunk, last_w = w % col_chunk;
@@ -471,7 +520,8 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
         int log_l = 0;
         if (n_full == 1 && last_w == 0 && a.bit_lo > 0 && !a.bitrev_store) {
             while (log_l < 4 && log_l < a.bit_lo && (w << (log_l + 1)) <= 128 &&
-                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= 64 * 1024 && threads_of(log_r, w << (log_l + 1)) <= 1024)
+                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= lds_cap && threads_of(log_r, w << (log_l + 1)) <= 1024 &&
+                   ((size_t)1 << (log_r + log_l + 1)) <= (size_t)4 * launch_threads(log_r, w << (log_l + 1), log_l + 1))
                 log_l++;
         }
         a.log_l = log_l;
@@ -484,10 +534,10 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
             a.n_chunks = part == 0 ? n_full : 1;
             const bool pair = aligned8 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
             const int cv = a.col_chunk / (pair ? 2 : 1);
-            const int slots = std::max(1, (1 << log_r) / 8);  // the kernel's SLOTS: eight tile rows per thread
+            const int slots = std::max(1, (1 << log_r) / rows_per_thread(log_r));  // the kernel's SLOTS
             LH_ARG(ctx, slots * cv <= 1024, "NTT tile shape");
             a.magic_cv = magic_for(cv);
-            const int threads = std::min(1024, (slots * cv + 63) / 64 * 64);
+            const int threads = launch_threads(log_r, a.col_chunk, log_l);
             const size_t tiles = ((size_t)1 << (log_n - log_r - log_l)) * a.n_chunks;
             LH_ARG(ctx, tiles <= 0x7fffffffu, "NTT grid too large");
             LH_ARG(ctx, ((size_t)1 << (log_r + log_l)) <= (size_t)4 * threads, "NTT twiddle staging");

@@ -1,7 +1,7 @@
 #!/usr/bin/env python3
 """Turns the rocprofv3 outputs of one bench run (gpurun_out/<tag>...) into the summaries kept under profiles/.
 
-usage: python tools/summarise_profiles.py <tag>     e.g. r1j
+usage: python tools/summarise_profiles.py <tag> [<prefix> [<bench json>]]     e.g. r02c r02 gpurun_out/bench_ntt10.json
 expects gpurun_out/prof_<tag>/bench_kernel_stats.csv, gpurun_out/pmc_<tag>_{FETCH_SIZE,WRITE_SIZE,sq}/bench_counter_collection.csv,
 gpurun_out/bench_<tag>.json
 """
@@ -13,6 +13,9 @@ import shutil
 import sys
 
 tag = sys.argv[1]
+prefix = sys.argv[2] if len(sys.argv) > 2 else "r02"
+bench_json = sys.argv[3] if len(sys.argv) > 3 else f"gpurun_out/bench_{tag}.json"
+bench = json.load(open(bench_json))
 
 
 def kname(s):
@@ -31,7 +34,7 @@ for c in ("FETCH_SIZE", "WRITE_SIZE"):
             tot[n] += float(row["Counter_Value"])
             cnt[n] += 1
     res[c] = (tot, cnt)
-with open("profiles/r01_pmc_hbm_per_kernel.csv", "w") as f:
+with open(f"profiles/{prefix}_pmc_hbm_per_kernel.csv", "w") as f:
     f.write("# rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes, --kernel-trace only) of `python bench.py --steps 1 --warmup 0`\n")
     f.write("# units: KB as reported; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, WRITE_SIZE uncalibrated\n")
     f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
@@ -51,20 +54,25 @@ with open(f"gpurun_out/pmc_{tag}_sq/bench_counter_collection.csv") as f:
             dur[n] += int(row["End_Timestamp"]) - int(row["Start_Timestamp"])
             cnt[n] += 1
 cols = ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INSTS_LDS", "SQ_INSTS_SMEM", "SQ_WAVE_CYCLES", "SQ_WAIT_INST_ANY", "SQ_WAIT_ANY", "SQ_ACTIVE_INST_VALU"]
-with open("profiles/r01_pmc_sq_per_kernel.csv", "w") as f:
-    f.write("# rocprofv3 --pmc " + " ".join(cols) + " --kernel-trace, `python bench.py --steps 1 --warmup 0`; valu_tinst_s = SQ_INSTS_VALU * 64 lanes / duration (int32 issue peak 39.3)\n")
+with open(f"profiles/{prefix}_pmc_sq_per_kernel.csv", "w") as f:
+    f.write("# rocprofv3 --pmc " + " ".join(cols) + " --kernel-trace, `python bench.py --steps 1 --warmup 0`; valu_tinst_s = SQ_INSTS_VALU * 64 lanes / duration (full rate 78.6, half rate 39.3 T lane-instr/s)\n")
     f.write("kernel,launches,ms," + ",".join(cols) + ",valu_tinst_s\n")
     for n in sorted(dur, key=lambda k: -dur[k]):
         v = tot[n]
         rate = v["SQ_INSTS_VALU"] * 64 / (dur[n] * 1e-9) / 1e12 if dur[n] else 0
         f.write(f"{n},{cnt[n]},{dur[n] / 1e6:.3f}," + ",".join(f"{v[c]:.4g}" for c in cols) + f",{rate:.2f}\n")
 hv = sum(tot[k]["SQ_INSTS_VALU"] for k in HASH) * 64 / (sum(dur[k] for k in HASH) * 1e-9) / 1e12
-json.dump({"log_rows": 20, "source": "rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (profiles/r01_pmc_hbm_per_kernel.csv)",
+NTT = [k for k in res["FETCH_SIZE"][0] if k.startswith("k_ntt_pass")]
+ntt_bytes = (2 * sum(res["FETCH_SIZE"][0][k] for k in NTT) + sum(res["WRITE_SIZE"][0][k] for k in NTT)) * 1024
+traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (profiles/{prefix}_pmc_hbm_per_kernel.csv)",
+           "ntt_pass_bytes_per_step": ntt_bytes,
            "correction": "FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
            "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
-           "merkle_hash_valu_tinst_s": hv, "int32_valu_peak_tinst_s": 39.3}, open("profiles/r01_pmc_traffic.json", "w"), indent=1)
-shutil.copy(f"gpurun_out/prof_{tag}/bench_kernel_stats.csv", "profiles/r01_full_prove_kernel_stats.csv")
-shutil.copy(f"gpurun_out/bench_{tag}.json", "profiles/r01_bench_full_prove.json")
-with open("profiles/r01_full_prove_under_rocprof.log", "w") as f:
+           "merkle_hash_valu_tinst_s": hv, "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
+json.dump(traffic, open(f"profiles/{prefix}_pmc_traffic.json", "w"), indent=1)
+json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)  # the copy bench.py reads (labelled static there)
+shutil.copy(f"gpurun_out/prof_{tag}/bench_kernel_stats.csv", f"profiles/{prefix}_full_prove_kernel_stats.csv")
+shutil.copy(bench_json, f"profiles/{prefix}_bench_full_prove.json")
+with open(f"profiles/{prefix}_full_prove_under_rocprof.log", "w") as f:
     f.write("".join(l for l in open(f"gpurun_out/prof_{tag}/bench.log") if l.startswith("{") or "rocprofv3" in l)[:6000])
-print("merkle hash: traffic", 2 * F + W, "B/step; VALU", round(hv, 2), "Tinstr/s")
+print("merkle hash: traffic", 2 * F + W, "B/step; VALU", round(hv, 2), "Tinstr/s; NTT passes", ntt_bytes / 1e9, "GB/step")
