@@ -266,6 +266,17 @@ typedef struct lurkhip_record lurkhip_record;
 /* with_lurk_chips != 0 registers the native chips of /root/reference/src/core/chipset.rs:28-63
  * (hasher3/4/5, u64_*, big_num_lessthan) for extern_call. */
 int32_t lurkhip_toplevel_new(const char* source, int32_t with_lurk_chips, lurkhip_toplevel** out);
+/* A toplevel from COMPILED functions: the index-based bytecode of /root/reference/src/lair/bytecode.rs:12-146
+ * (Func / Block / Ctrl / Cases / Op) flattened to u32 words, format "LBC1" (the grammar is the header comment of
+ * lurk_amd/csrc/lair/bytecode_io.cpp and INTEGRATION.md section 4).  This is how a host with its own compiler -- the
+ * reference's `Toplevel::new`, /root/reference/src/lair/toplevel.rs:38-72 -- obtains trace programs, AIRs and proofs for ITS
+ * functions without their source text.  Chip names are resolved against the native chips of
+ * /root/reference/src/core/chipset.rs:28-63.  The blob is validated (stack references, arities, selector numbering):
+ * a malformed one returns LURKHIP_ERR_PARSE with a message in lurkhip_lair_last_error(). */
+int32_t lurkhip_toplevel_from_bytecode(const uint32_t* blob, uint64_t n_words, lurkhip_toplevel** out);
+/* The same serialisation of a toplevel's compiled functions.  Returns the number of words (also when `out` is NULL or
+ * `capacity_words` is too small: nothing is written then), negative on error. */
+int64_t lurkhip_toplevel_to_bytecode(const lurkhip_toplevel* top, uint32_t* out, uint64_t capacity_words);
 int32_t lurkhip_toplevel_free(lurkhip_toplevel* top);
 int32_t lurkhip_toplevel_num_funcs(const lurkhip_toplevel* top);
 int32_t lurkhip_toplevel_func_index(const lurkhip_toplevel* top, const char* name);

@@ -100,6 +100,8 @@ SIGNATURES = {
     "lurkhip_trace_bytes_dev": (_i32, [_p, _u32p, _i32, _u32p, _i32]),
     "lurkhip_trace_bytes_preprocessed_dev": (_i32, [_p, _u32p, _i32]),
     "lurkhip_toplevel_new": (_i32, [C.c_char_p, _i32, C.POINTER(_p)]),
+    "lurkhip_toplevel_from_bytecode": (_i32, [_p, C.c_uint64, C.POINTER(_p)]),
+    "lurkhip_toplevel_to_bytecode": (C.c_int64, [_p, _p, C.c_uint64]),
     "lurkhip_toplevel_free": (_i32, [_p]),
     "lurkhip_toplevel_num_funcs": (_i32, [_p]),
     "lurkhip_toplevel_func_index": (_i32, [_p, C.c_char_p]),

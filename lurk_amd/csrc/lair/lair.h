@@ -232,6 +232,11 @@ struct Toplevel {
     const Func& func_by_name(const std::string& n) const;
 };
 
+// Flat u32 serialisation of the compiled functions (format "LBC1", bytecode_io.cpp): export of this compiler's bytecode and
+// import of another compiler's (the reference's Rust Toplevel), validated.
+std::vector<uint32_t> toplevel_to_bytecode(const Toplevel& t);
+Toplevel toplevel_from_bytecode(const uint32_t* words, size_t n_words);
+
 // ---------------------------------------------------------------- layout (func_chip.rs)
 struct LayoutSizes {
     uint32_t nonce = 1, input = 0, output = 0, aux = 0, sel = 0;

@@ -89,6 +89,30 @@ int32_t lurkhip_toplevel_new(const char* source, int32_t with_lurk_chips, lurkhi
     });
 }
 
+int32_t lurkhip_toplevel_from_bytecode(const uint32_t* blob, uint64_t n_words, lurkhip_toplevel** out) {
+    if (!blob || !out) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    return guarded(nullptr, [&]() -> int32_t {
+        auto top = std::make_unique<lurkhip_toplevel>();
+        top->t = lair::toplevel_from_bytecode(blob, (size_t)n_words);
+        for (const auto& f : top->t.funcs) top->layouts.push_back(lair::compute_layout_sizes(top->t, f));
+        *out = top.release();
+        return LURKHIP_OK;
+    });
+}
+
+int64_t lurkhip_toplevel_to_bytecode(const lurkhip_toplevel* top, uint32_t* out, uint64_t capacity_words) {
+    if (!top) return fail(nullptr, LURKHIP_ERR_INVALID_ARG, "null argument");
+    int64_t n = 0;
+    int32_t st = guarded(nullptr, [&]() -> int32_t {
+        std::vector<uint32_t> w = lair::toplevel_to_bytecode(top->t);
+        n = (int64_t)w.size();
+        if (out && capacity_words >= w.size()) memcpy(out, w.data(), w.size() * 4);
+        return LURKHIP_OK;
+    });
+    return st == LURKHIP_OK ? n : (int64_t)st;
+}
+
 int32_t lurkhip_toplevel_free(lurkhip_toplevel* top) {
     delete top;
     return LURKHIP_OK;

@@ -61,6 +61,26 @@ class Toplevel:
     def new_pure(cls, source: str) -> "Toplevel":  # toplevel.rs:52-55
         return cls(source, lurk_chips=False)
 
+    @classmethod
+    def from_bytecode(cls, blob) -> "Toplevel":
+        """A toplevel from compiled functions ("LBC1" words, lurk_amd/csrc/lair/bytecode_io.cpp): what a host with its own
+        compiler (the reference's Toplevel::new, toplevel.rs:38-72) hands over instead of source text."""
+        words = np.ascontiguousarray(blob, dtype=np.uint32)
+        self = cls.__new__(cls)
+        h = C.c_void_p()
+        _check(N.lib.lurkhip_toplevel_from_bytecode(_addr(words), words.size, C.byref(h)))
+        self.handle = h
+        return self
+
+    def to_bytecode(self) -> np.ndarray:
+        n = N.lib.lurkhip_toplevel_to_bytecode(self.handle, None, 0)
+        if n < 0:
+            _check(int(n))
+        out = np.zeros(n, dtype=np.uint32)
+        if N.lib.lurkhip_toplevel_to_bytecode(self.handle, _addr(out), n) != n:
+            raise RuntimeError("lurkhip_toplevel_to_bytecode: size changed")
+        return out
+
     def __del__(self):
         if getattr(self, "handle", None) and N is not None:
             N.lib.lurkhip_toplevel_free(self.handle)

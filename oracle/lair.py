@@ -918,3 +918,88 @@ def bytes_trace(q: QueryRecord, shard_index=0):
                 rows[key][1 + 2 * k] = r[0]
                 rows[key][2 + 2 * k] = r[1]
     return rows
+
+
+# ------------------------------------------------------------------ compiled-toplevel exchange ("LBC1")
+# The oracle compiler's bytecode in the flat u32 format of lurk_amd/csrc/lair/bytecode_io.cpp (its header comment is the
+# grammar; the types are /root/reference/src/lair/bytecode.rs:12-146).  Written from the oracle's own structures, so a
+# word-for-word match with the product's export means two independent compilers agree on every index.
+_OP_TAGS = {"assert_eq": 0, "assert_ne": 1, "contains": 2, "const": 3, "add": 4, "sub": 5, "mul": 6, "inv": 7, "not": 8,
+            "call": 9, "preimg": 10, "store": 11, "load": 12, "extern": 13, "emit": 14, "range_u8": 15}
+
+
+def to_bytecode(top: Toplevel):
+    w = []
+
+    def s(text):
+        b = text.encode()
+        w.append(len(b))
+        for i in range(0, len(b), 4):
+            w.append(int.from_bytes(b[i:i + 4].ljust(4, b"\0"), "little"))
+
+    def lst(xs):
+        w.append(len(xs))
+        w.extend(int(x) for x in xs)
+
+    def block(b):
+        """writes the block, returns its return idents"""
+        w.append(len(b["ops"]))
+        for op in b["ops"]:
+            k = op[0]
+            w.append(_OP_TAGS[k])
+            if k in ("assert_eq", "assert_ne"):
+                lst(op[1]); lst(op[2])
+            elif k == "contains":
+                lst(op[1]); w.append(op[2])
+            elif k == "const":
+                w.append(op[1] % P)
+            elif k in ("add", "sub", "mul"):
+                w.extend([op[1], op[2]])
+            elif k in ("inv", "not"):
+                w.append(op[1])
+            elif k in ("call", "preimg", "extern"):
+                w.append(op[1]); lst(op[2])
+            elif k in ("store", "emit", "range_u8"):
+                lst(op[1])
+            elif k == "load":
+                w.extend([op[1], op[2]])
+        c = b["ctrl"]
+        idents = []
+        if c[0] == "return":
+            w.append(0)
+            w.append(c[1])
+            lst(c[2])
+            idents = [c[1]]
+        else:
+            kind, v, cases, uniq, d = c
+            if kind == "choose":
+                w.extend([1, v[0], len(uniq)])
+                for u in uniq:
+                    idents += block(u)
+                keys = sorted(cases)
+                w.append(len(keys))
+                for key in keys:
+                    w.append(key[0] % P)
+                    w.append(next(i for i, u in enumerate(uniq) if u is cases[key]))
+            else:
+                w.append(2)
+                lst(v)
+                keys = sorted(cases)
+                w.append(len(keys))
+                for key in keys:
+                    lst([x % P for x in key])
+                    idents += block(cases[key])
+            w.append(1 if d is not None else 0)
+            if d is not None:
+                idents += block(d)
+        lst(idents)
+        return idents
+
+    w += [0x3143424C, 1, len(top.chips), len(top.funcs)]
+    for c in top.chips:
+        s(c.name)
+    for f in top.funcs:
+        s(f["name"])
+        w += [(1 if f["invertible"] else 0) | (2 if f["partial"] else 0), f["input_size"], f["output_size"]]
+        block(f["body"])
+    return w
