@@ -436,6 +436,18 @@ typedef struct lurkhip_proof lurkhip_proof;
 int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
                             const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                             lurkhip_proof** out);
+/* Pcs::open on its own (p3 TwoAdicFriPcs::open as sphinx calls it from prove_shard [UPSTREAM-RECALL]): opens the
+ * matrices of n_rounds commitments (lurkhip_commit / lurkhip_commit_dev / lurkhip_commit_cosets_dev handles, all with the same
+ * blow-up) at caller-chosen extension-field points and proves the openings with FRI.  n_points[k] (1 or 2) is the number of
+ * points of the k-th matrix, counting matrices round by round in committed order; `points` holds those points in the same
+ * order, 4 canonical words each.  The challenger must be in the state the verifier's will be in before it reads the opened
+ * values; it is advanced through alpha, the FRI betas, the proof-of-work check and the query indices.  The result is a flat
+ * array of canonical words read with lurkhip_proof_words / lurkhip_proof_read (layout: lurk_amd/commit.py parse_opening):
+ * opened values [round][matrix][point][column], FRI layer roots, final polynomial, proof-of-work witness, query indices, the
+ * Merkle openings of every round and layer. */
+int32_t lurkhip_open(lurkhip_ctx* ctx, int32_t n_rounds, lurkhip_commitment* const* commitments, const uint32_t* n_points,
+                     const uint32_t* points, lurkhip_challenger* challenger, uint32_t num_queries, uint32_t pow_bits,
+                     lurkhip_proof** out);
 int64_t lurkhip_proof_words(const lurkhip_proof* proof);
 /* copies the proof's words; capacity_words (the size of `out`) must be at least lurkhip_proof_words(proof) */
 int32_t lurkhip_proof_read(const lurkhip_proof* proof, uint32_t* out, uint64_t capacity_words);

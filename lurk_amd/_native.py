@@ -153,6 +153,7 @@ SIGNATURES = {
     "lurkhip_shard_commit": (_i32, [_p, _i32, _p, _u32p, _p, _p, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_shard_free": (_i32, [_p, _p]),
     "lurkhip_shard_prove": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_open": (_i32, [_p, _i32, _p, _p, _p, _p, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_proof_words": (_i64, [_p]),
     "lurkhip_proof_read": (_i32, [_p, _u32p, C.c_uint64]),
     "lurkhip_proof_free": (_i32, [_p]),

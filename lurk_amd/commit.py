@@ -3,6 +3,7 @@ trace matrix + one mixed-height Poseidon2-16 Merkle tree, all on the device."""
 from __future__ import annotations
 
 import ctypes as C
+from dataclasses import dataclass
 
 import numpy as np
 
@@ -109,3 +110,105 @@ def commit_cosets_dev(ctx: Context, mats, log_heights, widths, shifts, log_blowu
     root = np.empty(8, dtype=np.uint32)
     ctx.check(N.lib.lurkhip_commit_cosets_dev(ctx.handle, n, C.cast(ptrs, C.c_void_p), _addr(lh), _addr(ws), _addr(sh), log_blowup, repr, C.byref(handle), _addr(root)))
     return Commitment(ctx, handle, root, [int(x) for x in lh], [int(x) for x in ws], log_blowup)
+
+
+# ------------------------------------------------------------------ Pcs::open on its own (lurkhip_open)
+OPENING_MAGIC = 0x4E504F4C  # "LOPN"
+
+
+@dataclass
+class Opening:
+    """Parsed result of `open_rounds`.  Word layout (all canonical):
+    [magic "LOPN", n_rounds, log_blowup, num_queries, pow_bits, n_layers, log_max_height]
+    per round: n_mats, then per matrix (log_n, width, n_points)
+    opened values [round][matrix][point][column] (4 words each)
+    n_layers FRI layer roots (8 words each), final polynomial (4), proof-of-work witness (1), num_queries query indices
+    per round: record size R, then num_queries records of R words = the LDE rows of every matrix at the query's index
+      (concatenated, committed order) followed by the 8-word siblings of its Merkle path, leaf level first
+    per FRI layer: record size, then num_queries records = the pair of extension elements (8 words) + the path."""
+    log_blowup: int
+    num_queries: int
+    pow_bits: int
+    log_max_height: int
+    shapes: list          # per round: [(log_n, width, n_points)]
+    opened: list          # [round][matrix][point] -> list of EF tuples
+    fri_roots: list
+    final_poly: tuple
+    pow_witness: int
+    query_indices: list
+    round_openings: list  # per round: (record_words, [records])
+    layer_openings: list
+    words: np.ndarray = None
+
+
+def parse_opening(words) -> Opening:
+    w = [int(x) for x in words]
+    pos = [0]
+
+    def take(n):
+        out = w[pos[0]:pos[0] + n]
+        if len(out) != n:
+            raise ValueError("truncated opening")
+        pos[0] += n
+        return out
+
+    magic, n_rounds, log_blowup, nq, pow_bits, n_layers, log_max = take(7)
+    if magic != OPENING_MAGIC:
+        raise ValueError("not a lurkhip opening (bad magic)")
+    shapes = []
+    for _ in range(n_rounds):
+        (n_mats,) = take(1)
+        shapes.append([tuple(take(3)) for _ in range(n_mats)])
+    opened = []
+    for mats in shapes:
+        rnd = []
+        for _, width, n_pts in mats:
+            pts = []
+            for _ in range(n_pts):
+                flat = take(4 * width)
+                pts.append([tuple(flat[4 * i:4 * i + 4]) for i in range(width)])
+            rnd.append(pts)
+        opened.append(rnd)
+    fri_roots = [take(8) for _ in range(n_layers)]
+    final_poly = tuple(take(4))
+    (pow_witness,) = take(1)
+    indices = take(nq)
+    rounds = []
+    for _ in range(n_rounds):
+        (rw,) = take(1)
+        rounds.append((rw, [take(rw) for _ in range(nq)]))
+    layers = []
+    for _ in range(n_layers):
+        (rw,) = take(1)
+        layers.append((rw, [take(rw) for _ in range(nq)]))
+    if pos[0] != len(w):
+        raise ValueError("trailing words in opening")
+    return Opening(log_blowup, nq, pow_bits, log_max, shapes, opened, fri_roots, final_poly, pow_witness, indices, rounds, layers,
+                   np.asarray(words, dtype=np.uint32))
+
+
+def open_rounds(ctx: Context, commitments, points, challenger, num_queries: int = 100, pow_bits: int = 16, parse: bool = True):
+    """p3 `Pcs::open`: `commitments` = Commitment handles (one per round), `points[r][m]` = the one or two extension-field
+    points (4 canonical lanes each) matrix m of round r is opened at; `challenger` = lurk_amd.prover.Challenger in the
+    verifier's state.  Returns the opened values + FRI proof (Opening, or the raw words with parse=False)."""
+    n_points, flat = [], []
+    for c, rp in zip(commitments, points):
+        if len(rp) != len(c.widths):
+            raise ValueError("one point list per committed matrix")
+        for mp in rp:
+            n_points.append(len(mp))
+            for z in mp:
+                flat.extend(int(x) for x in z)
+    handles = (C.c_void_p * len(commitments))(*[c.handle for c in commitments])
+    npt = np.asarray(n_points, dtype=np.uint32)
+    pts = np.asarray(flat, dtype=np.uint32)
+    h = C.c_void_p()
+    ctx.check(N.lib.lurkhip_open(ctx.handle, len(commitments), C.cast(handles, C.c_void_p), _addr(npt), _addr(pts), challenger.handle,
+                                 num_queries, pow_bits, C.byref(h)))
+    try:
+        n = N.lib.lurkhip_proof_words(h)
+        words = np.empty(n, dtype=np.uint32)
+        ctx.check(N.lib.lurkhip_proof_read(h, _addr(words), n))
+    finally:
+        N.lib.lurkhip_proof_free(h)
+    return parse_opening(words) if parse else words

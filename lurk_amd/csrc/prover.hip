@@ -17,6 +17,7 @@
 //     proof-of-work grind, query indices, Merkle openings of every round and every layer.
 // The transcript is host state (challenger.h); roots, sums and opened values cross the boundary once each.
 #include <algorithm>
+#include <array>
 #include <cstring>
 #include <map>
 #include <new>
@@ -62,7 +63,8 @@ struct lurkhip_proof {
 
 namespace {
 
-constexpr uint32_t PROOF_MAGIC = 0x4652504cu;  // "LPRF"
+constexpr uint32_t PROOF_MAGIC = 0x4652504cu;    // "LPRF"
+constexpr uint32_t OPENING_MAGIC = 0x4e504f4cu;  // "LOPN"
 
 ef ef_pow_host(ef a, uint64_t e) {
     ef r = bb::ef_one();
@@ -224,6 +226,350 @@ int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* sh) {
     return LURKHIP_OK;
 }
 
+}  // extern "C"
+
+// ------------------------------------------------------------------ p3 TwoAdicFriPcs::open
+// Opens committed matrices at their points and proves the openings with FRI: barycentric evaluation on the low coset,
+// alpha-batched reduced openings per LDE height, FRI commit phase, proof of work, query openings.  `rounds[r].points[m]` lists
+// the (one or two) entries of `pts` matrix m of commitment r is opened at.  Device buffers go to `pooled`, layer commitments to
+// `to_free`: the caller releases both (also on failure).
+namespace {
+struct OpenOut {
+    std::vector<std::vector<std::vector<std::vector<ef>>>> opened;  // [round][matrix][point][column], Montgomery
+    std::vector<uint32_t> layer_roots_m;
+    ef final_poly;
+    uint32_t pow_witness = 0;
+    std::vector<uint32_t> indices;
+    std::vector<uint32_t> round_record_words, layer_record_words;
+    std::vector<size_t> round_off, layer_off;  // word offsets into rec_host
+    const uint32_t* rec_host = nullptr;        // page-locked staging of the context: read it before the next call on the context
+    size_t rec_words = 0;
+    int log_max = 0;
+    size_t n_layers = 0;
+};
+}  // namespace
+
+static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& prof, const std::vector<Round>& rounds,
+                             const std::vector<ef>& pts, int log_blowup, Challenger& ch, uint32_t num_queries, uint32_t pow_bits,
+                             std::vector<lurkhip_commitment*>& to_free, std::vector<void*>& pooled, OpenOut& out) {
+    auto palloc = [&](size_t bytes, uint32_t** p) -> int32_t {
+        void* v = nullptr;
+        int32_t s = pool_alloc(ctx, bytes, &v);
+        if (s == LURKHIP_OK) {
+            pooled.push_back(v);
+            *p = (uint32_t*)v;
+        }
+        return s;
+    };
+#define PTRY(expr) LH_TRY(expr)
+#define PHIP(expr) LH_HIP(ctx, expr)
+    // ---- p3 TwoAdicFriPcs::open
+    span_begin(ctx, "open");
+    uint32_t max_w = 1;
+    int log_global_max = 0;
+    for (const Round& r : rounds)
+        for (int m = 0; m < r.c->n_mats; m++) {
+            max_w = std::max(max_w, r.c->width[m]);
+            log_global_max = std::max(log_global_max, r.c->log_h[m]);
+        }
+    // caches keyed by (log size, point index)
+    std::map<std::pair<int, int>, uint32_t*> bary, denoms;
+    auto get_weights = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt, uint32_t** outp) -> int32_t {
+        auto key = std::make_pair(log_m, pt);
+        auto it = cache.find(key);
+        if (it == cache.end()) {
+            uint32_t* buf = nullptr;
+            LH_TRY(palloc(((size_t)16) << log_m, &buf));
+            LH_TRY(point_weights(ctx, mode, log_m, pts[pt], buf));
+            it = cache.emplace(key, buf).first;
+        }
+        *outp = it->second;
+        return LURKHIP_OK;
+    };
+    uint32_t* ro[32] = {};
+    uint64_t num_reduced[32] = {};
+    const uint32_t g_m = bb::to_monty(bb::GEN);
+    // phase 1: barycentric sums of every matrix at its points, one read-back for all of them
+    std::vector<size_t> dot_off;  // word offset of each matrix's [2][w][4] block
+    size_t dot_words = 0;
+    for (const Round& r : rounds)
+        for (int m = 0; m < r.c->n_mats; m++) {
+            dot_off.push_back(dot_words);
+            dot_words += (size_t)2 * r.c->width[m] * 4;
+        }
+    uint32_t* dot_out = nullptr;
+    PTRY(palloc(dot_words * 4, &dot_out));
+    {
+        // per-block partial sums of every matrix in one buffer, summed by one launch at the end
+        size_t partial_words = 0;
+        for (const Round& r : rounds)
+            for (int m = 0; m < r.c->n_mats; m++) partial_words += column_dot_partial_words(r.c->width[m], (size_t)1 << (r.c->log_h[m] - log_blowup));
+        uint32_t* partials = nullptr;
+        PTRY(palloc(std::max<size_t>(partial_words, 4) * 4, &partials));
+        std::vector<DotJob> jobs;
+        size_t k = 0, at = 0;
+        for (const Round& r : rounds)
+            for (int m = 0; m < r.c->n_mats; m++, k++) {
+                const int log_n = r.c->log_h[m] - log_blowup;
+                const std::vector<int>& mp = r.points[m];
+                uint32_t *u0 = nullptr, *u1 = nullptr;
+                PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
+                if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
+                PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
+                // the inverse denominators of the reduced openings do not depend on alpha_fri: queued here, ahead of the host wait
+                uint32_t* dn = nullptr;
+                for (int pt : mp) PTRY(get_weights(denoms, 1, r.c->log_h[m], pt, &dn));
+                jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
+                at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
+            }
+        PTRY(column_dot_finish(ctx, jobs, dot_out));
+    }
+    std::vector<uint32_t> dot_host(dot_words);
+    PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHIP(stream_wait(ctx));
+    // phase 2: opened values on the host: y = (z^N - g^N) / (N g^(N-1)) * sum
+    // per round, per matrix, per point: ys[c] (Montgomery)
+    auto& opened = out.opened;
+    opened.assign(rounds.size(), {});
+    {
+        size_t k = 0;
+        for (size_t ri = 0; ri < rounds.size(); ri++) {
+            const Round& r = rounds[ri];
+            opened[ri].resize(r.c->n_mats);
+            for (int m = 0; m < r.c->n_mats; m++, k++) {
+                const uint32_t w = r.c->width[m];
+                const size_t n = (size_t)1 << (r.c->log_h[m] - log_blowup);
+                const std::vector<int>& mp = r.points[m];
+                const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
+                const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
+                opened[ri][m].resize(mp.size());
+                for (size_t p = 0; p < mp.size(); p++) {
+                    ef zn = ef_pow_host(pts[mp[p]], n);
+                    zn.c[0] = bb::sub(zn.c[0], gn);
+                    const ef factor = bb::ef_scale(zn, denom_inv);
+                    std::vector<ef>& ys = opened[ri][m][p];
+                    ys.resize(w);
+                    for (uint32_t c = 0; c < w; c++) {
+                        const uint32_t* sp = &dot_host[dot_off[k] + ((size_t)p * w + c) * 4];
+                        ys[c] = bb::ef_mul(factor, ef{{sp[0], sp[1], sp[2], sp[3]}});
+                    }
+                }
+            }
+        }
+    }
+    // the batching challenge: right after zeta at the pinned revision; the later upstream fix observes every opened value first
+    if (prof.observe_openings)
+        for (size_t ri = 0; ri < rounds.size(); ri++)
+            for (auto& mat : opened[ri])
+                for (auto& ys : mat)
+                    for (const ef& y : ys) ch.observe_ef_m(y);
+    const ef alpha_fri = ch.sample_ef_m();
+    uint32_t* alpha_pows = nullptr;  // alpha_fri^c for c < max_w
+    PTRY(palloc((size_t)max_w * 16, &alpha_pows));
+    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows, max_w));
+    uint32_t* alpha_pows_c = nullptr;  // the same powers, centred, 8 words each (lazy accumulators)
+    PTRY(palloc((size_t)max_w * 32, &alpha_pows_c));
+    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows_c, max_w, true));
+    std::vector<ef> alpha_pows_host(max_w);
+    {
+        ef p = bb::ef_one();
+        for (uint32_t c = 0; c < max_w; c++) {
+            alpha_pows_host[c] = p;
+            p = bb::ef_mul(p, alpha_fri);
+        }
+    }
+    // phase 3: the reduced openings of every matrix
+    // narrow matrices wait per (height, first point) and go out together (fri.hip: k_reduce_openings_narrow)
+    std::map<std::pair<int, int>, NarrowArgs> narrow;
+    auto flush_narrow = [&](NarrowArgs& g) -> int32_t {
+        const int32_t st = reduce_openings_narrow(ctx, g);
+        g.n_mats = 0;
+        return st;
+    };
+    size_t mat_k = 0;
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        const Round& r = rounds[ri];
+        for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
+            const int log_h = r.c->log_h[m];
+            const uint32_t w = r.c->width[m];
+            const std::vector<int>& mp = r.points[m];
+            uint32_t *d0 = nullptr, *d1 = nullptr;
+            ef reduced_ys[2] = {bb::ef_zero(), bb::ef_zero()};
+            for (size_t p = 0; p < mp.size(); p++) {
+                const std::vector<ef>& ys = opened[ri][m][p];
+                for (uint32_t c = 0; c < w; c++) reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
+            }
+            if (!ro[log_h]) {
+                PTRY(palloc(((size_t)16) << log_h, &ro[log_h]));
+                PHIP(hipMemsetAsync(ro[log_h], 0, ((size_t)16) << log_h, ctx->stream));
+            }
+            PTRY(get_weights(denoms, 1, log_h, mp[0], &d0));
+            if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
+            // p3 keeps one alpha-power offset per LDE height (num_reduced[log_height]); fri_alpha_global: one for all heights
+            uint64_t& offset = num_reduced[prof.fri_alpha_global ? 0 : log_h];
+            const ef apow0 = ef_pow_host(alpha_fri, offset);
+            const ef apow1 = ef_pow_host(alpha_fri, offset + w);
+            if (w <= NARROW_MAX_W && alpha_pows_c) {
+                NarrowArgs& g = narrow[{log_h, mp[0]}];
+                if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
+                if (g.n_mats == 0) g = NarrowArgs{{}, 0, 1u << log_h, alpha_pows_c, d0, nullptr, ro[log_h]};
+                if (d1) g.d1 = d1;  // one second point per height (the first point's successor on that domain)
+                g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1};
+                if (g.n_mats == NARROW_MAX_MATS) PTRY(flush_narrow(g));
+            } else {
+                PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
+            }
+            offset += (uint64_t)mp.size() * w;
+        }
+    }
+    for (auto& kv : narrow) PTRY(flush_narrow(kv.second));
+    span_end(ctx, "open");
+
+    // ---- FRI commit phase
+    span_begin(ctx, "fri_commit");
+    const int log_max = log_global_max;
+    std::vector<lurkhip_commitment*> layers;
+    std::vector<uint32_t>& layer_roots_m = out.layer_roots_m;
+    uint32_t* current = ro[log_max];
+    // The transcript moves to the device for this phase (fri.hip: k_fri_challenge): per layer "commit, observe the root,
+    // sample beta, fold" is a chain of launches with no host round trip; the state comes back with the final polynomial.
+    const int n_layers = log_max > log_blowup ? log_max - log_blowup : 0;
+    DevChallenger hc{};
+    memcpy(hc.state, ch.state, sizeof hc.state);
+    hc.n_in = (uint32_t)ch.input.size();
+    hc.n_out = (uint32_t)ch.output.size();
+    hc.out_head = 0;
+    hc.squeeze = (uint32_t)ch.squeeze;
+    hc.pop_front = ch.pop_front ? 1u : 0u;
+    for (size_t i = 0; i < ch.input.size(); i++) hc.input[i] = ch.input[i];
+    for (size_t i = 0; i < ch.output.size(); i++) hc.output[i] = ch.output[i];
+    DevChallenger* ch_dev = nullptr;
+    uint32_t* betas_dev = nullptr;
+    PTRY(palloc(sizeof(DevChallenger), (uint32_t**)&ch_dev));
+    PTRY(palloc((size_t)std::max(n_layers, 1) * 16, &betas_dev));
+    uint32_t* roots_dev = nullptr;  // the layer roots, copied by k_fri_challenge as it observes them
+    PTRY(palloc((size_t)std::max(n_layers, 1) * 32, &roots_dev));
+    PHIP(hipMemcpyAsync(ch_dev, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
+    PHIP(stream_wait(ctx));  // hc is a stack object
+    for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
+        lurkhip_commitment* lc = nullptr;
+        PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
+        to_free.push_back(lc);
+        layers.push_back(lc);
+        const uint32_t* root_dev = lc->digests + lc->level_off[lc->log_max] * 8;
+        PTRY(fri_challenge(ctx, ch_dev, root_dev, betas_dev + 4 * li, roots_dev + 8 * li));
+        uint32_t* next = nullptr;
+        PTRY(palloc(((size_t)16) << log_folded, &next));
+        PTRY(fri_fold(ctx, current, log_folded + 1, betas_dev + 4 * li, ro[log_folded], next));
+        current = next;
+    }
+    std::vector<uint32_t> fin((size_t)4 << log_blowup);
+    layer_roots_m.resize((size_t)layers.size() * 8);
+    {
+        // one page-locked block: [roots | transcript state | final polynomial]
+        const size_t b_roots = layer_roots_m.size() * 4, o_hc = (b_roots + 15) & ~(size_t)15, o_fin = o_hc + ((sizeof hc + 15) & ~(size_t)15);
+        uint8_t* st = nullptr;
+        PTRY(host_staging(ctx, o_fin + fin.size() * 4, (void**)&st));
+        if (b_roots) PHIP(hipMemcpyAsync(st, roots_dev, b_roots, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(hipMemcpyAsync(st + o_hc, ch_dev, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(hipMemcpyAsync(st + o_fin, current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(stream_wait(ctx));
+        memcpy(layer_roots_m.data(), st, b_roots);
+        memcpy(&hc, st + o_hc, sizeof hc);
+        memcpy(fin.data(), st + o_fin, fin.size() * 4);
+    }
+    memcpy(ch.state, hc.state, sizeof hc.state);
+    ch.input.assign(hc.input, hc.input + hc.n_in);
+    ch.output.assign(hc.output + hc.out_head, hc.output + hc.out_head + hc.n_out);
+    for (size_t i = 4; i < fin.size(); i++)
+        if (fin[i] != fin[i & 3]) {
+            return set_error(ctx, LURKHIP_ERR_EXEC, "internal error: the FRI commit phase did not end on a constant");
+        }
+    const ef final_poly{{fin[0], fin[1], fin[2], fin[3]}};
+    out.final_poly = final_poly;
+    ch.observe_ef_m(final_poly);
+    span_end(ctx, "fri_commit");
+
+    // ---- proof of work, query indices
+    span_begin(ctx, "fri_query");
+    uint32_t& pow_witness = out.pow_witness;
+    pow_witness = 0;
+    if (pow_bits > 0) {
+        uint32_t st[16];
+        memcpy(st, ch.state, sizeof st);
+        for (size_t i = 0; i < ch.input.size(); i++) st[i] = ch.input[i];
+        PTRY(pow_grind(ctx, st, (int)ch.input.size(), (int)pow_bits, ch.first_sample_lane(), &pow_witness));
+    }
+    if (!ch.check_witness((int)pow_bits, pow_witness)) {
+        return set_error(ctx, LURKHIP_ERR_EXEC, "proof-of-work witness rejected by the host transcript");
+    }
+    std::vector<uint32_t>& indices = out.indices;
+    indices.assign(num_queries, 0);
+    for (auto& ix : indices) ix = ch.sample_bits(log_max);
+    uint32_t* indices_dev = nullptr;
+    PTRY(palloc((size_t)num_queries * 4, &indices_dev));
+    PHIP(hipMemcpyAsync(indices_dev, indices.data(), (size_t)num_queries * 4, hipMemcpyHostToDevice, ctx->stream));
+    PHIP(stream_wait(ctx));
+    // every record of every round and layer goes to one device buffer and comes back in one copy
+    auto& round_record_words = out.round_record_words;
+    auto& layer_record_words = out.layer_record_words;
+    round_record_words.assign(rounds.size(), 0);
+    layer_record_words.assign(layers.size(), 0);
+    std::vector<std::vector<OpenMat>> round_mats(rounds.size());
+    size_t rec_words = 0;
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        const lurkhip_commitment* c = rounds[ri].c;
+        for (int m = 0; m < c->n_mats; m++) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m]});
+        PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &round_record_words[ri]));
+        rec_words += (size_t)num_queries * round_record_words[ri];
+    }
+    for (size_t li = 0; li < layers.size(); li++) {
+        const lurkhip_commitment* c = layers[li];
+        PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0,
+                             nullptr, &layer_record_words[li]));
+        rec_words += (size_t)num_queries * layer_record_words[li];
+    }
+    uint32_t* rec_dev = nullptr;
+    PTRY(palloc(std::max<size_t>(rec_words, 4) * 4, &rec_dev));
+    auto& round_off = out.round_off;
+    auto& layer_off = out.layer_off;
+    round_off.assign(rounds.size(), 0);
+    layer_off.assign(layers.size(), 0);
+    size_t rec_at = 0;
+    for (size_t ri = 0; ri < rounds.size(); ri++) {
+        const lurkhip_commitment* c = rounds[ri].c;
+        uint32_t rw = 0;
+        round_off[ri] = rec_at;
+        PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)(log_max - c->log_max),
+                             rec_dev + rec_at, &rw));
+        rec_at += (size_t)num_queries * rw;
+    }
+    for (size_t li = 0; li < layers.size(); li++) {
+        const lurkhip_commitment* c = layers[li];
+        uint32_t rw = 0;
+        layer_off[li] = rec_at;
+        // index_i = index >> li, pair = index_i >> 1
+        PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries,
+                             (uint32_t)li + 1, rec_dev + rec_at, &rw));
+        rec_at += (size_t)num_queries * rw;
+    }
+    const uint32_t* rec_host = nullptr;
+    PTRY(host_staging(ctx, std::max<size_t>(rec_words, 4) * 4, (void**)&rec_host));
+    if (rec_words) PHIP(hipMemcpyAsync((void*)rec_host, rec_dev, rec_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    PHIP(stream_wait(ctx));
+    span_end(ctx, "fri_query");
+    out.rec_host = rec_host;
+    out.rec_words = rec_words;
+    out.log_max = log_max;
+    out.n_layers = layers.size();
+    return LURKHIP_OK;
+
+#undef PTRY
+#undef PHIP
+}
+
+extern "C" {
+
 // ------------------------------------------------------------------ prove_shard
 static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
                                 const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
@@ -381,17 +727,14 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // ---- opening points
     const ef zeta = ch.sample_ef_m();
     // point table: per trace height, (zeta, zeta * w_N); quotient chunks only use zeta
-    struct Pt {
-        ef z;
-    };
-    std::vector<Pt> pts;
+    std::vector<ef> pts;
     std::map<uint32_t, std::pair<int, int>> pts_of_logn;
     auto points_for = [&](uint32_t log_n) {
         auto it = pts_of_logn.find(log_n);
         if (it != pts_of_logn.end()) return it->second;
         // the zeta entry is shared by every height: index 0
-        if (pts.empty()) pts.push_back(Pt{zeta});
-        pts.push_back(Pt{bb::ef_scale(zeta, two_adic_generator_monty((int)log_n))});
+        if (pts.empty()) pts.push_back(zeta);
+        pts.push_back(bb::ef_scale(zeta, two_adic_generator_monty((int)log_n)));
         auto pr = std::make_pair(0, (int)pts.size() - 1);
         pts_of_logn.emplace(log_n, pr);
         return pr;
@@ -414,304 +757,33 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         rounds.push_back(r);
     }
     {
-        if (pts.empty()) pts.push_back(Pt{zeta});
+        if (pts.empty()) pts.push_back(zeta);
         Round r{quot_commit, {}};
         for (size_t m = 0; m < qmats.size(); m++) r.points.push_back({0});
         rounds.push_back(r);
     }
 
-    // ---- p3 TwoAdicFriPcs::open
-    span_begin(ctx, "open");
-    uint32_t max_w = 1;
-    int log_global_max = 0;
-    for (const Round& r : rounds)
-        for (int m = 0; m < r.c->n_mats; m++) {
-            max_w = std::max(max_w, r.c->width[m]);
-            log_global_max = std::max(log_global_max, r.c->log_h[m]);
-        }
-    // caches keyed by (log size, point index)
-    std::map<std::pair<int, int>, uint32_t*> bary, denoms;
-    auto get_weights = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt, uint32_t** outp) -> int32_t {
-        auto key = std::make_pair(log_m, pt);
-        auto it = cache.find(key);
-        if (it == cache.end()) {
-            uint32_t* buf = nullptr;
-            LH_TRY(palloc(((size_t)16) << log_m, &buf));
-            LH_TRY(point_weights(ctx, mode, log_m, pts[pt].z, buf));
-            it = cache.emplace(key, buf).first;
-        }
-        *outp = it->second;
-        return LURKHIP_OK;
-    };
-    uint32_t* ro[32] = {};
-    uint64_t num_reduced[32] = {};
-    const uint32_t g_m = bb::to_monty(bb::GEN);
-    // phase 1: barycentric sums of every matrix at its points, one read-back for all of them
-    std::vector<size_t> dot_off;  // word offset of each matrix's [2][w][4] block
-    size_t dot_words = 0;
-    for (const Round& r : rounds)
-        for (int m = 0; m < r.c->n_mats; m++) {
-            dot_off.push_back(dot_words);
-            dot_words += (size_t)2 * r.c->width[m] * 4;
-        }
-    uint32_t* dot_out = nullptr;
-    PTRY(palloc(dot_words * 4, &dot_out));
-    {
-        // per-block partial sums of every matrix in one buffer, summed by one launch at the end
-        size_t partial_words = 0;
-        for (const Round& r : rounds)
-            for (int m = 0; m < r.c->n_mats; m++) partial_words += column_dot_partial_words(r.c->width[m], (size_t)1 << (r.c->log_h[m] - log_blowup));
-        uint32_t* partials = nullptr;
-        PTRY(palloc(std::max<size_t>(partial_words, 4) * 4, &partials));
-        std::vector<DotJob> jobs;
-        size_t k = 0, at = 0;
-        for (const Round& r : rounds)
-            for (int m = 0; m < r.c->n_mats; m++, k++) {
-                const int log_n = r.c->log_h[m] - log_blowup;
-                const std::vector<int>& mp = r.points[m];
-                uint32_t *u0 = nullptr, *u1 = nullptr;
-                PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
-                if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
-                PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
-                // the inverse denominators of the reduced openings do not depend on alpha_fri: queued here, ahead of the host wait
-                uint32_t* dn = nullptr;
-                for (int pt : mp) PTRY(get_weights(denoms, 1, r.c->log_h[m], pt, &dn));
-                jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
-                at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
-            }
-        PTRY(column_dot_finish(ctx, jobs, dot_out));
-    }
-    std::vector<uint32_t> dot_host(dot_words);
-    PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PHIP(stream_wait(ctx));
-    // phase 2: opened values on the host: y = (z^N - g^N) / (N g^(N-1)) * sum
-    // per round, per matrix, per point: ys[c] (Montgomery)
-    std::vector<std::vector<std::vector<std::vector<ef>>>> opened(rounds.size());
-    {
-        size_t k = 0;
-        for (size_t ri = 0; ri < rounds.size(); ri++) {
-            const Round& r = rounds[ri];
-            opened[ri].resize(r.c->n_mats);
-            for (int m = 0; m < r.c->n_mats; m++, k++) {
-                const uint32_t w = r.c->width[m];
-                const size_t n = (size_t)1 << (r.c->log_h[m] - log_blowup);
-                const std::vector<int>& mp = r.points[m];
-                const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
-                const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
-                opened[ri][m].resize(mp.size());
-                for (size_t p = 0; p < mp.size(); p++) {
-                    ef zn = ef_pow_host(pts[mp[p]].z, n);
-                    zn.c[0] = bb::sub(zn.c[0], gn);
-                    const ef factor = bb::ef_scale(zn, denom_inv);
-                    std::vector<ef>& ys = opened[ri][m][p];
-                    ys.resize(w);
-                    for (uint32_t c = 0; c < w; c++) {
-                        const uint32_t* sp = &dot_host[dot_off[k] + ((size_t)p * w + c) * 4];
-                        ys[c] = bb::ef_mul(factor, ef{{sp[0], sp[1], sp[2], sp[3]}});
-                    }
-                }
-            }
-        }
-    }
-    // the batching challenge: right after zeta at the pinned revision; the later upstream fix observes every opened value first
-    if (prof.observe_openings)
-        for (size_t ri = 0; ri < rounds.size(); ri++)
-            for (auto& mat : opened[ri])
-                for (auto& ys : mat)
-                    for (const ef& y : ys) ch.observe_ef_m(y);
-    const ef alpha_fri = ch.sample_ef_m();
-    uint32_t* alpha_pows = nullptr;  // alpha_fri^c for c < max_w
-    PTRY(palloc((size_t)max_w * 16, &alpha_pows));
-    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows, max_w));
-    uint32_t* alpha_pows_c = nullptr;  // the same powers, centred, 8 words each (lazy accumulators)
-    PTRY(palloc((size_t)max_w * 32, &alpha_pows_c));
-    PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows_c, max_w, true));
-    std::vector<ef> alpha_pows_host(max_w);
-    {
-        ef p = bb::ef_one();
-        for (uint32_t c = 0; c < max_w; c++) {
-            alpha_pows_host[c] = p;
-            p = bb::ef_mul(p, alpha_fri);
-        }
-    }
-    // phase 3: the reduced openings of every matrix
-    // narrow matrices wait per (height, first point) and go out together (fri.hip: k_reduce_openings_narrow)
-    std::map<std::pair<int, int>, NarrowArgs> narrow;
-    auto flush_narrow = [&](NarrowArgs& g) -> int32_t {
-        const int32_t st = reduce_openings_narrow(ctx, g);
-        g.n_mats = 0;
-        return st;
-    };
-    size_t mat_k = 0;
-    for (size_t ri = 0; ri < rounds.size(); ri++) {
-        const Round& r = rounds[ri];
-        for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
-            const int log_h = r.c->log_h[m];
-            const uint32_t w = r.c->width[m];
-            const std::vector<int>& mp = r.points[m];
-            uint32_t *d0 = nullptr, *d1 = nullptr;
-            ef reduced_ys[2] = {bb::ef_zero(), bb::ef_zero()};
-            for (size_t p = 0; p < mp.size(); p++) {
-                const std::vector<ef>& ys = opened[ri][m][p];
-                for (uint32_t c = 0; c < w; c++) reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
-            }
-            if (!ro[log_h]) {
-                PTRY(palloc(((size_t)16) << log_h, &ro[log_h]));
-                PHIP(hipMemsetAsync(ro[log_h], 0, ((size_t)16) << log_h, ctx->stream));
-            }
-            PTRY(get_weights(denoms, 1, log_h, mp[0], &d0));
-            if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
-            // p3 keeps one alpha-power offset per LDE height (num_reduced[log_height]); fri_alpha_global: one for all heights
-            uint64_t& offset = num_reduced[prof.fri_alpha_global ? 0 : log_h];
-            const ef apow0 = ef_pow_host(alpha_fri, offset);
-            const ef apow1 = ef_pow_host(alpha_fri, offset + w);
-            if (w <= NARROW_MAX_W && alpha_pows_c) {
-                NarrowArgs& g = narrow[{log_h, mp[0]}];
-                if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
-                if (g.n_mats == 0) g = NarrowArgs{{}, 0, 1u << log_h, alpha_pows_c, d0, nullptr, ro[log_h]};
-                if (d1) g.d1 = d1;  // one second point per height (the first point's successor on that domain)
-                g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1};
-                if (g.n_mats == NARROW_MAX_MATS) PTRY(flush_narrow(g));
-            } else {
-                PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
-            }
-            offset += (uint64_t)mp.size() * w;
-        }
-    }
-    for (auto& kv : narrow) PTRY(flush_narrow(kv.second));
-    span_end(ctx, "open");
-
-    // ---- FRI commit phase
-    span_begin(ctx, "fri_commit");
-    const int log_max = log_global_max;
-    std::vector<lurkhip_commitment*> layers;
-    std::vector<uint32_t> layer_roots_m;
-    uint32_t* current = ro[log_max];
-    // The transcript moves to the device for this phase (fri.hip: k_fri_challenge): per layer "commit, observe the root,
-    // sample beta, fold" is a chain of launches with no host round trip; the state comes back with the final polynomial.
-    const int n_layers = log_max > log_blowup ? log_max - log_blowup : 0;
-    DevChallenger hc{};
-    memcpy(hc.state, ch.state, sizeof hc.state);
-    hc.n_in = (uint32_t)ch.input.size();
-    hc.n_out = (uint32_t)ch.output.size();
-    hc.out_head = 0;
-    hc.squeeze = (uint32_t)ch.squeeze;
-    hc.pop_front = ch.pop_front ? 1u : 0u;
-    for (size_t i = 0; i < ch.input.size(); i++) hc.input[i] = ch.input[i];
-    for (size_t i = 0; i < ch.output.size(); i++) hc.output[i] = ch.output[i];
-    DevChallenger* ch_dev = nullptr;
-    uint32_t* betas_dev = nullptr;
-    PTRY(palloc(sizeof(DevChallenger), (uint32_t**)&ch_dev));
-    PTRY(palloc((size_t)std::max(n_layers, 1) * 16, &betas_dev));
-    uint32_t* roots_dev = nullptr;  // the layer roots, copied by k_fri_challenge as it observes them
-    PTRY(palloc((size_t)std::max(n_layers, 1) * 32, &roots_dev));
-    PHIP(hipMemcpyAsync(ch_dev, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
-    PHIP(stream_wait(ctx));  // hc is a stack object
-    for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
-        lurkhip_commitment* lc = nullptr;
-        PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
-        to_free.push_back(lc);
-        layers.push_back(lc);
-        const uint32_t* root_dev = lc->digests + lc->level_off[lc->log_max] * 8;
-        PTRY(fri_challenge(ctx, ch_dev, root_dev, betas_dev + 4 * li, roots_dev + 8 * li));
-        uint32_t* next = nullptr;
-        PTRY(palloc(((size_t)16) << log_folded, &next));
-        PTRY(fri_fold(ctx, current, log_folded + 1, betas_dev + 4 * li, ro[log_folded], next));
-        current = next;
-    }
-    std::vector<uint32_t> fin((size_t)4 << log_blowup);
-    layer_roots_m.resize((size_t)layers.size() * 8);
-    {
-        // one page-locked block: [roots | transcript state | final polynomial]
-        const size_t b_roots = layer_roots_m.size() * 4, o_hc = (b_roots + 15) & ~(size_t)15, o_fin = o_hc + ((sizeof hc + 15) & ~(size_t)15);
-        uint8_t* st = nullptr;
-        PTRY(host_staging(ctx, o_fin + fin.size() * 4, (void**)&st));
-        if (b_roots) PHIP(hipMemcpyAsync(st, roots_dev, b_roots, hipMemcpyDeviceToHost, ctx->stream));
-        PHIP(hipMemcpyAsync(st + o_hc, ch_dev, sizeof hc, hipMemcpyDeviceToHost, ctx->stream));
-        PHIP(hipMemcpyAsync(st + o_fin, current, fin.size() * 4, hipMemcpyDeviceToHost, ctx->stream));
-        PHIP(stream_wait(ctx));
-        memcpy(layer_roots_m.data(), st, b_roots);
-        memcpy(&hc, st + o_hc, sizeof hc);
-        memcpy(fin.data(), st + o_fin, fin.size() * 4);
-    }
-    memcpy(ch.state, hc.state, sizeof hc.state);
-    ch.input.assign(hc.input, hc.input + hc.n_in);
-    ch.output.assign(hc.output + hc.out_head, hc.output + hc.out_head + hc.n_out);
-    for (size_t i = 4; i < fin.size(); i++)
-        if (fin[i] != fin[i & 3]) {
-            cleanup();
-            return set_error(ctx, LURKHIP_ERR_EXEC, "internal error: the FRI commit phase did not end on a constant");
-        }
-    const ef final_poly{{fin[0], fin[1], fin[2], fin[3]}};
-    ch.observe_ef_m(final_poly);
-    span_end(ctx, "fri_commit");
-
-    // ---- proof of work, query indices
-    span_begin(ctx, "fri_query");
-    uint32_t pow_witness = 0;
-    if (pow_bits > 0) {
-        uint32_t st[16];
-        memcpy(st, ch.state, sizeof st);
-        for (size_t i = 0; i < ch.input.size(); i++) st[i] = ch.input[i];
-        PTRY(pow_grind(ctx, st, (int)ch.input.size(), (int)pow_bits, ch.first_sample_lane(), &pow_witness));
-    }
-    if (!ch.check_witness((int)pow_bits, pow_witness)) {
-        cleanup();
-        return set_error(ctx, LURKHIP_ERR_EXEC, "proof-of-work witness rejected by the host transcript");
-    }
-    std::vector<uint32_t> indices(num_queries);
-    for (auto& ix : indices) ix = ch.sample_bits(log_max);
-    uint32_t* indices_dev = nullptr;
-    PTRY(palloc((size_t)num_queries * 4, &indices_dev));
-    PHIP(hipMemcpyAsync(indices_dev, indices.data(), (size_t)num_queries * 4, hipMemcpyHostToDevice, ctx->stream));
-    PHIP(stream_wait(ctx));
-    // every record of every round and layer goes to one device buffer and comes back in one copy
-    std::vector<uint32_t> round_record_words(rounds.size()), layer_record_words(layers.size());
-    std::vector<std::vector<OpenMat>> round_mats(rounds.size());
-    size_t rec_words = 0;
-    for (size_t ri = 0; ri < rounds.size(); ri++) {
-        const lurkhip_commitment* c = rounds[ri].c;
-        for (int m = 0; m < c->n_mats; m++) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m]});
-        PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &round_record_words[ri]));
-        rec_words += (size_t)num_queries * round_record_words[ri];
-    }
-    for (size_t li = 0; li < layers.size(); li++) {
-        const lurkhip_commitment* c = layers[li];
-        PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0,
-                             nullptr, &layer_record_words[li]));
-        rec_words += (size_t)num_queries * layer_record_words[li];
-    }
-    uint32_t* rec_dev = nullptr;
-    PTRY(palloc(std::max<size_t>(rec_words, 4) * 4, &rec_dev));
-    std::vector<size_t> round_off(rounds.size()), layer_off(layers.size());
-    size_t rec_at = 0;
-    for (size_t ri = 0; ri < rounds.size(); ri++) {
-        const lurkhip_commitment* c = rounds[ri].c;
-        uint32_t rw = 0;
-        round_off[ri] = rec_at;
-        PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)(log_max - c->log_max),
-                             rec_dev + rec_at, &rw));
-        rec_at += (size_t)num_queries * rw;
-    }
-    for (size_t li = 0; li < layers.size(); li++) {
-        const lurkhip_commitment* c = layers[li];
-        uint32_t rw = 0;
-        layer_off[li] = rec_at;
-        // index_i = index >> li, pair = index_i >> 1
-        PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries,
-                             (uint32_t)li + 1, rec_dev + rec_at, &rw));
-        rec_at += (size_t)num_queries * rw;
-    }
-    const uint32_t* rec_host = nullptr;
-    PTRY(host_staging(ctx, std::max<size_t>(rec_words, 4) * 4, (void**)&rec_host));
-    if (rec_words) PHIP(hipMemcpyAsync((void*)rec_host, rec_dev, rec_words * 4, hipMemcpyDeviceToHost, ctx->stream));
-    PHIP(stream_wait(ctx));
-    span_end(ctx, "fri_query");
+    // ---- p3 TwoAdicFriPcs::open (values at the points, reduced openings, FRI)
+    OpenOut oo;
+    PTRY(pcs_open_impl(ctx, prof, rounds, pts, log_blowup, ch, num_queries, pow_bits, to_free, pooled, oo));
+    const auto& opened = oo.opened;
+    const auto& layer_roots_m = oo.layer_roots_m;
+    const ef final_poly = oo.final_poly;
+    const uint32_t pow_witness = oo.pow_witness;
+    const auto& indices = oo.indices;
+    const auto& round_record_words = oo.round_record_words;
+    const auto& layer_record_words = oo.layer_record_words;
+    const auto& round_off = oo.round_off;
+    const auto& layer_off = oo.layer_off;
+    const uint32_t* rec_host = oo.rec_host;
+    const size_t rec_words = oo.rec_words;
+    const int log_max = oo.log_max;
+    const size_t n_fri_layers = oo.n_layers;
 
     // ---- serialise (canonical values); layout documented in lurk_amd/prover.py
     auto* proof = new lurkhip_proof();
     std::vector<uint32_t>& o = proof->words;
-    o.insert(o.end(), {PROOF_MAGIC, (uint32_t)n_chips, (uint32_t)log_blowup, num_queries, pow_bits, n_public, (uint32_t)layers.size(),
+    o.insert(o.end(), {PROOF_MAGIC, (uint32_t)n_chips, (uint32_t)log_blowup, num_queries, pow_bits, n_public, (uint32_t)n_fri_layers,
                        (uint32_t)log_max, (uint32_t)(pk->commit ? pk->traces.size() : 0), (uint32_t)qmats.size()});
     for (int i = 0; i < n_chips; i++) {
         const lair::ChipAir& air = air_of(sh->airs[i]);
@@ -732,13 +804,13 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     push_ef(o, final_poly);
     o.push_back(pow_witness);
     for (uint32_t ix : indices) o.push_back(ix);
-    o.reserve(o.size() + rec_words + rounds.size() + layers.size());
+    o.reserve(o.size() + rec_words + rounds.size() + n_fri_layers);
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         o.push_back(round_record_words[ri]);
         const size_t n = (size_t)num_queries * round_record_words[ri];
         for (size_t k = 0; k < n; k++) o.push_back(bb::from_monty(rec_host[round_off[ri] + k]));
     }
-    for (size_t li = 0; li < layers.size(); li++) {
+    for (size_t li = 0; li < n_fri_layers; li++) {
         o.push_back(layer_record_words[li]);
         const size_t n = (size_t)num_queries * layer_record_words[li];
         for (size_t k = 0; k < n; k++) o.push_back(bb::from_monty(rec_host[layer_off[li] + k]));
@@ -746,6 +818,94 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     cleanup();
 #undef PTRY
 #undef PHIP
+    *out = proof;
+    return LURKHIP_OK;
+}
+
+// ------------------------------------------------------------------ standalone Pcs::open
+int32_t lurkhip_open(lurkhip_ctx* ctx, int32_t n_rounds, lurkhip_commitment* const* commitments, const uint32_t* n_points,
+                     const uint32_t* points, lurkhip_challenger* chal, uint32_t num_queries, uint32_t pow_bits, lurkhip_proof** out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, n_rounds >= 1 && n_rounds <= 64 && commitments && n_points && points && chal && out, "bad open arguments");
+    LH_ARG(ctx, num_queries >= 1 && num_queries <= 1024 && pow_bits <= 30, "bad FRI parameters");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    std::vector<Round> rounds;
+    std::vector<ef> pts;
+    std::map<std::array<uint32_t, 4>, int> pt_index;
+    const int log_blowup = commitments[0] ? commitments[0]->log_blowup : 0;
+    size_t k = 0, pk_ = 0;
+    for (int r = 0; r < n_rounds; r++) {
+        lurkhip_commitment* c = commitments[r];
+        LH_ARG(ctx, c && c->n_mats > 0, "round %d: null or empty commitment", r);
+        LH_ARG(ctx, c->log_blowup == log_blowup && log_blowup >= 1, "round %d: every commitment must use the same blow-up (>= 2)", r);
+        Round rd{c, {}};
+        for (int m = 0; m < c->n_mats; m++, k++) {
+            LH_ARG(ctx, n_points[k] == 1 || n_points[k] == 2, "round %d matrix %d: one or two opening points per matrix", r, m);
+            std::vector<int> mp;
+            for (uint32_t q = 0; q < n_points[k]; q++, pk_++) {
+                std::array<uint32_t, 4> key;
+                for (int i = 0; i < 4; i++) {
+                    LH_ARG(ctx, points[4 * pk_ + i] < bb::P, "opening point is not canonical");
+                    key[i] = points[4 * pk_ + i];
+                }
+                auto it = pt_index.find(key);
+                if (it == pt_index.end()) {
+                    it = pt_index.emplace(key, (int)pts.size()).first;
+                    pts.push_back(ef{{bb::to_monty(key[0]), bb::to_monty(key[1]), bb::to_monty(key[2]), bb::to_monty(key[3])}});
+                }
+                mp.push_back(it->second);
+            }
+            LH_ARG(ctx, mp.size() == 1 || mp[0] != mp[1], "round %d matrix %d: the two points coincide", r, m);
+            rd.points.push_back(mp);
+        }
+        rounds.push_back(rd);
+    }
+    const lurkhip_protocol_profile prof = profile_of(ctx);
+    std::vector<lurkhip_commitment*> to_free;
+    std::vector<void*> pooled;
+    OpenOut oo;
+    int32_t st;
+    try {  // nothing unwinds across the C boundary
+        st = pcs_open_impl(ctx, prof, rounds, pts, log_blowup, chal->ch, num_queries, pow_bits, to_free, pooled, oo);
+    } catch (const std::bad_alloc&) {
+        st = set_error(ctx, LURKHIP_ERR_OOM, "host allocation failed while opening");
+    } catch (const std::exception& e) {
+        st = set_error(ctx, LURKHIP_ERR_EXEC, "internal error while opening: %s", e.what());
+    }
+    lurkhip_proof* proof = nullptr;
+    if (st == LURKHIP_OK) {
+        // layout documented in lurk_amd/commit.py (parse_opening)
+        proof = new lurkhip_proof();
+        std::vector<uint32_t>& o = proof->words;
+        o.insert(o.end(), {OPENING_MAGIC, (uint32_t)n_rounds, (uint32_t)log_blowup, num_queries, pow_bits, (uint32_t)oo.n_layers, (uint32_t)oo.log_max});
+        for (const Round& r : rounds) {
+            o.push_back((uint32_t)r.c->n_mats);
+            for (int m = 0; m < r.c->n_mats; m++)
+                o.insert(o.end(), {(uint32_t)(r.c->log_h[m] - log_blowup), r.c->width[m], (uint32_t)r.points[m].size()});
+        }
+        for (size_t ri = 0; ri < rounds.size(); ri++)
+            for (auto& mat : oo.opened[ri])
+                for (auto& ys : mat)
+                    for (const ef& y : ys) push_ef(o, y);
+        for (uint32_t v : oo.layer_roots_m) o.push_back(bb::from_monty(v));
+        push_ef(o, oo.final_poly);
+        o.push_back(oo.pow_witness);
+        for (uint32_t ix : oo.indices) o.push_back(ix);
+        for (size_t ri = 0; ri < rounds.size(); ri++) {
+            o.push_back(oo.round_record_words[ri]);
+            const size_t n = (size_t)num_queries * oo.round_record_words[ri];
+            for (size_t i = 0; i < n; i++) o.push_back(bb::from_monty(oo.rec_host[oo.round_off[ri] + i]));
+        }
+        for (size_t li = 0; li < oo.n_layers; li++) {
+            o.push_back(oo.layer_record_words[li]);
+            const size_t n = (size_t)num_queries * oo.layer_record_words[li];
+            for (size_t i = 0; i < n; i++) o.push_back(bb::from_monty(oo.rec_host[oo.layer_off[li] + i]));
+        }
+    }
+    (void)stream_wait(ctx);
+    for (auto* c : to_free) free_commitment(ctx, c);
+    for (void* p : pooled) pool_release(ctx, p);
+    if (st != LURKHIP_OK) return st;
     *out = proof;
     return LURKHIP_OK;
 }

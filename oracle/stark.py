@@ -488,42 +488,11 @@ def selectors_at_point(zeta, log_n):
     return (ef_mul(zh, ef_inv(ef_sub(zeta, ONE))), ef_mul(zh, ef_inv(ef_sub(zeta, ef(w_inv)))), ef_sub(zeta, ef(w_inv)), ef_inv(zh))
 
 
-def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, proof, challenger, merkle_verify):
-    """sphinx Verifier::verify_shard + p3 TwoAdicFriPcs::verify + p3_fri::verifier.  `challenger` must be in the state
-    the prover's was when prove_shard started.  Returns the chips' cumulative sums."""
-    chips = proof.chips
-    log_blowup = proof.log_blowup
+def pcs_verify(rounds, proof, log_blowup, challenger, merkle_verify):
+    """p3 TwoAdicFriPcs::verify + p3_fri::verifier.  rounds = [(root, [(log_n, width, [(point, values)])])] in the prover's
+    order; `proof` carries fri_roots, final_poly, pow_bits, pow_witness, log_max_height, num_queries, query_indices,
+    round_openings, layer_openings (a ShardProof or a standalone opening).  The challenger is advanced like the prover's."""
     prof = challenger.profile
-    if prof.observe_chip_meta:
-        for c in chips:
-            challenger.observe([c.log_n, c.width, c.prep_index + 1])
-    perm_alpha, perm_beta = challenger.sample_ext(), challenger.sample_ext()
-    challenger.observe(proof.perm_root)
-    if prof.observe_chip_meta:
-        for c in chips:
-            challenger.observe(list(c.cumulative_sum))
-    alpha = challenger.sample_ext()
-    challenger.observe(proof.quot_root)
-    zeta = challenger.sample_ext()
-
-    # ---- rounds: (root, [(log_n, width, [(point, values)])]) in the prover's order
-    def next_point(log_n):
-        return ef_scale(zeta, two_adic_generator(log_n))
-
-    rounds = []
-    if proof.n_preprocessed:
-        by_idx = {c.prep_index: c for c in chips if c.prep_index >= 0}
-        mats = []
-        for m in range(proof.n_preprocessed):
-            c = by_idx[m]
-            _need(c.log_n == prep_log_heights[m] and c.prep_width == prep_widths[m], "preprocessed shape")
-            mats.append((c.log_n, c.prep_width, [(zeta, c.opened["prep"][0]), (next_point(c.log_n), c.opened["prep"][1])]))
-        rounds.append((vk_root, mats))
-    rounds.append((proof.main_root, [(c.log_n, c.width, [(zeta, c.opened["main"][0]), (next_point(c.log_n), c.opened["main"][1])]) for c in chips]))
-    rounds.append((proof.perm_root, [(c.log_n, c.perm_width, [(zeta, c.opened["perm"][0]), (next_point(c.log_n), c.opened["perm"][1])]) for c in chips]))
-    rounds.append((proof.quot_root, [(c.log_n, 4, [(zeta, chunk)]) for c in chips for chunk in c.opened["quotient"]]))
-
-    # ---- pcs.verify
     if prof.observe_openings:
         for _, mats in rounds:
             for _, _, pts in mats:
@@ -591,6 +560,46 @@ def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, 
             x = x * x % P
         _need(idx < (1 << log_blowup), "final index")
         _need(folded == proof.final_poly, f"query {qi}: final polynomial mismatch")
+
+
+
+def verify_shard(airs_by_machine_index, vk_root, prep_log_heights, prep_widths, proof, challenger, merkle_verify):
+    """sphinx Verifier::verify_shard + p3 TwoAdicFriPcs::verify + p3_fri::verifier.  `challenger` must be in the state
+    the prover's was when prove_shard started.  Returns the chips' cumulative sums."""
+    chips = proof.chips
+    log_blowup = proof.log_blowup
+    prof = challenger.profile
+    if prof.observe_chip_meta:
+        for c in chips:
+            challenger.observe([c.log_n, c.width, c.prep_index + 1])
+    perm_alpha, perm_beta = challenger.sample_ext(), challenger.sample_ext()
+    challenger.observe(proof.perm_root)
+    if prof.observe_chip_meta:
+        for c in chips:
+            challenger.observe(list(c.cumulative_sum))
+    alpha = challenger.sample_ext()
+    challenger.observe(proof.quot_root)
+    zeta = challenger.sample_ext()
+
+    # ---- rounds: (root, [(log_n, width, [(point, values)])]) in the prover's order
+    def next_point(log_n):
+        return ef_scale(zeta, two_adic_generator(log_n))
+
+    rounds = []
+    if proof.n_preprocessed:
+        by_idx = {c.prep_index: c for c in chips if c.prep_index >= 0}
+        mats = []
+        for m in range(proof.n_preprocessed):
+            c = by_idx[m]
+            _need(c.log_n == prep_log_heights[m] and c.prep_width == prep_widths[m], "preprocessed shape")
+            mats.append((c.log_n, c.prep_width, [(zeta, c.opened["prep"][0]), (next_point(c.log_n), c.opened["prep"][1])]))
+        rounds.append((vk_root, mats))
+    rounds.append((proof.main_root, [(c.log_n, c.width, [(zeta, c.opened["main"][0]), (next_point(c.log_n), c.opened["main"][1])]) for c in chips]))
+    rounds.append((proof.perm_root, [(c.log_n, c.perm_width, [(zeta, c.opened["perm"][0]), (next_point(c.log_n), c.opened["perm"][1])]) for c in chips]))
+    rounds.append((proof.quot_root, [(c.log_n, 4, [(zeta, chunk)]) for c in chips for chunk in c.opened["quotient"]]))
+
+    # ---- pcs.verify
+    pcs_verify(rounds, proof, log_blowup, challenger, merkle_verify)
 
     # ---- constraints at zeta
     for c in chips:
