@@ -254,6 +254,41 @@ int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, i
  * Replaces BaseAir::preprocessed_trace, /root/reference/src/gadgets/bytes/trace.rs:49-72. */
 int32_t lurkhip_trace_bytes_preprocessed_dev(lurkhip_ctx* ctx, uint32_t* out_dev, int32_t repr);
 
+/* ------------------------------------------------------------------- ZStore */
+/* Content-addressed interning of Lurk data with level-order batched hashing.  Replaces the hashing side of
+ * ZStore, /root/reference/src/core/zstore.rs:252-267: the hash3 / hash4 / hash5 memo tables (zstore.rs:305-333), the Merkle
+ * DAG `dag` (zstore.rs:207-219,335-356) and memoize_dag (zstore.rs:569-702); the ZDag of a cached proof
+ * (/root/reference/src/core/cli/zdag.rs:16-55) is exported from it.  The reference hashes one node per Poseidon2 call,
+ * children first; here a caller hands over a whole pending DAG and every height of it is one lurkhip_poseidon2_hash8 launch per
+ * preimage width. */
+typedef struct lurkhip_zstore lurkhip_zstore;
+#define LURKHIP_ZNODE_WORDS 10
+#define LURKHIP_ZNODE_ATOM 0     /* tag, digest[8]: a leaf, recorded as ZPtrType::Atom (intern_num / _char / _u64 / _comm ...) */
+#define LURKHIP_ZNODE_TUPLE11 1  /* tag, a, b: digest = hash4(flatten(a) | flatten(b)), intern_tuple11 (zstore.rs:335-341) */
+#define LURKHIP_ZNODE_TUPLE110 2 /* tag, a, b, c: digest = hash5(flatten(a) | flatten(b) | c.digest), intern_tuple110 (zstore.rs:343-349) */
+#define LURKHIP_ZNODE_COMM 3     /* -, a, b: Comm with digest = hash3(a.digest | flatten(b)): `hide` / `commit` */
+#define LURKHIP_ZNODE_REF 4      /* tag, digest[8]: a pointer interned earlier; nothing is recorded for it */
+int32_t lurkhip_zstore_new(lurkhip_ctx* ctx, lurkhip_zstore** out);
+int32_t lurkhip_zstore_free(lurkhip_zstore* zs);
+const char* lurkhip_zstore_last_error(const lurkhip_zstore* zs);
+/* Interns n_nodes nodes given in topological order (children before parents).  nodes[i] = LURKHIP_ZNODE_WORDS words:
+ * kind, tag, then 8 digest words (ATOM / REF) or the indices of the children (earlier nodes).  out_zptrs[i] = tag + 8 digest
+ * words.  Tags are those of /root/reference/src/core/tag.rs:23-39; all values canonical. */
+int32_t lurkhip_zstore_intern_dag(lurkhip_zstore* zs, uint32_t n_nodes, const uint32_t* nodes, uint32_t* out_zptrs);
+/* out[6]: permutations computed at widths 24, 32, 40; kernel launches; memo-table hits; entries of the DAG */
+int32_t lurkhip_zstore_stats(const lurkhip_zstore* zs, uint64_t* out);
+/* The inverse hash tables memoize_dag walks (`hashes4_inv`, `hashes5_inv`: digest -> preimage, in the reference the inverse
+ * queries of the hash4 / hash5 functions of an execution): rows of [digest(8) | preimage(32)] and [digest(8) | preimage(40)]. */
+int32_t lurkhip_zstore_set_inverse_tables(lurkhip_zstore* zs, uint64_t n4, const uint32_t* inv4, uint64_t n5, const uint32_t* inv5);
+/* ZStore::memoize_dag (zstore.rs:569-702): records the Lurk data dependencies of tag/digest from the inverse tables. */
+int32_t lurkhip_zstore_memoize_dag(lurkhip_zstore* zs, uint32_t tag, const uint32_t* digest);
+/* out[28] = kind (0 Atom, 1 Tuple11, 2 Tuple110), then the children (9 words each, unused ones zero); error if unknown */
+int32_t lurkhip_zstore_fetch(const lurkhip_zstore* zs, const uint32_t* zptr, uint32_t* out);
+/* ZDag::populate_with_many (cli/zdag.rs:16-55): the DAG entries reachable from n_roots pointers (9 words each), children
+ * before parents, each once; an entry is 37 words: zptr (9), kind (1), children (27).  Returns the number of entries (writes at
+ * most cap_entries of them; out may be NULL to count), negative when data is missing from the DAG. */
+int64_t lurkhip_zstore_dag_export(const lurkhip_zstore* zs, uint32_t n_roots, const uint32_t* roots, uint32_t* out, uint64_t cap_entries);
+
 /* --------------------------------------------------------------------- Lair */
 /* Host side of Lair (C++ here because the reference's Rust toolchain is absent): functions written in the
  * surface syntax of the reference's `func!` macro are compiled to bytecode, executed by the memoising

@@ -99,6 +99,15 @@ SIGNATURES = {
     "lurkhip_trace_mem_dev": (_i32, [_p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _u32p, _i32]),
     "lurkhip_trace_bytes_dev": (_i32, [_p, _u32p, _i32, _u32p, _i32]),
     "lurkhip_trace_bytes_preprocessed_dev": (_i32, [_p, _u32p, _i32]),
+    "lurkhip_zstore_new": (_i32, [_p, C.POINTER(_p)]),
+    "lurkhip_zstore_free": (_i32, [_p]),
+    "lurkhip_zstore_last_error": (C.c_char_p, [_p]),
+    "lurkhip_zstore_intern_dag": (_i32, [_p, C.c_uint32, _p, _p]),
+    "lurkhip_zstore_stats": (_i32, [_p, _p]),
+    "lurkhip_zstore_set_inverse_tables": (_i32, [_p, C.c_uint64, _p, C.c_uint64, _p]),
+    "lurkhip_zstore_memoize_dag": (_i32, [_p, C.c_uint32, _p]),
+    "lurkhip_zstore_fetch": (_i32, [_p, _p, _p]),
+    "lurkhip_zstore_dag_export": (C.c_int64, [_p, C.c_uint32, _p, _p, C.c_uint64]),
     "lurkhip_toplevel_new": (_i32, [C.c_char_p, _i32, C.POINTER(_p)]),
     "lurkhip_toplevel_from_bytecode": (_i32, [_p, C.c_uint64, C.POINTER(_p)]),
     "lurkhip_toplevel_to_bytecode": (C.c_int64, [_p, _p, C.c_uint64]),
