@@ -488,6 +488,24 @@ int64_t lurkhip_proof_words(const lurkhip_proof* proof);
 int32_t lurkhip_proof_read(const lurkhip_proof* proof, uint32_t* out, uint64_t capacity_words);
 int32_t lurkhip_proof_free(lurkhip_proof* proof);
 
+/* ------------------------------------------------------------------- proof wire format */
+/* The reference's serialised proofs.  `CryptoProof { shard_proofs, verifier_version, depth }` with
+ * `CryptoShardProof { commitment, opened_values, opening_proof, chip_ordering }` as `bincode::serialize` writes them
+ * (/root/reference/src/core/cli/proofs.rs:22-35, /root/reference/src/core/cli/repl.rs:200-203), built from the flat words of
+ * lurkhip_proof_read, one array per shard.  chip_names[machine index] = the chips' `name()` (lurkhip_air_name) for
+ * `chip_ordering`; depth = the last four public values as little-endian bytes (proofs.rs:115-124).  The inner sphinx / Plonky3
+ * types are [UPSTREAM-RECALL] (field order in lurk_amd/csrc/wire.cpp); serialize_montgomery mirrors the profile field of that
+ * name.  Returns the byte count (written only when capacity suffices), negative on malformed input. */
+int64_t lurkhip_crypto_proof_bincode(int32_t n_shards, const uint32_t* const* shard_words, const uint64_t* shard_n_words, int32_t n_chip_names,
+                                     const char* const* chip_names, const char* verifier_version, int32_t serialize_montgomery, uint8_t* out,
+                                     uint64_t capacity);
+/* `CachedProof { crypto_proof, expr, env, result, zdag }` (proofs.rs:137-143): crypto_proof = bytes of the call above, the
+ * three pointers as tag + digest (9 words), zdag = entries of lurkhip_zstore_dag_export for [expr, env, result]
+ * (/root/reference/src/core/cli/zdag.rs:12, a map ZPtr -> ZPtrType). */
+int64_t lurkhip_cached_proof_bincode(const uint8_t* crypto_proof, uint64_t crypto_len, const uint32_t* expr, const uint32_t* env,
+                                     const uint32_t* result, uint64_t n_dag_entries, const uint32_t* dag_entries, int32_t serialize_montgomery,
+                                     uint8_t* out, uint64_t capacity);
+
 #ifdef __cplusplus
 }
 #endif

@@ -164,6 +164,8 @@ SIGNATURES = {
     "lurkhip_shard_prove": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_open": (_i32, [_p, _i32, _p, _p, _p, _p, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_proof_words": (_i64, [_p]),
+    "lurkhip_crypto_proof_bincode": (_i64, [_i32, _p, _p, _i32, _p, C.c_char_p, _i32, _p, C.c_uint64]),
+    "lurkhip_cached_proof_bincode": (_i64, [_p, C.c_uint64, _p, _p, _p, C.c_uint64, _p, _i32, _p, C.c_uint64]),
     "lurkhip_proof_read": (_i32, [_p, _u32p, C.c_uint64]),
     "lurkhip_proof_free": (_i32, [_p]),
     "lurkhip_quotient_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),

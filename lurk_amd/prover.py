@@ -206,14 +206,12 @@ class _ShardProver:
         words = np.zeros(n, dtype=np.uint32)
         N.check(N.lib.lurkhip_proof_read(p, _addr(words), n))
         N.lib.lurkhip_proof_free(p)
-        if not parse:
-            return words
-        proof = parse_proof(words)
-        # the C ABI numbers chips by their position in the shard's chip list: map back to the machine's chip vector
+        # the C ABI numbers chips by their position in the shard's chip list: map back to the machine's chip vector (in the
+        # words too, so that they stand on their own: lurk_amd/proofs.py names chips by machine index)
         included = self._included[shard_handle.value]
-        for c in proof.chips:
-            c.machine_index = included[c.machine_index]
-        return proof
+        for i in range(int(words[1])):
+            words[10 + 11 * i] = included[int(words[10 + 11 * i])]
+        return parse_proof(words) if parse else words
 
     def free_shard(self, shard_handle):
         self._included.pop(shard_handle.value, None)

@@ -509,7 +509,8 @@ def pcs_verify(rounds, proof, log_blowup, challenger, merkle_verify):
     log_max = len(proof.fri_roots) + log_blowup
     _need(log_max == proof.log_max_height, "log_max_height")
     indices = [challenger.sample_bits(log_max) for _ in range(proof.num_queries)]
-    _need(indices == proof.query_indices, "query indices differ from the transcript's")
+    if proof.query_indices is not None:  # (the upstream proof format does not carry them: oracle/wire.py)
+        _need(indices == proof.query_indices, "query indices differ from the transcript's")
 
     for qi, index in enumerate(indices):
         ro = {}
@@ -546,10 +547,18 @@ def pcs_verify(rounds, proof, log_blowup, challenger, merkle_verify):
             folded = ef_add(folded, ro.get(log_folded + 1, ZERO))
             rw, records = proof.layer_openings[li]
             rec = records[qi]
-            _need(rw == 8 + 8 * log_folded, "layer record size")
-            pair, path = rec[:8], rec[8:]
-            evals = [tuple(pair[0:4]), tuple(pair[4:8])]
-            _need(evals[idx % 2] == folded, f"query {qi}: layer {li} does not continue the fold")
+            if getattr(proof, "sibling_only", False):
+                # p3's CommitPhaseProofStep carries the sibling only: the queried element of the pair IS the running fold, and the
+                # Merkle opening of the pair binds it
+                _need(rw == 4 + 8 * log_folded, "layer record size")
+                evals = [None, None]
+                evals[idx % 2], evals[(idx ^ 1) % 2] = folded, tuple(rec[:4])
+                pair, path = list(evals[0]) + list(evals[1]), rec[4:]
+            else:
+                _need(rw == 8 + 8 * log_folded, "layer record size")
+                pair, path = rec[:8], rec[8:]
+                evals = [tuple(pair[0:4]), tuple(pair[4:8])]
+                _need(evals[idx % 2] == folded, f"query {qi}: layer {li} does not continue the fold")
             _need(merkle_verify([log_folded], [8], idx >> 1, pair, path, root), f"query {qi}: FRI layer {li} opening fails")
             xs = [x, x]
             xs[(idx ^ 1) % 2] = xs[(idx ^ 1) % 2] * (P - 1) % P  # times the generator of the order-2 subgroup
