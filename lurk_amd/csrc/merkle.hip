@@ -37,17 +37,50 @@ __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __res
     p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec, p->sum_mult_c);
 }
 
-// sponge over the uniform column table for row `row`; state must be zero on entry
+// Row words are read with global (not flat) loads; a dword-aligned 16-byte global load is legal on gfx950.
+typedef const __attribute__((address_space(1))) uint32_t* gwords;
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const __attribute__((address_space(1))) u32x4_a4* gquads;
+
+// The (up to) eight words chunk `g` of the concatenated row `row` absorbs.  When the eight columns are consecutive columns of
+// one matrix -- every chunk except those straddling two matrices and the ragged last one -- they are 32 contiguous bytes:
+// two descriptor loads, one address, two 16-byte loads; otherwise one descriptor and one load per word.
+__device__ __forceinline__ void load_chunk(uint32_t (&v)[8], const LeafCol* __restrict__ cols, uint32_t g, uint32_t total_w, size_t row) {
+    if (g + 8 <= total_w) {
+        const LeafCol d0 = cols[g], d7 = cols[g + 7];
+        if (d0.base == d7.base && d7.col == d0.col + 7) {
+            gquads a = (gquads)((gwords)d0.base + (row * d0.width + d0.col));
+            const u32x4_a4 lo = a[0], hi = a[1];
+            v[0] = lo.x; v[1] = lo.y; v[2] = lo.z; v[3] = lo.w;
+            v[4] = hi.x; v[5] = hi.y; v[6] = hi.z; v[7] = hi.w;
+            return;
+        }
+    }
+#pragma unroll
+    for (int j = 0; j < 8; j++) {
+        if (g + j < total_w) {
+            const LeafCol d = cols[g + j];
+            v[j] = ((gwords)d.base)[row * d.width + d.col];
+        }
+    }
+}
+
+// sponge over the uniform column table for row `row`; state must be zero on entry.  The words of chunk g + 1 are requested
+// before the permutation of chunk g runs, so a wave never waits for its row with nothing else to do.
 __device__ __forceinline__ void sponge_row(uint32_t (&s)[16], const P16Params* __restrict__ p,
                                            const LeafCol* __restrict__ cols, uint32_t total_w, size_t row) {
+    uint32_t nxt[8];
+    load_chunk(nxt, cols, 0, total_w, row);
     for (uint32_t g = 0; g < total_w; g += 8) {
+        if (g + 8 <= total_w) {
 #pragma unroll
-        for (int j = 0; j < 8; j++) {
-            if (g + j < total_w) {
-                LeafCol d = cols[g + j];
-                s[j] = d.base[row * d.width + d.col];
-            }
+            for (int j = 0; j < 8; j++) s[j] = nxt[j];
+        } else {
+#pragma unroll
+            for (int j = 0; j < 8; j++)
+                if (g + j < total_w) s[j] = nxt[j];
         }
+        if (g + 8 < total_w) load_chunk(nxt, cols, g + 8, total_w, row);
         perm16(s, p);
     }
 }
