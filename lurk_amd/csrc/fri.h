@@ -53,6 +53,23 @@ struct NarrowArgs {
     uint32_t* ro;
 };
 int32_t reduce_openings_narrow(lurkhip_ctx* ctx, const NarrowArgs& args);
+// reduced openings of one wide matrix (w > 128) as column slices of at most 128 words in one launch (fri.hip:
+// k_reduce_openings_wide).  Slice i covers columns c0[i] .. c0[i] + sw[i]; ys_p[i] = sum_j alpha^j y_p[c0[i] + j] and
+// apow_p[i] = (the matrix's alpha offset at point p) * alpha^c0[i].
+constexpr uint32_t WIDE_MAX_SLICES = 8;
+struct WideArgs {
+    const uint32_t* mat;
+    uint32_t w;       // row pitch in words
+    uint32_t m_rows;
+    const uint32_t* alpha_pows;  // centred table (k_ef_powers), at least max(sw) entries
+    const uint32_t* d0;
+    const uint32_t* d1;  // nullable
+    uint32_t* ro;
+    uint32_t n_slices;
+    uint32_t sw[WIDE_MAX_SLICES], c0[WIDE_MAX_SLICES], magic[WIDE_MAX_SLICES];  // magic: filled by reduce_openings_wide
+    bb::ef ys0[WIDE_MAX_SLICES], ys1[WIDE_MAX_SLICES], apow0[WIDE_MAX_SLICES], apow1[WIDE_MAX_SLICES];
+};
+int32_t reduce_openings_wide(lurkhip_ctx* ctx, WideArgs args);
 // ro[s] += apow0 * (rr_s - ys0) * d0[s] (+ apow1 * (rr_s - ys1) * d1[s]),  rr_s = sum_c alpha_pows[c] * mat[s][c]
 int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
                         const uint32_t* alpha_pows_centred /* 8 words per power (ef_powers centred), or null */, const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0, const bb::ef& ys1, const bb::ef& apow0,

@@ -314,6 +314,80 @@ __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
     }
 }
 
+// Wide matrices (w > 128: eval_builtin_expr's 148 columns, the hash chips' 493 / 655 / 815): the row is cut into column
+// slices of at most 128 words and a workgroup walks (tile, slice) items the way the streaming kernel walks tiles -- the
+// next item's words in flight while the current one is reduced --, the words of slice sl of the 64-row tile being
+// word (e / sw, e % sw) of a strided block.  With rr_sl = sum_j alpha^j mat[s][c0 + j] a row accumulates
+//   G_p += apow_p * alpha^c0 * (rr_sl - ys_p[sl])
+// over the slices and touches d0 / d1 / ro once: ro[s] += G_0 d0[s] + G_1 d1[s].
+template <int NV, bool BIG>
+__global__ __launch_bounds__(64) void k_reduce_openings_wide(WideArgs a) {
+    extern __shared__ uint32_t tile[];
+    using idx_t = typename std::conditional<BIG, size_t, uint32_t>::type;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_tiles = (a.m_rows + 63u) / 64u;
+    const uint32_t n_items = n_tiles * a.n_slices;
+    const idx_t last_row = (idx_t)a.m_rows - 1;
+    uint32_t v[NV];
+    auto fetch = [&](uint32_t item) {
+        const uint32_t t = item / a.n_slices, sl = item - t * a.n_slices;
+        const uint32_t sw = a.sw[sl], c0 = a.c0[sl], magic = a.magic[sl];
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            // words past the slice block re-read a valid word: no branch around a load
+            uint32_t e = (uint32_t)k * 64u + lane;
+            e = e < 64u * sw ? e : 64u * sw - 1u;
+            const uint32_t r = __umulhi(e, magic), j = e - r * sw;
+            idx_t row = (idx_t)t * 64u + r;
+            row = row < last_row ? row : last_row;
+            v[k] = a.mat[row * (idx_t)a.w + (idx_t)(c0 + j)];
+        }
+    };
+    uint32_t item = blockIdx.x * a.n_slices;  // a workgroup takes whole tiles
+    if (item >= n_items) return;
+    fetch(item);
+    uint32_t* __restrict__ apw = tile + (NV * 66 + 64 + 8);
+    for (uint32_t e = lane; e < 4u * NV; e += 64u) apw[e] = a.alpha_pows[8u * (e >> 2) + (e & 3u)];
+    const uint32_t wbase = lane + (lane >> 5);
+    ef g0 = bb::ef_zero(), g1 = bb::ef_zero();
+    while (true) {
+        const uint32_t t = item / a.n_slices, sl = item - t * a.n_slices;
+#pragma unroll
+        for (int k = 0; k < NV; k++) tile[wbase + (uint32_t)k * 66u] = v[k];
+        __syncthreads();
+        uint32_t next = item + 1;
+        if (sl + 1 == a.n_slices) next = (t + gridDim.x) * a.n_slices;
+        const bool more = next < n_items;
+        fetch(more ? next : item);
+        const uint32_t sw = a.sw[sl];
+        LazyEf rr;
+        rr.zero();
+        uint32_t e = lane * sw;
+        for (uint32_t c = 0; c < sw; c++, e++) {
+            const uint4 q = *reinterpret_cast<const uint4*>(apw + 4 * c);
+            const int32_t pw[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+            rr.add_base_v(tile[e + (e >> 5)], pw);
+        }
+        const ef r = rr.value();
+        g0 = bb::ef_add(g0, bb::ef_mul(a.apow0[sl], bb::ef_sub(r, a.ys0[sl])));
+        if (a.d1) g1 = bb::ef_add(g1, bb::ef_mul(a.apow1[sl], bb::ef_sub(r, a.ys1[sl])));
+        if (sl + 1 == a.n_slices) {
+            const uint32_t s = t * 64u + lane;
+            if (s < a.m_rows) {
+                ef acc = ef_load(a.ro + 4 * (size_t)s);
+                acc = bb::ef_add(acc, bb::ef_mul(g0, ef_load(a.d0 + 4 * (size_t)s)));
+                if (a.d1) acc = bb::ef_add(acc, bb::ef_mul(g1, ef_load(a.d1 + 4 * (size_t)s)));
+                ef_store(a.ro + 4 * (size_t)s, acc);
+            }
+            g0 = bb::ef_zero();
+            g1 = bb::ef_zero();
+        }
+        __syncthreads();  // the tile is free for the next item
+        if (!more) break;
+        item = next;
+    }
+}
+
 // Narrow matrices (w <= NARROW_MAX_W: memory tables, quotient chunks, the callee chip's permutation trace) of one height in one
 // launch.  Per row their own words are a few bytes next to the 64 bytes of d0 / d1 / ro traffic and the four extension products of
 // the tail, so one launch per matrix is bound by the tail: here a lane owns a row, walks the matrices
@@ -581,6 +655,34 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
     const bool staged = lds <= 64 * 1024;
     ReduceArgs a{mat, w, m_rows, alpha_pows, d0, d1, ys0, ys1, apow0, apow1, ro, staged ? 1 : 0};
     hipLaunchKernelGGL(k_reduce_openings, dim3((m_rows + 63) / 64), dim3(64), staged ? lds : 0, ctx->stream, a);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t reduce_openings_wide(lurkhip_ctx* ctx, WideArgs a) {
+    LH_ARG(ctx, a.n_slices >= 1 && a.n_slices <= WIDE_MAX_SLICES, "reduce_openings_wide: slice count");
+    uint32_t max_sw = 0;
+    for (uint32_t i = 0; i < a.n_slices; i++) {
+        LH_ARG(ctx, a.sw[i] >= 1 && a.sw[i] <= 128 && a.c0[i] + a.sw[i] <= a.w, "reduce_openings_wide: slice %u", i);
+        a.magic[i] = (uint32_t)((((uint64_t)1 << 32) + a.sw[i] - 1) / a.sw[i]);
+        max_sw = std::max(max_sw, a.sw[i]);
+    }
+    const uint32_t n_tiles = (a.m_rows + 63) / 64;
+    const bool big = (size_t)a.m_rows * a.w >= ((size_t)1 << 30) || getenv("LURKHIP_OPENINGS_FORCE_64BIT") != nullptr;
+    auto launch = [&](auto kernel, auto kernel_big, int nv) {
+        const size_t lds = ((size_t)nv * 66 + 64 + 8 + 4 * (size_t)nv) * 4;
+        const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(16, (160 * 1024) / (lds + 512)));
+        const unsigned blocks = (unsigned)std::min<size_t>(n_tiles, (size_t)per_cu * ctx->num_cus);
+        if (big) hipLaunchKernelGGL(kernel_big, dim3(blocks), dim3(64), lds, ctx->stream, a);
+        else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, ctx->stream, a);
+    };
+#define LH_RW(NV) launch(k_reduce_openings_wide<NV, false>, k_reduce_openings_wide<NV, true>, NV)
+    if (max_sw <= 64) LH_RW(64);
+    else if (max_sw <= 80) LH_RW(80);
+    else if (max_sw <= 96) LH_RW(96);
+    else if (max_sw <= 112) LH_RW(112);
+    else LH_RW(128);
+#undef LH_RW
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

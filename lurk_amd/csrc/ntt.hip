@@ -463,7 +463,8 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     if (const char* e = getenv("LURKHIP_NTT_MAX_LOG_R")) cap_log_r = std::max(1, std::min(10, atoi(e)));
     const int n_pass = std::max(1, (log_n + cap_log_r - 1) / cap_log_r);
     int max_log_r = std::max(1, (log_n + n_pass - 1) / n_pass);  // tallest tile of the schedule
-    const size_t lds_cap = max_log_r > 7 ? (size_t)140 * 1024 : (size_t)64 * 1024;
+    size_t lds_cap = max_log_r > 7 ? (size_t)140 * 1024 : (size_t)64 * 1024;
+    if (const char* e = getenv("LURKHIP_NTT_LDS_CAP_KB")) lds_cap = (size_t)std::max(8, atoi(e)) * 1024;  // A/B hook: tile bytes per workgroup
     // column chunk: the widest even divisor of w that fits (no ragged chunk), else the widest even width that fits (the ragged
     // remainder gets its own launch); narrow matrices are one chunk
     auto fits = [&](int cols) { return lds_bytes(max_log_r, cols, 0) <= lds_cap && threads_of(max_log_r, cols) <= 1024; };

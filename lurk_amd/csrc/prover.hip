@@ -416,6 +416,33 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 if (d1) g.d1 = d1;  // one second point per height (the first point's successor on that domain)
                 g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1};
                 if (g.n_mats == NARROW_MAX_MATS) PTRY(flush_narrow(g));
+            } else if (w > 128 && w <= 128 * WIDE_MAX_SLICES && alpha_pows_c) {
+                // column slices of equal width (the last one takes the remainder), each with its own alpha offset and
+                // reduced opened values
+                WideArgs wa{};
+                wa.mat = r.c->lde[m];
+                wa.w = w;
+                wa.m_rows = 1u << log_h;
+                wa.alpha_pows = alpha_pows_c;
+                wa.d0 = d0;
+                wa.d1 = d1;
+                wa.ro = ro[log_h];
+                wa.n_slices = (w + 127) / 128;
+                const uint32_t sw = (w + wa.n_slices - 1) / wa.n_slices;
+                for (uint32_t sl = 0; sl < wa.n_slices; sl++) {
+                    const uint32_t c0 = sl * sw, n = std::min(sw, w - c0);
+                    wa.c0[sl] = c0;
+                    wa.sw[sl] = n;
+                    const ef shift = ef_pow_host(alpha_fri, c0);
+                    wa.apow0[sl] = bb::ef_mul(apow0, shift);
+                    wa.apow1[sl] = bb::ef_mul(apow1, shift);
+                    for (size_t p = 0; p < mp.size(); p++) {
+                        ef y = bb::ef_zero();
+                        for (uint32_t j = 0; j < n; j++) y = bb::ef_add(y, bb::ef_mul(alpha_pows_host[j], opened[ri][m][p][c0 + j]));
+                        (p == 0 ? wa.ys0 : wa.ys1)[sl] = y;
+                    }
+                }
+                PTRY(reduce_openings_wide(ctx, wa));
             } else {
                 PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
             }
