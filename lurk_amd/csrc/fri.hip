@@ -174,6 +174,78 @@ __global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__
     }
 }
 
+// Matrices of 24 columns and more: a wave takes 64 consecutive columns of one row at a time, so the row's weights are
+// wave-uniform -- scalar loads, SGPR operands of the multiply-adds -- and a lane's only vector load is its matrix word
+// (k_column_dot reads two 16-byte weights per word through the vector path: 36 bytes requested per 4 bytes of matrix).
+// Workgroup = (block of `rows_per_block` rows, chunk of 64 columns); its four waves split the rows.
+__global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows, uint32_t rows_per_block,
+                                                          uint32_t n_chunks, const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
+                                                          uint32_t* __restrict__ partial) {
+    __shared__ uint32_t sh[2][4][64][4];
+    const uint32_t wave = (uint32_t)__builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)), lane = threadIdx.x & 63u;
+    const uint32_t per_wave = rows_per_block / 4u;
+    // (row block, column chunk) of this workgroup: workgroups are dealt round-robin to the 8 XCDs, each with its own L2, and the
+    // chunks of a row block share the cache lines their rows straddle -- every XCD takes a contiguous run of (block, chunk)
+    // pairs, chunk fastest, so those lines are fetched from HBM once
+    uint32_t g = blockIdx.x;
+    if ((gridDim.x & 7u) == 0) g = (blockIdx.x & 7u) * (gridDim.x >> 3) + (blockIdx.x >> 3);
+    const uint32_t blk = g / n_chunks, chunk = g - blk * n_chunks;
+    const size_t blk_row0 = (size_t)blk * rows_per_block;
+    size_t r = blk_row0 + (size_t)wave * per_wave;
+    const size_t wave_end = r + per_wave < n_rows ? r + per_wave : n_rows;
+    const uint32_t c = chunk * 64u + lane, cc = c < w ? c : w - 1u;
+    const uint32_t* __restrict__ col = mat + cc;
+    LazyEf l0, l1;
+    l0.zero();
+    l1.zero();
+    auto weights = [&](const uint32_t* __restrict__ u, size_t row, int32_t (&o)[8]) {
+        const uint4 q = *reinterpret_cast<const uint4*>(u + 4 * row);  // uniform address: a scalar load
+        o[0] = (int32_t)q.x; o[1] = (int32_t)q.y; o[2] = (int32_t)q.z; o[3] = (int32_t)q.w;
+        o[4] = o[5] = o[6] = o[7] = 0;
+    };
+    constexpr int UR = 8;  // rows per trip: their words go out as one batch of loads (16 rows and a software-pipelined variant measured the same)
+    for (; r + UR <= wave_end; r += UR) {
+        uint32_t m[UR];
+#pragma unroll
+        for (int k = 0; k < UR; k++) m[k] = col[(r + k) * w];
+#pragma unroll
+        for (int k = 0; k < UR; k++) {
+            int32_t w0[8];
+            weights(u0, r + k, w0);
+            l0.add_base(m[k], w0);
+            if (u1) {
+                int32_t w1[8];
+                weights(u1, r + k, w1);
+                l1.add_base(m[k], w1);
+            }
+        }
+    }
+    for (; r < wave_end; r++) {
+        const uint32_t m = col[r * w];
+        int32_t w0[8];
+        weights(u0, r, w0);
+        l0.add_base(m, w0);
+        if (u1) {
+            int32_t w1[8];
+            weights(u1, r, w1);
+            l1.add_base(m, w1);
+        }
+    }
+    const ef a0 = l0.value(), a1 = l1.value();
+    for (int k = 0; k < 4; k++) {
+        sh[0][wave][lane][k] = a0.c[k];
+        sh[1][wave][lane][k] = a1.c[k];
+    }
+    __syncthreads();
+    // threads 0..63 finish point 0, 64..127 point 1
+    const uint32_t p = threadIdx.x >> 6;
+    if (p < (u1 ? 2u : 1u) && c < w) {
+        ef t = bb::ef_zero();
+        for (int q = 0; q < 4; q++) t = bb::ef_add(t, ef{{sh[p][q][lane][0], sh[p][q][lane][1], sh[p][q][lane][2], sh[p][q][lane][3]}});
+        ef_store(partial + (((size_t)blk * 2 + p) * w + c) * 4, t);
+    }
+}
+
 // out[p][c] = sum over blocks of partial[blk][p][c]; one workgroup per (p, c),
 // every matrix of a proof in one launch: block -> (matrix, point, column) through the prefix sums in the arguments
 __global__ __launch_bounds__(256) void k_dot_finish_all(DotFinishArgs a) {
@@ -589,12 +661,31 @@ int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, ui
     return LURKHIP_OK;
 }
 
-size_t column_dot_partial_words(uint32_t w, size_t n_rows) { return ((n_rows + DOT_ROWS - 1) / DOT_ROWS) * 2 * w * 4; }
+// rows per partial-sum block: 1024, fewer for short matrices on the wave-per-row kernel so that the launch still fills the CUs
+constexpr uint32_t DOT_WAVE_MIN_W = 24;
+static uint32_t dot_block_rows(uint32_t w, size_t n_rows) {
+    uint32_t rb = DOT_ROWS;
+    if (w < DOT_WAVE_MIN_W || getenv("LURKHIP_DOT_OLD") != nullptr) return rb;
+    const size_t chunks = (w + 63) / 64;
+    while (rb > 64 && ((n_rows + rb - 1) / rb) * chunks < 512) rb /= 2;
+    return rb;
+}
+static uint32_t dot_blocks(uint32_t w, size_t n_rows) {
+    const uint32_t rb = dot_block_rows(w, n_rows);
+    return (uint32_t)((n_rows + rb - 1) / rb);
+}
+
+size_t column_dot_partial_words(uint32_t w, size_t n_rows) { return (size_t)dot_blocks(w, n_rows) * 2 * w * 4; }
 
 int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
                            uint32_t* partial_dev) {
-    const uint32_t n_blocks = (uint32_t)((n_rows + DOT_ROWS - 1) / DOT_ROWS);
-    hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, partial_dev);
+    const uint32_t n_blocks = dot_blocks(w, n_rows);
+    if (w >= DOT_WAVE_MIN_W && getenv("LURKHIP_DOT_OLD") == nullptr) {  // LURKHIP_DOT_OLD: A/B hook, every width on k_column_dot
+        const uint32_t n_chunks = (w + 63) / 64;
+        hipLaunchKernelGGL(k_column_dot_wave, dim3(n_blocks * n_chunks), dim3(256), 0, ctx->stream, mat, w, n_rows, dot_block_rows(w, n_rows), n_chunks,
+                           u0, u1, partial_dev);
+    } else
+        hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, partial_dev);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
@@ -610,7 +701,7 @@ int32_t column_dot_finish(lurkhip_ctx* ctx, const std::vector<DotJob>& jobs, uin
             a.col_start[m] = cols;
             a.partial[m] = j.partial;
             a.w[m] = j.w;
-            a.n_blocks[m] = (uint32_t)((j.n_rows + DOT_ROWS - 1) / DOT_ROWS);
+            a.n_blocks[m] = dot_blocks(j.w, j.n_rows);
             a.out_off[m] = j.out_off;
             cols += j.w * (j.two_points ? 2u : 1u);
         }
