@@ -116,6 +116,8 @@ def main():
     ap.add_argument("--no-spans", action="store_true", help="diagnostic: no per-stage HIP events in the timed region (stages_ms and roofline read 0)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra two-shards-in-flight measurement")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
+    ap.add_argument("--no-host-pipeline", action="store_true", help="skip the extra streamed multi-shard measurement (host flatten + upload under the proofs)")
+    ap.add_argument("--pipeline-shards", type=int, default=4)
     args = ap.parse_args()
 
     import torch
@@ -350,6 +352,67 @@ def main():
         except Exception as e:
             two_in_flight = {"error": repr(e)}
 
+    # Extra (N = 1 only, never `value`): the host side of the path.  ONE execution of pipeline_shards x 2^log_rows eval rows,
+    # sharded; (a) every shard's inputs staged beforehand (the resident-input reference), (b) streamed: a staging thread
+    # flattens shard k + 1 on host threads into page-locked memory and uploads it on a second context while this context
+    # commits shard k (prover.prove_streamed).  Same proofs; execute is reported separately and is in neither timing.
+    host_pipeline = None
+    if world == 1 and not args.no_host_pipeline and args.workload != "eval-only":
+        try:
+            S = args.pipeline_shards
+            src2, _, entry2, args2, _, _ = build_workload(args.workload, S, log_rows)
+            t1 = time.perf_counter()
+            top2 = lair.Toplevel(src2, lurk_chips=True)
+            q2 = lair.QueryRecord(top2)
+            top2.execute(top2.func_index(entry2), args2, q2)
+            t_exec2 = time.perf_counter() - t1
+            pv2 = q2.expect_public_values()
+            mach2 = prover.Machine(ctx, top2, entry2, len(pv2))
+            mach2.setup()
+            cfg2 = lair.ShardingConfig(n)
+            shards2 = lair.Shard.new(q2).shard(cfg2)
+            t1 = time.perf_counter()
+            prepared2 = [mach2.prepare_shard(sh) for sh in shards2]
+            t_stage = time.perf_counter() - t1
+            if not args.no_compile:
+                mach2.compile_airs(prepared2[0])  # same chips as above: served from the code cache
+            staged_bytes = sum(p.input_bytes for item in prepared2 for *_, p in item if p is not None)
+            ctx_in = lurk_amd.Context(local_rank)
+
+            def timed(**kw):
+                torch.cuda.synchronize()
+                t = time.perf_counter()
+                pr = prover.prove_streamed(mach2, q2, cfg2, num_queries=args.queries, pow_bits=args.pow_bits, parse=False, **kw)
+                ctx.sync()
+                torch.cuda.synchronize()
+                return time.perf_counter() - t, pr
+
+            timed(prepared=prepared2)  # warm-up (pool, tables)
+            t_res, ref = timed(prepared=prepared2)
+            for item in prepared2:
+                for *_, p in item:
+                    if p is not None:
+                        p.close()
+            del prepared2
+            st = {}
+            timed(input_ctx=ctx_in)  # warm-up (page-locked staging, the second context's pool)
+            t_str, got = timed(input_ctx=ctx_in, stats=st)
+            same = len(ref) == len(got) and all(len(a) == len(b) and bool((a == b).all()) for a, b in zip(ref, got))
+            host_pipeline = {
+                "shards": len(shards2), "eval_rows": len(shards2) * n, "host_execute_s": t_exec2,
+                "resident_ms_per_shard": t_res / len(shards2) * 1e3, "streamed_ms_per_shard": t_str / len(shards2) * 1e3,
+                "streamed_over_resident_rate": t_res / t_str,
+                "staging_s_per_shard": st.get("staging_s", 0.0) / len(shards2), "staging_threads": min(32, os.cpu_count() or 1),
+                "first_staging_s_per_shard": t_stage / len(shards2), "staged_bytes_per_shard": staged_bytes // len(shards2),
+                "proofs_match_resident": same,
+                "note": "one sharded execution, all shards' traces and main commitments resident for phase 2; flatten + upload of shard k+1 run under the commit of shard k; not the headline value",
+            }
+            mach2.close()
+            ctx_in.close()
+            del q2, top2
+        except Exception as e:
+            host_pipeline = {"error": repr(e)}
+
     if rank == 0:
         out = {
             "metric": "Lurk eval-steps proved/sec (fib trace)",
@@ -384,6 +447,7 @@ def main():
                 "compiled_air_chips": compiled,
                 "air_compile_s": t_jit,
                 "two_shards_in_flight": two_in_flight,
+                "host_pipeline": host_pipeline,
             },
             "roofline": {
                 "bound": "hbm",

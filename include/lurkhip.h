@@ -62,6 +62,11 @@ int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhi
 int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx);
 /* Blocks until everything enqueued on the ctx's stream has finished. */
 int32_t lurkhip_ctx_sync(lurkhip_ctx* ctx);
+/* Ordering between two contexts' streams without a host wait: record (*event == NULL: created) behind everything queued on
+ * ctx's stream; wait makes everything queued later on ctx's stream run after the event. */
+int32_t lurkhip_event_record(lurkhip_ctx* ctx, void** event);
+int32_t lurkhip_event_wait(lurkhip_ctx* ctx, void* event);
+int32_t lurkhip_event_destroy(void* event);
 /* Text of the last error on this ctx (or of the last ctx-less failure on this thread if ctx == NULL). */
 const char* lurkhip_last_error(lurkhip_ctx* ctx);
 
@@ -349,6 +354,14 @@ int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top,
 typedef struct lurkhip_func_trace lurkhip_func_trace;
 int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
                                    uint32_t shard_index, uint32_t max_shard_size, lurkhip_func_trace** out);
+/* lurkhip_func_trace_prepare for several functions of one shard at once: host threads (n_threads, 0 = one per hardware
+ * thread, at most 32) write the rows of all of them into one page-locked staging buffer and each function's block is queued for
+ * upload on the context's stream as soon as it is complete; the call does not wait for the copies (they are ordered before any
+ * later work on that stream).  out[i] = NULL for a function without rows in the shard.  This is the per-row parallelism of
+ * FuncChip::generate_trace (src/lair/trace.rs:86-132) applied to the part of it that stays on the host. */
+int32_t lurkhip_func_trace_prepare_many(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, uint32_t n_funcs,
+                                        const int32_t* func_idx, uint32_t shard_index, uint32_t max_shard_size, uint32_t n_threads,
+                                        lurkhip_func_trace** out);
 /* the same for a MemChip table and for the BytesChip (run with lurkhip_func_trace_run) */
 int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t mem_len, lurkhip_func_trace** out);
 int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index, lurkhip_func_trace** out);

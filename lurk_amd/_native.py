@@ -61,6 +61,9 @@ SIGNATURES = {
     "lurkhip_ctx_create_on_stream": (_i32, [_i32, _p, C.POINTER(_p)]),
     "lurkhip_ctx_destroy": (_i32, [_p]),
     "lurkhip_ctx_sync": (_i32, [_p]),
+    "lurkhip_event_record": (_i32, [_p, C.POINTER(_p)]),
+    "lurkhip_event_wait": (_i32, [_p, _p]),
+    "lurkhip_event_destroy": (_i32, [_p]),
     "lurkhip_last_error": (C.c_char_p, [_p]),
     "lurkhip_malloc": (_i32, [_p, _sz, C.POINTER(_p)]),
     "lurkhip_free": (_i32, [_p, _p]),
@@ -128,6 +131,7 @@ SIGNATURES = {
     "lurkhip_generate_trace_func": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, _u32p, _i32]),
     "lurkhip_generate_trace_func_dev": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, _u32p, _i32]),
     "lurkhip_func_trace_prepare": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_func_trace_prepare_many": (_i32, [_p, _p, _p, C.c_uint32, C.POINTER(_i32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_mem_trace_prepare": (_i32, [_p, _p, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_bytes_trace_prepare": (_i32, [_p, _p, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_func_trace_shape_of": (_i32, [_p, C.POINTER(C.c_uint64)]),

@@ -60,6 +60,20 @@ class Context:
     def sync(self):
         self.check(N.lib.lurkhip_ctx_sync(self.handle))
 
+    def record_event(self, event=None):
+        """An event behind everything queued on this context's stream (created when `event` is None); returns the handle."""
+        e = C.c_void_p(event)
+        self.check(N.lib.lurkhip_event_record(self.handle, C.byref(e)))
+        return e.value
+
+    def wait_event(self, event):
+        """Everything queued on this context's stream from now on runs after `event` (no host wait)."""
+        self.check(N.lib.lurkhip_event_wait(self.handle, C.c_void_p(event)))
+
+    @staticmethod
+    def destroy_event(event):
+        N.lib.lurkhip_event_destroy(C.c_void_p(event))
+
     def timer_start(self):
         self.check(N.lib.lurkhip_timer_start(self.handle))
 

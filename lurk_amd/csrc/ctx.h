@@ -6,6 +6,7 @@
 #include <cstdio>
 #include <functional>
 #include <map>
+#include <mutex>
 #include <string>
 #include <vector>
 
@@ -45,6 +46,13 @@ struct lurkhip_ctx {
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)
     std::multimap<size_t, void*> pool_free;
     std::map<void*, size_t> pool_live;
+    std::mutex pool_mu;  // a streaming prover releases one shard's inputs on its proving thread while the next shard's are allocated on its staging thread
+    // page-locked staging of the row-stream uploads (lair_api.cpp: lurkhip_func_trace_prepare_many): grow-only, a buffer is reused by a
+    // later call once its `prep_done` (recorded behind the last upload that read it) has passed
+    void* prep_stage[2] = {nullptr, nullptr};  // two buffers in turn: one is being filled while the other is still being read by its copies
+    size_t prep_stage_bytes[2] = {0, 0};
+    hipEvent_t prep_done[2] = {nullptr, nullptr};
+    int prep_turn = 0;
     // optional per-span HIP-event timing (lurkhip_profile_*)
     bool profiling = false;
     struct Span {

@@ -73,6 +73,7 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out) {
 
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
     // most recently released block of this size first (LIFO): a proof's sequence of allocations then lands in the same buffers
     // as the previous proof's, which is what the pointer-keyed table caches (Merkle leaf columns) rely on
     auto range = ctx->pool_free.equal_range(bytes);
@@ -108,6 +109,7 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
 // same stream, so no synchronisation is needed here.
 void pool_release(lurkhip_ctx* ctx, void* ptr) {
     if (!ptr) return;
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
     auto it = ctx->pool_live.find(ptr);
     if (it == ctx->pool_live.end()) {
         (void)hipFree(ptr);
@@ -242,6 +244,10 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     for (int i = 0; i < 4; i++)
         if (ctx->arena[i]) (void)hipFree(ctx->arena[i]);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    for (int i = 0; i < 2; i++) {
+        if (ctx->prep_stage[i]) (void)hipHostFree(ctx->prep_stage[i]);
+        if (ctx->prep_done[i]) (void)hipEventDestroy(ctx->prep_done[i]);
+    }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -252,6 +258,31 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
 int32_t lurkhip_ctx_sync(lurkhip_ctx* ctx) {
     LH_CHECK_CTX(ctx);
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    return LURKHIP_OK;
+}
+
+// Cross-context ordering without a host wait: an event recorded behind the work queued on one context's stream, waited for by
+// another context's stream (a staging context's uploads before the proving context's trace kernels).
+int32_t lurkhip_event_record(lurkhip_ctx* ctx, void** event) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, event != nullptr, "null argument");
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    hipEvent_t e = (hipEvent_t)*event;
+    if (!e) LH_HIP(ctx, hipEventCreateWithFlags(&e, hipEventDisableTiming));
+    LH_HIP(ctx, hipEventRecord(e, ctx->stream));
+    *event = e;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_event_wait(lurkhip_ctx* ctx, void* event) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, event != nullptr, "null argument");
+    LH_HIP(ctx, hipStreamWaitEvent(ctx->stream, (hipEvent_t)event, 0));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_event_destroy(void* event) {
+    if (event) (void)hipEventDestroy((hipEvent_t)event);
     return LURKHIP_OK;
 }
 

@@ -5,7 +5,12 @@
 //   Toplevel::{new, execute_by_name}        /root/reference/src/lair/toplevel.rs:28-50, execute.rs:375-417
 //   FuncChip::{from_name, width, generate_trace}   /root/reference/src/lair/func_chip.rs:34-80, trace.rs:72-135
 //   MemChip / BytesChip / Entrypoint generate_trace  /root/reference/src/lair/lair_chip.rs:96-120
+#include <algorithm>
+#include <atomic>
 #include <cstring>
+#include <mutex>
+#include <string>
+#include <thread>
 
 #include "../ctx.h"
 #include "../stark.h"
@@ -233,6 +238,7 @@ struct lurkhip_func_trace {
     int kind = 0;        // 0: FuncChip, 1: MemChip, 2: BytesChip
     uint32_t mem_len = 0;
     bool is_real = false;
+    void* host_keep = nullptr;  // page-locked source of an upload nobody waited for: lives as long as the handle
 };
 
 extern "C" {
@@ -322,6 +328,230 @@ int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, cons
     });
 }
 
+// The same flattening for several functions of one shard at once, on host threads: every function's rows are cut into
+// ranges, a first sweep sizes each range's part of the row stream, a second one writes the rows straight into one page-locked
+// staging buffer (no intermediate vectors), and a function's block is queued for upload on the context's stream as soon as its
+// last range is done -- the copy of one function runs under the flattening of the next.  Nothing waits for the copies here:
+// they are ordered before any later work on the stream, and the staging buffer is not rewritten before `prep_done` has passed.
+// (The reference parallelises trace generation per row, trace.rs:86-132; the per-row work left on the host here is this copy.)
+// out[i] = nullptr for a function without rows in the shard.  n_threads = 0: one per hardware thread, at most 32.
+int32_t lurkhip_func_trace_prepare_many(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, uint32_t n_funcs,
+                                        const int32_t* func_idx, uint32_t shard_index, uint32_t max_shard_size, uint32_t n_threads,
+                                        lurkhip_func_trace** out) {
+    LH_CHECK_CTX(ctx);
+    if (!top || !r || !out || !func_idx || r->top != top) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "bad toplevel/record");
+    for (uint32_t k = 0; k < n_funcs; k++) {
+        out[k] = nullptr;
+        if (func_idx[k] < 0 || (size_t)func_idx[k] >= top->t.funcs.size()) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "bad func index");
+    }
+    return guarded(ctx, [&]() -> int32_t {
+        constexpr uint32_t RANGE = 1u << 14;  // rows per task
+        struct Job {
+            const lair::Func* f = nullptr;
+            const lair::QueryMap* qm = nullptr;
+            const std::vector<uint32_t>* prog = nullptr;
+            size_t start = 0;
+            uint32_t n = 0, first_range = 0, n_ranges = 0;
+            size_t stage_off = 0;
+            lurkhip_func_trace* p = nullptr;
+            std::atomic<uint32_t> left{0};
+        };
+        std::vector<Job> jobs(n_funcs);
+        uint32_t total_ranges = 0;
+        for (uint32_t k = 0; k < n_funcs; k++) {
+            Job& j = jobs[k];
+            j.f = &top->t.funcs[func_idx[k]];
+            j.qm = &r->q.func_queries[func_idx[k]];
+            auto [s0, e0] = lair::shard_range(j.qm->size(), shard_index, max_shard_size);
+            j.start = s0;
+            j.n = (uint32_t)(e0 - s0);
+            j.prog = &program_of(top, (uint32_t)func_idx[k]);
+            j.first_range = total_ranges;
+            j.n_ranges = (j.n + RANGE - 1) / RANGE;
+            total_ranges += j.n_ranges;
+        }
+        struct Range {
+            uint32_t job, lo, hi;
+            size_t words = 0;  // row-stream words of the range, then its first word's offset
+        };
+        std::vector<Range> ranges(total_ranges);
+        for (uint32_t k = 0; k < n_funcs; k++)
+            for (uint32_t c = 0; c < jobs[k].n_ranges; c++)
+                ranges[jobs[k].first_range + c] = Range{k, c * RANGE, std::min(jobs[k].n, (c + 1) * RANGE), 0};
+        uint32_t nt = n_threads ? n_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        nt = std::max(1u, std::min(nt, std::max(1u, total_ranges)));
+        std::string worker_err;
+        std::mutex err_mu;
+        auto run_parallel = [&](auto&& body) {
+            std::atomic<uint32_t> next{0};
+            auto work = [&]() {
+                try {
+                    for (uint32_t i; (i = next.fetch_add(1)) < total_ranges;) body(i);
+                } catch (const std::exception& e) {
+                    std::lock_guard<std::mutex> g(err_mu);
+                    if (worker_err.empty()) worker_err = e.what();
+                    next.store(total_ranges);
+                }
+            };
+            std::vector<std::thread> ths;
+            for (uint32_t t = 1; t < nt; t++) ths.emplace_back(work);
+            work();
+            for (auto& t : ths) t.join();
+        };
+        // ---- sweep 1: words of the row stream per range
+        run_parallel([&](uint32_t i) {
+            Range& g = ranges[i];
+            const Job& j = jobs[g.job];
+            size_t wsum = 0;
+            for (uint32_t row = g.lo; row < g.hi; row++) {
+                const lair::QueryResult& res = j.qm->vals[j.start + row];
+                if (!res.has_output) throw lair::ExecError("Result not computed");
+                wsum += res.n_hints + 2 * ((size_t)res.n_requires + res.n_depth_requires);
+            }
+            g.words = wsum;
+        });
+        if (!worker_err.empty()) throw lair::ExecError(worker_err);
+        // ---- layouts: program | args | outs | prov | depths | meta | stream, one staging block per function
+        auto al = [](size_t x) { return (x + 63) & ~(size_t)63; };
+        size_t stage_total = 0;
+        for (uint32_t k = 0; k < n_funcs; k++) {
+            Job& j = jobs[k];
+            if (j.n == 0) continue;
+            size_t words = 0;
+            for (uint32_t c = 0; c < j.n_ranges; c++) {
+                Range& g = ranges[j.first_range + c];
+                const size_t w = g.words;
+                g.words = words;  // now: offset of the range's first word
+                words += w;
+            }
+            if (words > 0xffffff00ull) throw lair::ExecError("row stream exceeds 2^32 words; use a smaller shard");
+            auto* p = new lurkhip_func_trace();
+            j.p = p;
+            const lair::Func& f = *j.f;
+            p->o_prog = 0;
+            p->o_args = al(p->o_prog + j.prog->size() * 4);
+            p->o_outs = al(p->o_args + (size_t)j.n * f.input_size * 4);
+            p->o_prov = al(p->o_outs + (size_t)j.n * f.output_size * 4);
+            p->o_dep = al(p->o_prov + (size_t)j.n * 8);
+            p->o_meta = al(p->o_dep + (size_t)j.n * 4);
+            p->o_str = al(p->o_meta + (size_t)j.n * sizeof(lair::RowMeta));
+            p->total = al(p->o_str + words * 4 + 4);
+            p->n = j.n;
+            p->height = next_pow2(j.n);
+            p->width = (*j.prog)[lair::TH_WIDTH];
+            p->start = (uint32_t)j.start;
+            p->partial = f.partial;
+            p->stream_words = words;
+            p->header.assign(j.prog->begin(), j.prog->begin() + lair::TH_WORDS);
+            j.stage_off = stage_total;
+            stage_total += p->total;
+            j.left.store(j.n_ranges);
+        }
+        auto cleanup = [&]() {
+            for (Job& j : jobs)
+                if (j.p) {
+                    if (j.p->dev) lurkhip::pool_release(ctx, j.p->dev);
+                    delete j.p;
+                    j.p = nullptr;
+                }
+        };
+        // ---- the staging buffer of this call (two take turns): wait until the uploads that last read it are done, grow if needed
+        const int turn = ctx->prep_turn;
+        ctx->prep_turn ^= 1;
+        hipError_t e = hipSetDevice(ctx->device);
+        if (e == hipSuccess && ctx->prep_done[turn]) e = hipEventSynchronize(ctx->prep_done[turn]);
+        if (e == hipSuccess && ctx->prep_stage_bytes[turn] < stage_total) {
+            if (ctx->prep_stage[turn]) (void)hipHostFree(ctx->prep_stage[turn]);
+            ctx->prep_stage[turn] = nullptr;
+            ctx->prep_stage_bytes[turn] = 0;
+            e = hipHostMalloc(&ctx->prep_stage[turn], stage_total + stage_total / 8 + 4096, hipHostMallocDefault);
+            if (e == hipSuccess) ctx->prep_stage_bytes[turn] = stage_total + stage_total / 8 + 4096;
+        }
+        if (e == hipSuccess && !ctx->prep_done[turn]) e = hipEventCreateWithFlags(&ctx->prep_done[turn], hipEventDisableTiming);
+        if (e != hipSuccess) {
+            cleanup();
+            return lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "row-stream staging failed: %s", hipGetErrorString(e));
+        }
+        uint8_t* stage = (uint8_t*)ctx->prep_stage[turn];
+        // ---- sweep 2: the rows, written in place; the main thread uploads finished functions in order while the others run
+        std::atomic<uint32_t> next{0};
+        auto fill = [&](uint32_t i) {
+            const Range& g = ranges[i];
+            Job& j = jobs[g.job];
+            const lair::Func& f = *j.f;
+            const lair::QueryMap& qm = *j.qm;
+            uint8_t* base = stage + j.stage_off;
+            const lurkhip_func_trace* p = j.p;
+            uint32_t* args = (uint32_t*)(base + p->o_args);
+            uint32_t* outs = (uint32_t*)(base + p->o_outs);
+            uint32_t* prov = (uint32_t*)(base + p->o_prov);
+            uint32_t* deps = (uint32_t*)(base + p->o_dep);
+            lair::RowMeta* meta = (lair::RowMeta*)(base + p->o_meta);
+            uint32_t* str = (uint32_t*)(base + p->o_str);
+            if (g.lo == 0) {
+                memcpy(base + p->o_prog, j.prog->data(), j.prog->size() * 4);
+                str[p->stream_words] = 0;  // the padding word behind the stream
+            }
+            size_t at = g.words;
+            for (uint32_t row = g.lo; row < g.hi; row++) {
+                const uint32_t* key = qm.key(j.start + row);
+                const lair::QueryResult& res = qm.vals[j.start + row];
+                memcpy(&args[(size_t)row * f.input_size], key, f.input_size * 4);
+                memcpy(&outs[(size_t)row * f.output_size], qm.output(res), f.output_size * 4);
+                prov[2 * (size_t)row] = res.provide.nonce;
+                prov[2 * (size_t)row + 1] = res.provide.count;
+                deps[row] = res.depth;
+                meta[row].offset = (uint32_t)at;
+                meta[row].n_hints = res.n_hints;
+                meta[row].n_requires = res.n_requires;
+                meta[row].n_depth_requires = res.n_depth_requires;
+                memcpy(&str[at], qm.hints(res), (size_t)res.n_hints * 4);
+                at += res.n_hints;
+                const lair::Record* recs = qm.requires_of(res);  // requires, then depth requires
+                const uint32_t nr = res.n_requires + res.n_depth_requires;
+                for (uint32_t q = 0; q < nr; q++) {
+                    str[at++] = recs[q].nonce;
+                    str[at++] = recs[q].count;
+                }
+            }
+            j.left.fetch_sub(1, std::memory_order_release);
+        };
+        auto work = [&]() {
+            for (uint32_t i; (i = next.fetch_add(1)) < total_ranges;) fill(i);
+        };
+        std::vector<std::thread> ths;
+        for (uint32_t t = 1; t < nt; t++) ths.emplace_back(work);
+        int32_t status = LURKHIP_OK;
+        for (uint32_t k = 0; k < n_funcs && status == LURKHIP_OK; k++) {
+            Job& j = jobs[k];
+            if (!j.p) continue;
+            // help with the ranges until this function's block is complete
+            while (j.left.load(std::memory_order_acquire) != 0) {
+                const uint32_t i = next.fetch_add(1);
+                if (i < total_ranges) fill(i);
+                else std::this_thread::yield();
+            }
+            status = lurkhip::pool_alloc(ctx, j.p->total, &j.p->dev);
+            if (status != LURKHIP_OK) break;
+            e = hipMemcpyAsync(j.p->dev, stage + j.stage_off, j.p->total, hipMemcpyHostToDevice, ctx->stream);
+            if (e != hipSuccess) status = lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "row-stream upload failed: %s", hipGetErrorString(e));
+        }
+        next.store(total_ranges);
+        for (auto& t : ths) t.join();
+        if (status == LURKHIP_OK) {
+            e = hipEventRecord(ctx->prep_done[turn], ctx->stream);
+            if (e != hipSuccess) status = lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "row-stream upload failed: %s", hipGetErrorString(e));
+        }
+        if (status != LURKHIP_OK) {
+            (void)hipStreamSynchronize(ctx->stream);
+            cleanup();
+            return status;
+        }
+        for (uint32_t k = 0; k < n_funcs; k++) out[k] = jobs[k].p;
+        return LURKHIP_OK;
+    });
+}
+
 // shape[0..5) = n_real, height, width, bytes of device-resident inputs, stream words
 int32_t lurkhip_func_trace_shape_of(const lurkhip_func_trace* p, uint64_t* shape) {
     if (!p || !shape) return LURKHIP_ERR_INVALID_ARG;
@@ -342,7 +572,11 @@ int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uin
     return guarded(ctx, [&]() -> int32_t {
         const auto& mm = r->q.mem_queries[lair::mem_index_from_len(mem_len)];
         const uint32_t n = (uint32_t)mm.size();
-        std::vector<uint32_t> host((size_t)n * (mem_len + 2) + 4, 0);
+        const size_t host_words = (size_t)n * (mem_len + 2) + 4;
+        uint32_t* host = nullptr;
+        if (hipHostMalloc((void**)&host, host_words * 4, hipHostMallocDefault) != hipSuccess)
+            return lurkhip::set_error(ctx, LURKHIP_ERR_OOM, "page-locked staging of a memory table failed");
+        memset(host, 0, host_words * 4);
         for (uint32_t i = 0; i < n; i++) {
             memcpy(&host[(size_t)i * mem_len], mm.key(i), mem_len * 4);
             host[(size_t)n * mem_len + 2 * i] = mm.vals[i].provide.nonce;
@@ -354,13 +588,15 @@ int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uin
         p->n = n;
         p->height = std::max(4u, next_pow2(n));
         p->width = 4 + mem_len;
-        p->total = host.size() * 4;
+        p->total = host_words * 4;
+        p->host_keep = host;
         int32_t s = lurkhip::pool_alloc(ctx, p->total, &p->dev);
         hipError_t e = hipSuccess;
-        if (s == LURKHIP_OK) e = hipMemcpyAsync(p->dev, host.data(), p->total, hipMemcpyHostToDevice, ctx->stream);
-        if (s == LURKHIP_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (s == LURKHIP_OK) e = hipMemcpyAsync(p->dev, host, p->total, hipMemcpyHostToDevice, ctx->stream);  // ordered before later work on the stream
         if (s != LURKHIP_OK || e != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->stream);
             if (p->dev) lurkhip::pool_release(ctx, p->dev);
+            (void)hipHostFree(host);
             delete p;
             return s != LURKHIP_OK ? s : lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "mem table upload failed: %s", hipGetErrorString(e));
         }
@@ -375,7 +611,11 @@ int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, u
     *out = nullptr;
     return guarded(ctx, [&]() -> int32_t {
         const bool is_real = shard_index == 0 && !r->q.bytes.records.empty();
-        std::vector<uint32_t> host((size_t)65536 * 12, 0);
+        const size_t host_words = (size_t)65536 * 12;
+        uint32_t* host = nullptr;
+        if (hipHostMalloc((void**)&host, host_words * 4, hipHostMallocDefault) != hipSuccess)
+            return lurkhip::set_error(ctx, LURKHIP_ERR_OOM, "page-locked staging of the byte records failed");
+        memset(host, 0, host_words * 4);
         if (is_real)
             for (const auto& kv : r->q.bytes.records) {
                 const lair::Record recs[6] = {kv.second.range_u8, kv.second.range_u16, kv.second.less_than,
@@ -391,13 +631,15 @@ int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, u
         p->n = is_real ? 65536 : 0;
         p->height = 65536;
         p->width = 13;
-        p->total = host.size() * 4;
+        p->total = host_words * 4;
+        p->host_keep = host;
         int32_t s = lurkhip::pool_alloc(ctx, p->total, &p->dev);
         hipError_t e = hipSuccess;
-        if (s == LURKHIP_OK) e = hipMemcpyAsync(p->dev, host.data(), p->total, hipMemcpyHostToDevice, ctx->stream);
-        if (s == LURKHIP_OK && e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (s == LURKHIP_OK) e = hipMemcpyAsync(p->dev, host, p->total, hipMemcpyHostToDevice, ctx->stream);  // ordered before later work on the stream
         if (s != LURKHIP_OK || e != hipSuccess) {
+            (void)hipStreamSynchronize(ctx->stream);
             if (p->dev) lurkhip::pool_release(ctx, p->dev);
+            (void)hipHostFree(host);
             delete p;
             return s != LURKHIP_OK ? s : lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "byte record upload failed: %s", hipGetErrorString(e));
         }
@@ -424,6 +666,10 @@ int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p) {
     LH_CHECK_CTX(ctx);
     if (!p) return LURKHIP_OK;
     lurkhip::pool_release(ctx, p->dev);
+    if (p->host_keep) {
+        (void)hipStreamSynchronize(ctx->stream);  // the upload that reads it was queued on this context's stream
+        (void)hipHostFree(p->host_keep);
+    }
     delete p;
     return LURKHIP_OK;
 }

@@ -208,10 +208,12 @@ class PreparedFuncTrace:
     """Device-resident inputs of one chip's trace (FuncChip: program + per-row arrays + row stream; MemChip: values +
     provide records; BytesChip: the 65536 x 6 lookup records)."""
 
-    def __init__(self, chip, shard: Shard):
+    def __init__(self, chip, shard: Shard, handle=None):
         self.ctx = chip.ctx
         h = C.c_void_p()
-        if isinstance(chip, FuncChip):
+        if handle is not None:  # flattened by prepare_many
+            h, s = handle, N.OK
+        elif isinstance(chip, FuncChip):
             s = N.lib.lurkhip_func_trace_prepare(self.ctx.handle, chip.toplevel.handle, shard.queries.handle, chip.func_idx, shard.index, shard.shard_config.max_shard_size, C.byref(h))
         elif isinstance(chip, MemChip):
             s = N.lib.lurkhip_mem_trace_prepare(self.ctx.handle, shard.queries.handle, chip.len, C.byref(h))
@@ -224,8 +226,26 @@ class PreparedFuncTrace:
         _check(N.lib.lurkhip_func_trace_shape_of(h, shape))
         self.n_real, self.height, self.width, self.input_bytes, self.stream_words = [int(x) for x in shape]
 
-    def run(self, out_dev, repr: int = N.REPR_CANONICAL):
-        self.ctx.check(N.lib.lurkhip_func_trace_run(self.ctx.handle, self.handle, _addr(out_dev), repr))
+    @classmethod
+    def prepare_many(cls, chips, shard: Shard, n_threads: int = 0):
+        """The FuncChips' inputs of one shard flattened together on host threads into page-locked staging and queued for
+        upload on the chips' context (lurkhip_func_trace_prepare_many): [PreparedFuncTrace or None (no rows in the shard)]."""
+        if not chips:
+            return []
+        ctx, top = chips[0].ctx, chips[0].toplevel
+        idx = (C.c_int32 * len(chips))(*[c.func_idx for c in chips])
+        out = (C.c_void_p * len(chips))()
+        s = N.lib.lurkhip_func_trace_prepare_many(ctx.handle, top.handle, shard.queries.handle, len(chips), idx, shard.index,
+                                                  shard.shard_config.max_shard_size, n_threads, out)
+        if s != N.OK:
+            raise LairError(s, N.last_error(ctx.handle))
+        return [cls(c, shard, handle=C.c_void_p(h)) if h else None for c, h in zip(chips, out)]
+
+    def run(self, out_dev, repr: int = N.REPR_CANONICAL, ctx=None):
+        """Launches the trace kernel on `ctx` (default: the context the inputs were uploaded on; another context's stream must
+        only be used once that upload has completed)."""
+        ctx = ctx or self.ctx
+        ctx.check(N.lib.lurkhip_func_trace_run(ctx.handle, self.handle, _addr(out_dev), repr))
 
     def close(self):
         if self.handle:

@@ -320,13 +320,20 @@ class Machine(_ShardProver):
         self.ctx.sync()
         return out
 
-    def prepare_shard(self, shard: Shard):
+    def prepare_shard(self, shard: Shard, input_ctx=None, n_threads: int = 0):
         """Uploads every included chip's trace inputs once; returns [(machine index, air, log_height, out tensor,
-        prepared inputs or None)] -- `run_prepared` then regenerates all traces on the device without touching the host."""
+        prepared inputs or None)] -- `run_prepared` then regenerates all traces on the device without touching the host.
+        The FuncChips' row streams are flattened together on host threads (lurkhip_func_trace_prepare_many).
+        `input_ctx`: flatten and upload on that context (its own stream and pool) instead of the machine's -- a streaming
+        prover stages the next shard there while this context proves the current one; the call returns once the uploads
+        have completed, and the inputs must be closed only after this context has finished with them."""
         import torch
 
         from .lair import PreparedFuncTrace
 
+        ictx = input_ctx or self.ctx
+        func_chips = [FuncChip(ictx, arg, self.toplevel) for kind, arg, _ in self.chips if kind == "func"]
+        func_inputs = iter(PreparedFuncTrace.prepare_many(func_chips, shard, n_threads))
         out = []
         for mi, (kind, arg, air) in enumerate(self.chips):
             if kind == "entrypoint":
@@ -336,19 +343,25 @@ class Machine(_ShardProver):
                 out.append((mi, air, 0, t, None))
                 continue
             if kind == "func":
-                chip = FuncChip(self.ctx, arg, self.toplevel)
-                if chip.trace_shape(shard)[0] == 0:
+                p = next(func_inputs)
+                if p is None:
                     continue
             elif kind == "mem":
                 if shard.index != 0:
                     continue
-                chip = MemChip(self.ctx, arg)
+                p = PreparedFuncTrace(MemChip(ictx, arg), shard)
             else:
-                chip = BytesChip(self.ctx)
-            p = PreparedFuncTrace(chip, shard)
+                p = PreparedFuncTrace(BytesChip(ictx), shard)
             t = torch.empty((p.height, p.width), dtype=torch.int32, device="cuda")  # every word is written by the trace kernel
             out.append((mi, air, p.height.bit_length() - 1, t, p))
-        torch.cuda.synchronize()
+        if input_ctx is None:
+            ictx.sync()
+            torch.cuda.synchronize()
+            return out
+        # staged on another context: nobody waits here -- the uploads are followed by an event the proving context's stream
+        # waits for (run_prepared), so the staging thread is already flattening the next shard while these copies run
+        out = PreparedShard(out)
+        out.event = ictx.record_event()
         return out
 
     def compile_airs(self, prepared, min_log_rows: int | None = None, min_instrs: int | None = None):
@@ -372,9 +385,12 @@ class Machine(_ShardProver):
         return done
 
     def run_prepared(self, prepared):
+        ev = getattr(prepared, "event", None)
+        if ev:
+            self.ctx.wait_event(ev)  # inputs uploaded on a staging context: its copies first
         for _, _, _, t, p in prepared:
             if p is not None:
-                p.run(t, repr=N.REPR_MONTY)
+                p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
         return [(mi, air, lg, t) for mi, air, lg, t, _ in prepared]
 
     def prove(self, queries: QueryRecord, config: ShardingConfig | None = None, num_queries=NUM_QUERIES, pow_bits=POW_BITS, resident_shards: int = 1,
@@ -421,6 +437,94 @@ class Machine(_ShardProver):
             self.free_shard(handle)
             del traces
         return proofs
+
+
+class PreparedShard(list):
+    """prepare_shard's result when the inputs were uploaded on a staging context: the list plus the event behind its uploads."""
+    event = None
+
+    def close(self):
+        for *_, p in self:
+            if p is not None:
+                p.close()
+        if self.event:
+            Context.destroy_event(self.event)
+            self.event = None
+
+
+def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingConfig, num_queries=NUM_QUERIES, pow_bits=POW_BITS, input_ctx=None,
+                   n_threads: int = 0, parse=True, prepared=None, stats=None):
+    """`Machine.prove` fed by a host pipeline: a staging thread flattens shard k + 1 (host threads, page-locked staging) and
+    uploads it on `input_ctx` -- its own stream, so the copy runs under the kernels of this context -- while the machine's
+    context generates the traces of shard k and commits them.  Every shard's inputs, traces and main commitment stay resident
+    (a 2^20-row fib shard holds 0.7 GB of inputs and 4 GB of main LDEs: a dozen shards fit the 288 GB), so phase 2 proves the
+    shards without regenerating anything.  The proofs are `Machine.prove`'s, in shard order.
+    `prepared`: inputs staged beforehand ([prepare_shard result per shard]) -- the resident-input reference the streamed run is
+    measured against.  `stats` (dict) receives the host seconds spent staging."""
+    import queue
+    import threading
+    import time
+
+    if machine.pk is None:
+        machine.setup()
+    shards = Shard.new(queries).shard(config)
+    pv = queries.expect_public_values()
+    ready: "queue.Queue" = queue.Queue(maxsize=2)
+    staged_s = [0.0]
+
+    def stage():
+        try:
+            for sh in shards:
+                t0 = time.perf_counter()
+                item = machine.prepare_shard(sh, input_ctx=input_ctx, n_threads=n_threads)
+                staged_s[0] += time.perf_counter() - t0
+                ready.put(item)
+        except BaseException as e:  # surfaced on the proving thread
+            ready.put(e)
+
+    th, own_ctx = None, None
+    if prepared is None:
+        if input_ctx is None:  # the staging thread needs a stream and a pool of its own
+            input_ctx = own_ctx = Context(machine.ctx.device)
+        th = threading.Thread(target=stage)
+        th.start()
+    ch = Challenger(machine.ctx)
+    ch.observe(machine.vk_root)
+    ch.observe([0])
+    committed, inputs = [], []
+    try:
+        for i in range(len(shards)):
+            item = prepared[i] if prepared is not None else ready.get()
+            if isinstance(item, BaseException):
+                raise item
+            inputs.append(item)
+            traces = machine.run_prepared(item)
+            handle, root = machine.commit_shard(traces)
+            committed.append((handle, traces))
+            ch.observe(root)
+            ch.observe(pv)
+        proofs = []
+        for handle, _ in committed:
+            proofs.append(machine.prove_shard(handle, ch.clone(), pv, num_queries, pow_bits, parse=parse))
+    finally:
+        if th is not None:
+            while th.is_alive():  # a failure on this side: drain so the staging thread can finish
+                try:
+                    ready.get(timeout=0.05)
+                except queue.Empty:
+                    pass
+            th.join()
+        machine.ctx.sync()
+        for handle, _ in committed:
+            machine.free_shard(handle)
+        if prepared is None:
+            for item in inputs:
+                item.close() if isinstance(item, PreparedShard) else [p.close() for *_, p in item if p is not None]
+        if own_ctx is not None:
+            own_ctx.close()
+    if stats is not None:
+        stats["staging_s"] = staged_s[0]
+    return proofs
 
 
 def grand_sum(proofs):

@@ -26,3 +26,5 @@ for _, d in rows:
     c = d["config"]
     print({k: c.get(k) for k in ("proofs_identical_across_steps", "grand_sum_is_zero", "host_execute_s", "host_flatten_upload_s")},
           "two_in_flight:", (c.get("two_shards_in_flight") or {}).get("ms_per_shard"))
+    if c.get("host_pipeline"):
+        print("host_pipeline:", c["host_pipeline"])
