@@ -445,6 +445,7 @@ def main():
                 "host_execute_s": t_execute,
                 "host_flatten_upload_s": t_flatten,
                 "compiled_air_chips": compiled,
+                "compiled_trace_chips": list(machine.compiled_traces),
                 "air_compile_s": t_jit,
                 "two_shards_in_flight": two_in_flight,
                 "host_pipeline": host_pipeline,

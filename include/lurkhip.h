@@ -347,6 +347,13 @@ int32_t lurkhip_generate_trace_func(lurkhip_ctx* ctx, lurkhip_toplevel* top, con
 int32_t lurkhip_generate_trace_func_dev(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r,
                                         int32_t func_idx, uint32_t shard_index, uint32_t max_shard_size,
                                         uint32_t* out_dev, int32_t repr);
+/* Compiles the function's trace program (the row interpreter's input) to a straight-line gfx950 row kernel with hiprtc and uses it
+ * for every later trace of that function on the context's device (the interpreter otherwise); code objects are cached on disk
+ * like the AIR kernels'.  _check compiles without loading (no device needed) and returns the code object size; _source returns
+ * the generated text.  No reference counterpart (populate_row walks the bytecode per row, src/lair/trace.rs:145-418). */
+int32_t lurkhip_trace_compile(lurkhip_ctx* ctx, lurkhip_toplevel* top, int32_t func_idx);
+int32_t lurkhip_trace_compile_check(lurkhip_toplevel* top, int32_t func_idx, char* log, uint32_t log_cap);
+int32_t lurkhip_trace_source(lurkhip_toplevel* top, int32_t func_idx, char* out, uint32_t cap);
 /* generate_trace split in two for callers that re-run it or want the inputs resident in HBM:
  * prepare flattens one shard of one function into device buffers (program, per-row arrays, row stream),
  * run launches the row kernel into a height x width device buffer (asynchronous on the ctx stream).

@@ -130,6 +130,9 @@ SIGNATURES = {
     "lurkhip_func_trace_shape": (_i32, [_p, _i32, C.c_uint32, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "lurkhip_generate_trace_func": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, _u32p, _i32]),
     "lurkhip_generate_trace_func_dev": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, _u32p, _i32]),
+    "lurkhip_trace_compile": (_i32, [_p, _p, _i32]),
+    "lurkhip_trace_compile_check": (_i32, [_p, _i32, _p, C.c_uint32]),
+    "lurkhip_trace_source": (_i32, [_p, _i32, _p, C.c_uint32]),
     "lurkhip_func_trace_prepare": (_i32, [_p, _p, _p, _i32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_func_trace_prepare_many": (_i32, [_p, _p, _p, C.c_uint32, C.POINTER(_i32), C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_mem_trace_prepare": (_i32, [_p, _p, C.c_uint32, C.POINTER(_p)]),

@@ -261,6 +261,8 @@ bool get_code(const std::string& src, std::vector<char>* code, std::string* log,
 }
 }  // namespace
 
+bool jit_get_code(const std::string& src, std::vector<char>* code, std::string* log) { return get_code(src, code, log, nullptr); }
+
 size_t jit_compile_only(const lair::AirPrograms& prog, uint32_t batch, std::string* log) {
     std::vector<char> code;
     return get_code(jit_source(prog, batch), &code, log, nullptr) ? code.size() : 0;

@@ -175,6 +175,9 @@ std::vector<uint32_t> build_trace_program(const Toplevel& t, const Func& f, uint
     em.code[TH_PARTIAL] = f.partial ? 1 : 0;
     em.code[TH_ENTRY] = entry;
     em.code[TH_MAX_VARS] = em.max_vars;
+    const uint64_t hash = trace_program_hash(em.code.data(), em.code.size());
+    em.code[TH_HASH_LO] = (uint32_t)hash;
+    em.code[TH_HASH_HI] = (uint32_t)(hash >> 32);
     if (max_vars) *max_vars = em.max_vars;
     return em.code;
 }

@@ -13,6 +13,7 @@
 #include <thread>
 
 #include "../ctx.h"
+#include "../jit.h"
 #include "../stark.h"
 #include "air.h"
 #include "lair.h"
@@ -222,6 +223,56 @@ int32_t lurkhip_func_trace_shape(const lurkhip_record* r, int32_t func_idx, uint
     if (height) *height = next_pow2(n);  // `0.next_power_of_two()` is 1 in Rust (trace.rs:79)
     if (width) *width = r->top->layouts[func_idx].total();
     return LURKHIP_OK;
+}
+
+// Compiles the function's trace micro-program to a straight-line row kernel (trace_jit.cpp, hiprtc) and loads it on the
+// context's device: every later trace of that function on that device (lurkhip_trace_func_dev recognises the program by the
+// hash in its header) runs the compiled kernel instead of the interpreter.  Worth it for chips of 2^17 rows and more.
+int32_t lurkhip_trace_compile(lurkhip_ctx* ctx, lurkhip_toplevel* top, int32_t func_idx) {
+    LH_CHECK_CTX(ctx);
+    if (!top || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size()) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "bad toplevel/func index");
+    return guarded(ctx, [&]() -> int32_t {
+        if (hipSetDevice(ctx->device) != hipSuccess) return lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "hipSetDevice failed");
+        std::string log;
+        if (!lurkhip::trace_jit_compile(ctx->device, program_of(top, (uint32_t)func_idx), &log))
+            return lurkhip::set_error(ctx, LURKHIP_ERR_EXEC, "compiling the trace kernel of %s failed: %s", top->t.funcs[func_idx].name.c_str(), log.c_str());
+        return LURKHIP_OK;
+    });
+}
+
+// The same without loading (no device needed: build-time cache warming, CPU test of the generator): code object bytes, or a
+// negative error with the compiler's message in `log`.
+int32_t lurkhip_trace_compile_check(lurkhip_toplevel* top, int32_t func_idx, char* log, uint32_t log_cap) {
+    if (!top || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size()) return LURKHIP_ERR_INVALID_ARG;
+    std::string l;
+    size_t n = 0;
+    try {
+        n = lurkhip::trace_jit_compile_only(program_of(top, (uint32_t)func_idx), &l);
+    } catch (const std::exception& e) {
+        l = e.what();
+    }
+    if (log && log_cap) {
+        const size_t k = std::min<size_t>(l.size(), log_cap - 1);
+        memcpy(log, l.data(), k);
+        log[k] = 0;
+    }
+    return n ? (int32_t)std::min<size_t>(n, 0x7fffffff) : LURKHIP_ERR_EXEC;
+}
+
+// The generated source of that kernel (inspection / tests): returns its length, copying at most cap - 1 characters.
+int32_t lurkhip_trace_source(lurkhip_toplevel* top, int32_t func_idx, char* out, uint32_t cap) {
+    if (!top || func_idx < 0 || (size_t)func_idx >= top->t.funcs.size()) return LURKHIP_ERR_INVALID_ARG;
+    try {
+        const std::string src = lurkhip::trace_jit_source(program_of(top, (uint32_t)func_idx));
+        if (out && cap) {
+            const size_t k = std::min<size_t>(src.size(), cap - 1);
+            memcpy(out, src.data(), k);
+            out[k] = 0;
+        }
+        return (int32_t)std::min<size_t>(src.size(), 0x7fffffff);
+    } catch (const std::exception& e) {
+        return fail(nullptr, LURKHIP_ERR_EXEC, e.what());
+    }
 }
 
 // Device-resident inputs of one FuncChip trace (program + per-row arrays + row stream), so that the

@@ -57,6 +57,8 @@ enum TraceHeader : uint32_t {
     TH_PARTIAL,
     TH_ENTRY,
     TH_MAX_VARS,
+    TH_HASH_LO,  // 64-bit FNV-1a of the program words (these two taken as zero): names the function's compiled trace kernel
+    TH_HASH_HI,
     TH_WORDS
 };
 
@@ -67,5 +69,15 @@ struct RowMeta {
     uint32_t n_requires;
     uint32_t n_depth_requires;
 };
+
+// FNV-1a over the program words, the two hash words of the header taken as zero (never 0: 0 = "no hash")
+inline uint64_t trace_program_hash(const uint32_t* prog, uint64_t n_words) {
+    uint64_t h = 0xcbf29ce484222325ull;
+    for (uint64_t i = 0; i < n_words; i++) {
+        const uint32_t w = (i == TH_HASH_LO || i == TH_HASH_HI) ? 0u : prog[i];
+        for (int b = 0; b < 4; b++) h = (h ^ ((w >> (8 * b)) & 0xff)) * 0x100000001b3ull;
+    }
+    return h ? h : 1;
+}
 
 }  // namespace lair

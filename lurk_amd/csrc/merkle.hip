@@ -32,6 +32,7 @@ constexpr int MBLOCK = 256;
 // levels of at most this many parents run lane-cooperatively (above it one permutation per lane already fills the SIMDs)
 constexpr size_t COOP_MAX_PARENTS = 16384;
 
+// (inlined at its three call sites of k_level on purpose: as a call the state goes through scratch and the step loses 3 ms)
 __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
     p2::NoRecord rec;
     p2::permute_core<16>(s, p->rounds_p, p->ext_rc, p->int_rc, p->diag, p->ext_rc_mp, p->int_rc_mp, p->diag_c, rec, p->sum_mult_c);

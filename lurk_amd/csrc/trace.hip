@@ -15,138 +15,16 @@
 // same match arm stay converged; rows of different arms diverge as any SIMT interpreter does.
 // The row's variable map lives in per-lane scratch (dynamic indices).  Bound: HBM writes,
 // width*4 bytes per row plus the streamed inputs.
-#include "babybear.h"
+#include <stdlib.h>
+
 #include "ctx.h"
-#include "lair/trace_program.h"
-#include "poseidon2_dev.h"
+#include "jit.h"
+#include "trace_kernels.h"
 
 namespace {
 
 using namespace lair;
-
-constexpr int TBLOCK = 64;
-
-struct TraceArgs {
-    const uint32_t* prog;
-    const uint32_t* args;      // [n][input]
-    const uint32_t* outputs;   // [n][output]
-    const uint32_t* provides;  // [n][2]  (last_nonce, last_count)
-    const uint32_t* depths;    // [n] or null
-    const RowMeta* meta;       // [n]
-    const uint32_t* stream;
-    uint32_t* out;             // [height][width]
-    uint32_t n_real;
-    uint32_t height;
-    uint32_t nonce_start;
-    int canonical_out;
-};
-
-// Column col of the lane's row lives at base[e + (e >> sh)], e = e0 + col.  Staged (the workgroup's rows go through LDS and
-// leave with coalesced stores): base = the LDS tile, e0 = lane * width, sh = 5 (one pad word per 32 keeps a column of 64
-// rows off a single bank whatever the width).  Unstaged (rows wider than the tile budget): base = the row in global
-// memory, e0 = 0, sh = 31.
-struct RowWriter {
-    uint32_t* row;
-    uint32_t aux0;   // column of aux[0]
-    uint32_t aux;    // aux cursor
-    bool canonical;
-    uint32_t e0 = 0, sh = 31;
-    __device__ __forceinline__ uint32_t& at(uint32_t col) {
-        const uint32_t e = e0 + col;
-        return row[e + (e >> sh)];
-    }
-    __device__ __forceinline__ void put(uint32_t col, uint32_t v_m) { at(col) = canonical ? bb::from_monty(v_m) : v_m; }
-    __device__ __forceinline__ void push_aux(uint32_t v_m) { put(aux0 + aux++, v_m); }
-    // small non-negative integers (bytes, nonces, counts) given as plain integers
-    __device__ __forceinline__ void put_int(uint32_t col, uint32_t v) { at(col) = canonical ? v : bb::to_monty(v); }
-    __device__ __forceinline__ void push_aux_int(uint32_t v) { put_int(aux0 + aux++, v); }
-};
-
-// Inverses of the small integers (Montgomery form), built at compile time: the lookup counts whose successors a require
-// record inverts (air/builder.rs:162) are almost always a handful, and a Fermat ladder is 40 products per record.
-constexpr int INV_TABLE = 1024;
-struct InvTable {
-    uint32_t v[INV_TABLE];
-};
-constexpr uint32_t c_pow(uint32_t a, uint32_t e) {
-    uint32_t r = 1;
-    while (e) {
-        if (e & 1u) r = bb::cmulmod(r, a);
-        a = bb::cmulmod(a, a);
-        e >>= 1;
-    }
-    return r;
-}
-constexpr InvTable make_inv_table() {
-    InvTable t{};
-    t.v[0] = 0;
-    for (int i = 1; i < INV_TABLE; i++) t.v[i] = bb::c_to_monty(c_pow((uint32_t)i, bb::P - 2));
-    return t;
-}
-__constant__ const InvTable kInvSmall = make_inv_table();
-
-// RequireRecord: prev_nonce, prev_count, (prev_count + 1)^-1   (air/builder.rs:159-168)
-__device__ __forceinline__ void push_require(RowWriter& w, const uint32_t* rec) {
-    uint32_t nonce = rec[0], count = rec[1];
-    w.push_aux_int(nonce);
-    w.push_aux_int(count);
-    const uint32_t c1 = count + 1;
-    w.push_aux(c1 < (uint32_t)INV_TABLE ? kInvSmall.v[c1] : bb::inv(bb::to_monty(c1)));
-}
-
-// Poseidon2Cols recorder writing straight into the row (core/poseidon.rs:65-72: 8 outputs first)
-template <int W, int RP>
-struct RowRec {
-    RowWriter* w;
-    uint32_t base;  // column of the first witness lane (the 8 outputs)
-    __device__ __forceinline__ void ext_state(int r, int i, uint32_t v) { w->put(base + 8 + r * W + i, v); }
-    __device__ __forceinline__ void end_ext_state(int) {}
-    __device__ __forceinline__ void ext_sbox(int r, int i, uint32_t v) { w->put(base + 8 + 8 * W + r * W + i, v); }
-    __device__ __forceinline__ void end_ext_sbox(int) {}
-    __device__ __forceinline__ void int_init(int i, uint32_t v) { w->put(base + 8 + 16 * W + i, v); }
-    __device__ __forceinline__ void end_int_init() {}
-    __device__ __forceinline__ void int_state0(int r, uint32_t v) { w->put(base + 8 + 17 * W + r, v); }
-    __device__ __forceinline__ void int_sbox(int r, uint32_t v) { w->put(base + 8 + 17 * W + (RP - 1) + r, v); }
-    __device__ __forceinline__ void end_internal() {}
-};
-
-template <int W, class MapT>
-__device__ __noinline__ void extern_hasher(RowWriter& w, MapT& map, uint32_t& sp, const uint32_t* ins) {
-    constexpr int RP = p2::Cfg<W>::RP;
-    uint32_t s[W];
-#pragma unroll
-    for (int i = 0; i < W; i++) s[i] = map[ins[i]];
-    RowRec<W, RP> rec{&w, w.aux0 + w.aux};
-    const auto& p = p2::Cfg<W>::params();
-    p2::permute_core<W>(s, RP, p.ext_rc, p.int_rc, p.diag, p.ext_rc_mp, p.int_rc_mp, p.diag_c, rec);
-#pragma unroll
-    for (int i = 0; i < 8; i++) w.put(rec.base + i, s[i]);
-    w.aux += 8 + p2::Cfg<W>::NUM_COLS;
-    // populate_witness returns the whole state (core/poseidon.rs:71) and trace.rs:393-396 pushes all of it
-#pragma unroll
-    for (int i = 0; i < W; i++) map[sp++] = s[i];
-}
-
-template <class MapT>
-__device__ __forceinline__ uint64_t map_u64(MapT& map, const uint32_t* ins) {
-    uint64_t r = 0;
-    for (int i = 0; i < 8; i++) r |= (uint64_t)(bb::from_monty(map[ins[i]]) & 0xff) << (8 * i);
-    return r;
-}
-
-// LessThanWitness<_, 4> for depths (unsigned/less_than.rs:12-41): is_comp[4], lhs_limb, rhs_limb
-__device__ __forceinline__ void push_depth_less_than(RowWriter& w, uint32_t lhs, uint32_t rhs) {
-    int idx = -1;
-    for (int i = 3; i >= 0; i--) {
-        if (((lhs >> (8 * i)) & 0xff) != ((rhs >> (8 * i)) & 0xff)) {
-            idx = i;
-            break;
-        }
-    }
-    for (int i = 0; i < 4; i++) w.push_aux_int(i == idx ? 1u : 0u);
-    w.push_aux_int(idx >= 0 ? (lhs >> (8 * idx)) & 0xff : 0u);
-    w.push_aux_int(idx >= 0 ? (rhs >> (8 * idx)) & 0xff : 0u);
-}
+using namespace lurkhip_trace;
 
 template <int CAP>
 __device__ __forceinline__ void trace_row(const TraceArgs& a, const uint32_t row_i, RowWriter& w) {
@@ -267,158 +145,12 @@ __device__ __forceinline__ void trace_row(const TraceArgs& a, const uint32_t row
             push_require(w, reqs + 2 * r++);
             pc += 2;
         } else if (op == T_EXTERN) {
-            const uint32_t kind = prog[pc + 1], nin = prog[pc + 2], wit = prog[pc + 3], nreq = prog[pc + 4];
+            const uint32_t kind = prog[pc + 1], nin = prog[pc + 2], wit = prog[pc + 3], nreq = prog[pc + 4], nret = prog[pc + 5];
             const uint32_t* ins_v = prog + pc + 6;
-            if (kind == CHIP_HASHER3) extern_hasher<24>(w, map, sp, ins_v);
-            else if (kind == CHIP_HASHER4) extern_hasher<32>(w, map, sp, ins_v);
-            else if (kind == CHIP_HASHER5) extern_hasher<40>(w, map, sp, ins_v);
-            else if (kind == CHIP_U64_ADD || kind == CHIP_U64_SUB) {
-                uint64_t x = map_u64(map, ins_v), y = map_u64(map, ins_v + 8);
-                uint64_t z = kind == CHIP_U64_ADD ? x + y : x - y;
-                for (int i = 0; i < 8; i++) {
-                    uint32_t b = (uint32_t)(z >> (8 * i)) & 0xff;
-                    w.push_aux_int(b);
-                    map[sp++] = bb::to_monty(b);
-                }
-            } else if (kind == CHIP_U64_MUL) {
-                uint64_t x = map_u64(map, ins_v), y = map_u64(map, ins_v + 8);
-                uint32_t carry = 0;
-                uint32_t res[8];
-                for (int k = 0; k < 8; k++) {
-                    uint32_t prod = 0;
-                    for (int i = 0; i <= k; i++) prod += (uint32_t)((x >> (8 * i)) & 0xff) * (uint32_t)((y >> (8 * (k - i))) & 0xff);
-                    uint32_t o = prod + carry;
-                    res[k] = o & 0xff;
-                    carry = (o >> 8) & 0xffff;
-                    w.push_aux_int(carry);
-                }
-                for (int k = 0; k < 8; k++) {
-                    w.push_aux_int(res[k]);
-                    map[sp++] = bb::to_monty(res[k]);
-                }
-            } else if (kind == CHIP_U64_LESSTHAN) {
-                // CompareWitness<_, 8>: is_comp[8], lhs_limb, rhs_limb, diff_inv, is_less_than
-                uint64_t x = map_u64(map, ins_v), y = map_u64(map, ins_v + 8);
-                int idx = -1;
-                for (int i = 7; i >= 0; i--)
-                    if (((x >> (8 * i)) & 0xff) != ((y >> (8 * i)) & 0xff)) {
-                        idx = i;
-                        break;
-                    }
-                uint32_t l = idx >= 0 ? (uint32_t)(x >> (8 * idx)) & 0xff : 0, rr = idx >= 0 ? (uint32_t)(y >> (8 * idx)) & 0xff : 0;
-                for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
-                w.push_aux_int(l);
-                w.push_aux_int(rr);
-                w.push_aux(idx >= 0 ? bb::inv(bb::sub(bb::to_monty(l), bb::to_monty(rr))) : 0u);
-                uint32_t lt = (idx >= 0 && l < rr) ? 1u : 0u;
-                w.push_aux_int(lt);
-                map[sp++] = bb::to_monty(lt);
-            } else if (kind == CHIP_U64_ISZERO) {
-                // IsZero<_, 8>: inverses[8] (only the first non-zero limb), result
-                uint64_t x = map_u64(map, ins_v);
-                bool found = false;
-                for (int i = 0; i < 8; i++) {
-                    uint32_t limb = (uint32_t)(x >> (8 * i)) & 0xff;
-                    if (!found && limb) {
-                        w.push_aux(bb::inv(bb::to_monty(limb)));
-                        found = true;
-                    } else {
-                        w.push_aux(0u);
-                    }
-                }
-                uint32_t z = x == 0 ? 1u : 0u;
-                w.push_aux_int(z);
-                map[sp++] = bb::to_monty(z);
-            } else if (kind == CHIP_U64_DIVREM) {
-                // DivRem<_, 8> (unsigned/div_rem.rs:16-62): b_non_zero.inverses[8], q[8], qb { carry[8], result[8] },
-                // r[8], r_lt_b { is_comp[8], lhs, rhs }, qb_cmp_a { is_comp[8], lhs, rhs, diff_inv, is_less_than }
-                const uint64_t x = map_u64(map, ins_v), y = map_u64(map, ins_v + 8);
-                const uint64_t qv = y ? x / y : 0, qb = qv * y, rem = x - qb;
-                bool found = false;
-                for (int i = 0; i < 8; i++) {
-                    const uint32_t limb = (uint32_t)(y >> (8 * i)) & 0xff;
-                    if (!found && limb) {
-                        w.push_aux(bb::inv(bb::to_monty(limb)));
-                        found = true;
-                    } else {
-                        w.push_aux(0u);
-                    }
-                }
-                for (int i = 0; i < 8; i++) w.push_aux_int((uint32_t)(qv >> (8 * i)) & 0xff);
-                {
-                    uint32_t carry = 0, res[8];
-                    for (int k = 0; k < 8; k++) {
-                        uint32_t prod = 0;
-                        for (int i = 0; i <= k; i++) prod += (uint32_t)((qv >> (8 * i)) & 0xff) * (uint32_t)((y >> (8 * (k - i))) & 0xff);
-                        const uint32_t o = prod + carry;
-                        res[k] = o & 0xff;
-                        carry = (o >> 8) & 0xffff;
-                        w.push_aux_int(carry);
-                    }
-                    for (int k = 0; k < 8; k++) w.push_aux_int(res[k]);
-                }
-                for (int i = 0; i < 8; i++) w.push_aux_int((uint32_t)(rem >> (8 * i)) & 0xff);
-                auto msb_diff = [](uint64_t l, uint64_t r) {
-                    for (int i = 7; i >= 0; i--)
-                        if (((l >> (8 * i)) & 0xff) != ((r >> (8 * i)) & 0xff)) return i;
-                    return -1;
-                };
-                {  // LessThanWitness(rem, y)
-                    const int idx = msb_diff(rem, y);
-                    for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
-                    w.push_aux_int(idx >= 0 ? (uint32_t)(rem >> (8 * idx)) & 0xff : 0u);
-                    w.push_aux_int(idx >= 0 ? (uint32_t)(y >> (8 * idx)) & 0xff : 0u);
-                }
-                {  // CompareWitness(qb, x)
-                    const int idx = msb_diff(qb, x);
-                    const uint32_t l = idx >= 0 ? (uint32_t)(qb >> (8 * idx)) & 0xff : 0, rr = idx >= 0 ? (uint32_t)(x >> (8 * idx)) & 0xff : 0;
-                    for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
-                    w.push_aux_int(l);
-                    w.push_aux_int(rr);
-                    w.push_aux(idx >= 0 ? bb::inv(bb::sub(bb::to_monty(l), bb::to_monty(rr))) : 0u);
-                    w.push_aux_int((idx >= 0 && l < rr) ? 1u : 0u);
-                }
-                for (int i = 0; i < 8; i++) map[sp++] = bb::to_monty((uint32_t)(qv >> (8 * i)) & 0xff);
-                for (int i = 0; i < 8; i++) map[sp++] = bb::to_monty((uint32_t)(rem >> (8 * i)) & 0xff);
-            } else if (kind == CHIP_BIGNUM_LESSTHAN) {
-                // BigNumCompareWitness (big_num/cmp.rs:13-49): is_comp[8], lhs_limb, rhs_limb, lhs_word { is_msb_lt, bytes[4] },
-                // rhs_word { .. }, CompareWitness<_, 4> { is_comp[4], lhs, rhs, diff_inv, is_less_than }
-                int idx = -1;
-                uint32_t lm = 0, rm = 0;
-                for (int i = 7; i >= 0; i--)
-                    if (map[ins_v[i]] != map[ins_v[8 + i]]) {
-                        idx = i;
-                        lm = map[ins_v[i]];
-                        rm = map[ins_v[8 + i]];
-                        break;
-                    }
-                const uint32_t l = idx >= 0 ? bb::from_monty(lm) : 0u, r = idx >= 0 ? bb::from_monty(rm) : 0u;
-                for (int i = 0; i < 8; i++) w.push_aux_int(i == idx ? 1u : 0u);
-                w.push_aux_int(l);
-                w.push_aux_int(r);
-                for (int side = 0; side < 2; side++) {
-                    const uint32_t v = side ? r : l;
-                    w.push_aux_int((v >> 24) < 0x78 ? 1u : 0u);
-                    for (int i = 0; i < 4; i++) w.push_aux_int((v >> (8 * i)) & 0xff);
-                }
-                int j = -1;
-                for (int i = 3; i >= 0; i--)
-                    if (((l >> (8 * i)) & 0xff) != ((r >> (8 * i)) & 0xff)) {
-                        j = i;
-                        break;
-                    }
-                const uint32_t lb = j >= 0 ? (l >> (8 * j)) & 0xff : 0, rb = j >= 0 ? (r >> (8 * j)) & 0xff : 0;
-                for (int i = 0; i < 4; i++) w.push_aux_int(i == j ? 1u : 0u);
-                w.push_aux_int(lb);
-                w.push_aux_int(rb);
-                w.push_aux(j >= 0 ? bb::inv(bb::sub(bb::to_monty(lb), bb::to_monty(rb))) : 0u);
-                const uint32_t lt = (j >= 0 && lb < rb) ? 1u : 0u;
-                w.push_aux_int(lt);
-                map[sp++] = bb::to_monty(lt);
-            } else {
-                // unsupported chips are rejected on the host before launch
-                w.aux += wit;
-            }
+            uint32_t in[EXTERN_MAX_IO], out[EXTERN_MAX_IO];
+            for (uint32_t i = 0; i < nin && i < (uint32_t)EXTERN_MAX_IO; i++) in[i] = map[ins_v[i]];
+            extern_op(w, kind, in, out, wit);
+            for (uint32_t i = 0; i < nret && i < (uint32_t)EXTERN_MAX_IO; i++) map[sp++] = out[i];
             for (uint32_t i = 0; i < nreq; i++) push_require(w, reqs + 2 * r++);
             pc += 6 + nin;
         } else if (op == T_RANGE_U8) {
@@ -458,31 +190,9 @@ __device__ __forceinline__ void trace_row(const TraceArgs& a, const uint32_t row
     }
 }
 
-// One row per lane.  STAGED: the workgroup's 64 rows are built in a zero-filled LDS tile and leave as one contiguous run
-// of 64 * width words with coalesced stores (a lane writing its own row straight to HBM touches 64 lines per store
-// instruction: 4x write amplification measured); the output needs no memset then.
 template <int CAP, bool STAGED>
 __global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
-    extern __shared__ uint32_t tile[];
-    const uint32_t row0 = blockIdx.x * TBLOCK, row_i = row0 + threadIdx.x;
-    const uint32_t width = a.prog[TH_WIDTH], n_in = a.prog[TH_INPUT], n_out = a.prog[TH_OUTPUT];
-    if constexpr (STAGED) {
-        const uint32_t rows = a.height - row0 < (uint32_t)TBLOCK ? a.height - row0 : (uint32_t)TBLOCK;
-        const uint32_t words = rows * width, padded = TBLOCK * width + ((TBLOCK * width) >> 5) + 1;
-        for (uint32_t e = threadIdx.x; e < padded; e += TBLOCK) tile[e] = 0;
-        __syncthreads();
-        if (row_i < a.height) {
-            RowWriter w{tile, 1 + n_in + n_out, 0, a.canonical_out != 0, threadIdx.x * width, 5};
-            trace_row<CAP>(a, row_i, w);
-        }
-        __syncthreads();
-        uint32_t* __restrict__ dst = a.out + (size_t)row0 * width;
-        for (uint32_t e = threadIdx.x; e < words; e += TBLOCK) dst[e] = tile[e + (e >> 5)];
-    } else {
-        if (row_i >= a.height) return;
-        RowWriter w{a.out + (size_t)row_i * width, 1 + n_in + n_out, 0, a.canonical_out != 0};
-        trace_row<CAP>(a, row_i, w);
-    }
+    trace_kernel_body<STAGED>(a, [](const TraceArgs& aa, uint32_t row_i, RowWriter& w) { trace_row<CAP>(aa, row_i, w); });
 }
 
 // ---- MemChip (memory.rs:30-69): [is_real = 1, ptr = i + 1, last_nonce, last_count, values...] -----------
@@ -548,6 +258,16 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     dim3 grid((height + TBLOCK - 1) / TBLOCK), block(TBLOCK);
     lurkhip::span_begin(ctx, "trace_func");
     const size_t lds = staged ? tile_words * 4 : 0;
+    // the function's compiled row kernel, when lurkhip_trace_compile has produced one for this program (named by its hash)
+    const uint64_t prog_hash = (uint64_t)program_host_header[TH_HASH_LO] | ((uint64_t)program_host_header[TH_HASH_HI] << 32);
+    const lurkhip::TraceJitKernels jit = prog_hash && getenv("LURKHIP_TRACE_INTERPRET") == nullptr ? lurkhip::trace_jit_lookup(ctx->device, prog_hash) : lurkhip::TraceJitKernels{};
+    if (jit.module) {
+        void* params[] = {&a};
+        const hipError_t le = hipModuleLaunchKernel(staged ? jit.staged : jit.flat, grid.x, 1, 1, TBLOCK, 1, 1, (unsigned)lds, ctx->stream, params, nullptr);
+        lurkhip::span_end(ctx, "trace_func");
+        if (le != hipSuccess) return lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "launch of the compiled trace kernel failed: %s", hipGetErrorString(le));
+        return LURKHIP_OK;
+    }
 #define LH_TRACE_LAUNCH(CAP)                                                                             \
     do {                                                                                                 \
         if (staged) hipLaunchKernelGGL((k_trace_func<CAP, true>), grid, block, lds, ctx->stream, a);     \

@@ -22,6 +22,11 @@ def _compile_one(job):
     from . import _native as N
     from . import air, lair
 
+    if kind == "trace":  # the function's trace generator (csrc/trace_jit.cpp)
+        top = lair.Toplevel(source, lurk_chips=lurk_chips)
+        log = C.create_string_buffer(2048)
+        r = N.lib.lurkhip_trace_compile_check(top.handle, arg, log, 2048)
+        return "trace kernel of function #%d" % arg, int(r), log.value.decode("utf-8", "replace")
     if kind == "func":
         top = lair.Toplevel(source, lurk_chips=lurk_chips)
         a = air.ChipAir.for_func(top, arg)
@@ -49,6 +54,8 @@ def warm(source: str, lurk_chips: bool, rows_by_func: dict, mem_lens=(2, 3, 4, 5
         log_rows = max(0, (max(rows, 1) - 1).bit_length())
         if wants_compile(log_rows, a.constraint_instrs):
             jobs.append((source, lurk_chips, "func", idx, 0))
+        if log_rows >= COMPILE_MIN_LOG_ROWS:
+            jobs.append((source, lurk_chips, "trace", idx, 0))
     jobs += [(source, lurk_chips, "mem", ml, 0) for ml in mem_lens]
     jobs.append((source, lurk_chips, "bytes", 0, 0))
     workers = workers or min(len(jobs), os.cpu_count() or 1)

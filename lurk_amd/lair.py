@@ -185,6 +185,22 @@ class FuncChip:
     def width(self) -> int:
         return self.layout_sizes.total()
 
+    def compile_trace(self, ctx: Context | None = None):
+        """Compile this function's trace program to a straight-line row kernel (hiprtc / the code-object cache) and use it on
+        the context's device from now on (lurkhip_trace_compile)."""
+        ctx = ctx or self.ctx
+        s = N.lib.lurkhip_trace_compile(ctx.handle, self.toplevel.handle, self.func_idx)
+        if s != N.OK:
+            raise LairError(s, N.last_error(ctx.handle))
+
+    def trace_kernel_source(self) -> str:
+        n = N.lib.lurkhip_trace_source(self.toplevel.handle, self.func_idx, None, 0)
+        if n < 0:
+            raise LairError(n, N.lair_last_error() if hasattr(N, "lair_last_error") else "trace source generation failed")
+        buf = C.create_string_buffer(n + 1)
+        N.lib.lurkhip_trace_source(self.toplevel.handle, self.func_idx, buf, n + 1)
+        return buf.value.decode()
+
     def trace_shape(self, shard: Shard):
         n, h, w = C.c_uint32(), C.c_uint32(), C.c_uint32()
         _check(N.lib.lurkhip_func_trace_shape(shard.queries.handle, self.func_idx, shard.index, shard.shard_config.max_shard_size, C.byref(n), C.byref(h), C.byref(w)))

@@ -176,6 +176,13 @@ class _ShardProver:
         if self.pk:
             N.lib.lurkhip_pk_free(self.ctx.handle, self.pk)
             self.pk = None
+        if self._side_ctx is not None:
+            self._side_ctx.close()
+            self._side_ctx = None
+        for ev in (self._ev_fork, self._ev_join):
+            if ev:
+                Context.destroy_event(ev)
+        self._ev_fork = self._ev_join = None
 
     def __del__(self):
         try:
@@ -255,6 +262,9 @@ class StarkMachine(_ShardProver):
             self.free_shard(handle)
 
 
+SIDE_STREAM_MAX_LOG_ROWS = 12  # chips below 2^12 rows are "short" for run_prepared's side stream
+
+
 class Machine(_ShardProver):
     """Chip vector of one Lair toplevel with `entry` as its entrypoint (lair_chip.rs:196-211)."""
 
@@ -268,6 +278,10 @@ class Machine(_ShardProver):
         for ml in MEM_TABLE_SIZES:
             self.chips.append(("mem", ml, ChipAir.for_mem(ml)))
         self.chips.append(("bytes", None, ChipAir.for_bytes()))
+        self.compiled_traces = []  # names of the function chips whose trace generator runs compiled (compile_airs)
+        self.side_stream = True     # run_prepared: short chips' trace kernels on a side stream
+        self._side_ctx = None
+        self._ev_fork = self._ev_join = None
         self.pk = None
         self._prep = None
 
@@ -375,12 +389,20 @@ class Machine(_ShardProver):
         lo = jit_warm.COMPILE_MIN_LOG_ROWS if min_log_rows is None else min_log_rows
         ni = jit_warm.COMPILE_MIN_INSTRS if min_instrs is None else min_instrs
         done = []
-        for _, chip_air, lg, _, _ in prepared:
+        for mi, chip_air, lg, _, _ in prepared:
             if lg >= lo or chip_air.constraint_instrs >= ni:
                 try:
                     chip_air.compile(self.ctx)
                     done.append(chip_air.name)
                 except Exception:  # hiprtc unavailable / compilation error: the interpreter stays in place
+                    pass
+            # the same for the trace generator of a tall function chip: its micro-program as a straight-line row kernel
+            kind, arg, _ = self.chips[mi]
+            if kind == "func" and lg >= lo:
+                try:
+                    FuncChip(self.ctx, arg, self.toplevel).compile_trace()
+                    self.compiled_traces.append(chip_air.name)
+                except Exception:
                     pass
         return done
 
@@ -388,8 +410,25 @@ class Machine(_ShardProver):
         ev = getattr(prepared, "event", None)
         if ev:
             self.ctx.wait_event(ev)  # inputs uploaded on a staging context: its copies first
-        for _, _, _, t, p in prepared:
-            if p is not None:
+        # The short chips (hash chips: one Poseidon2 witness per lane, a few waves in all; ingress / egress / lurk_main) are
+        # latency-bound launches with nothing to fill the device: they go to a side stream, forked behind everything queued
+        # so far and joined before the commitment, and run under the tall chips' kernels.
+        todo = [(lg, t, p) for _, _, lg, t, p in prepared if p is not None]
+        short = [x for x in todo if x[0] < SIDE_STREAM_MAX_LOG_ROWS]
+        tall = [x for x in todo if x[0] >= SIDE_STREAM_MAX_LOG_ROWS]
+        if short and tall and self.side_stream:
+            if self._side_ctx is None:
+                self._side_ctx = Context(self.ctx.device)
+            self._ev_fork = self.ctx.record_event(self._ev_fork)
+            self._side_ctx.wait_event(self._ev_fork)
+            for _, t, p in short:
+                p.run(t, repr=N.REPR_MONTY, ctx=self._side_ctx)
+            self._ev_join = self._side_ctx.record_event(self._ev_join)
+            for _, t, p in tall:
+                p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
+            self.ctx.wait_event(self._ev_join)
+        else:
+            for _, t, p in todo:
                 p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
         return [(mi, air, lg, t) for mi, air, lg, t, _ in prepared]
 

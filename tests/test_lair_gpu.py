@@ -232,3 +232,41 @@ def test_large_fib_trace_properties(ctx):
     # inverse witnesses: n * (1/n) = 1 and (n-1) * 1/(n-1) = 1
     assert np.array_equal((d[:, 1] * d[:, 5]) % P, np.ones(len(d), dtype=np.uint64))
     assert np.array_equal(((d[:, 1] - 1) * d[:, 6]) % P, np.ones(len(d), dtype=np.uint64))
+
+
+@pytest.mark.parametrize("case", load_cases(), ids=lambda c: c["name"])
+def test_compiled_trace_kernels_golden(ctx, case, monkeypatch):
+    """lurkhip_trace_compile: the function's micro-program as a straight-line row kernel (csrc/trace_jit.cpp).  The compiled
+    kernel must give the reference's literal trace, like the interpreter (forced again by LURKHIP_TRACE_INTERPRET)."""
+    top = lair.Toplevel(case["source"], lurk_chips=case["lurk_chips"])
+    q = lair.QueryRecord(top)
+    for name, args in case["calls"]:
+        top.execute_by_name(name, args, q)
+    chip = lair.FuncChip.from_name(ctx, case["func"], top)
+    assert "jit_row" in chip.trace_kernel_source()
+    chip.compile_trace()
+    got = chip.generate_trace(lair.Shard.new(q))
+    assert got.flatten().tolist() == case["trace"]
+    monkeypatch.setenv("LURKHIP_TRACE_INTERPRET", "1")
+    assert np.array_equal(chip.generate_trace(lair.Shard.new(q)), got)
+
+
+@pytest.mark.parametrize("workload", ["fib-mix", "lurk-mix"])
+def test_compiled_trace_kernels_every_function(ctx, workload, monkeypatch):
+    """Every function of the bench machines (all 39 Lurk widths, partial functions, u64 / hasher extern chips, sharded):
+    compiled row kernels == interpreter, bit for bit, Montgomery output."""
+    from lurk_amd.programs import lurk_mix as lm
+
+    mix = lm.fib_mix(1 << 9) if workload == "fib-mix" else lm.lurk_mix(1 << 9)
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute(top.func_index(mix.entry), mix.main_args, q)
+    shards = lair.Shard.new(q).shard(lair.ShardingConfig(1 << 8))
+    chips = [lair.FuncChip(ctx, i, top) for i in range(top.num_funcs())]
+    monkeypatch.setenv("LURKHIP_TRACE_INTERPRET", "1")
+    want = [[c.generate_trace(sh, repr=1) for sh in shards] for c in chips]
+    monkeypatch.delenv("LURKHIP_TRACE_INTERPRET")
+    for c, w in zip(chips, want):
+        c.compile_trace()
+        for sh, t in zip(shards, w):
+            assert np.array_equal(c.generate_trace(sh, repr=1), t), (c.func_idx, sh.index)

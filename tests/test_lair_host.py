@@ -152,3 +152,24 @@ def test_air_run_time_compiler_builds_without_a_device():
         log = C.create_string_buffer(8192)
         size = N.lib.lurkhip_air_compile_check(a.handle, log, 8192)
         assert size > 1000, (a.name, log.value.decode(errors="replace"))
+
+
+def test_trace_run_time_compiler_builds_without_a_device():
+    """The generator of the per-function trace kernels (csrc/trace_jit.cpp): a function's micro-program unrolled along its block
+    tree -- every variable an SSA value, every hint / require offset and aux column a literal -- compiles with hiprtc here; the
+    program header carries the hash that names the compiled kernel."""
+    import ctypes as C
+
+    from lurk_amd import _native as N
+
+    for case in load_cases()[:4]:
+        top = lair.Toplevel(case["source"], lurk_chips=case["lurk_chips"])
+        chip = lair.FuncChip.from_name(None, case["func"], top)
+        src = chip.trace_kernel_source()
+        assert "jit_row" in src and "jit_trace_staged" in src and "map[" not in src
+        log = C.create_string_buffer(8192)
+        size = N.lib.lurkhip_trace_compile_check(top.handle, chip.func_idx, log, 8192)
+        assert size > 1000, (case["name"], log.value.decode(errors="replace"))
+    # a match with several keys per arm and a default arm is one if / else-if chain
+    top = lair.Toplevel(load_cases()[0]["source"])
+    assert lair.FuncChip.from_name(None, "fib", top).trace_kernel_source().count("if (") >= 1
