@@ -42,7 +42,7 @@ LOG_BLOWUP = 1
 HBM_PEAK_GBS = 8000.0   # MI355X_MICROARCH.md: 8 TB/s spec (6.29 TB/s measured copy)
 VALU_FULL_RATE = 78.6   # T lane-instr/s: 256 CUs x 4 SIMD-32 x 2.4 GHz (MI355X_MICROARCH.md "Wave scheduling"); = 157.3 TFLOPS fp32 / 2
 VALU_HALF_RATE = 39.3   # mul-class instructions (v_mul_lo/hi, v_mad_u64_u32, VOP3 adds, ...) issue at half rate (measured)
-SPANS = ("trace_func", "commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit", "fri_query",
+SPANS = ("trace_all", "commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit", "fri_query",
          "lde", "merkle_leaves", "merkle_levels", "merkle_top")
 
 
@@ -178,7 +178,9 @@ def main():
 
     def step():
         # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shard
+        ctx.span_begin("trace_all")
         traces = machine.run_prepared(prepared)
+        ctx.span_end("trace_all")
         handle, root = machine.commit_shard(traces)
         # the transcript prefix: every shard's main root (RCCL all-gather of 8 lanes per rank) and the public values
         ch = prover.Challenger(ctx)
@@ -263,7 +265,7 @@ def main():
         [(lg + LOG_BLOWUP, 4) for _, air, lg, _, _ in prepared for _ in range(1 << air.log_quotient_degree)],
     ]
     max_lg = max(lg for _, _, lg, _, _ in prepared) + LOG_BLOWUP
-    rounds += [[(lf, 8)] for lf in range(max_lg - 1, LOG_BLOWUP - 1, -1)]  # FRI layers
+    rounds += [[(lf, 8)] for lf in range(max_lg - 1, 15, -1)]  # FRI layers of 2^16 leaves and more (smaller trees are not in the hashing spans)
     hash_bytes_step = sum(merkle_hash_bytes(r)[0] for r in rounds)
     hash_launches_step = sum(merkle_hash_bytes(r)[1] for r in rounds)
     hash_ms_step = (spans["merkle_leaves"][0] + spans["merkle_levels"][0]) / args.steps

@@ -82,10 +82,15 @@ int32_t lurkhip_timer_start(lurkhip_ctx* ctx);
 int32_t lurkhip_timer_stop(lurkhip_ctx* ctx, float* elapsed_ms);
 
 /* Per-span device timing with HIP events on the ctx's stream.  While enabled, the library brackets its
- * named stages ("lde", "merkle_leaves", "merkle_levels", "trace_func", ...) with event pairs;
- * lurkhip_profile_read waits for the stream and returns the summed milliseconds and the number of
- * brackets of one span since the last reset. */
+ * named stages with event pairs: on = 1 the stages of a proof ("commit_main", "permutation", "commit_perm", "quotient_all",
+ * "commit_quotient", "open", "fri_commit", "fri_query", and inside the commitments "lde", "merkle_leaves", "merkle_levels",
+ * "merkle_top" for trees of 2^16 leaves and more), on = 2 also the per-chip and per-small-tree spans ("trace_func", "perm_rows",
+ * "perm_scan", "quotient": every event record is a marker packet the next kernel waits behind, so these cost about a
+ * millisecond per proof).  lurkhip_profile_read waits for the stream and returns the summed milliseconds and the number of
+ * brackets of one span since the last reset; lurkhip_profile_span_begin / _end bracket a caller's own span. */
 int32_t lurkhip_profile_enable(lurkhip_ctx* ctx, int32_t on);
+int32_t lurkhip_profile_span_begin(lurkhip_ctx* ctx, const char* span);
+int32_t lurkhip_profile_span_end(lurkhip_ctx* ctx, const char* span);
 int32_t lurkhip_profile_reset(lurkhip_ctx* ctx);
 int32_t lurkhip_profile_read(lurkhip_ctx* ctx, const char* span, double* total_ms, int64_t* count);
 /* Returns cached device blocks of the ctx's allocation pool to the driver. */

@@ -72,6 +72,8 @@ SIGNATURES = {
     "lurkhip_timer_start": (_i32, [_p]),
     "lurkhip_timer_stop": (_i32, [_p, C.POINTER(C.c_float)]),
     "lurkhip_profile_enable": (_i32, [_p, _i32]),
+    "lurkhip_profile_span_begin": (_i32, [_p, C.c_char_p]),
+    "lurkhip_profile_span_end": (_i32, [_p, C.c_char_p]),
     "lurkhip_profile_reset": (_i32, [_p]),
     "lurkhip_profile_read": (_i32, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lurkhip_pool_trim": (_i32, [_p]),

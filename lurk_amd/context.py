@@ -82,8 +82,15 @@ class Context:
         self.check(N.lib.lurkhip_timer_stop(self.handle, C.byref(ms)))
         return float(ms.value)
 
-    def profile_enable(self, on: bool = True):
+    def profile_enable(self, on=True):
+        """on: False / True (the stage spans) / 2 (also the per-chip detail spans)."""
         self.check(N.lib.lurkhip_profile_enable(self.handle, int(on)))
+
+    def span_begin(self, name: str):
+        self.check(N.lib.lurkhip_profile_span_begin(self.handle, name.encode()))
+
+    def span_end(self, name: str):
+        self.check(N.lib.lurkhip_profile_span_end(self.handle, name.encode()))
 
     def profile_reset(self):
         self.check(N.lib.lurkhip_profile_reset(self.handle))

@@ -216,7 +216,9 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
     LH_TRY(make_cols(ctx, c, tallest, &cols, &tw));
-    span_begin(ctx, "merkle_leaves");
+    // the hashing spans of a small tree (the FRI layers below 2^16 leaves: a latency chain of a few launches each) are detail
+    const int span_level = c->log_max >= 16 ? 1 : 2;
+    span_begin(ctx, "merkle_leaves", span_level);
     LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
     const char* stage = "merkle_leaves";  // the span that is open
     // inner levels
@@ -240,7 +242,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
                 LH_TRY(make_cols(ctx, c, inj, &tc, &ti.w[t]));
                 ti.cols[t] = tc;
             }
-            span_switch(ctx, stage, "merkle_top");
+            span_switch(ctx, stage, "merkle_top", span_level);
             stage = "merkle_top";
             LH_TRY(merkle_top(ctx, params, children, n_parents << 1, ti));
             break;
@@ -249,12 +251,12 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         uint32_t iw = 0;
         if (!inject.empty()) LH_TRY(make_cols(ctx, c, inject, &icols, &iw));
         if (l == 1) {
-            span_switch(ctx, stage, "merkle_levels");
+            span_switch(ctx, stage, "merkle_levels", span_level);
             stage = "merkle_levels";
         }
         LH_TRY(merkle_level(ctx, params, children, n_parents, icols, iw, parents));
     }
-    span_end(ctx, stage);
+    span_end(ctx, stage, span_level);
     return LURKHIP_OK;
 }
 

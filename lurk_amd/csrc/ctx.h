@@ -55,6 +55,7 @@ struct lurkhip_ctx {
     int prep_turn = 0;
     // optional per-span HIP-event timing (lurkhip_profile_*)
     bool profiling = false;
+    int profile_level = 0;  // 1: the stage spans (a dozen event records per commitment), 2: also per-chip / per-small-tree spans
     struct Span {
         std::vector<std::pair<hipEvent_t, hipEvent_t>> pending;
         double total_ms = 0;
@@ -78,9 +79,11 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out);
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
 void pool_release(lurkhip_ctx* ctx, void* ptr);
 // span timing (no-ops unless profiling is enabled)
-void span_begin(lurkhip_ctx* ctx, const char* name);
-void span_end(lurkhip_ctx* ctx, const char* name);
-void span_switch(lurkhip_ctx* ctx, const char* from, const char* to);  // span_end(from) + span_begin(to) on one event
+// `level`: 1 = stage span (recorded whenever profiling is on), 2 = detail span (per chip, per small tree: only at profile level 2 --
+// every event record is a marker packet the next kernel waits behind, a few hundred of them cost a millisecond per proof)
+void span_begin(lurkhip_ctx* ctx, const char* name, int level = 1);
+void span_end(lurkhip_ctx* ctx, const char* name, int level = 1);
+void span_switch(lurkhip_ctx* ctx, const char* from, const char* to, int level = 1);  // span_end(from) + span_begin(to) on one event
 
 }  // namespace lurkhip
 

@@ -130,15 +130,15 @@ static hipEvent_t get_event(lurkhip_ctx* ctx) {
     return e;
 }
 
-void span_begin(lurkhip_ctx* ctx, const char* name) {
-    if (!ctx->profiling) return;
+void span_begin(lurkhip_ctx* ctx, const char* name, int level) {
+    if (!ctx->profiling || ctx->profile_level < level) return;
     hipEvent_t a = get_event(ctx), b = get_event(ctx);
     (void)hipEventRecord(a, ctx->stream);
     ctx->spans[name].pending.push_back({a, b});
 }
 
-void span_end(lurkhip_ctx* ctx, const char* name) {
-    if (!ctx->profiling) return;
+void span_end(lurkhip_ctx* ctx, const char* name, int level) {
+    if (!ctx->profiling || ctx->profile_level < level) return;
     auto& sp = ctx->spans[name];
     if (sp.pending.empty()) return;
     (void)hipEventRecord(sp.pending.back().second, ctx->stream);
@@ -146,11 +146,11 @@ void span_end(lurkhip_ctx* ctx, const char* name) {
 
 // ends `from` and begins `to` on one event: back-to-back spans (the stages of a Merkle tree) cost one record, not two --
 // every record is a marker packet the next kernel waits behind
-void span_switch(lurkhip_ctx* ctx, const char* from, const char* to) {
-    if (!ctx->profiling) return;
+void span_switch(lurkhip_ctx* ctx, const char* from, const char* to, int level) {
+    if (!ctx->profiling || ctx->profile_level < level) return;
     auto& f = ctx->spans[from];
     if (f.pending.empty()) {
-        span_begin(ctx, to);
+        span_begin(ctx, to, level);
         return;
     }
     hipEvent_t e = f.pending.back().second;
@@ -338,6 +338,22 @@ int32_t lurkhip_timer_stop(lurkhip_ctx* ctx, float* elapsed_ms) {
 int32_t lurkhip_profile_enable(lurkhip_ctx* ctx, int32_t on) {
     LH_CHECK_CTX(ctx);
     ctx->profiling = on != 0;
+    ctx->profile_level = on < 0 ? 0 : on;
+    return LURKHIP_OK;
+}
+
+// a caller's own span on the context's stream (e.g. around the trace generation of all chips of a shard)
+int32_t lurkhip_profile_span_begin(lurkhip_ctx* ctx, const char* span) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, span != nullptr, "null span name");
+    span_begin(ctx, span);
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_profile_span_end(lurkhip_ctx* ctx, const char* span) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, span != nullptr, "null span name");
+    span_end(ctx, span);
     return LURKHIP_OK;
 }
 

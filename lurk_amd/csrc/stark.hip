@@ -453,7 +453,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     const uint32_t n_pows = a->max_tuple + 2, n_inter = a->air.num_interactions();
     LH_TRY(pool_alloc(ctx, (size_t)n_pows * 32 + (size_t)std::max(n_inter, 1u) * 16, &pows));
     uint32_t* starts = (uint32_t*)pows + (size_t)n_pows * 8;
-    span_begin(ctx, "perm_rows");
+    span_begin(ctx, "perm_rows", 2);
     int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
     if (s == LURKHIP_OK && n_inter)
         hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, (const uint32_t*)pows, alpha, starts);
@@ -487,9 +487,9 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         }
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
-    span_switch(ctx, "perm_rows", "perm_scan");
+    span_switch(ctx, "perm_rows", "perm_scan", 2);
     if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)perm_w * 4, height);
-    span_end(ctx, "perm_scan");
+    span_end(ctx, "perm_scan", 2);
     pool_release(ctx, pows);
     if (s == LURKHIP_OK && cumulative_sum_m) {
         LH_HIP(ctx, hipMemcpyAsync(cumulative_sum_m->c, out_dev + ((size_t)height * perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
@@ -586,7 +586,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.wp = lay.wp;
         q.staged = lay.staged ? 1 : 0;
         const uint32_t rows = 1u << q.log_q;
-        span_begin(ctx, "quotient");
+        span_begin(ctx, "quotient", 2);
         const JitKernels jit = jit_of(ctx, a);
         if (jit.quotient) {
             void* params[] = {&q};
@@ -596,7 +596,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         } else {
             hipLaunchKernelGGL(k_quotient, dim3((rows + 63) / 64), dim3(64 * lay.parts.n_parts), lay.lds_bytes, ctx->stream, q);
         }
-        span_end(ctx, "quotient");
+        span_end(ctx, "quotient", 2);
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_quotient launch failed");
     }
     pool_release(ctx, scratch);

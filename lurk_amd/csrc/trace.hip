@@ -256,7 +256,7 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     TraceArgs a{program_dev, args_dev, outputs_dev, provides_dev, depths_dev, (const RowMeta*)meta_dev, stream_dev, out_dev,
                 n_real, height, nonce_start, repr == LURKHIP_REPR_CANONICAL};
     dim3 grid((height + TBLOCK - 1) / TBLOCK), block(TBLOCK);
-    lurkhip::span_begin(ctx, "trace_func");
+    lurkhip::span_begin(ctx, "trace_func", 2);
     const size_t lds = staged ? tile_words * 4 : 0;
     // the function's compiled row kernel, when lurkhip_trace_compile has produced one for this program (named by its hash)
     const uint64_t prog_hash = (uint64_t)program_host_header[TH_HASH_LO] | ((uint64_t)program_host_header[TH_HASH_HI] << 32);
@@ -264,7 +264,7 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     if (jit.module) {
         void* params[] = {&a};
         const hipError_t le = hipModuleLaunchKernel(staged ? jit.staged : jit.flat, grid.x, 1, 1, TBLOCK, 1, 1, (unsigned)lds, ctx->stream, params, nullptr);
-        lurkhip::span_end(ctx, "trace_func");
+        lurkhip::span_end(ctx, "trace_func", 2);
         if (le != hipSuccess) return lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "launch of the compiled trace kernel failed: %s", hipGetErrorString(le));
         return LURKHIP_OK;
     }
@@ -278,7 +278,7 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     else if (max_vars <= 1024) LH_TRACE_LAUNCH(1024);
     else LH_TRACE_LAUNCH(4096);
 #undef LH_TRACE_LAUNCH
-    lurkhip::span_end(ctx, "trace_func");
+    lurkhip::span_end(ctx, "trace_func", 2);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
