@@ -242,8 +242,8 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
 
-    # dominant kernels: the Merkle hashing launches (k_leaves: leaf sponges; k_level: 2-to-1 compressions + the sponges of
-    # the shorter matrices injected at their level).  Algorithmic bytes: a leaf row reads its w*4 bytes and
+    # dominant kernels: the Merkle hashing launches (k_row_sponges: the sponges of the leaves and of the shorter matrices injected
+    # at their levels, one launch per tree; k_level_digests / k_level_coop: the 2-to-1 compressions).  Algorithmic bytes: a leaf row reads its w*4 bytes and
     # writes a 32-byte digest; a level node reads two digests (64 B) + the injected rows and writes 32 B.  `achieved` =
     # bytes of all those launches in one step / their summed HIP-event time (launch-weighted average).
     def merkle_hash_bytes(mats):
@@ -454,7 +454,7 @@ def main():
             },
             "roofline": {
                 "bound": "hbm",
-                "kernel": "Merkle hashing (k_leaves + k_level + k_level_coop), all launches of a step",
+                "kernel": "Merkle hashing (k_row_sponges + k_level_digests + k_level_coop; trees of 2^16 leaves and more), all launches of a step",
                 "achieved": achieved,
                 "peak": HBM_PEAK_GBS,
                 "unit": "GB/s",

@@ -86,6 +86,25 @@ int32_t merkle_leaves(lurkhip_ctx* ctx, const P16Params* params_dev, const LeafC
 // parents[i] = compress(children[2i], children[2i+1]); if inject_cols: then compress(that, hash(row i))
 int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
                      const LeafCol* inject_cols_dev, uint32_t inject_w, uint32_t* parents);
+// The row sponges of several height groups of one tree in ONE launch (a group = the matrices of one height, concatenated:
+// the leaves, or the rows injected at a level), longest rows first: a level kernel that hashes its injected rows itself runs
+// 40 permutations per lane for the 2^20-row group of a fib shard, sixteen such waves per SIMD at five or six resident -- the
+// last ones alone on the chip; hashed ahead of the levels, all groups share one grid whose tail is made of the shortest rows.
+// out[g] receives n_rows[g] digests of 8 words.
+constexpr int SPONGE_MAX_GROUPS = 12;
+constexpr size_t MERKLE_COOP_MAX_PARENTS = 16384;  // levels of at most this many parents run lane-cooperatively (merkle.hip)
+struct SpongeGroups {
+    int n = 0;
+    const LeafCol* cols[SPONGE_MAX_GROUPS];
+    uint32_t total_w[SPONGE_MAX_GROUPS];
+    uint64_t n_rows[SPONGE_MAX_GROUPS];
+    uint32_t* out[SPONGE_MAX_GROUPS];
+    uint32_t first_block[SPONGE_MAX_GROUPS + 1];  // filled by merkle_row_sponges
+};
+int32_t merkle_row_sponges(lurkhip_ctx* ctx, const P16Params* params_dev, SpongeGroups groups);
+// parents[i] = compress(children[2i], children[2i+1]); if inject_digests: then compress(that, inject_digests[i])
+int32_t merkle_level_digests(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
+                             const uint32_t* inject_digests, uint32_t* parents);
 // collapses the levels below `n` nodes down to the root inside one workgroup (n <= 2048)
 // matrices injected at the levels merkle_top collapses: entry t describes the rows absorbed into the parents of step t
 // (n >> (t + 1) of them); cols[t] == nullptr where nothing is injected

@@ -2,6 +2,8 @@
 //
 // Replaces (S1 in SURVEY.md 8a; third-party): p3 TwoAdicFriPcs::commit(Vec<(domain, RowMajorMatrix)>)
 // as called by sphinx's prover for the main, permutation and quotient traces [UPSTREAM-RECALL].
+#include <stdlib.h>
+
 #include <algorithm>
 #include <map>
 #include <numeric>
@@ -190,7 +192,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     // Bound the column-table cache HERE, before this tree hands out any table: make_cols results are kept (TopInject) until the
     // launch that reads them is enqueued, so nothing may be evicted between the first make_cols of a tree and its last launch.
     // The same invariant covers pool_alloc's out-of-memory path (ctx.hip), which also drops the tables: the only pool_alloc of
-    // a tree (the digests) comes before its first make_cols.
+    // a tree (the digests, then the digest buffers of the row groups hashed ahead of the levels) comes before its first make_cols.
     if (ctx->leafcol_tables.size() >= 1024) {
         LH_HIP(ctx, stream_wait(ctx));
         for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
@@ -213,16 +215,80 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     std::vector<int> tallest;
     for (int m : order)
         if (c->log_h[m] == c->log_max) tallest.push_back(m);
-    LeafCol* cols = nullptr;
-    uint32_t tw = 0;
-    LH_TRY(make_cols(ctx, c, tallest, &cols, &tw));
     // the hashing spans of a small tree (the FRI layers below 2^16 leaves: a latency chain of a few launches each) are detail
     const int span_level = c->log_max >= 16 ? 1 : 2;
+    // Row sponges ahead of the levels: the leaves and every group of rows injected at a level of more than COOP_MAX_PARENTS
+    // parents (the levels below that hash their few rows lane-cooperatively, merkle.hip) share ONE launch, longest rows first
+    // (merkle_row_sponges); the levels then only compress.  LURKHIP_MERKLE_FUSED=0: the round-1 schedule, every level hashing its own rows.
+    const char* fused_env = getenv("LURKHIP_MERKLE_FUSED");
+    const bool fused = (fused_env == nullptr || atoi(fused_env) != 0) && n_leaves > MERKLE_COOP_MAX_PARENTS;
+    std::vector<uint32_t*> inj_digests(c->log_max + 1, nullptr);  // by level
+    std::vector<void*> scratch;
+    auto drop_scratch = [&]() {
+        for (void* p : scratch) pool_release(ctx, p);  // stream-ordered: reusable by later work only
+    };
+    // (the digest buffers of the injected groups are allocated before the first make_cols: see the invariant above)
+    if (fused)
+        for (int l = 1, groups = 1; l <= c->log_max && groups < SPONGE_MAX_GROUPS; l++) {
+            const size_t n_parents = n_leaves >> l;
+            if (n_parents <= MERKLE_COOP_MAX_PARENTS) break;
+            bool any = false;
+            for (int m : order) any = any || c->log_h[m] == c->log_max - l;
+            if (!any) continue;
+            void* d = nullptr;
+            const int32_t st = pool_alloc(ctx, n_parents * 8 * sizeof(uint32_t), &d);
+            if (st != LURKHIP_OK) {
+                drop_scratch();
+                return st;
+            }
+            scratch.push_back(d);
+            inj_digests[l] = (uint32_t*)d;
+            groups++;
+        }
+    LeafCol* cols = nullptr;
+    uint32_t tw = 0;
+    {
+        const int32_t st = make_cols(ctx, c, tallest, &cols, &tw);
+        if (st != LURKHIP_OK) {
+            drop_scratch();
+            return st;
+        }
+    }
     span_begin(ctx, "merkle_leaves", span_level);
-    LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
+    if (fused) {
+        SpongeGroups g{};
+        g.cols[0] = cols;
+        g.total_w[0] = tw;
+        g.n_rows[0] = n_leaves;
+        g.out[0] = c->digests;
+        g.n = 1;
+        int32_t st = LURKHIP_OK;
+        for (int l = 1; l <= c->log_max && st == LURKHIP_OK; l++) {
+            if (!inj_digests[l]) continue;
+            std::vector<int> inject;
+            for (int m : order)
+                if (c->log_h[m] == c->log_max - l) inject.push_back(m);
+            LeafCol* icols = nullptr;
+            uint32_t iw = 0;
+            st = make_cols(ctx, c, inject, &icols, &iw);
+            g.cols[g.n] = icols;
+            g.total_w[g.n] = iw;
+            g.n_rows[g.n] = n_leaves >> l;
+            g.out[g.n] = inj_digests[l];
+            g.n++;
+        }
+        if (st == LURKHIP_OK) st = merkle_row_sponges(ctx, params, g);
+        if (st != LURKHIP_OK) {
+            drop_scratch();
+            return st;
+        }
+    } else {
+        LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
+    }
     const char* stage = "merkle_leaves";  // the span that is open
     // inner levels
-    for (int l = 1; l <= c->log_max; l++) {
+    int32_t status = LURKHIP_OK;
+    for (int l = 1; l <= c->log_max && status == LURKHIP_OK; l++) {
         const size_t n_parents = n_leaves >> l;
         const int lh = c->log_max - l;
         std::vector<int> inject;
@@ -233,29 +299,36 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         if ((n_parents << 1) <= TOP_NODES) {
             // finish the tree in one workgroup (wider levels are faster spread over the CUs)
             TopInject ti{};
-            for (int t = 0; l + t <= c->log_max; t++) {
+            for (int t = 0; l + t <= c->log_max && status == LURKHIP_OK; t++) {
                 std::vector<int> inj;
                 for (int m : order)
                     if (c->log_h[m] == lh - t) inj.push_back(m);
                 if (inj.empty()) continue;
                 LeafCol* tc = nullptr;
-                LH_TRY(make_cols(ctx, c, inj, &tc, &ti.w[t]));
+                status = make_cols(ctx, c, inj, &tc, &ti.w[t]);
                 ti.cols[t] = tc;
             }
+            if (status != LURKHIP_OK) break;
             span_switch(ctx, stage, "merkle_top", span_level);
             stage = "merkle_top";
-            LH_TRY(merkle_top(ctx, params, children, n_parents << 1, ti));
+            status = merkle_top(ctx, params, children, n_parents << 1, ti);
             break;
         }
-        LeafCol* icols = nullptr;
-        uint32_t iw = 0;
-        if (!inject.empty()) LH_TRY(make_cols(ctx, c, inject, &icols, &iw));
         if (l == 1) {
             span_switch(ctx, stage, "merkle_levels", span_level);
             stage = "merkle_levels";
         }
-        LH_TRY(merkle_level(ctx, params, children, n_parents, icols, iw, parents));
+        if (fused && n_parents > MERKLE_COOP_MAX_PARENTS && (inject.empty() || inj_digests[l])) {
+            status = merkle_level_digests(ctx, params, children, n_parents, inj_digests[l], parents);
+            continue;
+        }
+        LeafCol* icols = nullptr;
+        uint32_t iw = 0;
+        if (!inject.empty()) status = make_cols(ctx, c, inject, &icols, &iw);
+        if (status == LURKHIP_OK) status = merkle_level(ctx, params, children, n_parents, icols, iw, parents);
     }
+    drop_scratch();
+    if (status != LURKHIP_OK) return status;
     span_end(ctx, stage, span_level);
     return LURKHIP_OK;
 }

@@ -19,6 +19,7 @@
 #include <string.h>
 
 #include <string>
+#include <utility>
 
 #include "commit.h"
 #include "p16_coop.h"
@@ -30,7 +31,7 @@ namespace {
 
 constexpr int MBLOCK = 256;
 // levels of at most this many parents run lane-cooperatively (above it one permutation per lane already fills the SIMDs)
-constexpr size_t COOP_MAX_PARENTS = 16384;
+constexpr size_t COOP_MAX_PARENTS = MERKLE_COOP_MAX_PARENTS;
 
 // (inlined at its three call sites of k_level on purpose: as a call the state goes through scratch and the step loses 3 ms)
 __device__ __forceinline__ void perm16(uint32_t (&s)[16], const P16Params* __restrict__ p) {
@@ -126,6 +127,41 @@ __global__ __launch_bounds__(MBLOCK) void k_level(const P16Params* __restrict__ 
         sponge_row(t, p, inject_cols, inject_w, i);
 #pragma unroll
         for (int k = 0; k < 8; k++) s[8 + k] = t[k];
+        perm16(s, p);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(parents + i * 8);
+    dst[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// several height groups' row sponges in one grid (merkle_row_sponges): the block's group by its first_block range
+__global__ __launch_bounds__(MBLOCK) void k_row_sponges(const P16Params* __restrict__ p, SpongeGroups g) {
+    int k = 0;
+    while (k + 1 < g.n && blockIdx.x >= g.first_block[k + 1]) k++;
+    const size_t row = (size_t)(blockIdx.x - g.first_block[k]) * MBLOCK + threadIdx.x;
+    if (row >= g.n_rows[k]) return;
+    uint32_t s[16];
+#pragma unroll
+    for (int i = 0; i < 16; i++) s[i] = 0;
+    sponge_row(s, p, g.cols[k], g.total_w[k], row);
+    uint4* dst = reinterpret_cast<uint4*>(g.out[k] + row * 8);
+    dst[0] = make_uint4(s[0], s[1], s[2], s[3]);
+    dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
+}
+
+// a level whose injected rows were hashed ahead (k_row_sponges): two permutations per parent at most
+__global__ __launch_bounds__(MBLOCK) void k_level_digests(const P16Params* __restrict__ p, const uint32_t* __restrict__ children,
+                                                           size_t n_parents, const uint32_t* __restrict__ inject, uint32_t* __restrict__ parents) {
+    size_t i = (size_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (i >= n_parents) return;
+    uint32_t s[16];
+    load_pair(children, i, s);
+    perm16(s, p);
+    if (inject) {
+        const uint4* src = reinterpret_cast<const uint4*>(inject + i * 8);
+        const uint4 a = src[0], b = src[1];
+        s[8] = a.x; s[9] = a.y; s[10] = a.z; s[11] = a.w;
+        s[12] = b.x; s[13] = b.y; s[14] = b.z; s[15] = b.w;
         perm16(s, p);
     }
     uint4* dst = reinterpret_cast<uint4*>(parents + i * 8);
@@ -252,6 +288,38 @@ int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32
         hipLaunchKernelGGL(k_level, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents,
                            inject_cols_dev, inject_w, parents);
     }
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t merkle_row_sponges(lurkhip_ctx* ctx, const P16Params* params_dev, SpongeGroups g) {
+    if (g.n == 0) return LURKHIP_OK;
+    LH_ARG(ctx, g.n <= SPONGE_MAX_GROUPS, "too many height groups for one sponge launch");
+    // longest rows first (most permutations per lane): the grid's tail is then made of the cheapest lanes
+    for (int a = 1; a < g.n; a++)
+        for (int b = a; b > 0 && (g.total_w[b] + 7) / 8 > (g.total_w[b - 1] + 7) / 8; b--) {
+            std::swap(g.cols[b], g.cols[b - 1]);
+            std::swap(g.total_w[b], g.total_w[b - 1]);
+            std::swap(g.n_rows[b], g.n_rows[b - 1]);
+            std::swap(g.out[b], g.out[b - 1]);
+        }
+    size_t blocks = 0;
+    for (int k = 0; k < g.n; k++) {
+        g.first_block[k] = (uint32_t)blocks;
+        blocks += (g.n_rows[k] + MBLOCK - 1) / MBLOCK;
+    }
+    LH_ARG(ctx, blocks <= 0x7fffffffu, "too many rows for one sponge launch");
+    g.first_block[g.n] = (uint32_t)blocks;
+    hipLaunchKernelGGL(k_row_sponges, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, g);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t merkle_level_digests(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32_t* children, size_t n_parents,
+                             const uint32_t* inject_digests, uint32_t* parents) {
+    const size_t blocks = (n_parents + MBLOCK - 1) / MBLOCK;
+    hipLaunchKernelGGL(k_level_digests, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents, inject_digests,
+                       parents);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
