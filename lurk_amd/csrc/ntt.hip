@@ -97,6 +97,26 @@ __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
     dif_butterfly(x.y, y.y, tw);
 }
 
+// Row t of a tile column lives at element swz(t) of the column: t with its low five bits XORed by a linear function of bits
+// 5..7.  A column is walked with strides of 2^S_BOT elements by the lanes of a wave (stage groups below), and 32 elements of
+// 8 bytes are one sweep of the 64 LDS banks: unswizzled, the 16-element runs of the second group of a 1024-row tile start 128
+// elements apart (the same banks: 4-way conflicts), the third and fourth groups collide 8-way -- the PMC counted 2.5 bank-conflict
+// cycles per active LDS cycle, a fifth of the pass.  With A = {bit5 -> 0b00101, bit6 -> 0b01010, bit7 -> 0b10100} the low five
+// bits are a bijection of every group's 32-lane index set ({0-4}, {0-3,7}, {0,1,4,5,6}, {2-6} for 2^10 rows; {0-5}, {0-2,6,7},
+// {3-7} for 2^9), and the map is GF(2)-linear, so an item's rows t0 ^ (b << S_BOT) sit at swz(t0) ^ (a compile-time constant).
+// Tiles of 2^10 rows keep the plain layout: their kernel stages sixteen rows per thread at 118-128 VGPRs (the cap of a
+// 1024-thread workgroup), and the XOR-ed addresses -- no longer compile-time offsets from one base register -- pushed 60-77
+// registers into scratch there (LDE of 2^20 x 78: 1.73 -> 2.30 ms although the bank-conflict cycles fell by 72 %).
+#ifndef LURK_NTT_SWZ_MAX_LOG_R
+#define LURK_NTT_SWZ_MAX_LOG_R 9
+#endif
+template <int LOG_R>
+__host__ __device__ constexpr int swz(int t) {
+    if (LOG_R > LURK_NTT_SWZ_MAX_LOG_R) return t;
+    const int x = (t >> 5) & 7;
+    return t ^ x ^ (x << 2);
+}
+
 // G consecutive DIF stages S_TOP .. S_TOP-G+1 of one column (T = one or two matrix columns) of the LDS tile.  The tile is
 // stored column-major, col[t] = tile row t, so the 2^G rows t0 | b << S_BOT of an item sit at compile-time offsets from
 // one address, and so do the item's twiddles tw[(1 << st) + t_lo]: no per-element index arithmetic.  The thread's slot
@@ -111,11 +131,11 @@ __device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t*
     for (int q = slot; q < ITEMS; q += SLOTS) {
         const int low = q & ((1 << S_BOT) - 1);
         const int t0 = ((q >> S_BOT) << (S_TOP + 1)) | low;
-        T* __restrict__ p = col + t0;
+        const int s0 = swz<LOG_R>(t0);
         const uint32_t* __restrict__ twp = tw_l + low;
         T x[M];
 #pragma unroll
-        for (int b = 0; b < M; b++) x[b] = p[b << S_BOT];
+        for (int b = 0; b < M; b++) x[b] = col[s0 ^ swz<LOG_R>(b << S_BOT)];
 #pragma unroll
         for (int g = G - 1; g >= 0; g--) {
             uint32_t tw[1 << (G - 1)];
@@ -128,7 +148,7 @@ __device__ __forceinline__ void stage_group(T* __restrict__ col, const uint32_t*
             }
         }
 #pragma unroll
-        for (int b = 0; b < M; b++) p[b << S_BOT] = x[b];
+        for (int b = 0; b < M; b++) col[s0 ^ swz<LOG_R>(b << S_BOT)] = x[b];
     }
 }
 
@@ -272,7 +292,7 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
                 T x = v[k];
                 if (a.in_canonical) x = to_monty_elem(x);
                 if constexpr (SCALE) x = scale_elem(x, sc[k]);
-                my_col[slot + (k << LOG_SLOTS)] = x;
+                my_col[swz<LOG_R>(slot + (k << LOG_SLOTS))] = x;
             }
         }
 #pragma unroll
@@ -295,7 +315,7 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
             for (int k0 = 0; k0 < U; k0 += UB) {
                 T o[UB];
 #pragma unroll
-                for (int k = 0; k < UB; k++) o[k] = my_col[slot + ((k0 + k) << LOG_SLOTS)];
+                for (int k = 0; k < UB; k++) o[k] = my_col[swz<LOG_R>(slot + ((k0 + k) << LOG_SLOTS))];
 #pragma unroll
                 for (int k = 0; k < UB; k++) {
                     const int t = slot + ((k0 + k) << LOG_SLOTS);
