@@ -386,6 +386,77 @@ __global__ __launch_bounds__(64) void k_reduce_openings_stream(ReduceArgs a) {
     }
 }
 
+// Quad version of the streaming kernel (17 <= w <= 128): a tile is 16 rows, four lanes share a row (columns c = part, part + 4,
+// ...) and meet through two quad-permute additions.  The 64-rows-per-wave kernel above needs 66 * NV words of LDS and NV >= w
+// staging registers per lane: seven single-wave workgroups per CU at w = 78, each walking its row through LDS with nothing
+// else resident to hide the latency (12 T lane-instr/s, 39 % of the cycles waiting: 2.1 TB/s).  Here a lane stages w / 4 words,
+// a tile is a quarter of the LDS, and four times as many waves are resident.
+constexpr int DPP_QUAD_XOR1 = 0xB1, DPP_QUAD_XOR2 = 0x4E;  // quad_perm [1,0,3,2] / [2,3,0,1]
+template <int NV, bool BIG>
+__global__ __launch_bounds__(64) void k_reduce_openings_quad(ReduceArgs a) {
+    extern __shared__ uint32_t tile[];
+    using idx_t = typename std::conditional<BIG, size_t, uint32_t>::type;
+    const uint32_t lane = threadIdx.x;
+    const uint32_t n_tiles = (a.m_rows + 15u) / 16u;
+    const idx_t total = (idx_t)a.m_rows * (idx_t)a.w;
+    uint32_t v[NV];
+    auto fetch = [&](uint32_t t) {
+        const idx_t base = (idx_t)t * 16u * a.w + lane;
+        const idx_t lim = total - 1;
+#pragma unroll
+        for (int k = 0; k < NV; k++) {
+            idx_t e = base + (idx_t)(k * 64);  // words past the tile belong to the next one (or are clamped): read, never used
+            e = e < lim ? e : lim;
+            v[k] = a.mat[e];
+        }
+    };
+    uint32_t t = blockIdx.x;
+    if (t >= n_tiles) return;
+    fetch(t);
+    uint32_t* __restrict__ apw = tile + (NV * 66 + 8);
+    for (uint32_t e = lane; e < 4u * a.w; e += 64u) apw[e] = a.alpha_pows[8u * (e >> 2) + (e & 3u)];
+    const uint32_t wbase = lane + (lane >> 5);
+    const uint32_t r = lane >> 2, part = lane & 3u;
+    for (; t < n_tiles; t += gridDim.x) {
+#pragma unroll
+        for (int k = 0; k < NV; k++) tile[wbase + (uint32_t)k * 66u] = v[k];
+        __syncthreads();
+        const uint32_t t_next = t + gridDim.x < n_tiles ? t + gridDim.x : t;
+        fetch(t_next);
+        const uint32_t s = t * 16u + r;
+        LazyEf rr;
+        rr.zero();
+        uint32_t e = r * a.w + part;
+        for (uint32_t c = part; c < a.w; c += 4, e += 4) {
+            const uint4 q = *reinterpret_cast<const uint4*>(apw + 4 * c);
+            const int32_t pw[4] = {(int32_t)q.x, (int32_t)q.y, (int32_t)q.z, (int32_t)q.w};
+            rr.add_base_v(tile[e + (e >> 5)], pw);
+        }
+        ef x = rr.value();
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            x.c[k] = bb::add(x.c[k], dpp<DPP_QUAD_XOR1>(x.c[k]));
+            x.c[k] = bb::add(x.c[k], dpp<DPP_QUAD_XOR2>(x.c[k]));
+        }
+        // the tail, apow_p * (x - ys_p) * d_p[s]: lane 0 of the quad takes the first point, lane 1 the second, they meet in lane 0
+        const bool second = (part & 1u) != 0;
+        const size_t sr = s < a.m_rows ? s : a.m_rows - 1;
+        const uint32_t* __restrict__ dp = second && a.d1 ? a.d1 : a.d0;
+        ef ys, ap;
+#pragma unroll
+        for (int k = 0; k < 4; k++) {
+            ys.c[k] = second ? a.ys1.c[k] : a.ys0.c[k];
+            ap.c[k] = second ? a.apow1.c[k] : a.apow0.c[k];
+        }
+        ef term = bb::ef_mul(ap, bb::ef_mul(bb::ef_sub(x, ys), ef_load(dp + 4 * sr)));
+        if (second && !a.d1) term = bb::ef_zero();
+#pragma unroll
+        for (int k = 0; k < 4; k++) term.c[k] = bb::add(term.c[k], dpp<DPP_QUAD_XOR1>(term.c[k]));
+        if (part == 0 && s < a.m_rows) ef_store(a.ro + 4 * (size_t)s, bb::ef_add(ef_load(a.ro + 4 * (size_t)s), term));
+        __syncthreads();  // the tile is free for the next one
+    }
+}
+
 // Wide matrices (w > 128: eval_builtin_expr's 148 columns, the hash chips' 493 / 655 / 815): the row is cut into column
 // slices of at most 128 words and a workgroup walks (tile, slice) items the way the streaming kernel walks tiles -- the
 // next item's words in flight while the current one is reduced --, the words of slice sl of the 64-row tile being
@@ -715,6 +786,31 @@ int32_t column_dot_finish(lurkhip_ctx* ctx, const std::vector<DotJob>& jobs, uin
 int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t m_rows, const uint32_t* alpha_pows,
                         const uint32_t* alpha_pows_centred, const uint32_t* d0, const uint32_t* d1, const bb::ef& ys0,
                         const bb::ef& ys1, const bb::ef& apow0, const bb::ef& apow1, uint32_t* ro) {
+    if (w > 16 && w <= 128 && alpha_pows_centred && getenv("LURKHIP_OPENINGS_NO_QUAD") == nullptr) {
+        // four lanes per row, 16-row tiles (k_reduce_openings_quad)
+        ReduceArgs a{mat, w, m_rows, alpha_pows_centred, d0, d1, ys0, ys1, apow0, apow1, ro, 1};
+        const uint32_t n_tiles = (m_rows + 15) / 16;
+        const bool big = (size_t)m_rows * w >= ((size_t)1 << 30) || getenv("LURKHIP_OPENINGS_FORCE_64BIT") != nullptr;
+        auto launch = [&](auto kernel, auto kernel_big, int nv) {
+            const size_t lds = ((size_t)nv * 66 + 8 + 4 * (size_t)w) * 4;
+            const unsigned per_cu = (unsigned)std::max<size_t>(1, std::min<size_t>(32, (160 * 1024) / (lds + 512)));
+            const unsigned blocks = (unsigned)std::min<size_t>(n_tiles, (size_t)per_cu * ctx->num_cus);
+            if (big) hipLaunchKernelGGL(kernel_big, dim3(blocks), dim3(64), lds, ctx->stream, a);
+            else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, ctx->stream, a);
+        };
+#define LH_RQ(NV) launch(k_reduce_openings_quad<NV, false>, k_reduce_openings_quad<NV, true>, NV)
+        const uint32_t need = (16 * w + 63) / 64;  // words per lane and tile
+        if (need <= 8) LH_RQ(8);
+        else if (need <= 12) LH_RQ(12);
+        else if (need <= 16) LH_RQ(16);
+        else if (need <= 20) LH_RQ(20);
+        else if (need <= 24) LH_RQ(24);
+        else if (need <= 28) LH_RQ(28);
+        else LH_RQ(32);
+#undef LH_RQ
+        LH_HIP(ctx, hipGetLastError());
+        return LURKHIP_OK;
+    }
     if (w <= 128 && alpha_pows_centred) {
         ReduceArgs a{mat, w, m_rows, alpha_pows_centred, d0, d1, ys0, ys1, apow0, apow1, ro, 1};
         const uint32_t n_tiles = (m_rows + 63) / 64;
