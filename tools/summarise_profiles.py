@@ -40,7 +40,7 @@ with open(f"profiles/{prefix}_pmc_hbm_per_kernel.csv", "w") as f:
     f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
     for k in sorted(res["FETCH_SIZE"][0], key=lambda k: -(res["FETCH_SIZE"][0][k] + res["WRITE_SIZE"][0][k])):
         f.write(f"{k},{res['FETCH_SIZE'][1][k]},{res['FETCH_SIZE'][0][k]:.0f},{res['WRITE_SIZE'][0][k]:.0f}\n")
-HASH = ("k_level", "k_level_coop", "k_leaves")  # the launches inside bench.py's merkle_leaves + merkle_levels spans
+HASH = ("k_row_sponges", "k_level_digests", "k_level_coop", "k_level", "k_leaves", "k_leaves_coop")  # the hashing launches (bench.py's merkle_leaves + merkle_levels spans; the PMC pass also counts the small FRI-layer trees)
 F = sum(res["FETCH_SIZE"][0][k] for k in HASH) * 1024
 W = sum(res["WRITE_SIZE"][0][k] for k in HASH) * 1024
 
