@@ -79,7 +79,11 @@ def test_streamed_proof_equals_machine_prove(ctx):
     cfg = lair.ShardingConfig(1 << 8)
     m = prover.Machine(ctx, top, mix.entry, len(pv))
     m.setup()
-    want = m.prove(q, cfg, num_queries=4, pow_bits=2)
+    want = m.prove(q, cfg, num_queries=4, pow_bits=2, lanes=1)  # one shard at a time, regenerated in phase 2
+    two = m.prove(q, cfg, num_queries=4, pow_bits=2)            # the default: two shards in flight in phase 2 (prove_lanes)
+    assert len(two) == len(want)
+    for a, b in zip(two, want):
+        assert np.array_equal(a.words, b.words)
     with lurk_amd.Context(0) as ctx2:
         stats = {}
         got = prover.prove_streamed(m, q, cfg, num_queries=4, pow_bits=2, input_ctx=ctx2, stats=stats)

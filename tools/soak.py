@@ -43,4 +43,53 @@ with lurk_amd.Context(0) as ctx, lurk_amd.Context(0) as ctx2:
     m1.close()
     m2.close()
 print(f"{rounds} rounds, {bad} differing proofs, {time.time() - t0:.1f} s")
-sys.exit(1 if bad else 0)
+bad_total = bad
+
+# ---- the bench's step (device-resident inputs, compiled trace / AIR kernels, short chips' traces on a side stream, one sponge launch
+# per tree) and the streamed multi-shard prover (staging context, two prove lanes), on a small fib-mix machine
+from lurk_amd.programs import lurk_mix as lm  # noqa: E402
+
+mix_rounds = max(10, rounds * 3)
+mix = lm.fib_mix(1 << 13)
+top = lair.Toplevel(mix.source, lurk_chips=True)
+q = lair.QueryRecord(top)
+top.execute(top.func_index(mix.entry), mix.main_args, q)
+pv = q.expect_public_values()
+t0 = time.time()
+with lurk_amd.Context(0) as ctx, lurk_amd.Context(0) as ctx_in:
+    m = prover.Machine(ctx, top, mix.entry, len(pv))
+    vk = m.setup()
+    shard = lair.Shard.new(q)
+    prepared = m.prepare_shard(shard)
+    m.compile_airs(prepared, min_log_rows=10)
+
+    def step():
+        traces = m.run_prepared(prepared)
+        handle, root = m.commit_shard(traces)
+        ch = prover.Challenger(ctx)
+        ch.observe(vk)
+        ch.observe([0])
+        ch.observe(root)
+        ch.observe(pv)
+        w = m.prove_shard(handle, ch, pv, num_queries=8, pow_bits=4, parse=False)
+        m.free_shard(handle)
+        return w
+
+    want = step()
+    bad = 0
+    for r in range(mix_rounds):
+        if not np.array_equal(step(), want):
+            bad += 1
+            print(f"fib-mix round {r}: proof differs")
+    cfg = lair.ShardingConfig(1 << 11)
+    ref = [p.words.copy() for p in m.prove(q, cfg, num_queries=8, pow_bits=4, lanes=1)]
+    for r in range(max(5, rounds // 3)):
+        for name, got in (("prove, two lanes", m.prove(q, cfg, num_queries=8, pow_bits=4)),
+                          ("streamed", prover.prove_streamed(m, q, cfg, num_queries=8, pow_bits=4, input_ctx=ctx_in))):
+            for i, (a, b) in enumerate(zip(got, ref)):
+                if not np.array_equal(a.words, b):
+                    bad += 1
+                    print(f"fib-mix sharded round {r} {name}: shard {i} differs")
+    m.close()
+print(f"fib-mix: {mix_rounds} steps + {max(5, rounds // 3)} sharded rounds x 2 variants x {len(ref)} shards, {bad} differing, {time.time() - t0:.1f} s")
+sys.exit(1 if bad_total + bad else 0)
