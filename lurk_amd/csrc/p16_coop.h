@@ -49,6 +49,10 @@ __device__ __forceinline__ uint32_t coop_perm16(uint32_t x_in, const P16Params* 
     int32_t x = coop_external_layer((int32_t)x_in);
 #pragma unroll 1
     for (int r = 0; r < 4; r++) x = coop_external_layer(coop_sbox(x, p->ext_rc_mp[r * 16 + j]));
+    // (Measured and rejected in round 2: every lane carrying a copy of element 0 and running its S-box itself, so that the lane
+    // sum of the other fifteen starts beside the S-box instead of behind it -- 25 dependent instructions per round instead of 37,
+    // three more in all -- made the tree tops 11 % slower: a lone wave is bound by the instructions it issues, not by their
+    // dependences.)
 #pragma unroll 1
     for (int r = 0; r < p->rounds_p; r++) {
         const int32_t sb = coop_sbox(x, p->int_rc_mp[r]);
