@@ -681,6 +681,28 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     std::vector<ef> cumsum(n_chips);
     std::vector<uint32_t> perm_widths(n_chips), lqds(n_chips);
     span_begin(ctx, "permutation");
+    // one table of beta powers for the proof (every chip reads a prefix) and every chip's interaction start values, written by
+    // its permutation trace and read again by its quotient: two launches per chip in the permutation stage and three in the
+    // quotient stage fewer
+    uint32_t* beta_pows = nullptr;
+    std::vector<uint32_t*> chip_starts(n_chips, nullptr);
+    {
+        uint32_t n_bp = 1;
+        size_t start_words = 0;
+        for (int i = 0; i < n_chips; i++) {
+            n_bp = std::max(n_bp, air_beta_pows(sh->airs[i]));
+            start_words += (size_t)std::max(air_num_interactions(sh->airs[i]), 1u) * 4;
+        }
+        PTRY(palloc((size_t)n_bp * 32, &beta_pows));
+        PTRY(ef_powers(ctx, perm_beta.c, beta_pows, n_bp, true));
+        uint32_t* all_starts = nullptr;
+        PTRY(palloc(start_words * 4, &all_starts));
+        size_t at = 0;
+        for (int i = 0; i < n_chips; i++) {
+            chip_starts[i] = all_starts + at;
+            at += (size_t)std::max(air_num_interactions(sh->airs[i]), 1u) * 4;
+        }
+    }
     for (int i = 0; i < n_chips; i++) {
         const lair::ChipAir& air = air_of(sh->airs[i]);
         perm_widths[i] = 4 * air.permutation_width();
@@ -692,7 +714,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const size_t h = (size_t)1 << sh->log_n[i];
         PTRY(palloc(h * perm_widths[i] * 4, &perm[i]));
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
-        PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr));
+        PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i]));
     }
     // cumulative sums: last element of each trace, one batched read
     {
@@ -730,7 +752,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         PTRY(palloc(h * qd * 16, &chunks));
         const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde[sh->prep_index[i]] : nullptr;
         PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
-                           cumsum[i], public_values, chunks));
+                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i]));
         const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
         const uint32_t wq_inv = pow_host(wq, bb::P - 2);
         for (uint32_t c = 0; c < qd; c++) {

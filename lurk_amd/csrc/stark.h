@@ -24,12 +24,20 @@ int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev,
 // in-place inclusive scan of the EF elements data[r * stride_words .. +4], r < n
 int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, size_t n);
 
-// Montgomery-form entry points shared by the C ABI wrappers and the shard prover
+// Montgomery-form entry points shared by the C ABI wrappers and the shard prover.
+// `shared_beta_pows` / `shared_starts`: tables of one proof kept by the caller across its chips and stages -- the centred powers of
+// the permutation challenge beta (at least air_beta_pows(a) entries of 8 words; every chip reads a prefix of the same table) and
+// the chip's interaction start values (air_num_interactions(a) x 4 words; written by permutation_trace_impl, read by
+// quotient_impl).  nullptr: each call builds its own (two or three more launches per chip and stage).
+uint32_t air_beta_pows(const lurkhip_air* a);
+uint32_t air_num_interactions(const lurkhip_air* a);
 int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
-                               const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m);
+                               const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m,
+                               const uint32_t* shared_beta_pows = nullptr, uint32_t* shared_starts = nullptr);
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
-                      const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev);
+                      const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev,
+                      const uint32_t* shared_beta_pows = nullptr, const uint32_t* shared_starts = nullptr);
 
 }  // namespace lurkhip
 

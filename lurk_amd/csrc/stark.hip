@@ -440,8 +440,12 @@ int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, si
 }
 
 
+uint32_t air_beta_pows(const lurkhip_air* a) { return a->max_tuple + 2; }
+uint32_t air_num_interactions(const lurkhip_air* a) { return a->air.num_interactions(); }
+
 int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
-                               const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m) {
+                               const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m,
+                               const uint32_t* shared_beta_pows, uint32_t* shared_starts) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
     LH_ARG(ctx, height > 0, "empty trace");
     LH_HIP(ctx, hipSetDevice(ctx->device));
@@ -452,11 +456,12 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     void* pows = nullptr;  // beta powers | interaction start values
     const uint32_t n_pows = a->max_tuple + 2, n_inter = a->air.num_interactions();
     LH_TRY(pool_alloc(ctx, (size_t)n_pows * 32 + (size_t)std::max(n_inter, 1u) * 16, &pows));
-    uint32_t* starts = (uint32_t*)pows + (size_t)n_pows * 8;
+    uint32_t* starts = shared_starts ? shared_starts : (uint32_t*)pows + (size_t)n_pows * 8;
+    const uint32_t* beta_pows = shared_beta_pows ? shared_beta_pows : (const uint32_t*)pows;
     span_begin(ctx, "perm_rows", 2);
-    int32_t s = ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
+    int32_t s = shared_beta_pows ? LURKHIP_OK : ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
     if (s == LURKHIP_OK && n_inter)
-        hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, (const uint32_t*)pows, alpha, starts);
+        hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, beta_pows, alpha, starts);
     if (s == LURKHIP_OK) {
         PermArgs pa{};
         std::vector<const std::vector<uint32_t>*> host_parts;
@@ -465,7 +470,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         pa.parts = lay.parts;
         pa.main = main_dev;
         pa.prep = prep_dev ? prep_dev : main_dev;
-        pa.beta_pows = (const uint32_t*)pows;
+        pa.beta_pows = beta_pows;
         pa.starts = starts;
         pa.n = height;
         pa.w = a->air.width;
@@ -500,7 +505,8 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
 
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
-                      const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev) {
+                      const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
+                      const uint32_t* shared_starts) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
     LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
     const uint32_t lqd = a->air.log_quotient_degree();
@@ -525,9 +531,10 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     // the sinks weigh constraint k with table[K - 1 - k]: powers in natural order give sphinx's Horner folding (first constraint,
     // highest power); the table reversed gives constraint k the power alpha^k (lurkhip_protocol_profile::constraint_alpha_ascending)
     int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total, true, profile_of(ctx).constraint_alpha_ascending != 0);
-    if (s == LURKHIP_OK) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp, true);
-    if (s == LURKHIP_OK && n_inter)
-        hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, (const uint32_t*)(d + o_bp),
+    const uint32_t* beta_pows = shared_beta_pows ? shared_beta_pows : (const uint32_t*)(d + o_bp);
+    if (s == LURKHIP_OK && !shared_beta_pows) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp, true);
+    if (s == LURKHIP_OK && n_inter && !shared_starts)
+        hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, beta_pows,
                            bb::ef{{pa[0], pa[1], pa[2], pa[3]}}, (uint32_t*)(d + o_st));
     std::vector<uint32_t> pubm(np);
     if (s == LURKHIP_OK && np) {
@@ -557,8 +564,8 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.perm = perm_lde_dev;
         q.pub = (const uint32_t*)(d + o_pub);
         q.alpha_pows = (const uint32_t*)d;
-        q.beta_pows = (const uint32_t*)(d + o_bp);
-        q.starts = (const uint32_t*)(d + o_st);
+        q.beta_pows = beta_pows;
+        q.starts = shared_starts ? shared_starts : (const uint32_t*)(d + o_st);
         q.cumulative_sum = bb::ef{{cs[0], cs[1], cs[2], cs[3]}};
         q.log_n = log_n;
         q.log_q = log_n + lqd;
