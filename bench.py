@@ -16,12 +16,15 @@ every chip, main-trace commitment, LogUp permutation traces + commitment, quotie
 (100 queries, 16 proof-of-work bits).  Metric: eval-steps (rows of the eval chip) proved per second.
 
 Multi-GPU (--gpus N, launched by torch.distributed.run): ONE execution with N * 2^log_rows eval rows on every rank (the
-same program, so the same query record), `ShardingConfig(2^log_rows)` -> N shards (`Shard::shard`,
-/root/reference/src/lair/execute.rs:186-216; Entrypoint / memory chips only in shard 0, lair_chip.rs:124-139), rank r
-proves shard r (`shards.assign_shards`).  Per step: every rank commits its shard's main traces, the ranks all-gather the
-8-lane roots (RCCL; every shard's transcript observes every root before any challenge is drawn), every rank proves its
-shard, and the extension-field cumulative sums are all-reduced as 4 x int64: each rank's sum is non-zero, the total is
-zero.  BASELINE config 4 literally is `--gpus 8 --log-rows 19` (2^22 rows as 8 x 2^19).
+same program, so the same query record), cut by `Shard::shard` (/root/reference/src/lair/execute.rs:186-216; Entrypoint /
+memory chips only in shard 0, lair_chip.rs:124-139) into 2 N shards of 2^log_rows / 2 eval rows.  `Shard::shard` cuts every
+chip at the same row count, so the first shards hold every chip and the last ones only the eval chip: the shards are dealt to
+the ranks by work, two per rank (`shards.assign_shards_balanced`; one shard per rank would leave rank 0 with 2.3x the average),
+and a rank proves its two shards on two contexts (`prover.prove_lanes`).  Per step: every rank commits its shards' main traces,
+the ranks all-gather (shard index, 8-lane root) records (RCCL; every shard's transcript observes every root, in shard order,
+before any challenge is drawn), every rank proves its shards, and the extension-field cumulative sums are all-reduced as
+4 x int64: each rank's sum is non-zero, the total is zero.  Per-GPU work stays 2^log_rows eval rows as N grows ("weak").
+BASELINE config 4 is `--gpus 8 --log-rows 19` (2^22 rows over 8 GPUs).
 
 Prints ONE JSON line on rank 0.
 """
@@ -118,6 +121,8 @@ def main():
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the extra streamed multi-shard measurement (host flatten + upload under the proofs)")
     ap.add_argument("--pipeline-shards", type=int, default=4)
+    ap.add_argument("--shards-per-rank", type=int, default=None,
+                    help="distributed runs: shards of 2^log_rows / k eval rows, k per rank, dealt by work (default 2 when WORLD_SIZE > 1, else 1)")
     args = ap.parse_args()
 
     import torch
@@ -156,51 +161,76 @@ def main():
     assert eval_rows_total == world * n, (eval_rows_total, world, n)
     machine = prover.Machine(ctx, top, entry, len(pv))
     vk_root = machine.setup()
-    if world > 1 or args.workload != "eval-only":
-        all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(n))
+    # Shards of this rank.  One GPU: the execution is one shard.  Several: `Shard::shard` cuts every chip at the same row count,
+    # so the first shards hold all the chips and the last ones only the eval chip -- with one shard per rank, rank 0 would carry
+    # 2.3x the average.  The execution is cut into k = shards_per_rank shards per rank (2^log_rows / k eval rows each) and the
+    # shards are dealt to the ranks by their work (shards.assign_shards_balanced: heaviest first, k per rank).
+    spr = args.shards_per_rank if args.shards_per_rank is not None else (2 if world > 1 else 1)
+    assert spr >= 1 and n % spr == 0
+    if world > 1 or spr > 1 or args.workload != "eval-only":
+        all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(n // spr))
     else:
         all_shards = [lair.Shard.new(queries)]
-    assert len(all_shards) == world, f"{len(all_shards)} shards for {world} ranks: the eval chip must be the tallest"
-    mine = shards.assign_shards(len(all_shards), world, rank)
-    assert mine == [rank]
+    assert len(all_shards) == world * spr, f"{len(all_shards)} shards for {world} ranks x {spr}: the eval chip must be the tallest"
+    assignment = shards.assign_shards_balanced([machine.shard_cost(sh) for sh in all_shards], world)
+    mine = assignment[rank]
     t0 = time.perf_counter()
-    prepared = machine.prepare_shard(all_shards[rank])
+    prepared_all = [machine.prepare_shard(all_shards[i]) for i in mine]
+    prepared = prepared_all[0]
     t_flatten = time.perf_counter() - t0
     # once per machine, before the timed region: the big chips' AIR programs compiled to straight-line device code
     t_jit = time.perf_counter()
-    compiled = [] if args.no_compile else machine.compile_airs(prepared)
+    compiled = []
+    if not args.no_compile:
+        for pr in prepared_all:
+            compiled += [c for c in machine.compile_airs(pr) if c not in compiled]
     t_jit = time.perf_counter() - t_jit
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
-    input_bytes = sum(p.input_bytes for *_, p in prepared if p is not None)
-    main_cols_per_eval_row = sum(air.width << lg for _, air, lg, _, _ in prepared) / n
+    input_bytes = sum(p.input_bytes for pr in prepared_all for *_, p in pr if p is not None)
+    main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
+    lane_ctx = prover.lane_context(machine) if len(mine) > 1 else None  # the second proving lane of a rank with several shards
 
     grand_sums, rank_sums = [], []
+    host_ms = {}  # host milliseconds spent in the two collectives (all steps, warm-up included)
 
     def step():
-        # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shard
-        ctx.span_begin("trace_all")
-        traces = machine.run_prepared(prepared)
-        ctx.span_end("trace_all")
-        handle, root = machine.commit_shard(traces)
-        # the transcript prefix: every shard's main root (RCCL all-gather of 8 lanes per rank) and the public values
+        # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shards
+        handles, roots = [], []
+        for pr in prepared_all:
+            ctx.span_begin("trace_all")
+            traces = machine.run_prepared(pr)
+            ctx.span_end("trace_all")
+            handle, root = machine.commit_shard(traces)
+            handles.append(handle)
+            roots.append(root)
+        # the transcript prefix: every shard's main root in shard order (RCCL all-gather of index + 8 lanes per shard) and the
+        # public values
         ch = prover.Challenger(ctx)
         ch.observe(vk_root)
         ch.observe([0])
-        for r in shards.exchange_roots([root], device=dev):
+        t_x = time.perf_counter()
+        gathered = shards.exchange_roots(roots, device=dev, shard_indices=mine)
+        host_ms["exchange_roots"] = host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t_x) * 1e3
+        for r in gathered:
             ch.observe(r)
             ch.observe(pv)
-        # phase 2 (prove_shard)
-        words = machine.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
-        machine.free_shard(handle)
+        # phase 2 (prove_shard), two shards in flight when the rank has several
+        proofs = prover.prove_lanes(machine, handles, ch, pv, args.queries, args.pow_bits, parse=False, lane_ctx=lane_ctx)
+        for handle in handles:
+            machine.free_shard(handle)
         # grand-sum check: the chips' cumulative sums, reduced over all shards (RCCL all-reduce of 4 x int64)
-        n_chips = int(words[1])
-        cs = [words[10 + 11 * i + 7:10 + 11 * i + 11] for i in range(n_chips)]
+        cs = []
+        for words in proofs:
+            n_chips = int(words[1])
+            cs += [words[10 + 11 * i + 7:10 + 11 * i + 11] for i in range(n_chips)]
         mine_sum = np.zeros(4, dtype=np.int64)
         for c in cs:
             mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % 2013265921
         rank_sums.append(tuple(int(x) for x in mine_sum))
+        t_x = time.perf_counter()
         grand_sums.append(shards.reduce_cumulative_sums(cs, device=dev))
-        return words
+        host_ms["reduce_sums"] = host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t_x) * 1e3
+        return np.concatenate(proofs) if len(proofs) > 1 else proofs[0]
 
     def fence():
         ctx.sync()
@@ -209,16 +239,23 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    fence()  # (the first barrier of a process group sets RCCL up lazily; its aftermath showed up as a 90 ms first timed step)
     for _ in range(args.warmup):
         step()
     fence()
     ctx.profile_reset()
     ctx.profile_enable(not args.no_spans)
+    if lane_ctx is not None:  # the second proving lane's stages count too
+        lane_ctx.profile_reset()
+        lane_ctx.profile_enable(not args.no_spans)
     t0 = time.perf_counter()
     words = None
     step_words = []
+    step_ms = []
     for _ in range(args.steps):
+        t_s = time.perf_counter()
         words = step()
+        step_ms.append((time.perf_counter() - t_s) * 1e3)
         step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
     fence()
     elapsed = time.perf_counter() - t0
@@ -239,6 +276,11 @@ def main():
         all_rank_sums_nonzero = bool(flag.item())
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
+    if lane_ctx is not None:
+        lane_ctx.profile_enable(False)
+        for name in SPANS:
+            ms, cnt = lane_ctx.profile_read(name)
+            spans[name] = (spans[name][0] + ms, spans[name][1] + cnt)
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
 
@@ -259,15 +301,20 @@ def main():
             launches += 1
         return total, launches
 
-    rounds = [
-        [(lg + LOG_BLOWUP, air.width) for _, air, lg, _, _ in prepared],
-        [(lg + LOG_BLOWUP, 4 * air.permutation_width) for _, air, lg, _, _ in prepared],
-        [(lg + LOG_BLOWUP, 4) for _, air, lg, _, _ in prepared for _ in range(1 << air.log_quotient_degree)],
-    ]
-    max_lg = max(lg for _, _, lg, _, _ in prepared) + LOG_BLOWUP
-    rounds += [[(lf, 8)] for lf in range(max_lg - 1, 15, -1)]  # FRI layers of 2^16 leaves and more (smaller trees are not in the hashing spans)
-    hash_bytes_step = sum(merkle_hash_bytes(r)[0] for r in rounds)
-    hash_launches_step = sum(merkle_hash_bytes(r)[1] for r in rounds)
+    def rounds_of(pr):
+        rs = [
+            [(lg + LOG_BLOWUP, air.width) for _, air, lg, _, _ in pr],
+            [(lg + LOG_BLOWUP, 4 * air.permutation_width) for _, air, lg, _, _ in pr],
+            [(lg + LOG_BLOWUP, 4) for _, air, lg, _, _ in pr for _ in range(1 << air.log_quotient_degree)],
+        ]
+        max_lg = max(lg for _, _, lg, _, _ in pr) + LOG_BLOWUP
+        # FRI layers of 2^16 leaves and more (smaller trees are not in the hashing spans)
+        return rs + [[(lf, 8)] for lf in range(max_lg - 1, 15, -1)]
+
+    rounds_all = [rounds_of(pr) for pr in prepared_all]  # per shard of this rank
+    rounds = rounds_all[0]
+    hash_bytes_step = sum(merkle_hash_bytes(r)[0] for rs in rounds_all for r in rs)
+    hash_launches_step = sum(merkle_hash_bytes(r)[1] for rs in rounds_all for r in rs)
     hash_ms_step = (spans["merkle_leaves"][0] + spans["merkle_levels"][0]) / args.steps
     achieved = hash_bytes_step / (hash_ms_step * 1e-3) / 1e9 if hash_ms_step > 0 else 0.0
     # second-largest kernel family, the coset LDE passes (k_ntt_pass).  SURVEY.md 8(d) prices an LDE (blow-up 2) at read 4w +
@@ -275,8 +322,8 @@ def main():
     # every pass reads and writes its matrix once, a size-N transform takes ceil(log N / NTT_LOG_TILE) passes, an LDE is three
     # transforms.
     lde_alg_bytes, lde_pass_bytes = 0, 0
-    ntt_log_tile = int(os.environ.get("LURKHIP_NTT_LOG_TILE_REPORTED", "7"))
-    for r in rounds[:3]:
+    ntt_log_tile = int(os.environ.get("LURKHIP_NTT_MAX_LOG_R", "10"))  # rows of the tallest LDS tile: 2^10 (ntt.hip)
+    for r in (r for rs in rounds_all for r in rs[:3]):
         for lg, w in r:
             log_n = lg - LOG_BLOWUP
             lde_alg_bytes += 12 * w * (1 << log_n)
@@ -303,7 +350,7 @@ def main():
     # Extra (N = 1 only, never `value`): two shards proved concurrently on two HIP streams of the one GPU, the way a multi-shard
     # proof keeps the device busy through each shard's latency chains (tree tails, FRI layers, host transcript round trips).
     two_in_flight = None
-    if world == 1 and not args.no_two_in_flight:
+    if world == 1 and spr == 1 and not args.no_two_in_flight:
         try:
             import threading
 
@@ -359,7 +406,7 @@ def main():
     # flattens shard k + 1 on host threads into page-locked memory and uploads it on a second context while this context
     # commits shard k (prover.prove_streamed).  Same proofs; execute is reported separately and is in neither timing.
     host_pipeline = None
-    if world == 1 and not args.no_host_pipeline and args.workload != "eval-only":
+    if world == 1 and spr == 1 and not args.no_host_pipeline and args.workload != "eval-only":
         try:
             S = args.pipeline_shards
             src2, _, entry2, args2, _, _ = build_workload(args.workload, S, log_rows)
@@ -431,7 +478,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"fib trace 2^{log_rows} eval rows x 78 cols per GPU ({args.workload}) + the rest of its machine: lair trace-gen, main / LogUp permutation / quotient commits (coset LDE blow-up 2 + Poseidon2-16 Merkle), openings + FRI ({args.queries} queries, {args.pow_bits} PoW bits)"
-                + (f"; one execution of {world} x 2^{log_rows} eval rows sharded over {world} ranks, RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
+                + (f"; one execution of {world} x 2^{log_rows} eval rows in {len(all_shards)} shards dealt to {world} ranks by work, RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
                 "workload_detail": workload_desc,
                 "chips": chips_desc,
                 "main_columns_per_eval_row": main_cols_per_eval_row,
@@ -439,9 +486,13 @@ def main():
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),
                 "shards": len(all_shards),
+                "shards_per_rank": spr,
+                "shard_assignment": assignment if world > 1 or spr > 1 else None,
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
-                "per_rank_sum_nonzero": all_rank_sums_nonzero if world > 1 else None,  # one shard: its own sum is the (zero) total
+                "per_rank_sum_nonzero": all_rank_sums_nonzero if world > 1 else None,  # one rank: its own sum is the (zero) total
                 "per_rank_ms_per_step": per_rank_ms,
+                "rank0_step_ms": [round(x, 3) for x in step_ms],
+                "collectives_host_ms_per_step": {k: v / (args.steps + args.warmup) for k, v in host_ms.items()},
                 "proofs_identical_across_steps": proofs_identical,
                 "hbm_resident_input_bytes": int(input_bytes),
                 "host_execute_s": t_execute,
@@ -471,7 +522,7 @@ def main():
                 "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (~5.0 k int32 instructions each, ~60 % of them multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4)",
             },
         }
-        if world == 1 and not args.no_cpu_baseline:
+        if world == 1 and spr == 1 and not args.no_cpu_baseline:
             try:
                 out["cpu_baseline"] = cpu_baseline([[(lg - LOG_BLOWUP, w) for lg, w in r] for r in rounds[:3]], n)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
@@ -479,7 +530,9 @@ def main():
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()
-    del prepared
+    del prepared, prepared_all
+    if lane_ctx is not None:
+        lane_ctx.close()
     machine.close()
     ctx.close()
 

@@ -341,6 +341,17 @@ class Machine(_ShardProver):
         self.ctx.sync()
         return out
 
+    def shard_cost(self, shard: Shard) -> int:
+        """Main-trace cells (padded height x width) of the shard's function chips: the estimate of its proving work that
+        `shards.assign_shards_balanced` deals by."""
+        cells = 0
+        for kind, arg, _ in self.chips:
+            if kind == "func":
+                n, h, w = FuncChip(self.ctx, arg, self.toplevel).trace_shape(shard)
+                if n:
+                    cells += h * w
+        return cells
+
     def prepare_shard(self, shard: Shard, input_ctx=None, n_threads: int = 0):
         """Uploads every included chip's trace inputs once; returns [(machine index, air, log_height, out tensor,
         prepared inputs or None)] -- `run_prepared` then regenerates all traces on the device without touching the host.

@@ -1,5 +1,6 @@
 """Multi-GPU proving of one execution: shards are independent proofs (`Shard::shard`,
-/root/reference/src/lair/execute.rs:186-216), one process per GPU, shard s on rank s mod world.
+/root/reference/src/lair/execute.rs:186-216), one process per GPU, shards dealt to the ranks by work
+(`assign_shards_balanced`; `assign_shards` is the plain round robin).
 
 The only cross-shard data: every shard's transcript observes every shard's main-trace root before
 any challenge is drawn, and the verifier's grand-sum check needs the sum of all chips' cumulative sums.  Both are a
@@ -19,19 +20,53 @@ def assign_shards(n_shards: int, world: int, rank: int) -> list[int]:
     return [s for s in range(n_shards) if s % world == rank]
 
 
+def assign_shards_balanced(costs, world: int) -> list[list[int]]:
+    """Shards to ranks by estimated work (longest processing time first; every rank gets the same number of shards, the
+    all-gather's shape): `Shard::shard` cuts every chip at the same row count, so the first shards of an execution hold all
+    its chips and the last ones only the tallest -- round robin would leave rank 0 with twice the average.  Returns
+    [shard indices of rank 0, of rank 1, ...], each ascending; identical on every rank (ties broken by index).
+    len(costs) must be a multiple of world."""
+    n = len(costs)
+    if n % world:
+        raise ValueError(f"{n} shards do not divide over {world} ranks")
+    per_rank = n // world
+    load = [0.0] * world
+    out = [[] for _ in range(world)]
+    for s in sorted(range(n), key=lambda i: (-float(costs[i]), i)):
+        r = min((r for r in range(world) if len(out[r]) < per_rank), key=lambda r: (load[r], r))
+        out[r].append(s)
+        load[r] += float(costs[s])
+    return [sorted(x) for x in out]
+
+
 def _dist():
     import torch.distributed as dist
 
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def exchange_roots(local_roots, device="cpu"):
+def exchange_roots(local_roots, device="cpu", shard_indices=None):
     """local_roots: [k][8] roots of this rank's shards (every rank passes the same k; pad with zeros otherwise).
-    Returns the roots of all shards ordered by shard index (rank-major round robin undone)."""
+    Returns the roots of all shards ordered by shard index: the round-robin layout of `assign_shards` undone, or -- with
+    `shard_indices` (this rank's shard numbers, same order as local_roots; any assignment, e.g. assign_shards_balanced) -- by the
+    indices that travel with the roots."""
     import torch
 
     local = torch.tensor(np.asarray(local_roots, dtype=np.int64).reshape(-1, 8), device=device)
     dist = _dist()
+    if shard_indices is not None:
+        idx = torch.tensor(np.asarray(shard_indices, dtype=np.int64).reshape(-1, 1), device=device)
+        rec = torch.cat([idx, local], dim=1).contiguous()  # [k][9]
+        if dist is None:
+            rows = rec.cpu().tolist()
+        else:
+            out = torch.zeros((dist.get_world_size(),) + tuple(rec.shape), dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(out.view(-1), rec.view(-1))
+            rows = [r for per_rank in out.cpu().tolist() for r in per_rank]
+        rows.sort(key=lambda r: r[0])
+        if [r[0] for r in rows] != list(range(len(rows))):
+            raise ValueError("shard indices of the ranks are not a partition of 0 .. n-1")
+        return [[int(x) for x in r[1:]] for r in rows]
     if dist is None:
         return [[int(x) for x in r] for r in local.cpu().tolist()]
     world = dist.get_world_size()

@@ -42,6 +42,10 @@ def _worker(rank, world, port, q):
         total = (total + np.array(v)) % P
     sums[n_shards - 1] = tuple(int((P - x) % P) for x in total)
     roots = shards.exchange_roots([root_of(s) for s in mine])
+    # the balanced assignment (first shards of an execution are the heaviest) with the indices travelling beside the roots
+    balanced = shards.assign_shards_balanced([10, 9, 3, 2, 1, 1], world)
+    roots_b = shards.exchange_roots([root_of(s) for s in balanced[rank]], shard_indices=balanced[rank])
+    assert roots_b == roots and sorted(balanced[0] + balanced[1]) == list(range(6))
     grand = shards.reduce_cumulative_sums([sums[s] for s in mine])
     # the transcript every rank derives from the gathered roots
     ch = os_.Challenger(os_.default_permute16())
@@ -79,5 +83,8 @@ def test_single_process_paths_need_no_process_group():
     from lurk_amd import shards
 
     assert shards.assign_shards(5, 1, 0) == [0, 1, 2, 3, 4]
+    assert shards.assign_shards_balanced([5, 4, 3, 2, 1, 1], 2) == [[0, 3, 4], [1, 2, 5]]  # loads 8 and 8
+    assert shards.assign_shards_balanced([1, 1], 1) == [[0, 1]]
+    assert shards.exchange_roots([[2] * 8, [1] * 8], shard_indices=[1, 0]) == [[1] * 8, [2] * 8]
     assert shards.exchange_roots([[1] * 8, [2] * 8]) == [[1] * 8, [2] * 8]
     assert shards.reduce_cumulative_sums([(1, 2, 3, 4), (P - 1, P - 2, P - 3, P - 4)]) == (0, 0, 0, 0)
