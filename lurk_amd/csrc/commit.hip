@@ -407,11 +407,18 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
         TRY_C(pool_alloc(ctx, bytes, (void**)&c->coeffs[i]));
     }
+    // Short matrices (below 2^13 rows: a few workgroups per NTT pass) go through their passes on the context's side lane, under
+    // the tall matrices' passes; the tree needs all of them, so the lane is joined before it.  Only with device inputs and while
+    // the coset-shift table cache has room (its fallback scratch, arena slot 2, is shared by the streams).
+    SideLane lane(ctx);
+    constexpr uint32_t SIDE_MAX_LOG_N = 13;
+    if (!mats_on_host && log_blowup >= 1 && ctx->lde_scale_bytes + ((size_t)64 << 20) < ((size_t)1 << 30)) TRY_C(lane.open());
     if (!mats_on_host && log_blowup >= 1) {
         // device-resident matrices of one shape go through the passes together
         std::map<std::pair<uint32_t, uint32_t>, std::vector<int>> shapes;
         for (int i = 0; i < n_mats; i++) shapes[{log_heights[i], widths[i]}].push_back(i);
         for (const auto& kv : shapes) {
+            const auto on_side = lane.on_side(kv.first.first < SIDE_MAX_LOG_N);
             const std::vector<int>& idx = kv.second;
             for (size_t at = 0; at < idx.size(); at += NTT_MAX_BATCH) {
                 const int nb = (int)std::min<size_t>(NTT_MAX_BATCH, idx.size() - at);
@@ -435,6 +442,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     }
     for (int i = 0; i < n_mats; i++) {
         const int log_n = (int)log_heights[i];
+        const auto on_side = lane.on_side((uint32_t)log_n < SIDE_MAX_LOG_N);
         const int w = (int)widths[i];
         const size_t n = (size_t)1 << log_n;
         const size_t bytes = n * w * sizeof(uint32_t);
@@ -462,6 +470,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
             c->coeffs[i] = nullptr;
         }
     }
+    TRY_C(lane.close());
     span_end(ctx, "lde");
     TRY_C(build_tree(ctx, c));
     if (root) {

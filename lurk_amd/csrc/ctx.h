@@ -46,6 +46,12 @@ struct lurkhip_ctx {
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)
     std::multimap<size_t, void*> pool_free;
     std::map<void*, size_t> pool_live;
+    // Fork / join inside one proof (lurkhip::SideLane): a second stream of the context for the short chips' launches.  While a
+    // lane is open every pool_release is deferred to the join, so no block is handed out again while either stream may still use it.
+    hipStream_t side_stream = nullptr;
+    hipEvent_t side_fork = nullptr, side_join = nullptr;
+    bool defer_releases = false;
+    std::vector<void*> deferred;
     std::mutex pool_mu;  // a streaming prover releases one shard's inputs on its proving thread while the next shard's are allocated on its staging thread
     // page-locked staging of the row-stream uploads (lair_api.cpp: lurkhip_func_trace_prepare_many): grow-only, a buffer is reused by a
     // later call once its `prep_done` (recorded behind the last upload that read it) has passed
@@ -78,6 +84,27 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out);
 // pooled device allocations: released blocks are kept and reused for later requests of the same size
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
 void pool_release(lurkhip_ctx* ctx, void* ptr);
+// Fork / join of a side lane: between open() and close() work enqueued while `on_side()` guards are alive goes to the
+// context's second stream, ordered after everything queued before open(); close() makes the main stream wait for it.  The
+// short chips of a machine (a few workgroups per launch, latency-bound) run there under the tall chips' kernels.
+// LURKHIP_SIDE_LANE=0 disables it (everything on the main stream).
+struct SideLane {
+    lurkhip_ctx* ctx;
+    bool active = false;
+    explicit SideLane(lurkhip_ctx* c) : ctx(c) {}
+    int32_t open();
+    int32_t close();
+    ~SideLane() { (void)close(); }
+    struct Guard {  // routes the launches of its scope to the side stream
+        lurkhip_ctx* ctx;
+        hipStream_t saved;
+        Guard(lurkhip_ctx* c, bool on) : ctx(c), saved(c->stream) {
+            if (on) c->stream = c->side_stream;
+        }
+        ~Guard() { ctx->stream = saved; }
+    };
+    Guard on_side(bool on) { return Guard(ctx, on && active); }
+};
 // span timing (no-ops unless profiling is enabled)
 // `level`: 1 = stage span (recorded whenever profiling is on), 2 = detail span (per chip, per small tree: only at profile level 2 --
 // every event record is a marker packet the next kernel waits behind, a few hundred of them cost a millisecond per proof)

@@ -110,6 +110,10 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
 void pool_release(lurkhip_ctx* ctx, void* ptr) {
     if (!ptr) return;
     std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    if (ctx->defer_releases) {  // a side lane is open: the block may be in use on either stream until the join
+        ctx->deferred.push_back(ptr);
+        return;
+    }
     auto it = ctx->pool_live.find(ptr);
     if (it == ctx->pool_live.end()) {
         (void)hipFree(ptr);
@@ -117,6 +121,41 @@ void pool_release(lurkhip_ctx* ctx, void* ptr) {
     }
     ctx->pool_free.insert({it->second, ptr});
     ctx->pool_live.erase(it);
+}
+
+int32_t SideLane::open() {
+    static const bool enabled = getenv("LURKHIP_SIDE_LANE") == nullptr || atoi(getenv("LURKHIP_SIDE_LANE")) != 0;
+    if (!enabled || active) return LURKHIP_OK;
+    if (!ctx->side_stream) {
+        LH_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+        LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
+    }
+    LH_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
+    LH_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mu);
+        ctx->defer_releases = true;
+    }
+    active = true;
+    return LURKHIP_OK;
+}
+
+int32_t SideLane::close() {
+    if (!active) return LURKHIP_OK;
+    active = false;
+    hipError_t e = hipEventRecord(ctx->side_join, ctx->side_stream);
+    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_join, 0);
+    std::vector<void*> blocks;
+    {
+        std::lock_guard<std::mutex> lock(ctx->pool_mu);
+        ctx->defer_releases = false;
+        blocks.swap(ctx->deferred);
+    }
+    if (e != hipSuccess) (void)hipDeviceSynchronize();  // could not order the streams: drain before anything is reused
+    for (void* b : blocks) pool_release(ctx, b);  // later work on the main stream runs behind the join
+    if (e != hipSuccess) return set_error(ctx, LURKHIP_ERR_HIP, "joining the side lane failed: %s", hipGetErrorString(e));
+    return LURKHIP_OK;
 }
 
 static hipEvent_t get_event(lurkhip_ctx* ctx) {
@@ -250,6 +289,12 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
+    if (ctx->side_stream) {
+        (void)hipStreamSynchronize(ctx->side_stream);
+        (void)hipStreamDestroy(ctx->side_stream);
+        (void)hipEventDestroy(ctx->side_fork);
+        (void)hipEventDestroy(ctx->side_join);
+    }
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LURKHIP_OK;

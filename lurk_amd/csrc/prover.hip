@@ -63,6 +63,7 @@ struct lurkhip_proof {
 
 namespace {
 
+constexpr int SIDE_LANE_MAX_LOG_N = 13;          // chips below 2^13 rows are "short": their per-chip launches go to the side lane
 constexpr uint32_t PROOF_MAGIC = 0x4652504cu;    // "LPRF"
 constexpr uint32_t OPENING_MAGIC = 0x4e504f4cu;  // "LOPN"
 
@@ -308,9 +309,12 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         PTRY(palloc(std::max<size_t>(partial_words, 4) * 4, &partials));
         std::vector<DotJob> jobs;
         size_t k = 0, at = 0;
+        SideLane lane(ctx);  // short matrices (their weights, their dots) on the side lane; weights are cached per height, a height is one lane
+        PTRY(lane.open());
         for (const Round& r : rounds)
             for (int m = 0; m < r.c->n_mats; m++, k++) {
                 const int log_n = r.c->log_h[m] - log_blowup;
+                const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N);
                 const std::vector<int>& mp = r.points[m];
                 uint32_t *u0 = nullptr, *u1 = nullptr;
                 PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
@@ -322,6 +326,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
                 at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
             }
+        PTRY(lane.close());
         PTRY(column_dot_finish(ctx, jobs, dot_out));
     }
     std::vector<uint32_t> dot_host(dot_words);
@@ -387,10 +392,13 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         return st;
     };
     size_t mat_k = 0;
+    SideLane ro_lane(ctx);  // the accumulators are per height: a height is one lane
+    PTRY(ro_lane.open());
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const Round& r = rounds[ri];
         for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
             const int log_h = r.c->log_h[m];
+            const auto on_side = ro_lane.on_side(log_h - log_blowup < SIDE_LANE_MAX_LOG_N);
             const uint32_t w = r.c->width[m];
             const std::vector<int>& mp = r.points[m];
             uint32_t *d0 = nullptr, *d1 = nullptr;
@@ -449,7 +457,11 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             offset += (uint64_t)mp.size() * w;
         }
     }
-    for (auto& kv : narrow) PTRY(flush_narrow(kv.second));
+    for (auto& kv : narrow) {
+        const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N);
+        PTRY(flush_narrow(kv.second));
+    }
+    PTRY(ro_lane.close());
     span_end(ctx, "open");
 
     // ---- FRI commit phase
@@ -703,7 +715,12 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             at += (size_t)std::max(air_num_interactions(sh->airs[i]), 1u) * 4;
         }
     }
+    // the short chips' launches (a few workgroups each: starts, interpreter rows, one-block scan) go to the side lane, under the
+    // tall chips' kernels
+    SideLane lane(ctx);
+    PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
+        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N);
         const lair::ChipAir& air = air_of(sh->airs[i]);
         perm_widths[i] = 4 * air.permutation_width();
         lqds[i] = air.log_quotient_degree();
@@ -716,6 +733,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
         PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i]));
     }
+    PTRY(lane.close());
     // cumulative sums: last element of each trace, one batched read
     {
         uint32_t* cs = nullptr;  // page-locked: the copies queue up behind the kernels without a host round trip each
@@ -745,7 +763,9 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     std::vector<uint32_t> q_logn, q_widths, q_shifts;
     std::vector<int> q_chip;  // chip of each quotient chunk
     span_begin(ctx, "quotient_all");
+    PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
+        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N);
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t qd = 1u << lqds[i];
         uint32_t* chunks = nullptr;
@@ -763,6 +783,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             q_chip.push_back(i);
         }
     }
+    PTRY(lane.close());
     span_end(ctx, "quotient_all");
     lurkhip_commitment* quot_commit = nullptr;
     uint32_t quot_root_m[8];

@@ -50,7 +50,7 @@ bad_total = bad
 from lurk_amd.programs import lurk_mix as lm  # noqa: E402
 
 mix_rounds = max(10, rounds * 3)
-mix = lm.fib_mix(1 << 13)
+mix = lm.fib_mix(1 << 15)  # tall chips (>= 2^13 rows) on the main stream, short ones on the side lanes: both in every proof
 top = lair.Toplevel(mix.source, lurk_chips=True)
 q = lair.QueryRecord(top)
 top.execute(top.func_index(mix.entry), mix.main_args, q)
@@ -61,7 +61,7 @@ with lurk_amd.Context(0) as ctx, lurk_amd.Context(0) as ctx_in:
     vk = m.setup()
     shard = lair.Shard.new(q)
     prepared = m.prepare_shard(shard)
-    m.compile_airs(prepared, min_log_rows=10)
+    m.compile_airs(prepared, min_log_rows=12)
 
     def step():
         traces = m.run_prepared(prepared)
@@ -81,7 +81,7 @@ with lurk_amd.Context(0) as ctx, lurk_amd.Context(0) as ctx_in:
         if not np.array_equal(step(), want):
             bad += 1
             print(f"fib-mix round {r}: proof differs")
-    cfg = lair.ShardingConfig(1 << 11)
+    cfg = lair.ShardingConfig(1 << 13)
     ref = [p.words.copy() for p in m.prove(q, cfg, num_queries=8, pow_bits=4, lanes=1)]
     for r in range(max(5, rounds // 3)):
         for name, got in (("prove, two lanes", m.prove(q, cfg, num_queries=8, pow_bits=4)),
