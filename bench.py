@@ -59,32 +59,33 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
 
 
 def cpu_baseline(round_shapes, eval_rows: int):
-    """The CPU port (oracle/commit.c: row-major Montgomery FFT + Poseidon2-16 Merkle, OpenMP) of the step's three commitment
-    rounds -- main traces, LogUp permutation traces, quotient chunks -- on synthetic matrices of exactly the shapes the GPU
-    step commits (the CPU time of an LDE + Merkle commit does not depend on the values).  Trace generation, the
-    permutation / quotient arithmetic, openings and FRI have no compiled CPU port (the oracle does them in Python), so
-    the CPU figure is an upper bound on what the port would reach on the full step; the commits are about two thirds of
-    the GPU step.  kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be built here."""
+    """The CPU port (oracle/cpu_port.c: Montgomery row-major NTTs with a vectorised inner loop along the row, Montgomery
+    Poseidon2-16 Merkle tree, OpenMP; checked word for word against the oracle's checker by tests/test_cpu_port.py) of the
+    step's three commitment rounds -- main traces, LogUp permutation traces, quotient chunks -- on synthetic matrices of exactly
+    the shapes the GPU step commits (the CPU time of an LDE + Merkle commit does not depend on the values).  Trace generation,
+    the permutation / quotient arithmetic, openings and FRI have no compiled CPU port (the oracle does them in Python), so the CPU
+    figure is an upper bound on what the port would reach on the full step; the commits are about three quarters of the GPU step.
+    kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be built here."""
     from oracle import binding as ob
 
     ob.build()
-    cores = os.cpu_count() or 1
+    cores = ob.usable_cores()  # affinity mask capped by the cgroup CPU quota: the OpenMP team gets exactly that many threads
+    ob.cpu_port_set_threads(cores)
     dt, cols = 0.0, 0
     for k, shapes in enumerate(round_shapes):
-        mats = [synthetic_trace(lg, w, 100 * k + i) for i, (lg, w) in enumerate(shapes)]
+        mats = [synthetic_trace(lg, w, 100 * k + i) % 2013265921 for i, (lg, w) in enumerate(shapes)]
         cols += sum(w << lg for lg, w in shapes)
         t0 = time.perf_counter()
-        ldes = [ob.lde(m, LOG_BLOWUP) for m in mats]
-        ob.merkle_commit(ldes)
+        ob.cpu_port_commit_round(mats, LOG_BLOWUP)
         dt += time.perf_counter() - t0
-        del mats, ldes
+        del mats
     return {
         "value": eval_rows / dt,
         "unit": "eval-steps/s",
         "cores": cores,
         "kind": "port",
         "sample": f"the three commitment rounds of one step (coset LDE x2 + Poseidon2-16 Merkle over {cols / eval_rows:.0f} columns per eval row: main, permutation, quotient), "
-                  f"OpenMP over {cores} threads, {dt:.2f} s; the GPU step also does trace generation, the permutation / quotient arithmetic, openings and FRI; "
+                  f"oracle/cpu_port.c (Montgomery, row-major vectorised NTTs), OpenMP over {cores} threads, {dt:.2f} s; the GPU step also does trace generation, the permutation / quotient arithmetic, openings and FRI; "
                   "not the reference binary (no Rust toolchain): never quote the ratio as 'vs the reference'",
     }
 

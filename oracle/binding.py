@@ -153,6 +153,53 @@ def merkle_commit(lde_mats):
     return root, digests
 
 
+# ---- the CPU port timed by bench.py's cpu_baseline (oracle/cpu_port.c); checked against the functions above by tests/test_cpu_port.py
+
+def usable_cores() -> int:
+    """Cores this process may actually use: its affinity mask capped by the cgroup CPU quota (cpu.max) -- an OpenMP team of
+    one thread per host core on a 16-core quota spends its time being throttled."""
+    import os
+
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
+def cpu_port_set_threads(n: int) -> None:
+    lib().cp_set_threads(int(n))
+
+
+def cpu_port_lde(mat, log_blowup=1) -> np.ndarray:
+    L = lib()
+    mat = _u32(mat)
+    n, w = mat.shape
+    out = np.empty((n << log_blowup, w), dtype=np.uint32)
+    L.cp_lde.restype = C.c_int
+    L.cp_lde.argtypes = [C.c_int, C.c_int, C.c_int, C.c_void_p, C.c_void_p, C.c_int]
+    assert L.cp_lde(n.bit_length() - 1, w, log_blowup, mat.ctypes.data, out.ctypes.data, 0) == 0
+    return out
+
+
+def cpu_port_commit_round(mats, log_blowup=1) -> np.ndarray:
+    """Root (canonical) of the commitment of the trace matrices `mats` (canonical, 2^k x w): coset LDEs + Merkle tree, all in C."""
+    L = lib()
+    mats = [_u32(m) for m in mats]
+    n = len(mats)
+    ptrs = (C.c_void_p * n)(*[m.ctypes.data for m in mats])
+    ln = np.array([m.shape[0].bit_length() - 1 for m in mats], dtype=np.uint32)
+    ws = np.array([m.shape[1] for m in mats], dtype=np.uint32)
+    root = np.zeros(8, dtype=np.uint32)
+    L.cp_commit_round.restype = C.c_int
+    L.cp_commit_round.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_int, C.c_void_p]
+    assert L.cp_commit_round(n, C.cast(ptrs, C.c_void_p), ln.ctypes.data, ws.ctypes.data, log_blowup, root.ctypes.data) == 0
+    return root
+
+
 def merkle_verify(log_heights, widths, index, rows, path, root) -> bool:
     L = _setup_commit()
     lh = np.asarray(log_heights, dtype=np.uint32)
