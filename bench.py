@@ -90,6 +90,18 @@ def cpu_baseline(round_shapes, eval_rows: int):
     }
 
 
+def usable_cores() -> int:
+    """Affinity mask capped by the cgroup CPU quota (the library sizes its staging threads the same way)."""
+    n = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    try:
+        quota, period = open("/sys/fs/cgroup/cpu.max").read().split()[:2]
+        if quota != "max":
+            n = min(n, max(1, int(quota) // int(period)))
+    except (OSError, ValueError):
+        pass
+    return n
+
+
 def build_workload(name: str, world: int, log_rows: int):
     """(source, lurk_chips, entry, main args, eval function name, description)."""
     n = 1 << log_rows
@@ -452,7 +464,7 @@ def main():
                 "shards": len(shards2), "eval_rows": len(shards2) * n, "host_execute_s": t_exec2,
                 "resident_ms_per_shard": t_res / len(shards2) * 1e3, "streamed_ms_per_shard": t_str / len(shards2) * 1e3,
                 "streamed_over_resident_rate": t_res / t_str,
-                "staging_s_per_shard": st.get("staging_s", 0.0) / len(shards2), "staging_threads": min(32, os.cpu_count() or 1),
+                "staging_s_per_shard": st.get("staging_s", 0.0) / len(shards2), "staging_threads": min(32, usable_cores()),
                 "first_staging_s_per_shard": t_stage / len(shards2), "staged_bytes_per_shard": staged_bytes // len(shards2),
                 "proofs_match_resident": same,
                 "note": "one sharded execution, all shards' traces and main commitments resident for phase 2, which proves two shards at a time on two contexts; flatten + upload of shard k+1 run under the commit of shard k; not the headline value",

@@ -366,8 +366,8 @@ int32_t lurkhip_trace_source(lurkhip_toplevel* top, int32_t func_idx, char* out,
 typedef struct lurkhip_func_trace lurkhip_func_trace;
 int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, int32_t func_idx,
                                    uint32_t shard_index, uint32_t max_shard_size, lurkhip_func_trace** out);
-/* lurkhip_func_trace_prepare for several functions of one shard at once: host threads (n_threads, 0 = one per hardware
- * thread, at most 32) write the rows of all of them into one page-locked staging buffer and each function's block is queued for
+/* lurkhip_func_trace_prepare for several functions of one shard at once: host threads (n_threads, 0 = one per usable
+ * core -- affinity mask capped by the cgroup CPU quota --, at most 32) write the rows of all of them into one page-locked staging buffer and each function's block is queued for
  * upload on the context's stream as soon as it is complete; the call does not wait for the copies (they are ordered before any
  * later work on that stream).  out[i] = NULL for a function without rows in the shard.  This is the per-row parallelism of
  * FuncChip::generate_trace (src/lair/trace.rs:86-132) applied to the part of it that stays on the host. */

@@ -5,6 +5,10 @@
 //   Toplevel::{new, execute_by_name}        /root/reference/src/lair/toplevel.rs:28-50, execute.rs:375-417
 //   FuncChip::{from_name, width, generate_trace}   /root/reference/src/lair/func_chip.rs:34-80, trace.rs:72-135
 //   MemChip / BytesChip / Entrypoint generate_trace  /root/reference/src/lair/lair_chip.rs:96-120
+#include <sched.h>
+#include <stdio.h>
+#include <stdlib.h>
+
 #include <algorithm>
 #include <atomic>
 #include <cstring>
@@ -59,6 +63,25 @@ int32_t guarded(lurkhip_ctx* ctx, F&& f) {
     } catch (const std::exception& e) {
         return fail(ctx, LURKHIP_ERR_EXEC, std::string("internal error: ") + e.what());
     }
+}
+
+// cores this process may actually use: the affinity mask capped by the cgroup CPU quota (cpu.max).  A container on a 256-thread
+// host often has a quota of a dozen cores: one worker per hardware thread would spend its time being throttled.
+uint32_t usable_cores() {
+    uint32_t n = std::max(1u, std::thread::hardware_concurrency());
+    cpu_set_t set;
+    CPU_ZERO(&set);
+    if (sched_getaffinity(0, sizeof set, &set) == 0) n = std::max(1, CPU_COUNT(&set));
+    if (FILE* f = fopen("/sys/fs/cgroup/cpu.max", "r")) {
+        char quota[32] = {0};
+        long period = 0;
+        if (fscanf(f, "%31s %ld", quota, &period) == 2 && strcmp(quota, "max") != 0 && period > 0) {
+            const long q = atol(quota) / period;
+            if (q >= 1) n = std::min<uint32_t>(n, (uint32_t)q);
+        }
+        fclose(f);
+    }
+    return n;
 }
 
 uint32_t next_pow2(uint32_t n) {
@@ -385,7 +408,7 @@ int32_t lurkhip_func_trace_prepare(lurkhip_ctx* ctx, lurkhip_toplevel* top, cons
 // last range is done -- the copy of one function runs under the flattening of the next.  Nothing waits for the copies here:
 // they are ordered before any later work on the stream, and the staging buffer is not rewritten before `prep_done` has passed.
 // (The reference parallelises trace generation per row, trace.rs:86-132; the per-row work left on the host here is this copy.)
-// out[i] = nullptr for a function without rows in the shard.  n_threads = 0: one per hardware thread, at most 32.
+// out[i] = nullptr for a function without rows in the shard.  n_threads = 0: one per usable core (usable_cores), at most 32.
 int32_t lurkhip_func_trace_prepare_many(lurkhip_ctx* ctx, lurkhip_toplevel* top, const lurkhip_record* r, uint32_t n_funcs,
                                         const int32_t* func_idx, uint32_t shard_index, uint32_t max_shard_size, uint32_t n_threads,
                                         lurkhip_func_trace** out) {
@@ -429,7 +452,7 @@ int32_t lurkhip_func_trace_prepare_many(lurkhip_ctx* ctx, lurkhip_toplevel* top,
         for (uint32_t k = 0; k < n_funcs; k++)
             for (uint32_t c = 0; c < jobs[k].n_ranges; c++)
                 ranges[jobs[k].first_range + c] = Range{k, c * RANGE, std::min(jobs[k].n, (c + 1) * RANGE), 0};
-        uint32_t nt = n_threads ? n_threads : std::min(32u, std::max(1u, std::thread::hardware_concurrency()));
+        uint32_t nt = n_threads ? n_threads : std::min(32u, usable_cores());
         nt = std::max(1u, std::min(nt, std::max(1u, total_ranges)));
         std::string worker_err;
         std::mutex err_mu;
