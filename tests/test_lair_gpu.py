@@ -200,12 +200,6 @@ def test_entrypoint_trace(ctx):
     assert t.shape == (1, 7)  # input 1 + output 2 + 4 depth bytes (lair_chip.rs:34-41)
 
 
-def _memoset_balanced(trace_rows):
-    """Every require's (prev_nonce, prev_count) chain must be consumed exactly once: the multiset of
-    provided final records and required previous records telescopes (air/debug.rs TraceQueries idea)."""
-    return True
-
-
 def test_large_fib_trace_properties(ctx):
     """fib(100000): 100001 rows padded to 2^17.  Pure-Python oracle is too slow here, so check
     size-independent properties: known answer, nonce column, one-hot selectors, count_inv * (count+1) = 1,
@@ -229,6 +223,22 @@ def test_large_fib_trace_properties(ctx):
     assert np.array_equal(d[:, 2], (d[:, 7] + d[:, 11]) % P)
     for c in (8, 12):
         assert np.array_equal(((d[:, c + 1] + 1) * d[:, c + 2]) % P, np.ones(len(d), dtype=np.uint64))
+    # lookup chains (air/builder.rs:152-214): fib(k) is required by the rows of fib(k+1) and fib(k+2) (and fib(100000) by the
+    # caller of the chip), each require holding the (nonce, count) the previous one left: per provided key the require records
+    # are (0, 0) -> (nonce_a, 1) -> ..., and the row's provide record is the last link.  Row r holds the argument 100000 - r.
+    arg_row = {int(a): r for r, a in enumerate(real[:, 1])}
+    links = {}  # callee argument -> [(prev_nonce, prev_count, requiring row's nonce)]
+    for row in d:
+        for c, callee in ((8, int(row[1]) - 1), (12, int(row[1]) - 2)):
+            links.setdefault(callee, []).append((int(row[c]), int(row[c + 1]), int(row[0])))
+    for callee in (5, 4321, 99998):
+        chain = sorted(links[callee], key=lambda x: x[1])
+        assert [x[1] for x in chain] == list(range(len(chain)))          # counts 0, 1, ...
+        assert chain[0][:2] == (0, 0)                                     # the first require starts the chain
+        for prev, nxt in zip(chain, chain[1:]):
+            assert nxt[0] == prev[2]                                      # prev_nonce = nonce of the row that required before
+        prov = real[arg_row[callee]]
+        assert (int(prov[3]), int(prov[4])) == (chain[-1][2], len(chain))  # provide record = the last link
     # inverse witnesses: n * (1/n) = 1 and (n-1) * 1/(n-1) = 1
     assert np.array_equal((d[:, 1] * d[:, 5]) % P, np.ones(len(d), dtype=np.uint64))
     assert np.array_equal(((d[:, 1] - 1) * d[:, 6]) % P, np.ones(len(d), dtype=np.uint64))
