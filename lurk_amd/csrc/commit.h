@@ -91,7 +91,7 @@ int32_t merkle_level(lurkhip_ctx* ctx, const P16Params* params_dev, const uint32
 // 40 permutations per lane for the 2^20-row group of a fib shard, sixteen such waves per SIMD at five or six resident -- the
 // last ones alone on the chip; hashed ahead of the levels, all groups share one grid whose tail is made of the shortest rows.
 // out[g] receives n_rows[g] digests of 8 words.
-constexpr int SPONGE_MAX_GROUPS = 12;
+constexpr int SPONGE_MAX_GROUPS = 16;
 constexpr size_t MERKLE_COOP_MAX_PARENTS = 16384;  // levels of at most this many parents run lane-cooperatively (merkle.hip)
 struct SpongeGroups {
     int n = 0;
@@ -111,8 +111,13 @@ int32_t merkle_level_digests(lurkhip_ctx* ctx, const P16Params* params_dev, cons
 struct TopInject {
     const LeafCol* cols[11];
     uint32_t w[11];
+    const uint32_t* dig[11];  // the rows' sponge digests when they were hashed ahead (merkle_row_sponges): 8 words per row; then cols[t] is not used
 };
 int32_t merkle_top(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* level_base, size_t n, const TopInject& inject);
+// `levels` (1 .. 5) consecutive cooperative levels above the n_children nodes at `children` in one launch; the levels' digests
+// lie back to back behind them (inject as for merkle_top: entry t = the rows absorbed into the parents of step t)
+int32_t merkle_levels_coop(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* children, size_t n_children, int levels,
+                           const TopInject& inject);
 
 int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev);
 // the context's protocol profile (created with the "default" preset on first use)

@@ -227,11 +227,17 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     auto drop_scratch = [&]() {
         for (void* p : scratch) pool_release(ctx, p);  // stream-ordered: reusable by later work only
     };
+    const char* group_env = getenv("LURKHIP_MERKLE_COOP_GROUP");  // cooperative levels per launch (1 = one launch per level, round 1)
+    const int coop_group = group_env ? std::max(1, std::min(5, atoi(group_env))) : 5;
+    // With grouped cooperative levels the rows injected at the cooperative levels and in the one-workgroup top are hashed ahead
+    // too: hashed where they are injected, the 1963 columns of a fib machine's hash chips (512 LDE rows) were 246 cooperative
+    // permutations in a row -- one 0.9 ms launch of 512 workgroups -- and in the sponge launch they are 8 waves among thousands.
+    const bool prehash_all = fused && coop_group > 1;
     // (the digest buffers of the injected groups are allocated before the first make_cols: see the invariant above)
     if (fused)
         for (int l = 1, groups = 1; l <= c->log_max && groups < SPONGE_MAX_GROUPS; l++) {
             const size_t n_parents = n_leaves >> l;
-            if (n_parents <= MERKLE_COOP_MAX_PARENTS) break;
+            if (n_parents <= MERKLE_COOP_MAX_PARENTS && !prehash_all) break;
             bool any = false;
             for (int m : order) any = any || c->log_h[m] == c->log_max - l;
             if (!any) continue;
@@ -300,6 +306,10 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             // finish the tree in one workgroup (wider levels are faster spread over the CUs)
             TopInject ti{};
             for (int t = 0; l + t <= c->log_max && status == LURKHIP_OK; t++) {
+                if (inj_digests[l + t]) {  // hashed ahead
+                    ti.dig[t] = inj_digests[l + t];
+                    continue;
+                }
                 std::vector<int> inj;
                 for (int m : order)
                     if (c->log_h[m] == lh - t) inj.push_back(m);
@@ -320,6 +330,28 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         }
         if (fused && n_parents > MERKLE_COOP_MAX_PARENTS && (inject.empty() || inj_digests[l])) {
             status = merkle_level_digests(ctx, params, children, n_parents, inj_digests[l], parents);
+            continue;
+        }
+        if (n_parents <= MERKLE_COOP_MAX_PARENTS && coop_group > 1) {
+            // the cooperative levels from here to the one-workgroup top, up to five per launch (merkle.hip: k_levels_coop)
+            int group = 0;
+            while (group < coop_group && ((n_parents >> group) << 1) > TOP_NODES) group++;
+            TopInject ti{};
+            for (int t = 0; t < group && status == LURKHIP_OK; t++) {
+                if (inj_digests[l + t]) {  // hashed ahead
+                    ti.dig[t] = inj_digests[l + t];
+                    continue;
+                }
+                std::vector<int> inj;
+                for (int m : order)
+                    if (c->log_h[m] == lh - t) inj.push_back(m);
+                if (inj.empty()) continue;
+                LeafCol* tc = nullptr;
+                status = make_cols(ctx, c, inj, &tc, &ti.w[t]);
+                ti.cols[t] = tc;
+            }
+            if (status == LURKHIP_OK) status = merkle_levels_coop(ctx, params, children, n_parents << 1, group, ti);
+            l += group - 1;
             continue;
         }
         LeafCol* icols = nullptr;

@@ -188,6 +188,13 @@ __device__ __forceinline__ uint32_t coop_inject(uint32_t x, const P16Params* __r
     return coop_perm16(j < 8 ? x : up, p, j);
 }
 
+// the same when the row's sponge was hashed ahead: lanes 8..15 take its digest
+__device__ __forceinline__ uint32_t coop_inject_digest(uint32_t x, const P16Params* __restrict__ p, const uint32_t* __restrict__ dig, size_t row,
+                                                       int j) {
+    const uint32_t d = dig[row * 8 + (size_t)(j & 7)];
+    return coop_perm16(j < 8 ? x : d, p, j);
+}
+
 // leaves of a short tree (the later FRI layers, small commitments): one row per 16-lane group, lanes 0..7 absorb
 __global__ __launch_bounds__(MBLOCK) void k_leaves_coop(const P16Params* __restrict__ p, const LeafCol* __restrict__ cols, uint32_t total_w,
                                                          size_t n_rows, uint32_t* __restrict__ out) {
@@ -217,6 +224,39 @@ __global__ __launch_bounds__(MBLOCK) void k_level_coop(const P16Params* __restri
     if (g < n_parents && j < 8) parents[g * 8 + j] = x;
 }
 
+// Several consecutive cooperative levels in one launch: workgroup b owns the 2^levels children [b << levels, (b + 1) << levels)
+// of the first level and collapses them to one node, storing every level where the one-launch-per-level path stores it (the
+// levels lie back to back behind `children`, n_children / 2 parents first).  A cooperative level is one permutation's latency
+// whatever its width; launched one by one each also paid a dependent launch (14 us per level measured, 6 of them the permutation):
+// the 8 levels between 16384 nodes and the one-workgroup top are two launches instead of eight.
+// blockDim = 16 lanes x 2^(levels - 1) groups; inj as for k_top: entry t = the rows absorbed into the parents of step t.
+__global__ __launch_bounds__(256) void k_levels_coop(const P16Params* __restrict__ p, uint32_t* __restrict__ children, size_t n_children,
+                                                      int levels, TopInject inj) {
+    const int j = threadIdx.x & 15;
+    const uint32_t group = threadIdx.x >> 4;
+    uint32_t* cur = children;
+    size_t len = n_children;              // nodes of the current level in the whole tree
+    uint32_t local = 1u << levels;        // ... of them in this workgroup's subtree
+    for (int t = 0; t < levels; t++) {
+        const uint32_t half = local >> 1;
+        uint32_t* next = cur + len * 8;
+        const LeafCol* icols = inj.cols[t];
+        const size_t first = (size_t)blockIdx.x * half;  // this subtree's first parent of the level
+        // every lane of a group runs the permutation (DPP reads need all 16 active): groups past the subtree redo its first parent
+        const size_t g = first + (group < half ? group : 0);
+        uint32_t x = coop_perm16(cur[g * 16 + j], p, j);
+        if (inj.dig[t]) x = coop_inject_digest(x, p, inj.dig[t], g, j);
+        else if (icols) x = coop_inject(x, p, icols, inj.w[t], g, j);
+        if (group < half && j < 8) next[g * 8 + j] = x;
+        // same-workgroup hand-off through global memory
+        __threadfence_block();
+        __syncthreads();
+        cur = next;
+        len >>= 1;
+        local = half;
+    }
+}
+
 // Collapse n (<= 2048, power of two) nodes to the root in one workgroup.  The levels are stored back
 // to back after `level_base` exactly as the multi-launch path would store them.  Wide levels without injected matrices
 // run one permutation per lane; from 128 parents down, and wherever rows are injected, the permutations are lane-cooperative.
@@ -229,7 +269,7 @@ __global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, u
         size_t half = len >> 1;
         uint32_t* next = cur + len * 8;
         const LeafCol* icols = inj.cols[lvl];
-        if (half > 128 && !icols) {
+        if (half > 128 && !icols && !inj.dig[lvl]) {
             for (size_t i = threadIdx.x; i < half; i += blockDim.x) {
                 uint32_t s[16];
                 load_pair(cur, i, s);
@@ -244,7 +284,8 @@ __global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, u
                 const size_t g = g0 + (threadIdx.x >> 4);
                 const size_t gg = g < half ? g : 0;
                 uint32_t x = coop_perm16(cur[gg * 16 + j], p, j);
-                if (icols) x = coop_inject(x, p, icols, inj.w[lvl], gg, j);
+                if (inj.dig[lvl]) x = coop_inject_digest(x, p, inj.dig[lvl], gg, j);
+                else if (icols) x = coop_inject(x, p, icols, inj.w[lvl], gg, j);
                 if (g < half && j < 8) next[g * 8 + j] = x;
             }
         }
@@ -320,6 +361,15 @@ int32_t merkle_level_digests(lurkhip_ctx* ctx, const P16Params* params_dev, cons
     const size_t blocks = (n_parents + MBLOCK - 1) / MBLOCK;
     hipLaunchKernelGGL(k_level_digests, dim3((unsigned)blocks), dim3(MBLOCK), 0, ctx->stream, params_dev, children, n_parents, inject_digests,
                        parents);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t merkle_levels_coop(lurkhip_ctx* ctx, const P16Params* params_dev, uint32_t* children, size_t n_children, int levels,
+                           const TopInject& inject) {
+    LH_ARG(ctx, levels >= 1 && levels <= 5 && (n_children >> levels) >= 1 && (n_children & (n_children - 1)) == 0, "merkle_levels_coop: bad subtree shape");
+    const size_t blocks = n_children >> levels;
+    hipLaunchKernelGGL(k_levels_coop, dim3((unsigned)blocks), dim3(16u << (levels - 1)), 0, ctx->stream, params_dev, children, n_children, levels, inject);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
