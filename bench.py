@@ -29,6 +29,7 @@ BASELINE config 4 is `--gpus 8 --log-rows 19` (2^22 rows over 8 GPUs).
 Prints ONE JSON line on rank 0.
 """
 import argparse
+import gc
 import json
 import os
 import sys
@@ -252,6 +253,12 @@ def main():
             dist.barrier()
         torch.cuda.synchronize()
 
+    # The interpreter's cyclic collector: `import torch` alone leaves 170 k container objects behind, and the first full
+    # collection over them is a 40-50 ms pause that landed inside one timed step (always the 14th with 3 warm-up steps: one step
+    # of 84-126 ms among 46.9 ms ones).  The set-up's garbage is collected here and what survives is moved to the permanent
+    # generation; the collector stays enabled for everything allocated from now on.
+    gc.collect()
+    gc.freeze()
     fence()  # (the first barrier of a process group sets RCCL up lazily; its aftermath showed up as a 90 ms first timed step)
     for _ in range(args.warmup):
         step()

@@ -69,16 +69,37 @@ BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 // a * b + c on signed 32-bit factors with a 64-bit addend: one v_mad_i64_i32.  Spelled as inline assembly on the device:
 // left to itself the compiler expands a product with a wave-uniform factor into an unsigned multiply-add plus sign fix-ups
 // (five instructions instead of one).  mad_i64_u takes the uniform factor straight from a scalar register.
+// The instruction also writes a carry-out to a scalar register pair nobody reads.  Declared as an output ("=s") every
+// multiply-add defines the same pair, and the compiler -- which cannot look inside inline assembly -- separates any two
+// statements whose definitions overlap by a wait state: an `s_nop 0` after every product of the permutations (149 in the
+// 1918 static instructions of k_row_sponges).  The hardware needs none (the compiler's own v_mad_u64_u32 sequences reuse one
+// carry pair back to back).  So the pair is handed over as an *input* whose value nobody uses -- the program counter, one
+// s_getpc_b64 per kernel, hoisted -- and the instruction overwrites it: LURK_MAD_CARRY_DECLARED=1 restores the declared form.
+#ifndef LURK_MAD_CARRY_DECLARED
+#define LURK_MAD_CARRY_DECLARED 0
+#endif
+#if defined(__HIP_DEVICE_COMPILE__) && !LURK_MAD_CARRY_DECLARED
+#define LURK_MAD_ASM(TEMPLATE, D, ...)                                   \
+    do {                                                                 \
+        const uint64_t carry_scratch_ = __builtin_amdgcn_s_getpc();      \
+        asm(TEMPLATE : "=v"(D) : "s"(carry_scratch_), __VA_ARGS__);      \
+    } while (0)
+#elif defined(__HIP_DEVICE_COMPILE__)
+#define LURK_MAD_ASM(TEMPLATE, D, ...)                                   \
+    do {                                                                 \
+        uint64_t carry_;                                                 \
+        asm(TEMPLATE : "=v"(D), "=s"(carry_) : __VA_ARGS__);             \
+    } while (0)
+#endif
 BB_HD int64_t mad_i64(int32_t a, int32_t b, int64_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     int64_t d;
-    uint64_t carry;
     // a plain product takes the inline constant 0: a zero held in a VGPR pair costs the 64-bit operand read (measured
     // 5.0 against 4.3 cycles per wave-instruction, tools/ubench_issue.hip)
     if (__builtin_constant_p(c) && c == 0)
-        asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "v"(b));
+        LURK_MAD_ASM("v_mad_i64_i32 %0, %1, %2, %3, 0", d, "v"(a), "v"(b));
     else
-        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "v"(b), "v"(c));
+        LURK_MAD_ASM("v_mad_i64_i32 %0, %1, %2, %3, %4", d, "v"(a), "v"(b), "v"(c));
     return d;
 #else
     return (int64_t)a * b + c;
@@ -87,11 +108,10 @@ BB_HD int64_t mad_i64(int32_t a, int32_t b, int64_t c) {
 BB_HD int64_t mad_i64_u(int32_t a, int32_t b_uniform, int64_t c) {
 #if defined(__HIP_DEVICE_COMPILE__)
     int64_t d;
-    uint64_t carry;
     if (__builtin_constant_p(c) && c == 0)
-        asm("v_mad_i64_i32 %0, %1, %2, %3, 0" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform));
+        LURK_MAD_ASM("v_mad_i64_i32 %0, %1, %2, %3, 0", d, "v"(a), "s"(b_uniform));
     else
-        asm("v_mad_i64_i32 %0, %1, %2, %3, %4" : "=v"(d), "=s"(carry) : "v"(a), "s"(b_uniform), "v"(c));
+        LURK_MAD_ASM("v_mad_i64_i32 %0, %1, %2, %3, %4", d, "v"(a), "s"(b_uniform), "v"(c));
     return d;
 #else
     return (int64_t)a * b_uniform + c;

@@ -153,31 +153,59 @@ void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
 
 namespace {
 
-// Build (on device) the uniform column table for the matrices in `idx`
+// The uniform column table of the matrices in `idx` (one LeafCol per column of the concatenated row), written on the device by
+// a kernel that takes the matrices' (base, width) pairs as launch arguments: no host staging, no copy, nothing to keep alive.
+// The table is scratch of the tree being built (pooled, released with the tree's other scratch).  Round 1 cached the tables per
+// context keyed by their matrix pointers and uploaded a miss from host memory; the pool hands a proof's matrices back in a
+// different permutation every proof, so in a proving loop every lookup missed -- a hipMalloc and a pageable copy per group --
+// and the cache's bound (1024 tables, every 17th fib-mix proof) cost 1024 hipFree behind a stream wait: one 80-125 ms step.
+constexpr int COLFILL_MATS = 24;
+struct ColFill {
+    const uint32_t* base[COLFILL_MATS];
+    uint32_t width[COLFILL_MATS];
+    uint32_t start[COLFILL_MATS + 1];  // first column of matrix i in this launch's part of the table
+    uint32_t n;
+};
+__global__ __launch_bounds__(256) void k_fill_cols(LeafCol* __restrict__ out, ColFill a) {
+    const uint32_t i = blockIdx.x * 256u + threadIdx.x;
+    if (i >= a.start[a.n]) return;
+    // (selects over compile-time indices: a run-time index would move the argument block to scratch)
+    const uint32_t* base = a.base[0];
+    uint32_t width = a.width[0], first = 0;
+#pragma unroll
+    for (int k = 1; k < COLFILL_MATS; k++)
+        if ((uint32_t)k < a.n && i >= a.start[k]) {
+            base = a.base[k];
+            width = a.width[k];
+            first = a.start[k];
+        }
+    out[i] = LeafCol{base, width, i - first};
+}
+
 int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int>& idx, LeafCol** out_dev,
-                  uint32_t* total_w) {
-    std::vector<std::pair<const void*, uint32_t>> key;
+                  uint32_t* total_w, std::vector<void*>& scratch) {
     uint32_t n_cols = 0;
-    for (int m : idx) {
-        key.emplace_back(c->lde[m], c->width[m]);
-        n_cols += c->width[m];
-    }
+    for (int m : idx) n_cols += c->width[m];
     *total_w = n_cols;
-    auto it = ctx->leafcol_tables.find(key);
-    if (it != ctx->leafcol_tables.end()) {
-        *out_dev = (LeafCol*)it->second.dev;
-        return LURKHIP_OK;
+    void* dev = nullptr;
+    LH_TRY(pool_alloc(ctx, std::max<size_t>(n_cols, 1) * sizeof(LeafCol), &dev));
+    scratch.push_back(dev);
+    uint32_t done = 0;
+    for (size_t i0 = 0; i0 < idx.size(); i0 += COLFILL_MATS) {
+        ColFill a{};
+        a.n = (uint32_t)std::min<size_t>(COLFILL_MATS, idx.size() - i0);
+        for (uint32_t k = 0; k < a.n; k++) {
+            const int m = idx[i0 + k];
+            a.base[k] = c->lde[m];
+            a.width[k] = c->width[m];
+            a.start[k + 1] = a.start[k] + c->width[m];
+        }
+        const uint32_t part = a.start[a.n];
+        if (part) hipLaunchKernelGGL(k_fill_cols, dim3((part + 255) / 256), dim3(256), 0, ctx->stream, (LeafCol*)dev + done, a);
+        done += part;
     }
-    lurkhip_ctx::LeafColTable& t = ctx->leafcol_tables[key];
-    t.host.resize(std::max<size_t>(n_cols, 1) * sizeof(LeafCol));
-    LeafCol* cols = reinterpret_cast<LeafCol*>(t.host.data());
-    size_t k = 0;
-    for (int m : idx)
-        for (uint32_t j = 0; j < c->width[m]; j++) cols[k++] = LeafCol{c->lde[m], c->width[m], j};
-    LH_HIP(ctx, hipMalloc(&t.dev, t.host.size()));
-    // stream-ordered upload from the entry's own staging buffer: no host wait
-    if (n_cols) LH_HIP(ctx, hipMemcpyAsync(t.dev, t.host.data(), (size_t)n_cols * sizeof(LeafCol), hipMemcpyHostToDevice, ctx->stream));
-    *out_dev = (LeafCol*)t.dev;
+    LH_HIP(ctx, hipGetLastError());
+    *out_dev = (LeafCol*)dev;
     return LURKHIP_OK;
 }
 
@@ -189,15 +217,6 @@ constexpr size_t TOP_NODES = 64;
 int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
-    // Bound the column-table cache HERE, before this tree hands out any table: make_cols results are kept (TopInject) until the
-    // launch that reads them is enqueued, so nothing may be evicted between the first make_cols of a tree and its last launch.
-    // The same invariant covers pool_alloc's out-of-memory path (ctx.hip), which also drops the tables: the only pool_alloc of
-    // a tree (the digests, then the digest buffers of the row groups hashed ahead of the levels) comes before its first make_cols.
-    if (ctx->leafcol_tables.size() >= 1024) {
-        LH_HIP(ctx, stream_wait(ctx));
-        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
-        ctx->leafcol_tables.clear();
-    }
     c->log_max = *std::max_element(c->log_h.begin(), c->log_h.end());
     // stable order by height, tallest first (p3 sorts matrices by height descending)
     std::vector<int> order(c->n_mats);
@@ -233,7 +252,6 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     // too: hashed where they are injected, the 1963 columns of a fib machine's hash chips (512 LDE rows) were 246 cooperative
     // permutations in a row -- one 0.9 ms launch of 512 workgroups -- and in the sponge launch they are 8 waves among thousands.
     const bool prehash_all = fused && coop_group > 1;
-    // (the digest buffers of the injected groups are allocated before the first make_cols: see the invariant above)
     if (fused)
         for (int l = 1, groups = 1; l <= c->log_max && groups < SPONGE_MAX_GROUPS; l++) {
             const size_t n_parents = n_leaves >> l;
@@ -254,7 +272,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
     {
-        const int32_t st = make_cols(ctx, c, tallest, &cols, &tw);
+        const int32_t st = make_cols(ctx, c, tallest, &cols, &tw, scratch);
         if (st != LURKHIP_OK) {
             drop_scratch();
             return st;
@@ -276,7 +294,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
                 if (c->log_h[m] == c->log_max - l) inject.push_back(m);
             LeafCol* icols = nullptr;
             uint32_t iw = 0;
-            st = make_cols(ctx, c, inject, &icols, &iw);
+            st = make_cols(ctx, c, inject, &icols, &iw, scratch);
             g.cols[g.n] = icols;
             g.total_w[g.n] = iw;
             g.n_rows[g.n] = n_leaves >> l;
@@ -289,7 +307,11 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             return st;
         }
     } else {
-        LH_TRY(merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests));
+        const int32_t st = merkle_leaves(ctx, params, cols, tw, n_leaves, c->digests);
+        if (st != LURKHIP_OK) {
+            drop_scratch();
+            return st;
+        }
     }
     const char* stage = "merkle_leaves";  // the span that is open
     // inner levels
@@ -315,7 +337,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
                     if (c->log_h[m] == lh - t) inj.push_back(m);
                 if (inj.empty()) continue;
                 LeafCol* tc = nullptr;
-                status = make_cols(ctx, c, inj, &tc, &ti.w[t]);
+                status = make_cols(ctx, c, inj, &tc, &ti.w[t], scratch);
                 ti.cols[t] = tc;
             }
             if (status != LURKHIP_OK) break;
@@ -347,7 +369,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
                     if (c->log_h[m] == lh - t) inj.push_back(m);
                 if (inj.empty()) continue;
                 LeafCol* tc = nullptr;
-                status = make_cols(ctx, c, inj, &tc, &ti.w[t]);
+                status = make_cols(ctx, c, inj, &tc, &ti.w[t], scratch);
                 ti.cols[t] = tc;
             }
             if (status == LURKHIP_OK) status = merkle_levels_coop(ctx, params, children, n_parents << 1, group, ti);
@@ -356,7 +378,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         }
         LeafCol* icols = nullptr;
         uint32_t iw = 0;
-        if (!inject.empty()) status = make_cols(ctx, c, inject, &icols, &iw);
+        if (!inject.empty()) status = make_cols(ctx, c, inject, &icols, &iw, scratch);
         if (status == LURKHIP_OK) status = merkle_level(ctx, params, children, n_parents, icols, iw, parents);
     }
     drop_scratch();

@@ -34,13 +34,6 @@ struct lurkhip_ctx {
     // coset-shift power tables of the LDE, s^i / N for i < N, keyed by (log_n, s): immutable once filled, so a table is
     // computed once per context instead of once per matrix (commit.hip: extend)
     std::map<std::pair<int, uint32_t>, uint32_t*> lde_scale_tables;
-    // Merkle leaf-column tables (commit.hip: make_cols) keyed by their (matrix pointer, width) lists: the pooled allocator
-    // hands the same buffers to every proof, so after the first one a commit uploads nothing
-    struct LeafColTable {
-        void* dev = nullptr;
-        std::vector<unsigned char> host;  // staging of the asynchronous upload, kept as long as the entry
-    };
-    std::map<std::vector<std::pair<const void*, uint32_t>>, LeafColTable> leafcol_tables;
     size_t lde_scale_bytes = 0;
     std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)

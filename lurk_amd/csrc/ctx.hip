@@ -74,8 +74,7 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out) {
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
     std::lock_guard<std::mutex> lock(ctx->pool_mu);
-    // most recently released block of this size first (LIFO): a proof's sequence of allocations then lands in the same buffers
-    // as the previous proof's, which is what the pointer-keyed table caches (Merkle leaf columns) rely on
+    // most recently released block of this size first (LIFO): the block most likely still in the caches
     auto range = ctx->pool_free.equal_range(bytes);
     if (range.first != range.second) {
         auto it = std::prev(range.second);
@@ -94,8 +93,6 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
         for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
         ctx->lde_scale_tables.clear();
         ctx->lde_scale_bytes = 0;
-        for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
-        ctx->leafcol_tables.clear();
         e = hipMalloc(out, bytes);
     }
     if (e != hipSuccess)
@@ -277,7 +274,6 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     spans_resolve(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
-    for (auto& kv : ctx->leafcol_tables) (void)hipFree(kv.second.dev);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
     for (int i = 0; i < 4; i++)

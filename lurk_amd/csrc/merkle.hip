@@ -135,6 +135,12 @@ __global__ __launch_bounds__(MBLOCK) void k_level(const P16Params* __restrict__ 
 }
 
 // several height groups' row sponges in one grid (merkle_row_sponges): the block's group by its first_block range
+#ifndef LURK_SPONGE_WAVES_PER_EU
+#define LURK_SPONGE_WAVES_PER_EU 0
+#endif
+#if LURK_SPONGE_WAVES_PER_EU
+__attribute__((amdgpu_waves_per_eu(LURK_SPONGE_WAVES_PER_EU, LURK_SPONGE_WAVES_PER_EU)))
+#endif
 __global__ __launch_bounds__(MBLOCK) void k_row_sponges(const P16Params* __restrict__ p, SpongeGroups g) {
     int k = 0;
     while (k + 1 < g.n && blockIdx.x >= g.first_block[k + 1]) k++;
