@@ -57,6 +57,10 @@ int32_t lurkhip_abi_version(void);
 
 /* Creates a context on HIP device `device_id` with its own non-blocking stream. */
 int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out);
+/* Same with a stream priority: 0 = the device's default, > 0 lower, < 0 higher (clamped to the device's range), for a context
+ * that proves beside another one (a second prove lane, a staging context).  Measured on two half-shards in flight: no difference
+ * between equal and unequal queues on this part, so the Python mirror leaves it at 0. */
+int32_t lurkhip_ctx_create_with_priority(int32_t device_id, int32_t priority, lurkhip_ctx** out);
 /* Same, but all work is enqueued on the caller's hipStream_t (e.g. torch's current stream). */
 int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhip_ctx** out);
 int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx);

@@ -58,6 +58,7 @@ _i64 = C.c_int64
 SIGNATURES = {
     "lurkhip_abi_version": (_i32, []),
     "lurkhip_ctx_create": (_i32, [_i32, C.POINTER(_p)]),
+    "lurkhip_ctx_create_with_priority": (_i32, [_i32, _i32, C.POINTER(_p)]),
     "lurkhip_ctx_create_on_stream": (_i32, [_i32, _p, C.POINTER(_p)]),
     "lurkhip_ctx_destroy": (_i32, [_p]),
     "lurkhip_ctx_sync": (_i32, [_p]),

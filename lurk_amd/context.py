@@ -26,11 +26,14 @@ def as_u32(a) -> np.ndarray:
 
 class Context:
     """Owns a ``lurkhip_ctx``.  ``stream`` may be a raw ``hipStream_t`` value (for
-    example ``torch.cuda.current_stream().cuda_stream``) to enqueue on a caller stream."""
+    example ``torch.cuda.current_stream().cuda_stream``) to enqueue on a caller stream; ``priority`` (0 default, > 0 lower) is
+    that of the context's own streams."""
 
-    def __init__(self, device: int = 0, stream: int | None = None):
+    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0):
         h = C.c_void_p()
-        if stream is None:
+        if stream is None and priority:
+            N.check(N.lib.lurkhip_ctx_create_with_priority(device, priority, C.byref(h)))
+        elif stream is None:
             N.check(N.lib.lurkhip_ctx_create(device, C.byref(h)))
         else:
             N.check(N.lib.lurkhip_ctx_create_on_stream(device, C.c_void_p(stream), C.byref(h)))

@@ -17,6 +17,7 @@ struct lurkhip_ctx {
     int num_cus = 256;  // compute units of the device (persistent-kernel grids)
     hipStream_t stream = nullptr;
     bool owns_stream = false;
+    int stream_priority = 0;  // of the context's own streams (lurkhip_ctx_create_with_priority)
     std::string err;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // grow-only scratch arenas for the host-pointer entry points

@@ -124,7 +124,7 @@ int32_t SideLane::open() {
     static const bool enabled = getenv("LURKHIP_SIDE_LANE") == nullptr || atoi(getenv("LURKHIP_SIDE_LANE")) != 0;
     if (!enabled || active) return LURKHIP_OK;
     if (!ctx->side_stream) {
-        LH_HIP(ctx, hipStreamCreateWithFlags(&ctx->side_stream, hipStreamNonBlocking));
+        LH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, ctx->stream_priority));
         LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
         LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
     }
@@ -213,7 +213,7 @@ static void spans_resolve(lurkhip_ctx* ctx) {
     for (hipEvent_t e : used) ctx->event_pool.push_back(e);
 }
 
-static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkhip_ctx** out) {
+static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkhip_ctx** out, int32_t priority = 0) {
     if (!out) return set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null out pointer");
     *out = nullptr;
     int count = 0;
@@ -236,8 +236,11 @@ static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkh
         ctx->stream = (hipStream_t)stream;
         ctx->owns_stream = false;
     } else {
-        if ((e = hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking)) != hipSuccess)
-            return fail(e, "hipStreamCreateWithFlags");
+        int least = 0, greatest = 0;  // numerically: least >= greatest
+        if (priority != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
+            ctx->stream_priority = std::max(greatest, std::min(least, (int)priority));
+        if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ctx->stream_priority)) != hipSuccess)
+            return fail(e, "hipStreamCreateWithPriority");
         ctx->owns_stream = true;
     }
     {
@@ -257,6 +260,10 @@ using namespace lurkhip;
 extern "C" {
 
 int32_t lurkhip_abi_version(void) { return 2; }  // 2: protocol profile, lurkhip_proof_read capacity, bytecode import, lurkhip_open
+
+int32_t lurkhip_ctx_create_with_priority(int32_t device_id, int32_t priority, lurkhip_ctx** out) {
+    return create_common(device_id, nullptr, false, out, priority);
+}
 
 int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out) {
     return create_common(device_id, nullptr, false, out);

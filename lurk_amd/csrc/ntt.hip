@@ -110,6 +110,11 @@ __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
 #ifndef LURK_NTT_SWZ_MAX_LOG_R
 #define LURK_NTT_SWZ_MAX_LOG_R 9
 #endif
+// row slots per column of a 1024-row tile (A/B: 32 = sixteen column items x 32 slots = 512 threads of up to 256 VGPRs)
+#ifndef LURK_NTT_TALL_LOG_SLOTS
+#define LURK_NTT_TALL_LOG_SLOTS 6
+#endif
+#define LURK_NTT_TALL_SLOTS (1 << LURK_NTT_TALL_LOG_SLOTS)
 template <int LOG_R>
 __host__ __device__ constexpr int swz(int t) {
     if (LOG_R > LURK_NTT_SWZ_MAX_LOG_R) return t;
@@ -202,9 +207,9 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     constexpr int EW = (int)(sizeof(T) / 4);  // matrix columns per element
     // rows a thread stages per tile: 8, and 16 for the 1024-row tiles so that the row slots of a column stay the 64 lanes of
     // one wave (the stage groups rely on it: wave-local ordering instead of workgroup barriers)
-    constexpr int U = R < 8 ? R : (LOG_R > 9 ? R / 64 : 8);
+    constexpr int U = R < 8 ? R : (LOG_R > 9 ? R / LURK_NTT_TALL_SLOTS : 8);
     constexpr int SLOTS = R / U;              // row slots per workgroup: thread = (slot, column item), slot < SLOTS
-    constexpr int LOG_U = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - 6 : 3);
+    constexpr int LOG_U = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - LURK_NTT_TALL_LOG_SLOTS : 3);
     constexpr int LOG_SLOTS = LOG_R - LOG_U;
     static_assert(SLOTS <= 64, "a column's row slots are lanes of one wave");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -339,7 +344,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_W
 // tiles of 256 .. 1024 rows: one workgroup of up to 16 waves per CU (its LDS tile is most of the CU's 160 KiB), so each wave may
 // use the 128 VGPRs of a 4-waves-per-SIMD kernel -- the 1024-row tiles stage sixteen rows per thread
 template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
-__global__ __launch_bounds__(1024) void k_ntt_pass_tall(PassArgs a) {
+__global__ __launch_bounds__(LOG_R > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024) void k_ntt_pass_tall(PassArgs a) {
     ntt_pass_body<LOG_R, T, BIG, SCALE, TWN>(a);
 }
 
@@ -471,7 +476,8 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     }
     const bool aligned8 = (all_ptrs & 7u) == 0 && w % 2 == 0;
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
-    auto rows_per_thread = [](int log_r) { return log_r > 9 ? (1 << log_r) / 64 : 8; };  // the kernel's U
+    auto rows_per_thread = [](int log_r) { return log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8; };  // the kernel's U
+    auto max_threads = [](int log_r) { return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024; };  // the kernels' launch bounds
     auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r)) * items_of(cols); };
     auto lds_bytes = [](int log_r, int cols, int log_l) {
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
@@ -487,7 +493,7 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     if (const char* e = getenv("LURKHIP_NTT_LDS_CAP_KB")) lds_cap = (size_t)std::max(8, atoi(e)) * 1024;  // A/B hook: tile bytes per workgroup
     // column chunk: the widest even divisor of w that fits (no ragged chunk), else the widest even width that fits (the ragged
     // remainder gets its own launch); narrow matrices are one chunk
-    auto fits = [&](int cols) { return lds_bytes(max_log_r, cols, 0) <= lds_cap && threads_of(max_log_r, cols) <= 1024; };
+    auto fits = [&](int cols) { return lds_bytes(max_log_r, cols, 0) <= lds_cap && threads_of(max_log_r, cols) <= max_threads(max_log_r); };
     int col_chunk = w;
     if (!fits(w)) {
         int widest = 2;
@@ -503,13 +509,13 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
                 break;
             }
     }
-    while ((lds_bytes(max_log_r, col_chunk, 0) > lds_cap || threads_of(max_log_r, col_chunk) > 1024) && max_log_r > 1)
+    while ((lds_bytes(max_log_r, col_chunk, 0) > lds_cap || threads_of(max_log_r, col_chunk) > max_threads(max_log_r)) && max_log_r > 1)
         max_log_r--;
     // The tile's twiddles are staged by at most four loads per thread, so a launch has at least 2^(log_r + log_l) / 4 threads:
     // a narrow (ragged) chunk of a tall tile gets idle threads -- they shadow a real thread's loads and write nothing.
     auto launch_threads = [&](int log_r, int cols, int log_l) {
         const int need = (int)((((size_t)1 << (log_r + log_l)) + 3) / 4);
-        return std::min(1024, (std::max(threads_of(log_r, cols), need) + 63) / 64 * 64);
+        return std::min(max_threads(log_r), (std::max(threads_of(log_r, cols), need) + 63) / 64 * 64);
     };
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
@@ -541,7 +547,7 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
         int log_l = 0;
         if (n_full == 1 && last_w == 0 && a.bit_lo > 0 && !a.bitrev_store) {
             while (log_l < 4 && log_l < a.bit_lo && (w << (log_l + 1)) <= 128 &&
-                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= lds_cap && threads_of(log_r, w << (log_l + 1)) <= 1024 &&
+                   lds_bytes(log_r, w << (log_l + 1), log_l + 1) <= lds_cap && threads_of(log_r, w << (log_l + 1)) <= max_threads(log_r) &&
                    ((size_t)1 << (log_r + log_l + 1)) <= (size_t)4 * launch_threads(log_r, w << (log_l + 1), log_l + 1))
                 log_l++;
         }
@@ -556,7 +562,7 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
             const bool pair = aligned8 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
             const int cv = a.col_chunk / (pair ? 2 : 1);
             const int slots = std::max(1, (1 << log_r) / rows_per_thread(log_r));  // the kernel's SLOTS
-            LH_ARG(ctx, slots * cv <= 1024, "NTT tile shape");
+            LH_ARG(ctx, slots * cv <= max_threads(log_r), "NTT tile shape");
             a.magic_cv = magic_for(cv);
             const int threads = launch_threads(log_r, a.col_chunk, log_l);
             const size_t tiles = ((size_t)1 << (log_n - log_r - log_l)) * a.n_chunks;

@@ -22,6 +22,7 @@ Proof word layout (canonical values), written by lurk_amd/csrc/prover.hip:
 from __future__ import annotations
 
 import ctypes as C
+import os
 from dataclasses import dataclass, field as dfield
 
 import numpy as np
@@ -176,6 +177,10 @@ class _ShardProver:
         if self.pk:
             N.lib.lurkhip_pk_free(self.ctx.handle, self.pk)
             self.pk = None
+        pool = getattr(self, "_lane_pool", None)
+        if pool is not None:  # the second prove lane's worker thread (prove_lanes)
+            pool.shutdown(wait=True)
+            self._lane_pool = None
         if self._side_ctx is not None:
             self._side_ctx.close()
             self._side_ctx = None
@@ -488,7 +493,7 @@ class Machine(_ShardProver):
         lane_ctx = None
         if lanes > 1:
             if self._lane_ctx is None:
-                self._lane_ctx = Context(self.ctx.device)
+                self._lane_ctx = Context(self.ctx.device, priority=LANE_PRIORITY)
             lane_ctx = lane_context(self, self._lane_ctx)
         proofs = []
         for at in range(0, len(shards), lanes):
@@ -509,11 +514,16 @@ class Machine(_ShardProver):
         return proofs
 
 
+# stream priority of a second prove lane (0 = equal queues, > 0 lower; measured on the two-shard bench step: no difference
+# between 0, 1 and -1, so the queues stay equal; LURKHIP_LANE_PRIORITY for A/B measurements)
+LANE_PRIORITY = int(os.environ.get("LURKHIP_LANE_PRIORITY", "0"))
+
+
 def lane_context(machine, ctx=None):
     """A second context for `prove_lanes` on the machine's device with the machine context's protocol profile."""
     from .profile import ProtocolProfile
 
-    ctx = ctx or Context(machine.ctx.device)
+    ctx = ctx or Context(machine.ctx.device, priority=LANE_PRIORITY)
     ProtocolProfile.of(machine.ctx).install(ctx)
     return ctx
 
@@ -524,8 +534,6 @@ def prove_lanes(machine, handles, transcript: Challenger, pv, num_queries, pow_b
     shard sits in a latency chain (FRI layers, tree tails, transcript round trips) the other's big kernels fill the device
     (+14 % shards per second on the fib-mix shard).  The proofs are the sequential ones, in shard order.  One lane when
     `lane_ctx` is None or there is a single shard."""
-    import threading
-
     if lane_ctx is None or len(handles) < 2:
         return [machine.prove_shard(h, transcript.clone(), pv, num_queries, pow_bits, parse=parse) for h in handles]
     machine.ctx.sync()  # the commitments the second lane reads were made on this context's stream
@@ -539,11 +547,16 @@ def prove_lanes(machine, handles, transcript: Challenger, pv, num_queries, pow_b
         except BaseException as e:  # surfaced after the join
             errors.append(e)
 
-    ths = [threading.Thread(target=lane, args=(0, None)), threading.Thread(target=lane, args=(1, lane_ctx))]
-    for t in ths:
-        t.start()
-    for t in ths:
-        t.join()
+    # lane 0 on the calling thread, lane 1 on ONE long-lived worker of the machine: a host thread that has made HIP calls is not
+    # cheap to start and end (two fresh threads per call cost a bench step 4.5 or 9 ms every other time)
+    pool = getattr(machine, "_lane_pool", None)
+    if pool is None:
+        from concurrent.futures import ThreadPoolExecutor
+
+        pool = machine._lane_pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="lurkhip-lane")
+    other = pool.submit(lane, 1, lane_ctx)
+    lane(0, None)
+    other.result()
     if errors:
         raise errors[0]
     return proofs

@@ -6,7 +6,7 @@ cd /tmp && export TMPDIR=/tmp
 out=$R/gpurun_out/trace_$tag
 mkdir -p $out
 cd $R
-rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace_$tag -o bench -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-two-in-flight "$@" > $out/bench.log 2>&1
+rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/trace_$tag -o bench -- python bench.py --no-cpu-baseline --no-two-in-flight --no-host-pipeline "$@" > $out/bench.log 2>&1
 cp /tmp/trace_$tag/bench_kernel_stats.csv $out/ 2>/dev/null
 python3 - <<PY
 import csv

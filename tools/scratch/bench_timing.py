@@ -37,7 +37,9 @@ import time
 
 import numpy as np
 
-ROOT = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+_T = []
+
 if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
@@ -208,6 +210,7 @@ def main():
     host_ms = {}  # host milliseconds spent in the two collectives (all steps, warm-up included)
 
     def step():
+        _tt = [("start", time.perf_counter())]
         # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shards
         handles, roots = [], []
         for pr in prepared_all:
@@ -217,6 +220,7 @@ def main():
             handle, root = machine.commit_shard(traces)
             handles.append(handle)
             roots.append(root)
+            _tt.append(("phase1_shard", time.perf_counter()))
         # the transcript prefix: every shard's main root in shard order (RCCL all-gather of index + 8 lanes per shard) and the
         # public values
         ch = prover.Challenger(ctx)
@@ -228,10 +232,12 @@ def main():
         for r in gathered:
             ch.observe(r)
             ch.observe(pv)
-        # phase 2 (prove_shard), two shards in flight when the rank has several
+        _tt.append(("pre", time.perf_counter()))
         proofs = prover.prove_lanes(machine, handles, ch, pv, args.queries, args.pow_bits, parse=False, lane_ctx=lane_ctx)
+        _tt.append(("prove_lanes", time.perf_counter()))
         for handle in handles:
             machine.free_shard(handle)
+            _tt.append(("free_shard", time.perf_counter()))
         # grand-sum check: the chips' cumulative sums, reduced over all shards (RCCL all-reduce of 4 x int64)
         cs = []
         for words in proofs:
@@ -241,10 +247,14 @@ def main():
         for c in cs:
             mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % 2013265921
         rank_sums.append(tuple(int(x) for x in mine_sum))
+        _tt.append(("sums", time.perf_counter()))
         t_x = time.perf_counter()
         grand_sums.append(shards.reduce_cumulative_sums(cs, device=dev))
         host_ms["reduce_sums"] = host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t_x) * 1e3
-        return np.concatenate(proofs) if len(proofs) > 1 else proofs[0]
+        out = np.concatenate(proofs) if len(proofs) > 1 else proofs[0]
+        _tt.append(("end", time.perf_counter()))
+        _T.append(_tt)
+        return out
 
     def fence():
         ctx.sync()
@@ -279,6 +289,8 @@ def main():
         step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
     fence()
     elapsed = time.perf_counter() - t0
+    for _tt in _T[-args.steps:]:
+        print(" ".join("%s=%.2f" % (b[0], (b[1] - a[1]) * 1e3) for a, b in zip(_tt, _tt[1:])), file=sys.stderr)
     proofs_identical = all(len(w) == len(step_words[0]) and bool((w == step_words[0]).all()) for w in step_words[1:])
     del step_words
     ctx.profile_enable(False)
