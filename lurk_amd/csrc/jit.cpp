@@ -16,6 +16,7 @@
 
 #include <string.h>
 
+#include <atomic>
 #include <map>
 #include <mutex>
 #include <sstream>
@@ -117,6 +118,7 @@ std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
 namespace {
 // compiled code objects by source text: a second context / machine of the same toplevel compiles nothing
 std::mutex g_cache_mu;
+std::atomic<unsigned> g_tmp_serial{0};  // two threads of one process may compile the same source: distinct temporary files
 std::map<std::string, std::vector<char>> g_code_cache;
 
 bool load_module(const std::vector<char>& code, JitKernels* out, std::string* log) {
@@ -230,7 +232,7 @@ void disk_store(const std::string& key, const std::vector<char>& code) {
     const std::string dir = cache_dir();
     if (dir.empty()) return;
     (void)mkdir(dir.c_str(), 0755);
-    const std::string final_path = dir + "/" + key + ".hsaco", tmp = final_path + ".tmp" + std::to_string((long)getpid());
+    const std::string final_path = dir + "/" + key + ".hsaco", tmp = final_path + ".tmp" + std::to_string((long)getpid()) + "." + std::to_string(g_tmp_serial.fetch_add(1));
     FILE* f = fopen(tmp.c_str(), "wb");
     if (!f) return;  // read-only tree: the in-process cache still serves this process
     const bool ok = fwrite(code.data(), 1, code.size(), f) == code.size();

@@ -170,6 +170,8 @@ class _ShardProver:
     """commit / prove / free of one shard's chip list through the C ABI; shared by the Lair `Machine` and the generic
     `StarkMachine`.  Subclasses provide `self.ctx`, `self.pk`, `self.chips` and `_prep_index(machine_index)`."""
 
+    _lane_pool = None  # the second prove lane's worker thread (prove_lanes), started on first use
+
     def _prep_index(self, machine_index: int) -> int:
         return -1
 
@@ -177,8 +179,8 @@ class _ShardProver:
         if self.pk:
             N.lib.lurkhip_pk_free(self.ctx.handle, self.pk)
             self.pk = None
-        pool = getattr(self, "_lane_pool", None)
-        if pool is not None:  # the second prove lane's worker thread (prove_lanes)
+        pool = self._lane_pool
+        if pool is not None:
             pool.shutdown(wait=True)
             self._lane_pool = None
         if self._side_ctx is not None:
@@ -549,7 +551,7 @@ def prove_lanes(machine, handles, transcript: Challenger, pv, num_queries, pow_b
 
     # lane 0 on the calling thread, lane 1 on ONE long-lived worker of the machine: a host thread that has made HIP calls is not
     # cheap to start and end (two fresh threads per call cost a bench step 4.5 or 9 ms every other time)
-    pool = getattr(machine, "_lane_pool", None)
+    pool = machine._lane_pool
     if pool is None:
         from concurrent.futures import ThreadPoolExecutor
 

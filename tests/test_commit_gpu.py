@@ -92,6 +92,26 @@ def test_commit_injection_at_cooperative_levels(ctx, oracle):
     c.close()
 
 
+def test_commit_many_matrices_per_height_group(ctx, oracle):
+    """The column table of a height group is written on the device from launch arguments, 24 matrices per launch: groups of
+    more than 24 (and of exactly 24, 25 and 49) matrices -- as leaves, injected at a one-lane-per-node level, at a cooperative
+    level and inside the one-workgroup top -- must give the oracle's tree, and the openings their rows."""
+    shapes = [(15, 3)] * 25 + [(14, 2)] * 49 + [(9, 5)] * 24 + [(4, 7)] * 26 + [(2, 1)] * 30
+    mats = [synth.field_elements((1 << k, w), seed=2600 + i) for i, (k, w) in enumerate(shapes)]
+    c = cm.commit(ctx, mats, log_blowup=1)
+    ldes = [oracle.lde(m, 1) for m in mats]
+    root, _ = oracle.merkle_commit(ldes)
+    assert np.array_equal(c.root, root)
+    lh = [k + 1 for k, _ in shapes]
+    ws = [w for _, w in shapes]
+    for index in (0, 12345, 65535):
+        rows, path = c.open(index)
+        want = np.concatenate([ldes[i][index >> (16 - lh[i])] for i in range(len(mats))])
+        assert np.array_equal(rows, want)
+        assert oracle.merkle_verify(lh, ws, index, rows, path, c.root)
+    c.close()
+
+
 def test_commit_same_shape_matrices_share_their_passes(ctx, oracle):
     """Device-resident matrices of one (height, width) go through the NTT passes in one launch per pass (up to 8 per launch):
     eleven 2^10 x 4 matrices (a batch of 8 and one of 3), three 2^9 x 12, pairs with an odd width and a single one."""

@@ -97,3 +97,26 @@ def test_streamed_proof_equals_machine_prove(ctx):
         assert np.array_equal(a.words, b.words)
         assert np.array_equal(c.words, b.words)
     assert prover.grand_sum(got) == (0, 0, 0, 0)
+
+
+def test_second_lane_on_a_lower_priority_context(ctx):
+    """lurkhip_ctx_create_with_priority: the second prove lane on a context whose streams have a lower priority, called twice
+    (the lane's worker thread is the machine's, started once and reused): the proofs are the one-lane ones."""
+    mix = lm.fib_mix(1 << 10)
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute(top.func_index(mix.entry), mix.main_args, q)
+    pv = q.expect_public_values()
+    cfg = lair.ShardingConfig(1 << 8)
+    m = prover.Machine(ctx, top, mix.entry, len(pv))
+    m.setup()
+    want = m.prove(q, cfg, num_queries=4, pow_bits=2, lanes=1)
+    with lurk_amd.Context(0, priority=1) as low, lurk_amd.Context(0, priority=-1) as high:
+        for lane_ctx in (low, high, low):
+            got = prover.prove_streamed(m, q, cfg, num_queries=4, pow_bits=2, input_ctx=lane_ctx)
+            assert len(got) == len(want)
+            for a, b in zip(got, want):
+                assert np.array_equal(a.words, b.words)
+        assert m._lane_pool is not None  # one worker for all three calls
+    m.close()
+    assert m._lane_pool is None
