@@ -539,7 +539,7 @@ def main():
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,
                 "ms_per_step": hash_ms_step,
-                "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (~5.0 k int32 instructions each, ~60 % of them multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4)",
+                "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (4.76 k int32 instructions each, ~56 % of them four-cycle multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD): k_row_sponges takes 19.9 k SIMD cycles per wave-permutation, the rate of the permutation alone on registers (tools/ubench_perm.hip: 20.8-21.1 k), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4)",
             },
         }
         if world == 1 and spr == 1 and not args.no_cpu_baseline:
