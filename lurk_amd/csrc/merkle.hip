@@ -249,11 +249,15 @@ __global__ __launch_bounds__(256) void k_levels_coop(const P16Params* __restrict
         const LeafCol* icols = inj.cols[t];
         const size_t first = (size_t)blockIdx.x * half;  // this subtree's first parent of the level
         // every lane of a group runs the permutation (DPP reads need all 16 active): groups past the subtree redo its first parent
-        const size_t g = first + (group < half ? group : 0);
-        uint32_t x = coop_perm16(cur[g * 16 + j], p, j);
-        if (inj.dig[t]) x = coop_inject_digest(x, p, inj.dig[t], g, j);
-        else if (icols) x = coop_inject(x, p, icols, inj.w[t], g, j);
-        if (group < half && j < 8) next[g * 8 + j] = x;
+        // (a wave whose four groups all lie past the level skips it: with four workgroups per CU the idle waves' permutations
+        // took issue slots from the working ones)
+        if (((threadIdx.x & ~63u) >> 4) < half) {
+            const size_t g = first + (group < half ? group : 0);
+            uint32_t x = coop_perm16(cur[g * 16 + j], p, j);
+            if (inj.dig[t]) x = coop_inject_digest(x, p, inj.dig[t], g, j);
+            else if (icols) x = coop_inject(x, p, icols, inj.w[t], g, j);
+            if (group < half && j < 8) next[g * 8 + j] = x;
+        }
         // same-workgroup hand-off through global memory
         __threadfence_block();
         __syncthreads();
@@ -288,6 +292,9 @@ __global__ __launch_bounds__(1024) void k_top(const P16Params* __restrict__ p, u
             const int j = threadIdx.x & 15;
             for (size_t g0 = 0; g0 < half; g0 += blockDim.x / 16) {
                 const size_t g = g0 + (threadIdx.x >> 4);
+                // a wave whose four groups all lie past the level has nothing to do: sixteen waves redoing parent 0 shared the
+                // SIMDs four to one and made every level of the top cost four permutations' issue time (6.3 us against 3.5)
+                if (g0 + ((threadIdx.x & ~63u) >> 4) >= half) continue;
                 const size_t gg = g < half ? g : 0;
                 uint32_t x = coop_perm16(cur[gg * 16 + j], p, j);
                 if (inj.dig[lvl]) x = coop_inject_digest(x, p, inj.dig[lvl], gg, j);

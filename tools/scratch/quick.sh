@@ -1,0 +1,9 @@
+#!/bin/bash
+R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/quick
+python -m pytest tests/test_commit_gpu.py tests/test_prover_gpu.py tests/test_poseidon2_gpu.py -m gpu -x -q 2>&1 | tail -2
+for i in 1 2; do python bench.py --no-cpu-baseline --no-two-in-flight --no-host-pipeline > gpurun_out/quick/b$i.json 2>/dev/null; done
+python - <<'PY'
+import json,glob
+for f in sorted(glob.glob('gpurun_out/quick/b*.json')):
+    d=json.loads(open(f).read().strip().splitlines()[-1]); print(f.split('/')[-1], round(d['ms_per_step'],2), {k:round(v,2) for k,v in d['config']['stages_ms'].items()})
+PY
