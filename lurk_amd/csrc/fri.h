@@ -13,12 +13,31 @@ namespace lurkhip {
 //   mode 0: w_M^bitrev(s) / (z - x_s)   (barycentric weights of the coset 31 * <w_M>)
 //   mode 1: 1 / (x_s - z)
 int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, uint32_t* out_dev);
+// several tables in one launch (mode 0 tables centred, as point_weights writes them)
+constexpr int PW_BATCH_MAX = 48;
+struct WeightJob {
+    int mode, log_m;
+    bb::ef z;
+    uint32_t* out;
+};
+int32_t point_weights_batch(lurkhip_ctx* ctx, const std::vector<WeightJob>& jobs);
 // Opened values.  partial[blk][p][c] = sum over the block's rows of mat[s][c] * u_p[s] (p = 0, and 1 when u1 != null) for
 // one matrix; column_dot_finish then sums the blocks of every matrix of the proof in one launch:
 // out_dev[out_off + (p * w + c) * 4 ..] = sum_{s < n_rows} mat[s][c] * u_p[s].
 size_t column_dot_partial_words(uint32_t w, size_t n_rows);
 int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
                            uint32_t* partial_dev);
+// the narrow matrices (column_dot_is_narrow: the ones column_dot_partial gives to the slab kernel) of an opening in one launch
+constexpr int NARROW_DOT_MAX = 64;
+struct NarrowDot {
+    const uint32_t* mat;
+    uint32_t w;
+    size_t n_rows;
+    const uint32_t *u0, *u1;
+    uint32_t* partial;
+};
+bool column_dot_is_narrow(uint32_t w);
+int32_t column_dot_partial_batch(lurkhip_ctx* ctx, const std::vector<NarrowDot>& items);
 struct DotJob {
     const uint32_t* partial;
     uint32_t w;

@@ -46,8 +46,8 @@ __device__ __forceinline__ uint32_t brev_bits(uint32_t x, int bits) { return bit
 // norm N(a) = a * a' * (a a')'' in the base field (two conjugations), and the four norms are inverted together
 // (Montgomery's trick: 9 products + 1 Fermat ladder instead of 4 ladders).
 constexpr int PW_BATCH = 4;
-__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, const uint32_t* __restrict__ tw, ef z, uint32_t* __restrict__ out,
-                                int centred) {
+__device__ __forceinline__ void point_weights_body(int mode, int log_m, uint32_t g_m, const uint32_t* __restrict__ tw, const ef& z,
+                                                   uint32_t* __restrict__ out, int centred) {
     const uint32_t m = 1u << log_m, half = m >> 1;
     const uint32_t s0 = (blockIdx.x * blockDim.x + threadIdx.x) * PW_BATCH;
     if (s0 >= m) return;
@@ -91,6 +91,22 @@ __global__ void k_point_weights(int mode, int log_m, uint32_t g_m, const uint32_
         if (s0 + k < m) ef_store(out + 4 * (size_t)(s0 + k), r);
     }
 }
+__global__ void k_point_weights(int mode, int log_m, uint32_t g_m, const uint32_t* __restrict__ tw, ef z, uint32_t* __restrict__ out,
+                                int centred) {
+    point_weights_body(mode, log_m, g_m, tw, z, out, centred);
+}
+// every table of an opening in one launch (blockIdx.y = table): launched one by one the forty tables of a fib-mix proof were
+// forty dependent launches of 9-23 us on the main lane
+struct PwBatchArgs {
+    int mode[PW_BATCH_MAX], log_m[PW_BATCH_MAX];
+    const uint32_t* tw[PW_BATCH_MAX];
+    ef z[PW_BATCH_MAX];
+    uint32_t* out[PW_BATCH_MAX];
+};
+__global__ void k_point_weights_batch(PwBatchArgs a, uint32_t g_m) {
+    const int t = blockIdx.y;
+    point_weights_body(a.mode[t], a.log_m[t], g_m, a.tw[t], a.z[t], a.out[t], a.mode[t] == 0 ? 1 : 0);
+}
 
 // ---------------------------------------------------------------- column-wise dot products with EF weights
 // partial[blk][p][c] = sum over the block's rows of mat[s][c] * u_p[s].  A workgroup walks its rows R at a time, R =
@@ -99,9 +115,9 @@ __global__ void k_point_weights(int mode, int log_m, uint32_t g_m, const uint32_
 // wider matrices (w > 256) take one row per step in column chunks of 256.
 constexpr int DOT_ROWS = 1024;
 
-__global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
-                                                     const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
-                                                     uint32_t* __restrict__ partial) {
+__device__ __forceinline__ void column_dot_body(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
+                                                const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
+                                                uint32_t* __restrict__ partial) {
     __shared__ uint32_t sh[2][256][4];
     const size_t row0 = (size_t)blockIdx.x * DOT_ROWS;
     const size_t row_end = row0 + DOT_ROWS < n_rows ? row0 + DOT_ROWS : n_rows;
@@ -172,6 +188,25 @@ __global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__
         }
         __syncthreads();
     }
+}
+__global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
+                                                     const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
+                                                     uint32_t* __restrict__ partial) {
+    column_dot_body(mat, w, n_rows, u0, u1, partial);
+}
+// the narrow matrices of an opening in one launch (blockIdx.y = matrix, blockIdx.x = its block of DOT_ROWS rows): the memory
+// tables, quotient chunks and permutation traces of the small chips were sixty dependent launches of 9-18 us
+struct NarrowDotArgs {
+    const uint32_t* mat[NARROW_DOT_MAX];
+    const uint32_t *u0[NARROW_DOT_MAX], *u1[NARROW_DOT_MAX];
+    uint32_t* partial[NARROW_DOT_MAX];
+    uint32_t w[NARROW_DOT_MAX], n_rows[NARROW_DOT_MAX];
+};
+__global__ __launch_bounds__(256) void k_column_dot_batch(NarrowDotArgs a) {
+    const int t = blockIdx.y;
+    const size_t n_rows = a.n_rows[t];
+    if ((size_t)blockIdx.x * DOT_ROWS >= n_rows) return;
+    column_dot_body(a.mat[t], a.w[t], n_rows, a.u0[t], a.u1[t], a.partial[t]);
 }
 
 // Matrices of 24 columns and more: a wave takes 64 consecutive columns of one row at a time, so the row's weights are
@@ -732,6 +767,28 @@ int32_t point_weights(lurkhip_ctx* ctx, int mode, int log_m, const bb::ef& z, ui
     return LURKHIP_OK;
 }
 
+int32_t point_weights_batch(lurkhip_ctx* ctx, const std::vector<WeightJob>& jobs) {
+    for (size_t at = 0; at < jobs.size(); at += PW_BATCH_MAX) {
+        PwBatchArgs a{};
+        const size_t n = std::min<size_t>(PW_BATCH_MAX, jobs.size() - at);
+        uint32_t max_threads = 1;
+        for (size_t k = 0; k < n; k++) {
+            const WeightJob& j = jobs[at + k];
+            const NttPlan* plan = nullptr;
+            LH_TRY(get_ntt_plan(ctx, j.log_m, &plan));
+            a.mode[k] = j.mode;
+            a.log_m[k] = j.log_m;
+            a.tw[k] = (const uint32_t*)plan->tw_fwd;
+            a.z[k] = j.z;
+            a.out[k] = j.out;
+            max_threads = std::max(max_threads, ((1u << j.log_m) + PW_BATCH - 1) / PW_BATCH);
+        }
+        hipLaunchKernelGGL(k_point_weights_batch, dim3((max_threads + 255) / 256, (unsigned)n), dim3(256), 0, ctx->stream, a, bb::to_monty(bb::GEN));
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
 // rows per partial-sum block: 1024, fewer for short matrices on the wave-per-row kernel so that the launch still fills the CUs
 constexpr uint32_t DOT_WAVE_MIN_W = 24;
 static uint32_t dot_block_rows(uint32_t w, size_t n_rows) {
@@ -757,6 +814,29 @@ int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, si
                            u0, u1, partial_dev);
     } else
         hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, partial_dev);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+bool column_dot_is_narrow(uint32_t w) { return w < DOT_WAVE_MIN_W || getenv("LURKHIP_DOT_OLD") != nullptr; }
+
+int32_t column_dot_partial_batch(lurkhip_ctx* ctx, const std::vector<NarrowDot>& items) {
+    for (size_t at = 0; at < items.size(); at += NARROW_DOT_MAX) {
+        NarrowDotArgs a{};
+        const size_t n = std::min<size_t>(NARROW_DOT_MAX, items.size() - at);
+        uint32_t max_blocks = 1;
+        for (size_t k = 0; k < n; k++) {
+            const NarrowDot& d = items[at + k];
+            a.mat[k] = d.mat;
+            a.u0[k] = d.u0;
+            a.u1[k] = d.u1;
+            a.partial[k] = d.partial;
+            a.w[k] = d.w;
+            a.n_rows[k] = (uint32_t)d.n_rows;
+            max_blocks = std::max(max_blocks, dot_blocks(d.w, d.n_rows));
+        }
+        hipLaunchKernelGGL(k_column_dot_batch, dim3(max_blocks, (unsigned)n), dim3(256), 0, ctx->stream, a);
+    }
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

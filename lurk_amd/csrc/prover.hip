@@ -308,24 +308,48 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         uint32_t* partials = nullptr;
         PTRY(palloc(std::max<size_t>(partial_words, 4) * 4, &partials));
         std::vector<DotJob> jobs;
+        // every weight table of the opening first, in one launch: the barycentric weights of each (height, point) and the inverse
+        // denominators of the reduced openings (they do not depend on alpha_fri: queued here, ahead of the host wait)
+        {
+            std::vector<WeightJob> wjobs;
+            auto want = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt) -> int32_t {
+                const auto key = std::make_pair(log_m, pt);
+                if (cache.count(key)) return LURKHIP_OK;
+                uint32_t* buf = nullptr;
+                LH_TRY(palloc(((size_t)16) << log_m, &buf));
+                cache.emplace(key, buf);
+                wjobs.push_back(WeightJob{mode, log_m, pts[pt], buf});
+                return LURKHIP_OK;
+            };
+            for (const Round& r : rounds)
+                for (int m = 0; m < r.c->n_mats; m++)
+                    for (int pt : r.points[m]) {
+                        PTRY(want(bary, 0, r.c->log_h[m] - log_blowup, pt));
+                        PTRY(want(denoms, 1, r.c->log_h[m], pt));
+                    }
+            PTRY(point_weights_batch(ctx, wjobs));
+        }
         size_t k = 0, at = 0;
-        SideLane lane(ctx);  // short matrices (their weights, their dots) on the side lane; weights are cached per height, a height is one lane
+        std::vector<NarrowDot> narrow;  // the slab kernel's matrices: one launch for all of them
+        SideLane lane(ctx);  // short wide matrices on the side lane
         PTRY(lane.open());
         for (const Round& r : rounds)
             for (int m = 0; m < r.c->n_mats; m++, k++) {
                 const int log_n = r.c->log_h[m] - log_blowup;
-                const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N);
                 const std::vector<int>& mp = r.points[m];
                 uint32_t *u0 = nullptr, *u1 = nullptr;
                 PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
                 if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
-                PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
-                // the inverse denominators of the reduced openings do not depend on alpha_fri: queued here, ahead of the host wait
-                uint32_t* dn = nullptr;
-                for (int pt : mp) PTRY(get_weights(denoms, 1, r.c->log_h[m], pt, &dn));
+                if (column_dot_is_narrow(r.c->width[m])) {
+                    narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at});
+                } else {
+                    const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N);
+                    PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
+                }
                 jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
                 at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
             }
+        PTRY(column_dot_partial_batch(ctx, narrow));
         PTRY(lane.close());
         PTRY(column_dot_finish(ctx, jobs, dot_out));
     }

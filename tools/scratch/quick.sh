@@ -1,6 +1,6 @@
 #!/bin/bash
 R=$GRAFT_REPO_ROOT; cd $R; mkdir -p gpurun_out/quick
-python -m pytest tests/test_commit_gpu.py tests/test_prover_gpu.py tests/test_poseidon2_gpu.py -m gpu -x -q 2>&1 | tail -2
+python -m pytest tests/test_commit_gpu.py tests/test_prover_gpu.py tests/test_workloads_gpu.py tests/test_profile_gpu.py tests/test_open_gpu.py -m gpu -x -q 2>&1 | tail -2
 for i in 1 2; do python bench.py --no-cpu-baseline --no-two-in-flight --no-host-pipeline > gpurun_out/quick/b$i.json 2>/dev/null; done
 python - <<'PY'
 import json,glob
