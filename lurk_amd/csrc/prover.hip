@@ -67,6 +67,26 @@ constexpr int SIDE_LANE_MAX_LOG_N = 13;          // chips below 2^13 rows are "s
 constexpr uint32_t PROOF_MAGIC = 0x4652504cu;    // "LPRF"
 constexpr uint32_t OPENING_MAGIC = 0x4e504f4cu;  // "LOPN"
 
+// A few words from the host to the device as launch arguments: no staging buffer, no copy packet, nothing for the host to keep
+// alive or wait for (the FRI transcript state, the query indices).
+constexpr int UPLOAD_WORDS_MAX = 256;
+struct UploadWordsArgs {
+    uint32_t w[UPLOAD_WORDS_MAX];
+};
+__global__ void k_upload_words(UploadWordsArgs a, uint32_t* __restrict__ dst, uint32_t n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = a.w[threadIdx.x];
+}
+int32_t upload_words(lurkhip_ctx* ctx, uint32_t* dst_dev, const uint32_t* src, size_t n) {
+    for (size_t at = 0; at < n; at += UPLOAD_WORDS_MAX) {
+        UploadWordsArgs a;
+        const uint32_t m = (uint32_t)std::min<size_t>(UPLOAD_WORDS_MAX, n - at);
+        memcpy(a.w, src + at, (size_t)m * 4);
+        hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(UPLOAD_WORDS_MAX), 0, ctx->stream, a, dst_dev + at, m);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
 // dst[4 k ..] = the extension element at src[k]: the chips' cumulative sums, gathered for one read-back
 constexpr int GATHER_EF_MAX = 64;
 struct GatherEfArgs {
@@ -523,8 +543,8 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     PTRY(palloc((size_t)std::max(n_layers, 1) * 16, &betas_dev));
     uint32_t* roots_dev = nullptr;  // the layer roots, copied by k_fri_challenge as it observes them
     PTRY(palloc((size_t)std::max(n_layers, 1) * 32, &roots_dev));
-    PHIP(hipMemcpyAsync(ch_dev, &hc, sizeof hc, hipMemcpyHostToDevice, ctx->stream));
-    PHIP(stream_wait(ctx));  // hc is a stack object
+    static_assert(sizeof(DevChallenger) % 4 == 0, "uploaded as words");
+    PTRY(upload_words(ctx, (uint32_t*)ch_dev, (const uint32_t*)&hc, sizeof hc / 4));  // as launch arguments: no host wait
     for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
         lurkhip_commitment* lc = nullptr;
         PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
@@ -582,8 +602,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     for (auto& ix : indices) ix = ch.sample_bits(log_max);
     uint32_t* indices_dev = nullptr;
     PTRY(palloc((size_t)num_queries * 4, &indices_dev));
-    PHIP(hipMemcpyAsync(indices_dev, indices.data(), (size_t)num_queries * 4, hipMemcpyHostToDevice, ctx->stream));
-    PHIP(stream_wait(ctx));
+    PTRY(upload_words(ctx, indices_dev, indices.data(), (size_t)num_queries));
     // every record of every round and layer goes to one device buffer and comes back in one copy
     auto& round_record_words = out.round_record_words;
     auto& layer_record_words = out.layer_record_words;
