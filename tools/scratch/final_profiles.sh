@@ -5,7 +5,7 @@ python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 bash tools/prof_bench.sh $tag pmc > /dev/null 2>&1
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29517 bench.py --gpus 1 --no-cpu-baseline --no-two-in-flight --no-host-pipeline > gpurun_out/bench_${tag}_torchrun.json 2> gpurun_out/bench_${tag}_torchrun.err
 python -m torch.distributed.run --nnodes=1 --nproc-per-node 1 --master-addr 127.0.0.1 --master-port 29518 bench.py --gpus 1 --shards-per-rank 2 --no-cpu-baseline --no-two-in-flight --no-host-pipeline > gpurun_out/bench_${tag}_torchrun_2shards.json 2> gpurun_out/bench_${tag}_torchrun_2shards.err
-python tools/soak.py > gpurun_out/soak_$tag.txt 2>&1
+python tools/soak.py ${SOAK_ROUNDS:-30} > gpurun_out/soak_$tag.txt 2>&1
 tail -5 gpurun_out/soak_$tag.txt
 python - <<PY
 import json
