@@ -680,13 +680,16 @@ __global__ __launch_bounds__(64) void k_fri_challenge(const P16Params* __restric
 // ---------------------------------------------------------------- proof of work (DuplexChallenger::grind)
 // witness w is accepted when, after observing it, the next sampled element has `bits` low zero bits: one
 // permutation of the state with the pending inputs and w written over its first lanes; the sample is lane squeeze - 1 (7 or 15), or lane 0 when samples pop from the front.
-__global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__ p, const uint32_t* __restrict__ state_in,
+struct PowState {
+    uint32_t s[16];  // the transcript state, pending inputs already written over lanes [0, n_pending); a launch argument
+};
+__global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__ p, PowState state_in,
                                                     int n_pending, int sample_lane, uint32_t base, uint32_t mask, uint32_t* __restrict__ best) {
     const uint32_t wcan = base + blockIdx.x * blockDim.x + threadIdx.x;
     if (wcan >= bb::P) return;
     uint32_t s[16];
 #pragma unroll
-    for (int i = 0; i < 16; i++) s[i] = state_in[i];  // pending inputs already written over lanes [0, n_pending)
+    for (int i = 0; i < 16; i++) s[i] = state_in.s[i];
     const uint32_t wm = bb::to_monty(wcan);
     // the witness lands in lane n_pending (compile-time indices only: select per lane)
 #pragma unroll
@@ -982,21 +985,23 @@ int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
     void* scratch = nullptr;
-    LH_TRY(pool_alloc(ctx, 80, &scratch));
-    uint32_t host[17];
-    for (int i = 0; i < 16; i++) host[i] = state_with_pending_m[i];
-    host[16] = 0xffffffffu;
+    LH_TRY(pool_alloc(ctx, 16, &scratch));
+    PowState st;
+    for (int i = 0; i < 16; i++) st.s[i] = state_with_pending_m[i];
     int32_t s = LURKHIP_OK;
-    hipError_t e = hipMemcpyAsync(scratch, host, sizeof host, hipMemcpyHostToDevice, ctx->stream);
-    if (e == hipSuccess) e = stream_wait(ctx);
+    hipError_t e = hipMemsetAsync(scratch, 0xff, 4, ctx->stream);  // "no witness yet"
     const uint32_t mask = bits >= 31 ? 0x7fffffffu : ((1u << bits) - 1u);
-    const uint32_t batch = 1u << 20;
+    // Candidates in increasing ranges, the smallest accepted one of the first range that has any: a range of 2^(bits + 1)
+    // candidates holds a witness with probability 1 - e^-2, so the first launch is that size (2^17 permutations for 16 bits,
+    // where a fixed 2^20 cost 0.15 ms of every proof) and the ranges double from there up to 2^20.
+    uint64_t batch = (uint64_t)1 << std::min(20, std::max(12, bits + 1));
     uint32_t best = 0xffffffffu;
-    for (uint64_t base = 0; e == hipSuccess && base < bb::P && best == 0xffffffffu; base += batch) {
-        hipLaunchKernelGGL(k_pow_grind, dim3(batch / 256), dim3(256), 0, ctx->stream, params, (const uint32_t*)scratch, n_pending, sample_lane,
-                           (uint32_t)base, mask, (uint32_t*)scratch + 16);
+    for (uint64_t base = 0; e == hipSuccess && base < bb::P && best == 0xffffffffu; base += batch, batch = std::min<uint64_t>(batch * 2, (uint64_t)1 << 20)) {
+        // (base advanced by the range just searched, then the next range's size)
+        hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, params, st, n_pending, sample_lane,
+                           (uint32_t)base, mask, (uint32_t*)scratch);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&best, (uint32_t*)scratch + 16, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(&best, scratch, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = stream_wait(ctx);
     }
     pool_release(ctx, scratch);
