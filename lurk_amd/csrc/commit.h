@@ -100,6 +100,7 @@ struct SpongeGroups {
     uint64_t n_rows[SPONGE_MAX_GROUPS];
     uint32_t* out[SPONGE_MAX_GROUPS];
     uint32_t first_block[SPONGE_MAX_GROUPS + 1];  // filled by merkle_row_sponges
+    uint8_t coop[SPONGE_MAX_GROUPS];              // filled by merkle_row_sponges: the group's rows are hashed by 16 lanes each
 };
 int32_t merkle_row_sponges(lurkhip_ctx* ctx, const P16Params* params_dev, SpongeGroups groups);
 // parents[i] = compress(children[2i], children[2i+1]); if inject_digests: then compress(that, inject_digests[i])

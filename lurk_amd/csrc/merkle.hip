@@ -30,6 +30,9 @@ namespace lurkhip {
 namespace {
 
 constexpr int MBLOCK = 256;
+// a height group of at most this many rows, each at least this many permutations long, is hashed sixteen lanes to the row
+constexpr uint32_t SPONGE_COOP_MIN_PERMS = 48;
+constexpr uint64_t SPONGE_COOP_MAX_ROWS = 4096;
 // levels of at most this many parents run lane-cooperatively (above it one permutation per lane already fills the SIMDs)
 constexpr size_t COOP_MAX_PARENTS = MERKLE_COOP_MAX_PARENTS;
 
@@ -134,6 +137,29 @@ __global__ __launch_bounds__(MBLOCK) void k_level(const P16Params* __restrict__ 
     dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// One row of a few very long ones, by 16 lanes (p16_coop.h): lanes 0..7 absorb.  A row of the hash chips' group of a fib machine
+// is 2067 columns -- 259 permutations one after the other -- and there are 512 such rows: one row per lane that is eight waves
+// each walking a chain of 259 full-latency permutations (13.6 us alone on a SIMD, 50 us among five other waves), 3.4 ms of a
+// small proof's 12 and the last 0.8 ms of the 2^20-row shard's main sponge launch, alone on the chip.  Sixteen lanes per row
+// the chain is 259 cooperative permutations (3.5 us alone).  The word of chunk c + 1 and the descriptor of chunk c + 2 are
+// requested before the permutation of chunk c.
+__device__ __forceinline__ void coop_sponge_row(const P16Params* __restrict__ p, const LeafCol* __restrict__ cols, uint32_t w, size_t row,
+                                                int j, bool store, uint32_t* __restrict__ out) {
+    const bool absorbs = j < 8;
+    auto word = [&](const LeafCol& d) { return ((gwords)d.base)[row * d.width + d.col]; };
+    uint32_t t = 0, nxt = 0;
+    LeafCol dn{};
+    if (absorbs && (uint32_t)j < w) nxt = word(cols[j]);
+    if (absorbs && 8u + j < w) dn = cols[8 + j];
+    for (uint32_t c0 = 0; c0 < w; c0 += 8) {
+        if (absorbs && c0 + j < w) t = nxt;
+        if (absorbs && c0 + 8 + j < w) nxt = word(dn);
+        if (absorbs && c0 + 16 + j < w) dn = cols[c0 + 16 + j];
+        t = coop_perm16(t, p, j);
+    }
+    if (store && absorbs) out[row * 8 + j] = t;
+}
+
 // several height groups' row sponges in one grid (merkle_row_sponges): the block's group by its first_block range
 #ifndef LURK_SPONGE_WAVES_PER_EU
 #define LURK_SPONGE_WAVES_PER_EU 0
@@ -144,6 +170,13 @@ __attribute__((amdgpu_waves_per_eu(LURK_SPONGE_WAVES_PER_EU, LURK_SPONGE_WAVES_P
 __global__ __launch_bounds__(MBLOCK) void k_row_sponges(const P16Params* __restrict__ p, SpongeGroups g) {
     int k = 0;
     while (k + 1 < g.n && blockIdx.x >= g.first_block[k + 1]) k++;
+    if (g.coop[k]) {  // (uniform per block)
+        const size_t r = (size_t)(blockIdx.x - g.first_block[k]) * (MBLOCK / 16) + (threadIdx.x >> 4);
+        const bool live = r < g.n_rows[k];
+        // every lane of a group runs the permutations (DPP reads need all 16 active): groups past the end redo row 0
+        coop_sponge_row(p, g.cols[k], g.total_w[k], live ? r : 0, threadIdx.x & 15, live, g.out[k]);
+        return;
+    }
     const size_t row = (size_t)(blockIdx.x - g.first_block[k]) * MBLOCK + threadIdx.x;
     if (row >= g.n_rows[k]) return;
     uint32_t s[16];
@@ -357,10 +390,14 @@ int32_t merkle_row_sponges(lurkhip_ctx* ctx, const P16Params* params_dev, Sponge
             std::swap(g.n_rows[b], g.n_rows[b - 1]);
             std::swap(g.out[b], g.out[b - 1]);
         }
+    // few rows of many permutations each go sixteen lanes to the row (coop_sponge_row); LURKHIP_SPONGE_COOP=0: none do
+    static const bool coop_on = getenv("LURKHIP_SPONGE_COOP") == nullptr || atoi(getenv("LURKHIP_SPONGE_COOP")) != 0;
     size_t blocks = 0;
     for (int k = 0; k < g.n; k++) {
         g.first_block[k] = (uint32_t)blocks;
-        blocks += (g.n_rows[k] + MBLOCK - 1) / MBLOCK;
+        g.coop[k] = coop_on && (g.total_w[k] + 7) / 8 >= SPONGE_COOP_MIN_PERMS && g.n_rows[k] <= SPONGE_COOP_MAX_ROWS;
+        const size_t rows_per_block = g.coop[k] ? MBLOCK / 16 : MBLOCK;
+        blocks += (g.n_rows[k] + rows_per_block - 1) / rows_per_block;
     }
     LH_ARG(ctx, blocks <= 0x7fffffffu, "too many rows for one sponge launch");
     g.first_block[g.n] = (uint32_t)blocks;
