@@ -31,7 +31,7 @@ namespace {
 
 constexpr int MBLOCK = 256;
 // a height group of at most this many rows, each at least this many permutations long, is hashed sixteen lanes to the row
-constexpr uint32_t SPONGE_COOP_MIN_PERMS = 48;
+constexpr uint32_t SPONGE_COOP_MIN_PERMS = 16;
 constexpr uint64_t SPONGE_COOP_MAX_ROWS = 4096;
 // levels of at most this many parents run lane-cooperatively (above it one permutation per lane already fills the SIMDs)
 constexpr size_t COOP_MAX_PARENTS = MERKLE_COOP_MAX_PARENTS;
