@@ -133,6 +133,8 @@ def main():
     ap.add_argument("--no-spans", action="store_true", help="diagnostic: no per-stage HIP events in the timed region (stages_ms and roofline read 0)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra two-shards-in-flight measurement")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
+    ap.add_argument("--compile-min-log-rows", type=int, default=None,
+                    help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the extra streamed multi-shard measurement (host flatten + upload under the proofs)")
     ap.add_argument("--pipeline-shards", type=int, default=4)
     ap.add_argument("--shards-per-rank", type=int, default=None,
@@ -197,7 +199,7 @@ def main():
     compiled = []
     if not args.no_compile:
         for pr in prepared_all:
-            compiled += [c for c in machine.compile_airs(pr) if c not in compiled]
+            compiled += [c for c in machine.compile_airs(pr, min_log_rows=args.compile_min_log_rows) if c not in compiled]
     t_jit = time.perf_counter() - t_jit
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
     input_bytes = sum(p.input_bytes for pr in prepared_all for *_, p in pr if p is not None)
