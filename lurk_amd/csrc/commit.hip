@@ -5,6 +5,7 @@
 #include <stdlib.h>
 
 #include <algorithm>
+#include <cstring>
 #include <map>
 #include <numeric>
 
@@ -411,8 +412,11 @@ int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const s
 }
 
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m) {
-    LH_HIP(ctx, hipMemcpyAsync(root_m, c->digests + c->level_off[c->log_max] * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
+    void* pin = nullptr;
+    LH_TRY(pinned_small(ctx, &pin));
+    LH_HIP(ctx, hipMemcpyAsync(pin, c->digests + c->level_off[c->log_max] * 8, 32, hipMemcpyDeviceToHost, ctx->stream));
     LH_HIP(ctx, stream_wait(ctx));
+    memcpy(root_m, pin, 32);
     return LURKHIP_OK;
 }
 

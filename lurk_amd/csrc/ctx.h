@@ -27,6 +27,7 @@ struct lurkhip_ctx {
     // do not bounce through the runtime's own staging
     void* host_stage = nullptr;
     size_t host_stage_bytes = 0;
+    void* pin_small = nullptr;  // 256 page-locked bytes for the few-word read-backs (roots, PoW witness): pinned_small()
     // lazily created per-ctx device state owned by other translation units (commit.h)
     void* merkle_params_dev = nullptr;
     void* merkle_params_host = nullptr;  // P16Params copy for the host-side challenger
@@ -75,6 +76,9 @@ int32_t arena_get(lurkhip_ctx* ctx, int slot, size_t bytes, void** out);
 hipError_t stream_wait(lurkhip_ctx* ctx);
 // page-locked host buffer of at least `bytes` (grown on demand; the previous contents are dropped, the stream is drained first)
 int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out);
+// 256 page-locked bytes of the context for read-backs of a few words that are waited for at once (a copy into pageable memory
+// goes through the runtime's own staging and its blocking wait; into page-locked memory it is a plain DMA the caller polls for)
+int32_t pinned_small(lurkhip_ctx* ctx, void** out);
 // pooled device allocations: released blocks are kept and reused for later requests of the same size
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
 void pool_release(lurkhip_ctx* ctx, void* ptr);

@@ -71,6 +71,12 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out) {
     return LURKHIP_OK;
 }
 
+int32_t pinned_small(lurkhip_ctx* ctx, void** out) {
+    if (!ctx->pin_small) LH_HIP(ctx, hipHostMalloc(&ctx->pin_small, 256, hipHostMallocDefault));
+    *out = ctx->pin_small;
+    return LURKHIP_OK;
+}
+
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
     if (bytes == 0) bytes = 16;
     std::lock_guard<std::mutex> lock(ctx->pool_mu);
@@ -286,6 +292,7 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     for (int i = 0; i < 4; i++)
         if (ctx->arena[i]) (void)hipFree(ctx->arena[i]);
     if (ctx->host_stage) (void)hipHostFree(ctx->host_stage);
+    if (ctx->pin_small) (void)hipHostFree(ctx->pin_small);
     for (int i = 0; i < 2; i++) {
         if (ctx->prep_stage[i]) (void)hipHostFree(ctx->prep_stage[i]);
         if (ctx->prep_done[i]) (void)hipEventDestroy(ctx->prep_done[i]);

@@ -996,13 +996,24 @@ int32_t pow_grind(lurkhip_ctx* ctx, const uint32_t state_with_pending_m[16], int
     // where a fixed 2^20 cost 0.15 ms of every proof) and the ranges double from there up to 2^20.
     uint64_t batch = (uint64_t)1 << std::min(20, std::max(12, bits + 1));
     uint32_t best = 0xffffffffu;
+    volatile uint32_t* best_pin = nullptr;
+    {
+        void* pin = nullptr;
+        const int32_t ps = pinned_small(ctx, &pin);
+        if (ps != LURKHIP_OK) {
+            pool_release(ctx, scratch);
+            return ps;
+        }
+        best_pin = (volatile uint32_t*)((uint8_t*)pin + 64);
+    }
     for (uint64_t base = 0; e == hipSuccess && base < bb::P && best == 0xffffffffu; base += batch, batch = std::min<uint64_t>(batch * 2, (uint64_t)1 << 20)) {
         // (base advanced by the range just searched, then the next range's size)
         hipLaunchKernelGGL(k_pow_grind, dim3((unsigned)(batch / 256)), dim3(256), 0, ctx->stream, params, st, n_pending, sample_lane,
                            (uint32_t)base, mask, (uint32_t*)scratch);
         e = hipGetLastError();
-        if (e == hipSuccess) e = hipMemcpyAsync(&best, scratch, 4, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipMemcpyAsync(const_cast<uint32_t*>(best_pin), scratch, 4, hipMemcpyDeviceToHost, ctx->stream);
         if (e == hipSuccess) e = stream_wait(ctx);
+        if (e == hipSuccess) best = *best_pin;
     }
     pool_release(ctx, scratch);
     if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "pow_grind failed: %s", hipGetErrorString(e));

@@ -384,8 +384,9 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         PTRY(lane.close());
         PTRY(column_dot_finish(ctx, jobs, dot_out));
     }
-    std::vector<uint32_t> dot_host(dot_words);
-    PHIP(hipMemcpyAsync(dot_host.data(), dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
+    uint32_t* dot_host = nullptr;  // page-locked (host_staging is not asked for again before the opened values are formed below)
+    PTRY(host_staging(ctx, dot_words * 4, (void**)&dot_host));
+    PHIP(hipMemcpyAsync(dot_host, dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHIP(stream_wait(ctx));
     // phase 2: opened values on the host: y = (z^N - g^N) / (N g^(N-1)) * sum
     // per round, per matrix, per point: ys[c] (Montgomery)
