@@ -212,18 +212,20 @@ def main():
     def step():
         # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shards
         handles, roots = [], []
+        ch = None
         for pr in prepared_all:
             ctx.span_begin("trace_all")
             traces = machine.run_prepared(pr)
             ctx.span_end("trace_all")
+            if ch is None:  # the transcript is opened on the host while the trace kernels run
+                ch = prover.Challenger(ctx)
+                ch.observe(vk_root)
+                ch.observe([0])
             handle, root = machine.commit_shard(traces)
             handles.append(handle)
             roots.append(root)
         # the transcript prefix: every shard's main root in shard order (RCCL all-gather of index + 8 lanes per shard) and the
-        # public values
-        ch = prover.Challenger(ctx)
-        ch.observe(vk_root)
-        ch.observe([0])
+        # public values (the transcript itself was opened above, under the trace kernels)
         t_x = time.perf_counter()
         gathered = shards.exchange_roots(roots, device=dev, shard_indices=mine)
         host_ms["exchange_roots"] = host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t_x) * 1e3
