@@ -112,6 +112,27 @@ def test_commit_many_matrices_per_height_group(ctx, oracle):
     c.close()
 
 
+def test_commit_long_rows_hashed_by_sixteen_lanes(ctx, oracle):
+    """Height groups of at most 4096 LDE rows with at least 16 permutations per row are hashed sixteen lanes to the row
+    (merkle.hip: coop_sponge_row): widths around the threshold and around multiples of eight, one to 4096 rows, next to a group of
+    the same width just above the row limit (one row per lane) -- the oracle's tree, and the openings' rows."""
+    # (a 2^16-leaf tree: the row groups of trees above 16384 leaves share the sponge launch that has the sixteen-lane mode)
+    shapes = [(15, 3), (12, 121), (11, 121), (10, 127), (9, 128), (8, 129), (7, 655), (3, 120), (1, 250), (0, 135)]
+    mats = [synth.field_elements((1 << k, w), seed=3100 + i) for i, (k, w) in enumerate(shapes)]
+    c = cm.commit(ctx, mats, log_blowup=1)
+    ldes = [oracle.lde(m, 1) for m in mats]
+    root, _ = oracle.merkle_commit(ldes)
+    assert np.array_equal(c.root, root)
+    lh = [k + 1 for k, _ in shapes]
+    ws = [w for _, w in shapes]
+    for index in (0, 4097, 65535):
+        rows, path = c.open(index)
+        want = np.concatenate([ldes[i][index >> (16 - lh[i])] for i in range(len(mats))])
+        assert np.array_equal(rows, want)
+        assert oracle.merkle_verify(lh, ws, index, rows, path, c.root)
+    c.close()
+
+
 def test_commit_same_shape_matrices_share_their_passes(ctx, oracle):
     """Device-resident matrices of one (height, width) go through the NTT passes in one launch per pass (up to 8 per launch):
     eleven 2^10 x 4 matrices (a batch of 8 and one of 3), three 2^9 x 12, pairs with an odd width and a single one."""
