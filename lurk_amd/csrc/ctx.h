@@ -36,6 +36,9 @@ struct lurkhip_ctx {
     // coset-shift power tables of the LDE, s^i / N for i < N, keyed by (log_n, s): immutable once filled, so a table is
     // computed once per context instead of once per matrix (commit.hip: extend)
     std::map<std::pair<int, uint32_t>, uint32_t*> lde_scale_tables;
+    // quotient-domain selector tables (stark.hip: selector_table) keyed by (log_n, log quotient degree): is_first_row,
+    // is_last_row, is_transition at x = g w_Q^bitrev(s), three words per row -- functions of the domain only, immutable
+    std::map<std::pair<int, int>, uint32_t*> selector_tables;
     size_t lde_scale_bytes = 0;
     std::vector<std::function<void()>> cleanups;  // run in reverse order by lurkhip_ctx_destroy
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)
@@ -79,6 +82,9 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out);
 // 256 page-locked bytes of the context for read-backs of a few words that are waited for at once (a copy into pageable memory
 // goes through the runtime's own staging and its blocking wait; into page-locked memory it is a plain DMA the caller polls for)
 int32_t pinned_small(lurkhip_ctx* ctx, void** out);
+// a few words from the host to the device as launch arguments of a tiny kernel on the context's stream: no staging buffer, no
+// copy packet, nothing for the host to keep alive or wait for
+int32_t upload_words(lurkhip_ctx* ctx, uint32_t* dst_dev, const uint32_t* src, size_t n);
 // pooled device allocations: released blocks are kept and reused for later requests of the same size
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
 void pool_release(lurkhip_ctx* ctx, void* ptr);

@@ -71,6 +71,26 @@ int32_t host_staging(lurkhip_ctx* ctx, size_t bytes, void** out) {
     return LURKHIP_OK;
 }
 
+// A few words from the host to the device as launch arguments: no staging buffer, no copy packet, nothing for the host to keep
+// alive or wait for (the FRI transcript state, the query indices).
+constexpr int UPLOAD_WORDS_MAX = 256;
+struct UploadWordsArgs {
+    uint32_t w[UPLOAD_WORDS_MAX];
+};
+__global__ void k_upload_words(UploadWordsArgs a, uint32_t* __restrict__ dst, uint32_t n) {
+    if (threadIdx.x < n) dst[threadIdx.x] = a.w[threadIdx.x];
+}
+int32_t upload_words(lurkhip_ctx* ctx, uint32_t* dst_dev, const uint32_t* src, size_t n) {
+    for (size_t at = 0; at < n; at += UPLOAD_WORDS_MAX) {
+        UploadWordsArgs a;
+        const uint32_t m = (uint32_t)std::min<size_t>(UPLOAD_WORDS_MAX, n - at);
+        memcpy(a.w, src + at, (size_t)m * 4);
+        hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(UPLOAD_WORDS_MAX), 0, ctx->stream, a, dst_dev + at, m);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
 int32_t pinned_small(lurkhip_ctx* ctx, void** out) {
     if (!ctx->pin_small) LH_HIP(ctx, hipHostMalloc(&ctx->pin_small, 256, hipHostMallocDefault));
     *out = ctx->pin_small;
@@ -97,8 +117,11 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
         ctx->pool_free.clear();
         // the table caches are rebuilt on demand
         for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
+    for (auto& kv : ctx->selector_tables) (void)hipFree(kv.second);
         ctx->lde_scale_tables.clear();
         ctx->lde_scale_bytes = 0;
+        for (auto& kv : ctx->selector_tables) (void)hipFree(kv.second);
+        ctx->selector_tables.clear();
         e = hipMalloc(out, bytes);
     }
     if (e != hipSuccess)
@@ -287,6 +310,7 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     spans_resolve(ctx);
     for (auto e : ctx->event_pool) (void)hipEventDestroy(e);
     for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
+    for (auto& kv : ctx->selector_tables) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     for (auto& kv : ctx->pool_live) (void)hipFree(kv.first);
     for (int i = 0; i < 4; i++)

@@ -67,26 +67,6 @@ constexpr int SIDE_LANE_MAX_LOG_N = 13;          // chips below 2^13 rows are "s
 constexpr uint32_t PROOF_MAGIC = 0x4652504cu;    // "LPRF"
 constexpr uint32_t OPENING_MAGIC = 0x4e504f4cu;  // "LOPN"
 
-// A few words from the host to the device as launch arguments: no staging buffer, no copy packet, nothing for the host to keep
-// alive or wait for (the FRI transcript state, the query indices).
-constexpr int UPLOAD_WORDS_MAX = 256;
-struct UploadWordsArgs {
-    uint32_t w[UPLOAD_WORDS_MAX];
-};
-__global__ void k_upload_words(UploadWordsArgs a, uint32_t* __restrict__ dst, uint32_t n) {
-    if (threadIdx.x < n) dst[threadIdx.x] = a.w[threadIdx.x];
-}
-int32_t upload_words(lurkhip_ctx* ctx, uint32_t* dst_dev, const uint32_t* src, size_t n) {
-    for (size_t at = 0; at < n; at += UPLOAD_WORDS_MAX) {
-        UploadWordsArgs a;
-        const uint32_t m = (uint32_t)std::min<size_t>(UPLOAD_WORDS_MAX, n - at);
-        memcpy(a.w, src + at, (size_t)m * 4);
-        hipLaunchKernelGGL(k_upload_words, dim3(1), dim3(UPLOAD_WORDS_MAX), 0, ctx->stream, a, dst_dev + at, m);
-    }
-    LH_HIP(ctx, hipGetLastError());
-    return LURKHIP_OK;
-}
-
 // dst[4 k ..] = the extension element at src[k]: the chips' cumulative sums, gathered for one read-back
 constexpr int GATHER_EF_MAX = 64;
 struct GatherEfArgs {

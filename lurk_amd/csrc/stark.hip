@@ -388,6 +388,53 @@ namespace {
 
 __global__ void k_quotient(QuotientArgs a) { quotient_body<InterpreterRunner>(a); }
 
+// out[3 s ..] = is_first_row, is_last_row, is_transition (p3 TwoAdicMultiplicativeCoset::selectors_on_coset) at
+// x = g w_Q^i, i = bitrev(s): zh_i / (x - 1), zh_i / (x - w_N^-1), x - w_N^-1.  A thread takes four rows and inverts their eight
+// denominators with one Fermat ladder (Montgomery's trick); w_Q^i comes from the NTT twiddle table (tw[i], i < Q / 2).
+struct SelectorArgs {
+    uint32_t log_q, lqd, g_m, wn_inv_m;
+    uint32_t zh[4];
+    const uint32_t* tw;
+    uint32_t* out;
+};
+__global__ __launch_bounds__(256) void k_selectors(SelectorArgs a) {
+    const uint32_t q = 1u << a.log_q, half = q >> 1, qd_mask = (1u << a.lqd) - 1u;
+    const uint32_t s0 = (blockIdx.x * 256u + threadIdx.x) * 4u;
+    if (s0 >= q) return;
+    uint32_t den[8], zh[4], pre[8];
+    uint32_t acc = bb::R1;
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint32_t s = s0 + k < q ? s0 + k : q - 1;
+        const uint32_t i = a.log_q ? (__brev(s) >> (32 - a.log_q)) : 0u;
+        const uint32_t wi = half == 0 ? bb::R1 : (i < half ? a.tw[i] : bb::neg(a.tw[i - half]));
+        const uint32_t x = bb::mul(a.g_m, wi);
+        den[2 * k] = bb::sub(x, bb::R1);
+        den[2 * k + 1] = bb::sub(x, a.wn_inv_m);
+        zh[k] = a.zh[i & qd_mask];
+    }
+#pragma unroll
+    for (int k = 0; k < 8; k++) {
+        pre[k] = acc;
+        acc = bb::mul(acc, den[k] ? den[k] : bb::R1);
+    }
+    uint32_t inv = bb::inv(acc);
+    uint32_t dinv[8];
+#pragma unroll
+    for (int k = 7; k >= 0; k--) {
+        dinv[k] = den[k] ? bb::mul(inv, pre[k]) : 0u;  // (a zero denominator inverts to zero like bb::inv; the coset never meets H)
+        inv = bb::mul(inv, den[k] ? den[k] : bb::R1);
+    }
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        if (s0 + k >= q) break;
+        uint32_t* o = a.out + 3 * (size_t)(s0 + k);
+        o[0] = bb::mul(zh[k], dinv[2 * k]);
+        o[1] = bb::mul(zh[k], dinv[2 * k + 1]);
+        o[2] = den[2 * k + 1];
+    }
+}
+
 }  // namespace
 
 // LDS layout of a multi-piece VM launch: the pieces' register files, the staged tile of 64 rows (when it fits), 64 row
@@ -539,9 +586,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     std::vector<uint32_t> pubm(np);
     if (s == LURKHIP_OK && np) {
         for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
-        hipError_t e = hipMemcpyAsync(d + o_pub, pubm.data(), np * 4, hipMemcpyHostToDevice, ctx->stream);
-        if (e == hipSuccess) e = stream_wait(ctx);
-        if (e != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "public values upload failed: %s", hipGetErrorString(e));
+        s = upload_words(ctx, (uint32_t*)(d + o_pub), pubm.data(), np);  // launch arguments: no host wait in the middle of the stage
     }
     if (s == LURKHIP_OK) {
         QuotientArgs q{};
@@ -589,6 +634,31 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             cur = bb::mul(cur, w_qd);
         }
         q.out = out_dev;
+        {
+            // the selectors of this (height, quotient degree): a table of the context, written once
+            const auto key = std::make_pair((int)log_n, (int)lqd);
+            auto it = ctx->selector_tables.find(key);
+            if (it == ctx->selector_tables.end() && getenv("LURKHIP_QUOTIENT_SELECTORS_INLINE") == nullptr) {
+                const NttPlan* plan = nullptr;
+                void* tbl = nullptr;
+                if (get_ntt_plan(ctx, (int)q.log_q, &plan) == LURKHIP_OK && hipMalloc(&tbl, ((size_t)12) << q.log_q) == hipSuccess) {
+                    SelectorArgs sa{};
+                    sa.log_q = q.log_q;
+                    sa.lqd = lqd;
+                    sa.g_m = q.g_m;
+                    sa.wn_inv_m = q.wn_inv_m;
+                    for (int c = 0; c < 4; c++) sa.zh[c] = q.zh[c];
+                    sa.tw = (const uint32_t*)plan->tw_fwd;
+                    sa.out = (uint32_t*)tbl;
+                    const uint32_t threads = ((1u << q.log_q) + 3) / 4;
+                    hipLaunchKernelGGL(k_selectors, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sa);
+                    it = ctx->selector_tables.emplace(key, (uint32_t*)tbl).first;
+                } else {
+                    (void)hipGetLastError();  // no memory for the table: the kernel computes the selectors per row
+                }
+            }
+            q.sel = it != ctx->selector_tables.end() ? it->second : nullptr;
+        }
         q.regs_words = lay.regs_words;
         q.wp = lay.wp;
         q.staged = lay.staged ? 1 : 0;

@@ -241,6 +241,7 @@ struct QuotientArgs {
     uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
     uint32_t zh[4];
     uint32_t g_m, wq_m, wn_inv_m;
+    const uint32_t* sel;    // [2^log_q][3]: is_first_row, is_last_row, is_transition per (bit-reversed) row, or null: computed per row
     uint32_t regs_words, wp;    // LDS layout (layout_parts)
     int staged;
     uint32_t* out;          // [2^lqd][N][4]
@@ -336,7 +337,14 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset): the constraint wave needs them
     uint32_t is_first = 0, is_last = 0, is_trans = 0;
     const bool cons_wave = wave < a.n_cons_parts;
-    if (cons_wave) {
+    if (cons_wave && a.sel) {
+        // (functions of the domain only: a table of the context -- per row they were a power ladder and two Fermat inversions,
+        // some 660 instructions beside the two to three thousand of an eval row's constraints)
+        const uint32_t* sp = a.sel + 3 * (size_t)s;
+        is_first = sp[0];
+        is_last = sp[1];
+        is_trans = sp[2];
+    } else if (cons_wave) {
         const uint32_t x = bb::mul(a.g_m, bb::pow(a.wq_m, i));
         const uint32_t zh = a.zh[i & (qd - 1)];
         is_first = bb::mul(zh, bb::inv(bb::sub(x, bb::R1)));
