@@ -446,14 +446,18 @@ struct PartLayout {
     bool staged;
     size_t lds_bytes;
 };
-static PartLayout layout_parts(const std::vector<const std::vector<uint32_t>*>& host, const std::vector<uint32_t*>& dev, uint32_t w) {
+// `compiled`: the launch runs the chip's compiled kernels, whose values live in VGPRs -- no register files in LDS.  (They were
+// reserved all the same until the end of round 2: 64 lanes x n_regs words per piece, 30 KB and more beside a 20 KB tile, so a CU
+// held two or three workgroups of the compiled kernels and they waited for memory half of their cycles.)
+static PartLayout layout_parts(const std::vector<const std::vector<uint32_t>*>& host, const std::vector<uint32_t*>& dev, uint32_t w,
+                               bool compiled) {
     PartLayout l{};
     l.parts.n_parts = (uint32_t)host.size();
     uint32_t off = 0;
     for (size_t j = 0; j < host.size(); j++) {
         l.parts.prog[j] = dev[j];
         l.parts.reg_off[j] = off;
-        off += (*host[j])[airp::H_N_REGS] * 64u;
+        if (!compiled) off += (*host[j])[airp::H_N_REGS] * 64u;
     }
     l.regs_words = off;
     l.wp = w | 1u;
@@ -513,7 +517,8 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         PermArgs pa{};
         std::vector<const std::vector<uint32_t>*> host_parts;
         for (const auto& part : a->prog.interaction_parts) host_parts.push_back(&part);
-        const PartLayout lay = layout_parts(host_parts, *dparts, a->air.width);
+        const JitKernels jit = jit_of(ctx, a);
+        const PartLayout lay = layout_parts(host_parts, *dparts, a->air.width, jit.perm_rows != nullptr && getenv("LURKHIP_JIT_KEEP_LDS_REGS") == nullptr);
         pa.parts = lay.parts;
         pa.main = main_dev;
         pa.prep = prep_dev ? prep_dev : main_dev;
@@ -528,7 +533,6 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         pa.regs_words = lay.regs_words;
         pa.wp = lay.wp;
         pa.staged = lay.staged ? 1 : 0;
-        const JitKernels jit = jit_of(ctx, a);
         if (jit.perm_rows) {
             void* params[] = {&pa};
             if (hipModuleLaunchKernel(jit.perm_rows, (height + 63) / 64, 1, 1, 64 * lay.parts.n_parts, 1, 1, (unsigned)lay.lds_bytes, ctx->stream,
@@ -600,7 +604,8 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             host_parts.push_back(&a->prog.interaction_parts_coarse[j]);
             dev_parts.push_back((*dparts)[j]);
         }
-        const PartLayout lay = layout_parts(host_parts, dev_parts, a->air.width);
+        const JitKernels jit = jit_of(ctx, a);
+        const PartLayout lay = layout_parts(host_parts, dev_parts, a->air.width, jit.quotient != nullptr && getenv("LURKHIP_JIT_KEEP_LDS_REGS") == nullptr);
         q.parts = lay.parts;
         q.n_cons_parts = (uint32_t)a->prog.constraint_parts.size();
         q.n_cons = (uint32_t)a->air.constraints.size();
@@ -664,7 +669,6 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.staged = lay.staged ? 1 : 0;
         const uint32_t rows = 1u << q.log_q;
         span_begin(ctx, "quotient", 2);
-        const JitKernels jit = jit_of(ctx, a);
         if (jit.quotient) {
             void* params[] = {&q};
             if (hipModuleLaunchKernel(jit.quotient, (rows + 63) / 64, 1, 1, 64 * lay.parts.n_parts, 1, 1, (unsigned)lay.lds_bytes, ctx->stream, params,

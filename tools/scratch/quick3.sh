@@ -4,7 +4,7 @@ python -m pytest tests/test_air_gpu.py tests/test_prover_gpu.py tests/test_workl
 A="--no-cpu-baseline --no-two-in-flight --no-host-pipeline"
 for i in 1 2; do
 python bench.py $A > gpurun_out/quick3/b$i.json 2>/dev/null
-LURKHIP_QUOTIENT_SELECTORS_INLINE=1 python bench.py $A > gpurun_out/quick3/old$i.json 2>/dev/null
+LURKHIP_JIT_KEEP_LDS_REGS=1 python bench.py $A > gpurun_out/quick3/old$i.json 2>/dev/null
 done
 python - <<'PY'
 import json,glob
