@@ -62,7 +62,9 @@ struct LogupAccum {
     uint32_t in_batch = 0, m_first = 0;
     bool is_send = false;
     __device__ __forceinline__ void begin(uint32_t interaction, bool send) {
-        cur64.set(ef{{starts[4 * interaction], starts[4 * interaction + 1], starts[4 * interaction + 2], starts[4 * interaction + 3]}});
+        // (wave-uniform, written by an earlier kernel: through the constant address space like the power tables, lazy_ef.h)
+        const __attribute__((address_space(4))) uint32_t* sp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(starts + 4 * interaction);
+        cur64.set(ef{{sp[0], sp[1], sp[2], sp[3]}});
         is_send = send;
     }
     // the tuple element at position t (t = 1 + index in the tuple): += beta^t * v
