@@ -418,6 +418,17 @@ int32_t lurkhip_profile_enable(lurkhip_ctx* ctx, int32_t on) {
     LH_CHECK_CTX(ctx);
     ctx->profiling = on != 0;
     ctx->profile_level = on < 0 ? 0 : on;
+    // A span takes two events and keeps them until the spans are read; created on demand each was a 30-40 us host call in the
+    // middle of a stage (80 us of idle device at the first span of every Merkle tree).  They are created here, ahead of the
+    // region being measured.
+    if (on > 0) {
+        constexpr size_t PREPARED_EVENTS = 2048;
+        while (ctx->event_pool.size() < PREPARED_EVENTS) {
+            hipEvent_t e = nullptr;
+            if (hipEventCreate(&e) != hipSuccess) break;
+            ctx->event_pool.push_back(e);
+        }
+    }
     return LURKHIP_OK;
 }
 
