@@ -411,14 +411,13 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     uint32_t* alpha_pows_c = nullptr;  // the same powers, centred, 8 words each (lazy accumulators)
     PTRY(palloc((size_t)max_w * 32, &alpha_pows_c));
     PTRY(ef_powers(ctx, alpha_fri.c, alpha_pows_c, max_w, true));
-    std::vector<ef> alpha_pows_host(max_w);
-    {
-        ef p = bb::ef_one();
-        for (uint32_t c = 0; c < max_w; c++) {
-            alpha_pows_host[c] = p;
-            p = bb::ef_mul(p, alpha_fri);
-        }
-    }
+    // (host copies of the powers, extended as the matrices need them: the widest matrix is not the first to be launched, and
+    // the device waits for this thread here)
+    std::vector<ef> alpha_pows_host{bb::ef_one()};
+    alpha_pows_host.reserve(max_w);
+    auto alpha_pows_upto = [&](uint32_t w) {
+        while (alpha_pows_host.size() < w) alpha_pows_host.push_back(bb::ef_mul(alpha_pows_host.back(), alpha_fri));
+    };
     // phase 3: the reduced openings of every matrix
     // narrow matrices wait per (height, first point) and go out together (fri.hip: k_reduce_openings_narrow)
     std::map<std::pair<int, int>, NarrowArgs> narrow;
@@ -439,6 +438,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             const std::vector<int>& mp = r.points[m];
             uint32_t *d0 = nullptr, *d1 = nullptr;
             ef reduced_ys[2] = {bb::ef_zero(), bb::ef_zero()};
+            alpha_pows_upto(w);
             for (size_t p = 0; p < mp.size(); p++) {
                 const std::vector<ef>& ys = opened[ri][m][p];
                 for (uint32_t c = 0; c < w; c++) reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
