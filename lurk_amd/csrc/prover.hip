@@ -374,20 +374,31 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     opened.assign(rounds.size(), {});
     {
         size_t k = 0;
+        // the factor depends on the height and the point only (a ladder, an inversion and an extension ladder: 3 us of this
+        // thread per matrix, 66 matrices, while the device waits): once per (height, point)
+        std::map<std::pair<int, int>, ef> factors;
+        auto factor_of = [&](int log_n, int pt) -> const ef& {
+            const auto key = std::make_pair(log_n, pt);
+            auto it = factors.find(key);
+            if (it == factors.end()) {
+                const size_t n = (size_t)1 << log_n;
+                const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
+                const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
+                ef zn = ef_pow_host(pts[pt], n);
+                zn.c[0] = bb::sub(zn.c[0], gn);
+                it = factors.emplace(key, bb::ef_scale(zn, denom_inv)).first;
+            }
+            return it->second;
+        };
         for (size_t ri = 0; ri < rounds.size(); ri++) {
             const Round& r = rounds[ri];
             opened[ri].resize(r.c->n_mats);
             for (int m = 0; m < r.c->n_mats; m++, k++) {
                 const uint32_t w = r.c->width[m];
-                const size_t n = (size_t)1 << (r.c->log_h[m] - log_blowup);
                 const std::vector<int>& mp = r.points[m];
-                const uint32_t gn = pow_host(g_m, n), gn1 = pow_host(g_m, n - 1);
-                const uint32_t denom_inv = pow_host(bb::mul(bb::to_monty((uint32_t)(n % bb::P)), gn1), bb::P - 2);
                 opened[ri][m].resize(mp.size());
                 for (size_t p = 0; p < mp.size(); p++) {
-                    ef zn = ef_pow_host(pts[mp[p]], n);
-                    zn.c[0] = bb::sub(zn.c[0], gn);
-                    const ef factor = bb::ef_scale(zn, denom_inv);
+                    const ef factor = factor_of(r.c->log_h[m] - log_blowup, mp[p]);
                     std::vector<ef>& ys = opened[ri][m][p];
                     ys.resize(w);
                     for (uint32_t c = 0; c < w; c++) {
