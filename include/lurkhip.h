@@ -99,6 +99,14 @@ int32_t lurkhip_profile_reset(lurkhip_ctx* ctx);
 int32_t lurkhip_profile_read(lurkhip_ctx* ctx, const char* span, double* total_ms, int64_t* count);
 /* Returns cached device blocks of the ctx's allocation pool to the driver. */
 int32_t lurkhip_pool_trim(lurkhip_ctx* ctx);
+/* Pool accounting: out = {bytes handed out, bytes cached on the free lists, high-water mark of their sum since the last
+ * lurkhip_pool_reset_peak, hipMalloc calls, out-of-memory retries, bytes of cached coset-shift tables}.  The high-water mark
+ * is the HBM footprint of whatever was proved in between (the reference keeps its traces in host Vecs; no counterpart). */
+int32_t lurkhip_pool_stats(lurkhip_ctx* ctx, uint64_t out[6]);
+int32_t lurkhip_pool_reset_peak(lurkhip_ctx* ctx);
+/* Test hook: the next n device allocations of the pool fail as if the driver were out of memory, which drives the
+ * trim-and-retry path of the allocator. */
+int32_t lurkhip_debug_inject_alloc_failures(lurkhip_ctx* ctx, int32_t n);
 
 /* ---------------------------------------------------------------- Poseidon2 */
 /* Widths: 4, 8, ..., 48 (the reference's BabyBearConfig4..48,
@@ -179,7 +187,8 @@ typedef struct lurkhip_protocol_profile {
     uint32_t p16_diag[16];            /* internal layer: y_i = scale * (sum_j x_j + diag_i * x_i) */
     uint32_t p16_internal_scale;      /* 1 = the paper's 1 + diag; p3's Montgomery-shift diffusion layer computes 2^-32 (1 + diag) */
     /* p3 DuplexChallenger<_, _, 16, 8>: absorbs 8 lanes by overwrite */
-    uint32_t challenger_squeeze;      /* lanes of the state offered as output after a permutation: 16 (whole state) or 8 (rate) */
+    uint32_t challenger_squeeze;      /* lanes of the state offered as output after a permutation: 8 (the RATE lanes, default) or
+                                         16 (the whole state, capacity lanes included: opt-in, preset "whole-state-squeeze") */
     uint32_t challenger_pop_front;    /* 0: sample() pops the END of the output buffer (p3 Vec::pop), 1: the front */
     /* what the shard transcript observes */
     uint32_t observe_openings;        /* 0: alpha_fri is sampled right after zeta (the pinned revision); 1: every opened value is
@@ -198,7 +207,8 @@ typedef struct lurkhip_protocol_profile {
 
 /* Fills `out` with a named preset: "default" (this build's best recall of the pinned revision, with the reference's in-tree
  * BabyBearConfig16 constants because sphinx's RC_16_30 are not in /root/reference), "hardened" (default + observe_openings +
- * observe_chip_meta + squeeze 8), "p3-monty-diffusion" (default with diag = [-2, 1, 2, 4, ..., 2^13, 2^15] and scale 2^-32). */
+ * observe_chip_meta), "whole-state-squeeze" (default + challenger_squeeze 16), "p3-monty-diffusion" (default with
+ * diag = [-2, 1, 2, 4, ..., 2^13, 2^15] and scale 2^-32). */
 int32_t lurkhip_protocol_profile_preset(const char* name, lurkhip_protocol_profile* out);
 /* Installs / reads the context's profile.  Set it before anything is committed or any challenger is created on the ctx. */
 int32_t lurkhip_set_protocol_profile(lurkhip_ctx* ctx, const lurkhip_protocol_profile* profile);

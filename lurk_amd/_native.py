@@ -10,7 +10,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "liblurkhip.so")
+# LURKHIP_LIB_PATH selects another build of the same ABI (the A/B variant liblurkhip_declared.so of tests/test_mad_ab_gpu.py)
+LIB_PATH = os.environ.get("LURKHIP_LIB_PATH") or os.path.join(_HERE, "liblurkhip.so")
 
 
 class LurkHipError(RuntimeError):
@@ -78,6 +79,9 @@ SIGNATURES = {
     "lurkhip_profile_reset": (_i32, [_p]),
     "lurkhip_profile_read": (_i32, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
     "lurkhip_pool_trim": (_i32, [_p]),
+    "lurkhip_pool_stats": (_i32, [_p, _p]),
+    "lurkhip_pool_reset_peak": (_i32, [_p]),
+    "lurkhip_debug_inject_alloc_failures": (_i32, [_p, _i32]),
     "lurkhip_poseidon2_num_cols": (_i32, [_i32]),
     "lurkhip_poseidon2_permute": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),
     "lurkhip_poseidon2_permute_dev": (_i32, [_p, _i32, _sz, _u32p, _u32p, _i32]),

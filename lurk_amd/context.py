@@ -108,6 +108,19 @@ class Context:
     def pool_trim(self):
         self.check(N.lib.lurkhip_pool_trim(self.handle))
 
+    def pool_stats(self) -> dict:
+        """Allocator accounting of this context (bytes): live, cached, peak of live + cached, hipMalloc calls, OOM retries."""
+        out = np.zeros(6, dtype=np.uint64)
+        self.check(N.lib.lurkhip_pool_stats(self.handle, out.ctypes.data))
+        keys = ("live_bytes", "cached_bytes", "peak_bytes", "mallocs", "oom_retries", "scale_table_bytes")
+        return {k: int(v) for k, v in zip(keys, out)}
+
+    def pool_reset_peak(self):
+        self.check(N.lib.lurkhip_pool_reset_peak(self.handle))
+
+    def debug_inject_alloc_failures(self, n: int):
+        self.check(N.lib.lurkhip_debug_inject_alloc_failures(self.handle, int(n)))
+
     # raw device memory (hosts without torch)
     def malloc(self, nbytes: int) -> int:
         p = C.c_void_p()

@@ -62,7 +62,7 @@ struct Challenger {
     std::vector<uint32_t> input;   // Montgomery
     std::vector<uint32_t> output;  // Montgomery
     // lurkhip_protocol_profile: lanes offered after a permutation (8 or 16), and which end sample() pops
-    int squeeze = 16;
+    int squeeze = 8;
     bool pop_front = false;
 
     void duplexing() {

@@ -44,6 +44,10 @@ struct lurkhip_ctx {
     // size-keyed free lists so steady-state proving does no hipMalloc/hipFree (pool_alloc/pool_release)
     std::multimap<size_t, void*> pool_free;
     std::map<void*, size_t> pool_live;
+    // pool accounting (lurkhip_pool_stats): bytes handed out, bytes cached on the free list, high-water mark of their sum,
+    // hipMalloc calls, OOM retries; inject_alloc_failures is the test hook that forces the retry path
+    uint64_t pool_live_bytes = 0, pool_cached_bytes = 0, pool_peak_bytes = 0, pool_mallocs = 0, pool_retries = 0;
+    int inject_alloc_failures = 0;
     // Fork / join inside one proof (lurkhip::SideLane): a second stream of the context for the short chips' launches.  While a
     // lane is open every pool_release is deferred to the join, so no block is handed out again while either stream may still use it.
     hipStream_t side_stream = nullptr;

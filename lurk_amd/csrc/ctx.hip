@@ -107,26 +107,39 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
         *out = it->second;
         ctx->pool_free.erase(it);
         ctx->pool_live[*out] = bytes;
+        ctx->pool_cached_bytes -= bytes;
+        ctx->pool_live_bytes += bytes;
         return LURKHIP_OK;
     }
-    hipError_t e = hipMalloc(out, bytes);
+    auto device_malloc = [&]() -> hipError_t {
+        if (ctx->inject_alloc_failures > 0) {  // test hook (lurkhip_debug_inject_alloc_failures): pretend the driver is out of memory
+            ctx->inject_alloc_failures--;
+            *out = nullptr;
+            return hipErrorOutOfMemory;
+        }
+        ctx->pool_mallocs++;
+        return hipMalloc(out, bytes);
+    };
+    hipError_t e = device_malloc();
     if (e != hipSuccess && !ctx->pool_free.empty()) {
-        // give cached blocks back to the driver and retry once
+        // Give the cached blocks back to the driver and retry once.  Only blocks on the free list go: nobody holds a pointer to
+        // them.  The scale / selector table caches stay -- a caller up the stack may be holding one of their pointers.
         (void)hipStreamSynchronize(ctx->stream);
+        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
         for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
         ctx->pool_free.clear();
-        // the table caches are rebuilt on demand
-        for (auto& kv : ctx->lde_scale_tables) (void)hipFree(kv.second);
-    for (auto& kv : ctx->selector_tables) (void)hipFree(kv.second);
-        ctx->lde_scale_tables.clear();
-        ctx->lde_scale_bytes = 0;
-        for (auto& kv : ctx->selector_tables) (void)hipFree(kv.second);
-        ctx->selector_tables.clear();
-        e = hipMalloc(out, bytes);
+        ctx->pool_cached_bytes = 0;
+        ctx->pool_retries++;
+        (void)hipGetLastError();  // the failed hipMalloc must not surface at the next launch check
+        e = device_malloc();
     }
-    if (e != hipSuccess)
+    if (e != hipSuccess) {
+        (void)hipGetLastError();
         return set_error(ctx, e == hipErrorOutOfMemory ? LURKHIP_ERR_OOM : LURKHIP_ERR_HIP, "hipMalloc(%zu) failed: %s", bytes,
                          hipGetErrorString(e));
+    }
+    ctx->pool_live_bytes += bytes;
+    ctx->pool_peak_bytes = std::max(ctx->pool_peak_bytes, ctx->pool_live_bytes + ctx->pool_cached_bytes);
     ctx->pool_live[*out] = bytes;
     return LURKHIP_OK;
 }
@@ -146,6 +159,8 @@ void pool_release(lurkhip_ctx* ctx, void* ptr) {
         return;
     }
     ctx->pool_free.insert({it->second, ptr});
+    ctx->pool_cached_bytes += it->second;
+    ctx->pool_live_bytes -= it->second;
     ctx->pool_live.erase(it);
 }
 
@@ -472,8 +487,37 @@ int32_t lurkhip_profile_read(lurkhip_ctx* ctx, const char* span, double* total_m
 int32_t lurkhip_pool_trim(lurkhip_ctx* ctx) {
     LH_CHECK_CTX(ctx);
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
     for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
     ctx->pool_free.clear();
+    ctx->pool_cached_bytes = 0;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_pool_stats(lurkhip_ctx* ctx, uint64_t out[6]) {
+    LH_CHECK_CTX(ctx);
+    if (!out) return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "lurkhip_pool_stats: out is null");
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    out[0] = ctx->pool_live_bytes;
+    out[1] = ctx->pool_cached_bytes;
+    out[2] = ctx->pool_peak_bytes;
+    out[3] = ctx->pool_mallocs;
+    out[4] = ctx->pool_retries;
+    out[5] = ctx->lde_scale_bytes;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_pool_reset_peak(lurkhip_ctx* ctx) {
+    LH_CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    ctx->pool_peak_bytes = ctx->pool_live_bytes + ctx->pool_cached_bytes;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_debug_inject_alloc_failures(lurkhip_ctx* ctx, int32_t n) {
+    LH_CHECK_CTX(ctx);
+    std::lock_guard<std::mutex> lock(ctx->pool_mu);
+    ctx->inject_alloc_failures = n < 0 ? 0 : n;
     return LURKHIP_OK;
 }
 

@@ -294,13 +294,18 @@ struct Validator {
     const Func& f;
     uint32_t next_ident = 0;
     void bad(const std::string& m) const { throw ParseError("bytecode of " + f.name + ": " + m); }
-    void refs(const std::vector<uint32_t>& l, uint32_t height) const {
+    void refs(const std::vector<uint32_t>& l, uint64_t height) const {
         for (uint32_t v : l)
             if (v >= height) bad("stack reference " + std::to_string(v) + " above the stack height " + std::to_string(height));
     }
     // returns the return idents of the block, in order
-    std::vector<uint32_t> block(const Block& b, uint32_t height) {
+    static bool has_mem_table(size_t len) { return len == 2 || len == 3 || len == 4 || len == 5 || len == 6 || len == 8; }
+    // the stack height is tracked in 64 bits with a bound: a crafted blob must not wrap it past the reference checks
+    static constexpr uint64_t MAX_HEIGHT = 1u << 24;
+    std::vector<uint32_t> block(const Block& b, uint64_t height) {
+        if (height > MAX_HEIGHT) bad("stack height out of range");
         for (const Op& op : b.ops) {
+            if (height > MAX_HEIGHT) bad("stack height out of range");
             switch (op.kind) {
                 case OpKind::AssertEq:
                 case OpKind::AssertNe:
@@ -335,17 +340,18 @@ struct Validator {
                     const bool call = op.kind == OpKind::Call;
                     if (op.a.size() != (call ? g.input_size : g.output_size)) bad("wrong number of arguments for " + g.name);
                     if (g.partial && !f.partial) bad("the partial " + g.name + " called from a non-partial function");
+                    if (!call && !g.invertible) bad("preimage of " + g.name + ", which is not invertible");
                     refs(op.a, height);
                     height += call ? g.output_size : g.input_size;
                     break;
                 }
                 case OpKind::Store:
-                    if (op.a.empty()) bad("store of nothing");
+                    if (!has_mem_table(op.a.size())) bad("store of " + std::to_string(op.a.size()) + " values: memory tables exist for 2, 3, 4, 5, 6 and 8");
                     refs(op.a, height);
                     height += 1;
                     break;
                 case OpKind::Load:
-                    if (op.x == 0 || op.x > 64) bad("load of an implausible length");
+                    if (!has_mem_table(op.x)) bad("load of " + std::to_string(op.x) + " values: memory tables exist for 2, 3, 4, 5, 6 and 8");
                     refs({op.y}, height);
                     height += op.x;
                     break;
@@ -377,7 +383,12 @@ struct Validator {
         } else {
             if (c.kind == Ctrl::Choose) {
                 refs({c.var}, height);
+                for (const auto& kv : c.branches)
+                    if (kv.first[0] >= P) bad("match key is not a canonical field element");
                 for (const auto& blk : c.unique_branches) {
+                    bool referenced = false;
+                    for (const auto& kv : c.branches) referenced = referenced || kv.second == blk;
+                    if (!referenced) bad("a unique branch that no key selects");
                     auto sub = block(*blk, height);
                     idents.insert(idents.end(), sub.begin(), sub.end());
                 }

@@ -444,7 +444,9 @@ void preset_default(lurkhip_protocol_profile* p) {
     for (int i = 0; i < 13; i++) p->p16_int_rc[i] = LURK_P2_INT_RC_16[i];
     for (int i = 0; i < 16; i++) p->p16_diag[i] = LURK_P2_DIAG_16[i];
     p->p16_internal_scale = 1;
-    p->challenger_squeeze = 16;  // p3 at the pinned revision offered the whole state after a permutation [UPSTREAM-RECALL]
+    // DuplexChallenger<Val, Perm, 16, 8>: the RATE parameter bounds both the absorbed and the offered lanes (sponge_state[..RATE])
+    // [UPSTREAM-RECALL]; offering the capacity lanes (16, preset "whole-state-squeeze") is opt-in until an upstream vector pins it
+    p->challenger_squeeze = 8;
     p->challenger_pop_front = 0;
     p->observe_openings = 0;
     p->observe_chip_meta = 0;
@@ -540,6 +542,10 @@ int32_t lurkhip_protocol_profile_preset(const char* name, lurkhip_protocol_profi
         out->observe_openings = 1;
         out->observe_chip_meta = 1;
         out->challenger_squeeze = 8;
+        return LURKHIP_OK;
+    }
+    if (n == "whole-state-squeeze") {  // round 2's default: all 16 lanes offered after a permutation
+        out->challenger_squeeze = 16;
         return LURKHIP_OK;
     }
     if (n == "p3-monty-diffusion") {

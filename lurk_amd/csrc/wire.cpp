@@ -47,7 +47,10 @@ struct Out {
     void u64(uint64_t v) {
         for (int i = 0; i < 8; i++) b.push_back((uint8_t)(v >> (8 * i)));
     }
-    void f(uint32_t canon) { u32(monty ? (uint32_t)(((uint64_t)canon << 32) % P) : canon); }
+    void f(uint32_t canon) {
+        if (canon >= P) throw std::runtime_error("field word is not canonical");  // upstream's deserialiser rejects it
+        u32(monty ? (uint32_t)(((uint64_t)canon << 32) % P) : canon);
+    }
     void fs(const uint32_t* p, size_t n) {
         for (size_t i = 0; i < n; i++) f(p[i]);
     }
@@ -98,7 +101,7 @@ void shard_proof(Out& o, const uint32_t* words, uint64_t n_words, int32_t n_name
         const uint32_t* q = w.take(7);
         c.machine_index = q[0], c.log_n = q[1], c.width = q[2], c.prep_width = q[3], c.perm_width = q[4], c.quotient_degree = q[5], c.prep_index_plus1 = q[6];
         c.cumulative_sum = w.take(4);
-        if ((int32_t)c.machine_index >= n_names) throw std::runtime_error("chip without a name");
+        if (n_names < 0 || c.machine_index >= (uint32_t)n_names) throw std::runtime_error("chip without a name");
     }
     w.take(n_public);
     const uint32_t *main_root = w.take(8), *perm_root = w.take(8), *quot_root = w.take(8);
@@ -217,7 +220,10 @@ int64_t finish(const Out& o, uint8_t* out, uint64_t capacity) {
 }
 
 void zptr(Out& o, const uint32_t* z) {
-    o.u32(z[0]);  // Tag: a unit-variant enum, bincode writes the variant index
+    // Tag: a unit-variant enum of 15 variants (U64 = 0 ... Err = 14, /root/reference/src/core/tag.rs:23-39); bincode writes the
+    // variant index and rejects any other on the way back in
+    if (z[0] > 14) throw std::runtime_error("ZPtr tag out of range");
+    o.u32(z[0]);
     o.fs(z + 1, 8);
 }
 

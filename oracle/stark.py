@@ -30,7 +30,7 @@ class Profile:
     field by field.  `install()` hands the permutation tables to the oracle's C side (Merkle tree, sponge, transcript)."""
 
     FIELDS = {"p16_rounds_p": 13, "p16_ext_rc": None, "p16_int_rc": None, "p16_diag": None, "p16_internal_scale": 1,
-              "challenger_squeeze": 16, "challenger_pop_front": 0, "observe_openings": 0, "observe_chip_meta": 0,
+              "challenger_squeeze": 8, "challenger_pop_front": 0, "observe_openings": 0, "observe_chip_meta": 0,
               "constraint_alpha_ascending": 0, "fri_alpha_global": 0, "fri_log_arity": 1, "fri_log_blowup": 1, "fri_num_queries": 100,
               "fri_pow_bits": 16, "serialize_montgomery": 0}
 

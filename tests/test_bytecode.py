@@ -134,3 +134,44 @@ def test_semantic_checks():
     otop2.chips[0].name = "no_such_chip"
     with pytest.raises(lair.LairError, match="no native chip"):
         lair.Toplevel.from_bytecode(ol.to_bytecode(otop2))
+
+
+def test_semantic_checks_of_the_trust_boundary():
+    """the importer must refuse what the interpreter / layout pass would later throw on or index with --
+    Load / Store lengths without a memory table, preimages of non-invertible callees, non-canonical Choose keys."""
+    import copy
+
+    base = ol.Toplevel(PARTIAL_SRC)
+
+    def variant(edit):
+        t = copy.deepcopy(base)
+        edit(t)
+        return ol.to_bytecode(t)
+
+    assert _import_status(variant(lambda t: None)) == N.OK
+    # Store of 7 values / Load of 7: there are tables for 2, 3, 4, 5, 6, 8 only (/root/reference/src/lair/execute.rs:243-257)
+    with pytest.raises(lair.LairError, match="memory tables"):
+        lair.Toplevel.from_bytecode(variant(lambda t: t.funcs[0]["body"]["ops"].insert(0, ("store", [0] * 7))))
+    with pytest.raises(lair.LairError, match="memory tables"):
+        lair.Toplevel.from_bytecode(variant(lambda t: t.funcs[0]["body"]["ops"].insert(0, ("load", 7, 0))))
+    with pytest.raises(lair.LairError, match="memory tables"):
+        lair.Toplevel.from_bytecode(variant(lambda t: t.funcs[0]["body"]["ops"].insert(0, ("load", 1, 0))))
+    # PreImg of a callee that is not invertible
+    def preimg(t):
+        g = next(i for i, f in enumerate(t.funcs) if not f["invertible"])
+        t.funcs[0]["body"]["ops"].insert(0, ("preimg", g, [0] * t.funcs[g]["output_size"]))
+    with pytest.raises(lair.LairError, match="not invertible"):
+        lair.Toplevel.from_bytecode(variant(preimg))
+    # a Choose key that is not a canonical field element: patch the key word of a one-variable match in an exported blob
+    src = "fn f(x): [1] {\n    match x {\n        77777 => {\n            let a = 3;\n            return a\n        }\n    };\n    return x\n}\n"
+    blob = lair.Toplevel(src).to_bytecode()
+    at = [i for i, w in enumerate(blob.tolist()) if w == 77777]
+    assert len(at) >= 1 and _import_status(blob) == N.OK  # (the default branch re-states the key as a Const for its AssertNe)
+    messages = []
+    for i in at:
+        bad = blob.copy()
+        bad[i] = 2013265921 + 5
+        with pytest.raises(lair.LairError, match="canonical") as e:
+            lair.Toplevel.from_bytecode(bad)
+        messages.append(str(e.value))
+    assert any("match key" in m for m in messages), messages

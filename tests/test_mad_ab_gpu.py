@@ -1,0 +1,66 @@
+"""A/B guard of the inline-assembly carry operand of v_mad_i64_i32 (lurk_amd/csrc/babybear.h): the default
+build hands the instruction's unused carry-out pair over as an *input* (no s_nop between products), the variant build
+(`make -C lurk_amd/csrc variant` -> liblurkhip_declared.so, -DLURK_MAD_CARRY_DECLARED=1) declares it as an output.  Every field
+multiplication of the hashing, NTT, AIR and opening kernels goes through that macro: both builds must produce the same
+hashes, commitments and proof words."""
+import hashlib
+import json
+import os
+import subprocess
+import sys
+
+import pytest
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+VARIANT = os.path.join(ROOT, "lurk_amd", "liblurkhip_declared.so")
+
+SCRIPT = r"""
+import hashlib, json, sys
+import numpy as np
+import lurk_amd
+from lurk_amd import synth, lair, prover, commit as lcommit
+from lurk_amd.poseidon import PoseidonChipset
+from lurk_amd.programs import synth_eval as se
+out = {"lib": lurk_amd.LIB_PATH}
+h = lambda a: hashlib.sha256(np.ascontiguousarray(a).tobytes()).hexdigest()
+with lurk_amd.Context(0) as ctx:
+    for width in (16, 24, 40):
+        x = synth.field_elements((4096, width), seed=width)
+        chip = PoseidonChipset(ctx, width)
+        out[f"hash{width}"] = h(chip.hash_batch(x))
+    out["wide24"] = h(PoseidonChipset(ctx, 24).witness_batch(synth.field_elements((300, 24), seed=5)))
+    mats = [synth.field_elements((1 << 12, 78), seed=1), synth.field_elements((1 << 9, 20), seed=2), synth.field_elements((1 << 12, 5), seed=3)]
+    c = lcommit.commit(ctx, mats, log_blowup=1)
+    out["root"] = [int(v) for v in c.root]
+    c.close()
+    top = lair.Toplevel(se.SOURCE)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(se.FUNC, se.args_for_rows(2048), q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, se.FUNC, len(pv))
+    m.setup()
+    proofs = m.prove(q, num_queries=8, pow_bits=6)
+    out["proof"] = [h(p.words) for p in proofs]
+    m.close()
+print("AB " + json.dumps(out))
+"""
+
+
+def run(lib_path):
+    env = dict(os.environ)
+    if lib_path:
+        env["LURKHIP_LIB_PATH"] = lib_path
+    else:
+        env.pop("LURKHIP_LIB_PATH", None)
+    r = subprocess.run([sys.executable, "-c", SCRIPT], cwd=ROOT, env=env, capture_output=True, text=True, timeout=900)
+    assert r.returncode == 0, r.stderr[-2000:]
+    line = [l for l in r.stdout.splitlines() if l.startswith("AB ")][-1]
+    return json.loads(line[3:])
+
+
+@pytest.mark.skipif(not os.path.exists(VARIANT), reason="variant library not built (make -C lurk_amd/csrc variant)")
+def test_declared_carry_build_gives_identical_results():
+    a, b = run(None), run(VARIANT)
+    assert a.pop("lib") != b.pop("lib")
+    assert a == b

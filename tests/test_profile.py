@@ -21,9 +21,10 @@ def test_struct_layout_and_presets():
         if v is not None:
             assert d[k] == v, k
     assert set(d) == set(os_.Profile.FIELDS)
-    assert d["challenger_squeeze"] == 16 and d["p16_internal_scale"] == 1 and d["fri_log_arity"] == 1
+    assert d["challenger_squeeze"] == 8 and d["p16_internal_scale"] == 1 and d["fri_log_arity"] == 1
     h = ProtocolProfile.preset("hardened").to_dict()
     assert (h["observe_openings"], h["observe_chip_meta"], h["challenger_squeeze"]) == (1, 1, 8)
+    assert ProtocolProfile.preset("whole-state-squeeze").to_dict()["challenger_squeeze"] == 16
     m = ProtocolProfile.preset("p3-monty-diffusion").to_dict()
     assert m["p16_diag"] == [P - 2] + [1 << s for s in (0, 1, 2, 3, 4, 5, 6, 7, 8, 9, 10, 11, 12, 13, 15)]
     assert m["p16_internal_scale"] * pow(2, 32, P) % P == 1
@@ -50,7 +51,7 @@ def test_oracle_custom_perm16_equals_table_driven_one(oracle):
     assert ob.perm16(states[1]) == want[1]
 
 
-@pytest.mark.parametrize("field,value", [("challenger_squeeze", 8), ("challenger_pop_front", 1)])
+@pytest.mark.parametrize("field,value", [("challenger_squeeze", 16), ("challenger_pop_front", 1)])
 def test_oracle_transcript_reacts_to_challenger_fields(oracle, field, value):
     def run(profile):
         ch = os_.Challenger(os_.default_permute16(), profile)
@@ -62,8 +63,8 @@ def test_oracle_transcript_reacts_to_challenger_fields(oracle, field, value):
     base, other = run(os_.Profile()), run(os_.Profile(**{field: value}))
     assert base != other
     if field == "challenger_squeeze":
-        # 16 outputs per permutation instead of 8: the first 8 samples of the rate-8 transcript are lanes 7..0, of the whole-
-        # state one lanes 15..8
+        # 16 outputs per permutation instead of the default 8: the first 8 samples of the rate-8 transcript are lanes 7..0, of
+        # the whole-state one lanes 15..8
         assert base[:8] != other[:8]
 
 
@@ -109,3 +110,23 @@ def test_upstream_loader_mechanics(oracle, tmp_path, monkeypatch):
                 tv.test_mmcs_commit((d, pr))
         finally:
             os_.Profile().install()
+
+
+def test_default_transcript_tripwire(oracle):
+    """The default profile cannot move silently: a fixed transcript under it is committed (tests/golden/default_transcript.json,
+    written by make_default_transcript.py from the oracle).  The library's default preset must carry the same scalars."""
+    import importlib.util
+    import json
+    import os
+
+    here = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+    doc = json.load(open(os.path.join(here, "default_transcript.json")))
+    spec = importlib.util.spec_from_file_location("make_default_transcript", os.path.join(here, "make_default_transcript.py"))
+    gen = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(gen)
+    assert gen.OPS == doc["ops"]
+    assert gen.run() == doc["outputs"]
+    lib = ProtocolProfile.preset("default").to_dict()
+    for k, v in doc["profile_scalars"].items():
+        assert lib[k] == v, k
+    assert gen.run(os_.Profile(challenger_squeeze=16)) != doc["outputs"]

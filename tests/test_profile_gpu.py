@@ -19,7 +19,7 @@ pytestmark = pytest.mark.gpu
 P = 2013265921
 
 VARIANTS = {
-    "squeeze8": {"challenger_squeeze": 8},
+    "squeeze16": {"challenger_squeeze": 16},
     "pop_front": {"challenger_pop_front": 1},
     "observe_openings": {"observe_openings": 1},
     "observe_chip_meta": {"observe_chip_meta": 1},
@@ -103,6 +103,23 @@ def test_host_transcript_matches_oracle_under_every_challenger_setting():
                     ch.observe(obs)
                     och.observe(obs)
                     assert ch.sample(n) == [och.sample() for _ in range(n)], (squeeze, front)
+
+
+def test_default_transcript_tripwire_on_the_library(ctx):
+    """tests/golden/default_transcript.json through the library's host challenger under its default profile."""
+    import json
+    import os
+
+    doc = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "default_transcript.json")))
+    ch, got = prover.Challenger(ctx), []
+    for op, arg in doc["ops"]:
+        if op == "observe":
+            ch.observe(list(arg))
+        elif op == "sample":
+            got += ch.sample(arg)
+        else:
+            got.append(ch.sample_bits(arg))
+    assert got == doc["outputs"]
 
 
 def test_unsupported_profiles_are_refused(ctx):
