@@ -15,7 +15,8 @@ i.e. what `machine.prove::<LocalProver>` does after `execute` (/root/reference/b
 every chip, main-trace commitment, LogUp permutation traces + commitment, quotient + commitment, openings at zeta and FRI
 (100 queries, 16 proof-of-work bits).  Metric: eval-steps (rows of the eval chip) proved per second.
 
-Multi-GPU (--gpus N, launched by torch.distributed.run): ONE execution with N * 2^log_rows eval rows on every rank (the
+Multi-GPU (--gpus N: launched by torch.distributed.run, or -- run as a plain command -- bench.py starts its own N ranks
+that way, one per visible GPU, and refuses if there are fewer than N): ONE execution with N * 2^log_rows eval rows on every rank (the
 same program, so the same query record), cut by `Shard::shard` (/root/reference/src/lair/execute.rs:186-216; Entrypoint /
 memory chips only in shard 0, lair_chip.rs:124-139) into 2 N shards of 2^log_rows / 2 eval rows.  `Shard::shard` cuts every
 chip at the same row count, so the first shards hold every chip and the last ones only the eval chip: the shards are dealt to
@@ -137,32 +138,68 @@ def main():
                     help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the extra streamed multi-shard measurement (host flatten + upload under the proofs)")
     ap.add_argument("--pipeline-shards", type=int, default=4)
+    ap.add_argument("--oversubscribe", action="store_true",
+                    help="diagnostic: allow more ranks than visible GPUs (ranks share devices, collectives over gloo); never a scaling number")
+    ap.add_argument("--profile", default="default", help="protocol profile preset (lurkhip_protocol_profile_preset): default, hardened, whole-state-squeeze, p3-monty-diffusion")
     ap.add_argument("--shards-per-rank", type=int, default=None,
                     help="distributed runs: shards of 2^log_rows / k eval rows, k per rank, dealt by work (default 2 when WORLD_SIZE > 1, else 1)")
     args = ap.parse_args()
 
     import torch
 
+    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (any N, also 1)
+    n_devices = torch.cuda.device_count()
+    if not distributed and args.gpus > 1:
+        # `python bench.py --gpus N` on its own: start the N ranks here, one per visible GPU, the way the driver's launcher does
+        # (round 2 silently ran ONE rank and printed n_gpus 1).  Fewer than N devices is an error unless --oversubscribe asks for
+        # the diagnostic run in which several ranks share a device.
+        if n_devices < args.gpus and not args.oversubscribe:
+            raise SystemExit(f"bench.py --gpus {args.gpus}: only {n_devices} GPU(s) visible to this process; refusing to run fewer ranks than asked "
+                             "(--oversubscribe runs N ranks on the devices present over gloo, as a diagnostic, not as a scaling number)")
+        import socket
+        import subprocess
+
+        with socket.socket() as sock:
+            sock.bind(("127.0.0.1", 0))
+            port = sock.getsockname()[1]
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr", "127.0.0.1",
+               "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+        raise SystemExit(subprocess.call(cmd))
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    distributed = "RANK" in os.environ and "WORLD_SIZE" in os.environ  # launched by torch.distributed.run (any N, also 1)
+    if args.gpus != world:
+        raise SystemExit(f"bench.py --gpus {args.gpus} but WORLD_SIZE is {world}: the launcher's rank count and --gpus must agree")
+    oversubscribed = world > n_devices
+    if oversubscribed and not args.oversubscribe:
+        raise SystemExit(f"bench.py: {world} ranks but only {n_devices} GPU(s) visible (pass --oversubscribe for the shared-device diagnostic run)")
+    if n_devices < 1:
+        raise SystemExit("bench.py: no GPU visible; the proving path has no CPU fallback")
+    device_index = local_rank % n_devices
+    rccl_world_size = None
     if distributed:
         import torch.distributed as dist
 
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
-        dist.init_process_group(backend="nccl", device_id=torch.device("cuda", local_rank))
-    if args.gpus != world and rank == 0 and distributed:
-        print(f"warning: --gpus {args.gpus} but WORLD_SIZE {world}", file=sys.stderr)
-    torch.cuda.set_device(local_rank)
+        if oversubscribed:  # RCCL refuses two ranks on one device: the two tiny collectives go over gloo
+            dist.init_process_group(backend="gloo")
+        else:
+            dist.init_process_group(backend="nccl", device_id=torch.device("cuda", device_index))
+        rccl_world_size = dist.get_world_size()
+        assert rccl_world_size == world
+    torch.cuda.set_device(device_index)
 
     import lurk_amd
     from lurk_amd import lair, prover, shards
 
-    ctx = lurk_amd.Context(local_rank)
+    ctx = lurk_amd.Context(device_index)
+    if args.profile != "default":
+        from lurk_amd.profile import ProtocolProfile
+
+        ProtocolProfile.preset(args.profile).install(ctx)
     log_rows = args.log_rows if args.log_rows is not None else (18 if args.workload == "lurk-mix" else LOG_ROWS)
     n = 1 << log_rows
-    dev = "cuda" if distributed else "cpu"
+    dev = "cuda" if distributed and not oversubscribed else "cpu"
 
     # ---- host side, once: execute the ONE program on every rank, flatten this rank's shard into HBM
     source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, world, log_rows)
@@ -206,48 +243,12 @@ def main():
     main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     lane_ctx = prover.lane_context(machine) if len(mine) > 1 else None  # the second proving lane of a rank with several shards
 
-    grand_sums, rank_sums = [], []
-    host_ms = {}  # host milliseconds spent in the two collectives (all steps, warm-up included)
+    # the step itself lives in lurk_amd/shards.py (RankStep) so that the multi-process tests run exactly what is timed here
+    rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx)
+    grand_sums, rank_sums, host_ms = rank_step.grand_sums, rank_step.rank_sums, rank_step.host_ms
 
     def step():
-        # phase 1 (LocalProver::commit_shards): traces + main commitment of this rank's shards
-        handles, roots = [], []
-        ch = None
-        for pr in prepared_all:
-            ctx.span_begin("trace_all")
-            traces = machine.run_prepared(pr)
-            ctx.span_end("trace_all")
-            if ch is None:  # the transcript is opened on the host while the trace kernels run
-                ch = prover.Challenger(ctx)
-                ch.observe(vk_root)
-                ch.observe([0])
-            handle, root = machine.commit_shard(traces)
-            handles.append(handle)
-            roots.append(root)
-        # the transcript prefix: every shard's main root in shard order (RCCL all-gather of index + 8 lanes per shard) and the
-        # public values (the transcript itself was opened above, under the trace kernels)
-        t_x = time.perf_counter()
-        gathered = shards.exchange_roots(roots, device=dev, shard_indices=mine)
-        host_ms["exchange_roots"] = host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t_x) * 1e3
-        for r in gathered:
-            ch.observe(r)
-            ch.observe(pv)
-        # phase 2 (prove_shard), two shards in flight when the rank has several
-        proofs = prover.prove_lanes(machine, handles, ch, pv, args.queries, args.pow_bits, parse=False, lane_ctx=lane_ctx)
-        for handle in handles:
-            machine.free_shard(handle)
-        # grand-sum check: the chips' cumulative sums, reduced over all shards (RCCL all-reduce of 4 x int64)
-        cs = []
-        for words in proofs:
-            n_chips = int(words[1])
-            cs += [words[10 + 11 * i + 7:10 + 11 * i + 11] for i in range(n_chips)]
-        mine_sum = np.zeros(4, dtype=np.int64)
-        for c in cs:
-            mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % 2013265921
-        rank_sums.append(tuple(int(x) for x in mine_sum))
-        t_x = time.perf_counter()
-        grand_sums.append(shards.reduce_cumulative_sums(cs, device=dev))
-        host_ms["reduce_sums"] = host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t_x) * 1e3
+        proofs = rank_step()
         return np.concatenate(proofs) if len(proofs) > 1 else proofs[0]
 
     def fence():
@@ -289,15 +290,36 @@ def main():
     rank_ms = elapsed / args.steps * 1e3
     per_rank_ms = [rank_ms]
     all_rank_sums_nonzero = all(s != (0, 0, 0, 0) for s in rank_sums)
+    exec_s_per_rank = [t_execute]
     if distributed:
-        t = torch.tensor([elapsed], dtype=torch.float64, device="cuda")
+        tdev = "cuda" if dev == "cuda" else "cpu"
+        t = torch.tensor([elapsed, t_execute], dtype=torch.float64, device=tdev)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
-        per_rank_ms = [float(g.item()) / args.steps * 1e3 for g in gathered]
-        elapsed = max(float(g.item()) for g in gathered)
-        flag = torch.tensor([1 if all_rank_sums_nonzero else 0], dtype=torch.int64, device="cuda")
+        per_rank_ms = [float(g[0].item()) / args.steps * 1e3 for g in gathered]
+        exec_s_per_rank = [float(g[1].item()) for g in gathered]
+        elapsed = max(float(g[0].item()) for g in gathered)
+        flag = torch.tensor([1 if all_rank_sums_nonzero else 0], dtype=torch.int64, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
         all_rank_sums_nonzero = bool(flag.item())
+    # The proofs of the last step as a SET, outside the timed region: every rank's proof words travel to rank 0, which checks
+    # that the shard indices are a partition, that proof s carries the main root the ranks all-gathered for shard s (the root
+    # every transcript observed in position s), and that the cumulative sums of the gathered proofs cancel.  (The oracle's
+    # verifier accepting such a gathered set is tests/test_multirank_gpu.py; the bench does not import the oracle here.)
+    last = rank_step.last_proofs
+    proof_set = None
+    got = shards.gather_proofs(last, mine, dst=0)
+    if got is not None:
+        tot = np.zeros(4, dtype=np.int64)
+        roots_ok = True
+        for sidx, w in enumerate(got):
+            n_chips, n_public = int(w[1]), int(w[5])
+            at = 10 + 11 * n_chips + n_public
+            roots_ok = roots_ok and [int(x) for x in w[at:at + 8]] == rank_step.roots[sidx]
+            for c in shards.proof_cumulative_sums(w):
+                tot = (tot + np.asarray(c, dtype=np.int64)) % 2013265921
+        proof_set = {"shards_gathered_on_rank0": len(got), "main_roots_match_exchanged_roots_in_shard_order": bool(roots_ok),
+                     "grand_sum_of_gathered_proofs_is_zero": bool((tot == 0).all()), "proof_words_total": int(sum(len(w) for w in got))}
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
     if lane_ctx is not None:
@@ -378,7 +400,7 @@ def main():
         try:
             import threading
 
-            ctx2 = lurk_amd.Context(local_rank)
+            ctx2 = lurk_amd.Context(device_index)
             m2 = prover.Machine(ctx2, top, entry, len(pv))
             vk2 = m2.setup()
             prep2 = m2.prepare_shard(all_shards[0])
@@ -450,7 +472,7 @@ def main():
             if not args.no_compile:
                 mach2.compile_airs(prepared2[0])  # same chips as above: served from the code cache
             staged_bytes = sum(p.input_bytes for item in prepared2 for *_, p in item if p is not None)
-            ctx_in = lurk_amd.Context(local_rank)
+            ctx_in = lurk_amd.Context(device_index)
 
             def timed(**kw):
                 torch.cuda.synchronize()
@@ -491,7 +513,8 @@ def main():
             "metric": "Lurk eval-steps proved/sec (fib trace)",
             "value": value,
             "unit": "eval-steps/s",
-            "n_gpus": world,
+            "n_gpus": world if not oversubscribed else n_devices,
+            "ranks": world,
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
@@ -512,6 +535,11 @@ def main():
                 "shards": len(all_shards),
                 "shards_per_rank": spr,
                 "shard_assignment": assignment if world > 1 or spr > 1 else None,
+                "rccl_world_size": rccl_world_size if not oversubscribed else None,
+                "process_group": None if not distributed else ("gloo (oversubscribed diagnostic: ranks share a device; NOT a scaling number)" if oversubscribed else "nccl (RCCL)"),
+                "visible_gpus": n_devices,
+                "protocol_profile": args.profile,
+                "gathered_proof_set": proof_set,
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
                 "per_rank_sum_nonzero": all_rank_sums_nonzero if world > 1 else None,  # one rank: its own sum is the (zero) total
                 "per_rank_ms_per_step": per_rank_ms,
@@ -520,6 +548,13 @@ def main():
                 "proofs_identical_across_steps": proofs_identical,
                 "hbm_resident_input_bytes": int(input_bytes),
                 "host_execute_s": t_execute,
+                "host_execute_s_per_rank": exec_s_per_rank,
+                "end_to_end": {
+                    "note": "every rank runs the WHOLE program through the host interpreter before proving (same query record on every rank, no broadcast of row streams); that time is outside the timed region and is the end-to-end Amdahl bound",
+                    "host_execute_s_wall": max(exec_s_per_rank), "host_execute_s_summed_over_ranks": sum(exec_s_per_rank),
+                    "host_interpreter_eval_rows_per_s": world * n / max(exec_s_per_rank),
+                    "eval_steps_per_s_including_execute": world * n / (max(exec_s_per_rank) + ms_per_step * 1e-3),
+                },
                 "host_flatten_upload_s": t_flatten,
                 "compiled_air_chips": compiled,
                 "compiled_trace_chips": list(machine.compiled_traces),

@@ -92,3 +92,92 @@ def reduce_cumulative_sums(local_sums, device="cpu"):
     if dist is not None:
         dist.all_reduce(t, op=dist.ReduceOp.SUM)
     return tuple(int(x) % P for x in t.cpu().tolist())
+
+
+def proof_cumulative_sums(words) -> list:
+    """The chips' cumulative sums (4 canonical lanes each) straight from the flat proof words of lurkhip_shard_prove
+    (header 10 words, then 11 words per chip: 7 of metadata + the sum)."""
+    n_chips = int(words[1])
+    return [words[10 + 11 * i + 7:10 + 11 * i + 11] for i in range(n_chips)]
+
+
+class RankStep:
+    """One rank's share of ONE machine proof over several ranks -- the body of bench.py's timed step and of the multi-process
+    tests, so that what is timed is what is verified.
+
+    phase 1 (`LocalProver::commit_shards` [UPSTREAM-RECALL]): trace generation + main commitment of this rank's shards;
+    exchange: all-gather of (shard index, main root) records -- every shard's transcript observes the verifying key, pc_start,
+              then every shard's root and the public values in SHARD order, whatever the assignment -- (`exchange_roots`);
+    phase 2: this rank's shards proved with clones of that transcript, two in flight when the rank has several (`prove_lanes`);
+    check:   the extension-field cumulative sums all-reduced as 4 x int64 (`reduce_cumulative_sums`): each rank's own sum is
+             non-zero, the total must vanish (/root/reference/src/lair/execute.rs:186-241 shards, lair_chip.rs:104-139).
+    `device` is where the two tiny collectives' tensors live: "cuda" over RCCL, "cpu" over gloo or without a process group."""
+
+    def __init__(self, machine, vk_root, public_values, prepared_all, shard_indices, num_queries, pow_bits, device="cpu", lane_ctx=None):
+        self.machine, self.vk_root, self.pv = machine, vk_root, list(public_values)
+        self.prepared_all, self.mine = prepared_all, list(shard_indices)
+        self.num_queries, self.pow_bits, self.device, self.lane_ctx = num_queries, pow_bits, device, lane_ctx
+        self.host_ms = {}       # host milliseconds spent in the two collectives, summed over calls
+        self.calls = 0
+        self.rank_sums = []     # this rank's own sum, per call
+        self.grand_sums = []    # the all-reduced total, per call
+        self.roots = None       # the gathered roots of the last call, in shard order
+        self.last_proofs = None  # this rank's proof words of the last call
+
+    def __call__(self, parse=False):
+        import time
+
+        from . import prover
+
+        m, ctx = self.machine, self.machine.ctx
+        handles, roots, ch = [], [], None
+        for pr in self.prepared_all:
+            ctx.span_begin("trace_all")
+            traces = m.run_prepared(pr)
+            ctx.span_end("trace_all")
+            if ch is None:  # the transcript is opened on the host while the trace kernels run
+                ch = prover.Challenger(ctx)
+                ch.observe(self.vk_root)
+                ch.observe([0])
+            handle, root = m.commit_shard(traces)
+            handles.append(handle)
+            roots.append(root)
+        t = time.perf_counter()
+        self.roots = exchange_roots(roots, device=self.device, shard_indices=self.mine)
+        self.host_ms["exchange_roots"] = self.host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t) * 1e3
+        for r in self.roots:
+            ch.observe(r)
+            ch.observe(self.pv)
+        proofs = prover.prove_lanes(m, handles, ch, self.pv, self.num_queries, self.pow_bits, parse=False, lane_ctx=self.lane_ctx)
+        for handle in handles:
+            m.free_shard(handle)
+        cs = [c for words in proofs for c in proof_cumulative_sums(words)]
+        mine_sum = np.zeros(4, dtype=np.int64)
+        for c in cs:
+            mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % P
+        self.rank_sums.append(tuple(int(x) for x in mine_sum))
+        t = time.perf_counter()
+        self.grand_sums.append(reduce_cumulative_sums(cs, device=self.device))
+        self.host_ms["reduce_sums"] = self.host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t) * 1e3
+        self.calls += 1
+        self.last_proofs = proofs
+        return [prover.parse_proof(w) for w in proofs] if parse else proofs
+
+
+def gather_proofs(words_list, shard_indices, dst: int = 0):
+    """Collects the flat proof words of every rank's shards on rank `dst`, ordered by shard index (None elsewhere): the set a
+    verifier receives.  Not part of a timed step -- proofs are megabytes; `gather_object` over the process group's default
+    backend (object collectives go through host memory on either backend)."""
+    dist = _dist()
+    rec = [(int(i), np.ascontiguousarray(w, dtype=np.uint32)) for i, w in zip(shard_indices, words_list)]
+    if dist is None:
+        got = [rec]
+    else:
+        got = [None] * dist.get_world_size() if dist.get_rank() == dst else None
+        dist.gather_object(rec, got, dst=dst)
+        if got is None:
+            return None
+    flat = sorted((r for per_rank in got for r in per_rank), key=lambda r: r[0])
+    if [i for i, _ in flat] != list(range(len(flat))):
+        raise ValueError("gathered shard indices are not a partition of 0 .. n-1")
+    return [w for _, w in flat]

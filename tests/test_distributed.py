@@ -53,6 +53,13 @@ def _worker(rank, world, port, q):
     ch.observe(0)
     for r in roots:
         ch.observe(r)
+    # the proofs of all ranks as a set on rank 0, ordered by shard index (shards.gather_proofs)
+    words = [np.full(3 + s, s, dtype=np.uint32) for s in balanced[rank]]
+    got = shards.gather_proofs(words, balanced[rank], dst=0)
+    if rank == 0:
+        assert [int(w[0]) for w in got] == list(range(6)) and [len(w) for w in got] == [3 + s for s in range(6)]
+    else:
+        assert got is None
     q.put((rank, mine, roots, grand, ch.sample_ext()))
     dist.barrier()
     dist.destroy_process_group()
@@ -88,3 +95,20 @@ def test_single_process_paths_need_no_process_group():
     assert shards.exchange_roots([[2] * 8, [1] * 8], shard_indices=[1, 0]) == [[1] * 8, [2] * 8]
     assert shards.exchange_roots([[1] * 8, [2] * 8]) == [[1] * 8, [2] * 8]
     assert shards.reduce_cumulative_sums([(1, 2, 3, 4), (P - 1, P - 2, P - 3, P - 4)]) == (0, 0, 0, 0)
+
+
+def test_bench_refuses_to_run_fewer_ranks_than_asked():
+    """`python bench.py --gpus N` starts its own N ranks; with fewer than N visible GPUs (none here) it must say so and exit
+    non-zero instead of printing a one-rank line."""
+    import subprocess
+
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0
+    assert "refusing to run fewer ranks" in r.stderr and "{" not in r.stdout
+    # a launcher whose rank count disagrees with --gpus is an error too
+    env2 = dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env2,
+                       capture_output=True, text=True, timeout=300)
+    assert r.returncode != 0 and "must agree" in r.stderr

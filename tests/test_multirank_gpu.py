@@ -1,0 +1,142 @@
+"""The N > 1 path with real proofs: TWO processes share the one GPU of the test box (gloo carries the two tiny collectives --
+RCCL refuses two ranks on one device; on an 8-GPU node the same code runs over backend "nccl"), run `shards.RankStep` -- the
+body of bench.py's timed step -- on ONE fib-mix execution cut into 4 shards and dealt by work, send every rank's proofs to
+rank 0, and the oracle's machine verifier accepts the GATHERED set: per-rank sums non-zero, total zero, main roots observed in
+shard order whatever the assignment (/root/reference/src/lair/execute.rs:186-241, lair_chip.rs:104-139).
+Also: `python bench.py --gpus 2` on a box with one GPU must refuse loudly, and `--oversubscribe` must run both ranks."""
+import json
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+LOG_SHARD = 10  # 4 shards of 2^10 eval rows
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, q):
+    try:
+        sys.path.insert(0, ROOT)
+        sys.path.insert(0, os.path.join(ROOT, "tests"))
+        os.environ["MASTER_ADDR"] = "127.0.0.1"
+        os.environ["MASTER_PORT"] = str(port)
+        import torch.distributed as dist
+
+        dist.init_process_group("gloo", rank=rank, world_size=world)
+        import lurk_amd
+        from lurk_amd import lair, prover, shards
+        from lurk_amd.programs import lurk_mix as lm
+
+        mix = lm.fib_mix(4 << LOG_SHARD)
+        ctx = lurk_amd.Context(0)
+        top = lair.Toplevel(mix.source, lurk_chips=True)
+        qr = lair.QueryRecord(top)
+        top.execute_by_name(mix.entry, mix.main_args, qr)
+        pv = qr.expect_public_values()
+        m = prover.Machine(ctx, top, mix.entry, len(pv))
+        vk_root = m.setup()
+        all_shards = lair.Shard.new(qr).shard(lair.ShardingConfig(1 << LOG_SHARD))
+        assert len(all_shards) == 4
+        assignment = shards.assign_shards_balanced([m.shard_cost(sh) for sh in all_shards], world)
+        mine = assignment[rank]
+        prepared = [m.prepare_shard(all_shards[i]) for i in mine]
+        lane_ctx = prover.lane_context(m)
+        step = shards.RankStep(m, vk_root, pv, prepared, mine, num_queries=8, pow_bits=6, device="cpu", lane_ctx=lane_ctx)
+        words = step()
+        words2 = step()  # a second step gives the same proofs
+        same = all(len(a) == len(b) and bool((a == b).all()) for a, b in zip(words, words2))
+        gathered = shards.gather_proofs(words, mine, dst=0)
+        out = {"rank": rank, "mine": mine, "rank_sum": step.rank_sums[-1], "grand": step.grand_sums[-1], "same": same, "roots": step.roots}
+        if rank == 0:
+            from test_workloads_gpu import oracle_airs
+            from oracle import binding as ob
+            from oracle import stark as os_
+
+            proofs = [prover.parse_proof(w) for w in gathered]
+            out["n_gathered"] = len(proofs)
+            out["shard_sums"] = [prover.shard_sum(p) for p in proofs]
+            out["verified"] = bool(os_.verify_machine(oracle_airs(mix, len(pv)), vk_root, [16], [6], proofs, ob.merkle_verify))
+            # the set is order-sensitive: swapping two shards' proofs must break the transcript
+            swapped = [proofs[1], proofs[0]] + proofs[2:]
+            try:
+                os_.verify_machine(oracle_airs(mix, len(pv)), vk_root, [16], [6], swapped, ob.merkle_verify)
+                out["swapped_rejected"] = False
+            except os_.VerifyError:
+                out["swapped_rejected"] = True
+        q.put(out)
+        dist.barrier()
+        for pr in prepared:
+            del pr
+        lane_ctx.close()
+        m.close()
+        ctx.close()
+        dist.destroy_process_group()
+    except BaseException as e:  # surface the failure instead of a queue timeout
+        import traceback
+
+        q.put({"rank": rank, "error": traceback.format_exc()})
+        raise e
+
+
+def test_two_ranks_on_one_gpu_prove_one_execution_and_the_set_verifies():
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=900) for _ in range(world)]
+    for p in procs:
+        p.join(timeout=120)
+    for r in results:
+        assert "error" not in r, r.get("error")
+    results.sort(key=lambda r: r["rank"])
+    r0, r1 = results
+    assert sorted(r0["mine"] + r1["mine"]) == [0, 1, 2, 3] and len(r0["mine"]) == len(r1["mine"]) == 2
+    assert 0 in r0["mine"] or 0 in r1["mine"]
+    assert r0["roots"] == r1["roots"] and len(r0["roots"]) == 4       # same transcript prefix on both ranks
+    assert r0["rank_sum"] != (0, 0, 0, 0) and r1["rank_sum"] != (0, 0, 0, 0)  # only the total cancels
+    assert r0["grand"] == r1["grand"] == (0, 0, 0, 0)
+    assert r0["same"] and r1["same"]
+    assert r0["n_gathered"] == 4 and all(s != (0, 0, 0, 0) for s in r0["shard_sums"])
+    assert r0["verified"] and r0["swapped_rejected"]
+    for p in procs:
+        assert p.exitcode == 0
+
+
+def _bench(*extra, timeout=1500):
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "2", "--warmup", "1", "--log-rows", "12", "--no-cpu-baseline", "--queries", "8",
+           "--pow-bits", "6", "--no-compile"] + list(extra)
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    return subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=timeout)
+
+
+def test_bench_refuses_more_ranks_than_gpus_and_runs_them_oversubscribed():
+    import torch
+
+    n = torch.cuda.device_count()
+    r = _bench("--gpus", str(n + 1))
+    assert r.returncode != 0 and "refusing to run fewer ranks" in (r.stderr + r.stdout)
+    r = _bench("--gpus", "2", "--oversubscribe") if n < 2 else _bench("--gpus", "2")
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["ranks"] == 2 and line["config"]["shards"] == 4
+    cfg = line["config"]
+    assert cfg["grand_sum_is_zero"] and cfg["per_rank_sum_nonzero"] and cfg["proofs_identical_across_steps"]
+    gs = cfg["gathered_proof_set"]
+    assert gs["shards_gathered_on_rank0"] == 4 and gs["main_roots_match_exchanged_roots_in_shard_order"] and gs["grand_sum_of_gathered_proofs_is_zero"]
+    if n < 2:
+        assert line["n_gpus"] == n and "oversubscribed" in cfg["process_group"]
+    else:
+        assert cfg["rccl_world_size"] == 2
