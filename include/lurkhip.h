@@ -210,6 +210,11 @@ typedef struct lurkhip_protocol_profile {
  * observe_chip_meta), "whole-state-squeeze" (default + challenger_squeeze 16), "p3-monty-diffusion" (default with
  * diag = [-2, 1, 2, 4, ..., 2^13, 2^15] and scale 2^-32). */
 int32_t lurkhip_protocol_profile_preset(const char* name, lurkhip_protocol_profile* out);
+/* out[k] = Perm16(in[k]) for k < n, states of 16 words: the profile's width-16 Poseidon2 (Merkle compression, leaf sponge,
+ * transcript) on the device, one state per lane.  Replaces sphinx `inner_perm().permute` [UPSTREAM-RECALL]
+ * (call site: machine.config(), /root/reference/benches/fib.rs:114-120). */
+int32_t lurkhip_perm16(lurkhip_ctx* ctx, size_t n, const uint32_t* in, uint32_t* out, int32_t repr);
+int32_t lurkhip_perm16_dev(lurkhip_ctx* ctx, size_t n, const uint32_t* in, uint32_t* out, int32_t repr);
 /* Installs / reads the context's profile.  Set it before anything is committed or any challenger is created on the ctx. */
 int32_t lurkhip_set_protocol_profile(lurkhip_ctx* ctx, const lurkhip_protocol_profile* profile);
 int32_t lurkhip_get_protocol_profile(lurkhip_ctx* ctx, lurkhip_protocol_profile* out);
@@ -535,6 +540,12 @@ int32_t lurkhip_proof_free(lurkhip_proof* proof);
  * `chip_ordering`; depth = the last four public values as little-endian bytes (proofs.rs:115-124).  The inner sphinx / Plonky3
  * types are [UPSTREAM-RECALL] (field order in lurk_amd/csrc/wire.cpp); serialize_montgomery mirrors the profile field of that
  * name.  Returns the byte count (written only when capacity suffices), negative on malformed input. */
+/* One sphinx `ShardProof { commitment, opened_values, opening_proof, chip_ordering, public_values }` as bincode: the
+ * CryptoShardProof of the entry point below plus the trailing `public_values: Vec<Val>` it drops
+ * (/root/reference/src/core/cli/proofs.rs:61-74,94-101).  This is the byte string an upstream vector
+ * (`bincode::serialize(&proof.shard_proofs[0])`, tests/golden/upstream/README.md key "shard_proof") is compared with. */
+int64_t lurkhip_shard_proof_bincode(const uint32_t* words, uint64_t n_words, int32_t n_chip_names, const char* const* chip_names,
+                                    int32_t serialize_montgomery, uint8_t* out, uint64_t capacity);
 int64_t lurkhip_crypto_proof_bincode(int32_t n_shards, const uint32_t* const* shard_words, const uint64_t* shard_n_words, int32_t n_chip_names,
                                      const char* const* chip_names, const char* verifier_version, int32_t serialize_montgomery, uint8_t* out,
                                      uint64_t capacity);

@@ -78,6 +78,8 @@ SIGNATURES = {
     "lurkhip_profile_span_end": (_i32, [_p, C.c_char_p]),
     "lurkhip_profile_reset": (_i32, [_p]),
     "lurkhip_profile_read": (_i32, [_p, C.c_char_p, C.POINTER(C.c_double), C.POINTER(C.c_int64)]),
+    "lurkhip_perm16": (_i32, [_p, _sz, _p, _p, _i32]),
+    "lurkhip_perm16_dev": (_i32, [_p, _sz, _p, _p, _i32]),
     "lurkhip_pool_trim": (_i32, [_p]),
     "lurkhip_pool_stats": (_i32, [_p, _p]),
     "lurkhip_pool_reset_peak": (_i32, [_p]),
@@ -178,6 +180,7 @@ SIGNATURES = {
     "lurkhip_shard_prove": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_open": (_i32, [_p, _i32, _p, _p, _p, _p, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_proof_words": (_i64, [_p]),
+    "lurkhip_shard_proof_bincode": (_i64, [_p, C.c_uint64, _i32, _p, _i32, _p, C.c_uint64]),
     "lurkhip_crypto_proof_bincode": (_i64, [_i32, _p, _p, _i32, _p, C.c_char_p, _i32, _p, C.c_uint64]),
     "lurkhip_cached_proof_bincode": (_i64, [_p, C.c_uint64, _p, _p, _p, C.c_uint64, _p, _i32, _p, C.c_uint64]),
     "lurkhip_proof_read": (_i32, [_p, _u32p, C.c_uint64]),

@@ -103,6 +103,32 @@ __global__ __launch_bounds__(MBLOCK) void k_leaves(const P16Params* __restrict__
     dst[1] = make_uint4(s[4], s[5], s[6], s[7]);
 }
 
+// the permutation alone, one state per lane (lurkhip_perm16_dev)
+__global__ __launch_bounds__(MBLOCK) void k_perm16_states(const P16Params* __restrict__ p, const uint32_t* __restrict__ in,
+                                                           uint32_t* __restrict__ out, size_t n, bool canonical) {
+    const size_t i = (size_t)blockIdx.x * MBLOCK + threadIdx.x;
+    if (i >= n) return;
+    uint32_t s[16];
+    const uint4* src = reinterpret_cast<const uint4*>(in + i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) {
+        const uint4 v = src[k];
+        s[4 * k] = v.x, s[4 * k + 1] = v.y, s[4 * k + 2] = v.z, s[4 * k + 3] = v.w;
+    }
+    if (canonical) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) s[k] = bb::to_monty(s[k]);
+    }
+    perm16(s, p);
+    if (canonical) {
+#pragma unroll
+        for (int k = 0; k < 16; k++) s[k] = bb::from_monty(s[k]);
+    }
+    uint4* dst = reinterpret_cast<uint4*>(out + i * 16);
+#pragma unroll
+    for (int k = 0; k < 4; k++) dst[k] = make_uint4(s[4 * k], s[4 * k + 1], s[4 * k + 2], s[4 * k + 3]);
+}
+
 __device__ __forceinline__ void load_pair(const uint32_t* __restrict__ children, size_t i, uint32_t (&s)[16]) {
     const uint4* src = reinterpret_cast<const uint4*>(children + i * 16);
 #pragma unroll
@@ -581,6 +607,40 @@ int32_t lurkhip_get_protocol_profile(lurkhip_ctx* ctx, lurkhip_protocol_profile*
     LH_ARG(ctx, out != nullptr, "null argument");
     *out = profile_of(ctx);
     return LURKHIP_OK;
+}
+
+/* The profile's width-16 permutation itself, one state per lane: what the Merkle kernels, the sponge and the transcript run
+ * (an upstream `poseidon2_16` vector is checked against this, tests/test_profile_gpu.py). */
+int32_t lurkhip_perm16_dev(lurkhip_ctx* ctx, size_t n, const uint32_t* in, uint32_t* out, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, in && out, "null argument");
+    LH_ARG(ctx, repr == LURKHIP_REPR_CANONICAL || repr == LURKHIP_REPR_MONTY, "bad repr");
+    if (n == 0) return LURKHIP_OK;
+    const P16Params* params = nullptr;
+    LH_TRY(get_merkle_params(ctx, &params));
+    hipLaunchKernelGGL(k_perm16_states, dim3((unsigned)((n + MBLOCK - 1) / MBLOCK)), dim3(MBLOCK), 0, ctx->stream, params, in, out, n,
+                       repr == LURKHIP_REPR_CANONICAL);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_perm16(lurkhip_ctx* ctx, size_t n, const uint32_t* in, uint32_t* out, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, in && out, "null argument");
+    if (n == 0) return LURKHIP_OK;
+    void *din = nullptr, *dout = nullptr;
+    LH_TRY(pool_alloc(ctx, n * 64, &din));
+    LH_TRY(pool_alloc(ctx, n * 64, &dout));
+    LH_HIP(ctx, hipMemcpyAsync(din, in, n * 64, hipMemcpyHostToDevice, ctx->stream));
+    int32_t st = lurkhip_perm16_dev(ctx, n, (const uint32_t*)din, (uint32_t*)dout, repr);
+    if (st == LURKHIP_OK) {
+        hipError_t e = hipMemcpyAsync(out, dout, n * 64, hipMemcpyDeviceToHost, ctx->stream);
+        if (e == hipSuccess) e = hipStreamSynchronize(ctx->stream);
+        if (e != hipSuccess) st = set_error(ctx, LURKHIP_ERR_HIP, "lurkhip_perm16: %s", hipGetErrorString(e));
+    }
+    pool_release(ctx, din);
+    pool_release(ctx, dout);
+    return st;
 }
 
 /* older entry point: only the permutation tables (internal scale 1); kept for callers of ABI 1 */

@@ -149,14 +149,22 @@ __device__ __forceinline__ void internal_rounds_lazy(uint32_t (&s)[W], int round
             x[0] = bb::smul(y6, y);
         }
         int64_t v = 0;
+        if (sum_mult_c == 1) {
+            // Montgomery-shift diffusion layer (scale 2^-32: the multiplier of the lane sum is the integer 1 and the diagonal
+            // entries are small integers, powers of two in p3's DiffusionMatrixBabyBear): V is the plain 64-bit sum of the lanes,
+            // |V| < W * 1.06 p -- no products by R, no group reductions (uniform branch)
 #pragma unroll
-        for (int g = 0; g < W; g += 8) {
-            int64_t u = 0;
+            for (int j = 0; j < W; j++) v = bb::mad_i64(x[j], 1, v);
+        } else {
 #pragma unroll
-            for (int j = g; j < g + 8 && j < W; j++) u = bb::mad_i64(x[j], (int32_t)bb::R1, u);
-            v = bb::mad_i64(bb::sred(u), (int32_t)bb::R1, v);
+            for (int g = 0; g < W; g += 8) {
+                int64_t u = 0;
+#pragma unroll
+                for (int j = g; j < g + 8 && j < W; j++) u = bb::mad_i64(x[j], (int32_t)bb::R1, u);
+                v = bb::mad_i64(bb::sred(u), (int32_t)bb::R1, v);
+            }
+            if (sum_mult_c != (int32_t)bb::R1) v = bb::mad_i64(bb::sred(v), sum_mult_c, 0);  // |sred(v)| < 0.7 p, |v| < 0.35 p^2
         }
-        if (sum_mult_c != (int32_t)bb::R1) v = bb::mad_i64(bb::sred(v), sum_mult_c, 0);  // |sred(v)| < 0.7 p, |v| < 0.35 p^2
 #pragma unroll
         for (int i = 0; i < W; i++) x[i] = bb::sred(bb::mad_i64_u(x[i], diag_c[i], v));
     }

@@ -263,6 +263,24 @@ int64_t lurkhip_crypto_proof_bincode(int32_t n_shards, const uint32_t* const* sh
     }
 }
 
+int64_t lurkhip_shard_proof_bincode(const uint32_t* words, uint64_t n_words, int32_t n_chip_names, const char* const* chip_names,
+                                    int32_t serialize_montgomery, uint8_t* out, uint64_t capacity) {
+    if (!words || n_chip_names < 1 || !chip_names) return LURKHIP_ERR_INVALID_ARG;
+    try {
+        Out o;
+        o.monty = serialize_montgomery != 0;
+        shard_proof(o, words, n_words, n_chip_names, chip_names);
+        // sphinx's ShardProof ends with `public_values: Vec<Val>` (the field CryptoShardProof drops, proofs.rs:61-74)
+        const uint32_t n_chips = words[1], n_public = words[5];
+        const uint32_t* pv = words + 10 + 11 * (uint64_t)n_chips;
+        o.u64(n_public);
+        o.fs(pv, n_public);
+        return finish(o, out, capacity);
+    } catch (const std::exception&) {
+        return LURKHIP_ERR_INVALID_ARG;
+    }
+}
+
 int64_t lurkhip_cached_proof_bincode(const uint8_t* crypto_proof, uint64_t crypto_len, const uint32_t* expr, const uint32_t* env,
                                      const uint32_t* result, uint64_t n_dag_entries, const uint32_t* dag_entries, int32_t serialize_montgomery,
                                      uint8_t* out, uint64_t capacity) {

@@ -56,6 +56,19 @@ class CryptoProof:
         return bytes(buf)
 
 
+def shard_proof_bincode(words, chip_names, serialize_montgomery: bool = False) -> bytes:
+    """`bincode::serialize(&ShardProof)` of one shard proof (sphinx's struct, public values included) from its flat words."""
+    w = np.ascontiguousarray(words, dtype=np.uint32)
+    names = (C.c_char_p * len(chip_names))(*[s.encode() for s in chip_names])
+    args = (w.ctypes.data_as(C.c_void_p), w.size, len(chip_names), C.cast(names, C.c_void_p), int(serialize_montgomery))
+    size = N.lib.lurkhip_shard_proof_bincode(*args, None, 0)
+    if size < 0:
+        raise ValueError(f"malformed proof words (status {size})")
+    buf = (C.c_uint8 * size)()
+    assert N.lib.lurkhip_shard_proof_bincode(*args, C.cast(buf, C.c_void_p), size) == size
+    return bytes(buf)
+
+
 class CachedProof:
     """crypto_proof + the Lurk data of its public values, fully specified (proofs.rs:137-169)."""
 

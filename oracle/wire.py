@@ -164,6 +164,17 @@ def decode_shard(r: Reader, chip_names, public_values, log_blowup, pow_bits) -> 
                  pow_witness, rounds, layers, k)
 
 
+def decode_shard_proof(data: bytes, chip_names, log_blowup=1, pow_bits=16, montgomery=False) -> Shard:
+    """One sphinx `ShardProof` (bincode): the CryptoShardProof fields followed by `public_values: Vec<Val>`
+    (/root/reference/src/core/cli/proofs.rs:61-74,94-101 show the two structs side by side)."""
+    r = Reader(data, montgomery)
+    s = decode_shard(r, chip_names, [], log_blowup, pow_bits)
+    s.public_values = r.vec(r.f)
+    if r.pos != len(data):
+        raise ValueError("trailing bytes after the ShardProof")
+    return s
+
+
 def decode_crypto_proof(data: bytes, chip_names, public_values_of_depth, log_blowup=1, pow_bits=16, montgomery=False, reader=None):
     """-> (shards, verifier_version, depth).  `public_values_of_depth(depth)` rebuilds the public values the way
     CryptoProof::into_machine_proof does (proofs.rs:44-79); they are not in the bytes."""

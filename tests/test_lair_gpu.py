@@ -150,6 +150,28 @@ def _compare_all_funcs(ctx, oracle, src, calls, lurk_chips=False, shard_sizes=(1
     return top, q, oq
 
 
+@pytest.mark.parametrize("workload,rows,shard", [("fib-mix", 40, 16), ("lurk-mix", 60, 32)])
+def test_mix_machines_vs_oracle_interpreter_and_compiled(ctx, oracle, workload, rows, shard):
+    """The bench machines themselves: every function of fib_mix(40) / lurk_mix(60) -- all 39 Lurk
+    widths, partial functions with depth columns, u64 / hasher extern chips -- GPU trace == the oracle's independent trace
+    generator, unsharded and sharded, first on the row interpreter, then on the compiled row kernels."""
+    from lurk_amd.programs import lurk_mix as lm
+
+    mix = lm.fib_mix(rows) if workload == "fib-mix" else lm.lurk_mix(rows)
+    top, q, oq = _compare_all_funcs(ctx, oracle, mix.source, [[mix.entry, list(mix.main_args)]], lurk_chips=True, shard_sizes=(1 << 22, shard))
+    poseidon, witness = oracle_chip_callbacks(oracle)
+    otop = ol.Toplevel(mix.source, chips=ol.lurk_chips())
+    assert q.num_func_queries(top.func_index("eval")) == rows
+    for size in (1 << 22, shard):
+        for sh in lair.Shard.new(q).shard(lair.ShardingConfig(size)):
+            for i, f in enumerate(otop.funcs):
+                chip = lair.FuncChip(ctx, i, top)
+                chip.compile_trace()
+                rows_, width = ol.generate_trace(otop, f["name"], oq, sh.index, size, witness=witness)
+                got = chip.generate_trace(sh)
+                assert got.shape == (len(rows_), width) and got.tolist() == rows_, (f["name"], sh.index, size, "compiled")
+
+
 def test_demo_functions_vs_oracle_with_sharding(ctx, oracle):
     demo = load_cases()[0]["source"]
     # shard size 4 is what the reference's own tests use (src/core/tests/mod.rs:59-63)

@@ -98,3 +98,51 @@ def test_config4_one_execution_2p22_rows_in_8_shards(ctx):
     assert prover.grand_sum(proofs) == (0, 0, 0, 0)
     assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
     m.close()
+
+
+def test_bench_workload_fib_mix_2p20_one_shard_verifies(ctx):
+    """bench.py's default step exactly: fib-mix, ONE shard of 2^20 eval rows, chips of 2^17 rows and
+    more on compiled AIR / trace kernels, 100 queries, 16 PoW bits; the oracle's verifier accepts the proof."""
+    mix = lm.fib_mix(1 << 20)
+    m, top, q, root, proofs, pv = run(ctx, mix, num_queries=100, pow_bits=16, compile_min_log_rows=17)
+    assert len(proofs) == 1
+    ev = [c for c in proofs[0].chips if m.chips[c.machine_index][:2] == ("func", top.func_index("eval"))]
+    assert len(ev) == 1 and ev[0].log_n == 20 and ev[0].width == 78
+    assert sum(c.width << c.log_n for c in proofs[0].chips) / (1 << 20) > 280  # the bench's 285 main columns per eval row
+    assert prover.grand_sum(proofs) == (0, 0, 0, 0)
+    assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
+    m.close()
+
+
+def test_config5_lurk_mix_2p18_verifies(ctx):
+    """BASELINE.json configs[4] at the bench height (`bench.py --workload lurk-mix`: 2^18 eval rows, all 39 functions, widths
+    9 ... 815): full FRI parameters, compiled chips, oracle-verified."""
+    mix = lm.lurk_mix(1 << 18)
+    m, top, q, root, proofs, pv = run(ctx, mix, num_queries=100, pow_bits=16, compile_min_log_rows=17)
+    assert len(proofs) == 1 and len(proofs[0].chips) >= top.num_funcs() + 2
+    assert prover.grand_sum(proofs) == (0, 0, 0, 0)
+    assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
+    m.close()
+
+
+def test_reference_default_shard_2p22_rows_one_shard(ctx):
+    """The reference's default SHARD_SIZE (/root/reference/src/lair/execute.rs:231-241: 1 << 22): ONE fib-mix shard of 2^22 eval
+    rows on one GPU -- LDE height 2^23, matrices past 4 GiB (64-bit offsets without monkeypatching) -- oracle-verified; the
+    allocator's high-water mark is the shard's HBM footprint."""
+    mix = lm.fib_mix(1 << 22)
+    ctx.pool_trim()
+    ctx.pool_reset_peak()
+    m, top, q, root, proofs, pv = run(ctx, mix, num_queries=100, pow_bits=16, compile_min_log_rows=17)
+    assert len(proofs) == 1
+    ev = [c for c in proofs[0].chips if m.chips[c.machine_index][:2] == ("func", top.func_index("eval"))]
+    assert len(ev) == 1 and ev[0].log_n == 22
+    assert proofs[0].log_max_height >= 23
+    peak = ctx.pool_stats()["peak_bytes"]
+    main_bytes = sum(4 * (c.width << c.log_n) for c in proofs[0].chips)
+    assert main_bytes > 4 << 30                      # the main traces alone exceed 4 GiB
+    assert 2 * main_bytes < peak < 200 << 30, peak   # traces + LDEs + permutation / quotient rounds resident, inside one MI355X
+    print(f"2^22-row shard: main traces {main_bytes / 2**30:.1f} GiB, pool high-water mark {peak / 2**30:.1f} GiB")
+    assert prover.grand_sum(proofs) == (0, 0, 0, 0)
+    assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
+    m.close()
+    ctx.pool_trim()
