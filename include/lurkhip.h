@@ -231,6 +231,11 @@ int32_t lurkhip_coset_lde_dev(lurkhip_ctx* ctx, int32_t log_n, int32_t width, in
  * 8-lane Merkle root and a handle that keeps the LDE matrices and every tree level on the device for
  * later openings.  `mats` is a host array of host (lurkhip_commit) or device (lurkhip_commit_dev)
  * pointers.  keep_coeffs != 0 also keeps the interpolated coefficient matrices. */
+/* The MMCS alone: the Merkle commitment of host matrices AS GIVEN (no interpolation, no coset extension) -- p3
+ * FieldMerkleTreeMmcs::commit [UPSTREAM-RECALL]; the handle opens like any other commitment.  (An upstream `mmcs_commit`
+ * vector is checked against this.) */
+int32_t lurkhip_mmcs_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, const uint32_t* log_heights, const uint32_t* widths,
+                            int32_t repr, lurkhip_commitment** out, uint32_t* root);
 int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, const uint32_t* log_heights,
                        const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t keep_coeffs,
                        lurkhip_commitment** out, uint32_t* root);

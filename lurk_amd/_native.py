@@ -100,6 +100,7 @@ SIGNATURES = {
     "lurkhip_get_protocol_profile": (_i32, [_p, _p]),
     "lurkhip_coset_lde": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
     "lurkhip_coset_lde_dev": (_i32, [_p, _i32, _i32, _i32, _u32p, _u32p, _i32]),
+    "lurkhip_mmcs_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commit_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commit_cosets_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _u32p, _i32, _i32, C.POINTER(_p), _u32p]),

@@ -94,6 +94,21 @@ def commit(ctx: Context, mats, log_blowup: int = 1, repr: int = N.REPR_CANONICAL
     return _commit(ctx, N.lib.lurkhip_commit, mats, lh, [m.shape[1] for m in mats], log_blowup, repr, keep_coeffs)
 
 
+def mmcs_commit(ctx: Context, mats, repr: int = N.REPR_CANONICAL) -> Commitment:
+    """The Merkle commitment of host matrices as given (no LDE): p3 FieldMerkleTreeMmcs::commit."""
+    mats = [as_u32(m) for m in mats]
+    lh = [m.shape[0].bit_length() - 1 for m in mats]
+    if any(m.ndim != 2 or m.shape[0] != 1 << k for m, k in zip(mats, lh)):
+        raise ValueError("every matrix must be [2^k, w]")
+    n = len(mats)
+    ptrs = (C.c_void_p * n)(*[_addr(m) for m in mats])
+    lha, ws = np.asarray(lh, dtype=np.uint32), np.asarray([m.shape[1] for m in mats], dtype=np.uint32)
+    handle = C.c_void_p()
+    root = np.empty(8, dtype=np.uint32)
+    ctx.check(N.lib.lurkhip_mmcs_commit(ctx.handle, n, C.cast(ptrs, C.c_void_p), _addr(lha), _addr(ws), repr, C.byref(handle), _addr(root)))
+    return Commitment(ctx, handle, root, lh, [int(x) for x in ws], 0)
+
+
 def commit_dev(ctx: Context, mats, log_heights, widths, log_blowup: int = 1, repr: int = N.REPR_CANONICAL, keep_coeffs: bool = False) -> Commitment:
     """mats: list of device buffers (torch tensors or raw pointers)."""
     return _commit(ctx, N.lib.lurkhip_commit_dev, mats, log_heights, widths, log_blowup, repr, keep_coeffs)

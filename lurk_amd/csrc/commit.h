@@ -127,7 +127,8 @@ const lurkhip_protocol_profile& profile_of(lurkhip_ctx* ctx);
 // ---- commit pipeline entry points shared with the prover (commit.hip)
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
-                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr);
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr,
+                    bool raw = false /* the matrices as given: no interpolation, no coset extension (lurkhip_mmcs_commit) */);
 int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const std::vector<int>& log_heights,
                    const std::vector<uint32_t>& widths, lurkhip_commitment** out);
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m);

@@ -420,9 +420,15 @@ int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_
     return LURKHIP_OK;
 }
 
+// the matrix as given, Montgomery form (lurkhip_mmcs_commit: no LDE)
+__global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restrict__ out, size_t n, bool to_monty) {
+    for (size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (size_t)gridDim.x * blockDim.x)
+        out[i] = to_monty ? bb::to_monty(in[i]) : in[i];
+}
+
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
-                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts) {
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
     LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
@@ -505,7 +511,19 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         const size_t n = (size_t)1 << log_n;
         const size_t bytes = n * w * sizeof(uint32_t);
         uint32_t* coef = c->coeffs[i];
-        if (!extended[i]) {
+        if (raw) {  // FieldMerkleTreeMmcs::commit on the matrices as they are
+            const uint32_t* src = mats[i];
+            if (mats_on_host) {
+                void* staged = nullptr;
+                TRY_C(arena_get(ctx, 0, bytes, &staged));
+                HIP_C(hipMemcpyAsync(staged, mats[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+                src = (const uint32_t*)staged;
+            }
+            const size_t words = n * (size_t)w;
+            hipLaunchKernelGGL(k_copy_words, dim3((unsigned)std::min<size_t>((words + 255) / 256, 65535)), dim3(256), 0, ctx->stream, src, c->lde[i],
+                               words, repr == LURKHIP_REPR_CANONICAL);
+            HIP_C(hipGetLastError());
+        } else if (!extended[i]) {
             const uint32_t* src = mats[i];
             void* staged = nullptr;
             if (mats_on_host) {
@@ -598,6 +616,11 @@ int32_t lurkhip_commit_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* con
                            const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t keep_coeffs,
                            lurkhip_commitment** out, uint32_t* root) {
     return commit_impl(ctx, n_mats, mats_dev, false, log_heights, widths, log_blowup, repr, keep_coeffs, out, root);
+}
+
+int32_t lurkhip_mmcs_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, const uint32_t* log_heights, const uint32_t* widths,
+                            int32_t repr, lurkhip_commitment** out, uint32_t* root) {
+    return commit_impl(ctx, n_mats, mats, true, log_heights, widths, 0, repr, 0, out, root, nullptr, /*raw=*/true);
 }
 
 int32_t lurkhip_commit_cosets_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev, const uint32_t* log_heights,

@@ -94,6 +94,20 @@ def test_upstream_loader_mechanics(oracle, tmp_path, monkeypatch):
         doc["coset_lde"] = [{"log_n": 3, "width": 3, "values": m.reshape(-1).tolist(), "log_blowup": 1, "lde_bit_reversed": lde.reshape(-1).tolist()}]
         doc["pcs_commit"] = [{"matrices": [{"log_height": 3, "width": 3, "values": m.reshape(-1).tolist()}], "log_blowup": 1, "root": root.tolist()}]
         doc["mmcs_commit"] = [{"matrices": [{"log_height": 4, "width": 3, "values": lde.reshape(-1).tolist()}], "root": root.tolist()}]
+        # the permutation_trace key, from the oracle's own generator on the reference's demo fib
+        from lair_helpers import load_cases
+        from oracle import air as oa
+        from oracle import lair as ol
+
+        demo = load_cases()[0]["source"]
+        otop = ol.Toplevel(demo)
+        oq = ol.QueryRecord(otop)
+        ol.execute(otop, "fib", [7], oq)
+        rows, _ = ol.generate_trace(otop, "fib", oq)
+        alpha, beta = (1, 2, 3, 4), (9, 8, 7, 6)
+        pt = os_.permutation_trace(oa.FuncAir(otop, "fib"), rows, None, alpha, beta, 2, public=oq.public_values)
+        doc["permutation_trace"] = [{"program": demo, "entry": "fib", "args": [7], "chip": "fib", "challenges": list(alpha + beta),
+                                     "trace": [x for r in pt for c in r for x in c], "cumulative_sum": list(pt[-1][-1])}]
     finally:
         os_.Profile().install()
     (tmp_path / "selfcheck.json").write_text(json.dumps(doc))
@@ -108,6 +122,9 @@ def test_upstream_loader_mechanics(oracle, tmp_path, monkeypatch):
             d["mmcs_commit"][0]["root"][0] ^= 1
             with pytest.raises(AssertionError):
                 tv.test_mmcs_commit((d, pr))
+            d["permutation_trace"][0]["trace"][5] ^= 1
+            with pytest.raises(AssertionError):
+                tv.test_permutation_trace((d, pr))
         finally:
             os_.Profile().install()
 

@@ -140,15 +140,23 @@ def test_unsupported_profiles_are_refused(ctx):
 
 
 # ---------------------------------------------------------------- upstream vectors, GPU side
-DOCS = uh.load_all()
+DOCS = uh.load_all() + uh.load_all(uh.SELFCHECK_DIR)
 
 
-@pytest.mark.skipif(not DOCS, reason="no upstream vectors in tests/golden/upstream/ (S1 parity unpinned)")
+@pytest.mark.skipif(not DOCS, reason="no vectors in tests/golden/upstream/ or tests/golden/selfcheck/")
 @pytest.mark.parametrize("name,doc", DOCS or [("none", {})], ids=[n for n, _ in DOCS] or ["none"])
 def test_upstream_vectors_on_the_gpu(name, doc):
+    """Every vector file -- real upstream dumps (tests/golden/upstream/, none yet: S1 parity unpinned) and the repository's own
+    schema self-check file (tests/golden/selfcheck/, made by the HIP prover: exercises every key of the schema, pins nothing
+    upstream) -- through the C ABI on the GPU."""
     lib = ProtocolProfile.from_dict(uh.profile_dict(doc), base=uh.preset_of(doc))
     with lurk_amd.Context(0) as ctx:
         lib.install(ctx)
+        for v in doc.get("poseidon2_16", []):  # the profile's permutation on the device (lurkhip_perm16)
+            x = np.array([v["input"]], dtype=np.uint32)
+            out = np.zeros_like(x)
+            ctx.check(lurk_amd._native.lib.lurkhip_perm16(ctx.handle, 1, x.ctypes.data, out.ctypes.data, 0))
+            assert out[0].tolist() == [int(t) for t in v["output"]]
         for v in doc.get("challenger", []):
             ch, got = prover.Challenger(ctx), []
             for op, arg in v["ops"]:
@@ -165,6 +173,46 @@ def test_upstream_vectors_on_the_gpu(name, doc):
         for key, blow in (("pcs_commit", None), ("mmcs_commit", 0)):
             for v in doc.get(key, []):
                 mats = [np.array(m["values"], dtype=np.uint32).reshape(1 << m["log_height"], m["width"]) for m in v["matrices"]]
-                c = lcommit.commit(ctx, mats, log_blowup=v["log_blowup"] if blow is None else blow)
+                c = lcommit.commit(ctx, mats, log_blowup=v["log_blowup"]) if blow is None else lcommit.mmcs_commit(ctx, mats)
                 assert [int(x) for x in c.root] == [int(x) for x in v["root"]]
                 c.close()
+        _gpu_permutation_trace_and_shard_proof(ctx, doc)
+
+
+def _gpu_permutation_trace_and_shard_proof(ctx, doc):
+    """GPU side of the `permutation_trace` and `shard_proof` keys: the device permutation trace of the chip equals the vector,
+    and the HIP prover's ShardProof bincode equals the vector's bytes."""
+    import torch
+
+    from lurk_amd import air, field, proofs
+    from lurk_amd import _native as N
+
+    for v in doc.get("permutation_trace", []):
+        top = lair.Toplevel(v["program"], lurk_chips=v.get("lurk_chips", False))
+        q = lair.QueryRecord(top)
+        top.execute_by_name(v["entry"], list(v["args"]), q)
+        i = top.func_index(v["chip"])
+        a = air.ChipAir.for_func(top, i)
+        t_host = lair.FuncChip(ctx, i, top).generate_trace(lair.Shard.new(q), repr=N.REPR_MONTY)
+        h = t_host.shape[0]
+        t = torch.from_numpy(np.ascontiguousarray(t_host).view(np.int32)).cuda()
+        out = torch.zeros((h, 4 * a.permutation_width), dtype=torch.int32, device="cuda")
+        cs = a.permutation_trace(ctx, h, t, None, [int(x) for x in v["challenges"]], out)
+        got = field.from_monty(out.cpu().numpy().view(np.uint32)).reshape(-1)
+        assert got.tolist() == [int(x) for x in v["trace"]]
+        assert [int(x) for x in cs] == [int(x) for x in v["cumulative_sum"]]
+    for v in doc.get("shard_proof", []):
+        top = lair.Toplevel(v["program"], lurk_chips=v.get("lurk_chips", False))
+        q = lair.QueryRecord(top)
+        top.execute_by_name(v["entry"], list(v["args"]), q)
+        pv = q.expect_public_values()
+        m = prover.Machine(ctx, top, v["entry"], len(pv))
+        root = m.setup()
+        if "vk_root" in v:
+            assert [int(x) for x in root] == [int(x) for x in v["vk_root"]]
+        (p,) = m.prove(q, num_queries=v["num_queries"], pow_bits=v["pow_bits"])
+        names = [ch_air.name for _, _, ch_air in m.chips]
+        prof = ProtocolProfile.of(ctx).to_dict()
+        got = proofs.shard_proof_bincode(p.words, names, serialize_montgomery=bool(prof["serialize_montgomery"]))
+        assert got.hex() == v["bincode_hex"]
+        m.close()

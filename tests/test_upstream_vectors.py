@@ -1,5 +1,7 @@
 """Pins for S1 from the real crates: loads every tests/golden/upstream/*.json (README.md there) and checks the ORACLE against
-it.  Skipped while the directory holds no vectors (parity of S1 is then "unpinned")."""
+it.  While that directory holds no vectors parity of S1 is "unpinned"; the repository's own file in the same schema
+(tests/golden/selfcheck/, made by make_selfcheck_vectors.py from the oracle and the HIP prover) keeps every checker below
+running -- it pins nothing upstream."""
 import numpy as np
 import pytest
 
@@ -7,8 +9,15 @@ import upstream_helpers as uh
 from oracle import binding as ob
 from oracle import stark as os_
 
-DOCS = uh.load_all()
-pytestmark = pytest.mark.skipif(not DOCS, reason="no upstream vectors in tests/golden/upstream/ (S1 parity unpinned)")
+UPSTREAM_DOCS = uh.load_all()
+DOCS = UPSTREAM_DOCS + uh.load_all(uh.SELFCHECK_DIR)
+pytestmark = pytest.mark.skipif(not DOCS, reason="no vectors in tests/golden/upstream/ or tests/golden/selfcheck/")
+
+
+def test_upstream_pins_present_or_declared_absent():
+    """Bookkeeping, not parity: with no real upstream file the S1 rows stay "parity unpinned" (DESIGN.md 5)."""
+    for name, d in UPSTREAM_DOCS:
+        assert "self-check" not in d.get("source", ""), f"{name}: self-made vectors belong in tests/golden/selfcheck/"
 
 
 def oracle_profile_of(d):
@@ -92,3 +101,39 @@ def test_pcs_commit(doc):
     for v in d.get("pcs_commit", []):
         root, _ = ob.merkle_commit([ob.lde(m, v["log_blowup"]) for m in _mats(v)])
         assert [int(x) for x in root] == [int(x) for x in v["root"]]
+
+
+@check
+def test_permutation_trace(doc):
+    """sphinx generate_permutation_trace of one chip under given challenges: the extension-field matrix (flattened to base,
+    row-major) and its cumulative sum."""
+    from oracle import air as oa
+    from oracle import lair as ol
+
+    d, _ = doc
+    for v in d.get("permutation_trace", []):
+        otop, oq = uh.oracle_machine(v["program"], v["entry"], v["args"], v.get("lurk_chips", False))
+        rows, width = ol.generate_trace(otop, v["chip"], oq)
+        air = oa.FuncAir(otop, v["chip"])
+        alpha, beta = tuple(int(x) for x in v["challenges"][:4]), tuple(int(x) for x in v["challenges"][4:8])
+        want = os_.permutation_trace(air, rows, None, alpha, beta, v.get("batch_size", 2), public=oq.public_values)  # batch = 1 << log_quotient_degree
+        assert [x for r in want for c in r for x in c] == [int(x) for x in v["trace"]]
+        assert list(want[-1][-1]) == [int(x) for x in v["cumulative_sum"]]
+
+
+@check
+def test_shard_proof(doc):
+    """`bincode::serialize(&ShardProof)`: decoded by the oracle's reader (oracle/wire.py) and ACCEPTED by the oracle's verifier
+    under the file's profile -- the verifier side of "same transcript, same proof bytes"."""
+    from oracle import wire as ow
+
+    d, prof = doc
+    for v in d.get("shard_proof", []):
+        otop, oq = uh.oracle_machine(v["program"], v["entry"], v["args"], v.get("lurk_chips", False))
+        airs, names = uh.oracle_airs_and_names(otop, v["entry"], len(oq.public_values))
+        shard = ow.decode_shard_proof(bytes.fromhex(v["bincode_hex"]), names, log_blowup=prof.fri_log_blowup, pow_bits=v["pow_bits"],
+                                      montgomery=bool(prof.serialize_montgomery))
+        assert shard.num_queries == v["num_queries"]
+        assert shard.public_values == [int(x) for x in oq.public_values]
+        vk_root = [int(x) for x in v["vk_root"]] if "vk_root" in v else uh.oracle_vk_root()
+        assert os_.verify_machine(airs, vk_root, [16], [6], [shard], ob.merkle_verify, profile=prof)
