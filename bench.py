@@ -60,35 +60,73 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
     return t
 
 
-def cpu_baseline(round_shapes, eval_rows: int):
-    """The CPU port (oracle/cpu_port.c: Montgomery row-major NTTs with a vectorised inner loop along the row, Montgomery
-    Poseidon2-16 Merkle tree, OpenMP; checked word for word against the oracle's checker by tests/test_cpu_port.py) of the
-    step's three commitment rounds -- main traces, LogUp permutation traces, quotient chunks -- on synthetic matrices of exactly
-    the shapes the GPU step commits (the CPU time of an LDE + Merkle commit does not depend on the values).  Trace generation,
-    the permutation / quotient arithmetic, openings and FRI have no compiled CPU port (the oracle does them in Python), so the CPU
-    figure is an upper bound on what the port would reach on the full step; the commits are about three quarters of the GPU step.
-    kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be built here."""
+CPU_SAMPLE_LOG_SHRINK = 2  # the CPU port proves a shard of 2^(log_rows - 2) eval rows: about 10-30 s of CPU work on the box's 16-core quota
+
+
+def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bits: int):
+    """The CPU PORT of the WHOLE step (oracle/cpu_prover.py: the oracle's transcript driving oracle/cpu_step.c -- coset LDEs and
+    Poseidon2-16 Merkle trees of the three commitment rounds, LogUp permutation traces + running sums, quotient values from C
+    evaluators generated out of the oracle's AIR, opened values, reduced openings, the FRI commit phase, proof-of-work, query
+    openings; OpenMP, Montgomery arithmetic), every stage checked word for word against oracle/stark.py and the whole proof
+    accepted by the oracle's verifier and equal to the HIP prover's (tests/test_cpu_step*.py).  Timed on a BOUNDED SAMPLE: the
+    same machine with every chip of 2^12 rows and more a quarter as tall (2^(log_rows - 2) eval rows), on synthetic traces of
+    those shapes (no stage's cost depends on the values; the constraints need not hold for the openings and FRI to be
+    well-formed).  `value` = sample eval rows / seconds.  Trace generation is not in the port (it needs the interpreter's query
+    record; 2 % of the GPU step) and is reported as null.  kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be
+    built here; a tuned CPU prover (packed AVX-512 field, cache-blocked NTTs) would be several times faster per core."""
+    from oracle import air as oa
     from oracle import binding as ob
+    from oracle import cpu_prover as cpv
+    from oracle import lair as ol
+    from oracle import stark as os_
+    from lurk_amd.programs import lurk_mix as lm
 
     ob.build()
-    cores = ob.usable_cores()  # affinity mask capped by the cgroup CPU quota: the OpenMP team gets exactly that many threads
-    ob.cpu_port_set_threads(cores)
-    dt, cols = 0.0, 0
-    for k, shapes in enumerate(round_shapes):
-        mats = [synthetic_trace(lg, w, 100 * k + i) % 2013265921 for i, (lg, w) in enumerate(shapes)]
-        cols += sum(w << lg for lg, w in shapes)
-        t0 = time.perf_counter()
-        ob.cpu_port_commit_round(mats, LOG_BLOWUP)
-        dt += time.perf_counter() - t0
-        del mats
+    cores = ob.usable_cores()
+    mix = lm.fib_mix(64) if workload == "fib-mix" else lm.lurk_mix(64)
+    otop = ol.Toplevel(mix.source, chips=ol.lurk_chips())
+    n_public = 44
+    idx = otop.index[mix.entry]
+    airs = [oa.EntrypointAir(idx, n_public)] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs] + [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
+    names = [f"Entrypoint[{idx}]"] + [f"Func[{f['name']}]" for f in otop.funcs] + [f"Mem[{ml}-wide]" for ml in ol.MEM_TABLE_SIZES] + ["CPU"]
+    pr = cpv.CpuProver(airs, names, n_public, threads=cores)
+    rng = np.random.default_rng(0x4C55524B)
+    traces, sample_rows = [], None
+    for name, lg, w in chip_shapes:
+        mi = names.index(name)
+        assert airs[mi].width == w, (name, airs[mi].width, w)
+        lgs = lg - CPU_SAMPLE_LOG_SHRINK if lg >= 12 and name != "CPU" else lg
+        traces.append((mi, rng.integers(0, 2013265921, size=(1 << lgs, w), dtype=np.uint32)))
+        if name == "Func[eval]":
+            sample_rows = 1 << lgs
+    i = np.arange(1 << 16)
+    i1, i2 = i & 0xFF, i >> 8
+    prep_m, pc = pr.setup({len(airs) - 1: np.stack([i1, i2, (i1 < i2).astype(int), i1 & i2, i1 ^ i2, i1 | i2], axis=1).astype(np.uint32)})
+    ch = os_.Challenger(os_.default_permute16())
+    ch.observe(pc["root"])
+    ch.observe(0)
+    stages = {}
+    t0 = time.perf_counter()
+    pr.prove_shard(traces, prep_m, pc, [0] * n_public, ch, num_queries=queries, pow_bits=pow_bits, timings=stages)
+    dt = time.perf_counter() - t0
+    gpu_names = {"commit_main": "commit_main", "permutation": "permutation", "commit_perm": "commit_perm", "quotient_all": "quotient_all",
+                 "commit_quotient": "commit_quotient", "open": "open", "fri_commit": "fri_commit", "pow": "fri_query", "fri_query": "fri_query"}
+    stages_s = {"trace_all": None}
+    for k, v in stages.items():
+        g = gpu_names.get(k, k)
+        stages_s[g] = stages_s.get(g, 0.0) + v
     return {
-        "value": eval_rows / dt,
+        "value": sample_rows / dt,
         "unit": "eval-steps/s",
         "cores": cores,
         "kind": "port",
-        "sample": f"the three commitment rounds of one step (coset LDE x2 + Poseidon2-16 Merkle over {cols / eval_rows:.0f} columns per eval row: main, permutation, quotient), "
-                  f"oracle/cpu_port.c (Montgomery, row-major vectorised NTTs), OpenMP over {cores} threads, {dt:.2f} s; the GPU step also does trace generation, the permutation / quotient arithmetic, openings and FRI; "
+        "seconds": dt,
+        "stages_s": stages_s,
+        "sample": f"the WHOLE step except trace generation (main / permutation / quotient commitments, LogUp rows, quotient, openings, FRI with {queries} queries and {pow_bits} PoW bits) "
+                  f"on a shard a quarter as tall: 2^{log_rows - CPU_SAMPLE_LOG_SHRINK} eval rows of the {workload} machine, synthetic traces of its shapes; oracle/cpu_prover.py + cpu_step.c, OpenMP over "
+                  f"{cores} threads, {dt:.1f} s; stage names as in config.stages_s of the GPU line (proof-of-work counted under fri_query; to_montgomery = input conversion); "
                   "not the reference binary (no Rust toolchain): never quote the ratio as 'vs the reference'",
+        "evaluator_build_s": pr.build_s,
     }
 
 
@@ -581,9 +619,10 @@ def main():
                 "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (4.76 k int32 instructions each, ~56 % of them four-cycle multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD): k_row_sponges takes 19.9 k SIMD cycles per wave-permutation, the rate of the permutation alone on registers (tools/ubench_perm.hip: 20.8-21.1 k), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4)",
             },
         }
-        if world == 1 and spr == 1 and not args.no_cpu_baseline:
+        if world == 1 and spr == 1 and not args.no_cpu_baseline and args.workload != "eval-only":
             try:
-                out["cpu_baseline"] = cpu_baseline([[(lg - LOG_BLOWUP, w) for lg, w in r] for r in rounds[:3]], n)
+                shapes = [(air.name, lg, air.width) for _, air, lg, _, _ in prepared]
+                out["cpu_baseline"] = cpu_baseline(args.workload, shapes, log_rows, args.queries, args.pow_bits)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
                 out["cpu_baseline"] = {"error": repr(e)}
         print(json.dumps(out), flush=True)
