@@ -60,7 +60,7 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
     return t
 
 
-CPU_SAMPLE_LOG_SHRINK = 2  # the CPU port proves a shard of 2^(log_rows - 2) eval rows: about 10-30 s of CPU work on the box's 16-core quota
+CPU_SAMPLE_LOG_SHRINK = 1  # the CPU port proves a shard of 2^(log_rows - 1) eval rows: about 10 s of CPU work on the box's 16-core quota
 
 
 def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bits: int):
@@ -69,7 +69,7 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     evaluators generated out of the oracle's AIR, opened values, reduced openings, the FRI commit phase, proof-of-work, query
     openings; OpenMP, Montgomery arithmetic), every stage checked word for word against oracle/stark.py and the whole proof
     accepted by the oracle's verifier and equal to the HIP prover's (tests/test_cpu_step*.py).  Timed on a BOUNDED SAMPLE: the
-    same machine with every chip of 2^12 rows and more a quarter as tall (2^(log_rows - 2) eval rows), on synthetic traces of
+    same machine with every chip of 2^12 rows and more half as tall (2^(log_rows - 1) eval rows), on synthetic traces of
     those shapes (no stage's cost depends on the values; the constraints need not hold for the openings and FRI to be
     well-formed).  `value` = sample eval rows / seconds.  Trace generation is not in the port (it needs the interpreter's query
     record; 2 % of the GPU step) and is reported as null.  kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be
@@ -123,7 +123,7 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
         "seconds": dt,
         "stages_s": stages_s,
         "sample": f"the WHOLE step except trace generation (main / permutation / quotient commitments, LogUp rows, quotient, openings, FRI with {queries} queries and {pow_bits} PoW bits) "
-                  f"on a shard a quarter as tall: 2^{log_rows - CPU_SAMPLE_LOG_SHRINK} eval rows of the {workload} machine, synthetic traces of its shapes; oracle/cpu_prover.py + cpu_step.c, OpenMP over "
+                  f"on a shard half as tall: 2^{log_rows - CPU_SAMPLE_LOG_SHRINK} eval rows of the {workload} machine, synthetic traces of its shapes; oracle/cpu_prover.py + cpu_step.c, OpenMP over "
                   f"{cores} threads, {dt:.1f} s; stage names as in config.stages_s of the GPU line (proof-of-work counted under fri_query; to_montgomery = input conversion); "
                   "not the reference binary (no Rust toolchain): never quote the ratio as 'vs the reference'",
         "evaluator_build_s": pr.build_s,

@@ -139,6 +139,12 @@ class CpuProver:
         self.L.cp2_tree_open(tree, index, _ptr(rows), _ptr(path))
         return [int(x) for x in rows] + [int(x) for x in path]
 
+    @staticmethod
+    def prover_order(traces):
+        """The chips of a shard in the prover's order: by trace height, tallest first, machine order among equals (sphinx sorts
+        the shard's chips by height before committing [UPSTREAM-RECALL]; the HIP prover does the same, prover.hip)."""
+        return sorted(traces, key=lambda t: -t[1].shape[0])
+
     # ------------------------------------------------------------------ one shard
     def prove_shard(self, traces, prep, prep_commit, public_values, challenger, num_queries=100, pow_bits=16, timings=None):
         """traces: [(machine index, canonical main trace [N][w])] in machine order; prep: {machine index: Montgomery
@@ -156,6 +162,7 @@ class CpuProver:
                     tm[name] = tm.get(name, 0.0) + time.perf_counter() - s.t
             return T()
 
+        traces = self.prover_order(traces)
         ch = challenger
         prof = ch.profile
         pub_m = to_m(np.array(list(public_values) + [0], dtype=np.uint64))

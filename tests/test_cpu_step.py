@@ -30,8 +30,8 @@ def machine(src, entry, args, lurk_chips=False):
     traces = [(0, np.array([pv], dtype=np.uint32))]
     mi = 1
     for f in otop.funcs:
-        rows, _ = ol.generate_trace(otop, f["name"], oq)
-        if rows:
+        if oq.func[f["index"]]:  # LairChip::included: a function chip takes part iff it has queries (lair_chip.rs:124-129)
+            rows, _ = ol.generate_trace(otop, f["name"], oq)
             traces.append((mi, np.array(rows, dtype=np.uint32)))
         mi += 1
     for ml in ol.MEM_TABLE_SIZES:
@@ -112,7 +112,7 @@ def prove(pr, traces, pv, num_queries=5, pow_bits=4, timings=None):
     ch.observe(pc["root"])
     ch.observe(0)
     # phase 1 of machine.prove: the shard's main root (recomputed inside prove_shard) and the public values
-    main_root = pr.commit([pr.lde(pr.monty(t)) for _, t in traces])[1]
+    main_root = pr.commit([pr.lde(pr.monty(t)) for _, t in pr.prover_order(traces)])[1]
     ch.observe(main_root)
     ch.observe(pv)
     shard = pr.prove_shard(traces, prep_m, pc, pv, ch, num_queries=num_queries, pow_bits=pow_bits, timings=timings)

@@ -37,8 +37,11 @@ def test_cpu_port_and_hip_prover_produce_the_same_proof(ctx, oracle, src, entry,
     ch.observe(gp.main_root)
     ch.observe(opv)
     cp = pr.prove_shard(traces, prep_m, pc, opv, ch, num_queries=7, pow_bits=5)
+    assert [(c.machine_index, c.log_n, c.width) for c in cp.chips] == [(c.machine_index, c.log_n, c.width) for c in gp.chips]
+    assert cp.main_root == gp.main_root
+    assert [tuple(c.cumulative_sum) for c in cp.chips] == [tuple(c.cumulative_sum) for c in gp.chips]
+    assert (cp.perm_root, cp.quot_root) == (gp.perm_root, gp.quot_root)
     assert os_.verify_machine(airs, pc["root"], [16], [6], [cp], ob.merkle_verify)
-    assert (cp.main_root, cp.perm_root, cp.quot_root) == (gp.main_root, gp.perm_root, gp.quot_root)
     assert [(c.machine_index, c.log_n, c.width, c.prep_width, c.perm_width, c.quotient_degree, c.prep_index, tuple(c.cumulative_sum)) for c in cp.chips] == \
            [(c.machine_index, c.log_n, c.width, c.prep_width, c.perm_width, c.quotient_degree, c.prep_index, tuple(c.cumulative_sum)) for c in gp.chips]
     for a, b in zip(cp.chips, gp.chips):
