@@ -49,7 +49,14 @@ struct NttBatch {
     uint32_t* dst[NTT_MAX_BATCH];
     uint32_t* scratch[NTT_MAX_BATCH];
     const uint32_t* row_scale[NTT_MAX_BATCH];
+    // Chunk-tiled layouts (ntt.hip: PassArgs::in_tiled): src / dst hold the matrix as [column chunk][N][32 words] instead of
+    // row-major; scratch_tiled: scratch[m] holds ntt_tiled_words(log_n, w) words and the matrix between two passes goes there
+    // tiled.  Only for shapes with ntt_tiled_words != 0.
+    bool src_tiled = false, dst_tiled = false, scratch_tiled = false;
 };
+// words of the chunk-tiled form of a 2^log_n x w matrix under the NTT's column-chunk plan, or 0 when the shape is not tiled
+// (a single chunk, odd widths, chunks wider than a 128-byte line, one-pass transforms)
+size_t ntt_tiled_words(int log_n, int w);
 int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const NttBatch& b, int w, bool in_canonical,
                       bool out_canonical, bool bitrev_store);
 

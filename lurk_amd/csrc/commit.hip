@@ -107,12 +107,19 @@ int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_
 // interpolate + extend for up to NTT_MAX_BATCH device-resident matrices of one shape (blow-up >= 1: the LDE buffer is the
 // interpolation scratch): one launch per pass for all of them.  *done = false (nothing launched for the extension) when a
 // coset's scale table is not cacheable; the caller then extends the matrices one by one.
+// `coef_tiled_words`: capacity of every coefs[m] in words when it is at least ntt_tiled_words(log_n, w) (else 0): the
+// coefficients then live chunk-tiled between the inverse and the forward transforms, the inverse's intermediate goes tiled into
+// the LDE buffer (2 N w words: always large enough) and the forward transforms' into a pooled temporary -- of the twelve matrix
+// transfers of an LDE only the first read (the caller's row-major trace) and the last two writes (the committed row-major
+// LDE) keep unaligned row segments.
 int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batch, const uint32_t* const* evals, bool canonical,
-                  uint32_t* const* coefs, uint32_t* const* ldes, const uint32_t* shifts_m, bool* done) {
+                  uint32_t* const* coefs, uint32_t* const* ldes, const uint32_t* shifts_m, bool* done, size_t coef_tiled_words) {
     const NttPlan* plan = nullptr;
     LH_TRY(get_ntt_plan(ctx, log_n, &plan));
     const size_t n = (size_t)1 << log_n;
     *done = false;
+    const size_t tw = ntt_tiled_words(log_n, w);
+    const bool tiled = tw != 0 && coef_tiled_words >= tw && tw <= ((size_t)w << (log_n + log_blowup));
     const uint32_t w_big = two_adic_generator_monty(log_n + log_blowup);
     std::vector<NttBatch> cosets((size_t)1 << log_blowup);
     for (uint32_t q = 0; q < (1u << log_blowup); q++) {
@@ -134,8 +141,25 @@ int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batc
         b.dst[m] = coefs[m];
         b.scratch[m] = ldes[m];
     }
-    LH_TRY(ntt_dif_batch(ctx, *plan, /*inverse=*/true, b, w, canonical, false, /*bitrev_store=*/true));
-    for (const NttBatch& e : cosets) LH_TRY(ntt_dif_batch(ctx, *plan, /*inverse=*/false, e, w, false, false, /*bitrev_store=*/false));
+    b.dst_tiled = b.scratch_tiled = tiled;
+    std::vector<void*> temps;
+    if (tiled)
+        for (int m = 0; m < n_batch; m++) {
+            void* t = nullptr;
+            const int32_t st = pool_alloc(ctx, tw * 4, &t);
+            if (st != LURKHIP_OK) {
+                for (void* p : temps) pool_release(ctx, p);
+                return st;
+            }
+            temps.push_back(t);
+            for (NttBatch& e : cosets) e.scratch[m] = (uint32_t*)t;  // the cosets run one after the other on the stream
+        }
+    for (NttBatch& e : cosets) e.src_tiled = e.scratch_tiled = tiled;
+    int32_t st = ntt_dif_batch(ctx, *plan, /*inverse=*/true, b, w, canonical, false, /*bitrev_store=*/true);
+    for (const NttBatch& e : cosets)
+        if (st == LURKHIP_OK) st = ntt_dif_batch(ctx, *plan, /*inverse=*/false, e, w, false, false, /*bitrev_store=*/false);
+    for (void* p : temps) pool_release(ctx, p);  // stream-ordered (deferred while a side lane is open)
+    LH_TRY(st);
     *done = true;
     return LURKHIP_OK;
 }
@@ -465,11 +489,14 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
 
     span_begin(ctx, "lde");  // one span for the matrices of the commitment (with host inputs it includes their uploads)
     std::vector<char> extended(n_mats, 0);
+    std::vector<size_t> coef_words(n_mats, 0);
     for (int i = 0; i < n_mats; i++) {
         const size_t bytes = ((size_t)widths[i] << log_heights[i]) * sizeof(uint32_t);
         c->log_h[i] = (int)log_heights[i] + log_blowup;
         TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
-        TRY_C(pool_alloc(ctx, bytes, (void**)&c->coeffs[i]));
+        // coefficient buffer: room for the chunk-tiled form when nobody asked to keep (row-major) coefficients
+        coef_words[i] = (!keep_coeffs && !mats_on_host && !raw && log_blowup >= 1) ? ntt_tiled_words((int)log_heights[i], (int)widths[i]) : 0;
+        TRY_C(pool_alloc(ctx, std::max(bytes, coef_words[i] * 4), (void**)&c->coeffs[i]));
     }
     // Short matrices (below 2^13 rows: a few workgroups per NTT pass) go through their passes on the context's side lane, under
     // the tall matrices' passes; the tree needs all of them, so the lane is joined before it.  Only with device inputs and while
@@ -486,7 +513,6 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
             const std::vector<int>& idx = kv.second;
             for (size_t at = 0; at < idx.size(); at += NTT_MAX_BATCH) {
                 const int nb = (int)std::min<size_t>(NTT_MAX_BATCH, idx.size() - at);
-                if (nb < 2) continue;
                 const uint32_t* ev[NTT_MAX_BATCH];
                 uint32_t *co[NTT_MAX_BATCH], *ld[NTT_MAX_BATCH];
                 uint32_t sh[NTT_MAX_BATCH];
@@ -498,7 +524,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                     sh[m] = bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN);
                 }
                 bool done = false;
-                TRY_C(lde_batch(ctx, (int)kv.first.first, (int)kv.first.second, log_blowup, nb, ev, repr == LURKHIP_REPR_CANONICAL, co, ld, sh, &done));
+                TRY_C(lde_batch(ctx, (int)kv.first.first, (int)kv.first.second, log_blowup, nb, ev, repr == LURKHIP_REPR_CANONICAL, co, ld, sh, &done,
+                                coef_words[idx[at]]));
                 if (done)
                     for (int m = 0; m < nb; m++) extended[idx[at + m]] = 1;
             }

@@ -78,7 +78,14 @@ struct PassArgs {
     uint32_t magic_w;
     uint32_t n_tiles;  // (row tile, column chunk) pairs of the launch; a workgroup takes several
     uint32_t xcd_run;  // tiles per XCD when the tile count is a multiple of 8 (XCD-contiguous tile order), else 0
+    // Chunk-tiled intermediates (round 3): the matrix between two passes of a transform is not the caller's row-major [N][w] but
+    // [column chunk][N][NTT_TILE_PITCH words] -- a tile's row segment is then one aligned 128-byte line instead of 104..128
+    // bytes at an arbitrary offset of a (w * 4)-byte row (78 columns: 312-byte rows; tools/ubench_fetch.hip: an unaligned
+    // segment fetches two lines, and tools/lde_throughput.py: widths that are multiples of 32 run 20 % faster per element).
+    int in_tiled, out_tiled;
+    int chunk0;        // index of this launch's first column chunk in the matrix (the ragged last chunk has its own launch)
 };
+constexpr int NTT_TILE_PITCH = 32;
 
 __device__ __forceinline__ int fast_div(uint32_t e, uint32_t magic, int c) {
     return c == 1 ? (int)e : (int)__umulhi(e, magic);
@@ -243,14 +250,21 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     const uint32_t run0 = a.xcd_run ? (blockIdx.x & 7u) * a.xcd_run : 0u;
     if (wg >= run) return;
     const uint32_t my_tiles = (run - wg + wgs - 1) / wgs;
-    auto locate = [&](uint32_t it, uint32_t& row0, int& col, uint32_t& lo) {
+    // word offset of this thread's column inside a row (row-major), or inside the chunk's [N][pitch] slab plus the slab's start
+    // (tiled): the element of matrix row `row` is at (row * stride + off) words
+    const boff_t in_stride = a.in_tiled ? (boff_t)NTT_TILE_PITCH : (boff_t)a.w;
+    const boff_t out_stride = a.out_tiled ? (boff_t)NTT_TILE_PITCH : (boff_t)a.w;
+    auto locate = [&](uint32_t it, uint32_t& row0, boff_t& off_in, boff_t& off_out, uint32_t& lo) {
         const uint32_t bid = run0 + wg + it * wgs;
         const uint32_t tile_id = bid / (uint32_t)a.n_chunks;
         const int chunk = (int)(bid - tile_id * (uint32_t)a.n_chunks);
         lo = (tile_id & ((1u << lo_bits) - 1u)) << a.log_l;  // first of the tile's L adjacent low-bit values
         const uint32_t hi = tile_id >> lo_bits;
         row0 = ((hi << (a.bit_lo + LOG_R)) | lo) + (uint32_t)l_of;
-        col = a.col0 + chunk * a.col_chunk + col_in_chunk;
+        const boff_t col = (boff_t)(a.col0 + chunk * a.col_chunk + col_in_chunk);
+        const boff_t slab = (((boff_t)(a.chunk0 + chunk)) << a.log_n) * (boff_t)NTT_TILE_PITCH + (boff_t)col_in_chunk;
+        off_in = a.in_tiled ? slab : col;
+        off_out = a.out_tiled ? slab : col;
     };
     // this thread's twiddle slots (TWN of them: 1, or 4 when grouped rows multiply the table): entry idx = [l][k] of the
     // table, k = (1 << s) + t_lo; slots past the table (and k = 0) read entry 0 and are not written
@@ -268,12 +282,12 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     const char* __restrict__ src = reinterpret_cast<const char*>(a.in[blockIdx.y]);
     char* __restrict__ dst = reinterpret_cast<char*>(a.out[blockIdx.y]);
     const uint32_t* __restrict__ row_scale = a.row_scale[blockIdx.y];
-    auto fetch = [&](uint32_t row0, int col, uint32_t lo) {
+    auto fetch = [&](uint32_t row0, boff_t off_in, uint32_t lo) {
 #pragma unroll
         for (int k = 0; k < U; k++) {
             const int t = slot + (k << LOG_SLOTS);
             const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
-            v[k] = *reinterpret_cast<const T*>(src + ((boff_t)row * (boff_t)a.w + (boff_t)col) * 4);
+            v[k] = *reinterpret_cast<const T*>(src + ((boff_t)row * in_stride + off_in) * 4);
             if constexpr (SCALE) sc[k] = row_scale[row];
         }
         // twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l)
@@ -286,9 +300,9 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     };
 
     uint32_t row0, lo;
-    int col;
-    locate(0, row0, col, lo);
-    fetch(row0, col, lo);
+    boff_t off_in, off_out;
+    locate(0, row0, off_in, off_out, lo);
+    fetch(row0, off_in, lo);
     for (uint32_t it = 0; it < my_tiles; it++) {
         // staged registers -> LDS
         if (active) {
@@ -306,12 +320,12 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
             if (idx < n_tw && (idx & (R - 1)) != 0) tw_lds[idx] = twv[i];
         }
         const uint32_t cur_row0 = row0;
-        const int cur_col = col;
+        const boff_t cur_off_out = off_out;
         __syncthreads();
         // the next tile's rows fly while this one's remaining stages run (the last iteration re-reads its own tile: no branch)
         run_stages<LOG_R, LOG_R - 1, SLOTS, T>(st_col, tw_lds + (st_l << LOG_R), st_slot, st_active, [&]() {
-            locate(it + 1 < my_tiles ? it + 1 : it, row0, col, lo);
-            fetch(row0, col, lo);
+            locate(it + 1 < my_tiles ? it + 1 : it, row0, off_in, off_out, lo);
+            fetch(row0, off_in, lo);
         });
         __syncthreads();  // the stages ran under the column-per-wave map, the write-back uses the row-contiguous one
         if (active) {
@@ -328,7 +342,7 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
                     if (a.bitrev_store) row = bitrev32(row, a.log_n);
                     T x = o[k];
                     if (a.out_canonical) x = from_monty_elem(x);
-                    *reinterpret_cast<T*>(dst + ((boff_t)row * (boff_t)a.w + (boff_t)cur_col) * 4) = x;
+                    *reinterpret_cast<T*>(dst + ((boff_t)row * out_stride + cur_off_out) * 4) = x;
                 }
             }
         }
@@ -447,6 +461,63 @@ static void schedule(int log_n, int max_log_r, std::vector<std::pair<int, int>>&
     }
 }
 
+// The column-chunk plan of a transform: tile height and chunk width, decided once per (log_n, w) so that every pass of a transform
+// -- and the inverse / forward transforms that hand a chunk-tiled matrix to each other -- cut the columns the same way.
+struct ChunkPlan {
+    int max_log_r, col_chunk, n_pass;
+    size_t lds_cap;
+};
+static ChunkPlan plan_chunks(int log_n, int w, bool aligned8) {
+    auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
+    auto rows_per_thread = [](int log_r) { return log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8; };  // the kernel's U
+    auto max_threads = [](int log_r) { return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024; };  // the kernels' launch bounds
+    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r)) * items_of(cols); };
+    auto lds_bytes = [](int log_r, int cols, int log_l) {
+        return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
+    };
+    // Every pass reads and writes the whole matrix, so the number of passes is what the LDE costs in HBM traffic: tiles of up to
+    // 2^10 rows (132 KiB of the CU's 160 KiB of LDS at 32 columns) take a 2^20-row transform in two passes instead of three.
+    // LURKHIP_NTT_MAX_LOG_R caps the tile height (7 = the 64 KiB tiles of round 1; for A/B measurements).
+    int cap_log_r = 10;
+    if (const char* e = getenv("LURKHIP_NTT_MAX_LOG_R")) cap_log_r = std::max(1, std::min(10, atoi(e)));
+    const int n_pass = std::max(1, (log_n + cap_log_r - 1) / cap_log_r);
+    int max_log_r = std::max(1, (log_n + n_pass - 1) / n_pass);  // tallest tile of the schedule
+    size_t lds_cap = max_log_r > 7 ? (size_t)140 * 1024 : (size_t)64 * 1024;
+    if (const char* e = getenv("LURKHIP_NTT_LDS_CAP_KB")) lds_cap = (size_t)std::max(8, atoi(e)) * 1024;  // A/B hook: tile bytes per workgroup
+    // column chunk: the widest even divisor of w that fits (no ragged chunk), else the widest even width that fits (the ragged
+    // remainder gets its own launch); narrow matrices are one chunk
+    auto fits = [&](int cols) { return lds_bytes(max_log_r, cols, 0) <= lds_cap && threads_of(max_log_r, cols) <= max_threads(max_log_r); };
+    int col_chunk = w;
+    if (!fits(w)) {
+        int widest = 2;
+        for (int c = std::min(w, 112); c >= 2; c--)
+            if (c % 2 == 0 && fits(c)) {
+                widest = c;
+                break;
+            }
+        col_chunk = widest;
+        for (int c = widest; c >= std::max(2, widest * 3 / 4); c--)
+            if (c % 2 == 0 && w % c == 0) {
+                col_chunk = c;
+                break;
+            }
+    }
+    while ((lds_bytes(max_log_r, col_chunk, 0) > lds_cap || threads_of(max_log_r, col_chunk) > max_threads(max_log_r)) && max_log_r > 1)
+        max_log_r--;
+    return ChunkPlan{max_log_r, col_chunk, std::max(1, (log_n + max_log_r - 1) / max_log_r), lds_cap};
+}
+
+size_t ntt_tiled_words(int log_n, int w) {
+    // off by default: measured on the fib-mix step (round 3) the tiled intermediates are 5 % SLOWER (lde 11.8 against 11.2 ms)
+    // -- see DESIGN.md 3.3; LURKHIP_NTT_TILED=1 turns them on for A/B measurements
+    static const bool enabled = getenv("LURKHIP_NTT_TILED") != nullptr && atoi(getenv("LURKHIP_NTT_TILED")) != 0;
+    if (!enabled || w % 2 != 0) return 0;
+    const ChunkPlan cp = plan_chunks(log_n, w, true);
+    const int n_chunks = (w + cp.col_chunk - 1) / cp.col_chunk;
+    if (n_chunks < 2 || cp.col_chunk > NTT_TILE_PITCH || cp.n_pass < 2) return 0;
+    return ((size_t)n_chunks << log_n) * NTT_TILE_PITCH;
+}
+
 // Full size-N DIF transform of an N x w row-major matrix.
 //   src -> dst, natural-order input; output bit-reversed, or natural when bitrev_store (the
 //   permutation is fused into the last pass's store).  `scratch` (N x w) is needed when more than one
@@ -485,32 +556,10 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     // Every pass reads and writes the whole matrix, so the number of passes is what the LDE costs in HBM traffic: tiles of up to
     // 2^10 rows (132 KiB of the CU's 160 KiB of LDS at 32 columns) take a 2^20-row transform in two passes instead of three.
     // LURKHIP_NTT_MAX_LOG_R caps the tile height (7 = the 64 KiB tiles of round 1; for A/B measurements).
-    int cap_log_r = 10;
-    if (const char* e = getenv("LURKHIP_NTT_MAX_LOG_R")) cap_log_r = std::max(1, std::min(10, atoi(e)));
-    const int n_pass = std::max(1, (log_n + cap_log_r - 1) / cap_log_r);
-    int max_log_r = std::max(1, (log_n + n_pass - 1) / n_pass);  // tallest tile of the schedule
-    size_t lds_cap = max_log_r > 7 ? (size_t)140 * 1024 : (size_t)64 * 1024;
-    if (const char* e = getenv("LURKHIP_NTT_LDS_CAP_KB")) lds_cap = (size_t)std::max(8, atoi(e)) * 1024;  // A/B hook: tile bytes per workgroup
-    // column chunk: the widest even divisor of w that fits (no ragged chunk), else the widest even width that fits (the ragged
-    // remainder gets its own launch); narrow matrices are one chunk
-    auto fits = [&](int cols) { return lds_bytes(max_log_r, cols, 0) <= lds_cap && threads_of(max_log_r, cols) <= max_threads(max_log_r); };
-    int col_chunk = w;
-    if (!fits(w)) {
-        int widest = 2;
-        for (int c = std::min(w, 112); c >= 2; c--)
-            if (c % 2 == 0 && fits(c)) {
-                widest = c;
-                break;
-            }
-        col_chunk = widest;
-        for (int c = widest; c >= std::max(2, widest * 3 / 4); c--)
-            if (c % 2 == 0 && w % c == 0) {
-                col_chunk = c;
-                break;
-            }
-    }
-    while ((lds_bytes(max_log_r, col_chunk, 0) > lds_cap || threads_of(max_log_r, col_chunk) > max_threads(max_log_r)) && max_log_r > 1)
-        max_log_r--;
+    ChunkPlan cp = plan_chunks(log_n, w, aligned8);
+    int max_log_r = cp.max_log_r;
+    const int col_chunk = cp.col_chunk;
+    const size_t lds_cap = cp.lds_cap;
     // The tile's twiddles are staged by at most four loads per thread, so a launch has at least 2^(log_r + log_l) / 4 threads:
     // a narrow (ragged) chunk of a tall tile gets idle threads -- they shadow a real thread's loads and write nothing.
     auto launch_threads = [&](int log_r, int cols, int log_l) {
@@ -520,6 +569,13 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
     const int n_full = w / col_chunk, last_w = w % col_chunk;
+    // chunk-tiled layouts: only for shapes ntt_tiled_words() admits, cut exactly as it assumes
+    const size_t tiled_words = (b.src_tiled || b.dst_tiled || b.scratch_tiled) ? ntt_tiled_words(log_n, w) : 0;
+    if (b.src_tiled || b.dst_tiled || b.scratch_tiled)
+        LH_ARG(ctx, tiled_words != 0 && aligned8 && col_chunk <= NTT_TILE_PITCH, "this NTT shape has no chunk-tiled form");
+    const bool inter_tiled = b.scratch_tiled && passes.size() >= 2;
+    if (inter_tiled)
+        for (int m = 0; m < b.n; m++) LH_ARG(ctx, b.scratch[m] != nullptr, "tiled intermediates need a scratch buffer");
     const uint32_t* cur_in[NTT_MAX_BATCH] = {};
     for (int m = 0; m < b.n; m++) cur_in[m] = b.src[m];
     for (size_t p = 0; p < passes.size(); p++) {
@@ -528,12 +584,15 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
         for (int m = 0; m < b.n; m++) {
             uint32_t* cur_out;
             if (last) cur_out = b.dst[m];
+            else if (inter_tiled) cur_out = b.scratch[m];   // chunk-tiled intermediates (in place for the middle passes)
             else if (bitrev_store) cur_out = b.scratch[m];  // keep dst free for the final scatter
             else cur_out = b.dst[m];                         // in-place chain inside dst
             a.in[m] = cur_in[m];
             a.out[m] = cur_out;
             a.row_scale[m] = p == 0 ? b.row_scale[m] : nullptr;
         }
+        a.in_tiled = (p == 0 ? b.src_tiled : inter_tiled) ? 1 : 0;
+        a.out_tiled = (last ? b.dst_tiled : inter_tiled) ? 1 : 0;
         a.tw = inverse ? plan.tw_inv : plan.tw_fwd;
         a.log_n = log_n;
         a.w = w;
@@ -557,6 +616,7 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
             if (part == 0 && n_full == 0) continue;
             if (part == 1 && last_w == 0) continue;
             a.col0 = part == 0 ? 0 : n_full * col_chunk;
+            a.chunk0 = part == 0 ? 0 : n_full;
             a.col_chunk = part == 0 ? (col_chunk << log_l) : last_w;
             a.n_chunks = part == 0 ? n_full : 1;
             const bool pair = aligned8 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
@@ -578,7 +638,8 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
             size_t blocks = std::min<size_t>(tiles, std::max<size_t>(8, (size_t)per_cu * ctx->num_cus / b.n));
             if (a.xcd_run) blocks = blocks / 8 * 8;
             // matrices of 4 GiB and more need 64-bit offsets; LURKHIP_NTT_FORCE_64BIT (test hook) takes that path at any size
-            const bool big = (((size_t)w) << (log_n + 2)) >= ((size_t)1 << 32) || getenv("LURKHIP_NTT_FORCE_64BIT") != nullptr;
+            const size_t widest_row = std::max<size_t>((size_t)w, tiled_words >> log_n);  // words per row of the larger layout in use
+            const bool big = (widest_row << (log_n + 2)) >= ((size_t)1 << 32) || getenv("LURKHIP_NTT_FORCE_64BIT") != nullptr;
             const dim3 grid((unsigned)blocks, (unsigned)b.n);
             if (pair && big) launch_pass<uint2, true>(log_r, grid, threads, lds, ctx->stream, a);
             else if (pair) launch_pass<uint2, false>(log_r, grid, threads, lds, ctx->stream, a);
