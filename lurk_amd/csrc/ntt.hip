@@ -122,6 +122,9 @@ __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
 #define LURK_NTT_TALL_LOG_SLOTS 6
 #endif
 #define LURK_NTT_TALL_SLOTS (1 << LURK_NTT_TALL_LOG_SLOTS)
+#ifndef LURK_NTT_WIDE_SCALAR
+#define LURK_NTT_WIDE_SCALAR 0
+#endif
 template <int LOG_R>
 __host__ __device__ constexpr int swz(int t) {
     if (LOG_R > LURK_NTT_SWZ_MAX_LOG_R) return t;
@@ -214,9 +217,15 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     constexpr int EW = (int)(sizeof(T) / 4);  // matrix columns per element
     // rows a thread stages per tile: 8, and 16 for the 1024-row tiles so that the row slots of a column stay the 64 lanes of
     // one wave (the stage groups rely on it: wave-local ordering instead of workgroup barriers)
-    constexpr int U = R < 8 ? R : (LOG_R > 9 ? R / LURK_NTT_TALL_SLOTS : 8);
+    // -DLURK_NTT_WIDE_SCALAR=1 (round 3, measured and rejected): one-column items (odd widths: rows are not 8-byte aligned, no
+    // column pairs) stage twice the rows per thread, i.e. the same bytes per thread as a pair item, so that a tile is 32 columns
+    // wide either way -- the 107- and 53-column chips take 7 and 4 tiles per row block where 4 and 2 would do.  The 32 staged rows
+    // plus 32 row scales put 144 .. 416 bytes of the 128-VGPR kernels into scratch: lde 11.2 -> 11.9 ms per fib-mix step.
+    constexpr int U_PAIR = R < 8 ? R : (LOG_R > 9 ? R / LURK_NTT_TALL_SLOTS : 8);
+    constexpr int U = (LURK_NTT_WIDE_SCALAR && EW == 1 && LOG_R >= 4) ? 2 * U_PAIR : U_PAIR;
     constexpr int SLOTS = R / U;              // row slots per workgroup: thread = (slot, column item), slot < SLOTS
-    constexpr int LOG_U = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - LURK_NTT_TALL_LOG_SLOTS : 3);
+    constexpr int LOG_U_PAIR = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - LURK_NTT_TALL_LOG_SLOTS : 3);
+    constexpr int LOG_U = (LURK_NTT_WIDE_SCALAR && EW == 1 && LOG_R >= 4) ? LOG_U_PAIR + 1 : LOG_U_PAIR;
     constexpr int LOG_SLOTS = LOG_R - LOG_U;
     static_assert(SLOTS <= 64, "a column's row slots are lanes of one wave");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -288,7 +297,6 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
             const int t = slot + (k << LOG_SLOTS);
             const uint32_t row = row0 | ((uint32_t)t << a.bit_lo);
             v[k] = *reinterpret_cast<const T*>(src + ((boff_t)row * in_stride + off_in) * 4);
-            if constexpr (SCALE) sc[k] = row_scale[row];
         }
         // twiddles: w_{2h}^j, h = 2^(bit_lo+s), j = (t_lo << bit_lo) | (lo + l)
 #pragma unroll
@@ -299,11 +307,26 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
         }
     };
 
+    // The row scales of a tile are requested when the tile is about to enter LDS, not with its rows one tile ahead (round 3):
+    // prefetched, their U registers were live through the stage groups of the previous tile, on top of the radix-8 group's sixteen
+    // data registers and seven twiddles, and pushed the 128-VGPR kernels 36 .. 124 bytes into scratch -- the scaled pass (the first
+    // of every forward transform) took 345 us for 2^20 x 78 against 234 us for the same access pattern unscaled, its PMC fetch
+    // 1.92 x the matrix against 1.51 x (the spills' traffic).  The table is L2-resident: one exposed L2 latency per tile.
+    auto fetch_scales = [&](uint32_t row0) {
+        if constexpr (SCALE) {
+#pragma unroll
+            for (int k = 0; k < U; k++) {
+                const int t = slot + (k << LOG_SLOTS);
+                sc[k] = row_scale[row0 | ((uint32_t)t << a.bit_lo)];
+            }
+        }
+    };
     uint32_t row0, lo;
     boff_t off_in, off_out;
     locate(0, row0, off_in, off_out, lo);
     fetch(row0, off_in, lo);
     for (uint32_t it = 0; it < my_tiles; it++) {
+        fetch_scales(row0);
         // staged registers -> LDS
         if (active) {
 #pragma unroll
@@ -469,9 +492,13 @@ struct ChunkPlan {
 };
 static ChunkPlan plan_chunks(int log_n, int w, bool aligned8) {
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
-    auto rows_per_thread = [](int log_r) { return log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8; };  // the kernel's U
+    auto is_pair = [&](int cols) { return aligned8 && cols % 2 == 0; };
+    auto rows_per_thread = [](int log_r, bool pair) {  // the kernel's U
+        const int u = log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8;
+        return (LURK_NTT_WIDE_SCALAR && !pair && log_r >= 4) ? 2 * u : u;
+    };
     auto max_threads = [](int log_r) { return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024; };  // the kernels' launch bounds
-    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r)) * items_of(cols); };
+    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r, is_pair(cols))) * items_of(cols); };
     auto lds_bytes = [](int log_r, int cols, int log_l) {
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
     };
@@ -547,9 +574,13 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     }
     const bool aligned8 = (all_ptrs & 7u) == 0 && w % 2 == 0;
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
-    auto rows_per_thread = [](int log_r) { return log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8; };  // the kernel's U
+    auto is_pair = [&](int cols) { return aligned8 && cols % 2 == 0; };
+    auto rows_per_thread = [](int log_r, bool pair) {  // the kernel's U
+        const int u = log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8;
+        return (LURK_NTT_WIDE_SCALAR && !pair && log_r >= 4) ? 2 * u : u;
+    };
     auto max_threads = [](int log_r) { return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024; };  // the kernels' launch bounds
-    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r)) * items_of(cols); };
+    auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r, is_pair(cols))) * items_of(cols); };
     auto lds_bytes = [](int log_r, int cols, int log_l) {
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
     };
@@ -621,7 +652,7 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
             a.n_chunks = part == 0 ? n_full : 1;
             const bool pair = aligned8 && a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
             const int cv = a.col_chunk / (pair ? 2 : 1);
-            const int slots = std::max(1, (1 << log_r) / rows_per_thread(log_r));  // the kernel's SLOTS
+            const int slots = std::max(1, (1 << log_r) / rows_per_thread(log_r, pair));  // the kernel's SLOTS
             LH_ARG(ctx, slots * cv <= max_threads(log_r), "NTT tile shape");
             a.magic_cv = magic_for(cv);
             const int threads = launch_threads(log_r, a.col_chunk, log_l);
