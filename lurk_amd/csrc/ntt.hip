@@ -594,7 +594,11 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     // The tile's twiddles are staged by at most four loads per thread, so a launch has at least 2^(log_r + log_l) / 4 threads:
     // a narrow (ragged) chunk of a tall tile gets idle threads -- they shadow a real thread's loads and write nothing.
     auto launch_threads = [&](int log_r, int cols, int log_l) {
-        const int need = (int)((((size_t)1 << (log_r + log_l)) + 3) / 4);
+        int need = (int)((((size_t)1 << (log_r + log_l)) + 3) / 4);
+        // tall tiles: enough threads for ONE twiddle load each whenever the launch bounds allow it (the four-load variants of the
+        // 128-VGPR kernels spill 12 .. 48 bytes; the 26-column chunks of a 78-column matrix launched 832 threads and took them)
+        static const bool one_tw = getenv("LURKHIP_NTT_ONE_TW") == nullptr || atoi(getenv("LURKHIP_NTT_ONE_TW")) != 0;
+        if (one_tw && log_r >= 8 && ((size_t)1 << (log_r + log_l)) <= (size_t)max_threads(log_r)) need = 1 << (log_r + log_l);
         return std::min(max_threads(log_r), (std::max(threads_of(log_r, cols), need) + 63) / 64 * 64);
     };
     std::vector<std::pair<int, int>> passes;
