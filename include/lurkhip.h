@@ -537,6 +537,34 @@ int64_t lurkhip_proof_words(const lurkhip_proof* proof);
 int32_t lurkhip_proof_read(const lurkhip_proof* proof, uint32_t* out, uint64_t capacity_words);
 int32_t lurkhip_proof_free(lurkhip_proof* proof);
 
+/* ------------------------------------------------------------------- the in-tree LogUp module */
+/* Device twin of /root/reference/src/logup/ -- dead code upstream (`// pub mod logup;`, src/lib.rs:6); the permutation argument
+ * that runs is sphinx's (lurkhip_permutation_trace_dev).  Host pointers, canonical words, extension elements as 4 words.
+ * `program` is the flat form of the interactions (PairColLC, src/air/symbolic/virtual_col.rs:8-13), provides first:
+ *   n_provides, n_requires, then per interaction: has_is_real, [lc], n_values, lc * n_values;
+ *   lc = n_terms, (kind, index, weight) * n_terms, constant;  kind 0 = identity column, 1 = preprocessed, 2 = main.
+ *
+ * lurkhip_logup_multiplicities     = generate_multiplicities_trace (logup/trace.rs:10-50): out[row][i] = sum_j z^(traces_i[j] + 1)
+ *   counts_i[row][j]; `traces` holds the n_traces[i] trace indices of every provide back to back, counts[i] is [height][n_traces[i]].
+ * lurkhip_logup_permutation_trace  = generate_permutation_trace (logup/trace.rs:53-151): rows [s, 1/d_0, 1/d_1, ...] with
+ *   d_k = r + sum_j gamma^j v_kj (gamma^0 = 1, logup/air.rs:79-109), 0 where is_real evaluates to 0, column 0 the running sum of
+ *   sum_k m_k / d_k (m_k = the multiplicity witness for provides, -z for requires): inclusive as upstream computes it, or --
+ *   exclusive != 0 -- the s_0 = 0 form its constraints ask for.  `sum` (may be null) receives the total.
+ * lurkhip_logup_eval_constraints   = eval_logup_constraints (logup/air.rs:11-77) on n_rows row pairs: per pair the n_int inverse
+ *   constraints, then first-row, transition and last-row constraints (extension values).  air_order != 0 walks the interactions
+ *   requires-then-provides as the AIR does (air.rs:37; its multiplicities still come provides-first, air.rs:39-43), 0 provides
+ *   first like the trace generator.  selectors[row] = is_first_row, is_last_row, is_transition. */
+int32_t lurkhip_logup_multiplicities(lurkhip_ctx* ctx, uint32_t height, uint32_t n_provides, const uint32_t* n_traces, const uint32_t* traces,
+                                     const uint32_t* const* counts, const uint32_t* z, uint32_t* out);
+int32_t lurkhip_logup_permutation_trace(lurkhip_ctx* ctx, uint32_t height, uint32_t prep_width, uint32_t main_width, const uint32_t* identity,
+                                        const uint32_t* prep, const uint32_t* main, const uint32_t* multiplicities, const uint32_t* program,
+                                        uint64_t program_words, const uint32_t* z, const uint32_t* r, const uint32_t* gamma, int32_t exclusive,
+                                        uint32_t* out, uint32_t* sum);
+int32_t lurkhip_logup_eval_constraints(lurkhip_ctx* ctx, uint32_t n_rows, uint32_t prep_width, uint32_t main_width, const uint32_t* perm_local,
+                                       const uint32_t* perm_next, const uint32_t* multiplicities, const uint32_t* identity, const uint32_t* prep,
+                                       const uint32_t* main, const uint32_t* program, uint64_t program_words, const uint32_t* z, const uint32_t* r,
+                                       const uint32_t* gamma, const uint32_t* final_sum, const uint32_t* selectors, int32_t air_order, uint32_t* out);
+
 /* ------------------------------------------------------------------- proof wire format */
 /* The reference's serialised proofs.  `CryptoProof { shard_proofs, verifier_version, depth }` with
  * `CryptoShardProof { commitment, opened_values, opening_proof, chip_ordering }` as `bincode::serialize` writes them
