@@ -415,12 +415,17 @@ def main():
     lde_ms_step = spans["lde"][0] / args.steps
     lde_alg = lde_alg_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     lde_pass = lde_pass_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
-    traffic, valu = None, None
+    traffic, valu, lde_traffic = None, None, None
     try:  # HBM bytes / instruction counts of the same kernels from committed rocprofv3 PMC passes (NOT measured in this run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
         if pmc.get("log_rows") == log_rows and pmc.get("workload") == args.workload:
-            traffic = {"bytes_per_step": pmc["merkle_hash_bytes_per_step"], "source": f"profiles (static): {pmc.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}"}
+            src = f"profiles (static): {pmc.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE')}; {pmc.get('correction', '')}"
+            traffic = {"bytes_per_step": pmc["merkle_hash_bytes_per_step"], "over_algorithmic": pmc["merkle_hash_bytes_per_step"] / hash_bytes_step if hash_bytes_step else None,
+                       "source": src,
+                       "note": "the re-fetches are L2 misses on lines shared by four consecutive 32-byte chunk loads of a lane's row, about 20 k cycles apart; the counter includes Infinity-Cache hits; the kernel is instruction-bound, not waiting for them (SQ_WAIT_ANY 5 %)"}
+            lde_traffic = {"bytes_per_step": pmc["ntt_pass_bytes_per_step"], "over_algorithmic": pmc["ntt_pass_bytes_per_step"] / lde_alg_bytes if lde_alg_bytes else None,
+                           "over_pass_model": pmc["ntt_pass_bytes_per_step"] / lde_pass_bytes if lde_pass_bytes else None, "source": src}
             mul_frac = pmc.get("merkle_hash_mul_class_frac", 0.6)
             # instruction-mix ceiling: add-class at the full rate, mul-class at half rate, no overlap between the classes
             ceiling = 1.0 / ((1 - mul_frac) / VALU_FULL_RATE + mul_frac / VALU_HALF_RATE)
@@ -600,23 +605,29 @@ def main():
                 "two_shards_in_flight": two_in_flight,
                 "host_pipeline": host_pipeline,
             },
+            # The dominant kernels (Merkle hashing) are int32-VALU-issue-bound: the headline fraction is against the instruction-mix
+            # ceiling of the VALU; the HBM fraction the contract names is kept beside it (`hbm`).
             "roofline": {
-                "bound": "hbm",
+                # (no PMC summary for this workload / size: the live HBM fraction is the headline)
+                "bound": "valu" if valu else "hbm",
                 "kernel": "Merkle hashing (k_row_sponges + k_level_digests + k_level_coop; trees of 2^16 leaves and more), all launches of a step",
-                "achieved": achieved,
-                "peak": HBM_PEAK_GBS,
-                "unit": "GB/s",
-                "frac": achieved / HBM_PEAK_GBS,
-                "traffic": traffic,
+                "achieved": valu["achieved"] if valu else achieved,
+                "peak": valu["mix_ceiling"] if valu else HBM_PEAK_GBS,
+                "unit": "T lane-instr/s" if valu else "GB/s",
+                "frac": valu["frac_of_mix_ceiling"] if valu else achieved / HBM_PEAK_GBS,
                 "int32_valu": valu,
+                "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
+                        "note": "algorithmic bytes / summed HIP-event time of the hashing launches, measured live in this run"},
+                "traffic": traffic,
                 "also": {"kernel": "coset LDE passes (k_ntt_pass), all launches of a step", "bound": "hbm",
                          "achieved": lde_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_alg / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": lde_alg_bytes, "algorithmic_bytes_rule": "SURVEY 8(d): 12 w B per trace row (read 4w, write 8w)",
-                         "pass_traffic_bytes_per_step": lde_pass_bytes, "pass_traffic_GBs": lde_pass, "ms_per_step": lde_ms_step},
+                         "pass_traffic_bytes_per_step": lde_pass_bytes, "pass_traffic_GBs": lde_pass, "ms_per_step": lde_ms_step,
+                         "traffic": lde_traffic},
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,
                 "ms_per_step": hash_ms_step,
-                "note": "int32-VALU bound, not HBM bound: ceil(w/8) width-16 Poseidon2 permutations (4.76 k int32 instructions each, ~56 % of them four-cycle multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD): k_row_sponges takes 19.9 k SIMD cycles per wave-permutation, the rate of the permutation alone on registers (tools/ubench_perm.hip: 20.8-21.1 k), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4)",
+                "note": "int32-VALU bound: ceil(w/8) width-16 Poseidon2 permutations (4.76 k int32 instructions each, ~56 % of them four-cycle multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD): k_row_sponges takes 19.9 k SIMD cycles per wave-permutation, the rate of the permutation alone on registers (tools/ubench_perm.hip: 20.8-21.1 k), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4); `frac` = achieved VALU rate / the ceiling of its instruction mix (static PMC pass: profiles/pmc_traffic.json), `hbm.frac` = the HBM fraction measured live",
             },
         }
         if world == 1 and spr == 1 and not args.no_cpu_baseline and args.workload != "eval-only":

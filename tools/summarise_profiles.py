@@ -66,7 +66,9 @@ NTT = [k for k in res["FETCH_SIZE"][0] if k.startswith("k_ntt_pass")]
 ntt_bytes = (2 * sum(res["FETCH_SIZE"][0][k] for k in NTT) + sum(res["WRITE_SIZE"][0][k] for k in NTT)) * 1024
 traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (profiles/{prefix}_pmc_hbm_per_kernel.csv)",
            "ntt_pass_bytes_per_step": ntt_bytes,
-           "correction": "FETCH_SIZE doubled (gfx950 counts 128-byte requests as 64, MI355X_MICROARCH.md HBM section); WRITE_SIZE as reported",
+           "correction": "calibrated (profiles/r03_pmc_calibration.json, tools/ubench_fetch.hip): FETCH_SIZE x 2.0 for every access pattern of this repository (a 128-byte line request is tallied as 64 bytes whatever the load width), WRITE_SIZE x 1.0 (exact in 32-byte sectors)",
+           "fetch_factor": 2.0, "write_factor": 1.0,
+           "ntt_pass_fetch_bytes_reported": sum(res["FETCH_SIZE"][0][k] for k in NTT) * 1024, "ntt_pass_write_bytes_reported": sum(res["WRITE_SIZE"][0][k] for k in NTT) * 1024,
            "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
            "merkle_hash_valu_tinst_s": hv, "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
 json.dump(traffic, open(f"profiles/{prefix}_pmc_traffic.json", "w"), indent=1)
