@@ -10,7 +10,10 @@ extern chips and the row ratios of SURVEY.md appendix C.  `--workload eval-only`
 machine, `--workload lurk-mix` all 39 functions (BASELINE config 5, irregular widths 9 ... 815).
 
 The host interpreter runs once before the timed region and the flattened inputs of every chip (row streams, memory
-tables, byte-lookup records) are resident in HBM.  One *step* = one pass of the proving hot path over one shard per GPU,
+tables, byte-lookup records) are resident in HBM.  At N = 1 the K timed steps are K independent proofs of the shard with two
+in flight on two HIP streams (--lanes 2, the schedule of every multi-shard proof: Machine.prove / prove_lanes); the
+one-proof-at-a-time time is measured in the same run and reported as config.sequential (--lanes 1 times that instead).
+One *step* = one pass of the proving hot path over one shard per GPU,
 i.e. what `machine.prove::<LocalProver>` does after `execute` (/root/reference/benches/fib.rs:88-124): trace generation of
 every chip, main-trace commitment, LogUp permutation traces + commitment, quotient + commitment, openings at zeta and FRI
 (100 queries, 16 proof-of-work bits).  Metric: eval-steps (rows of the eval chip) proved per second.
@@ -170,7 +173,10 @@ def main():
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="diagnostic: no per-stage HIP events in the timed region (stages_ms and roofline read 0)")
-    ap.add_argument("--no-two-in-flight", action="store_true", help="skip the extra two-shards-in-flight measurement")
+    ap.add_argument("--lanes", type=int, choices=(1, 2), default=2,
+                    help="N = 1: proofs in flight during the timed steps (2 = the K steps are K independent proofs of the shard dealt to two HIP "
+                         "streams of the GPU, the way Machine.prove / prove_lanes run a multi-shard proof; 1 = one proof at a time)")
+    ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; same as --lanes 1)")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
     ap.add_argument("--compile-min-log-rows", type=int, default=None,
                     help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
@@ -306,20 +312,116 @@ def main():
     for _ in range(args.warmup):
         step()
     fence()
+    # N = 1, --lanes 2 (default): the K timed steps are K independent proofs of the shard with TWO IN FLIGHT, each lane on its own
+    # context (HIP stream, pool, host thread) -- while one proof sits in a latency chain (tree tails, FRI layers, transcript round
+    # trips) the other's big kernels fill the device; this is how Machine.prove runs every multi-shard proof and how a rank of the
+    # N > 1 bench proves its two shards.  A short one-proof-at-a-time pass comes first, for the stage table, the live roofline
+    # spans (a kernel alone on the device) and the `sequential` number reported beside the headline.
+    lanes = 2 if (world == 1 and spr == 1 and args.lanes == 2 and not args.no_two_in_flight) else 1
+    sequential = None
+    seq_spans = None
+    lane2 = None
+    if lanes == 2:
+        import threading
+
+        n_seq = max(3, min(5, args.steps))
+        ctx.profile_reset()
+        ctx.profile_enable(not args.no_spans)
+        t_q = time.perf_counter()
+        for _ in range(n_seq):
+            words_seq = step()
+        fence()
+        dt_seq = time.perf_counter() - t_q
+        ctx.profile_enable(False)
+        seq_spans = {name: ctx.profile_read(name) for name in SPANS}
+        sequential = {"steps": n_seq, "ms_per_step": dt_seq / n_seq * 1e3, "eval_steps_per_s": n * n_seq / dt_seq,
+                      "stages_ms": {k: v[0] / n_seq for k, v in seq_spans.items() if v[1]},
+                      "note": "one proof at a time on one HIP stream (the headline of rounds 1-2), measured in this run before the timed region"}
+        ctx2 = lurk_amd.Context(device_index)
+        if args.profile != "default":
+            from lurk_amd.profile import ProtocolProfile
+
+            ProtocolProfile.preset(args.profile).install(ctx2)
+        m2 = prover.Machine(ctx2, top, entry, len(pv))
+        vk2 = m2.setup()
+        assert vk2 == vk_root
+        prep2 = m2.prepare_shard(all_shards[0])
+        if not args.no_compile:
+            m2.compile_airs(prep2, min_log_rows=args.compile_min_log_rows)  # same programs: served from the in-process code cache
+        lane2 = (m2, ctx2, prep2)
+
+        def one(mach, cx, prep):
+            cx.span_begin("trace_all")
+            traces = mach.run_prepared(prep)
+            cx.span_end("trace_all")
+            handle, root = mach.commit_shard(traces)
+            ch = prover.Challenger(cx)
+            ch.observe(vk_root)
+            ch.observe([0])
+            ch.observe(root)
+            ch.observe(pv)
+            w = mach.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
+            mach.free_shard(handle)
+            cs = shards.proof_cumulative_sums(w)
+            tot = np.zeros(4, dtype=np.int64)
+            for c in cs:
+                tot = (tot + np.asarray(c, dtype=np.int64)) % 2013265921
+            return w, tuple(int(x) for x in tot)
+
+        def run_lanes(k_total, sink):
+            """k_total proofs over the two lanes, each lane taking the next proof as it finishes one."""
+            nxt = [0]
+            lock = threading.Lock()
+            errors = []
+
+            def worker(mach, cx, prep):
+                try:
+                    while True:
+                        with lock:
+                            if nxt[0] >= k_total:
+                                break
+                            nxt[0] += 1
+                        sink.append(one(mach, cx, prep))
+                    cx.sync()
+                except BaseException as e:  # surfaced after the join
+                    errors.append(e)
+
+            ths = [threading.Thread(target=worker, args=(machine, ctx, prepared)), threading.Thread(target=worker, args=(m2, ctx2, prep2))]
+            for th in ths:
+                th.start()
+            for th in ths:
+                th.join()
+            if errors:
+                raise errors[0]
+
+        run_lanes(2, [])  # warm both lanes (pools, tables)
+        fence()
+        ctx2.sync()
     ctx.profile_reset()
     ctx.profile_enable(not args.no_spans)
     if lane_ctx is not None:  # the second proving lane's stages count too
         lane_ctx.profile_reset()
         lane_ctx.profile_enable(not args.no_spans)
+    if lane2 is not None:
+        lane2[1].profile_reset()
+        lane2[1].profile_enable(not args.no_spans)
     t0 = time.perf_counter()
     words = None
     step_words = []
     step_ms = []
-    for _ in range(args.steps):
-        t_s = time.perf_counter()
-        words = step()
-        step_ms.append((time.perf_counter() - t_s) * 1e3)
-        step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
+    if lanes == 2:
+        results = []
+        run_lanes(args.steps, results)
+        lane2[1].sync()
+        step_words = [w for w, _ in results] + [words_seq]
+        words = step_words[0]
+        grand_sums += [g for _, g in results]
+    else:
+        for _ in range(args.steps):
+            t_s = time.perf_counter()
+            words = step()
+            step_ms.append((time.perf_counter() - t_s) * 1e3)
+            step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
     fence()
     elapsed = time.perf_counter() - t0
     proofs_identical = all(len(w) == len(step_words[0]) and bool((w == step_words[0]).all()) for w in step_words[1:])
@@ -360,6 +462,11 @@ def main():
                      "grand_sum_of_gathered_proofs_is_zero": bool((tot == 0).all()), "proof_words_total": int(sum(len(w) for w in got))}
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
+    if lane2 is not None:
+        lane2[1].profile_enable(False)
+        for name in SPANS:
+            ms, cnt = lane2[1].profile_read(name)
+            spans[name] = (spans[name][0] + ms, spans[name][1] + cnt)
     if lane_ctx is not None:
         lane_ctx.profile_enable(False)
         for name in SPANS:
@@ -399,7 +506,9 @@ def main():
     rounds = rounds_all[0]
     hash_bytes_step = sum(merkle_hash_bytes(r)[0] for rs in rounds_all for r in rs)
     hash_launches_step = sum(merkle_hash_bytes(r)[1] for rs in rounds_all for r in rs)
-    hash_ms_step = (spans["merkle_leaves"][0] + spans["merkle_levels"][0]) / args.steps
+    # the live roofline spans: the kernels alone on the device (the sequential pass when two proofs are in flight in the timed region)
+    rs, rs_steps = (seq_spans, sequential["steps"]) if seq_spans is not None else (spans, args.steps)
+    hash_ms_step = (rs["merkle_leaves"][0] + rs["merkle_levels"][0]) / rs_steps
     achieved = hash_bytes_step / (hash_ms_step * 1e-3) / 1e9 if hash_ms_step > 0 else 0.0
     # second-largest kernel family, the coset LDE passes (k_ntt_pass).  SURVEY.md 8(d) prices an LDE (blow-up 2) at read 4w +
     # write 8w bytes per trace row = 12 w B/row: that is `algorithmic`.  `pass_traffic` is what the implementation moves:
@@ -412,7 +521,7 @@ def main():
             log_n = lg - LOG_BLOWUP
             lde_alg_bytes += 12 * w * (1 << log_n)
             lde_pass_bytes += 3 * max(1, -(-log_n // ntt_log_tile)) * 2 * (1 << log_n) * w * 4
-    lde_ms_step = spans["lde"][0] / args.steps
+    lde_ms_step = rs["lde"][0] / rs_steps
     lde_alg = lde_alg_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     lde_pass = lde_pass_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     traffic, valu, lde_traffic = None, None, None
@@ -435,60 +544,6 @@ def main():
                     "source": "profiles (static): SQ_INSTS_VALU x 64 lanes / kernel time"}
     except Exception:
         pass
-
-    # Extra (N = 1 only, never `value`): two shards proved concurrently on two HIP streams of the one GPU, the way a multi-shard
-    # proof keeps the device busy through each shard's latency chains (tree tails, FRI layers, host transcript round trips).
-    two_in_flight = None
-    if world == 1 and spr == 1 and not args.no_two_in_flight:
-        try:
-            import threading
-
-            ctx2 = lurk_amd.Context(device_index)
-            m2 = prover.Machine(ctx2, top, entry, len(pv))
-            vk2 = m2.setup()
-            prep2 = m2.prepare_shard(all_shards[0])
-            if not args.no_compile:
-                m2.compile_airs(prep2)  # same programs: served from the in-process code cache
-
-            def one(mach, cx, prep, vk):
-                traces = mach.run_prepared(prep)
-                handle, root = mach.commit_shard(traces)
-                ch = prover.Challenger(cx)
-                ch.observe(vk)
-                ch.observe([0])
-                ch.observe(root)
-                ch.observe(pv)
-                w = mach.prove_shard(handle, ch, pv, num_queries=args.queries, pow_bits=args.pow_bits, parse=False)
-                mach.free_shard(handle)
-                return w
-
-            in_flight_ok = []  # both lanes prove the timed region's shard: every proof must be that proof
-
-            def worker(mach, cx, prep, vk, k):
-                for _ in range(k):
-                    w = one(mach, cx, prep, vk)
-                    in_flight_ok.append(len(w) == len(words) and bool((w == words).all()))
-                cx.sync()
-
-            for k in (1, args.steps):  # warm-up pass, then the timed one
-                ths = [threading.Thread(target=worker, args=(machine, ctx, prepared, vk_root, k)),
-                       threading.Thread(target=worker, args=(m2, ctx2, prep2, vk2, k))]
-                torch.cuda.synchronize()
-                t1 = time.perf_counter()
-                for th in ths:
-                    th.start()
-                for th in ths:
-                    th.join()
-                torch.cuda.synchronize()
-                dt2 = time.perf_counter() - t1
-            two_in_flight = {"shards": 2 * args.steps, "ms_per_shard": dt2 / (2 * args.steps) * 1e3, "eval_steps_per_s": 2 * n * args.steps / dt2,
-                             "proofs_match_sequential": bool(in_flight_ok) and all(in_flight_ok),
-                             "note": "the same shard proved on two HIP streams of the one GPU concurrently; not the headline value"}
-            del prep2
-            m2.close()
-            ctx2.close()
-        except Exception as e:
-            two_in_flight = {"error": repr(e)}
 
     # Extra (N = 1 only, never `value`): the host side of the path.  ONE execution of pipeline_shards x 2^log_rows eval rows,
     # sharded; (a) every shard's inputs staged beforehand (the resident-input reference), (b) streamed: a staging thread
@@ -572,7 +627,7 @@ def main():
                 "workload_detail": workload_desc,
                 "chips": chips_desc,
                 "main_columns_per_eval_row": main_cols_per_eval_row,
-                "stages_ms": {k: v[0] / args.steps for k, v in spans.items() if v[1]},
+                "stages_ms": sequential["stages_ms"] if sequential else {k: v[0] / args.steps for k, v in spans.items() if v[1]},
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),
                 "shards": len(all_shards),
@@ -602,7 +657,13 @@ def main():
                 "compiled_air_chips": compiled,
                 "compiled_trace_chips": list(machine.compiled_traces),
                 "air_compile_s": t_jit,
-                "two_shards_in_flight": two_in_flight,
+                "proofs_in_flight": lanes,
+                "schedule": ("the K timed steps are K independent proofs of the shard, two in flight on two HIP streams / contexts of the GPU (prove lanes); "
+                             "`sequential` is one proof at a time, measured before the timed region; stages_ms / roofline.hbm come from that sequential pass "
+                             "(a kernel alone on the device), stages_ms_in_flight from the timed region (spans of the two lanes overlap in time)") if lanes == 2
+                            else "one proof at a time on one HIP stream",
+                "sequential": sequential,
+                "stages_ms_in_flight": {k: v[0] / args.steps for k, v in spans.items() if v[1]} if lanes == 2 else None,
                 "host_pipeline": host_pipeline,
             },
             # The dominant kernels (Merkle hashing) are int32-VALU-issue-bound: the headline fraction is against the instruction-mix
@@ -640,6 +701,11 @@ def main():
     if distributed:
         dist.destroy_process_group()
     del prepared, prepared_all
+    if lane2 is not None:
+        m2_, ctx2_, prep2_ = lane2
+        del prep2_, lane2
+        m2_.close()
+        ctx2_.close()
     if lane_ctx is not None:
         lane_ctx.close()
     machine.close()

@@ -25,6 +25,7 @@ for k in keys:
 for _, d in rows:
     c = d["config"]
     print({k: c.get(k) for k in ("proofs_identical_across_steps", "grand_sum_is_zero", "host_execute_s", "host_flatten_upload_s")},
-          "two_in_flight:", (c.get("two_shards_in_flight") or {}).get("ms_per_shard"))
+          "in flight:", c.get("proofs_in_flight"), "sequential ms:", (c.get("sequential") or {}).get("ms_per_step"),
+          "(r02 two_in_flight:", (c.get("two_shards_in_flight") or {}).get("ms_per_shard"), ")")
     if c.get("host_pipeline"):
         print("host_pipeline:", c["host_pipeline"])
