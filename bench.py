@@ -173,7 +173,7 @@ def main():
     ap.add_argument("--pow-bits", type=int, default=16)
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-spans", action="store_true", help="diagnostic: no per-stage HIP events in the timed region (stages_ms and roofline read 0)")
-    ap.add_argument("--lanes", type=int, choices=(1, 2), default=2,
+    ap.add_argument("--lanes", type=int, choices=(1, 2, 3, 4), default=2,
                     help="N = 1: proofs in flight during the timed steps (2 = the K steps are K independent proofs of the shard dealt to two HIP "
                          "streams of the GPU, the way Machine.prove / prove_lanes run a multi-shard proof; 1 = one proof at a time)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; same as --lanes 1)")
@@ -317,11 +317,11 @@ def main():
     # trips) the other's big kernels fill the device; this is how Machine.prove runs every multi-shard proof and how a rank of the
     # N > 1 bench proves its two shards.  A short one-proof-at-a-time pass comes first, for the stage table, the live roofline
     # spans (a kernel alone on the device) and the `sequential` number reported beside the headline.
-    lanes = 2 if (world == 1 and spr == 1 and args.lanes == 2 and not args.no_two_in_flight) else 1
+    lanes = args.lanes if (world == 1 and spr == 1 and args.lanes >= 2 and not args.no_two_in_flight) else 1
     sequential = None
     seq_spans = None
     lane2 = None
-    if lanes == 2:
+    if lanes >= 2:
         import threading
 
         n_seq = max(3, min(5, args.steps))
@@ -337,18 +337,21 @@ def main():
         sequential = {"steps": n_seq, "ms_per_step": dt_seq / n_seq * 1e3, "eval_steps_per_s": n * n_seq / dt_seq,
                       "stages_ms": {k: v[0] / n_seq for k, v in seq_spans.items() if v[1]},
                       "note": "one proof at a time on one HIP stream (the headline of rounds 1-2), measured in this run before the timed region"}
-        ctx2 = lurk_amd.Context(device_index)
-        if args.profile != "default":
-            from lurk_amd.profile import ProtocolProfile
+        extra_lanes = []
+        for _ in range(lanes - 1):
+            ctx2 = lurk_amd.Context(device_index)
+            if args.profile != "default":
+                from lurk_amd.profile import ProtocolProfile
 
-            ProtocolProfile.preset(args.profile).install(ctx2)
-        m2 = prover.Machine(ctx2, top, entry, len(pv))
-        vk2 = m2.setup()
-        assert vk2 == vk_root
-        prep2 = m2.prepare_shard(all_shards[0])
-        if not args.no_compile:
-            m2.compile_airs(prep2, min_log_rows=args.compile_min_log_rows)  # same programs: served from the in-process code cache
-        lane2 = (m2, ctx2, prep2)
+                ProtocolProfile.preset(args.profile).install(ctx2)
+            m2 = prover.Machine(ctx2, top, entry, len(pv))
+            vk2 = m2.setup()
+            assert vk2 == vk_root
+            prep2 = m2.prepare_shard(all_shards[0])
+            if not args.no_compile:
+                m2.compile_airs(prep2, min_log_rows=args.compile_min_log_rows)  # same programs: served from the in-process code cache
+            extra_lanes.append((m2, ctx2, prep2))
+        lane2 = extra_lanes
 
         def one(mach, cx, prep):
             cx.span_begin("trace_all")
@@ -386,7 +389,7 @@ def main():
                 except BaseException as e:  # surfaced after the join
                     errors.append(e)
 
-            ths = [threading.Thread(target=worker, args=(machine, ctx, prepared)), threading.Thread(target=worker, args=(m2, ctx2, prep2))]
+            ths = [threading.Thread(target=worker, args=(machine, ctx, prepared))] + [threading.Thread(target=worker, args=l) for l in extra_lanes]
             for th in ths:
                 th.start()
             for th in ths:
@@ -394,25 +397,27 @@ def main():
             if errors:
                 raise errors[0]
 
-        run_lanes(2, [])  # warm both lanes (pools, tables)
+        run_lanes(2 * lanes, [])  # warm every lane (pools, tables)
         fence()
-        ctx2.sync()
+        for _, cx_, _ in extra_lanes:
+            cx_.sync()
     ctx.profile_reset()
     ctx.profile_enable(not args.no_spans)
     if lane_ctx is not None:  # the second proving lane's stages count too
         lane_ctx.profile_reset()
         lane_ctx.profile_enable(not args.no_spans)
-    if lane2 is not None:
-        lane2[1].profile_reset()
-        lane2[1].profile_enable(not args.no_spans)
+    for _, cx_, _ in (lane2 or []):
+        cx_.profile_reset()
+        cx_.profile_enable(not args.no_spans)
     t0 = time.perf_counter()
     words = None
     step_words = []
     step_ms = []
-    if lanes == 2:
+    if lanes >= 2:
         results = []
         run_lanes(args.steps, results)
-        lane2[1].sync()
+        for _, cx_, _ in lane2:
+            cx_.sync()
         step_words = [w for w, _ in results] + [words_seq]
         words = step_words[0]
         grand_sums += [g for _, g in results]
@@ -462,10 +467,10 @@ def main():
                      "grand_sum_of_gathered_proofs_is_zero": bool((tot == 0).all()), "proof_words_total": int(sum(len(w) for w in got))}
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
-    if lane2 is not None:
-        lane2[1].profile_enable(False)
+    for _, cx_, _ in (lane2 or []):
+        cx_.profile_enable(False)
         for name in SPANS:
-            ms, cnt = lane2[1].profile_read(name)
+            ms, cnt = cx_.profile_read(name)
             spans[name] = (spans[name][0] + ms, spans[name][1] + cnt)
     if lane_ctx is not None:
         lane_ctx.profile_enable(False)
@@ -658,12 +663,12 @@ def main():
                 "compiled_trace_chips": list(machine.compiled_traces),
                 "air_compile_s": t_jit,
                 "proofs_in_flight": lanes,
-                "schedule": ("the K timed steps are K independent proofs of the shard, two in flight on two HIP streams / contexts of the GPU (prove lanes); "
+                "schedule": (f"the K timed steps are K independent proofs of the shard, {lanes} in flight on {lanes} HIP streams / contexts of the GPU (prove lanes); "
                              "`sequential` is one proof at a time, measured before the timed region; stages_ms / roofline.hbm come from that sequential pass "
-                             "(a kernel alone on the device), stages_ms_in_flight from the timed region (spans of the two lanes overlap in time)") if lanes == 2
+                             "(a kernel alone on the device), stages_ms_in_flight from the timed region (spans of the lanes overlap in time)") if lanes >= 2
                             else "one proof at a time on one HIP stream",
                 "sequential": sequential,
-                "stages_ms_in_flight": {k: v[0] / args.steps for k, v in spans.items() if v[1]} if lanes == 2 else None,
+                "stages_ms_in_flight": {k: v[0] / args.steps for k, v in spans.items() if v[1]} if lanes >= 2 else None,
                 "host_pipeline": host_pipeline,
             },
             # The dominant kernels (Merkle hashing) are int32-VALU-issue-bound: the headline fraction is against the instruction-mix
@@ -701,9 +706,9 @@ def main():
     if distributed:
         dist.destroy_process_group()
     del prepared, prepared_all
-    if lane2 is not None:
-        m2_, ctx2_, prep2_ = lane2
-        del prep2_, lane2
+    while lane2:
+        m2_, ctx2_, prep2_ = lane2.pop()
+        del prep2_
         m2_.close()
         ctx2_.close()
     if lane_ctx is not None:
