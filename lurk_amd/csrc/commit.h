@@ -53,7 +53,18 @@ struct NttBatch {
     // row-major; scratch_tiled: scratch[m] holds ntt_tiled_words(log_n, w) words and the matrix between two passes goes there
     // tiled.  Only for shapes with ntt_tiled_words != 0.
     bool src_tiled = false, dst_tiled = false, scratch_tiled = false;
+    // For the fused LDE pass (ntt_lde_fused): reversed_schedule cuts the row bits into the same pass sizes, smallest first (so
+    // that the LAST pass of an inverse transform is as tall as the FIRST of the forward one); skip_last_pass stops before the last
+    // pass (its output goes to dst, in bit-reversed order so far); skip_first_pass starts at the second pass, src holding the
+    // first pass's output.
+    bool reversed_schedule = false, skip_last_pass = false, skip_first_pass = false;
 };
+// The last pass of the inverse transform of b.n matrices (inter[m]: output of its earlier passes), the coset scalings and the
+// first pass of each of the two forward transforms in one launch per column part (ntt.hip: k_ntt_fused); out[m][q] receives the
+// first-pass output of coset q.  *done = false when the shape is not eligible (nothing launched).
+int32_t ntt_lde_fused(lurkhip_ctx* ctx, const NttPlan& plan, int n, const uint32_t* const* inter, uint32_t* const (*out)[2],
+                      const uint32_t* const (*scale)[2], int w, bool* done);
+bool ntt_lde_fused_eligible(int log_n, int w);
 // words of the chunk-tiled form of a 2^log_n x w matrix under the NTT's column-chunk plan, or 0 when the shape is not tiled
 // (a single chunk, odd widths, chunks wider than a 128-byte line, one-pass transforms)
 size_t ntt_tiled_words(int log_n, int w);

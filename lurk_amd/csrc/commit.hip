@@ -113,7 +113,8 @@ int32_t extend(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, const uint32_
 // transfers of an LDE only the first read (the caller's row-major trace) and the last two writes (the committed row-major
 // LDE) keep unaligned row segments.
 int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batch, const uint32_t* const* evals, bool canonical,
-                  uint32_t* const* coefs, uint32_t* const* ldes, const uint32_t* shifts_m, bool* done, size_t coef_tiled_words) {
+                  uint32_t* const* coefs, uint32_t* const* ldes, const uint32_t* shifts_m, bool* done, size_t coef_tiled_words,
+                  bool coefs_wanted) {
     const NttPlan* plan = nullptr;
     LH_TRY(get_ntt_plan(ctx, log_n, &plan));
     const size_t n = (size_t)1 << log_n;
@@ -140,6 +141,35 @@ int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batc
         b.src[m] = evals[m];
         b.dst[m] = coefs[m];
         b.scratch[m] = ldes[m];
+    }
+    // Fused route (round 3, ntt.hip: k_ntt_fused): the inverse's last pass, the coset scalings and both forward first passes in
+    // one launch; coefs[m] is only the inverse's intermediate buffer then (never holds coefficients).
+    if (!tiled && !coefs_wanted && log_blowup == 1 && ntt_lde_fused_eligible(log_n, w)) {
+        NttBatch inv = b;
+        inv.reversed_schedule = true;
+        inv.skip_last_pass = true;
+        for (int m = 0; m < n_batch; m++) inv.scratch[m] = nullptr;
+        LH_TRY(ntt_dif_batch(ctx, *plan, /*inverse=*/true, inv, w, canonical, false, /*bitrev_store=*/false));
+        uint32_t* outs[NTT_MAX_BATCH][2];
+        const uint32_t* scales[NTT_MAX_BATCH][2];
+        for (int m = 0; m < n_batch; m++)
+            for (int q = 0; q < 2; q++) {
+                outs[m][q] = cosets[q].dst[m];
+                scales[m][q] = cosets[q].row_scale[m];
+            }
+        bool fused = false;
+        LH_TRY(ntt_lde_fused(ctx, *plan, n_batch, coefs, outs, scales, w, &fused));
+        if (!fused) return set_error(ctx, LURKHIP_ERR_HIP, "fused LDE pass refused a shape it declared eligible");
+        for (NttBatch e : cosets) {
+            for (int m = 0; m < n_batch; m++) {
+                e.src[m] = e.dst[m];
+                e.row_scale[m] = nullptr;
+            }
+            e.skip_first_pass = true;
+            LH_TRY(ntt_dif_batch(ctx, *plan, /*inverse=*/false, e, w, false, false, /*bitrev_store=*/false));
+        }
+        *done = true;
+        return LURKHIP_OK;
     }
     b.dst_tiled = b.scratch_tiled = tiled;
     std::vector<void*> temps;
@@ -525,7 +555,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                 }
                 bool done = false;
                 TRY_C(lde_batch(ctx, (int)kv.first.first, (int)kv.first.second, log_blowup, nb, ev, repr == LURKHIP_REPR_CANONICAL, co, ld, sh, &done,
-                                coef_words[idx[at]]));
+                                coef_words[idx[at]], keep_coeffs != 0));
                 if (done)
                     for (int m = 0; m < nb; m++) extended[idx[at + m]] = 1;
             }

@@ -373,6 +373,143 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     }
 }
 
+// ---------------------------------------------------------------- fused pass of the LDE (round 3)
+// The LAST pass of the inverse transform and the FIRST pass of every coset's forward transform in one kernel, the coefficients
+// never leaving the chip: a tile of the inverse's last pass (2^LOG_R consecutive storage rows s = hi << LOG_R | t) holds, after
+// its stages, the coefficients k = bitrev_r(t) << (log_n - LOG_R) | bitrev(hi) -- every value of the top LOG_R bits of k for one
+// value of the rest, i.e. exactly a tile of a forward first pass (rows t' << bit_lo_f | lo with lo = bitrev(hi)), its rows in
+// bit-reversed order.  Per tile: rows -> LDS, inverse stages, tile back into the staging registers, then per coset: registers x
+// that coset's scale (s_q^k / N) -> LDS at the bit-reversed local row, forward stages, store as the forward transform's
+// first-pass output.  Of the twelve matrix transfers of an LDE (three transforms x two passes x read + write) three go: the
+// inverse's coefficient write and both cosets' coefficient reads; the coefficient buffer itself is never written.
+struct FusedArgs {
+    const uint32_t* in[NTT_MAX_BATCH];       // output of the inverse transform's earlier passes (N x w, bit-reversed order so far)
+    uint32_t* out[NTT_MAX_BATCH][2];         // per coset: first-pass output of its forward transform (N x w)
+    const uint32_t* scale[NTT_MAX_BATCH][2];  // per coset: s_q^k / N, k < N
+    const uint32_t *tw_inv, *tw_fwd;          // N/2 powers of the inverse / forward root
+    int log_n, w, n_cosets;
+    int col0, col_chunk, n_chunks;
+    uint32_t magic_cv, n_tiles, xcd_run;
+};
+
+template <int LOG_R, class T, bool BIG>
+__device__ __forceinline__ void ntt_fused_body(const FusedArgs& a) {
+    using boff_t = typename std::conditional<BIG, size_t, uint32_t>::type;
+    constexpr int R = 1 << LOG_R;
+    constexpr int RP = R + 1;
+    constexpr int EW = (int)(sizeof(T) / 4);
+    constexpr int U = R < 8 ? R : (LOG_R > 9 ? R / LURK_NTT_TALL_SLOTS : 8);
+    constexpr int SLOTS = R / U;
+    constexpr int LOG_U = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - LURK_NTT_TALL_LOG_SLOTS : 3);
+    constexpr int LOG_SLOTS = LOG_R - LOG_U;
+    static_assert(SLOTS <= 64, "a column's row slots are lanes of one wave");
+    extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
+    T* tile = reinterpret_cast<T*>(smem);
+    const int Cv = a.col_chunk / EW;
+    uint32_t* tw_i = smem + (size_t)Cv * RP * EW;  // inverse twiddles of the pass: the same for every tile (bit_lo = 0)
+    uint32_t* tw_f = tw_i + R;                     // forward twiddles of the tile
+    const int hi_bits = a.log_n - LOG_R;           // = bit_lo of the forward first pass
+    const int slot_raw = fast_div(threadIdx.x, a.magic_cv, Cv), cv = (int)threadIdx.x - slot_raw * Cv;
+    const bool active = slot_raw < SLOTS;
+    const int slot = active ? slot_raw : SLOTS - 1;
+    T* __restrict__ my_col = tile + cv * RP;
+    const int st_cv = (int)threadIdx.x >> LOG_SLOTS, st_slot = (int)threadIdx.x & (SLOTS - 1);
+    const bool st_active = st_cv < Cv;
+    T* __restrict__ st_col = tile + (st_active ? st_cv : 0) * RP;
+
+    const uint32_t wg = a.xcd_run ? (blockIdx.x >> 3) : blockIdx.x;
+    const uint32_t wgs = a.xcd_run ? (gridDim.x >> 3) : gridDim.x;
+    const uint32_t run = a.xcd_run ? a.xcd_run : a.n_tiles;
+    const uint32_t run0 = a.xcd_run ? (blockIdx.x & 7u) * a.xcd_run : 0u;
+    if (wg >= run) return;
+    const uint32_t my_tiles = (run - wg + wgs - 1) / wgs;
+    // one twiddle per thread (the launch has at least R threads): entry k = (1 << s) + t_lo of stage s
+    const int twk = (int)threadIdx.x;
+    const bool tw_ok = twk < R && twk != 0;
+    const int tw_s = 31 - __clz(twk | 1);
+    const uint32_t tw_tlo = (uint32_t)twk - (1u << tw_s);
+    if (tw_ok) tw_i[twk] = a.tw_inv[(size_t)tw_tlo << (a.log_n - tw_s - 1)];  // w_{2h}^j, h = 2^s, j = t_lo
+    auto locate = [&](uint32_t it, uint32_t& hi, boff_t& col) {
+        const uint32_t bid = run0 + wg + it * wgs;
+        hi = bid / (uint32_t)a.n_chunks;
+        const int chunk = (int)(bid - hi * (uint32_t)a.n_chunks);
+        col = (boff_t)(a.col0 + chunk * a.col_chunk + cv * EW);
+    };
+    const char* __restrict__ src = reinterpret_cast<const char*>(a.in[blockIdx.y]);
+    T v[U];
+    auto fetch = [&](uint32_t hi, boff_t col) {
+#pragma unroll
+        for (int k = 0; k < U; k++) {
+            const uint32_t row = (hi << LOG_R) | (uint32_t)(slot + (k << LOG_SLOTS));
+            v[k] = *reinterpret_cast<const T*>(src + ((boff_t)row * (boff_t)a.w + col) * 4);
+        }
+    };
+    uint32_t hi;
+    boff_t col;
+    locate(0, hi, col);
+    fetch(hi, col);
+    for (uint32_t it = 0; it < my_tiles; it++) {
+        const uint32_t lo = hi_bits ? bitrev32(hi, hi_bits) : 0u;  // the forward tile's fixed low bits
+        const boff_t cur_col = col;
+        // forward twiddles of this tile: w_{2h}^j, h = 2^(hi_bits + s), j = t_lo << hi_bits | lo
+        uint32_t twf = 0;
+        if (tw_ok) twf = a.tw_fwd[(size_t)((tw_tlo << hi_bits) | lo) << (a.log_n - hi_bits - tw_s - 1)];
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < U; k++) my_col[swz<LOG_R>(slot + (k << LOG_SLOTS))] = v[k];
+        }
+        __syncthreads();
+        run_stages<LOG_R, LOG_R - 1, SLOTS, T>(st_col, tw_i, st_slot, st_active, [&]() {});
+        __syncthreads();
+        // the tile (coefficients, local row t = coefficient top bits bitrev_r(t)) back into the staging registers
+        if (active) {
+#pragma unroll
+            for (int k = 0; k < U; k++) v[k] = my_col[swz<LOG_R>(slot + (k << LOG_SLOTS))];
+        }
+        if (tw_ok) tw_f[twk] = twf;
+        __syncthreads();
+        for (int q = 0; q < a.n_cosets; q++) {
+            const uint32_t* __restrict__ scale = a.scale[blockIdx.y][q];
+            if (active) {
+#pragma unroll
+                for (int k = 0; k < U; k++) {
+                    const uint32_t tp = bitrev32((uint32_t)(slot + (k << LOG_SLOTS)), LOG_R);  // forward local row
+                    my_col[swz<LOG_R>((int)tp)] = scale_elem(v[k], scale[(tp << hi_bits) | lo]);
+                }
+            }
+            const bool last_q = q + 1 == a.n_cosets;
+            if (last_q) {  // the staging registers are free: the next tile's rows fly under this coset's stages
+                locate(it + 1 < my_tiles ? it + 1 : it, hi, col);
+                fetch(hi, col);
+            }
+            __syncthreads();
+            run_stages<LOG_R, LOG_R - 1, SLOTS, T>(st_col, tw_f, st_slot, st_active, [&]() {});
+            __syncthreads();
+            if (active) {
+                char* __restrict__ dst = reinterpret_cast<char*>(a.out[blockIdx.y][q]);
+                constexpr int UB = U < 4 ? U : 4;
+#pragma unroll
+                for (int k0 = 0; k0 < U; k0 += UB) {
+                    T o[UB];
+#pragma unroll
+                    for (int k = 0; k < UB; k++) o[k] = my_col[swz<LOG_R>(slot + ((k0 + k) << LOG_SLOTS))];
+#pragma unroll
+                    for (int k = 0; k < UB; k++) {
+                        const uint32_t row = ((uint32_t)(slot + ((k0 + k) << LOG_SLOTS)) << hi_bits) | lo;
+                        *reinterpret_cast<T*>(dst + ((boff_t)row * (boff_t)a.w + cur_col) * 4) = o[k];
+                    }
+                }
+            }
+            __syncthreads();
+        }
+    }
+}
+
+template <int LOG_R, class T, bool BIG>
+__global__ __launch_bounds__(LOG_R > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024) void k_ntt_fused(FusedArgs a) {
+    ntt_fused_body<LOG_R, T, BIG>(a);
+}
+
 // tiles of up to 128 rows: two or three workgroups per CU, registers capped for five waves per SIMD
 template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
 __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_WAVES, 8))) void k_ntt_pass(PassArgs a) {
@@ -603,6 +740,18 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     };
     std::vector<std::pair<int, int>> passes;
     schedule(log_n, max_log_r, passes);
+    if (b.reversed_schedule) {  // the same pass sizes, smallest first (top bits first all the same: DIF order)
+        std::vector<int> sizes;
+        for (auto& pr : passes) sizes.push_back(pr.second);
+        std::reverse(sizes.begin(), sizes.end());
+        int remaining = log_n;
+        for (size_t i = 0; i < passes.size(); i++) {
+            remaining -= sizes[i];
+            passes[i] = {remaining, sizes[i]};
+        }
+    }
+    const size_t p_begin = b.skip_first_pass ? 1 : 0, p_end = passes.size() - (b.skip_last_pass ? 1 : 0);
+    LH_ARG(ctx, p_begin <= p_end && !(b.skip_first_pass && b.skip_last_pass && passes.size() < 2), "NTT pass range");
     const int n_full = w / col_chunk, last_w = w % col_chunk;
     // chunk-tiled layouts: only for shapes ntt_tiled_words() admits, cut exactly as it assumes
     const size_t tiled_words = (b.src_tiled || b.dst_tiled || b.scratch_tiled) ? ntt_tiled_words(log_n, w) : 0;
@@ -613,8 +762,8 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
         for (int m = 0; m < b.n; m++) LH_ARG(ctx, b.scratch[m] != nullptr, "tiled intermediates need a scratch buffer");
     const uint32_t* cur_in[NTT_MAX_BATCH] = {};
     for (int m = 0; m < b.n; m++) cur_in[m] = b.src[m];
-    for (size_t p = 0; p < passes.size(); p++) {
-        bool last = p + 1 == passes.size();
+    for (size_t p = p_begin; p < p_end; p++) {
+        bool last = p + 1 == p_end;
         PassArgs a{};
         for (int m = 0; m < b.n; m++) {
             uint32_t* cur_out;
@@ -634,8 +783,8 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
         a.bit_lo = passes[p].first;
         const int log_r = passes[p].second;
         a.in_canonical = (p == 0 && in_canonical) ? 1 : 0;
-        a.out_canonical = (last && out_canonical) ? 1 : 0;
-        a.bitrev_store = (last && bitrev_store) ? 1 : 0;
+        a.out_canonical = (last && out_canonical && !b.skip_last_pass) ? 1 : 0;
+        a.bitrev_store = (last && bitrev_store && !b.skip_last_pass) ? 1 : 0;
         a.magic_w = magic_for(w);
         // narrow matrices: group adjacent rows in the strided passes so that global runs are >= ~256 bytes
         int log_l = 0;
@@ -684,6 +833,101 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
         }
         for (int m = 0; m < b.n; m++) cur_in[m] = a.out[m];
     }
+    return LURKHIP_OK;
+}
+
+template <class T, bool BIG>
+static void launch_fused(int log_r, dim3 blocks, int threads, size_t lds, hipStream_t stream, const FusedArgs& a) {
+    switch (log_r) {
+#define LH_FUSED_CASE(LR)                                                                                                    \
+    case LR: {                                                                                                               \
+        auto kern = k_ntt_fused<LR, T, BIG>;                                                                                 \
+        if (lds > 64 * 1024) {                                                                                               \
+            static bool big_lds_ok = false;                                                                                  \
+            if (!big_lds_ok) {                                                                                               \
+                (void)hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 160 * 1024);        \
+                big_lds_ok = true;                                                                                           \
+            }                                                                                                                \
+        }                                                                                                                    \
+        hipLaunchKernelGGL(kern, blocks, dim3(threads), lds, stream, a);                                                     \
+        break;                                                                                                               \
+    }
+        LH_FUSED_CASE(6) LH_FUSED_CASE(7) LH_FUSED_CASE(8) LH_FUSED_CASE(9) LH_FUSED_CASE(10)
+#undef LH_FUSED_CASE
+    }
+}
+
+// shapes the fused pass takes: at least two passes per transform, first-pass tiles of 2^6 .. 2^10 rows, even widths in more
+// than one column chunk or at least a line wide (narrow matrices keep the row-grouping passes)
+bool ntt_lde_fused_eligible(int log_n, int w) {
+    // off by default (round 3, measured): correct -- the commitment and prover parity tests pass under LURKHIP_NTT_FUSED=1 -- and
+    // slower: the tile's coefficients must survive the first coset's forward stages in the staging registers, on top of the
+    // radix-8 group's sixteen data registers and seven twiddles, and the 128-VGPR kernels spill 164 .. 572 bytes per thread
+    // (2^10-row tiles: 572): lde 13.65 against 10.46 ms per fib-mix step, same box.  With 512-thread workgroups (256 VGPRs,
+    // -DLURK_NTT_TALL_LOG_SLOTS=5) nothing spills but the plain passes are 9 % slower already (11.5 ms).  DESIGN.md 3.3.
+    static const bool enabled = getenv("LURKHIP_NTT_FUSED") != nullptr && atoi(getenv("LURKHIP_NTT_FUSED")) != 0;
+    if (!enabled || w % 2 != 0 || w < 32) return false;
+    const ChunkPlan cp = plan_chunks(log_n, w, true);
+    return cp.n_pass >= 2 && cp.max_log_r >= 6 && cp.max_log_r <= 10;
+}
+
+int32_t ntt_lde_fused(lurkhip_ctx* ctx, const NttPlan& plan, int n, const uint32_t* const* inter, uint32_t* const (*out)[2],
+                      const uint32_t* const (*scale)[2], int w, bool* done) {
+    *done = false;
+    const int log_n = plan.log_n;
+    if (!ntt_lde_fused_eligible(log_n, w)) return LURKHIP_OK;
+    LH_ARG(ctx, n >= 1 && n <= NTT_MAX_BATCH, "NTT batch size");
+    uintptr_t all_ptrs = 0;
+    for (int m = 0; m < n; m++) all_ptrs |= (uintptr_t)inter[m] | (uintptr_t)out[m][0] | (uintptr_t)out[m][1];
+    if ((all_ptrs & 7u) != 0) return LURKHIP_OK;
+    const ChunkPlan cp = plan_chunks(log_n, w, true);
+    const int log_r = cp.max_log_r, col_chunk = cp.col_chunk;
+    std::vector<std::pair<int, int>> passes;
+    schedule(log_n, log_r, passes);
+    if (passes[0].second != log_r) return LURKHIP_OK;  // the forward first pass is the tallest by construction
+    const int n_full = w / col_chunk, last_w = w % col_chunk;
+    const int U = log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8, slots = (1 << log_r) / U;
+    const int max_thr = log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024;
+    FusedArgs a{};
+    for (int m = 0; m < n; m++) {
+        a.in[m] = inter[m];
+        for (int q = 0; q < 2; q++) {
+            a.out[m][q] = out[m][q];
+            a.scale[m][q] = scale[m][q];
+        }
+    }
+    a.tw_inv = plan.tw_inv;
+    a.tw_fwd = plan.tw_fwd;
+    a.log_n = log_n;
+    a.w = w;
+    a.n_cosets = 2;
+    for (int part = 0; part < 2; part++) {
+        if (part == 0 && n_full == 0) continue;
+        if (part == 1 && last_w == 0) continue;
+        a.col0 = part == 0 ? 0 : n_full * col_chunk;
+        a.col_chunk = part == 0 ? col_chunk : last_w;
+        a.n_chunks = part == 0 ? n_full : 1;
+        const bool pair = a.col_chunk % 2 == 0 && a.col0 % 2 == 0;
+        const int cv = a.col_chunk / (pair ? 2 : 1);
+        if (slots * cv > max_thr || (1 << log_r) > max_thr) return set_error(ctx, LURKHIP_ERR_INVALID_ARG, "fused NTT tile shape");
+        a.magic_cv = magic_for(cv);
+        const int threads = std::min(max_thr, (std::max(slots * cv, 1 << log_r) + 63) / 64 * 64);
+        const size_t tiles = ((size_t)1 << (log_n - log_r)) * a.n_chunks;
+        a.n_tiles = (uint32_t)tiles;
+        a.xcd_run = (tiles % 8 == 0 && tiles >= 64) ? (uint32_t)(tiles / 8) : 0u;
+        const size_t lds = ((size_t)a.col_chunk * (((size_t)1 << log_r) + 1) + ((size_t)2 << log_r)) * 4;
+        const int per_cu = std::max(1, std::min(20 / std::max(1, threads / 64), (int)((160 * 1024) / (lds + 256))));
+        size_t blocks = std::min<size_t>(tiles, std::max<size_t>(8, (size_t)per_cu * ctx->num_cus / n));
+        if (a.xcd_run) blocks = blocks / 8 * 8;
+        const bool big = (((size_t)w) << (log_n + 2)) >= ((size_t)1 << 32) || getenv("LURKHIP_NTT_FORCE_64BIT") != nullptr;
+        const dim3 grid((unsigned)blocks, (unsigned)n);
+        if (pair && big) launch_fused<uint2, true>(log_r, grid, threads, lds, ctx->stream, a);
+        else if (pair) launch_fused<uint2, false>(log_r, grid, threads, lds, ctx->stream, a);
+        else if (big) launch_fused<uint32_t, true>(log_r, grid, threads, lds, ctx->stream, a);
+        else launch_fused<uint32_t, false>(log_r, grid, threads, lds, ctx->stream, a);
+        LH_HIP(ctx, hipGetLastError());
+    }
+    *done = true;
     return LURKHIP_OK;
 }
 
