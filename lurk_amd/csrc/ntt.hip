@@ -125,6 +125,23 @@ __device__ __forceinline__ void dif_butterfly(uint2& x, uint2& y, uint32_t tw) {
 #ifndef LURK_NTT_WIDE_SCALAR
 #define LURK_NTT_WIDE_SCALAR 0
 #endif
+// -DLURK_NTT_R9_TWO_PER_CU=1 (round 3, measured and rejected): two workgroups per CU for the 2^9-row tiles -- sixteen rows per
+// thread like the 2^10-row tiles, i.e. 32 row slots x 16 column items = 512 threads and 66 KiB of LDS per workgroup, registers
+// capped at the 128 of four waves per SIMD: two tiles of a CU in different phases of the load / stages / store chain instead of
+// one 1024-thread workgroup using half the CU's LDS.  2^18 x 114: 0.857 against 0.527 ms, lde 12.9 against 10.4 ms per step (a
+// column's 32 row slots are half a wave: twice the stage-group trips per thread, half the lanes per LDS access run).
+#ifndef LURK_NTT_R9_TWO_PER_CU
+#define LURK_NTT_R9_TWO_PER_CU 0
+#endif
+__host__ __device__ constexpr int ntt_rows_per_thread(int log_r) {  // of a column-pair item (the kernel's U)
+    return log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : (LURK_NTT_R9_TWO_PER_CU && log_r == 9 ? 16 : ((1 << log_r) < 8 ? (1 << log_r) : 8));
+}
+__host__ __device__ constexpr int ntt_log_rows_per_thread(int log_r) {
+    return log_r > 9 ? log_r - LURK_NTT_TALL_LOG_SLOTS : (LURK_NTT_R9_TWO_PER_CU && log_r == 9 ? 4 : (log_r < 3 ? log_r : 3));
+}
+__host__ __device__ constexpr int ntt_max_threads(int log_r) {  // the kernels' launch bounds
+    return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : (LURK_NTT_R9_TWO_PER_CU && log_r == 9 ? 512 : 1024);
+}
 template <int LOG_R>
 __host__ __device__ constexpr int swz(int t) {
     if (LOG_R > LURK_NTT_SWZ_MAX_LOG_R) return t;
@@ -221,10 +238,10 @@ __device__ __forceinline__ void ntt_pass_body(const PassArgs& a) {
     // column pairs) stage twice the rows per thread, i.e. the same bytes per thread as a pair item, so that a tile is 32 columns
     // wide either way -- the 107- and 53-column chips take 7 and 4 tiles per row block where 4 and 2 would do.  The 32 staged rows
     // plus 32 row scales put 144 .. 416 bytes of the 128-VGPR kernels into scratch: lde 11.2 -> 11.9 ms per fib-mix step.
-    constexpr int U_PAIR = R < 8 ? R : (LOG_R > 9 ? R / LURK_NTT_TALL_SLOTS : 8);
+    constexpr int U_PAIR = ntt_rows_per_thread(LOG_R);
     constexpr int U = (LURK_NTT_WIDE_SCALAR && EW == 1 && LOG_R >= 4) ? 2 * U_PAIR : U_PAIR;
     constexpr int SLOTS = R / U;              // row slots per workgroup: thread = (slot, column item), slot < SLOTS
-    constexpr int LOG_U_PAIR = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - LURK_NTT_TALL_LOG_SLOTS : 3);
+    constexpr int LOG_U_PAIR = ntt_log_rows_per_thread(LOG_R);
     constexpr int LOG_U = (LURK_NTT_WIDE_SCALAR && EW == 1 && LOG_R >= 4) ? LOG_U_PAIR + 1 : LOG_U_PAIR;
     constexpr int LOG_SLOTS = LOG_R - LOG_U;
     static_assert(SLOTS <= 64, "a column's row slots are lanes of one wave");
@@ -398,9 +415,9 @@ __device__ __forceinline__ void ntt_fused_body(const FusedArgs& a) {
     constexpr int R = 1 << LOG_R;
     constexpr int RP = R + 1;
     constexpr int EW = (int)(sizeof(T) / 4);
-    constexpr int U = R < 8 ? R : (LOG_R > 9 ? R / LURK_NTT_TALL_SLOTS : 8);
+    constexpr int U = ntt_rows_per_thread(LOG_R);
     constexpr int SLOTS = R / U;
-    constexpr int LOG_U = LOG_R < 3 ? LOG_R : (LOG_R > 9 ? LOG_R - LURK_NTT_TALL_LOG_SLOTS : 3);
+    constexpr int LOG_U = ntt_log_rows_per_thread(LOG_R);
     constexpr int LOG_SLOTS = LOG_R - LOG_U;
     static_assert(SLOTS <= 64, "a column's row slots are lanes of one wave");
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
@@ -506,7 +523,7 @@ __device__ __forceinline__ void ntt_fused_body(const FusedArgs& a) {
 }
 
 template <int LOG_R, class T, bool BIG>
-__global__ __launch_bounds__(LOG_R > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024) void k_ntt_fused(FusedArgs a) {
+__global__ __launch_bounds__(ntt_max_threads(LOG_R)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_fused(FusedArgs a) {
     ntt_fused_body<LOG_R, T, BIG>(a);
 }
 
@@ -518,7 +535,7 @@ __global__ __launch_bounds__(1024) __attribute__((amdgpu_waves_per_eu(LURK_NTT_W
 // tiles of 256 .. 1024 rows: one workgroup of up to 16 waves per CU (its LDS tile is most of the CU's 160 KiB), so each wave may
 // use the 128 VGPRs of a 4-waves-per-SIMD kernel -- the 1024-row tiles stage sixteen rows per thread
 template <int LOG_R, class T, bool BIG, bool SCALE, int TWN>
-__global__ __launch_bounds__(LOG_R > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024) void k_ntt_pass_tall(PassArgs a) {
+__global__ __launch_bounds__(ntt_max_threads(LOG_R)) __attribute__((amdgpu_waves_per_eu(4, 4))) void k_ntt_pass_tall(PassArgs a) {
     ntt_pass_body<LOG_R, T, BIG, SCALE, TWN>(a);
 }
 
@@ -631,10 +648,10 @@ static ChunkPlan plan_chunks(int log_n, int w, bool aligned8) {
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
     auto is_pair = [&](int cols) { return aligned8 && cols % 2 == 0; };
     auto rows_per_thread = [](int log_r, bool pair) {  // the kernel's U
-        const int u = log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8;
+        const int u = ntt_rows_per_thread(log_r);
         return (LURK_NTT_WIDE_SCALAR && !pair && log_r >= 4) ? 2 * u : u;
     };
-    auto max_threads = [](int log_r) { return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024; };  // the kernels' launch bounds
+    auto max_threads = [](int log_r) { return ntt_max_threads(log_r); };  // the kernels' launch bounds
     auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r, is_pair(cols))) * items_of(cols); };
     auto lds_bytes = [](int log_r, int cols, int log_l) {
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
@@ -713,10 +730,10 @@ int32_t ntt_dif_batch(lurkhip_ctx* ctx, const NttPlan& plan, bool inverse, const
     auto items_of = [&](int cols) { return (aligned8 && cols % 2 == 0) ? cols / 2 : cols; };
     auto is_pair = [&](int cols) { return aligned8 && cols % 2 == 0; };
     auto rows_per_thread = [](int log_r, bool pair) {  // the kernel's U
-        const int u = log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8;
+        const int u = ntt_rows_per_thread(log_r);
         return (LURK_NTT_WIDE_SCALAR && !pair && log_r >= 4) ? 2 * u : u;
     };
-    auto max_threads = [](int log_r) { return log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024; };  // the kernels' launch bounds
+    auto max_threads = [](int log_r) { return ntt_max_threads(log_r); };  // the kernels' launch bounds
     auto threads_of = [&](int log_r, int cols) { return std::max(1, (1 << log_r) / rows_per_thread(log_r, is_pair(cols))) * items_of(cols); };
     auto lds_bytes = [](int log_r, int cols, int log_l) {
         return ((size_t)cols * (((size_t)1 << log_r) + 1) + ((size_t)1 << (log_r + log_l))) * 4;
@@ -886,8 +903,8 @@ int32_t ntt_lde_fused(lurkhip_ctx* ctx, const NttPlan& plan, int n, const uint32
     schedule(log_n, log_r, passes);
     if (passes[0].second != log_r) return LURKHIP_OK;  // the forward first pass is the tallest by construction
     const int n_full = w / col_chunk, last_w = w % col_chunk;
-    const int U = log_r > 9 ? (1 << log_r) / LURK_NTT_TALL_SLOTS : 8, slots = (1 << log_r) / U;
-    const int max_thr = log_r > 9 ? 16 * LURK_NTT_TALL_SLOTS : 1024;
+    const int U = ntt_rows_per_thread(log_r), slots = (1 << log_r) / U;
+    const int max_thr = ntt_max_threads(log_r);
     FusedArgs a{};
     for (int m = 0; m < n; m++) {
         a.in[m] = inter[m];
