@@ -140,3 +140,17 @@ def test_bench_refuses_more_ranks_than_gpus_and_runs_them_oversubscribed():
         assert line["n_gpus"] == n and "oversubscribed" in cfg["process_group"]
     else:
         assert cfg["rccl_world_size"] == 2
+
+
+def test_bench_two_proofs_in_flight_line_is_complete():
+    """The N = 1 default schedule (--lanes 2) at a small height: the line carries the sequential measurement beside the headline,
+    every proof of the timed region equals the sequential one, the sums cancel."""
+    r = _bench("--gpus", "1", "--lanes", "2", "--no-host-pipeline")
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["n_gpus"] == 1 and cfg["proofs_in_flight"] == 2 and cfg["sequential"]["ms_per_step"] > 0
+    assert cfg["proofs_identical_across_steps"] and cfg["grand_sum_is_zero"]
+    assert set(cfg["stages_ms"]) >= {"commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit"}
+    assert cfg["gathered_proof_set"]["grand_sum_of_gathered_proofs_is_zero"]
+    assert line["roofline"]["frac"] > 0 and line["roofline"]["hbm"]["frac"] > 0
