@@ -309,7 +309,7 @@ void QueryMap::grow() {
     }
 }
 
-uint32_t QueryMap::push(const uint32_t* k, uint32_t n, const QueryResult& v) {
+uint32_t QueryMap::push_hashed(const uint32_t* k, uint32_t n, const QueryResult& v, uint64_t h) {
     if (vals.empty()) key_len = n;
     if (n != key_len) throw ExecError("query table key length changed");
     if ((vals.size() + 1) * 2 > slots.size()) grow();
@@ -317,7 +317,7 @@ uint32_t QueryMap::push(const uint32_t* k, uint32_t n, const QueryResult& v) {
     key_pool.insert(key_pool.end(), k, k + n);
     vals.push_back(v);
     const size_t mask = slots.size() - 1;
-    size_t s = hash(k, n) & mask;
+    size_t s = h & mask;
     while (slots[s]) s = (s + 1) & mask;
     slots[s] = i + 1;
     return i;
@@ -410,8 +410,9 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
     List key, inp, out;  // scratch, reused
     std::vector<Record> chip_requires;
 
-    auto enter = [&](bool preimg, uint32_t callee_index, const List& input) {
-        const uint32_t callee_nonce = q.func_queries[callee_index].insert_full(input, QueryResult());
+    auto enter = [&](bool preimg, uint32_t callee_index, const List& input, uint64_t input_hash) {
+        // (the lookup that brought us here missed: the key is absent, its hash known)
+        const uint32_t callee_nonce = q.func_queries[callee_index].push_hashed(input.data(), (uint32_t)input.size(), QueryResult(), input_hash);
         depth++;
         if (depth == frames.size()) frames.emplace_back();
         Frame* n = &frames[depth];
@@ -475,7 +476,9 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                         inp = key;
                     }
                     QueryMap& cqm = q.func_queries[callee];
-                    int idx = cqm.find(inp);
+                    const uint64_t inp_hash = QueryMap::hash(inp.data(), (uint32_t)inp.size());
+                    if (!cqm.vals.empty() && inp.size() != cqm.key_len) throw ExecError("query table key length changed");
+                    int idx = cqm.find_hashed(inp.data(), (uint32_t)inp.size(), inp_hash);
                     if (idx >= 0) {
                         QueryResult& res = cqm.vals[idx];
                         if (!res.has_output) throw ExecError("Loop detected");
@@ -492,7 +495,7 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                         if (callee_partial) A.hints.push_back(res.depth);
                         if (f->partial && callee_partial) A.depths.push_back(res.depth);
                     } else {
-                        enter(pre, callee, inp);
+                        enter(pre, callee, inp, inp_hash);
                     }
                     break;
                 }
@@ -518,8 +521,9 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                     key.clear();
                     for (uint32_t v : op.a) key.push_back(map[v]);
                     QueryMap& mm = q.mem_queries[mem_index_from_len((uint32_t)key.size())];
-                    int i = mm.find(key);
-                    if (i < 0) i = (int)mm.insert_full(key, QueryResult());
+                    const uint64_t key_hash = QueryMap::hash(key.data(), (uint32_t)key.size());
+                    int i = mm.find_hashed(key.data(), (uint32_t)key.size(), key_hash);
+                    if (i < 0) i = (int)mm.push_hashed(key.data(), (uint32_t)key.size(), QueryResult(), key_hash);
                     uint32_t ptr = (uint32_t)(i + 1);
                     A.map.push_back(ptr);
                     A.hints.push_back(ptr);

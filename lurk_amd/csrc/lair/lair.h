@@ -284,26 +284,39 @@ struct QueryMap {
     BigVec<uint32_t> slots;           // entry index + 1, 0 = empty; power-of-two size
     size_t size() const { return vals.size(); }
     const uint32_t* key(size_t i) const { return key_pool.data() + i * key_len; }
+    // Four independent multiply chains over the key words, folded at the end (round 3: the one-chain hash -- xor, 64-bit
+    // multiply, shift-xor per word, each waiting for the last -- was 35 % of the interpreter under gprof: keys are 8 .. 40 words
+    // and every Call hashes one, every new query three).
     static uint64_t hash(const uint32_t* k, uint32_t n) {
-        uint64_t h = 0x9e3779b97f4a7c15ull ^ n;
-        for (uint32_t i = 0; i < n; i++) {
-            h = (h ^ k[i]) * 0xff51afd7ed558ccdull;
-            h ^= h >> 29;
+        constexpr uint64_t C = 0xff51afd7ed558ccdull;
+        uint64_t h0 = 0x9e3779b97f4a7c15ull ^ n, h1 = 0xc2b2ae3d27d4eb4full, h2 = 0x165667b19e3779f9ull, h3 = 0x85ebca77c2b2ae63ull;
+        uint32_t i = 0;
+        for (; i + 4 <= n; i += 4) {
+            h0 = (h0 ^ k[i]) * C;
+            h1 = (h1 ^ k[i + 1]) * C;
+            h2 = (h2 ^ k[i + 2]) * C;
+            h3 = (h3 ^ k[i + 3]) * C;
         }
-        return h;
+        for (; i < n; i++) h0 = ((h0 ^ k[i]) * C) ^ (h0 >> 31);
+        uint64_t h = (h0 ^ (h1 >> 17) ^ (h1 << 47)) * C;
+        h = (h ^ h2 ^ (h3 >> 29) ^ (h3 << 35)) * C;
+        return h ^ (h >> 32);
     }
-    int find(const uint32_t* k, uint32_t n) const {
+    int find_hashed(const uint32_t* k, uint32_t n, uint64_t h) const {
         if (slots.empty() || n != key_len) return -1;
         const size_t mask = slots.size() - 1;
-        for (size_t s = hash(k, n) & mask;; s = (s + 1) & mask) {
+        for (size_t s = h & mask;; s = (s + 1) & mask) {
             const uint32_t e = slots[s];
             if (!e) return -1;
             if (memcmp(key(e - 1), k, (size_t)n * 4) == 0) return (int)(e - 1);
         }
     }
+    int find(const uint32_t* k, uint32_t n) const { return slots.empty() || n != key_len ? -1 : find_hashed(k, n, hash(k, n)); }
     int find(const List& k) const { return find(k.data(), (uint32_t)k.size()); }
-    // appends a new entry (the key must be absent); returns its index
-    uint32_t push(const uint32_t* k, uint32_t n, const QueryResult& v);
+    // appends a new entry (the key must be absent); returns its index.  push_hashed: with the key's hash already at hand (a
+    // lookup that missed is followed by the insertion of the same key).
+    uint32_t push(const uint32_t* k, uint32_t n, const QueryResult& v) { return push_hashed(k, n, v, hash(k, n)); }
+    uint32_t push_hashed(const uint32_t* k, uint32_t n, const QueryResult& v, uint64_t h);
     // IndexMap::insert_full: replaces the value when the key exists
     uint32_t insert_full(const List& k, const QueryResult& v) {
         int i = find(k);
