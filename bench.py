@@ -177,6 +177,8 @@ def main():
                     help="N = 1: proofs in flight during the timed steps (2 = the K steps are K independent proofs of the shard dealt to two HIP "
                          "streams of the GPU, the way Machine.prove / prove_lanes run a multi-shard proof; 1 = one proof at a time)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; same as --lanes 1)")
+    ap.add_argument("--stagger-ms", type=float, default=0.0,
+                    help="--lanes >= 2: lane k starts its first timed proof k * this many milliseconds late (inside the timed region), so that the lanes run out of phase")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
     ap.add_argument("--compile-min-log-rows", type=int, default=None,
                     help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
@@ -377,8 +379,10 @@ def main():
             lock = threading.Lock()
             errors = []
 
-            def worker(mach, cx, prep):
+            def worker(mach, cx, prep, delay_s=0.0):
                 try:
+                    if delay_s:
+                        time.sleep(delay_s)
                     while True:
                         with lock:
                             if nxt[0] >= k_total:
@@ -389,7 +393,8 @@ def main():
                 except BaseException as e:  # surfaced after the join
                     errors.append(e)
 
-            ths = [threading.Thread(target=worker, args=(machine, ctx, prepared))] + [threading.Thread(target=worker, args=l) for l in extra_lanes]
+            ths = [threading.Thread(target=worker, args=(machine, ctx, prepared))]
+            ths += [threading.Thread(target=worker, args=l + ((k + 1) * args.stagger_ms * 1e-3,)) for k, l in enumerate(extra_lanes)]
             for th in ths:
                 th.start()
             for th in ths:
