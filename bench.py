@@ -177,6 +177,9 @@ def main():
                     help="N = 1: proofs in flight during the timed steps (2 = the K steps are K independent proofs of the shard dealt to two HIP "
                          "streams of the GPU, the way Machine.prove / prove_lanes run a multi-shard proof; 1 = one proof at a time)")
     ap.add_argument("--no-two-in-flight", action="store_true", help="(accepted for old command lines; same as --lanes 1)")
+    ap.add_argument("--rank-pipeline", action="store_true",
+                    help="N > 1 (or --shards-per-rank > 1): phase 1 of machine proof j + 1 under phase 2 of proof j on a second machine (measured on one "
+                         "GPU through RCCL at world 1: 47.9 against 46.4 ms per step -- phase 2 already keeps two shards in flight; off by default)")
     ap.add_argument("--stagger-ms", type=float, default=0.0,
                     help="--lanes >= 2: lane k starts its first timed proof k * this many milliseconds late (inside the timed region), so that the lanes run out of phase")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
@@ -297,6 +300,26 @@ def main():
         proofs = rank_step()
         return np.concatenate(proofs) if len(proofs) > 1 else proofs[0]
 
+    # Ranks with several shards (the N > 1 schedule): a second machine on its own contexts, so that phase 1 of machine proof j + 1
+    # (traces + main commitments: throughput-bound) runs under phase 2 of proof j (latency chains, and a light last shard whose
+    # lane idles early) -- shards.run_pipelined.  All collectives stay on this thread, in the same order on every rank.
+    pipe = None
+    if len(mine) > 1 and args.rank_pipeline:
+        ctx_b = lurk_amd.Context(device_index)
+        if args.profile != "default":
+            from lurk_amd.profile import ProtocolProfile
+
+            ProtocolProfile.preset(args.profile).install(ctx_b)
+        machine_b = prover.Machine(ctx_b, top, entry, len(pv))
+        assert machine_b.setup() == vk_root
+        prepared_b = [machine_b.prepare_shard(all_shards[i]) for i in mine]
+        if not args.no_compile:
+            for pr in prepared_b:
+                machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
+        lane_ctx_b = prover.lane_context(machine_b)
+        rank_step_b = shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b)
+        pipe = {"steps": [rank_step, rank_step_b], "ctxs": [ctx_b, lane_ctx_b], "machine": machine_b, "prepared": prepared_b}
+
     def fence():
         ctx.sync()
         torch.cuda.synchronize()
@@ -313,6 +336,10 @@ def main():
     fence()  # (the first barrier of a process group sets RCCL up lazily; its aftermath showed up as a 90 ms first timed step)
     for _ in range(args.warmup):
         step()
+    if pipe is not None:  # warm the second machine and the pipeline's worker
+        shards.run_pipelined(pipe["steps"], 2)
+        for cx_ in pipe["ctxs"]:
+            cx_.sync()
     fence()
     # N = 1, --lanes 2 (default): the K timed steps are K independent proofs of the shard with TWO IN FLIGHT, each lane on its own
     # context (HIP stream, pool, host thread) -- while one proof sits in a latency chain (tree tails, FRI layers, transcript round
@@ -414,6 +441,9 @@ def main():
     for _, cx_, _ in (lane2 or []):
         cx_.profile_reset()
         cx_.profile_enable(not args.no_spans)
+    for cx_ in (pipe["ctxs"] if pipe else []):
+        cx_.profile_reset()
+        cx_.profile_enable(not args.no_spans)
     t0 = time.perf_counter()
     words = None
     step_words = []
@@ -426,6 +456,14 @@ def main():
         step_words = [w for w, _ in results] + [words_seq]
         words = step_words[0]
         grand_sums += [g for _, g in results]
+    elif pipe is not None:
+        def keep(j, proofs):
+            step_words.append(np.concatenate(proofs) if len(proofs) > 1 else proofs[0])
+
+        shards.run_pipelined(pipe["steps"], args.steps, on_proofs=keep)
+        for cx_ in pipe["ctxs"]:
+            cx_.sync()
+        words = step_words[-1]
     else:
         for _ in range(args.steps):
             t_s = time.perf_counter()
@@ -434,6 +472,15 @@ def main():
             step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
     fence()
     elapsed = time.perf_counter() - t0
+    if pipe is not None:
+        # the second machine's records count too (collectives' host time, sums); the gathered-set check below takes the LAST proof
+        other = pipe["steps"][1]
+        grand_sums += other.grand_sums
+        rank_sums += other.rank_sums
+        for k_, v_ in other.host_ms.items():
+            host_ms[k_] = host_ms.get(k_, 0.0) + v_
+        if (args.steps - 1) % 2 == 1:
+            rank_step = other
     proofs_identical = all(len(w) == len(step_words[0]) and bool((w == step_words[0]).all()) for w in step_words[1:])
     del step_words
     ctx.profile_enable(False)
@@ -472,6 +519,13 @@ def main():
                      "grand_sum_of_gathered_proofs_is_zero": bool((tot == 0).all()), "proof_words_total": int(sum(len(w) for w in got))}
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
+    if pipe is not None:
+        for cx_ in pipe["ctxs"]:
+            cx_.profile_enable(False)
+            for name in SPANS:
+                ms, cnt = cx_.profile_read(name)
+                spans[name] = (spans[name][0] + ms, spans[name][1] + cnt)
+
     for _, cx_, _ in (lane2 or []):
         cx_.profile_enable(False)
         for name in SPANS:
@@ -667,6 +721,8 @@ def main():
                 "compiled_air_chips": compiled,
                 "compiled_trace_chips": list(machine.compiled_traces),
                 "air_compile_s": t_jit,
+                "rank_pipeline": ("phase 1 of machine proof j + 1 (traces + main commitments, on a second machine's context) under phase 2 of proof j; "
+                                  "collectives on one thread in a fixed order" if pipe is not None else None),
                 "proofs_in_flight": lanes,
                 "schedule": (f"the K timed steps are K independent proofs of the shard, {lanes} in flight on {lanes} HIP streams / contexts of the GPU (prove lanes); "
                              "`sequential` is one proof at a time, measured before the timed region; stages_ms / roofline.hbm come from that sequential pass "
@@ -711,6 +767,11 @@ def main():
     if distributed:
         dist.destroy_process_group()
     del prepared, prepared_all
+    if pipe is not None:
+        del pipe["prepared"]
+        pipe["machine"].close()
+        for cx_ in reversed(pipe["ctxs"]):
+            cx_.close()
     while lane2:
         m2_, ctx2_, prep2_ = lane2.pop()
         del prep2_

@@ -124,9 +124,10 @@ class RankStep:
         self.roots = None       # the gathered roots of the last call, in shard order
         self.last_proofs = None  # this rank's proof words of the last call
 
-    def __call__(self, parse=False):
-        import time
-
+    # ---- the four parts of a step; only `exchange` and `check` are collectives
+    def commit(self):
+        """Phase 1 on this rank: traces + main commitments of its shards (GPU work on the machine's context, no collective).
+        Returns the state `prove` continues from."""
         from . import prover
 
         m, ctx = self.machine, self.machine.ctx
@@ -142,15 +143,34 @@ class RankStep:
             handle, root = m.commit_shard(traces)
             handles.append(handle)
             roots.append(root)
+        return {"handles": handles, "roots": roots, "ch": ch}
+
+    def exchange(self, state):
+        """Collective: every shard's main root to every rank, in shard order."""
+        import time
+
         t = time.perf_counter()
-        self.roots = exchange_roots(roots, device=self.device, shard_indices=self.mine)
+        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine)
         self.host_ms["exchange_roots"] = self.host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t) * 1e3
-        for r in self.roots:
+        return self.roots
+
+    def prove(self, state, gathered):
+        """Phase 2 on this rank (GPU work on the machine's context and its second lane, no collective)."""
+        from . import prover
+
+        m, ch = self.machine, state["ch"]
+        for r in gathered:
             ch.observe(r)
             ch.observe(self.pv)
-        proofs = prover.prove_lanes(m, handles, ch, self.pv, self.num_queries, self.pow_bits, parse=False, lane_ctx=self.lane_ctx)
-        for handle in handles:
+        proofs = prover.prove_lanes(m, state["handles"], ch, self.pv, self.num_queries, self.pow_bits, parse=False, lane_ctx=self.lane_ctx)
+        for handle in state["handles"]:
             m.free_shard(handle)
+        return proofs
+
+    def check(self, proofs):
+        """Collective: the cumulative sums of all ranks' proofs, all-reduced; records this rank's own sum and the total."""
+        import time
+
         cs = [c for words in proofs for c in proof_cumulative_sums(words)]
         mine_sum = np.zeros(4, dtype=np.int64)
         for c in cs:
@@ -161,7 +181,45 @@ class RankStep:
         self.host_ms["reduce_sums"] = self.host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t) * 1e3
         self.calls += 1
         self.last_proofs = proofs
+
+    def __call__(self, parse=False):
+        from . import prover
+
+        state = self.commit()
+        gathered = self.exchange(state)
+        proofs = self.prove(state, gathered)
+        self.check(proofs)
         return [prover.parse_proof(w) for w in proofs] if parse else proofs
+
+
+def run_pipelined(steps, n_steps: int, on_proofs=None):
+    """n_steps machine proofs on this rank with phase 1 of proof j + 1 under phase 2 of proof j (round 3).
+
+    `steps` = two RankStep objects over two Machines of the same toplevel (own contexts, own prepared inputs): proof j runs on
+    steps[j % 2].  While proof j is in phase 2 -- latency chains: tree tails, FRI layers, transcript round trips, and with the
+    reference's sharding a light second shard whose lane idles early -- the throughput-bound traces and main commitments of proof
+    j + 1 run on the other machine's context.  Every collective is issued by the calling thread, in the same order on every rank
+    (exchange j, check j, exchange j + 1, ...): the worker thread only proves.  `on_proofs(j, proofs)` sees each proof's words."""
+    from concurrent.futures import ThreadPoolExecutor
+
+    assert len(steps) == 2 and n_steps >= 1
+    pool = ThreadPoolExecutor(max_workers=1, thread_name_prefix="lurkhip-phase2")
+    try:
+        pending = steps[0].commit()
+        for j in range(n_steps):
+            cur = steps[j % 2]
+            gathered = cur.exchange(pending)
+            fut = pool.submit(cur.prove, pending, gathered)
+            try:
+                nxt = steps[(j + 1) % 2].commit() if j + 1 < n_steps else None
+            finally:
+                proofs = fut.result()
+            cur.check(proofs)
+            if on_proofs is not None:
+                on_proofs(j, proofs)
+            pending = nxt
+    finally:
+        pool.shutdown(wait=True)
 
 
 def gather_proofs(words_list, shard_indices, dst: int = 0):

@@ -55,7 +55,19 @@ def _worker(rank, world, port, q):
         words = step()
         words2 = step()  # a second step gives the same proofs
         same = all(len(a) == len(b) and bool((a == b).all()) for a, b in zip(words, words2))
-        gathered = shards.gather_proofs(words, mine, dst=0)
+        # the pipelined schedule of the bench's N > 1 path (shards.run_pipelined): a second machine on its own contexts, phase 1 of
+        # proof j + 1 under phase 2 of proof j, collectives on this thread only -- same proofs
+        ctx_b = lurk_amd.Context(0)
+        m_b = prover.Machine(ctx_b, top, mix.entry, len(pv))
+        assert m_b.setup() == vk_root
+        prepared_b = [m_b.prepare_shard(all_shards[i]) for i in mine]
+        lane_b = prover.lane_context(m_b)
+        step_b = shards.RankStep(m_b, vk_root, pv, prepared_b, mine, num_queries=8, pow_bits=6, device="cpu", lane_ctx=lane_b)
+        piped = []
+        shards.run_pipelined([step, step_b], 3, on_proofs=lambda j, pr: piped.append(pr))
+        same = same and len(piped) == 3 and all(len(a) == len(b) and bool((a == b).all()) for pr in piped for a, b in zip(pr, words))
+        same = same and step_b.grand_sums[-1] == (0, 0, 0, 0) and step_b.rank_sums[-1] == step.rank_sums[-1]
+        gathered = shards.gather_proofs(piped[-1], mine, dst=0)
         out = {"rank": rank, "mine": mine, "rank_sum": step.rank_sums[-1], "grand": step.grand_sums[-1], "same": same, "roots": step.roots}
         if rank == 0:
             from test_workloads_gpu import oracle_airs
@@ -75,8 +87,10 @@ def _worker(rank, world, port, q):
                 out["swapped_rejected"] = True
         q.put(out)
         dist.barrier()
-        for pr in prepared:
-            del pr
+        del prepared, prepared_b
+        lane_b.close()
+        m_b.close()
+        ctx_b.close()
         lane_ctx.close()
         m.close()
         ctx.close()
@@ -128,11 +142,12 @@ def test_bench_refuses_more_ranks_than_gpus_and_runs_them_oversubscribed():
     n = torch.cuda.device_count()
     r = _bench("--gpus", str(n + 1))
     assert r.returncode != 0 and "refusing to run fewer ranks" in (r.stderr + r.stdout)
-    r = _bench("--gpus", "2", "--oversubscribe") if n < 2 else _bench("--gpus", "2")
+    r = _bench("--gpus", "2", "--oversubscribe", "--rank-pipeline") if n < 2 else _bench("--gpus", "2", "--rank-pipeline")
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
     assert line["ranks"] == 2 and line["config"]["shards"] == 4
     cfg = line["config"]
+    assert cfg["rank_pipeline"]
     assert cfg["grand_sum_is_zero"] and cfg["per_rank_sum_nonzero"] and cfg["proofs_identical_across_steps"]
     gs = cfg["gathered_proof_set"]
     assert gs["shards_gathered_on_rank0"] == 4 and gs["main_roots_match_exchanged_roots_in_shard_order"] and gs["grand_sum_of_gathered_proofs_is_zero"]
