@@ -74,8 +74,9 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     accepted by the oracle's verifier and equal to the HIP prover's (tests/test_cpu_step*.py).  Timed on a BOUNDED SAMPLE: the
     same machine with every chip of 2^12 rows and more half as tall (2^(log_rows - 1) eval rows), on synthetic traces of
     those shapes (no stage's cost depends on the values; the constraints need not hold for the openings and FRI to be
-    well-formed).  `value` = sample eval rows / seconds.  Trace generation is not in the port (it needs the interpreter's query
-    record; 2 % of the GPU step) and is reported as null.  kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be
+    well-formed).  `value` = sample eval rows / seconds.  Trace generation of the function chips is oracle/cpu_trace.c (a C row
+    loop over flattened query records, checked word for word against the oracle's generator): a small real execution of the
+    machine through the oracle's interpreter, its rows repeated up to the sample's heights.  kind "port": the reference prover (Rust, sphinx + Plonky3) cannot be
     built here; a tuned CPU prover (packed AVX-512 field, cache-blocked NTTs) would be several times faster per core."""
     from oracle import air as oa
     from oracle import binding as ob
@@ -94,12 +95,39 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     names = [f"Entrypoint[{idx}]"] + [f"Func[{f['name']}]" for f in otop.funcs] + [f"Mem[{ml}-wide]" for ml in ol.MEM_TABLE_SIZES] + ["CPU"]
     pr = cpv.CpuProver(airs, names, n_public, threads=cores)
     rng = np.random.default_rng(0x4C55524B)
+    # trace generation (oracle/cpu_trace.c, checked word for word against the oracle's generator by tests/test_cpu_trace.py): the
+    # function chips' rows from flattened query records -- a small REAL execution of the same machine through the oracle's
+    # interpreter, its rows repeated up to the sample's heights (rows are independent of one another in trace generation)
+    from oracle import cpu_trace as ct
+
+    small_q = ol.QueryRecord(otop)
+    ol.execute(otop, mix.entry, list(mix.main_args), small_q,
+               poseidon=lambda w_, inp: [int(v) for v in ob.p2_permute(w_, np.array(inp, dtype=np.uint32))[0]])
+    t_trace = 0.0
     traces, sample_rows = [], None
     for name, lg, w in chip_shapes:
         mi = names.index(name)
         assert airs[mi].width == w, (name, airs[mi].width, w)
         lgs = lg - CPU_SAMPLE_LOG_SHRINK if lg >= 12 and name != "CPU" else lg
-        traces.append((mi, rng.integers(0, 2013265921, size=(1 << lgs, w), dtype=np.uint32)))
+        mat = None
+        if name.startswith("Func["):
+            fname = name[5:-1]
+            n0, hdr0, hints0, offs0 = ct.flatten(otop, fname, small_q)
+            if n0:
+                prog = ct.FuncProgram(otop, fname)
+                rows_ = 1 << lgs
+                reps = -(-rows_ // n0)
+                lens = np.diff(offs0.astype(np.int64))
+                hdr_t = np.tile(hdr0[:n0], (reps, 1))[:rows_]
+                hints_t = np.tile(hints0[:int(offs0[-1])], reps)
+                offs_t = np.concatenate([[0], np.cumsum(np.tile(lens, reps))]).astype(np.uint64)[:rows_ + 1]
+                hints_t = np.concatenate([hints_t, np.zeros(1, dtype=np.uint32)])
+                t_q = time.perf_counter()
+                mat = ct.run(prog, rows_, hdr_t, hints_t, offs_t, rows_)
+                t_trace += time.perf_counter() - t_q
+        if mat is None:
+            mat = rng.integers(0, 2013265921, size=(1 << lgs, w), dtype=np.uint32)
+        traces.append((mi, mat))
         if name == "Func[eval]":
             sample_rows = 1 << lgs
     i = np.arange(1 << 16)
@@ -111,10 +139,10 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     stages = {}
     t0 = time.perf_counter()
     pr.prove_shard(traces, prep_m, pc, [0] * n_public, ch, num_queries=queries, pow_bits=pow_bits, timings=stages)
-    dt = time.perf_counter() - t0
+    dt = time.perf_counter() - t0 + t_trace
     gpu_names = {"commit_main": "commit_main", "permutation": "permutation", "commit_perm": "commit_perm", "quotient_all": "quotient_all",
                  "commit_quotient": "commit_quotient", "open": "open", "fri_commit": "fri_commit", "pow": "fri_query", "fri_query": "fri_query"}
-    stages_s = {"trace_all": None}
+    stages_s = {"trace_all": t_trace}
     for k, v in stages.items():
         g = gpu_names.get(k, k)
         stages_s[g] = stages_s.get(g, 0.0) + v
@@ -125,8 +153,8 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
         "kind": "port",
         "seconds": dt,
         "stages_s": stages_s,
-        "sample": f"the WHOLE step except trace generation (main / permutation / quotient commitments, LogUp rows, quotient, openings, FRI with {queries} queries and {pow_bits} PoW bits) "
-                  f"on a shard half as tall: 2^{log_rows - CPU_SAMPLE_LOG_SHRINK} eval rows of the {workload} machine, synthetic traces of its shapes; oracle/cpu_prover.py + cpu_step.c, OpenMP over "
+        "sample": f"the WHOLE step (function-chip trace generation from flattened query records, main / permutation / quotient commitments, LogUp rows, quotient, openings, FRI with {queries} queries and {pow_bits} PoW bits) "
+                  f"on a shard half as tall: 2^{log_rows - CPU_SAMPLE_LOG_SHRINK} eval rows of the {workload} machine (a small real execution's rows repeated; memory / byte / entry chips synthetic); oracle/cpu_trace.c + cpu_prover.py + cpu_step.c, OpenMP over "
                   f"{cores} threads, {dt:.1f} s; stage names as in config.stages_s of the GPU line (proof-of-work counted under fri_query; to_montgomery = input conversion); "
                   "not the reference binary (no Rust toolchain): never quote the ratio as 'vs the reference'",
         "evaluator_build_s": pr.build_s,

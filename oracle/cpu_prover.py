@@ -8,9 +8,9 @@ the structure the oracle's verifier consumes (`wire.Shard`), and `stark.verify_m
 (tests/test_cpu_step.py; on the GPU box the same test compares it with the HIP prover's proof field by field).
 
 It is the `cpu_baseline` of bench.py: kind "port" -- neither the reference binary (Rust: not buildable here) nor tuned like
-one (scalar field arithmetic per row, no packed AVX-512 field).  Trace generation is not ported (it needs the interpreter's
-query record; the oracle's generator is Python): the port starts from the traces, like `machine.prove` does after
-`generate_trace`.  Only tests/ and bench.py's cpu_baseline leg import this."""
+one (scalar field arithmetic per row, no packed AVX-512 field).  Trace generation is its own port (oracle/cpu_trace.c, driven
+by oracle/cpu_trace.py from the oracle interpreter's query record); this prover starts from the traces, like `machine.prove`
+does after `generate_trace`.  Only tests/ and bench.py's cpu_baseline leg import this."""
 from __future__ import annotations
 
 import ctypes as C
