@@ -10,8 +10,9 @@
 // kernel then needs no lookups at all (DESIGN.md "row stream").
 #include <algorithm>
 #include <cstring>
-#include <deque>
+#include <mutex>
 #include <new>
+#include <unordered_map>
 
 #include <sys/mman.h>
 
@@ -49,18 +50,18 @@ void huge_free(void* p, size_t bytes) {
 // ------------------------------------------------------------------ byte records (gadgets/bytes/record.rs:112-158)
 void BytesRecord::range_check_u8_pair(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& rq) {
     uint16_t key = (uint16_t)(i1 | (i2 << 8));
-    rq.push_back(at(key).range_u8.new_lookup(nonce));
+    rq.push_back(at(key, BYTES_RANGE_U8).new_lookup(nonce));
 }
 void BytesRecord::range_check_u8_iter(const uint8_t* b, size_t n, uint32_t nonce, std::vector<Record>& rq) {
     for (size_t i = 0; i < n; i += 2) range_check_u8_pair(b[i], i + 1 < n ? b[i + 1] : 0, nonce, rq);
 }
 bool BytesRecord::less_than(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& rq) {
     uint16_t key = (uint16_t)(i1 | (i2 << 8));
-    rq.push_back(at(key).less_than.new_lookup(nonce));
+    rq.push_back(at(key, BYTES_LESS_THAN).new_lookup(nonce));
     return i1 < i2;
 }
 void BytesRecord::range_check_u16(uint16_t v, uint32_t nonce, std::vector<Record>& rq) {
-    rq.push_back(at(v).range_u16.new_lookup(nonce));
+    rq.push_back(at(v, BYTES_RANGE_U16).new_lookup(nonce));
 }
 
 // ------------------------------------------------------------------ host Poseidon2 (for `execute` only)
@@ -302,10 +303,19 @@ void QueryMap::grow() {
     const size_t cap = slots.empty() ? 1024 : slots.size() * 2;
     slots.assign(cap, 0);
     const size_t mask = cap - 1;
+    // bits = 4 x slots -> blocks of 512 bits = cap / 128; the entries waiting for their seat are re-seated with the rest
+    const size_t blocks = cap / 128;
+    uint32_t log_blocks = 0;
+    while (((size_t)1 << log_blocks) < blocks) log_blocks++;
+    bloom.assign(blocks * 8, 0);
+    bloom_shift = 32 - log_blocks;
+    if (log_blocks == 0) throw ExecError("query table index too small for its filter");
+    pending_head = n_pending = 0;
     for (size_t i = 0; i < vals.size(); i++) {
-        size_t s = hash(key(i), key_len) & mask;
+        size_t s = hashes[i] & mask;  // (a table holds fewer than 2^31 entries: the index needs no more than 32 hash bits)
         while (slots[s]) s = (s + 1) & mask;
         slots[s] = (uint32_t)i + 1;
+        bloom_add(hashes[i]);
     }
 }
 
@@ -313,13 +323,25 @@ uint32_t QueryMap::push_hashed(const uint32_t* k, uint32_t n, const QueryResult&
     if (vals.empty()) key_len = n;
     if (n != key_len) throw ExecError("query table key length changed");
     if ((vals.size() + 1) * 2 > slots.size()) grow();
+    if (vals.size() >= 0x7fffffffull) throw ExecError("query table exceeds 2^31 entries");
     const uint32_t i = (uint32_t)vals.size();
-    key_pool.insert(key_pool.end(), k, k + n);
+    key_pool.append(k, n);
     vals.push_back(v);
+    hashes.push_back((uint32_t)h);
+    bloom_add((uint32_t)h);
     const size_t mask = slots.size() - 1;
-    size_t s = h & mask;
-    while (slots[s]) s = (s + 1) & mask;
-    slots[s] = i + 1;
+    if (n_pending == MAX_PENDING) {
+        // the oldest waiting entry takes its seat: its line was requested MAX_PENDING insertions ago
+        const Pending p = pending[pending_head];
+        pending_head = (pending_head + 1) % MAX_PENDING;
+        n_pending--;
+        size_t s = p.h32 & mask;
+        while (slots[s]) s = (s + 1) & mask;
+        slots[s] = p.index + 1;
+    }
+    pending[(pending_head + n_pending) % MAX_PENDING] = Pending{i, (uint32_t)h};
+    n_pending++;
+    __builtin_prefetch(&slots[(uint32_t)h & mask], 1);
     return i;
 }
 
@@ -353,17 +375,159 @@ size_t num_shards(const QueryRecord& r, uint32_t max_shard_size) {
 // ------------------------------------------------------------------ the interpreter (execute.rs:436-784)
 namespace {
 
-// One activation of a Func.  The reference keeps an exec-entry stack plus a caller stack (execute.rs:436-470); a block's
-// control node is always its last entry, so a (block, next op) cursor per activation is the same traversal.  Activations
-// live in a grow-only pool and are reused (their vectors keep their capacity): multi-million-query executions recurse
-// millions of frames deep, and allocating five vectors per call was most of the interpreter's time.
+// Pre-decoded functions.  A function is one flat array of fixed-size operations: a block's operations, its control
+// operation, then the blocks it branches to; operand lists live in one pool.  (Round 3: walking `Block::ops` -- 80-byte
+// `Op`s with two std::vectors each -- and `Ctrl` through shared_ptrs was a fifth of the interpreter's time; runs of constants,
+// which the Lurk toplevel is full of (tags), become one copy.)
+enum XKind : uint32_t {
+    X_ASSERT_EQ, X_ASSERT_NE, X_CONTAINS, X_CONST, X_CONST_RUN, X_ADD, X_SUB, X_MUL, X_INV, X_NOT, X_CALL, X_PREIMG, X_STORE,
+    X_LOAD, X_EXTERN, X_EMIT, X_RANGE_U8, X_CHOOSE, X_CHOOSE_MANY, X_RETURN
+};
+constexpr uint32_t X_NONE = 0xffffffffu;
+struct XOp {
+    uint32_t kind;
+    uint32_t n;        // length of the operand list `a` (CONST_RUN: constants; CHOOSE / CHOOSE_MANY: cases)
+    uint32_t x, y, c;  // as in Op; STORE / LOAD: x = memory table index, LOAD: n = length; CHOOSE: x = variable, y = default
+                       // target; CHOOSE_MANY: x = key length, y = default target
+    uint32_t a, b;     // offsets into XProgram::args.  CHOOSE: a = keys[n] (sorted), b = targets[n]; CHOOSE_MANY: a = vars[x],
+                       // b = keys[n][x] (sorted) then targets[n]
+};
+struct XProgram {
+    std::vector<XOp> ops;
+    std::vector<uint32_t> args;
+    std::vector<uint32_t> entry;  // per function: its first operation
+};
+
+struct XBuilder {
+    XProgram& p;
+    std::unordered_map<const Block*, uint32_t> placed;
+    uint32_t list(const std::vector<uint32_t>& v) {
+        const uint32_t off = (uint32_t)p.args.size();
+        p.args.insert(p.args.end(), v.begin(), v.end());
+        return off;
+    }
+    // a length without a table fails when the operation runs, as in the reference (execute.rs:243-256), not when it is decoded
+    static uint32_t table_of(uint32_t len) {
+        for (int i = 0; i < NUM_MEM_TABLES; i++)
+            if (MEM_TABLE_SIZES[i] == len) return (uint32_t)i;
+        return X_NONE;
+    }
+    uint32_t block(const Block& blk) {
+        auto it = placed.find(&blk);
+        if (it != placed.end()) return it->second;
+        const uint32_t start = (uint32_t)p.ops.size();
+        placed[&blk] = start;
+        for (size_t i = 0; i < blk.ops.size(); i++) {
+            const Op& op = blk.ops[i];
+            XOp x{};
+            x.x = op.x, x.y = op.y, x.c = op.c;
+            switch (op.kind) {
+                case OpKind::AssertEq:
+                case OpKind::AssertNe:
+                    x.kind = op.kind == OpKind::AssertEq ? X_ASSERT_EQ : X_ASSERT_NE;
+                    x.n = (uint32_t)op.a.size(), x.a = list(op.a), x.b = list(op.b);
+                    break;
+                case OpKind::Contains:
+                    x.kind = X_CONTAINS, x.n = (uint32_t)op.a.size(), x.a = list(op.a);
+                    break;
+                case OpKind::Const: {
+                    size_t j = i;
+                    while (j < blk.ops.size() && blk.ops[j].kind == OpKind::Const) j++;
+                    if (j - i >= 2) {
+                        List cs;
+                        for (size_t k = i; k < j; k++) cs.push_back(blk.ops[k].c);
+                        x.kind = X_CONST_RUN, x.n = (uint32_t)cs.size(), x.a = list(cs);
+                        i = j - 1;
+                    } else {
+                        x.kind = X_CONST;
+                    }
+                    break;
+                }
+                case OpKind::Add: x.kind = X_ADD; break;
+                case OpKind::Sub: x.kind = X_SUB; break;
+                case OpKind::Mul: x.kind = X_MUL; break;
+                case OpKind::Inv: x.kind = X_INV; break;
+                case OpKind::Not: x.kind = X_NOT; break;
+                case OpKind::Call:
+                case OpKind::PreImg:
+                    x.kind = op.kind == OpKind::Call ? X_CALL : X_PREIMG;
+                    x.n = (uint32_t)op.a.size(), x.a = list(op.a);
+                    break;
+                case OpKind::Store:
+                    x.kind = X_STORE, x.n = (uint32_t)op.a.size(), x.a = list(op.a), x.x = table_of(x.n);
+                    break;
+                case OpKind::Load:
+                    x.kind = X_LOAD, x.n = op.x, x.x = table_of(op.x);
+                    break;
+                case OpKind::ExternCall:
+                    x.kind = X_EXTERN, x.n = (uint32_t)op.a.size(), x.a = list(op.a);
+                    break;
+                case OpKind::Emit:
+                    x.kind = X_EMIT, x.n = (uint32_t)op.a.size(), x.a = list(op.a);
+                    break;
+                case OpKind::RangeU8:
+                    x.kind = X_RANGE_U8, x.n = (uint32_t)op.a.size(), x.a = list(op.a);
+                    break;
+                case OpKind::Breakpoint:
+                case OpKind::Debug:
+                    continue;
+            }
+            p.ops.push_back(x);
+        }
+        const Ctrl& c = blk.ctrl;
+        const uint32_t at = (uint32_t)p.ops.size();
+        XOp x{};
+        if (c.kind == Ctrl::Return) {
+            x.kind = X_RETURN, x.n = (uint32_t)c.ret.size(), x.a = list(c.ret), x.x = c.ident;
+            p.ops.push_back(x);
+            return start;
+        }
+        const bool many = c.kind == Ctrl::ChooseMany;
+        const uint32_t m = many ? (uint32_t)c.vars.size() : 1, n = (uint32_t)c.branches.size();
+        x.kind = many ? X_CHOOSE_MANY : X_CHOOSE;
+        x.n = n, x.x = many ? m : c.var, x.y = X_NONE;
+        if (many) x.a = list(c.vars);
+        List keys;
+        for (const auto& br : c.branches) {  // sorted by key (compile.cpp, bytecode_io.cpp)
+            if (br.first.size() != m) throw ExecError("match key length differs from the matched variables");
+            keys.insert(keys.end(), br.first.begin(), br.first.end());
+        }
+        const uint32_t keys_off = list(keys), targets_off = list(List(n, X_NONE));
+        if (many) x.b = keys_off;
+        else x.a = keys_off, x.b = targets_off;
+        p.ops.push_back(x);
+        for (uint32_t i = 0; i < n; i++) {
+            const uint32_t target = block(*c.branches[i].second);
+            p.args[targets_off + i] = target;
+        }
+        if (c.def) {
+            const uint32_t target = block(*c.def);
+            p.ops[at].y = target;
+        }
+        return start;
+    }
+};
+
+std::shared_ptr<const XProgram> program_of(const Toplevel& t) {
+    std::lock_guard<std::mutex> lock(t.exec_cache.mu);
+    if (!t.exec_cache.program) {
+        auto p = std::make_shared<XProgram>();
+        XBuilder b{*p, {}};
+        for (const Func& f : t.funcs) p->entry.push_back(b.block(f.body));
+        t.exec_cache.program = p;
+    }
+    return std::static_pointer_cast<const XProgram>(t.exec_cache.program);
+}
+
+// One suspended activation of a Func.  The reference keeps an exec-entry stack plus a caller stack (execute.rs:436-470); an
+// operation cursor per activation is the same traversal.  Activations live in one grow-only array: multi-million-query
+// executions recurse millions of frames deep.
 struct Frame {
-    const Block* blk = nullptr;
-    size_t ip = 0;
-    bool preimg = false;
-    bool partial = false;
+    const XOp* ip = nullptr;
     uint32_t func_index = 0;
     uint32_t nonce = 0;
+    bool preimg = false;
+    bool partial = false;
     // where this activation's slices start in the five arenas (Arenas below)
     size_t map0 = 0, req0 = 0, dep0 = 0, dreq0 = 0, hint0 = 0;
 };
@@ -392,258 +556,292 @@ void depth_less_than_populate(uint32_t lhs, uint32_t rhs, BytesRecord& bytes, ui
 }  // namespace
 
 static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& self, const List& args, QueryRecord& q) {
+    const std::shared_ptr<const XProgram> prog = program_of(t);
+    const XOp* const code = prog->ops.data();
+    const uint32_t* const pargs = prog->args.data();
     {
         QueryResult top;
         top.provide.count = 1;
         q.func_queries[self.index].insert_full(args, top);
     }
-    std::deque<Frame> frames;  // stable addresses; frames[0 .. depth] are live
+    // frames[0 .. depth] are live, contiguous: a deep recursion returns through them in descending order, which the hardware
+    // prefetchers follow in one array (a deque's 512-byte blocks were a cache miss per return) and the return below can name
+    // the frames it will resume next.  The innermost activation `cur` is a local copy; frames[depth] is written when it
+    // suspends.
+    BigVec<Frame> frames;
     Arenas A;
     size_t depth = 0;
-    frames.emplace_back();
-    Frame* f = &frames[0];
-    f->blk = &self.body;
-    f->func_index = self.index;
-    f->nonce = (uint32_t)q.func_queries[self.index].find(args);
-    f->partial = self.partial;
-    A.map.insert(A.map.end(), args.begin(), args.end());
+    frames.push_back(Frame());
+    Frame cur;
+    cur.ip = code + prog->entry[self.index];
+    cur.func_index = self.index;
+    cur.nonce = (uint32_t)q.func_queries[self.index].find(args);
+    cur.partial = self.partial;
+    A.map.append(args.data(), args.size());
     List key, inp, out;  // scratch, reused
     std::vector<Record> chip_requires;
-
-    auto enter = [&](bool preimg, uint32_t callee_index, const List& input, uint64_t input_hash) {
-        // (the lookup that brought us here missed: the key is absent, its hash known)
-        const uint32_t callee_nonce = q.func_queries[callee_index].push_hashed(input.data(), (uint32_t)input.size(), QueryResult(), input_hash);
-        depth++;
-        if (depth == frames.size()) frames.emplace_back();
-        Frame* n = &frames[depth];
-        const Func& cf = t.funcs[callee_index];
-        n->blk = &cf.body;
-        n->ip = 0;
-        n->preimg = preimg;
-        n->partial = cf.partial;
-        n->func_index = callee_index;
-        n->nonce = callee_nonce;
-        n->map0 = A.map.size();
-        n->req0 = A.requires_.size();
-        n->dep0 = A.depths.size();
-        n->dreq0 = A.depth_requires.size();
-        n->hint0 = A.hints.size();
-        A.map.insert(A.map.end(), input.begin(), input.end());
-        f = n;
-    };
+    std::vector<uint8_t> by_scratch;
 
     for (;;) {
-        if (f->ip < f->blk->ops.size()) {
-            const Op& op = f->blk->ops[f->ip++];
-            // the innermost activation's variable map is the top slice of A.map; `map` is re-read per op because a push may
-            // move the arena (values are fetched before they are pushed)
-            const uint32_t* map = A.map.data() + f->map0;
-            const uint32_t nonce = f->nonce;
-            switch (op.kind) {
-                case OpKind::AssertEq:
-                    for (size_t i = 0; i < op.a.size(); i++)
-                        if (map[op.a[i]] != map[op.b[i]]) throw ExecError("assert_eq! failed in " + t.funcs[f->func_index].name);
-                    break;
-                case OpKind::AssertNe: {
-                    bool unequal = false;
-                    for (size_t i = 0; i < op.a.size(); i++)
-                        if (map[op.a[i]] != map[op.b[i]]) {
-                            unequal = true;
-                            break;
-                        }
-                    if (!unequal) throw ExecError("assert_ne! failed in " + t.funcs[f->func_index].name);
-                    break;
-                }
-                case OpKind::Contains: {
-                    bool found = false;
-                    for (uint32_t a : op.a) found = found || map[a] == map[op.y];
-                    if (!found) throw ExecError("contains! failed in " + t.funcs[f->func_index].name);
-                    break;
-                }
-                case OpKind::Call:
-                case OpKind::PreImg: {
-                    const bool pre = op.kind == OpKind::PreImg;
-                    const uint32_t callee = op.x;
-                    key.clear();
-                    for (uint32_t v : op.a) key.push_back(map[v]);
-                    if (pre) {
-                        auto& inv = q.inv_func_queries[callee];
-                        if (!inv) throw ExecError("Missing inverse map");
-                        auto it = inv->find(key);
-                        if (it == inv->end()) throw ExecError("Preimg not found");
-                        inp = it->second;
-                    } else {
-                        inp = key;
-                    }
-                    QueryMap& cqm = q.func_queries[callee];
-                    const uint64_t inp_hash = QueryMap::hash(inp.data(), (uint32_t)inp.size());
-                    if (!cqm.vals.empty() && inp.size() != cqm.key_len) throw ExecError("query table key length changed");
-                    int idx = cqm.find_hashed(inp.data(), (uint32_t)inp.size(), inp_hash);
-                    if (idx >= 0) {
-                        QueryResult& res = cqm.vals[idx];
-                        if (!res.has_output) throw ExecError("Loop detected");
-                        const uint32_t n_out = t.funcs[callee].output_size;
-                        const uint32_t* res_out = cqm.output(res);
-                        if (pre && (key.size() != n_out || memcmp(res_out, key.data(), (size_t)n_out * 4) != 0))
-                            throw ExecError("memoized output differs from preimage key");
-                        const uint32_t* ext = pre ? inp.data() : res_out;
-                        const size_t n_ext = pre ? inp.size() : n_out;
-                        A.map.insert(A.map.end(), ext, ext + n_ext);
-                        A.hints.insert(A.hints.end(), ext, ext + n_ext);
-                        A.requires_.push_back(res.provide.new_lookup(nonce));
-                        const bool callee_partial = t.funcs[callee].partial;
-                        if (callee_partial) A.hints.push_back(res.depth);
-                        if (f->partial && callee_partial) A.depths.push_back(res.depth);
-                    } else {
-                        enter(pre, callee, inp, inp_hash);
-                    }
-                    break;
-                }
-                case OpKind::Const:
-                    A.map.push_back(op.c);
-                    break;
-                case OpKind::Add:
-                    A.map.push_back(fadd(map[op.x], map[op.y]));
-                    break;
-                case OpKind::Sub:
-                    A.map.push_back(fsub(map[op.x], map[op.y]));
-                    break;
-                case OpKind::Mul:
-                    A.map.push_back(fmul(map[op.x], map[op.y]));
-                    break;
-                case OpKind::Inv:
-                    A.map.push_back(finv(map[op.x]));
-                    break;
-                case OpKind::Not:
-                    A.map.push_back(map[op.x] == 0 ? 1u : 0u);
-                    break;
-                case OpKind::Store: {
-                    key.clear();
-                    for (uint32_t v : op.a) key.push_back(map[v]);
-                    QueryMap& mm = q.mem_queries[mem_index_from_len((uint32_t)key.size())];
-                    const uint64_t key_hash = QueryMap::hash(key.data(), (uint32_t)key.size());
-                    int i = mm.find_hashed(key.data(), (uint32_t)key.size(), key_hash);
-                    if (i < 0) i = (int)mm.push_hashed(key.data(), (uint32_t)key.size(), QueryResult(), key_hash);
-                    uint32_t ptr = (uint32_t)(i + 1);
-                    A.map.push_back(ptr);
-                    A.hints.push_back(ptr);
-                    A.requires_.push_back(mm.vals[i].provide.new_lookup(nonce));
-                    break;
-                }
-                case OpKind::Load: {
-                    uint32_t ptr = map[op.y];
-                    QueryMap& mm = q.mem_queries[mem_index_from_len(op.x)];
-                    if (ptr == 0 || ptr > mm.size()) throw ExecError("Unbound pointer");
-                    const uint32_t* vals = mm.key(ptr - 1);
-                    A.map.insert(A.map.end(), vals, vals + op.x);
-                    A.hints.insert(A.hints.end(), vals, vals + op.x);
-                    A.requires_.push_back(mm.vals[ptr - 1].provide.new_lookup(nonce));
-                    break;
-                }
-                case OpKind::ExternCall: {
-                    key.clear();
-                    for (uint32_t v : op.a) key.push_back(map[v]);
-                    chip_requires.clear();
-                    List res = t.chips[op.x].execute(key, nonce, q.bytes, chip_requires);
-                    A.requires_.insert(A.requires_.end(), chip_requires.begin(), chip_requires.end());
-                    A.map.insert(A.map.end(), res.begin(), res.end());
-                    break;
-                }
-                case OpKind::Emit: {
-                    List v;
-                    for (uint32_t a : op.a) v.push_back(map[a]);
-                    q.emitted.push_back(v);
-                    break;
-                }
-                case OpKind::RangeU8: {
-                    std::vector<uint8_t> by;
-                    for (uint32_t a : op.a) {
-                        if (map[a] > 255) throw ExecError("Variable not in u8 range");
-                        by.push_back((uint8_t)map[a]);
-                    }
-                    chip_requires.clear();
-                    q.bytes.range_check_u8_iter(by.data(), by.size(), nonce, chip_requires);
-                    A.requires_.insert(A.requires_.end(), chip_requires.begin(), chip_requires.end());
-                    break;
-                }
-                case OpKind::Breakpoint:
-                case OpKind::Debug:
-                    break;
+        const XOp& op = *cur.ip++;
+        // the innermost activation's variable map is the top slice of A.map; `map` is re-read per operation because a push
+        // may move the arena (values are fetched before they are pushed)
+        const uint32_t* map = A.map.data() + cur.map0;
+        const uint32_t nonce = cur.nonce;
+        switch (op.kind) {
+            case X_ASSERT_EQ: {
+                const uint32_t *a = pargs + op.a, *b = pargs + op.b;
+                for (uint32_t i = 0; i < op.n; i++)
+                    if (map[a[i]] != map[b[i]]) throw ExecError("assert_eq! failed in " + t.funcs[cur.func_index].name);
+                break;
             }
-            continue;
+            case X_ASSERT_NE: {
+                const uint32_t *a = pargs + op.a, *b = pargs + op.b;
+                bool unequal = false;
+                for (uint32_t i = 0; i < op.n; i++)
+                    if (map[a[i]] != map[b[i]]) {
+                        unequal = true;
+                        break;
+                    }
+                if (!unequal) throw ExecError("assert_ne! failed in " + t.funcs[cur.func_index].name);
+                break;
+            }
+            case X_CONTAINS: {
+                const uint32_t* a = pargs + op.a;
+                bool found = false;
+                for (uint32_t i = 0; i < op.n; i++) found = found || map[a[i]] == map[op.y];
+                if (!found) throw ExecError("contains! failed in " + t.funcs[cur.func_index].name);
+                break;
+            }
+            case X_CALL:
+            case X_PREIMG: {
+                const bool pre = op.kind == X_PREIMG;
+                const uint32_t callee = op.x;
+                const uint32_t* a = pargs + op.a;
+                key.resize(op.n);
+                for (uint32_t i = 0; i < op.n; i++) key[i] = map[a[i]];
+                const List* input = &key;
+                if (pre) {
+                    auto& inv = q.inv_func_queries[callee];
+                    if (!inv) throw ExecError("Missing inverse map");
+                    auto it = inv->find(key);
+                    if (it == inv->end()) throw ExecError("Preimg not found");
+                    inp = it->second;
+                    input = &inp;
+                }
+                QueryMap& cqm = q.func_queries[callee];
+                const uint32_t n_in = (uint32_t)input->size();
+                const uint64_t inp_hash = QueryMap::hash(input->data(), n_in);
+                if (!cqm.vals.empty() && n_in != cqm.key_len) throw ExecError("query table key length changed");
+                const int idx = cqm.find_hashed(input->data(), n_in, inp_hash);
+                const Func& cf = t.funcs[callee];
+                if (idx >= 0) {
+                    QueryResult& res = cqm.vals[idx];
+                    if (!res.has_output) throw ExecError("Loop detected");
+                    const uint32_t n_out = cf.output_size;
+                    const uint32_t* res_out = cqm.output(res);
+                    if (pre && (key.size() != n_out || memcmp(res_out, key.data(), (size_t)n_out * 4) != 0))
+                        throw ExecError("memoized output differs from preimage key");
+                    const uint32_t* ext = pre ? inp.data() : res_out;
+                    const size_t n_ext = pre ? inp.size() : n_out;
+                    A.map.append(ext, n_ext);
+                    A.hints.append(ext, n_ext);
+                    A.requires_.push_back(res.provide.new_lookup(nonce));
+                    if (cf.partial) A.hints.push_back(res.depth);
+                    if (cur.partial && cf.partial) A.depths.push_back(res.depth);
+                } else {
+                    // the lookup missed: the key is absent, its hash known.  Suspend this activation, start the callee's.
+                    const uint32_t callee_nonce = cqm.push_hashed(input->data(), n_in, QueryResult(), inp_hash);
+                    frames[depth] = cur;
+                    depth++;
+                    if (depth == frames.size()) frames.push_back(Frame());
+                    cur.ip = code + prog->entry[callee];
+                    cur.preimg = pre;
+                    cur.partial = cf.partial;
+                    cur.func_index = callee;
+                    cur.nonce = callee_nonce;
+                    cur.map0 = A.map.size();
+                    cur.req0 = A.requires_.size();
+                    cur.dep0 = A.depths.size();
+                    cur.dreq0 = A.depth_requires.size();
+                    cur.hint0 = A.hints.size();
+                    A.map.append(input->data(), n_in);
+                }
+                break;
+            }
+            case X_CONST:
+                A.map.push_back(op.c);
+                break;
+            case X_CONST_RUN:
+                A.map.append(pargs + op.a, op.n);
+                break;
+            case X_ADD:
+                A.map.push_back(fadd(map[op.x], map[op.y]));
+                break;
+            case X_SUB:
+                A.map.push_back(fsub(map[op.x], map[op.y]));
+                break;
+            case X_MUL:
+                A.map.push_back(fmul(map[op.x], map[op.y]));
+                break;
+            case X_INV:
+                A.map.push_back(finv(map[op.x]));
+                break;
+            case X_NOT:
+                A.map.push_back(map[op.x] == 0 ? 1u : 0u);
+                break;
+            case X_STORE: {
+                if (op.x == X_NONE) (void)mem_index_from_len(op.n);  // throws
+                const uint32_t* a = pargs + op.a;
+                uint32_t kbuf[8];  // memory tables are at most 8 wide (execute.rs:243-244)
+                for (uint32_t i = 0; i < op.n; i++) kbuf[i] = map[a[i]];
+                QueryMap& mm = q.mem_queries[op.x];
+                const uint64_t key_hash = QueryMap::hash(kbuf, op.n);
+                int i = mm.find_hashed(kbuf, op.n, key_hash);
+                if (i < 0) i = (int)mm.push_hashed(kbuf, op.n, QueryResult(), key_hash);
+                const uint32_t ptr = (uint32_t)(i + 1);
+                A.map.push_back(ptr);
+                A.hints.push_back(ptr);
+                A.requires_.push_back(mm.vals[i].provide.new_lookup(nonce));
+                break;
+            }
+            case X_LOAD: {
+                if (op.x == X_NONE) (void)mem_index_from_len(op.n);  // throws
+                const uint32_t ptr = map[op.y];
+                QueryMap& mm = q.mem_queries[op.x];
+                if (ptr == 0 || ptr > mm.size()) throw ExecError("Unbound pointer");
+                const uint32_t* vals = mm.key(ptr - 1);
+                A.map.append(vals, op.n);
+                A.hints.append(vals, op.n);
+                A.requires_.push_back(mm.vals[ptr - 1].provide.new_lookup(nonce));
+                break;
+            }
+            case X_EXTERN: {
+                const uint32_t* a = pargs + op.a;
+                key.resize(op.n);
+                for (uint32_t i = 0; i < op.n; i++) key[i] = map[a[i]];
+                chip_requires.clear();
+                List res = t.chips[op.x].execute(key, nonce, q.bytes, chip_requires);
+                A.requires_.append(chip_requires.data(), chip_requires.size());
+                A.map.append(res.data(), res.size());
+                break;
+            }
+            case X_EMIT: {
+                const uint32_t* a = pargs + op.a;
+                List v;
+                for (uint32_t i = 0; i < op.n; i++) v.push_back(map[a[i]]);
+                q.emitted.push_back(v);
+                break;
+            }
+            case X_RANGE_U8: {
+                const uint32_t* a = pargs + op.a;
+                by_scratch.clear();
+                for (uint32_t i = 0; i < op.n; i++) {
+                    if (map[a[i]] > 255) throw ExecError("Variable not in u8 range");
+                    by_scratch.push_back((uint8_t)map[a[i]]);
+                }
+                chip_requires.clear();
+                q.bytes.range_check_u8_iter(by_scratch.data(), by_scratch.size(), nonce, chip_requires);
+                A.requires_.append(chip_requires.data(), chip_requires.size());
+                break;
+            }
+            case X_CHOOSE: {
+                const uint32_t v = map[op.x];
+                const uint32_t *keys = pargs + op.a, *targets = pargs + op.b;
+                const uint32_t* it = std::lower_bound(keys, keys + op.n, v);
+                const uint32_t target = it != keys + op.n && *it == v ? targets[it - keys] : op.y;
+                if (target == X_NONE) throw ExecError("No match");
+                cur.ip = code + target;
+                break;
+            }
+            case X_CHOOSE_MANY: {
+                const uint32_t m = op.x;
+                const uint32_t *vars = pargs + op.a, *keys = pargs + op.b, *targets = keys + (size_t)op.n * m;
+                key.resize(m);
+                for (uint32_t i = 0; i < m; i++) key[i] = map[vars[i]];
+                uint32_t lo = 0, hi = op.n;  // first case >= key (lexicographic)
+                while (lo < hi) {
+                    const uint32_t mid = (lo + hi) / 2;
+                    if (std::lexicographical_compare(keys + (size_t)mid * m, keys + (size_t)(mid + 1) * m, key.begin(), key.end())) lo = mid + 1;
+                    else hi = mid;
+                }
+                const uint32_t target = lo < op.n && std::equal(key.begin(), key.end(), keys + (size_t)lo * m) ? targets[lo] : op.y;
+                if (target == X_NONE) throw ExecError("No match");
+                cur.ip = code + target;
+                break;
+            }
+            case X_RETURN: {
+                const uint32_t* rv = pargs + op.a;
+                out.resize(op.n);
+                for (uint32_t i = 0; i < op.n; i++) out[i] = map[rv[i]];
+                const uint32_t func_index = cur.func_index;
+                QueryMap& qm = q.func_queries[func_index];
+                QueryResult& result = qm.vals[nonce];
+                if (result.has_output) throw ExecError("query evaluated twice");
+                const bool need_input = cur.preimg || q.inv_func_queries[func_index];
+                if (need_input) inp.assign(qm.key(nonce), qm.key(nonce) + qm.key_len);
+                if (q.inv_func_queries[func_index]) (*q.inv_func_queries[func_index])[out] = inp;
+                if (cur.partial) {
+                    uint32_t d_self = 0;
+                    for (size_t i = cur.dep0; i < A.depths.size(); i++) d_self = std::max(d_self, A.depths[i] + 1);
+                    uint8_t by[4] = {(uint8_t)d_self, (uint8_t)(d_self >> 8), (uint8_t)(d_self >> 16), (uint8_t)(d_self >> 24)};
+                    chip_requires.clear();
+                    q.bytes.range_check_u8_iter(by, 4, nonce, chip_requires);
+                    for (size_t i = cur.dep0; i < A.depths.size(); i++) depth_less_than_populate(A.depths[i], d_self, q.bytes, nonce, chip_requires);
+                    A.depth_requires.append(chip_requires.data(), chip_requires.size());
+                    result.depth = d_self;
+                }
+                // finalize: the activation's slices move into the table's pools
+                result.out_off = (uint32_t)qm.pool.size();
+                qm.pool.append(out.data(), out.size());
+                result.hint_off = (uint32_t)qm.pool.size();
+                result.n_hints = (uint32_t)(A.hints.size() - cur.hint0);
+                qm.pool.append(A.hints.data() + cur.hint0, A.hints.size() - cur.hint0);
+                result.req_off = (uint32_t)qm.rec_pool.size();
+                result.n_requires = (uint32_t)(A.requires_.size() - cur.req0);
+                result.n_depth_requires = (uint32_t)(A.depth_requires.size() - cur.dreq0);
+                qm.rec_pool.append(A.requires_.data() + cur.req0, A.requires_.size() - cur.req0);
+                qm.rec_pool.append(A.depth_requires.data() + cur.dreq0, A.depth_requires.size() - cur.dreq0);
+                if (qm.pool.size() > 0xfffffff0ull || qm.rec_pool.size() > 0xfffffff0ull) throw ExecError("query table pools exceed 2^32 words");
+                result.has_output = true;
+                if (depth == 0) {
+                    uint32_t d_top = 0;
+                    for (size_t i = cur.dep0; i < A.depths.size(); i++) d_top = std::max(d_top, A.depths[i] + 1);
+                    return {out, d_top};
+                }
+                // pop: the caller's slices are the arenas' tops again
+                A.map.resize(cur.map0);
+                A.requires_.resize(cur.req0);
+                A.depths.resize(cur.dep0);
+                A.depth_requires.resize(cur.dreq0);
+                A.hints.resize(cur.hint0);
+                const bool callee_partial = cur.partial, callee_preimg = cur.preimg;
+                const uint32_t callee_depth = result.depth;
+                depth--;
+                cur = frames[depth];
+                if (depth >= 2) {
+                    // the activation resumed after this one was suspended long ago when the recursion is deep: ask for its
+                    // variables and its table entry now
+                    const Frame& up = frames[depth - 1];
+                    const QueryMap& uq = q.func_queries[up.func_index];
+                    __builtin_prefetch(A.map.data() + up.map0);
+                    __builtin_prefetch(A.map.data() + up.map0 + 16);
+                    __builtin_prefetch(&uq.vals[up.nonce]);
+                    __builtin_prefetch(uq.key(up.nonce));
+                    __builtin_prefetch(&frames[depth - 2]);
+                }
+                const List& ext = callee_preimg ? inp : out;
+                A.map.append(ext.data(), ext.size());
+                A.hints.append(ext.data(), ext.size());
+                // `result` still refers to the callee's table slot: nothing was inserted between the Return and here
+                A.requires_.push_back(result.provide.new_lookup(cur.nonce));
+                if (callee_partial) A.hints.push_back(callee_depth);
+                if (cur.partial && callee_partial) A.depths.push_back(callee_depth);
+                break;
+            }
+            default:
+                throw ExecError("corrupt interpreter program");
         }
-        const Ctrl& c = f->blk->ctrl;
-        if (c.kind == Ctrl::Choose) {
-            key.assign(1, A.map[f->map0 + c.var]);
-            const Block* b = c.match_case(key);
-            if (!b) throw ExecError("No match");
-            f->blk = b;
-            f->ip = 0;
-            continue;
-        }
-        if (c.kind == Ctrl::ChooseMany) {
-            key.clear();
-            for (uint32_t v : c.vars) key.push_back(A.map[f->map0 + v]);
-            const Block* b = c.match_case(key);
-            if (!b) throw ExecError("No match");
-            f->blk = b;
-            f->ip = 0;
-            continue;
-        }
-        // Return
-        out.clear();
-        for (uint32_t v : c.ret) out.push_back(A.map[f->map0 + v]);
-        const uint32_t func_index = f->func_index, nonce = f->nonce;
-        QueryMap& qm = q.func_queries[func_index];
-        QueryResult& result = qm.vals[nonce];
-        if (result.has_output) throw ExecError("query evaluated twice");
-        inp.assign(qm.key(nonce), qm.key(nonce) + qm.key_len);
-        if (q.inv_func_queries[func_index]) (*q.inv_func_queries[func_index])[out] = inp;
-        if (f->partial) {
-            uint32_t d_self = 0;
-            for (size_t i = f->dep0; i < A.depths.size(); i++) d_self = std::max(d_self, A.depths[i] + 1);
-            uint8_t by[4] = {(uint8_t)d_self, (uint8_t)(d_self >> 8), (uint8_t)(d_self >> 16), (uint8_t)(d_self >> 24)};
-            chip_requires.clear();
-            q.bytes.range_check_u8_iter(by, 4, nonce, chip_requires);
-            for (size_t i = f->dep0; i < A.depths.size(); i++) depth_less_than_populate(A.depths[i], d_self, q.bytes, nonce, chip_requires);
-            A.depth_requires.insert(A.depth_requires.end(), chip_requires.begin(), chip_requires.end());
-            result.depth = d_self;
-        }
-        // finalize: the activation's slices move into the table's pools
-        result.out_off = (uint32_t)qm.pool.size();
-        qm.pool.insert(qm.pool.end(), out.begin(), out.end());
-        result.hint_off = (uint32_t)qm.pool.size();
-        result.n_hints = (uint32_t)(A.hints.size() - f->hint0);
-        qm.pool.insert(qm.pool.end(), A.hints.begin() + f->hint0, A.hints.end());
-        result.req_off = (uint32_t)qm.rec_pool.size();
-        result.n_requires = (uint32_t)(A.requires_.size() - f->req0);
-        result.n_depth_requires = (uint32_t)(A.depth_requires.size() - f->dreq0);
-        qm.rec_pool.insert(qm.rec_pool.end(), A.requires_.begin() + f->req0, A.requires_.end());
-        qm.rec_pool.insert(qm.rec_pool.end(), A.depth_requires.begin() + f->dreq0, A.depth_requires.end());
-        if (qm.pool.size() > 0xfffffff0ull || qm.rec_pool.size() > 0xfffffff0ull) throw ExecError("query table pools exceed 2^32 words");
-        result.has_output = true;
-        if (depth == 0) {
-            uint32_t d_top = 0;
-            for (size_t i = f->dep0; i < A.depths.size(); i++) d_top = std::max(d_top, A.depths[i] + 1);
-            return {out, d_top};
-        }
-        // pop: the caller's slices are the arenas' tops again
-        A.map.resize(f->map0);
-        A.requires_.resize(f->req0);
-        A.depths.resize(f->dep0);
-        A.depth_requires.resize(f->dreq0);
-        A.hints.resize(f->hint0);
-        const bool callee_partial = f->partial, callee_preimg = f->preimg;
-        const uint32_t callee_depth = result.depth;
-        depth--;
-        f = &frames[depth];
-        const List& ext = callee_preimg ? inp : out;
-        A.map.insert(A.map.end(), ext.begin(), ext.end());
-        A.hints.insert(A.hints.end(), ext.begin(), ext.end());
-        // `result` still refers to the callee's table slot: nothing was inserted between the Return and here
-        A.requires_.push_back(result.provide.new_lookup(f->nonce));
-        if (callee_partial) A.hints.push_back(callee_depth);
-        if (f->partial && callee_partial) A.depths.push_back(callee_depth);
     }
 }
 

@@ -16,8 +16,11 @@
 
 #include <map>
 #include <memory>
+#include <mutex>
 #include <stdexcept>
+#include <cstring>
 #include <string>
+#include <type_traits>
 #include <unordered_map>
 #include <vector>
 
@@ -50,21 +53,94 @@ using List = std::vector<uint32_t>;
 // the interpreter's own work (measured: 3.5 s of system time in a 5.5 s execution of 0.8 M queries).
 void* huge_alloc(size_t bytes);
 void huge_free(void* p, size_t bytes);
+// Growable array of trivially copyable T on huge_alloc blocks (round 3: a std::vector with a custom allocator copies a range
+// element by element through allocator_traits::construct -- the appends of a query's hints and requires were a scalar loop).
 template <class T>
-struct HugeAlloc {
-    using value_type = T;
-    HugeAlloc() = default;
-    template <class U>
-    HugeAlloc(const HugeAlloc<U>&) {}
-    T* allocate(size_t n) { return static_cast<T*>(huge_alloc(n * sizeof(T))); }
-    void deallocate(T* p, size_t n) { huge_free(p, n * sizeof(T)); }
-    template <class U>
-    bool operator==(const HugeAlloc<U>&) const { return true; }
-    template <class U>
-    bool operator!=(const HugeAlloc<U>&) const { return false; }
+class BigVec {
+    static_assert(std::is_trivially_copyable<T>::value, "BigVec holds plain data");
+    T* d_ = nullptr;
+    size_t n_ = 0, cap_ = 0;
+    void grow_to(size_t want) {
+        size_t cap = cap_ ? cap_ * 2 : 64;
+        if (cap < want) cap = want;
+        T* nd = static_cast<T*>(huge_alloc(cap * sizeof(T)));
+        if (n_) memcpy(static_cast<void*>(nd), d_, n_ * sizeof(T));
+        if (d_) huge_free(d_, cap_ * sizeof(T));
+        d_ = nd;
+        cap_ = cap;
+    }
+
+   public:
+    BigVec() = default;
+    BigVec(const BigVec& o) { append(o.d_, o.n_); }
+    BigVec(BigVec&& o) noexcept : d_(o.d_), n_(o.n_), cap_(o.cap_) { o.d_ = nullptr, o.n_ = o.cap_ = 0; }
+    BigVec& operator=(const BigVec& o) {
+        if (this != &o) n_ = 0, append(o.d_, o.n_);
+        return *this;
+    }
+    BigVec& operator=(BigVec&& o) noexcept {
+        if (this != &o) {
+            release();
+            d_ = o.d_, n_ = o.n_, cap_ = o.cap_;
+            o.d_ = nullptr, o.n_ = o.cap_ = 0;
+        }
+        return *this;
+    }
+    ~BigVec() { release(); }
+    void release() {
+        if (d_) huge_free(d_, cap_ * sizeof(T));
+        d_ = nullptr, n_ = cap_ = 0;
+    }
+    size_t size() const { return n_; }
+    bool empty() const { return n_ == 0; }
+    T* data() { return d_; }
+    const T* data() const { return d_; }
+    T& operator[](size_t i) { return d_[i]; }
+    const T& operator[](size_t i) const { return d_[i]; }
+    T* begin() { return d_; }
+    T* end() { return d_ + n_; }
+    const T* begin() const { return d_; }
+    const T* end() const { return d_ + n_; }
+    void clear() { n_ = 0; }
+    void reserve(size_t n) {
+        if (n > cap_) grow_to(n);
+    }
+    void push_back(const T& v) {
+        if (n_ == cap_) {
+            const T copy = v;  // `v` may live in this array
+            grow_to(n_ + 1);
+            d_[n_++] = copy;
+            return;
+        }
+        d_[n_++] = v;
+    }
+    // appends p[0 .. n); p may point into this array
+    void append(const T* p, size_t n) {
+        if (!n) return;
+        if (n_ + n > cap_) {
+            const bool inside = p >= d_ && p < d_ + cap_;
+            const size_t off = inside ? (size_t)(p - d_) : 0;
+            grow_to(n_ + n);
+            if (inside) p = d_ + off;
+        }
+        memcpy(static_cast<void*>(d_ + n_), p, n * sizeof(T));
+        n_ += n;
+    }
+    // shrinks, or grows with value-initialised elements
+    void resize(size_t n) {
+        if (n > n_) {
+            if (n > cap_) grow_to(n);
+            for (size_t i = n_; i < n; i++) d_[i] = T();
+        }
+        n_ = n;
+    }
+    void assign(size_t n, const T& v) {
+        n_ = 0;
+        if (n > cap_) grow_to(n);
+        for (size_t i = 0; i < n; i++) d_[i] = v;
+        n_ = n;
+    }
 };
-template <class T>
-using BigVec = std::vector<T, HugeAlloc<T>>;
 
 // ---------------------------------------------------------------- IR (expr.rs)
 struct Var {
@@ -178,29 +254,34 @@ struct Record {  // air/builder.rs:135-150
     }
 };
 
-struct BytesInputRecord {  // gadgets/bytes/record.rs:50-71, order fixed by iter_records()
-    Record range_u8, range_u16, less_than, and_, xor_, or_;
-};
+enum BytesKind { BYTES_RANGE_U8 = 0, BYTES_RANGE_U16, BYTES_LESS_THAN, BYTES_AND, BYTES_XOR, BYTES_OR, BYTES_KINDS };  // gadgets/bytes/record.rs:50-71, order fixed by iter_records()
 
-struct BytesRecord {  // gadgets/bytes/record.rs:14-17
-    std::map<uint16_t, BytesInputRecord> records;   // ordered: the trace rows are emitted in key order
-    std::vector<BytesInputRecord*> slot;            // direct index into `records` (map nodes never move)
-    BytesRecord() = default;
-    BytesRecord(const BytesRecord& o) : records(o.records) {}  // the index points into the source's nodes: rebuilt on demand
-    BytesRecord& operator=(const BytesRecord& o) {
-        records = o.records;
-        slot.clear();
-        return *this;
+// gadgets/bytes/record.rs:14-17: a BTreeMap from the two input bytes to six records.  Every key of the map is a 16-bit number,
+// so the map is a table: one array of 65536 records per kind (round 3: the std::map's nodes were a cache miss per lookup,
+// a quarter of the interpreter's time on partial functions whose depth bytes walk through every key; a kind's array is
+// 512 KiB) and a bitmap of the keys the reference's map would hold.
+struct BytesRecord {
+    std::vector<Record> table;      // [BYTES_KINDS][65536], empty until the first lookup
+    std::vector<uint64_t> touched;  // bit per key
+    uint32_t n_touched = 0;
+    Record& at(uint16_t key, BytesKind k) {
+        if (table.empty()) {
+            table.assign((size_t)BYTES_KINDS * 65536, Record());
+            touched.assign(65536 / 64, 0);
+        }
+        uint64_t& w = touched[key >> 6];
+        const uint64_t bit = 1ull << (key & 63);
+        if (!(w & bit)) w |= bit, n_touched++;
+        return table[(size_t)k * 65536 + key];
     }
-    BytesInputRecord& at(uint16_t key) {
-        if (slot.empty()) slot.assign(65536, nullptr);
-        BytesInputRecord*& p = slot[key];
-        if (!p) p = &records[key];
-        return *p;
-    }
+    // number of keys with a record (the reference map's len()) / a record as stored (zeroes when the key was never looked up)
+    size_t size() const { return n_touched; }
+    bool empty() const { return n_touched == 0; }
+    Record get(uint16_t key, int k) const { return table.empty() ? Record() : table[(size_t)k * 65536 + key]; }
     void clear() {
-        records.clear();
-        slot.clear();
+        table.clear();
+        touched.clear();
+        n_touched = 0;
     }
     void range_check_u8_pair(uint8_t i1, uint8_t i2, uint32_t nonce, std::vector<Record>& requires_);
     void range_check_u8_iter(const uint8_t* bytes, size_t n, uint32_t nonce, std::vector<Record>& requires_);
@@ -222,11 +303,25 @@ struct Chip {
 std::vector<Chip> lurk_chip_map();  // core/chipset.rs:28-63, in that order
 
 // ---------------------------------------------------------------- toplevel (toplevel.rs)
+// The interpreter's pre-decoded form of a toplevel's functions (execute.cpp: XProgram), built on first execution.  It points
+// into the toplevel's blocks, so a copy of the toplevel starts without one.
+struct ExecCacheSlot {
+    mutable std::mutex mu;
+    mutable std::shared_ptr<const void> program;
+    ExecCacheSlot() = default;
+    ExecCacheSlot(const ExecCacheSlot&) {}
+    ExecCacheSlot& operator=(const ExecCacheSlot&) {
+        program.reset();
+        return *this;
+    }
+};
+
 struct Toplevel {
     std::vector<Func> funcs;          // insertion order = index
     std::unordered_map<std::string, uint32_t> func_index;
     std::vector<Chip> chips;
     std::unordered_map<std::string, uint32_t> chip_index;
+    ExecCacheSlot exec_cache;
 
     static Toplevel build(const std::vector<FuncE>& funcs, const std::vector<Chip>& chips);
     const Func& func_by_name(const std::string& n) const;
@@ -282,6 +377,8 @@ struct QueryMap {
     BigVec<uint32_t> pool;            // outputs and hints
     BigVec<Record> rec_pool;          // require records
     BigVec<uint32_t> slots;           // entry index + 1, 0 = empty; power-of-two size
+    BigVec<uint32_t> hashes;          // per entry: the low half of its key's hash (re-seats entries when the index grows
+                                      // without reading the keys again, and screens probes before a key comparison)
     size_t size() const { return vals.size(); }
     const uint32_t* key(size_t i) const { return key_pool.data() + i * key_len; }
     // Four independent multiply chains over the key words, folded at the end (round 3: the one-chain hash -- xor, 64-bit
@@ -302,13 +399,45 @@ struct QueryMap {
         h = (h ^ h2 ^ (h3 >> 29) ^ (h3 << 35)) * C;
         return h ^ (h >> 32);
     }
+    // Absent keys are the common lookup (every new query, every fresh memory cell), and the index of a multi-million-entry
+    // table is a DRAM access per probe.  So (round 3): a blocked Bloom filter beside the index -- three bits in one 64-byte
+    // block per key, 8 .. 16 bits per entry, small enough to stay in the last-level cache -- answers "absent" without
+    // touching the index, and a new entry's seat in the index is taken a few insertions later (`pending`), when the line
+    // requested at insertion time has arrived.
+    static constexpr uint32_t MAX_PENDING = 8;
+    struct Pending {
+        uint32_t index, h32;
+    };
+    BigVec<uint64_t> bloom;           // 8 words per block; bits = 4 x slots
+    uint32_t bloom_shift = 32;        // block = (h32 * K) >> bloom_shift
+    Pending pending[MAX_PENDING];
+    uint32_t pending_head = 0, n_pending = 0;
+    bool bloom_maybe(uint32_t h32) const {
+        const uint64_t* blk = bloom.data() + ((size_t)((h32 * 0x9e3779b1u) >> bloom_shift) << 3);
+        const uint32_t m = h32 * 0x85ebca6bu;
+        const uint32_t b0 = m & 511, b1 = (m >> 9) & 511, b2 = (m >> 18) & 511;
+        return ((blk[b0 >> 6] >> (b0 & 63)) & (blk[b1 >> 6] >> (b1 & 63)) & (blk[b2 >> 6] >> (b2 & 63)) & 1) != 0;
+    }
+    void bloom_add(uint32_t h32) {
+        uint64_t* blk = bloom.data() + ((size_t)((h32 * 0x9e3779b1u) >> bloom_shift) << 3);
+        const uint32_t m = h32 * 0x85ebca6bu;
+        const uint32_t b0 = m & 511, b1 = (m >> 9) & 511, b2 = (m >> 18) & 511;
+        blk[b0 >> 6] |= 1ull << (b0 & 63);
+        blk[b1 >> 6] |= 1ull << (b1 & 63);
+        blk[b2 >> 6] |= 1ull << (b2 & 63);
+    }
     int find_hashed(const uint32_t* k, uint32_t n, uint64_t h) const {
         if (slots.empty() || n != key_len) return -1;
+        if (!bloom_maybe((uint32_t)h)) return -1;
+        for (uint32_t j = 0; j < n_pending; j++) {
+            const Pending& p = pending[(pending_head + j) % MAX_PENDING];
+            if (p.h32 == (uint32_t)h && memcmp(key(p.index), k, (size_t)n * 4) == 0) return (int)p.index;
+        }
         const size_t mask = slots.size() - 1;
         for (size_t s = h & mask;; s = (s + 1) & mask) {
             const uint32_t e = slots[s];
             if (!e) return -1;
-            if (memcmp(key(e - 1), k, (size_t)n * 4) == 0) return (int)(e - 1);
+            if (hashes[e - 1] == (uint32_t)h && memcmp(key(e - 1), k, (size_t)n * 4) == 0) return (int)(e - 1);
         }
     }
     int find(const uint32_t* k, uint32_t n) const { return slots.empty() || n != key_len ? -1 : find_hashed(k, n, hash(k, n)); }
@@ -335,6 +464,10 @@ struct QueryMap {
         pool.clear();
         rec_pool.clear();
         slots.clear();
+        hashes.clear();
+        bloom.clear();
+        bloom_shift = 32;
+        pending_head = n_pending = 0;
     }
 
    private:

@@ -218,7 +218,7 @@ int64_t lurkhip_record_count(const lurkhip_record* r, int32_t kind, int32_t inde
         if (kind == 0) return (int64_t)r->q.func_queries.at(index).size();
         if (kind == 1) return (int64_t)r->q.mem_queries.at(lair::mem_index_from_len((uint32_t)index)).size();
         if (kind == 2) return r->q.has_public_values ? (int64_t)r->q.public_values.size() : -1;
-        if (kind == 3) return (int64_t)r->q.bytes.records.size();
+        if (kind == 3) return (int64_t)r->q.bytes.size();
         if (kind == 4) return (int64_t)r->q.emitted.size();
     } catch (...) {
     }
@@ -684,21 +684,19 @@ int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, u
     if (!r || !out) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
     *out = nullptr;
     return guarded(ctx, [&]() -> int32_t {
-        const bool is_real = shard_index == 0 && !r->q.bytes.records.empty();
+        const bool is_real = shard_index == 0 && !r->q.bytes.empty();
         const size_t host_words = (size_t)65536 * 12;
         uint32_t* host = nullptr;
         if (hipHostMalloc((void**)&host, host_words * 4, hipHostMallocDefault) != hipSuccess)
             return lurkhip::set_error(ctx, LURKHIP_ERR_OOM, "page-locked staging of the byte records failed");
         memset(host, 0, host_words * 4);
         if (is_real)
-            for (const auto& kv : r->q.bytes.records) {
-                const lair::Record recs[6] = {kv.second.range_u8, kv.second.range_u16, kv.second.less_than,
-                                              kv.second.and_,     kv.second.xor_,      kv.second.or_};
-                for (int k = 0; k < 6; k++) {
-                    host[(size_t)kv.first * 12 + 2 * k] = recs[k].nonce;
-                    host[(size_t)kv.first * 12 + 2 * k + 1] = recs[k].count;
+            for (uint32_t key = 0; key < 65536; key++)
+                for (int k = 0; k < lair::BYTES_KINDS; k++) {
+                    const lair::Record rec = r->q.bytes.get((uint16_t)key, k);
+                    host[(size_t)key * 12 + 2 * k] = rec.nonce;
+                    host[(size_t)key * 12 + 2 * k + 1] = rec.count;
                 }
-            }
         auto* p = new lurkhip_func_trace();
         p->kind = 2;
         p->is_real = is_real;
@@ -813,17 +811,15 @@ int32_t lurkhip_generate_trace_bytes(lurkhip_ctx* ctx, const lurkhip_record* r, 
     LH_CHECK_CTX(ctx);
     if (!r || !out_host) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
     return guarded(ctx, [&]() -> int32_t {
-        const bool is_real = shard_index == 0 && !r->q.bytes.records.empty();
+        const bool is_real = shard_index == 0 && !r->q.bytes.empty();
         std::vector<uint32_t> host((size_t)65536 * 12, 0);
         if (is_real)
-            for (const auto& kv : r->q.bytes.records) {
-                const lair::Record recs[6] = {kv.second.range_u8, kv.second.range_u16, kv.second.less_than,
-                                              kv.second.and_,     kv.second.xor_,      kv.second.or_};
-                for (int k = 0; k < 6; k++) {
-                    host[(size_t)kv.first * 12 + 2 * k] = recs[k].nonce;
-                    host[(size_t)kv.first * 12 + 2 * k + 1] = recs[k].count;
+            for (uint32_t key = 0; key < 65536; key++)
+                for (int k = 0; k < lair::BYTES_KINDS; k++) {
+                    const lair::Record rec = r->q.bytes.get((uint16_t)key, k);
+                    host[(size_t)key * 12 + 2 * k] = rec.nonce;
+                    host[(size_t)key * 12 + 2 * k + 1] = rec.count;
                 }
-            }
         void *din = nullptr, *dout = nullptr;
         LH_TRY(lurkhip::arena_get(ctx, 3, host.size() * 4, &din));
         LH_TRY(lurkhip::arena_get(ctx, 1, (size_t)65536 * 13 * 4, &dout));
