@@ -381,23 +381,31 @@ struct QueryMap {
                                       // without reading the keys again, and screens probes before a key comparison)
     size_t size() const { return vals.size(); }
     const uint32_t* key(size_t i) const { return key_pool.data() + i * key_len; }
-    // Four independent multiply chains over the key words, folded at the end (round 3: the one-chain hash -- xor, 64-bit
-    // multiply, shift-xor per word, each waiting for the last -- was 35 % of the interpreter under gprof: keys are 8 .. 40 words
-    // and every Call hashes one, every new query three).
+    // Keys are 2 .. 40 words and every Call / Store hashes one.  Round 3, first: four independent multiply chains instead of
+    // one (the one-chain hash was 35 % of the interpreter under gprof); then this: 64 x 64 -> 128-bit multiply-folds over four
+    // words at a time on two alternating accumulators and one fold at the end -- two multiplies for a 3-wide memory key.
+    static uint64_t mum(uint64_t a, uint64_t b) {
+        const unsigned __int128 r = (unsigned __int128)a * b;
+        return (uint64_t)r ^ (uint64_t)(r >> 64);
+    }
     static uint64_t hash(const uint32_t* k, uint32_t n) {
-        constexpr uint64_t C = 0xff51afd7ed558ccdull;
-        uint64_t h0 = 0x9e3779b97f4a7c15ull ^ n, h1 = 0xc2b2ae3d27d4eb4full, h2 = 0x165667b19e3779f9ull, h3 = 0x85ebca77c2b2ae63ull;
+        constexpr uint64_t S0 = 0x9e3779b97f4a7c15ull, S1 = 0xc2b2ae3d27d4eb4full, S2 = 0x165667b19e3779f9ull, S3 = 0x85ebca77c2b2ae63ull,
+                           S4 = 0xff51afd7ed558ccdull;
+        uint64_t h0 = S0 ^ n, h1 = S1;
         uint32_t i = 0;
-        for (; i + 4 <= n; i += 4) {
-            h0 = (h0 ^ k[i]) * C;
-            h1 = (h1 ^ k[i + 1]) * C;
-            h2 = (h2 ^ k[i + 2]) * C;
-            h3 = (h3 ^ k[i + 3]) * C;
+        for (; i + 8 <= n; i += 8) {
+            h0 = mum((k[i] | (uint64_t)k[i + 1] << 32) ^ S2, (k[i + 2] | (uint64_t)k[i + 3] << 32) ^ h0);
+            h1 = mum((k[i + 4] | (uint64_t)k[i + 5] << 32) ^ S3, (k[i + 6] | (uint64_t)k[i + 7] << 32) ^ h1);
         }
-        for (; i < n; i++) h0 = ((h0 ^ k[i]) * C) ^ (h0 >> 31);
-        uint64_t h = (h0 ^ (h1 >> 17) ^ (h1 << 47)) * C;
-        h = (h ^ h2 ^ (h3 >> 29) ^ (h3 << 35)) * C;
-        return h ^ (h >> 32);
+        if (i + 4 <= n) {
+            h0 = mum((k[i] | (uint64_t)k[i + 1] << 32) ^ S2, (k[i + 2] | (uint64_t)k[i + 3] << 32) ^ h0);
+            i += 4;
+        }
+        if (i < n) {
+            const uint64_t a = k[i] | (i + 1 < n ? (uint64_t)k[i + 1] << 32 : 0), b = i + 2 < n ? k[i + 2] : 0;
+            h1 = mum(a ^ S3, (b | (uint64_t)(n - i) << 32) ^ h1);
+        }
+        return mum(h0 ^ S4, h1 ^ S2);
     }
     // Absent keys are the common lookup (every new query, every fresh memory cell), and the index of a multi-million-entry
     // table is a DRAM access per probe.  So (round 3): a blocked Bloom filter beside the index -- three bits in one 64-byte
