@@ -439,13 +439,13 @@ struct QueryMap {
         if (!bloom_maybe((uint32_t)h)) return -1;
         for (uint32_t j = 0; j < n_pending; j++) {
             const Pending& p = pending[(pending_head + j) % MAX_PENDING];
-            if (p.h32 == (uint32_t)h && memcmp(key(p.index), k, (size_t)n * 4) == 0) return (int)p.index;
+            if (p.h32 == (uint32_t)h && (n == 0 || memcmp(key(p.index), k, (size_t)n * 4) == 0)) return (int)p.index;
         }
         const size_t mask = slots.size() - 1;
         for (size_t s = h & mask;; s = (s + 1) & mask) {
             const uint32_t e = slots[s];
             if (!e) return -1;
-            if (hashes[e - 1] == (uint32_t)h && memcmp(key(e - 1), k, (size_t)n * 4) == 0) return (int)(e - 1);
+            if (hashes[e - 1] == (uint32_t)h && (n == 0 || memcmp(key(e - 1), k, (size_t)n * 4) == 0)) return (int)(e - 1);
         }
     }
     int find(const uint32_t* k, uint32_t n) const { return slots.empty() || n != key_len ? -1 : find_hashed(k, n, hash(k, n)); }

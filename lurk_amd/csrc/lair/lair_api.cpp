@@ -197,7 +197,7 @@ int32_t lurkhip_execute(lurkhip_record* r, int32_t func_idx, const uint32_t* arg
         for (uint32_t v : a)
             if (v >= lair::P) throw lair::ExecError("argument is not a canonical field element");
         lair::List o = lair::execute(r->top->t, r->top->t.funcs[func_idx], a, r->q);
-        if (out) memcpy(out, o.data(), o.size() * 4);
+        if (out && !o.empty()) memcpy(out, o.data(), o.size() * 4);
         return LURKHIP_OK;
     });
 }
