@@ -208,6 +208,8 @@ def main():
     ap.add_argument("--rank-pipeline", action="store_true",
                     help="N > 1 (or --shards-per-rank > 1): phase 1 of machine proof j + 1 under phase 2 of proof j on a second machine (measured on one "
                          "GPU through RCCL at world 1: 47.9 against 46.4 ms per step -- phase 2 already keeps two shards in flight; off by default)")
+    ap.add_argument("--rank-pipeline-one-lane", action="store_true",
+                    help="with --rank-pipeline: phase 2 proves the rank's shards one after the other on ONE lane (two streams busy in all: phase 2 of proof j, phase 1 of proof j + 1) instead of two")
     ap.add_argument("--stagger-ms", type=float, default=0.0,
                     help="--lanes >= 2: lane k starts its first timed proof k * this many milliseconds late (inside the timed region), so that the lanes run out of phase")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
@@ -286,6 +288,8 @@ def main():
     top.execute(top.func_index(entry), main_args, queries)
     t_execute = time.perf_counter() - t0
     pv = queries.expect_public_values()
+    host_queries = sum(queries.num_func_queries(i) for i in range(top.num_funcs()))
+    host_mem_cells = sum(queries.num_mem_queries(ml) for ml in (2, 3, 4, 5, 6, 8))
     eval_idx = top.func_index(eval_name)
     eval_rows_total = queries.num_func_queries(eval_idx)
     assert eval_rows_total == world * n, (eval_rows_total, world, n)
@@ -318,7 +322,8 @@ def main():
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
     input_bytes = sum(p.input_bytes for pr in prepared_all for *_, p in pr if p is not None)
     main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
-    lane_ctx = prover.lane_context(machine) if len(mine) > 1 else None  # the second proving lane of a rank with several shards
+    one_lane = args.rank_pipeline and args.rank_pipeline_one_lane
+    lane_ctx = prover.lane_context(machine) if len(mine) > 1 and not one_lane else None  # the second proving lane of a rank with several shards
 
     # the step itself lives in lurk_amd/shards.py (RankStep) so that the multi-process tests run exactly what is timed here
     rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx)
@@ -344,9 +349,9 @@ def main():
         if not args.no_compile:
             for pr in prepared_b:
                 machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
-        lane_ctx_b = prover.lane_context(machine_b)
+        lane_ctx_b = prover.lane_context(machine_b) if not one_lane else None
         rank_step_b = shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b)
-        pipe = {"steps": [rank_step, rank_step_b], "ctxs": [ctx_b, lane_ctx_b], "machine": machine_b, "prepared": prepared_b}
+        pipe = {"steps": [rank_step, rank_step_b], "ctxs": [c for c in (ctx_b, lane_ctx_b) if c is not None], "machine": machine_b, "prepared": prepared_b}
 
     def fence():
         ctx.sync()
@@ -743,6 +748,8 @@ def main():
                     "note": "every rank runs the WHOLE program through the host interpreter before proving (same query record on every rank, no broadcast of row streams); that time is outside the timed region and is the end-to-end Amdahl bound",
                     "host_execute_s_wall": max(exec_s_per_rank), "host_execute_s_summed_over_ranks": sum(exec_s_per_rank),
                     "host_interpreter_eval_rows_per_s": world * n / max(exec_s_per_rank),
+                    "host_interpreter_queries": host_queries, "host_interpreter_memory_cells": host_mem_cells,
+                    "host_interpreter_queries_per_s": host_queries / t_execute,
                     "eval_steps_per_s_including_execute": world * n / (max(exec_s_per_rank) + ms_per_step * 1e-3),
                 },
                 "host_flatten_upload_s": t_flatten,

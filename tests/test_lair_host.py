@@ -173,3 +173,52 @@ def test_trace_run_time_compiler_builds_without_a_device():
     # a match with several keys per arm and a default arm is one if / else-if chain
     top = lair.Toplevel(load_cases()[0]["source"])
     assert lair.FuncChip.from_name(None, "fib", top).trace_kernel_source().count("if (") >= 1
+
+
+def test_memo_index_screens_and_deferred_seats_agree_with_the_oracle():
+    """The query tables' Bloom screen and deferred index seats (lair.h: QueryMap, round 3): a key inserted a moment ago is
+    looked up again before it has its seat (same store twice in a row, same call twice in a row), tables grow several times
+    with entries waiting, and stores alternate between fresh and repeated tuples.  Pointers are outputs here, so a wrong
+    index shows in the result; the query and memory counts must equal the oracle interpreter's."""
+    src = """
+    fn leaf(a, b): [2] {
+        let p = store(a, b);
+        let q = store(a, b);
+        let d = sub(p, q);
+        let (x, y) = load(p);
+        let s = add(x, y);
+        return (s, d)
+    }
+    fn walk(n, acc): [2] {
+        if !n {
+            let z = 0;
+            return (acc, z)
+        }
+        let one = 1;
+        let three = 3;
+        let m = sub(n, one);
+        let k = mul(n, three);
+        let (s1, d1) = call(leaf, n, k);
+        let (s2, d2) = call(leaf, n, k);
+        let t = store(s1, s2, d1);
+        let u = store(s1, s2, d1);
+        let e = sub(t, u);
+        let f = add(d1, d2);
+        let g = add(e, f);
+        let acc1 = add(acc, s1);
+        let acc2 = add(acc1, g);
+        let (r, w) = call(walk, m, acc2);
+        let v = add(w, t);
+        return (r, v)
+    }
+    """
+    top, otop = lair.Toplevel.new_pure(src), ol.Toplevel(src)
+    q, oq = lair.QueryRecord(top), ol.QueryRecord(otop)
+    n = 5000  # 10 k table entries per kind: the index grows four times past its first 1024 slots
+    got, want = top.execute_by_name("walk", [n, 7], q), ol.execute(otop, "walk", [n, 7], oq)
+    assert got == want
+    for i in range(top.num_funcs()):
+        assert q.num_func_queries(i) == len(oq.func[i])
+    for k, ml in enumerate(ol.MEM_TABLE_SIZES):
+        assert q.num_mem_queries(ml) == len(oq.mem[k])
+    assert q.num_mem_queries(2) == n and q.num_mem_queries(3) == n
