@@ -122,9 +122,13 @@ void span_switch(lurkhip_ctx* ctx, const char* from, const char* to, int level =
 
 }  // namespace lurkhip
 
+// Every entry point starts here: the calling thread's current device becomes the context's (a new host thread starts on
+// device 0 -- the lanes' worker threads of a rank that owns GPU 3 would otherwise launch on streams of another device).
 #define LH_CHECK_CTX(ctx)                                                            \
     do {                                                                             \
         if (!(ctx)) return lurkhip::set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null ctx"); \
+        if (hipSetDevice((ctx)->device) != hipSuccess)                               \
+            return lurkhip::set_error((ctx), LURKHIP_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device); \
     } while (0)
 
 #define LH_HIP(ctx, expr)                                                                              \

@@ -304,7 +304,7 @@ class Machine(_ShardProver):
         import torch
 
         prep = BytesChip(self.ctx).generate_preprocessed_trace(repr=N.REPR_MONTY)
-        self._prep = torch.from_numpy(prep.view(np.int32)).cuda()
+        self._prep = torch.from_numpy(prep.view(np.int32)).cuda(self.ctx.device)
         ptrs = (C.c_void_p * 1)(self._prep.data_ptr())
         lh = np.array([16], dtype=np.uint32)
         ws = np.array([6], dtype=np.uint32)
@@ -328,7 +328,7 @@ class Machine(_ShardProver):
             if kind == "entrypoint":
                 if shard.index != 0:
                     continue
-                t = torch.from_numpy(field.to_monty(entrypoint_trace(shard.queries)).view(np.int32)).cuda()
+                t = torch.from_numpy(field.to_monty(entrypoint_trace(shard.queries)).view(np.int32)).cuda(self.ctx.device)
             elif kind == "func":
                 chip = FuncChip(self.ctx, arg, self.toplevel)
                 n, h, w = chip.trace_shape(shard)
@@ -336,14 +336,14 @@ class Machine(_ShardProver):
                     continue
                 # torch.empty, not zeros: a fill would be enqueued on torch's stream, which is not ordered with the
                 # context's (non-blocking) stream, and could land after the trace kernel; the kernel writes every word
-                t = torch.empty((h, w), dtype=torch.int32, device="cuda")
+                t = torch.empty((h, w), dtype=torch.int32, device=f"cuda:{self.ctx.device}")
                 chip.generate_trace_dev(shard, t, repr=N.REPR_MONTY)
             elif kind == "mem":
                 if shard.index != 0:
                     continue
-                t = torch.from_numpy(MemChip(self.ctx, arg).generate_trace(shard, repr=N.REPR_MONTY).view(np.int32)).cuda()
+                t = torch.from_numpy(MemChip(self.ctx, arg).generate_trace(shard, repr=N.REPR_MONTY).view(np.int32)).cuda(self.ctx.device)
             else:
-                t = torch.from_numpy(BytesChip(self.ctx).generate_trace(shard, repr=N.REPR_MONTY).view(np.int32)).cuda()
+                t = torch.from_numpy(BytesChip(self.ctx).generate_trace(shard, repr=N.REPR_MONTY).view(np.int32)).cuda(self.ctx.device)
             out.append((mi, air, t.shape[0].bit_length() - 1, t))
         self.ctx.sync()
         return out
@@ -378,7 +378,7 @@ class Machine(_ShardProver):
             if kind == "entrypoint":
                 if shard.index != 0:
                     continue
-                t = torch.from_numpy(field.to_monty(entrypoint_trace(shard.queries)).view(np.int32)).cuda()
+                t = torch.from_numpy(field.to_monty(entrypoint_trace(shard.queries)).view(np.int32)).cuda(self.ctx.device)
                 out.append((mi, air, 0, t, None))
                 continue
             if kind == "func":
@@ -391,7 +391,7 @@ class Machine(_ShardProver):
                 p = PreparedFuncTrace(MemChip(ictx, arg), shard)
             else:
                 p = PreparedFuncTrace(BytesChip(ictx), shard)
-            t = torch.empty((p.height, p.width), dtype=torch.int32, device="cuda")  # every word is written by the trace kernel
+            t = torch.empty((p.height, p.width), dtype=torch.int32, device=f"cuda:{self.ctx.device}")  # every word is written by the trace kernel
             out.append((mi, air, p.height.bit_length() - 1, t, p))
         if input_ctx is None:
             ictx.sync()
