@@ -292,7 +292,11 @@ std::shared_ptr<Block> read_block(Reader& r) {
 struct Validator {
     const Toplevel& t;
     const Func& f;
-    uint32_t next_ident = 0;
+    // Return selectors: a permutation of 0 .. n_returns-1.  NOT required to ascend in the order the blocks are stored: the
+    // reference numbers them in SOURCE order (toplevel.rs:531-540) and then sorts a ChooseMany's arms by key
+    // (toplevel.rs:557-570, map.rs:16-22), so a `match` over an array whose arms are not written in ascending key order has
+    // its selectors out of storage order.
+    std::vector<bool> ident_seen;
     void bad(const std::string& m) const { throw ParseError("bytecode of " + f.name + ": " + m); }
     void refs(const std::vector<uint32_t>& l, uint64_t height) const {
         for (uint32_t v : l)
@@ -377,8 +381,10 @@ struct Validator {
         if (c.kind == Ctrl::Return) {
             if (c.ret.size() != f.output_size) bad("return size differs from the declared output size");
             refs(c.ret, height);
-            if (c.ident != next_ident) bad("return selectors must be numbered in block order");
-            next_ident++;
+            if (c.ident >= (1u << 24)) bad("implausible return selector");
+            if (ident_seen.size() <= c.ident) ident_seen.resize((size_t)c.ident + 1, false);
+            if (ident_seen[c.ident]) bad("two returns share a selector");
+            ident_seen[c.ident] = true;
             idents.push_back(c.ident);
         } else {
             if (c.kind == Ctrl::Choose) {
@@ -408,7 +414,12 @@ struct Validator {
             }
             if (idents.empty()) bad("a block must have at least one return");
         }
-        if (idents != b.return_idents) bad("return_idents do not list the block's returns");
+        {
+            std::vector<uint32_t> have = idents, want = b.return_idents;
+            std::sort(have.begin(), have.end());
+            std::sort(want.begin(), want.end());
+            if (have != want) bad("return_idents do not list the block's returns");
+        }
         return idents;
     }
 };
@@ -465,8 +476,10 @@ Toplevel toplevel_from_bytecode(const uint32_t* words, size_t n_words) {
     }
     if (r.pos != r.n) throw ParseError("bytecode blob: trailing words");
     for (const auto& f : t.funcs) {
-        Validator v{t, f};
+        Validator v{t, f, {}};
         v.block(f.body, f.input_size);
+        for (bool seen : v.ident_seen)
+            if (!seen) v.bad("return selectors are not 0 .. n_returns-1");
     }
     return t;
 }

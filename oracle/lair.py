@@ -307,6 +307,9 @@ class Toplevel:
                 ops.append(("inv", [t], [inp[1]], None))
                 ops.append(("mul", out, [inp[0], t], None))
             elif kind == "eq":
+                # /root/reference/src/lair/toplevel.rs:622-629: eq (like not) is defined on single elements only
+                if inp[0][1] != 1 or inp[1][1] != 1 or out[0][1] != 1:
+                    raise ValueError("eq needs size-1 operands")
                 t = (f"${ctx[0]}", inp[0][1])
                 ctx[0] += 1
                 ops.append(("sub", [t], [inp[0], inp[1]], None))
@@ -406,6 +409,8 @@ class Toplevel:
                 ops += [("inv", x) for x in st["link"][inp[0]]]
                 self._new(out[0], st)
             elif kind == "not":
+                if len(st["link"][inp[0]]) != 1:  # toplevel.rs:616-621
+                    raise ValueError("not needs a size-1 operand")
                 ops.append(("not", st["link"][inp[0]][0]))
                 self._new(out[0], st)
             elif kind in ("call", "preimg"):
@@ -986,9 +991,14 @@ def to_bytecode(top: Toplevel):
                 lst(v)
                 keys = sorted(cases)
                 w.append(len(keys))
+                by_arm = {}
                 for key in keys:
                     lst([x % P for x in key])
-                    idents += block(cases[key])
+                    by_arm[id(cases[key])] = block(cases[key])
+                # `return_idents` is the list the compiler collected, i.e. in SOURCE order of the arms
+                # (/root/reference/src/lair/toplevel.rs:557-570: compiled in source order, then sorted by key for storage)
+                for u in uniq:
+                    idents += by_arm[id(u)]
             w.append(1 if d is not None else 0)
             if d is not None:
                 idents += block(d)

@@ -276,3 +276,33 @@ def test_extern_chip_airs_match_oracle(ctx, oracle):
         assert a.width == width and a.max_constraint_degree <= 3
         local, nxt, sels = rows_for(width, rows[:4], seed=300 + i)
         compare(ctx, a, oa.FuncAir(otop, f["name"]), local[:8], nxt[:8], sels[:8])
+
+
+@pytest.mark.parametrize("seed", [6, 16, 35, 41, 52, 62, 68])
+def test_random_programs_func_air_matches_oracle(ctx, seed):
+    """AIRs of random programs (tests/lair_random.py): the device evaluator and the oracle's numeric AIR agree constraint by
+    constraint and tuple by tuple on real row pairs and on random rows with random selectors; and the oracle's own property
+    check (every constraint vanishes on every real row, lookups balance) accepts the machine."""
+    import lair_random as lr
+
+    src, calls, _ = lr.program(seed)
+    top, otop = lair.Toplevel(src), ol.Toplevel(src)
+    oq = ol.QueryRecord(otop)
+    for name, args in calls[:1]:
+        ol.execute(otop, name, args, oq)
+    chips = [(oa.EntrypointAir(otop.index[calls[0][0]], len(oq.public_values)), [list(oq.public_values)], None)]
+    for i, f in enumerate(otop.funcs):
+        rows, width = ol.generate_trace(otop, f["name"], oq)
+        if rows:
+            chips.append((oa.FuncAir(otop, f["name"]), rows, None))
+        if len(rows) < 2:
+            rows = [[0] * width, [0] * width]
+        a = air.ChipAir.for_func(top, i)
+        assert a.width == width
+        local, nxt, sels = rows_for(width, rows[:40], seed=300 + i)
+        compare(ctx, a, oa.FuncAir(otop, f["name"]), local, nxt, sels)
+    for ml in ol.MEM_TABLE_SIZES:
+        chips.append((oa.MemAir(ml), ol.mem_trace(oq, ml), None))
+    prep = [[i & 0xFF, i >> 8, int((i & 0xFF) < (i >> 8)), (i & 0xFF) & (i >> 8), (i & 0xFF) ^ (i >> 8), (i & 0xFF) | (i >> 8)] for i in range(1 << 16)]
+    chips.append((oa.BytesAir(), ol.bytes_trace(oq), prep))
+    assert oa.debug_check(chips, public=oq.public_values) > 0

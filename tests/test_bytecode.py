@@ -26,6 +26,28 @@ def _programs():
     out.append(("partial", PARTIAL_SRC, False, [("top", [9])]))
     out.append(("u64", U64_SRC, True, [("chain", [1, 2, 3, 4, 5, 6, 7, 8])]))
     out.append(("synth_eval", se.SOURCE, False, [(se.FUNC, se.args_for_rows(50))]))
+    # arms of an array match written in DESCENDING key order: the reference numbers the return selectors in source order and
+    # then sorts the arms by key (toplevel.rs:557-570, map.rs:16-22), so the stored blocks carry selectors 2, 1, 0
+    out.append(("match_many_descending", """
+fn t(a: [2]): [1] {
+    match a {
+        [2, 0] => {
+            let x = 20;
+            return x
+        }
+        [1, 0] => {
+            let x = 10;
+            return x
+        }
+        [0, 1] => {
+            let x = 1;
+            return x
+        }
+    };
+    let z = 0;
+    return z
+}
+""", False, [("t", [2, 0]), ("t", [0, 1]), ("t", [1, 0]), ("t", [5, 5])]))
     fm, mm = lm.fib_mix(520), lm.lurk_mix(700)
     out.append(("fib-mix", fm.source, True, [(fm.entry, fm.main_args)]))
     out.append(("lurk-mix", mm.source, True, [(mm.entry, mm.main_args)]))

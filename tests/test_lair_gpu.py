@@ -302,3 +302,25 @@ def test_compiled_trace_kernels_every_function(ctx, workload, monkeypatch):
         c.compile_trace()
         for sh, t in zip(shards, w):
             assert np.array_equal(c.generate_trace(sh, repr=1), t), (c.func_idx, sh.index)
+
+
+@pytest.mark.parametrize("seed,const_times_var", [(s, False) for s in (6, 9, 16, 22, 24, 29, 35, 41, 51, 52, 58, 62, 68)] + [(27, True), (52, True), (94, True)])
+def test_random_programs_vs_oracle(ctx, oracle, seed, const_times_var):
+    """Random programs (tests/lair_random.py: nested and array matches in any arm order, if / if !, every memory width,
+    div / eq / not, asserts, preimages, partial functions): every function's GPU trace == the oracle's trace generator, unsharded
+    and in shards of 3 rows, on the row interpreter and on the compiled row kernels; memory and byte chips too."""
+    import lair_random as lr
+
+    # const_times_var: products of a constant and a variable -- they have a trace (no aux column: func_chip.rs:202-211,
+    # trace.rs:291-302) although the reference's AIR disagrees with its own layout about them (air.rs:345-358)
+    src, calls, _ = lr.program(seed, const_times_var=const_times_var)
+    top, q, oq = _compare_all_funcs(ctx, oracle, src, calls, shard_sizes=(1 << 22, 3))
+    otop = ol.Toplevel(src)
+    for size in (1 << 22, 3):
+        for sh in lair.Shard.new(q).shard(lair.ShardingConfig(size)):
+            for i, f in enumerate(otop.funcs):
+                chip = lair.FuncChip(ctx, i, top)
+                chip.compile_trace()
+                rows_, width = ol.generate_trace(otop, f["name"], oq, sh.index, size)
+                got = chip.generate_trace(sh)
+                assert got.shape == (len(rows_), width) and got.tolist() == rows_, (f["name"], sh.index, size, "compiled")
