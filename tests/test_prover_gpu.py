@@ -281,3 +281,17 @@ def test_prover_edge_parameters_and_errors(ctx):
     ch.observe([1, 2, 3])
     a = ch.clone()
     assert a.sample_ext() == ch.sample_ext()  # clones continue identically
+
+
+@pytest.mark.parametrize("seed,shard_size", [(s, (None, 2, None, 3, None, 4)[s % 6]) for s in range(48)])
+def test_random_machines_prove_and_verify(ctx, seed, shard_size):
+    """Random programs (tests/lair_random.py) as whole machines: chips of 1 .. 64 rows with every kind of column (nested and
+    array matches, every memory width, preimages, partial functions with depth columns and byte lookups), proved -- some of them
+    in shards of 2 .. 4 rows -- and verified by the oracle from its own AIRs; the compiled AIR kernels produce the same proof."""
+    import lair_random as lr
+
+    src, calls, _ = lr.program(seed)
+    entry, args = calls[0]
+    m, root, proofs, pv = prove(ctx, src, entry, args, shard_size=shard_size)
+    assert verify(src, entry, root, proofs, len(pv))
+    assert prover.grand_sum(proofs) == (0, 0, 0, 0)
