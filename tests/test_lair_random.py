@@ -40,3 +40,42 @@ def test_random_programs_interpreter_and_layout_vs_oracle(chunk):
         q2, _ = _run(again, otop, calls)
         assert [q2.num_func_queries(i) for i in range(top.num_funcs())] == [q.num_func_queries(i) for i in range(top.num_funcs())], seed
     assert total_queries > 100  # the chunk exercised something
+
+
+def test_parser_and_compiler_survive_mutated_sources():
+    """Token-level mutations of valid programs (dropped, duplicated, swapped and replaced tokens): the C++ parser / compiler
+    answers with a program or an error status, never a crash; whatever still compiles round-trips through the bytecode.
+    (tools/asan_host.sh runs this under AddressSanitizer + UBSan.)"""
+    import random
+    import re
+
+    rnd = random.Random(0x4C55524B)
+    vocab = ["{", "}", "(", ")", "[", "]", ";", ",", "=>", "=", "let", "match", "if", "!", "return", "call", "store", "load", "fn", "partial",
+             "invertible", "preimg", "0", "1", "2013265921", "4294967295", "99999999999999999999", "x", "n", ":", "add", "mul", "assert_eq!", "range_u8!"]
+    compiled = errors = 0
+    for seed in range(40):
+        src, _, _ = lr.program(seed)
+        toks = re.findall(r"[A-Za-z_][A-Za-z_0-9]*!?|\d+|=>|\S", src)
+        for _ in range(12):
+            t = list(toks)
+            for _ in range(rnd.randint(1, 3)):
+                i = rnd.randrange(len(t))
+                k = rnd.random()
+                if k < 0.3:
+                    del t[i]
+                elif k < 0.5:
+                    t.insert(i, t[i])
+                elif k < 0.7:
+                    j = rnd.randrange(len(t))
+                    t[i], t[j] = t[j], t[i]
+                else:
+                    t[i] = rnd.choice(vocab)
+            try:
+                top = lair.Toplevel.new_pure(" ".join(t))
+            except lair.LairError:
+                errors += 1
+                continue
+            compiled += 1
+            again = lair.Toplevel.from_bytecode(top.to_bytecode())
+            assert again.num_funcs() == top.num_funcs()
+    assert errors > 100 and compiled >= 3, (errors, compiled)
