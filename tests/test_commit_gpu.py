@@ -310,3 +310,36 @@ def test_baseline_config5_at_full_height(ctx, oracle):
         for i, col in col_lde.items():
             assert rows[offs[i] + 7] == col[index >> (top - lh[i])]
     c.close()
+
+
+@pytest.mark.parametrize("seed", range(40))
+def test_commit_random_shape_sets(ctx, oracle, seed):
+    """Random sets of 1 .. 14 matrices -- heights 2^0 .. 2^13 (repeated heights, gaps, one tall matrix or none), widths 1 .. 140
+    with a few hash-chip-wide ones, blow-up 1 or 2 -- against the oracle: root, opened rows at random indices, Merkle paths."""
+    import random
+
+    rng = random.Random(7000 + seed)
+    n = rng.randint(1, 14)
+    top = rng.randint(0, 13)
+    shapes = []
+    for i in range(n):
+        k = top if i == 0 else rng.choice([top, rng.randint(0, top), rng.randint(0, top), max(0, top - 1)])
+        w = rng.choice([1, 2, 3, 4, 7, 8, 9, 16, 17, 31, 32, 33, 52, 64, 78, 107, 140, rng.randint(1, 140)])
+        if rng.random() < 0.08 and k <= 9:
+            w = rng.choice([493, 655, 815])
+        shapes.append((k, w))
+    b = rng.choice([1, 1, 2])
+    mats = [synth.field_elements((1 << k, w), seed=9000 + 40 * seed + i) for i, (k, w) in enumerate(shapes)]
+    c = cm.commit(ctx, mats, log_blowup=b)
+    ldes = [oracle.lde(m, b) for m in mats]
+    root, _ = oracle.merkle_commit(ldes)
+    assert np.array_equal(c.root, root), shapes
+    lh = [k + b for k, _ in shapes]
+    ws = [w for _, w in shapes]
+    hmax = max(lh)
+    for index in [0, (1 << hmax) - 1] + [rng.randrange(1 << hmax) for _ in range(3)]:
+        rows, path = c.open(index)
+        want = np.concatenate([ldes[i][index >> (hmax - lh[i])] for i in range(len(mats))])
+        assert np.array_equal(rows, want), (shapes, index)
+        assert oracle.merkle_verify(lh, ws, index, rows, path, c.root), (shapes, index)
+    c.close()
