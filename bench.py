@@ -477,6 +477,13 @@ def main():
     for cx_ in (pipe["ctxs"] if pipe else []):
         cx_.profile_reset()
         cx_.profile_enable(not args.no_spans)
+    # every context that works in the timed region: no device allocation may happen there (a hipMalloc synchronises the device)
+    timed_ctxs = [("main", ctx)] + ([("lane", lane_ctx)] if lane_ctx is not None else [])
+    if pipe is not None:
+        timed_ctxs += [(f"pipe{k}", c) for k, c in enumerate(pipe["ctxs"])]
+    if lane2:
+        timed_ctxs += [(f"proof_lane{k + 1}", c) for k, (_, c, _) in enumerate(lane2)]
+    mallocs_before = {k: c.pool_stats()["mallocs"] for k, c in timed_ctxs}
     t0 = time.perf_counter()
     words = None
     step_words = []
@@ -505,6 +512,9 @@ def main():
             step_words.append(words)  # compared after the timed region: the same shard must give the same proof every step
     fence()
     elapsed = time.perf_counter() - t0
+    pool_after = {k: c.pool_stats() for k, c in timed_ctxs}
+    pool_report = {"hipMalloc_calls_in_timed_region": {k: v["mallocs"] - mallocs_before[k] for k, v in pool_after.items()},
+                   "peak_bytes": {k: v["peak_bytes"] for k, v in pool_after.items()}}
     if pipe is not None:
         # the second machine's records count too (collectives' host time, sums); the gathered-set check below takes the LAST proof
         other = pipe["steps"][1]
@@ -742,6 +752,7 @@ def main():
                 "collectives_host_ms_per_step": {k: v / (args.steps + args.warmup) for k, v in host_ms.items()},
                 "proofs_identical_across_steps": proofs_identical,
                 "hbm_resident_input_bytes": int(input_bytes),
+                "device_pools": pool_report,
                 "host_execute_s": t_execute,
                 "host_execute_s_per_rank": exec_s_per_rank,
                 "end_to_end": {
