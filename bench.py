@@ -208,6 +208,9 @@ def main():
     ap.add_argument("--rank-pipeline", action="store_true",
                     help="N > 1 (or --shards-per-rank > 1): phase 1 of machine proof j + 1 under phase 2 of proof j on a second machine (measured on one "
                          "GPU through RCCL at world 1: 47.9 against 46.4 ms per step -- phase 2 already keeps two shards in flight; off by default)")
+    ap.add_argument("--rank-pipeline-depth", type=int, default=2,
+                    help="with --rank-pipeline: machines per rank.  2 = phase 1 of proof j + 1 under phase 2 of proof j, joined once per proof "
+                         "(shards.run_pipelined); >= 3 = a committer thread runs phase 1 up to depth - 1 proofs ahead (shards.run_committed_ahead)")
     ap.add_argument("--rank-pipeline-one-lane", action="store_true",
                     help="with --rank-pipeline: phase 2 proves the rank's shards one after the other on ONE lane (two streams busy in all: phase 2 of proof j, phase 1 of proof j + 1) instead of two")
     ap.add_argument("--stagger-ms", type=float, default=0.0,
@@ -338,20 +341,25 @@ def main():
     # lane idles early) -- shards.run_pipelined.  All collectives stay on this thread, in the same order on every rank.
     pipe = None
     if len(mine) > 1 and args.rank_pipeline:
-        ctx_b = lurk_amd.Context(device_index)
-        if args.profile != "default":
-            from lurk_amd.profile import ProtocolProfile
+        pipe = {"steps": [rank_step], "ctxs": [], "machines": [], "prepared": []}
+        for _ in range(max(2, args.rank_pipeline_depth) - 1):
+            ctx_b = lurk_amd.Context(device_index)
+            if args.profile != "default":
+                from lurk_amd.profile import ProtocolProfile
 
-            ProtocolProfile.preset(args.profile).install(ctx_b)
-        machine_b = prover.Machine(ctx_b, top, entry, len(pv))
-        assert machine_b.setup() == vk_root
-        prepared_b = [machine_b.prepare_shard(all_shards[i]) for i in mine]
-        if not args.no_compile:
-            for pr in prepared_b:
-                machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
-        lane_ctx_b = prover.lane_context(machine_b) if not one_lane else None
-        rank_step_b = shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b)
-        pipe = {"steps": [rank_step, rank_step_b], "ctxs": [c for c in (ctx_b, lane_ctx_b) if c is not None], "machine": machine_b, "prepared": prepared_b}
+                ProtocolProfile.preset(args.profile).install(ctx_b)
+            machine_b = prover.Machine(ctx_b, top, entry, len(pv))
+            assert machine_b.setup() == vk_root
+            prepared_b = [machine_b.prepare_shard(all_shards[i]) for i in mine]
+            if not args.no_compile:
+                for pr in prepared_b:
+                    machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
+            lane_ctx_b = prover.lane_context(machine_b) if not one_lane else None
+            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b))
+            pipe["ctxs"] += [c for c in (ctx_b, lane_ctx_b) if c is not None]
+            pipe["machines"].append(machine_b)
+            pipe["prepared"].append(prepared_b)
+        pipe["run"] = shards.run_pipelined if len(pipe["steps"]) == 2 else shards.run_committed_ahead
 
     def fence():
         ctx.sync()
@@ -370,7 +378,7 @@ def main():
     for _ in range(args.warmup):
         step()
     if pipe is not None:  # warm the second machine and the pipeline's worker
-        shards.run_pipelined(pipe["steps"], 2)
+        pipe["run"](pipe["steps"], len(pipe["steps"]))
         for cx_ in pipe["ctxs"]:
             cx_.sync()
     fence()
@@ -500,7 +508,7 @@ def main():
         def keep(j, proofs):
             step_words.append(np.concatenate(proofs) if len(proofs) > 1 else proofs[0])
 
-        shards.run_pipelined(pipe["steps"], args.steps, on_proofs=keep)
+        pipe["run"](pipe["steps"], args.steps, on_proofs=keep)
         for cx_ in pipe["ctxs"]:
             cx_.sync()
         words = step_words[-1]
@@ -517,13 +525,12 @@ def main():
                    "peak_bytes": {k: v["peak_bytes"] for k, v in pool_after.items()}}
     if pipe is not None:
         # the second machine's records count too (collectives' host time, sums); the gathered-set check below takes the LAST proof
-        other = pipe["steps"][1]
-        grand_sums += other.grand_sums
-        rank_sums += other.rank_sums
-        for k_, v_ in other.host_ms.items():
-            host_ms[k_] = host_ms.get(k_, 0.0) + v_
-        if (args.steps - 1) % 2 == 1:
-            rank_step = other
+        for other in pipe["steps"][1:]:
+            grand_sums += other.grand_sums
+            rank_sums += other.rank_sums
+            for k_, v_ in other.host_ms.items():
+                host_ms[k_] = host_ms.get(k_, 0.0) + v_
+        rank_step = pipe["steps"][(args.steps - 1) % len(pipe["steps"])]
     proofs_identical = all(len(w) == len(step_words[0]) and bool((w == step_words[0]).all()) for w in step_words[1:])
     del step_words
     ctx.profile_enable(False)
@@ -815,7 +822,8 @@ def main():
     del prepared, prepared_all
     if pipe is not None:
         del pipe["prepared"]
-        pipe["machine"].close()
+        for m_ in pipe["machines"]:
+            m_.close()
         for cx_ in reversed(pipe["ctxs"]):
             cx_.close()
     while lane2:

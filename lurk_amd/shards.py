@@ -222,6 +222,51 @@ def run_pipelined(steps, n_steps: int, on_proofs=None):
         pool.shutdown(wait=True)
 
 
+def run_committed_ahead(steps, n_steps: int, on_proofs=None):
+    """n_steps machine proofs on this rank with phase 1 running AHEAD on its own thread (round 3, second attempt at filling a
+    rank's device: `run_pipelined` joins the two phases once per proof, so phase 2 runs alone whenever phase 1 of the next proof
+    is done first).
+
+    `steps` = K >= 2 RankStep objects over K Machines of the same toplevel (own contexts, own prepared inputs); proof j runs on
+    steps[j % K].  A committer thread produces phase 1 (traces + main commitments, no collective) of proofs 0, 1, 2, ... as fast
+    as machines come free -- at most K - 1 ahead of the proof being finished --, the calling thread does exchange -> phase 2 ->
+    check for each proof in order: every collective is issued by the calling thread, in the same order on every rank."""
+    import queue
+    import threading
+
+    k = len(steps)
+    assert k >= 2 and n_steps >= 1
+    committed: "queue.Queue" = queue.Queue()
+    free = threading.Semaphore(k)   # machines whose previous proof is finished
+
+    def committer():
+        try:
+            for j in range(n_steps):
+                free.acquire()
+                committed.put(steps[j % k].commit())
+        except BaseException as e:  # surfaced on the calling thread
+            committed.put(e)
+
+    th = threading.Thread(target=committer, name="lurkhip-phase1")
+    th.start()
+    try:
+        for j in range(n_steps):
+            state = committed.get()
+            if isinstance(state, BaseException):
+                raise state
+            cur = steps[j % k]
+            gathered = cur.exchange(state)
+            proofs = cur.prove(state, gathered)
+            cur.check(proofs)
+            free.release()
+            if on_proofs is not None:
+                on_proofs(j, proofs)
+    finally:
+        for _ in range(n_steps):  # a failure on this side: let the committer run out
+            free.release()
+        th.join()
+
+
 def gather_proofs(words_list, shard_indices, dst: int = 0):
     """Collects the flat proof words of every rank's shards on rank `dst`, ordered by shard index (None elsewhere): the set a
     verifier receives.  Not part of a timed step -- proofs are megabytes; `gather_object` over the process group's default

@@ -67,6 +67,16 @@ def _worker(rank, world, port, q):
         shards.run_pipelined([step, step_b], 3, on_proofs=lambda j, pr: piped.append(pr))
         same = same and len(piped) == 3 and all(len(a) == len(b) and bool((a == b).all()) for pr in piped for a, b in zip(pr, words))
         same = same and step_b.grand_sums[-1] == (0, 0, 0, 0) and step_b.rank_sums[-1] == step.rank_sums[-1]
+        # ... and with phase 1 running ahead on its own thread over three machines (shards.run_committed_ahead)
+        ctx_c = lurk_amd.Context(0)
+        m_c = prover.Machine(ctx_c, top, mix.entry, len(pv))
+        assert m_c.setup() == vk_root
+        prepared_c = [m_c.prepare_shard(all_shards[i]) for i in mine]
+        step_c = shards.RankStep(m_c, vk_root, pv, prepared_c, mine, num_queries=8, pow_bits=6, device="cpu", lane_ctx=prover.lane_context(m_c))
+        ahead = []
+        shards.run_committed_ahead([step, step_b, step_c], 5, on_proofs=lambda j, pr: ahead.append(pr))
+        same = same and len(ahead) == 5 and all(len(a) == len(b) and bool((a == b).all()) for pr in ahead for a, b in zip(pr, words))
+        same = same and step_c.grand_sums[-1] == (0, 0, 0, 0)
         gathered = shards.gather_proofs(piped[-1], mine, dst=0)
         out = {"rank": rank, "mine": mine, "rank_sum": step.rank_sums[-1], "grand": step.grand_sums[-1], "same": same, "roots": step.roots}
         if rank == 0:
