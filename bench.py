@@ -567,6 +567,19 @@ def main():
                 tot = (tot + np.asarray(c, dtype=np.int64)) % 2013265921
         proof_set = {"shards_gathered_on_rank0": len(got), "main_roots_match_exchanged_roots_in_shard_order": bool(roots_ok),
                      "grand_sum_of_gathered_proofs_is_zero": bool((tot == 0).all()), "proof_words_total": int(sum(len(w) for w in got))}
+        # ... and the product's own verifier (csrc/verify.cpp, host only: transcript, every Merkle opening, every FRI query, the
+        # constraint identity of every chip at zeta, the cumulative sums) on the gathered set -- the reference's `fib-verification`
+        # stage (benches/fib.rs:105-133); outside the timed region
+        from lurk_amd.profile import ProtocolProfile
+
+        t_v = time.perf_counter()
+        try:
+            accepted = bool(machine.verify(got, profile=ProtocolProfile.of(ctx)))
+            why = None
+        except prover.VerificationError as e:
+            accepted, why = False, str(e)
+        proof_set["product_verifier"] = {"accepted": accepted, "reason": why, "host_verify_s": time.perf_counter() - t_v,
+                                         "note": "lurkhip_machine_verify on one host thread, every shard proof of the last step"}
 
     spans = {name: ctx.profile_read(name) for name in SPANS}
     if pipe is not None:

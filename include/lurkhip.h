@@ -41,7 +41,8 @@ typedef enum {
     LURKHIP_ERR_OOM = -4,
     LURKHIP_ERR_UNSUPPORTED = -5,
     LURKHIP_ERR_EXEC = -6, /* Lair execution error (the reference's `bail!`/panic cases) */
-    LURKHIP_ERR_PARSE = -7
+    LURKHIP_ERR_PARSE = -7,
+    LURKHIP_ERR_VERIFY = -8 /* lurkhip_machine_verify: the proof is rejected (the reference's `verify` returning Err) */
 } lurkhip_status;
 
 #define LURKHIP_REPR_CANONICAL 0
@@ -520,6 +521,18 @@ typedef struct lurkhip_proof lurkhip_proof;
 int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
                             const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                             lurkhip_proof** out);
+/* StarkMachine::verify on the HOST (no device, no context): rebuilds the transcript from the verifying key and the shard proofs
+ * (in shard order), checks every Merkle opening, every FRI query with its proof of work, the constraint identity of every chip
+ * at zeta -- evaluated from airs[machine index], the same AIR handles the prover was given -- and that the cumulative sums of all
+ * chips of all shards cancel.  `profile` NULL = the "default" preset; prep_log_heights / prep_widths describe the preprocessed
+ * traces committed by lurkhip_setup (n_prep of them, in key order); proofs[s] / proof_words[s] = the words of shard s
+ * (lurkhip_proof_words).  Returns LURKHIP_OK, or LURKHIP_ERR_VERIFY with the reason in `err` (NUL-terminated, at most err_cap
+ * bytes).  Replaces `machine.verify(&vk, &proof, &mut challenger)` (sphinx StarkMachine::verify [UPSTREAM-RECALL];
+ * /root/reference/benches/fib.rs:105-133, /root/reference/src/lair/lair_chip.rs:246-276). */
+int32_t lurkhip_machine_verify(const struct lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, uint32_t n_airs,
+                               const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths, uint32_t n_prep,
+                               const uint32_t* const* proofs, const uint64_t* proof_words, uint32_t n_proofs, char* err,
+                               uint32_t err_cap);
 /* Pcs::open on its own (p3 TwoAdicFriPcs::open as sphinx calls it from prove_shard [UPSTREAM-RECALL]): opens the
  * matrices of n_rounds commitments (lurkhip_commit / lurkhip_commit_dev / lurkhip_commit_cosets_dev handles, all with the same
  * blow-up) at caller-chosen extension-field points and proves the openings with FRI.  n_points[k] (1 or 2) is the number of

@@ -524,6 +524,8 @@ P16Params tables_of(const lurkhip_protocol_profile& p) {
 
 }  // namespace
 
+P16Params p16_tables_of(const lurkhip_protocol_profile& p) { return tables_of(p); }  // the host verifier's (verify.cpp)
+
 const lurkhip_protocol_profile& profile_of(lurkhip_ctx* ctx) {
     if (!ctx->profile) {
         auto* p = new lurkhip_protocol_profile();

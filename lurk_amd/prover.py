@@ -318,6 +318,14 @@ class Machine(_ShardProver):
     def _prep_index(self, machine_index: int) -> int:
         return 0 if self.chips[machine_index][0] == "bytes" else -1
 
+    def verify(self, proofs, profile=None):
+        """machine.verify(&vk, &proof, &mut challenger) (benches/fib.rs:105-133) on the host: raises VerificationError unless
+        every shard proof checks out and the cumulative sums cancel.  `profile`: the ProtocolProfile the proofs were made
+        under when it is not the default (ProtocolProfile.of(ctx))."""
+        if self.pk is None:
+            self.setup()
+        return verify_machine_proof([air for _, _, air in self.chips], self.vk_root, [16], [6], proofs, profile)
+
     def shard_traces(self, shard: Shard):
         """[(machine index, air, log_height, device trace (Montgomery))] of the chips included in the shard
         (LairChip::included, lair_chip.rs:124-139)."""
@@ -657,6 +665,29 @@ def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingCon
     if stats is not None:
         stats["staging_s"] = staged_s[0]
     return proofs
+
+
+class VerificationError(Exception):
+    """lurkhip_machine_verify rejected the proof (the reference's `verify` returning Err)."""
+
+
+def verify_machine_proof(airs, vk_root, prep_log_heights, prep_widths, proofs, profile=None):
+    """StarkMachine::verify on the host (csrc/verify.cpp; no device is used): `airs` = the ChipAir of every machine index,
+    `proofs` = the shard proofs in shard order (ShardProof objects or their flat words), `profile` = a ProtocolProfile or None
+    for the default preset.  Returns True; raises VerificationError with the verifier's reason otherwise."""
+    words = [np.ascontiguousarray(p.words if hasattr(p, "words") else p, dtype=np.uint32) for p in proofs]
+    air_ptrs = (C.c_void_p * len(airs))(*[a.handle for a in airs])
+    proof_ptrs = (C.c_void_p * len(words))(*[w.ctypes.data for w in words])
+    n_words = np.array([w.size for w in words], dtype=np.uint64)
+    vk = np.array(vk_root, dtype=np.uint32)
+    lh, ws = np.array(prep_log_heights, dtype=np.uint32), np.array(prep_widths, dtype=np.uint32)
+    err = C.create_string_buffer(512)
+    st = N.lib.lurkhip_machine_verify(C.byref(profile) if profile is not None else None, C.cast(air_ptrs, C.c_void_p), len(airs), _addr(vk),
+                                      _addr(lh) if lh.size else None, _addr(ws) if ws.size else None, lh.size,
+                                      C.cast(proof_ptrs, C.c_void_p), n_words.ctypes.data, len(words), err, len(err))
+    if st != N.OK:
+        raise VerificationError(f"lurkhip status {st}: {err.value.decode('utf-8', 'replace')}")
+    return True
 
 
 def grand_sum(proofs):

@@ -54,6 +54,10 @@ def prove_with(profile, src=PARTIAL_SRC, entry="top", args=(8,)):
         m = prover.Machine(ctx, top, entry, len(pv))
         root = m.setup()
         proofs = m.prove(q, num_queries=6, pow_bits=4)
+        assert m.verify(proofs, profile=ProtocolProfile.of(ctx))  # the product's verifier under the profile the proofs were made with
+        if profile is not None and profile.to_dict() != ProtocolProfile.preset("default").to_dict():
+            with pytest.raises(prover.VerificationError):  # ... and not under another one
+                m.verify(proofs)
         m.close()
     return root, proofs, pv
 

@@ -37,6 +37,7 @@ def prove(ctx, src, entry, args, num_queries=8, pow_bits=6, shard_size=None):
     m = prover.Machine(ctx, top, entry, len(pv))
     root = m.setup()
     proofs = m.prove(q, lair.ShardingConfig(shard_size) if shard_size else None, num_queries=num_queries, pow_bits=pow_bits)
+    assert m.verify(proofs)  # the product's own host verifier (csrc/verify.cpp) accepts what the oracle's is about to be asked
     return m, root, proofs, pv
 
 
@@ -56,11 +57,15 @@ def test_tampered_proofs_are_rejected(ctx):
     m, root, proofs, pv = prove(ctx, DEMO, "fib", [9])
     airs = oracle_airs(DEMO, "fib", len(pv))
 
+    from proof_words import encode_words
+
     def check(mutate):
         bad = copy.deepcopy(proofs)
         mutate(bad[0])
         with pytest.raises(os_.VerifyError):
             os_.verify_machine(airs, root, [16], [6], bad, ob.merkle_verify)
+        with pytest.raises(prover.VerificationError):  # ... and so does the product's verifier
+            m.verify([encode_words(b) for b in bad])
 
     def bump_opened(p):
         loc, nxt = p.chips[1].opened["main"]
@@ -108,6 +113,8 @@ def test_proof_of_a_wrong_trace_is_rejected(ctx):
     m.free_shard(handle)
     with pytest.raises(os_.VerifyError, match="do not match the quotient"):
         verify(DEMO, "fib", root, [proof], len(pv))
+    with pytest.raises(prover.VerificationError, match="do not match the quotient"):
+        m.verify([proof])
 
 
 def test_sharded_proof_verifies(ctx):
@@ -207,6 +214,7 @@ def test_machine_with_extern_chips_proves_and_verifies(ctx):
     airs = [oa.EntrypointAir(otop.index["chain"], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
     airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
     assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+    assert m.verify(proofs)
 
 
 def test_u64_gadget_machine_proves_and_verifies(ctx):
@@ -226,6 +234,7 @@ def test_u64_gadget_machine_proves_and_verifies(ctx):
     airs = [oa.EntrypointAir(otop.index["u64_ops"], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
     airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
     assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+    assert m.verify(proofs)
 
 
 def test_large_shard_proof_verifies(ctx):
@@ -241,6 +250,7 @@ def test_large_shard_proof_verifies(ctx):
     proofs = m.prove(q, num_queries=100, pow_bits=16)
     assert proofs[0].log_max_height == LOG_ROWS_LARGE + 2
     assert verify(se.SOURCE, se.FUNC, root, proofs, len(pv))
+    assert m.verify(proofs)
 
 
 @pytest.mark.parametrize("entry,args", [("u64_more", [0x10, 0x32, 0x54, 0x76, 0x98, 0xBA, 0xDC, 0xFE, 0x67, 0x45, 0x23, 0x01, 0, 0, 0, 0]),
@@ -259,6 +269,7 @@ def test_mul_divrem_bignum_machines_prove_and_verify(ctx, entry, args):
     airs = [oa.EntrypointAir(otop.index[entry], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
     airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
     assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+    assert m.verify(proofs)
 
 
 def test_prover_edge_parameters_and_errors(ctx):

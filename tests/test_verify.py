@@ -1,0 +1,133 @@
+"""The product's host verifier (csrc/verify.cpp: lurkhip_machine_verify, no device) on proofs made WITHOUT the GPU: the CPU port
+of the prover (oracle/cpu_prover.py) proves small machines, the proofs are written in the product's word format and the product
+verifier must accept them, reject every tampered variant the oracle's verifier rejects, and agree with it under a non-default
+protocol profile.  (tests/test_prover_gpu.py runs it on the HIP prover's proofs.)"""
+import copy
+
+import numpy as np
+import pytest
+
+import upstream_helpers as uh
+from lair_helpers import PARTIAL_SRC, load_cases
+from lurk_amd import lair, prover
+from lurk_amd.air import ChipAir
+from lurk_amd.profile import ProtocolProfile
+from oracle import binding as ob
+from oracle import cpu_prover as cpv
+from oracle import lair as ol
+from oracle import stark as os_
+from proof_words import encode_words
+from test_cpu_step import machine, prove
+
+P = os_.P
+
+
+def product_airs(src, entry, n_public, lurk_chips=False):
+    top = lair.Toplevel(src, lurk_chips=lurk_chips)
+    airs = [ChipAir.for_entrypoint(top.func_index(entry), n_public)]
+    airs += [ChipAir.for_func(top, i) for i in range(top.num_funcs())]
+    airs += [ChipAir.for_mem(ml) for ml in lair.MEM_TABLE_SIZES]
+    airs.append(ChipAir.for_bytes())
+    return airs
+
+
+@pytest.fixture(scope="module")
+def proved(oracle):
+    src = load_cases()[0]["source"]
+    airs, names, pv, traces = machine(src, "fib", [9])
+    pr = cpv.CpuProver(airs, names, len(pv), threads=4)
+    shard, vk = prove(pr, traces, pv)
+    return src, airs, pv, shard, vk
+
+
+def test_round_trip_of_the_word_format(proved):
+    _, _, _, shard, _ = proved
+    words = encode_words(shard)
+    back = prover.parse_proof(words)
+    assert encode_words(back).tolist() == words.tolist()
+
+
+def test_accepts_the_cpu_provers_proof_and_rejects_what_the_oracle_rejects(proved):
+    src, oairs, pv, shard, vk = proved
+    pairs = product_airs(src, "fib", len(pv))
+    assert prover.verify_machine_proof(pairs, vk, [16], [6], [encode_words(shard)])
+
+    def both_reject(mutate, what):
+        bad = copy.deepcopy(shard)
+        mutate(bad)
+        with pytest.raises(os_.VerifyError):
+            os_.verify_machine(oairs, vk, [16], [6], [bad], ob.merkle_verify)
+        with pytest.raises(prover.VerificationError):
+            prover.verify_machine_proof(pairs, vk, [16], [6], [encode_words(bad)])
+
+    def bump(t, k=0):
+        t = list(t)
+        t[k] = (t[k] + 1) % P
+        return tuple(t)
+
+    def m_opened(b):
+        b.chips[1].opened["main"][0][0] = bump(b.chips[1].opened["main"][0][0])
+
+    def m_next(b):
+        b.chips[1].opened["main"][1][2] = bump(b.chips[1].opened["main"][1][2], 3)
+
+    def m_perm(b):
+        b.chips[2].opened["perm"][0][1] = bump(b.chips[2].opened["perm"][0][1])
+
+    def m_quot(b):
+        b.chips[0].opened["quotient"][0][0] = bump(b.chips[0].opened["quotient"][0][0])
+
+    def m_cumsum(b):
+        b.chips[1].cumulative_sum = bump(b.chips[1].cumulative_sum)
+
+    def m_pow(b):
+        b.pow_witness += 1
+
+    def m_final(b):
+        b.final_poly = bump(b.final_poly, 2)
+
+    def m_root(b):
+        b.perm_root = list(bump(b.perm_root, 5))
+
+    def m_fri_root(b):
+        b.fri_roots[1] = list(bump(b.fri_roots[1], 7))
+
+    def m_public(b):
+        b.public_values = list(bump(b.public_values, 1))
+
+    def m_path(b):
+        rw, recs = b.round_openings[1]
+        recs = [list(r) for r in recs]
+        recs[2][-3] = (recs[2][-3] + 1) % P
+        b.round_openings[1] = (rw, recs)
+
+    def m_layer(b):
+        rw, recs = b.layer_openings[0]
+        recs = [list(r) for r in recs]
+        recs[0][5] = (recs[0][5] + 1) % P
+        b.layer_openings[0] = (rw, recs)
+
+    for k, m in enumerate((m_opened, m_next, m_perm, m_quot, m_cumsum, m_pow, m_final, m_root, m_fri_root, m_public, m_path, m_layer)):
+        both_reject(m, k)
+    # malformed words are rejections too, never crashes
+    words = encode_words(shard)
+    for bad in (words[:-1], words[:200], np.concatenate([words, [0]]).astype(np.uint32), np.zeros(4, dtype=np.uint32)):
+        with pytest.raises(prover.VerificationError):
+            prover.verify_machine_proof(pairs, vk, [16], [6], [bad])
+    flipped = words.copy()
+    flipped[40] = 0xFFFFFFFF  # not a canonical field element
+    with pytest.raises(prover.VerificationError):
+        prover.verify_machine_proof(pairs, vk, [16], [6], [flipped])
+    # a wrong verifying key / a different machine
+    with pytest.raises(prover.VerificationError):
+        prover.verify_machine_proof(pairs, [(x + 1) % P for x in vk], [16], [6], [words])
+    with pytest.raises(prover.VerificationError):
+        prover.verify_machine_proof(product_airs(PARTIAL_SRC, "top", len(pv)), vk, [16], [6], [words])
+
+
+def test_partial_machine_with_the_preprocessed_round(oracle):
+    airs, names, pv, traces = machine(PARTIAL_SRC, "top", [9])
+    pr = cpv.CpuProver(airs, names, len(pv), threads=4)
+    shard, vk = prove(pr, traces, pv)
+    assert any(c.prep_index == 0 for c in shard.chips)
+    assert prover.verify_machine_proof(product_airs(PARTIAL_SRC, "top", len(pv)), vk, [16], [6], [encode_words(shard)])

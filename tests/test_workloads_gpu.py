@@ -42,6 +42,7 @@ def run(ctx, mix, shard_size=None, num_queries=8, pow_bits=6, compile_min_log_ro
         m.compile_airs(prepared, compile_min_log_rows)
         del prepared
     proofs = m.prove(q, cfg, num_queries=num_queries, pow_bits=pow_bits)
+    assert m.verify(proofs)  # the product's host verifier (csrc/verify.cpp), before the oracle's
     return m, top, q, root, proofs, pv
 
 

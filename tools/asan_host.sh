@@ -19,4 +19,4 @@ HIP_OBJS=$(for f in *.hip; do echo ${f%.hip}.o; done)
 /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -shared-libsan -fsanitize=address,undefined -o ../liblurkhip_asan.so $HIP_OBJS obj_asan/*.o obj_asan/lair/*.o -L/opt/rocm/lib -lhiprtc
 cd /root/repo
 ASAN_OPTIONS=detect_leaks=0:abort_on_error=0:halt_on_error=0:log_path=/tmp/asan.log UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=0:log_path=/tmp/ubsan.log LD_PRELOAD=$RT LURKHIP_LIB_PATH=lurk_amd/liblurkhip_asan.so \
-  python -m pytest tests/test_lair_host.py tests/test_bytecode.py tests/test_mix_programs.py tests/test_abi.py tests/test_lair_random.py -x -q "$@"
+  python -m pytest tests/test_lair_host.py tests/test_bytecode.py tests/test_mix_programs.py tests/test_abi.py tests/test_lair_random.py tests/test_verify.py -x -q "$@"
