@@ -95,6 +95,13 @@ def _worker(rank, world, port, q):
                 out["swapped_rejected"] = False
             except os_.VerifyError:
                 out["swapped_rejected"] = True
+            # the product's own verifier on the same gathered set, and on the swapped one
+            out["verified"] = out["verified"] and bool(m.verify(gathered))
+            try:
+                m.verify([gathered[1], gathered[0]] + list(gathered[2:]))
+                out["swapped_rejected"] = False
+            except prover.VerificationError:
+                pass
         q.put(out)
         dist.barrier()
         del prepared, prepared_b
