@@ -274,6 +274,12 @@ class StarkMachine(_ShardProver):
         finally:
             self.free_shard(handle)
 
+    def verify(self, proof, profile=None):
+        """The host verifier (csrc/verify.cpp) on this machine's one-shard proof."""
+        if self.pk is None:
+            self.setup()
+        return verify_machine_proof([air for _, _, air in self.chips], self.vk_root, [], [], [proof], profile)
+
 
 SIDE_STREAM_MAX_LOG_ROWS = 12  # chips below 2^12 rows are "short" for run_prepared's side stream
 

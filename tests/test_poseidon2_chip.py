@@ -139,8 +139,13 @@ def test_batch_of_permutations_proves_and_verifies(ctx, oracle, width, n):
     proof = m.prove([t], num_queries=8, pow_bits=4)
     airs = [oa.Poseidon2NarrowAir(width)]
     assert os_.verify_machine(airs, root, [], [], [proof], oracle.merkle_verify)
+    assert m.verify(proof)  # the product's host verifier: a machine without preprocessed traces or interactions
     bad = copy.deepcopy(proof)
     loc, nxt = bad.chips[0].opened["main"]
     loc[1] = ((loc[1][0] + 1) % field.P,) + tuple(loc[1][1:])
     with pytest.raises(os_.VerifyError):
         os_.verify_machine(airs, root, [], [], [bad], oracle.merkle_verify)
+    from proof_words import encode_words
+
+    with pytest.raises(prover.VerificationError):
+        m.verify(encode_words(bad))
