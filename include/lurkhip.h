@@ -533,6 +533,16 @@ int32_t lurkhip_machine_verify(const struct lurkhip_protocol_profile* profile, c
                                const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths, uint32_t n_prep,
                                const uint32_t* const* proofs, const uint64_t* proof_words, uint32_t n_proofs, char* err,
                                uint32_t err_cap);
+/* The same verification from the reference's serialised form: `bytes` = bincode of a `CryptoProof` (lurkhip_crypto_proof_bincode;
+ * /root/reference/src/core/cli/proofs.rs:22-35), which carries neither the public values (the caller rebuilds the 44 lanes from
+ * the claim: proofs.rs:46-56), nor the FRI parameters (the machine's: num_queries, pow_bits, log_blowup), nor the query indices and
+ * the queried half of each FRI pair (re-derived).  chip_names[k] = name of machine index k (lurkhip_air_name), resolving the
+ * proof's `chip_ordering`.  The `verify` path of the reference's CLI: load a CachedProof, rebuild the public values, then
+ * `machine.verify` (/root/reference/src/core/cli/proofs.rs:94-131).  Host only. */
+int32_t lurkhip_crypto_proof_verify(const struct lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, const char* const* chip_names,
+                                    uint32_t n_airs, const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths,
+                                    uint32_t n_prep, const uint8_t* bytes, uint64_t n_bytes, const uint32_t* public_values, uint32_t n_public,
+                                    uint32_t num_queries, uint32_t pow_bits, uint32_t log_blowup, char* err, uint32_t err_cap);
 /* Pcs::open on its own (p3 TwoAdicFriPcs::open as sphinx calls it from prove_shard [UPSTREAM-RECALL]): opens the
  * matrices of n_rounds commitments (lurkhip_commit / lurkhip_commit_dev / lurkhip_commit_cosets_dev handles, all with the same
  * blow-up) at caller-chosen extension-field points and proves the openings with FRI.  n_points[k] (1 or 2) is the number of

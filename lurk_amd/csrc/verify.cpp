@@ -94,6 +94,9 @@ struct VProof {
     uint32_t pow_witness;  // canonical
     std::vector<uint32_t> indices;
     std::vector<std::pair<uint32_t, std::vector<uint32_t>>> rounds, layers;  // (record words, nq records back to back; Montgomery)
+    // a proof decoded from the reference's wire format (CryptoShardProof) carries neither the query indices nor the queried
+    // element of a FRI pair: p3's CommitPhaseProofStep holds the sibling only -- the queried element IS the running fold
+    bool has_indices = true, sibling_only = false;
 };
 
 struct Cursor {
@@ -274,7 +277,7 @@ void pcs_verify(const lurkhip_protocol_profile& prof, const Hasher& H, const std
     NEED(rounds.size() == p.rounds.size(), "number of opening rounds");
     for (uint32_t qi = 0; qi < p.nq; qi++) {
         const uint32_t index = ch.sample_bits((int)log_max);
-        NEED(index == p.indices[qi], "query indices differ from the transcript's");
+        NEED(!p.has_indices || index == p.indices[qi], "query indices differ from the transcript's");
         std::map<uint32_t, ef> ro, alpha_pow;
         for (size_t ri = 0; ri < rounds.size(); ri++) {
             const VRound& r = rounds[ri];
@@ -327,11 +330,22 @@ void pcs_verify(const lurkhip_protocol_profile& prof, const Hasher& H, const std
             const uint32_t log_folded = log_max - 1 - li;
             if (ro.count(log_folded + 1)) folded = bb::ef_add(folded, ro[log_folded + 1]);
             const uint32_t rw = p.layers[li].first;
-            NEED(rw == 8 + 8 * log_folded, "layer record size");
             const uint32_t* rec = p.layers[li].second.data() + (size_t)qi * rw;
-            ef evals[2] = {ef{{rec[0], rec[1], rec[2], rec[3]}}, ef{{rec[4], rec[5], rec[6], rec[7]}}};
-            NEED(ef_eq(evals[idx & 1], folded), "query %u: layer %u does not continue the fold", qi, li);
-            NEED(H.verify({log_folded}, {8}, idx >> 1, rec, rec + 8, p.fri_roots[li].data()), "query %u: FRI layer %u opening fails", qi, li);
+            ef evals[2];
+            const uint32_t* path;
+            if (p.sibling_only) {  // the Merkle opening of the pair binds the running fold
+                NEED(rw == 4 + 8 * log_folded, "layer record size");
+                evals[idx & 1] = folded;
+                evals[(idx ^ 1) & 1] = ef{{rec[0], rec[1], rec[2], rec[3]}};
+                path = rec + 4;
+            } else {
+                NEED(rw == 8 + 8 * log_folded, "layer record size");
+                evals[0] = ef{{rec[0], rec[1], rec[2], rec[3]}}, evals[1] = ef{{rec[4], rec[5], rec[6], rec[7]}};
+                NEED(ef_eq(evals[idx & 1], folded), "query %u: layer %u does not continue the fold", qi, li);
+                path = rec + 8;
+            }
+            const uint32_t pair[8] = {evals[0].c[0], evals[0].c[1], evals[0].c[2], evals[0].c[3], evals[1].c[0], evals[1].c[1], evals[1].c[2], evals[1].c[3]};
+            NEED(H.verify({log_folded}, {8}, idx >> 1, pair, path, p.fri_roots[li].data()), "query %u: FRI layer %u opening fails", qi, li);
             uint32_t xs[2] = {x, x};
             xs[(idx ^ 1) & 1] = bb::mul(xs[(idx ^ 1) & 1], minus_one);  // times the generator of the order-2 subgroup
             // the line through (xs[0], evals[0]), (xs[1], evals[1]) at beta
@@ -552,66 +566,218 @@ void verify_shard(const VerifyInput& in, const VProof& p, Challenger ch, ef* sum
     }
 }
 
-}  // namespace
+// ---- the reference's serialised proofs (/root/reference/src/core/cli/proofs.rs:22-35; inner sphinx / p3 types [UPSTREAM-RECALL],
+// field order as lurk_amd/csrc/wire.cpp writes them) back into shard proofs
+struct Bytes {
+    const uint8_t* p;
+    uint64_t n, pos = 0;
+    bool monty;
+    uint64_t u64() {
+        NEED(n - pos >= 8, "truncated proof bytes");
+        uint64_t v = 0;
+        for (int i = 0; i < 8; i++) v |= (uint64_t)p[pos + i] << (8 * i);
+        pos += 8;
+        return v;
+    }
+    uint32_t u32() {
+        NEED(n - pos >= 4, "truncated proof bytes");
+        uint32_t v = 0;
+        for (int i = 0; i < 4; i++) v |= (uint32_t)p[pos + i] << (8 * i);
+        pos += 4;
+        return v;
+    }
+    uint64_t len(uint64_t each_bytes) {  // a Vec's length, which the rest of the bytes must be able to hold
+        const uint64_t v = u64();
+        NEED(each_bytes == 0 || v <= (n - pos) / each_bytes, "a length in the proof bytes runs past their end");
+        return v;
+    }
+    uint32_t f() {  // a field element -> Montgomery form
+        const uint32_t v = u32();
+        NEED(v < bb::P, "proof bytes hold a word that is not a field element");
+        return monty ? v : bb::to_monty(v);
+    }
+    ef e() {
+        ef r;
+        for (int i = 0; i < 4; i++) r.c[i] = f();
+        return r;
+    }
+    std::string str() {
+        const uint64_t k = len(1);
+        std::string s((const char*)p + pos, (size_t)k);
+        pos += k;
+        return s;
+    }
+};
 
-extern "C" int32_t lurkhip_machine_verify(const lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, uint32_t n_airs,
-                                          const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths, uint32_t n_prep,
-                                          const uint32_t* const* proofs, const uint64_t* proof_words, uint32_t n_proofs, char* err,
-                                          uint32_t err_cap) {
+VProof decode_shard(Bytes& b, const lurkhip_air* const* airs, uint32_t n_airs, const char* const* chip_names, const std::vector<uint32_t>& pub,
+                    uint32_t log_blowup, uint32_t pow_bits) {
+    VProof p;
+    p.has_indices = false;
+    p.sibling_only = true;
+    p.log_blowup = log_blowup, p.pow_bits = pow_bits, p.pub = pub, p.n_public = (uint32_t)pub.size();
+    for (uint32_t* root : {p.main_root, p.perm_root, p.quot_root})
+        for (int i = 0; i < 8; i++) root[i] = b.f();
+    const uint64_t n_chips = b.len(64);
+    NEED(n_chips >= 1 && n_chips <= 4096, "implausible chip count");
+    p.chips.resize(n_chips);
+    auto air_values = [&](std::vector<ef> (&out)[2]) {
+        for (int k = 0; k < 2; k++) {
+            const uint64_t w = b.len(16);
+            out[k].resize(w);
+            for (auto& v : out[k]) v = b.e();
+        }
+        NEED(out[0].size() == out[1].size(), "local and next rows differ in width");
+    };
+    p.n_chunks = 0;
+    for (VChip& c : p.chips) {
+        air_values(c.prep), air_values(c.main), air_values(c.perm);
+        c.prep_width = (uint32_t)c.prep[0].size(), c.width = (uint32_t)c.main[0].size(), c.perm_width = (uint32_t)c.perm[0].size();
+        NEED(c.perm_width >= 4 && c.perm_width % 4 == 0, "permutation width");
+        const uint64_t qd = b.len(8 + 64);
+        NEED(qd >= 1 && qd <= 16 && (qd & (qd - 1)) == 0, "quotient degree");
+        c.qd = (uint32_t)qd;
+        c.quotient.resize(qd);
+        for (auto& q : c.quotient) {
+            NEED(b.len(16) == 4, "a quotient chunk has four columns");
+            for (int e = 0; e < 4; e++) q[e] = b.e();
+        }
+        p.n_chunks += c.qd;
+        c.cumsum = b.e();
+        const uint64_t lg = b.u64();
+        NEED(lg <= 32, "log_degree");
+        c.log_n = (uint32_t)lg;
+        c.prep_index = -1;
+    }
+    // fri_proof
+    const uint64_t n_layers = b.len(32);
+    NEED(n_layers <= 40, "FRI layers");
+    p.n_layers = (uint32_t)n_layers;
+    p.log_max = p.n_layers + log_blowup;
+    p.fri_roots.resize(n_layers);
+    for (auto& r : p.fri_roots)
+        for (int i = 0; i < 8; i++) r[i] = b.f();
+    const uint64_t nq = b.len(8);
+    NEED(nq >= 1 && nq <= 1024, "number of queries");
+    p.nq = (uint32_t)nq;
+    p.layers.resize(n_layers);
+    for (uint32_t l = 0; l < p.n_layers; l++) p.layers[l].first = 4 + 8 * (p.log_max - 1 - l), p.layers[l].second.resize((size_t)nq * p.layers[l].first);
+    for (uint32_t q = 0; q < p.nq; q++) {
+        NEED(b.len(16 + 8) == n_layers, "a query proof has one step per layer");
+        for (uint32_t l = 0; l < p.n_layers; l++) {
+            uint32_t* rec = p.layers[l].second.data() + (size_t)q * p.layers[l].first;
+            for (int k = 0; k < 4; k++) rec[k] = b.f();
+            NEED(b.len(32) == p.log_max - 1 - l, "FRI layer path length");
+            for (uint32_t k = 0; k < 8 * (p.log_max - 1 - l); k++) rec[4 + k] = b.f();
+        }
+    }
+    p.final_poly = b.e();
+    {
+        const uint32_t w = b.u32();
+        NEED(w < bb::P, "proof-of-work witness is not a field element");
+        p.pow_witness = b.monty ? bb::from_monty(w) : w;
+    }
+    // query_openings[query][round]
+    NEED(b.len(8) == nq, "query openings");
+    uint32_t n_rounds = 0;
+    for (uint32_t q = 0; q < p.nq; q++) {
+        const uint64_t nr = b.len(16);
+        NEED(nr == 3 || nr == 4, "opening rounds");
+        if (q == 0) {
+            n_rounds = (uint32_t)nr;
+            p.rounds.resize(n_rounds);
+        }
+        NEED(nr == n_rounds, "opening rounds");
+        for (uint32_t r = 0; r < n_rounds; r++) {
+            std::vector<uint32_t> rec;
+            const uint64_t n_mats = b.len(8);
+            for (uint64_t m = 0; m < n_mats; m++) {
+                const uint64_t w = b.len(4);
+                for (uint64_t k = 0; k < w; k++) rec.push_back(b.f());
+            }
+            const uint64_t levels = b.len(32);
+            for (uint64_t k = 0; k < 8 * levels; k++) rec.push_back(b.f());
+            if (q == 0) p.rounds[r].first = (uint32_t)rec.size();
+            NEED(rec.size() == p.rounds[r].first, "opening records of a round differ in size");
+            p.rounds[r].second.insert(p.rounds[r].second.end(), rec.begin(), rec.end());
+        }
+    }
+    p.n_prep = n_rounds - 3;
+    // chip_ordering: name -> position; names resolve to machine indices, preprocessed traces are numbered in machine-index order
+    NEED(b.len(16) == n_chips, "chip ordering");
+    std::vector<bool> placed(n_chips, false);
+    for (uint64_t i = 0; i < n_chips; i++) {
+        const std::string name = b.str();
+        const uint64_t at = b.u64();
+        NEED(at < n_chips && !placed[at], "chip ordering is not a permutation");
+        placed[at] = true;
+        uint32_t mi = n_airs;
+        for (uint32_t k = 0; k < n_airs; k++)
+            if (chip_names[k] && name == chip_names[k]) mi = k;
+        NEED(mi < n_airs, "chip %s is not part of the machine", name.c_str());
+        p.chips[at].machine_index = mi;
+    }
+    for (VChip& c : p.chips)
+        if (c.prep_width) {
+            int rank = 0;
+            for (uint32_t k = 0; k < c.machine_index; k++)
+                if (airs[k] && lurkhip::air_of(airs[k]).prep_width) rank++;
+            c.prep_index = rank;
+        }
+    uint32_t with_prep = 0;
+    for (const VChip& c : p.chips) with_prep += c.prep_index >= 0;
+    NEED(p.n_prep == 0 ? with_prep == 0 : with_prep >= 1, "preprocessed round and preprocessed openings disagree");
+    if (p.n_prep) p.n_prep = with_prep;  // (verify_shard compares it with the verifying key's count)
+    return p;
+}
+
+int32_t verify_parsed(const lurkhip_protocol_profile& prof, const lurkhip_air* const* airs, uint32_t n_airs, const uint32_t* vk_root,
+                      const uint32_t* prep_log_heights, const uint32_t* prep_widths, uint32_t n_prep, const std::vector<VProof>& parsed,
+                      const P16Params& tables) {
+    const Hasher H{tables};
+    uint32_t vk_m[8];
+    for (int i = 0; i < 8; i++) {
+        NEED(vk_root[i] < bb::P, "verifying-key root is not canonical");
+        vk_m[i] = bb::to_monty(vk_root[i]);
+    }
+    // sphinx StarkMachine::verify: the verifying key, pc_start, then every shard's main root and public values
+    Challenger ch;
+    ch.params = &tables;
+    ch.squeeze = (int)prof.challenger_squeeze;
+    ch.pop_front = prof.challenger_pop_front != 0;
+    ch.observe_digest_m(vk_m);
+    ch.observe(0);
+    for (const VProof& p : parsed) {
+        ch.observe_digest_m(p.main_root);
+        for (uint32_t v : p.pub) ch.observe(v);
+    }
+    const VerifyInput in{prof, H, airs, n_airs, vk_m, prep_log_heights, prep_widths, n_prep};
+    ef total = bb::ef_zero();
+    for (size_t s = 0; s < parsed.size(); s++) {
+        try {
+            verify_shard(in, parsed[s], ch, &total);
+        } catch (const Reject& r) {
+            reject("shard %zu: %s", s, r.what());
+        }
+    }
+    NEED(bb::ef_is_zero(total), "cumulative sums do not cancel");
+    return LURKHIP_OK;
+}
+
+bool resolve_profile(const lurkhip_protocol_profile* profile, lurkhip_protocol_profile& prof) {
+    if (!profile) return lurkhip_protocol_profile_preset("default", &prof) == LURKHIP_OK;
+    prof = *profile;
+    return prof.struct_bytes == sizeof prof && prof.p16_rounds_p >= 1 && prof.p16_rounds_p <= (uint32_t)lurkhip::P16_MAX_RP &&
+           prof.p16_internal_scale % bb::P != 0 && (prof.challenger_squeeze == 8 || prof.challenger_squeeze == 16) && prof.fri_log_arity == 1;
+}
+
+template <class Body>
+int32_t guarded_verify(char* err, uint32_t err_cap, Body&& body) {
     auto say = [&](const std::string& m) {
         if (err && err_cap) snprintf(err, err_cap, "%s", m.c_str());
     };
     if (err && err_cap) err[0] = 0;
-    if (!airs || !n_airs || !vk_root || !proofs || !proof_words || !n_proofs || (n_prep && (!prep_log_heights || !prep_widths))) {
-        say("null or empty argument");
-        return LURKHIP_ERR_INVALID_ARG;
-    }
-    lurkhip_protocol_profile prof;
-    if (profile) {
-        prof = *profile;
-        if (prof.struct_bytes != sizeof prof || prof.p16_rounds_p < 1 || prof.p16_rounds_p > (uint32_t)lurkhip::P16_MAX_RP ||
-            prof.p16_internal_scale % bb::P == 0 || (prof.challenger_squeeze != 8 && prof.challenger_squeeze != 16) || prof.fri_log_arity != 1) {
-            say("invalid protocol profile");
-            return LURKHIP_ERR_INVALID_ARG;
-        }
-    } else if (lurkhip_protocol_profile_preset("default", &prof) != LURKHIP_OK) {
-        say("no default profile");
-        return LURKHIP_ERR_INVALID_ARG;
-    }
     try {
-        const P16Params tables = lurkhip::p16_tables_of(prof);
-        const Hasher H{tables};
-        uint32_t vk_m[8];
-        for (int i = 0; i < 8; i++) {
-            NEED(vk_root[i] < bb::P, "verifying-key root is not canonical");
-            vk_m[i] = bb::to_monty(vk_root[i]);
-        }
-        std::vector<VProof> parsed;
-        for (uint32_t s = 0; s < n_proofs; s++) {
-            NEED(proofs[s] != nullptr, "null proof");
-            parsed.push_back(parse(proofs[s], proof_words[s]));
-        }
-        // sphinx StarkMachine::verify: the verifying key, pc_start, then every shard's main root and public values
-        Challenger ch;
-        ch.params = &tables;
-        ch.squeeze = (int)prof.challenger_squeeze;
-        ch.pop_front = prof.challenger_pop_front != 0;
-        ch.observe_digest_m(vk_m);
-        ch.observe(0);
-        for (const VProof& p : parsed) {
-            ch.observe_digest_m(p.main_root);
-            for (uint32_t v : p.pub) ch.observe(v);
-        }
-        const VerifyInput in{prof, H, airs, n_airs, vk_m, prep_log_heights, prep_widths, n_prep};
-        ef total = bb::ef_zero();
-        for (size_t s = 0; s < parsed.size(); s++) {
-            try {
-                verify_shard(in, parsed[s], ch, &total);
-            } catch (const Reject& r) {
-                reject("shard %zu: %s", s, r.what());
-            }
-        }
-        NEED(bb::ef_is_zero(total), "cumulative sums do not cancel");
+        return body();
     } catch (const Reject& r) {
         say(r.what());
         return LURKHIP_ERR_VERIFY;
@@ -622,5 +788,64 @@ extern "C" int32_t lurkhip_machine_verify(const lurkhip_protocol_profile* profil
         say(std::string("internal error: ") + e.what());
         return LURKHIP_ERR_EXEC;
     }
-    return LURKHIP_OK;
+}
+
+}  // namespace
+
+extern "C" int32_t lurkhip_crypto_proof_verify(const lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, const char* const* chip_names,
+                                               uint32_t n_airs, const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths,
+                                               uint32_t n_prep, const uint8_t* bytes, uint64_t n_bytes, const uint32_t* public_values,
+                                               uint32_t n_public, uint32_t num_queries, uint32_t pow_bits, uint32_t log_blowup, char* err,
+                                               uint32_t err_cap) {
+    return guarded_verify(err, err_cap, [&]() -> int32_t {
+        NEED(airs && chip_names && n_airs && vk_root && bytes && (public_values || !n_public) && (!n_prep || (prep_log_heights && prep_widths)),
+             "null or empty argument");
+        lurkhip_protocol_profile prof;
+        NEED(resolve_profile(profile, prof), "invalid protocol profile");
+        NEED(log_blowup >= 1 && log_blowup <= 4 && pow_bits <= 30 && num_queries >= 1 && num_queries <= 1024 && n_public >= 4, "bad parameters");
+        std::vector<uint32_t> pub(public_values, public_values + n_public);
+        uint32_t depth = 0;
+        for (uint32_t v : pub) NEED(v < bb::P, "public value is not canonical");
+        for (int k = 0; k < 4; k++) {
+            NEED(pub[n_public - 4 + k] <= 255, "the depth lanes of the public values are bytes");
+            depth |= pub[n_public - 4 + k] << (8 * k);
+        }
+        const P16Params tables = lurkhip::p16_tables_of(prof);
+        Bytes b{bytes, n_bytes, 0, prof.serialize_montgomery != 0};
+        const uint64_t n_shards = b.len(96);
+        NEED(n_shards >= 1 && n_shards <= (1u << 20), "shard count");
+        std::vector<VProof> parsed;
+        for (uint64_t s = 0; s < n_shards; s++) {
+            parsed.push_back(decode_shard(b, airs, n_airs, chip_names, pub, log_blowup, pow_bits));
+            NEED(parsed.back().nq == num_queries, "the proof answers %u queries, the machine asks %u", parsed.back().nq, num_queries);
+        }
+        (void)b.str();  // verifier_version: informational (the reference compares it before it deserialises the rest)
+        NEED(b.u32() == depth, "the proof's depth differs from the public values'");
+        NEED(b.pos == b.n, "trailing bytes after the proof");
+        return verify_parsed(prof, airs, n_airs, vk_root, prep_log_heights, prep_widths, n_prep, parsed, tables);
+    });
+}
+
+extern "C" int32_t lurkhip_machine_verify(const lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, uint32_t n_airs,
+                                          const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths, uint32_t n_prep,
+                                          const uint32_t* const* proofs, const uint64_t* proof_words, uint32_t n_proofs, char* err,
+                                          uint32_t err_cap) {
+    if (!airs || !n_airs || !vk_root || !proofs || !proof_words || !n_proofs || (n_prep && (!prep_log_heights || !prep_widths))) {
+        if (err && err_cap) snprintf(err, err_cap, "null or empty argument");
+        return LURKHIP_ERR_INVALID_ARG;
+    }
+    lurkhip_protocol_profile prof;
+    if (!resolve_profile(profile, prof)) {
+        if (err && err_cap) snprintf(err, err_cap, "invalid protocol profile");
+        return LURKHIP_ERR_INVALID_ARG;
+    }
+    return guarded_verify(err, err_cap, [&]() -> int32_t {
+        const P16Params tables = lurkhip::p16_tables_of(prof);
+        std::vector<VProof> parsed;
+        for (uint32_t s = 0; s < n_proofs; s++) {
+            NEED(proofs[s] != nullptr, "null proof");
+            parsed.push_back(parse(proofs[s], proof_words[s]));
+        }
+        return verify_parsed(prof, airs, n_airs, vk_root, prep_log_heights, prep_widths, n_prep, parsed, tables);
+    });
 }

@@ -56,6 +56,31 @@ class CryptoProof:
         return bytes(buf)
 
 
+def verify_crypto_proof(machine, data: bytes, public_values, num_queries: int, pow_bits: int, log_blowup: int = 1, profile=None) -> bool:
+    """The reference CLI's `verify` on the host (csrc/verify.cpp: lurkhip_crypto_proof_verify): `data` = the bincode of a CryptoProof,
+    `public_values` = the 44 lanes rebuilt from the claim (`public_values` above), `machine` = a lurk_amd.prover.Machine of the same
+    toplevel (its AIRs, chip names and verifying key).  Raises lurk_amd.prover.VerificationError when the proof is rejected."""
+    from .prover import VerificationError
+
+    if machine.pk is None:
+        machine.setup()
+    airs = [air for _, _, air in machine.chips]
+    air_ptrs = (C.c_void_p * len(airs))(*[a.handle for a in airs])
+    names = (C.c_char_p * len(airs))(*[a.name.encode() for a in airs])
+    vk = np.array(machine.vk_root, dtype=np.uint32)
+    lh, ws = np.array([16], dtype=np.uint32), np.array([6], dtype=np.uint32)
+    pv = np.array(list(public_values), dtype=np.uint32)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    err = C.create_string_buffer(512)
+    u32p = lambda a: a.ctypes.data_as(C.POINTER(C.c_uint32))
+    st = N.lib.lurkhip_crypto_proof_verify(C.byref(profile) if profile is not None else None, C.cast(air_ptrs, C.c_void_p), C.cast(names, C.c_void_p),
+                                           len(airs), u32p(vk), u32p(lh), u32p(ws), 1, C.cast(buf, C.c_void_p), len(data), u32p(pv), pv.size,
+                                           num_queries, pow_bits, log_blowup, err, len(err))
+    if st != N.OK:
+        raise VerificationError(f"lurkhip status {st}: {err.value.decode('utf-8', 'replace')}")
+    return True
+
+
 def shard_proof_bincode(words, chip_names, serialize_montgomery: bool = False) -> bytes:
     """`bincode::serialize(&ShardProof)` of one shard proof (sphinx's struct, public values included) from its flat words."""
     w = np.ascontiguousarray(words, dtype=np.uint32)

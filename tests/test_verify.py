@@ -131,3 +131,62 @@ def test_partial_machine_with_the_preprocessed_round(oracle):
     shard, vk = prove(pr, traces, pv)
     assert any(c.prep_index == 0 for c in shard.chips)
     assert prover.verify_machine_proof(product_airs(PARTIAL_SRC, "top", len(pv)), vk, [16], [6], [encode_words(shard)])
+
+
+def test_verification_from_the_reference_wire_format(oracle):
+    """CryptoProof bytes (lurk_amd/csrc/wire.cpp) of a CPU-port proof back through the product's decoder and verifier: the wire
+    format drops the query indices, the queried half of every FRI pair, the public values and every size that a length prefix
+    carries -- the verifier re-derives them."""
+    import ctypes as C
+
+    from lurk_amd import _native as N
+    from lurk_amd import proofs
+
+    airs, names, pv, traces = machine(PARTIAL_SRC, "top", [9])
+    assert len(pv) >= 4
+    pr = cpv.CpuProver(airs, names, len(pv), threads=4)
+    shard, vk = prove(pr, traces, pv)
+    pairs = product_airs(PARTIAL_SRC, "top", len(pv))
+    cp = proofs.CryptoProof([encode_words(shard)], [a.name for a in pairs], verifier_version="test")
+    data = cp.to_bytes()
+
+    def run(data, pv, nq=shard.num_queries, pow_bits=shard.pow_bits):
+        air_ptrs = (C.c_void_p * len(pairs))(*[a.handle for a in pairs])
+        cnames = (C.c_char_p * len(pairs))(*[a.name.encode() for a in pairs])
+        vk_a, lh, ws, pv_a = (np.array(x, dtype=np.uint32) for x in (vk, [16], [6], list(pv)))
+        buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+        err = C.create_string_buffer(256)
+        st = N.lib.lurkhip_crypto_proof_verify(None, C.cast(air_ptrs, C.c_void_p), C.cast(cnames, C.c_void_p), len(pairs), vk_a.ctypes.data, lh.ctypes.data,
+                                               ws.ctypes.data, 1, C.cast(buf, C.c_void_p), len(data), pv_a.ctypes.data, pv_a.size, nq, pow_bits, 1, err, 256)
+        return st, err.value.decode()
+
+    assert run(data, pv) == (N.OK, "")
+    flipped = bytearray(data)
+    flipped[8 + 40] ^= 1  # inside the permutation root
+    for bad, bad_pv, kw in ((bytes(flipped), pv, {}), (data[:-1], pv, {}), (data + b"\0", pv, {}), (data, pv[:-1] + [(pv[-1] + 1) % 256], {}),
+                            (data, pv, {"nq": shard.num_queries + 1}), (data, pv, {"pow_bits": shard.pow_bits + 9})):
+        st, why = run(bad, bad_pv, **kw)
+        assert st == -8 and why, (st, why)
+    # byte-level fuzz of the decoder: flips, truncations, length fields blown up -- a status, never a crash (tools/asan_host.sh runs
+    # this under AddressSanitizer); only a flip inside the informational version string may still verify
+    import random
+
+    rnd = random.Random(5)
+    accepted = 0
+    for _ in range(400):
+        b = bytearray(data)
+        k = rnd.random()
+        if k < 0.5:
+            b[rnd.randrange(len(b))] ^= 1 << rnd.randrange(8)
+        elif k < 0.7:
+            del b[rnd.randrange(len(b)):]
+        elif k < 0.9:
+            at = rnd.randrange(len(b) - 8)
+            b[at:at + 8] = rnd.choice([b"\xff" * 8, (1 << 40).to_bytes(8, "little"), (0).to_bytes(8, "little")])
+        else:
+            at = rnd.randrange(len(b))
+            b[at:at] = bytes(rnd.randrange(256) for _ in range(rnd.randint(1, 9)))
+        st, why = run(bytes(b), pv)
+        assert st in (N.OK, -8), (st, why)
+        accepted += st == N.OK
+    assert accepted <= 8

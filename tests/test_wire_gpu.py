@@ -73,6 +73,17 @@ def test_crypto_proof_bytes_verify(proved):
         os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], shards_bad, ob.merkle_verify)
     with pytest.raises(Exception):
         ow.decode_crypto_proof(data[:-3], names, lambda d: pv, pow_bits=4)
+    # the product's own verifier, from the bytes alone (csrc/verify.cpp: lurkhip_crypto_proof_verify): both spellings accepted, the
+    # flipped element, a truncation, other public values and another query count rejected
+    from lurk_amd.profile import ProtocolProfile
+
+    assert proofs.verify_crypto_proof(m, data, pv, num_queries=6, pow_bits=4)
+    mprof = ProtocolProfile.preset("default")
+    mprof.serialize_montgomery = 1
+    assert proofs.verify_crypto_proof(m, mont, pv, num_queries=6, pow_bits=4, profile=mprof)
+    for bad_data, bad_pv, nq in ((bytes(bad), pv, 6), (data[:-3], pv, 6), (data, pv[:7] + [(pv[7] + 1) % os_.P] + pv[8:], 6), (data, pv, 7), (mont, pv, 6)):
+        with pytest.raises(prover.VerificationError):
+            proofs.verify_crypto_proof(m, bad_data, bad_pv, num_queries=nq, pow_bits=4)
 
 
 def test_bincode_framing(proved):
