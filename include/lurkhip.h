@@ -543,6 +543,14 @@ int32_t lurkhip_crypto_proof_verify(const struct lurkhip_protocol_profile* profi
                                     uint32_t n_airs, const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths,
                                     uint32_t n_prep, const uint8_t* bytes, uint64_t n_bytes, const uint32_t* public_values, uint32_t n_public,
                                     uint32_t num_queries, uint32_t pow_bits, uint32_t log_blowup, char* err, uint32_t err_cap);
+/* ... and from a `CachedProof { crypto_proof, expr, env, result, zdag }` (lurkhip_cached_proof_bincode;
+ * /root/reference/src/core/cli/proofs.rs:137-169): the claim travels with the proof, so the 44 public values are rebuilt from
+ * expr / env / result / depth as `into_machine_proof` does (proofs.rs:46-56,94-131) and returned in public_values_out (44 words,
+ * may be NULL); the ZDag is checked for its framing only.  What `lurk verify <key>` does after loading the file.  Host only. */
+int32_t lurkhip_cached_proof_verify(const struct lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, const char* const* chip_names,
+                                    uint32_t n_airs, const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths,
+                                    uint32_t n_prep, const uint8_t* bytes, uint64_t n_bytes, uint32_t num_queries, uint32_t pow_bits,
+                                    uint32_t log_blowup, uint32_t* public_values_out, char* err, uint32_t err_cap);
 /* Pcs::open on its own (p3 TwoAdicFriPcs::open as sphinx calls it from prove_shard [UPSTREAM-RECALL]): opens the
  * matrices of n_rounds commitments (lurkhip_commit / lurkhip_commit_dev / lurkhip_commit_cosets_dev handles, all with the same
  * blow-up) at caller-chosen extension-field points and proves the openings with FRI.  n_points[k] (1 or 2) is the number of

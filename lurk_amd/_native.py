@@ -183,6 +183,8 @@ SIGNATURES = {
     "lurkhip_proof_words": (_i64, [_p]),
     "lurkhip_crypto_proof_verify": (_i32, [_p, _p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _p, C.c_uint64, _u32p, C.c_uint32, C.c_uint32,
                                             C.c_uint32, C.c_uint32, C.c_char_p, C.c_uint32]),
+    "lurkhip_cached_proof_verify": (_i32, [_p, _p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _p, C.c_uint64, C.c_uint32, C.c_uint32, C.c_uint32,
+                                            _u32p, C.c_char_p, C.c_uint32]),
     "lurkhip_machine_verify": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, C.c_uint32, _p, _p, C.c_uint32, C.c_char_p, C.c_uint32]),
     "lurkhip_logup_multiplicities": (_i32, [_p, C.c_uint32, C.c_uint32, _p, _p, _p, _p, _p]),
     "lurkhip_logup_permutation_trace": (_i32, [_p, C.c_uint32, C.c_uint32, C.c_uint32, _p, _p, _p, _p, _p, C.c_uint64, _p, _p, _p, _i32, _p, _p]),

@@ -790,7 +790,81 @@ int32_t guarded_verify(char* err, uint32_t err_cap, Body&& body) {
     }
 }
 
+// CryptoProof { shard_proofs, verifier_version, depth } (proofs.rs:22-28) from the cursor; the public values are set by the caller
+std::vector<VProof> decode_crypto_proof(Bytes& b, const lurkhip_air* const* airs, uint32_t n_airs, const char* const* chip_names, uint32_t num_queries,
+                                        uint32_t pow_bits, uint32_t log_blowup, uint32_t* depth) {
+    const uint64_t n_shards = b.len(96);
+    NEED(n_shards >= 1 && n_shards <= (1u << 20), "shard count");
+    std::vector<VProof> parsed;
+    for (uint64_t s = 0; s < n_shards; s++) {
+        parsed.push_back(decode_shard(b, airs, n_airs, chip_names, {}, log_blowup, pow_bits));
+        NEED(parsed.back().nq == num_queries, "the proof answers %u queries, the machine asks %u", parsed.back().nq, num_queries);
+    }
+    (void)b.str();  // verifier_version: informational (the reference compares it before it deserialises the rest)
+    *depth = b.u32();
+    return parsed;
+}
+
+void set_public_values(std::vector<VProof>& parsed, const std::vector<uint32_t>& pub, uint32_t depth) {
+    NEED(pub.size() >= 4, "the public values end with the four depth bytes");
+    uint32_t d = 0;
+    for (uint32_t v : pub) NEED(v < bb::P, "public value is not canonical");
+    for (int k = 0; k < 4; k++) {
+        NEED(pub[pub.size() - 4 + k] <= 255, "the depth lanes of the public values are bytes");
+        d |= pub[pub.size() - 4 + k] << (8 * k);
+    }
+    NEED(d == depth, "the proof's depth differs from the public values'");
+    for (VProof& p : parsed) p.pub = pub, p.n_public = (uint32_t)pub.size();
+}
+
 }  // namespace
+
+// CachedProof { crypto_proof, expr, env, result, zdag } (proofs.rs:137-143): the claim travels with the proof, so the 44 public
+// values are rebuilt here: [expr flat 16 | env digest 8 | result flat 16 | depth as 4 bytes] (proofs.rs:46-56); the ZDag (the
+// data behind the pointers, for display) is parsed for its framing only
+extern "C" int32_t lurkhip_cached_proof_verify(const lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, const char* const* chip_names,
+                                               uint32_t n_airs, const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths,
+                                               uint32_t n_prep, const uint8_t* bytes, uint64_t n_bytes, uint32_t num_queries, uint32_t pow_bits,
+                                               uint32_t log_blowup, uint32_t* public_values_out /* 44 words or NULL */, char* err, uint32_t err_cap) {
+    return guarded_verify(err, err_cap, [&]() -> int32_t {
+        NEED(airs && chip_names && n_airs && vk_root && bytes && (!n_prep || (prep_log_heights && prep_widths)), "null or empty argument");
+        lurkhip_protocol_profile prof;
+        NEED(resolve_profile(profile, prof), "invalid protocol profile");
+        NEED(log_blowup >= 1 && log_blowup <= 4 && pow_bits <= 30 && num_queries >= 1 && num_queries <= 1024, "bad parameters");
+        const P16Params tables = lurkhip::p16_tables_of(prof);
+        Bytes b{bytes, n_bytes, 0, prof.serialize_montgomery != 0};
+        uint32_t depth = 0;
+        std::vector<VProof> parsed = decode_crypto_proof(b, airs, n_airs, chip_names, num_queries, pow_bits, log_blowup, &depth);
+        uint32_t z[3][9];  // tag, digest (canonical)
+        auto zptr = [&](uint32_t* out) {
+            out[0] = b.u32();
+            NEED(out[0] <= 14, "ZPtr tag out of range");
+            for (int i = 0; i < 8; i++) out[1 + i] = bb::from_monty(b.f());
+        };
+        for (auto& x : z) zptr(x);
+        const uint64_t n_dag = b.len(36 + 4);
+        for (uint64_t i = 0; i < n_dag; i++) {
+            uint32_t key[9], kid[9];
+            zptr(key);
+            const uint32_t kind = b.u32();  // ZPtrType: Atom | Tuple11(a, b) | Tuple110(a, b, c)
+            NEED(kind <= 2, "ZPtrType variant");
+            for (uint32_t k = 0; k < (kind == 0 ? 0u : kind + 1); k++) zptr(kid);
+        }
+        NEED(b.pos == b.n, "trailing bytes after the cached proof");
+        std::vector<uint32_t> pub;
+        pub.push_back(z[0][0]);
+        pub.insert(pub.end(), 7, 0u);
+        pub.insert(pub.end(), z[0] + 1, z[0] + 9);
+        pub.insert(pub.end(), z[1] + 1, z[1] + 9);
+        pub.push_back(z[2][0]);
+        pub.insert(pub.end(), 7, 0u);
+        pub.insert(pub.end(), z[2] + 1, z[2] + 9);
+        for (int k = 0; k < 4; k++) pub.push_back((depth >> (8 * k)) & 0xffu);
+        if (public_values_out) memcpy(public_values_out, pub.data(), pub.size() * 4);
+        set_public_values(parsed, pub, depth);
+        return verify_parsed(prof, airs, n_airs, vk_root, prep_log_heights, prep_widths, n_prep, parsed, tables);
+    });
+}
 
 extern "C" int32_t lurkhip_crypto_proof_verify(const lurkhip_protocol_profile* profile, const lurkhip_air* const* airs, const char* const* chip_names,
                                                uint32_t n_airs, const uint32_t* vk_root, const uint32_t* prep_log_heights, const uint32_t* prep_widths,
@@ -798,30 +872,17 @@ extern "C" int32_t lurkhip_crypto_proof_verify(const lurkhip_protocol_profile* p
                                                uint32_t n_public, uint32_t num_queries, uint32_t pow_bits, uint32_t log_blowup, char* err,
                                                uint32_t err_cap) {
     return guarded_verify(err, err_cap, [&]() -> int32_t {
-        NEED(airs && chip_names && n_airs && vk_root && bytes && (public_values || !n_public) && (!n_prep || (prep_log_heights && prep_widths)),
+        NEED(airs && chip_names && n_airs && vk_root && bytes && public_values && n_public && (!n_prep || (prep_log_heights && prep_widths)),
              "null or empty argument");
         lurkhip_protocol_profile prof;
         NEED(resolve_profile(profile, prof), "invalid protocol profile");
-        NEED(log_blowup >= 1 && log_blowup <= 4 && pow_bits <= 30 && num_queries >= 1 && num_queries <= 1024 && n_public >= 4, "bad parameters");
-        std::vector<uint32_t> pub(public_values, public_values + n_public);
-        uint32_t depth = 0;
-        for (uint32_t v : pub) NEED(v < bb::P, "public value is not canonical");
-        for (int k = 0; k < 4; k++) {
-            NEED(pub[n_public - 4 + k] <= 255, "the depth lanes of the public values are bytes");
-            depth |= pub[n_public - 4 + k] << (8 * k);
-        }
+        NEED(log_blowup >= 1 && log_blowup <= 4 && pow_bits <= 30 && num_queries >= 1 && num_queries <= 1024, "bad parameters");
         const P16Params tables = lurkhip::p16_tables_of(prof);
         Bytes b{bytes, n_bytes, 0, prof.serialize_montgomery != 0};
-        const uint64_t n_shards = b.len(96);
-        NEED(n_shards >= 1 && n_shards <= (1u << 20), "shard count");
-        std::vector<VProof> parsed;
-        for (uint64_t s = 0; s < n_shards; s++) {
-            parsed.push_back(decode_shard(b, airs, n_airs, chip_names, pub, log_blowup, pow_bits));
-            NEED(parsed.back().nq == num_queries, "the proof answers %u queries, the machine asks %u", parsed.back().nq, num_queries);
-        }
-        (void)b.str();  // verifier_version: informational (the reference compares it before it deserialises the rest)
-        NEED(b.u32() == depth, "the proof's depth differs from the public values'");
+        uint32_t depth = 0;
+        std::vector<VProof> parsed = decode_crypto_proof(b, airs, n_airs, chip_names, num_queries, pow_bits, log_blowup, &depth);
         NEED(b.pos == b.n, "trailing bytes after the proof");
+        set_public_values(parsed, std::vector<uint32_t>(public_values, public_values + n_public), depth);
         return verify_parsed(prof, airs, n_airs, vk_root, prep_log_heights, prep_widths, n_prep, parsed, tables);
     });
 }

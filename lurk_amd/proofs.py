@@ -81,6 +81,28 @@ def verify_crypto_proof(machine, data: bytes, public_values, num_queries: int, p
     return True
 
 
+def verify_cached_proof(machine, data: bytes, num_queries: int, pow_bits: int, log_blowup: int = 1, profile=None) -> list[int]:
+    """`lurk verify` after loading the file (lurkhip_cached_proof_verify): the bincode of a CachedProof carries the claim, the 44
+    public values are rebuilt from it and returned.  Raises lurk_amd.prover.VerificationError when the proof is rejected."""
+    from .prover import VerificationError
+
+    if machine.pk is None:
+        machine.setup()
+    airs = [air for _, _, air in machine.chips]
+    air_ptrs = (C.c_void_p * len(airs))(*[a.handle for a in airs])
+    names = (C.c_char_p * len(airs))(*[a.name.encode() for a in airs])
+    vk, lh, ws = np.array(machine.vk_root, dtype=np.uint32), np.array([16], dtype=np.uint32), np.array([6], dtype=np.uint32)
+    pv = np.zeros(44, dtype=np.uint32)
+    buf = (C.c_uint8 * len(data)).from_buffer_copy(data)
+    err = C.create_string_buffer(512)
+    st = N.lib.lurkhip_cached_proof_verify(C.byref(profile) if profile is not None else None, C.cast(air_ptrs, C.c_void_p), C.cast(names, C.c_void_p),
+                                           len(airs), vk.ctypes.data, lh.ctypes.data, ws.ctypes.data, 1, C.cast(buf, C.c_void_p), len(data), num_queries,
+                                           pow_bits, log_blowup, pv.ctypes.data, err, len(err))
+    if st != N.OK:
+        raise VerificationError(f"lurkhip status {st}: {err.value.decode('utf-8', 'replace')}")
+    return [int(x) for x in pv]
+
+
 def shard_proof_bincode(words, chip_names, serialize_montgomery: bool = False) -> bytes:
     """`bincode::serialize(&ShardProof)` of one shard proof (sphinx's struct, public values included) from its flat words."""
     w = np.ascontiguousarray(words, dtype=np.uint32)

@@ -119,3 +119,55 @@ def test_cached_proof_and_public_values(ctx, proved):
     # the decoder rebuilt the public values from expr / env / result / depth exactly as into_machine_proof does
     assert shards[0].public_values == proofs.public_values(b[expr], b[env], b[result], depth)
     st.close()
+
+
+def test_cached_proof_verifies_from_bytes_alone(ctx):
+    """The reference CLI's `verify`: a machine whose 44 public values have the claim's shape (expr flat 16 | env digest 8 | result
+    flat 16 | depth bytes) is proved, stored as CachedProof bytes and verified by the product from those bytes alone
+    (lurkhip_cached_proof_verify rebuilds the public values from expr / env / result / depth); another claim is rejected."""
+    import ctypes as C
+
+    from lurk_amd import _native as N
+    from lurk_amd.zstore import ZPtr
+
+    src = """
+    partial fn lurk_main(e: [16], v: [8]): [16] {
+        let (t, z1, z2, z3, z4, z5, z6, z7, d0, d1, d2, d3, d4, d5, d6, d7) = e;
+        let tag = 1;
+        let z = 0;
+        let (v0, v1, v2, v3, v4, v5, v6, v7) = v;
+        let s0 = add(d0, v0);
+        let p = store(d1, v1, t);
+        let (l0, l1, l2) = load(p);
+        let s1 = mul(l0, l1);
+        return (tag, z, z, z, z, z, z, z, s0, s1, d2, d3, v4, v5, d6, v7)
+    }
+    """
+    top = lair.Toplevel(src)
+    q = lair.QueryRecord(top)
+    expr = ZPtr(11, (5, 6, 7, 8, 9, 10, 11, 12))
+    env = ZPtr(12, (21, 22, 23, 24, 25, 26, 27, 28))
+    top.execute_by_name("lurk_main", expr.flatten() + list(env.digest), q)
+    pv = q.expect_public_values()
+    assert len(pv) == 44
+    result = ZPtr(pv[24], tuple(pv[32:40]))
+    m = prover.Machine(ctx, top, "lurk_main", 44)
+    m.setup()
+    shard_proofs = m.prove(q, num_queries=7, pow_bits=5)
+    cp = proofs.CryptoProof.from_machine_proof(m, shard_proofs, verifier_version="deadbeef").to_bytes()
+
+    def cached(e, v, r):
+        zp = [np.asarray([z.tag] + list(z.digest), dtype=np.uint32) for z in (e, v, r)]
+        p = C.c_void_p
+        args = (cp, len(cp), zp[0].ctypes.data_as(p), zp[1].ctypes.data_as(p), zp[2].ctypes.data_as(p), 0, None, 0)
+        size = N.lib.lurkhip_cached_proof_bincode(*args, None, 0)
+        buf = (C.c_uint8 * size)()
+        assert N.lib.lurkhip_cached_proof_bincode(*args, C.cast(buf, p), size) == size
+        return bytes(buf)
+
+    assert proofs.verify_cached_proof(m, cached(expr, env, result), num_queries=7, pow_bits=5) == pv
+    for other in (cached(ZPtr(10, expr.digest), env, result), cached(expr, ZPtr(12, (1,) * 8), result), cached(expr, env, ZPtr(1, (0,) * 8)),
+                  cached(expr, env, result)[:-1]):
+        with pytest.raises(prover.VerificationError):
+            proofs.verify_cached_proof(m, other, num_queries=7, pow_bits=5)
+    m.close()
