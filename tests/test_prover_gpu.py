@@ -306,3 +306,12 @@ def test_random_machines_prove_and_verify(ctx, seed, shard_size):
     m, root, proofs, pv = prove(ctx, src, entry, args, shard_size=shard_size)
     assert verify(src, entry, root, proofs, len(pv))
     assert prover.grand_sum(proofs) == (0, 0, 0, 0)
+    if len(pv) >= 4 and all(v <= 255 for v in pv[-4:]):
+        # public values that end in four bytes (every partial program's: its depth) fit the reference's CryptoProof, whose `depth`
+        # field they must equal: prove -> bincode -> the product's verifier from the bytes alone
+        from lurk_amd import proofs as lp
+
+        data = lp.CryptoProof.from_machine_proof(m, proofs, verifier_version="r").to_bytes()
+        assert lp.verify_crypto_proof(m, data, pv, num_queries=8, pow_bits=6)
+        with pytest.raises(prover.VerificationError):
+            lp.verify_crypto_proof(m, data[:100] + bytes([data[100] ^ 1]) + data[101:], pv, num_queries=8, pow_bits=6)
