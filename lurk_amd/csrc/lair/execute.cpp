@@ -676,10 +676,10 @@ static std::pair<List, uint32_t> func_execute(const Toplevel& t, const Func& sel
                 A.map.append(pargs + op.a, op.n);
                 break;
             case X_ADD:
-                A.map.push_back(fadd(map[op.x], map[op.y]));
+                A.map.push_back(fadd_c(map[op.x], map[op.y]));
                 break;
             case X_SUB:
-                A.map.push_back(fsub(map[op.x], map[op.y]));
+                A.map.push_back(fsub_c(map[op.x], map[op.y]));
                 break;
             case X_MUL:
                 A.map.push_back(fmul(map[op.x], map[op.y]));

@@ -32,6 +32,13 @@ constexpr uint32_t P = 2013265921u;
 inline uint32_t fadd(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + b) % P); }
 inline uint32_t fsub(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a + P - b) % P); }
 inline uint32_t fmul(uint32_t a, uint32_t b) { return (uint32_t)(((uint64_t)a * b) % P); }
+// the same on operands known to be canonical (the interpreter's variables always are: arguments are checked at the boundary,
+// constants are reduced by the compiler, everything else is a result): a compare instead of a 64-bit division
+inline uint32_t fadd_c(uint32_t a, uint32_t b) {
+    const uint32_t s = a + b;  // < 2^32: both operands are below p < 2^31
+    return s >= P ? s - P : s;
+}
+inline uint32_t fsub_c(uint32_t a, uint32_t b) { return a >= b ? a - b : a + P - b; }
 uint32_t finv(uint32_t a);  // panics (throws) on zero like p3's inverse()
 inline uint32_t field_from_i64(int64_t v) {
     int64_t m = v % (int64_t)P;

@@ -206,6 +206,10 @@ int32_t lurkhip_record_inject_inv_query(lurkhip_record* r, int32_t func_idx, con
                                         const uint32_t* out, uint32_t n_out) {
     if (!r) return LURKHIP_ERR_INVALID_ARG;
     return guarded(nullptr, [&]() -> int32_t {
+        for (uint32_t i = 0; i < n_inp; i++)
+            if (inp[i] >= lair::P) throw lair::ExecError("injected preimage is not made of canonical field elements");
+        for (uint32_t i = 0; i < n_out; i++)
+            if (out[i] >= lair::P) throw lair::ExecError("injected image is not made of canonical field elements");
         r->q.inject_inv_query((uint32_t)func_idx, lair::List(inp, inp + n_inp), lair::List(out, out + n_out));
         return LURKHIP_OK;
     });
