@@ -497,8 +497,11 @@ struct VerifyInput {
 void verify_shard(const VerifyInput& in, const VProof& p, Challenger ch, ef* sum) {
     const lurkhip_protocol_profile& prof = in.prof;
     NEED(p.n_prep == 0 || p.n_prep == in.n_prep, "the proof opens %u preprocessed traces, the verifying key has %u", p.n_prep, in.n_prep);
+    std::vector<bool> seen(in.n_airs, false);
     for (const VChip& c : p.chips) {
         NEED(c.machine_index < in.n_airs && in.airs[c.machine_index], "chip with machine index %u is not part of the machine", c.machine_index);
+        NEED(!seen[c.machine_index], "chip %u appears twice in one shard", c.machine_index);
+        seen[c.machine_index] = true;
         const lair::ChipAir& air = lurkhip::air_of(in.airs[c.machine_index]);
         NEED(air.width == c.width && air.prep_width == c.prep_width, "shape of chip %u", c.machine_index);
         NEED(c.qd == (1u << air.log_quotient_degree()), "quotient degree of chip %u", c.machine_index);
