@@ -171,3 +171,17 @@ def test_cached_proof_verifies_from_bytes_alone(ctx):
         with pytest.raises(prover.VerificationError):
             proofs.verify_cached_proof(m, other, num_queries=7, pow_bits=5)
     m.close()
+
+
+def test_the_example_script_runs():
+    import importlib.util
+    import os
+
+    path = os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "examples", "prove_and_verify.py")
+    spec = importlib.util.spec_from_file_location("example_prove_and_verify", path)
+    mod = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(mod)
+    a, b = 0, 1
+    for _ in range(300):
+        a, b = b, (a + b) % 2013265921
+    assert mod.main(300) == a
