@@ -532,6 +532,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     // the tall matrices' passes; the tree needs all of them, so the lane is joined before it.  Only with device inputs and while
     // the coset-shift table cache has room (its fallback scratch, arena slot 2, is shared by the streams).
     SideLane lane(ctx);
+    lane.want = 1;  // one side stream: the short matrices' passes share the coset-table scratch in order
     constexpr uint32_t SIDE_MAX_LOG_N = 13;
     if (!mats_on_host && log_blowup >= 1 && ctx->lde_scale_bytes + ((size_t)64 << 20) < ((size_t)1 << 30)) TRY_C(lane.open());
     if (!mats_on_host && log_blowup >= 1) {

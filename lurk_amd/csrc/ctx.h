@@ -50,8 +50,10 @@ struct lurkhip_ctx {
     int inject_alloc_failures = 0;
     // Fork / join inside one proof (lurkhip::SideLane): a second stream of the context for the short chips' launches.  While a
     // lane is open every pool_release is deferred to the join, so no block is handed out again while either stream may still use it.
-    hipStream_t side_stream = nullptr;
-    hipEvent_t side_fork = nullptr, side_join = nullptr;
+    static constexpr int N_SIDE = 4;
+    hipStream_t side_stream[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+    hipEvent_t side_fork = nullptr, side_join[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
+    bool side_used[N_SIDE] = {false, false, false, false};
     bool defer_releases = false;
     std::vector<void*> deferred;
     std::mutex pool_mu;  // a streaming prover releases one shard's inputs on its proving thread while the next shard's are allocated on its staging thread
@@ -92,10 +94,11 @@ int32_t upload_words(lurkhip_ctx* ctx, uint32_t* dst_dev, const uint32_t* src, s
 // pooled device allocations: released blocks are kept and reused for later requests of the same size
 int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out);
 void pool_release(lurkhip_ctx* ctx, void* ptr);
-// Fork / join of a side lane: between open() and close() work enqueued while `on_side()` guards are alive goes to the
-// context's second stream, ordered after everything queued before open(); close() makes the main stream wait for it.  The
-// short chips of a machine (a few workgroups per launch, latency-bound) run there under the tall chips' kernels.
-// LURKHIP_SIDE_LANE=0 disables it (everything on the main stream).
+// Fork / join of the side lanes: between open() and close() work enqueued while an `on_side(true, key)` guard is alive goes to
+// side stream `key mod N_SIDE` of the context, ordered after everything queued before open(); close() makes the main stream
+// wait for every side stream used.  The short chips of a machine (a few workgroups per launch, latency-bound) run there under
+// the tall chips' kernels -- and, since round 3, under one another: work that shares an accumulator must share a key.
+// LURKHIP_SIDE_LANE=0 disables it (everything on the main stream); LURKHIP_SIDE_LANES=1 keeps one side stream (round 2).
 struct SideLane {
     lurkhip_ctx* ctx;
     bool active = false;
@@ -106,12 +109,19 @@ struct SideLane {
     struct Guard {  // routes the launches of its scope to the side stream
         lurkhip_ctx* ctx;
         hipStream_t saved;
-        Guard(lurkhip_ctx* c, bool on) : ctx(c), saved(c->stream) {
-            if (on) c->stream = c->side_stream;
+        Guard(lurkhip_ctx* c, bool on, uint32_t lane) : ctx(c), saved(c->stream) {
+            if (on) {
+                c->stream = c->side_stream[lane];
+                c->side_used[lane] = true;
+            }
         }
         ~Guard() { ctx->stream = saved; }
     };
-    Guard on_side(bool on) { return Guard(ctx, on && active); }
+    int lanes = 1;
+    // side streams to use (set before open()): 1 when tall chips own the device anyway -- four lanes of short kernels under them
+    // measured 0.5 % slower on the 2^20-row step --, N_SIDE for a proof made of short chips only (2^12 rows: 9.8 -> 9.1 ms)
+    int want = lurkhip_ctx::N_SIDE;
+    Guard on_side(bool on, uint32_t key = 0) { return Guard(ctx, on && active, key % (uint32_t)lanes); }
 };
 // span timing (no-ops unless profiling is enabled)
 // `level`: 1 = stage span (recorded whenever profiling is on), 2 = detail span (per chip, per small tree: only at profile level 2 --

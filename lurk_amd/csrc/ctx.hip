@@ -125,7 +125,8 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
         // Give the cached blocks back to the driver and retry once.  Only blocks on the free list go: nobody holds a pointer to
         // them.  The scale / selector table caches stay -- a caller up the stack may be holding one of their pointers.
         (void)hipStreamSynchronize(ctx->stream);
-        if (ctx->side_stream) (void)hipStreamSynchronize(ctx->side_stream);
+        for (hipStream_t ss : ctx->side_stream)
+            if (ss) (void)hipStreamSynchronize(ss);
         for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
         ctx->pool_free.clear();
         ctx->pool_cached_bytes = 0;
@@ -167,13 +168,20 @@ void pool_release(lurkhip_ctx* ctx, void* ptr) {
 int32_t SideLane::open() {
     static const bool enabled = getenv("LURKHIP_SIDE_LANE") == nullptr || atoi(getenv("LURKHIP_SIDE_LANE")) != 0;
     if (!enabled || active) return LURKHIP_OK;
-    if (!ctx->side_stream) {
-        LH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream, hipStreamNonBlocking, ctx->stream_priority));
+    static const int n_lanes = getenv("LURKHIP_SIDE_LANES") ? std::max(1, std::min((int)lurkhip_ctx::N_SIDE, atoi(getenv("LURKHIP_SIDE_LANES")))) : (int)lurkhip_ctx::N_SIDE;
+    lanes = std::max(1, std::min(n_lanes, want));
+    if (!ctx->side_fork) {
+        for (int k = 0; k < lurkhip_ctx::N_SIDE; k++) {
+            LH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[k], hipStreamNonBlocking, ctx->stream_priority));
+            LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[k], hipEventDisableTiming));
+        }
         LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-        LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join, hipEventDisableTiming));
     }
     LH_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
-    LH_HIP(ctx, hipStreamWaitEvent(ctx->side_stream, ctx->side_fork, 0));
+    for (int k = 0; k < lanes; k++) {
+        LH_HIP(ctx, hipStreamWaitEvent(ctx->side_stream[k], ctx->side_fork, 0));
+        ctx->side_used[k] = false;
+    }
     {
         std::lock_guard<std::mutex> lock(ctx->pool_mu);
         ctx->defer_releases = true;
@@ -185,8 +193,12 @@ int32_t SideLane::open() {
 int32_t SideLane::close() {
     if (!active) return LURKHIP_OK;
     active = false;
-    hipError_t e = hipEventRecord(ctx->side_join, ctx->side_stream);
-    if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_join, 0);
+    hipError_t e = hipSuccess;
+    for (int k = 0; k < lurkhip_ctx::N_SIDE && e == hipSuccess; k++) {
+        if (!ctx->side_used[k]) continue;
+        e = hipEventRecord(ctx->side_join[k], ctx->side_stream[k]);
+        if (e == hipSuccess) e = hipStreamWaitEvent(ctx->stream, ctx->side_join[k], 0);
+    }
     std::vector<void*> blocks;
     {
         std::lock_guard<std::mutex> lock(ctx->pool_mu);
@@ -338,12 +350,13 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
     }
     if (ctx->ev_start) (void)hipEventDestroy(ctx->ev_start);
     if (ctx->ev_stop) (void)hipEventDestroy(ctx->ev_stop);
-    if (ctx->side_stream) {
-        (void)hipStreamSynchronize(ctx->side_stream);
-        (void)hipStreamDestroy(ctx->side_stream);
-        (void)hipEventDestroy(ctx->side_fork);
-        (void)hipEventDestroy(ctx->side_join);
-    }
+    for (int k = 0; k < lurkhip_ctx::N_SIDE; k++)
+        if (ctx->side_stream[k]) {
+            (void)hipStreamSynchronize(ctx->side_stream[k]);
+            (void)hipStreamDestroy(ctx->side_stream[k]);
+            (void)hipEventDestroy(ctx->side_join[k]);
+        }
+    if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LURKHIP_OK;

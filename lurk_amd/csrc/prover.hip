@@ -63,6 +63,7 @@ struct lurkhip_proof {
 
 namespace {
 
+constexpr uint32_t SIDE_LANES_SHORT_PROOF_LOG_N = 17;  // a shard whose tallest chip is below 2^17 rows (the byte chip is always 2^16) spreads its short chips over all side lanes
 constexpr int SIDE_LANE_MAX_LOG_N = 13;          // chips below 2^13 rows are "short": their per-chip launches go to the side lane
 constexpr uint32_t PROOF_MAGIC = 0x4652504cu;    // "LPRF"
 constexpr uint32_t OPENING_MAGIC = 0x4e504f4cu;  // "LOPN"
@@ -284,6 +285,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             max_w = std::max(max_w, r.c->width[m]);
             log_global_max = std::max(log_global_max, r.c->log_h[m]);
         }
+    const int side_lanes_wanted = log_global_max - log_blowup >= (int)SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : (int)lurkhip_ctx::N_SIDE;
     // caches keyed by (log size, point index)
     std::map<std::pair<int, int>, uint32_t*> bary, denoms;
     auto get_weights = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt, uint32_t** outp) -> int32_t {
@@ -343,6 +345,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         size_t k = 0, at = 0;
         std::vector<NarrowDot> narrow;  // the slab kernel's matrices: one launch for all of them
         SideLane lane(ctx);  // short wide matrices on the side lane
+        lane.want = side_lanes_wanted;
         PTRY(lane.open());
         for (const Round& r : rounds)
             for (int m = 0; m < r.c->n_mats; m++, k++) {
@@ -354,7 +357,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 if (column_dot_is_narrow(r.c->width[m])) {
                     narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at});
                 } else {
-                    const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N);
+                    const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N, (uint32_t)k);
                     PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
                 }
                 jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
@@ -439,12 +442,13 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     };
     size_t mat_k = 0;
     SideLane ro_lane(ctx);  // the accumulators are per height: a height is one lane
+    ro_lane.want = side_lanes_wanted;
     PTRY(ro_lane.open());
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const Round& r = rounds[ri];
         for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
             const int log_h = r.c->log_h[m];
-            const auto on_side = ro_lane.on_side(log_h - log_blowup < SIDE_LANE_MAX_LOG_N);
+            const auto on_side = ro_lane.on_side(log_h - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)log_h);  // one accumulator per height
             const uint32_t w = r.c->width[m];
             const std::vector<int>& mp = r.points[m];
             uint32_t *d0 = nullptr, *d1 = nullptr;
@@ -505,7 +509,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         }
     }
     for (auto& kv : narrow) {
-        const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N);
+        const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
         PTRY(flush_narrow(kv.second));
     }
     PTRY(ro_lane.close());
@@ -764,9 +768,14 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // the short chips' launches (a few workgroups each: starts, interpreter rows, one-block scan) go to the side lane, under the
     // tall chips' kernels
     SideLane lane(ctx);
+    {
+        uint32_t tallest = 0;
+        for (int i = 0; i < n_chips; i++) tallest = std::max(tallest, sh->log_n[i]);
+        lane.want = tallest >= SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : lurkhip_ctx::N_SIDE;
+    }
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
-        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N);
+        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const lair::ChipAir& air = air_of(sh->airs[i]);
         perm_widths[i] = 4 * air.permutation_width();
         lqds[i] = air.log_quotient_degree();
@@ -819,9 +828,12 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     std::vector<uint32_t> q_logn, q_widths, q_shifts;
     std::vector<int> q_chip;  // chip of each quotient chunk
     span_begin(ctx, "quotient_all");
+    // tables a chip's quotient finds in the context's caches are written at first use on the stream that asks: ask on the main
+    // stream, before the lanes fork (two chips of one height on two side lanes raced for the first proof of a context)
+    for (int i = 0; i < n_chips; i++) (void)selector_table_of(ctx, sh->log_n[i], lqds[i]);
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
-        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N);
+        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t qd = 1u << lqds[i];
         uint32_t* chunks = nullptr;

@@ -554,6 +554,44 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     return s;
 }
 
+// The quotient-domain selectors of a (height, quotient degree): a table of the context, written once by a kernel on the
+// context's CURRENT stream -- a caller that spreads chips over several streams (prover.hip's side lanes) asks for the tables
+// of all its chips on the main stream first, so that the write is ordered before every reader.  nullptr: no memory for the
+// table (or LURKHIP_QUOTIENT_SELECTORS_INLINE): the quotient kernel computes the selectors per row.
+uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd) {
+    const auto key = std::make_pair((int)log_n, (int)lqd);
+    auto it = ctx->selector_tables.find(key);
+    if (it != ctx->selector_tables.end()) return it->second;
+    if (getenv("LURKHIP_QUOTIENT_SELECTORS_INLINE") != nullptr) return nullptr;
+    const uint32_t log_q = log_n + lqd;
+    const NttPlan* plan = nullptr;
+    void* tbl = nullptr;
+    if (get_ntt_plan(ctx, (int)log_q, &plan) != LURKHIP_OK || hipMalloc(&tbl, ((size_t)12) << log_q) != hipSuccess) {
+        (void)hipGetLastError();
+        return nullptr;
+    }
+    SelectorArgs sa{};
+    sa.log_q = log_q;
+    sa.lqd = lqd;
+    sa.g_m = bb::to_monty(bb::GEN);
+    sa.wn_inv_m = bb::pow(two_adic_generator_monty((int)log_n), bb::P - 2);
+    // Z_H(x) = x^N - 1 on the coset: g^N * (w_Q^N)^i - 1, i mod 2^lqd
+    uint32_t gn = sa.g_m;
+    for (uint32_t i = 0; i < log_n; i++) gn = bb::mul(gn, gn);
+    const uint32_t w_qd = two_adic_generator_monty((int)lqd);
+    uint32_t cur = bb::R1;
+    for (uint32_t c = 0; c < (1u << lqd) && c < 4; c++) {
+        sa.zh[c] = bb::sub(bb::mul(gn, cur), bb::R1);
+        cur = bb::mul(cur, w_qd);
+    }
+    sa.tw = (const uint32_t*)plan->tw_fwd;
+    sa.out = (uint32_t*)tbl;
+    const uint32_t threads = ((1u << log_q) + 3) / 4;
+    hipLaunchKernelGGL(k_selectors, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sa);
+    ctx->selector_tables.emplace(key, (uint32_t*)tbl);
+    return (uint32_t*)tbl;
+}
+
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
@@ -639,31 +677,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             cur = bb::mul(cur, w_qd);
         }
         q.out = out_dev;
-        {
-            // the selectors of this (height, quotient degree): a table of the context, written once
-            const auto key = std::make_pair((int)log_n, (int)lqd);
-            auto it = ctx->selector_tables.find(key);
-            if (it == ctx->selector_tables.end() && getenv("LURKHIP_QUOTIENT_SELECTORS_INLINE") == nullptr) {
-                const NttPlan* plan = nullptr;
-                void* tbl = nullptr;
-                if (get_ntt_plan(ctx, (int)q.log_q, &plan) == LURKHIP_OK && hipMalloc(&tbl, ((size_t)12) << q.log_q) == hipSuccess) {
-                    SelectorArgs sa{};
-                    sa.log_q = q.log_q;
-                    sa.lqd = lqd;
-                    sa.g_m = q.g_m;
-                    sa.wn_inv_m = q.wn_inv_m;
-                    for (int c = 0; c < 4; c++) sa.zh[c] = q.zh[c];
-                    sa.tw = (const uint32_t*)plan->tw_fwd;
-                    sa.out = (uint32_t*)tbl;
-                    const uint32_t threads = ((1u << q.log_q) + 3) / 4;
-                    hipLaunchKernelGGL(k_selectors, dim3((threads + 255) / 256), dim3(256), 0, ctx->stream, sa);
-                    it = ctx->selector_tables.emplace(key, (uint32_t*)tbl).first;
-                } else {
-                    (void)hipGetLastError();  // no memory for the table: the kernel computes the selectors per row
-                }
-            }
-            q.sel = it != ctx->selector_tables.end() ? it->second : nullptr;
-        }
+        q.sel = selector_table_of(ctx, log_n, lqd);
         q.regs_words = lay.regs_words;
         q.wp = lay.wp;
         q.staged = lay.staged ? 1 : 0;

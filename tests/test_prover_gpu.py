@@ -315,3 +315,22 @@ def test_random_machines_prove_and_verify(ctx, seed, shard_size):
         assert lp.verify_crypto_proof(m, data, pv, num_queries=8, pow_bits=6)
         with pytest.raises(prover.VerificationError):
             lp.verify_crypto_proof(m, data[:100] + bytes([data[100] ^ 1]) + data[101:], pv, num_queries=8, pow_bits=6)
+
+
+@pytest.mark.parametrize("seed", [6, 16, 41, 52, 62])
+def test_first_proofs_of_fresh_contexts_are_identical(seed):
+    """A proof made of short chips spreads them over the context's side streams (ctx.h: SideLane); tables a context builds at
+    first use (selector tables, twiddles, programs) must be complete before any of those streams reads them: the FIRST proof of
+    three fresh contexts is the same proof (a race on the selector tables of chips of one height showed up here)."""
+    import lair_random as lr
+
+    src, calls, _ = lr.program(seed)
+    entry, args = calls[0]
+    words = []
+    for _ in range(3):
+        with lurk_amd.Context(0) as c:
+            m, root, proofs, pv = prove(c, src, entry, args)
+            words.append([p.words.copy() for p in proofs])
+            m.close()
+    for other in words[1:]:
+        assert len(other) == len(words[0]) and all(np.array_equal(a, b) for a, b in zip(other, words[0]))
