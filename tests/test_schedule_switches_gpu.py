@@ -37,6 +37,7 @@ print("PROOF", len(proofs), h.hexdigest())
 SWITCHES = [
     {},
     {"LURKHIP_SIDE_LANE": "0"},
+    {"LURKHIP_SIDE_LANES": "1"},
     {"LURKHIP_MERKLE_FUSED": "0"},
     {"LURKHIP_MERKLE_COOP_GROUP": "1"},
     {"LURKHIP_SPONGE_COOP": "0"},
