@@ -611,12 +611,16 @@ def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingCon
     pv = queries.expect_public_values()
     ready: "queue.Queue" = queue.Queue(maxsize=2)
     staged_s = [0.0]
+    # Phase 1 takes the shards LIGHTEST FIRST: nothing overlaps the staging of the first shard, and the reference's sharding
+    # makes the first shard the heaviest (every chip) and the last ones the lightest (the tallest chip only).  The main
+    # commitments do not depend on one another; the transcript observes the roots in shard order afterwards.
+    order = sorted(range(len(shards)), key=lambda i: machine.shard_cost(shards[i])) if prepared is None else list(range(len(shards)))
 
     def stage():
         try:
-            for sh in shards:
+            for i in order:
                 t0 = time.perf_counter()
-                item = machine.prepare_shard(sh, input_ctx=input_ctx, n_threads=n_threads)
+                item = machine.prepare_shard(shards[i], input_ctx=input_ctx, n_threads=n_threads)
                 staged_s[0] += time.perf_counter() - t0
                 ready.put(item)
         except BaseException as e:  # surfaced on the proving thread
@@ -631,16 +635,17 @@ def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingCon
     ch = Challenger(machine.ctx)
     ch.observe(machine.vk_root)
     ch.observe([0])
-    committed, inputs = [], []
+    committed, inputs, roots = [None] * len(shards), [], [None] * len(shards)
     try:
-        for i in range(len(shards)):
+        for i in order:
             item = prepared[i] if prepared is not None else ready.get()
             if isinstance(item, BaseException):
                 raise item
             inputs.append(item)
             traces = machine.run_prepared(item)
-            handle, root = machine.commit_shard(traces)
-            committed.append((handle, traces))
+            handle, roots[i] = machine.commit_shard(traces)
+            committed[i] = (handle, traces)
+        for root in roots:
             ch.observe(root)
             ch.observe(pv)
         # phase 2 on two lanes: the staging context is idle by now and serves as the second one
@@ -661,8 +666,9 @@ def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingCon
                     pass
             th.join()
         machine.ctx.sync()
-        for handle, _ in committed:
-            machine.free_shard(handle)
+        for c in committed:
+            if c is not None:
+                machine.free_shard(c[0])
         if prepared is None:
             for item in inputs:
                 item.close() if isinstance(item, PreparedShard) else [p.close() for *_, p in item if p is not None]
