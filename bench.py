@@ -66,6 +66,25 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
 CPU_SAMPLE_LOG_SHRINK = 1  # the CPU port proves a shard of 2^(log_rows - 1) eval rows: about 10 s of CPU work on the box's 16-core quota
 
 
+def host_info():
+    """The host the ranks' launch threads run on: the two-proofs-in-flight schedule needs two of them to keep up with the device,
+    and the boxes of the pool differ (the same build reads 40.7 .. 45.3 ms per step over boxes while one proof at a time reads
+    45.4 .. 46.4 on all of them)."""
+    info = {"cpu_count": os.cpu_count()}
+    try:
+        with open("/proc/cpuinfo") as f:
+            for line in f:
+                if line.startswith("model name"):
+                    info["cpu_model"] = line.split(":", 1)[1].strip()
+                    break
+        info["loadavg"] = [float(x) for x in open("/proc/loadavg").read().split()[:3]]
+        quota = open("/sys/fs/cgroup/cpu.max").read().split()
+        info["cpu_quota_cores"] = None if quota[0] == "max" else round(int(quota[0]) / int(quota[1]), 2)
+    except (OSError, ValueError, IndexError):
+        pass
+    return info
+
+
 def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bits: int):
     """The CPU PORT of the WHOLE step (oracle/cpu_prover.py: the oracle's transcript driving oracle/cpu_step.c -- coset LDEs and
     Poseidon2-16 Merkle trees of the three commitment rounds, LogUp permutation traces + running sums, quotient values from C
@@ -763,6 +782,7 @@ def main():
                 "rccl_world_size": rccl_world_size if not oversubscribed else None,
                 "process_group": None if not distributed else ("gloo (oversubscribed diagnostic: ranks share a device; NOT a scaling number)" if oversubscribed else "nccl (RCCL)"),
                 "visible_gpus": n_devices,
+                "host": host_info(),
                 "protocol_profile": args.profile,
                 "gathered_proof_set": proof_set,
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
