@@ -170,13 +170,18 @@ int32_t SideLane::open() {
     if (!enabled || active) return LURKHIP_OK;
     static const int n_lanes = getenv("LURKHIP_SIDE_LANES") ? std::max(1, std::min((int)lurkhip_ctx::N_SIDE, atoi(getenv("LURKHIP_SIDE_LANES")))) : (int)lurkhip_ctx::N_SIDE;
     lanes = std::max(1, std::min(n_lanes, want));
-    if (!ctx->side_fork) {
-        for (int k = 0; k < lurkhip_ctx::N_SIDE; k++) {
+    // Streams are created when a lane is first wanted.  The runtime deals streams to its four hardware queues as they are created
+    // (a new stream takes the least used queue), and which of a process's streams end up sharing a queue decides whether two
+    // proofs in flight overlap: three idle side streams per context were enough to take the step from 40.6 to 44.5 ms, creating
+    // this stream together with the context's own instead of here made the same step 45.3 ms under torchrun (RCCL's streams come
+    // in between), and a queue set of their own (stream priority -1) 46 ms.  DESIGN.md section 4 has the table; LURKHIP_PAD_STREAMS
+    // and LURKHIP_CTX_PRIORITY are the hooks it was measured with.
+    if (!ctx->side_fork) LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
+    for (int k = 0; k < lanes; k++)
+        if (!ctx->side_stream[k]) {
             LH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[k], hipStreamNonBlocking, ctx->stream_priority));
             LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[k], hipEventDisableTiming));
         }
-        LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
-    }
     LH_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
     for (int k = 0; k < lanes; k++) {
         LH_HIP(ctx, hipStreamWaitEvent(ctx->side_stream[k], ctx->side_fork, 0));
@@ -292,7 +297,15 @@ static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkh
         ctx->stream = (hipStream_t)stream;
         ctx->owns_stream = false;
     } else {
+        // A/B hook (measurements only): LURKHIP_PAD_STREAMS=n creates n idle streams ahead of this context's own, shifting the
+        // hardware queue its streams land on (the runtime deals streams to queues in creation order)
+        if (const char* pad = getenv("LURKHIP_PAD_STREAMS"))
+            for (int k = 0; k < std::min(16, atoi(pad)); k++) {
+                hipStream_t idle = nullptr;
+                (void)hipStreamCreateWithFlags(&idle, hipStreamNonBlocking);
+            }
         int least = 0, greatest = 0;  // numerically: least >= greatest
+        if (priority == 0 && getenv("LURKHIP_CTX_PRIORITY")) priority = atoi(getenv("LURKHIP_CTX_PRIORITY"));  // A/B hook
         if (priority != 0 && hipDeviceGetStreamPriorityRange(&least, &greatest) == hipSuccess)
             ctx->stream_priority = std::max(greatest, std::min(least, (int)priority));
         if ((e = hipStreamCreateWithPriority(&ctx->stream, hipStreamNonBlocking, ctx->stream_priority)) != hipSuccess)

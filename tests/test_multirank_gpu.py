@@ -186,3 +186,18 @@ def test_bench_two_proofs_in_flight_line_is_complete():
     assert set(cfg["stages_ms"]) >= {"commit_main", "permutation", "commit_perm", "quotient_all", "commit_quotient", "open", "fri_commit"}
     assert cfg["gathered_proof_set"]["grand_sum_of_gathered_proofs_is_zero"]
     assert line["roofline"]["frac"] > 0 and line["roofline"]["hbm"]["frac"] > 0
+
+
+def test_two_proofs_in_flight_overlap_at_the_bench_height():
+    """The default bench command's schedule at its own height (2^20 eval rows): two proofs in flight must be clearly faster than
+    one at a time in the same run.  Whether they overlap at all is decided by where the runtime puts the process's streams on its
+    hardware queues (idle streams created in the wrong place cost the whole 10 %); this is the tripwire."""
+    cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-host-pipeline"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["proofs_in_flight"] == 2 and cfg["proofs_identical_across_steps"] and cfg["gathered_proof_set"]["product_verifier"]["accepted"]
+    assert cfg["device_pools"]["hipMalloc_calls_in_timed_region"] == {"main": 0, "proof_lane1": 0}
+    assert line["ms_per_step"] < 0.95 * cfg["sequential"]["ms_per_step"], (line["ms_per_step"], cfg["sequential"]["ms_per_step"])
