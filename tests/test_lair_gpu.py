@@ -324,3 +324,46 @@ def test_random_programs_vs_oracle(ctx, oracle, seed, const_times_var):
                 rows_, width = ol.generate_trace(otop, f["name"], oq, sh.index, size)
                 got = chip.generate_trace(sh)
                 assert got.shape == (len(rows_), width) and got.tolist() == rows_, (f["name"], sh.index, size, "compiled")
+
+
+@pytest.mark.parametrize("seed", [1, 2, 3])
+def test_extern_chips_on_random_and_edge_operands(ctx, oracle, seed):
+    """The u64 / big-num / hasher chips on 60 random and edge operand pairs per seed (0, 1, 2^64 - 1, equal operands, divisor 1 and
+    dividend < divisor, operands that differ in one byte only, field elements next to p): results, every function's trace, the
+    memory and byte chips -- GPU == the oracle's generator."""
+    import random
+
+    rnd = random.Random(9000 + seed)
+    P = 2013265921
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    edge = [0, 1, 2, 255, 256, 2**32 - 1, 2**32, 2**63, 2**64 - 1, 2**64 - 2, 0x0101010101010101, 0xFF00FF00FF00FF00]
+
+    def operand():
+        k = rnd.random()
+        if k < 0.35:
+            return rnd.choice(edge)
+        if k < 0.5:
+            return rnd.getrandbits(rnd.choice([1, 8, 9, 16, 33, 63]))
+        return rnd.getrandbits(64)
+
+    calls = []
+    for _ in range(20):
+        a, b = operand(), operand()
+        if rnd.random() < 0.15:
+            b = a
+        if rnd.random() < 0.15:
+            b = a ^ (1 << (8 * rnd.randrange(8)))  # one differing byte
+        calls.append(["u64_ops", u64(a) + u64(b)])
+        calls.append(["u64_more", u64(a) + u64(b if b else 1)])
+        x = [rnd.choice([0, 1, P - 1, P - 2, rnd.randrange(P)]) for _ in range(8)]
+        y = list(x) if rnd.random() < 0.2 else [rnd.choice([0, 1, P - 1, rnd.randrange(P)]) for _ in range(8)]
+        if rnd.random() < 0.3:
+            y = list(x)
+            y[rnd.randrange(8)] = rnd.randrange(P)
+        calls.append(["big_lt", x + y])
+    calls.append(["chain", [rnd.randrange(P) for _ in range(8)]])
+    top, q, oq = _compare_all_funcs(ctx, oracle, U64_SRC, calls, lurk_chips=True)
+    assert q.num_byte_records() == len(oq.bytes) > 0
