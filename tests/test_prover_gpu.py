@@ -334,3 +334,38 @@ def test_first_proofs_of_fresh_contexts_are_identical(seed):
             m.close()
     for other in words[1:]:
         assert len(other) == len(words[0]) and all(np.array_equal(a, b) for a, b in zip(other, words[0]))
+
+
+@pytest.mark.parametrize("seed", range(6))
+def test_u64_and_bignum_machines_on_random_operands_prove_and_verify(ctx, seed):
+    """u64_ops / u64_more / big_lt machines on random and edge operands: proved, accepted by the product's verifier and the oracle's."""
+    import random
+
+    from lair_helpers import U64_SRC
+
+    rnd = random.Random(77 + seed)
+    P = 2013265921
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    edge = [0, 1, 255, 256, 2**32 - 1, 2**63, 2**64 - 1]
+    a = rnd.choice(edge) if rnd.random() < 0.4 else rnd.getrandbits(64)
+    b = a if rnd.random() < 0.2 else (rnd.choice(edge) if rnd.random() < 0.4 else rnd.getrandbits(rnd.choice([8, 33, 64])))
+    x = [rnd.choice([0, P - 1, rnd.randrange(P)]) for _ in range(8)]
+    y = list(x)
+    y[rnd.randrange(8)] = rnd.randrange(P)
+    entry, args = [("u64_ops", u64(a) + u64(b)), ("u64_more", u64(a) + u64(b or 3)), ("big_lt", x + y)][seed % 3]
+    top = lair.Toplevel(U64_SRC, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(entry, args, q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, entry, len(pv))
+    root = m.setup()
+    proofs = m.prove(q, num_queries=6, pow_bits=4)
+    assert m.verify(proofs)
+    otop = ol.Toplevel(U64_SRC, chips=ol.lurk_chips())
+    airs = [oa.EntrypointAir(otop.index[entry], len(pv))] + [oa.FuncAir(otop, f["name"]) for f in otop.funcs]
+    airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
+    assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
+    m.close()
