@@ -9,11 +9,13 @@
 // evaluated on the opened values straight from its symbolic AIR (lair::ChipAir: the node list is in topological order).
 // Every choice the prover takes from the protocol profile (include/lurkhip.h) is taken from the same profile here.
 #include <array>
+#include <atomic>
 #include <cstdarg>
 #include <cstring>
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <thread>
 #include <vector>
 
 #include "../../include/lurkhip.h"
@@ -754,13 +756,39 @@ int32_t verify_parsed(const lurkhip_protocol_profile& prof, const lurkhip_air* c
         for (uint32_t v : p.pub) ch.observe(v);
     }
     const VerifyInput in{prof, H, airs, n_airs, vk_m, prep_log_heights, prep_widths, n_prep};
-    ef total = bb::ef_zero();
-    for (size_t s = 0; s < parsed.size(); s++) {
+    // the shards are independent once the transcript prefix is fixed: a few host threads share them (LURKHIP_VERIFY_THREADS caps
+    // the count; 1 = in order on the calling thread); the first rejection in shard order is the one reported
+    const size_t n = parsed.size();
+    std::vector<ef> sums(n, bb::ef_zero());
+    std::vector<std::string> why(n);
+    std::vector<char> failed(n, 0);
+    auto one = [&](size_t s) {
         try {
-            verify_shard(in, parsed[s], ch, &total);
+            verify_shard(in, parsed[s], ch, &sums[s]);
         } catch (const Reject& r) {
-            reject("shard %zu: %s", s, r.what());
+            failed[s] = 1, why[s] = r.what();
+        } catch (const std::exception& e) {
+            failed[s] = 2, why[s] = e.what();
         }
+    };
+    unsigned threads = std::min<size_t>({n, 16, std::max(1u, std::thread::hardware_concurrency())});
+    if (const char* e = getenv("LURKHIP_VERIFY_THREADS")) threads = (unsigned)std::max(1, std::min((int)threads, atoi(e)));
+    if (threads <= 1) {
+        for (size_t s = 0; s < n; s++) one(s);
+    } else {
+        std::atomic<size_t> next{0};
+        std::vector<std::thread> pool;
+        for (unsigned t = 0; t < threads; t++)
+            pool.emplace_back([&]() {
+                for (size_t s = next.fetch_add(1); s < n; s = next.fetch_add(1)) one(s);
+            });
+        for (auto& t : pool) t.join();
+    }
+    ef total = bb::ef_zero();
+    for (size_t s = 0; s < n; s++) {
+        if (failed[s] == 2) throw std::runtime_error(why[s]);
+        if (failed[s]) reject("shard %zu: %s", s, why[s].c_str());
+        total = bb::ef_add(total, sums[s]);
     }
     NEED(bb::ef_is_zero(total), "cumulative sums do not cancel");
     return LURKHIP_OK;
