@@ -428,7 +428,9 @@ def main():
                       "note": "one proof at a time on one HIP stream (the headline of rounds 1-2), measured in this run before the timed region"}
         extra_lanes = []
         for _ in range(lanes - 1):
-            ctx2 = lurk_amd.Context(device_index)
+            # a context whose stream is measured to run beside the first lane's (lurkhip_ctx_create_beside); LURKHIP_LANE_UNPLACED=1
+            # takes whatever hardware queue the runtime hands out (A/B)
+            ctx2 = lurk_amd.Context(device_index) if os.environ.get("LURKHIP_LANE_UNPLACED") else lurk_amd.Context(beside=ctx)
             if args.profile != "default":
                 from lurk_amd.profile import ProtocolProfile
 

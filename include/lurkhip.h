@@ -62,6 +62,10 @@ int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out);
  * that proves beside another one (a second prove lane, a staging context).  Measured on two half-shards in flight: no difference
  * between equal and unequal queues on this part, so the Python mirror leaves it at 0. */
 int32_t lurkhip_ctx_create_with_priority(int32_t device_id, int32_t priority, lurkhip_ctx** out);
+/* A context on `other`'s device whose own stream provably runs BESIDE `other`'s: candidate streams are created and a short
+ * busy kernel is timed on both until one overlaps (the runtime deals streams to a few hardware queues without saying which; two
+ * streams on one queue run one kernel at a time).  For the second proof in flight (lurk_amd.prover.lane_context). */
+int32_t lurkhip_ctx_create_beside(lurkhip_ctx* other, lurkhip_ctx** out);
 /* Same, but all work is enqueued on the caller's hipStream_t (e.g. torch's current stream). */
 int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhip_ctx** out);
 int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx);

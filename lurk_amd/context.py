@@ -29,9 +29,13 @@ class Context:
     example ``torch.cuda.current_stream().cuda_stream``) to enqueue on a caller stream; ``priority`` (0 default, > 0 lower) is
     that of the context's own streams."""
 
-    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0):
+    def __init__(self, device: int = 0, stream: int | None = None, priority: int = 0, beside: "Context | None" = None):
         h = C.c_void_p()
-        if stream is None and priority:
+        if beside is not None:
+            # a context whose stream was MEASURED to run beside `beside`'s (lurkhip_ctx_create_beside): the second proof in flight
+            N.check(N.lib.lurkhip_ctx_create_beside(beside.handle, C.byref(h)))
+            device = beside.device
+        elif stream is None and priority:
             N.check(N.lib.lurkhip_ctx_create_with_priority(device, priority, C.byref(h)))
         elif stream is None:
             N.check(N.lib.lurkhip_ctx_create(device, C.byref(h)))

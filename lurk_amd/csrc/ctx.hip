@@ -165,6 +165,52 @@ void pool_release(lurkhip_ctx* ctx, void* ptr) {
     ctx->pool_live.erase(it);
 }
 
+namespace {
+__global__ void k_occupy(uint64_t ticks) {  // one wave busy for `ticks` of the 100 MHz wall clock
+    const uint64_t t0 = wall_clock64();
+    while (wall_clock64() - t0 < ticks) {
+    }
+}
+// seconds for one k_occupy on each of the two streams, launched back to back: ~one kernel's time when the streams sit on
+// different hardware queues, two when they share one
+double occupy_both(hipStream_t a, hipStream_t b, uint64_t ticks) {
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_occupy, dim3(1), dim3(64), 0, a, ticks);
+    hipLaunchKernelGGL(k_occupy, dim3(1), dim3(64), 0, b, ticks);
+    (void)hipStreamSynchronize(a);
+    (void)hipStreamSynchronize(b);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+// a new stream that a kernel was MEASURED to run on beside a kernel on `ref` (nullptr: creation failed); `alone` = seconds of one
+// k_occupy(ticks) by itself on `ref`
+hipStream_t stream_beside(hipStream_t ref, int priority, uint64_t ticks, double alone) {
+    constexpr int MAX_TRIES = 8;
+    std::vector<hipStream_t> parked;
+    hipStream_t chosen = nullptr;
+    for (int t = 0; t < MAX_TRIES && !chosen; t++) {
+        hipStream_t s = nullptr;
+        if (hipStreamCreateWithPriority(&s, hipStreamNonBlocking, priority) != hipSuccess) break;
+        (void)occupy_both(ref, s, ticks / 10);  // first launch on a new stream: not timed
+        if (occupy_both(ref, s, ticks) < 1.5 * alone) chosen = s;
+        else parked.push_back(s);  // kept until the choice is made, so that the next candidate lands elsewhere
+    }
+    if (!chosen && !parked.empty()) {  // every candidate shared the queue (a runtime with one queue): take one anyway
+        chosen = parked.back();
+        parked.pop_back();
+    }
+    for (hipStream_t s : parked) (void)hipStreamDestroy(s);
+    return chosen;
+}
+double occupy_alone(hipStream_t ref, uint64_t ticks) {
+    (void)hipStreamSynchronize(ref);
+    const auto t0 = std::chrono::steady_clock::now();
+    hipLaunchKernelGGL(k_occupy, dim3(1), dim3(64), 0, ref, ticks);
+    (void)hipStreamSynchronize(ref);
+    return std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+}
+constexpr uint64_t PLACE_TICKS = 50000;  // 0.5 ms of the 100 MHz wall clock
+}  // namespace
+
 int32_t SideLane::open() {
     static const bool enabled = getenv("LURKHIP_SIDE_LANE") == nullptr || atoi(getenv("LURKHIP_SIDE_LANE")) != 0;
     if (!enabled || active) return LURKHIP_OK;
@@ -179,7 +225,10 @@ int32_t SideLane::open() {
     if (!ctx->side_fork) LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_fork, hipEventDisableTiming));
     for (int k = 0; k < lanes; k++)
         if (!ctx->side_stream[k]) {
-            LH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[k], hipStreamNonBlocking, ctx->stream_priority));
+            // (the first one is measured to run beside the context's own stream; once per context, ~2 ms)
+            static const bool placed = getenv("LURKHIP_SIDE_UNPLACED") == nullptr;
+            if (k == 0 && placed) ctx->side_stream[k] = stream_beside(ctx->stream, ctx->stream_priority, PLACE_TICKS, occupy_alone(ctx->stream, PLACE_TICKS));
+            if (!ctx->side_stream[k]) LH_HIP(ctx, hipStreamCreateWithPriority(&ctx->side_stream[k], hipStreamNonBlocking, ctx->stream_priority));
             LH_HIP(ctx, hipEventCreateWithFlags(&ctx->side_join[k], hipEventDisableTiming));
         }
     LH_HIP(ctx, hipEventRecord(ctx->side_fork, ctx->stream));
@@ -336,6 +385,29 @@ int32_t lurkhip_ctx_create_with_priority(int32_t device_id, int32_t priority, lu
 
 int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out) {
     return create_common(device_id, nullptr, false, out);
+}
+
+// A context for work that must overlap `other`'s (a second proof in flight).  The runtime deals streams to its four hardware
+// queues as they are created and tells nobody where; two streams on one queue run one kernel at a time.  So: create a stream,
+// MEASURE whether a kernel on it runs beside a kernel on the other context's stream, and keep the first stream that does
+// (streams that do not are parked until the choice is made, so that the next candidate lands elsewhere).  A few milliseconds,
+// once per context.  DESIGN.md section 4 has the numbers this is for (40.6 against 45 ms per step, by placement alone).
+int32_t lurkhip_ctx_create_beside(lurkhip_ctx* other, lurkhip_ctx** out) {
+    LH_CHECK_CTX(other);
+    if (!out) return set_error(other, LURKHIP_ERR_INVALID_ARG, "null out pointer");
+    *out = nullptr;
+    hipStream_t chosen = stream_beside(other->stream, other->stream_priority, PLACE_TICKS, occupy_alone(other->stream, PLACE_TICKS));
+    if (!chosen) return set_error(other, LURKHIP_ERR_HIP, "no stream could be created beside the context's");
+    lurkhip_ctx* ctx = nullptr;
+    const int32_t st = create_common(other->device, chosen, true, &ctx);
+    if (st != LURKHIP_OK) {
+        (void)hipStreamDestroy(chosen);
+        return st;
+    }
+    ctx->owns_stream = true;  // created here: destroyed with the context
+    ctx->stream_priority = other->stream_priority;
+    *out = ctx;
+    return LURKHIP_OK;
 }
 
 int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhip_ctx** out) {

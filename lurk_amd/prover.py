@@ -539,7 +539,8 @@ def lane_context(machine, ctx=None):
     """A second context for `prove_lanes` on the machine's device with the machine context's protocol profile."""
     from .profile import ProtocolProfile
 
-    ctx = ctx or Context(machine.ctx.device, priority=LANE_PRIORITY)
+    # (its stream is measured to run beside the machine context's: Context(beside=...), DESIGN.md section 4)
+    ctx = ctx or (Context(machine.ctx.device, priority=LANE_PRIORITY) if LANE_PRIORITY else Context(beside=machine.ctx))
     ProtocolProfile.of(machine.ctx).install(ctx)
     return ctx
 

@@ -188,12 +188,17 @@ def test_bench_two_proofs_in_flight_line_is_complete():
     assert line["roofline"]["frac"] > 0 and line["roofline"]["hbm"]["frac"] > 0
 
 
-def test_two_proofs_in_flight_overlap_at_the_bench_height():
+@pytest.mark.parametrize("pad", [0, 4])
+def test_two_proofs_in_flight_overlap_at_the_bench_height(pad):
     """The default bench command's schedule at its own height (2^20 eval rows): two proofs in flight must be clearly faster than
     one at a time in the same run.  Whether they overlap at all is decided by where the runtime puts the process's streams on its
-    hardware queues (idle streams created in the wrong place cost the whole 10 %); this is the tripwire."""
+    hardware queues (idle streams created in the wrong place cost the whole 10 %); this is the tripwire.
+    `pad` = 4: four idle streams ahead of every context, the placement that read 45 ms before the second lane's stream and the
+    side streams were MEASURED into place (lurkhip_ctx_create_beside)."""
     cmd = [sys.executable, os.path.join(ROOT, "bench.py"), "--steps", "10", "--warmup", "2", "--no-cpu-baseline", "--no-host-pipeline"]
     env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    if pad:
+        env["LURKHIP_PAD_STREAMS"] = str(pad)
     r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
     assert r.returncode == 0, r.stderr[-3000:]
     line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
