@@ -362,7 +362,7 @@ def main():
     if len(mine) > 1 and args.rank_pipeline:
         pipe = {"steps": [rank_step], "ctxs": [], "machines": [], "prepared": []}
         for _ in range(max(2, args.rank_pipeline_depth) - 1):
-            ctx_b = lurk_amd.Context(device_index)
+            ctx_b = lurk_amd.Context(device_index) if os.environ.get("LURKHIP_LANE_UNPLACED") else lurk_amd.Context(beside=ctx)
             if args.profile != "default":
                 from lurk_amd.profile import ProtocolProfile
 
