@@ -718,7 +718,7 @@ def main():
             if not args.no_compile:
                 mach2.compile_airs(prepared2[0])  # same chips as above: served from the code cache
             staged_bytes = sum(p.input_bytes for item in prepared2 for *_, p in item if p is not None)
-            ctx_in = lurk_amd.Context(device_index)
+            ctx_in = lurk_amd.Context(beside=ctx)
 
             def timed(**kw):
                 torch.cuda.synchronize()

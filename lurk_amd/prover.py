@@ -457,7 +457,7 @@ class Machine(_ShardProver):
         tall = [x for x in todo if x[0] >= SIDE_STREAM_MAX_LOG_ROWS]
         if short and tall and self.side_stream:
             if self._side_ctx is None:
-                self._side_ctx = Context(self.ctx.device)
+                self._side_ctx = Context(beside=self.ctx)  # (a stream measured to run beside this context's)
             self._ev_fork = self.ctx.record_event(self._ev_fork)
             self._side_ctx.wait_event(self._ev_fork)
             for _, t, p in short:
@@ -509,7 +509,7 @@ class Machine(_ShardProver):
         lane_ctx = None
         if lanes > 1:
             if self._lane_ctx is None:
-                self._lane_ctx = Context(self.ctx.device, priority=LANE_PRIORITY)
+                self._lane_ctx = lane_context(self)  # a stream measured to run beside this context's (Context(beside=...))
             lane_ctx = lane_context(self, self._lane_ctx)
         proofs = []
         for at in range(0, len(shards), lanes):
@@ -630,7 +630,7 @@ def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingCon
     th, own_ctx = None, None
     if prepared is None:
         if input_ctx is None:  # the staging thread needs a stream and a pool of its own
-            input_ctx = own_ctx = Context(machine.ctx.device)
+            input_ctx = own_ctx = Context(beside=machine.ctx)  # (it is the second proving lane of phase 2 too)
         th = threading.Thread(target=stage)
         th.start()
     ch = Challenger(machine.ctx)
@@ -653,7 +653,7 @@ def prove_streamed(machine: "Machine", queries: QueryRecord, config: ShardingCon
         lane_ctx = None
         if lanes > 1 and len(committed) > 1:
             if input_ctx is None:
-                input_ctx = own_ctx = Context(machine.ctx.device)
+                input_ctx = own_ctx = Context(beside=machine.ctx)
             if th is not None:
                 th.join()
             lane_ctx = lane_context(machine, input_ctx)
