@@ -232,8 +232,10 @@ def main():
                          "(shards.run_pipelined); >= 3 = a committer thread runs phase 1 up to depth - 1 proofs ahead (shards.run_committed_ahead)")
     ap.add_argument("--rank-pipeline-one-lane", action="store_true",
                     help="with --rank-pipeline: phase 2 proves the rank's shards one after the other on ONE lane (two streams busy in all: phase 2 of proof j, phase 1 of proof j + 1) instead of two")
-    ap.add_argument("--stagger-ms", type=float, default=0.0,
-                    help="--lanes >= 2: lane k starts its first timed proof k * this many milliseconds late (inside the timed region), so that the lanes run out of phase")
+    ap.add_argument("--stagger-ms", type=float, default=None,
+                    help="--lanes >= 2: lane k starts its first timed proof k * this many milliseconds late (inside the timed region), so that the lanes run "
+                         "out of phase (one lane's commitments under the other's openings and FRI).  Default: one proof's sequential time / lanes, "
+                         "measured in the same run (two lanes: half a proof); 0 = all lanes start together (2.2-2.7 %% slower, DESIGN.md section 4)")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
     ap.add_argument("--compile-min-log-rows", type=int, default=None,
                     help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
@@ -462,6 +464,9 @@ def main():
                 tot = (tot + np.asarray(c, dtype=np.int64)) % 2013265921
             return w, tuple(int(x) for x in tot)
 
+        # the lanes' offset: by default a proof's sequential time (just measured) divided by the number of lanes
+        stagger_ms = args.stagger_ms if args.stagger_ms is not None else sequential["ms_per_step"] / lanes
+
         def run_lanes(k_total, sink):
             """k_total proofs over the two lanes, each lane taking the next proof as it finishes one."""
             nxt = [0]
@@ -483,7 +488,7 @@ def main():
                     errors.append(e)
 
             ths = [threading.Thread(target=worker, args=(machine, ctx, prepared))]
-            ths += [threading.Thread(target=worker, args=l + ((k + 1) * args.stagger_ms * 1e-3,)) for k, l in enumerate(extra_lanes)]
+            ths += [threading.Thread(target=worker, args=l + ((k + 1) * stagger_ms * 1e-3,)) for k, l in enumerate(extra_lanes)]
             for th in ths:
                 th.start()
             for th in ths:
@@ -812,6 +817,7 @@ def main():
                 "rank_pipeline": ("phase 1 of machine proof j + 1 (traces + main commitments, on a second machine's context) under phase 2 of proof j; "
                                   "collectives on one thread in a fixed order" if pipe is not None else None),
                 "proofs_in_flight": lanes,
+                "lane_stagger_ms": (stagger_ms if lanes >= 2 else None),
                 "schedule": (f"the K timed steps are K independent proofs of the shard, {lanes} in flight on {lanes} HIP streams / contexts of the GPU (prove lanes); "
                              "`sequential` is one proof at a time, measured before the timed region; stages_ms / roofline.hbm come from that sequential pass "
                              "(a kernel alone on the device), stages_ms_in_flight from the timed region (spans of the lanes overlap in time)") if lanes >= 2
