@@ -235,7 +235,7 @@ def main():
     ap.add_argument("--stagger-ms", type=float, default=None,
                     help="--lanes >= 2: lane k starts its first timed proof k * this many milliseconds late (inside the timed region), so that the lanes run "
                          "out of phase (one lane's commitments under the other's openings and FRI).  Default: one proof's sequential time / lanes, "
-                         "measured in the same run (two lanes: half a proof); 0 = all lanes start together (2.2-2.7 %% slower, DESIGN.md section 4)")
+                         "measured in the same run (two lanes: half a proof) when there are at least 16 timed steps, else 0; 0 = all lanes start together (2.2-2.7 %% slower, DESIGN.md section 4)")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
     ap.add_argument("--compile-min-log-rows", type=int, default=None,
                     help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
@@ -465,7 +465,8 @@ def main():
             return w, tuple(int(x) for x in tot)
 
         # the lanes' offset: by default a proof's sequential time (just measured) divided by the number of lanes
-        stagger_ms = args.stagger_ms if args.stagger_ms is not None else sequential["ms_per_step"] / lanes
+        # (the delay is paid once per timed region: with fewer than 16 timed proofs it costs more than the phase shift returns)
+        stagger_ms = args.stagger_ms if args.stagger_ms is not None else (sequential["ms_per_step"] / lanes if args.steps >= 16 else 0.0)
 
         def run_lanes(k_total, sink):
             """k_total proofs over the two lanes, each lane taking the next proof as it finishes one."""
