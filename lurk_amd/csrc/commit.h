@@ -23,6 +23,10 @@ struct lurkhip_commitment {
     std::vector<size_t> level_off;    // in digests (units of 8 words)
     int log_max = 0;
     std::vector<void*> owned;         // extra device allocations (column tables)
+    // the leaf sponge of the tallest height group launched ahead on the context's hash stream, under the LDE passes of the
+    // shorter groups (commit.hip: early_leaves; LURKHIP_EARLY_LEAVES)
+    bool early_leaves = false;
+    std::vector<void*> early_scratch;
 };
 
 namespace lurkhip {

@@ -198,6 +198,8 @@ int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batc
 
 void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     if (!c) return;
+    for (void* p : c->early_scratch) pool_release(ctx, p);
+    c->early_scratch.clear();
     if (c->owns_lde)
         for (auto p : c->lde) pool_release(ctx, p);
     for (auto p : c->coeffs) pool_release(ctx, p);
@@ -269,6 +271,48 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
 // from being spread over the CUs) and no different from 16 or 2.
 constexpr size_t TOP_NODES = 64;
 
+// The leaf sponge of the tallest height group, launched on the context's hash stream behind `ctx->hash_ready` (recorded by the
+// caller on the main stream right after that group's LDE passes): it runs under the LDE passes of the shorter groups, which the
+// caller has queued on the main stream behind that event.  The sponge is VALU-bound, the passes are not (round 2 verdict,
+// item 5, second experiment).  Allocates the tree's digests; build_tree then skips group 0 and waits for `hash_done` before the
+// first level.  Must be called while the caller's side lane is open (pool releases deferred: nothing this hands to the hash
+// stream is a block that work queued behind the event has just released).
+int32_t early_leaves(lurkhip_ctx* ctx, lurkhip_commitment* c) {
+    const P16Params* params = nullptr;
+    LH_TRY(get_merkle_params(ctx, &params));
+    c->log_max = *std::max_element(c->log_h.begin(), c->log_h.end());
+    const size_t n_leaves = (size_t)1 << c->log_max;
+    if (n_leaves <= MERKLE_COOP_MAX_PARENTS) return LURKHIP_OK;
+    std::vector<int> tallest;
+    for (int m = 0; m < c->n_mats; m++)
+        if (c->log_h[m] == c->log_max) tallest.push_back(m);  // (ascending index = the stable height order of build_tree)
+    c->level_off.assign(c->log_max + 1, 0);
+    size_t total = 0;
+    for (int l = 0; l <= c->log_max; l++) {
+        c->level_off[l] = total;
+        total += n_leaves >> l;
+    }
+    LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
+    hipStream_t main_stream = ctx->stream;
+    LH_HIP(ctx, hipStreamWaitEvent(ctx->hash_stream, ctx->hash_ready, 0));
+    ctx->stream = ctx->hash_stream;
+    LeafCol* cols = nullptr;
+    uint32_t tw = 0;
+    int32_t st = make_cols(ctx, c, tallest, &cols, &tw, c->early_scratch);
+    if (st == LURKHIP_OK) {
+        span_begin(ctx, "merkle_leaves", c->log_max >= 16 ? 1 : 2);
+        SpongeGroups g{};
+        g.cols[0] = cols, g.total_w[0] = tw, g.n_rows[0] = n_leaves, g.out[0] = c->digests, g.n = 1;
+        st = merkle_row_sponges(ctx, params, g);
+        span_end(ctx, "merkle_leaves", c->log_max >= 16 ? 1 : 2);
+    }
+    hipError_t e = hipEventRecord(ctx->hash_done, ctx->hash_stream);
+    ctx->stream = main_stream;
+    if (st == LURKHIP_OK && e != hipSuccess) st = set_error(ctx, LURKHIP_ERR_HIP, "hash stream: %s", hipGetErrorString(e));
+    if (st == LURKHIP_OK) c->early_leaves = true;
+    return st;
+}
+
 int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
@@ -284,7 +328,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         c->level_off[l] = total;
         total += n_leaves >> l;
     }
-    LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
+    if (!c->early_leaves) LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
     // leaves
     std::vector<int> tallest;
     for (int m : order)
@@ -298,6 +342,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     const bool fused = (fused_env == nullptr || atoi(fused_env) != 0) && n_leaves > MERKLE_COOP_MAX_PARENTS;
     std::vector<uint32_t*> inj_digests(c->log_max + 1, nullptr);  // by level
     std::vector<void*> scratch;
+    scratch.swap(c->early_scratch);  // (the early leaf sponge's column table: released with the rest, behind the join below)
     auto drop_scratch = [&]() {
         for (void* p : scratch) pool_release(ctx, p);  // stream-ordered: reusable by later work only
     };
@@ -326,7 +371,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         }
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
-    {
+    if (!c->early_leaves) {
         const int32_t st = make_cols(ctx, c, tallest, &cols, &tw, scratch);
         if (st != LURKHIP_OK) {
             drop_scratch();
@@ -336,11 +381,13 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     span_begin(ctx, "merkle_leaves", span_level);
     if (fused) {
         SpongeGroups g{};
-        g.cols[0] = cols;
-        g.total_w[0] = tw;
-        g.n_rows[0] = n_leaves;
-        g.out[0] = c->digests;
-        g.n = 1;
+        if (!c->early_leaves) {
+            g.cols[0] = cols;
+            g.total_w[0] = tw;
+            g.n_rows[0] = n_leaves;
+            g.out[0] = c->digests;
+            g.n = 1;
+        }
         int32_t st = LURKHIP_OK;
         for (int l = 1; l <= c->log_max && st == LURKHIP_OK; l++) {
             if (!inj_digests[l]) continue;
@@ -356,7 +403,10 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             g.out[g.n] = inj_digests[l];
             g.n++;
         }
-        if (st == LURKHIP_OK) st = merkle_row_sponges(ctx, params, g);
+        if (st == LURKHIP_OK && g.n) st = merkle_row_sponges(ctx, params, g);
+        if (st == LURKHIP_OK && c->early_leaves && hipStreamWaitEvent(ctx->stream, ctx->hash_done, 0) != hipSuccess)
+            st = set_error(ctx, LURKHIP_ERR_HIP, "joining the hash stream failed");
+        c->early_leaves = false;
         if (st != LURKHIP_OK) {
             drop_scratch();
             return st;
@@ -539,7 +589,29 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         // device-resident matrices of one shape go through the passes together
         std::map<std::pair<uint32_t, uint32_t>, std::vector<int>> shapes;
         for (int i = 0; i < n_mats; i++) shapes[{log_heights[i], widths[i]}].push_back(i);
-        for (const auto& kv : shapes) {
+        // tallest first: the leaf sponge of the tallest height group can then start (on the hash stream) while the shorter
+        // groups' passes are still running (early_leaves; LURKHIP_EARLY_LEAVES=1)
+        uint32_t max_log = 0;
+        size_t n_heights = 0;
+        {
+            std::vector<uint32_t> hs;
+            for (const auto& kv : shapes) hs.push_back(kv.first.first);
+            hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
+            n_heights = hs.size();
+            max_log = hs.empty() ? 0 : hs.back();
+        }
+        static const bool early_on = getenv("LURKHIP_EARLY_LEAVES") != nullptr && atoi(getenv("LURKHIP_EARLY_LEAVES")) != 0 &&
+                                     (getenv("LURKHIP_MERKLE_FUSED") == nullptr || atoi(getenv("LURKHIP_MERKLE_FUSED")) != 0);
+        const bool early = early_on && lane.active && n_heights >= 2 && max_log >= SIDE_MAX_LOG_N &&
+                           (((size_t)1 << (max_log + log_blowup)) > MERKLE_COOP_MAX_PARENTS);
+        bool early_marked = false;
+        for (auto it = shapes.rbegin(); it != shapes.rend(); ++it) {
+            const auto& kv = *it;
+            if (early && !early_marked && kv.first.first != max_log) {  // every matrix of the tallest height is queued: mark it
+                TRY_C(hash_stream_of(ctx));
+                HIP_C(hipEventRecord(ctx->hash_ready, ctx->stream));
+                early_marked = true;
+            }
             const auto on_side = lane.on_side(kv.first.first < SIDE_MAX_LOG_N);
             const std::vector<int>& idx = kv.second;
             for (size_t at = 0; at < idx.size(); at += NTT_MAX_BATCH) {
@@ -560,6 +632,12 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                 if (done)
                     for (int m = 0; m < nb; m++) extended[idx[at + m]] = 1;
             }
+        }
+        if (early_marked) {
+            bool all_tall_extended = true;
+            for (int i = 0; i < n_mats; i++)
+                if (log_heights[i] == max_log && !extended[i]) all_tall_extended = false;
+            if (all_tall_extended) TRY_C(early_leaves(ctx, c));
         }
     }
     for (int i = 0; i < n_mats; i++) {

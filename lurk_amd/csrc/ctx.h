@@ -50,6 +50,8 @@ struct lurkhip_ctx {
     int inject_alloc_failures = 0;
     // Fork / join inside one proof (lurkhip::SideLane): a second stream of the context for the short chips' launches.  While a
     // lane is open every pool_release is deferred to the join, so no block is handed out again while either stream may still use it.
+    hipStream_t hash_stream = nullptr;  // commit.hip: early_leaves (a stream measured to run beside the context's own)
+    hipEvent_t hash_ready = nullptr, hash_done = nullptr;
     static constexpr int N_SIDE = 4;
     hipStream_t side_stream[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
     hipEvent_t side_fork = nullptr, side_join[N_SIDE] = {nullptr, nullptr, nullptr, nullptr};
@@ -123,6 +125,8 @@ struct SideLane {
     int want = lurkhip_ctx::N_SIDE;
     Guard on_side(bool on, uint32_t key = 0) { return Guard(ctx, on && active, key % (uint32_t)lanes); }
 };
+// the context's hash stream (created at first use, measured to run beside the context's own stream) with its two events
+int32_t hash_stream_of(lurkhip_ctx* ctx);
 // span timing (no-ops unless profiling is enabled)
 // `level`: 1 = stage span (recorded whenever profiling is on), 2 = detail span (per chip, per small tree: only at profile level 2 --
 // every event record is a marker packet the next kernel waits behind, a few hundred of them cost a millisecond per proof)

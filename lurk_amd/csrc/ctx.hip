@@ -127,6 +127,7 @@ int32_t pool_alloc(lurkhip_ctx* ctx, size_t bytes, void** out) {
         (void)hipStreamSynchronize(ctx->stream);
         for (hipStream_t ss : ctx->side_stream)
             if (ss) (void)hipStreamSynchronize(ss);
+        if (ctx->hash_stream) (void)hipStreamSynchronize(ctx->hash_stream);
         for (auto& kv : ctx->pool_free) (void)hipFree(kv.second);
         ctx->pool_free.clear();
         ctx->pool_cached_bytes = 0;
@@ -210,6 +211,15 @@ double occupy_alone(hipStream_t ref, uint64_t ticks) {
 }
 constexpr uint64_t PLACE_TICKS = 50000;  // 0.5 ms of the 100 MHz wall clock
 }  // namespace
+
+int32_t hash_stream_of(lurkhip_ctx* ctx) {
+    if (ctx->hash_stream) return LURKHIP_OK;
+    ctx->hash_stream = stream_beside(ctx->stream, ctx->stream_priority, PLACE_TICKS, occupy_alone(ctx->stream, PLACE_TICKS));
+    if (!ctx->hash_stream) return set_error(ctx, LURKHIP_ERR_HIP, "no hash stream could be created");
+    LH_HIP(ctx, hipEventCreateWithFlags(&ctx->hash_ready, hipEventDisableTiming));
+    LH_HIP(ctx, hipEventCreateWithFlags(&ctx->hash_done, hipEventDisableTiming));
+    return LURKHIP_OK;
+}
 
 int32_t SideLane::open() {
     static const bool enabled = getenv("LURKHIP_SIDE_LANE") == nullptr || atoi(getenv("LURKHIP_SIDE_LANE")) != 0;
@@ -442,6 +452,12 @@ int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx) {
             (void)hipEventDestroy(ctx->side_join[k]);
         }
     if (ctx->side_fork) (void)hipEventDestroy(ctx->side_fork);
+    if (ctx->hash_stream) {
+        (void)hipStreamSynchronize(ctx->hash_stream);
+        (void)hipStreamDestroy(ctx->hash_stream);
+        (void)hipEventDestroy(ctx->hash_ready);
+        (void)hipEventDestroy(ctx->hash_done);
+    }
     if (ctx->owns_stream && ctx->stream) (void)hipStreamDestroy(ctx->stream);
     delete ctx;
     return LURKHIP_OK;
