@@ -11,6 +11,7 @@
 
 #include "babybear.h"
 #include "commit.h"
+#include "lde.h"
 
 namespace lurkhip {
 
@@ -549,8 +550,10 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     c->coeffs.assign(n_mats, nullptr);
     c->log_h.resize(n_mats);
     c->width.assign(widths, widths + n_mats);
+    std::vector<void*> uploads;  // host inputs staged in pooled device buffers (released, stream-ordered, once the LDEs are queued)
     auto fail = [&](int32_t s) {
         (void)stream_wait(ctx);
+        for (void* u : uploads) pool_release(ctx, u);
         free_commitment(ctx, c);
         return s;
     };
@@ -568,12 +571,91 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     } while (0)
 
     span_begin(ctx, "lde");  // one span for the matrices of the commitment (with host inputs it includes their uploads)
+    // Host inputs of an extending commitment are uploaded whole and then take the device route (round 4): one code path for the
+    // LDE, and the caller's matrices of one height share tiles like the prover's do.
+    std::vector<const uint32_t*> uploaded_mats;
+    if (mats_on_host && !raw && log_blowup == 1 && !keep_coeffs && lde_group_enabled()) {
+        uploaded_mats.resize(n_mats);
+        for (int i = 0; i < n_mats; i++) {
+            const size_t bytes = ((size_t)widths[i] << log_heights[i]) * sizeof(uint32_t);
+            void* d = nullptr;
+            TRY_C(pool_alloc(ctx, bytes, &d));
+            uploads.push_back(d);
+            HIP_C(hipMemcpyAsync(d, mats[i], bytes, hipMemcpyHostToDevice, ctx->stream));
+            uploaded_mats[i] = (const uint32_t*)d;
+        }
+        mats = uploaded_mats.data();
+        mats_on_host = false;
+    }
     std::vector<char> extended(n_mats, 0);
     std::vector<size_t> coef_words(n_mats, 0);
+    // Round 4: device-resident matrices of one height go through the grouped LDE (lde.hip) as ONE virtual row -- blow-up 2, nobody
+    // keeping coefficients, 2^5 .. 2^20 rows.  A group holds up to LDE_MAX_MATS matrices of up to LDE_MAX_CLASSES coset shifts
+    // (the quotient chunks of a height: shift w_Q^-c for chunk c), filled in shift order; tallest heights first.
+    struct GroupPlan {
+        int log_n;
+        std::vector<int> idx;
+        std::vector<uint32_t> cls, shift_m;
+        const uint32_t* scale[2][LDE_MAX_CLASSES];
+    };
+    std::vector<GroupPlan> groups;
+    std::vector<char> grouped(n_mats, 0);
+    if (!mats_on_host && !raw && log_blowup == 1 && !keep_coeffs) {
+        std::map<uint32_t, std::vector<int>> by_height;
+        for (int i = 0; i < n_mats; i++)
+            if (lde_group_takes((int)log_heights[i])) by_height[log_heights[i]].push_back(i);
+        for (auto it = by_height.rbegin(); it != by_height.rend(); ++it) {
+            auto shift_of = [&](int i) { return bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN); };
+            std::vector<uint32_t> order;  // shifts in order of first appearance
+            for (int i : it->second)
+                if (std::find(order.begin(), order.end(), shift_of(i)) == order.end()) order.push_back(shift_of(i));
+            std::vector<int> sorted;
+            for (uint32_t sh : order)
+                for (int i : it->second)
+                    if (shift_of(i) == sh) sorted.push_back(i);
+            GroupPlan g{};
+            g.log_n = (int)it->first;
+            auto flush = [&]() {
+                if (!g.idx.empty()) groups.push_back(g);
+                g.idx.clear();
+                g.cls.clear();
+                g.shift_m.clear();
+            };
+            for (int i : sorted) {
+                const uint32_t sh = shift_of(i);
+                size_t cl = std::find(g.shift_m.begin(), g.shift_m.end(), sh) - g.shift_m.begin();
+                if (g.idx.size() == (size_t)LDE_MAX_MATS || (cl == g.shift_m.size() && cl == (size_t)LDE_MAX_CLASSES)) {
+                    flush();
+                    cl = 0;
+                }
+                if (cl == g.shift_m.size()) g.shift_m.push_back(sh);
+                g.idx.push_back(i);
+                g.cls.push_back((uint32_t)cl);
+            }
+            flush();
+        }
+        // the groups' coset tables (cached per context); a group whose tables do not fit the cache keeps the old route
+        std::vector<GroupPlan> kept;
+        for (GroupPlan& g : groups) {
+            const uint32_t w_big = two_adic_generator_monty(g.log_n + 1);
+            bool ok = true;
+            for (int q = 0; q < 2 && ok; q++)
+                for (size_t cl = 0; cl < g.shift_m.size() && ok; cl++) {
+                    const uint32_t s_q = q ? bb::mul(g.shift_m[cl], w_big) : g.shift_m[cl];
+                    TRY_C(cached_scale_table(ctx, g.log_n, s_q, &g.scale[q][cl]));
+                    ok = g.scale[q][cl] != nullptr;
+                }
+            if (!ok) continue;
+            for (int i : g.idx) grouped[i] = 1;
+            kept.push_back(g);
+        }
+        groups.swap(kept);
+    }
     for (int i = 0; i < n_mats; i++) {
         const size_t bytes = ((size_t)widths[i] << log_heights[i]) * sizeof(uint32_t);
         c->log_h[i] = (int)log_heights[i] + log_blowup;
         TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
+        if (grouped[i]) continue;  // no coefficient buffer: the grouped LDE never writes coefficients
         // coefficient buffer: room for the chunk-tiled form when nobody asked to keep (row-major) coefficients
         coef_words[i] = (!keep_coeffs && !mats_on_host && !raw && log_blowup >= 1) ? ntt_tiled_words((int)log_heights[i], (int)widths[i]) : 0;
         TRY_C(pool_alloc(ctx, std::max(bytes, coef_words[i] * 4), (void**)&c->coeffs[i]));
@@ -585,10 +667,24 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     lane.want = 1;  // one side stream: the short matrices' passes share the coset-table scratch in order
     constexpr uint32_t SIDE_MAX_LOG_N = 13;
     if (!mats_on_host && log_blowup >= 1 && ctx->lde_scale_bytes + ((size_t)64 << 20) < ((size_t)1 << 30)) TRY_C(lane.open());
+    for (const GroupPlan& g : groups) {
+        const auto on_side = lane.on_side((uint32_t)g.log_n < SIDE_MAX_LOG_N);
+        const uint32_t* ev[LDE_MAX_MATS];
+        uint32_t* ld[LDE_MAX_MATS];
+        uint32_t gw[LDE_MAX_MATS];
+        for (size_t m = 0; m < g.idx.size(); m++) {
+            ev[m] = mats[g.idx[m]];
+            ld[m] = c->lde[g.idx[m]];
+            gw[m] = widths[g.idx[m]];
+        }
+        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false));
+        for (int i : g.idx) extended[i] = 1;
+    }
     if (!mats_on_host && log_blowup >= 1) {
         // device-resident matrices of one shape go through the passes together
         std::map<std::pair<uint32_t, uint32_t>, std::vector<int>> shapes;
-        for (int i = 0; i < n_mats; i++) shapes[{log_heights[i], widths[i]}].push_back(i);
+        for (int i = 0; i < n_mats; i++)
+            if (!grouped[i]) shapes[{log_heights[i], widths[i]}].push_back(i);
         // tallest first: the leaf sponge of the tallest height group can then start (on the hash stream) while the shorter
         // groups' passes are still running (early_leaves; LURKHIP_EARLY_LEAVES=1)
         uint32_t max_log = 0;
@@ -683,6 +779,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         }
     }
     TRY_C(lane.close());
+    for (void* u : uploads) pool_release(ctx, u);
+    uploads.clear();
     span_end(ctx, "lde");
     TRY_C(build_tree(ctx, c));
     if (root) {
@@ -713,6 +811,16 @@ int32_t lurkhip_coset_lde_dev(lurkhip_ctx* ctx, int32_t log_n, int32_t width, in
     LH_HIP(ctx, hipSetDevice(ctx->device));
     const size_t n = (size_t)1 << log_n;
     const size_t bytes = n * width * sizeof(uint32_t);
+    if (log_blowup == 1 && lde_group_takes(log_n)) {  // the grouped route (lde.hip) on a group of one
+        const uint32_t gen_m = bb::to_monty(bb::GEN);
+        const uint32_t* scale[2][LDE_MAX_CLASSES] = {};
+        LH_TRY(cached_scale_table(ctx, log_n, gen_m, &scale[0][0]));
+        LH_TRY(cached_scale_table(ctx, log_n, bb::mul(gen_m, two_adic_generator_monty(log_n + 1)), &scale[1][0]));
+        if (scale[0][0] && scale[1][0]) {
+            const uint32_t w = (uint32_t)width, cls = 0;
+            return lde_group(ctx, log_n, 1, &in, &w, &out, &cls, 1, scale, repr == LURKHIP_REPR_CANONICAL, repr == LURKHIP_REPR_CANONICAL);
+        }
+    }
     void *coef = nullptr, *scratch = nullptr, *row_scale = nullptr;
     LH_TRY(arena_get(ctx, 1, bytes, &coef));
     LH_TRY(arena_get(ctx, 3, bytes, &scratch));

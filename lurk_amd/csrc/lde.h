@@ -1,0 +1,23 @@
+// Coset LDE of a height group of device-resident matrices (lde.hip).
+#pragma once
+#include <stdint.h>
+
+#include "ctx.h"
+
+namespace lurkhip {
+
+constexpr int LDE_MAX_MATS = 16;    // matrices of one launch group (one virtual row)
+constexpr int LDE_MAX_CLASSES = 2;  // distinct coset shifts inside a group (the quotient chunks of one height)
+constexpr int LDE_GROUP_MIN_LOG_N = 5, LDE_GROUP_MAX_LOG_N = 20;
+
+// heights lde_group takes (LURKHIP_LDE_V2=0 turns the route off: every matrix goes through ntt.hip's transforms)
+bool lde_group_takes(int log_n);
+// Blow-up 2: ldes[m] (2N x widths[m]) <- evaluations of matrix m's column polynomials on shift_m * <w_2N>, rows in bit-reversed
+// order (block q = coset q).  cls[m] < n_cls is the matrix's shift class, scales[q][cls] the table (shift_cls * w_2N^q)^k / N,
+// k < N (commit.hip: cached_scale_table).  in_canonical / out_canonical: the caller's words are canonical (converted on the first load /
+// last store); between the kernels everything is Montgomery.  Everything on ctx->stream; scratch comes from the context's pool.
+bool lde_group_enabled();
+int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
+                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical);
+
+}  // namespace lurkhip
