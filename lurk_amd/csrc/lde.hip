@@ -53,10 +53,12 @@ struct LdeArgs {
     uint32_t* A;                        // inverse first pass -> fused pass: [slabs][N][32]
     uint32_t* B;                        // fused pass -> forward last pass: [2 cosets][slabs][N][32]
     uint32_t n_mats, W, n_cls, slabs;
+    uint32_t col_base;                  // host side: first virtual column of the launches (a slab batch)
     int log_n, r1, r2;
     int col0, n_chunks;                 // this launch: chunks of (1 << LOG_C) virtual columns from col0 on
     uint32_t n_tiles, xcd_run;
     int in_canonical, out_canonical;    // convert the caller's words on the first load / the last store
+    int stagger;                        // s_sleep(127) rounds the second half of the grid waits before its first tile (A/B hook)
 };
 
 template <int LOG_R>
@@ -192,18 +194,42 @@ struct ColRef {
     uint32_t cls;
     bool valid;
 };
-__device__ __forceinline__ ColRef locate_col(const LdeArgs& a, uint32_t vc) {
+// The matrices' descriptors live in LDS: a lane finds its matrix by comparing its virtual column with the start columns (scalar
+// operands) and reads the entry with LDS loads.  (Read from the kernel-argument segment with a per-lane index they were vector
+// memory loads -- and a dependent vector load must wait for everything issued before it on the same in-order counter, i.e. for
+// the previous tile's stores to drain.)
+struct MatDesc {
+    const uint32_t* src;
+    uint32_t* dst;
+    uint32_t w, cls, start, pad;
+};
+constexpr int DESC_WORDS = LDE_MAX_MATS * (int)(sizeof(MatDesc) / 4);
+__device__ __forceinline__ void stage_descs(const LdeArgs& a, MatDesc* __restrict__ descs) {
+    if (threadIdx.x < LDE_MAX_MATS) {
+        const int m = (int)threadIdx.x;
+        MatDesc d;
+        d.src = a.src[m];
+        d.dst = a.dst[m];
+        d.w = a.width[m];
+        d.cls = a.cls[m];
+        d.start = a.start[m];
+        d.pad = 0;
+        descs[m] = d;
+    }
+}
+__device__ __forceinline__ ColRef locate_col(const LdeArgs& a, const MatDesc* __restrict__ descs, uint32_t vc) {
     uint32_t m = 0;
 #pragma unroll
     for (int i = 1; i < LDE_MAX_MATS; i++)
         if (vc >= a.start[i]) m = (uint32_t)i;  // start[i] = 2^32 - 1 past the last matrix
+    const MatDesc d = descs[m];
     ColRef r;
     r.valid = vc < a.W;
-    const uint32_t col = r.valid ? vc - a.start[m] : 0u;
-    r.src = a.src[m] + col;
-    r.dst = a.dst[m] + col;
-    r.w = a.width[m];
-    r.cls = a.cls[m];
+    const uint32_t col = r.valid ? vc - d.start : 0u;
+    r.src = d.src + col;
+    r.dst = d.dst + col;
+    r.w = d.w;
+    r.cls = d.cls;
     return r;
 }
 
@@ -212,6 +238,13 @@ __device__ __forceinline__ ColRef locate_col(const LdeArgs& a, uint32_t vc) {
 struct TileWalk {
     uint32_t first, step, count;
 };
+// Workgroups that share a CU start in lockstep and stay there (same tile, same phases): the second half of the grid -- the
+// second workgroup of every CU under round-robin dispatch -- may start a fraction of a tile late, so that one's memory
+// phases fall under the other's butterflies.
+__device__ __forceinline__ void stagger_start(const LdeArgs& a) {
+    if (a.stagger > 0 && blockIdx.x >= (gridDim.x >> 1))
+        for (int i = 0; i < a.stagger; i++) __builtin_amdgcn_s_sleep(127);
+}
 __device__ __forceinline__ TileWalk tile_walk(const LdeArgs& a) {
     const uint32_t wg = a.xcd_run ? (blockIdx.x >> 3) : blockIdx.x;
     const uint32_t wgs = a.xcd_run ? (gridDim.x >> 3) : gridDim.x;
@@ -251,11 +284,15 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_in(Lde
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* tile = smem;
     uint32_t* twb = smem + tile_words<LOG_R, LOG_C>();  // two tables of R entries, used in turn
+    MatDesc* descs = reinterpret_cast<MatDesc*>(twb + 2 * G::R);
     const int tid = NT > THREADS ? (int)threadIdx.x % THREADS : (int)threadIdx.x;  // surplus threads of tiny tiles shadow real ones
     const int s = tid >> LOG_C, c = tid & (C - 1);
     const int r2 = a.r2;
     const TileWalk walk = tile_walk(a);
     if (walk.count == 0) return;
+    stagger_start(a);
+    stage_descs(a, descs);
+    __syncthreads();
 
     uint32_t x[G::U], y[G::U], tv[TWN];
     ColRef ref;
@@ -264,7 +301,7 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_in(Lde
         const uint32_t id = walk.first + it * walk.step;
         lo = id / (uint32_t)a.n_chunks;
         vc = (uint32_t)a.col0 + (id - lo * (uint32_t)a.n_chunks) * C + (uint32_t)c;
-        ref = locate_col(a, vc);
+        ref = locate_col(a, descs, vc);
         if (ref.valid) walk_load<G::U>(x, ref.src + (((size_t)s << r2) | lo) * ref.w, ((size_t)G::S << r2) * ref.w);
         else zero_rows<G::U>(x);
 #pragma unroll
@@ -291,14 +328,14 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_in(Lde
         group1<LOG_R>(x, tw + s);
         if constexpr (G::LOG_S > 0) {
             tile_write<LOG_R, LOG_C>(tile, s, c, x);
-            if (it + 1 < walk.count) fetch(it + 1);
+            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
             __syncthreads();
             tile_read<LOG_R, LOG_C>(tile, s, c, y);
             group2<LOG_R, false>(y, tw);
         } else {
 #pragma unroll
             for (int j = 0; j < G::U; j++) y[j] = x[j];
-            if (it + 1 < walk.count) fetch(it + 1);
+            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
         }
         walk_store<G::U>(y, a.A + out_off + (((((size_t)(G::U * s)) << r2) | cur_lo) << SLAB_LOG_W), (size_t)1 << (r2 + SLAB_LOG_W));
     }
@@ -314,12 +351,16 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* tile = smem;
     uint32_t* tw = smem + tile_words<LOG_R, LOG_C>();
+    MatDesc* descs = reinterpret_cast<MatDesc*>(tw + G::R);
     const int tid = NT > THREADS ? (int)threadIdx.x % THREADS : (int)threadIdx.x;
     const int s = tid >> LOG_C, c = tid & (C - 1);
     const int r2 = a.r2;
     const TileWalk walk = tile_walk(a);
     if (walk.count == 0) return;
+    stagger_start(a);
+    stage_descs(a, descs);
     for (int idx = (int)threadIdx.x; idx < G::R; idx += NT) tw[idx] = tile_twiddle(a.tw_fwd, idx, a.log_n, 0, 0u);
+    __syncthreads();
 
     uint32_t x[G::U], y[G::U];
     uint32_t q = 0, hi = 0, vc = 0;
@@ -334,20 +375,20 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
     };
     fetch(0);
     for (uint32_t it = 0; it < walk.count; it++) {
-        const ColRef ref = locate_col(a, vc);
+        const ColRef ref = locate_col(a, descs, vc);
         const size_t row0 = ((size_t)q << a.log_n) | ((size_t)hi << LOG_R);
         __syncthreads();  // (first tile: the table is complete) every thread has left the previous tile
         group1<LOG_R>(x, tw + s);
         if constexpr (G::LOG_S > 0) {
             tile_write<LOG_R, LOG_C>(tile, s, c, x);
-            if (it + 1 < walk.count) fetch(it + 1);
+            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
             __syncthreads();
             tile_read<LOG_R, LOG_C>(tile, s, c, y);
             group2<LOG_R, true>(y, tw);
         } else {
 #pragma unroll
             for (int j = 0; j < G::U; j++) y[j] = x[j];
-            if (it + 1 < walk.count) fetch(it + 1);
+            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
         }
         if (a.out_canonical) {
 #pragma unroll
@@ -371,7 +412,8 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
     constexpr int TWN = (G::R + NT - 1) / NT;
     extern __shared__ __attribute__((aligned(16))) uint32_t smem[];
     uint32_t* tile = smem;
-    uint32_t* twi = smem + tile_words<LOG_R, LOG_C>();  // inverse twiddles of the pass (every tile)
+    MatDesc* descs = reinterpret_cast<MatDesc*>(smem + tile_words<LOG_R, LOG_C>());
+    uint32_t* twi = smem + tile_words<LOG_R, LOG_C>() + DESC_WORDS;  // inverse twiddles of the pass (every tile)
     uint32_t* twf = twi + G::R;                         // forward twiddles of the tile
     uint32_t* scl = twf + G::R;                         // [class][R]: the current coset's scales of the tile's rows
     const int tid = NT > THREADS ? (int)threadIdx.x % THREADS : (int)threadIdx.x;
@@ -380,7 +422,10 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
     const int r1 = DIRECT ? 0 : a.r1;
     const TileWalk walk = tile_walk(a);
     if (walk.count == 0) return;
+    stagger_start(a);
+    stage_descs(a, descs);
     for (int idx = (int)threadIdx.x; idx < G::R; idx += NT) twi[idx] = tile_twiddle(a.tw_inv, idx, a.log_n, 0, 0u);
+    __syncthreads();
 
     uint32_t x[G::U], coef[G::U], tfv[TWN], scv[2][LDE_MAX_CLASSES][TWN];
     ColRef ref;
@@ -389,7 +434,7 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
         const uint32_t id = walk.first + it * walk.step;
         lo2 = id / (uint32_t)a.n_chunks;
         vc = (uint32_t)a.col0 + (id - lo2 * (uint32_t)a.n_chunks) * C + (uint32_t)c;
-        ref = locate_col(a, vc);
+        ref = locate_col(a, descs, vc);
         if constexpr (DIRECT) {
             if (ref.valid) walk_load<G::U>(x, ref.src + (size_t)s * ref.w, (size_t)G::S * ref.w);
             else zero_rows<G::U>(x);
@@ -453,6 +498,10 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
             }
             group1<LOG_R>(x, twf + s2);
             uint32_t z[G::U];
+            if constexpr (G::LOG_S == 0) {  // no second group: the results leave x before the next tile's rows are requested into it
+#pragma unroll
+                for (int j = 0; j < G::U; j++) z[j] = x[j];
+            }
             if constexpr (G::LOG_S > 0) {
                 __syncthreads();  // B2 / B4: every thread has read the tile (and this coset's scales)
                 tile_write<LOG_R, LOG_C>(tile, s2, c, x);
@@ -468,8 +517,8 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
                             if ((uint32_t)cl < a.n_cls) scl[cl * G::R + idx] = scv[1][cl][i];
                     }
                 }
-            } else if (it + 1 < walk.count) {
-                fetch(it + 1);  // x is free: the next tile's rows fly under this coset's second stage group and its stores
+            } else {
+                fetch(it + 1 < walk.count ? it + 1 : it);  // x is free: the next tile's rows fly under this coset's second stage group and its stores
             }
             if constexpr (G::LOG_S > 0) {
                 __syncthreads();  // B3 / B5
@@ -477,8 +526,6 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
                 group2<LOG_R, false>(z, twf);
             } else {
                 if (q == 0) __syncthreads();  // coset 1's scales are complete
-#pragma unroll
-                for (int j = 0; j < G::U; j++) z[j] = x[j];
             }
             if constexpr (DIRECT) {
                 if (a.out_canonical) {
@@ -502,11 +549,11 @@ void opt_in_lds(K kern, size_t lds) {
 constexpr size_t LDS_PER_CU = 160 * 1024;
 
 template <int LOG_R, int LOG_C>
-size_t lds_in() { return ((size_t)tile_words<LOG_R, LOG_C>() + 2u * Geo<LOG_R>::R) * 4; }
+size_t lds_in() { return ((size_t)tile_words<LOG_R, LOG_C>() + 2u * Geo<LOG_R>::R + DESC_WORDS) * 4; }
 template <int LOG_R, int LOG_C>
-size_t lds_out() { return ((size_t)tile_words<LOG_R, LOG_C>() + Geo<LOG_R>::R) * 4; }
+size_t lds_out() { return ((size_t)tile_words<LOG_R, LOG_C>() + Geo<LOG_R>::R + DESC_WORDS) * 4; }
 template <int LOG_R, int LOG_C>
-size_t lds_mid(uint32_t n_cls) { return ((size_t)tile_words<LOG_R, LOG_C>() + (2u + n_cls) * Geo<LOG_R>::R) * 4; }
+size_t lds_mid(uint32_t n_cls) { return ((size_t)tile_words<LOG_R, LOG_C>() + (2u + n_cls) * Geo<LOG_R>::R + DESC_WORDS) * 4; }
 
 // grid of a persistent launch: as many workgroups as stay resident (LDS, 16 waves per CU at 128 VGPRs), a multiple of 8 when
 // the tile order is XCD-contiguous
@@ -516,6 +563,8 @@ void size_grid(lurkhip_ctx* ctx, LdeArgs& a, size_t tiles, int threads, size_t l
     const int per_cu = (int)std::max<size_t>(1, std::min<size_t>(1024 / (size_t)threads, LDS_PER_CU / (lds + 128)));
     size_t b = std::min<size_t>(tiles, (size_t)per_cu * (size_t)ctx->num_cus);
     if (a.xcd_run) b = std::max<size_t>(8, b / 8 * 8);
+    static const int stagger = getenv("LURKHIP_LDE_STAGGER") ? atoi(getenv("LURKHIP_LDE_STAGGER")) : 0;
+    a.stagger = (per_cu >= 2 && b >= (size_t)2 * ctx->num_cus) ? stagger : 0;
     *blocks = (unsigned)b;
 }
 
@@ -588,15 +637,16 @@ int32_t launch_c(lurkhip_ctx* ctx, Kind kind, int log_r, LdeArgs& a, size_t tile
 // rest (16 columns when it fits, else a partly idle 32-column tile).  tiles_per_chunk = row tiles (times cosets for k_out).
 int32_t launch_cols(lurkhip_ctx* ctx, Kind kind, int log_r, LdeArgs a, size_t tiles_per_chunk, int log_c_full) {
     const uint32_t cw = 1u << log_c_full;
-    const uint32_t n_full = a.W / cw, rest = a.W % cw;
+    const uint32_t span = a.W - a.col_base;  // virtual columns [col_base, W): col_base is a multiple of the slab width
+    const uint32_t n_full = span / cw, rest = span % cw;
     if (n_full) {
-        a.col0 = 0;
+        a.col0 = (int)a.col_base;
         a.n_chunks = (int)n_full;
         if (log_c_full == 5) LH_TRY(launch_c<5>(ctx, kind, log_r, a, tiles_per_chunk * n_full));
         else LH_TRY(launch_c<4>(ctx, kind, log_r, a, tiles_per_chunk * n_full));
     }
     if (rest) {
-        a.col0 = (int)(n_full * cw);
+        a.col0 = (int)(a.col_base + n_full * cw);
         a.n_chunks = 1;
         if (rest <= 16) LH_TRY(launch_c<4>(ctx, kind, log_r, a, tiles_per_chunk));
         else LH_TRY(launch_c<5>(ctx, kind, log_r, a, tiles_per_chunk));
@@ -659,10 +709,23 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     }
     a.A = (uint32_t*)A;
     a.B = (uint32_t*)B;
-    st = launch_cols(ctx, K_IN, a.r1, a, (size_t)1 << a.r2, 5);
-    // the fused pass keeps two workgroups on a CU: 2^10-row tiles are 16 columns wide
-    if (st == LURKHIP_OK) st = launch_cols(ctx, K_MID, a.r2, a, (size_t)1 << a.r1, a.r2 >= 10 ? 4 : 5);
-    if (st == LURKHIP_OK) st = launch_cols(ctx, K_OUT, a.r1, a, (size_t)2 << a.r2, 5);
+    // first / last pass: LURKHIP_LDE_IO_LOG_C = 4 gives 2^10-row tiles 16 columns (two workgroups per CU) -- A/B hook
+    static const int io_log_c = getenv("LURKHIP_LDE_IO_LOG_C") ? std::max(4, std::min(5, atoi(getenv("LURKHIP_LDE_IO_LOG_C")))) : 5;
+    const int io_c = a.r1 >= 10 ? io_log_c : 5;
+    // LURKHIP_LDE_SLAB_BATCH = k (A/B hook): the three kernels run over k slabs at a time, so that a batch's intermediates
+    // (3 k N 128 bytes) may stay in the 256 MiB Infinity Cache between the kernel that writes them and the one that reads them
+    static const int slab_batch = getenv("LURKHIP_LDE_SLAB_BATCH") ? atoi(getenv("LURKHIP_LDE_SLAB_BATCH")) : 0;
+    const uint32_t W_all = a.W;
+    const uint32_t step = slab_batch > 0 ? (uint32_t)slab_batch << SLAB_LOG_W : W_all;
+    for (uint32_t c0 = 0; c0 < W_all && st == LURKHIP_OK; c0 += step) {
+        LdeArgs b = a;
+        b.col_base = c0;
+        b.W = std::min(W_all, c0 + step);
+        st = launch_cols(ctx, K_IN, a.r1, b, (size_t)1 << a.r2, io_c);
+        // the fused pass keeps two workgroups on a CU: 2^10-row tiles are 16 columns wide
+        if (st == LURKHIP_OK) st = launch_cols(ctx, K_MID, a.r2, b, (size_t)1 << a.r1, a.r2 >= 10 ? 4 : 5);
+        if (st == LURKHIP_OK) st = launch_cols(ctx, K_OUT, a.r1, b, (size_t)2 << a.r2, io_c);
+    }
     pool_release(ctx, A);  // stream-ordered
     pool_release(ctx, B);
     return st;

@@ -15,6 +15,7 @@
 #include <map>
 #include <stdexcept>
 #include <string>
+#include <system_error>
 #include <thread>
 #include <vector>
 
@@ -139,7 +140,7 @@ VProof parse(const uint32_t* words, uint64_t n_words) {
     for (VChip& ch : p.chips) {
         ch.machine_index = c.u(), ch.log_n = c.u(), ch.width = c.u(), ch.prep_width = c.u(), ch.perm_width = c.u(), ch.qd = c.u();
         ch.prep_index = (int)c.u() - 1;
-        NEED(ch.log_n <= 32 && ch.width <= (1u << 20) && ch.prep_width <= (1u << 20) && ch.perm_width <= (1u << 20) && ch.perm_width % 4 == 0 &&
+        NEED(ch.log_n + p.log_blowup <= (uint32_t)bb::TWO_ADICITY && ch.width <= (1u << 20) && ch.prep_width <= (1u << 20) && ch.perm_width <= (1u << 20) && ch.perm_width % 4 == 0 &&
                  ch.perm_width >= 4 && ch.qd >= 1 && ch.qd <= 16 && (ch.qd & (ch.qd - 1)) == 0 && ch.prep_index < (int)p.n_prep,
              "implausible chip header");
         ch.cumsum = c.e();
@@ -275,7 +276,7 @@ void pcs_verify(const lurkhip_protocol_profile& prof, const Hasher& H, const std
     ch.observe_ef_m(p.final_poly);
     NEED(ch.check_witness((int)p.pow_bits, p.pow_witness), "invalid proof-of-work witness");
     const uint32_t log_max = p.n_layers + p.log_blowup;
-    NEED(log_max == p.log_max && log_max <= 31, "log_max_height");
+    NEED(log_max == p.log_max && log_max <= (uint32_t)bb::TWO_ADICITY, "log_max_height");  // BabyBear has no larger two-adic subgroup
     NEED(rounds.size() == p.rounds.size(), "number of opening rounds");
     for (uint32_t qi = 0; qi < p.nq; qi++) {
         const uint32_t index = ch.sample_bits((int)log_max);
@@ -323,6 +324,12 @@ void pcs_verify(const lurkhip_protocol_profile& prof, const Hasher& H, const std
                 }
             }
         }
+        // A matrix of height 2^log_blowup (a one-row trace: the entrypoint chip, always) is never folded into the FRI chain below,
+        // which starts at height 2^(log_blowup + 1): its polynomial is a constant, so every quotient (p(x) - p(z)) / (x - z) of an
+        // honest opening is zero -- and must be checked to be, or the opened values of such a chip are bound to nothing (the
+        // later p3 fix of verify_query)
+        for (const auto& kv : ro)
+            NEED(kv.first > p.log_blowup || bb::ef_is_zero(kv.second), "query %u: the reduced opening at height 2^%u is not zero", qi, kv.first);
         // ---- p3_fri verify_query
         ef folded = bb::ef_zero();
         uint32_t idx = index;
@@ -649,7 +656,7 @@ VProof decode_shard(Bytes& b, const lurkhip_air* const* airs, uint32_t n_airs, c
         p.n_chunks += c.qd;
         c.cumsum = b.e();
         const uint64_t lg = b.u64();
-        NEED(lg <= 32, "log_degree");
+        NEED(lg <= (uint64_t)bb::TWO_ADICITY, "log_degree");
         c.log_n = (uint32_t)lg;
         c.prep_index = -1;
     }
@@ -778,10 +785,14 @@ int32_t verify_parsed(const lurkhip_protocol_profile& prof, const lurkhip_air* c
     } else {
         std::atomic<size_t> next{0};
         std::vector<std::thread> pool;
-        for (unsigned t = 0; t < threads; t++)
-            pool.emplace_back([&]() {
-                for (size_t s = next.fetch_add(1); s < n; s = next.fetch_add(1)) one(s);
-            });
+        auto work = [&]() {
+            for (size_t s = next.fetch_add(1); s < n; s = next.fetch_add(1)) one(s);
+        };
+        try {
+            for (unsigned t = 0; t + 1 < threads; t++) pool.emplace_back(work);
+        } catch (const std::system_error&) {  // no more threads to be had: the ones that started and this one share the shards
+        }
+        work();
         for (auto& t : pool) t.join();
     }
     ef total = bb::ef_zero();

@@ -507,7 +507,7 @@ def pcs_verify(rounds, proof, log_blowup, challenger, merkle_verify):
     challenger.observe(list(proof.final_poly))
     _need(challenger.check_witness(proof.pow_bits, proof.pow_witness), "invalid proof-of-work witness")
     log_max = len(proof.fri_roots) + log_blowup
-    _need(log_max == proof.log_max_height, "log_max_height")
+    _need(log_max == proof.log_max_height and log_max <= 27, "log_max_height")
     indices = [challenger.sample_bits(log_max) for _ in range(proof.num_queries)]
     if proof.query_indices is not None:  # (the upstream proof format does not carry them: oracle/wire.py)
         _need(indices == proof.query_indices, "query indices differ from the transcript's")
@@ -539,6 +539,10 @@ def pcs_verify(rounds, proof, log_blowup, challenger, merkle_verify):
                         ap = alpha_pow.get(key, ONE)
                         ro[log_h] = ef_add(ro.get(log_h, ZERO), ef_mul(ap, quotient))
                         alpha_pow[key] = ef_mul(ap, alpha_fri)
+        # heights of 2^log_blowup rows (one-row traces) never enter the fold below: their reduced openings must be zero, or the
+        # opened values of such a chip are bound to nothing (the later p3 fix of verify_query)
+        for log_h, acc in ro.items():
+            _need(log_h > log_blowup or acc == ZERO, f"query {qi}: the reduced opening at height 2^{log_h} is not zero")
         # ---- fri verify_query
         folded = ZERO
         idx = index

@@ -125,6 +125,46 @@ def test_accepts_the_cpu_provers_proof_and_rejects_what_the_oracle_rejects(prove
         prover.verify_machine_proof(product_airs(PARTIAL_SRC, "top", len(pv)), vk, [16], [6], [words])
 
 
+def test_forged_openings_of_a_one_row_chip_are_rejected(proved):
+    """a chip proved at height 1 -- the entrypoint chip, always -- has LDE height 2^log_blowup, below the first
+    height the FRI query chain folds in, so its reduced openings were never checked: any opened values with a matching forged
+    quotient passed both verifiers (the default profile does not observe opened values into the transcript).  Forge exactly that --
+    garbage opened values of the entrypoint chip, quotient chosen so that constraints(zeta) / Z_H(zeta) == quotient(zeta) -- and
+    require both verifiers to reject it: the reduced opening at height 2^log_blowup must be zero."""
+    src, oairs, pv, shard, vk = proved
+    pairs = product_airs(src, "fib", len(pv))
+    bad = copy.deepcopy(shard)
+    k = next(i for i, c in enumerate(bad.chips) if c.log_n == 0)
+    chip = bad.chips[k]
+    # replay the transcript up to zeta (oracle/stark.py: verify_machine, verify_shard)
+    ch = os_.Challenger(os_.default_permute16(), None)
+    ch.observe(vk)
+    ch.observe(0)
+    ch.observe(bad.main_root)
+    ch.observe(bad.public_values)
+    perm_alpha, perm_beta = ch.sample_ext(), ch.sample_ext()
+    ch.observe(bad.perm_root)
+    alpha = ch.sample_ext()
+    ch.observe(bad.quot_root)
+    zeta = ch.sample_ext()
+    chip.opened["main"] = tuple([tuple((7 * j + 3 * e + side + 1) % P for e in range(4)) for j in range(chip.width)] for side in (0, 1))
+    sels = os_.selectors_at_point(zeta, 0)
+    folded = os_.eval_constraints_at(oairs[chip.machine_index], chip, sels, alpha, perm_alpha, perm_beta, bad.public_values)
+    target = os_.ef_mul(folded, sels[3])
+    # the recomputed quotient is affine in the first word of the first chunk: solve for it
+    zero4 = [os_.ZERO] * 4
+    chip.opened["quotient"] = [list(zero4) for _ in chip.opened["quotient"]]
+    t0 = os_.recompute_quotient(chip, zeta)
+    chip.opened["quotient"][0][0] = os_.ONE
+    t1 = os_.recompute_quotient(chip, zeta)
+    chip.opened["quotient"][0][0] = os_.ef_mul(os_.ef_sub(target, t0), os_.ef_inv(os_.ef_sub(t1, t0)))
+    assert os_.recompute_quotient(chip, zeta) == target  # the forgery passes the constraint check at zeta ...
+    with pytest.raises(os_.VerifyError, match="reduced opening"):  # ... and is caught by the opening argument alone
+        os_.verify_machine(oairs, vk, [16], [6], [bad], ob.merkle_verify)
+    with pytest.raises(prover.VerificationError, match="reduced opening"):
+        prover.verify_machine_proof(pairs, vk, [16], [6], [encode_words(bad)])
+
+
 def test_partial_machine_with_the_preprocessed_round(oracle):
     airs, names, pv, traces = machine(PARTIAL_SRC, "top", [9])
     pr = cpv.CpuProver(airs, names, len(pv), threads=4)
