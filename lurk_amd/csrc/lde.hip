@@ -41,6 +41,15 @@ namespace lurkhip {
 namespace {
 
 constexpr int SLAB_LOG_W = 5;  // columns per slab of the intermediate layout: one 128-byte line per row
+// 16-byte accesses through quad transposes (walk_load_x4 / walk_store_x4 below), measured and off: the tile kernels' memory time does
+// not depend on the access width (2^20 x 64, butterflies skipped: k_out 218 us with dwords, 235 us with 16-byte pieces), only on the
+// ALIGNMENT of the row segments (pitch 78 words: 421 us) -- tools/ubench_tilemem.hip's 5.2 against 3.5 TB/s is a copy loop's gain.
+#ifndef LDE_SLAB_X4
+#define LDE_SLAB_X4 0  // k_in's stores and k_out's loads
+#endif
+#ifndef LDE_MID_X4
+#define LDE_MID_X4 0   // the fused pass's slab rows
+#endif
 
 struct LdeArgs {
     const uint32_t* src[LDE_MAX_MATS];  // N x width[m], row-major
@@ -59,6 +68,8 @@ struct LdeArgs {
     uint32_t n_tiles, xcd_run;
     int in_canonical, out_canonical;    // convert the caller's words on the first load / the last store
     int stagger;                        // s_sleep(127) rounds the second half of the grid waits before its first tile (A/B hook)
+    int x4;                             // 16-byte accesses on the matrices' side too (the slabs' side always has them)
+    int dbg;                            // measurement hook (LURKHIP_LDE_DBG): bit 0 = skip the butterflies (memory traffic and exchanges only)
 };
 
 template <int LOG_R>
@@ -98,40 +109,125 @@ __device__ __forceinline__ void bfly_1(uint32_t& x, uint32_t& y) {  // twiddle o
     x = sum;
 }
 
+// K butterflies in lockstep: every step of the dependent chain (difference, product, m = lo * p^-1, reduction, the two range
+// corrections) is issued for all K before the next step, so that a wave's consecutive instructions do not wait for one another
+// (tools/ubench_bfly.hip: 43 -> 37 cycles per wave-butterfly at four waves per SIMD).  UNIFORM: the twiddles are scalar registers.
+#ifndef LDE_BFLY_K
+#define LDE_BFLY_K 4
+#endif
+template <int K, bool UNIFORM>
+__device__ __forceinline__ void bfly_k(uint32_t* (&xs)[K], uint32_t* (&ys)[K], const uint32_t (&tw)[K]) {
+    int32_t d[K], m[K];
+    int64_t t[K];
+    uint32_t sum[K];
+#pragma unroll
+    for (int i = 0; i < K; i++) d[i] = (int32_t)(*xs[i] - *ys[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) t[i] = UNIFORM ? bb::mad_i64_u(d[i], (int32_t)tw[i], 0) : bb::mad_i64(d[i], (int32_t)tw[i], 0);
+#pragma unroll
+    for (int i = 0; i < K; i++) sum[i] = *xs[i] + *ys[i];
+#pragma unroll
+    for (int i = 0; i < K; i++) m[i] = (int32_t)((uint32_t)t[i] * bb::MU);
+#pragma unroll
+    for (int i = 0; i < K; i++) t[i] = bb::mad_i64(m[i], -(int32_t)bb::P, t[i]);
+#pragma unroll
+    for (int i = 0; i < K; i++) *xs[i] = bb::umin(sum[i], sum[i] - bb::P);
+#pragma unroll
+    for (int i = 0; i < K; i++) {
+        const uint32_t r = (uint32_t)(t[i] >> 32);
+        *ys[i] = bb::umin(r, r + bb::P);
+    }
+}
+
 // Stage group 1: register j of slot s is tile row s + S j; in-register bit g is tile-row bit LOG_S + g.  The butterfly of rows
 // (t, t + 2^b) takes tw[(1 << b) + (t mod 2^b)] = tw[s + S ((1 << g) + (j mod 2^g))]: thirty-one entries per thread at
 // compile-time offsets from tw + s.
 template <int LOG_R>
 __device__ __forceinline__ void group1(uint32_t (&x)[Geo<LOG_R>::U], const uint32_t* __restrict__ tw_s) {
     using G = Geo<LOG_R>;
+    constexpr int K = (G::U / 2) % LDE_BFLY_K == 0 && LDE_BFLY_K > 1 ? LDE_BFLY_K : 1;
 #pragma unroll
     for (int g = G::LOG_U - 1; g >= 0; g--) {
+        if constexpr (K > 1) {
 #pragma unroll
-        for (int j = 0; j < G::U; j++) {
-            if (j & (1 << g)) continue;
-            const int m = (1 << g) + (j & ((1 << g) - 1));
-            bfly(x[j], x[j | (1 << g)], tw_s[G::S * m]);
+            for (int p0 = 0; p0 < G::U / 2; p0 += K) {
+                uint32_t *xs[K], *ys[K], tws[K];
+#pragma unroll
+                for (int i = 0; i < K; i++) {
+                    const int p = p0 + i;
+                    const int j = ((p >> g) << (g + 1)) | (p & ((1 << g) - 1));  // pair p of the stage: bit g clear
+                    xs[i] = &x[j];
+                    ys[i] = &x[j | (1 << g)];
+                    tws[i] = tw_s[G::S * ((1 << g) + (j & ((1 << g) - 1)))];
+                }
+                bfly_k<K, false>(xs, ys, tws);
+            }
+        } else {
+#pragma unroll
+            for (int j = 0; j < G::U; j++) {
+                if (j & (1 << g)) continue;
+                const int m = (1 << g) + (j & ((1 << g) - 1));
+                bfly(x[j], x[j | (1 << g)], tw_s[G::S * m]);
+            }
         }
     }
 }
 // Stage group 2: register j of slot s is tile row 32 s + j; stages LOG_S-1 .. 0 on in-register bits, the twiddle
 // tw[(1 << g) + (j mod 2^g)] is the same for every thread: read once into scalar registers.  ONE0: the tile's lowest
 // row bits are the transform's (a last pass) -- entry (1 << g) + 0 is one, no product.
+// one stage (in-register bit GBIT) of group 2, K butterflies in lockstep: pairs in the order of their twiddle index jl, so that a last
+// pass's twiddle-one butterflies (jl = 0) come in whole blocks
+template <int LOG_R, bool ONE0, int GBIT, int K>
+__device__ __forceinline__ void group2_stage(uint32_t (&x)[Geo<LOG_R>::U], const uint32_t (&tws)[Geo<LOG_R>::S]) {
+    using G = Geo<LOG_R>;
+    constexpr int PER_JL = (G::U / 2) >> GBIT;  // pairs sharing one jl
+    constexpr int KK = PER_JL < K ? PER_JL : K;
+#pragma unroll
+    for (int jl = 0; jl < (1 << GBIT); jl++) {
+#pragma unroll
+        for (int h0 = 0; h0 < PER_JL; h0 += KK) {
+            if (ONE0 && jl == 0) {
+#pragma unroll
+                for (int i = 0; i < KK; i++) {
+                    const int j = ((h0 + i) << (GBIT + 1)) | jl;
+                    bfly_1(x[j], x[j | (1 << GBIT)]);
+                }
+            } else {
+                uint32_t *xs[KK], *ys[KK], tk[KK];
+#pragma unroll
+                for (int i = 0; i < KK; i++) {
+                    const int j = ((h0 + i) << (GBIT + 1)) | jl;
+                    xs[i] = &x[j];
+                    ys[i] = &x[j | (1 << GBIT)];
+                    tk[i] = tws[(1 << GBIT) + jl];
+                }
+                bfly_k<KK, true>(xs, ys, tk);
+            }
+        }
+    }
+    if constexpr (GBIT > 0) group2_stage<LOG_R, ONE0, GBIT - 1, K>(x, tws);
+}
 template <int LOG_R, bool ONE0>
 __device__ __forceinline__ void group2(uint32_t (&x)[Geo<LOG_R>::U], const uint32_t* __restrict__ tw) {
     using G = Geo<LOG_R>;
+    constexpr int K = (G::U / 2) % LDE_BFLY_K == 0 && LDE_BFLY_K > 1 ? LDE_BFLY_K : 1;
     if constexpr (G::LOG_S > 0) {
         uint32_t tws[G::S];
+        tws[0] = 0;
 #pragma unroll
         for (int i = 1; i < G::S; i++) tws[i] = (uint32_t)__builtin_amdgcn_readfirstlane((int)tw[i]);
+        if constexpr (K > 1) {
+            group2_stage<LOG_R, ONE0, G::LOG_S - 1, K>(x, tws);
+        } else {
 #pragma unroll
-        for (int g = G::LOG_S - 1; g >= 0; g--) {
+            for (int g = G::LOG_S - 1; g >= 0; g--) {
 #pragma unroll
-            for (int j = 0; j < G::U; j++) {
-                if (j & (1 << g)) continue;
-                const int jl = j & ((1 << g) - 1);
-                if (ONE0 && jl == 0) bfly_1(x[j], x[j | (1 << g)]);
-                else bfly_u(x[j], x[j | (1 << g)], tws[(1 << g) + jl]);
+                for (int j = 0; j < G::U; j++) {
+                    if (j & (1 << g)) continue;
+                    const int jl = j & ((1 << g) - 1);
+                    if (ONE0 && jl == 0) bfly_1(x[j], x[j | (1 << g)]);
+                    else bfly_u(x[j], x[j | (1 << g)], tws[(1 << g) + jl]);
+                }
             }
         }
     }
@@ -165,8 +261,12 @@ __device__ __forceinline__ void tile_read(const uint32_t* __restrict__ tile, int
 
 // Global accesses of a thread's U rows walk ONE pointer by a stride.  (Spelled as base + f(j) the compiler hoists the thirty-two
 // tile-invariant row offsets of a thread out of the persistent loop -- as 64-bit pairs -- and spills them.)
+// (The pointers are cast to the global address space: read out of the LDS descriptor table their address space is unknown to the
+// compiler, and a FLAT load also counts on the LDS counter -- every wait for an LDS read would wait for the prefetched rows.)
+typedef __attribute__((address_space(1))) uint32_t global_u32;
 template <int U>
-__device__ __forceinline__ void walk_load(uint32_t (&x)[U], const uint32_t* __restrict__ p, size_t stride) {
+__device__ __forceinline__ void walk_load(uint32_t (&x)[U], const uint32_t* __restrict__ p0, size_t stride) {
+    const global_u32* p = (const global_u32*)p0;
 #pragma unroll
     for (int j = 0; j < U; j++) {
         x[j] = *p;
@@ -174,11 +274,79 @@ __device__ __forceinline__ void walk_load(uint32_t (&x)[U], const uint32_t* __re
     }
 }
 template <int U>
-__device__ __forceinline__ void walk_store(const uint32_t (&x)[U], uint32_t* __restrict__ p, size_t stride) {
+__device__ __forceinline__ void walk_store(const uint32_t (&x)[U], uint32_t* __restrict__ p0, size_t stride) {
+    global_u32* p = (global_u32*)p0;
 #pragma unroll
     for (int j = 0; j < U; j++) {
         *p = x[j];
         p += stride;
+    }
+}
+// 16-byte accesses.  One dword per lane sustains about 3.5 TB/s on this chip however well the lanes coalesce, four dwords per lane
+// 5.2 TB/s (tools/ubench_tilemem.hip) -- and with the butterflies removed these kernels run at their memory time.
+// A thread owns ONE column, so the four lanes of a quad (four adjacent columns of one row slot) each move a 16-byte piece of a
+// different row -- lane q rows 4 m + q of the thread's rows -- and a 4 x 4 transpose inside the quad (two conditional register
+// rotations around three DPP quad_perm moves, 19 full-rate instructions) turns row pieces into the per-column registers and back.
+typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(1))) u32x4 global_u32x4;
+template <int CTRL>
+__device__ __forceinline__ uint32_t quad_perm(uint32_t v) {
+    return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+// lane q of a quad holds a[0..3]: on return it holds what lanes 0..3 held in their a[q]
+__device__ __forceinline__ void quad_transpose(uint32_t (&a)[4], int q) {
+    const bool b0 = (q & 1) != 0, b1 = (q & 2) != 0;
+    uint32_t t[4], u[4], w[4];
+#pragma unroll
+    for (int r = 0; r < 4; r++) t[r] = b0 ? a[(r + 1) & 3] : a[r];
+#pragma unroll
+    for (int r = 0; r < 4; r++) u[r] = b1 ? t[(r + 2) & 3] : t[r];  // u[r] = a[(r + q) mod 4]
+    w[0] = u[0];
+    w[1] = quad_perm<147>(u[1]);  // quad_perm:[3,0,1,2]: lane q takes register r from lane (q - r) mod 4
+    w[2] = quad_perm<78>(u[2]);   // [2,3,0,1]
+    w[3] = quad_perm<57>(u[3]);   // [1,2,3,0]
+    const uint32_t z[4] = {w[0], w[3], w[2], w[1]};  // w[r] came from lane (q - r): z[i] from lane (q + i)
+#pragma unroll
+    for (int j = 0; j < 4; j++) t[j] = b0 ? z[(j + 3) & 3] : z[j];
+#pragma unroll
+    for (int j = 0; j < 4; j++) a[j] = b1 ? t[(j + 2) & 3] : t[j];  // a[j] = z[(j - q) mod 4]: from lane j
+}
+// p0: element (first row of the thread, first column of its quad); register j is row j * row_step words further on.
+// The loads leave the row pieces as they arrive (raw[4 m + i] = word i of the m-th piece); quad_unpack turns them into the thread's
+// column -- separately, so that a prefetch can stay in flight as plain registers and be transposed when it is consumed.
+template <int U>
+__device__ __forceinline__ void walk_load_x4(uint32_t (&raw)[U], const uint32_t* __restrict__ p0, size_t row_step, int q) {
+    static_assert(U % 4 == 0, "quads of rows");
+    const global_u32* p = (const global_u32*)p0 + (size_t)q * row_step;
+#pragma unroll
+    for (int m = 0; m < U / 4; m++) {
+        const u32x4 v = *(const global_u32x4*)p;
+        p += 4 * row_step;
+        raw[4 * m] = v.x, raw[4 * m + 1] = v.y, raw[4 * m + 2] = v.z, raw[4 * m + 3] = v.w;
+    }
+}
+template <int U>
+__device__ __forceinline__ void quad_unpack(uint32_t (&x)[U], const uint32_t (&raw)[U], int q) {
+#pragma unroll
+    for (int m = 0; m < U / 4; m++) {
+        uint32_t a[4] = {raw[4 * m], raw[4 * m + 1], raw[4 * m + 2], raw[4 * m + 3]};
+        quad_transpose(a, q);
+#pragma unroll
+        for (int i = 0; i < 4; i++) x[4 * m + i] = a[i];
+    }
+}
+template <int U>
+__device__ __forceinline__ void walk_store_x4(const uint32_t (&x)[U], uint32_t* __restrict__ p0, size_t row_step, int q) {
+    static_assert(U % 4 == 0, "quads of rows");
+    global_u32* p = (global_u32*)p0 + (size_t)q * row_step;
+#pragma unroll
+    for (int m = 0; m < U / 4; m++) {
+        uint32_t a[4] = {x[4 * m], x[4 * m + 1], x[4 * m + 2], x[4 * m + 3]};
+        quad_transpose(a, q);
+        u32x4 v;
+        v.x = a[0], v.y = a[1], v.z = a[2], v.w = a[3];
+        *(global_u32x4*)p = v;
+        p += 4 * row_step;
     }
 }
 template <int U>
@@ -294,50 +462,77 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_in(Lde
     stage_descs(a, descs);
     __syncthreads();
 
-    uint32_t x[G::U], y[G::U], tv[TWN];
-    ColRef ref;
-    uint32_t lo = 0, vc = 0;
-    auto fetch = [&](uint32_t it) {
+    // (memory schedule: see k_lde_out -- next tile's rows first, this tile's stores after they have landed)
+    uint32_t x[G::U], nx[G::U], y[G::U], tv[TWN], ntv[TWN];
+    struct At {
+        uint32_t lo, vc;
+    };
+    auto fetch = [&](uint32_t it, uint32_t (&dst)[G::U], uint32_t (&dtv)[TWN]) {
         const uint32_t id = walk.first + it * walk.step;
-        lo = id / (uint32_t)a.n_chunks;
-        vc = (uint32_t)a.col0 + (id - lo * (uint32_t)a.n_chunks) * C + (uint32_t)c;
-        ref = locate_col(a, descs, vc);
-        if (ref.valid) walk_load<G::U>(x, ref.src + (((size_t)s << r2) | lo) * ref.w, ((size_t)G::S << r2) * ref.w);
-        else zero_rows<G::U>(x);
+        At at;
+        at.lo = id / (uint32_t)a.n_chunks;
+        at.vc = (uint32_t)a.col0 + (id - at.lo * (uint32_t)a.n_chunks) * C + (uint32_t)c;
+        if (G::U >= 4 && a.x4) {  // every matrix of the group starts and ends on a 16-byte boundary: a quad shares one matrix
+            const ColRef ref = locate_col(a, descs, at.vc & ~3u);
+            walk_load_x4<G::U>(dst, ref.src + (((size_t)s << r2) | at.lo) * ref.w, ((size_t)G::S << r2) * ref.w, c & 3);
+        } else {
+            const ColRef ref = locate_col(a, descs, at.vc);
+            // a padding column reads column 0 of the last matrix (its values go nowhere): no branch around memory operations
+            walk_load<G::U>(dst, ref.src + (((size_t)s << r2) | at.lo) * ref.w, ((size_t)G::S << r2) * ref.w);
+        }
 #pragma unroll
         for (int i = 0; i < TWN; i++) {
             const int idx = (int)threadIdx.x + i * NT;
-            tv[i] = idx < G::R ? tile_twiddle(a.tw_inv, idx, a.log_n, r2, lo) : 0u;
+            dtv[i] = tile_twiddle(a.tw_inv, idx < G::R ? idx : 0, a.log_n, r2, at.lo);
         }
+        return at;
     };
-    fetch(0);
+    At nxt = fetch(0, nx, ntv);
+#pragma unroll
+    for (int j = 0; j < G::U; j++) asm volatile("" : "+v"(nx[j]));  // landed before the loop: no load is pending on any path into its head
+#pragma unroll
+    for (int i = 0; i < TWN; i++) asm volatile("" : "+v"(ntv[i]));
     for (uint32_t it = 0; it < walk.count; it++) {
+        const At cur = nxt;
+        if (G::U >= 4 && a.x4) quad_unpack<G::U>(x, nx, c & 3);
+        else {
+#pragma unroll
+            for (int j = 0; j < G::U; j++) x[j] = nx[j];
+        }
+#pragma unroll
+        for (int i = 0; i < TWN; i++) tv[i] = ntv[i];
+        if (a.dbg & 2) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx, ntv);
         uint32_t* __restrict__ tw = twb + (it & 1u) * G::R;
 #pragma unroll
         for (int i = 0; i < TWN; i++) {
             const int idx = (int)threadIdx.x + i * NT;
             if (idx < G::R) tw[idx] = tv[i];
         }
-        const size_t out_off = slab_off(a, vc);
-        const uint32_t cur_lo = lo;
         __syncthreads();  // the table is complete; every thread has left the previous tile
         if (a.in_canonical) {
 #pragma unroll
             for (int j = 0; j < G::U; j++) x[j] = bb::to_monty(x[j]);
         }
-        group1<LOG_R>(x, tw + s);
+        if (!(a.dbg & 1)) group1<LOG_R>(x, tw + s);
         if constexpr (G::LOG_S > 0) {
             tile_write<LOG_R, LOG_C>(tile, s, c, x);
-            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
+            if (!(a.dbg & 2)) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx, ntv);  // (see k_lde_out: half a tile after the stores)
             __syncthreads();
             tile_read<LOG_R, LOG_C>(tile, s, c, y);
-            group2<LOG_R, false>(y, tw);
+            if (!(a.dbg & 1)) group2<LOG_R, false>(y, tw);
         } else {
 #pragma unroll
             for (int j = 0; j < G::U; j++) y[j] = x[j];
-            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
+            if (!(a.dbg & 2)) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx, ntv);
         }
-        walk_store<G::U>(y, a.A + out_off + (((((size_t)(G::U * s)) << r2) | cur_lo) << SLAB_LOG_W), (size_t)1 << (r2 + SLAB_LOG_W));
+#pragma unroll
+        for (int j = 0; j < G::U; j++) asm volatile("" : "+v"(nx[j]));  // the next tile's rows have landed BEFORE this tile's stores are issued
+#pragma unroll
+        for (int i = 0; i < TWN; i++) asm volatile("" : "+v"(ntv[i]));
+        if constexpr (G::U >= 4 && LDE_SLAB_X4)
+            walk_store_x4<G::U>(y, a.A + slab_off(a, cur.vc & ~3u) + (((((size_t)(G::U * s)) << r2) | cur.lo) << SLAB_LOG_W), (size_t)1 << (r2 + SLAB_LOG_W), c & 3);
+        else
+            walk_store<G::U>(y, a.A + slab_off(a, cur.vc) + (((((size_t)(G::U * s)) << r2) | cur.lo) << SLAB_LOG_W), (size_t)1 << (r2 + SLAB_LOG_W));
     }
 }
 
@@ -362,39 +557,70 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
     for (int idx = (int)threadIdx.x; idx < G::R; idx += NT) tw[idx] = tile_twiddle(a.tw_fwd, idx, a.log_n, 0, 0u);
     __syncthreads();
 
-    uint32_t x[G::U], y[G::U];
-    uint32_t q = 0, hi = 0, vc = 0;
-    auto fetch = [&](uint32_t it) {
+    // Memory schedule of a tile: the NEXT tile's rows are requested first (into nx), then this tile runs, and its stores are
+    // issued only after nx has landed and moved to x.  A wave's loads and stores share one in-order counter and the compiler waits
+    // for "everything" whenever both kinds are pending: with the loads requested after the stores (or the stores pending when the
+    // loads are needed) every tile waited for the previous tile's stores to drain.  In this order the loads have a whole tile to
+    // arrive and nothing ever waits for a store.
+    uint32_t x[G::U], nx[G::U], y[G::U];
+    struct At {
+        uint32_t q, hi, vc;
+    };
+    auto fetch = [&](uint32_t it, uint32_t (&dst)[G::U]) {
         const uint32_t id = walk.first + it * walk.step;
         const uint32_t blk = id / (uint32_t)a.n_chunks;
-        vc = (uint32_t)a.col0 + (id - blk * (uint32_t)a.n_chunks) * C + (uint32_t)c;
-        q = blk >> r2;
-        hi = blk & ((1u << r2) - 1u);
-        const uint32_t* __restrict__ in = a.B + ((size_t)q * a.slabs << (a.log_n + SLAB_LOG_W)) + slab_off(a, vc);
-        walk_load<G::U>(x, in + ((((size_t)hi << LOG_R) | (size_t)s) << SLAB_LOG_W), (size_t)G::S << SLAB_LOG_W);
+        At at;
+        at.vc = (uint32_t)a.col0 + (id - blk * (uint32_t)a.n_chunks) * C + (uint32_t)c;
+        at.q = blk >> r2;
+        at.hi = blk & ((1u << r2) - 1u);
+        const uint32_t* __restrict__ in = a.B + ((size_t)at.q * a.slabs << (a.log_n + SLAB_LOG_W)) + ((((size_t)at.hi << LOG_R) | (size_t)s) << SLAB_LOG_W);
+        if constexpr (G::U >= 4 && LDE_SLAB_X4) walk_load_x4<G::U>(dst, in + slab_off(a, at.vc & ~3u), (size_t)G::S << SLAB_LOG_W, c & 3);
+        else walk_load<G::U>(dst, in + slab_off(a, at.vc), (size_t)G::S << SLAB_LOG_W);
+        return at;
     };
-    fetch(0);
+    At nxt = fetch(0, nx);
+#pragma unroll
+    for (int j = 0; j < G::U; j++) asm volatile("" : "+v"(nx[j]));  // landed before the loop: no load is pending on any path into its head
     for (uint32_t it = 0; it < walk.count; it++) {
-        const ColRef ref = locate_col(a, descs, vc);
-        const size_t row0 = ((size_t)q << a.log_n) | ((size_t)hi << LOG_R);
+        const At cur = nxt;
+        if constexpr (G::U >= 4 && LDE_SLAB_X4) quad_unpack<G::U>(x, nx, c & 3);
+        else {
+#pragma unroll
+            for (int j = 0; j < G::U; j++) x[j] = nx[j];
+        }
+        if (a.dbg & 2) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx);  // (A/B: the request at the head of the tile)
+        const ColRef ref = locate_col(a, descs, cur.vc);
+        const size_t row0 = ((size_t)cur.q << a.log_n) | ((size_t)cur.hi << LOG_R);
         __syncthreads();  // (first tile: the table is complete) every thread has left the previous tile
-        group1<LOG_R>(x, tw + s);
+        if (!(a.dbg & 1)) group1<LOG_R>(x, tw + s);
         if constexpr (G::LOG_S > 0) {
             tile_write<LOG_R, LOG_C>(tile, s, c, x);
-            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
+            // The next tile's rows are requested HERE: a wave has 64 memory operations in flight at most, so at the head of the
+            // tile the thirty-two requests queue behind the previous tile's thirty-two stores (the wave stands at the issue until
+            // they have drained); half a tile later those are gone and the rows still have the second stage group to arrive.
+            if (!(a.dbg & 2)) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx);  // (the last tile re-reads itself: no branch around memory operations)
             __syncthreads();
             tile_read<LOG_R, LOG_C>(tile, s, c, y);
-            group2<LOG_R, true>(y, tw);
+            if (!(a.dbg & 1)) group2<LOG_R, true>(y, tw);
         } else {
 #pragma unroll
             for (int j = 0; j < G::U; j++) y[j] = x[j];
-            fetch(it + 1 < walk.count ? it + 1 : it);  // (the last tile re-reads itself: no branch around memory operations)
+            if (!(a.dbg & 2)) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx);
         }
         if (a.out_canonical) {
 #pragma unroll
             for (int j = 0; j < G::U; j++) y[j] = bb::from_monty(y[j]);
         }
-        if (ref.valid) walk_store<G::U>(y, ref.dst + (row0 + (size_t)(G::U * s)) * ref.w, (size_t)ref.w);
+#pragma unroll
+        for (int j = 0; j < G::U; j++) asm volatile("" : "+v"(nx[j]));  // the next tile's rows have landed BEFORE this tile's stores are issued
+        if (G::U >= 4 && a.x4) {
+            const ColRef rq = locate_col(a, descs, cur.vc & ~3u);
+            uint32_t* __restrict__ out = rq.valid ? rq.dst + (row0 + (size_t)(G::U * s)) * rq.w : a.B + slab_off(a, cur.vc & ~3u);
+            walk_store_x4<G::U>(y, out, rq.valid ? (size_t)rq.w : (size_t)0, c & 3);
+        } else {
+            uint32_t* __restrict__ out = ref.valid ? ref.dst + (row0 + (size_t)(G::U * s)) * ref.w : a.B + slab_off(a, cur.vc);
+            walk_store<G::U>(y, out, ref.valid ? (size_t)ref.w : (size_t)0);  // a padding column stores into its own slab column: no branch
+        }
     }
 }
 
@@ -440,7 +666,10 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
             else zero_rows<G::U>(x);
         } else {
             const uint32_t hi = r1 ? (__brev(lo2) >> (32 - r1)) : 0u;
-            walk_load<G::U>(x, a.A + slab_off(a, vc) + ((((size_t)hi << LOG_R) | (size_t)s) << SLAB_LOG_W), (size_t)G::S << SLAB_LOG_W);
+            if constexpr (G::U >= 4 && LDE_MID_X4)  // raw row pieces: transposed into the thread's column where the tile starts (quad_unpack)
+                walk_load_x4<G::U>(x, a.A + slab_off(a, vc & ~3u) + ((((size_t)hi << LOG_R) | (size_t)s) << SLAB_LOG_W), (size_t)G::S << SLAB_LOG_W, c & 3);
+            else
+                walk_load<G::U>(x, a.A + slab_off(a, vc) + ((((size_t)hi << LOG_R) | (size_t)s) << SLAB_LOG_W), (size_t)G::S << SLAB_LOG_W);
         }
     };
     fetch(0);
@@ -473,16 +702,22 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
                     if ((uint32_t)cl < a.n_cls) scl[cl * G::R + idx] = scv[0][cl][i];
             }
         }
+        if constexpr (!DIRECT && G::U >= 4 && LDE_MID_X4) {
+            uint32_t raw[G::U];
+#pragma unroll
+            for (int j = 0; j < G::U; j++) raw[j] = x[j];
+            quad_unpack<G::U>(x, raw, c & 3);
+        }
         if (DIRECT && a.in_canonical) {
 #pragma unroll
             for (int j = 0; j < G::U; j++) x[j] = bb::to_monty(x[j]);
         }
-        group1<LOG_R>(x, twi + s);
+        if (!(a.dbg & 1)) group1<LOG_R>(x, twi + s);
         if constexpr (G::LOG_S > 0) {
             tile_write<LOG_R, LOG_C>(tile, s, c, x);
             __syncthreads();  // B1
             tile_read<LOG_R, LOG_C>(tile, s, c, coef);
-            group2<LOG_R, true>(coef, twi);
+            if (!(a.dbg & 1)) group2<LOG_R, true>(coef, twi);
         } else {
 #pragma unroll
             for (int j = 0; j < G::U; j++) coef[j] = x[j];
@@ -496,7 +731,7 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
                 const int j2 = brev_c(j, G::LOG_U);
                 x[j2] = mulc(coef[j], sc[G::S * j2]);
             }
-            group1<LOG_R>(x, twf + s2);
+            if (!(a.dbg & 1)) group1<LOG_R>(x, twf + s2);
             uint32_t z[G::U];
             if constexpr (G::LOG_S == 0) {  // no second group: the results leave x before the next tile's rows are requested into it
 #pragma unroll
@@ -523,7 +758,7 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
             if constexpr (G::LOG_S > 0) {
                 __syncthreads();  // B3 / B5
                 tile_read<LOG_R, LOG_C>(tile, s, c, z);
-                group2<LOG_R, false>(z, twf);
+                if (!(a.dbg & 1)) group2<LOG_R, false>(z, twf);
             } else {
                 if (q == 0) __syncthreads();  // coset 1's scales are complete
             }
@@ -535,7 +770,12 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
                 if (cur.valid) walk_store<G::U>(z, cur.dst + (((size_t)q << a.log_n) + (size_t)(G::U * s)) * cur.w, (size_t)cur.w);
             } else {
                 uint32_t* __restrict__ out = a.B + ((size_t)q * a.slabs << (a.log_n + SLAB_LOG_W)) + slab_off(a, cur_vc);
-                walk_store<G::U>(z, out + (((((size_t)(G::U * s)) << r1) | cur_lo2) << SLAB_LOG_W), (size_t)1 << (r1 + SLAB_LOG_W));
+                if constexpr (G::U >= 4 && LDE_MID_X4) {
+                    uint32_t* __restrict__ outq = a.B + ((size_t)q * a.slabs << (a.log_n + SLAB_LOG_W)) + slab_off(a, cur_vc & ~3u);
+                    walk_store_x4<G::U>(z, outq + (((((size_t)(G::U * s)) << r1) | cur_lo2) << SLAB_LOG_W), (size_t)1 << (r1 + SLAB_LOG_W), c & 3);
+                } else {
+                    walk_store<G::U>(z, out + (((((size_t)(G::U * s)) << r1) | cur_lo2) << SLAB_LOG_W), (size_t)1 << (r1 + SLAB_LOG_W));
+                }
             }
         }
     }
@@ -565,6 +805,8 @@ void size_grid(lurkhip_ctx* ctx, LdeArgs& a, size_t tiles, int threads, size_t l
     if (a.xcd_run) b = std::max<size_t>(8, b / 8 * 8);
     static const int stagger = getenv("LURKHIP_LDE_STAGGER") ? atoi(getenv("LURKHIP_LDE_STAGGER")) : 0;
     a.stagger = (per_cu >= 2 && b >= (size_t)2 * ctx->num_cus) ? stagger : 0;
+    static const int dbg = getenv("LURKHIP_LDE_DBG") ? atoi(getenv("LURKHIP_LDE_DBG")) : 0;
+    a.dbg = dbg;
     *blocks = (unsigned)b;
 }
 
@@ -691,6 +933,13 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     a.in_canonical = in_canonical ? 1 : 0;
     a.out_canonical = out_canonical ? 1 : 0;
     a.slabs = (a.W + (1u << SLAB_LOG_W) - 1) >> SLAB_LOG_W;
+    // 16-byte accesses: the slabs always; the matrices' side when every matrix of the group is 16-byte aligned and a multiple of
+    // four columns wide (the extension-field matrices of the permutation and quotient rounds always are).  LURKHIP_LDE_X4 masks the bits.
+    static const int x4_mask = getenv("LURKHIP_LDE_X4") ? atoi(getenv("LURKHIP_LDE_X4")) : 0;
+    bool mats_x4 = true;
+    for (int m = 0; m < n_mats; m++)
+        mats_x4 = mats_x4 && widths[m] % 4 == 0 && ((uintptr_t)evals[m] & 15u) == 0 && ((uintptr_t)ldes[m] & 15u) == 0;
+    a.x4 = (mats_x4 ? 1 : 0) & x4_mask;
     if (log_n <= 10) {
         a.r1 = 0;
         a.r2 = log_n;
