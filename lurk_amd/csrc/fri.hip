@@ -281,6 +281,91 @@ __global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restr
     }
 }
 
+// Matrices of 24 .. 256 columns (round 4): the slab walk of k_column_dot -- thread = (row of the slab, column), so the 256 lanes
+// read CONSECUTIVE words of the row-major matrix whatever its width and alignment -- with the block's weights staged in LDS once
+// (k_column_dot_wave read one word per lane at a stride of w words: 64-column pieces of 312-byte rows, the last piece mostly
+// idle lanes, and two scalar loads per row on the critical path -- 1.7 TB/s, 76 % of the wave cycles waiting; k_column_dot's own
+// per-lane weight loads were 36 bytes requested per 4 bytes of matrix).  V = 2: rows wider than 128 columns are cut in two halves
+// of T = ceil(w / 2) columns and a thread takes column ct of both, so that R = 256 / T >= 2 rows fit a step.
+template <int V>
+__global__ __launch_bounds__(256) void k_column_dot_slab(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows, uint32_t rows_per_block,
+                                                          const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
+                                                          uint32_t* __restrict__ partial) {
+    extern __shared__ __attribute__((aligned(16))) uint32_t dot_lds[];
+    uint4* wts = reinterpret_cast<uint4*>(dot_lds);                     // [row][point]
+    uint32_t* red = dot_lds + (size_t)rows_per_block * 8;              // [point][V][256][4]
+    const size_t row0 = (size_t)blockIdx.x * rows_per_block;
+    const uint32_t rows = (uint32_t)(row0 + rows_per_block <= n_rows ? rows_per_block : n_rows - row0);
+    for (uint32_t i = threadIdx.x; i < rows; i += 256) {
+        wts[2 * i] = *reinterpret_cast<const uint4*>(u0 + 4 * (row0 + i));
+        wts[2 * i + 1] = u1 ? *reinterpret_cast<const uint4*>(u1 + 4 * (row0 + i)) : make_uint4(0, 0, 0, 0);
+    }
+    __syncthreads();
+    const uint32_t T = (w + V - 1) / V, R = 256u / T;
+    const uint32_t rl = threadIdx.x / T, ct = threadIdx.x - rl * T;
+    const bool active = rl < R;
+    uint32_t col[V];
+    bool real[V];
+#pragma unroll
+    for (int v = 0; v < V; v++) {
+        const uint32_t c = ct + (uint32_t)v * T;
+        real[v] = c < w;
+        col[v] = real[v] ? c : w - 1u;  // an idle half-column shadows the last one: no branch around the loads
+    }
+    LazyEf acc[V][2];
+#pragma unroll
+    for (int v = 0; v < V; v++) acc[v][0].zero(), acc[v][1].zero();
+    const uint32_t* __restrict__ base = mat + row0 * w;
+    auto step = [&](const uint32_t (&m)[V], uint32_t r) {
+        const uint4 p0 = wts[2 * r], p1 = wts[2 * r + 1];
+        const int32_t w0[4] = {(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w};
+        const int32_t w1[4] = {(int32_t)p1.x, (int32_t)p1.y, (int32_t)p1.z, (int32_t)p1.w};
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            acc[v][0].add_base_v(m[v], w0);
+            if (u1) acc[v][1].add_base_v(m[v], w1);
+        }
+    };
+    if (active) {
+        constexpr int UR = 8;  // rows in flight per lane
+        uint32_t r = rl;
+        for (; r + (UR - 1) * R < rows; r += UR * R) {
+            uint32_t m[UR][V];
+#pragma unroll
+            for (int k = 0; k < UR; k++)
+#pragma unroll
+                for (int v = 0; v < V; v++) m[k][v] = base[(size_t)(r + k * R) * w + col[v]];
+#pragma unroll
+            for (int k = 0; k < UR; k++) step(m[k], r + k * R);
+        }
+        for (; r < rows; r += R) {
+            uint32_t m[V];
+#pragma unroll
+            for (int v = 0; v < V; v++) m[v] = base[(size_t)r * w + col[v]];
+            step(m, r);
+        }
+    }
+#pragma unroll
+    for (int p = 0; p < 2; p++)
+#pragma unroll
+        for (int v = 0; v < V; v++) {
+            const ef a = acc[v][p].value();
+            for (int k = 0; k < 4; k++) red[((p * V + v) * 256 + threadIdx.x) * 4 + k] = a.c[k];
+        }
+    __syncthreads();
+    if (rl == 0) {
+        const int n_pts = u1 ? 2 : 1;
+        for (int p = 0; p < n_pts; p++)
+#pragma unroll
+            for (int v = 0; v < V; v++) {
+                if (!real[v]) continue;
+                ef t = bb::ef_zero();
+                for (uint32_t q = 0; q < R; q++) t = bb::ef_add(t, ef_load(red + ((p * V + v) * 256 + q * T + ct) * 4));
+                ef_store(partial + (((size_t)blockIdx.x * 2 + p) * w + col[v]) * 4, t);
+            }
+    }
+}
+
 // out[p][c] = sum over blocks of partial[blk][p][c]; one workgroup per (p, c),
 // every matrix of a proof in one launch: block -> (matrix, point, column) through the prefix sums in the arguments
 __global__ __launch_bounds__(256) void k_dot_finish_all(DotFinishArgs a) {
@@ -794,9 +879,19 @@ int32_t point_weights_batch(lurkhip_ctx* ctx, const std::vector<WeightJob>& jobs
 
 // rows per partial-sum block: 1024, fewer for short matrices on the wave-per-row kernel so that the launch still fills the CUs
 constexpr uint32_t DOT_WAVE_MIN_W = 24;
+constexpr uint32_t DOT_SLAB_MAX_W = 256;  // k_column_dot_slab: DOT_WAVE_MIN_W .. 256 columns (LURKHIP_DOT_SLAB=0: the wave kernel, A/B)
+static bool dot_slab(uint32_t w) {
+    static const bool on = getenv("LURKHIP_DOT_SLAB") == nullptr || atoi(getenv("LURKHIP_DOT_SLAB")) != 0;
+    return on && w >= DOT_WAVE_MIN_W && w <= DOT_SLAB_MAX_W && getenv("LURKHIP_DOT_OLD") == nullptr;
+}
 static uint32_t dot_block_rows(uint32_t w, size_t n_rows) {
     uint32_t rb = DOT_ROWS;
     if (w < DOT_WAVE_MIN_W || getenv("LURKHIP_DOT_OLD") != nullptr) return rb;
+    if (dot_slab(w)) {  // one workgroup per row block: 512 rows (16 KiB of staged weights), fewer while the launch is short of workgroups
+        rb = 512;
+        while (rb > 64 && (n_rows + rb - 1) / rb < 1024) rb /= 2;
+        return rb;
+    }
     const size_t chunks = (w + 63) / 64;
     while (rb > 64 && ((n_rows + rb - 1) / rb) * chunks < 512) rb /= 2;
     return rb;
@@ -811,7 +906,13 @@ size_t column_dot_partial_words(uint32_t w, size_t n_rows) { return (size_t)dot_
 int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
                            uint32_t* partial_dev) {
     const uint32_t n_blocks = dot_blocks(w, n_rows);
-    if (w >= DOT_WAVE_MIN_W && getenv("LURKHIP_DOT_OLD") == nullptr) {  // LURKHIP_DOT_OLD: A/B hook, every width on k_column_dot
+    if (dot_slab(w)) {
+        const uint32_t rb = dot_block_rows(w, n_rows);
+        const int v = w > 128 ? 2 : 1;
+        const size_t lds = ((size_t)rb * 8 + (size_t)2 * v * 256 * 4) * 4;
+        if (v == 2) hipLaunchKernelGGL(k_column_dot_slab<2>, dim3(n_blocks), dim3(256), lds, ctx->stream, mat, w, n_rows, rb, u0, u1, partial_dev);
+        else hipLaunchKernelGGL(k_column_dot_slab<1>, dim3(n_blocks), dim3(256), lds, ctx->stream, mat, w, n_rows, rb, u0, u1, partial_dev);
+    } else if (w >= DOT_WAVE_MIN_W && getenv("LURKHIP_DOT_OLD") == nullptr) {  // LURKHIP_DOT_OLD: A/B hook, every width on k_column_dot
         const uint32_t n_chunks = (w + 63) / 64;
         hipLaunchKernelGGL(k_column_dot_wave, dim3(n_blocks * n_chunks), dim3(256), 0, ctx->stream, mat, w, n_rows, dot_block_rows(w, n_rows), n_chunks,
                            u0, u1, partial_dev);

@@ -1,5 +1,13 @@
 cd $GRAFT_REPO_ROOT
-timeout 600 python -m pytest tests/test_commit_gpu.py -x -q -m gpu 2>&1 | tail -2
-echo "== K=4"; timeout 200 python tools/lde_throughput.py 20x64 20x78 19x314 18x114 2>&1 | grep "2^"
-echo "== K=1"; LURKHIP_LIB_PATH=$GRAFT_REPO_ROOT/lurk_amd/liblurkhip_mx0.so timeout 200 python tools/lde_throughput.py 20x64 20x78 19x314 18x114 2>&1 | grep "2^"
-timeout 300 python bench.py --steps 10 --warmup 3 --no-cpu-baseline --no-host-pipeline > gpurun_out/b5.log 2>&1; python tools/show_bench.py gpurun_out/b5.log 2>/dev/null | head -20
+timeout 900 python -m pytest tests/test_open_gpu.py tests/test_cpu_step_gpu.py -x -q -m gpu 2>&1 | tail -3
+cd /tmp && export TMPDIR=/tmp
+for slab in 1 0; do
+LURKHIP_DOT_SLAB=$slab rocprofv3 --kernel-trace --stats --output-format csv -d /tmp/pd_$slab -o run -- python $GRAFT_REPO_ROOT/bench.py --lanes 1 --steps 4 --warmup 1 --no-cpu-baseline --no-host-pipeline > /tmp/pd_$slab.log 2>&1
+python3 - <<PY
+import csv, re
+tot=0
+for r in csv.DictReader(open('/tmp/pd_$slab/run_kernel_stats.csv')):
+    if 'column_dot' in r['Name'] or 'dot_finish' in r['Name']:
+        print('  slab=$slab', r['Name'][:60], r['Calls'], 'ms/proof=%.3f'%(float(r['TotalDurationNs'])/1e6/5))
+PY
+done
