@@ -243,6 +243,8 @@ def main():
     ap.add_argument("--pipeline-shards", type=int, default=4)
     ap.add_argument("--oversubscribe", action="store_true",
                     help="diagnostic: allow more ranks than visible GPUs (ranks share devices, collectives over gloo); never a scaling number")
+    ap.add_argument("--torch-collectives", action="store_true",
+                    help="the two collectives of a multi-rank step through torch.distributed instead of the C ABI (lurkhip_exchange_roots / lurkhip_reduce_sums)")
     ap.add_argument("--profile", default="default", help="protocol profile preset (lurkhip_protocol_profile_preset): default, hardened, whole-state-squeeze, p3-monty-diffusion")
     ap.add_argument("--shards-per-rank", type=int, default=None,
                     help="distributed runs: shards of 2^log_rows / k eval rows, k per rank, dealt by work (default 2 when WORLD_SIZE > 1, else 1)")
@@ -350,7 +352,14 @@ def main():
     lane_ctx = prover.lane_context(machine) if len(mine) > 1 and not one_lane else None  # the second proving lane of a rank with several shards
 
     # the step itself lives in lurk_amd/shards.py (RankStep) so that the multi-process tests run exactly what is timed here
-    rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx)
+    # the two collectives of a step behind the C ABI (lurkhip_exchange_roots / lurkhip_reduce_sums on RCCL, csrc/comm.cpp) whenever the
+    # process group is RCCL's: what a Rust host drives; two ranks on one device (the oversubscribed test mode) keep gloo
+    comm = None
+    if distributed and not oversubscribed and not args.torch_collectives:
+        from lurk_amd.comm import Comm
+
+        comm = Comm.from_process_group(ctx)
+    rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx, comm=comm)
     grand_sums, rank_sums, host_ms = rank_step.grand_sums, rank_step.rank_sums, rank_step.host_ms
 
     def step():
@@ -376,7 +385,7 @@ def main():
                 for pr in prepared_b:
                     machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
             lane_ctx_b = prover.lane_context(machine_b) if not one_lane else None
-            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b))
+            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm))
             pipe["ctxs"] += [c for c in (ctx_b, lane_ctx_b) if c is not None]
             pipe["machines"].append(machine_b)
             pipe["prepared"].append(prepared_b)
@@ -626,6 +635,25 @@ def main():
         for name in SPANS:
             ms, cnt = lane_ctx.profile_read(name)
             spans[name] = (spans[name][0] + ms, spans[name][1] + cnt)
+    # N > 1: what makes the first multi-GPU run diagnosable from its one line -- every rank's stage spans, the work the assignment
+    # gave each rank (Machine.shard_cost, the quantity assign_shards_balanced equalises) and the efficiency that predicts
+    per_rank_stages = None
+    assignment_cost = None
+    if distributed:
+        mine_stages = {k: v[0] / args.steps for k, v in spans.items() if v[1]}
+        boxes = [None] * world
+        dist.all_gather_object(boxes, mine_stages)
+        per_rank_stages = boxes
+        cost = [float(machine.shard_cost(sh)) for sh in all_shards]
+        per_rank_cost = [sum(cost[i] for i in a_) for a_ in assignment]
+        mean_cost = sum(per_rank_cost) / len(per_rank_cost)
+        # the rank schedule (two half-shards on two lanes) measured 46.4 ms against 40.9 ms for one shard with two proofs in flight on
+        # one GPU (round 3): 0.88 before any communication; the slowest rank sets the step
+        sched = 0.88 if world > 1 else 1.0
+        assignment_cost = {"per_rank_cost": per_rank_cost, "predicted_imbalance_max_over_mean": max(per_rank_cost) / mean_cost,
+                           "schedule_factor_vs_n1": sched, "expected_efficiency_vs_n1": sched * mean_cost / max(per_rank_cost),
+                           "note": "cost = Machine.shard_cost (columns x rows of the shard's chips); expected efficiency = schedule factor x mean / max rank cost, "
+                                   "before the two collectives (tens of bytes per shard: host_ms below)"}
     ms_per_step = elapsed / args.steps * 1e3
     value = world * n * args.steps / elapsed
 
@@ -788,6 +816,7 @@ def main():
                 "shards_per_rank": spr,
                 "shard_assignment": assignment if world > 1 or spr > 1 else None,
                 "rccl_world_size": rccl_world_size if not oversubscribed else None,
+                "collectives": None if not distributed else ("c-abi: lurkhip_exchange_roots + lurkhip_reduce_sums on RCCL, the context's stream (csrc/comm.cpp)" if comm is not None else "torch.distributed"),
                 "process_group": None if not distributed else ("gloo (oversubscribed diagnostic: ranks share a device; NOT a scaling number)" if oversubscribed else "nccl (RCCL)"),
                 "visible_gpus": n_devices,
                 "host": host_info(),
@@ -796,6 +825,8 @@ def main():
                 "grand_sum_is_zero": all(g == (0, 0, 0, 0) for g in grand_sums),
                 "per_rank_sum_nonzero": all_rank_sums_nonzero if world > 1 else None,  # one rank: its own sum is the (zero) total
                 "per_rank_ms_per_step": per_rank_ms,
+                "per_rank_stages_ms": per_rank_stages,
+                "assignment_cost": assignment_cost,
                 "rank0_step_ms": [round(x, 3) for x in step_ms],
                 "collectives_host_ms_per_step": {k: v / (args.steps + args.warmup) for k, v in host_ms.items()},
                 "proofs_identical_across_steps": proofs_identical,

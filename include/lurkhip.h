@@ -600,6 +600,36 @@ int32_t lurkhip_logup_eval_constraints(lurkhip_ctx* ctx, uint32_t n_rows, uint32
                                        const uint32_t* main, const uint32_t* program, uint64_t program_words, const uint32_t* z, const uint32_t* r,
                                        const uint32_t* gamma, const uint32_t* final_sum, const uint32_t* selectors, int32_t air_order, uint32_t* out);
 
+/* ------------------------------------------------------------------- multi-GPU: the two collectives of a sharded proof */
+/* One process per GPU.  What the reference does inside one process -- sphinx's prover observes the main-trace
+ * commitment of EVERY shard (`Shard::shard`, /root/reference/src/lair/execute.rs:186-241) into the shared challenger before any
+ * shard's challenges are drawn, and the verifier requires the chips' cumulative sums over all shards to cancel
+ * (/root/reference/src/lair/lair_chip.rs:104-139) -- becomes an all-gather of (shard index, root) records and an all-reduce of
+ * extension-field sums over RCCL (xGMI), both enqueued on the context's stream.  librccl is loaded when the first
+ * communicator is asked for.  Rank 0 draws the id and the HOST distributes it (the Rust prover: over whatever channel
+ * started its ranks; the Python mirror: torch.distributed.broadcast_object_list). */
+typedef struct lurkhip_comm lurkhip_comm;
+#define LURKHIP_COMM_ID_BYTES 128      /* ncclUniqueId */
+#define LURKHIP_ROOT_RECORD_WORDS 9    /* shard index, then the 8 words of the shard's main-trace root */
+int32_t lurkhip_comm_unique_id(uint8_t* id_out /* [LURKHIP_COMM_ID_BYTES] */);
+/* Collective over all `world` ranks (ncclCommInitRank); the context's device is the rank's GPU. */
+int32_t lurkhip_comm_create(lurkhip_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world, lurkhip_comm** out);
+int32_t lurkhip_comm_destroy(lurkhip_ctx* ctx, lurkhip_comm* comm);
+int32_t lurkhip_comm_info(const lurkhip_comm* comm, int32_t* rank, int32_t* world);
+/* gathered_dev[world * n_local][9] <- every rank's records_dev[n_local][9], in rank order; every rank passes the same n_local.
+ * Device pointers; returns when the all-gather is enqueued. */
+int32_t lurkhip_exchange_roots_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* records_dev, int32_t n_local, uint32_t* gathered_dev);
+/* Host convenience: this rank's (shard_indices[i], roots[i][8]) in, roots_out[shard][8] of ALL world * n_local shards out, in shard
+ * order (what every shard's transcript observes); fails unless the ranks' indices are a partition of 0 .. world * n_local - 1. */
+int32_t lurkhip_exchange_roots(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
+                               uint32_t* roots_out);
+/* lanes_dev[4] (int64: sums of canonical coefficients, one lane per extension-field coefficient) all-reduced in place, then
+ * total_dev[4] <- lanes mod p.  RCCL has no modular reduction: addends below 2^31 cannot overflow 64 bits over any node. */
+int32_t lurkhip_reduce_sums_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, int64_t* lanes_dev, uint32_t* total_dev);
+/* Host convenience: local_sums[n_sums][4] canonical extension-field elements (the cumulative sums of every chip of every shard
+ * this rank proved) -> total[4], the machine-wide sum on every rank: a consistent proof set gives zero. */
+int32_t lurkhip_reduce_sums(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* local_sums, int32_t n_sums, uint32_t* total);
+
 /* ------------------------------------------------------------------- proof wire format */
 /* The reference's serialised proofs.  `CryptoProof { shard_proofs, verifier_version, depth }` with
  * `CryptoShardProof { commitment, opened_values, opening_proof, chip_ordering }` as `bincode::serialize` writes them

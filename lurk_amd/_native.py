@@ -196,6 +196,14 @@ SIGNATURES = {
     "lurkhip_proof_read": (_i32, [_p, _u32p, C.c_uint64]),
     "lurkhip_proof_free": (_i32, [_p]),
     "lurkhip_quotient_dev": (_i32, [_p, _p, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
+    "lurkhip_comm_unique_id": (_i32, [_p]),
+    "lurkhip_comm_create": (_i32, [_p, _p, _i32, _i32, C.POINTER(_p)]),
+    "lurkhip_comm_destroy": (_i32, [_p, _p]),
+    "lurkhip_comm_info": (_i32, [_p, C.POINTER(_i32), C.POINTER(_i32)]),
+    "lurkhip_exchange_roots_dev": (_i32, [_p, _p, _u32p, _i32, _u32p]),
+    "lurkhip_exchange_roots": (_i32, [_p, _p, _u32p, _u32p, _i32, _u32p]),
+    "lurkhip_reduce_sums_dev": (_i32, [_p, _p, _p, _u32p]),
+    "lurkhip_reduce_sums": (_i32, [_p, _p, _u32p, _i32, _u32p]),
 }
 
 

@@ -1,0 +1,84 @@
+"""`Comm`: the RCCL communicator of a multi-GPU proof behind the lurkhip C ABI (csrc/comm.cpp, include/lurkhip.h).
+
+The two collectives of a sharded proof -- the all-gather of (shard index, main-trace root) records every shard's transcript
+observes, and the all-reduce of the chips' cumulative sums the verifier's grand-sum check needs
+(/root/reference/src/lair/execute.rs:186-241, /root/reference/src/lair/lair_chip.rs:104-139) -- run inside the library, on the
+context's stream.  The host only distributes the 128-byte communicator id: a Rust host over whatever started its ranks, this
+mirror over `torch.distributed.broadcast_object_list` (any backend; the id is host data)."""
+from __future__ import annotations
+
+import ctypes as C
+
+import numpy as np
+
+from . import _native as N
+from .context import Context, as_u32
+
+ID_BYTES = 128
+RECORD_WORDS = 9
+
+
+def unique_id() -> bytes:
+    buf = (C.c_uint8 * ID_BYTES)()
+    N.check(N.lib.lurkhip_comm_unique_id(C.addressof(buf)))
+    return bytes(buf)
+
+
+class Comm:
+    def __init__(self, ctx: Context, uid: bytes, rank: int, world: int):
+        if len(uid) != ID_BYTES:
+            raise ValueError("a communicator id is 128 bytes")
+        self.ctx, self.rank, self.world = ctx, rank, world
+        buf = (C.c_uint8 * ID_BYTES).from_buffer_copy(uid)
+        h = C.c_void_p()
+        ctx.check(N.lib.lurkhip_comm_create(ctx.handle, C.addressof(buf), rank, world, C.byref(h)))
+        self.handle = h
+
+    @classmethod
+    def from_process_group(cls, ctx: Context) -> "Comm":
+        """One communicator over the ranks of the initialised torch.distributed process group (rank 0 draws the id)."""
+        import torch.distributed as dist
+
+        rank, world = dist.get_rank(), dist.get_world_size()
+        box = [unique_id() if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        return cls(ctx, box[0], rank, world)
+
+    def close(self):
+        if getattr(self, "handle", None):
+            N.lib.lurkhip_comm_destroy(self.ctx.handle, self.handle)
+            self.handle = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def exchange_roots(self, shard_indices, roots):
+        """This rank's (index, root[8]) pairs -> the roots of ALL shards in shard order (lists of 8 ints)."""
+        idx = as_u32(np.asarray(shard_indices).reshape(-1))
+        r = as_u32(np.asarray(roots).reshape(-1, 8))
+        if len(idx) != len(r):
+            raise ValueError("one index per root")
+        out = np.zeros((len(idx) * self.world, 8), dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_exchange_roots(self.ctx.handle, self.handle, idx.ctypes.data, r.ctypes.data, len(idx), out.ctypes.data))
+        return [[int(x) for x in row] for row in out]
+
+    def reduce_sums(self, local_sums):
+        """Canonical extension-field elements (4 lanes each) of this rank -> the machine-wide sum, on every rank."""
+        s = as_u32(np.asarray(list(local_sums), dtype=np.int64).reshape(-1, 4))
+        out = np.zeros(4, dtype=np.uint32)
+        self.ctx.check(N.lib.lurkhip_reduce_sums(self.ctx.handle, self.handle, s.ctypes.data, len(s), out.ctypes.data))
+        return tuple(int(x) for x in out)
+
+    def exchange_roots_dev(self, records_dev, n_local: int, gathered_dev):
+        """Device-resident records ([n_local][9] words) -> [world * n_local][9] words in rank order; enqueued, not waited for."""
+        from .context import _addr
+
+        self.ctx.check(N.lib.lurkhip_exchange_roots_dev(self.ctx.handle, self.handle, _addr(records_dev), n_local, _addr(gathered_dev)))
+
+    def reduce_sums_dev(self, lanes_dev, total_dev):
+        from .context import _addr
+
+        self.ctx.check(N.lib.lurkhip_reduce_sums_dev(self.ctx.handle, self.handle, _addr(lanes_dev), _addr(total_dev)))

@@ -24,7 +24,7 @@
 //  * k_mid's tiles are at most 64 KiB (16 columns for 2^10-row tiles), two workgroups per CU: one's exchange and load/store
 //    phases run under the other's butterflies.
 //
-// Index arithmetic: tools/lde_model.py is this file's decomposition in numpy, checked against oracle/stark.py.
+// Index arithmetic: tools/lde_model.py is this file's decomposition in numpy, checked there against the CPU restatement of the LDE.
 #include <stdlib.h>
 
 #include <algorithm>

@@ -45,11 +45,17 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def exchange_roots(local_roots, device="cpu", shard_indices=None):
+def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None):
     """local_roots: [k][8] roots of this rank's shards (every rank passes the same k; pad with zeros otherwise).
+    `comm` (lurk_amd.comm.Comm, with shard_indices): the all-gather runs behind the C ABI on RCCL (lurkhip_exchange_roots) instead
+    of torch.distributed -- the route a Rust host takes; the gloo CPU tests and single-process runs keep the torch path.
     Returns the roots of all shards ordered by shard index: the round-robin layout of `assign_shards` undone, or -- with
     `shard_indices` (this rank's shard numbers, same order as local_roots; any assignment, e.g. assign_shards_balanced) -- by the
     indices that travel with the roots."""
+    if comm is not None:
+        if shard_indices is None:
+            raise ValueError("the C-ABI exchange carries the shard indices with the roots")
+        return comm.exchange_roots(shard_indices, local_roots)
     import torch
 
     local = torch.tensor(np.asarray(local_roots, dtype=np.int64).reshape(-1, 8), device=device)
@@ -77,10 +83,12 @@ def exchange_roots(local_roots, device="cpu", shard_indices=None):
     return [[int(x) for x in gathered[s % world][s // world]] for s in range(k * world)]
 
 
-def reduce_cumulative_sums(local_sums, device="cpu"):
+def reduce_cumulative_sums(local_sums, device="cpu", comm=None):
     """local_sums: iterable of extension-field elements (4 canonical lanes each): the cumulative sums of every chip of
     every shard this rank proved.  Returns the machine-wide total (4 lanes, reduced mod p) on every rank; the proof
-    set is consistent iff it is zero."""
+    set is consistent iff it is zero.  `comm`: behind the C ABI on RCCL (lurkhip_reduce_sums)."""
+    if comm is not None:
+        return comm.reduce_sums(local_sums)
     import torch
 
     acc = np.zeros(4, dtype=np.int64)
@@ -111,12 +119,14 @@ class RankStep:
     phase 2: this rank's shards proved with clones of that transcript, two in flight when the rank has several (`prove_lanes`);
     check:   the extension-field cumulative sums all-reduced as 4 x int64 (`reduce_cumulative_sums`): each rank's own sum is
              non-zero, the total must vanish (/root/reference/src/lair/execute.rs:186-241 shards, lair_chip.rs:104-139).
-    `device` is where the two tiny collectives' tensors live: "cuda" over RCCL, "cpu" over gloo or without a process group."""
+    `device` is where the two tiny collectives' tensors live: "cuda" over RCCL, "cpu" over gloo or without a process group;
+    with `comm` both collectives run inside the library (lurkhip_exchange_roots / lurkhip_reduce_sums on the context's stream)."""
 
-    def __init__(self, machine, vk_root, public_values, prepared_all, shard_indices, num_queries, pow_bits, device="cpu", lane_ctx=None):
+    def __init__(self, machine, vk_root, public_values, prepared_all, shard_indices, num_queries, pow_bits, device="cpu", lane_ctx=None, comm=None):
         self.machine, self.vk_root, self.pv = machine, vk_root, list(public_values)
         self.prepared_all, self.mine = prepared_all, list(shard_indices)
         self.num_queries, self.pow_bits, self.device, self.lane_ctx = num_queries, pow_bits, device, lane_ctx
+        self.comm = comm        # lurk_amd.comm.Comm: the collectives behind the C ABI (RCCL); None: torch.distributed / single process
         self.host_ms = {}       # host milliseconds spent in the two collectives, summed over calls
         self.calls = 0
         self.rank_sums = []     # this rank's own sum, per call
@@ -150,7 +160,7 @@ class RankStep:
         import time
 
         t = time.perf_counter()
-        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine)
+        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine, comm=self.comm)
         self.host_ms["exchange_roots"] = self.host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t) * 1e3
         return self.roots
 
@@ -177,7 +187,7 @@ class RankStep:
             mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % P
         self.rank_sums.append(tuple(int(x) for x in mine_sum))
         t = time.perf_counter()
-        self.grand_sums.append(reduce_cumulative_sums(cs, device=self.device))
+        self.grand_sums.append(reduce_cumulative_sums(cs, device=self.device, comm=self.comm))
         self.host_ms["reduce_sums"] = self.host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t) * 1e3
         self.calls += 1
         self.last_proofs = proofs
