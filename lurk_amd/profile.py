@@ -67,6 +67,35 @@ class ProtocolProfile(C.Structure):
             p.p16_diag[:] = [int(x) for x in d["p16_diag"]]
         return p
 
+    @classmethod
+    def sphinx(cls, vector_file: str | None = None) -> "ProtocolProfile":
+        """sphinx's `BabyBearPoseidon2` as far as this repository can state it: the `p3-monty-diffusion` preset (power-of-two internal
+        diagonal, layer scaled by 2^-32) with the width-16 round constants RC_16_30 of an upstream vector file
+        (tests/golden/upstream/*.json, key "profile.rc_16_30", written by tools/upstream_dump from the real crates -- tools/pin_s1.sh).
+        The constants are not in the reference tree, so no such file ships: without one this raises."""
+        import glob
+        import json
+        import os
+
+        if vector_file is None:
+            here = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+            found = sorted(glob.glob(os.path.join(here, "tests", "golden", "upstream", "*.json")))
+            if not found:
+                raise FileNotFoundError("no upstream vector file: run tools/pin_s1.sh on a machine with cargo (sphinx's RC_16_30 are not in the reference tree)")
+            vector_file = found[0]
+        with open(vector_file) as fh:
+            prof = dict(json.load(fh).get("profile", {}))
+        base = prof.pop("preset", "p3-monty-diffusion")
+        rc = prof.pop("rc_16_30", None)
+        if rc is None:
+            raise ValueError(f"{vector_file} carries no profile.rc_16_30")
+        if len(rc) != 30 or any(len(r) != 16 for r in rc):
+            raise ValueError("RC_16_30 is 30 rounds of 16 constants")
+        # rounds 0..3 and 17..20 are the external ones, 4..16 the internal ones (lane 0) [UPSTREAM-RECALL: sphinx inner_perm]
+        prof["p16_ext_rc"] = [list(r) for r in rc[0:4]] + [list(r) for r in rc[17:21]]
+        prof["p16_int_rc"] = [r[0] for r in rc[4:17]]
+        return cls.from_dict(prof, base=base)
+
     def install(self, ctx) -> None:
         ctx.check(N.lib.lurkhip_set_protocol_profile(ctx.handle, C.byref(self)))
 

@@ -147,3 +147,25 @@ def test_default_transcript_tripwire(oracle):
     for k, v in doc["profile_scalars"].items():
         assert lib[k] == v, k
     assert gen.run(os_.Profile(challenger_squeeze=16)) != doc["outputs"]
+
+
+def test_sphinx_preset_takes_its_round_constants_from_a_vector_file(tmp_path):
+    """tools/upstream_dump writes RC_16_30 into the vector file's profile; `ProtocolProfile.sphinx` builds the profile from it
+    (external rounds 0..3 and 17..20, internal rounds 4..16 lane 0) on top of the p3-monty-diffusion preset -- and refuses to
+    invent the constants when no file exists (none ships: they are not in the reference tree)."""
+    import json
+
+    from lurk_amd.profile import ProtocolProfile
+
+    rc = [[(1000 * r + c) % 2013265921 for c in range(16)] for r in range(30)]
+    f = tmp_path / "sphinx.json"
+    f.write_text(json.dumps({"source": "synthetic", "profile": {"rc_16_30": rc, "preset": "p3-monty-diffusion"}}))
+    p = ProtocolProfile.sphinx(str(f)).to_dict()
+    base = ProtocolProfile.preset("p3-monty-diffusion").to_dict()
+    assert p["p16_ext_rc"] == [x for r in rc[0:4] + rc[17:21] for x in r]
+    assert p["p16_int_rc"] == [r[0] for r in rc[4:17]] and p["p16_rounds_p"] == 13
+    assert p["p16_diag"] == base["p16_diag"] and p["p16_internal_scale"] == base["p16_internal_scale"]
+    bad = tmp_path / "bad.json"
+    bad.write_text(json.dumps({"profile": {}}))
+    with pytest.raises(ValueError):
+        ProtocolProfile.sphinx(str(bad))
