@@ -56,6 +56,17 @@ typedef enum {
 /* ABI version of this header (bumped on any signature change). */
 int32_t lurkhip_abi_version(void);
 
+/* Threads.  The reference calls this boundary from rayon workers (`Chipset::populate_witness` per row, `generate_trace` per chip:
+ * /root/reference/src/lair/trace.rs:86-132,388-406, /root/reference/src/lair/chipset.rs:9-47).  The contract here:
+ *   - contexts are independent: any number of host threads may work on their OWN contexts at once (one stream and one pool each);
+ *   - ONE context may also be used from several threads: every entry point holds the context's lock until it returns, so the
+ *     calls serialise (results are exactly those of some sequential order).  The `*_free` entry points, lurkhip_malloc /
+ *     lurkhip_free and lurkhip_pool_stats only take the pool's lock and never wait for a long call.  lurkhip_last_error is
+ *     per context, not per thread: with several threads on one context, read it before the next call of any of them;
+ *   - host-side objects (toplevel, record, AIR) are read-only in every entry point that takes them `const` and may be shared;
+ *   - an entry point makes the context's HIP device current on the calling thread for its duration and restores the previous
+ *     one before it returns.
+ * tests/test_concurrency_gpu.py holds the contract; tools/tsan_host.sh runs the host-only threads under ThreadSanitizer. */
 /* Creates a context on HIP device `device_id` with its own non-blocking stream. */
 int32_t lurkhip_ctx_create(int32_t device_id, lurkhip_ctx** out);
 /* Same with a stream priority: 0 = the device's default, > 0 lower, < 0 higher (clamped to the device's range), for a context

@@ -882,7 +882,7 @@ int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* 
 }
 
 int32_t lurkhip_commitment_free(lurkhip_ctx* ctx, lurkhip_commitment* c) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     if (!c) return LURKHIP_OK;
     free_commitment(ctx, c);
     return LURKHIP_OK;

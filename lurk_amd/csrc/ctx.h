@@ -58,6 +58,11 @@ struct lurkhip_ctx {
     bool side_used[N_SIDE] = {false, false, false, false};
     bool defer_releases = false;
     std::vector<void*> deferred;
+    // One API call on a context at a time: every entry point holds this lock for its duration (LH_CHECK_CTX), so that calls from
+    // several host threads on ONE context serialise instead of racing on its arenas, caches and error string.  Recursive: entry
+    // points call entry points.  The entry points that only hand pooled memory back (`*_free`) take pool_mu alone
+    // (LH_CHECK_CTX_NOLOCK): a proving thread may release a shard's inputs while the staging thread is inside an upload call.
+    std::recursive_mutex api_mu;
     std::mutex pool_mu;  // a streaming prover releases one shard's inputs on its proving thread while the next shard's are allocated on its staging thread
     // page-locked staging of the row-stream uploads (lair_api.cpp: lurkhip_func_trace_prepare_many): grow-only, a buffer is reused by a
     // later call once its `prep_done` (recorded behind the last upload that read it) has passed
@@ -136,14 +141,40 @@ void span_switch(lurkhip_ctx* ctx, const char* from, const char* to, int level =
 
 }  // namespace lurkhip
 
-// Every entry point starts here: the calling thread's current device becomes the context's (a new host thread starts on
-// device 0 -- the lanes' worker threads of a rank that owns GPU 3 would otherwise launch on streams of another device).
-#define LH_CHECK_CTX(ctx)                                                            \
-    do {                                                                             \
-        if (!(ctx)) return lurkhip::set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null ctx"); \
-        if (hipSetDevice((ctx)->device) != hipSuccess)                               \
-            return lurkhip::set_error((ctx), LURKHIP_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device); \
-    } while (0)
+// Every entry point starts here.  The context's lock is held until the entry point returns (see lurkhip_ctx::api_mu), and the
+// calling thread's current HIP device is the context's for that time: a new host thread starts on device 0 -- the lanes' worker
+// threads of a rank that owns GPU 3 would otherwise launch on streams of another device -- and is put back afterwards (ADVICE
+// round 3: a caller's later torch.empty(device="cuda") must not land on the context's device because it proved something).
+namespace lurkhip {
+struct CtxEntry {
+    lurkhip_ctx* ctx;
+    int prev = -1;
+    bool ok = true;
+    explicit CtxEntry(lurkhip_ctx* c, bool lock) : ctx(c), locked(lock) {
+        if (locked) c->api_mu.lock();
+        if (hipGetDevice(&prev) != hipSuccess) prev = -1;
+        if (prev != c->device && hipSetDevice(c->device) != hipSuccess) ok = false;
+    }
+    ~CtxEntry() {
+        if (prev >= 0 && prev != ctx->device) (void)hipSetDevice(prev);
+        if (locked) ctx->api_mu.unlock();
+    }
+    CtxEntry(const CtxEntry&) = delete;
+    CtxEntry& operator=(const CtxEntry&) = delete;
+
+   private:
+    bool locked;
+};
+}  // namespace lurkhip
+#define LH_ENTRY_CAT2(a, b) a##b
+#define LH_ENTRY_CAT(a, b) LH_ENTRY_CAT2(a, b)
+#define LH_CHECK_CTX_IMPL(ctx, lock)                                                                              \
+    if (!(ctx)) return lurkhip::set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null ctx");                          \
+    lurkhip::CtxEntry LH_ENTRY_CAT(lh_entry_, __LINE__)((ctx), (lock));                                            \
+    if (!LH_ENTRY_CAT(lh_entry_, __LINE__).ok)                                                                     \
+    return lurkhip::set_error((ctx), LURKHIP_ERR_HIP, "hipSetDevice(%d) failed", (ctx)->device)
+#define LH_CHECK_CTX(ctx) LH_CHECK_CTX_IMPL(ctx, true)
+#define LH_CHECK_CTX_NOLOCK(ctx) LH_CHECK_CTX_IMPL(ctx, false)
 
 #define LH_HIP(ctx, expr)                                                                              \
     do {                                                                                               \

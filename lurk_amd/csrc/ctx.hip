@@ -497,7 +497,7 @@ int32_t lurkhip_event_destroy(void* event) {
 const char* lurkhip_last_error(lurkhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
 
 int32_t lurkhip_malloc(lurkhip_ctx* ctx, size_t bytes, void** dev_ptr) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     LH_ARG(ctx, dev_ptr != nullptr, "null dev_ptr");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipMalloc(dev_ptr, bytes ? bytes : 16));
@@ -505,7 +505,7 @@ int32_t lurkhip_malloc(lurkhip_ctx* ctx, size_t bytes, void** dev_ptr) {
 }
 
 int32_t lurkhip_free(lurkhip_ctx* ctx, void* dev_ptr) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     if (!dev_ptr) return LURKHIP_OK;
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
     LH_HIP(ctx, hipFree(dev_ptr));
@@ -609,7 +609,7 @@ int32_t lurkhip_pool_trim(lurkhip_ctx* ctx) {
 }
 
 int32_t lurkhip_pool_stats(lurkhip_ctx* ctx, uint64_t out[6]) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     if (!out) return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "lurkhip_pool_stats: out is null");
     std::lock_guard<std::mutex> lock(ctx->pool_mu);
     out[0] = ctx->pool_live_bytes;

@@ -739,7 +739,7 @@ int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, ui
 }
 
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     if (!p) return LURKHIP_OK;
     lurkhip::pool_release(ctx, p->dev);
     if (p->host_keep) {

@@ -276,6 +276,7 @@ int32_t check_common(lurkhip_ctx* ctx, int32_t width, size_t n, const void* in, 
 }
 
 int32_t run_dev(lurkhip_ctx* ctx, Op op, int32_t width, size_t n, const uint32_t* in, uint32_t* out, int32_t repr) {
+    LH_CHECK_CTX(ctx);
     LH_TRY(check_common(ctx, width, n, in, out, repr));
     LH_ARG(ctx, ((uintptr_t)in & 15) == 0 && ((uintptr_t)out & 15) == 0, "device buffers must be 16-byte aligned");
     LH_ARG(ctx, op != Op::Narrow || out, "null trace buffer");
@@ -284,6 +285,7 @@ int32_t run_dev(lurkhip_ctx* ctx, Op op, int32_t width, size_t n, const uint32_t
 }
 
 int32_t run_host(lurkhip_ctx* ctx, Op op, int32_t width, size_t n, const uint32_t* in, uint32_t* out, int32_t repr) {
+    LH_CHECK_CTX(ctx);  // held for the whole call: the host variants share the context's scratch arenas
     LH_TRY(check_common(ctx, width, n, in, out, repr));
     if (n == 0) {
         // an empty batch still has a trace: one zero row (0.next_power_of_two() == 1, poseidon/trace.rs:20-23)

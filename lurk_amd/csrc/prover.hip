@@ -190,7 +190,7 @@ int32_t lurkhip_setup(lurkhip_ctx* ctx, int32_t n_prep, const uint32_t* const* p
 }
 
 int32_t lurkhip_pk_free(lurkhip_ctx* ctx, lurkhip_pk* pk) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     if (!pk) return LURKHIP_OK;
     if (pk->commit) free_commitment(ctx, pk->commit);
     delete pk;
@@ -232,7 +232,7 @@ int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* con
 }
 
 int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* sh) {
-    LH_CHECK_CTX(ctx);
+    LH_CHECK_CTX_NOLOCK(ctx);
     if (!sh) return LURKHIP_OK;
     if (sh->main_commit) free_commitment(ctx, sh->main_commit);
     delete sh;
