@@ -506,6 +506,12 @@ def main():
             if errors:
                 raise errors[0]
 
+        # placement of the lanes' streams (a query, independent of load): a busy kernel alone on the main stream against one on each
+        # lane's stream together -- lanes on a shared hardware queue would read twice the time and never overlap their proofs
+        lane_placement = []
+        for _, cx_, _ in extra_lanes:
+            alone_s, both_s = ctx.overlap_probe(cx_)
+            lane_placement.append({"alone_ms": alone_s * 1e3, "both_ms": both_s * 1e3, "streams_run_beside_each_other": bool(both_s < 1.5 * alone_s)})
         run_lanes(2 * lanes, [])  # warm every lane (pools, tables)
         fence()
         for _, cx_, _ in extra_lanes:
@@ -702,7 +708,12 @@ def main():
         for lg, w in r:
             log_n = lg - LOG_BLOWUP
             lde_alg_bytes += 12 * w * (1 << log_n)
-            lde_pass_bytes += 3 * max(1, -(-log_n // ntt_log_tile)) * 2 * (1 << log_n) * w * 4
+            # transfers of the implementation: the grouped route (2^5 .. 2^20 rows) moves a matrix 9 times above 2^10 rows (k_in r + w,
+            # k_mid r + 2 w, k_out 2 r + 2 w) and 3 times below (one fused kernel); ntt.hip's three transforms r + w per pass otherwise
+            if 5 <= log_n <= 20:
+                lde_pass_bytes += (9 if log_n > 10 else 3) * (1 << log_n) * w * 4
+            else:
+                lde_pass_bytes += 3 * max(1, -(-log_n // ntt_log_tile)) * 2 * (1 << log_n) * w * 4
     lde_ms_step = rs["lde"][0] / rs_steps
     lde_alg = lde_alg_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     lde_pass = lde_pass_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
@@ -720,10 +731,20 @@ def main():
             mul_frac = pmc.get("merkle_hash_mul_class_frac", 0.6)
             # instruction-mix ceiling: add-class at the full rate, mul-class at half rate, no overlap between the classes
             ceiling = 1.0 / ((1 - mul_frac) / VALU_FULL_RATE + mul_frac / VALU_HALF_RATE)
-            valu = {"achieved": pmc["merkle_hash_valu_tinst_s"], "unit": "T lane-instr/s", "peak_full_rate": VALU_FULL_RATE, "peak_half_rate": VALU_HALF_RATE,
-                    "mul_class_frac": mul_frac, "mix_ceiling": ceiling, "frac_of_mix_ceiling": pmc["merkle_hash_valu_tinst_s"] / ceiling,
-                    "frac_of_full_rate": pmc["merkle_hash_valu_tinst_s"] / VALU_FULL_RATE,
-                    "source": "profiles (static): SQ_INSTS_VALU x 64 lanes / kernel time"}
+            # `achieved` is LIVE: the hashing launches' instruction count is a property of the code and the shapes (deterministic; the
+            # committed PMC pass counted it: SQ_INSTS_VALU x 64 lanes over k_row_sponges + the level kernels of one step), their time
+            # is measured in THIS run (HIP events on the library's stream, the one-proof-at-a-time pass)
+            insts = pmc.get("merkle_hash_valu_lane_insts_per_step")
+            if insts and hash_ms_step > 0:
+                live = insts * len(mine) / (hash_ms_step * 1e-3) / 1e12
+                src_v = ("instruction count from the committed PMC pass (profiles/pmc_traffic.json: SQ_INSTS_VALU x 64 lanes of the hashing launches of one step, "
+                         "deterministic) / the hashing launches' HIP-event time measured live in this run")
+            else:
+                live, src_v = pmc["merkle_hash_valu_tinst_s"], "profiles (static): SQ_INSTS_VALU x 64 lanes / kernel time of the PMC pass"
+            valu = {"achieved": live, "unit": "T lane-instr/s", "peak_full_rate": VALU_FULL_RATE, "peak_half_rate": VALU_HALF_RATE,
+                    "mul_class_frac": mul_frac, "mix_ceiling": ceiling, "frac_of_mix_ceiling": live / ceiling,
+                    "frac_of_full_rate": live / VALU_FULL_RATE, "static_pmc_rate": pmc["merkle_hash_valu_tinst_s"],
+                    "source": src_v}
     except Exception:
         pass
 
@@ -798,6 +819,12 @@ def main():
             "steps": args.steps,
             "warmup": args.warmup,
             "ms_per_step": ms_per_step,
+            # two different quantities, under two names: `value` / `ms_per_step` are THROUGHPUT of the timed schedule
+            # (proofs_in_flight independent proofs of the shard overlapping on the GPU); `proof_latency_ms` is ONE proof at a time on one
+            # stream -- the quantity rounds 1-2 reported as ms_per_step -- measured in the same run before the timed region
+            "proofs_in_flight": lanes if world == 1 else (2 if len(mine) > 1 else 1),
+            "proof_latency_ms": sequential["ms_per_step"] if sequential else (ms_per_step if lanes < 2 and pipe is None else None),
+            "eval_steps_per_s_one_proof_at_a_time": sequential["eval_steps_per_s"] if sequential else None,
             "higher_is_better": True,
             "scaling": "weak",
             "vs_baseline": None,
@@ -850,6 +877,7 @@ def main():
                                   "collectives on one thread in a fixed order" if pipe is not None else None),
                 "proofs_in_flight": lanes,
                 "lane_stagger_ms": (stagger_ms if lanes >= 2 else None),
+                "lane_placement": (lane_placement if lanes >= 2 else None),
                 "schedule": (f"the K timed steps are K independent proofs of the shard, {lanes} in flight on {lanes} HIP streams / contexts of the GPU (prove lanes); "
                              "`sequential` is one proof at a time, measured before the timed region; stages_ms / roofline.hbm come from that sequential pass "
                              "(a kernel alone on the device), stages_ms_in_flight from the timed region (spans of the lanes overlap in time)") if lanes >= 2
@@ -865,14 +893,16 @@ def main():
                 "bound": "valu" if valu else "hbm",
                 "kernel": "Merkle hashing (k_row_sponges + k_level_digests + k_level_coop; trees of 2^16 leaves and more), all launches of a step",
                 "achieved": valu["achieved"] if valu else achieved,
-                "peak": valu["mix_ceiling"] if valu else HBM_PEAK_GBS,
+                # the guide's number: 78.6 T lane-instr/s = 256 CUs x 4 SIMD-32 x 2.4 GHz, one VALU instruction per two cycles
+                # (MI355X_MICROARCH.md "Wave scheduling"); the ceiling of THIS instruction mix is beside it (int32_valu.mix_ceiling)
+                "peak": VALU_FULL_RATE if valu else HBM_PEAK_GBS,
                 "unit": "T lane-instr/s" if valu else "GB/s",
-                "frac": valu["frac_of_mix_ceiling"] if valu else achieved / HBM_PEAK_GBS,
+                "frac": valu["frac_of_full_rate"] if valu else achieved / HBM_PEAK_GBS,
                 "int32_valu": valu,
                 "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "note": "algorithmic bytes / summed HIP-event time of the hashing launches, measured live in this run"},
                 "traffic": traffic,
-                "also": {"kernel": "coset LDE passes (k_ntt_pass), all launches of a step", "bound": "hbm",
+                "also": {"kernel": "coset LDE (lde.hip: k_lde_in / k_lde_mid / k_lde_out per height group; ntt.hip for the shapes it does not take), all launches of a step", "bound": "hbm",
                          "achieved": lde_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_alg / HBM_PEAK_GBS,
                          "algorithmic_bytes_per_step": lde_alg_bytes, "algorithmic_bytes_rule": "SURVEY 8(d): 12 w B per trace row (read 4w, write 8w)",
                          "pass_traffic_bytes_per_step": lde_pass_bytes, "pass_traffic_GBs": lde_pass, "ms_per_step": lde_ms_step,
@@ -880,7 +910,7 @@ def main():
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,
                 "ms_per_step": hash_ms_step,
-                "note": "int32-VALU bound: ceil(w/8) width-16 Poseidon2 permutations (4.76 k int32 instructions each, ~56 % of them four-cycle multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD): k_row_sponges takes 19.9 k SIMD cycles per wave-permutation, the rate of the permutation alone on registers (tools/ubench_perm.hip: 20.8-21.1 k), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4); `frac` = achieved VALU rate / the ceiling of its instruction mix (static PMC pass: profiles/pmc_traffic.json), `hbm.frac` = the HBM fraction measured live",
+                "note": "`frac` = achieved int32 VALU rate / the guide's 78.6 T lane-instr/s full rate (achieved: static instruction count / time measured live); int32_valu.frac_of_mix_ceiling is against the ceiling of this instruction mix (60 % four-cycle multiply-class).  int32-VALU bound: ceil(w/8) width-16 Poseidon2 permutations (4.76 k int32 instructions each, ~56 % of them four-cycle multiply-class) per w*4-byte row; throughput-bound on instruction issue (same speed at 4 and 8 waves per SIMD): k_row_sponges takes 19.9 k SIMD cycles per wave-permutation, the rate of the permutation alone on registers (tools/ubench_perm.hip: 20.8-21.1 k), i.e. ~0.3 TB/s algorithmic is this kernel's ceiling (DESIGN.md 3.4); `frac` = achieved VALU rate / the ceiling of its instruction mix (static PMC pass: profiles/pmc_traffic.json), `hbm.frac` = the HBM fraction measured live",
             },
         }
         if world == 1 and spr == 1 and not args.no_cpu_baseline and args.workload != "eval-only":

@@ -77,6 +77,10 @@ int32_t lurkhip_ctx_create_with_priority(int32_t device_id, int32_t priority, lu
  * busy kernel is timed on both until one overlaps (the runtime deals streams to a few hardware queues without saying which; two
  * streams on one queue run one kernel at a time).  For the second proof in flight (lurk_amd.prover.lane_context). */
 int32_t lurkhip_ctx_create_beside(lurkhip_ctx* other, lurkhip_ctx** out);
+/* Do the two contexts' streams run BESIDE each other?  alone_s = seconds of a 0.5 ms busy kernel on `a`'s stream, both_s = of one on
+ * each stream launched together: about alone_s on different hardware queues, about twice that on a shared one.  (What
+ * lurkhip_ctx_create_beside measures while it chooses; here as a query, for a placement check that does not depend on load.) */
+int32_t lurkhip_ctx_overlap_probe(lurkhip_ctx* a, lurkhip_ctx* b, double* alone_s, double* both_s);
 /* Same, but all work is enqueued on the caller's hipStream_t (e.g. torch's current stream). */
 int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhip_ctx** out);
 int32_t lurkhip_ctx_destroy(lurkhip_ctx* ctx);

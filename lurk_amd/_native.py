@@ -62,6 +62,7 @@ SIGNATURES = {
     "lurkhip_ctx_create_with_priority": (_i32, [_i32, _i32, C.POINTER(_p)]),
     "lurkhip_ctx_create_on_stream": (_i32, [_i32, _p, C.POINTER(_p)]),
     "lurkhip_ctx_create_beside": (_i32, [_p, C.POINTER(_p)]),
+    "lurkhip_ctx_overlap_probe": (_i32, [_p, _p, C.POINTER(C.c_double), C.POINTER(C.c_double)]),
     "lurkhip_ctx_destroy": (_i32, [_p]),
     "lurkhip_ctx_sync": (_i32, [_p]),
     "lurkhip_event_record": (_i32, [_p, C.POINTER(_p)]),

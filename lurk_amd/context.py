@@ -64,6 +64,13 @@ class Context:
     def check(self, status: int):
         N.check(status, self.handle)
 
+    def overlap_probe(self, other: "Context"):
+        """(alone_s, both_s): a short busy kernel alone on this context's stream, then one on each context's stream together --
+        about equal when the streams sit on different hardware queues, both_s about twice alone_s when they share one."""
+        a, b = C.c_double(), C.c_double()
+        self.check(N.lib.lurkhip_ctx_overlap_probe(self.handle, other.handle, C.byref(a), C.byref(b)))
+        return a.value, b.value
+
     def sync(self):
         self.check(N.lib.lurkhip_ctx_sync(self.handle))
 

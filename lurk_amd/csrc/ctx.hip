@@ -420,6 +420,21 @@ int32_t lurkhip_ctx_create_beside(lurkhip_ctx* other, lurkhip_ctx** out) {
     return LURKHIP_OK;
 }
 
+// The placement check behind lurkhip_ctx_create_beside as a query: a 0.5 ms one-wave busy kernel alone on `a`'s stream, then one
+// on each stream together.  Streams on different hardware queues take the time of one; streams sharing a queue take two.  Both
+// streams are drained first; the probe occupies one wave of the device for about a millisecond.
+int32_t lurkhip_ctx_overlap_probe(lurkhip_ctx* a, lurkhip_ctx* b, double* alone_s, double* both_s) {
+    LH_CHECK_CTX(a);
+    if (!b || !alone_s || !both_s) return set_error(a, LURKHIP_ERR_INVALID_ARG, "null argument");
+    if (a->device != b->device) return set_error(a, LURKHIP_ERR_INVALID_ARG, "the contexts are on different devices");
+    (void)hipStreamSynchronize(b->stream);
+    (void)occupy_both(a->stream, b->stream, PLACE_TICKS / 10);  // warm both
+    *alone_s = occupy_alone(a->stream, PLACE_TICKS);
+    *both_s = occupy_both(a->stream, b->stream, PLACE_TICKS);
+    LH_HIP(a, hipGetLastError());
+    return LURKHIP_OK;
+}
+
 int32_t lurkhip_ctx_create_on_stream(int32_t device_id, void* hip_stream, lurkhip_ctx** out) {
     return create_common(device_id, hip_stream, true, out);
 }

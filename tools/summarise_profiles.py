@@ -19,8 +19,8 @@ bench = json.load(open(bench_json))
 
 
 def kname(s):
-    m = re.search(r"(k_[a-z_0-9]+|jit_[a-z_]+)", s)
-    return m.group(1) if m else s[:40]
+    m = re.search(r"(k_lde_[a-z]+<[0-9, a-z]*>|k_[a-z_0-9]+|jit_[a-z_]+)", s)  # the grouped LDE's kernels keep their tile shape
+    return m.group(1).replace(" ", "") if m else s[:40]
 
 
 res = {}
@@ -62,7 +62,8 @@ with open(f"profiles/{prefix}_pmc_sq_per_kernel.csv", "w") as f:
         rate = v["SQ_INSTS_VALU"] * 64 / (dur[n] * 1e-9) / 1e12 if dur[n] else 0
         f.write(f"{n},{cnt[n]},{dur[n] / 1e6:.3f}," + ",".join(f"{v[c]:.4g}" for c in cols) + f",{rate:.2f}\n")
 hv = sum(tot[k]["SQ_INSTS_VALU"] for k in HASH) * 64 / (sum(dur[k] for k in HASH) * 1e-9) / 1e12
-NTT = [k for k in res["FETCH_SIZE"][0] if k.startswith("k_ntt_pass")]
+NTT = [k for k in res["FETCH_SIZE"][0] if k.startswith("k_ntt_pass") or k.startswith("k_lde_")]  # every coset-LDE launch (lde.hip + ntt.hip)
+hash_lane_insts = sum(tot[k]["SQ_INSTS_VALU"] for k in HASH) * 64
 ntt_bytes = (2 * sum(res["FETCH_SIZE"][0][k] for k in NTT) + sum(res["WRITE_SIZE"][0][k] for k in NTT)) * 1024
 traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FETCH_SIZE and --pmc WRITE_SIZE, separate passes, bench.py --steps 1 --warmup 0 (profiles/{prefix}_pmc_hbm_per_kernel.csv)",
            "ntt_pass_bytes_per_step": ntt_bytes,
@@ -70,7 +71,8 @@ traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FE
            "fetch_factor": 2.0, "write_factor": 1.0,
            "ntt_pass_fetch_bytes_reported": sum(res["FETCH_SIZE"][0][k] for k in NTT) * 1024, "ntt_pass_write_bytes_reported": sum(res["WRITE_SIZE"][0][k] for k in NTT) * 1024,
            "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
-           "merkle_hash_valu_tinst_s": hv, "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
+           "merkle_hash_valu_tinst_s": hv, "merkle_hash_valu_lane_insts_per_step": hash_lane_insts,
+           "lde_kernels": sorted(NTT), "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
 json.dump(traffic, open(f"profiles/{prefix}_pmc_traffic.json", "w"), indent=1)
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)  # the copy bench.py reads (labelled static there)
 shutil.copy(f"gpurun_out/prof_{tag}/bench_kernel_stats.csv", f"profiles/{prefix}_full_prove_kernel_stats.csv")
