@@ -461,7 +461,7 @@ static PartLayout layout_parts(const std::vector<const std::vector<uint32_t>*>& 
     }
     l.regs_words = off;
     l.wp = w | 1u;
-    const size_t fixed = (size_t)off + 64 + (size_t)host.size() * 256;
+    const size_t fixed = (size_t)off + 64 + (size_t)host.size() * 512;  // row indices; per piece and lane one fold and one column sum
     l.staged = (fixed + 64u * l.wp) * 4 <= VM_LDS_BUDGET;
     l.lds_bytes = (fixed + (l.staged ? 64u * l.wp : 0u)) * 4;
     return l;

@@ -257,9 +257,11 @@ struct QuotientSink {
     const uint32_t* perm_l;
     uint32_t k = 0, col = 0;
     LazyEf folded;
+    ef sum_cols;        // sum of the permutation entries this piece's batch columns read (the running-sum constraint needs their total)
     int32_t next_w[8];  // alpha^(K-1-k), loaded one constraint ahead (see LogupAccum::next_pow)
     __device__ __forceinline__ void prime(uint32_t k_start) {
         folded.zero();
+        sum_cols = bb::ef_zero();
         seek(k_start);
     }
     __device__ __forceinline__ void seek(uint32_t k_next) {
@@ -292,6 +294,7 @@ struct QuotientSink {
     __device__ __forceinline__ void flush() {
         // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
         ef entry = ef_load(perm_l + 4 * col);
+        sum_cols = bb::ef_add(sum_cols, entry);
         assert_zero_ext(bb::ef_sub(sink_ef_mul(acc.den, entry), acc.numerator()));
         col++;
         acc.in_batch = 0;
@@ -364,19 +367,24 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     sink.prime(cons_wave ? first : a.n_cons + first);
     Runner::run(prog, wave, src, regs + a.parts.reg_off[wave] + lane, sink);
     if (sink.acc.in_batch) sink.flush();
+    // every batch column's entry of the local row was read by the piece that owns the column (QuotientSink::flush): the pieces
+    // hand their sums over with their folds, so that the local row is read once (round 4: the quotient kernels fetched the
+    // permutation LDE three times -- entries, local sum, next sum -- 7.3 GB against 5.4 per fib-mix step)
+    uint32_t* sums = folds + a.parts.n_parts * 256u;
     if (wave != 0) {
         const ef f = sink.folded.value();
 #pragma unroll
-        for (int c = 0; c < 4; c++) folds[(wave * 64u + lane) * 4 + c] = f.c[c];
+        for (int c = 0; c < 4; c++) {
+            folds[(wave * 64u + lane) * 4 + c] = f.c[c];
+            sums[(wave * 64u + lane) * 4 + c] = sink.sum_cols.c[c];
+        }
     }
     __syncthreads();
     if (wave != 0 || !live) return;
     // running-sum constraints (sphinx eval_permutation_constraints)
-    ef sum_l = bb::ef_zero(), sum_n = bb::ef_zero();
-    for (uint32_t c = 0; c + 1 < a.perm_w; c++) {
-        sum_l = bb::ef_add(sum_l, ef_load(perm_l + 4 * c));
-        sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
-    }
+    ef sum_l = sink.sum_cols, sum_n = bb::ef_zero();
+    for (uint32_t j = 1; j < a.parts.n_parts; j++) sum_l = bb::ef_add(sum_l, ef_load(sums + (j * 64u + lane) * 4));
+    for (uint32_t c = 0; c + 1 < a.perm_w; c++) sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
     const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1)), phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
     sink.seek(a.k_total - 3);
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));

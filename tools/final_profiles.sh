@@ -1,5 +1,5 @@
 #!/bin/bash
-# GPU box: everything profiles/r02_* is made from, at one state of the tree (then: python tools/summarise_profiles.py <tag> r02 gpurun_out/bench_<tag>.json)
+# GPU box: everything profiles/rNN_* is made from, at one state of the tree (then: python tools/summarise_profiles.py <tag> rNN gpurun_out/bench_<tag>.json)
 R=$GRAFT_REPO_ROOT; cd $R; tag=${1:-fin}
 python bench.py > gpurun_out/bench_$tag.json 2> gpurun_out/bench_$tag.err
 bash tools/prof_bench.sh $tag pmc > /dev/null 2>&1
