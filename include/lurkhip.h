@@ -274,6 +274,9 @@ int32_t lurkhip_commitment_root(lurkhip_ctx* ctx, lurkhip_commitment* c, uint32_
 /* Device pointer (Montgomery form) and shape of the LDE of matrix `index`. */
 int32_t lurkhip_commitment_matrix_dev(lurkhip_ctx* ctx, lurkhip_commitment* c, int32_t index,
                                       const uint32_t** lde_dev, uint32_t* log_height, uint32_t* width);
+/* Row pitch of that matrix in words: its width for every commitment made through this header's entry points; the prover's own
+ * commitments keep the matrices of one height as column ranges of one buffer with a 128-byte-aligned pitch. */
+int32_t lurkhip_commitment_matrix_pitch(lurkhip_ctx* ctx, lurkhip_commitment* c, int32_t index, uint32_t* pitch_words);
 /* Opens leaf `index` of the tallest LDE: the opened row of every matrix back to back (caller order;
  * matrix m at row index >> (log_max - log_height_m)) and the log_max sibling digests, leaf level first. */
 int32_t lurkhip_commitment_open(lurkhip_ctx* ctx, lurkhip_commitment* c, uint64_t index, uint32_t* rows,

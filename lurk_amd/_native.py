@@ -109,6 +109,7 @@ SIGNATURES = {
     "lurkhip_commitment_free": (_i32, [_p, _p]),
     "lurkhip_commitment_root": (_i32, [_p, _p, _u32p, _i32]),
     "lurkhip_commitment_matrix_dev": (_i32, [_p, _p, _i32, C.POINTER(_p), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
+    "lurkhip_commitment_matrix_pitch": (_i32, [_p, _p, _i32, C.POINTER(C.c_uint32)]),
     "lurkhip_commitment_open": (_i32, [_p, _p, C.c_uint64, _u32p, _u32p, _i32]),
     "lurkhip_trace_func_dev": (_i32, [_p, _u32p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _u32p, _u32p, _p, _u32p, _u32p, _i32]),
     "lurkhip_trace_mem_dev": (_i32, [_p, C.c_uint32, C.c_uint32, C.c_uint32, _u32p, _u32p, _u32p, _i32]),

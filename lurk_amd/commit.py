@@ -66,9 +66,16 @@ class Commitment:
         from .field import from_monty
 
         ptr, lh, w = self.matrix_dev(index)
-        out = np.empty((1 << lh, w), dtype=np.uint32)
-        self.ctx.d2h(out, ptr)
-        return from_monty(out)
+        pitch = C.c_uint32()
+        self.ctx.check(N.lib.lurkhip_commitment_matrix_pitch(self.ctx.handle, self.handle, index, C.byref(pitch)))
+        h, pitch = 1 << lh, pitch.value
+        if pitch == w:
+            out = np.empty((h, w), dtype=np.uint32)
+            self.ctx.d2h(out, ptr)
+            return from_monty(out)
+        flat = np.zeros(h * pitch, dtype=np.uint32)  # a column range of a wider buffer: rows are `pitch` words apart
+        self.ctx.d2h(flat[: (h - 1) * pitch + w], ptr)
+        return from_monty(np.ascontiguousarray(flat.reshape(h, pitch)[:, :w]))
 
 
 def _commit(ctx: Context, fn, mats, log_heights, widths, log_blowup, repr, keep_coeffs) -> Commitment:

@@ -18,6 +18,14 @@ struct lurkhip_commitment {
     bool owns_lde = true;
     std::vector<int> log_h;           // log2 of the LDE height
     std::vector<uint32_t> width;
+    // Row pitch of lde[i] in words.  Equal to width[i] for a matrix with its own buffer; the matrices of one height that went through
+    // the grouped LDE together (commit_impl with padded_groups) are column ranges of ONE buffer [2N][pitch], pitch = the group's
+    // total width rounded up to 32 words: every row, and every 32-column tile of the LDE's last pass, starts on a 128-byte line.
+    std::vector<uint32_t> pitch;
+    std::vector<char> lde_is_view;    // lde[i] points into a group buffer (owned through `owned`): not released on its own
+    std::vector<int> group;           // index of the matrix's group buffer, -1: its own buffer
+    std::vector<uint32_t> col_start;  // first column of the matrix inside its group buffer
+    std::vector<uint32_t*> group_base;
     std::vector<uint32_t*> coeffs;    // device, Montgomery, natural-order coefficients (N x w), may be null
     uint32_t* digests = nullptr;      // all levels back to back, level 0 first
     std::vector<size_t> level_off;    // in digests (units of 8 words)
@@ -150,7 +158,8 @@ const lurkhip_protocol_profile& profile_of(lurkhip_ctx* ctx);
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                     int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr,
-                    bool raw = false /* the matrices as given: no interpolation, no coset extension (lurkhip_mmcs_commit) */);
+                    bool raw = false /* the matrices as given: no interpolation, no coset extension (lurkhip_mmcs_commit) */,
+                    bool padded_groups = false /* the prover's own commitments: height groups in one aligned-pitch buffer (lurkhip_commitment::pitch) */);
 int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const std::vector<int>& log_heights,
                    const std::vector<uint32_t>& widths, lurkhip_commitment** out);
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m);

@@ -202,7 +202,8 @@ void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     for (void* p : c->early_scratch) pool_release(ctx, p);
     c->early_scratch.clear();
     if (c->owns_lde)
-        for (auto p : c->lde) pool_release(ctx, p);
+        for (size_t i = 0; i < c->lde.size(); i++)
+            if (i >= c->lde_is_view.size() || !c->lde_is_view[i]) pool_release(ctx, c->lde[i]);
     for (auto p : c->coeffs) pool_release(ctx, p);
     for (auto p : c->owned) pool_release(ctx, p);
     pool_release(ctx, c->digests);
@@ -220,7 +221,7 @@ namespace {
 constexpr int COLFILL_MATS = 24;
 struct ColFill {
     const uint32_t* base[COLFILL_MATS];
-    uint32_t width[COLFILL_MATS];
+    uint32_t width[COLFILL_MATS];      // row pitch in words (LeafCol::width is what the hashing kernels multiply a row index by)
     uint32_t start[COLFILL_MATS + 1];  // first column of matrix i in this launch's part of the table
     uint32_t n;
 };
@@ -255,7 +256,7 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
         for (uint32_t k = 0; k < a.n; k++) {
             const int m = idx[i0 + k];
             a.base[k] = c->lde[m];
-            a.width[k] = c->width[m];
+            a.width[k] = c->pitch[m];
             a.start[k + 1] = a.start[k] + c->width[m];
         }
         const uint32_t part = a.start[a.n];
@@ -506,6 +507,7 @@ int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const s
     c->coeffs.assign(mats.size(), nullptr);
     c->log_h = log_heights;
     c->width = widths;
+    c->pitch = widths;
     int32_t s = build_tree(ctx, c);
     if (s != LURKHIP_OK) {
         (void)stream_wait(ctx);
@@ -533,7 +535,7 @@ __global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restri
 
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
-                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw) {
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw, bool padded_groups) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
     LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
@@ -550,6 +552,10 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     c->coeffs.assign(n_mats, nullptr);
     c->log_h.resize(n_mats);
     c->width.assign(widths, widths + n_mats);
+    c->pitch.assign(widths, widths + n_mats);
+    c->lde_is_view.assign(n_mats, 0);
+    c->group.assign(n_mats, -1);
+    c->col_start.assign(n_mats, 0);
     std::vector<void*> uploads;  // host inputs staged in pooled device buffers (released, stream-ordered, once the LDEs are queued)
     auto fail = [&](int32_t s) {
         (void)stream_wait(ctx);
@@ -651,10 +657,36 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         }
         groups.swap(kept);
     }
+    // Padded group buffers (the prover's own commitments): the LDEs of a group are column ranges of ONE buffer [2N][pitch], pitch =
+    // the group's width rounded up to a 128-byte line, when that costs at most an eighth more memory -- the last LDE pass then
+    // writes whole lines (a 32-column tile of a 92-word row straddles two lines on every row) and every reader takes the pitch.
+    static const int pad_mode = getenv("LURKHIP_LDE_PADDED") ? atoi(getenv("LURKHIP_LDE_PADDED")) : 1;
+    if (padded_groups && pad_mode)
+        for (const GroupPlan& g : groups) {
+            uint32_t W = 0;
+            for (int i : g.idx) W += widths[i];
+            const uint32_t Wp = (W + 31u) & ~31u;
+            if (Wp == W && g.idx.size() == 1) continue;
+            if (pad_mode == 1 && (Wp - W) * 8 > W) continue;
+            uint32_t* base = nullptr;
+            TRY_C(pool_alloc(ctx, ((size_t)Wp << (g.log_n + log_blowup)) * sizeof(uint32_t), (void**)&base));
+            c->owned.push_back(base);
+            const int gi = (int)c->group_base.size();
+            c->group_base.push_back(base);
+            uint32_t at = 0;
+            for (int i : g.idx) {
+                c->lde[i] = base + at;
+                c->lde_is_view[i] = 1;
+                c->pitch[i] = Wp;
+                c->group[i] = gi;
+                c->col_start[i] = at;
+                at += widths[i];
+            }
+        }
     for (int i = 0; i < n_mats; i++) {
         const size_t bytes = ((size_t)widths[i] << log_heights[i]) * sizeof(uint32_t);
         c->log_h[i] = (int)log_heights[i] + log_blowup;
-        TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
+        if (!c->lde_is_view[i]) TRY_C(pool_alloc(ctx, bytes << log_blowup, (void**)&c->lde[i]));
         if (grouped[i]) continue;  // no coefficient buffer: the grouped LDE never writes coefficients
         // coefficient buffer: room for the chunk-tiled form when nobody asked to keep (row-major) coefficients
         coef_words[i] = (!keep_coeffs && !mats_on_host && !raw && log_blowup >= 1) ? ntt_tiled_words((int)log_heights[i], (int)widths[i]) : 0;
@@ -671,13 +703,14 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         const auto on_side = lane.on_side((uint32_t)g.log_n < SIDE_MAX_LOG_N);
         const uint32_t* ev[LDE_MAX_MATS];
         uint32_t* ld[LDE_MAX_MATS];
-        uint32_t gw[LDE_MAX_MATS];
+        uint32_t gw[LDE_MAX_MATS], gp[LDE_MAX_MATS];
         for (size_t m = 0; m < g.idx.size(); m++) {
             ev[m] = mats[g.idx[m]];
             ld[m] = c->lde[g.idx[m]];
             gw[m] = widths[g.idx[m]];
+            gp[m] = c->pitch[g.idx[m]];
         }
-        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false));
+        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false, gp));
         for (int i : g.idx) extended[i] = 1;
     }
     if (!mats_on_host && log_blowup >= 1) {
@@ -888,6 +921,13 @@ int32_t lurkhip_commitment_free(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     return LURKHIP_OK;
 }
 
+int32_t lurkhip_commitment_matrix_pitch(lurkhip_ctx* ctx, lurkhip_commitment* c, int32_t index, uint32_t* pitch_words) {
+    LH_CHECK_CTX_NOLOCK(ctx);
+    LH_ARG(ctx, c && pitch_words && index >= 0 && index < c->n_mats, "bad matrix index %d", index);
+    *pitch_words = c->pitch[index];
+    return LURKHIP_OK;
+}
+
 int32_t lurkhip_commitment_matrix_dev(lurkhip_ctx* ctx, lurkhip_commitment* c, int32_t index, const uint32_t** lde_dev,
                                       uint32_t* log_height, uint32_t* width) {
     LH_CHECK_CTX(ctx);
@@ -919,7 +959,7 @@ int32_t lurkhip_commitment_open(lurkhip_ctx* ctx, lurkhip_commitment* c, uint64_
     size_t off = 0;
     for (int m = 0; m < c->n_mats; m++) {
         uint64_t r = index >> (c->log_max - c->log_h[m]);
-        LH_HIP(ctx, hipMemcpyAsync(rows + off, c->lde[m] + r * c->width[m], c->width[m] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipMemcpyAsync(rows + off, c->lde[m] + r * c->pitch[m], c->width[m] * 4, hipMemcpyDeviceToHost, ctx->stream));
         off += c->width[m];
     }
     for (int l = 0; l < c->log_max; l++) {

@@ -25,7 +25,7 @@ int32_t point_weights_batch(lurkhip_ctx* ctx, const std::vector<WeightJob>& jobs
 // one matrix; column_dot_finish then sums the blocks of every matrix of the proof in one launch:
 // out_dev[out_off + (p * w + c) * 4 ..] = sum_{s < n_rows} mat[s][c] * u_p[s].
 size_t column_dot_partial_words(uint32_t w, size_t n_rows);
-int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
+int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t pitch /* words between rows */, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
                            uint32_t* partial_dev);
 // the narrow matrices (column_dot_is_narrow: the ones column_dot_partial gives to the slab kernel) of an opening in one launch
 constexpr int NARROW_DOT_MAX = 64;
@@ -35,6 +35,7 @@ struct NarrowDot {
     size_t n_rows;
     const uint32_t *u0, *u1;
     uint32_t* partial;
+    uint32_t pitch = 0;  // words between rows; 0: w
 };
 bool column_dot_is_narrow(uint32_t w);
 int32_t column_dot_partial_batch(lurkhip_ctx* ctx, const std::vector<NarrowDot>& items);
@@ -75,7 +76,7 @@ int32_t reduce_openings_narrow(lurkhip_ctx* ctx, const NarrowArgs& args);
 // reduced openings of one wide matrix (w > 128) as column slices of at most 128 words in one launch (fri.hip:
 // k_reduce_openings_wide).  Slice i covers columns c0[i] .. c0[i] + sw[i]; ys_p[i] = sum_j alpha^j y_p[c0[i] + j] and
 // apow_p[i] = (the matrix's alpha offset at point p) * alpha^c0[i].
-constexpr uint32_t WIDE_MAX_SLICES = 8;
+constexpr uint32_t WIDE_MAX_SLICES = 24;  // (round 4: a padded height group is reduced as slices of one wide matrix)
 struct WideArgs {
     const uint32_t* mat;
     uint32_t w;       // row pitch in words
@@ -116,6 +117,7 @@ struct OpenMat {
     const uint32_t* base;
     uint32_t width;
     uint32_t log_h;
+    uint32_t pitch = 0;  // row pitch in words; 0: the width (lurkhip_commitment::pitch)
 };
 // MMCS open_batch for n_queries indices at once: record q = [row of every matrix at (indices[q] >> shift) >>
 // (log_max - log_h) | log_max sibling digests].  out_dev == null only computes record_words.

@@ -115,7 +115,7 @@ __global__ void k_point_weights_batch(PwBatchArgs a, uint32_t g_m) {
 // wider matrices (w > 256) take one row per step in column chunks of 256.
 constexpr int DOT_ROWS = 1024;
 
-__device__ __forceinline__ void column_dot_body(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
+__device__ __forceinline__ void column_dot_body(const uint32_t* __restrict__ mat, uint32_t w, uint32_t pitch, size_t n_rows,
                                                 const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
                                                 uint32_t* __restrict__ partial) {
     __shared__ uint32_t sh[2][256][4];
@@ -144,7 +144,7 @@ __device__ __forceinline__ void column_dot_body(const uint32_t* __restrict__ mat
 #pragma unroll
                 for (int k = 0; k < UR; k++) {
                     const size_t rr = r + (size_t)k * R;
-                    m[k] = mat[rr * w + c];
+                    m[k] = mat[rr * pitch + c];
                     p0[k] = *reinterpret_cast<const uint4*>(u0 + 4 * rr);
                     p1[k] = *reinterpret_cast<const uint4*>((u1 ? u1 : u0) + 4 * rr);
                 }
@@ -159,7 +159,7 @@ __device__ __forceinline__ void column_dot_body(const uint32_t* __restrict__ mat
                 }
             }
             for (; r < row_end; r += R) {
-                const uint32_t m = mat[r * w + c];
+                const uint32_t m = mat[r * pitch + c];
                 const uint4 p0 = *reinterpret_cast<const uint4*>(u0 + 4 * r);
                 const int32_t w0[4] = {(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w};
                 l0.add_base_v(m, w0);
@@ -189,10 +189,10 @@ __device__ __forceinline__ void column_dot_body(const uint32_t* __restrict__ mat
         __syncthreads();
     }
 }
-__global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows,
+__global__ __launch_bounds__(256) void k_column_dot(const uint32_t* __restrict__ mat, uint32_t w, uint32_t pitch, size_t n_rows,
                                                      const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
                                                      uint32_t* __restrict__ partial) {
-    column_dot_body(mat, w, n_rows, u0, u1, partial);
+    column_dot_body(mat, w, pitch, n_rows, u0, u1, partial);
 }
 // the narrow matrices of an opening in one launch (blockIdx.y = matrix, blockIdx.x = its block of DOT_ROWS rows): the memory
 // tables, quotient chunks and permutation traces of the small chips were sixty dependent launches of 9-18 us
@@ -200,20 +200,20 @@ struct NarrowDotArgs {
     const uint32_t* mat[NARROW_DOT_MAX];
     const uint32_t *u0[NARROW_DOT_MAX], *u1[NARROW_DOT_MAX];
     uint32_t* partial[NARROW_DOT_MAX];
-    uint32_t w[NARROW_DOT_MAX], n_rows[NARROW_DOT_MAX];
+    uint32_t w[NARROW_DOT_MAX], pitch[NARROW_DOT_MAX], n_rows[NARROW_DOT_MAX];
 };
 __global__ __launch_bounds__(256) void k_column_dot_batch(NarrowDotArgs a) {
     const int t = blockIdx.y;
     const size_t n_rows = a.n_rows[t];
     if ((size_t)blockIdx.x * DOT_ROWS >= n_rows) return;
-    column_dot_body(a.mat[t], a.w[t], n_rows, a.u0[t], a.u1[t], a.partial[t]);
+    column_dot_body(a.mat[t], a.w[t], a.pitch[t], n_rows, a.u0[t], a.u1[t], a.partial[t]);
 }
 
 // Matrices of 24 columns and more: a wave takes 64 consecutive columns of one row at a time, so the row's weights are
 // wave-uniform -- scalar loads, SGPR operands of the multiply-adds -- and a lane's only vector load is its matrix word
 // (k_column_dot reads two 16-byte weights per word through the vector path: 36 bytes requested per 4 bytes of matrix).
 // Workgroup = (block of `rows_per_block` rows, chunk of 64 columns); its four waves split the rows.
-__global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows, uint32_t rows_per_block,
+__global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restrict__ mat, uint32_t w, uint32_t pitch, size_t n_rows, uint32_t rows_per_block,
                                                           uint32_t n_chunks, const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
                                                           uint32_t* __restrict__ partial) {
     __shared__ uint32_t sh[2][4][64][4];
@@ -242,7 +242,7 @@ __global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restr
     for (; r + UR <= wave_end; r += UR) {
         uint32_t m[UR];
 #pragma unroll
-        for (int k = 0; k < UR; k++) m[k] = col[(r + k) * w];
+        for (int k = 0; k < UR; k++) m[k] = col[(r + k) * pitch];
 #pragma unroll
         for (int k = 0; k < UR; k++) {
             int32_t w0[8];
@@ -256,7 +256,7 @@ __global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restr
         }
     }
     for (; r < wave_end; r++) {
-        const uint32_t m = col[r * w];
+        const uint32_t m = col[r * pitch];
         int32_t w0[8];
         weights(u0, r, w0);
         l0.add_base(m, w0);
@@ -288,7 +288,7 @@ __global__ __launch_bounds__(256) void k_column_dot_wave(const uint32_t* __restr
 // per-lane weight loads were 36 bytes requested per 4 bytes of matrix).  V = 2: rows wider than 128 columns are cut in two halves
 // of T = ceil(w / 2) columns and a thread takes column ct of both, so that R = 256 / T >= 2 rows fit a step.
 template <int V>
-__global__ __launch_bounds__(256) void k_column_dot_slab(const uint32_t* __restrict__ mat, uint32_t w, size_t n_rows, uint32_t rows_per_block,
+__global__ __launch_bounds__(256) void k_column_dot_slab(const uint32_t* __restrict__ mat, uint32_t w, uint32_t pitch, size_t n_rows, uint32_t rows_per_block,
                                                           const uint32_t* __restrict__ u0, const uint32_t* __restrict__ u1,
                                                           uint32_t* __restrict__ partial) {
     extern __shared__ __attribute__((aligned(16))) uint32_t dot_lds[];
@@ -315,7 +315,7 @@ __global__ __launch_bounds__(256) void k_column_dot_slab(const uint32_t* __restr
     LazyEf acc[V][2];
 #pragma unroll
     for (int v = 0; v < V; v++) acc[v][0].zero(), acc[v][1].zero();
-    const uint32_t* __restrict__ base = mat + row0 * w;
+    const uint32_t* __restrict__ base = mat + row0 * pitch;
     auto step = [&](const uint32_t (&m)[V], uint32_t r) {
         const uint4 p0 = wts[2 * r], p1 = wts[2 * r + 1];
         const int32_t w0[4] = {(int32_t)p0.x, (int32_t)p0.y, (int32_t)p0.z, (int32_t)p0.w};
@@ -334,14 +334,14 @@ __global__ __launch_bounds__(256) void k_column_dot_slab(const uint32_t* __restr
 #pragma unroll
             for (int k = 0; k < UR; k++)
 #pragma unroll
-                for (int v = 0; v < V; v++) m[k][v] = base[(size_t)(r + k * R) * w + col[v]];
+                for (int v = 0; v < V; v++) m[k][v] = base[(size_t)(r + k * R) * pitch + col[v]];
 #pragma unroll
             for (int k = 0; k < UR; k++) step(m[k], r + k * R);
         }
         for (; r < rows; r += R) {
             uint32_t m[V];
 #pragma unroll
-            for (int v = 0; v < V; v++) m[v] = base[(size_t)r * w + col[v]];
+            for (int v = 0; v < V; v++) m[v] = base[(size_t)r * pitch + col[v]];
             step(m, r);
         }
     }
@@ -794,6 +794,7 @@ __global__ __launch_bounds__(256) void k_pow_grind(const P16Params* __restrict__
 struct GatherMat {
     const uint32_t* base;
     uint32_t width;
+    uint32_t pitch;   // words between rows
     uint32_t log_h;
     uint32_t out_off;  // word offset of this matrix's row inside a query's record
 };
@@ -808,7 +809,7 @@ __global__ __launch_bounds__(256) void k_gather_openings(const GatherMat* __rest
     for (uint32_t m = 0; m < n_mats; m++) {
         const GatherMat g = mats[m];
         const size_t r = index >> (log_max - g.log_h);
-        for (uint32_t c = threadIdx.x; c < g.width; c += blockDim.x) rec[g.out_off + c] = g.base[r * g.width + c];
+        for (uint32_t c = threadIdx.x; c < g.width; c += blockDim.x) rec[g.out_off + c] = g.base[r * g.pitch + c];
     }
     for (uint32_t t = threadIdx.x; t < 8 * log_max; t += blockDim.x) {
         const uint32_t l = t >> 3, k = t & 7;
@@ -833,7 +834,7 @@ __global__ __launch_bounds__(256) void k_gather_openings_inline(GatherInline t, 
     for (uint32_t m = 0; m < n_mats; m++) {
         const GatherMat g = t.mats[m];
         const size_t r = index >> (log_max - g.log_h);
-        for (uint32_t c = threadIdx.x; c < g.width; c += blockDim.x) rec[g.out_off + c] = g.base[r * g.width + c];
+        for (uint32_t c = threadIdx.x; c < g.width; c += blockDim.x) rec[g.out_off + c] = g.base[r * g.pitch + c];
     }
     for (uint32_t e = threadIdx.x; e < 8 * log_max; e += blockDim.x) {
         const uint32_t l = e >> 3, k = e & 7;
@@ -903,21 +904,22 @@ static uint32_t dot_blocks(uint32_t w, size_t n_rows) {
 
 size_t column_dot_partial_words(uint32_t w, size_t n_rows) { return (size_t)dot_blocks(w, n_rows) * 2 * w * 4; }
 
-int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
+int32_t column_dot_partial(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint32_t pitch, size_t n_rows, const uint32_t* u0, const uint32_t* u1,
                            uint32_t* partial_dev) {
+    if (pitch == 0) pitch = w;
     const uint32_t n_blocks = dot_blocks(w, n_rows);
     if (dot_slab(w)) {
         const uint32_t rb = dot_block_rows(w, n_rows);
         const int v = w > 128 ? 2 : 1;
         const size_t lds = ((size_t)rb * 8 + (size_t)2 * v * 256 * 4) * 4;
-        if (v == 2) hipLaunchKernelGGL(k_column_dot_slab<2>, dim3(n_blocks), dim3(256), lds, ctx->stream, mat, w, n_rows, rb, u0, u1, partial_dev);
-        else hipLaunchKernelGGL(k_column_dot_slab<1>, dim3(n_blocks), dim3(256), lds, ctx->stream, mat, w, n_rows, rb, u0, u1, partial_dev);
+        if (v == 2) hipLaunchKernelGGL(k_column_dot_slab<2>, dim3(n_blocks), dim3(256), lds, ctx->stream, mat, w, pitch, n_rows, rb, u0, u1, partial_dev);
+        else hipLaunchKernelGGL(k_column_dot_slab<1>, dim3(n_blocks), dim3(256), lds, ctx->stream, mat, w, pitch, n_rows, rb, u0, u1, partial_dev);
     } else if (w >= DOT_WAVE_MIN_W && getenv("LURKHIP_DOT_OLD") == nullptr) {  // LURKHIP_DOT_OLD: A/B hook, every width on k_column_dot
         const uint32_t n_chunks = (w + 63) / 64;
-        hipLaunchKernelGGL(k_column_dot_wave, dim3(n_blocks * n_chunks), dim3(256), 0, ctx->stream, mat, w, n_rows, dot_block_rows(w, n_rows), n_chunks,
+        hipLaunchKernelGGL(k_column_dot_wave, dim3(n_blocks * n_chunks), dim3(256), 0, ctx->stream, mat, w, pitch, n_rows, dot_block_rows(w, n_rows), n_chunks,
                            u0, u1, partial_dev);
     } else
-        hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, n_rows, u0, u1, partial_dev);
+        hipLaunchKernelGGL(k_column_dot, dim3(n_blocks), dim3(256), 0, ctx->stream, mat, w, pitch, n_rows, u0, u1, partial_dev);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
@@ -936,6 +938,7 @@ int32_t column_dot_partial_batch(lurkhip_ctx* ctx, const std::vector<NarrowDot>&
             a.u1[k] = d.u1;
             a.partial[k] = d.partial;
             a.w[k] = d.w;
+            a.pitch[k] = d.pitch ? d.pitch : d.w;
             a.n_rows[k] = (uint32_t)d.n_rows;
             max_blocks = std::max(max_blocks, dot_blocks(d.w, d.n_rows));
         }
@@ -1048,7 +1051,8 @@ int32_t reduce_openings_wide(lurkhip_ctx* ctx, WideArgs a) {
         else hipLaunchKernelGGL(kernel, dim3(blocks), dim3(64), lds, ctx->stream, a);
     };
 #define LH_RW(NV) launch(k_reduce_openings_wide<NV, false>, k_reduce_openings_wide<NV, true>, NV)
-    if (max_sw <= 64) LH_RW(64);
+    if (max_sw <= 32) LH_RW(32);
+    else if (max_sw <= 64) LH_RW(64);
     else if (max_sw <= 80) LH_RW(80);
     else if (max_sw <= 96) LH_RW(96);
     else if (max_sw <= 112) LH_RW(112);
@@ -1129,7 +1133,7 @@ int32_t gather_openings(lurkhip_ctx* ctx, const std::vector<OpenMat>& mats, cons
     std::vector<GatherMat> g(mats.size());
     uint32_t off = 0;
     for (size_t i = 0; i < mats.size(); i++) {
-        g[i] = GatherMat{mats[i].base, mats[i].width, mats[i].log_h, off};
+        g[i] = GatherMat{mats[i].base, mats[i].width, mats[i].pitch ? mats[i].pitch : mats[i].width, mats[i].log_h, off};
         off += mats[i].width;
     }
     *record_words = off + 8 * log_max;

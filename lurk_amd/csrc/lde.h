@@ -18,6 +18,7 @@ bool lde_group_takes(int log_n);
 // last store); between the kernels everything is Montgomery.  Everything on ctx->stream; scratch comes from the context's pool.
 bool lde_group_enabled();
 int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
-                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical);
+                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical,
+                  const uint32_t* lde_pitches = nullptr);  // row pitch of ldes[m] in words (null: widths[m]): column ranges of one padded buffer
 
 }  // namespace lurkhip

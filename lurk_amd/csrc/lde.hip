@@ -55,6 +55,7 @@ struct LdeArgs {
     const uint32_t* src[LDE_MAX_MATS];  // N x width[m], row-major
     uint32_t* dst[LDE_MAX_MATS];        // 2N x width[m]: block q = coset q, rows in the DIF's (bit-reversed) order
     uint32_t width[LDE_MAX_MATS];
+    uint32_t dpitch[LDE_MAX_MATS];      // row pitch of dst[m] in words: width[m], or the pitch of the padded group buffer dst[m] is a column range of
     uint32_t start[LDE_MAX_MATS];       // virtual column of the matrix's first column (2^32 - 1 for unused slots)
     uint32_t cls[LDE_MAX_MATS];         // shift class of the matrix
     const uint32_t* scale[2][LDE_MAX_CLASSES];  // per coset and class: s_q^k / N, k < N
@@ -359,6 +360,7 @@ struct ColRef {
     const uint32_t* src;  // the column's first element (row 0)
     uint32_t* dst;
     uint32_t w;           // row pitch of its matrix in words
+    uint32_t dw;          // row pitch of its LDE in words
     uint32_t cls;
     bool valid;
 };
@@ -369,7 +371,7 @@ struct ColRef {
 struct MatDesc {
     const uint32_t* src;
     uint32_t* dst;
-    uint32_t w, cls, start, pad;
+    uint32_t w, cls, start, dw;
 };
 constexpr int DESC_WORDS = LDE_MAX_MATS * (int)(sizeof(MatDesc) / 4);
 __device__ __forceinline__ void stage_descs(const LdeArgs& a, MatDesc* __restrict__ descs) {
@@ -381,7 +383,7 @@ __device__ __forceinline__ void stage_descs(const LdeArgs& a, MatDesc* __restric
         d.w = a.width[m];
         d.cls = a.cls[m];
         d.start = a.start[m];
-        d.pad = 0;
+        d.dw = a.dpitch[m];
         descs[m] = d;
     }
 }
@@ -397,6 +399,7 @@ __device__ __forceinline__ ColRef locate_col(const LdeArgs& a, const MatDesc* __
     r.src = d.src + col;
     r.dst = d.dst + col;
     r.w = d.w;
+    r.dw = d.dw;
     r.cls = d.cls;
     return r;
 }
@@ -615,11 +618,11 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
         for (int j = 0; j < G::U; j++) asm volatile("" : "+v"(nx[j]));  // the next tile's rows have landed BEFORE this tile's stores are issued
         if (G::U >= 4 && a.x4) {
             const ColRef rq = locate_col(a, descs, cur.vc & ~3u);
-            uint32_t* __restrict__ out = rq.valid ? rq.dst + (row0 + (size_t)(G::U * s)) * rq.w : a.B + slab_off(a, cur.vc & ~3u);
-            walk_store_x4<G::U>(y, out, rq.valid ? (size_t)rq.w : (size_t)0, c & 3);
+            uint32_t* __restrict__ out = rq.valid ? rq.dst + (row0 + (size_t)(G::U * s)) * rq.dw : a.B + slab_off(a, cur.vc & ~3u);
+            walk_store_x4<G::U>(y, out, rq.valid ? (size_t)rq.dw : (size_t)0, c & 3);
         } else {
-            uint32_t* __restrict__ out = ref.valid ? ref.dst + (row0 + (size_t)(G::U * s)) * ref.w : a.B + slab_off(a, cur.vc);
-            walk_store<G::U>(y, out, ref.valid ? (size_t)ref.w : (size_t)0);  // a padding column stores into its own slab column: no branch
+            uint32_t* __restrict__ out = ref.valid ? ref.dst + (row0 + (size_t)(G::U * s)) * ref.dw : a.B + slab_off(a, cur.vc);
+            walk_store<G::U>(y, out, ref.valid ? (size_t)ref.dw : (size_t)0);  // a padding column stores into its own slab column: no branch
         }
     }
 }
@@ -767,7 +770,7 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_mid(Ld
 #pragma unroll
                     for (int j = 0; j < G::U; j++) z[j] = bb::from_monty(z[j]);
                 }
-                if (cur.valid) walk_store<G::U>(z, cur.dst + (((size_t)q << a.log_n) + (size_t)(G::U * s)) * cur.w, (size_t)cur.w);
+                if (cur.valid) walk_store<G::U>(z, cur.dst + (((size_t)q << a.log_n) + (size_t)(G::U * s)) * cur.dw, (size_t)cur.dw);
             } else {
                 uint32_t* __restrict__ out = a.B + ((size_t)q * a.slabs << (a.log_n + SLAB_LOG_W)) + slab_off(a, cur_vc);
                 if constexpr (G::U >= 4 && LDE_MID_X4) {
@@ -906,7 +909,7 @@ bool lde_group_enabled() {
 bool lde_group_takes(int log_n) { return lde_group_enabled() && log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N; }
 
 int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
-                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical) {
+                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical, const uint32_t* lde_pitches) {
     LH_ARG(ctx, n_mats >= 1 && n_mats <= LDE_MAX_MATS && n_cls >= 1 && n_cls <= LDE_MAX_CLASSES, "LDE group shape");
     LH_ARG(ctx, log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N, "LDE group height 2^%d", log_n);
     const NttPlan* plan = nullptr;
@@ -918,6 +921,7 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
         a.src[m] = evals[m];
         a.dst[m] = ldes[m];
         a.width[m] = widths[m];
+        a.dpitch[m] = lde_pitches ? lde_pitches[m] : widths[m];
         a.start[m] = at;
         a.cls[m] = cls[m];
         at += widths[m];
@@ -938,7 +942,7 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     static const int x4_mask = getenv("LURKHIP_LDE_X4") ? atoi(getenv("LURKHIP_LDE_X4")) : 0;
     bool mats_x4 = true;
     for (int m = 0; m < n_mats; m++)
-        mats_x4 = mats_x4 && widths[m] % 4 == 0 && ((uintptr_t)evals[m] & 15u) == 0 && ((uintptr_t)ldes[m] & 15u) == 0;
+        mats_x4 = mats_x4 && widths[m] % 4 == 0 && a.dpitch[m] % 4 == 0 && ((uintptr_t)evals[m] & 15u) == 0 && ((uintptr_t)ldes[m] & 15u) == 0;
     a.x4 = (mats_x4 ? 1 : 0) & x4_mask;
     if (log_n <= 10) {
         a.r1 = 0;

@@ -219,7 +219,7 @@ int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* con
     }
     span_begin(ctx, "commit_main");
     int32_t s = commit_impl(ctx, n_chips, sh->main.data(), false, sh->log_n.data(), widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
-                            &sh->main_commit, sh->root_m);
+                            &sh->main_commit, sh->root_m, nullptr, false, /*padded_groups=*/true);
     span_end(ctx, "commit_main");
     if (s != LURKHIP_OK) {
         delete sh;
@@ -355,10 +355,10 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
                 if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
                 if (column_dot_is_narrow(r.c->width[m])) {
-                    narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at});
+                    narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at, r.c->pitch[m]});
                 } else {
                     const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N, (uint32_t)k);
-                    PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at));
+                    PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], r.c->pitch[m], (size_t)1 << log_n, u0, u1, partials + at));
                 }
                 jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
                 at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
@@ -440,6 +440,22 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         g.n_mats = 0;
         return st;
     };
+    // Matrices that are column ranges of a padded group buffer (lurkhip_commitment::pitch != width: the prover's own commitments)
+    // wait per (round, group) and go out as ONE launch of the slice kernel: the group buffer is a wide matrix whose row pitch is
+    // its width, each matrix a run of column slices with its own alpha offsets and reduced opened values (k_reduce_openings_wide
+    // was written for one wide matrix cut into slices; nothing in it asks that the slices belong to the same matrix).
+    static const uint32_t group_slice_w = getenv("LURKHIP_REDUCE_SLICE_W") ? (uint32_t)std::max(8, std::min(128, atoi(getenv("LURKHIP_REDUCE_SLICE_W")))) : 64u;
+    struct GroupWide {
+        WideArgs wa{};
+        int log_h = 0;
+    };
+    std::map<std::pair<size_t, int>, GroupWide> group_wide;
+    auto flush_group = [&](GroupWide& g) -> int32_t {
+        if (g.wa.n_slices == 0) return LURKHIP_OK;
+        const int32_t st = reduce_openings_wide(ctx, g.wa);
+        g.wa.n_slices = 0;
+        return st;
+    };
     size_t mat_k = 0;
     SideLane ro_lane(ctx);  // the accumulators are per height: a height is one lane
     ro_lane.want = side_lanes_wanted;
@@ -468,7 +484,35 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             uint64_t& offset = num_reduced[prof.fri_alpha_global ? 0 : log_h];
             const ef apow0 = ef_pow_host(alpha_fri, offset);
             const ef apow1 = ef_pow_host(alpha_fri, offset + w);
-            if (w <= NARROW_MAX_W && alpha_pows_c) {
+            if (r.c->pitch[m] != w && alpha_pows_c) {
+                GroupWide& g = group_wide[{ri, r.c->group[m]}];
+                if (g.wa.n_slices && g.wa.d1 != d1) PTRY(flush_group(g));  // a different second point: its own launch
+                for (uint32_t c0 = 0; c0 < w; c0 += group_slice_w) {
+                    if (g.wa.n_slices == WIDE_MAX_SLICES) PTRY(flush_group(g));  // (the accumulators are additive: a matrix may span launches)
+                    if (g.wa.n_slices == 0) {
+                        g.wa = WideArgs{};
+                        g.wa.mat = r.c->group_base[r.c->group[m]];
+                        g.wa.w = r.c->pitch[m];
+                        g.wa.m_rows = 1u << log_h;
+                        g.wa.alpha_pows = alpha_pows_c;
+                        g.wa.d0 = d0;
+                        g.wa.d1 = d1;
+                        g.wa.ro = ro[log_h];
+                        g.log_h = log_h;
+                    }
+                    const uint32_t sl = g.wa.n_slices++, n = std::min(group_slice_w, w - c0);
+                    g.wa.c0[sl] = r.c->col_start[m] + c0;
+                    g.wa.sw[sl] = n;
+                    const ef shift = ef_pow_host(alpha_fri, c0);
+                    g.wa.apow0[sl] = bb::ef_mul(apow0, shift);
+                    g.wa.apow1[sl] = bb::ef_mul(apow1, shift);
+                    for (size_t p = 0; p < mp.size(); p++) {
+                        ef y = bb::ef_zero();
+                        for (uint32_t j = 0; j < n; j++) y = bb::ef_add(y, bb::ef_mul(alpha_pows_host[j], opened[ri][m][p][c0 + j]));
+                        (p == 0 ? g.wa.ys0 : g.wa.ys1)[sl] = y;
+                    }
+                }
+            } else if (w <= NARROW_MAX_W && alpha_pows_c) {
                 NarrowArgs& g = narrow[{log_h, mp[0]}];
                 if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
                 if (g.n_mats == 0) g = NarrowArgs{{}, 0, 1u << log_h, alpha_pows_c, d0, nullptr, ro[log_h]};
@@ -511,6 +555,10 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     for (auto& kv : narrow) {
         const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
         PTRY(flush_narrow(kv.second));
+    }
+    for (auto& kv : group_wide) {
+        const auto on_side = ro_lane.on_side(kv.second.log_h - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.second.log_h);
+        PTRY(flush_group(kv.second));
     }
     PTRY(ro_lane.close());
     span_end(ctx, "open");
@@ -608,7 +656,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     size_t rec_words = 0;
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const lurkhip_commitment* c = rounds[ri].c;
-        for (int m = 0; m < c->n_mats; m++) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m]});
+        for (int m = 0; m < c->n_mats; m++) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m], c->pitch[m]});
         PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &round_record_words[ri]));
         rec_words += (size_t)num_queries * round_record_words[ri];
     }
@@ -814,7 +862,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     uint32_t perm_root_m[8];
     span_begin(ctx, "commit_perm");
     PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
-                     perm_root_m));
+                     perm_root_m, nullptr, false, /*padded_groups=*/true));
     span_end(ctx, "commit_perm");
     to_free.push_back(perm_commit);
     for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
@@ -839,8 +887,9 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         uint32_t* chunks = nullptr;
         PTRY(palloc(h * qd * 16, &chunks));
         const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde[sh->prep_index[i]] : nullptr;
+        const uint32_t pitches[3] = {sh->main_commit->pitch[i], sh->prep_index[i] >= 0 ? pk->commit->pitch[sh->prep_index[i]] : 0u, perm_commit->pitch[i]};
         PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
-                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i]));
+                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches));
         const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
         const uint32_t wq_inv = pow_host(wq, bb::P - 2);
         for (uint32_t c = 0; c < qd; c++) {
@@ -857,7 +906,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     uint32_t quot_root_m[8];
     span_begin(ctx, "commit_quotient");
     PTRY(commit_impl(ctx, (int32_t)qmats.size(), qmats.data(), false, q_logn.data(), q_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
-                     &quot_commit, quot_root_m, q_shifts.data()));
+                     &quot_commit, quot_root_m, q_shifts.data(), false, /*padded_groups=*/true));
     span_end(ctx, "commit_quotient");
     to_free.push_back(quot_commit);
     ch.observe_digest_m(quot_root_m);

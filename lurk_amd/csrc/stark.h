@@ -38,7 +38,8 @@ uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd);  //
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev,
-                      const uint32_t* shared_beta_pows = nullptr, const uint32_t* shared_starts = nullptr);
+                      const uint32_t* shared_beta_pows = nullptr, const uint32_t* shared_starts = nullptr,
+                      const uint32_t* pitches = nullptr /* {main, prep, perm} row pitches in words, 0 or null: the matrix's width */);
 
 }  // namespace lurkhip
 

@@ -595,7 +595,7 @@ uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd) {
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
-                      const uint32_t* shared_starts) {
+                      const uint32_t* shared_starts, const uint32_t* pitches) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
     LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
     const uint32_t lqd = a->air.log_quotient_degree();
@@ -660,6 +660,9 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.w = a->air.width;
         q.pw = a->air.prep_width;
         q.perm_w = perm_w;
+        q.main_pitch = pitches && pitches[0] ? pitches[0] : q.w;
+        q.prep_pitch = prep_lde_dev ? (pitches && pitches[1] ? pitches[1] : q.pw) : q.main_pitch;  // (no preprocessed columns: the pointer aliases the main matrix)
+        q.perm_pitch = pitches && pitches[2] ? pitches[2] : perm_w * 4;
         q.batch = batch;
         q.k_total = k_total;
         q.g_m = bb::to_monty(bb::GEN);

@@ -29,7 +29,8 @@ __device__ LURKHIP_SINK_OP ef sink_ef_mul(ef a, ef b) { return bb::ef_mul(a, b);
 // threads of the workgroup and eight loads go out before the first is awaited: one load per trip, awaited on the spot, made
 // the staging a chain of n_rows memory round trips -- the longest phase of the permutation and quotient kernels.
 __device__ __forceinline__ void stage_rows(uint32_t* __restrict__ tile, uint32_t wp, const uint32_t* __restrict__ mat, uint32_t w,
-                                           const uint32_t* __restrict__ idx, uint32_t n_rows) {
+                                           const uint32_t* __restrict__ idx, uint32_t n_rows, uint32_t pitch = 0 /* words between rows; 0: w */) {
+    if (pitch == 0) pitch = w;
     constexpr int UR = 8;
     const uint32_t total = n_rows * w;  // < 2^24: the quotient e / w below is exact after one correction step
     const float inv_w = 1.0f / (float)w;
@@ -44,7 +45,7 @@ __device__ __forceinline__ void stage_rows(uint32_t* __restrict__ tile, uint32_t
             r -= r * w > ec ? 1u : 0u;
             const uint32_t c = ec - r * w;
             at[k] = r * wp + c;
-            v[k] = mat[(size_t)idx[r] * w + c];
+            v[k] = mat[(size_t)idx[r] * pitch + c];
         }
 #pragma unroll
         for (int k = 0; k < UR; k++)
@@ -240,6 +241,7 @@ struct QuotientArgs {
     const uint32_t* starts;  // per interaction: alpha + kind + sum beta^t * constants (k_interaction_starts)
     ef cumulative_sum;
     uint32_t log_n, log_q, w, pw, perm_w, batch, k_total;
+    uint32_t main_pitch, prep_pitch, perm_pitch;  // words between rows of the three LDE matrices (>= w, pw, 4 perm_w: lurkhip_commitment::pitch)
     uint32_t zh_inv[4];     // 1 / Z_H(x) for i mod 2^lqd
     uint32_t zh[4];
     uint32_t g_m, wq_m, wn_inv_m;
@@ -325,8 +327,8 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const uint32_t i = a.log_q ? (__brev(s) >> (32 - a.log_q)) : 0u;
     const uint32_t i_next = (i + qd) & (q - 1);
     const uint32_t s_next = a.log_q ? (__brev(i_next) >> (32 - a.log_q)) : 0u;
-    const uint32_t* main_l = a.main + (size_t)s * a.w;
-    const uint32_t* main_n = a.main + (size_t)s_next * a.w;
+    const uint32_t* main_l = a.main + (size_t)s * a.main_pitch;
+    const uint32_t* main_n = a.main + (size_t)s_next * a.main_pitch;
     uint32_t* tile_l = regs + a.regs_words;
     uint32_t* idx = tile_l + (a.staged ? 64u * a.wp : 0u);
     uint32_t* folds = idx + 64;  // [n_parts][64][4]
@@ -335,7 +337,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
         // which stay in global memory, and a second tile would halve the waves an LDS-bound CU can hold
         if (wave == 0) idx[lane] = s;
         __syncthreads();
-        stage_rows(tile_l, a.wp, a.main, a.w, idx, 64u);
+        stage_rows(tile_l, a.wp, a.main, a.w, idx, 64u, a.main_pitch);
         __syncthreads();
         main_l = tile_l + lane * a.wp;
     }
@@ -357,9 +359,9 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
         is_last = bb::mul(zh, bb::inv(x_minus_last));
         is_trans = x_minus_last;
     }
-    airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.pw, a.prep + (size_t)s_next * a.pw, a.pub, {is_first, is_last, is_trans}};
-    const uint32_t* perm_l = a.perm + (size_t)s * a.perm_w * 4;
-    const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_w * 4;
+    airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.prep_pitch, a.prep + (size_t)s_next * a.prep_pitch, a.pub, {is_first, is_last, is_trans}};
+    const uint32_t* perm_l = a.perm + (size_t)s * a.perm_pitch;
+    const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_pitch;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.starts}, a.batch, perm_l};
     const uint32_t* prog = a.parts.prog[wave];
     const uint32_t first = prog[airp::H_FIRST_COLUMN];  // constraint piece: its first constraint; interaction piece: its first column

@@ -545,7 +545,10 @@ def lane_context(machine, ctx=None):
     return ctx
 
 
-def prove_lanes(machine, handles, transcript: Challenger, pv, num_queries, pow_bits, parse=True, lane_ctx=None):
+LANE_OFFSET_MAX_S = 0.25  # cap of prove_lanes' lane_offset_s
+
+
+def prove_lanes(machine, handles, transcript: Challenger, pv, num_queries, pow_bits, parse=True, lane_ctx=None, lane_offset_s=0.0):
     """Phase 2 of a multi-shard proof on two lanes: the committed shards `handles` are proved alternately on the machine's
     context and on `lane_ctx` (its own stream, one host thread each), every shard with a clone of `transcript` -- while one
     shard sits in a latency chain (FRI layers, tree tails, transcript round trips) the other's big kernels fill the device
@@ -556,22 +559,21 @@ def prove_lanes(machine, handles, transcript: Challenger, pv, num_queries, pow_b
     machine.ctx.sync()  # the commitments the second lane reads were made on this context's stream
     proofs, errors = [None] * len(handles), []
 
-    # Out of phase: two lanes that start together run the same stages at the same time; with the second lane half a proof behind,
-    # one lane's commitments (hashing) run under the other's openings and FRI (bench.py: 40.0 against 41.4 ms per proof, the delay
-    # included).  Worth it from four shards up; the proof time is the machine's last measured one (none yet: no offset).
+    # Out of phase (lane_offset_s > 0, the caller's choice; default none): two lanes that start together run the same stages at the
+    # same time; with the second lane half a SEQUENTIAL proof behind, one lane's commitments (hashing) run under the other's openings
+    # and FRI (bench.py --stagger-ms: 40.0 against 41.4 ms per proof, the delay included).  Round 3 derived the offset from the last
+    # proof time seen -- measured with two proofs in flight, i.e. about twice the sequential time -- on a field written from the
+    # worker thread; now the library never sleeps unless asked to, and never longer than LANE_OFFSET_MAX_S.
     import time
 
-    offset_s = 0.5 * machine._proof_seconds if len(handles) >= 4 and getattr(machine, "_proof_seconds", 0.0) else 0.0
+    offset_s = min(max(float(lane_offset_s), 0.0), LANE_OFFSET_MAX_S) if len(handles) >= 4 else 0.0
 
     def lane(j, ctx):
         try:
             if j == 1 and offset_s:
                 time.sleep(offset_s)
             for i in range(j, len(handles), 2):
-                t0 = time.perf_counter()
                 proofs[i] = machine.prove_shard(handles[i], transcript.clone(), pv, num_queries, pow_bits, parse=parse, ctx=ctx)
-                if j == 0:
-                    machine._proof_seconds = time.perf_counter() - t0
             (ctx or machine.ctx).sync()
         except BaseException as e:  # surfaced after the join
             errors.append(e)

@@ -44,6 +44,8 @@ SWITCHES = [
     {"LURKHIP_SPONGE_COOP": "0"},
     {"LURKHIP_DOT_OLD": "1", "LURKHIP_OPENINGS_NO_QUAD": "1"},
     {"LURKHIP_TRACE_INTERPRET": "1", "LURKHIP_NTT_MAX_LOG_R": "7"},
+    {"LURKHIP_LDE_PADDED": "0"},  # every LDE in its own dense buffer (round 3's layout)
+    {"LURKHIP_LDE_PADDED": "2", "LURKHIP_REDUCE_SLICE_W": "32"},  # every height group in one padded buffer, whatever the padding costs
 ]
 
 
