@@ -184,34 +184,31 @@ BB_HD uint32_t pow(uint32_t a, uint32_t e) {
     }
     return r;
 }
-// Fermat inverse a^(p-2); inv(0) = 0.  p - 2 = 0x77ffffff.
-BB_HD uint32_t inv(uint32_t a) {
-    // addition chain: a^(2^27-1) then the top nibble 0111 -> exponent 0x77ffffff
-    // = 0b0111_0111_1111_1111_1111_1111_1111_1111
-    uint32_t a2 = sqr(a);            // 2
-    uint32_t a3 = mul(a2, a);        // 3
-    uint32_t a6 = sqr(a3);
-    uint32_t a7 = mul(a6, a);        // 2^3-1
-    uint32_t t = a7;
-    // build 2^27 - 1 = 27 ones: (2^3-1) -> 2^6-1 -> 2^12-1 -> 2^24-1 -> 2^27-1
-    uint32_t x6 = t;
-    for (int i = 0; i < 3; i++) x6 = sqr(x6);
-    x6 = mul(x6, a7);                // 2^6-1
-    uint32_t x12 = x6;
-    for (int i = 0; i < 6; i++) x12 = sqr(x12);
-    x12 = mul(x12, x6);              // 2^12-1
-    uint32_t x24 = x12;
-    for (int i = 0; i < 12; i++) x24 = sqr(x24);
-    x24 = mul(x24, x12);             // 2^24-1
-    uint32_t x27 = x24;
-    for (int i = 0; i < 3; i++) x27 = sqr(x27);
-    x27 = mul(x27, a7);              // 2^27-1
-    // exponent = 0b111 << 28 | 0 << 27 | (2^27-1)  = 7*2^28 + 2^27 - 1
-    uint32_t hi = a7;                // 0b111
-    for (int i = 0; i < 28; i++) hi = sqr(hi);
-    return mul(hi, x27);
+// canonical representative of a signed lane value in (-p, p); centred representative (|r| <= (p - 1) / 2) of a canonical word
+BB_HD uint32_t canon(int32_t r) {
+    const uint32_t u = (uint32_t)r;
+    return umin(u, u + P);
 }
-static_assert(7u * (1u << 28) + (1u << 27) - 1u == P - 2u, "inverse exponent");
+BB_HD int32_t centre(uint32_t x) { return (int32_t)(x - (x > (P - 1u) / 2u ? P : 0u)); }
+// Fermat inverse a^(p-2) of a signed lane value in (-p, p), result in (-p, p); 0 -> 0.  p - 2 = 0x77ffffff = 0b111_0111 followed
+// by 24 ones: a^7, four squarings and a^7 again give the prefix, then eight times "three squarings, times a^7" -- 30 squarings
+// and 11 products, all three-instruction signed products (round 4; the canonical-range chain before it took 54 + 8 products
+// of seven instructions each and was 60 % of the instructions of the LogUp permutation kernel).
+BB_HD int32_t inv_s(int32_t a) {
+    const int32_t a2 = smul(a, a), a3 = smul(a2, a), a6 = smul(a3, a3), a7 = smul(a6, a);
+    int32_t t = a7;
+    for (int i = 0; i < 4; i++) t = smul(t, t);
+    t = smul(t, a7);  // 0b1110111
+    for (int g = 0; g < 8; g++) {
+        t = smul(t, t);
+        t = smul(t, t);
+        t = smul(t, t);
+        t = smul(t, a7);
+    }
+    return t;
+}
+BB_HD uint32_t inv(uint32_t a) { return canon(inv_s((int32_t)a)); }
+static_assert((0x77u << 24) + 0xffffffu == P - 2u, "inverse exponent");
 
 // ---------------------------------------------------------------------------
 // quartic extension F[x]/(x^4 - 11), coefficients in Montgomery form
@@ -231,32 +228,58 @@ BB_HD ef ef_sub(const ef& a, const ef& b) {
     return ef{{sub(a.c[0], b.c[0]), sub(a.c[1], b.c[1]), sub(a.c[2], b.c[2]), sub(a.c[3], b.c[3])}};
 }
 BB_HD ef ef_scale(const ef& a, uint32_t s) {
-    return ef{{mul(a.c[0], s), mul(a.c[1], s), mul(a.c[2], s), mul(a.c[3], s)}};
+    return ef{{canon(smul((int32_t)a.c[0], (int32_t)s)), canon(smul((int32_t)a.c[1], (int32_t)s)), canon(smul((int32_t)a.c[2], (int32_t)s)),
+               canon(smul((int32_t)a.c[3], (int32_t)s))}};
 }
 BB_HD ef ef_add_base(const ef& a, uint32_t s) { return ef{{add(a.c[0], s), a.c[1], a.c[2], a.c[3]}}; }
-BB_HD ef ef_mul(const ef& a, const ef& b) {
-    // c_k = sum_{i+j=k} a_i b_j + 11 * sum_{i+j=k+4} a_i b_j.  With b'_j = 11 b_j every coefficient is a sum of four
-    // products of reduced operands; two of them are < 2 p^2 < p * 2^32, the Montgomery-reduction bound, so each
-    // coefficient costs four multiply-adds, two reductions and one modular add (no 64-bit comparisons).
-    const uint32_t w1 = mul(EXT_W_M, b.c[1]), w2 = mul(EXT_W_M, b.c[2]), w3 = mul(EXT_W_M, b.c[3]);
-    auto dot2 = [](uint32_t x0, uint32_t y0, uint32_t x1, uint32_t y1) -> uint32_t {
-        return mred((uint64_t)x0 * y0 + (uint64_t)x1 * y1);
-    };
-    return ef{{add(dot2(a.c[0], b.c[0], a.c[1], w3), dot2(a.c[2], w2, a.c[3], w1)),
-               add(dot2(a.c[0], b.c[1], a.c[1], b.c[0]), dot2(a.c[2], w3, a.c[3], w2)),
-               add(dot2(a.c[0], b.c[2], a.c[1], b.c[1]), dot2(a.c[2], b.c[0], a.c[3], w3)),
-               add(dot2(a.c[0], b.c[3], a.c[1], b.c[2]), dot2(a.c[2], b.c[1], a.c[3], b.c[0]))}};
+// Extension products on signed lanes (round 4).  With both operands centred (|.| <= p/2) a coefficient
+//   c_k = sum_{i+j=k} a_i b_j + 11 * sum_{i+j=k+4} a_i b_j
+// is one 64-bit chain: the wrapped-around products are summed and reduced first (h, |h| < 0.86 p), then h * 11~ (11~ the centred
+// Montgomery form of 11, 0.47 p) joins the direct products: every chain stays below 1.06 p^2 -- inside sred's 1.2 p^2 and small
+// enough that the result is in (-p, p) again.  16 + 3 multiply-adds and 7 two-instruction reductions: 33 instructions, against 93
+// for the canonical-range version (three products by 11, eight two-term dot products with their own reductions, four modular adds).
+struct sef {
+    int32_t c[4];
+};
+constexpr int32_t EXT_W_MC = EXT_W_M > P / 2u ? (int32_t)(EXT_W_M - P) : (int32_t)EXT_W_M;
+BB_HD sef ef_centre(const ef& a) { return sef{{centre(a.c[0]), centre(a.c[1]), centre(a.c[2]), centre(a.c[3])}}; }
+BB_HD ef ef_canon(const sef& a) { return ef{{canon(a.c[0]), canon(a.c[1]), canon(a.c[2]), canon(a.c[3])}}; }
+// a, b centred; the coefficients of a * b as signed lane values in (-p, p)
+BB_HD int32_t sef_mul_c0(const sef& a, const sef& b) {
+    const int32_t h = sred(mad_i64(a.c[1], b.c[3], mad_i64(a.c[2], b.c[2], mad_i64(a.c[3], b.c[1], 0))));
+    return sred(mad_i64(a.c[0], b.c[0], mad_i64_u(h, EXT_W_MC, 0)));
 }
+BB_HD int32_t sef_mul_c1(const sef& a, const sef& b) {
+    const int32_t h = sred(mad_i64(a.c[2], b.c[3], mad_i64(a.c[3], b.c[2], 0)));
+    return sred(mad_i64(a.c[0], b.c[1], mad_i64(a.c[1], b.c[0], mad_i64_u(h, EXT_W_MC, 0))));
+}
+BB_HD int32_t sef_mul_c2(const sef& a, const sef& b) {
+    const int32_t h = sred(mad_i64(a.c[3], b.c[3], 0));
+    return sred(mad_i64(a.c[0], b.c[2], mad_i64(a.c[1], b.c[1], mad_i64(a.c[2], b.c[0], mad_i64_u(h, EXT_W_MC, 0)))));
+}
+BB_HD int32_t sef_mul_c3(const sef& a, const sef& b) {
+    return sred(mad_i64(a.c[0], b.c[3], mad_i64(a.c[1], b.c[2], mad_i64(a.c[2], b.c[1], mad_i64(a.c[3], b.c[0], 0)))));
+}
+BB_HD sef sef_mul(const sef& a, const sef& b) { return sef{{sef_mul_c0(a, b), sef_mul_c1(a, b), sef_mul_c2(a, b), sef_mul_c3(a, b)}}; }
+BB_HD ef ef_mul(const ef& a, const ef& b) { return ef_canon(sef_mul(ef_centre(a), ef_centre(b))); }
 BB_HD ef ef_sqr(const ef& a) { return ef_mul(a, a); }
 BB_HD bool ef_is_zero(const ef& a) { return (a.c[0] | a.c[1] | a.c[2] | a.c[3]) == 0; }
-// inverse by two conjugations down to the base field (x -> -x, then x^2 -> -x^2)
+// inverse by two conjugations down to the base field (x -> -x, then x^2 -> -x^2): with a' = a(-x), b = a a' in span{1, x^2},
+// b' = b(-x^2) and n = b b' in F, 1/a = a' b' / n.  Signed lanes throughout: only the coefficients that are not zero by
+// construction are computed, the base inverse is the 41-product signed chain (inv_s), one correction per output word.
 BB_HD ef ef_inv(const ef& a) {
-    ef a1{{a.c[0], neg(a.c[1]), a.c[2], neg(a.c[3])}};
-    ef b = ef_mul(a, a1);  // in span{1, x^2}
-    ef b1{{b.c[0], 0, neg(b.c[2]), 0}};
-    ef n = ef_mul(b, b1);  // in F
-    uint32_t ninv = inv(n.c[0]);
-    return ef_scale(ef_mul(a1, b1), ninv);
+    const sef x = ef_centre(a);
+    const sef x1{{x.c[0], -x.c[1], x.c[2], -x.c[3]}};
+    const int32_t b0 = centre(canon(sef_mul_c0(x, x1))), b2 = centre(canon(sef_mul_c2(x, x1)));
+    // n = b0^2 - 11 b2^2
+    const int32_t n = sred(mad_i64(b0, b0, mad_i64_u(sred(mad_i64(b2, -b2, 0)), EXT_W_MC, 0)));
+    const int32_t ninv = inv_s(n);
+    // a' * (b0 - b2 x^2)
+    const int32_t t0 = sred(mad_i64(x1.c[0], b0, mad_i64_u(sred(mad_i64(x1.c[2], -b2, 0)), EXT_W_MC, 0)));
+    const int32_t t1 = sred(mad_i64(x1.c[1], b0, mad_i64_u(sred(mad_i64(x1.c[3], -b2, 0)), EXT_W_MC, 0)));
+    const int32_t t2 = sred(mad_i64(x1.c[2], b0, mad_i64(x1.c[0], -b2, 0)));
+    const int32_t t3 = sred(mad_i64(x1.c[3], b0, mad_i64(x1.c[1], -b2, 0)));
+    return ef{{canon(smul(t0, ninv)), canon(smul(t1, ninv)), canon(smul(t2, ninv)), canon(smul(t3, ninv))}};
 }
 
 }  // namespace bb
