@@ -426,6 +426,11 @@ int32_t lurkhip_mem_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uin
 int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, uint32_t shard_index, lurkhip_func_trace** out);
 int32_t lurkhip_func_trace_shape_of(const lurkhip_func_trace* p, uint64_t* shape);
 int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, int32_t repr);
+/* lurkhip_func_trace_run for every chip of a shard (function, memory and byte chips alike) in one call: the launches are
+ * independent, the short chips' kernels go to the context's side streams and run under the tall ones (src/lair/trace.rs:86-132
+ * generates the chips of a shard with rayon: par_iter over chips); everything queued on the context afterwards is ordered
+ * behind all of them. */
+int32_t lurkhip_func_trace_run_many(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev, int32_t repr);
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p);
 int32_t lurkhip_mem_trace_shape(const lurkhip_record* r, uint32_t mem_len, uint32_t* n_real, uint32_t* height,
                                 uint32_t* width);

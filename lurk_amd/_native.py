@@ -152,6 +152,7 @@ SIGNATURES = {
     "lurkhip_bytes_trace_prepare": (_i32, [_p, _p, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_func_trace_shape_of": (_i32, [_p, C.POINTER(C.c_uint64)]),
     "lurkhip_func_trace_run": (_i32, [_p, _p, _u32p, _i32]),
+    "lurkhip_func_trace_run_many": (_i32, [_p, C.c_uint32, C.POINTER(_p), C.POINTER(_p), _i32]),
     "lurkhip_func_trace_free": (_i32, [_p, _p]),
     "lurkhip_mem_trace_shape": (_i32, [_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),
     "lurkhip_generate_trace_mem": (_i32, [_p, _p, C.c_uint32, _u32p, _i32]),

@@ -63,8 +63,6 @@ BB_HD uint32_t mred(uint64_t t) {
     uint32_t r = hi - u;
     return umin(r, r + P);
 }
-BB_HD uint32_t mul(uint32_t a, uint32_t b) { return mred((uint64_t)a * b); }
-BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 
 // a * b + c on signed 32-bit factors with a 64-bit addend: one v_mad_i64_i32.  Spelled as inline assembly on the device:
 // left to itself the compiler expands a product with a wave-uniform factor into an unsigned multiply-add plus sign fix-ups
@@ -151,6 +149,18 @@ BB_HD int32_t sred(int64_t t) {
 // (v_mad_i64_i32, v_mul_lo_u32, v_mad_i64_i32) against six for the canonical-range product.  Used for the x^7 chains of
 // Poseidon2 and the NTT butterflies, whose intermediates never leave the chain.
 BB_HD int32_t smul(int32_t a, int32_t b) { return sred(mad_i64(a, b, 0)); }
+// canonical representative of a signed lane value in (-p, p)
+BB_HD uint32_t canon(int32_t r) {
+    const uint32_t u = (uint32_t)r;
+    return umin(u, u + P);
+}
+BB_HD uint32_t mul(uint32_t a, uint32_t b) { return mred((uint64_t)a * b); }
+// The same canonical-range product as the signed product and one correction: five instructions on the device against seven
+// (64-bit product + the wait state the compiler puts behind it, low product, high product, subtract, correct).  Opt-in (the
+// compiled AIR and trace kernels use it for their constraint products): inside divergent control flow the compiler may move the
+// multiply-add's scalar carry operand (LURK_MAD_ASM) into vector registers, which does not assemble -- `mul` stays the default.
+BB_HD uint32_t mul_s(uint32_t a, uint32_t b) { return canon(smul((int32_t)a, (int32_t)b)); }
+BB_HD uint32_t sqr(uint32_t a) { return mul(a, a); }
 // (s + rc)^7 for canonical-range s, rc, given rc_mp = rc - p (mod 2^32): the sum s + rc_mp lies in (-p, p), the chain
 // runs on signed values, one correction at the end
 BB_HD uint32_t add_pow7_mp(uint32_t s, uint32_t rc_mp) {
@@ -184,11 +194,7 @@ BB_HD uint32_t pow(uint32_t a, uint32_t e) {
     }
     return r;
 }
-// canonical representative of a signed lane value in (-p, p); centred representative (|r| <= (p - 1) / 2) of a canonical word
-BB_HD uint32_t canon(int32_t r) {
-    const uint32_t u = (uint32_t)r;
-    return umin(u, u + P);
-}
+// centred representative (|r| <= (p - 1) / 2) of a canonical word
 BB_HD int32_t centre(uint32_t x) { return (int32_t)(x - (x > (P - 1u) / 2u ? P : 0u)); }
 // Fermat inverse a^(p-2) of a signed lane value in (-p, p), result in (-p, p); 0 -> 0.  p - 2 = 0x77ffffff = 0b111_0111 followed
 // by 24 ones: a^7, four squarings and a^7 again give the prefix, then eight times "three squarings, times a^7" -- 30 squarings

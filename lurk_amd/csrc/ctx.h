@@ -138,6 +138,7 @@ int32_t hash_stream_of(lurkhip_ctx* ctx);
 void span_begin(lurkhip_ctx* ctx, const char* name, int level = 1);
 void span_end(lurkhip_ctx* ctx, const char* name, int level = 1);
 void span_switch(lurkhip_ctx* ctx, const char* from, const char* to, int level = 1);  // span_end(from) + span_begin(to) on one event
+void host_mark(const char* what);  // LURKHIP_HOST_TRACE=1: the host clock at this point, on stderr (development aid)
 
 }  // namespace lurkhip
 

@@ -286,7 +286,19 @@ static hipEvent_t get_event(lurkhip_ctx* ctx) {
     return e;
 }
 
+// LURKHIP_HOST_TRACE=1: host clock of every span edge on stderr (microseconds since the first one) -- where the host thread is
+// when it enqueues a stage, i.e. which stages it waits in and what it does between them; a development aid, off by default
+static void host_trace(const char* edge, const char* name) {
+    static const bool on = getenv("LURKHIP_HOST_TRACE") != nullptr && atoi(getenv("LURKHIP_HOST_TRACE")) != 0;
+    if (!on) return;
+    static const auto t0 = std::chrono::steady_clock::now();
+    fprintf(stderr, "[host %10.1f us] %s %s\n", std::chrono::duration<double, std::micro>(std::chrono::steady_clock::now() - t0).count(), edge, name);
+}
+
+void host_mark(const char* what) { host_trace("mark ", what); }
+
 void span_begin(lurkhip_ctx* ctx, const char* name, int level) {
+    if (level <= 1) host_trace("begin", name);
     if (!ctx->profiling || ctx->profile_level < level) return;
     hipEvent_t a = get_event(ctx), b = get_event(ctx);
     (void)hipEventRecord(a, ctx->stream);
@@ -294,6 +306,7 @@ void span_begin(lurkhip_ctx* ctx, const char* name, int level) {
 }
 
 void span_end(lurkhip_ctx* ctx, const char* name, int level) {
+    if (level <= 1) host_trace("end  ", name);
     if (!ctx->profiling || ctx->profile_level < level) return;
     auto& sp = ctx->spans[name];
     if (sp.pending.empty()) return;
@@ -303,6 +316,7 @@ void span_end(lurkhip_ctx* ctx, const char* name, int level) {
 // ends `from` and begins `to` on one event: back-to-back spans (the stages of a Merkle tree) cost one record, not two --
 // every record is a marker packet the next kernel waits behind
 void span_switch(lurkhip_ctx* ctx, const char* from, const char* to, int level) {
+    if (level <= 1) host_trace("switch to", to);
     if (!ctx->profiling || ctx->profile_level < level) return;
     auto& f = ctx->spans[from];
     if (f.pending.empty()) {

@@ -58,7 +58,7 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
         switch (op) {
             case airp::OP_ADD: o << "    const uint32_t " << t << " = bb::add(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
             case airp::OP_SUB: o << "    const uint32_t " << t << " = bb::sub(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
-            case airp::OP_MUL: o << "    const uint32_t " << t << " = bb::mul(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
+            case airp::OP_MUL: o << "    const uint32_t " << t << " = bb::mul_s(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
             case airp::OP_ASSERT: o << "    sink.assert_zero(" << operand(a) << ");\n"; break;
             case airp::OP_IBEGIN: o << "    sink.ibegin(" << dst << "u, " << (a ? "true" : "false") << ", " << b << "u);\n"; break;
             case airp::OP_IVAL: o << "    sink.ival(" << operand(a) << ");\n"; break;

@@ -738,6 +738,36 @@ int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, ui
                                   out_dev, repr);
 }
 
+int32_t lurkhip_func_trace_run_many(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev, int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    if (n && (!ps || !outs_dev)) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    // The chips' trace kernels are independent of one another.  The tall ones (2^13 rows and more) fill the device and stay on the
+    // context's stream; the short ones -- the hash chips' one Poseidon2 witness per lane, ingress / egress, the memory tables: a few
+    // waves each, 70 us of latency per launch -- are dealt to the context's side lanes, tallest first, and run under one another
+    // and under the tall kernels (with no tall chip the context's own stream takes a share).  Joined before the call returns
+    // control of the stream: whatever is queued next (the main commitment) is ordered after every trace.
+    constexpr uint32_t TALL = 1u << 13;
+    std::vector<uint32_t> order;
+    uint32_t n_tall = 0;
+    for (uint32_t i = 0; i < n; i++) {
+        if (!ps[i] || !outs_dev[i]) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+        order.push_back(i);
+        n_tall += ps[i]->height >= TALL ? 1u : 0u;
+    }
+    std::stable_sort(order.begin(), order.end(), [&](uint32_t a, uint32_t b) { return ps[a]->height > ps[b]->height; });
+    lurkhip::SideLane lane(ctx);
+    if (n - n_tall >= 2) LH_TRY(lane.open());
+    const uint32_t slots = (uint32_t)lane.lanes + (n_tall ? 0u : 1u);  // slot `lanes` (when there is one) = the context's own stream
+    uint32_t k = 0;
+    for (uint32_t i : order) {
+        const bool tall = ps[i]->height >= TALL;
+        const uint32_t slot = tall ? 0u : k++ % slots;
+        const auto on_side = lane.on_side(!tall && slot < (uint32_t)lane.lanes, slot);
+        LH_TRY(lurkhip_func_trace_run(ctx, ps[i], outs_dev[i], repr));
+    }
+    return lane.close();
+}
+
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p) {
     LH_CHECK_CTX_NOLOCK(ctx);
     if (!p) return LURKHIP_OK;

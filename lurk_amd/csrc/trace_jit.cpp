@@ -49,7 +49,7 @@ struct Gen {
                 case T_ADD: def(ind, sp++, "bb::add(" + m(prog.at(pc + 1)) + ", " + m(prog.at(pc + 2)) + ")"); pc += 3; break;
                 case T_SUB: def(ind, sp++, "bb::sub(" + m(prog.at(pc + 1)) + ", " + m(prog.at(pc + 2)) + ")"); pc += 3; break;
                 case T_MUL:
-                    def(ind, sp, "bb::mul(" + m(prog.at(pc + 1)) + ", " + m(prog.at(pc + 2)) + ")");
+                    def(ind, sp, "bb::mul_s(" + m(prog.at(pc + 1)) + ", " + m(prog.at(pc + 2)) + ")");
                     if (flag) line(ind, "w.push_aux(" + m(sp) + ");");
                     sp++;
                     pc += 3;
@@ -90,7 +90,7 @@ struct Gen {
                     line(ind, "{");
                     line(ind + 1, "uint32_t acc = bb::sub(" + m(prog.at(pc + 2)) + ", " + b + ");");
                     for (uint32_t i = 1; i < n; i++) {
-                        line(ind + 1, "acc = bb::mul(acc, bb::sub(" + m(prog.at(pc + 2 + i)) + ", " + b + "));");
+                        line(ind + 1, "acc = bb::mul_s(acc, bb::sub(" + m(prog.at(pc + 2 + i)) + ", " + b + "));");
                         line(ind + 1, "w.push_aux(acc);");
                     }
                     line(ind, "}");

@@ -183,16 +183,9 @@ class _ShardProver:
         if pool is not None:
             pool.shutdown(wait=True)
             self._lane_pool = None
-        if self._side_ctx is not None:
-            self._side_ctx.close()
-            self._side_ctx = None
         if self._lane_ctx is not None:
             self._lane_ctx.close()
             self._lane_ctx = None
-        for ev in (self._ev_fork, self._ev_join):
-            if ev:
-                Context.destroy_event(ev)
-        self._ev_fork = self._ev_join = None
 
     def __del__(self):
         try:
@@ -281,9 +274,6 @@ class StarkMachine(_ShardProver):
         return verify_machine_proof([air for _, _, air in self.chips], self.vk_root, [], [], [proof], profile)
 
 
-SIDE_STREAM_MAX_LOG_ROWS = 12  # chips below 2^12 rows are "short" for run_prepared's side stream
-
-
 class Machine(_ShardProver):
     """Chip vector of one Lair toplevel with `entry` as its entrypoint (lair_chip.rs:196-211)."""
 
@@ -298,10 +288,8 @@ class Machine(_ShardProver):
             self.chips.append(("mem", ml, ChipAir.for_mem(ml)))
         self.chips.append(("bytes", None, ChipAir.for_bytes()))
         self.compiled_traces = []  # names of the function chips whose trace generator runs compiled (compile_airs)
-        self.side_stream = True     # run_prepared: short chips' trace kernels on a side stream
-        self._side_ctx = None
+        self.side_stream = True     # run_prepared: the short chips' trace kernels on the context's side streams
         self._lane_ctx = None       # second proving context of multi-shard proofs (prove)
-        self._ev_fork = self._ev_join = None
         self.pk = None
         self._prep = None
 
@@ -449,25 +437,18 @@ class Machine(_ShardProver):
         ev = getattr(prepared, "event", None)
         if ev:
             self.ctx.wait_event(ev)  # inputs uploaded on a staging context: its copies first
-        # The short chips (hash chips: one Poseidon2 witness per lane, a few waves in all; ingress / egress / lurk_main) are
-        # latency-bound launches with nothing to fill the device: they go to a side stream, forked behind everything queued
-        # so far and joined before the commitment, and run under the tall chips' kernels.
-        todo = [(lg, t, p) for _, _, lg, t, p in prepared if p is not None]
-        short = [x for x in todo if x[0] < SIDE_STREAM_MAX_LOG_ROWS]
-        tall = [x for x in todo if x[0] >= SIDE_STREAM_MAX_LOG_ROWS]
-        if short and tall and self.side_stream:
-            if self._side_ctx is None:
-                self._side_ctx = Context(beside=self.ctx)  # (a stream measured to run beside this context's)
-            self._ev_fork = self.ctx.record_event(self._ev_fork)
-            self._side_ctx.wait_event(self._ev_fork)
-            for _, t, p in short:
-                p.run(t, repr=N.REPR_MONTY, ctx=self._side_ctx)
-            self._ev_join = self._side_ctx.record_event(self._ev_join)
-            for _, t, p in tall:
-                p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
-            self.ctx.wait_event(self._ev_join)
+        # One call for the shard's chips: the short ones (hash chips: one Poseidon2 witness per lane, a few waves in all; ingress /
+        # egress / lurk_main; memory tables) are latency-bound launches with nothing to fill the device -- the library deals them to
+        # the context's side streams, forked behind everything queued so far and joined before the commitment, where they run
+        # under one another and under the tall chips' kernels (lurkhip_func_trace_run_many; round 3 ran them one after another on
+        # one side stream: 0.95 ms of a 2^12-row proof).
+        todo = [(t, p) for _, _, lg, t, p in prepared if p is not None]
+        if self.side_stream and len(todo) > 1:
+            ps = (C.c_void_p * len(todo))(*[p.handle for _, p in todo])
+            outs = (C.c_void_p * len(todo))(*[_addr(t) for t, _ in todo])
+            self.ctx.check(N.lib.lurkhip_func_trace_run_many(self.ctx.handle, len(todo), ps, outs, N.REPR_MONTY))
         else:
-            for _, t, p in todo:
+            for t, p in todo:
                 p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
         return [(mi, air, lg, t) for mi, air, lg, t, _ in prepared]
 
