@@ -31,9 +31,11 @@ struct lurkhip_commitment {
     std::vector<size_t> level_off;    // in digests (units of 8 words)
     int log_max = 0;
     std::vector<void*> owned;         // extra device allocations (column tables)
-    // the leaf sponge of the tallest height group launched ahead on the context's hash stream, under the LDE passes of the
-    // shorter groups (commit.hip: early_leaves; LURKHIP_EARLY_LEAVES)
-    bool early_leaves = false;
+    // The row sponge of ONE height group launched ahead on the context's hash stream, under the LDE passes of the other groups
+    // (commit.hip: early_sponge): early_level = the tree level its rows are injected at (0: the leaves), -1: none; for a level
+    // above the leaves early_digests holds the group's row digests (pooled, released with the tree's scratch).
+    int early_level = -1;
+    uint32_t* early_digests = nullptr;
     std::vector<void*> early_scratch;
 };
 

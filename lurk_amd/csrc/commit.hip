@@ -201,6 +201,7 @@ void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     if (!c) return;
     for (void* p : c->early_scratch) pool_release(ctx, p);
     c->early_scratch.clear();
+    if (c->early_level > 0) pool_release(ctx, c->early_digests);  // (an early sponge whose tree was never built)
     if (c->owns_lde)
         for (size_t i = 0; i < c->lde.size(); i++)
             if (i >= c->lde_is_view.size() || !c->lde_is_view[i]) pool_release(ctx, c->lde[i]);
@@ -211,6 +212,11 @@ void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
 }
 
 namespace {
+
+// early_sponge: a group of at most this many LDE rows (the row sponge kernel hashes such rows sixteen lanes to the row) and at least
+// this many columns (128 permutations one after the other: 0.4 ms)
+constexpr size_t EARLY_SPONGE_MAX_ROWS = 4096;
+constexpr uint32_t EARLY_SPONGE_MIN_WIDTH = 1024;
 
 // The uniform column table of the matrices in `idx` (one LeafCol per column of the concatenated row), written on the device by
 // a kernel that takes the matrices' (base, width) pairs as launch arguments: no host staging, no copy, nothing to keep alive.
@@ -273,45 +279,61 @@ int32_t make_cols(lurkhip_ctx* ctx, lurkhip_commitment* c, const std::vector<int
 // from being spread over the CUs) and no different from 16 or 2.
 constexpr size_t TOP_NODES = 64;
 
-// The leaf sponge of the tallest height group, launched on the context's hash stream behind `ctx->hash_ready` (recorded by the
-// caller on the main stream right after that group's LDE passes): it runs under the LDE passes of the shorter groups, which the
-// caller has queued on the main stream behind that event.  The sponge is VALU-bound, the passes are not (round 2 verdict,
-// item 5, second experiment).  Allocates the tree's digests; build_tree then skips group 0 and waits for `hash_done` before the
-// first level.  Must be called while the caller's side lane is open (pool releases deferred: nothing this hands to the hash
-// stream is a block that work queued behind the event has just released).
-int32_t early_leaves(lurkhip_ctx* ctx, lurkhip_commitment* c) {
+// whether build_tree hashes every injected group's rows ahead of the levels (one launch of row sponges, the levels only compress)
+bool tree_prehashes_rows(size_t n_leaves) {
+    const char* fused_env = getenv("LURKHIP_MERKLE_FUSED");
+    const char* group_env = getenv("LURKHIP_MERKLE_COOP_GROUP");
+    return (fused_env == nullptr || atoi(fused_env) != 0) && n_leaves > MERKLE_COOP_MAX_PARENTS && (group_env == nullptr || atoi(group_env) > 1);
+}
+
+// The row sponge of the height group of LDE height 2^lde_log_h, launched on the context's hash stream behind `ctx->hash_ready`
+// (recorded by the caller right after that group's LDE passes, on the stream they were queued on): it runs under the LDE passes
+// of the other groups.  Meant for the group whose rows are the longest CHAIN -- a fib machine's hash chips, 2125 columns at 2^9
+// rows: 266 sixteen-lane permutations one after the other, 0.83 ms whatever else the device does, which used to start only when
+// every LDE of the commitment was done (0.6 ms later in a 2^12-row proof).  build_tree then leaves that group out of its sponge
+// launch and waits for `hash_done` before the first level.  Must be called while the caller's side lane is open (pool releases
+// deferred: nothing this hands to the hash stream is a block that work queued behind the event has just released).
+int32_t early_sponge(lurkhip_ctx* ctx, lurkhip_commitment* c, int lde_log_h) {
     const P16Params* params = nullptr;
     LH_TRY(get_merkle_params(ctx, &params));
     c->log_max = *std::max_element(c->log_h.begin(), c->log_h.end());
     const size_t n_leaves = (size_t)1 << c->log_max;
-    if (n_leaves <= MERKLE_COOP_MAX_PARENTS) return LURKHIP_OK;
-    std::vector<int> tallest;
+    if (!tree_prehashes_rows(n_leaves)) return LURKHIP_OK;
+    const int level = c->log_max - lde_log_h;
+    std::vector<int> group;
     for (int m = 0; m < c->n_mats; m++)
-        if (c->log_h[m] == c->log_max) tallest.push_back(m);  // (ascending index = the stable height order of build_tree)
-    c->level_off.assign(c->log_max + 1, 0);
-    size_t total = 0;
-    for (int l = 0; l <= c->log_max; l++) {
-        c->level_off[l] = total;
-        total += n_leaves >> l;
+        if (c->log_h[m] == lde_log_h) group.push_back(m);  // (ascending index = the stable height order of build_tree)
+    if (group.empty()) return LURKHIP_OK;
+    const size_t n_rows = (size_t)1 << lde_log_h;
+    uint32_t* out = nullptr;
+    if (level == 0) {
+        c->level_off.assign(c->log_max + 1, 0);
+        size_t total = 0;
+        for (int l = 0; l <= c->log_max; l++) {
+            c->level_off[l] = total;
+            total += n_leaves >> l;
+        }
+        LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
+        out = c->digests;
+    } else {
+        LH_TRY(pool_alloc(ctx, n_rows * 8 * sizeof(uint32_t), (void**)&c->early_digests));
+        out = c->early_digests;
     }
-    LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
+    c->early_level = level;
     hipStream_t main_stream = ctx->stream;
     LH_HIP(ctx, hipStreamWaitEvent(ctx->hash_stream, ctx->hash_ready, 0));
     ctx->stream = ctx->hash_stream;
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
-    int32_t st = make_cols(ctx, c, tallest, &cols, &tw, c->early_scratch);
+    int32_t st = make_cols(ctx, c, group, &cols, &tw, c->early_scratch);
     if (st == LURKHIP_OK) {
-        span_begin(ctx, "merkle_leaves", c->log_max >= 16 ? 1 : 2);
         SpongeGroups g{};
-        g.cols[0] = cols, g.total_w[0] = tw, g.n_rows[0] = n_leaves, g.out[0] = c->digests, g.n = 1;
+        g.cols[0] = cols, g.total_w[0] = tw, g.n_rows[0] = n_rows, g.out[0] = out, g.n = 1;
         st = merkle_row_sponges(ctx, params, g);
-        span_end(ctx, "merkle_leaves", c->log_max >= 16 ? 1 : 2);
     }
     hipError_t e = hipEventRecord(ctx->hash_done, ctx->hash_stream);
     ctx->stream = main_stream;
     if (st == LURKHIP_OK && e != hipSuccess) st = set_error(ctx, LURKHIP_ERR_HIP, "hash stream: %s", hipGetErrorString(e));
-    if (st == LURKHIP_OK) c->early_leaves = true;
     return st;
 }
 
@@ -330,7 +352,9 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         c->level_off[l] = total;
         total += n_leaves >> l;
     }
-    if (!c->early_leaves) LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
+    const int early_level = c->early_level;  // (-1: no group was hashed ahead)
+    c->early_level = -1;
+    if (early_level != 0) LH_TRY(pool_alloc(ctx, total * 8 * sizeof(uint32_t), (void**)&c->digests));
     // leaves
     std::vector<int> tallest;
     for (int m : order)
@@ -344,7 +368,8 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     const bool fused = (fused_env == nullptr || atoi(fused_env) != 0) && n_leaves > MERKLE_COOP_MAX_PARENTS;
     std::vector<uint32_t*> inj_digests(c->log_max + 1, nullptr);  // by level
     std::vector<void*> scratch;
-    scratch.swap(c->early_scratch);  // (the early leaf sponge's column table: released with the rest, behind the join below)
+    scratch.swap(c->early_scratch);  // (the early sponge's column table and digests: released with the rest, behind the join below)
+    if (early_level > 0) scratch.push_back(c->early_digests);
     auto drop_scratch = [&]() {
         for (void* p : scratch) pool_release(ctx, p);  // stream-ordered: reusable by later work only
     };
@@ -361,6 +386,10 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             bool any = false;
             for (int m : order) any = any || c->log_h[m] == c->log_max - l;
             if (!any) continue;
+            if (l == early_level) {  // hashed ahead on the hash stream (early_sponge)
+                inj_digests[l] = c->early_digests;
+                continue;
+            }
             void* d = nullptr;
             const int32_t st = pool_alloc(ctx, n_parents * 8 * sizeof(uint32_t), &d);
             if (st != LURKHIP_OK) {
@@ -373,7 +402,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         }
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
-    if (!c->early_leaves) {
+    if (early_level != 0) {
         const int32_t st = make_cols(ctx, c, tallest, &cols, &tw, scratch);
         if (st != LURKHIP_OK) {
             drop_scratch();
@@ -383,7 +412,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     span_begin(ctx, "merkle_leaves", span_level);
     if (fused) {
         SpongeGroups g{};
-        if (!c->early_leaves) {
+        if (early_level != 0) {
             g.cols[0] = cols;
             g.total_w[0] = tw;
             g.n_rows[0] = n_leaves;
@@ -392,7 +421,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         }
         int32_t st = LURKHIP_OK;
         for (int l = 1; l <= c->log_max && st == LURKHIP_OK; l++) {
-            if (!inj_digests[l]) continue;
+            if (!inj_digests[l] || l == early_level) continue;
             std::vector<int> inject;
             for (int m : order)
                 if (c->log_h[m] == c->log_max - l) inject.push_back(m);
@@ -406,9 +435,8 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
             g.n++;
         }
         if (st == LURKHIP_OK && g.n) st = merkle_row_sponges(ctx, params, g);
-        if (st == LURKHIP_OK && c->early_leaves && hipStreamWaitEvent(ctx->stream, ctx->hash_done, 0) != hipSuccess)
+        if (st == LURKHIP_OK && early_level >= 0 && hipStreamWaitEvent(ctx->stream, ctx->hash_done, 0) != hipSuccess)
             st = set_error(ctx, LURKHIP_ERR_HIP, "joining the hash stream failed");
-        c->early_leaves = false;
         if (st != LURKHIP_OK) {
             drop_scratch();
             return st;
@@ -559,6 +587,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     std::vector<void*> uploads;  // host inputs staged in pooled device buffers (released, stream-ordered, once the LDEs are queued)
     auto fail = [&](int32_t s) {
         (void)stream_wait(ctx);
+        if (ctx->hash_stream) (void)hipStreamSynchronize(ctx->hash_stream);  // (an early sponge may still be writing)
         for (void* u : uploads) pool_release(ctx, u);
         free_commitment(ctx, c);
         return s;
@@ -699,7 +728,33 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     lane.want = 1;  // one side stream: the short matrices' passes share the coset-table scratch in order
     constexpr uint32_t SIDE_MAX_LOG_N = 13;
     if (!mats_on_host && log_blowup >= 1 && ctx->lde_scale_bytes + ((size_t)64 << 20) < ((size_t)1 << 30)) TRY_C(lane.open());
-    for (const GroupPlan& g : groups) {
+    // The chain group: the height whose concatenated row is the longest run of permutations hashed sixteen lanes to the row (few
+    // rows, thousands of columns: the hash chips).  Its LDE goes first and its row sponge starts at once on the hash stream
+    // (early_sponge), under the LDE passes of every other group.  Opt-in (LURKHIP_EARLY_SPONGE=1): measured on a 2^12-row proof the
+    // main commitment drops from 1.42 to 1.09 ms and the proof from 7.34 to 7.1-7.35 ms, but with two proofs in flight a step goes
+    // from 5.0 to 5.8 ms (one more stream per context competing for the hardware queues), and the 2^20-row step does not move.
+    static const bool early_on = getenv("LURKHIP_EARLY_SPONGE") != nullptr && atoi(getenv("LURKHIP_EARLY_SPONGE")) != 0;
+    int chain_log_n = -1;
+    if (early_on && lane.active && groups.size() >= 2) {
+        std::map<int, uint32_t> width_of;  // per height, grouped matrices only
+        std::map<int, bool> all_grouped;
+        for (int i = 0; i < n_mats; i++) {
+            width_of[(int)log_heights[i]] += widths[i];
+            all_grouped[(int)log_heights[i]] = (all_grouped.count((int)log_heights[i]) ? all_grouped[(int)log_heights[i]] : true) && grouped[i];
+        }
+        uint32_t best = 0;
+        for (const auto& kv : width_of)
+            if (all_grouped[kv.first] && ((size_t)1 << (kv.first + log_blowup)) <= EARLY_SPONGE_MAX_ROWS && kv.second >= EARLY_SPONGE_MIN_WIDTH && kv.second > best) {
+                best = kv.second;
+                chain_log_n = kv.first;
+            }
+        uint32_t max_log_n = 0;
+        for (int i = 0; i < n_mats; i++) max_log_n = std::max(max_log_n, log_heights[i]);
+        if (chain_log_n >= 0 && !tree_prehashes_rows((size_t)1 << (max_log_n + log_blowup))) chain_log_n = -1;
+        if (chain_log_n >= 0) std::stable_partition(groups.begin(), groups.end(), [&](const GroupPlan& g) { return g.log_n == chain_log_n; });
+    }
+    for (size_t gi = 0; gi < groups.size(); gi++) {
+        const GroupPlan& g = groups[gi];
         const auto on_side = lane.on_side((uint32_t)g.log_n < SIDE_MAX_LOG_N);
         const uint32_t* ev[LDE_MAX_MATS];
         uint32_t* ld[LDE_MAX_MATS];
@@ -712,35 +767,20 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         }
         TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false, gp));
         for (int i : g.idx) extended[i] = 1;
+        if (g.log_n == chain_log_n && (gi + 1 == groups.size() || groups[gi + 1].log_n != chain_log_n)) {  // the chain group's last plan is queued
+            TRY_C(hash_stream_of(ctx));
+            HIP_C(hipEventRecord(ctx->hash_ready, ctx->stream));  // (on the stream its passes were queued on)
+            TRY_C(early_sponge(ctx, c, chain_log_n + log_blowup));
+        }
     }
     if (!mats_on_host && log_blowup >= 1) {
         // device-resident matrices of one shape go through the passes together
         std::map<std::pair<uint32_t, uint32_t>, std::vector<int>> shapes;
         for (int i = 0; i < n_mats; i++)
             if (!grouped[i]) shapes[{log_heights[i], widths[i]}].push_back(i);
-        // tallest first: the leaf sponge of the tallest height group can then start (on the hash stream) while the shorter
-        // groups' passes are still running (early_leaves; LURKHIP_EARLY_LEAVES=1)
-        uint32_t max_log = 0;
-        size_t n_heights = 0;
-        {
-            std::vector<uint32_t> hs;
-            for (const auto& kv : shapes) hs.push_back(kv.first.first);
-            hs.erase(std::unique(hs.begin(), hs.end()), hs.end());
-            n_heights = hs.size();
-            max_log = hs.empty() ? 0 : hs.back();
-        }
-        static const bool early_on = getenv("LURKHIP_EARLY_LEAVES") != nullptr && atoi(getenv("LURKHIP_EARLY_LEAVES")) != 0 &&
-                                     (getenv("LURKHIP_MERKLE_FUSED") == nullptr || atoi(getenv("LURKHIP_MERKLE_FUSED")) != 0);
-        const bool early = early_on && lane.active && n_heights >= 2 && max_log >= SIDE_MAX_LOG_N &&
-                           (((size_t)1 << (max_log + log_blowup)) > MERKLE_COOP_MAX_PARENTS);
-        bool early_marked = false;
+        // tallest first
         for (auto it = shapes.rbegin(); it != shapes.rend(); ++it) {
             const auto& kv = *it;
-            if (early && !early_marked && kv.first.first != max_log) {  // every matrix of the tallest height is queued: mark it
-                TRY_C(hash_stream_of(ctx));
-                HIP_C(hipEventRecord(ctx->hash_ready, ctx->stream));
-                early_marked = true;
-            }
             const auto on_side = lane.on_side(kv.first.first < SIDE_MAX_LOG_N);
             const std::vector<int>& idx = kv.second;
             for (size_t at = 0; at < idx.size(); at += NTT_MAX_BATCH) {
@@ -761,12 +801,6 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                 if (done)
                     for (int m = 0; m < nb; m++) extended[idx[at + m]] = 1;
             }
-        }
-        if (early_marked) {
-            bool all_tall_extended = true;
-            for (int i = 0; i < n_mats; i++)
-                if (log_heights[i] == max_log && !extended[i]) all_tall_extended = false;
-            if (all_tall_extended) TRY_C(early_leaves(ctx, c));
         }
     }
     for (int i = 0; i < n_mats; i++) {

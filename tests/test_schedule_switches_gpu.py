@@ -38,7 +38,7 @@ SWITCHES = [
     {},
     {"LURKHIP_SIDE_LANE": "0"},
     {"LURKHIP_SIDE_LANES": "1"},
-    {"LURKHIP_EARLY_LEAVES": "1"},
+    {"LURKHIP_EARLY_SPONGE": "1"},  # the hash chips' row sponge ahead on the hash stream, under the other groups' LDE passes
     {"LURKHIP_MERKLE_FUSED": "0"},
     {"LURKHIP_MERKLE_COOP_GROUP": "1"},
     {"LURKHIP_SPONGE_COOP": "0"},
