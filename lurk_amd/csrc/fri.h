@@ -62,6 +62,7 @@ struct NarrowMat {
     uint32_t w;
     uint32_t two;  // opened at both points (else only at the first)
     bb::ef ys0, ys1, apow0, apow1;
+    uint32_t pitch = 0;  // words between rows; 0: w
 };
 struct NarrowArgs {
     NarrowMat m[NARROW_MAX_MATS];
@@ -73,6 +74,27 @@ struct NarrowArgs {
     uint32_t* ro;
 };
 int32_t reduce_openings_narrow(lurkhip_ctx* ctx, const NarrowArgs& args);
+// Reduced openings of the matrices of one height, any width from 4 columns up, any row pitch, in one launch (fri.hip:
+// k_reduce_openings_rows, round 4): four lanes to a row, every lane reads 16-byte pieces of its row straight from memory.
+constexpr uint32_t ROWS_MAX_MATS = 12, ROWS_MAX_W = 2048;
+struct RowsMat {
+    const uint32_t* mat;  // first column of row 0
+    uint32_t pitch;       // words between rows
+    uint32_t w;           // >= 4
+    uint32_t two;         // opened at both points (else only at the first)
+    bb::ef ys0, ys1, apow0, apow1;
+};
+struct RowsArgs {
+    RowsMat m[ROWS_MAX_MATS];
+    uint32_t n_mats;
+    uint32_t m_rows;
+    uint32_t max_w;
+    const uint32_t* alpha_pows;  // centred table (k_ef_powers), at least max_w entries
+    const uint32_t* d0;
+    const uint32_t* d1;  // nullable: no matrix of the group is opened at a second point
+    uint32_t* ro;
+};
+int32_t reduce_openings_rows(lurkhip_ctx* ctx, RowsArgs args);
 // reduced openings of one wide matrix (w > 128) as column slices of at most 128 words in one launch (fri.hip:
 // k_reduce_openings_wide).  Slice i covers columns c0[i] .. c0[i] + sw[i]; ys_p[i] = sum_j alpha^j y_p[c0[i] + j] and
 // apow_p[i] = (the matrix's alpha offset at point p) * alpha^c0[i].

@@ -664,7 +664,7 @@ __global__ __launch_bounds__(256) void k_reduce_openings_narrow(NarrowArgs a) {
     for (uint32_t m = 0; m < a.n_mats; m++) {
         const NarrowMat& nm = a.m[m];
         const uint32_t w = nm.w;
-        const uint32_t* __restrict__ row = nm.mat + (size_t)s * w;
+        const uint32_t* __restrict__ row = nm.mat + (size_t)s * (nm.pitch ? nm.pitch : w);
         LazyEf rr;
         rr.zero();
         for (uint32_t c0 = 0; c0 < w; c0 += 4) {
@@ -1058,6 +1058,117 @@ int32_t reduce_openings_wide(lurkhip_ctx* ctx, WideArgs a) {
     else if (max_sw <= 112) LH_RW(112);
     else LH_RW(128);
 #undef LH_RW
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+// Round 4: four lanes to a row, no staging.  The streaming kernels above bring a tile into LDS with coalesced dword loads and
+// read it back row-wise: per matrix word a load, an LDS store, an LDS load and their address arithmetic around the four
+// multiply-adds that are the work -- about 30 instructions per word, VALU-bound at a quarter of the memory rate (PMC round 3:
+// 22 T lane-instr/s, 2-3 TB/s).  Here the lanes of a quad take the 16-byte pieces k = part, part + 4, ... of their row (dword-
+// aligned 16-byte loads, which gfx950 allows): a wave reads 16 rows, i.e. one contiguous run of memory when the matrix is dense,
+// every line of it within a few instructions.  Per piece: one load, four 16-byte LDS reads of the alpha powers, sixteen
+// multiply-adds and eight fold multiply-adds.  The last piece of a row is the four columns w - 4 .. w - 1 with zero weights
+// for the columns its neighbour already took (a table of four weights per matrix), so nothing is read past a row and any
+// pitch and column offset work: matrices with their own buffer and column ranges of a padded group alike.  All the matrices
+// of a height share the launch: ro / d0 / d1 are touched once per row.
+typedef const __attribute__((address_space(1))) uint32_t* gwords;
+typedef uint32_t u32x4_a4 __attribute__((ext_vector_type(4), aligned(4)));
+typedef const __attribute__((address_space(1))) u32x4_a4* gquads;
+__global__ __launch_bounds__(256) void k_reduce_openings_rows(RowsArgs a) {
+    extern __shared__ uint32_t rows_lds[];
+    uint32_t* __restrict__ tbl = rows_lds;                      // [max_w][4]: centred alpha^c
+    uint32_t* __restrict__ tails = rows_lds + 4 * a.max_w;      // [n_mats][4][4]: the weights of a row's last piece
+    uint32_t* __restrict__ zeros = tails + 16 * ROWS_MAX_MATS;  // [4][4]: the weights of a piece past the row
+    for (uint32_t e = threadIdx.x; e < 4u * a.max_w; e += 256u) tbl[e] = a.alpha_pows[8u * (e >> 2) + (e & 3u)];
+    for (uint32_t e = threadIdx.x; e < 16u * a.n_mats; e += 256u) {
+        const uint32_t m = e >> 4, j = (e >> 2) & 3u, w = a.m[m].w;
+        const uint32_t c = w - 4u + j, first = 4u * ((w + 3u) / 4u - 1u);  // first column of the last piece proper
+        tails[e] = c >= first ? a.alpha_pows[8u * c + (e & 3u)] : 0u;
+    }
+    if (threadIdx.x < 16u) zeros[threadIdx.x] = 0u;
+    __syncthreads();
+    const uint32_t part = threadIdx.x & 3u, r_in = threadIdx.x >> 2;
+    const uint32_t n_tiles = (a.m_rows + 63u) / 64u;
+    constexpr int UN = 4;
+    for (uint32_t t = blockIdx.x; t < n_tiles; t += gridDim.x) {
+        const uint32_t s = t * 64u + r_in;
+        const bool live = s < a.m_rows;
+        const size_t sr = live ? s : a.m_rows - 1;
+        ef g = bb::ef_zero();  // lane 0 of the quad: the first point's sum, lane 1: the second point's
+        for (uint32_t m = 0; m < a.n_mats; m++) {
+            const RowsMat& rm = a.m[m];
+            const uint32_t w = rm.w, n_pieces = (w + 3u) / 4u, n_iter = (n_pieces + 3u) / 4u;
+            gwords row = (gwords)rm.mat + sr * rm.pitch;
+            const uint32_t* __restrict__ tail = tails + 16u * m;
+            // Four 64-bit lanes of R * (sum of value x centred weight), two terms between folds on a fixed schedule (lazy_ef.h:
+            // a folded lane is below 0.08 p^2, a term below 0.5 p^2, the reduction takes 1.2 p^2)
+            int64_t acc[4] = {0, 0, 0, 0};
+            for (uint32_t kb = 0; kb < n_iter; kb += UN) {
+                u32x4_a4 v[UN];
+                const uint32_t* wp[UN];
+#pragma unroll
+                for (int j = 0; j < UN; j++) {
+                    const uint32_t k = (kb + (uint32_t)j) * 4u + part;
+                    const bool valid = k < n_pieces, last = k + 1u == n_pieces;
+                    v[j] = *(gquads)(row + (!valid ? 0u : last ? w - 4u : 4u * k));  // (a piece past the row re-reads its start: zero weights)
+                    wp[j] = !valid ? zeros : last ? tail : tbl + 16u * k;
+                }
+#pragma unroll
+                for (int j = 0; j < UN; j++) {
+                    if (kb + (uint32_t)j >= n_iter) break;  // (uniform)
+#pragma unroll
+                    for (int e = 0; e < 4; e += 2) {
+                        const uint4 q0 = *reinterpret_cast<const uint4*>(wp[j] + 4 * e), q1 = *reinterpret_cast<const uint4*>(wp[j] + 4 * e + 4);
+                        const int32_t v0 = (int32_t)v[j][e], v1 = (int32_t)v[j][e + 1];
+                        acc[0] = bb::mad_i64(v1, (int32_t)q1.x, bb::mad_i64(v0, (int32_t)q0.x, acc[0]));
+                        acc[1] = bb::mad_i64(v1, (int32_t)q1.y, bb::mad_i64(v0, (int32_t)q0.y, acc[1]));
+                        acc[2] = bb::mad_i64(v1, (int32_t)q1.z, bb::mad_i64(v0, (int32_t)q0.z, acc[2]));
+                        acc[3] = bb::mad_i64(v1, (int32_t)q1.w, bb::mad_i64(v0, (int32_t)q0.w, acc[3]));
+#pragma unroll
+                        for (int c = 0; c < 4; c++) acc[c] = bb::mad_i64((int32_t)(acc[c] >> 32), (int32_t)bb::R1, (int64_t)(uint64_t)(uint32_t)acc[c]);
+                    }
+                }
+            }
+            ef x;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                x.c[k] = bb::canon(bb::sred(acc[k]));
+                x.c[k] = bb::add(x.c[k], dpp<DPP_QUAD_XOR1>(x.c[k]));
+                x.c[k] = bb::add(x.c[k], dpp<DPP_QUAD_XOR2>(x.c[k]));
+            }
+            const bool second = part == 1u;
+            ef ys, ap;
+#pragma unroll
+            for (int k = 0; k < 4; k++) {
+                ys.c[k] = second ? rm.ys1.c[k] : rm.ys0.c[k];
+                ap.c[k] = second ? rm.apow1.c[k] : rm.apow0.c[k];
+            }
+            const ef term = bb::ef_mul(ap, bb::ef_sub(x, ys));
+            if (!second || rm.two) g = bb::ef_add(g, term);
+        }
+        const uint32_t* __restrict__ dp = part == 1u && a.d1 ? a.d1 : a.d0;
+        ef term = bb::ef_mul(g, ef_load(dp + 4 * sr));
+        if (part >= 2u || (part == 1u && !a.d1)) term = bb::ef_zero();
+#pragma unroll
+        for (int k = 0; k < 4; k++) term.c[k] = bb::add(term.c[k], dpp<DPP_QUAD_XOR1>(term.c[k]));
+        if (part == 0u && live) ef_store(a.ro + 4 * (size_t)s, bb::ef_add(ef_load(a.ro + 4 * (size_t)s), term));
+    }
+}
+
+int32_t reduce_openings_rows(lurkhip_ctx* ctx, RowsArgs a) {
+    if (a.n_mats == 0) return LURKHIP_OK;
+    LH_ARG(ctx, a.n_mats <= ROWS_MAX_MATS, "reduce_openings_rows: %u matrices", a.n_mats);
+    a.max_w = 0;
+    for (uint32_t m = 0; m < a.n_mats; m++) {
+        LH_ARG(ctx, a.m[m].w >= 4 && a.m[m].w <= ROWS_MAX_W && a.m[m].pitch >= a.m[m].w, "reduce_openings_rows: matrix %u", m);
+        a.max_w = std::max(a.max_w, a.m[m].w);
+    }
+    const size_t lds = ((size_t)4 * a.max_w + 16 * ROWS_MAX_MATS + 16) * 4;
+    const uint32_t n_tiles = (a.m_rows + 63) / 64;
+    static const int per_cu = getenv("LURKHIP_ROWS_PER_CU") ? std::max(1, atoi(getenv("LURKHIP_ROWS_PER_CU"))) : 8;
+    const unsigned blocks = (unsigned)std::min<size_t>(n_tiles, (size_t)ctx->num_cus * per_cu);
+    hipLaunchKernelGGL(k_reduce_openings_rows, dim3(blocks), dim3(256), lds, ctx->stream, a);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

@@ -8,15 +8,18 @@ using bb::ef;
 
 // Extension-field accumulator for sums of (lane value) x (wave-uniform extension constant): four 64-bit lanes holding
 // R * value, fed by one v_mad_i64_i32 per coefficient and term and reduced only when the next term would not fit.
-// A term is (|v| <= p) x (|w_c| <= p/2) <= p^2 / 2; a freshly folded lane is below 0.15 p^2 and sred needs |t| < 1.2 p^2,
-// so two terms fit between folds: 4 multiply-adds + 6 fold instructions per term against 36 for scale + add in
+// A term is (|v| <= p) x (|w_c| <= p/2) <= p^2 / 2; a freshly folded lane is below 0.08 p^2 and sred needs |t| < 1.2 p^2,
+// so two terms fit between folds: 4 multiply-adds + 2 fold multiply-adds per term against 36 instructions for scale + add in
 // canonical form.
 struct LazyEf {
     int64_t a[4];
     uint32_t room;  // terms that still fit (wave-uniform)
+    // a = hi * 2^32 + lo (hi signed, lo unsigned) is congruent to hi * R1 + lo, R1 = 2^32 mod p < 2^28: one multiply-add per lane,
+    // and the folded lane is below 2^58.1 = 0.08 p^2 (|hi| < 2^30.1 for |a| < 1.2 p^2).  (Rounds 2-3 folded through a full
+    // Montgomery reduction and a product by R1: three multiply-class instructions per lane instead of one.)
     __device__ __forceinline__ void fold() {
 #pragma unroll
-        for (int c = 0; c < 4; c++) a[c] = bb::mad_i64(bb::sred(a[c]), (int32_t)bb::R1, 0);
+        for (int c = 0; c < 4; c++) a[c] = bb::mad_i64((int32_t)(a[c] >> 32), (int32_t)bb::R1, (int64_t)(uint64_t)(uint32_t)a[c]);
         room = 2;
     }
     __device__ __forceinline__ void set(const ef& x) {  // canonical x

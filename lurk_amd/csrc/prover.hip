@@ -463,6 +463,15 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         g.wa.n_slices = 0;
         return st;
     };
+    // every matrix of four columns and more that is not narrow waits per (height, first point) for the rows kernel (fri.hip:
+    // k_reduce_openings_rows); LURKHIP_REDUCE_ROWS=0: the round-3 kernels (quad / stream / slices)
+    static const bool rows_on = getenv("LURKHIP_REDUCE_ROWS") == nullptr || atoi(getenv("LURKHIP_REDUCE_ROWS")) != 0;
+    std::map<std::pair<int, int>, RowsArgs> rows_groups;
+    auto flush_rows = [&](RowsArgs& g) -> int32_t {
+        const int32_t st = reduce_openings_rows(ctx, g);
+        g.n_mats = 0;
+        return st;
+    };
     size_t mat_k = 0;
     SideLane ro_lane(ctx);  // the accumulators are per height: a height is one lane
     ro_lane.want = side_lanes_wanted;
@@ -491,7 +500,20 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             uint64_t& offset = num_reduced[prof.fri_alpha_global ? 0 : log_h];
             const ef apow0 = ef_pow_host(alpha_fri, offset);
             const ef apow1 = ef_pow_host(alpha_fri, offset + w);
-            if (r.c->pitch[m] != w && alpha_pows_c) {
+            if (rows_on && alpha_pows_c && w > NARROW_MAX_W && w <= ROWS_MAX_W) {
+                RowsArgs& g = rows_groups[{log_h, mp[0]}];
+                if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_rows(g));  // a different second point: its own launch
+                if (g.n_mats == 0) {
+                    g = RowsArgs{};
+                    g.m_rows = 1u << log_h;
+                    g.alpha_pows = alpha_pows_c;
+                    g.d0 = d0;
+                    g.ro = ro[log_h];
+                }
+                if (d1) g.d1 = d1;
+                g.m[g.n_mats++] = RowsMat{r.c->lde[m], r.c->pitch[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1};
+                if (g.n_mats == ROWS_MAX_MATS) PTRY(flush_rows(g));
+            } else if (r.c->pitch[m] != w && alpha_pows_c && !(rows_on && w <= NARROW_MAX_W)) {
                 GroupWide& g = group_wide[{ri, r.c->group[m]}];
                 if (g.wa.n_slices && g.wa.d1 != d1) PTRY(flush_group(g));  // a different second point: its own launch
                 for (uint32_t c0 = 0; c0 < w; c0 += group_slice_w) {
@@ -524,7 +546,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
                 if (g.n_mats == 0) g = NarrowArgs{{}, 0, 1u << log_h, alpha_pows_c, d0, nullptr, ro[log_h]};
                 if (d1) g.d1 = d1;  // one second point per height (the first point's successor on that domain)
-                g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1};
+                g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1, r.c->pitch[m]};
                 if (g.n_mats == NARROW_MAX_MATS) PTRY(flush_narrow(g));
             } else if (w > 128 && w <= 128 * WIDE_MAX_SLICES && alpha_pows_c) {
                 // column slices of equal width (the last one takes the remainder), each with its own alpha offset and
@@ -562,6 +584,10 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     for (auto& kv : narrow) {
         const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
         PTRY(flush_narrow(kv.second));
+    }
+    for (auto& kv : rows_groups) {
+        const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
+        PTRY(flush_rows(kv.second));
     }
     for (auto& kv : group_wide) {
         const auto on_side = ro_lane.on_side(kv.second.log_h - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.second.log_h);

@@ -44,8 +44,10 @@ SWITCHES = [
     {"LURKHIP_SPONGE_COOP": "0"},
     {"LURKHIP_DOT_OLD": "1", "LURKHIP_OPENINGS_NO_QUAD": "1"},
     {"LURKHIP_TRACE_INTERPRET": "1", "LURKHIP_NTT_MAX_LOG_R": "7"},
+    {"LURKHIP_REDUCE_ROWS": "0"},  # reduced openings through the round-3 kernels (tiles staged in LDS)
     {"LURKHIP_LDE_PADDED": "0"},  # every LDE in its own dense buffer (round 3's layout)
-    {"LURKHIP_LDE_PADDED": "2", "LURKHIP_REDUCE_SLICE_W": "32"},  # every height group in one padded buffer, whatever the padding costs
+    {"LURKHIP_LDE_PADDED": "2"},  # every height group in one padded buffer, whatever the padding costs
+    {"LURKHIP_LDE_PADDED": "2", "LURKHIP_REDUCE_SLICE_W": "32", "LURKHIP_REDUCE_ROWS": "0"},  # every height group in one padded buffer, whatever the padding costs
 ]
 
 
