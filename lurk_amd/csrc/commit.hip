@@ -726,6 +726,10 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     // the coset-shift table cache has room (its fallback scratch, arena slot 2, is shared by the streams).
     SideLane lane(ctx);
     lane.want = 1;  // one side stream: the short matrices' passes share the coset-table scratch in order
+    // LURKHIP_LDE_TALL_LANES=1 (A/B): the tall height groups alternate between the context's stream and a second side stream, so
+    // that one group's first pass runs in the tail of another's last
+    static const bool tall_lanes = getenv("LURKHIP_LDE_TALL_LANES") != nullptr && atoi(getenv("LURKHIP_LDE_TALL_LANES")) != 0;
+    if (tall_lanes) lane.want = 2;
     constexpr uint32_t SIDE_MAX_LOG_N = 13;
     if (!mats_on_host && log_blowup >= 1 && ctx->lde_scale_bytes + ((size_t)64 << 20) < ((size_t)1 << 30)) TRY_C(lane.open());
     // The chain group: the height whose concatenated row is the longest run of permutations hashed sixteen lanes to the row (few
@@ -755,7 +759,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     }
     for (size_t gi = 0; gi < groups.size(); gi++) {
         const GroupPlan& g = groups[gi];
-        const auto on_side = lane.on_side((uint32_t)g.log_n < SIDE_MAX_LOG_N);
+        const bool short_group = (uint32_t)g.log_n < SIDE_MAX_LOG_N;
+        const auto on_side = lane.on_side(short_group || (tall_lanes && lane.lanes >= 2 && (gi & 1)), short_group ? 0u : 1u);
         const uint32_t* ev[LDE_MAX_MATS];
         uint32_t* ld[LDE_MAX_MATS];
         uint32_t gw[LDE_MAX_MATS], gp[LDE_MAX_MATS];
