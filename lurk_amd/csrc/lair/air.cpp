@@ -1171,8 +1171,11 @@ AirPrograms lower_air(const ChipAir& air) {
             out.push_back(lower_range(std::min(b0 * batch, all.size()), std::min(b1 * batch, all.size()), (uint32_t)b0, true));
         }
     };
-    cut(12, p.interaction_parts);
-    cut(24, p.interaction_parts_coarse);
+    static const size_t perm_per_part = getenv("LURKHIP_PERM_PER_PART") ? (size_t)std::max(2, atoi(getenv("LURKHIP_PERM_PER_PART"))) : 12;  // (A/B hook)
+    cut(perm_per_part, p.interaction_parts);
+    // (LURKHIP_QUOT_PER_PART: interactions per quotient piece, A/B hook; round 2 settled on 24 -- more pieces were slower then: the per-lane reads of the permutation row thrashed L1; round 4, with the sinks' arithmetic a third cheaper, 12 measures 3.02 -> 2.83 ms for the quotient stage, 8 and 16 2.9)
+    static const size_t quot_per_part = getenv("LURKHIP_QUOT_PER_PART") ? (size_t)std::max(2, atoi(getenv("LURKHIP_QUOT_PER_PART"))) : 12;
+    cut(quot_per_part, p.interaction_parts_coarse);
     return p;
 }
 

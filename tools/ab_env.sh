@@ -6,6 +6,6 @@ for round in 1 2; do
     env $e python bench.py --no-cpu-baseline --no-host-pipeline 2>/dev/null | python -c "
 import json,sys
 d=json.loads(sys.stdin.read().strip().splitlines()[-1]); s=d['config']['stages_ms']
-print('%-40s in-flight %.2f ms  latency %.2f ms  lde %.2f leaves %.2f open %.2f quot %.2f' % ('[$e]', d['ms_per_step'], d.get('proof_latency_ms') or 0, s['lde'], s['merkle_leaves'], s['open'], s['quotient_all']))"
+print('%-40s in-flight %.2f ms  latency %.2f ms  lde %.2f leaves %.2f open %.2f quot %.2f perm %.2f' % ('[$e]', d['ms_per_step'], d.get('proof_latency_ms') or 0, s['lde'], s['merkle_leaves'], s['open'], s['quotient_all'], s['permutation']))"
   done
 done
