@@ -976,7 +976,8 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
         b.W = std::min(W_all, c0 + step);
         st = launch_cols(ctx, K_IN, a.r1, b, (size_t)1 << a.r2, io_c);
         // the fused pass keeps two workgroups on a CU: 2^10-row tiles are 16 columns wide
-        if (st == LURKHIP_OK) st = launch_cols(ctx, K_MID, a.r2, b, (size_t)1 << a.r1, a.r2 >= 10 ? 4 : 5);
+        static const int mid_log_c = getenv("LURKHIP_LDE_MID_LOG_C") ? std::max(4, std::min(5, atoi(getenv("LURKHIP_LDE_MID_LOG_C")))) : 5;  // (A/B hook)
+        if (st == LURKHIP_OK) st = launch_cols(ctx, K_MID, a.r2, b, (size_t)1 << a.r1, a.r2 >= 10 ? 4 : mid_log_c);
         if (st == LURKHIP_OK) st = launch_cols(ctx, K_OUT, a.r1, b, (size_t)2 << a.r2, io_c);
     }
     pool_release(ctx, A);  // stream-ordered
