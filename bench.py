@@ -63,7 +63,7 @@ def synthetic_trace(log_rows: int, width: int, seed_offset: int) -> np.ndarray:
     return t
 
 
-CPU_SAMPLE_LOG_SHRINK = 1  # the CPU port proves a shard of 2^(log_rows - 1) eval rows: about 10 s of CPU work on the box's 16-core quota
+CPU_SAMPLE_MAX_LOG_ROWS = 20  # the CPU port proves the bench's own shard up to 2^20 eval rows (about 20 s of CPU work on the box's 16-core quota; rounds 2-3: half height), a taller one cut down to that
 
 
 def host_info():
@@ -91,7 +91,8 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     evaluators generated out of the oracle's AIR, opened values, reduced openings, the FRI commit phase, proof-of-work, query
     openings; OpenMP, Montgomery arithmetic), every stage checked word for word against oracle/stark.py and the whole proof
     accepted by the oracle's verifier and equal to the HIP prover's (tests/test_cpu_step*.py).  Timed on a BOUNDED SAMPLE: the
-    same machine with every chip of 2^12 rows and more half as tall (2^(log_rows - 1) eval rows), on synthetic traces of
+    same machine at the bench's own heights (from 2^21 eval rows up: every chip of 2^12 rows and more cut down by the same factor to
+    2^20 eval rows), on synthetic traces of
     those shapes (no stage's cost depends on the values; the constraints need not hold for the openings and FRI to be
     well-formed).  `value` = sample eval rows / seconds.  Trace generation of the function chips is oracle/cpu_trace.c (a C row
     loop over flattened query records, checked word for word against the oracle's generator): a small real execution of the
@@ -106,6 +107,7 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
 
     ob.build()
     cores = ob.usable_cores()
+    shrink = max(0, log_rows - CPU_SAMPLE_MAX_LOG_ROWS)
     mix = lm.fib_mix(64) if workload == "fib-mix" else lm.lurk_mix(64)
     otop = ol.Toplevel(mix.source, chips=ol.lurk_chips())
     n_public = 44
@@ -127,7 +129,7 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     for name, lg, w in chip_shapes:
         mi = names.index(name)
         assert airs[mi].width == w, (name, airs[mi].width, w)
-        lgs = lg - CPU_SAMPLE_LOG_SHRINK if lg >= 12 and name != "CPU" else lg
+        lgs = lg - shrink if lg >= 12 and name != "CPU" else lg
         mat = None
         if name.startswith("Func["):
             fname = name[5:-1]
@@ -173,7 +175,7 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
         "seconds": dt,
         "stages_s": stages_s,
         "sample": f"the WHOLE step (function-chip trace generation from flattened query records, main / permutation / quotient commitments, LogUp rows, quotient, openings, FRI with {queries} queries and {pow_bits} PoW bits) "
-                  f"on a shard half as tall: 2^{log_rows - CPU_SAMPLE_LOG_SHRINK} eval rows of the {workload} machine (a small real execution's rows repeated; memory / byte / entry chips synthetic); oracle/cpu_trace.c + cpu_prover.py + cpu_step.c, OpenMP over "
+                  f"on {'the bench shard itself' if shrink == 0 else 'a shard cut down by 2^' + str(shrink)}: 2^{log_rows - shrink} eval rows of the {workload} machine (a small real execution's rows repeated; memory / byte / entry chips synthetic); oracle/cpu_trace.c + cpu_prover.py + cpu_step.c, OpenMP over "
                   f"{cores} threads, {dt:.1f} s; stage names as in config.stages_s of the GPU line (proof-of-work counted under fri_query; to_montgomery = input conversion); "
                   "not the reference binary (no Rust toolchain): never quote the ratio as 'vs the reference'",
         "evaluator_build_s": pr.build_s,
