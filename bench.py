@@ -741,7 +741,11 @@ def main():
             # is measured in THIS run (HIP events on the library's stream, the one-proof-at-a-time pass)
             insts = pmc.get("merkle_hash_valu_lane_insts_per_step")
             if insts and hash_ms_step > 0:
-                live = insts * len(mine) / (hash_ms_step * 1e-3) / 1e12
+                # (the count is proportional to the words hashed: scaled from the PMC pass's shapes -- one 2^20-row shard -- to this
+                # rank's shards by the algorithmic bytes of the hashing launches)
+                ref_bytes = pmc.get("merkle_hash_algorithmic_bytes_per_step")
+                scale = hash_bytes_step / ref_bytes if ref_bytes else float(len(mine))
+                live = insts * scale / (hash_ms_step * 1e-3) / 1e12
                 src_v = ("instruction count from the committed PMC pass (profiles/pmc_traffic.json: SQ_INSTS_VALU x 64 lanes of the hashing launches of one step, "
                          "deterministic) / the hashing launches' HIP-event time measured live in this run")
             else:

@@ -72,6 +72,7 @@ traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FE
            "ntt_pass_fetch_bytes_reported": sum(res["FETCH_SIZE"][0][k] for k in NTT) * 1024, "ntt_pass_write_bytes_reported": sum(res["WRITE_SIZE"][0][k] for k in NTT) * 1024,
            "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
            "merkle_hash_valu_tinst_s": hv, "merkle_hash_valu_lane_insts_per_step": hash_lane_insts,
+           "merkle_hash_algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_step"],  # the shapes the instruction count belongs to
            "lde_kernels": sorted(NTT), "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
 json.dump(traffic, open(f"profiles/{prefix}_pmc_traffic.json", "w"), indent=1)
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)  # the copy bench.py reads (labelled static there)
