@@ -239,8 +239,9 @@ def main():
                          "out of phase (one lane's commitments under the other's openings and FRI).  Default: one proof's sequential time / lanes, "
                          "measured in the same run (two lanes: half a proof) when there are at least 16 timed steps, else 0; 0 = all lanes start together (2.2-2.7 %% slower, DESIGN.md section 4)")
     ap.add_argument("--no-compile", action="store_true", help="keep every chip's AIR programs on the interpreter")
-    ap.add_argument("--compile-min-log-rows", type=int, default=None,
-                    help="compile the AIR programs and trace generators of chips from 2^this rows up (default: lurk_amd.jit_warm's 2^17; 0 = every chip)")
+    ap.add_argument("--compile-min-log-rows", type=int, default=0,
+                    help="compile the AIR programs and trace generators of chips from 2^this rows up (default 0 = every chip: build() warms the code-object "
+                         "cache for the whole fib-mix machine, and a 2^12-row proof is 5.9 ms with every chip compiled against 6.5-7.0; the library's own default is 2^17)")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the extra streamed multi-shard measurement (host flatten + upload under the proofs)")
     ap.add_argument("--pipeline-shards", type=int, default=4)
     ap.add_argument("--oversubscribe", action="store_true",

@@ -41,9 +41,12 @@ def _compile_one(job):
     return a.name, int(r), log.value.decode("utf-8", "replace")
 
 
-def warm(source: str, lurk_chips: bool, rows_by_func: dict, mem_lens=(2, 3, 4, 5, 6, 8), workers: int | None = None, verbose=False):
+def warm(source: str, lurk_chips: bool, rows_by_func: dict, mem_lens=(2, 3, 4, 5, 6, 8), workers: int | None = None, verbose=False,
+         min_log_rows: int = COMPILE_MIN_LOG_ROWS, entry: str | None = None, n_public: int = 0):
     """rows_by_func: function name -> expected number of trace rows.  Compiles (or finds in the cache) the kernels of every
-    function chip `wants_compile` selects at those heights, of the given memory tables and of the byte chip."""
+    function chip `wants_compile` selects at those heights (min_log_rows = 0: of every function chip, whatever its height -- a
+    prover of small programs compiles them all, Machine.compile_airs(min_log_rows=0)), of the given memory tables, of the byte
+    chip and, given `entry`, of that function's entrypoint chip."""
     from . import air, lair
 
     top = lair.Toplevel(source, lurk_chips=lurk_chips)
@@ -52,12 +55,14 @@ def warm(source: str, lurk_chips: bool, rows_by_func: dict, mem_lens=(2, 3, 4, 5
         idx = top.func_index(name)
         a = air.ChipAir.for_func(top, idx)
         log_rows = max(0, (max(rows, 1) - 1).bit_length())
-        if wants_compile(log_rows, a.constraint_instrs):
+        if log_rows >= min_log_rows or wants_compile(log_rows, a.constraint_instrs):
             jobs.append((source, lurk_chips, "func", idx, 0))
-        if log_rows >= COMPILE_MIN_LOG_ROWS:
+        if log_rows >= min_log_rows:
             jobs.append((source, lurk_chips, "trace", idx, 0))
     jobs += [(source, lurk_chips, "mem", ml, 0) for ml in mem_lens]
     jobs.append((source, lurk_chips, "bytes", 0, 0))
+    if entry is not None:
+        jobs.append((source, lurk_chips, "entry", top.func_index(entry), n_public))
     workers = workers or min(len(jobs), os.cpu_count() or 1)
     out = []
     with ProcessPoolExecutor(max_workers=workers) as ex:
