@@ -83,6 +83,29 @@ def test_open_two_rounds(ctx, oracle):
         c.close()
 
 
+@pytest.mark.parametrize("widths", [(17, 18, 19), (20, 21, 33, 5), (130, 257), (64, 16, 127, 4)])
+def test_open_odd_widths_through_the_rows_kernel(ctx, oracle, widths):
+    """Matrices wider than 16 columns are reduced four lanes to a row in 16-byte pieces (fri.hip: k_reduce_openings_rows): every
+    remainder of the width modulo 4 and modulo 16, several matrices of one height in a launch, narrow ones beside them; the oracle's
+    verifier recomputes the reduced openings from the opened values and checks the FRI queries against them."""
+    lg = 5
+    mats = [synth.field_elements((1 << lg, w), seed=1300 + w) for w in widths]
+    c = cm.commit(ctx, mats, log_blowup=1)
+    z = (1234567, 7654321, 99, 1 << 29)
+    zn = os_.ef_scale(z, os_.two_adic_generator(lg))
+    points = [[[z, zn] if i % 2 == 0 else [z] for i in range(len(widths))]]
+    ch, och = prover.Challenger(ctx), os_.Challenger(os_.default_permute16())
+    ch.observe(c.root)
+    och.observe([int(x) for x in c.root])
+    op = cm.open_rounds(ctx, [c], points, ch, num_queries=8, pow_bits=2)
+    for i, m in enumerate(mats):
+        for k, pt in enumerate(points[0][i]):
+            assert op.opened[0][i][k] == eval_columns_at(m, pt), (i, k)
+    rounds = [([int(x) for x in c.root], [(lg, w, list(zip(points[0][i], op.opened[0][i]))) for i, w in enumerate(widths)])]
+    os_.pcs_verify(rounds, op, 1, och, oracle.merkle_verify)
+    c.close()
+
+
 def test_open_argument_checks(ctx):
     c = cm.commit(ctx, [synth.field_elements((64, 3), seed=5)], log_blowup=1)
     ch = prover.Challenger(ctx)
