@@ -402,7 +402,7 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
         }
     LeafCol* cols = nullptr;
     uint32_t tw = 0;
-    if (early_level != 0) {
+    if (early_level != 0 && !fused) {
         const int32_t st = make_cols(ctx, c, tallest, &cols, &tw, scratch);
         if (st != LURKHIP_OK) {
             drop_scratch();
@@ -411,28 +411,42 @@ int32_t build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     }
     span_begin(ctx, "merkle_leaves", span_level);
     if (fused) {
+        // ONE column table for every group of the sponge launch (round 4: one k_fill_cols launch per tree instead of one per height
+        // group -- a dozen 4 us kernels in a row on the stream of every commitment): the groups' matrices in group order, a group's
+        // table is a run of it
         SpongeGroups g{};
-        if (early_level != 0) {
-            g.cols[0] = cols;
-            g.total_w[0] = tw;
-            g.n_rows[0] = n_leaves;
-            g.out[0] = c->digests;
-            g.n = 1;
-        }
-        int32_t st = LURKHIP_OK;
-        for (int l = 1; l <= c->log_max && st == LURKHIP_OK; l++) {
+        std::vector<int> flat;
+        std::vector<uint32_t> group_w;
+        auto add_group = [&](const std::vector<int>& mats, uint64_t n_rows, uint32_t* out) {
+            uint32_t w = 0;
+            for (int m : mats) {
+                flat.push_back(m);
+                w += c->width[m];
+            }
+            group_w.push_back(w);
+            g.total_w[g.n] = w;
+            g.n_rows[g.n] = n_rows;
+            g.out[g.n] = out;
+            g.n++;
+        };
+        if (early_level != 0) add_group(tallest, n_leaves, c->digests);
+        for (int l = 1; l <= c->log_max; l++) {
             if (!inj_digests[l] || l == early_level) continue;
             std::vector<int> inject;
             for (int m : order)
                 if (c->log_h[m] == c->log_max - l) inject.push_back(m);
-            LeafCol* icols = nullptr;
-            uint32_t iw = 0;
-            st = make_cols(ctx, c, inject, &icols, &iw, scratch);
-            g.cols[g.n] = icols;
-            g.total_w[g.n] = iw;
-            g.n_rows[g.n] = n_leaves >> l;
-            g.out[g.n] = inj_digests[l];
-            g.n++;
+            add_group(inject, n_leaves >> l, inj_digests[l]);
+        }
+        int32_t st = LURKHIP_OK;
+        if (g.n) {
+            LeafCol* all_cols = nullptr;
+            uint32_t all_w = 0;
+            st = make_cols(ctx, c, flat, &all_cols, &all_w, scratch);
+            uint32_t at = 0;
+            for (int k = 0; k < g.n; k++) {
+                g.cols[k] = all_cols + at;
+                at += group_w[k];
+            }
         }
         if (st == LURKHIP_OK && g.n) st = merkle_row_sponges(ctx, params, g);
         if (st == LURKHIP_OK && early_level >= 0 && hipStreamWaitEvent(ctx->stream, ctx->hash_done, 0) != hipSuccess)
