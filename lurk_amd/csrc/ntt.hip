@@ -582,7 +582,10 @@ uint32_t host_pow(uint32_t a_m, uint64_t e) {
 }  // namespace
 
 uint32_t two_adic_generator_monty(int bits) {
-    // w_{2^bits} = root27^(2^(27-bits))
+    // w_{2^bits} = root27^(2^(27-bits)).  BabyBear has no subgroup of order 2^28 and more: the callers bound their heights
+    // (commit_impl, the verifier's decoders), and a request outside [0, 27] gets 0 -- not a root of anything -- instead of
+    // silently the 2^27 root
+    if (bits < 0 || bits > bb::TWO_ADICITY) return 0;
     uint32_t r = bb::to_monty(TWO_ADIC_ROOT_27);
     for (int i = bits; i < bb::TWO_ADICITY; i++) r = bb::mul(r, r);
     return r;
