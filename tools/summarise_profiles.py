@@ -39,7 +39,7 @@ with open(f"profiles/{prefix}_pmc_hbm_per_kernel.csv", "w") as f:
     f.write("# units: KB as reported; MI355X_MICROARCH.md: FETCH_SIZE under-reports wide coalesced reads by 2x on gfx950, WRITE_SIZE uncalibrated\n")
     f.write("kernel,launches,FETCH_SIZE_KB,WRITE_SIZE_KB\n")
     for k in sorted(res["FETCH_SIZE"][0], key=lambda k: -(res["FETCH_SIZE"][0][k] + res["WRITE_SIZE"][0][k])):
-        f.write(f"{k},{res['FETCH_SIZE'][1][k]},{res['FETCH_SIZE'][0][k]:.0f},{res['WRITE_SIZE'][0][k]:.0f}\n")
+        f.write(f"\"{k}\",{res['FETCH_SIZE'][1][k]},{res['FETCH_SIZE'][0][k]:.0f},{res['WRITE_SIZE'][0][k]:.0f}\n")  # (quoted: template arguments hold commas)
 HASH = ("k_row_sponges", "k_level_digests", "k_level_coop", "k_level", "k_leaves", "k_leaves_coop")  # the hashing launches (bench.py's merkle_leaves + merkle_levels spans; the PMC pass also counts the small FRI-layer trees)
 F = sum(res["FETCH_SIZE"][0][k] for k in HASH) * 1024
 W = sum(res["WRITE_SIZE"][0][k] for k in HASH) * 1024
@@ -60,7 +60,7 @@ with open(f"profiles/{prefix}_pmc_sq_per_kernel.csv", "w") as f:
     for n in sorted(dur, key=lambda k: -dur[k]):
         v = tot[n]
         rate = v["SQ_INSTS_VALU"] * 64 / (dur[n] * 1e-9) / 1e12 if dur[n] else 0
-        f.write(f"{n},{cnt[n]},{dur[n] / 1e6:.3f}," + ",".join(f"{v[c]:.4g}" for c in cols) + f",{rate:.2f}\n")
+        f.write(f"\"{n}\",{cnt[n]},{dur[n] / 1e6:.3f}," + ",".join(f"{v[c]:.4g}" for c in cols) + f",{rate:.2f}\n")
 hv = sum(tot[k]["SQ_INSTS_VALU"] for k in HASH) * 64 / (sum(dur[k] for k in HASH) * 1e-9) / 1e12
 NTT = [k for k in res["FETCH_SIZE"][0] if k.startswith("k_ntt_pass") or k.startswith("k_lde_")]  # every coset-LDE launch (lde.hip + ntt.hip)
 hash_lane_insts = sum(tot[k]["SQ_INSTS_VALU"] for k in HASH) * 64
