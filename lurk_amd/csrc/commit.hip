@@ -751,7 +751,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     // (early_sponge), under the LDE passes of every other group.  Opt-in (LURKHIP_EARLY_SPONGE=1): measured on a 2^12-row proof the
     // main commitment drops from 1.42 to 1.09 ms and the proof from 7.34 to 7.1-7.35 ms, but with two proofs in flight a step goes
     // from 5.0 to 5.8 ms (one more stream per context competing for the hardware queues), and the 2^20-row step does not move.
-    static const bool early_on = getenv("LURKHIP_EARLY_SPONGE") != nullptr && atoi(getenv("LURKHIP_EARLY_SPONGE")) != 0;
+    static const int early_mode = getenv("LURKHIP_EARLY_SPONGE") ? atoi(getenv("LURKHIP_EARLY_SPONGE")) : 0;
+    static const bool early_on = early_mode != 0;
     int chain_log_n = -1;
     if (early_on && lane.active && groups.size() >= 2) {
         std::map<int, uint32_t> width_of;  // per height, grouped matrices only
@@ -768,6 +769,17 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
             }
         uint32_t max_log_n = 0;
         for (int i = 0; i < n_mats; i++) max_log_n = std::max(max_log_n, log_heights[i]);
+        // (LURKHIP_EARLY_SPONGE=2, A/B: the group with the most WORDS instead -- the tallest one of a big shard: its sponge, bound by
+        // instruction issue, under the memory-bound first / last LDE passes of the other groups)
+        if (early_mode == 2) {
+            uint64_t most = 0;
+            chain_log_n = -1;
+            for (const auto& kv : width_of)
+                if (all_grouped[kv.first] && ((uint64_t)kv.second << kv.first) > most) {
+                    most = (uint64_t)kv.second << kv.first;
+                    chain_log_n = kv.first;
+                }
+        }
         if (chain_log_n >= 0 && !tree_prehashes_rows((size_t)1 << (max_log_n + log_blowup))) chain_log_n = -1;
         if (chain_log_n >= 0) std::stable_partition(groups.begin(), groups.end(), [&](const GroupPlan& g) { return g.log_n == chain_log_n; });
     }
