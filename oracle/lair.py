@@ -444,6 +444,9 @@ class Toplevel:
             st["ret"] += 1
         else:
             kind, v, branches, default = c
+            # the scrutinee is resolved HERE: the default block is compiled in the running scope (toplevel.rs:541-556) and may
+            # rebind the same name (the real `eval` does: `let (head_tag, head) = call(eval, head_tag, ..)` inside a default)
+            scrutinee = list(st["link"][v])
             cases, uniq = [], []
             for keys, blk in branches:
                 saved = (st["var"], dict(st["link"]))
@@ -455,7 +458,7 @@ class Toplevel:
                 else:
                     cases.append((tuple(keys), cb))
             d = self._compile_block(default, st) if default is not None else None
-            ctrl = (kind, st["link"][v], dict(cases), uniq, d)
+            ctrl = (kind, scrutinee, dict(cases), uniq, d)
         return {"ops": ops, "ctrl": ctrl}
 
     # --- layout (func_chip.rs)

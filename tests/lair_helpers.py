@@ -47,6 +47,34 @@ fn helper(x, y): [1] {
 }
 """
 
+# a `match` whose default block rebinds the scrutinee's name (the reference's `eval` does, eval_direct.rs:409-423): found by running
+# the real evaluator through the oracle in round 5 -- its compiler resolved the scrutinee after compiling the default
+SHADOW_SRC = """
+fn shadow(t, x): [2] {
+    match t {
+        3 => {
+            return (t, x)
+        }
+    };
+    let (t, x) = call(step, t, x);
+    match t {
+        5, 6 => {
+            let one = 1;
+            let x = add(x, one);
+            return (t, x)
+        }
+    };
+    return (x, t)
+}
+fn step(t, x): [2] {
+    let one = 1;
+    let t = add(t, one);
+    let x = mul(x, t);
+    return (t, x)
+}
+"""
+SHADOW_CALLS = [(("shadow", [3, 7]), [3, 7]), (("shadow", [4, 2]), [5, 11]), (("shadow", [1, 2]), [4, 2]), (("shadow", [5, 3]), [6, 19])]
+
 U64_SRC = """
 fn u64_ops(a: [8], b: [8]): [18] {
     let s: [8] = extern_call(u64_add, a, b);

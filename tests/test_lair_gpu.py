@@ -3,7 +3,7 @@ golden traces and the independent Python oracle."""
 import numpy as np
 import pytest
 
-from lair_helpers import PARTIAL_SRC, U64_SRC, load_cases
+from lair_helpers import PARTIAL_SRC, SHADOW_CALLS, SHADOW_SRC, U64_SRC, load_cases
 from lurk_amd import field, lair
 from oracle import lair as ol
 
@@ -176,6 +176,10 @@ def test_demo_functions_vs_oracle_with_sharding(ctx, oracle):
     demo = load_cases()[0]["source"]
     # shard size 4 is what the reference's own tests use (src/core/tests/mod.rs:59-63)
     _compare_all_funcs(ctx, oracle, demo, [["fib", [40]], ["factorial", [11]], ["even", [9]]], shard_sizes=(1 << 22, 4))
+
+
+def test_rebinding_default_vs_oracle(ctx, oracle):
+    _compare_all_funcs(ctx, oracle, SHADOW_SRC, [[n, a] for (n, a), _ in SHADOW_CALLS], shard_sizes=(1 << 22, 2))
 
 
 def test_partial_functions_vs_oracle(ctx, oracle):

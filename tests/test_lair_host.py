@@ -2,7 +2,7 @@
 No GPU: nothing here generates a trace."""
 import pytest
 
-from lair_helpers import PARTIAL_SRC, U64_SRC, load_cases
+from lair_helpers import PARTIAL_SRC, SHADOW_CALLS, SHADOW_SRC, U64_SRC, load_cases
 from lurk_amd import lair
 from oracle import lair as ol
 
@@ -26,6 +26,17 @@ def test_layout_and_execution_match_golden_and_oracle(case):
         got = top.func_info(idx)["layout"]
         assert dict(nonce=got.nonce, input=got.input, aux=got.aux, sel=got.sel, output=got.output) == case["layout"]
     assert q.expect_public_values() == oq.public_values
+
+
+def test_default_block_may_rebind_the_scrutinee():
+    """Hand-computed answers; both compilers (the oracle's had the bug)."""
+    top, otop = lair.Toplevel(SHADOW_SRC), ol.Toplevel(SHADOW_SRC)
+    q, oq = lair.QueryRecord(top), ol.QueryRecord(otop)
+    for (name, args), want in SHADOW_CALLS:
+        assert top.execute_by_name(name, args, q) == want
+        assert ol.execute(otop, name, args, oq) == want
+    for i in range(top.num_funcs()):
+        assert q.num_func_queries(i) == len(oq.func[i])
 
 
 def test_iterative_interpreter_known_answers():
