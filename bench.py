@@ -3,11 +3,16 @@
 
 Workload (BASELINE.json configs[2]): a `fib`-shaped Lair machine whose `eval` chip (width 78,
 /root/reference/src/core/eval_direct.rs:2028) has 2^20 rows per GPU.  The evaluator's program text cannot be shipped, so
-the machine is the width-matched `fib-mix` of lurk_amd/programs/lurk_mix.py: the 14 chips a fib run touches with the
-reference's names, widths (eval 78 partial, eval_builtin_expr 148, eval_binop_num 107, apply 114, env_lookup 52,
-u64_add/sub 53, u64_lessthan 44, ingress 104, egress 81, hash3/4/5 493/655/815, lurk_main 97), `partial` depth columns,
-extern chips and the row ratios of SURVEY.md appendix C.  `--workload eval-only` is round 1's thinner single-function
-machine, `--workload lurk-mix` all 39 functions (BASELINE config 5, irregular widths 9 ... 815).
+the machine is the shape-matched `fib-mix` of lurk_amd/programs/lurk_mix.py: the 17 function chips a real `(fib N)` touches
+(+ 3 memory tables, byte table, entrypoint), each with the reference's name, signature and the shape MEASURED on the
+reference's own function in the build container (tests/golden/fib_shape.json, tools/measure_lurk_shape.py: main-trace
+width, selectors, lookups = permutation-trace columns exactly; constraints and lookup-tuple words exactly for the four tall
+chips), at the measured heights per eval row (5 eval_builtin_expr, 4 eval_binop_num, 4 apply, 2 env_lookup, 1 eval_begin,
+1 each u64_add / u64_sub / u64_lessthan, 2 + 2 memory rows per 10 eval rows).  Rounds 1-4 ran SURVEY appendix C's hand
+estimate instead: 285 main columns per eval row against the measured 277, but 3.4 permutation-trace columns per main column
+fewer than the real machine has (its chips have 2-3 x the lookups the estimate's stand-ins had): this round's step is the
+heavier, real one, and its time is not comparable with BENCH_r01-r04.  `--workload eval-only` is round 1's thinner
+single-function machine, `--workload lurk-mix` all 39 functions (BASELINE config 5, irregular widths 9 ... 815).
 
 The host interpreter runs once before the timed region and the flattened inputs of every chip (row streams, memory
 tables, byte-lookup records) are resident in HBM.  At N = 1 the K timed steps are K independent proofs of the shard with two
@@ -194,6 +199,21 @@ def usable_cores() -> int:
     return n
 
 
+def measured_shape(workload: str):
+    """What tools/measure_lurk_shape.py measured on the reference's own functions for the largest `(fib N)` it ran (unpadded rows;
+    the fields above count the padded heights the prover works on)."""
+    if workload != "fib-mix":
+        return None
+    from lurk_amd.programs import lurk_mix as lm
+
+    shape = lm.load_shape()
+    n = max(shape["fib"], key=int)
+    r = shape["fib"][n]
+    return {"source": "tests/golden/fib_shape.json", "fib_n": int(n), "eval_rows": r["rows"]["eval"], "main_columns_per_eval_row": r["main_columns_per_eval_row"],
+            "func_permutation_columns_per_eval_row": r["func_permutation_columns_per_eval_row"], "widths_reproduced": shape["widths_reproduced"],
+            "per_fib_level": shape["fib_per_level"]}
+
+
 def build_workload(name: str, world: int, log_rows: int):
     """(source, lurk_chips, entry, main args, eval function name, description)."""
     n = 1 << log_rows
@@ -206,8 +226,9 @@ def build_workload(name: str, world: int, log_rows: int):
     from lurk_amd.programs import lurk_mix as lm
 
     mix = lm.fib_mix(world * n) if name == "fib-mix" else lm.lurk_mix(world * n)
-    desc = ("fib-mix: the 14 chips of a fib run with the reference's widths, partial eval, u64 extern chips, appendix-C row ratios"
-            if name == "fib-mix" else "lurk-mix: all 39 Lurk functions (widths 9 ... 815), 6 memory tables, byte table, entrypoint")
+    desc = ("fib-mix: the 17 function chips of a real (fib N) run at the shapes and heights measured on the reference's own functions "
+            "(tests/golden/fib_shape.json), partial eval, u64 extern chips"
+            if name == "fib-mix" else "lurk-mix: all 39 Lurk functions at their measured shapes (widths 9 ... 815), 6 memory tables, byte table, entrypoint")
     return mix.source, True, mix.entry, mix.main_args, "eval", desc
 
 
@@ -249,6 +270,9 @@ def main():
     ap.add_argument("--torch-collectives", action="store_true",
                     help="the two collectives of a multi-rank step through torch.distributed instead of the C ABI (lurkhip_exchange_roots / lurkhip_reduce_sums)")
     ap.add_argument("--profile", default="default", help="protocol profile preset (lurkhip_protocol_profile_preset): default, hardened, whole-state-squeeze, p3-monty-diffusion")
+    ap.add_argument("--shards-total", type=int, default=None,
+                    help="cut the execution into exactly this many shards (any number: 9 on 8 ranks is an ordinary case of the reference's "
+                         "ceil(rows / max_shard_size)); the ranks then hold different numbers of shards.  Default: ranks x --shards-per-rank")
     ap.add_argument("--shards-per-rank", type=int, default=None,
                     help="distributed runs: shards of 2^log_rows / k eval rows, k per rank, dealt by work (default 2 when WORLD_SIZE > 1, else 1)")
     args = ap.parse_args()
@@ -330,13 +354,21 @@ def main():
     # shards are dealt to the ranks by their work (shards.assign_shards_balanced: heaviest first, k per rank).
     spr = args.shards_per_rank if args.shards_per_rank is not None else (2 if world > 1 else 1)
     assert spr >= 1 and n % spr == 0
-    if world > 1 or spr > 1 or args.workload != "eval-only":
+    if args.shards_total:
+        # any number of shards (`Shard::shard`: ceil(rows / max_shard_size), /root/reference/src/lair/execute.rs:186-216), e.g. 9 on 8 ranks:
+        # the ranks then hold different numbers of shards and the root exchange gathers the counts first (lurkhip_exchange_roots_var)
+        shard_rows = -(-world * n // args.shards_total)
+        all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(shard_rows))
+        assert len(all_shards) == args.shards_total, f"{len(all_shards)} shards of {shard_rows} rows, {args.shards_total} asked for"
+    elif world > 1 or spr > 1 or args.workload != "eval-only":
         all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(n // spr))
+        assert len(all_shards) == world * spr, f"{len(all_shards)} shards for {world} ranks x {spr}: the eval chip must be the tallest"
     else:
         all_shards = [lair.Shard.new(queries)]
-    assert len(all_shards) == world * spr, f"{len(all_shards)} shards for {world} ranks x {spr}: the eval chip must be the tallest"
     assignment = shards.assign_shards_balanced([machine.shard_cost(sh) for sh in all_shards], world)
     mine = assignment[rank]
+    if not mine:
+        raise SystemExit(f"rank {rank} holds no shard ({len(all_shards)} shards over {world} ranks): nothing to time on it")
     t0 = time.perf_counter()
     prepared_all = [machine.prepare_shard(all_shards[i]) for i in mine]
     prepared = prepared_all[0]
@@ -351,6 +383,8 @@ def main():
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
     input_bytes = sum(p.input_bytes for pr in prepared_all for *_, p in pr if p is not None)
     main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
+    perm_cols_per_eval_row = sum(4 * air.permutation_width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
+    constraints_per_eval_row = sum(air.num_constraints << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     one_lane = args.rank_pipeline and args.rank_pipeline_one_lane
     lane_ctx = prover.lane_context(machine) if len(mine) > 1 and not one_lane else None  # the second proving lane of a rank with several shards
 
@@ -362,7 +396,8 @@ def main():
         from lurk_amd.comm import Comm
 
         comm = Comm.from_process_group(ctx)
-    rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx, comm=comm)
+    rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx, comm=comm,
+                                n_shards=len(all_shards))
     grand_sums, rank_sums, host_ms = rank_step.grand_sums, rank_step.rank_sums, rank_step.host_ms
 
     def step():
@@ -388,7 +423,8 @@ def main():
                 for pr in prepared_b:
                     machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
             lane_ctx_b = prover.lane_context(machine_b) if not one_lane else None
-            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm))
+            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm,
+                                                 n_shards=len(all_shards)))
             pipe["ctxs"] += [c for c in (ctx_b, lane_ctx_b) if c is not None]
             pipe["machines"].append(machine_b)
             pipe["prepared"].append(prepared_b)
@@ -846,6 +882,9 @@ def main():
                 "workload_detail": workload_desc,
                 "chips": chips_desc,
                 "main_columns_per_eval_row": main_cols_per_eval_row,
+                "permutation_columns_per_eval_row": perm_cols_per_eval_row,
+                "constraint_evaluations_per_eval_row": constraints_per_eval_row,
+                "measured_shape": measured_shape(args.workload),
                 "stages_ms": sequential["stages_ms"] if sequential else {k: v[0] / args.steps for k, v in spans.items() if v[1]},
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),

@@ -635,6 +635,10 @@ typedef struct lurkhip_comm lurkhip_comm;
 #define LURKHIP_COMM_ID_BYTES 128      /* ncclUniqueId */
 #define LURKHIP_ROOT_RECORD_WORDS 9    /* shard index, then the 8 words of the shard's main-trace root */
 int32_t lurkhip_comm_unique_id(uint8_t* id_out /* [LURKHIP_COMM_ID_BYTES] */);
+/* Which librccl the library bound (loading it if need be): LURKHIP_RCCL_LIB when set (and nothing else), else a librccl the
+ * process has already mapped (PyTorch's bundled copy: one RCCL per process), else the system's by name.  NULL when none could be
+ * loaded; lurkhip_last_error(NULL) then says why. */
+const char* lurkhip_comm_library(void);
 /* Collective over all `world` ranks (ncclCommInitRank); the context's device is the rank's GPU. */
 int32_t lurkhip_comm_create(lurkhip_ctx* ctx, const uint8_t* id, int32_t rank, int32_t world, lurkhip_comm** out);
 int32_t lurkhip_comm_destroy(lurkhip_ctx* ctx, lurkhip_comm* comm);
@@ -643,9 +647,18 @@ int32_t lurkhip_comm_info(const lurkhip_comm* comm, int32_t* rank, int32_t* worl
  * Device pointers; returns when the all-gather is enqueued. */
 int32_t lurkhip_exchange_roots_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* records_dev, int32_t n_local, uint32_t* gathered_dev);
 /* Host convenience: this rank's (shard_indices[i], roots[i][8]) in, roots_out[shard][8] of ALL world * n_local shards out, in shard
- * order (what every shard's transcript observes); fails unless the ranks' indices are a partition of 0 .. world * n_local - 1. */
+ * order (what every shard's transcript observes); fails unless the ranks' indices are a partition of 0 .. world * n_local - 1.
+ * Every rank passes the same n_local (checked: the ranks all-gather their counts first, so a disagreement is an error on every
+ * rank, not a hang). */
 int32_t lurkhip_exchange_roots(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
                                uint32_t* roots_out);
+/* The same for ANY number of shards per rank (`Shard::shard` cuts an execution into ceil(rows / max_shard_size) shards,
+ * /root/reference/src/lair/execute.rs:186-216 -- nine shards on eight GPUs is an ordinary case): n_local >= 0 may differ from rank
+ * to rank and be 0; n_total = the number of shards of the execution, the same on every rank; roots_out[n_total][8].  Two all-gathers:
+ * the counts (one word per rank; a rank whose arguments are unusable sends -1 and EVERY rank returns LURKHIP_ERR_INVALID_ARG),
+ * then records padded to the largest count.  Fails on every rank alike unless the indices are a partition of 0 .. n_total - 1. */
+int32_t lurkhip_exchange_roots_var(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
+                                   int32_t n_total, uint32_t* roots_out);
 /* lanes_dev[4] (int64: sums of canonical coefficients, one lane per extension-field coefficient) all-reduced in place, then
  * total_dev[4] <- lanes mod p.  RCCL has no modular reduction: addends below 2^31 cannot overflow 64 bits over any node. */
 int32_t lurkhip_reduce_sums_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, int64_t* lanes_dev, uint32_t* total_dev);

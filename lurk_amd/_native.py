@@ -205,6 +205,8 @@ SIGNATURES = {
     "lurkhip_comm_info": (_i32, [_p, C.POINTER(_i32), C.POINTER(_i32)]),
     "lurkhip_exchange_roots_dev": (_i32, [_p, _p, _u32p, _i32, _u32p]),
     "lurkhip_exchange_roots": (_i32, [_p, _p, _u32p, _u32p, _i32, _u32p]),
+    "lurkhip_exchange_roots_var": (_i32, [_p, _p, _u32p, _u32p, _i32, _i32, _u32p]),
+    "lurkhip_comm_library": (C.c_char_p, []),
     "lurkhip_reduce_sums_dev": (_i32, [_p, _p, _p, _u32p]),
     "lurkhip_reduce_sums": (_i32, [_p, _p, _u32p, _i32, _u32p]),
 }

@@ -24,6 +24,15 @@ def unique_id() -> bytes:
     return bytes(buf)
 
 
+def library() -> str:
+    """The librccl the C ABI bound (LURKHIP_RCCL_LIB, else the copy the process has already mapped -- PyTorch's --, else the
+    system's); raises with the loader's message when there is none."""
+    p = N.lib.lurkhip_comm_library()
+    if p is None:
+        raise RuntimeError(N.last_error(None))
+    return p.decode()
+
+
 class Comm:
     def __init__(self, ctx: Context, uid: bytes, rank: int, world: int):
         if len(uid) != ID_BYTES:
@@ -55,14 +64,22 @@ class Comm:
         except Exception:
             pass
 
-    def exchange_roots(self, shard_indices, roots):
-        """This rank's (index, root[8]) pairs -> the roots of ALL shards in shard order (lists of 8 ints)."""
+    def exchange_roots(self, shard_indices, roots, n_shards=None):
+        """This rank's (index, root[8]) pairs -> the roots of ALL shards in shard order (lists of 8 ints).  With `n_shards` (the
+        number of shards of the execution, known to every rank) the ranks may hold different numbers of shards, or none
+        (lurkhip_exchange_roots_var); without it every rank passes the same number."""
         idx = as_u32(np.asarray(shard_indices).reshape(-1))
         r = as_u32(np.asarray(roots).reshape(-1, 8))
         if len(idx) != len(r):
             raise ValueError("one index per root")
-        out = np.zeros((len(idx) * self.world, 8), dtype=np.uint32)
-        self.ctx.check(N.lib.lurkhip_exchange_roots(self.ctx.handle, self.handle, idx.ctypes.data, r.ctypes.data, len(idx), out.ctypes.data))
+        if n_shards is None:
+            out = np.zeros((len(idx) * self.world, 8), dtype=np.uint32)
+            self.ctx.check(N.lib.lurkhip_exchange_roots(self.ctx.handle, self.handle, idx.ctypes.data, r.ctypes.data, len(idx), out.ctypes.data))
+        else:
+            out = np.zeros((max(int(n_shards), 1), 8), dtype=np.uint32)
+            self.ctx.check(N.lib.lurkhip_exchange_roots_var(self.ctx.handle, self.handle, idx.ctypes.data if len(idx) else None,
+                                                            r.ctypes.data if len(idx) else None, len(idx), int(n_shards), out.ctypes.data))
+            out = out[: int(n_shards)]
         return [[int(x) for x in row] for row in out]
 
     def reduce_sums(self, local_sums):

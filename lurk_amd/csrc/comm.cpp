@@ -38,20 +38,45 @@ struct Rccl {
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
+    std::string path;  // what was loaded (lurkhip_comm_library)
 };
 
 const Rccl& rccl() {
     static Rccl r;
     static std::once_flag once;
     std::call_once(once, []() {
-        const char* names[] = {getenv("LURKHIP_RCCL_LIB"), "librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
-        for (const char* n : names) {
-            if (!n || !*n) continue;
-            r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
-            if (r.lib) break;
+        // 1. LURKHIP_RCCL_LIB, when set, is THE library (nothing else is tried: a host that names its RCCL means it).
+        // 2. A librccl the process has already mapped -- PyTorch maps its own bundled torch/lib/librccl.so and owns communicators on
+        //    the same devices -- is re-used (RTLD_NOLOAD on the mapped path): two RCCL copies in one process would each keep their
+        //    own device state.  3. Otherwise the system library by name.
+        const char* forced = getenv("LURKHIP_RCCL_LIB");
+        if (forced && *forced) {
+            r.lib = dlopen(forced, RTLD_NOW | RTLD_GLOBAL);
+            r.path = forced;
+        } else {
+            if (FILE* maps = fopen("/proc/self/maps", "r")) {
+                char ln[4352];
+                while (!r.lib && fgets(ln, sizeof ln, maps)) {
+                    const char* path = strchr(ln, '/');
+                    if (!path || !strstr(path, "/librccl.so")) continue;
+                    std::string p(path);
+                    while (!p.empty() && (p.back() == '\n' || p.back() == ' ')) p.pop_back();
+                    r.lib = dlopen(p.c_str(), RTLD_NOW | RTLD_GLOBAL | RTLD_NOLOAD);
+                    if (r.lib) r.path = p + " (already mapped by the process)";
+                }
+                fclose(maps);
+            }
+            const char* names[] = {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"};
+            for (const char* n : names) {
+                if (r.lib) break;
+                r.lib = dlopen(n, RTLD_NOW | RTLD_GLOBAL);
+                if (r.lib) r.path = n;
+            }
         }
         if (!r.lib) {
-            r.why = std::string("librccl could not be loaded: ") + (dlerror() ? dlerror() : "not found");
+            const char* e = dlerror();  // one call: dlerror() clears the message it returns
+            r.why = std::string("librccl could not be loaded") + (forced && *forced ? std::string(" from LURKHIP_RCCL_LIB=") + forced : std::string()) + ": " +
+                    (e ? e : "not found");
             return;
         }
         auto sym = [&](const char* name) {
@@ -91,10 +116,15 @@ using namespace lurkhip;
 
 extern "C" {
 
-int32_t lurkhip_comm_unique_id(uint8_t* id_out) {
-    if (!id_out) return LURKHIP_ERR_INVALID_ARG;
+const char* lurkhip_comm_library(void) {
     const Rccl& r = rccl();
-    if (!r.why.empty()) return LURKHIP_ERR_HIP;
+    return r.why.empty() ? r.path.c_str() : nullptr;
+}
+
+int32_t lurkhip_comm_unique_id(uint8_t* id_out) {
+    if (!id_out) return set_error(nullptr, LURKHIP_ERR_INVALID_ARG, "null id_out");
+    const Rccl& r = rccl();
+    if (!r.why.empty()) return set_error(nullptr, LURKHIP_ERR_HIP, "%s", r.why.c_str());
     ncclUniqueId id;
     if (r.GetUniqueId(&id) != ncclSuccess) return LURKHIP_ERR_HIP;
     static_assert(sizeof id == LURKHIP_COMM_ID_BYTES, "ncclUniqueId size");
@@ -144,45 +174,86 @@ int32_t lurkhip_exchange_roots_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, const u
     return LURKHIP_OK;
 }
 
-int32_t lurkhip_exchange_roots(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
-                               uint32_t* roots_out) {
-    LH_CHECK_CTX(ctx);
-    LH_ARG(ctx, comm && shard_indices && roots && roots_out && n_local >= 1 && n_local <= 4096, "bad exchange arguments");
-    const size_t rec_words = (size_t)n_local * LURKHIP_ROOT_RECORD_WORDS, all_words = rec_words * (size_t)comm->world;
-    std::vector<uint32_t> rec(rec_words);
+// The exchange for any number of shards per rank.  Two collectives, both of a size every rank knows without asking: the counts
+// (one word per rank), then records padded to the largest count.  A rank that cannot take part properly (bad arguments, an
+// allocation that failed) still enters both collectives -- with count -1 -- so that its peers return an error instead of waiting
+// for it forever (an early return before a collective leaves the other ranks blocked inside it).
+static int32_t exchange_var(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local, int64_t n_total,
+                            bool equal_counts, uint32_t* roots_out) {
+    const int world = comm->world;
+    const bool args_ok = n_local >= 0 && n_local <= 4096 && roots_out && (n_local == 0 || (shard_indices && roots));
+    void* cnt = nullptr;  // world + 1 words: [0] mine, [1 ..] everybody's
+    LH_TRY(pool_alloc(ctx, ((size_t)world + 1) * 4, &cnt));
+    void *send = nullptr, *recv = nullptr;
+    auto done = [&](int32_t s) {
+        pool_release(ctx, cnt);
+        if (send) pool_release(ctx, send);
+        if (recv) pool_release(ctx, recv);
+        return s;
+    };
+    const uint32_t mine = args_ok ? (uint32_t)n_local : 0xFFFFFFFFu;
+    std::vector<uint32_t> counts((size_t)world);
+    if (upload_words(ctx, (uint32_t*)cnt, &mine, 1) != LURKHIP_OK) return done(set_error(ctx, LURKHIP_ERR_HIP, "upload of the shard count failed"));
+    ncclResult_t nr = rccl().AllGather(cnt, (uint32_t*)cnt + 1, 1, ncclUint32, comm->comm, ctx->stream);
+    if (nr != ncclSuccess) return done(set_error(ctx, LURKHIP_ERR_HIP, "ncclAllGather of the shard counts failed: %s", rccl().GetErrorString(nr)));
+    if (hipMemcpyAsync(counts.data(), (uint32_t*)cnt + 1, (size_t)world * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx) != hipSuccess)
+        return done(set_error(ctx, LURKHIP_ERR_HIP, "read-back of the gathered shard counts failed"));
+    uint32_t most = 0;
+    int64_t sum = 0;
+    for (int r = 0; r < world; r++) {
+        if (counts[(size_t)r] == 0xFFFFFFFFu) return done(set_error(ctx, LURKHIP_ERR_INVALID_ARG, "rank %d entered the root exchange with unusable arguments", r));
+        if (equal_counts && counts[(size_t)r] != counts[0])
+            return done(set_error(ctx, LURKHIP_ERR_INVALID_ARG, "rank %d passes %u shards, rank 0 passes %u: lurkhip_exchange_roots needs equal counts (use lurkhip_exchange_roots_var)",
+                                  r, counts[(size_t)r], counts[0]));
+        most = std::max(most, counts[(size_t)r]);
+        sum += counts[(size_t)r];
+    }
+    if (n_total < 0) n_total = sum;
+    if (sum != n_total) return done(set_error(ctx, LURKHIP_ERR_INVALID_ARG, "the ranks hold %lld shards in all, the execution has %lld", (long long)sum, (long long)n_total));
+    if (n_total == 0) return done(LURKHIP_OK);
+    const size_t rec_words = (size_t)most * LURKHIP_ROOT_RECORD_WORDS, all_words = rec_words * (size_t)world;
+    std::vector<uint32_t> rec(rec_words, 0xFFFFFFFFu);  // index 0xFFFFFFFF = padding
     for (int i = 0; i < n_local; i++) {
         rec[(size_t)i * LURKHIP_ROOT_RECORD_WORDS] = shard_indices[i];
         memcpy(&rec[(size_t)i * LURKHIP_ROOT_RECORD_WORDS + 1], roots + (size_t)i * 8, 32);
     }
-    void *send = nullptr, *recv = nullptr;
-    LH_TRY(pool_alloc(ctx, rec_words * 4, &send));
-    int32_t st = pool_alloc(ctx, all_words * 4, &recv);
-    if (st != LURKHIP_OK) {
-        pool_release(ctx, send);
-        return st;
-    }
+    // (an allocation failure here cannot be reported to the peers any more: they are about to enter the second all-gather.  The two
+    // buffers are tens of bytes per shard from the context's pool.)
+    int32_t st = pool_alloc(ctx, rec_words * 4, &send);
+    if (st == LURKHIP_OK) st = pool_alloc(ctx, all_words * 4, &recv);
+    if (st != LURKHIP_OK) return done(st);
     std::vector<uint32_t> all(all_words);
-    auto done = [&](int32_t s) {
-        pool_release(ctx, send);
-        pool_release(ctx, recv);
-        return s;
-    };
     if (hipMemcpyAsync(send, rec.data(), rec_words * 4, hipMemcpyHostToDevice, ctx->stream) != hipSuccess)
         return done(set_error(ctx, LURKHIP_ERR_HIP, "upload of the root records failed"));
-    st = lurkhip_exchange_roots_dev(ctx, comm, (const uint32_t*)send, n_local, (uint32_t*)recv);
-    if (st != LURKHIP_OK) return done(st);
+    nr = rccl().AllGather(send, recv, rec_words, ncclUint32, comm->comm, ctx->stream);
+    if (nr != ncclSuccess) return done(set_error(ctx, LURKHIP_ERR_HIP, "ncclAllGather of the root records failed: %s", rccl().GetErrorString(nr)));
     if (hipMemcpyAsync(all.data(), recv, all_words * 4, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx) != hipSuccess)
         return done(set_error(ctx, LURKHIP_ERR_HIP, "read-back of the gathered roots failed"));
-    // shard order; the indices of all ranks must be a partition of 0 .. n-1
-    const size_t n = (size_t)n_local * (size_t)comm->world;
-    std::vector<char> seen(n, 0);
-    for (size_t k = 0; k < n; k++) {
-        const uint32_t idx = all[k * LURKHIP_ROOT_RECORD_WORDS];
-        if (idx >= n || seen[idx]) return done(set_error(ctx, LURKHIP_ERR_INVALID_ARG, "shard indices of the ranks are not a partition of 0 .. %zu", n - 1));
-        seen[idx] = 1;
-        memcpy(roots_out + (size_t)idx * 8, &all[k * LURKHIP_ROOT_RECORD_WORDS + 1], 32);
-    }
+    // shard order; the indices of all ranks must be a partition of 0 .. n_total - 1
+    std::vector<char> seen((size_t)n_total, 0);
+    for (int r = 0; r < world; r++)
+        for (uint32_t k = 0; k < counts[(size_t)r]; k++) {
+            const uint32_t* w = &all[((size_t)r * most + k) * LURKHIP_ROOT_RECORD_WORDS];
+            if (w[0] >= (uint64_t)n_total || seen[w[0]])
+                return done(set_error(ctx, LURKHIP_ERR_INVALID_ARG, "shard indices of the ranks are not a partition of 0 .. %lld", (long long)n_total - 1));
+            seen[w[0]] = 1;
+            memcpy(roots_out + (size_t)w[0] * 8, w + 1, 32);
+        }
     return done(LURKHIP_OK);
+}
+
+int32_t lurkhip_exchange_roots(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
+                               uint32_t* roots_out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, comm != nullptr, "null communicator");
+    return exchange_var(ctx, comm, shard_indices, roots, n_local >= 1 ? n_local : -1, -1, true, roots_out);
+}
+
+int32_t lurkhip_exchange_roots_var(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
+                                   int32_t n_total, uint32_t* roots_out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, comm != nullptr && n_total >= 0, "null communicator or negative shard count");
+    return exchange_var(ctx, comm, shard_indices, roots, n_local, n_total, false, roots_out);
 }
 
 int32_t lurkhip_reduce_sums_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, int64_t* lanes_dev, uint32_t* total_dev) {

@@ -16,9 +16,14 @@ struct lurkhip_ctx {
     int device = 0;
     int num_cus = 256;  // compute units of the device (persistent-kernel grids)
     hipStream_t stream = nullptr;
+    // the context's own stream, set once at creation and never swapped: `stream` is rerouted to a side / hash stream for the
+    // duration of a scope by calls that hold api_mu (SideLane::Guard, early_sponge), so the entry points that run WITHOUT api_mu
+    // (LH_CHECK_CTX_NOLOCK: the *_free family) must not read it
+    hipStream_t main_stream = nullptr;
     bool owns_stream = false;
     int stream_priority = 0;  // of the context's own streams (lurkhip_ctx_create_with_priority)
-    std::string err;
+    std::string err;      // written under err_mu (set_error), read by lurkhip_last_error into the calling thread's copy
+    std::mutex err_mu;
     hipEvent_t ev_start = nullptr, ev_stop = nullptr;
     // grow-only scratch arenas for the host-pointer entry points
     void* arena[4] = {nullptr, nullptr, nullptr, nullptr};

@@ -18,7 +18,10 @@ int32_t set_error(lurkhip_ctx* ctx, int32_t code, const char* fmt, ...) {
     va_start(ap, fmt);
     vsnprintf(buf, sizeof buf, fmt, ap);
     va_end(ap);
-    if (ctx) ctx->err = buf;
+    if (ctx) {
+        std::lock_guard<std::mutex> lock(ctx->err_mu);  // an unlocked *_free may fail beside a locked call that fails
+        ctx->err = buf;
+    }
     g_tls_err = buf;
     return code;
 }
@@ -389,6 +392,7 @@ static int32_t create_common(int32_t device_id, void* stream, bool borrow, lurkh
         int cus = 0;
         if (hipDeviceGetAttribute(&cus, hipDeviceAttributeMultiprocessorCount, device_id) == hipSuccess && cus > 0) ctx->num_cus = cus;
     }
+    ctx->main_stream = ctx->stream;
     if ((e = hipEventCreate(&ctx->ev_start)) != hipSuccess) return fail(e, "hipEventCreate");
     if ((e = hipEventCreate(&ctx->ev_stop)) != hipSuccess) return fail(e, "hipEventCreate");
     *out = ctx;
@@ -523,7 +527,13 @@ int32_t lurkhip_event_destroy(void* event) {
     return LURKHIP_OK;
 }
 
-const char* lurkhip_last_error(lurkhip_ctx* ctx) { return ctx ? ctx->err.c_str() : g_tls_err.c_str(); }
+const char* lurkhip_last_error(lurkhip_ctx* ctx) {
+    if (!ctx) return g_tls_err.c_str();
+    static thread_local std::string copy;  // the caller's own copy: another thread's failing call may rewrite ctx->err at any time
+    std::lock_guard<std::mutex> lock(ctx->err_mu);
+    copy = ctx->err;
+    return copy.c_str();
+}
 
 int32_t lurkhip_malloc(lurkhip_ctx* ctx, size_t bytes, void** dev_ptr) {
     LH_CHECK_CTX_NOLOCK(ctx);
@@ -536,7 +546,7 @@ int32_t lurkhip_malloc(lurkhip_ctx* ctx, size_t bytes, void** dev_ptr) {
 int32_t lurkhip_free(lurkhip_ctx* ctx, void* dev_ptr) {
     LH_CHECK_CTX_NOLOCK(ctx);
     if (!dev_ptr) return LURKHIP_OK;
-    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->main_stream));  // not ctx->stream: a locked call on another thread may have rerouted it
     LH_HIP(ctx, hipFree(dev_ptr));
     return LURKHIP_OK;
 }

@@ -773,7 +773,9 @@ int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p) {
     if (!p) return LURKHIP_OK;
     lurkhip::pool_release(ctx, p->dev);
     if (p->host_keep) {
-        (void)hipStreamSynchronize(ctx->stream);  // the upload that reads it was queued on this context's stream
+        // the upload that reads it was queued on this context's own stream; ctx->stream may be a side stream right now (a locked
+        // call on another thread reroutes it for a scope), main_stream never is
+        (void)hipStreamSynchronize(ctx->main_stream);
         (void)hipHostFree(p->host_keep);
     }
     delete p;

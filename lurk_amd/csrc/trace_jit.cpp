@@ -252,11 +252,18 @@ struct Gen {
             def(1, i, "bb::to_monty(a" + std::to_string(i) + ")");
         }
         block(prog.at(TH_ENTRY), n_in, 0, 0, d, 1);
-        o << "}\n}  // namespace lurkhip_trace\n"
+        // The row function reaches the kernel body through a functor whose call operator is always_inline, not a lambda: a lambda's
+        // operator() is inlined only when the inliner's cost model says so, and for a function with dozens of match arms (the
+        // shape-matched eval_builtin_expr: 59 arms, 230 KB of code) it does not -- the row writer then travels as a reference to
+        // private memory and the LDS tile as a generic pointer through a real call, and the kernel faults (round 5:
+        // HSA_STATUS_ERROR_MEMORY_APERTURE_VIOLATION on the first launch; every smaller function was inlined and ran).
+        o << "}\nstruct JitRow {\n"
+          << "    __device__ __forceinline__ void operator()(const TraceArgs& a, uint32_t row_i, RowWriter& w) const { jit_row(a, row_i, w); }\n"
+          << "};\n}  // namespace lurkhip_trace\n"
           << "extern \"C\" __global__ __launch_bounds__(64) void jit_trace_staged(lurkhip_trace::TraceArgs a) {\n"
-          << "    lurkhip_trace::trace_kernel_body<true>(a, [](const lurkhip_trace::TraceArgs& aa, uint32_t row_i, lurkhip_trace::RowWriter& w) { lurkhip_trace::jit_row(aa, row_i, w); });\n}\n"
+          << "    lurkhip_trace::trace_kernel_body<true>(a, lurkhip_trace::JitRow{});\n}\n"
           << "extern \"C\" __global__ __launch_bounds__(64) void jit_trace_flat(lurkhip_trace::TraceArgs a) {\n"
-          << "    lurkhip_trace::trace_kernel_body<false>(a, [](const lurkhip_trace::TraceArgs& aa, uint32_t row_i, lurkhip_trace::RowWriter& w) { lurkhip_trace::jit_row(aa, row_i, w); });\n}\n";
+          << "    lurkhip_trace::trace_kernel_body<false>(a, lurkhip_trace::JitRow{});\n}\n";
         return o.str();
     }
 };

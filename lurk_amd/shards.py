@@ -21,19 +21,18 @@ def assign_shards(n_shards: int, world: int, rank: int) -> list[int]:
 
 
 def assign_shards_balanced(costs, world: int) -> list[list[int]]:
-    """Shards to ranks by estimated work (longest processing time first; every rank gets the same number of shards, the
-    all-gather's shape): `Shard::shard` cuts every chip at the same row count, so the first shards of an execution hold all
-    its chips and the last ones only the tallest -- round robin would leave rank 0 with twice the average.  Returns
-    [shard indices of rank 0, of rank 1, ...], each ascending; identical on every rank (ties broken by index).
-    len(costs) must be a multiple of world."""
+    """Shards to ranks by estimated work (longest processing time first; rank sizes differ by at most one shard):
+    `Shard::shard` cuts every chip at the same row count (/root/reference/src/lair/execute.rs:186-216: ceil(rows / max_shard_size)
+    shards -- any number, not a multiple of the rank count), so the first shards of an execution hold all its chips and the last
+    ones only the tallest -- round robin would leave rank 0 with twice the average.  Returns [shard indices of rank 0, of rank
+    1, ...], each ascending (a rank's list is empty when there are fewer shards than ranks); identical on every rank (ties
+    broken by index)."""
     n = len(costs)
-    if n % world:
-        raise ValueError(f"{n} shards do not divide over {world} ranks")
-    per_rank = n // world
+    most = -(-n // world)  # no rank holds more than ceil(n / world) shards: the device memory of a rank bounds what it can keep resident
     load = [0.0] * world
     out = [[] for _ in range(world)]
     for s in sorted(range(n), key=lambda i: (-float(costs[i]), i)):
-        r = min((r for r in range(world) if len(out[r]) < per_rank), key=lambda r: (load[r], r))
+        r = min((r for r in range(world) if len(out[r]) < most), key=lambda r: (load[r], r))
         out[r].append(s)
         load[r] += float(costs[s])
     return [sorted(x) for x in out]
@@ -45,32 +44,41 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None):
-    """local_roots: [k][8] roots of this rank's shards (every rank passes the same k; pad with zeros otherwise).
-    `comm` (lurk_amd.comm.Comm, with shard_indices): the all-gather runs behind the C ABI on RCCL (lurkhip_exchange_roots) instead
-    of torch.distributed -- the route a Rust host takes; the gloo CPU tests and single-process runs keep the torch path.
-    Returns the roots of all shards ordered by shard index: the round-robin layout of `assign_shards` undone, or -- with
-    `shard_indices` (this rank's shard numbers, same order as local_roots; any assignment, e.g. assign_shards_balanced) -- by the
-    indices that travel with the roots."""
+def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None, n_shards=None):
+    """local_roots: [k][8] roots of this rank's shards.  With `shard_indices` (this rank's shard numbers, same order as
+    local_roots; any assignment, e.g. assign_shards_balanced) k may differ from rank to rank and may be 0: the ranks first
+    all-gather their counts, then records padded to the largest count (a 9-word (index, root) record per shard, index -1 = padding).
+    Without indices every rank passes the same k (the round-robin layout of `assign_shards`, undone on return).
+    `comm` (lurk_amd.comm.Comm, with shard_indices): the all-gathers run behind the C ABI on RCCL (lurkhip_exchange_roots_var)
+    instead of torch.distributed -- the route a Rust host takes; the gloo CPU tests and single-process runs keep the torch path.
+    Returns the roots of all shards ordered by shard index.  `n_shards` (optional): the number of shards every rank expects."""
     if comm is not None:
         if shard_indices is None:
             raise ValueError("the C-ABI exchange carries the shard indices with the roots")
-        return comm.exchange_roots(shard_indices, local_roots)
+        return comm.exchange_roots(shard_indices, local_roots, n_shards=n_shards)
     import torch
 
     local = torch.tensor(np.asarray(local_roots, dtype=np.int64).reshape(-1, 8), device=device)
     dist = _dist()
     if shard_indices is not None:
         idx = torch.tensor(np.asarray(shard_indices, dtype=np.int64).reshape(-1, 1), device=device)
+        if idx.shape[0] != local.shape[0]:
+            raise ValueError("one shard index per root")
         rec = torch.cat([idx, local], dim=1).contiguous()  # [k][9]
         if dist is None:
             rows = rec.cpu().tolist()
         else:
-            out = torch.zeros((dist.get_world_size(),) + tuple(rec.shape), dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(out.view(-1), rec.view(-1))
-            rows = [r for per_rank in out.cpu().tolist() for r in per_rank]
+            world = dist.get_world_size()
+            counts = torch.zeros(world, dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(counts, torch.tensor([rec.shape[0]], dtype=torch.int64, device=device))
+            most = int(counts.max())
+            padded = torch.full((max(most, 1), 9), -1, dtype=torch.int64, device=device)
+            padded[: rec.shape[0]] = rec
+            out = torch.zeros((world,) + tuple(padded.shape), dtype=torch.int64, device=device)
+            dist.all_gather_into_tensor(out.view(-1), padded.view(-1))
+            rows = [r for per_rank in out.cpu().tolist() for r in per_rank if r[0] >= 0]
         rows.sort(key=lambda r: r[0])
-        if [r[0] for r in rows] != list(range(len(rows))):
+        if [r[0] for r in rows] != list(range(len(rows))) or (n_shards is not None and len(rows) != n_shards):
             raise ValueError("shard indices of the ranks are not a partition of 0 .. n-1")
         return [[int(x) for x in r[1:]] for r in rows]
     if dist is None:
@@ -122,7 +130,9 @@ class RankStep:
     `device` is where the two tiny collectives' tensors live: "cuda" over RCCL, "cpu" over gloo or without a process group;
     with `comm` both collectives run inside the library (lurkhip_exchange_roots / lurkhip_reduce_sums on the context's stream)."""
 
-    def __init__(self, machine, vk_root, public_values, prepared_all, shard_indices, num_queries, pow_bits, device="cpu", lane_ctx=None, comm=None):
+    def __init__(self, machine, vk_root, public_values, prepared_all, shard_indices, num_queries, pow_bits, device="cpu", lane_ctx=None, comm=None,
+                 n_shards=None):
+        self.n_shards = n_shards  # shards of the whole execution: with it the ranks may hold different numbers of shards (or none)
         self.machine, self.vk_root, self.pv = machine, vk_root, list(public_values)
         self.prepared_all, self.mine = prepared_all, list(shard_indices)
         self.num_queries, self.pow_bits, self.device, self.lane_ctx = num_queries, pow_bits, device, lane_ctx
@@ -160,7 +170,7 @@ class RankStep:
         import time
 
         t = time.perf_counter()
-        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine, comm=self.comm)
+        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine, comm=self.comm, n_shards=self.n_shards)
         self.host_ms["exchange_roots"] = self.host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t) * 1e3
         return self.roots
 

@@ -85,6 +85,102 @@ def test_two_process_root_exchange_and_grand_sum():
     assert ch0 == ch1
 
 
+def _worker_ragged(rank, world, port, q, n_shards):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lurk_amd import shards
+
+    def root_of(s):
+        return [(1000 * s + k) % P for k in range(8)]
+
+    # `Shard::shard` cuts an execution into ceil(rows / max_shard_size) shards (execute.rs:186-216): any number.  The first shards hold
+    # every chip, the last ones only the tallest: costs fall with the index
+    costs = [10 - s for s in range(n_shards)]
+    assignment = shards.assign_shards_balanced(costs, world)
+    mine = assignment[rank]
+    roots = shards.exchange_roots([root_of(s) for s in mine], shard_indices=mine, n_shards=n_shards)
+    # a rank that passes a wrong total is told so (every rank alike: nobody is left waiting in a collective)
+    try:
+        shards.exchange_roots([root_of(s) for s in mine], shard_indices=mine, n_shards=n_shards + 1)
+        wrong_total = "accepted"
+    except ValueError:
+        wrong_total = "refused"
+    sums = {s: (s + 1, 2 * s + 3, P - 5 * s - 1, 7) for s in range(n_shards - 1)}
+    total = np.zeros(4, dtype=np.int64)
+    for v in sums.values():
+        total = (total + np.array(v)) % P
+    sums[n_shards - 1] = tuple(int((P - x) % P) for x in total)
+    grand = shards.reduce_cumulative_sums([sums[s] for s in mine])  # a rank without shards adds nothing
+    words = [np.full(3 + s, s, dtype=np.uint32) for s in mine]
+    got = shards.gather_proofs(words, mine, dst=0)
+    gathered_ok = (rank != 0 and got is None) or (rank == 0 and [int(w[0]) for w in got] == list(range(n_shards)))
+    q.put((rank, assignment, roots, grand, wrong_total, gathered_ok))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.parametrize("world,n_shards", [(2, 5), (3, 7), (3, 2)], ids=["5-shards-2-ranks", "7-shards-3-ranks", "2-shards-3-ranks"])
+def test_ragged_shard_counts_over_gloo(world, n_shards):
+    """A shard count that is not a multiple of the rank count (missing 3): counts are gathered first, records padded
+    to the largest; a rank may hold no shard at all."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_ragged, args=(r, world, port, q, n_shards)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    assignment = results[0][1]
+    assert sorted(s for a in assignment for s in a) == list(range(n_shards))
+    assert max(len(a) for a in assignment) - min(len(a) for a in assignment) <= 1
+    for rank, a, roots, grand, wrong_total, gathered_ok in results:
+        assert a == assignment
+        assert roots == [[(1000 * s + k) % P for k in range(8)] for s in range(n_shards)]
+        assert grand == (0, 0, 0, 0) and wrong_total == "refused" and gathered_ok
+
+
+def test_rccl_loader_reports_instead_of_crashing():
+    """with no loadable librccl the communicator entry points must return an error with the loader's message (the
+    message used to be built from a second dlerror() call, i.e. from a null pointer).  LURKHIP_RCCL_LIB names THE library to use."""
+    import subprocess
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "from lurk_amd import comm, _native as N\n"
+            "import ctypes as C\n"
+            "buf = (C.c_uint8 * 128)()\n"
+            "st = N.lib.lurkhip_comm_unique_id(C.addressof(buf))\n"
+            "print('status', st); print('error', N.last_error(None)); print('library', N.lib.lurkhip_comm_library())\n") % ROOT
+    env = dict(os.environ, LURKHIP_RCCL_LIB="/nonexistent/librccl-not-here.so")
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=120, env=env)
+    assert r.returncode == 0, r.stderr
+    assert "status -" in r.stdout and "could not be loaded from LURKHIP_RCCL_LIB=/nonexistent/librccl-not-here.so" in r.stdout and "library None" in r.stdout
+
+
+def test_rccl_loader_reuses_the_copy_the_process_has_mapped():
+    """One RCCL per process: once PyTorch has mapped its bundled librccl, the C ABI binds THAT copy, not a second one by name."""
+    import subprocess
+
+    code = ("import sys; sys.path.insert(0, %r)\n"
+            "import torch\n"
+            "mapped = sorted({l.split()[-1] for l in open('/proc/self/maps') if '/librccl.so' in l})\n"
+            "from lurk_amd import comm\n"
+            "print('mapped', mapped); print('bound', comm.library())\n") % ROOT
+    env = {k: v for k, v in os.environ.items() if k != "LURKHIP_RCCL_LIB"}
+    r = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, timeout=300, env=env)
+    assert r.returncode == 0, r.stderr
+    mapped = eval(r.stdout.split("mapped ", 1)[1].splitlines()[0])
+    bound = r.stdout.split("bound ", 1)[1].strip()
+    if mapped:
+        assert bound.startswith(mapped[0]) and "already mapped" in bound
+    else:
+        assert "librccl" in bound
+
+
 def test_single_process_paths_need_no_process_group():
     sys.path.insert(0, ROOT)
     from lurk_amd import shards
@@ -92,6 +188,8 @@ def test_single_process_paths_need_no_process_group():
     assert shards.assign_shards(5, 1, 0) == [0, 1, 2, 3, 4]
     assert shards.assign_shards_balanced([5, 4, 3, 2, 1, 1], 2) == [[0, 3, 4], [1, 2, 5]]  # loads 8 and 8
     assert shards.assign_shards_balanced([1, 1], 1) == [[0, 1]]
+    assert shards.assign_shards_balanced([9, 8, 7, 6, 5, 4, 3, 2, 1], 8) == [[0], [1], [2], [3], [4], [5], [6], [7, 8]]  # nine shards, eight GPUs: the lightest two share a rank
+    assert shards.assign_shards_balanced([3, 1], 4) == [[0], [1], [], []]
     assert shards.exchange_roots([[2] * 8, [1] * 8], shard_indices=[1, 0]) == [[1] * 8, [2] * 8]
     assert shards.exchange_roots([[1] * 8, [2] * 8]) == [[1] * 8, [2] * 8]
     assert shards.reduce_cumulative_sums([(1, 2, 3, 4), (P - 1, P - 2, P - 3, P - 4)]) == (0, 0, 0, 0)

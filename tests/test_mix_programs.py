@@ -1,8 +1,13 @@
 """The generated fib-mix / lurk-mix machines (lurk_amd/programs/lurk_mix.py): every function has the width the reference's
 own `test_widths` expects (/root/reference/src/core/eval_direct.rs:2025-2063) under BOTH layout implementations (the C++
-host compiler and the oracle's independent Python one), the walkers produce exactly the dialled row counts, and a small
+host compiler and the oracle's independent Python one), the walkers produce exactly the dialled row counts, a small
 run satisfies the property the reference checks on its machines (every constraint vanishes on every row, lookups balance:
-/root/reference/src/air/debug.rs:119-206)."""
+/root/reference/src/air/debug.rs:119-206) -- and, since round 5, every chip has the SHAPE measured on the reference's real
+functions (tests/golden/fib_shape.json, written by tools/measure_lurk_shape.py and kept fresh by tests/test_real_evaluator.py)
+and a fib-mix run the measured heights."""
+import json
+import os
+
 import pytest
 
 from lurk_amd import lair
@@ -57,3 +62,103 @@ def test_machine_satisfies_the_reference_property(mix, oracle):
     prep = [[i & 0xFF, i >> 8, int((i & 0xFF) < (i >> 8)), (i & 0xFF) & (i >> 8), (i & 0xFF) ^ (i >> 8), (i & 0xFF) | (i >> 8)] for i in range(1 << 16)]
     chips.append((oa.BytesAir(), ol.bytes_trace(q), prep))
     assert oa.debug_check(chips, public=pv) > 0
+
+
+SHAPE = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "fib_shape.json")))
+TALL = ("eval", "eval_builtin_expr", "eval_binop_num", "apply")  # 93 % of a fib run's function-chip cells
+
+
+def _air_shape(top, name):
+    from lurk_amd.air import ChipAir
+
+    i = top.func_index(name)
+    lay = top.func_info(i)["layout"]
+    a = ChipAir.for_func(top, i)
+    return {"width": lay.total(), "aux": lay.aux, "sel": lay.sel, "sends": a.num_sends, "receives": a.num_receives, "constraints": a.num_constraints,
+            "permutation_width": a.permutation_width, "interaction_tuple_words": sum(a.interaction_sizes())}
+
+
+@pytest.mark.parametrize("mix", [lm.fib_mix(520), lm.lurk_mix(700)], ids=["fib-mix", "lurk-mix"])
+def test_every_chip_has_the_measured_shape(mix):
+    """Columns, selectors, lookups (hence permutation-trace columns) of every chip = the real function's, exactly; constraints and
+    lookup-tuple words exactly for the four tall chips and the native-chip wrappers, within the construction's reach for the rest
+    (few lookups to spend and many columns to fill leave products, one constraint each)."""
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    checked = 0
+    for name in lm.LURK_FUNC_ORDER:
+        try:
+            top.func_index(name)
+        except KeyError:
+            continue
+        got, want = _air_shape(top, name), SHAPE["chips"][name]
+        if name == "eval_coroutine_expr":  # the stub of the native toplevel without its failing assertion (it is never called upstream)
+            assert got["width"] == want["width"]
+            continue
+        for k in ("width", "aux", "sel", "sends", "receives", "permutation_width"):
+            assert got[k] == want[k], (name, k, got[k], want[k])
+        exact = name in TALL or name in lm.LEAVES or name in ("preallocate_symbols", "coerce_if_sym")
+        if exact and not (mix.name == "lurk-mix" and name == "eval_binop_num"):  # (owns 8 u64 gadgets there: no slack left for the tuple words)
+            assert got["constraints"] == want["constraints"], (name, got, want)
+            assert got["interaction_tuple_words"] == want["interaction_tuple_words"], (name, got, want)
+        else:
+            assert want["constraints"] - 2 <= got["constraints"] <= max(1.9 * want["constraints"], want["constraints"] + 20), (name, got, want)
+        checked += 1
+    assert checked == (17 if mix.name == "fib-mix" else 38)
+
+
+def test_fib_mix_has_the_measured_heights_and_columns_per_eval_row():
+    """A fib-mix run of as many eval rows as the measured `(fib 75000)`: every chip that grows with N within 2 % of the real run's
+    rows (memory tables included), and the totals the prover's cost follows -- main-trace cells, permutation-trace cells,
+    constraint evaluations, per eval row -- within 2 % of the real machine's."""
+    real = SHAPE["fib"]["75000"]
+    e = real["rows"]["eval"]
+    mix = lm.fib_mix(e)
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(mix.entry, mix.main_args, q)
+    rows = {f: q.num_func_queries(top.func_index(f)) for f in lm.FIB_FUNCS}
+    assert set(rows) == set(real["rows"])  # the 17 function chips of a real run, no other
+    for f, r in real["rows"].items():
+        if r > 1000:
+            assert abs(rows[f] - r) <= 0.02 * r, (f, rows[f], r)
+        else:
+            assert rows[f] <= max(2 * r, 64), (f, rows[f], r)
+    for ml in lair.MEM_TABLE_SIZES:
+        r = real["mem_rows"].get(str(ml), 0)
+        got = q.num_mem_queries(ml)
+        if r > 1000:
+            assert abs(got - r) <= 0.02 * r, (ml, got, r)
+        else:
+            assert got <= 256, (ml, got, r)
+    chips = SHAPE["chips"]
+    mine = {f: _air_shape(top, f) for f in lm.FIB_FUNCS}
+    for key in ("width", "permutation_width", "constraints", "interaction_tuple_words"):
+        want = sum(chips[f][key] * real["rows"][f] for f in real["rows"]) / e
+        got = sum(mine[f][key] * rows[f] for f in rows) / e
+        assert abs(got - want) <= 0.02 * want, (key, got, want)
+
+
+def test_lurk_mix_has_the_measured_mastermind_ratios():
+    """Config 5: the chips the real evaluator touches on demo/mastermind.lurk at its ratios per eval row (run-length chips within 6 %:
+    counts are rounded down and u64 gadgets share their owner's rows; the ingress-side chips at their measured sizes), the 13 it
+    never calls at a token height, memory tables 4 and 5 near the measured rates."""
+    real = SHAPE["mastermind"]
+    e = 1 << 14
+    mix = lm.lurk_mix(e)
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(mix.entry, mix.main_args, q)
+    scale = e / real["rows"]["eval"]
+    for f in lm.LURK_FUNC_ORDER:
+        got, r = q.num_func_queries(top.func_index(f)), real["rows"].get(f, 0)
+        if f in lm.INGRESS_SIDE:
+            assert got <= max(1.1 * r, 32), (f, got, r)  # (hash3 / hash5 are as tall as egress: 25 rows for the measured 6 and 0)
+        elif f in lm.LEAVES or f in lm.SHAPED_LEAVES or f in ("lurk_main", "eval_coroutine_expr"):
+            continue  # (leaves are as tall as the walker that calls them)
+        elif r * scale > 500:
+            assert abs(got - r * scale) <= 0.06 * r * scale, (f, got, r * scale)
+        else:
+            assert got <= max(2 * r * scale, 8), (f, got, r * scale)
+    for ml, tol in ((4, 0.2), (5, 0.1)):
+        want = real["mem_rows"][str(ml)] * scale
+        assert abs(q.num_mem_queries(ml) - want) <= tol * want, (ml, q.num_mem_queries(ml), want)

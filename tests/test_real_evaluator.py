@@ -143,3 +143,23 @@ def test_committed_shape_is_a_fresh_measurement(real):
     assert got["rows"] == {c: r for c, r in rows.items() if r}
     assert got["mem_rows"] == {l: r for l, r in mem.items() if r}
     assert got["byte_records"] == nbytes
+
+
+def test_mastermind_script_holds_under_the_real_evaluator(real):
+    """BASELINE config 5's program: demo/mastermind.lurk with its REPL commands folded into one expression (13 `def`, 3 `defrec`, 24
+    chain transitions, 41 assertions).  The fold evaluates to `t` only when every assertion of the script holds -- letrec, closures,
+    `hide` / `commit` / `open` (hash3 inverse queries made and used within one run), u64 arithmetic and comparisons, `eq` on
+    data: a broad check of the interpreter the row streams come from -- and the rows per chip are the ones the lurk-mix heights
+    are dialled from (tests/golden/fib_shape.json "mastermind")."""
+    out, q, _ = real.run(lr.fold_repl_script(lr.demo_script("mastermind.lurk")))
+    t_digest = [int(x) for x in real.resolver.digest[("lurk", "t")]]
+    assert list(out) == [lr.enums()["Tag"]["Sym"]] + [0] * 7 + t_digest
+    rows, mem, nbytes = real.record_counts(q)
+    with open(os.path.join(ROOT, "tests", "golden", "fib_shape.json")) as f:
+        m = json.load(f)["mastermind"]
+    assert m["rows"] == {c: r for c, r in rows.items() if r}
+    assert m["mem_rows"] == {l: r for l, r in mem.items() if r} and m["byte_records"] == nbytes
+    # one assertion made false: the fold must not evaluate to `t` any more
+    broken = lr.demo_script("mastermind.lurk").replace("!(assert-eq '(t 3 2) (maybe-remove 1 '(1 2 3)))", "!(assert-eq '(t 3 3) (maybe-remove 1 '(1 2 3)))", 1)
+    out2, _, _ = real.run(lr.fold_repl_script(broken))
+    assert list(out2)[0] == lr.enums()["Tag"]["Key"]  # :assertion-failed

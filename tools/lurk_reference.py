@@ -185,7 +185,7 @@ class Resolver:
 # Symbols resolve the way State::init_lurk_state does for the user package (state.rs:196-213): a name that is a builtin or
 # `nil` / `t` / `&rest` is imported from `.lurk(.builtin)`, anything else lives in `.lurk-user`; `:x` is a keyword.
 
-_TOKEN = re.compile(r"""\s*(?:;[^\n]*\n\s*)*(\(|\)|'|"(?:[^"\\]|\\.)*"|\#\\.|'.'|[^\s()']+)""")
+_TOKEN = re.compile(r"""\s*(?:;[^\n]*(?:\n|$)\s*)*(!\(|\(|\)|'.'|'|"(?:[^"\\]|\\.)*"|[^\s()']+)""")
 
 
 def read_lurk(text: str):
@@ -198,6 +198,13 @@ def read_lurk(text: str):
     pos = 0
 
     def atom(t):
+        if t.startswith("#0x"):  # big-num literal: base-p digits, little-endian (parser/syntax.rs:267-290)
+            v, digest = int(t[3:], 16), []
+            for _ in range(8):
+                digest.append(v % 2013265921)
+                v //= 2013265921
+            assert v == 0, "digest literal too big"
+            return ("bignum", tuple(digest))
         if re.fullmatch(r"\d+(u64)?", t):
             return zs.syn_u64(int(t.removesuffix("u64")))
         if re.fullmatch(r"\d+n", t):
@@ -237,6 +244,80 @@ def read_lurk(text: str):
     out = expr()
     assert pos == len(toks), "trailing input"
     return out
+
+
+def fold_repl_script(text: str) -> str:
+    """A REPL script (`!(def ..)`, `!(defrec ..)`, `!(defq x !(transition s args..))`, `!(assert ..)`, `!(assert-eq a b)`, bare
+    expressions: src/core/cli/meta.rs) as ONE Lurk expression with the same evaluation work: a definition becomes a `let` / `letrec`
+    around everything after it, a chain transition the application `((cdr s) args..)` it performs, an assertion the expression it
+    evaluates.  The REPL proves each top-level evaluation on its own; folded, the script is one execution of the same machine --
+    which is what a measurement of the chips' relative heights needs (the script's own assertions guard it: the fold evaluates to
+    `t` only when every one of them held).  Text in, text out; nothing is stored."""
+    toks = _TOKEN.findall(re.sub(r";[^\n]*", "", text))  # (no `;` inside the scripts' string literals)
+    pos = 0
+
+    def form():  # one balanced form as a token list
+        nonlocal pos
+        t = toks[pos]
+        pos += 1
+        if t in ("(", "!("):
+            out = [t]
+            while toks[pos] != ")":
+                out += form()
+            pos += 1
+            return out + [")"]
+        if t == "'":
+            return [t] + form()
+        return [t]
+
+    def split(fm):  # the direct children of a parenthesised form
+        kids, i, depth, cur = [], 1, 0, []
+        while i < len(fm) - 1:
+            t = fm[i]
+            cur.append(t)
+            depth += t in ("(", "!(")
+            depth -= t == ")"
+            if depth == 0 and t != "'":
+                kids.append(cur)
+                cur = []
+            i += 1
+        return kids
+
+    def txt(fm):
+        return " ".join(fm).replace("( ", "(").replace(" )", ")").replace("' ", "'")
+
+    def value(fm):  # an expression that may be a `!(transition s args..)` meta form
+        if fm[0] == "!(":
+            kids = split(fm)
+            assert txt(kids[0]) == "transition", txt(kids[0])
+            return "((cdr " + value(kids[1]) + ")" + "".join(" " + value(k) for k in kids[2:]) + ")"
+        return txt(fm)
+
+    forms = []
+    while pos < len(toks):
+        forms.append(form())
+    out = "t"
+    for fm in reversed(forms):
+        if fm[0] == "!(":
+            kids = split(fm)
+            head = txt(kids[0])
+            if head in ("def", "defq"):
+                out = f"(let (({txt(kids[1])} {value(kids[2])})) {out})"
+            elif head == "defrec":
+                out = f"(letrec (({txt(kids[1])} {value(kids[2])})) {out})"
+            elif head == "assert":  # a failing assertion ends the evaluation with a keyword instead of the final `t`
+                out = f"(if {value(kids[1])} {out} :assertion-failed)"
+            elif head == "assert-eq":
+                out = f"(if (eq {value(kids[1])} {value(kids[2])}) {out} :assertion-failed)"
+            else:
+                raise ValueError(f"meta command {head} is not folded")
+        else:
+            out = f"(begin {txt(fm)} {out})"
+    return out
+
+
+def demo_script(name: str) -> str:
+    return _read(os.path.join("demo", name))
 
 
 def fib_program(arg: int) -> str:

@@ -11,6 +11,9 @@ What is checked on the way (the script fails when one does not hold):
   * all 39 literals of `test_widths` (/root/reference/src/core/eval_direct.rs:2025-2063) on the real function bodies;
   * `(fib N)` evaluates to U64 fib(N) mod 2^64 (tag lane + 8 little-endian bytes) for every N measured.
 
+  * demo/mastermind.lurk (BASELINE config 5), its REPL commands folded into one expression, evaluates to `t`: all 41 assertions
+    of the script hold under the evaluator.
+
 What is written: per chip the layout and the AIR's size (columns, selectors, interactions, constraints, the product's
 program lengths) and per N the rows of every chip, memory-table sizes and byte records -- the numbers SURVEY.md appendix C
 estimated by hand.  `lurk_amd/programs/lurk_mix.py` dials its stand-in machine from this file.
@@ -61,6 +64,8 @@ def intern_syntax(z, syn):
         return z.num(syn[1])
     if k == "char":
         return z.char(syn[1])
+    if k == "bignum":
+        return z.big_num(syn[1])
     if k == "str":
         return z.intern_string(syn[1])
     if k == "sym":
@@ -196,16 +201,32 @@ def measure(ns):
             if d:
                 per_level["mem" + l] = round(d, 6)
         per_level["byte_records"] = round((rb["byte_records"] - ra["byte_records"]) / (b - a), 6)
+    # BASELINE config 5: demo/mastermind.lurk, its REPL commands folded into one expression (lurk_reference.fold_repl_script); every
+    # assertion of the script holds iff the fold evaluates to `t`
+    out, q, dt = real.run(lr.fold_repl_script(lr.demo_script("mastermind.lurk")))
+    t_digest = [int(x) for x in real.resolver.digest[("lurk", "t")]]
+    if list(out) != [lr.enums()["Tag"]["Sym"]] + [0] * 7 + t_digest:
+        raise SystemExit(f"demo/mastermind.lurk: an assertion of the script failed under the evaluator (result {out})")
+    rows, mem, nbytes = real.record_counts(q)
+    e = rows["eval"]
+    mastermind = {
+        "script": "demo/mastermind.lurk: 13 def + 24 defq/transition + 3 defrec folded to let / letrec, 41 assertions folded to `if` (all hold)",
+        "rows": {c: r for c, r in rows.items() if r}, "mem_rows": {l: r for l, r in mem.items() if r}, "byte_records": nbytes,
+        "main_columns_per_eval_row": round((sum(chips[c]["width"] * r for c, r in rows.items()) + sum(mem_w[l] * r for l, r in mem.items())) / e, 3),
+        "func_permutation_columns_per_eval_row": round(sum(4 * chips[c]["permutation_width"] * r for c, r in rows.items()) / e, 3),
+    }
+    print(f"demo/mastermind.lurk: all assertions hold; eval rows {e}, {sum(1 for r in rows.values() if r)} function chips with rows")
     return {
         "_about": "Measured by tools/measure_lurk_shape.py on the reference's own Lair functions (read from /root/reference at run time, "
                   "compiled and executed by this repo's host code). Numbers only: no program text, no bytecode.",
         "sources": {"functions": "src/core/eval_direct.rs:119-1957, src/core/ingress.rs:99-325, src/core/misc.rs:5-121",
-                    "program": "benches/fib.rs:36-44", "widths": "src/core/eval_direct.rs:2025-2063"},
+                    "program": "benches/fib.rs:36-44", "widths": "src/core/eval_direct.rs:2025-2063", "mastermind": "demo/mastermind.lurk"},
         "widths_reproduced": f"{len(want)}/{len(want)}",
         "func_order": real.names,
         "chips": chips,
         "fib": runs,
         "fib_per_level": per_level,
+        "mastermind": mastermind,
     }
 
 
