@@ -250,6 +250,11 @@ def main():
     ap.add_argument("--rank-pipeline", action="store_true",
                     help="N > 1 (or --shards-per-rank > 1): phase 1 of machine proof j + 1 under phase 2 of proof j on a second machine (measured on one "
                          "GPU through RCCL at world 1: 47.9 against 46.4 ms per step -- phase 2 already keeps two shards in flight; off by default)")
+    ap.add_argument("--rank-in-flight", type=int, default=None,
+                    help="N > 1 (or --shards-per-rank > 1): machine proofs IN FLIGHT per rank, each on its own machine, contexts and communicator "
+                         "(shards.run_in_flight: a rank never idles at a collective).  Default 2; 1 = one machine proof at a time (rounds 2-4)")
+    ap.add_argument("--rank-in-flight-lanes", type=int, choices=(1, 2), default=1,
+                    help="with --rank-in-flight >= 2: streams per machine proof (1 = its shards one after the other on the machine's stream; 2 = two of its shards at a time)")
     ap.add_argument("--rank-pipeline-depth", type=int, default=2,
                     help="with --rank-pipeline: machines per rank.  2 = phase 1 of proof j + 1 under phase 2 of proof j, joined once per proof "
                          "(shards.run_pipelined); >= 3 = a committer thread runs phase 1 up to depth - 1 proofs ahead (shards.run_committed_ahead)")
@@ -385,16 +390,22 @@ def main():
     main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     perm_cols_per_eval_row = sum(4 * air.permutation_width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     constraints_per_eval_row = sum(air.num_constraints << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
-    one_lane = args.rank_pipeline and args.rank_pipeline_one_lane
+    multi = world > 1 or len(all_shards) > 1
+    in_flight = 1 if (args.rank_pipeline or not multi) else (args.rank_in_flight if args.rank_in_flight is not None else 2)
+    one_lane = (args.rank_pipeline and args.rank_pipeline_one_lane) or (in_flight >= 2 and args.rank_in_flight_lanes == 1)
     lane_ctx = prover.lane_context(machine) if len(mine) > 1 and not one_lane else None  # the second proving lane of a rank with several shards
 
     # the step itself lives in lurk_amd/shards.py (RankStep) so that the multi-process tests run exactly what is timed here
     # the two collectives of a step behind the C ABI (lurkhip_exchange_roots / lurkhip_reduce_sums on RCCL, csrc/comm.cpp) whenever the
     # process group is RCCL's: what a Rust host drives; two ranks on one device (the oversubscribed test mode) keep gloo
     comm = None
+    rccl_library = None
     if distributed and not oversubscribed and not args.torch_collectives:
         from lurk_amd.comm import Comm
 
+        from lurk_amd.comm import library as rccl_library_of
+
+        rccl_library = rccl_library_of()  # which librccl the C ABI bound: the copy torch has mapped (one RCCL per process)
         comm = Comm.from_process_group(ctx)
     rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx, comm=comm,
                                 n_shards=len(all_shards))
@@ -408,9 +419,9 @@ def main():
     # (traces + main commitments: throughput-bound) runs under phase 2 of proof j (latency chains, and a light last shard whose
     # lane idles early) -- shards.run_pipelined.  All collectives stay on this thread, in the same order on every rank.
     pipe = None
-    if len(mine) > 1 and args.rank_pipeline:
-        pipe = {"steps": [rank_step], "ctxs": [], "machines": [], "prepared": []}
-        for _ in range(max(2, args.rank_pipeline_depth) - 1):
+    if (len(mine) > 1 and args.rank_pipeline) or in_flight >= 2:
+        pipe = {"steps": [rank_step], "ctxs": [], "machines": [], "prepared": [], "comms": []}
+        for _ in range((in_flight if in_flight >= 2 else max(2, args.rank_pipeline_depth)) - 1):
             ctx_b = lurk_amd.Context(device_index) if os.environ.get("LURKHIP_LANE_UNPLACED") else lurk_amd.Context(beside=ctx)
             if args.profile != "default":
                 from lurk_amd.profile import ProtocolProfile
@@ -422,13 +433,26 @@ def main():
             if not args.no_compile:
                 for pr in prepared_b:
                     machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
-            lane_ctx_b = prover.lane_context(machine_b) if not one_lane else None
-            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm,
-                                                 n_shards=len(all_shards)))
+            lane_ctx_b = prover.lane_context(machine_b) if (len(mine) > 1 and not one_lane) else None
+            comm_b, group_b = comm, None
+            if in_flight >= 2 and distributed:
+                # a machine proof in flight issues its collectives from its own thread: its own communicator (created here, in the same
+                # order on every rank), on its own context's stream
+                if comm is not None:
+                    comm_b = Comm.from_process_group(ctx_b)
+                    pipe["comms"].append(comm_b)
+                else:
+                    group_b = dist.new_group(backend="gloo" if oversubscribed else None)
+            pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm_b,
+                                                 n_shards=len(all_shards), group=group_b))
             pipe["ctxs"] += [c for c in (ctx_b, lane_ctx_b) if c is not None]
             pipe["machines"].append(machine_b)
             pipe["prepared"].append(prepared_b)
-        pipe["run"] = shards.run_pipelined if len(pipe["steps"]) == 2 else shards.run_committed_ahead
+        if in_flight >= 2:
+            pipe["stagger_s"] = 0.0
+            pipe["run"] = lambda steps_, n_, on_proofs=None: shards.run_in_flight(steps_, n_, on_proofs=on_proofs, stagger_s=pipe["stagger_s"])
+        else:
+            pipe["run"] = shards.run_pipelined if len(pipe["steps"]) == 2 else shards.run_committed_ahead
 
     def fence():
         ctx.sync()
@@ -448,6 +472,10 @@ def main():
         step()
     if pipe is not None:  # warm the second machine and the pipeline's worker
         pipe["run"](pipe["steps"], len(pipe["steps"]))
+        if in_flight >= 2:  # the proofs in flight run out of phase: lane t starts t / K of one machine proof's own time late
+            t_w = time.perf_counter()
+            step()
+            pipe["stagger_s"] = (time.perf_counter() - t_w) / in_flight
         for cx_ in pipe["ctxs"]:
             cx_.sync()
     fence()
@@ -622,13 +650,18 @@ def main():
     per_rank_ms = [rank_ms]
     all_rank_sums_nonzero = all(s != (0, 0, 0, 0) for s in rank_sums)
     exec_s_per_rank = [t_execute]
+    import resource
+
+    rss_mb = resource.getrusage(resource.RUSAGE_SELF).ru_maxrss / 1024.0  # this rank's peak resident set (the whole query record lives in it)
+    rss_per_rank = [rss_mb]
     if distributed:
         tdev = "cuda" if dev == "cuda" else "cpu"
-        t = torch.tensor([elapsed, t_execute], dtype=torch.float64, device=tdev)
+        t = torch.tensor([elapsed, t_execute, rss_mb], dtype=torch.float64, device=tdev)
         gathered = [torch.zeros_like(t) for _ in range(world)]
         dist.all_gather(gathered, t)
         per_rank_ms = [float(g[0].item()) / args.steps * 1e3 for g in gathered]
         exec_s_per_rank = [float(g[1].item()) for g in gathered]
+        rss_per_rank = [float(g[2].item()) for g in gathered]
         elapsed = max(float(g[0].item()) for g in gathered)
         flag = torch.tensor([1 if all_rank_sums_nonzero else 0], dtype=torch.int64, device=tdev)
         dist.all_reduce(flag, op=dist.ReduceOp.MIN)
@@ -892,6 +925,7 @@ def main():
                 "shards_per_rank": spr,
                 "shard_assignment": assignment if world > 1 or spr > 1 else None,
                 "rccl_world_size": rccl_world_size if not oversubscribed else None,
+                "rccl_library": rccl_library,
                 "collectives": None if not distributed else ("c-abi: lurkhip_exchange_roots + lurkhip_reduce_sums on RCCL, the context's stream (csrc/comm.cpp)" if comm is not None else "torch.distributed"),
                 "process_group": None if not distributed else ("gloo (oversubscribed diagnostic: ranks share a device; NOT a scaling number)" if oversubscribed else "nccl (RCCL)"),
                 "visible_gpus": n_devices,
@@ -913,6 +947,7 @@ def main():
                 "end_to_end": {
                     "note": "every rank runs the WHOLE program through the host interpreter before proving (same query record on every rank, no broadcast of row streams); that time is outside the timed region and is the end-to-end Amdahl bound",
                     "host_execute_s_wall": max(exec_s_per_rank), "host_execute_s_summed_over_ranks": sum(exec_s_per_rank),
+                    "host_execute_s_per_rank": exec_s_per_rank, "peak_rss_mb_per_rank": rss_per_rank,
                     "host_interpreter_eval_rows_per_s": world * n / max(exec_s_per_rank),
                     "host_interpreter_queries": host_queries, "host_interpreter_memory_cells": host_mem_cells,
                     "host_interpreter_queries_per_s": host_queries / t_execute,
@@ -922,7 +957,9 @@ def main():
                 "compiled_air_chips": compiled,
                 "compiled_trace_chips": list(machine.compiled_traces),
                 "air_compile_s": t_jit,
-                "rank_pipeline": ("phase 1 of machine proof j + 1 (traces + main commitments, on a second machine's context) under phase 2 of proof j; "
+                "rank_proofs_in_flight": in_flight,
+                "rank_in_flight_stagger_ms": (pipe["stagger_s"] * 1e3 if pipe is not None and in_flight >= 2 else None),
+                "rank_pipeline": None if in_flight >= 2 else ("phase 1 of machine proof j + 1 (traces + main commitments, on a second machine's context) under phase 2 of proof j; "
                                   "collectives on one thread in a fixed order" if pipe is not None else None),
                 "proofs_in_flight": lanes,
                 "lane_stagger_ms": (stagger_ms if lanes >= 2 else None),
@@ -974,6 +1011,8 @@ def main():
     del prepared, prepared_all
     if pipe is not None:
         del pipe["prepared"]
+        for c_ in pipe.get("comms", []):
+            c_.close()
         for m_ in pipe["machines"]:
             m_.close()
         for cx_ in reversed(pipe["ctxs"]):

@@ -44,14 +44,16 @@ def _dist():
     return dist if dist.is_available() and dist.is_initialized() else None
 
 
-def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None, n_shards=None):
+def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None, n_shards=None, group=None):
     """local_roots: [k][8] roots of this rank's shards.  With `shard_indices` (this rank's shard numbers, same order as
     local_roots; any assignment, e.g. assign_shards_balanced) k may differ from rank to rank and may be 0: the ranks first
     all-gather their counts, then records padded to the largest count (a 9-word (index, root) record per shard, index -1 = padding).
     Without indices every rank passes the same k (the round-robin layout of `assign_shards`, undone on return).
     `comm` (lurk_amd.comm.Comm, with shard_indices): the all-gathers run behind the C ABI on RCCL (lurkhip_exchange_roots_var)
     instead of torch.distributed -- the route a Rust host takes; the gloo CPU tests and single-process runs keep the torch path.
-    Returns the roots of all shards ordered by shard index.  `n_shards` (optional): the number of shards every rank expects."""
+    Returns the roots of all shards ordered by shard index.  `n_shards` (optional): the number of shards every rank expects.
+    `group`: the torch process group to use (two machine proofs in flight on one rank issue their collectives from two threads:
+    each thread has its own group, so that the order of collectives is the same on every rank within each group)."""
     if comm is not None:
         if shard_indices is None:
             raise ValueError("the C-ABI exchange carries the shard indices with the roots")
@@ -70,12 +72,12 @@ def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None, n_s
         else:
             world = dist.get_world_size()
             counts = torch.zeros(world, dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(counts, torch.tensor([rec.shape[0]], dtype=torch.int64, device=device))
+            dist.all_gather_into_tensor(counts, torch.tensor([rec.shape[0]], dtype=torch.int64, device=device), group=group)
             most = int(counts.max())
             padded = torch.full((max(most, 1), 9), -1, dtype=torch.int64, device=device)
             padded[: rec.shape[0]] = rec
             out = torch.zeros((world,) + tuple(padded.shape), dtype=torch.int64, device=device)
-            dist.all_gather_into_tensor(out.view(-1), padded.view(-1))
+            dist.all_gather_into_tensor(out.view(-1), padded.view(-1), group=group)
             rows = [r for per_rank in out.cpu().tolist() for r in per_rank if r[0] >= 0]
         rows.sort(key=lambda r: r[0])
         if [r[0] for r in rows] != list(range(len(rows))) or (n_shards is not None and len(rows) != n_shards):
@@ -85,13 +87,13 @@ def exchange_roots(local_roots, device="cpu", shard_indices=None, comm=None, n_s
         return [[int(x) for x in r] for r in local.cpu().tolist()]
     world = dist.get_world_size()
     out = torch.zeros((world,) + tuple(local.shape), dtype=torch.int64, device=device)
-    dist.all_gather_into_tensor(out.view(-1), local.view(-1))
+    dist.all_gather_into_tensor(out.view(-1), local.view(-1), group=group)
     gathered = out.cpu().tolist()  # [rank][k][8]
     k = local.shape[0]
     return [[int(x) for x in gathered[s % world][s // world]] for s in range(k * world)]
 
 
-def reduce_cumulative_sums(local_sums, device="cpu", comm=None):
+def reduce_cumulative_sums(local_sums, device="cpu", comm=None, group=None):
     """local_sums: iterable of extension-field elements (4 canonical lanes each): the cumulative sums of every chip of
     every shard this rank proved.  Returns the machine-wide total (4 lanes, reduced mod p) on every rank; the proof
     set is consistent iff it is zero.  `comm`: behind the C ABI on RCCL (lurkhip_reduce_sums)."""
@@ -106,7 +108,7 @@ def reduce_cumulative_sums(local_sums, device="cpu", comm=None):
     t = torch.from_numpy(acc).to(device)
     dist = _dist()
     if dist is not None:
-        dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        dist.all_reduce(t, op=dist.ReduceOp.SUM, group=group)
     return tuple(int(x) % P for x in t.cpu().tolist())
 
 
@@ -131,7 +133,8 @@ class RankStep:
     with `comm` both collectives run inside the library (lurkhip_exchange_roots / lurkhip_reduce_sums on the context's stream)."""
 
     def __init__(self, machine, vk_root, public_values, prepared_all, shard_indices, num_queries, pow_bits, device="cpu", lane_ctx=None, comm=None,
-                 n_shards=None):
+                 n_shards=None, group=None):
+        self.group = group        # torch process group of the two collectives (None: the default group)
         self.n_shards = n_shards  # shards of the whole execution: with it the ranks may hold different numbers of shards (or none)
         self.machine, self.vk_root, self.pv = machine, vk_root, list(public_values)
         self.prepared_all, self.mine = prepared_all, list(shard_indices)
@@ -170,7 +173,7 @@ class RankStep:
         import time
 
         t = time.perf_counter()
-        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine, comm=self.comm, n_shards=self.n_shards)
+        self.roots = exchange_roots(state["roots"], device=self.device, shard_indices=self.mine, comm=self.comm, n_shards=self.n_shards, group=self.group)
         self.host_ms["exchange_roots"] = self.host_ms.get("exchange_roots", 0.0) + (time.perf_counter() - t) * 1e3
         return self.roots
 
@@ -197,7 +200,7 @@ class RankStep:
             mine_sum = (mine_sum + np.asarray(c, dtype=np.int64)) % P
         self.rank_sums.append(tuple(int(x) for x in mine_sum))
         t = time.perf_counter()
-        self.grand_sums.append(reduce_cumulative_sums(cs, device=self.device, comm=self.comm))
+        self.grand_sums.append(reduce_cumulative_sums(cs, device=self.device, comm=self.comm, group=self.group))
         self.host_ms["reduce_sums"] = self.host_ms.get("reduce_sums", 0.0) + (time.perf_counter() - t) * 1e3
         self.calls += 1
         self.last_proofs = proofs
@@ -240,6 +243,42 @@ def run_pipelined(steps, n_steps: int, on_proofs=None):
             pending = nxt
     finally:
         pool.shutdown(wait=True)
+
+
+def run_in_flight(steps, n_steps: int, on_proofs=None, stagger_s: float = 0.0):
+    """n_steps machine proofs on this rank, K = len(steps) of them IN FLIGHT (round 5): thread t runs proofs t, t + K, t + 2K, ...
+    from start to end (commit -> exchange -> prove -> check) on steps[t] -- its own Machine and contexts and, what makes this legal,
+    its own communicator (RCCL `Comm` or torch process group): within one communicator the collectives are issued by one thread, in
+    proof order, the same on every rank; across communicators nothing is ordered and nothing needs to be.  While one proof waits in
+    a collective or in a latency chain, the other's kernels have the device: a rank never idles at a collective (the
+    one-proof-at-a-time rank schedule lost 7 % per GPU to exactly that).  Thread t starts t * stagger_s
+    late so that the proofs run out of phase.  `on_proofs(j, proofs)` may be called from any of the threads."""
+    import threading
+    import time
+
+    k = len(steps)
+    assert k >= 1 and n_steps >= 1
+    errors = []
+
+    def lane(t):
+        try:
+            if t and stagger_s:
+                time.sleep(t * stagger_s)
+            for j in range(t, n_steps, k):
+                proofs = steps[t]()
+                if on_proofs is not None:
+                    on_proofs(j, proofs)
+        except BaseException as e:  # surfaced on the calling thread
+            errors.append(e)
+
+    threads = [threading.Thread(target=lane, args=(t,), name=f"lurkhip-proof-lane{t}") for t in range(1, k)]
+    for th in threads:
+        th.start()
+    lane(0)
+    for th in threads:
+        th.join()
+    if errors:
+        raise errors[0]
 
 
 def run_committed_ahead(steps, n_steps: int, on_proofs=None):

@@ -144,6 +144,64 @@ def test_ragged_shard_counts_over_gloo(world, n_shards):
         assert grand == (0, 0, 0, 0) and wrong_total == "refused" and gathered_ok
 
 
+def _worker_in_flight(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lurk_amd import shards
+
+    groups = [dist.new_group(backend="gloo") for _ in range(2)]  # one per proof lane, created in the same order on every rank
+
+    class FakeStep:
+        """The collectives of a RankStep without the GPU work between them: exchange -> (a pause of a different length on every
+        rank and lane, so that the lanes' collectives interleave differently on the two ranks) -> reduce."""
+
+        def __init__(self, lane):
+            self.lane, self.calls, self.seen = lane, 0, []
+
+        def __call__(self):
+            import time
+
+            j = 2 * self.calls + self.lane  # the proof this call is
+            mine = [s for s in range(3) if s % world == rank]
+            roots = shards.exchange_roots([[(100 * j + 10 * s + k) % P for k in range(8)] for s in mine], shard_indices=mine, n_shards=3, group=groups[self.lane])
+            time.sleep(0.002 * ((rank + 1) * (self.lane + 2) + j % 3))
+            total = shards.reduce_cumulative_sums([(j + 1, 0, 0, 0)] if rank == 0 else [(P - j - 1, 0, 0, 0)], group=groups[self.lane])
+            self.calls += 1
+            self.seen.append((j, roots, total))
+            return [np.array([j], dtype=np.uint32)]
+
+    steps = [FakeStep(0), FakeStep(1)]
+    order = []
+    shards.run_in_flight(steps, 9, on_proofs=lambda j, proofs: order.append((j, int(proofs[0][0]))), stagger_s=0.003)
+    q.put((rank, [st.seen for st in steps], sorted(order)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_two_machine_proofs_in_flight_on_two_process_groups():
+    """shards.run_in_flight (round 5): two proof lanes per rank, each issuing its collectives on its own process group from its own
+    thread; the lanes interleave differently on the two ranks and every proof still sees its own roots and a zero grand sum."""
+    world = 2
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker_in_flight, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted(q.get(timeout=180) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+        assert p.exitcode == 0
+    for rank, seen, order in results:
+        assert order == [(j, j) for j in range(9)]
+        assert [j for j, _, _ in seen[0]] == [0, 2, 4, 6, 8] and [j for j, _, _ in seen[1]] == [1, 3, 5, 7]
+        for lane in seen:
+            for j, roots, total in lane:
+                assert roots == [[(100 * j + 10 * s + k) % P for k in range(8)] for s in range(3)] and total == (0, 0, 0, 0)
+
+
 def test_rccl_loader_reports_instead_of_crashing():
     """with no loadable librccl the communicator entry points must return an error with the loader's message (the
     message used to be built from a second dlerror() call, i.e. from a null pointer).  LURKHIP_RCCL_LIB names THE library to use."""

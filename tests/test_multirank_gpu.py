@@ -174,6 +174,46 @@ def test_bench_refuses_more_ranks_than_gpus_and_runs_them_oversubscribed():
         assert cfg["rccl_world_size"] == 2
 
 
+def test_bench_eight_ranks_nine_shards_rehearsal():
+    """The first 8-GPU run, rehearsed: `bench.py --gpus 8` as the driver starts it, eight ranks on the
+    devices present (oversubscribed over gloo when there are fewer than eight), ONE execution cut into NINE shards -- not a multiple
+    of the rank count: the ranks hold one or two shards, the root exchange gathers the counts first --, two machine proofs in flight
+    per rank on two process groups.  The gathered proof set must be a partition with matching roots and a zero grand sum, and
+    every rank's host seconds and peak resident set are in the line."""
+    import torch
+
+    n = torch.cuda.device_count()
+    extra = ["--gpus", "8", "--shards-total", "9", "--log-rows", "13"] + (["--oversubscribe"] if n < 8 else [])
+    r = _bench(*extra, timeout=2400)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert line["ranks"] == 8 and cfg["shards"] == 9 and cfg["rank_proofs_in_flight"] == 2
+    assert sorted(s for a in cfg["shard_assignment"] for s in a) == list(range(9)) and sorted(len(a) for a in cfg["shard_assignment"]) == [1] * 7 + [2]
+    assert cfg["grand_sum_is_zero"] and cfg["per_rank_sum_nonzero"] and cfg["proofs_identical_across_steps"]
+    gs = cfg["gathered_proof_set"]
+    assert gs["shards_gathered_on_rank0"] == 9 and gs["main_roots_match_exchanged_roots_in_shard_order"] and gs["grand_sum_of_gathered_proofs_is_zero"]
+    assert len(cfg["host_execute_s_per_rank"]) == 8 and len(cfg["end_to_end"]["peak_rss_mb_per_rank"]) == 8 and min(cfg["end_to_end"]["peak_rss_mb_per_rank"]) > 100
+
+
+def test_bench_world_one_two_machine_proofs_in_flight_on_two_rccl_communicators():
+    """torchrun with one rank, two shards: the N > 1 schedule on RCCL at world 1 -- two machine proofs in flight on two
+    communicators behind the C ABI (csrc/comm.cpp: the counts' all-gather, the records' all-gather, the sums' all-reduce per proof,
+    from two host threads), the librccl bound being the copy PyTorch has mapped."""
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=1", "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(ROOT, "bench.py"), "--gpus", "1", "--shards-per-rank", "2", "--steps", "4", "--warmup", "1", "--log-rows", "12", "--no-cpu-baseline",
+           "--queries", "8", "--pow-bits", "6", "--no-compile"]
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    r = subprocess.run(cmd, cwd=ROOT, env=env, capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    cfg = line["config"]
+    assert cfg["rank_proofs_in_flight"] == 2 and cfg["shards"] == 2 and cfg["rccl_world_size"] == 1
+    assert "c-abi" in cfg["collectives"] and "librccl" in cfg["rccl_library"]
+    assert cfg["grand_sum_is_zero"] and cfg["proofs_identical_across_steps"]
+    assert cfg["gathered_proof_set"]["grand_sum_of_gathered_proofs_is_zero"]
+
+
 def test_bench_two_proofs_in_flight_line_is_complete():
     """The N = 1 default schedule (--lanes 2) at a small height: the line carries the sequential measurement beside the headline,
     every proof of the timed region equals the sequential one, the sums cancel."""

@@ -54,7 +54,8 @@ def test_mix_machine_proves_and_verifies(ctx, mix):
     # every function of the machine has rows, plus entrypoint, the used memory tables and the byte table
     assert len(p.chips) >= top.num_funcs() + 2
     widths = sorted(c.width for c in p.chips)
-    assert widths[-1] == 815 and widths[0] <= 10
+    # (a real fib run touches hash4 only: 655 columns; mastermind's machine has all three hashers, 815 the widest)
+    assert widths[-1] == (655 if mix.name == "fib-mix" else 815) and widths[0] <= 10
     assert prover.grand_sum(proofs) == (0, 0, 0, 0)
     assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
     m.close()
