@@ -928,7 +928,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde[sh->prep_index[i]] : nullptr;
         const uint32_t pitches[3] = {sh->main_commit->pitch[i], sh->prep_index[i] >= 0 ? pk->commit->pitch[sh->prep_index[i]] : 0u, perm_commit->pitch[i]};
         PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
-                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches));
+                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true));
         const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
         const uint32_t wq_inv = pow_host(wq, bb::P - 2);
         for (uint32_t c = 0; c < qd; c++) {

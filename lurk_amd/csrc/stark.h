@@ -39,7 +39,9 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev,
                       const uint32_t* shared_beta_pows = nullptr, const uint32_t* shared_starts = nullptr,
-                      const uint32_t* pitches = nullptr /* {main, prep, perm} row pitches in words, 0 or null: the matrix's width */);
+                      const uint32_t* pitches = nullptr /* {main, prep, perm} row pitches in words, 0 or null: the matrix's width */,
+                      bool honest_running_sum = false /* the permutation LDE is the LDE of a trace this prover built: its last column IS the
+                      running sum of the row sums and ends in cumsum_m, so the next row's sum need not be read (stark_kernels.h) */);
 
 }  // namespace lurkhip
 

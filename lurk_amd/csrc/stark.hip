@@ -595,7 +595,7 @@ uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd) {
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
-                      const uint32_t* shared_starts, const uint32_t* pitches) {
+                      const uint32_t* shared_starts, const uint32_t* pitches, bool honest_running_sum) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
     LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
     const uint32_t lqd = a->air.log_quotient_degree();
@@ -678,6 +678,13 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             q.zh[c] = bb::sub(bb::mul(gn, cur), bb::R1);
             q.zh_inv[c] = bb::pow(q.zh[c], bb::P - 2);
             cur = bb::mul(cur, w_qd);
+        }
+        // the transition constraint of the running sum on an honest trace: -cumulative_sum / (N w_N) times Z_H(x) (stark_kernels.h)
+        q.honest_running_sum = honest_running_sum && getenv("LURKHIP_QUOTIENT_READ_NEXT_SUM") == nullptr ? 1 : 0;
+        {
+            const uint32_t n_w = bb::mul(bb::to_monty((uint32_t)(((uint64_t)1 << log_n) % bb::P)), wn);
+            const uint32_t neg_inv = bb::sub(0u, bb::pow(n_w, bb::P - 2));
+            for (int c = 0; c < 4; c++) q.trans_const.c[c] = bb::mul(cs[c], neg_inv);
         }
         q.out = out_dev;
         q.sel = selector_table_of(ctx, log_n, lqd);

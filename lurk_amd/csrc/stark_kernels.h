@@ -249,6 +249,17 @@ struct QuotientArgs {
     uint32_t regs_words, wp;    // LDS layout (layout_parts)
     int staged;
     uint32_t* out;          // [2^lqd][N][4]
+    // Round 5.  The transition constraint of the running sum, (phi(xw) - phi(x) - S(xw)) * (x - w^-1) with S = the sum of the batch
+    // columns, needs S on the NEXT row: the kernel used to read the whole next row of the permutation LDE for it (one lane per row,
+    // perm_w dependent 16-byte loads: 36 % of a fib step's quotient traffic, and the latency chain `SQ_WAIT_ANY 58 %` pointed at).
+    // On a trace the prover built itself phi IS the running sum of S and ends in the cumulative sum c, so as polynomials of degree
+    // < N:  S(X) = phi(X) - phi(X / w) + L_0(X) c  (both sides interpolate S on the trace domain; L_0 = the first row's Lagrange
+    // basis).  Hence S(xw) = phi(xw) - phi(x) + L_0(xw) c and the constraint's value is -L_0(xw) c (x - w^-1)
+    // = -c Z_H(x) / (N w): nothing of the next row is read.  Same field element as the direct evaluation -- the proofs do not change
+    // by a bit (tests/test_prover_gpu.py, test_cpu_step_gpu.py) -- but only for an honest running sum: the standalone entry point
+    // lurkhip_quotient_dev, which may be handed any matrices, keeps the direct evaluation (honest_running_sum = 0).
+    int honest_running_sum;
+    ef trans_const;         // -cumulative_sum / (N w_N)
 };
 
 struct QuotientSink {
@@ -384,13 +395,19 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     __syncthreads();
     if (wave != 0 || !live) return;
     // running-sum constraints (sphinx eval_permutation_constraints)
-    ef sum_l = sink.sum_cols, sum_n = bb::ef_zero();
+    ef sum_l = sink.sum_cols;
     for (uint32_t j = 1; j < a.parts.n_parts; j++) sum_l = bb::ef_add(sum_l, ef_load(sums + (j * 64u + lane) * 4));
-    for (uint32_t c = 0; c + 1 < a.perm_w; c++) sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
-    const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1)), phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
+    const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1));
     sink.seek(a.k_total - 3);
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));
-    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
+    if (a.honest_running_sum) {
+        sink.assert_zero_ext(bb::ef_scale(a.trans_const, a.zh[i & (qd - 1)]));  // (QuotientArgs: no read of the next row)
+    } else {
+        ef sum_n = bb::ef_zero();
+        for (uint32_t c = 0; c + 1 < a.perm_w; c++) sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
+        const ef phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
+        sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
+    }
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, a.cumulative_sum), is_last));
     ef folded = sink.folded.value();
     for (uint32_t j = 1; j < a.parts.n_parts; j++) folded = bb::ef_add(folded, ef_load(folds + (j * 64u + lane) * 4));
