@@ -166,6 +166,10 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
     t0 = time.perf_counter()
     pr.prove_shard(traces, prep_m, pc, [0] * n_public, ch, num_queries=queries, pow_bits=pow_bits, timings=stages)
     dt = time.perf_counter() - t0 + t_trace
+    import ctypes
+
+    avx512 = ctypes.c_int(0)
+    perm_ns = float(pr.L.cp2_perm_ns(20000, ctypes.byref(avx512)))  # one core, sixteen states at a time
     gpu_names = {"commit_main": "commit_main", "permutation": "permutation", "commit_perm": "commit_perm", "quotient_all": "quotient_all",
                  "commit_quotient": "commit_quotient", "open": "open", "fri_commit": "fri_commit", "pow": "fri_query", "fri_query": "fri_query"}
     stages_s = {"trace_all": t_trace}
@@ -178,6 +182,9 @@ def cpu_baseline(workload: str, chip_shapes, log_rows: int, queries: int, pow_bi
         "cores": cores,
         "kind": "port",
         "seconds": dt,
+        "poseidon2_16_permutations_per_s_per_core": 1e9 / perm_ns,
+        "poseidon2_16_routine": "AVX-512 packed Montgomery (oracle/cpu_port.c: perm16_v_avx512)" if avx512.value else "auto-vectorised loop (no AVX-512 on this host)",
+        "ntt": "row-major radix-2 DIF, cache-blocked: stages in groups whose rows fit L2 (two passes over a 2^20-row matrix)",
         "stages_s": stages_s,
         "sample": f"the WHOLE step (function-chip trace generation from flattened query records, main / permutation / quotient commitments, LogUp rows, quotient, openings, FRI with {queries} queries and {pow_bits} PoW bits) "
                   f"on {'the bench shard itself' if shrink == 0 else 'a shard cut down by 2^' + str(shrink)}: 2^{log_rows - shrink} eval rows of the {workload} machine (a small real execution's rows repeated; memory / byte / entry chips synthetic); oracle/cpu_trace.c + cpu_prover.py + cpu_step.c, OpenMP over "
@@ -291,6 +298,7 @@ def main():
     ap.add_argument("--compile-min-log-rows", type=int, default=0,
                     help="compile the AIR programs and trace generators of chips from 2^this rows up (default 0 = every chip: build() warms the code-object "
                          "cache for the whole fib-mix machine, and a 2^12-row proof is 5.9 ms with every chip compiled against 6.5-7.0; the library's own default is 2^17)")
+    ap.add_argument("--no-second-profile", action="store_true", help="skip the child run under the p3-monty-diffusion protocol profile (ms_per_step_p3_monty_diffusion)")
     ap.add_argument("--no-host-pipeline", action="store_true", help="skip the extra streamed multi-shard measurement (host flatten + upload under the proofs)")
     ap.add_argument("--pipeline-shards", type=int, default=4)
     ap.add_argument("--oversubscribe", action="store_true",
@@ -1030,6 +1038,24 @@ def main():
                 out["cpu_baseline"] = cpu_baseline(args.workload, shapes, log_rows, args.queries, args.pow_bits)
             except Exception as e:  # the baseline is a reported extra, never a reason to lose the line
                 out["cpu_baseline"] = {"error": repr(e)}
+        # the same command under the protocol profile whose width-16 permutation has the shape of the reference's (Plonky3's
+        # Montgomery diffusion matrix, `p3-monty-diffusion`: lurk_amd/profile.py; the default profile's internal layer is knowingly
+        # not sphinx's, csrc/merkle.hip) as a second named field, measured by a child process of this one
+        if (world == 1 and spr == 1 and not distributed and args.profile == "default" and args.workload == "fib-mix" and not args.no_second_profile
+                and os.environ.get("LURKHIP_BENCH_CHILD") != "1"):
+            try:
+                import subprocess
+
+                cmd = [sys.executable, os.path.abspath(__file__), "--profile", "p3-monty-diffusion", "--no-cpu-baseline", "--no-host-pipeline", "--steps", str(args.steps),
+                       "--warmup", str(args.warmup), "--log-rows", str(log_rows), "--queries", str(args.queries), "--pow-bits", str(args.pow_bits), "--lanes", str(args.lanes)]
+                r = subprocess.run(cmd, capture_output=True, text=True, timeout=1200, env=dict(os.environ, LURKHIP_BENCH_CHILD="1"))
+                child = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+                out["ms_per_step_p3_monty_diffusion"] = child["ms_per_step"]
+                out["proof_latency_ms_p3_monty_diffusion"] = child["proof_latency_ms"]
+                out["value_p3_monty_diffusion"] = child["value"]
+            except Exception as e:  # a reported extra, never a reason to lose the line
+                out["ms_per_step_p3_monty_diffusion"] = None
+                out["p3_monty_diffusion_error"] = repr(e)
         print(json.dumps(out), flush=True)
     if distributed:
         dist.destroy_process_group()

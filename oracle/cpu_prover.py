@@ -102,6 +102,8 @@ class CpuProver:
         L.cp2_inv_denoms.argtypes = [C.c_int, C.c_void_p, C.c_void_p]
         L.cp2_reduce.argtypes = [C.c_int, C.c_int, C.c_void_p, C.c_int, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p]
         L.cp2_fri_fold.argtypes = [C.c_int, C.c_void_p, C.c_void_p, C.c_void_p]
+        L.cp2_perm_ns.restype = C.c_double
+        L.cp2_perm_ns.argtypes = [C.c_int, C.c_void_p]
         L.cp2_pow_grind.restype = C.c_uint32
         L.cp2_pow_grind.argtypes = [C.c_void_p, C.c_int, C.c_void_p, C.c_int, C.c_int]
         L.cp2_to_monty.argtypes = [C.c_void_p, C.c_void_p, C.c_size_t]

@@ -585,4 +585,27 @@ uint32_t cp2_pow_grind(const uint32_t* state, int n_pending, const uint32_t* pen
 }
 
 int cp2_n_chips(void) { return cp_n_chips; }
+
+/* nanoseconds per width-16 permutation on the calling core (sixteen states at a time: the rate the tree hashing runs at), and
+ * whether the AVX-512 routine is the one in use: printed beside the baseline so that its quality can be judged. */
+#include <time.h>
+double cp2_perm_ns(int iters, int* avx512) {
+    p16_init();
+    vstate s;
+    for (int i = 0; i < 16; i++)
+        for (int l = 0; l < VL; l++) s[i][l] = (uint32_t)(i * 131 + l * 7919 + 1);
+    struct timespec a, b;
+    perm16_v(s);
+    clock_gettime(CLOCK_MONOTONIC, &a);
+    for (int k = 0; k < iters; k++) perm16_v(s);
+    clock_gettime(CLOCK_MONOTONIC, &b);
+#if defined(__x86_64__)
+    if (avx512) *avx512 = g_have_512 > 0;
+#else
+    if (avx512) *avx512 = 0;
+#endif
+    volatile uint32_t sink = s[3][5];
+    (void)sink;
+    return ((double)(b.tv_sec - a.tv_sec) * 1e9 + (double)(b.tv_nsec - a.tv_nsec)) / ((double)iters * VL);
+}
 const char* cp2_chip_name(int i) { return cp_chips[i].name; }

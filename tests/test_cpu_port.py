@@ -7,7 +7,8 @@ from lurk_amd import synth
 from oracle import binding as ob
 
 
-@pytest.mark.parametrize("log_n,w", [(0, 3), (1, 1), (3, 5), (6, 13), (9, 78), (11, 4)])
+# (11, 700) and (13, 300): rows so wide that the cache-blocked NTT takes its stages in two and three groups (round 5)
+@pytest.mark.parametrize("log_n,w", [(0, 3), (1, 1), (3, 5), (6, 13), (9, 78), (11, 4), (11, 700), (13, 300)])
 def test_cpu_port_lde_equals_checker(log_n, w):
     x = synth.field_elements((1 << log_n, w), seed=100 * log_n + w)
     assert np.array_equal(ob.cpu_port_lde(x, 1), ob.lde(x, 1))

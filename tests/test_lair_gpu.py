@@ -330,6 +330,37 @@ def test_random_programs_vs_oracle(ctx, oracle, seed, const_times_var):
                 assert got.shape == (len(rows_), width) and got.tolist() == rows_, (f["name"], sh.index, size, "compiled")
 
 
+def test_reference_proptest_regression_seeds(ctx, oracle):
+    """The six failure cases the reference's property tests have found and keep re-running
+    (/root/reference/proptest-regressions/gadgets/{unsigned/cmp,unsigned/div_rem,unsigned/field,comm/cmp}.txt), as explicit cases:
+    compare a = b = 0 (twice), divide a = 0 by b = 1 (twice), a field element written as the modulus itself (2013265921 = 0: the
+    boundary canonicalises it, so the case becomes its limb 0 -- beside it the limbs around BABYBEAR_MSB = 0x78 that the
+    field-to-word witness of unsigned/field.rs:7-36 distinguishes), and the big-num comparison of all-zero limbs against a limb
+    written as the modulus (equal after reduction: not less) with its neighbours 1 and p - 1."""
+    P = 2013265921
+
+    def u64(v):
+        return [(v >> (8 * i)) & 0xFF for i in range(8)]
+
+    zero8 = [0] * 8
+    calls = [
+        ["u64_ops", u64(0) + u64(0)],                     # unsigned/cmp.txt: a = 0, b = 0 (both seeds)
+        ["u64_more", u64(0) + u64(1)],                    # unsigned/div_rem.txt: a = 0, b = 1 (both seeds)
+        ["big_lt", zero8 + [0, 0, 0, 0, 0, 0, P % P, 0]],  # comm/cmp.txt: rhs limb 6 = 2013265921 = 0
+        ["big_lt", zero8 + [0, 0, 0, 0, 0, 0, 1, 0]],
+        ["big_lt", zero8 + [0, 0, 0, 0, 0, 0, P - 1, 0]],
+        ["big_lt", [0, 0, 0, 0, 0, 0, P - 1, 0] + zero8],
+        ["big_lt", [P - 1] * 8 + [P - 1] * 8],            # unsigned/field.txt: around the modulus: msb byte 0x78 (p - 1 = 0x78000000) ...
+        ["big_lt", [0x77FFFFFF] * 8 + [0x78000000] * 8],  # ... and just below it (msb byte 0x77)
+        ["big_lt", [0x78000000] * 8 + [0x77FFFFFF] * 8],
+    ]
+    top, q, oq = _compare_all_funcs(ctx, oracle, U64_SRC, calls, lurk_chips=True)
+    assert top.execute_by_name("u64_ops", u64(0) + u64(0), q)[16:] == [0, 1]      # not less, difference is zero
+    assert top.execute_by_name("u64_more", u64(0) + u64(1), q) == [0] * 24         # 0 * 1, 0 / 1, 0 % 1
+    assert top.execute_by_name("big_lt", zero8 + [0, 0, 0, 0, 0, 0, 0, 0], q) == [0]
+    assert top.execute_by_name("big_lt", zero8 + [0, 0, 0, 0, 0, 0, 1, 0], q) == [1]
+
+
 @pytest.mark.parametrize("seed", [1, 2, 3])
 def test_extern_chips_on_random_and_edge_operands(ctx, oracle, seed):
     """The u64 / big-num / hasher chips on 60 random and edge operand pairs per seed (0, 1, 2^64 - 1, equal operands, divisor 1 and
