@@ -431,6 +431,22 @@ int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, ui
  * generates the chips of a shard with rayon: par_iter over chips); everything queued on the context afterwards is ordered
  * behind all of them. */
 int32_t lurkhip_func_trace_run_many(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev, int32_t repr);
+/* Row pitches (ABI 2, round 5).  RowMajorMatrix::new(values, width) (src/lair/trace.rs:133) is dense; a caller that owns the
+ * allocation can do better: the traces of one height as column ranges of ONE device buffer [height][pitch], pitch a multiple of
+ * 32 words, so that every row and every 32-column tile of the coset LDE's first pass starts on a 128-byte line (dense 78- and
+ * 148-word rows straddle lines on every tile: 1.5 x read amplification measured).  lurkhip_trace_group_layout says how the
+ * library would lay out n matrices of the given shapes: matrix i belongs to buffer groups[i] (0 .. *n_groups - 1; a buffer
+ * holds 2^log_heights[i] rows of pitches[i] words) from column col_starts[i] on; a matrix that is not worth padding gets a
+ * buffer of its own with pitches[i] = widths[i].  The _pitched variants of run / run_many / shard_commit take outs_dev[i] =
+ * buffer + col_starts[i] and the pitch in words (>= the trace's width; NULL or 0: dense); words of a row beyond a matrix's
+ * columns are never read or written by the library.  Any layout is valid -- results do not depend on it.  Measured on the
+ * fib-mix step: the first LDE pass does not gain from aligned sources and the trace kernels lose what their
+ * contiguous tile stores had, so lurkhip_trace_group_layout answers "dense" unless LURKHIP_SRC_PADDED=1 is set. */
+int32_t lurkhip_trace_group_layout(uint32_t n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitches,
+                                   uint32_t* col_starts, int32_t* groups, int32_t* n_groups);
+int32_t lurkhip_func_trace_run_pitched(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, uint32_t out_pitch, int32_t repr);
+int32_t lurkhip_func_trace_run_many_pitched(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev,
+                                            const uint32_t* out_pitches, int32_t repr);
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p);
 int32_t lurkhip_mem_trace_shape(const lurkhip_record* r, uint32_t mem_len, uint32_t* n_real, uint32_t* height,
                                 uint32_t* width);
@@ -537,6 +553,10 @@ typedef struct lurkhip_shard lurkhip_shard;
 int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* const* airs, const uint32_t* log_heights,
                              const uint32_t* const* main_traces_dev, const int32_t* prep_indices, int32_t log_blowup,
                              lurkhip_shard** out, uint32_t* root);
+/* the same with main_pitches[i] words between the rows of main_traces_dev[i] (lurkhip_trace_group_layout; NULL: dense) */
+int32_t lurkhip_shard_commit_pitched(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* const* airs, const uint32_t* log_heights,
+                                     const uint32_t* const* main_traces_dev, const uint32_t* main_pitches, const int32_t* prep_indices,
+                                     int32_t log_blowup, lurkhip_shard** out, uint32_t* root);
 int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* shard);
 
 /* LocalProver::prove_shard: permutation traces, quotient, openings and FRI for a committed shard.  The challenger

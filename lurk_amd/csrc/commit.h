@@ -161,7 +161,14 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                     int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr,
                     bool raw = false /* the matrices as given: no interpolation, no coset extension (lurkhip_mmcs_commit) */,
-                    bool padded_groups = false /* the prover's own commitments: height groups in one aligned-pitch buffer (lurkhip_commitment::pitch) */);
+                    bool padded_groups = false /* the prover's own commitments: height groups in one aligned-pitch buffer (lurkhip_commitment::pitch) */,
+                    const uint32_t* src_pitches = nullptr /* words between rows of mats[i] (device matrices only; null: widths[i]) */);
+// Row pitches for the matrices of a commitment-to-be (the prover's own traces): the matrices of one height that the grouped LDE
+// takes become column ranges of ONE buffer [N][pitch], pitch = the group's width rounded up to a 128-byte line, when that costs at
+// most half more memory (transient scratch whose padding is never read); otherwise a matrix keeps its own dense buffer.
+// group[i] = index of the matrix's buffer (0 .. *n_groups - 1), col_start[i] = its first column there, pitch[i] = the buffer's pitch.
+void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitch, uint32_t* col_start, int32_t* group,
+                        int32_t* n_groups);
 int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const std::vector<int>& log_heights,
                    const std::vector<uint32_t>& widths, lurkhip_commitment** out);
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m);

@@ -575,16 +575,58 @@ __global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restri
         out[i] = to_monty ? bb::to_monty(in[i]) : in[i];
 }
 
+// (commit.h) Layout of the prover's own traces ahead of their commitment: see the declaration.  Measured at the end of round 5 and
+// OFF by default: with aligned sources k_lde_in<10,5> takes 1.650 ms per fib-mix proof against 1.603 dense (the line re-fetches of
+// dense 78- / 148-word rows are served by L2: adjacent column chunks of a row run on neighbouring workgroups), while the writers
+// lose -- a 64-row tile of a trace kernel is one contiguous run in a dense matrix and 64 runs ending mid-line in a pitched one
+// (jit_trace_staged 0.94 -> 1.11 ms, jit_perm_rows 2.23 -> 2.28 ms).  LURKHIP_SRC_PADDED=1 turns the aligned layout on (at most
+// half more memory per group), =2 pads every group whatever it costs; read on every call so that a test can switch it.
+void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitch, uint32_t* col_start, int32_t* group,
+                        int32_t* n_groups) {
+    const char* env = getenv("LURKHIP_SRC_PADDED");
+    const int mode = env ? atoi(env) : 0;
+    int32_t ng = 0;
+    std::map<uint32_t, std::vector<int>> by_height;
+    for (int i = 0; i < n; i++) {
+        pitch[i] = widths[i];
+        col_start[i] = 0;
+        group[i] = -1;
+        if (mode && lde_group_takes((int)log_heights[i])) by_height[log_heights[i]].push_back(i);
+    }
+    for (auto it = by_height.rbegin(); it != by_height.rend(); ++it) {
+        uint32_t W = 0;
+        for (int i : it->second) W += widths[i];
+        const uint32_t Wp = (W + 31u) & ~31u;
+        // (a source buffer is scratch of one proof and its padding is never read: up to half more memory is accepted here, where
+        // the LDE buffers, which stay resident until the proof is out, stop at an eighth -- the 2^20 x 78 eval trace gets pitch 96)
+        if ((Wp == W && it->second.size() == 1) || (mode == 1 && (Wp - W) * 2 > W)) continue;
+        uint32_t at = 0;
+        for (int i : it->second) {
+            pitch[i] = Wp;
+            col_start[i] = at;
+            group[i] = ng;
+            at += widths[i];
+        }
+        ng++;
+    }
+    for (int i = 0; i < n; i++)
+        if (group[i] < 0) group[i] = ng++;
+    *n_groups = ng;
+}
+
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
-                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw, bool padded_groups) {
+                    int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw, bool padded_groups,
+                    const uint32_t* src_pitches) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
+    LH_ARG(ctx, !src_pitches || !mats_on_host, "row pitches are for device-resident matrices");
     LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
     LH_ARG(ctx, repr == LURKHIP_REPR_CANONICAL || repr == LURKHIP_REPR_MONTY, "bad repr %d", repr);
     for (int i = 0; i < n_mats; i++) {
         LH_ARG(ctx, mats[i] != nullptr && widths[i] > 0, "matrix %d is empty", i);
         LH_ARG(ctx, (int)log_heights[i] + log_blowup <= bb::TWO_ADICITY, "matrix %d too tall", i);
+        LH_ARG(ctx, !src_pitches || src_pitches[i] >= widths[i], "matrix %d: row pitch below its width", i);
     }
     LH_HIP(ctx, hipSetDevice(ctx->device));
     lurkhip_commitment* c = new lurkhip_commitment();
@@ -700,6 +742,26 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         }
         groups.swap(kept);
     }
+    // Pitched sources (round 5: the prover's traces are column ranges of aligned group buffers, so that the LDE's first pass reads
+    // whole lines): the grouped LDE takes the pitch; a matrix on any other route is first copied to a dense pooled buffer.
+    std::vector<const uint32_t*> dense_mats;
+    if (src_pitches) {
+        bool any = false;
+        for (int i = 0; i < n_mats; i++) any = any || (!grouped[i] && src_pitches[i] != widths[i]);
+        if (any) {
+            dense_mats.assign(mats, mats + n_mats);
+            for (int i = 0; i < n_mats; i++) {
+                if (grouped[i] || src_pitches[i] == widths[i]) continue;
+                void* d = nullptr;
+                TRY_C(pool_alloc(ctx, ((size_t)widths[i] << log_heights[i]) * sizeof(uint32_t), &d));
+                uploads.push_back(d);
+                HIP_C(hipMemcpy2DAsync(d, (size_t)widths[i] * 4, mats[i], (size_t)src_pitches[i] * 4, (size_t)widths[i] * 4, (size_t)1 << log_heights[i],
+                                       hipMemcpyDeviceToDevice, ctx->stream));
+                dense_mats[i] = (const uint32_t*)d;
+            }
+            mats = dense_mats.data();
+        }
+    }
     // Padded group buffers (the prover's own commitments): the LDEs of a group are column ranges of ONE buffer [2N][pitch], pitch =
     // the group's width rounded up to a 128-byte line, when that costs at most an eighth more memory -- the last LDE pass then
     // writes whole lines (a 32-column tile of a 92-word row straddles two lines on every row) and every reader takes the pitch.
@@ -789,14 +851,15 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         const auto on_side = lane.on_side(short_group || (tall_lanes && lane.lanes >= 2 && (gi & 1)), short_group ? 0u : 1u);
         const uint32_t* ev[LDE_MAX_MATS];
         uint32_t* ld[LDE_MAX_MATS];
-        uint32_t gw[LDE_MAX_MATS], gp[LDE_MAX_MATS];
+        uint32_t gw[LDE_MAX_MATS], gp[LDE_MAX_MATS], gs[LDE_MAX_MATS];
         for (size_t m = 0; m < g.idx.size(); m++) {
             ev[m] = mats[g.idx[m]];
             ld[m] = c->lde[g.idx[m]];
             gw[m] = widths[g.idx[m]];
             gp[m] = c->pitch[g.idx[m]];
+            gs[m] = src_pitches ? src_pitches[g.idx[m]] : widths[g.idx[m]];
         }
-        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false, gp));
+        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false, gp, gs));
         for (int i : g.idx) extended[i] = 1;
         if (g.log_n == chain_log_n && (gi + 1 == groups.size() || groups[gi + 1].log_n != chain_log_n)) {  // the chain group's last plan is queued
             TRY_C(hash_stream_of(ctx));

@@ -42,6 +42,17 @@ extern "C" int32_t lurkhip_trace_mem_dev(lurkhip_ctx* ctx, uint32_t len, uint32_
                                          const uint32_t* values_dev, const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr);
 extern "C" int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev,
                                            int32_t repr);
+namespace lurkhip {  // trace.hip: the generators with a row pitch (0: dense)
+int32_t trace_func_dev_pitched(lurkhip_ctx* ctx, const uint32_t* program_dev, const uint32_t* program_host_header, uint32_t n_real, uint32_t height,
+                               uint32_t nonce_start, const uint32_t* args_dev, const uint32_t* outputs_dev, const uint32_t* provides_dev,
+                               const uint32_t* depths_dev, const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr,
+                               uint32_t out_pitch);
+int32_t trace_mem_dev_pitched(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev, const uint32_t* provides_dev,
+                              uint32_t* out_dev, int32_t repr, uint32_t out_pitch);
+int32_t trace_bytes_dev_pitched(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr, uint32_t out_pitch);
+// commit.hip: the layout lurkhip_trace_group_layout reports
+void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitch, uint32_t* col_start, int32_t* group, int32_t* n_groups);
+}  // namespace lurkhip
 
 namespace {
 
@@ -725,20 +736,36 @@ int32_t lurkhip_bytes_trace_prepare(lurkhip_ctx* ctx, const lurkhip_record* r, u
 }
 
 int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, int32_t repr) {
+    return lurkhip_func_trace_run_pitched(ctx, p, out_dev, 0, repr);
+}
+
+int32_t lurkhip_func_trace_run_pitched(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, uint32_t out_pitch, int32_t repr) {
     LH_CHECK_CTX(ctx);
     if (!p || !out_dev) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
     if (p->kind == 1)
-        return lurkhip_trace_mem_dev(ctx, p->mem_len, p->n, p->height, (const uint32_t*)p->dev,
-                                     (const uint32_t*)p->dev + (size_t)p->n * p->mem_len, out_dev, repr);
-    if (p->kind == 2) return lurkhip_trace_bytes_dev(ctx, (const uint32_t*)p->dev, p->is_real ? 1 : 0, out_dev, repr);
+        return lurkhip::trace_mem_dev_pitched(ctx, p->mem_len, p->n, p->height, (const uint32_t*)p->dev,
+                                              (const uint32_t*)p->dev + (size_t)p->n * p->mem_len, out_dev, repr, out_pitch);
+    if (p->kind == 2) return lurkhip::trace_bytes_dev_pitched(ctx, (const uint32_t*)p->dev, p->is_real ? 1 : 0, out_dev, repr, out_pitch);
     const uint8_t* d = (const uint8_t*)p->dev;
-    return lurkhip_trace_func_dev(ctx, (const uint32_t*)(d + p->o_prog), p->header.data(), p->n, p->height, p->start,
-                                  (const uint32_t*)(d + p->o_args), (const uint32_t*)(d + p->o_outs), (const uint32_t*)(d + p->o_prov),
-                                  p->partial ? (const uint32_t*)(d + p->o_dep) : nullptr, d + p->o_meta, (const uint32_t*)(d + p->o_str),
-                                  out_dev, repr);
+    return lurkhip::trace_func_dev_pitched(ctx, (const uint32_t*)(d + p->o_prog), p->header.data(), p->n, p->height, p->start,
+                                           (const uint32_t*)(d + p->o_args), (const uint32_t*)(d + p->o_outs), (const uint32_t*)(d + p->o_prov),
+                                           p->partial ? (const uint32_t*)(d + p->o_dep) : nullptr, d + p->o_meta, (const uint32_t*)(d + p->o_str),
+                                           out_dev, repr, out_pitch);
+}
+
+int32_t lurkhip_trace_group_layout(uint32_t n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitches, uint32_t* col_starts,
+                                   int32_t* groups, int32_t* n_groups) {
+    if (!log_heights || !widths || !pitches || !col_starts || !groups || !n_groups) return LURKHIP_ERR_INVALID_ARG;
+    lurkhip::plan_source_groups((int)n, log_heights, widths, pitches, col_starts, groups, n_groups);
+    return LURKHIP_OK;
 }
 
 int32_t lurkhip_func_trace_run_many(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev, int32_t repr) {
+    return lurkhip_func_trace_run_many_pitched(ctx, n, ps, outs_dev, nullptr, repr);
+}
+
+int32_t lurkhip_func_trace_run_many_pitched(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev,
+                                            const uint32_t* out_pitches, int32_t repr) {
     LH_CHECK_CTX(ctx);
     if (n && (!ps || !outs_dev)) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
     // The chips' trace kernels are independent of one another.  The tall ones (2^13 rows and more) fill the device and stay on the
@@ -763,7 +790,7 @@ int32_t lurkhip_func_trace_run_many(lurkhip_ctx* ctx, uint32_t n, const lurkhip_
         const bool tall = ps[i]->height >= TALL;
         const uint32_t slot = tall ? 0u : k++ % slots;
         const auto on_side = lane.on_side(!tall && slot < (uint32_t)lane.lanes, slot);
-        LH_TRY(lurkhip_func_trace_run(ctx, ps[i], outs_dev[i], repr));
+        LH_TRY(lurkhip_func_trace_run_pitched(ctx, ps[i], outs_dev[i], out_pitches ? out_pitches[i] : 0u, repr));
     }
     return lane.close();
 }

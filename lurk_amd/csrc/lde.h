@@ -19,6 +19,7 @@ bool lde_group_takes(int log_n);
 bool lde_group_enabled();
 int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
                   const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical,
-                  const uint32_t* lde_pitches = nullptr);  // row pitch of ldes[m] in words (null: widths[m]): column ranges of one padded buffer
+                  const uint32_t* lde_pitches = nullptr,   // row pitch of ldes[m] in words (null: widths[m]): column ranges of one padded buffer
+                  const uint32_t* src_pitches = nullptr);  // row pitch of evals[m] in words (null: widths[m])
 
 }  // namespace lurkhip

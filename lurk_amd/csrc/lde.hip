@@ -56,6 +56,7 @@ struct LdeArgs {
     uint32_t* dst[LDE_MAX_MATS];        // 2N x width[m]: block q = coset q, rows in the DIF's (bit-reversed) order
     uint32_t width[LDE_MAX_MATS];
     uint32_t dpitch[LDE_MAX_MATS];      // row pitch of dst[m] in words: width[m], or the pitch of the padded group buffer dst[m] is a column range of
+    uint32_t spitch[LDE_MAX_MATS];      // row pitch of src[m] in words (round 5: the prover's own traces are column ranges of aligned group buffers too)
     uint32_t start[LDE_MAX_MATS];       // virtual column of the matrix's first column (2^32 - 1 for unused slots)
     uint32_t cls[LDE_MAX_MATS];         // shift class of the matrix
     const uint32_t* scale[2][LDE_MAX_CLASSES];  // per coset and class: s_q^k / N, k < N
@@ -380,7 +381,7 @@ __device__ __forceinline__ void stage_descs(const LdeArgs& a, MatDesc* __restric
         MatDesc d;
         d.src = a.src[m];
         d.dst = a.dst[m];
-        d.w = a.width[m];
+        d.w = a.spitch[m];
         d.cls = a.cls[m];
         d.start = a.start[m];
         d.dw = a.dpitch[m];
@@ -909,7 +910,8 @@ bool lde_group_enabled() {
 bool lde_group_takes(int log_n) { return lde_group_enabled() && log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N; }
 
 int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
-                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical, const uint32_t* lde_pitches) {
+                  const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical, const uint32_t* lde_pitches,
+                  const uint32_t* src_pitches) {
     LH_ARG(ctx, n_mats >= 1 && n_mats <= LDE_MAX_MATS && n_cls >= 1 && n_cls <= LDE_MAX_CLASSES, "LDE group shape");
     LH_ARG(ctx, log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N, "LDE group height 2^%d", log_n);
     const NttPlan* plan = nullptr;
@@ -922,6 +924,8 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
         a.dst[m] = ldes[m];
         a.width[m] = widths[m];
         a.dpitch[m] = lde_pitches ? lde_pitches[m] : widths[m];
+        a.spitch[m] = src_pitches ? src_pitches[m] : widths[m];
+        LH_ARG(ctx, a.spitch[m] >= widths[m] && a.dpitch[m] >= widths[m], "LDE group: matrix %d has a row pitch below its width", m);
         a.start[m] = at;
         a.cls[m] = cls[m];
         at += widths[m];
@@ -942,7 +946,7 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     static const int x4_mask = getenv("LURKHIP_LDE_X4") ? atoi(getenv("LURKHIP_LDE_X4")) : 0;
     bool mats_x4 = true;
     for (int m = 0; m < n_mats; m++)
-        mats_x4 = mats_x4 && widths[m] % 4 == 0 && a.dpitch[m] % 4 == 0 && ((uintptr_t)evals[m] & 15u) == 0 && ((uintptr_t)ldes[m] & 15u) == 0;
+        mats_x4 = mats_x4 && widths[m] % 4 == 0 && a.dpitch[m] % 4 == 0 && a.spitch[m] % 4 == 0 && ((uintptr_t)evals[m] & 15u) == 0 && ((uintptr_t)ldes[m] & 15u) == 0;
     a.x4 = (mats_x4 ? 1 : 0) & x4_mask;
     if (log_n <= 10) {
         a.r1 = 0;

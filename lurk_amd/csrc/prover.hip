@@ -51,6 +51,7 @@ struct lurkhip_shard {
     std::vector<int> machine_index;              // position in the caller's chip list
     std::vector<uint32_t> log_n;
     std::vector<const uint32_t*> main;           // natural order, Montgomery, caller-owned
+    std::vector<uint32_t> main_pitch;            // words between rows of main[i] (>= the chip's width: lurkhip_shard_commit_pitched)
     std::vector<int> prep_index;                 // index into the pk's matrices or -1
     lurkhip_commitment* main_commit = nullptr;
     uint32_t root_m[8] = {};
@@ -207,8 +208,17 @@ int32_t lurkhip_pk_free(lurkhip_ctx* ctx, lurkhip_pk* pk) {
 int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* const* airs, const uint32_t* log_heights,
                              const uint32_t* const* main_traces_dev, const int32_t* prep_indices, int32_t log_blowup,
                              lurkhip_shard** out, uint32_t* root) {
+    return lurkhip_shard_commit_pitched(ctx, n_chips, airs, log_heights, main_traces_dev, nullptr, prep_indices, log_blowup, out, root);
+}
+
+int32_t lurkhip_shard_commit_pitched(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* const* airs, const uint32_t* log_heights,
+                                     const uint32_t* const* main_traces_dev, const uint32_t* main_pitches, const int32_t* prep_indices,
+                                     int32_t log_blowup, lurkhip_shard** out, uint32_t* root) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_chips > 0 && airs && log_heights && main_traces_dev && out, "bad shard arguments");
+    if (main_pitches)
+        for (int i = 0; i < n_chips; i++)
+            LH_ARG(ctx, airs[i] && main_pitches[i] >= air_of(airs[i]).width, "chip %d: row pitch %u below its width", i, main_pitches[i]);
     host_mark("shard_commit in");
     auto* sh = new lurkhip_shard();
     sh->log_blowup = log_blowup;
@@ -223,10 +233,11 @@ int32_t lurkhip_shard_commit(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_air* con
         sh->main.push_back(main_traces_dev[i]);
         sh->prep_index.push_back(prep_indices ? prep_indices[i] : -1);
         widths.push_back(air_of(airs[i]).width);
+        sh->main_pitch.push_back(main_pitches ? main_pitches[i] : widths.back());
     }
     span_begin(ctx, "commit_main");
     int32_t s = commit_impl(ctx, n_chips, sh->main.data(), false, sh->log_n.data(), widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
-                            &sh->main_commit, sh->root_m, nullptr, false, /*padded_groups=*/true);
+                            &sh->main_commit, sh->root_m, nullptr, false, /*padded_groups=*/true, sh->main_pitch.data());
     span_end(ctx, "commit_main");
     if (s != LURKHIP_OK) {
         delete sh;
@@ -862,7 +873,6 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     }
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
-        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const lair::ChipAir& air = air_of(sh->airs[i]);
         perm_widths[i] = 4 * air.permutation_width();
         lqds[i] = air.log_quotient_degree();
@@ -870,10 +880,26 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             cleanup();
             return set_error(ctx, LURKHIP_ERR_UNSUPPORTED, "chip %s needs a quotient domain larger than the LDE", air.name.c_str());
         }
+    }
+    // The permutation traces of one height are column ranges of one buffer with a 128-byte-aligned row pitch (plan_source_groups):
+    // the first pass of their LDE then reads whole lines, like the main traces a caller lays out that way.
+    std::vector<uint32_t> perm_pitch(n_chips), perm_col(n_chips);
+    {
+        std::vector<int32_t> grp(n_chips);
+        int32_t n_groups = 0;
+        plan_source_groups(n_chips, sh->log_n.data(), perm_widths.data(), perm_pitch.data(), perm_col.data(), grp.data(), &n_groups);
+        std::vector<uint32_t*> base(n_groups, nullptr);
+        for (int i = 0; i < n_chips; i++) {
+            if (!base[grp[i]]) PTRY(palloc(((size_t)perm_pitch[i] << sh->log_n[i]) * 4, &base[grp[i]]));
+            perm[i] = base[grp[i]] + perm_col[i];
+        }
+    }
+    for (int i = 0; i < n_chips; i++) {
+        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const size_t h = (size_t)1 << sh->log_n[i];
-        PTRY(palloc(h * perm_widths[i] * 4, &perm[i]));
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
-        PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i]));
+        PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i],
+                                    sh->main_pitch[i], perm_pitch[i]));
     }
     PTRY(lane.close());
     // cumulative sums: the last element of each trace, gathered by one launch into one buffer and copied once -- and not waited
@@ -889,7 +915,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             a.n = (uint32_t)std::min(GATHER_EF_MAX, n_chips - at);
             for (uint32_t k = 0; k < a.n; k++) {
                 const int i = at + (int)k;
-                a.src[k] = perm[i] + ((size_t)1 << sh->log_n[i]) * perm_widths[i] - 4;
+                a.src[k] = perm[i] + (((size_t)1 << sh->log_n[i]) - 1) * perm_pitch[i] + perm_widths[i] - 4;
             }
             hipLaunchKernelGGL(k_gather_ef, dim3(1), dim3(GATHER_EF_MAX * 4), 0, ctx->stream, a, cs_dev + (size_t)at * 4);
         }
@@ -901,7 +927,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     uint32_t perm_root_m[8];
     span_begin(ctx, "commit_perm");
     PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
-                     perm_root_m, nullptr, false, /*padded_groups=*/true));
+                     perm_root_m, nullptr, false, /*padded_groups=*/true, perm_pitch.data()));
     span_end(ctx, "commit_perm");
     to_free.push_back(perm_commit);
     for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};

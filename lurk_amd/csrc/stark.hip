@@ -496,8 +496,11 @@ uint32_t air_num_interactions(const lurkhip_air* a) { return a->air.num_interact
 
 int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
                                const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m,
-                               const uint32_t* shared_beta_pows, uint32_t* shared_starts) {
+                               const uint32_t* shared_beta_pows, uint32_t* shared_starts, uint32_t main_pitch, uint32_t out_pitch) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
+    if (main_pitch == 0) main_pitch = a->air.width;
+    if (out_pitch == 0) out_pitch = 4 * a->air.permutation_width();
+    LH_ARG(ctx, main_pitch >= a->air.width && out_pitch >= 4 * a->air.permutation_width() && out_pitch % 4 == 0, "bad row pitch");
     LH_ARG(ctx, height > 0, "empty trace");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     const std::vector<uint32_t*>* dparts = nullptr;
@@ -533,6 +536,8 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         pa.regs_words = lay.regs_words;
         pa.wp = lay.wp;
         pa.staged = lay.staged ? 1 : 0;
+        pa.main_pitch = main_pitch;
+        pa.out_pitch = out_pitch;
         if (jit.perm_rows) {
             void* params[] = {&pa};
             if (hipModuleLaunchKernel(jit.perm_rows, (height + 63) / 64, 1, 1, 64 * lay.parts.n_parts, 1, 1, (unsigned)lay.lds_bytes, ctx->stream,
@@ -544,11 +549,11 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
     span_switch(ctx, "perm_rows", "perm_scan", 2);
-    if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)perm_w * 4, height);
+    if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)out_pitch, height);
     span_end(ctx, "perm_scan", 2);
     pool_release(ctx, pows);
     if (s == LURKHIP_OK && cumulative_sum_m) {
-        LH_HIP(ctx, hipMemcpyAsync(cumulative_sum_m->c, out_dev + ((size_t)height * perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
+        LH_HIP(ctx, hipMemcpyAsync(cumulative_sum_m->c, out_dev + (size_t)(height - 1) * out_pitch + (size_t)(perm_w - 1) * 4, 16, hipMemcpyDeviceToHost, ctx->stream));
         LH_HIP(ctx, stream_wait(ctx));
     }
     return s;

@@ -177,6 +177,9 @@ struct PermArgs {
     uint32_t regs_words;  // all register files
     uint32_t wp;
     int staged;
+    // Round 5: words between rows of the main trace and of the permutation trace (>= w, 4 perm_w).  Inside the prover both are
+    // column ranges of aligned group buffers, so that the LDE's first pass reads whole 128-byte lines.
+    uint32_t main_pitch, out_pitch;
 };
 
 // Workgroup = 64 rows x n_parts waves: wave j runs interaction piece j (its own permutation columns) on the shared tile;
@@ -189,7 +192,7 @@ __device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
     const bool live = i < a.n;
     const uint32_t ic = live ? i : 0u;
     const uint32_t nx = ic + 1 >= a.n ? 0 : ic + 1;
-    const uint32_t* main_l = a.main + (size_t)ic * a.w;
+    const uint32_t* main_l = a.main + (size_t)ic * a.main_pitch;
     uint32_t* tile = lds + a.regs_words;
     uint32_t* idx = tile + (a.staged ? 64u * a.wp : 0u);
     uint32_t* sums = idx + 64;  // [n_parts][64][4]
@@ -197,13 +200,13 @@ __device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
         // interactions only read the local row
         if (wave == 0) idx[lane] = ic;
         __syncthreads();
-        stage_rows(tile, a.wp, a.main, a.w, idx, 64u);
+        stage_rows(tile, a.wp, a.main, a.w, idx, 64u, a.main_pitch);
         __syncthreads();
         main_l = tile + lane * a.wp;
     }
     const uint32_t* prog = a.parts.prog[wave];
-    airvm::Sources src{main_l, a.main + (size_t)nx * a.w, a.prep + (size_t)ic * a.pw, a.prep + (size_t)nx * a.pw, nullptr, {0u, 0u, 0u}};
-    PermSink sink{LogupAccum{a.beta_pows, a.starts}, a.batch, a.out + (size_t)ic * a.perm_w * 4};
+    airvm::Sources src{main_l, a.main + (size_t)nx * a.main_pitch, a.prep + (size_t)ic * a.pw, a.prep + (size_t)nx * a.pw, nullptr, {0u, 0u, 0u}};
+    PermSink sink{LogupAccum{a.beta_pows, a.starts}, a.batch, a.out + (size_t)ic * a.out_pitch};
     sink.col = prog[airp::H_FIRST_COLUMN];
     sink.live = live;
     Runner::run(prog, wave, src, lds + a.parts.reg_off[wave] + lane, sink);

@@ -197,7 +197,7 @@ __global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
 
 // ---- MemChip (memory.rs:30-69): [is_real = 1, ptr = i + 1, last_nonce, last_count, values...] -----------
 __global__ void k_trace_mem(const uint32_t* __restrict__ values, const uint32_t* __restrict__ provides, uint32_t len,
-                            uint32_t n_real, uint32_t height, uint32_t* __restrict__ out, int canonical) {
+                            uint32_t n_real, uint32_t height, uint32_t* __restrict__ out, int canonical, uint32_t pitch) {
     const uint32_t width = 4 + len;
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)height * width) return;
@@ -209,18 +209,18 @@ __global__ void k_trace_mem(const uint32_t* __restrict__ values, const uint32_t*
         else if (c < 4) v = provides[2 * (size_t)row + (c - 2)];
         else v = values[(size_t)row * len + (c - 4)];
     }
-    out[e] = canonical ? v : bb::to_monty(v);
+    out[(size_t)row * pitch + c] = canonical ? v : bb::to_monty(v);
 }
 
 // ---- BytesChip main trace (bytes/trace.rs:75-101): [is_real, 6 x (last_nonce, last_count)] ----------------
 // records: [65536][12] (range_u8, range_u16, less_than, and, xor, or) x (nonce, count); all-zero rows = never required
-__global__ void k_trace_bytes(const uint32_t* __restrict__ records, int is_real, uint32_t* __restrict__ out, int canonical) {
+__global__ void k_trace_bytes(const uint32_t* __restrict__ records, int is_real, uint32_t* __restrict__ out, int canonical, uint32_t pitch) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)65536 * 13) return;
     uint32_t row = (uint32_t)(e / 13), c = (uint32_t)(e - (size_t)row * 13);
     uint32_t v = 0;
     if (is_real) v = c == 0 ? 1u : records[(size_t)row * 12 + (c - 1)];
-    out[e] = canonical ? v : bb::to_monty(v);
+    out[(size_t)row * pitch + c] = canonical ? v : bb::to_monty(v);
 }
 
 // ---- BytesChip preprocessed trace (bytes/trace.rs:49-72): [i1, i2, i1 < i2, and, xor, or] -----------------
@@ -234,12 +234,13 @@ __global__ void k_trace_bytes_preprocessed(uint32_t* __restrict__ out, int canon
 
 }  // namespace
 
-extern "C" {
-
-int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, const uint32_t* program_host_header,
+// The three trace generators with a row pitch (0: the trace's width): the prover's own traces are column ranges of aligned group
+// buffers (lurkhip_trace_group_layout); the dense public entry points below pass 0.
+namespace lurkhip {
+int32_t trace_func_dev_pitched(lurkhip_ctx* ctx, const uint32_t* program_dev, const uint32_t* program_host_header,
                                uint32_t n_real, uint32_t height, uint32_t nonce_start, const uint32_t* args_dev,
                                const uint32_t* outputs_dev, const uint32_t* provides_dev, const uint32_t* depths_dev,
-                               const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr) {
+                               const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr, uint32_t out_pitch) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, program_dev && program_host_header && out_dev, "null argument");
     LH_ARG(ctx, program_host_header[TH_MAGIC] == TRACE_PROGRAM_MAGIC, "bad trace program header");
@@ -249,12 +250,14 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     const uint32_t width = program_host_header[TH_WIDTH];
     const uint32_t max_vars = program_host_header[TH_MAX_VARS];
     LH_ARG(ctx, max_vars <= 4096, "function needs %u variables, more than the kernel's map capacity", max_vars);
+    if (out_pitch == 0) out_pitch = width;
+    LH_ARG(ctx, out_pitch >= width, "row pitch %u below the trace's width %u", out_pitch, width);
     if (height == 0) return LURKHIP_OK;
     const size_t tile_words = (size_t)TBLOCK * width + (((size_t)TBLOCK * width) >> 5) + 1;
     const bool staged = tile_words * 4 <= 64 * 1024;
-    if (!staged) LH_HIP(ctx, hipMemsetAsync(out_dev, 0, (size_t)height * width * sizeof(uint32_t), ctx->stream));
+    if (!staged) LH_HIP(ctx, hipMemset2DAsync(out_dev, (size_t)out_pitch * 4, 0, (size_t)width * 4, height, ctx->stream));
     TraceArgs a{program_dev, args_dev, outputs_dev, provides_dev, depths_dev, (const RowMeta*)meta_dev, stream_dev, out_dev,
-                n_real, height, nonce_start, repr == LURKHIP_REPR_CANONICAL};
+                n_real, height, nonce_start, repr == LURKHIP_REPR_CANONICAL, out_pitch};
     dim3 grid((height + TBLOCK - 1) / TBLOCK), block(TBLOCK);
     lurkhip::span_begin(ctx, "trace_func", 2);
     const size_t lds = staged ? tile_words * 4 : 0;
@@ -283,29 +286,53 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
     return LURKHIP_OK;
 }
 
-int32_t lurkhip_trace_mem_dev(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev,
-                              const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr) {
+int32_t trace_mem_dev_pitched(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev,
+                              const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr, uint32_t out_pitch) {
     LH_CHECK_CTX(ctx);
+    if (out_pitch == 0) out_pitch = 4 + len;
+    LH_ARG(ctx, out_pitch >= 4 + len, "row pitch %u below the trace's width %u", out_pitch, 4 + len);
     LH_ARG(ctx, out_dev && (n_real == 0 || (values_dev && provides_dev)), "null argument");
     LH_ARG(ctx, n_real <= height, "n_real exceeds height");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     size_t total = (size_t)height * (4 + len);
     if (total == 0) return LURKHIP_OK;
     hipLaunchKernelGGL(k_trace_mem, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, values_dev, provides_dev, len,
-                       n_real, height, out_dev, repr == LURKHIP_REPR_CANONICAL);
+                       n_real, height, out_dev, repr == LURKHIP_REPR_CANONICAL, out_pitch);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
 
-int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr) {
+int32_t trace_bytes_dev_pitched(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr, uint32_t out_pitch) {
     LH_CHECK_CTX(ctx);
+    if (out_pitch == 0) out_pitch = 13;
+    LH_ARG(ctx, out_pitch >= 13, "row pitch %u below the byte chip's width", out_pitch);
     LH_ARG(ctx, out_dev && (!is_real || records_dev), "null argument");
     LH_HIP(ctx, hipSetDevice(ctx->device));
     size_t total = (size_t)65536 * 13;
     hipLaunchKernelGGL(k_trace_bytes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, records_dev, is_real, out_dev,
-                       repr == LURKHIP_REPR_CANONICAL);
+                       repr == LURKHIP_REPR_CANONICAL, out_pitch);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
+}
+}  // namespace lurkhip
+
+extern "C" {
+
+int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, const uint32_t* program_host_header,
+                               uint32_t n_real, uint32_t height, uint32_t nonce_start, const uint32_t* args_dev,
+                               const uint32_t* outputs_dev, const uint32_t* provides_dev, const uint32_t* depths_dev,
+                               const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr) {
+    return lurkhip::trace_func_dev_pitched(ctx, program_dev, program_host_header, n_real, height, nonce_start, args_dev, outputs_dev, provides_dev,
+                                           depths_dev, meta_dev, stream_dev, out_dev, repr, 0);
+}
+
+int32_t lurkhip_trace_mem_dev(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev,
+                              const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr) {
+    return lurkhip::trace_mem_dev_pitched(ctx, len, n_real, height, values_dev, provides_dev, out_dev, repr, 0);
+}
+
+int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr) {
+    return lurkhip::trace_bytes_dev_pitched(ctx, records_dev, is_real, out_dev, repr, 0);
 }
 
 int32_t lurkhip_trace_bytes_preprocessed_dev(lurkhip_ctx* ctx, uint32_t* out_dev, int32_t repr) {

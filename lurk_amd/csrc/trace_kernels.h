@@ -38,6 +38,7 @@ struct TraceArgs {
     uint32_t height;
     uint32_t nonce_start;
     int canonical_out;
+    uint32_t out_pitch;        // words between rows of `out` (>= width; round 5: a column range of an aligned group buffer)
 };
 
 // Column col of the lane's row lives at base[e + (e >> sh)], e = e0 + col.  Staged (the workgroup's rows go through LDS and
@@ -326,11 +327,22 @@ __device__ __forceinline__ void trace_kernel_body(const TraceArgs& a, RowFn&& ro
             row_fn(a, row_i, w);
         }
         __syncthreads();
-        uint32_t* __restrict__ dst = a.out + (size_t)row0 * width;
-        for (uint32_t e = threadIdx.x; e < words; e += TBLOCK) dst[e] = tile[e + (e >> 5)];
+        uint32_t* __restrict__ dst = a.out + (size_t)row0 * a.out_pitch;
+        if (a.out_pitch == width) {
+            for (uint32_t e = threadIdx.x; e < words; e += TBLOCK) dst[e] = tile[e + (e >> 5)];
+        } else {
+            // pitched rows: lanes still run along the rows (the row of word e by a float quotient, exact after one correction: e < 2^24)
+            const float inv_w = 1.0f / (float)width;
+            for (uint32_t e = threadIdx.x; e < words; e += TBLOCK) {
+                uint32_t r = (uint32_t)((float)e * inv_w);
+                r += (r + 1u) * width <= e ? 1u : 0u;
+                r -= r * width > e ? 1u : 0u;
+                dst[(size_t)r * a.out_pitch + (e - r * width)] = tile[e + (e >> 5)];
+            }
+        }
     } else {
         if (row_i >= a.height) return;
-        RowWriter w{a.out + (size_t)row_i * width, 1 + n_in + n_out, 0, a.canonical_out != 0};
+        RowWriter w{a.out + (size_t)row_i * a.out_pitch, 1 + n_in + n_out, 0, a.canonical_out != 0};
         row_fn(a, row_i, w);
     }
 }

@@ -220,6 +220,15 @@ class FuncChip:
             raise LairError(s, N.last_error(self.ctx.handle))
 
 
+def _row_pitch(buf) -> int:
+    """Words between the rows of a 2-D device tensor (a column range of an aligned group buffer has stride(0) > its width);
+    0 = dense, for anything else."""
+    if hasattr(buf, "stride") and hasattr(buf, "dim") and buf.dim() == 2:
+        assert buf.stride(1) == 1, "trace matrices are row-major"
+        return int(buf.stride(0))
+    return 0
+
+
 class PreparedFuncTrace:
     """Device-resident inputs of one chip's trace (FuncChip: program + per-row arrays + row stream; MemChip: values +
     provide records; BytesChip: the 65536 x 6 lookup records)."""
@@ -261,7 +270,7 @@ class PreparedFuncTrace:
         """Launches the trace kernel on `ctx` (default: the context the inputs were uploaded on; another context's stream must
         only be used once that upload has completed)."""
         ctx = ctx or self.ctx
-        ctx.check(N.lib.lurkhip_func_trace_run(ctx.handle, self.handle, _addr(out_dev), repr))
+        ctx.check(N.lib.lurkhip_func_trace_run_pitched(ctx.handle, self.handle, _addr(out_dev), _row_pitch(out_dev), repr))
 
     def close(self):
         if self.handle:

@@ -166,6 +166,31 @@ def parse_proof(words: np.ndarray) -> ShardProof:
                       pow_witness, indices, rounds, layers, n_prep, words)
 
 
+def alloc_trace_buffers(shapes, device):
+    """Device tensors for the traces of one shard, shapes = [(height, width)]: the matrices of one height are column ranges of ONE
+    buffer whose row pitch is a multiple of 32 words where the library says that pays (lurkhip_trace_group_layout: the coset
+    LDE's first pass then reads whole 128-byte lines), dense tensors of their own otherwise.  Every trace kernel and the shard
+    commitment take the pitch (tensor.stride(0))."""
+    import torch
+
+    n = len(shapes)
+    if n == 0:
+        return []
+    lh = np.array([h.bit_length() - 1 for h, _ in shapes], dtype=np.uint32)
+    ws = np.array([w for _, w in shapes], dtype=np.uint32)
+    pitch, col = np.zeros(n, dtype=np.uint32), np.zeros(n, dtype=np.uint32)
+    grp, ng = np.zeros(n, dtype=np.int32), np.zeros(1, dtype=np.int32)
+    N.check(N.lib.lurkhip_trace_group_layout(n, _addr(lh), _addr(ws), _addr(pitch), _addr(col), _addr(grp), _addr(ng)))
+    bufs = {}
+    out = []
+    for i, (h, w) in enumerate(shapes):
+        g = int(grp[i])
+        if g not in bufs:
+            bufs[g] = torch.empty((h, int(pitch[i])), dtype=torch.int32, device=device)  # every word a reader touches is written by a trace kernel
+        out.append(bufs[g][:, int(col[i]):int(col[i]) + w])
+    return out
+
+
 class _ShardProver:
     """commit / prove / free of one shard's chip list through the C ABI; shared by the Lair `Machine` and the generic
     `StarkMachine`.  Subclasses provide `self.ctx`, `self.pk`, `self.chips` and `_prep_index(machine_index)`."""
@@ -198,11 +223,13 @@ class _ShardProver:
         airs = (C.c_void_p * n)(*[a.handle.value for _, a, _, _ in traces])
         ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, _, _, t in traces])
         lh = np.array([lg for _, _, lg, _ in traces], dtype=np.uint32)
+        # a trace may be a column range of an aligned group buffer (alloc_trace_buffers): its rows are stride(0) words apart
+        pitches = np.array([t.stride(0) for _, _, _, t in traces], dtype=np.uint32)
         prep_idx = np.array([self._prep_index(mi) for mi, _, _, _ in traces], dtype=np.int32)
         h = C.c_void_p()
         root = np.zeros(8, dtype=np.uint32)
-        self.ctx.check(N.lib.lurkhip_shard_commit(self.ctx.handle, n, C.cast(airs, C.c_void_p), _addr(lh), C.cast(ptrs, C.c_void_p), _addr(prep_idx),
-                                                  LOG_BLOWUP, C.byref(h), _addr(root)))
+        self.ctx.check(N.lib.lurkhip_shard_commit_pitched(self.ctx.handle, n, C.cast(airs, C.c_void_p), _addr(lh), C.cast(ptrs, C.c_void_p), _addr(pitches),
+                                                          _addr(prep_idx), LOG_BLOWUP, C.byref(h), _addr(root)))
         self._included = getattr(self, "_included", {})
         self._included[h.value] = [mi for mi, _, _, _ in traces]
         return h, [int(x) for x in root]
@@ -393,8 +420,10 @@ class Machine(_ShardProver):
                 p = PreparedFuncTrace(MemChip(ictx, arg), shard)
             else:
                 p = PreparedFuncTrace(BytesChip(ictx), shard)
-            t = torch.empty((p.height, p.width), dtype=torch.int32, device=f"cuda:{self.ctx.device}")  # every word is written by the trace kernel
-            out.append((mi, air, p.height.bit_length() - 1, t, p))
+            out.append((mi, air, p.height.bit_length() - 1, None, p))
+        todo = [k for k, e in enumerate(out) if e[4] is not None]
+        for k, t in zip(todo, alloc_trace_buffers([(out[k][4].height, out[k][4].width) for k in todo], f"cuda:{self.ctx.device}")):
+            out[k] = out[k][:3] + (t,) + out[k][4:]
         if input_ctx is None:
             ictx.sync()
             torch.cuda.synchronize()
@@ -446,7 +475,8 @@ class Machine(_ShardProver):
         if self.side_stream and len(todo) > 1:
             ps = (C.c_void_p * len(todo))(*[p.handle for _, p in todo])
             outs = (C.c_void_p * len(todo))(*[_addr(t) for t, _ in todo])
-            self.ctx.check(N.lib.lurkhip_func_trace_run_many(self.ctx.handle, len(todo), ps, outs, N.REPR_MONTY))
+            pitches = np.array([t.stride(0) for t, _ in todo], dtype=np.uint32)
+            self.ctx.check(N.lib.lurkhip_func_trace_run_many_pitched(self.ctx.handle, len(todo), ps, outs, _addr(pitches), N.REPR_MONTY))
         else:
             for t, p in todo:
                 p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
