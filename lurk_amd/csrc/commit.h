@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <utility>
 #include <vector>
 
 #include "ctx.h"
@@ -156,13 +157,16 @@ int32_t get_merkle_params(lurkhip_ctx* ctx, const P16Params** out_dev);
 // the context's protocol profile (created with the "default" preset on first use)
 const lurkhip_protocol_profile& profile_of(lurkhip_ctx* ctx);
 
+using ColumnRuns = std::vector<std::pair<uint32_t, uint32_t>>;
 // ---- commit pipeline entry points shared with the prover (commit.hip)
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                     int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts = nullptr,
                     bool raw = false /* the matrices as given: no interpolation, no coset extension (lurkhip_mmcs_commit) */,
                     bool padded_groups = false /* the prover's own commitments: height groups in one aligned-pitch buffer (lurkhip_commitment::pitch) */,
-                    const uint32_t* src_pitches = nullptr /* words between rows of mats[i] (device matrices only; null: widths[i]) */);
+                    const uint32_t* src_pitches = nullptr /* words between rows of mats[i] (device matrices only; null: widths[i]) */,
+                    const std::vector<ColumnRuns>* live_runs = nullptr /* per matrix: the ascending, disjoint (first column, width) runs outside
+                    which the matrix is identically zero -- those columns' extension is zero-filled instead of computed */);
 // Row pitches for the matrices of a commitment-to-be (the prover's own traces): the matrices of one height that the grouped LDE
 // takes become column ranges of ONE buffer [N][pitch], pitch = the group's width rounded up to a 128-byte line, when that costs at
 // most half more memory (transient scratch whose padding is never read); otherwise a matrix keeps its own dense buffer.

@@ -617,10 +617,11 @@ void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widt
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                     int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw, bool padded_groups,
-                    const uint32_t* src_pitches) {
+                    const uint32_t* src_pitches, const std::vector<ColumnRuns>* live_runs) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
     LH_ARG(ctx, !src_pitches || !mats_on_host, "row pitches are for device-resident matrices");
+    LH_ARG(ctx, !live_runs || (!mats_on_host && (int)live_runs->size() == n_mats), "live column runs: one list per device-resident matrix");
     LH_ARG(ctx, log_blowup >= 0 && log_blowup <= 4, "log_blowup %d outside [0,4]", log_blowup);
     LH_ARG(ctx, repr == LURKHIP_REPR_CANONICAL || repr == LURKHIP_REPR_MONTY, "bad repr %d", repr);
     for (int i = 0; i < n_mats; i++) {
@@ -683,20 +684,45 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     // Round 4: device-resident matrices of one height go through the grouped LDE (lde.hip) as ONE virtual row -- blow-up 2, nobody
     // keeping coefficients, 2^5 .. 2^20 rows.  A group holds up to LDE_MAX_MATS matrices of up to LDE_MAX_CLASSES coset shifts
     // (the quotient chunks of a height: shift w_Q^-c for chunk c), filled in shift order; tallest heights first.
+    // Round 5: an entry of a group is a RUN of columns of a matrix (c0, w) -- the whole matrix unless the caller says which columns
+    // are not identically zero (live_runs: the permutation traces; the other columns of those LDEs are zero-filled below).
     struct GroupPlan {
         int log_n;
         std::vector<int> idx;
+        std::vector<uint32_t> c0, w, ostart;  // ostart: the run's first column in the group's output row (whole matrices side by side)
+        uint32_t out_w = 0;
         std::vector<uint32_t> cls, shift_m;
         const uint32_t* scale[2][LDE_MAX_CLASSES];
     };
+    std::vector<char> sparse(n_mats, 0);  // the matrix is extended run by run: its dead columns are zero-filled
     std::vector<GroupPlan> groups;
     std::vector<char> grouped(n_mats, 0);
+    std::vector<std::pair<int, std::vector<int>>> height_members;  // per height (tallest first): its matrices in group order
     if (!mats_on_host && !raw && log_blowup == 1 && !keep_coeffs) {
         std::map<uint32_t, std::vector<int>> by_height;
-        for (int i = 0; i < n_mats; i++)
-            if (lde_group_takes((int)log_heights[i])) by_height[log_heights[i]].push_back(i);
+        auto shift_of = [&](int i) { return bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN); };
+        for (int i = 0; i < n_mats; i++) {
+            if (!lde_group_takes((int)log_heights[i])) continue;
+            by_height[log_heights[i]].push_back(i);
+            if (!live_runs) continue;
+            // run by run only when the matrix is sure to stay on this route: its two coset tables exist (they are cached: the groups
+            // below find them again), and its runs are well-formed
+            const uint32_t w_big = two_adic_generator_monty((int)log_heights[i] + 1);
+            const uint32_t* t0 = nullptr;
+            const uint32_t* t1 = nullptr;
+            TRY_C(cached_scale_table(ctx, (int)log_heights[i], shift_of(i), &t0));
+            TRY_C(cached_scale_table(ctx, (int)log_heights[i], bb::mul(shift_of(i), w_big), &t1));
+            bool ok = t0 && t1;
+            uint32_t at = 0;
+            for (const auto& r : (*live_runs)[i]) {
+                ok = ok && r.first >= at && r.second > 0 && r.first + r.second <= widths[i];
+                at = r.first + r.second;
+            }
+            uint32_t covered = 0;
+            for (const auto& r : (*live_runs)[i]) covered += r.second;
+            sparse[i] = ok && covered < widths[i] && log_heights[i] > 10;  // (up to 2^10 rows an LDE is one kernel: nothing to leave out)
+        }
         for (auto it = by_height.rbegin(); it != by_height.rend(); ++it) {
-            auto shift_of = [&](int i) { return bb::to_monty(shifts ? shifts[i] % bb::P : bb::GEN); };
             std::vector<uint32_t> order;  // shifts in order of first appearance
             for (int i : it->second)
                 if (std::find(order.begin(), order.end(), shift_of(i)) == order.end()) order.push_back(shift_of(i));
@@ -704,24 +730,51 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
             for (uint32_t sh : order)
                 for (int i : it->second)
                     if (shift_of(i) == sh) sorted.push_back(i);
+            height_members.push_back({(int)it->first, sorted});
             GroupPlan g{};
             g.log_n = (int)it->first;
             auto flush = [&]() {
                 if (!g.idx.empty()) groups.push_back(g);
                 g.idx.clear();
+                g.c0.clear();
+                g.w.clear();
+                g.ostart.clear();
+                g.out_w = 0;
                 g.cls.clear();
                 g.shift_m.clear();
             };
             for (int i : sorted) {
                 const uint32_t sh = shift_of(i);
+                // the matrix's entries: its live runs (the whole matrix unless it is extended run by run), preceded by an entry of
+                // width 0 when its first columns are dead; never more than a launch holds -- the narrowest dead gaps are bridged
+                // (their zeros are transformed like any other column) until the runs fit
+                ColumnRuns runs{{0u, widths[i]}};
+                if (sparse[i]) {
+                    runs = (*live_runs)[i];
+                    if (runs.empty() || runs[0].first != 0) runs.insert(runs.begin(), {0u, 0u});
+                    while (runs.size() > (size_t)LDE_MAX_MATS) {
+                        size_t best = 1;
+                        for (size_t k = 1; k + 1 < runs.size(); k++)
+                            if (runs[k + 1].first - (runs[k].first + runs[k].second) < runs[best + 1].first - (runs[best].first + runs[best].second)) best = k;
+                        runs[best].second = runs[best + 1].first + runs[best + 1].second - runs[best].first;
+                        runs.erase(runs.begin() + (long)best + 1);
+                    }
+                }
                 size_t cl = std::find(g.shift_m.begin(), g.shift_m.end(), sh) - g.shift_m.begin();
-                if (g.idx.size() == (size_t)LDE_MAX_MATS || (cl == g.shift_m.size() && cl == (size_t)LDE_MAX_CLASSES)) {
+                if (g.idx.size() + runs.size() > (size_t)LDE_MAX_MATS || (cl == g.shift_m.size() && cl == (size_t)LDE_MAX_CLASSES)) {
                     flush();
                     cl = 0;
                 }
                 if (cl == g.shift_m.size()) g.shift_m.push_back(sh);
-                g.idx.push_back(i);
-                g.cls.push_back((uint32_t)cl);
+                for (const auto& r : runs) {
+                    g.idx.push_back(i);
+                    g.c0.push_back(r.first);
+                    g.w.push_back(r.second);
+                    g.ostart.push_back(g.out_w + r.first);
+                    g.cls.push_back((uint32_t)cl);
+                }
+                g.out_w += widths[i];
+                if (sparse[i]) grouped[i] = 1;
             }
             flush();
         }
@@ -736,7 +789,11 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                     TRY_C(cached_scale_table(ctx, g.log_n, s_q, &g.scale[q][cl]));
                     ok = g.scale[q][cl] != nullptr;
                 }
-            if (!ok) continue;
+            if (!ok) {
+                for (int i : g.idx)
+                    if (sparse[i]) return fail(set_error(ctx, LURKHIP_ERR_EXEC, "a coset table vanished between two look-ups"));
+                continue;
+            }
             for (int i : g.idx) grouped[i] = 1;
             kept.push_back(g);
         }
@@ -767,19 +824,23 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     // writes whole lines (a 32-column tile of a 92-word row straddles two lines on every row) and every reader takes the pitch.
     static const int pad_mode = getenv("LURKHIP_LDE_PADDED") ? atoi(getenv("LURKHIP_LDE_PADDED")) : 1;
     if (padded_groups && pad_mode)
-        for (const GroupPlan& g : groups) {
+        for (const auto& hm : height_members) {
+            std::vector<int> members;
+            for (int i : hm.second)
+                if (grouped[i]) members.push_back(i);
+            if (members.empty()) continue;
             uint32_t W = 0;
-            for (int i : g.idx) W += widths[i];
+            for (int i : members) W += widths[i];
             const uint32_t Wp = (W + 31u) & ~31u;
-            if (Wp == W && g.idx.size() == 1) continue;
+            if (Wp == W && members.size() == 1) continue;
             if (pad_mode == 1 && (Wp - W) * 8 > W) continue;
             uint32_t* base = nullptr;
-            TRY_C(pool_alloc(ctx, ((size_t)Wp << (g.log_n + log_blowup)) * sizeof(uint32_t), (void**)&base));
+            TRY_C(pool_alloc(ctx, ((size_t)Wp << (hm.first + log_blowup)) * sizeof(uint32_t), (void**)&base));
             c->owned.push_back(base);
             const int gi = (int)c->group_base.size();
             c->group_base.push_back(base);
             uint32_t at = 0;
-            for (int i : g.idx) {
+            for (int i : members) {
                 c->lde[i] = base + at;
                 c->lde_is_view[i] = 1;
                 c->pitch[i] = Wp;
@@ -852,14 +913,18 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
         const uint32_t* ev[LDE_MAX_MATS];
         uint32_t* ld[LDE_MAX_MATS];
         uint32_t gw[LDE_MAX_MATS], gp[LDE_MAX_MATS], gs[LDE_MAX_MATS];
+        uint32_t live_w = 0;
+        for (uint32_t w : g.w) live_w += w;
+        const bool dead_columns = live_w != g.out_w;
         for (size_t m = 0; m < g.idx.size(); m++) {
-            ev[m] = mats[g.idx[m]];
-            ld[m] = c->lde[g.idx[m]];
-            gw[m] = widths[g.idx[m]];
+            ev[m] = mats[g.idx[m]] + g.c0[m];
+            ld[m] = c->lde[g.idx[m]] + g.c0[m];
+            gw[m] = g.w[m];
             gp[m] = c->pitch[g.idx[m]];
             gs[m] = src_pitches ? src_pitches[g.idx[m]] : widths[g.idx[m]];
         }
-        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false, gp, gs));
+        TRY_C(lde_group(ctx, g.log_n, (int)g.idx.size(), ev, gw, ld, g.cls.data(), (int)g.shift_m.size(), g.scale, repr == LURKHIP_REPR_CANONICAL, false, gp, gs,
+                        dead_columns ? g.ostart.data() : nullptr, g.out_w));
         for (int i : g.idx) extended[i] = 1;
         if (g.log_n == chain_log_n && (gi + 1 == groups.size() || groups[gi + 1].log_n != chain_log_n)) {  // the chain group's last plan is queued
             TRY_C(hash_stream_of(ctx));

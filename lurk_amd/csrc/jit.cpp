@@ -31,7 +31,9 @@ namespace {
 // one program (classic 2-word encoding, compact interaction ops included) -> a function template over the sink
 // `batch` > 0: the program is an interaction piece that starts at a batch boundary; every IEND then names its position in the
 // batch and whether it closes it (sink.iend_at<POS, LAST>), so the sink's batch bookkeeping folds away at compile time
-void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, const std::string& name, uint32_t batch) {
+// `skip_dead`: (permutation pieces) a batch's sink operations run only when one of its multiplicities is non-zero on some row of
+// the wave (PermSink::batch_live); the arithmetic that feeds them stays outside the branch (SSA values later batches may share)
+void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, const std::string& name, uint32_t batch, bool skip_dead = false) {
     const uint32_t n = prog[airp::H_N_INSTR];
     const uint32_t* code = prog.data() + prog[airp::H_CODE_OFF];
     const uint32_t* consts = prog.data() + prog[airp::H_CONST_OFF];
@@ -51,10 +53,15 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
     };
     o << "template <class Sink> __device__ __forceinline__ void " << name << "(const airvm::Sources& s, Sink& sink) {\n";
     uint32_t seen_ends = 0;
+    std::ostringstream pending;           // skip_dead: the sink operations of the batch being assembled
+    std::vector<std::string> batch_mults;
+    std::ostringstream& body = o;
     for (uint32_t i = 0; i < n; i++) {
         const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
         const uint32_t op = w0 & 0xffu, dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
         const std::string t = "t" + std::to_string(i);
+        const bool sink_op = op == airp::OP_IBEGIN || op == airp::OP_IVAL || op == airp::OP_IEND || op == airp::OP_IVALS || op == airp::OP_IVALT;
+        std::ostringstream& o = (skip_dead && batch && sink_op) ? pending : body;
         switch (op) {
             case airp::OP_ADD: o << "    const uint32_t " << t << " = bb::add(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
             case airp::OP_SUB: o << "    const uint32_t " << t << " = bb::sub(" << operand(a) << ", " << operand(b) << ");\n"; reg[dst] = t; break;
@@ -69,6 +76,16 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
                     const bool last = pos + 1 == batch;
                     o << "    sink.template iend_at<" << (pos < 2 ? pos : 2u) << ", " << (last ? "true" : "false") << ">(" << operand(a) << ");\n";
                     seen_ends++;
+                    if (skip_dead) {
+                        batch_mults.push_back(operand(a));
+                        if (last) {
+                            body << "    if (sink.batch_live(";
+                            for (size_t k = 0; k < batch_mults.size(); k++) body << (k ? " | " : "") << batch_mults[k];
+                            body << ")) {\n" << pending.str() << "    } else {\n        sink.skip_batch();\n    }\n";
+                            pending.str("");
+                            batch_mults.clear();
+                        }
+                    }
                 } else {
                     o << "    sink.iend(" << operand(a) << ");\n";
                 }
@@ -78,6 +95,7 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
             default: break;  // OP_NOP padding
         }
     }
+    o << pending.str();  // a partial last batch (flushed by the kernel body) runs unconditionally
     o << "}\n";
 }
 
@@ -97,7 +115,7 @@ std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     std::vector<std::string> perm, quot;
     for (size_t j = 0; j < prog.interaction_parts.size(); j++) {
         perm.push_back("perm_piece" + std::to_string(j));
-        emit_function(o, prog.interaction_parts[j], perm.back(), batch);
+        emit_function(o, prog.interaction_parts[j], perm.back(), batch, getenv("LURKHIP_PERM_SKIP_DEAD") == nullptr || atoi(getenv("LURKHIP_PERM_SKIP_DEAD")) != 0);
     }
     for (size_t j = 0; j < prog.constraint_parts.size(); j++) {
         quot.push_back("quot_cons" + std::to_string(j));

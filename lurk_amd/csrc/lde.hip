@@ -58,11 +58,18 @@ struct LdeArgs {
     uint32_t dpitch[LDE_MAX_MATS];      // row pitch of dst[m] in words: width[m], or the pitch of the padded group buffer dst[m] is a column range of
     uint32_t spitch[LDE_MAX_MATS];      // row pitch of src[m] in words (round 5: the prover's own traces are column ranges of aligned group buffers too)
     uint32_t start[LDE_MAX_MATS];       // virtual column of the matrix's first column (2^32 - 1 for unused slots)
+    // Round 5: the LAST pass may walk another virtual row than the first two -- the output layout, in which entry m starts at
+    // ostart[m] and the columns between the end of one entry and the start of the next are identically-zero columns of the
+    // caller's matrices (commit.hip: live_runs; an entry of width 0 marks the start of a matrix whose first columns are dead):
+    // their lanes load nothing, run the butterflies on zeros and store zeros, so that the pass still writes whole lines.
+    // Without dead columns ostart == start and W_out == W.
+    uint32_t ostart[LDE_MAX_MATS];
+    uint32_t W_out;
     uint32_t cls[LDE_MAX_MATS];         // shift class of the matrix
     const uint32_t* scale[2][LDE_MAX_CLASSES];  // per coset and class: s_q^k / N, k < N
     const uint32_t *tw_inv, *tw_fwd;    // N/2 powers of the inverse / forward size-N root
     uint32_t* A;                        // inverse first pass -> fused pass: [slabs][N][32]
-    uint32_t* B;                        // fused pass -> forward last pass: [2 cosets][slabs][N][32]
+    uint32_t* B;                        // fused pass -> forward last pass: [2 cosets][slabs][N][32], then one spare slab (k_lde_out's padding lanes store there)
     uint32_t n_mats, W, n_cls, slabs;
     uint32_t col_base;                  // host side: first virtual column of the launches (a slab batch)
     int log_n, r1, r2;
@@ -372,7 +379,7 @@ struct ColRef {
 struct MatDesc {
     const uint32_t* src;
     uint32_t* dst;
-    uint32_t w, cls, start, dw;
+    uint32_t w, cls, start, dw, cols, ostart;
 };
 constexpr int DESC_WORDS = LDE_MAX_MATS * (int)(sizeof(MatDesc) / 4);
 __device__ __forceinline__ void stage_descs(const LdeArgs& a, MatDesc* __restrict__ descs) {
@@ -385,6 +392,8 @@ __device__ __forceinline__ void stage_descs(const LdeArgs& a, MatDesc* __restric
         d.cls = a.cls[m];
         d.start = a.start[m];
         d.dw = a.dpitch[m];
+        d.cols = a.width[m];
+        d.ostart = a.ostart[m];
         descs[m] = d;
     }
 }
@@ -402,6 +411,29 @@ __device__ __forceinline__ ColRef locate_col(const LdeArgs& a, const MatDesc* __
     r.w = d.w;
     r.dw = d.dw;
     r.cls = d.cls;
+    return r;
+}
+
+// the last pass's view of a column of the OUTPUT layout (LdeArgs::ostart)
+struct OutRef {
+    uint32_t* dst;  // the column's first element in the LDE matrix it belongs to
+    uint32_t dw;
+    uint32_t svc;   // its virtual column in the slabs (live columns only)
+    bool live, valid;
+};
+__device__ __forceinline__ OutRef locate_out(const LdeArgs& a, const MatDesc* __restrict__ descs, uint32_t vc) {
+    uint32_t m = 0;
+#pragma unroll
+    for (int i = 1; i < LDE_MAX_MATS; i++)
+        if (vc >= a.ostart[i]) m = (uint32_t)i;
+    const MatDesc d = descs[m];
+    OutRef r;
+    r.valid = vc < a.W_out;
+    const uint32_t off = r.valid ? vc - d.ostart : 0u;
+    r.live = r.valid && off < d.cols;
+    r.dst = d.dst + off;
+    r.dw = d.dw;
+    r.svc = d.start + off;
     return r;
 }
 
@@ -574,12 +606,22 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
         const uint32_t id = walk.first + it * walk.step;
         const uint32_t blk = id / (uint32_t)a.n_chunks;
         At at;
-        at.vc = (uint32_t)a.col0 + (id - blk * (uint32_t)a.n_chunks) * C + (uint32_t)c;
+        at.vc = (uint32_t)a.col0 + (id - blk * (uint32_t)a.n_chunks) * C + (uint32_t)c;  // a column of the OUTPUT layout
         at.q = blk >> r2;
         at.hi = blk & ((1u << r2) - 1u);
         const uint32_t* __restrict__ in = a.B + ((size_t)at.q * a.slabs << (a.log_n + SLAB_LOG_W)) + ((((size_t)at.hi << LOG_R) | (size_t)s) << SLAB_LOG_W);
-        if constexpr (G::U >= 4 && LDE_SLAB_X4) walk_load_x4<G::U>(dst, in + slab_off(a, at.vc & ~3u), (size_t)G::S << SLAB_LOG_W, c & 3);
-        else walk_load<G::U>(dst, in + slab_off(a, at.vc), (size_t)G::S << SLAB_LOG_W);
+        const OutRef o = locate_out(a, descs, at.vc);
+        if constexpr (G::U >= 4 && LDE_SLAB_X4) {
+            walk_load_x4<G::U>(dst, in + slab_off(a, o.svc & ~3u), (size_t)G::S << SLAB_LOG_W, c & 3);
+        } else {
+            // A dead or padding column is the zero polynomial, and so is every butterfly of it: it loads nothing.  (The zeros are
+            // written BEFORE the live lanes' loads are issued: moves into registers that loads of other lanes are in flight for make
+            // the compiler wait for those loads.  Measured alternatives, all slower: every row of a dead column loaded from one
+            // line of zeros at stride 0 -- a per-lane stride costs the address arithmetic of 32 loads --; the slabs of the last
+            // hand-over laid out by output columns so that this pass loads and stores 1:1 -- the fused pass then scatters.)
+            zero_rows<G::U>(dst);
+            if (o.live) walk_load<G::U>(dst, in + slab_off(a, o.svc), (size_t)G::S << SLAB_LOG_W);
+        }
         return at;
     };
     At nxt = fetch(0, nx);
@@ -593,7 +635,7 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
             for (int j = 0; j < G::U; j++) x[j] = nx[j];
         }
         if (a.dbg & 2) nxt = fetch(it + 1 < walk.count ? it + 1 : it, nx);  // (A/B: the request at the head of the tile)
-        const ColRef ref = locate_col(a, descs, cur.vc);
+        const OutRef ref = locate_out(a, descs, cur.vc);
         const size_t row0 = ((size_t)cur.q << a.log_n) | ((size_t)cur.hi << LOG_R);
         __syncthreads();  // (first tile: the table is complete) every thread has left the previous tile
         if (!(a.dbg & 1)) group1<LOG_R>(x, tw + s);
@@ -617,13 +659,15 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
         }
 #pragma unroll
         for (int j = 0; j < G::U; j++) asm volatile("" : "+v"(nx[j]));  // the next tile's rows have landed BEFORE this tile's stores are issued
+        // a padding column (past the last matrix: the ragged last chunk) stores into the spare slab behind the two cosets': no branch
+        uint32_t* const spare = a.B + ((size_t)2 * a.slabs << (a.log_n + SLAB_LOG_W));
         if (G::U >= 4 && a.x4) {
-            const ColRef rq = locate_col(a, descs, cur.vc & ~3u);
-            uint32_t* __restrict__ out = rq.valid ? rq.dst + (row0 + (size_t)(G::U * s)) * rq.dw : a.B + slab_off(a, cur.vc & ~3u);
+            const OutRef rq = locate_out(a, descs, cur.vc & ~3u);
+            uint32_t* __restrict__ out = rq.valid ? rq.dst + (row0 + (size_t)(G::U * s)) * rq.dw : spare + (cur.vc & 28u);
             walk_store_x4<G::U>(y, out, rq.valid ? (size_t)rq.dw : (size_t)0, c & 3);
         } else {
-            uint32_t* __restrict__ out = ref.valid ? ref.dst + (row0 + (size_t)(G::U * s)) * ref.dw : a.B + slab_off(a, cur.vc);
-            walk_store<G::U>(y, out, ref.valid ? (size_t)ref.dw : (size_t)0);  // a padding column stores into its own slab column: no branch
+            uint32_t* __restrict__ out = ref.valid ? ref.dst + (row0 + (size_t)(G::U * s)) * ref.dw : spare + (cur.vc & 31u);
+            walk_store<G::U>(y, out, ref.valid ? (size_t)ref.dw : (size_t)0);
         }
     }
 }
@@ -883,7 +927,8 @@ int32_t launch_c(lurkhip_ctx* ctx, Kind kind, int log_r, LdeArgs& a, size_t tile
 // rest (16 columns when it fits, else a partly idle 32-column tile).  tiles_per_chunk = row tiles (times cosets for k_out).
 int32_t launch_cols(lurkhip_ctx* ctx, Kind kind, int log_r, LdeArgs a, size_t tiles_per_chunk, int log_c_full) {
     const uint32_t cw = 1u << log_c_full;
-    const uint32_t span = a.W - a.col_base;  // virtual columns [col_base, W): col_base is a multiple of the slab width
+    const uint32_t span = (kind == K_OUT ? a.W_out : a.W) - a.col_base;  // virtual columns [col_base, W): col_base is a multiple of the slab width
+    if (span == 0) return LURKHIP_OK;
     const uint32_t n_full = span / cw, rest = span % cw;
     if (n_full) {
         a.col0 = (int)a.col_base;
@@ -911,7 +956,7 @@ bool lde_group_takes(int log_n) { return lde_group_enabled() && log_n >= LDE_GRO
 
 int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
                   const uint32_t* cls, int n_cls, const uint32_t* const (*scales)[LDE_MAX_CLASSES], bool in_canonical, bool out_canonical, const uint32_t* lde_pitches,
-                  const uint32_t* src_pitches) {
+                  const uint32_t* src_pitches, const uint32_t* out_starts, uint32_t out_width) {
     LH_ARG(ctx, n_mats >= 1 && n_mats <= LDE_MAX_MATS && n_cls >= 1 && n_cls <= LDE_MAX_CLASSES, "LDE group shape");
     LH_ARG(ctx, log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N, "LDE group height 2^%d", log_n);
     const NttPlan* plan = nullptr;
@@ -927,11 +972,17 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
         a.spitch[m] = src_pitches ? src_pitches[m] : widths[m];
         LH_ARG(ctx, a.spitch[m] >= widths[m] && a.dpitch[m] >= widths[m], "LDE group: matrix %d has a row pitch below its width", m);
         a.start[m] = at;
+        a.ostart[m] = out_starts ? out_starts[m] : at;
         a.cls[m] = cls[m];
+        LH_ARG(ctx, m == 0 || a.ostart[m] >= a.ostart[m - 1] + widths[m - 1], "LDE group: output columns of entry %d overlap the previous entry's", m);
         at += widths[m];
     }
-    for (int m = n_mats; m < LDE_MAX_MATS; m++) a.start[m] = 0xffffffffu;
+    for (int m = n_mats; m < LDE_MAX_MATS; m++) a.start[m] = a.ostart[m] = 0xffffffffu;
     a.W = at;
+    a.W_out = out_starts ? out_width : at;
+    const bool dead_columns = a.W_out != a.W;
+    LH_ARG(ctx, a.W_out >= a.W && (n_mats == 0 || a.W_out >= a.ostart[n_mats - 1] + widths[n_mats - 1]), "LDE group: output width below its entries");
+    LH_ARG(ctx, !dead_columns || log_n > 10, "LDE group: dead columns are for the three-pass shapes");
     a.n_cls = (uint32_t)n_cls;
     for (int q = 0; q < 2; q++)
         for (int c = 0; c < n_cls; c++) a.scale[q][c] = scales[q][c];
@@ -947,7 +998,7 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     bool mats_x4 = true;
     for (int m = 0; m < n_mats; m++)
         mats_x4 = mats_x4 && widths[m] % 4 == 0 && a.dpitch[m] % 4 == 0 && a.spitch[m] % 4 == 0 && ((uintptr_t)evals[m] & 15u) == 0 && ((uintptr_t)ldes[m] & 15u) == 0;
-    a.x4 = (mats_x4 ? 1 : 0) & x4_mask;
+    a.x4 = dead_columns ? 0 : ((mats_x4 ? 1 : 0) & x4_mask);
     if (log_n <= 10) {
         a.r1 = 0;
         a.r2 = log_n;
@@ -958,8 +1009,8 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     a.r2 = log_n - a.r1;
     const size_t slab_words = (size_t)a.slabs << (log_n + SLAB_LOG_W);
     void *A = nullptr, *B = nullptr;
-    LH_TRY(pool_alloc(ctx, slab_words * 4, &A));
-    int32_t st = pool_alloc(ctx, slab_words * 8, &B);
+    LH_TRY(pool_alloc(ctx, std::max<size_t>(slab_words, 8) * 4, &A));
+    int32_t st = pool_alloc(ctx, slab_words * 8 + ((size_t)4 << (log_n + SLAB_LOG_W)), &B);  // two cosets + the spare slab of k_lde_out's padding lanes
     if (st != LURKHIP_OK) {
         pool_release(ctx, A);
         return st;
@@ -973,11 +1024,12 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     // (3 k N 128 bytes) may stay in the 256 MiB Infinity Cache between the kernel that writes them and the one that reads them
     static const int slab_batch = getenv("LURKHIP_LDE_SLAB_BATCH") ? atoi(getenv("LURKHIP_LDE_SLAB_BATCH")) : 0;
     const uint32_t W_all = a.W;
-    const uint32_t step = slab_batch > 0 ? (uint32_t)slab_batch << SLAB_LOG_W : W_all;
-    for (uint32_t c0 = 0; c0 < W_all && st == LURKHIP_OK; c0 += step) {
+    const uint32_t step = (slab_batch > 0 && !dead_columns) ? (uint32_t)slab_batch << SLAB_LOG_W : std::max(W_all, 1u);
+    for (uint32_t c0 = 0; c0 < std::max(W_all, 1u) && st == LURKHIP_OK; c0 += step) {
         LdeArgs b = a;
         b.col_base = c0;
         b.W = std::min(W_all, c0 + step);
+        if (!dead_columns) b.W_out = b.W;
         st = launch_cols(ctx, K_IN, a.r1, b, (size_t)1 << a.r2, io_c);
         // the fused pass keeps two workgroups on a CU: 2^10-row tiles are 16 columns wide
         static const int mid_log_c = getenv("LURKHIP_LDE_MID_LOG_C") ? std::max(4, std::min(5, atoi(getenv("LURKHIP_LDE_MID_LOG_C")))) : 5;  // (A/B hook)

@@ -871,6 +871,18 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         for (int i = 0; i < n_chips; i++) tallest = std::max(tallest, sh->log_n[i]);
         lane.want = tallest >= SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : lurkhip_ctx::N_SIDE;
     }
+    // Round 5: which batch columns does anybody compute?  (stark_kernels.h: PermSink -- a compiled permutation kernel skips a batch
+    // whose multiplicities are zero on all 64 rows of a wave; a column no wave marks is identically zero.)  One word per column,
+    // zeroed before the lanes fork, read back with the cumulative sums: the LDE of the permutation traces then leaves the dead
+    // columns out (commit_impl: live_runs) -- 42 % of the permutation cells of a real `(fib N)` shard.  LURKHIP_PERM_SPARSE_LDE=0: off.
+    static const bool sparse_lde = getenv("LURKHIP_PERM_SPARSE_LDE") == nullptr || atoi(getenv("LURKHIP_PERM_SPARSE_LDE")) != 0;
+    uint32_t* live_dev = nullptr;
+    std::vector<size_t> live_off(n_chips + 1, 0);
+    for (int i = 0; i < n_chips; i++) live_off[i + 1] = live_off[i] + air_of(sh->airs[i]).permutation_width();
+    if (sparse_lde) {
+        PTRY(palloc(live_off[n_chips] * 4, &live_dev));
+        PHIP(hipMemsetAsync(live_dev, 0, live_off[n_chips] * 4, ctx->stream));
+    }
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
         const lair::ChipAir& air = air_of(sh->airs[i]);
@@ -899,7 +911,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
         PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i],
-                                    sh->main_pitch[i], perm_pitch[i]));
+                                    sh->main_pitch[i], perm_pitch[i], live_dev ? live_dev + live_off[i] : nullptr));
     }
     PTRY(lane.close());
     // cumulative sums: the last element of each trace, gathered by one launch into one buffer and copied once -- and not waited
@@ -909,7 +921,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     {
         uint32_t* cs_dev = nullptr;
         PTRY(palloc((size_t)n_chips * 16, &cs_dev));
-        PTRY(host_staging(ctx, (size_t)n_chips * 16, (void**)&cs_host));
+        PTRY(host_staging(ctx, (size_t)n_chips * 16 + live_off[n_chips] * 4, (void**)&cs_host));
         for (int at = 0; at < n_chips; at += GATHER_EF_MAX) {
             GatherEfArgs a{};
             a.n = (uint32_t)std::min(GATHER_EF_MAX, n_chips - at);
@@ -922,12 +934,30 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         PHIP(hipGetLastError());
         PHIP(hipMemcpyAsync(cs_host, cs_dev, (size_t)n_chips * 16, hipMemcpyDeviceToHost, ctx->stream));
     }
+    // the live batch columns as runs of base columns (the running-sum column is always live); this is the one place the proof
+    // waits for the device between the main root and the permutation root
+    std::vector<ColumnRuns> live_runs;
+    if (live_dev) {
+        const uint32_t* live_host = cs_host + (size_t)n_chips * 4;
+        PHIP(hipMemcpyAsync((void*)live_host, live_dev, live_off[n_chips] * 4, hipMemcpyDeviceToHost, ctx->stream));
+        PHIP(stream_wait(ctx));
+        live_runs.resize(n_chips);
+        for (int i = 0; i < n_chips; i++) {
+            const uint32_t pw = perm_widths[i] / 4;
+            ColumnRuns& runs = live_runs[i];
+            for (uint32_t c = 0; c < pw; c++) {
+                if (c + 1 < pw && !live_host[live_off[i] + c]) continue;
+                if (!runs.empty() && runs.back().first + runs.back().second == 4 * c) runs.back().second += 4;
+                else runs.push_back({4 * c, 4u});
+            }
+        }
+    }
     span_end(ctx, "permutation");
     lurkhip_commitment* perm_commit = nullptr;
     uint32_t perm_root_m[8];
     span_begin(ctx, "commit_perm");
     PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
-                     perm_root_m, nullptr, false, /*padded_groups=*/true, perm_pitch.data()));
+                     perm_root_m, nullptr, false, /*padded_groups=*/true, perm_pitch.data(), live_dev ? &live_runs : nullptr));
     span_end(ctx, "commit_perm");
     to_free.push_back(perm_commit);
     for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};

@@ -35,7 +35,9 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
                                const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m,
                                const uint32_t* shared_beta_pows = nullptr, uint32_t* shared_starts = nullptr,
                                uint32_t main_pitch = 0 /* words between rows of main_dev; 0: the chip's width */,
-                               uint32_t out_pitch = 0 /* words between rows of out_dev; 0: 4 x permutation width */);
+                               uint32_t out_pitch = 0 /* words between rows of out_dev; 0: 4 x permutation width */,
+                               uint32_t* col_live = nullptr /* device, [permutation width - 1], zeroed by the caller: receives a 1 per batch column
+                               some wave computed; a column left at 0 is identically zero (stark_kernels.h: PermSink) */);
 
 uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd);  // stark.hip: written on the current stream at first use
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,

@@ -496,7 +496,7 @@ uint32_t air_num_interactions(const lurkhip_air* a) { return a->air.num_interact
 
 int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
                                const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m,
-                               const uint32_t* shared_beta_pows, uint32_t* shared_starts, uint32_t main_pitch, uint32_t out_pitch) {
+                               const uint32_t* shared_beta_pows, uint32_t* shared_starts, uint32_t main_pitch, uint32_t out_pitch, uint32_t* col_live) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
     if (main_pitch == 0) main_pitch = a->air.width;
     if (out_pitch == 0) out_pitch = 4 * a->air.permutation_width();
@@ -538,6 +538,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         pa.staged = lay.staged ? 1 : 0;
         pa.main_pitch = main_pitch;
         pa.out_pitch = out_pitch;
+        pa.col_live = col_live;
         if (jit.perm_rows) {
             void* params[] = {&pa};
             if (hipModuleLaunchKernel(jit.perm_rows, (height + 63) / 64, 1, 1, 64 * lay.parts.n_parts, 1, 1, (unsigned)lay.lds_bytes, ctx->stream,

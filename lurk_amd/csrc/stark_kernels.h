@@ -134,6 +134,20 @@ struct PermSink {
     uint32_t col = 0;
     ef row_sum = bb::ef_zero();
     bool live = true;  // lanes past the last row run along (workgroup barriers) and store nothing
+    // Round 5: dead batches.  A row of a Lair function takes one branch and every branch has its own lookups: most interactions
+    // of a chip have multiplicity zero on most rows, and those of branches a shard never takes on every row (a real `(fib N)`:
+    // 52 of eval_builtin_expr's 78 batch columns, tests/golden/fib_shape.json "lookup_sparsity").  A batch all of whose
+    // multiplicities are zero on all 64 rows of the wave has the entry 0 whatever its denominators are: compiled pieces test that
+    // first (batch_live, wave-uniform) and skip the fingerprints, the products and the inverse.  `col_live` (optional) receives a 1
+    // per column some wave computed: a column nobody marks is identically zero and its LDE need not be computed (prover.hip).
+    uint32_t* col_live = nullptr;
+    bool marker = false;  // lane 0 of the wave
+    __device__ __forceinline__ bool batch_live(uint32_t mults_or) const { return __builtin_amdgcn_ballot_w64(mults_or != 0u) != 0ull; }
+    __device__ __forceinline__ void skip_batch() {
+        uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
+        if (live) *dst = make_uint4(0u, 0u, 0u, 0u);
+        col++;
+    }
     __device__ __forceinline__ void assert_zero(uint32_t) {}
     __device__ __forceinline__ void ibegin(uint32_t, bool send, uint32_t interaction) { acc.begin(interaction, send); }
     __device__ __forceinline__ void ival(uint32_t) {}  // compact pieces carry no plain IVAL
@@ -143,6 +157,7 @@ struct PermSink {
         ef v = acc.in_batch == 1 ? bb::ef_scale(sink_ef_inv(acc.den), acc.m_first) : sink_ef_mul(acc.num, sink_ef_inv(acc.den));
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
         if (live) *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
+        if (col_live && marker) col_live[col] = 1u;
         row_sum = bb::ef_add(row_sum, v);
         col++;
         acc.in_batch = 0;
@@ -180,6 +195,7 @@ struct PermArgs {
     // Round 5: words between rows of the main trace and of the permutation trace (>= w, 4 perm_w).  Inside the prover both are
     // column ranges of aligned group buffers, so that the LDE's first pass reads whole 128-byte lines.
     uint32_t main_pitch, out_pitch;
+    uint32_t* col_live;  // [perm_w - 1] or null: 1 = some wave computed the batch column (PermSink)
 };
 
 // Workgroup = 64 rows x n_parts waves: wave j runs interaction piece j (its own permutation columns) on the shared tile;
@@ -209,6 +225,8 @@ __device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
     PermSink sink{LogupAccum{a.beta_pows, a.starts}, a.batch, a.out + (size_t)ic * a.out_pitch};
     sink.col = prog[airp::H_FIRST_COLUMN];
     sink.live = live;
+    sink.col_live = a.col_live;
+    sink.marker = lane == 0u;
     Runner::run(prog, wave, src, lds + a.parts.reg_off[wave] + lane, sink);
     if (sink.acc.in_batch) sink.flush();
     if (a.parts.n_parts > 1) {
