@@ -241,7 +241,11 @@ def measured_shape(workload: str):
     r = shape["fib"][n]
     return {"source": "tests/golden/fib_shape.json", "fib_n": int(n), "eval_rows": r["rows"]["eval"], "main_columns_per_eval_row": r["main_columns_per_eval_row"],
             "func_permutation_columns_per_eval_row": r["func_permutation_columns_per_eval_row"], "widths_reproduced": shape["widths_reproduced"],
-            "per_fib_level": shape["fib_per_level"]}
+            "per_fib_level": shape["fib_per_level"],
+            # (round 5) the prover skips permutation batches no row of a wave uses and leaves identically-zero permutation columns out
+            # of the LDE: the share of such cells on the real machine (the reference's functions, tools/measure_lookup_sparsity.py) --
+            # the stand-in is dialled to it and held at or below it (tests/test_mix_programs.py)
+            "dead_permutation_cell_share_real": shape.get("lookup_sparsity", {}).get("dead_cell_share_at_2^20")}
 
 
 def build_workload(name: str, world: int, log_rows: int):

@@ -470,21 +470,35 @@ def _fit_once(fname, target, emit, n_branches, live, others_src, fixed_live=Fals
     #    loads of it (a load of an L-lane cell is one lookup like a store but L + 3 columns instead of 4 and no constraint more: the
     #    way the real functions spend their columns), what remains with products (one column and one constraint each); the other
     #    lookups are stores spread over the other branches, byte-pair range checks (3 columns) where 4 do not fit
+    # (round 5) `dead_quota`: how many of the function's lookups sit in branches a run never takes -- measured on the real function
+    # (tests/golden/fib_shape.json "lookup_sparsity": sends - live sends): the filler's lookups go to never-taken branches up to
+    # that number and to live ones beyond it, so that the stand-in's permutation trace has the real one's share of identically-zero
+    # columns (the prover leaves those out of the LDE); None: spread by room alone
+    dead_quota = target.get("dead_lookups")
+    is_dead = [not b.live for b in spec.branches]
+
     def place(pad_k, n_loads, l0):
         left = list(rooms)
         for b in spec.branches:
             b.cells, b.loads, b.ranges, b.muls, b.pinned = [], 0, 0, 0, False
         todo = need
+        placed_dead = 0
         if n_loads >= 0 and need >= 1 + n_loads and left[pad_k] >= 4 + n_loads * (l0 + 3):
             bk = spec.branches[pad_k]
             bk.cells, bk.loads, bk.pinned = [l0], n_loads, n_loads > 0
             left[pad_k] -= 4 + n_loads * (l0 + 3)
             todo -= 1 + n_loads
+            placed_dead += (1 + n_loads) if is_dead[pad_k] else 0
         order = [i for i in range(n_branches) if i != pad_k]
         for _ in range(todo):
-            k = max(order, key=lambda i: (left[i], -i)) if order else pad_k
+            cand = order
+            if dead_quota is not None:
+                want_dead = placed_dead < dead_quota
+                cand = [i for i in order if is_dead[i] == want_dead and left[i] >= 3] or order
+            k = max(cand, key=lambda i: (left[i], -i)) if cand else pad_k
             if left[k] < 3 and left[pad_k] >= 3:
                 k = pad_k
+            placed_dead += 1 if is_dead[k] else 0
             if left[k] >= 4:
                 spec.branches[k].cells.append(4)
                 left[k] -= 4
@@ -502,8 +516,14 @@ def _fit_once(fname, target, emit, n_branches, live, others_src, fixed_live=Fals
         left = list(rooms)
         for b in spec.branches:
             b.cells, b.loads, b.ranges, b.muls, b.pinned = [], 0, 0, 0, False
+        placed_dead = 0
         for _ in range(need):
-            k = max(range(n_branches), key=lambda i: (left[i], -i))
+            cand = list(range(n_branches))
+            if dead_quota is not None:
+                want_dead = placed_dead < dead_quota
+                cand = [i for i in cand if is_dead[i] == want_dead and left[i] >= 3] or cand
+            k = max(cand, key=lambda i: (left[i], -i))
+            placed_dead += 1 if is_dead[k] else 0
             if left[k] >= 4:
                 spec.branches[k].cells.append(4)
                 left[k] -= 4
@@ -590,13 +610,23 @@ def _fit(fname, target, emit, n_branches, live, others_src, fixed_live=False, ca
 _PLAN_CACHE = {}
 
 
-def _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted):
-    """Specs of every shaped function of a machine (independent of the row counts: they only appear as constants)."""
-    key = (tuple(funcs), tuple(walkers), u64_owner, tuple(sorted(live_wanted.items())), tuple(sorted((k, tuple(v)) for k, v in pre.items())),
+# The stand-in's `eval` cannot hold the real function's share of live lookups in its live branches (their columns go to the recursive
+# call): it ends up with 6 dead permutation columns where the real one has 2, at the tallest height of the machine.  eval_builtin_expr,
+# half as tall, gives the difference back twice over, so that the machine's share of identically-zero permutation cells stays at or
+# below the real machine's (tests/test_mix_programs.py holds it there; tools/measure_lookup_sparsity.py prints both tables).
+DEAD_COLUMN_ADJUST = {"eval_builtin_expr": -6}
+
+
+def _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted, sparsity=False):
+    """Specs of every shaped function of a machine (independent of the row counts: they only appear as constants).
+    `sparsity`: dial the walkers' live branches and the share of lookups in never-taken branches to the measured ones of a real
+    `(fib N)` (fib_shape.json "lookup_sparsity")."""
+    key = (sparsity, tuple(funcs), tuple(walkers), u64_owner, tuple(sorted(live_wanted.items())), tuple(sorted((k, tuple(v)) for k, v in pre.items())),
            tuple(sorted((k, tuple(sorted((b, tuple(x)) for b, x in v.items()))) for k, v in phase_pre.items())))
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     chips = load_shape()["chips"]
+    sparse = load_shape().get("lookup_sparsity", {}).get("real", {}) if sparsity else {}
     have = set(funcs)
     fixed_src = "".join(FIXED[f] for f in funcs if f in FIXED)
     specs, fits = {}, {}
@@ -619,15 +649,23 @@ def _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted):
             assert nb >= 1, f"{f}: a walker needs two selectors"
             want = live_wanted.get(f)
             live = want or min(4, max(1, nb - 1))
+            if f in sparse:
+                t = dict(t)
+                # (the real function's dead interactions do not all pair up into dead columns -- 58 dead lookups of eval_builtin_expr
+                # make 52 dead columns --, the stand-in's branch-by-branch ones do: the quota is the number of dead COLUMNS, which
+                # leaves the stand-in with a few live interactions more than the real function has)
+                t["dead_lookups"] = max(0, sparse[f]["dead_columns"] + DEAD_COLUMN_ADJUST.get(f, 0))
+                if want is None:  # the selectors a real run takes, less the bottom frame's return
+                    want = live = max(1, min(nb, sparse[f]["live_selectors"] - 1))
             emit = lambda s, f=f, base=base: emit_walker(f, s, pre[f], phase_pre[f], base)
             specs[f], got = _fit(f, t, emit, nb, min(live, nb), others, fixed_live=want is not None)
             specs[f].next_walker = nxt
-        fits[f] = {"got": got, "target": {k: t[k] for k in got}}
+        fits[f] = {"got": got, "target": {k: chips[f][k] for k in got}}
     _PLAN_CACHE[key] = (specs, fits)
     return specs, fits
 
 
-def build_mix(name, funcs, counts, u64_owner=None, u64_every=4, fresh=None):
+def build_mix(name, funcs, counts, u64_owner=None, u64_every=4, fresh=None, sparsity=False):
     """funcs: function names in machine order (a subset of LURK_FUNC_ORDER, `lurk_main` first); counts: walker name -> rows.
     Walkers are chained: `lurk_main` starts the first one, each walker's bottom frame starts the next.  The u64 gadgets are
     called from branch 0 of `u64_owner`, which has `u64_every` live branches."""
@@ -668,7 +706,7 @@ def build_mix(name, funcs, counts, u64_owner=None, u64_every=4, fresh=None):
             lines.append(call)
         assert live_wanted.get(u64_owner, R) == R, "the u64 owner's live branches are already dialled otherwise"
         live_wanted[u64_owner] = R
-    specs, fits = _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted)
+    specs, fits = _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted, sparsity)
     if u64_ops:
         R = specs[u64_owner].live
         steps = counts[u64_owner] - 1  # rows of the owner that are not its bottom frame; phases run 0, 1, .., R - 1, 0, ..
@@ -722,7 +760,7 @@ def fib_mix(eval_rows: int) -> Mix:
     """The chips of a real `(fib N)` run at the measured shape (see the module docstring): `apply` owns the u64 gadgets and calls
     them in branch 0 of 4 live branches (4 apply rows per fib level, one u64_add / u64_sub / u64_lessthan each; u64_add and u64_sub
     store one 8-lane cell per row), env_lookup stores one 5-lane cell per row."""
-    return build_mix("fib-mix", FIB_FUNCS, fib_counts(eval_rows), u64_owner="apply", u64_every=4, fresh=FIB_FRESH)
+    return build_mix("fib-mix", FIB_FUNCS, fib_counts(eval_rows), u64_owner="apply", u64_every=4, fresh=FIB_FRESH, sparsity=True)
 
 
 # lurk-mix (BASELINE config 5, `demo/mastermind.lurk`): every function of the Lurk toplevel.  Heights: the rows the REAL evaluator

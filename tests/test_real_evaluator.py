@@ -163,3 +163,18 @@ def test_mastermind_script_holds_under_the_real_evaluator(real):
     broken = lr.demo_script("mastermind.lurk").replace("!(assert-eq '(t 3 2) (maybe-remove 1 '(1 2 3)))", "!(assert-eq '(t 3 3) (maybe-remove 1 '(1 2 3)))", 1)
     out2, _, _ = real.run(lr.fold_repl_script(broken))
     assert list(out2)[0] == lr.enums()["Tag"]["Key"]  # :assertion-failed
+
+
+def test_committed_lookup_sparsity_is_a_fresh_measurement():
+    """tests/golden/fib_shape.json "lookup_sparsity" (round 5: which interactions of the real functions are ever real on a `(fib N)`
+    run, which permutation columns never are -- what the fib-mix stand-in's branches are dialled to and what the prover's dead-batch
+    skip and sparse permutation LDE are worth on a real machine) is what tools/measure_lookup_sparsity.py measures today."""
+    import measure_lookup_sparsity as msp
+
+    with open(os.path.join(ROOT, "tests", "golden", "fib_shape.json")) as f:
+        sp = json.load(f)["lookup_sparsity"]
+    got = msp.real_fib(sp["fib_n"])
+    assert {c: s for c, (s, _) in got.items()} == sp["real"]
+    # the liveness pattern does not depend on N once every branch of the recursion has been taken
+    again = msp.real_fib(sp["fib_n"] + 5)
+    assert {c: s for c, (s, _) in again.items()} == sp["real"]

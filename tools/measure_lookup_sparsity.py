@@ -39,9 +39,12 @@ def chip_liveness(air, rows, prep=None, public=()):
     return live or []
 
 
-def summarise(live, batch=2):
+def summarise(live, batch=2, sel_live=None):
     cols = [(live[i:i + batch]) for i in range(0, len(live), batch)]
-    return {"interactions": len(live), "live_interactions": sum(live), "columns": len(cols), "dead_columns": sum(1 for c in cols if not any(c))}
+    out = {"interactions": len(live), "live_interactions": sum(live), "columns": len(cols), "dead_columns": sum(1 for c in cols if not any(c))}
+    if sel_live is not None:
+        out["selectors"], out["live_selectors"] = len(sel_live), sum(sel_live)
+    return out
 
 
 def oracle_machine(otop, q, witness, entry, pv):
@@ -54,7 +57,9 @@ def oracle_machine(otop, q, witness, entry, pv):
             continue
         rows, _ = ol.generate_trace(otop, g["name"], q, witness=witness)
         if rows:
-            out[g["name"]] = (summarise(chip_liveness(oa.FuncAir(otop, g["name"]), rows, public=pv)), len(rows))
+            nsel = otop.layout(g)["sel"]
+            sel_live = [int(any(r[len(r) - nsel + k] for r in rows)) for k in range(nsel)]
+            out[g["name"]] = (summarise(chip_liveness(oa.FuncAir(otop, g["name"]), rows, public=pv), sel_live=sel_live), len(rows))
     return out
 
 
@@ -137,11 +142,10 @@ def main():
     print("dead share of the permutation-trace cells of the growing chips at 2^20 eval rows: real %.3f, fib-mix %.3f" % (fr, fm))
     if "--write" in sys.argv:
         shape["lookup_sparsity"] = {
-            "_about": "tools/measure_lookup_sparsity.py on (fib %d): per chip, interactions / interactions real on some row / permutation columns (batches of two) / columns with no real interaction; real = the reference's functions on the oracle, fib_mix = the stand-in" % n,
+            "_about": "tools/measure_lookup_sparsity.py on (fib %d), the reference's functions on the oracle's traces: per chip, interactions / interactions real on some row / permutation columns (batches of two) / columns with no real interaction / return selectors / selectors some row takes; the stand-ins are dialled to live_interactions and live_selectors (lurk_amd/programs/lurk_mix.py)" % n,
             "fib_n": n,
             "real": {c: s for c, (s, _) in real.items()},
-            "fib_mix": {c: s for c, (s, _) in mix.items()},
-            "dead_cell_share_at_2^20": {"real": round(fr, 4), "fib_mix": round(fm, 4)},
+            "dead_cell_share_at_2^20": round(fr, 4),
         }
         with open(os.path.join(ROOT, "tests", "golden", "fib_shape.json"), "w") as f:
             json.dump(shape, f, indent=1, sort_keys=False)
