@@ -123,7 +123,7 @@ std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     }
     for (size_t j = 0; j < prog.interaction_parts_coarse.size(); j++) {
         quot.push_back("quot_piece" + std::to_string(j));
-        emit_function(o, prog.interaction_parts_coarse[j], quot.back(), batch);
+        emit_function(o, prog.interaction_parts_coarse[j], quot.back(), batch, getenv("LURKHIP_QUOT_SKIP_DEAD") == nullptr || atoi(getenv("LURKHIP_QUOT_SKIP_DEAD")) != 0);
     }
     emit_runner(o, "JitPermRunner", perm);
     emit_runner(o, "JitQuotRunner", quot);

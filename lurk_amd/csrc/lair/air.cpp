@@ -1082,7 +1082,12 @@ AirPrograms lower_air(const ChipAir& air) {
     {
         const size_t n_cons = air.constraints.size();
         const size_t n_instr = p.constraints[airp::H_N_INSTR];
-        size_t n_parts = std::min<size_t>({(size_t)airp::MAX_CONSTRAINT_PARTS, std::max<size_t>(1, (n_instr + 1023) / 1024), std::max<size_t>(n_cons, 1)});
+        // (LURKHIP_CONS_INSTR_PER_PART: instructions per constraint piece, A/B hook.  1024 in rounds 2-4.  Round 5: the interaction
+        // waves of a quotient workgroup skip their dead batches, so the constraint waves became the longest of the workgroup:
+        // pieces of 256 instructions and 24 interactions measure quotient_all 5.44 -> 4.30 ms on the fib-mix step (512 / 24: 4.83,
+        // 384 / 24: 4.48, 256 / 32: 4.32, 192 / 24: 4.70; ten constraint pieces instead of eight: no gain))
+        static const size_t per_piece = getenv("LURKHIP_CONS_INSTR_PER_PART") ? (size_t)std::max(64, atoi(getenv("LURKHIP_CONS_INSTR_PER_PART"))) : 256;
+        size_t n_parts = std::min<size_t>({(size_t)airp::MAX_CONSTRAINT_PARTS, std::max<size_t>(1, (n_instr + per_piece - 1) / per_piece), std::max<size_t>(n_cons, 1)});
         // every piece keeps its register file regs[n_regs][64] in LDS next to the other pieces': stay within 128 KiB of the CU's 160
         for (;; n_parts--) {
             p.constraint_parts.clear();
@@ -1174,7 +1179,8 @@ AirPrograms lower_air(const ChipAir& air) {
     static const size_t perm_per_part = getenv("LURKHIP_PERM_PER_PART") ? (size_t)std::max(2, atoi(getenv("LURKHIP_PERM_PER_PART"))) : 12;  // (A/B hook)
     cut(perm_per_part, p.interaction_parts);
     // (LURKHIP_QUOT_PER_PART: interactions per quotient piece, A/B hook; round 2 settled on 24 -- more pieces were slower then: the per-lane reads of the permutation row thrashed L1; round 4, with the sinks' arithmetic a third cheaper, 12 measures 3.02 -> 2.83 ms for the quotient stage, 8 and 16 2.9)
-    static const size_t quot_per_part = getenv("LURKHIP_QUOT_PER_PART") ? (size_t)std::max(2, atoi(getenv("LURKHIP_QUOT_PER_PART"))) : 12;
+    // (round 5, with the dead-batch skip: 24 again, see the constraint pieces above)
+    static const size_t quot_per_part = getenv("LURKHIP_QUOT_PER_PART") ? (size_t)std::max(2, atoi(getenv("LURKHIP_QUOT_PER_PART"))) : 24;
     cut(quot_per_part, p.interaction_parts_coarse);
     return p;
 }

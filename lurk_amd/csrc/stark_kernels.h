@@ -325,6 +325,22 @@ struct QuotientSink {
     __device__ __forceinline__ void ival(uint32_t) {}  // compact pieces carry no plain IVAL
     __device__ __forceinline__ void ival_at(uint32_t v, uint32_t t) { acc.value_at(v, t); }
     __device__ __forceinline__ void ival_run(const uint32_t* vals, uint32_t t, uint32_t count) { acc.value_run(vals, t, count); }
+    // Round 5: dead batches on the quotient domain.  The batch constraint is entry * prod(d_i) - sum_i m_i prod_{j != i} d_j: where
+    // the column's entry AND every multiplicity are zero it is zero whatever the denominators are.  That is the case on the whole
+    // coset for a batch of interactions no row of the shard uses (their multiplicities are sums of selector columns that are zero
+    // columns, hence zero polynomials, and so is the batch column: 42 % of the permutation cells of a real `(fib N)` shard), and
+    // the test below does not rely on it: it looks at the values of THIS wave's 64 points.  Compiled pieces ask before the
+    // fingerprints (batch_live) and, on no, only step the constraint index past the batch (skip_batch).
+    __device__ __forceinline__ bool batch_live(uint32_t mults_or) const {
+        const uint4 e = *reinterpret_cast<const uint4*>(perm_l + 4 * col);
+        return __builtin_amdgcn_ballot_w64((mults_or | e.x | e.y | e.z | e.w) != 0u) != 0ull;
+    }
+    __device__ __forceinline__ void skip_batch() {
+        int32_t w[8];
+        weight(w);  // (keeps the one-ahead load of the next constraint's weight going)
+        k++;
+        col++;
+    }
     __device__ __forceinline__ void flush() {
         // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
         ef entry = ef_load(perm_l + 4 * col);
