@@ -20,6 +20,7 @@
 #include <map>
 #include <mutex>
 #include <sstream>
+#include <vector>
 
 #include "air_program.h"
 #include "jit_headers.inc"
@@ -99,6 +100,133 @@ void emit_function(std::ostringstream& o, const std::vector<uint32_t>& prog, con
     o << "}\n";
 }
 
+// A constraint piece with dead branches skipped (round 5).  Almost every constraint of a Lair function is `sel * x`, sel the
+// selector sum of the block the constraint belongs to, and a row takes one branch: on the quotient domain the selectors of the
+// branches a shard never takes are zero polynomials, and sel * x is zero wherever sel is, whatever x is.  Consecutive ASSERTs whose
+// root products share a factor form a group: the group's factor is computed first, then -- wave-uniform -- either the group's
+// arithmetic and its folds run, or only the constraint index moves on (QuotientSink::cond_live / skip_asserts: the test looks at
+// the values of the wave's own 64 points, it assumes nothing about the trace).  Values a later group reads are computed outside the
+// branch.  (eval_builtin_expr: 60 return selectors, 5 of them taken by a `(fib N)` run.)
+void emit_constraint_function(std::ostringstream& o, const std::vector<uint32_t>& prog, const std::string& name) {
+    const uint32_t n = prog[airp::H_N_INSTR];
+    const uint32_t* code = prog.data() + prog[airp::H_CODE_OFF];
+    const uint32_t* consts = prog.data() + prog[airp::H_CONST_OFF];
+    struct Ins {
+        uint32_t op = 0;
+        std::string a, b;      // operand texts (SSA names or leaves)
+        int da = -1, db = -1;  // defining instruction of an SSA operand
+        int last_use = -1;
+    };
+    std::vector<Ins> ins(n);
+    std::map<uint32_t, int> reg;  // interpreter register -> defining instruction
+    auto leaf = [&](uint32_t op) -> std::string {
+        const uint32_t idx = op & airp::SRC_MASK;
+        switch (op >> airp::SRC_SHIFT) {
+            case airp::S_MAIN: return "s.main_l[" + std::to_string(idx) + "]";
+            case airp::S_MAIN_NEXT: return "s.main_n[" + std::to_string(idx) + "]";
+            case airp::S_PREP: return "s.prep_l[" + std::to_string(idx) + "]";
+            case airp::S_PREP_NEXT: return "s.prep_n[" + std::to_string(idx) + "]";
+            case airp::S_CONST: return std::to_string(consts[idx]) + "u";
+            case airp::S_PUBLIC: return "s.pub[" + std::to_string(idx) + "]";
+            default: return "s.sel[" + std::to_string(idx) + "]";
+        }
+    };
+    auto resolve = [&](uint32_t op, std::string* text, int* def, int user) {
+        if ((op >> airp::SRC_SHIFT) == airp::S_REG) {
+            *def = reg.at(op & airp::SRC_MASK);
+            *text = "t" + std::to_string(*def);
+            ins[(size_t)*def].last_use = user;
+        } else {
+            *text = leaf(op);
+        }
+    };
+    for (uint32_t i = 0; i < n; i++) {
+        const uint32_t w0 = code[2 * i], w1 = code[2 * i + 1];
+        Ins& x = ins[i];
+        x.op = w0 & 0xffu;
+        const uint32_t dst = w0 >> 8, a = w1 & 0xffffu, b = w1 >> 16;
+        if (x.op == airp::OP_ADD || x.op == airp::OP_SUB || x.op == airp::OP_MUL) {
+            resolve(a, &x.a, &x.da, (int)i);
+            resolve(b, &x.b, &x.db, (int)i);
+            reg[dst] = (int)i;
+        } else if (x.op == airp::OP_ASSERT) {
+            resolve(a, &x.a, &x.da, (int)i);
+        }
+    }
+    auto emit_ins = [&](uint32_t i, const char* ind) {
+        const Ins& x = ins[i];
+        const std::string t = "t" + std::to_string(i);
+        switch (x.op) {
+            case airp::OP_ADD: o << ind << "const uint32_t " << t << " = bb::add(" << x.a << ", " << x.b << ");\n"; break;
+            case airp::OP_SUB: o << ind << "const uint32_t " << t << " = bb::sub(" << x.a << ", " << x.b << ");\n"; break;
+            case airp::OP_MUL: o << ind << "const uint32_t " << t << " = bb::mul_s(" << x.a << ", " << x.b << ");\n"; break;
+            case airp::OP_ASSERT: o << ind << "sink.assert_zero(" << x.a << ");\n"; break;
+            default: break;
+        }
+    };
+    // the factors of an ASSERT's root product ({} for a constraint that is not a product: it is evaluated unconditionally)
+    auto factors = [&](uint32_t i) -> std::vector<std::pair<std::string, int>> {
+        const Ins& x = ins[i];
+        if (x.da < 0 || ins[(size_t)x.da].op != airp::OP_MUL) return {};
+        const Ins& m = ins[(size_t)x.da];
+        return {{m.a, m.da}, {m.b, m.db}};
+    };
+    o << "template <class Sink> __device__ __forceinline__ void " << name << "(const airvm::Sources& s, Sink& sink) {\n";
+    uint32_t lo = 0;  // first instruction not emitted yet
+    while (lo < n) {
+        // the next group: from lo to the last of a run of consecutive ASSERTs (with the arithmetic between them) that share a factor
+        uint32_t first_assert = lo;
+        while (first_assert < n && ins[first_assert].op != airp::OP_ASSERT) first_assert++;
+        if (first_assert == n) {  // trailing arithmetic / padding
+            for (uint32_t i = lo; i < n; i++) emit_ins(i, "    ");
+            break;
+        }
+        std::vector<std::pair<std::string, int>> common = factors(first_assert);
+        uint32_t hi = first_assert, count = 1;
+        for (uint32_t i = first_assert + 1; i < n && !common.empty(); i++) {
+            if (ins[i].op != airp::OP_ASSERT) continue;
+            std::vector<std::pair<std::string, int>> keep;
+            for (const auto& f : factors(i))
+                for (const auto& c : common)
+                    if (c.first == f.first) keep.push_back(c);
+            if (keep.empty()) break;
+            common = keep;
+            hi = i;
+            count++;
+        }
+        // a factor that is a literal constant says nothing
+        while (!common.empty() && !common[0].first.empty() && isdigit((unsigned char)common[0].first[0])) common.erase(common.begin());
+        if (common.empty() || count < 2) {  // nothing to share (or one constraint: the test would cost what it saves)
+            for (uint32_t i = lo; i <= first_assert; i++) emit_ins(i, "    ");
+            lo = first_assert + 1;
+            continue;
+        }
+        const std::pair<std::string, int> cond = common[0];
+        // hoisted: the factor's own arithmetic and everything a later group reads, with what those read inside the span
+        std::vector<char> hoist(hi + 1, 0);
+        std::vector<int> work;
+        if (cond.second >= (int)lo) work.push_back(cond.second);
+        for (uint32_t i = lo; i <= hi; i++)
+            if (ins[i].op != airp::OP_ASSERT && ins[i].last_use > (int)hi) work.push_back((int)i);
+        while (!work.empty()) {
+            const int i = work.back();
+            work.pop_back();
+            if (i < (int)lo || hoist[(size_t)i]) continue;
+            hoist[(size_t)i] = 1;
+            if (ins[(size_t)i].da >= (int)lo) work.push_back(ins[(size_t)i].da);
+            if (ins[(size_t)i].db >= (int)lo) work.push_back(ins[(size_t)i].db);
+        }
+        for (uint32_t i = lo; i <= hi; i++)
+            if (hoist[i]) emit_ins(i, "    ");
+        o << "    if (sink.cond_live(" << cond.first << ")) {\n";
+        for (uint32_t i = lo; i <= hi; i++)
+            if (!hoist[i]) emit_ins(i, "        ");
+        o << "    } else {\n        sink.skip_asserts(" << count << "u);\n    }\n";
+        lo = hi + 1;
+    }
+    o << "}\n";
+}
+
 void emit_runner(std::ostringstream& o, const std::string& name, const std::vector<std::string>& funcs) {
     o << "struct " << name << " {\n    template <class Sink>\n"
       << "    static __device__ __forceinline__ void run(const uint32_t*, uint32_t wave, const airvm::Sources& src, uint32_t*, Sink& sink) {\n"
@@ -119,7 +247,11 @@ std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     }
     for (size_t j = 0; j < prog.constraint_parts.size(); j++) {
         quot.push_back("quot_cons" + std::to_string(j));
-        emit_function(o, prog.constraint_parts[j], quot.back(), 0);
+        // (opt-in: measured 4.30 -> 4.21 ms for quotient_all on the fib-mix step -- with the constraint pieces cut to 256 instructions
+        // they are no longer what a workgroup waits for -- and the stand-in's constraints are not dialled to the real functions'
+        // share of dead ones: tools/measure_constraint_sparsity.py, 301 of eval_builtin_expr's 616 real constraints against 516)
+        if (getenv("LURKHIP_CONS_SKIP_DEAD") != nullptr && atoi(getenv("LURKHIP_CONS_SKIP_DEAD")) != 0) emit_constraint_function(o, prog.constraint_parts[j], quot.back());
+        else emit_function(o, prog.constraint_parts[j], quot.back(), 0);
     }
     for (size_t j = 0; j < prog.interaction_parts_coarse.size(); j++) {
         quot.push_back("quot_piece" + std::to_string(j));

@@ -315,6 +315,12 @@ struct QuotientSink {
         folded.add_base(v, w);
         k++;
     }
+    // compiled constraint pieces (jit.cpp: emit_constraint_function): a group of `n` constraints that all have the factor `c`
+    __device__ __forceinline__ bool cond_live(uint32_t c) const { return __builtin_amdgcn_ballot_w64(c != 0u) != 0ull; }
+    __device__ __forceinline__ void skip_asserts(uint32_t n) {
+        k += n;
+        load_w8(next_w, alpha_pows + 8 * (k < k_total ? k_total - 1 - k : 0u));  // (past the last constraint index 0 is re-read: valid, unused)
+    }
     __device__ __forceinline__ void assert_zero_ext(const ef& v) {
         int32_t w[8];
         weight(w);
