@@ -313,6 +313,10 @@ def main():
     ap.add_argument("--shards-total", type=int, default=None,
                     help="cut the execution into exactly this many shards (any number: 9 on 8 ranks is an ordinary case of the reference's "
                          "ceil(rows / max_shard_size)); the ranks then hold different numbers of shards.  Default: ranks x --shards-per-rank")
+    ap.add_argument("--execute-on", choices=("rank0", "all"), default="rank0",
+                    help="distributed runs: who runs the host interpreter.  rank0 (default): rank 0 executes the ONE program, flattens every rank's shards "
+                         "and sends them to their owners (shards.scatter_prepared; lurkhip_func_trace_export / _import): the other ranks' host seconds and "
+                         "resident set do not grow with N.  all: every rank executes the whole program (rounds 2-5)")
     ap.add_argument("--shards-per-rank", type=int, default=None,
                     help="distributed runs: shards of 2^log_rows / k eval rows, k per rank, dealt by work (default 2 when WORLD_SIZE > 1, else 1)")
     args = ap.parse_args()
@@ -373,44 +377,69 @@ def main():
     n = 1 << log_rows
     dev = "cuda" if distributed and not oversubscribed else "cpu"
 
-    # ---- host side, once: execute the ONE program on every rank, flatten this rank's shard into HBM
+    # ---- host side, once: execute the ONE program (on rank 0, or on every rank with --execute-on all), flatten this rank's shards into HBM
     source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, world, log_rows)
-    t0 = time.perf_counter()
+    scatter = distributed and world > 1 and args.execute_on == "rank0"
+    executes = not scatter or rank == 0
     top = lair.Toplevel(source, lurk_chips=lurk_chips)
-    queries = lair.QueryRecord(top)
-    top.execute(top.func_index(entry), main_args, queries)
-    t_execute = time.perf_counter() - t0
-    pv = queries.expect_public_values()
-    host_queries = sum(queries.num_func_queries(i) for i in range(top.num_funcs()))
-    host_mem_cells = sum(queries.num_mem_queries(ml) for ml in (2, 3, 4, 5, 6, 8))
-    eval_idx = top.func_index(eval_name)
-    eval_rows_total = queries.num_func_queries(eval_idx)
-    assert eval_rows_total == world * n, (eval_rows_total, world, n)
-    machine = prover.Machine(ctx, top, entry, len(pv))
-    vk_root = machine.setup()
-    # Shards of this rank.  One GPU: the execution is one shard.  Several: `Shard::shard` cuts every chip at the same row count,
-    # so the first shards hold all the chips and the last ones only the eval chip -- with one shard per rank, rank 0 would carry
-    # 2.3x the average.  The execution is cut into k = shards_per_rank shards per rank (2^log_rows / k eval rows each) and the
-    # shards are dealt to the ranks by their work (shards.assign_shards_balanced: heaviest first, k per rank).
     spr = args.shards_per_rank if args.shards_per_rank is not None else (2 if world > 1 else 1)
     assert spr >= 1 and n % spr == 0
-    if args.shards_total:
-        # any number of shards (`Shard::shard`: ceil(rows / max_shard_size), /root/reference/src/lair/execute.rs:186-216), e.g. 9 on 8 ranks:
-        # the ranks then hold different numbers of shards and the root exchange gathers the counts first (lurkhip_exchange_roots_var)
-        shard_rows = -(-world * n // args.shards_total)
-        all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(shard_rows))
-        assert len(all_shards) == args.shards_total, f"{len(all_shards)} shards of {shard_rows} rows, {args.shards_total} asked for"
-    elif world > 1 or spr > 1 or args.workload != "eval-only":
-        all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(n // spr))
-        assert len(all_shards) == world * spr, f"{len(all_shards)} shards for {world} ranks x {spr}: the eval chip must be the tallest"
+    queries, all_shards, host = None, None, None
+    if executes:
+        t0 = time.perf_counter()
+        queries = lair.QueryRecord(top)
+        top.execute(top.func_index(entry), main_args, queries)
+        t_execute = time.perf_counter() - t0
+        eval_rows_total = queries.num_func_queries(top.func_index(eval_name))
+        assert eval_rows_total == world * n, (eval_rows_total, world, n)
+        host = {"pv": queries.expect_public_values(), "t_execute": t_execute,
+                "host_queries": sum(queries.num_func_queries(i) for i in range(top.num_funcs())),
+                "host_mem_cells": sum(queries.num_mem_queries(ml) for ml in (2, 3, 4, 5, 6, 8))}
+    if scatter:  # the public values first: the machine's entrypoint chip is sized by them
+        box = [host["pv"] if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        pv = box[0]
     else:
-        all_shards = [lair.Shard.new(queries)]
-    assignment = shards.assign_shards_balanced([machine.shard_cost(sh) for sh in all_shards], world)
+        pv = host["pv"]
+    machine = prover.Machine(ctx, top, entry, len(pv))
+    vk_root = machine.setup()
+    if executes:
+        # Shards.  One GPU: the execution is one shard.  Several: `Shard::shard` cuts every chip at the same row count, so the first
+        # shards hold all the chips and the last ones only the eval chip -- with one shard per rank, rank 0 would carry 2.3x the
+        # average.  The execution is cut into k = shards_per_rank shards per rank (2^log_rows / k eval rows each) and the shards are
+        # dealt to the ranks by their work (shards.assign_shards_balanced: heaviest first, k per rank).
+        if args.shards_total:
+            # any number of shards (`Shard::shard`: ceil(rows / max_shard_size), /root/reference/src/lair/execute.rs:186-216), e.g. 9 on 8 ranks:
+            # the ranks then hold different numbers of shards and the root exchange gathers the counts first (lurkhip_exchange_roots_var)
+            shard_rows = -(-world * n // args.shards_total)
+            all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(shard_rows))
+            assert len(all_shards) == args.shards_total, f"{len(all_shards)} shards of {shard_rows} rows, {args.shards_total} asked for"
+        elif world > 1 or spr > 1 or args.workload != "eval-only":
+            all_shards = lair.Shard.new(queries).shard(lair.ShardingConfig(n // spr))
+            assert len(all_shards) == world * spr, f"{len(all_shards)} shards for {world} ranks x {spr}: the eval chip must be the tallest"
+        else:
+            all_shards = [lair.Shard.new(queries)]
+        host["shard_cost"] = [float(machine.shard_cost(sh)) for sh in all_shards]
+        host["assignment"] = shards.assign_shards_balanced(host["shard_cost"], world)
+    if scatter:
+        box = [host if rank == 0 else None]
+        dist.broadcast_object_list(box, src=0)
+        if rank != 0:
+            host = dict(box[0], t_execute=0.0)  # (this rank ran no interpreter)
+    t_execute, host_queries, host_mem_cells = host["t_execute"], host["host_queries"], host["host_mem_cells"]
+    shard_cost, assignment = host["shard_cost"], host["assignment"]
+    n_shards = len(shard_cost)
     mine = assignment[rank]
     if not mine:
-        raise SystemExit(f"rank {rank} holds no shard ({len(all_shards)} shards over {world} ranks): nothing to time on it")
+        raise SystemExit(f"rank {rank} holds no shard ({n_shards} shards over {world} ranks): nothing to time on it")
     t0 = time.perf_counter()
-    prepared_all = [machine.prepare_shard(all_shards[i]) for i in mine]
+    my_blobs = shards.scatter_prepared(machine, all_shards, assignment, device=dev) if scatter else {}
+
+    def prepare_on(mach, i):
+        """shard i's kernel inputs on machine `mach`: from the QueryRecord where this rank has it, else from the bytes rank 0 sent"""
+        return mach.prepare_shard(all_shards[i]) if executes else mach.import_prepared(my_blobs[i], pv)
+
+    prepared_all = [prepare_on(machine, i) for i in mine]
     prepared = prepared_all[0]
     t_flatten = time.perf_counter() - t0
     # once per machine, before the timed region: the big chips' AIR programs compiled to straight-line device code
@@ -425,7 +454,7 @@ def main():
     main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     perm_cols_per_eval_row = sum(4 * air.permutation_width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     constraints_per_eval_row = sum(air.num_constraints << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
-    multi = world > 1 or len(all_shards) > 1
+    multi = world > 1 or n_shards > 1
     in_flight = 1 if (args.rank_pipeline or not multi) else (args.rank_in_flight if args.rank_in_flight is not None else 2)
     one_lane = (args.rank_pipeline and args.rank_pipeline_one_lane) or (in_flight >= 2 and args.rank_in_flight_lanes == 1)
     lane_ctx = prover.lane_context(machine) if len(mine) > 1 and not one_lane else None  # the second proving lane of a rank with several shards
@@ -443,7 +472,7 @@ def main():
         rccl_library = rccl_library_of()  # which librccl the C ABI bound: the copy torch has mapped (one RCCL per process)
         comm = Comm.from_process_group(ctx)
     rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx, comm=comm,
-                                n_shards=len(all_shards))
+                                n_shards=n_shards)
     grand_sums, rank_sums, host_ms = rank_step.grand_sums, rank_step.rank_sums, rank_step.host_ms
 
     def step():
@@ -464,7 +493,7 @@ def main():
                 ProtocolProfile.preset(args.profile).install(ctx_b)
             machine_b = prover.Machine(ctx_b, top, entry, len(pv))
             assert machine_b.setup() == vk_root
-            prepared_b = [machine_b.prepare_shard(all_shards[i]) for i in mine]
+            prepared_b = [prepare_on(machine_b, i) for i in mine]
             if not args.no_compile:
                 for pr in prepared_b:
                     machine_b.compile_airs(pr, min_log_rows=args.compile_min_log_rows)
@@ -479,7 +508,7 @@ def main():
                 else:
                     group_b = dist.new_group(backend="gloo" if oversubscribed else None)
             pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm_b,
-                                                 n_shards=len(all_shards), group=group_b))
+                                                 n_shards=n_shards, group=group_b))
             pipe["ctxs"] += [c for c in (ctx_b, lane_ctx_b) if c is not None]
             pipe["machines"].append(machine_b)
             pipe["prepared"].append(prepared_b)
@@ -762,7 +791,7 @@ def main():
         boxes = [None] * world
         dist.all_gather_object(boxes, mine_stages)
         per_rank_stages = boxes
-        cost = [float(machine.shard_cost(sh)) for sh in all_shards]
+        cost = shard_cost
         per_rank_cost = [sum(cost[i] for i in a_) for a_ in assignment]
         mean_cost = sum(per_rank_cost) / len(per_rank_cost)
         # the rank schedule (two half-shards on two lanes) measured 46.4 ms against 40.9 ms for one shard with two proofs in flight on
@@ -948,7 +977,7 @@ def main():
             "data": "synthetic",
             "config": {
                 "workload": f"fib trace 2^{log_rows} eval rows x 78 cols per GPU ({args.workload}) + the rest of its machine: lair trace-gen, main / LogUp permutation / quotient commits (coset LDE blow-up 2 + Poseidon2-16 Merkle), openings + FRI ({args.queries} queries, {args.pow_bits} PoW bits)"
-                + (f"; one execution of {world} x 2^{log_rows} eval rows in {len(all_shards)} shards dealt to {world} ranks by work, RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
+                + (f"; one execution of {world} x 2^{log_rows} eval rows in {n_shards} shards dealt to {world} ranks by work, RCCL all-gather of shard roots + all-reduce of cumulative sums" if distributed else ""),
                 "workload_detail": workload_desc,
                 "chips": chips_desc,
                 "main_columns_per_eval_row": main_cols_per_eval_row,
@@ -958,7 +987,8 @@ def main():
                 "stages_ms": sequential["stages_ms"] if sequential else {k: v[0] / args.steps for k, v in spans.items() if v[1]},
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),
-                "shards": len(all_shards),
+                "shards": n_shards,
+                "executed_on": ("rank 0 (its shards' kernel inputs sent to their owners: shards.scatter_prepared)" if scatter else "every rank") if distributed else "this process",
                 "shards_per_rank": spr,
                 "shard_assignment": assignment if world > 1 or spr > 1 else None,
                 "rccl_world_size": rccl_world_size if not oversubscribed else None,

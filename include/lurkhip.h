@@ -447,6 +447,14 @@ int32_t lurkhip_trace_group_layout(uint32_t n, const uint32_t* log_heights, cons
 int32_t lurkhip_func_trace_run_pitched(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, uint32_t out_pitch, int32_t repr);
 int32_t lurkhip_func_trace_run_many_pitched(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev,
                                             const uint32_t* out_pitches, int32_t repr);
+/* A prepared trace as bytes (round 5): the process that executed the program hands a shard's kernel inputs to the process
+ * (GPU) that proves the shard -- `Shard::shard` (src/lair/execute.rs:186-216) cuts ONE QueryRecord, which only the executing
+ * process holds.  export: the handle's numbers and its device block into a host buffer of lurkhip_func_trace_export_size bytes
+ * (waits for the context's stream); import: a new handle on `ctx` (any device) that lurkhip_func_trace_run* take like one made
+ * by the prepare calls.  The blob is validated for shape, not for content: it is as trusted as a bytecode blob. */
+int32_t lurkhip_func_trace_export_size(const lurkhip_func_trace* p, uint64_t* bytes);
+int32_t lurkhip_func_trace_export(lurkhip_ctx* ctx, const lurkhip_func_trace* p, void* out_host, uint64_t bytes);
+int32_t lurkhip_func_trace_import(lurkhip_ctx* ctx, const void* blob_host, uint64_t bytes, lurkhip_func_trace** out);
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p);
 int32_t lurkhip_mem_trace_shape(const lurkhip_record* r, uint32_t mem_len, uint32_t* n_real, uint32_t* height,
                                 uint32_t* width);

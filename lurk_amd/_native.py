@@ -155,6 +155,9 @@ SIGNATURES = {
     "lurkhip_func_trace_run_many": (_i32, [_p, C.c_uint32, C.POINTER(_p), C.POINTER(_p), _i32]),
     "lurkhip_trace_group_layout": (_i32, [C.c_uint32, _u32p, _u32p, _u32p, _u32p, _u32p, _u32p]),
     "lurkhip_func_trace_run_pitched": (_i32, [_p, _p, _u32p, C.c_uint32, _i32]),
+    "lurkhip_func_trace_export_size": (_i32, [_p, C.POINTER(C.c_uint64)]),
+    "lurkhip_func_trace_export": (_i32, [_p, _p, _u32p, C.c_uint64]),
+    "lurkhip_func_trace_import": (_i32, [_p, _u32p, C.c_uint64, C.POINTER(_p)]),
     "lurkhip_func_trace_run_many_pitched": (_i32, [_p, C.c_uint32, C.POINTER(_p), C.POINTER(_p), _u32p, _i32]),
     "lurkhip_func_trace_free": (_i32, [_p, _p]),
     "lurkhip_mem_trace_shape": (_i32, [_p, C.c_uint32, C.POINTER(C.c_uint32), C.POINTER(C.c_uint32), C.POINTER(C.c_uint32)]),

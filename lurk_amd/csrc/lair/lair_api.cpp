@@ -795,6 +795,96 @@ int32_t lurkhip_func_trace_run_many_pitched(lurkhip_ctx* ctx, uint32_t n, const 
     return lane.close();
 }
 
+// ---- a prepared trace as bytes (round 5): the executing process hands a shard's kernel inputs to the process that proves it.
+// The handle IS one device block plus a few numbers, so the blob is: 24 words of header | the TH_WORDS program header (FuncChip) |
+// the block.  Little-endian words; the block's own layout is lurkhip_func_trace_prepare's.
+namespace {
+constexpr uint32_t BLOB_MAGIC = 0x3154464cu;  // "LFT1"
+constexpr size_t BLOB_HEAD_WORDS = 24;
+}  // namespace
+
+int32_t lurkhip_func_trace_export_size(const lurkhip_func_trace* p, uint64_t* bytes) {
+    if (!p || !bytes) return LURKHIP_ERR_INVALID_ARG;
+    *bytes = (BLOB_HEAD_WORDS + p->header.size()) * 4 + p->total;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_func_trace_export(lurkhip_ctx* ctx, const lurkhip_func_trace* p, void* out_host, uint64_t bytes) {
+    LH_CHECK_CTX(ctx);
+    if (!p || !out_host) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    uint64_t need = 0;
+    (void)lurkhip_func_trace_export_size(p, &need);
+    if (bytes < need) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "export buffer too small");
+    uint32_t* w = (uint32_t*)out_host;
+    const uint64_t offs[7] = {p->o_prog, p->o_args, p->o_outs, p->o_prov, p->o_dep, p->o_meta, p->o_str};
+    w[0] = BLOB_MAGIC;
+    w[1] = (uint32_t)p->kind;
+    w[2] = p->mem_len;
+    w[3] = (p->is_real ? 1u : 0u) | (p->partial ? 2u : 0u);
+    w[4] = p->n;
+    w[5] = p->height;
+    w[6] = p->width;
+    w[7] = p->start;
+    w[8] = (uint32_t)p->header.size();
+    w[9] = (uint32_t)p->stream_words;                  // (< 2^32: a shard has at most 2^22 rows of a few hundred words)
+    memcpy(&w[10], offs, sizeof offs);                 // words 10 .. 23
+    memcpy(&w[BLOB_HEAD_WORDS], p->header.data(), p->header.size() * 4);
+    uint8_t* body = (uint8_t*)(w + BLOB_HEAD_WORDS + p->header.size());
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the upload that filled the block (and anything still reading it)
+    LH_HIP(ctx, hipMemcpy(body, p->dev, p->total, hipMemcpyDeviceToHost));
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_func_trace_import(lurkhip_ctx* ctx, const void* blob_host, uint64_t bytes, lurkhip_func_trace** out) {
+    LH_CHECK_CTX(ctx);
+    if (!blob_host || !out) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    *out = nullptr;
+    return guarded(ctx, [&]() -> int32_t {
+        const uint32_t* w = (const uint32_t*)blob_host;
+        if (bytes < BLOB_HEAD_WORDS * 4 || w[0] != BLOB_MAGIC) return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "not a prepared-trace blob");
+        const uint32_t kind = w[1], hw = w[8];
+        uint64_t offs[7];
+        memcpy(offs, &w[10], sizeof offs);
+        if (kind > 2 || hw > 4096 || (kind == 0 ? hw != lair::TH_WORDS : hw != 0) || bytes < (BLOB_HEAD_WORDS + hw) * 4)
+            return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "prepared-trace blob: bad header");
+        const uint64_t total = bytes - (BLOB_HEAD_WORDS + hw) * 4;
+        auto* p = new lurkhip_func_trace();
+        p->kind = (int)kind;
+        p->mem_len = w[2];
+        p->is_real = (w[3] & 1u) != 0;
+        p->partial = (w[3] & 2u) != 0;
+        p->n = w[4];
+        p->height = w[5];
+        p->width = w[6];
+        p->start = w[7];
+        p->stream_words = w[9];
+        p->header.assign(w + BLOB_HEAD_WORDS, w + BLOB_HEAD_WORDS + hw);
+        p->o_prog = offs[0], p->o_args = offs[1], p->o_outs = offs[2], p->o_prov = offs[3], p->o_dep = offs[4], p->o_meta = offs[5], p->o_str = offs[6];
+        p->total = total;
+        bool ok = p->n <= p->height && p->height > 0 && (p->height & (p->height - 1)) == 0 && p->width > 0 && total > 0;
+        for (uint64_t o : offs) ok = ok && o <= total && o % 4 == 0;
+        if (kind == 0) ok = ok && p->header[lair::TH_MAGIC] == lair::TRACE_PROGRAM_MAGIC && p->header[lair::TH_WIDTH] == p->width;
+        if (kind == 1) ok = ok && (p->mem_len == 2 || p->mem_len == 3 || p->mem_len == 4 || p->mem_len == 5 || p->mem_len == 6 || p->mem_len == 8) &&
+                            p->width == 4 + p->mem_len && total >= ((uint64_t)p->n * (p->mem_len + 2)) * 4;
+        if (kind == 2) ok = ok && p->width == 13 && p->height == 65536 && total >= (uint64_t)65536 * 12 * 4;
+        if (!ok) {
+            delete p;
+            return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "prepared-trace blob: inconsistent shape");
+        }
+        int32_t s = lurkhip::pool_alloc(ctx, total, &p->dev);
+        if (s == LURKHIP_OK && hipMemcpy(p->dev, (const uint8_t*)blob_host + (BLOB_HEAD_WORDS + hw) * 4, total, hipMemcpyHostToDevice) != hipSuccess)
+            s = lurkhip::set_error(ctx, LURKHIP_ERR_HIP, "upload of a prepared trace failed");
+        if (s != LURKHIP_OK) {
+            if (p->dev) lurkhip::pool_release(ctx, p->dev);
+            delete p;
+            return s;
+        }
+        *out = p;
+        return LURKHIP_OK;
+    });
+}
+
 int32_t lurkhip_func_trace_free(lurkhip_ctx* ctx, lurkhip_func_trace* p) {
     LH_CHECK_CTX_NOLOCK(ctx);
     if (!p) return LURKHIP_OK;

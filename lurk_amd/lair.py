@@ -266,6 +266,28 @@ class PreparedFuncTrace:
             raise LairError(s, N.last_error(ctx.handle))
         return [cls(c, shard, handle=C.c_void_p(h)) if h else None for c, h in zip(chips, out)]
 
+    def export(self) -> np.ndarray:
+        """The prepared inputs as bytes (lurkhip_func_trace_export): what a process that did not execute the program needs to
+        generate this chip's trace (`from_blob`)."""
+        size = C.c_uint64()
+        _check(N.lib.lurkhip_func_trace_export_size(self.handle, C.byref(size)))
+        blob = np.empty(int(size.value), dtype=np.uint8)
+        self.ctx.check(N.lib.lurkhip_func_trace_export(self.ctx.handle, self.handle, _addr(blob), int(size.value)))
+        return blob
+
+    @classmethod
+    def from_blob(cls, ctx, blob: np.ndarray) -> "PreparedFuncTrace":
+        """A prepared trace on `ctx` from `export`'s bytes (lurkhip_func_trace_import)."""
+        blob = np.ascontiguousarray(blob, dtype=np.uint8)
+        h = C.c_void_p()
+        ctx.check(N.lib.lurkhip_func_trace_import(ctx.handle, _addr(blob), blob.nbytes, C.byref(h)))
+        self = cls.__new__(cls)
+        self.ctx, self.handle = ctx, h
+        shape = (C.c_uint64 * 5)()
+        _check(N.lib.lurkhip_func_trace_shape_of(h, shape))
+        self.n_real, self.height, self.width, self.input_bytes, self.stream_words = [int(x) for x in shape]
+        return self
+
     def run(self, out_dev, repr: int = N.REPR_CANONICAL, ctx=None):
         """Launches the trace kernel on `ctx` (default: the context the inputs were uploaded on; another context's stream must
         only be used once that upload has completed)."""

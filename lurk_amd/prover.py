@@ -434,6 +434,38 @@ class Machine(_ShardProver):
         out.event = ictx.record_event()
         return out
 
+    # ---- a prepared shard as bytes: rank 0 executes the program, every rank proves the shards it is dealt (shards.scatter_prepared)
+    def export_prepared(self, prepared):
+        """[(machine index, blob or None)] of `prepare_shard`'s result: each chip's kernel inputs as bytes
+        (PreparedFuncTrace.export); None for the entrypoint chip, whose one row is the public values."""
+        return [(mi, p.export() if p is not None else None) for mi, _, _, _, p in prepared]
+
+    def import_prepared(self, entries, public_values):
+        """`prepare_shard`'s result rebuilt from `export_prepared`'s entries on this machine's context -- on a process that never
+        ran the program: chip AIRs come from the (compiled) toplevel, kernel inputs from the blobs, the entrypoint row from the
+        public values."""
+        import torch
+
+        from .lair import PreparedFuncTrace
+
+        out = []
+        for mi, blob in entries:
+            air = self.chips[mi][2]
+            if blob is None:
+                assert self.chips[mi][0] == "entrypoint"
+                t = torch.from_numpy(field.to_monty(np.array([list(public_values)], dtype=np.uint32)).view(np.int32)).cuda(self.ctx.device)
+                out.append((mi, air, 0, t, None))
+            else:
+                p = PreparedFuncTrace.from_blob(self.ctx, blob)
+                assert p.width == air.width, (air.name, p.width, air.width)
+                out.append((mi, air, p.height.bit_length() - 1, None, p))
+        todo = [k for k, e in enumerate(out) if e[4] is not None]
+        for k, t in zip(todo, alloc_trace_buffers([(out[k][4].height, out[k][4].width) for k in todo], f"cuda:{self.ctx.device}")):
+            out[k] = out[k][:3] + (t,) + out[k][4:]
+        self.ctx.sync()
+        torch.cuda.synchronize()
+        return out
+
     def compile_airs(self, prepared, min_log_rows: int | None = None, min_instrs: int | None = None):
         """Compile (hiprtc, or the on-disk code-object cache) the AIR programs of the chips whose traces in `prepared` have at
         least 2^min_log_rows rows or whose constraint program has at least min_instrs instructions (the Poseidon2 chips: on

@@ -326,6 +326,52 @@ def run_committed_ahead(steps, n_steps: int, on_proofs=None):
         th.join()
 
 
+def scatter_prepared(machine, all_shards, assignment, device="cpu", src: int = 0):
+    """ONE rank executed the program (`src`: it holds the QueryRecord, hence `all_shards`); every rank proves the shards it is dealt.
+    `src` prepares the other ranks' shards one at a time (Machine.prepare_shard: the chips' kernel inputs on its device), exports
+    them (Machine.export_prepared: bytes) and sends them to their owner; returns {shard index: entries} for this rank's shards on
+    every other rank ({} on `src`, which prepares its own shards from the record as before).  Every rank calls this with the same
+    `assignment`; the ranks other than `src` pass all_shards = None.  Point-to-point sends on `device` ("cuda": RCCL, "cpu": gloo),
+    a small broadcast per shard for the blob sizes; the host side of a rank other than `src` never sees the QueryRecord -- its
+    host seconds and resident set do not grow with the number of ranks."""
+    import numpy as np
+    import torch
+
+    d = _dist()
+    rank, world = d.get_rank(), d.get_world_size()
+    mine = {}
+    for r in range(world):
+        if r == src:
+            continue
+        for i in assignment[r]:
+            entries = None
+            head = [None]
+            if rank == src:
+                prep = machine.prepare_shard(all_shards[i])
+                entries = machine.export_prepared(prep)
+                for *_, p in prep:
+                    if p is not None:
+                        p.close()
+                head = [[(mi, None if b is None else int(b.nbytes)) for mi, b in entries]]
+            d.broadcast_object_list(head, src=src)
+            if rank == src:
+                for _, b in entries:
+                    if b is not None:
+                        t = torch.from_numpy(b)
+                        d.send(t.to(device) if device != "cpu" else t, dst=r)
+            elif rank == r:
+                got = []
+                for mi, nbytes in head[0]:
+                    if nbytes is None:
+                        got.append((mi, None))
+                        continue
+                    buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
+                    d.recv(buf, src=src)
+                    got.append((mi, np.ascontiguousarray(buf.cpu().numpy())))
+                mine[i] = got
+    return mine
+
+
 def gather_proofs(words_list, shard_indices, dst: int = 0):
     """Collects the flat proof words of every rank's shards on rank `dst`, ordered by shard index (None elsewhere): the set a
     verifier receives.  Not part of a timed step -- proofs are megabytes; `gather_object` over the process group's default
