@@ -449,6 +449,10 @@ def main():
         for pr in prepared_all:
             compiled += [c for c in machine.compile_airs(pr, min_log_rows=args.compile_min_log_rows) if c not in compiled]
     t_jit = time.perf_counter() - t_jit
+    # the headline is quoted with every chip on compiled kernels: a chip that silently stayed on the interpreter (hiprtc failure) would
+    # make the number mean something else
+    if not args.no_compile and getattr(machine, "compile_failures", None):
+        raise SystemExit("bench.py: kernels that were to be compiled were not: " + "; ".join(f"{w}: {e}" for w, e in machine.compile_failures))
     chips_desc = [f"{air.name}:2^{lg}x{air.width}" for _, air, lg, _, _ in prepared]
     input_bytes = sum(p.input_bytes for pr in prepared_all for *_, p in pr if p is not None)
     main_cols_per_eval_row = sum(air.width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
@@ -876,6 +880,19 @@ def main():
             # committed PMC pass counted it: SQ_INSTS_VALU x 64 lanes over k_row_sponges + the level kernels of one step), their time
             # is measured in THIS run (HIP events on the library's stream, the one-proof-at-a-time pass)
             insts = pmc.get("merkle_hash_valu_lane_insts_per_step")
+            # the count is a property of the hashing kernels' code: it is only used while the sources the PMC pass ran on are the
+            # sources of this tree (a changed kernel would have been priced with a stale count, silently)
+            stale = False
+            if pmc.get("hash_kernel_sources_sha256"):
+                import hashlib
+
+                hh = hashlib.sha256()
+                for rel in pmc.get("hash_kernel_sources", []):
+                    with open(os.path.join(ROOT, rel), "rb") as fsrc:
+                        hh.update(fsrc.read())
+                stale = hh.hexdigest() != pmc["hash_kernel_sources_sha256"]
+            if stale:
+                insts = None
             if insts and hash_ms_step > 0:
                 # (the count is proportional to the words hashed: scaled from the PMC pass's shapes -- one 2^20-row shard -- to this
                 # rank's shards by the algorithmic bytes of the hashing launches)
@@ -885,7 +902,8 @@ def main():
                 src_v = ("instruction count from the committed PMC pass (profiles/pmc_traffic.json: SQ_INSTS_VALU x 64 lanes of the hashing launches of one step, "
                          "deterministic) / the hashing launches' HIP-event time measured live in this run")
             else:
-                live, src_v = pmc["merkle_hash_valu_tinst_s"], "profiles (static): SQ_INSTS_VALU x 64 lanes / kernel time of the PMC pass"
+                live, src_v = pmc["merkle_hash_valu_tinst_s"], ("profiles (static): SQ_INSTS_VALU x 64 lanes / kernel time of the PMC pass"
+                                                                + (" -- the hashing kernels' sources have changed since that pass: its instruction count is not applied to this run's time" if stale else ""))
             valu = {"achieved": live, "unit": "T lane-instr/s", "peak_full_rate": VALU_FULL_RATE, "peak_half_rate": VALU_HALF_RATE,
                     "mul_class_frac": mul_frac, "mix_ceiling": ceiling, "frac_of_mix_ceiling": live / ceiling,
                     "frac_of_full_rate": live / VALU_FULL_RATE, "static_pmc_rate": pmc["merkle_hash_valu_tinst_s"],

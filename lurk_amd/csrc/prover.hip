@@ -879,7 +879,9 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     uint32_t* live_dev = nullptr;
     std::vector<size_t> live_off(n_chips + 1, 0);
     for (int i = 0; i < n_chips; i++) live_off[i + 1] = live_off[i] + air_of(sh->airs[i]).permutation_width();
-    if (sparse_lde) {
+    bool any_three_pass = false;  // (an LDE of up to 2^10 rows is one kernel: nothing to leave out, and a small proof keeps its round trips few)
+    for (int i = 0; i < n_chips; i++) any_three_pass = any_three_pass || sh->log_n[i] > 10;
+    if (sparse_lde && any_three_pass) {
         PTRY(palloc(live_off[n_chips] * 4, &live_dev));
         PHIP(hipMemsetAsync(live_dev, 0, live_off[n_chips] * 4, ctx->stream));
     }

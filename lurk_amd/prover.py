@@ -477,21 +477,22 @@ class Machine(_ShardProver):
         lo = jit_warm.COMPILE_MIN_LOG_ROWS if min_log_rows is None else min_log_rows
         ni = jit_warm.COMPILE_MIN_INSTRS if min_instrs is None else min_instrs
         done = []
+        self.compile_failures = getattr(self, "compile_failures", [])  # [(what, error)]: a caller that counts on compiled kernels looks here
         for mi, chip_air, lg, _, _ in prepared:
             if lg >= lo or chip_air.constraint_instrs >= ni:
                 try:
                     chip_air.compile(self.ctx)
                     done.append(chip_air.name)
-                except Exception:  # hiprtc unavailable / compilation error: the interpreter stays in place
-                    pass
+                except Exception as e:  # hiprtc unavailable / compilation error: the interpreter stays in place
+                    self.compile_failures.append((f"AIR of {chip_air.name}", str(e)[:300]))
             # the same for the trace generator of a tall function chip: its micro-program as a straight-line row kernel
             kind, arg, _ = self.chips[mi]
             if kind == "func" and lg >= lo:
                 try:
                     FuncChip(self.ctx, arg, self.toplevel).compile_trace()
                     self.compiled_traces.append(chip_air.name)
-                except Exception:
-                    pass
+                except Exception as e:
+                    self.compile_failures.append((f"trace generator of {chip_air.name}", str(e)[:300]))
         return done
 
     def run_prepared(self, prepared):

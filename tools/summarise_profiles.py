@@ -74,6 +74,17 @@ traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FE
            "merkle_hash_valu_tinst_s": hv, "merkle_hash_valu_lane_insts_per_step": hash_lane_insts,
            "merkle_hash_algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_step"],  # the shapes the instruction count belongs to
            "lde_kernels": sorted(NTT), "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
+# the instruction count belongs to these sources: bench.py recomputes the hash and stops using the count when they have changed
+import hashlib
+import os
+
+HASH_SOURCES = ["lurk_amd/csrc/merkle.hip", "lurk_amd/csrc/poseidon2_dev.h", "lurk_amd/csrc/p16_coop.h", "lurk_amd/csrc/babybear.h", "lurk_amd/csrc/commit.h"]
+root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+h = hashlib.sha256()
+for rel in HASH_SOURCES:
+    h.update(open(os.path.join(root, rel), "rb").read())
+traffic["hash_kernel_sources"] = HASH_SOURCES
+traffic["hash_kernel_sources_sha256"] = h.hexdigest()
 json.dump(traffic, open(f"profiles/{prefix}_pmc_traffic.json", "w"), indent=1)
 json.dump(traffic, open("profiles/pmc_traffic.json", "w"), indent=1)  # the copy bench.py reads (labelled static there)
 shutil.copy(f"gpurun_out/prof_{tag}/bench_kernel_stats.csv", f"profiles/{prefix}_full_prove_kernel_stats.csv")
