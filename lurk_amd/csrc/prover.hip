@@ -879,9 +879,12 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     uint32_t* live_dev = nullptr;
     std::vector<size_t> live_off(n_chips + 1, 0);
     for (int i = 0; i < n_chips; i++) live_off[i + 1] = live_off[i] + air_of(sh->airs[i]).permutation_width();
-    bool any_three_pass = false;  // (an LDE of up to 2^10 rows is one kernel: nothing to leave out, and a small proof keeps its round trips few)
-    for (int i = 0; i < n_chips; i++) any_three_pass = any_three_pass || sh->log_n[i] > 10;
-    if (sparse_lde && any_three_pass) {
+    // (an LDE of up to 2^10 rows is one kernel: nothing to leave out; and a small proof keeps its round trips few: the read-back
+    // is only worth a wait when there are at least 2^22 permutation cells it could spare)
+    uint64_t eligible_cells = 0;
+    for (int i = 0; i < n_chips; i++)
+        if (sh->log_n[i] > 10) eligible_cells += (uint64_t)air_of(sh->airs[i]).permutation_width() << sh->log_n[i];
+    if (sparse_lde && eligible_cells >= ((uint64_t)1 << 22)) {
         PTRY(palloc(live_off[n_chips] * 4, &live_dev));
         PHIP(hipMemsetAsync(live_dev, 0, live_off[n_chips] * 4, ctx->stream));
     }
