@@ -260,8 +260,13 @@ std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     emit_runner(o, "JitPermRunner", perm);
     emit_runner(o, "JitQuotRunner", quot);
     o << "}  // namespace lurkhip\n"
-      << "extern \"C\" __global__ void jit_perm_rows(lurkhip::PermArgs a) { lurkhip::perm_rows_body<lurkhip::JitPermRunner>(a); }\n"
-      << "extern \"C\" __global__ void jit_quotient(lurkhip::QuotientArgs a) { lurkhip::quotient_body<lurkhip::JitQuotRunner>(a); }\n";
+      ;
+    // LURKHIP_JIT_WAVES_PER_EU = n (A/B hook): ask the compiler for n waves per SIMD (512 / n VGPRs): a quotient workgroup is up to 14
+    // waves, and two of them only share a CU when a wave stays below 73 registers
+    const char* wpe = getenv("LURKHIP_JIT_WAVES_PER_EU");
+    const std::string attr = wpe && atoi(wpe) > 0 ? "__attribute__((amdgpu_waves_per_eu(" + std::to_string(atoi(wpe)) + "))) " : "";
+    o << "extern \"C\" __global__ " << attr << "void jit_perm_rows(lurkhip::PermArgs a) { lurkhip::perm_rows_body<lurkhip::JitPermRunner>(a); }\n"
+      << "extern \"C\" __global__ " << attr << "void jit_quotient(lurkhip::QuotientArgs a) { lurkhip::quotient_body<lurkhip::JitQuotRunner>(a); }\n";
     return o.str();
 }
 

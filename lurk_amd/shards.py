@@ -331,9 +331,9 @@ def scatter_prepared(machine, all_shards, assignment, device="cpu", src: int = 0
     `src` prepares the other ranks' shards one at a time (Machine.prepare_shard: the chips' kernel inputs on its device), exports
     them (Machine.export_prepared: bytes) and sends them to their owner; returns {shard index: entries} for this rank's shards on
     every other rank ({} on `src`, which prepares its own shards from the record as before).  Every rank calls this with the same
-    `assignment`; the ranks other than `src` pass all_shards = None.  Point-to-point sends on `device` ("cuda": RCCL, "cpu": gloo),
-    a small broadcast per shard for the blob sizes; the host side of a rank other than `src` never sees the QueryRecord -- its
-    host seconds and resident set do not grow with the number of ranks."""
+    `assignment`; the ranks other than `src` pass all_shards = None.  Broadcasts on `device` ("cuda": RCCL, "cpu": gloo) that only
+    the owner keeps, a small object broadcast per shard for the blob sizes; a rank other than `src` never sees the QueryRecord and
+    holds one blob at a time beyond its own shards -- its host seconds and resident set do not grow with the number of ranks."""
     import numpy as np
     import torch
 
@@ -354,20 +354,23 @@ def scatter_prepared(machine, all_shards, assignment, device="cpu", src: int = 0
                         p.close()
                 head = [[(mi, None if b is None else int(b.nbytes)) for mi, b in entries]]
             d.broadcast_object_list(head, src=src)
-            if rank == src:
-                for _, b in entries:
-                    if b is not None:
-                        t = torch.from_numpy(b)
-                        d.send(t.to(device) if device != "cpu" else t, dst=r)
-            elif rank == r:
-                got = []
-                for mi, nbytes in head[0]:
-                    if nbytes is None:
-                        got.append((mi, None))
-                        continue
+            # the blobs go out as broadcasts that only the owner keeps: the one collective family the timed region uses as well
+            # (first contact with a real multi-GPU box should not meet a second kind of communicator before the first proof)
+            got = []
+            for k, (mi, nbytes) in enumerate(head[0]):
+                if nbytes is None:
+                    got.append((mi, None))
+                    continue
+                if rank == src:
+                    t = torch.from_numpy(entries[k][1])
+                    buf = t.to(device) if device != "cpu" else t
+                else:
                     buf = torch.empty(nbytes, dtype=torch.uint8, device=device)
-                    d.recv(buf, src=src)
+                d.broadcast(buf, src=src)
+                if rank == r:
                     got.append((mi, np.ascontiguousarray(buf.cpu().numpy())))
+                del buf
+            if rank == r:
                 mine[i] = got
     return mine
 

@@ -268,3 +268,90 @@ def test_bench_refuses_to_run_fewer_ranks_than_asked():
     r = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "4", "--steps", "1", "--warmup", "0"], cwd=ROOT, env=env2,
                        capture_output=True, text=True, timeout=300)
     assert r.returncode != 0 and "must agree" in r.stderr
+
+
+class _FakePrepared:
+    def __init__(self):
+        self.closed = False
+
+    def close(self):
+        self.closed = True
+
+
+class _FakeMachine:
+    """What shards.scatter_prepared asks of a Machine, without a GPU: a shard's "kernel inputs" are bytes derived from its index."""
+
+    def __init__(self):
+        self.prepared = []
+
+    @staticmethod
+    def blobs(i):
+        return [(0, None)] + [(mi, np.full(1000 * (i + 1) + 17 * mi, (31 * i + mi) % 251, dtype=np.uint8)) for mi in (1, 4, 9)] if i == 0 else \
+            [(mi, np.full(1000 * (i + 1) + 17 * mi, (31 * i + mi) % 251, dtype=np.uint8)) for mi in (1, 4)]
+
+    def prepare_shard(self, shard):
+        ps = [_FakePrepared() for _ in self.blobs(shard)]
+        self.prepared += ps
+        return [(mi, None, 0, None, (p if b is not None else None)) for (mi, b), p in zip(self.blobs(shard), ps)]
+
+    def export_prepared(self, prep):
+        i = self._current
+        return self.blobs(i)
+
+
+def _scatter_worker(rank, world, port, q):
+    sys.path.insert(0, ROOT)
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    from lurk_amd import shards
+
+    n_shards = 7
+    assignment = shards.assign_shards_balanced([10, 9, 8, 3, 2, 1, 1], world)
+    m = _FakeMachine()
+    # (the fake needs to know which shard it is exporting: scatter_prepared prepares and exports one shard at a time)
+    real_prepare = m.prepare_shard
+
+    def prepare(i):
+        m._current = i
+        return real_prepare(i)
+
+    m.prepare_shard = prepare
+    got = shards.scatter_prepared(m, list(range(n_shards)) if rank == 0 else None, assignment, device="cpu", src=0)
+    ok = True
+    if rank == 0:
+        ok = got == {} and all(p.closed for p in m.prepared)  # rank 0 keeps nothing and releases what it prepared for the others
+    else:
+        ok = sorted(got) == sorted(assignment[rank])
+        for i, entries in got.items():
+            want = _FakeMachine.blobs(i)
+            ok = ok and [mi for mi, _ in entries] == [mi for mi, _ in want]
+            for (_, a), (_, b) in zip(entries, want):
+                ok = ok and ((a is None and b is None) or (a is not None and b is not None and np.array_equal(a, b)))
+    q.put((rank, bool(ok), sorted(got)))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+def test_three_process_scatter_of_prepared_shards():
+    """shards.scatter_prepared over gloo: rank 0 "executed", the other two ranks receive exactly the shards the balanced assignment
+    deals them (7 shards on 3 ranks, shard 0 with its entrypoint entry), byte for byte; rank 0 keeps nothing of theirs."""
+    world = 3
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_scatter_worker, args=(r, world, port, q)) for r in range(world)]
+    for p in procs:
+        p.start()
+    out = sorted(q.get(timeout=120) for _ in range(world))
+    for p in procs:
+        p.join(timeout=60)
+    assert all(ok for _, ok, _ in out), out
+    assert sorted(i for _, _, mine in out[1:] for i in mine) + [] == sorted(set(range(7)) - set(_assignment0()))
+
+
+def _assignment0():
+    sys.path.insert(0, ROOT)
+    from lurk_amd import shards
+
+    return shards.assign_shards_balanced([10, 9, 8, 3, 2, 1, 1], 3)[0]
