@@ -337,19 +337,29 @@ struct QuotientSink {
     // columns, hence zero polynomials, and so is the batch column: 42 % of the permutation cells of a real `(fib N)` shard), and
     // the test below does not rely on it: it looks at the values of THIS wave's 64 points.  Compiled pieces ask before the
     // fingerprints (batch_live) and, on no, only step the constraint index past the batch (skip_batch).
-    __device__ __forceinline__ bool batch_live(uint32_t mults_or) const {
-        const uint4 e = *reinterpret_cast<const uint4*>(perm_l + 4 * col);
-        return __builtin_amdgcn_ballot_w64((mults_or | e.x | e.y | e.z | e.w) != 0u) != 0ull;
+    // The column's entry is asked for one batch AHEAD (prefetch, then at every test): a lane's entries are perm_pitch words apart from
+    // its neighbours', every load is a memory round trip of its own, and the test needs the value before anything else of the batch
+    // has been issued -- loaded on the spot it exposed that latency once per batch (a dozen times per wave).
+    uint4 next_e = make_uint4(0u, 0u, 0u, 0u), cur_e = make_uint4(0u, 0u, 0u, 0u);
+    bool have_e = false;
+    __device__ __forceinline__ void prefetch() { next_e = *reinterpret_cast<const uint4*>(perm_l + 4 * col); }
+    __device__ __forceinline__ bool batch_live(uint32_t mults_or) {
+        cur_e = next_e;
+        have_e = true;
+        next_e = *reinterpret_cast<const uint4*>(perm_l + 4 * (col + 1));  // (past a piece's last batch: the next piece's column or the running sum's -- valid, unused)
+        return __builtin_amdgcn_ballot_w64((mults_or | cur_e.x | cur_e.y | cur_e.z | cur_e.w) != 0u) != 0ull;
     }
     __device__ __forceinline__ void skip_batch() {
         int32_t w[8];
         weight(w);  // (keeps the one-ahead load of the next constraint's weight going)
         k++;
         col++;
+        have_e = false;
     }
     __device__ __forceinline__ void flush() {
         // entry * prod(rlc) - sum_i m_i prod_{j != i} rlc_j
-        ef entry = ef_load(perm_l + 4 * col);
+        ef entry = have_e ? ef{{cur_e.x, cur_e.y, cur_e.z, cur_e.w}} : ef_load(perm_l + 4 * col);
+        have_e = false;
         sum_cols = bb::ef_add(sum_cols, entry);
         assert_zero_ext(bb::ef_sub(sink_ef_mul(acc.den, entry), acc.numerator()));
         col++;
@@ -421,6 +431,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const uint32_t first = prog[airp::H_FIRST_COLUMN];  // constraint piece: its first constraint; interaction piece: its first column
     sink.col = cons_wave ? 0u : first;
     sink.prime(cons_wave ? first : a.n_cons + first);
+    if (!cons_wave) sink.prefetch();
     Runner::run(prog, wave, src, regs + a.parts.reg_off[wave] + lane, sink);
     if (sink.acc.in_batch) sink.flush();
     // every batch column's entry of the local row was read by the piece that owns the column (QuotientSink::flush): the pieces
