@@ -468,13 +468,16 @@ def main():
     # process group is RCCL's: what a Rust host drives; two ranks on one device (the oversubscribed test mode) keep gloo
     comm = None
     rccl_library = None
+    cabi_fallback = None  # why the collectives run through torch.distributed although the C-ABI route was asked for
     if distributed and not oversubscribed and not args.torch_collectives:
-        from lurk_amd.comm import Comm
-
+        from lurk_amd.comm import bring_up
         from lurk_amd.comm import library as rccl_library_of
 
-        rccl_library = rccl_library_of()  # which librccl the C ABI bound: the copy torch has mapped (one RCCL per process)
-        comm = Comm.from_process_group(ctx)
+        # brought up collectively, with a self-test, BEFORE the timed region: if any rank cannot (loader, ncclCommInitRank, a wrong
+        # word), every rank falls back to torch.distributed together and the line says why
+        comm, cabi_fallback = bring_up(ctx)
+        if comm is not None:
+            rccl_library = rccl_library_of()  # which librccl the C ABI bound: the copy torch has mapped (one RCCL per process)
     rank_step = shards.RankStep(machine, vk_root, pv, prepared_all, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx, comm=comm,
                                 n_shards=n_shards)
     grand_sums, rank_sums, host_ms = rank_step.grand_sums, rank_step.rank_sums, rank_step.host_ms
@@ -507,8 +510,18 @@ def main():
                 # a machine proof in flight issues its collectives from its own thread: its own communicator (created here, in the same
                 # order on every rank), on its own context's stream
                 if comm is not None:
-                    comm_b = Comm.from_process_group(ctx_b)
-                    pipe["comms"].append(comm_b)
+                    comm_b, why_b = bring_up(ctx_b)
+                    if comm_b is None:  # (agreed by every rank) the whole run goes back to torch.distributed, one group per machine proof in flight
+                        cabi_fallback = why_b
+                        for c_old in [comm] + pipe["comms"]:
+                            c_old.close()
+                        comm, pipe["comms"], rccl_library = None, [], None
+                        for k_, st_ in enumerate(pipe["steps"]):
+                            st_.comm = None
+                            st_.group = None if k_ == 0 else dist.new_group(backend=None)
+                        group_b = dist.new_group(backend=None)
+                    else:
+                        pipe["comms"].append(comm_b)
                 else:
                     group_b = dist.new_group(backend="gloo" if oversubscribed else None)
             pipe["steps"].append(shards.RankStep(machine_b, vk_root, pv, prepared_b, mine, args.queries, args.pow_bits, device=dev, lane_ctx=lane_ctx_b, comm=comm_b,
@@ -1011,6 +1024,7 @@ def main():
                 "shard_assignment": assignment if world > 1 or spr > 1 else None,
                 "rccl_world_size": rccl_world_size if not oversubscribed else None,
                 "rccl_library": rccl_library,
+                "c_abi_collectives_fallback": cabi_fallback,
                 "collectives": None if not distributed else ("c-abi: lurkhip_exchange_roots + lurkhip_reduce_sums on RCCL, the context's stream (csrc/comm.cpp)" if comm is not None else "torch.distributed"),
                 "process_group": None if not distributed else ("gloo (oversubscribed diagnostic: ranks share a device; NOT a scaling number)" if oversubscribed else "nccl (RCCL)"),
                 "visible_gpus": n_devices,

@@ -99,3 +99,50 @@ class Comm:
         from .context import _addr
 
         self.ctx.check(N.lib.lurkhip_reduce_sums_dev(self.ctx.handle, self.handle, _addr(lanes_dev), _addr(total_dev)))
+
+
+def bring_up(ctx: Context, device="cuda"):
+    """(Comm, None) when the C-ABI route works on EVERY rank of the torch process group, else (None, why): the decision is taken
+    collectively, so that all ranks fall back to torch.distributed together -- a rank that cannot load librccl must not leave the
+    others inside ncclCommInitRank, and a communicator that comes up wrong must not be found out inside the timed region.
+    Three agreed steps: the loader binds a library; the communicator is created; one exchange of roots and one reduction of sums
+    give the expected words."""
+    import torch
+    import torch.distributed as dist
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+
+    def agreed(ok: bool) -> bool:
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int64, device=device)
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+        return bool(flag.item())
+
+    why = None
+    try:
+        library()
+    except Exception as e:  # noqa: BLE001
+        why = f"loader: {e}" if str(e) else "loader: librccl could not be loaded (LURKHIP_RCCL_LIB, the copy the process has mapped, the system's: none bound)"
+    if not agreed(why is None):
+        return None, why or "another rank could not load librccl"
+    c = None
+    try:
+        c = Comm.from_process_group(ctx)
+    except Exception as e:  # noqa: BLE001
+        why = f"lurkhip_comm_create: {e}"
+    if not agreed(c is not None):
+        if c is not None:
+            c.close()
+        return None, why or "another rank could not create its communicator"
+    try:
+        P = 2013265921
+        roots = c.exchange_roots([rank], [[rank + 1] * 8], n_shards=world)
+        total = c.reduce_sums([(rank + 1, 0, 0, 7)])
+        good = roots == [[r + 1] * 8 for r in range(world)] and total == ((world * (world + 1) // 2) % P, 0, 0, (7 * world) % P)
+        if not good:
+            why = f"self-test: roots {roots[:2]}..., sums {total}"
+    except Exception as e:  # noqa: BLE001
+        good, why = False, f"self-test: {e}"
+    if not agreed(good):
+        c.close()
+        return None, why or "another rank failed the communicator's self-test"
+    return c, None
