@@ -888,6 +888,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         PTRY(palloc(live_off[n_chips] * 4, &live_dev));
         PHIP(hipMemsetAsync(live_dev, 0, live_off[n_chips] * 4, ctx->stream));
     }
+    PTRY(interaction_starts_batch(ctx, n_chips, sh->airs.data(), perm_alpha, beta_pows, chip_starts.data()));  // one launch, before the lanes fork
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
         const lair::ChipAir& air = air_of(sh->airs[i]);
@@ -916,17 +917,30 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
         PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i],
-                                    sh->main_pitch[i], perm_pitch[i], live_dev ? live_dev + live_off[i] : nullptr));
+                                    sh->main_pitch[i], perm_pitch[i], live_dev ? live_dev + live_off[i] : nullptr, /*starts_ready=*/true,
+                                    /*defer_scan=*/scan_is_one_chunk(h)));
     }
     PTRY(lane.close());
+    {  // the short chips' running sums in one launch (each was a launch of one workgroup on its lane)
+        std::vector<uint32_t*> cols;
+        std::vector<uint32_t> strides, ns;
+        for (int i = 0; i < n_chips; i++)
+            if (scan_is_one_chunk((size_t)1 << sh->log_n[i])) {
+                cols.push_back(perm[i] + perm_widths[i] - 4);
+                strides.push_back(perm_pitch[i]);
+                ns.push_back(1u << sh->log_n[i]);
+            }
+        if (!cols.empty()) PTRY(scan_ef_columns_one_chunk(ctx, (int)cols.size(), cols.data(), strides.data(), ns.data()));
+    }
     // cumulative sums: the last element of each trace, gathered by one launch into one buffer and copied once -- and not waited
     // for: nothing needs them before the permutation commitment's root is read back, whose wait covers this copy too
     // (22 16-byte copies and a host round trip before: 0.3 ms of the stage)
     uint32_t* cs_host = nullptr;  // page-locked (host_staging is not used again before the sums are read below)
+    uint32_t* cs_dev = nullptr;
+    const size_t stage_words = (size_t)n_chips * 4 + live_off[n_chips] + 12;  // sums | live flags | permutation root (8) | alpha (4)
     {
-        uint32_t* cs_dev = nullptr;
         PTRY(palloc((size_t)n_chips * 16, &cs_dev));
-        PTRY(host_staging(ctx, (size_t)n_chips * 16 + live_off[n_chips] * 4, (void**)&cs_host));
+        PTRY(host_staging(ctx, stage_words * 4, (void**)&cs_host));
         for (int at = 0; at < n_chips; at += GATHER_EF_MAX) {
             GatherEfArgs a{};
             a.n = (uint32_t)std::min(GATHER_EF_MAX, n_chips - at);
@@ -958,20 +972,55 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         }
     }
     span_end(ctx, "permutation");
+    // Round 5: the constraint-folding challenge on the device.  "Observe the permutation root, sample alpha" is what k_fri_challenge
+    // does for a FRI layer; drawn there -- the host's transcript state uploaded as launch arguments --, alpha's powers are built
+    // from device memory (ef_powers_dev) and the quotient kernels read the chips' cumulative sums where the permutation stage left
+    // them: the host goes on queueing the quotient stage and its commitment while the device is still inside the permutation
+    // commitment's chain of tree levels, and catches its own transcript up at the quotient root's read-back (one wait instead of
+    // two; alpha is compared).  Not for the profiles that observe the sums or fold with ascending powers.
+    // Measured and OFF by default (LURKHIP_DEV_ALPHA=1 turns it on; read per proof): a 2^12-row proof takes 5.48 / 5.50 ms with it and
+    // 5.30 / 5.43 without, the 2^20-row step 47.7 against 47.6 -- the round trip it removes was never on the critical path: while the
+    // host waits for the permutation root the device is inside that commitment's chain of tree levels, and the quotient stage's
+    // kernels (0.55 ms of kernel time on four lanes) take as long to run as to queue.  What a small proof waits for is the device.
+    const char* dev_alpha_env = getenv("LURKHIP_DEV_ALPHA");
+    const bool dev_alpha = dev_alpha_env != nullptr && atoi(dev_alpha_env) != 0 && !prof.observe_chip_meta && !prof.constraint_alpha_ascending;
     lurkhip_commitment* perm_commit = nullptr;
     uint32_t perm_root_m[8];
     span_begin(ctx, "commit_perm");
     PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
-                     perm_root_m, nullptr, false, /*padded_groups=*/true, perm_pitch.data(), live_dev ? &live_runs : nullptr));
+                     dev_alpha ? nullptr : perm_root_m, nullptr, false, /*padded_groups=*/true, perm_pitch.data(), live_dev ? &live_runs : nullptr));
     span_end(ctx, "commit_perm");
     to_free.push_back(perm_commit);
-    for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
-    ch.observe_digest_m(perm_root_m);
-    if (prof.observe_chip_meta)  // ... and the cumulative sums before the constraint-folding challenge
-        for (int i = 0; i < n_chips; i++) ch.observe_ef_m(cumsum[i]);
+    uint32_t* alpha_dev = nullptr;
+    uint32_t* const root_alpha_host = cs_host + stage_words - 12;
+    if (dev_alpha) {
+        DevChallenger hc{};
+        memcpy(hc.state, ch.state, sizeof hc.state);
+        hc.n_in = (uint32_t)ch.input.size();
+        hc.n_out = (uint32_t)ch.output.size();
+        hc.out_head = 0;
+        hc.squeeze = (uint32_t)ch.squeeze;
+        hc.pop_front = ch.pop_front ? 1u : 0u;
+        for (size_t i = 0; i < ch.input.size(); i++) hc.input[i] = ch.input[i];
+        for (size_t i = 0; i < ch.output.size(); i++) hc.output[i] = ch.output[i];
+        DevChallenger* ch_dev = nullptr;
+        uint32_t* root_copy_dev = nullptr;
+        PTRY(palloc(sizeof(DevChallenger), (uint32_t**)&ch_dev));
+        PTRY(palloc(48, &root_copy_dev));
+        alpha_dev = root_copy_dev + 8;
+        PTRY(upload_words(ctx, (uint32_t*)ch_dev, (const uint32_t*)&hc, sizeof hc / 4));
+        const uint32_t* root_dev = perm_commit->digests + perm_commit->level_off[perm_commit->log_max] * 8;
+        PTRY(fri_challenge(ctx, ch_dev, root_dev, alpha_dev, root_copy_dev));
+        PHIP(hipMemcpyAsync(root_alpha_host, root_copy_dev, 48, hipMemcpyDeviceToHost, ctx->stream));  // read with the quotient root
+    } else {
+        for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
+        ch.observe_digest_m(perm_root_m);
+        if (prof.observe_chip_meta)  // ... and the cumulative sums before the constraint-folding challenge
+            for (int i = 0; i < n_chips; i++) ch.observe_ef_m(cumsum[i]);
+    }
 
     // ---- quotient
-    const ef alpha = ch.sample_ef_m();
+    const ef alpha = dev_alpha ? bb::ef_zero() : ch.sample_ef_m();
     std::vector<uint32_t*> qmats;
     std::vector<uint32_t> q_logn, q_widths, q_shifts;
     std::vector<int> q_chip;  // chip of each quotient chunk
@@ -979,6 +1028,23 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // tables a chip's quotient finds in the context's caches are written at first use on the stream that asks: ask on the main
     // stream, before the lanes fork (two chips of one height on two side lanes raced for the first proof of a context)
     for (int i = 0; i < n_chips; i++) (void)selector_table_of(ctx, sh->log_n[i], lqds[i]);
+    // one table of alpha powers and one copy of the public values for all chips (natural order only: the reversed table of the
+    // constraint_alpha_ascending profiles depends on the chip's own constraint count)
+    uint32_t* alpha_pows_all = nullptr;
+    uint32_t* public_m_dev = nullptr;
+    if (!prof.constraint_alpha_ascending) {
+        uint32_t k_max = 1;
+        for (int i = 0; i < n_chips; i++) k_max = std::max(k_max, air_total_constraints(sh->airs[i]));
+        PTRY(palloc((size_t)k_max * 32, &alpha_pows_all));
+        if (dev_alpha) PTRY(ef_powers_dev(ctx, alpha_dev, alpha_pows_all, k_max, true));
+        else PTRY(ef_powers(ctx, alpha.c, alpha_pows_all, k_max, true));
+    }
+    if (n_public) {
+        std::vector<uint32_t> pubm(n_public);
+        for (uint32_t i = 0; i < n_public; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
+        PTRY(palloc((size_t)n_public * 4, &public_m_dev));
+        PTRY(upload_words(ctx, public_m_dev, pubm.data(), n_public));
+    }
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
         const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
@@ -989,7 +1055,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde[sh->prep_index[i]] : nullptr;
         const uint32_t pitches[3] = {sh->main_commit->pitch[i], sh->prep_index[i] >= 0 ? pk->commit->pitch[sh->prep_index[i]] : 0u, perm_commit->pitch[i]};
         PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
-                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true));
+                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true, alpha_pows_all, public_m_dev,
+                           dev_alpha ? cs_dev + 4 * (size_t)i : nullptr));
         const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
         const uint32_t wq_inv = pow_host(wq, bb::P - 2);
         for (uint32_t c = 0; c < qd; c++) {
@@ -1009,6 +1076,16 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
                      &quot_commit, quot_root_m, q_shifts.data(), false, /*padded_groups=*/true));
     span_end(ctx, "commit_quotient");
     to_free.push_back(quot_commit);
+    if (dev_alpha) {  // the host's transcript catches up (the quotient root's read-back waited for everything queued before it)
+        memcpy(perm_root_m, root_alpha_host, sizeof perm_root_m);
+        for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
+        ch.observe_digest_m(perm_root_m);
+        const ef alpha_host = ch.sample_ef_m();
+        if (memcmp(alpha_host.c, root_alpha_host + 8, 16) != 0) {
+            cleanup();
+            return set_error(ctx, LURKHIP_ERR_EXEC, "internal error: the device's and the host's transcript drew different constraint-folding challenges");
+        }
+    }
     ch.observe_digest_m(quot_root_m);
 
     // ---- opening points

@@ -37,7 +37,14 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
                                uint32_t main_pitch = 0 /* words between rows of main_dev; 0: the chip's width */,
                                uint32_t out_pitch = 0 /* words between rows of out_dev; 0: 4 x permutation width */,
                                uint32_t* col_live = nullptr /* device, [permutation width - 1], zeroed by the caller: receives a 1 per batch column
-                               some wave computed; a column left at 0 is identically zero (stark_kernels.h: PermSink) */);
+                               some wave computed; a column left at 0 is identically zero (stark_kernels.h: PermSink) */,
+                               bool starts_ready = false /* shared_starts already holds the chip's start values (interaction_starts_batch) */,
+                               bool defer_scan = false /* leave the last column as the rows' sums: the caller scans it (scan_ef_columns_one_chunk) */);
+// the running sums of several short columns (scan_is_one_chunk(n) each) in one launch: data[i] = the column's first element
+bool scan_is_one_chunk(size_t n);
+int32_t scan_ef_columns_one_chunk(lurkhip_ctx* ctx, int n_cols, uint32_t* const* data, const uint32_t* strides, const uint32_t* ns);
+// the interaction start values of n chips (starts[i]: air_num_interactions(airs[i]) x 4 words) in as few launches as their number allows
+int32_t interaction_starts_batch(lurkhip_ctx* ctx, int n, lurkhip_air* const* airs, const bb::ef& alpha, const uint32_t* beta_pows, uint32_t* const* starts);
 
 uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd);  // stark.hip: written on the current stream at first use
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
@@ -46,7 +53,14 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
                       const uint32_t* shared_beta_pows = nullptr, const uint32_t* shared_starts = nullptr,
                       const uint32_t* pitches = nullptr /* {main, prep, perm} row pitches in words, 0 or null: the matrix's width */,
                       bool honest_running_sum = false /* the permutation LDE is the LDE of a trace this prover built: its last column IS the
-                      running sum of the row sums and ends in cumsum_m, so the next row's sum need not be read (stark_kernels.h) */);
+                      running sum of the row sums and ends in cumsum_m, so the next row's sum need not be read (stark_kernels.h) */,
+                      const uint32_t* shared_alpha_pows = nullptr /* centred powers alpha^j, j < at least the chip's constraint count, natural
+                      order (ef_powers(.., centred = true, reversed = false)): one table for all chips of a proof; null: the call builds its own */,
+                      const uint32_t* shared_public_m = nullptr /* the public values on the device, Montgomery; null: uploaded by the call */,
+                      const uint32_t* cumsum_dev = nullptr /* the chip's cumulative sum on the device (4 words, Montgomery): read by the kernel
+                      instead of cumsum_m, which the host may not know yet (with shared_alpha_pows only) */);
+int32_t ef_powers_dev(lurkhip_ctx* ctx, const uint32_t* base_dev /* 4 words, device */, uint32_t* out_dev, uint32_t count, bool centred, bool reversed = false);
+uint32_t air_total_constraints(const lurkhip_air* a);  // constraints + batch columns + the three running-sum constraints
 
 }  // namespace lurkhip
 

@@ -270,6 +270,28 @@ __global__ void k_ef_powers(uint32_t b0, uint32_t b1, uint32_t b2, uint32_t b3, 
 
 }  // namespace
 
+// the same with the base read from device memory (a challenge the device drew: prover.hip, the constraint-folding alpha)
+__global__ void k_ef_powers_dev(const uint32_t* __restrict__ base_dev, uint32_t* __restrict__ out, uint32_t count, int centred, int reversed) {
+    const uint32_t i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= count) return;
+    const uint32_t slot = reversed ? count - 1 - i : i;
+    ef base{{base_dev[0], base_dev[1], base_dev[2], base_dev[3]}}, r = bb::ef_one();
+    uint32_t e = i;
+    while (e) {
+        if (e & 1u) r = bb::ef_mul(r, base);
+        base = bb::ef_sqr(base);
+        e >>= 1;
+    }
+    if (!centred) {
+        for (int c = 0; c < 4; c++) out[4 * slot + c] = r.c[c];
+        return;
+    }
+    auto centre = [](uint32_t x) -> uint32_t { return x > bb::P / 2 ? x - bb::P : x; };
+    for (int c = 0; c < 4; c++) out[8 * slot + c] = centre(r.c[c]);
+    for (int c = 1; c < 4; c++) out[8 * slot + 3 + c] = centre(bb::mul(bb::EXT_W_M, r.c[c]));
+    out[8 * slot + 7] = 0;
+}
+
 namespace {
 
 // Start value of every interaction's denominator: alpha + kind + sum over its constant tuple elements of beta^t * c.
@@ -293,6 +315,38 @@ __global__ void k_interaction_starts(const uint32_t* __restrict__ stat, const ui
         s_ = bb::ef_add(s_, bb::ef_scale(pw, c));
     }
     for (int k = 0; k < 4; k++) starts[4 * j + k] = s_.c[k];
+}
+
+// the same for several chips in one launch (a small proof is made of launches): block b belongs to the chip whose first_block is the
+// last one at or below b
+constexpr int STARTS_BATCH = 48;
+struct StartsBatch {
+    const uint32_t* stat[STARTS_BATCH];
+    uint32_t* starts[STARTS_BATCH];
+    uint32_t first_block[STARTS_BATCH + 1];
+    uint32_t n;
+};
+__global__ void k_interaction_starts_batch(StartsBatch b, const uint32_t* __restrict__ beta_pows, ef alpha) {
+    uint32_t c = 0;
+    for (uint32_t i = 1; i < b.n; i++)
+        if (blockIdx.x >= b.first_block[i]) c = i;
+    const uint32_t* __restrict__ stat = b.stat[c];
+    const uint32_t n = stat[0], j = (blockIdx.x - b.first_block[c]) * blockDim.x + threadIdx.x;
+    if (j >= n) return;
+    const uint32_t* kinds = stat + 1;
+    const uint32_t* offs = kinds + n;
+    const uint32_t* terms = offs + n + 1;
+    ef s_ = bb::ef_add_base(alpha, bb::to_monty(kinds[j]));
+    for (uint32_t e = offs[j]; e < offs[j + 1]; e++) {
+        const uint32_t t = terms[2 * e], cst = terms[2 * e + 1];
+        ef pw;
+        for (int k = 0; k < 4; k++) {
+            const uint32_t x = beta_pows[8 * t + k];  // centred -> canonical
+            pw.c[k] = (int32_t)x < 0 ? x + bb::P : x;
+        }
+        s_ = bb::ef_add(s_, bb::ef_scale(pw, cst));
+    }
+    for (int k = 0; k < 4; k++) b.starts[c][4 * j + k] = s_.c[k];
 }
 
 __global__ void k_perm_rows(PermArgs a) { perm_rows_body<InterpreterRunner>(a); }
@@ -339,6 +393,43 @@ __global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local(uint32_t* __restrict_
         if (r < n) *reinterpret_cast<uint4*>(data + r * stride_words) = add4(v[k], prefix);
     }
     if (threadIdx.x == SCAN_BLOCK - 1) totals[blockIdx.x] = sh[SCAN_BLOCK - 1];
+}
+
+// the same for several one-chunk columns in one launch (block b scans column b): the short chips of a small proof
+constexpr int SCAN_BATCH = 48;
+struct ScanBatch {
+    uint32_t* data[SCAN_BATCH];
+    uint32_t stride[SCAN_BATCH], n[SCAN_BATCH];
+};
+__global__ __launch_bounds__(SCAN_BLOCK) void k_scan_local_batch(ScanBatch b) {
+    __shared__ uint4 sh[SCAN_BLOCK];
+    uint32_t* __restrict__ data = b.data[blockIdx.x];
+    const size_t stride_words = b.stride[blockIdx.x], n = b.n[blockIdx.x];
+    const size_t base = (size_t)threadIdx.x * SCAN_PER_THREAD;
+    uint4 v[SCAN_PER_THREAD];
+    uint4 run = make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        size_t r = base + k;
+        uint4 x = r < n ? *reinterpret_cast<const uint4*>(data + r * stride_words) : make_uint4(0, 0, 0, 0);
+        run = add4(run, x);
+        v[k] = run;
+    }
+    sh[threadIdx.x] = run;
+    __syncthreads();
+    for (int off = 1; off < SCAN_BLOCK; off <<= 1) {
+        uint4 t = make_uint4(0, 0, 0, 0);
+        if ((int)threadIdx.x >= off) t = sh[threadIdx.x - off];
+        __syncthreads();
+        if ((int)threadIdx.x >= off) sh[threadIdx.x] = add4(sh[threadIdx.x], t);
+        __syncthreads();
+    }
+    uint4 prefix = threadIdx.x ? sh[threadIdx.x - 1] : make_uint4(0, 0, 0, 0);
+#pragma unroll
+    for (int k = 0; k < SCAN_PER_THREAD; k++) {
+        size_t r = base + k;
+        if (r < n) *reinterpret_cast<uint4*>(data + r * stride_words) = add4(v[k], prefix);
+    }
 }
 
 // exclusive scan of `count` totals in one workgroup (count <= 2^27 / 1024 fits a loop)
@@ -474,6 +565,12 @@ int32_t ef_powers(lurkhip_ctx* ctx, const uint32_t base_m[4], uint32_t* out_dev,
     return LURKHIP_OK;
 }
 
+int32_t ef_powers_dev(lurkhip_ctx* ctx, const uint32_t* base_dev, uint32_t* out_dev, uint32_t count, bool centred, bool reversed) {
+    hipLaunchKernelGGL(k_ef_powers_dev, dim3((count + 63) / 64), dim3(64), 0, ctx->stream, base_dev, out_dev, count, centred ? 1 : 0, reversed ? 1 : 0);
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
 int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, size_t n) {
     if (n == 0) return LURKHIP_OK;
     const size_t chunks = (n + SCAN_CHUNK - 1) / SCAN_CHUNK;
@@ -491,12 +588,52 @@ int32_t scan_ef_column(lurkhip_ctx* ctx, uint32_t* data, size_t stride_words, si
 }
 
 
+bool scan_is_one_chunk(size_t n) { return n <= (size_t)SCAN_CHUNK; }
+int32_t scan_ef_columns_one_chunk(lurkhip_ctx* ctx, int n_cols, uint32_t* const* data, const uint32_t* strides, const uint32_t* ns) {
+    for (int at = 0; at < n_cols; at += SCAN_BATCH) {
+        ScanBatch b{};
+        const int m = std::min(SCAN_BATCH, n_cols - at);
+        for (int k = 0; k < m; k++) {
+            b.data[k] = data[at + k];
+            b.stride[k] = strides[at + k];
+            b.n[k] = ns[at + k];
+        }
+        hipLaunchKernelGGL(k_scan_local_batch, dim3((unsigned)m), dim3(SCAN_BLOCK), 0, ctx->stream, b);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+int32_t interaction_starts_batch(lurkhip_ctx* ctx, int n, lurkhip_air* const* airs, const bb::ef& alpha, const uint32_t* beta_pows, uint32_t* const* starts) {
+    for (int at = 0; at < n;) {
+        StartsBatch b{};
+        uint32_t blocks = 0;
+        for (; at < n && b.n < (uint32_t)STARTS_BATCH; at++) {
+            const uint32_t n_inter = airs[at]->air.num_interactions();
+            if (n_inter == 0) continue;
+            const uint32_t* istat = nullptr;
+            LH_TRY(air_programs_dev(ctx, airs[at], nullptr, nullptr, nullptr, false, &istat));
+            b.stat[b.n] = istat;
+            b.starts[b.n] = starts[at];
+            b.first_block[b.n] = blocks;
+            blocks += (n_inter + 63) / 64;
+            b.n++;
+        }
+        b.first_block[b.n] = blocks;
+        if (blocks) hipLaunchKernelGGL(k_interaction_starts_batch, dim3(blocks), dim3(64), 0, ctx->stream, b, beta_pows, alpha);
+    }
+    LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
 uint32_t air_beta_pows(const lurkhip_air* a) { return a->max_tuple + 2; }
 uint32_t air_num_interactions(const lurkhip_air* a) { return a->air.num_interactions(); }
+uint32_t air_total_constraints(const lurkhip_air* a) { return (uint32_t)a->air.constraints.size() + (a->air.permutation_width() - 1) + 3; }
 
 int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height, const uint32_t* main_dev, const uint32_t* prep_dev,
                                const bb::ef& alpha, const bb::ef& beta, uint32_t* out_dev, bb::ef* cumulative_sum_m,
-                               const uint32_t* shared_beta_pows, uint32_t* shared_starts, uint32_t main_pitch, uint32_t out_pitch, uint32_t* col_live) {
+                               const uint32_t* shared_beta_pows, uint32_t* shared_starts, uint32_t main_pitch, uint32_t out_pitch, uint32_t* col_live,
+                               bool starts_ready, bool defer_scan) {
     LH_ARG(ctx, a->air.prep_width == 0 || prep_dev, "chip has preprocessed columns: pass them");
     if (main_pitch == 0) main_pitch = a->air.width;
     if (out_pitch == 0) out_pitch = 4 * a->air.permutation_width();
@@ -514,7 +651,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
     const uint32_t* beta_pows = shared_beta_pows ? shared_beta_pows : (const uint32_t*)pows;
     span_begin(ctx, "perm_rows", 2);
     int32_t s = shared_beta_pows ? LURKHIP_OK : ef_powers(ctx, beta.c, (uint32_t*)pows, n_pows, true);
-    if (s == LURKHIP_OK && n_inter)
+    if (s == LURKHIP_OK && n_inter && !(shared_starts && starts_ready))
         hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, beta_pows, alpha, starts);
     if (s == LURKHIP_OK) {
         PermArgs pa{};
@@ -550,7 +687,7 @@ int32_t permutation_trace_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t height
         if (hipGetLastError() != hipSuccess) s = set_error(ctx, LURKHIP_ERR_HIP, "k_perm_rows launch failed");
     }
     span_switch(ctx, "perm_rows", "perm_scan", 2);
-    if (s == LURKHIP_OK) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)out_pitch, height);
+    if (s == LURKHIP_OK && !defer_scan) s = scan_ef_column(ctx, out_dev + 4 * (perm_w - 1), (size_t)out_pitch, height);
     span_end(ctx, "perm_scan", 2);
     pool_release(ctx, pows);
     if (s == LURKHIP_OK && cumulative_sum_m) {
@@ -601,7 +738,9 @@ uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd) {
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
-                      const uint32_t* shared_starts, const uint32_t* pitches, bool honest_running_sum) {
+                      const uint32_t* shared_starts, const uint32_t* pitches, bool honest_running_sum, const uint32_t* shared_alpha_pows,
+                      const uint32_t* shared_public_m, const uint32_t* cumsum_dev) {
+    LH_ARG(ctx, !cumsum_dev || shared_alpha_pows, "a cumulative sum on the device goes with a shared table of alpha powers");
     LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
     LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
     const uint32_t lqd = a->air.log_quotient_degree();
@@ -625,14 +764,16 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
     uint8_t* d = (uint8_t*)scratch;
     // the sinks weigh constraint k with table[K - 1 - k]: powers in natural order give sphinx's Horner folding (first constraint,
     // highest power); the table reversed gives constraint k the power alpha^k (lurkhip_protocol_profile::constraint_alpha_ascending)
-    int32_t s = ef_powers(ctx, al, (uint32_t*)d, k_total, true, profile_of(ctx).constraint_alpha_ascending != 0);
+    // (a proof's chips share ONE table of alpha powers in natural order -- a chip reads table[K - 1 - k] with its own K -- and one copy
+    // of the public values: two launches per chip fewer, which is what a small proof is made of)
+    int32_t s = shared_alpha_pows ? LURKHIP_OK : ef_powers(ctx, al, (uint32_t*)d, k_total, true, profile_of(ctx).constraint_alpha_ascending != 0);
     const uint32_t* beta_pows = shared_beta_pows ? shared_beta_pows : (const uint32_t*)(d + o_bp);
     if (s == LURKHIP_OK && !shared_beta_pows) s = ef_powers(ctx, pb, (uint32_t*)(d + o_bp), n_bp, true);
     if (s == LURKHIP_OK && n_inter && !shared_starts)
         hipLaunchKernelGGL(k_interaction_starts, dim3((n_inter + 63) / 64), dim3(64), 0, ctx->stream, istat, beta_pows,
                            bb::ef{{pa[0], pa[1], pa[2], pa[3]}}, (uint32_t*)(d + o_st));
     std::vector<uint32_t> pubm(np);
-    if (s == LURKHIP_OK && np) {
+    if (s == LURKHIP_OK && np && !shared_public_m) {
         for (uint32_t i = 0; i < np; i++) pubm[i] = bb::to_monty(public_values[i] % bb::P);
         s = upload_words(ctx, (uint32_t*)(d + o_pub), pubm.data(), np);  // launch arguments: no host wait in the middle of the stage
     }
@@ -656,8 +797,8 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.main = main_lde_dev;
         q.prep = prep_lde_dev ? prep_lde_dev : main_lde_dev;
         q.perm = perm_lde_dev;
-        q.pub = (const uint32_t*)(d + o_pub);
-        q.alpha_pows = (const uint32_t*)d;
+        q.pub = shared_public_m ? shared_public_m : (const uint32_t*)(d + o_pub);
+        q.alpha_pows = shared_alpha_pows ? shared_alpha_pows : (const uint32_t*)d;
         q.beta_pows = beta_pows;
         q.starts = shared_starts ? shared_starts : (const uint32_t*)(d + o_st);
         q.cumulative_sum = bb::ef{{cs[0], cs[1], cs[2], cs[3]}};
@@ -691,6 +832,8 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             const uint32_t n_w = bb::mul(bb::to_monty((uint32_t)(((uint64_t)1 << log_n) % bb::P)), wn);
             const uint32_t neg_inv = bb::sub(0u, bb::pow(n_w, bb::P - 2));
             for (int c = 0; c < 4; c++) q.trans_const.c[c] = bb::mul(cs[c], neg_inv);
+            q.cumsum_dev = cumsum_dev;
+            q.trans_scale = neg_inv;
         }
         q.out = out_dev;
         q.sel = selector_table_of(ctx, log_n, lqd);

@@ -281,6 +281,11 @@ struct QuotientArgs {
     // lurkhip_quotient_dev, which may be handed any matrices, keeps the direct evaluation (honest_running_sum = 0).
     int honest_running_sum;
     ef trans_const;         // -cumulative_sum / (N w_N)
+    // Round 5: the chip's cumulative sum may still be on its way (the constraint-folding challenge was drawn on the device, the host
+    // has not read the permutation stage back yet): then it is read from here (4 words, Montgomery) and trans_const is
+    // cumulative_sum * trans_scale, trans_scale = -1 / (N w_N); null: the two fields above hold the values
+    const uint32_t* cumsum_dev;
+    uint32_t trans_scale;
 };
 
 struct QuotientSink {
@@ -449,20 +454,22 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     __syncthreads();
     if (wave != 0 || !live) return;
     // running-sum constraints (sphinx eval_permutation_constraints)
+    const ef cumulative_sum = a.cumsum_dev ? ef_load(a.cumsum_dev) : a.cumulative_sum;
+    const ef trans_const = a.cumsum_dev ? bb::ef_scale(cumulative_sum, a.trans_scale) : a.trans_const;
     ef sum_l = sink.sum_cols;
     for (uint32_t j = 1; j < a.parts.n_parts; j++) sum_l = bb::ef_add(sum_l, ef_load(sums + (j * 64u + lane) * 4));
     const ef phi_l = ef_load(perm_l + 4 * (a.perm_w - 1));
     sink.seek(a.k_total - 3);
     sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, sum_l), is_first));
     if (a.honest_running_sum) {
-        sink.assert_zero_ext(bb::ef_scale(a.trans_const, a.zh[i & (qd - 1)]));  // (QuotientArgs: no read of the next row)
+        sink.assert_zero_ext(bb::ef_scale(trans_const, a.zh[i & (qd - 1)]));  // (QuotientArgs: no read of the next row)
     } else {
         ef sum_n = bb::ef_zero();
         for (uint32_t c = 0; c + 1 < a.perm_w; c++) sum_n = bb::ef_add(sum_n, ef_load(perm_n + 4 * c));
         const ef phi_n = ef_load(perm_n + 4 * (a.perm_w - 1));
         sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(bb::ef_sub(phi_n, phi_l), sum_n), is_trans));
     }
-    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, a.cumulative_sum), is_last));
+    sink.assert_zero_ext(bb::ef_scale(bb::ef_sub(phi_l, cumulative_sum), is_last));
     ef folded = sink.folded.value();
     for (uint32_t j = 1; j < a.parts.n_parts; j++) folded = bb::ef_add(folded, ef_load(folds + (j * 64u + lane) * 4));
     const ef quot = bb::ef_scale(folded, a.zh_inv[i & (qd - 1)]);

@@ -369,3 +369,24 @@ def test_u64_and_bignum_machines_on_random_operands_prove_and_verify(ctx, seed):
     airs += [oa.MemAir(ml) for ml in ol.MEM_TABLE_SIZES] + [oa.BytesAir()]
     assert os_.verify_machine(airs, root, [16], [6], proofs, ob.merkle_verify)
     m.close()
+
+
+def test_alpha_drawn_on_the_device_gives_the_same_proof(ctx, monkeypatch):
+    """LURKHIP_DEV_ALPHA=1 (round 5, off by default: measured, no gain): the constraint-folding challenge is drawn by the device's
+    copy of the transcript (k_fri_challenge on the permutation root), its powers are built from device memory and the quotient
+    kernels read the cumulative sums where the permutation stage left them; the host catches its transcript up at the quotient
+    root's read-back and compares the two alphas.  Same proof words as the host-drawn route, and the verifier accepts them."""
+    from lurk_amd.programs import lurk_mix as lm
+
+    mix = lm.fib_mix(300)
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(mix.entry, mix.main_args, q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, mix.entry, len(pv))
+    m.setup()
+    host = m.prove(q, num_queries=6, pow_bits=4, parse=False)
+    monkeypatch.setenv("LURKHIP_DEV_ALPHA", "1")
+    dev = m.prove(q, num_queries=6, pow_bits=4, parse=False)
+    assert len(host) == len(dev) == 1 and np.array_equal(host[0], dev[0])
+    assert m.verify([prover.parse_proof(dev[0])])
