@@ -262,6 +262,18 @@ int32_t lurkhip_commit(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* 
 int32_t lurkhip_commit_dev(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev,
                            const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                            int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root);
+/* lurkhip_commit_dev for matrices with identically-zero columns (round 5): the columns are found by one pass over the matrices
+ * (a word per column, read back: the call waits for the device once before the LDE), and their extension -- the zero polynomial's
+ * -- is written as zeros by the last LDE pass instead of being computed; the first two passes run on the other columns only.  Same
+ * root, same LDE words, same openings as lurkhip_commit_dev (tests/test_commit_sparse_gpu.py); worth it where a good part of the
+ * columns is zero -- the selectors and auxiliary columns of branches a Lair shard never takes: a third of a real `(fib N)` shard's
+ * main cells, 42 % of its permutation cells (which the shard prover leaves out by itself, without this pass: its permutation
+ * kernels know which columns they computed).  aligned_groups != 0: the LDEs of one height in one buffer with a 128-byte-aligned row
+ * pitch (lurkhip_commitment_matrix_pitch), the layout of the prover's own commitments.  *zero_columns (may be NULL) receives the
+ * number of columns left out.  Blow-up 2, 2^11 ... 2^20 rows take the route; other shapes are committed as by lurkhip_commit_dev. */
+int32_t lurkhip_commit_dev_sparse(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev, const uint32_t* log_heights,
+                                  const uint32_t* widths, int32_t log_blowup, int32_t repr, int32_t aligned_groups,
+                                  lurkhip_commitment** out, uint32_t* root, uint32_t* zero_columns);
 /* As lurkhip_commit_dev, for matrices given as evaluations over cosets: the LDE of matrix i is taken with p3's
  * `shift` = shifts[i] (canonical) instead of the generator, i.e. shifts[i] = 31 / (coset shift of matrix i), so that
  * every committed LDE holds the values of the underlying polynomial on 31 * <w> again.  This is how the quotient

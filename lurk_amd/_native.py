@@ -105,6 +105,7 @@ SIGNATURES = {
     "lurkhip_mmcs_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commit": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commit_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_commit_dev_sparse": (_i32, [_p, _i32, _p, _u32p, _u32p, _i32, _i32, _i32, C.POINTER(_p), _u32p, _u32p]),
     "lurkhip_commit_cosets_dev": (_i32, [_p, _i32, _p, _u32p, _u32p, _u32p, _i32, _i32, C.POINTER(_p), _u32p]),
     "lurkhip_commitment_free": (_i32, [_p, _p]),
     "lurkhip_commitment_root": (_i32, [_p, _p, _u32p, _i32]),

@@ -121,6 +121,20 @@ def commit_dev(ctx: Context, mats, log_heights, widths, log_blowup: int = 1, rep
     return _commit(ctx, N.lib.lurkhip_commit_dev, mats, log_heights, widths, log_blowup, repr, keep_coeffs)
 
 
+def commit_dev_sparse(ctx: Context, mats, log_heights, widths, log_blowup: int = 1, repr: int = N.REPR_CANONICAL, aligned_groups: bool = False):
+    """commit_dev that leaves identically-zero columns out of the LDE (lurkhip_commit_dev_sparse): (Commitment, columns left out)."""
+    n = len(mats)
+    ptrs = (C.c_void_p * n)(*[_addr(m) for m in mats])
+    lh = np.asarray(log_heights, dtype=np.uint32)
+    ws = np.asarray(widths, dtype=np.uint32)
+    handle = C.c_void_p()
+    root = np.empty(8, dtype=np.uint32)
+    nz = np.zeros(1, dtype=np.uint32)
+    ctx.check(N.lib.lurkhip_commit_dev_sparse(ctx.handle, n, C.cast(ptrs, C.c_void_p), _addr(lh), _addr(ws), log_blowup, repr, 1 if aligned_groups else 0,
+                                              C.byref(handle), _addr(root), _addr(nz)))
+    return Commitment(ctx, handle, root, [int(x) for x in lh], [int(x) for x in ws], log_blowup), int(nz[0])
+
+
 def commit_cosets_dev(ctx: Context, mats, log_heights, widths, shifts, log_blowup: int = 1, repr: int = N.REPR_MONTY) -> Commitment:
     """As commit_dev for matrices given over cosets: shifts[i] = 31 / (coset shift of matrix i) (canonical)."""
     n = len(mats)
