@@ -173,6 +173,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
 // group[i] = index of the matrix's buffer (0 .. *n_groups - 1), col_start[i] = its first column there, pitch[i] = the buffer's pitch.
 void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitch, uint32_t* col_start, int32_t* group,
                         int32_t* n_groups);
+int32_t nonzero_column_runs(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev, const uint32_t* log_heights, const uint32_t* widths,
+                            const uint32_t* pitches /* null: dense */, std::vector<ColumnRuns>* runs, uint32_t* zero_columns);
 int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const std::vector<int>& log_heights,
                    const std::vector<uint32_t>& widths, lurkhip_commitment** out);
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m);

@@ -577,12 +577,12 @@ __global__ void k_copy_words(const uint32_t* __restrict__ in, uint32_t* __restri
 
 // flags[c] = 1 when column c of a row-major device matrix holds a non-zero word (lurkhip_commit_dev_sparse): lanes along the row,
 // a workgroup per block of rows, one plain store per non-zero column and workgroup
-__global__ void k_columns_nonzero(const uint32_t* __restrict__ mat, uint32_t width, size_t rows, uint32_t* __restrict__ flags) {
+__global__ void k_columns_nonzero(const uint32_t* __restrict__ mat, uint32_t width, uint32_t pitch, size_t rows, uint32_t* __restrict__ flags) {
     const size_t rows_per_block = (rows + gridDim.x - 1) / gridDim.x;
     const size_t r0 = (size_t)blockIdx.x * rows_per_block, r1 = r0 + rows_per_block < rows ? r0 + rows_per_block : rows;
     for (uint32_t c = threadIdx.x; c < width; c += blockDim.x) {
         uint32_t any = 0;
-        for (size_t r = r0; r < r1; r++) any |= mat[r * width + c];
+        for (size_t r = r0; r < r1; r++) any |= mat[r * pitch + c];
         if (any) flags[c] = 1u;
     }
 }
@@ -1034,6 +1034,51 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     return LURKHIP_OK;
 }
 
+// the runs of columns of device matrices that hold a non-zero word (one pass over the matrices, one wait)
+int32_t nonzero_column_runs(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats_dev, const uint32_t* log_heights, const uint32_t* widths,
+                            const uint32_t* pitches, std::vector<ColumnRuns>* runs, uint32_t* zero_columns) {
+    LH_HIP(ctx, hipSetDevice(ctx->device));
+    size_t total_w = 0;
+    for (int i = 0; i < n_mats; i++) {
+        LH_ARG(ctx, mats_dev[i] != nullptr && widths[i] > 0 && log_heights[i] < 31, "matrix %d is empty", i);
+        total_w += widths[i];
+    }
+    void* flags_dev = nullptr;
+    LH_TRY(pool_alloc(ctx, total_w * 4, &flags_dev));
+    std::vector<uint32_t> flags(total_w, 0);
+    hipError_t e = hipMemsetAsync(flags_dev, 0, total_w * 4, ctx->stream);
+    size_t at = 0;
+    for (int i = 0; i < n_mats && e == hipSuccess; i++) {
+        const size_t rows = (size_t)1 << log_heights[i];
+        const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, rows / 64));
+        hipLaunchKernelGGL(k_columns_nonzero, dim3(blocks), dim3(256), 0, ctx->stream, mats_dev[i], widths[i], pitches ? pitches[i] : widths[i], rows,
+                           (uint32_t*)flags_dev + at);
+        e = hipGetLastError();
+        at += widths[i];
+    }
+    if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), flags_dev, total_w * 4, hipMemcpyDeviceToHost, ctx->stream);
+    if (e == hipSuccess) e = stream_wait(ctx);
+    pool_release(ctx, flags_dev);
+    if (e != hipSuccess) return set_error(ctx, LURKHIP_ERR_HIP, "column scan failed: %s", hipGetErrorString(e));
+    runs->assign(n_mats, {});
+    uint32_t n_zero = 0;
+    at = 0;
+    for (int i = 0; i < n_mats; i++) {
+        for (uint32_t c = 0; c < widths[i]; c++) {
+            if (!flags[at + c]) {
+                n_zero++;
+                continue;
+            }
+            ColumnRuns& r = (*runs)[i];
+            if (!r.empty() && r.back().first + r.back().second == c) r.back().second++;
+            else r.push_back({c, 1u});
+        }
+        at += widths[i];
+    }
+    if (zero_columns) *zero_columns = n_zero;
+    return LURKHIP_OK;
+}
+
 }  // namespace lurkhip
 
 using namespace lurkhip;
@@ -1105,43 +1150,8 @@ int32_t lurkhip_commit_dev_sparse(lurkhip_ctx* ctx, int32_t n_mats, const uint32
                                   lurkhip_commitment** out, uint32_t* root, uint32_t* zero_columns) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats_dev && log_heights && widths && out, "bad commit arguments");
-    LH_HIP(ctx, hipSetDevice(ctx->device));
-    size_t total_w = 0;
-    for (int i = 0; i < n_mats; i++) {
-        LH_ARG(ctx, mats_dev[i] != nullptr && widths[i] > 0 && log_heights[i] < 31, "matrix %d is empty", i);
-        total_w += widths[i];
-    }
-    void* flags_dev = nullptr;
-    LH_TRY(pool_alloc(ctx, total_w * 4, &flags_dev));
-    std::vector<uint32_t> flags(total_w, 0);
-    hipError_t e = hipMemsetAsync(flags_dev, 0, total_w * 4, ctx->stream);
-    size_t at = 0;
-    for (int i = 0; i < n_mats && e == hipSuccess; i++) {
-        const size_t rows = (size_t)1 << log_heights[i];
-        const unsigned blocks = (unsigned)std::min<size_t>(1024, std::max<size_t>(1, rows / 64));
-        hipLaunchKernelGGL(k_columns_nonzero, dim3(blocks), dim3(256), 0, ctx->stream, mats_dev[i], widths[i], rows, (uint32_t*)flags_dev + at);
-        e = hipGetLastError();
-        at += widths[i];
-    }
-    if (e == hipSuccess) e = hipMemcpyAsync(flags.data(), flags_dev, total_w * 4, hipMemcpyDeviceToHost, ctx->stream);
-    if (e == hipSuccess) e = stream_wait(ctx);
-    pool_release(ctx, flags_dev);
-    if (e != hipSuccess) return set_error(ctx, LURKHIP_ERR_HIP, "column scan failed: %s", hipGetErrorString(e));
-    std::vector<ColumnRuns> runs(n_mats);
-    uint32_t n_zero = 0;
-    at = 0;
-    for (int i = 0; i < n_mats; i++) {
-        for (uint32_t c = 0; c < widths[i]; c++) {
-            if (!flags[at + c]) {
-                n_zero++;
-                continue;
-            }
-            if (!runs[i].empty() && runs[i].back().first + runs[i].back().second == c) runs[i].back().second++;
-            else runs[i].push_back({c, 1u});
-        }
-        at += widths[i];
-    }
-    if (zero_columns) *zero_columns = n_zero;
+    std::vector<ColumnRuns> runs;
+    LH_TRY(nonzero_column_runs(ctx, n_mats, mats_dev, log_heights, widths, nullptr, &runs, zero_columns));
     return commit_impl(ctx, n_mats, mats_dev, false, log_heights, widths, log_blowup, repr, 0, out, root, nullptr, false, aligned_groups != 0, nullptr, &runs);
 }
 

@@ -236,8 +236,18 @@ int32_t lurkhip_shard_commit_pitched(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_
         sh->main_pitch.push_back(main_pitches ? main_pitches[i] : widths.back());
     }
     span_begin(ctx, "commit_main");
-    int32_t s = commit_impl(ctx, n_chips, sh->main.data(), false, sh->log_n.data(), widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
-                            &sh->main_commit, sh->root_m, nullptr, false, /*padded_groups=*/true, sh->main_pitch.data());
+    // LURKHIP_MAIN_SPARSE_LDE=1 (opt-in, measured, not part of the headline): the main traces' identically-zero columns -- selectors and
+    // auxiliary columns of never-taken branches, high bytes of small numbers: a third of a real `(fib N)` shard's main cells -- found by
+    // one pass over the traces and left out of the LDE like the permutation traces' (the stand-in is sparser than the real
+    // functions here, so the number it gives is not the real machine's)
+    std::vector<ColumnRuns> main_runs;
+    const char* main_sparse = getenv("LURKHIP_MAIN_SPARSE_LDE");
+    int32_t s = LURKHIP_OK;
+    if (main_sparse && atoi(main_sparse) != 0)
+        s = nonzero_column_runs(ctx, n_chips, sh->main.data(), sh->log_n.data(), widths.data(), sh->main_pitch.data(), &main_runs, nullptr);
+    if (s == LURKHIP_OK)
+        s = commit_impl(ctx, n_chips, sh->main.data(), false, sh->log_n.data(), widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &sh->main_commit,
+                        sh->root_m, nullptr, false, /*padded_groups=*/true, sh->main_pitch.data(), main_runs.empty() ? nullptr : &main_runs);
     span_end(ctx, "commit_main");
     if (s != LURKHIP_OK) {
         delete sh;
