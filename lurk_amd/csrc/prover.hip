@@ -885,7 +885,11 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // whose multiplicities are zero on all 64 rows of a wave; a column no wave marks is identically zero.)  One word per column,
     // zeroed before the lanes fork, read back with the cumulative sums: the LDE of the permutation traces then leaves the dead
     // columns out (commit_impl: live_runs) -- 42 % of the permutation cells of a real `(fib N)` shard.  LURKHIP_PERM_SPARSE_LDE=0: off.
-    static const bool sparse_lde = getenv("LURKHIP_PERM_SPARSE_LDE") == nullptr || atoi(getenv("LURKHIP_PERM_SPARSE_LDE")) != 0;
+    // (read per proof: a test switches it; LURKHIP_PERM_SPARSE_MIN_CELLS lowers the threshold below so that mid-sized test machines take the route)
+    const char* sparse_env = getenv("LURKHIP_PERM_SPARSE_LDE");
+    const bool sparse_lde = sparse_env == nullptr || atoi(sparse_env) != 0;
+    const char* min_cells_env = getenv("LURKHIP_PERM_SPARSE_MIN_CELLS");
+    const uint64_t min_cells = min_cells_env ? (uint64_t)strtoull(min_cells_env, nullptr, 10) : ((uint64_t)1 << 22);
     uint32_t* live_dev = nullptr;
     std::vector<size_t> live_off(n_chips + 1, 0);
     for (int i = 0; i < n_chips; i++) live_off[i + 1] = live_off[i] + air_of(sh->airs[i]).permutation_width();
@@ -894,7 +898,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     uint64_t eligible_cells = 0;
     for (int i = 0; i < n_chips; i++)
         if (sh->log_n[i] > 10) eligible_cells += (uint64_t)air_of(sh->airs[i]).permutation_width() << sh->log_n[i];
-    if (sparse_lde && eligible_cells >= ((uint64_t)1 << 22)) {
+    if (sparse_lde && eligible_cells >= min_cells && eligible_cells > 0) {
         PTRY(palloc(live_off[n_chips] * 4, &live_dev));
         PHIP(hipMemsetAsync(live_dev, 0, live_off[n_chips] * 4, ctx->stream));
     }

@@ -148,3 +148,28 @@ def test_reference_default_shard_2p22_rows_one_shard(ctx):
     assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
     m.close()
     ctx.pool_trim()
+
+
+@pytest.mark.parametrize("mix", [lm.fib_mix(1 << 13), lm.lurk_mix(1 << 13)], ids=["fib-mix-2^13", "lurk-mix-2^13"])
+def test_sparse_permutation_lde_gives_the_dense_proof(ctx, mix, monkeypatch):
+    """Round 5: the permutation traces' identically-zero columns are left out of the LDE (only above 2^22 eligible cells by
+    default: the threshold is lowered here so that a mid-sized machine with every chip compiled takes the route on its chips of
+    2^11 rows and more).  Same proof words as with the route switched off; the oracle's verifier accepts them."""
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(mix.entry, mix.main_args, q)
+    pv = q.expect_public_values()
+    m = prover.Machine(ctx, top, mix.entry, len(pv))
+    root = m.setup()
+    prepared = m.prepare_shard(lair.Shard.new(q))
+    assert m.compile_airs(prepared, 11)  # the compiled permutation kernels mark the columns they compute; chips of 2^11 rows and more take the route
+    del prepared
+    monkeypatch.setenv("LURKHIP_PERM_SPARSE_LDE", "0")
+    dense = m.prove(q, num_queries=6, pow_bits=4, parse=False)
+    monkeypatch.setenv("LURKHIP_PERM_SPARSE_LDE", "1")
+    monkeypatch.setenv("LURKHIP_PERM_SPARSE_MIN_CELLS", "1")
+    sparse = m.prove(q, num_queries=6, pow_bits=4, parse=False)
+    assert len(dense) == len(sparse) == 1 and np.array_equal(dense[0], sparse[0])
+    proofs = [prover.parse_proof(sparse[0])]
+    assert m.verify(proofs)
+    assert os_.verify_machine(oracle_airs(mix, len(pv)), root, [16], [6], proofs, ob.merkle_verify)
