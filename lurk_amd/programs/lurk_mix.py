@@ -615,6 +615,7 @@ _PLAN_CACHE = {}
 # half as tall, gives the difference back twice over, so that the machine's share of identically-zero permutation cells stays at or
 # below the real machine's (tests/test_mix_programs.py holds it there; tools/measure_lookup_sparsity.py prints both tables).
 DEAD_COLUMN_ADJUST = {"eval_builtin_expr": -6}
+DEAD_COLUMN_ADJUST_MASTERMIND = {"eval_builtin_expr": -9}  # (the same trade on lurk-mix, whose eval_builtin_expr is half as tall as eval too)
 
 
 def _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted, sparsity=False):
@@ -626,7 +627,7 @@ def _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted, sparsity=False
     if key in _PLAN_CACHE:
         return _PLAN_CACHE[key]
     chips = load_shape()["chips"]
-    sparse = load_shape().get("lookup_sparsity", {}).get("real", {}) if sparsity else {}
+    sparse = load_shape().get({"fib": "lookup_sparsity", "mastermind": "lookup_sparsity_mastermind"}.get(sparsity, "lookup_sparsity") if sparsity else "", {}).get("real", {}) if sparsity else {}
     have = set(funcs)
     fixed_src = "".join(FIXED[f] for f in funcs if f in FIXED)
     specs, fits = {}, {}
@@ -654,7 +655,8 @@ def _plan(funcs, walkers, pre, phase_pre, u64_owner, live_wanted, sparsity=False
                 # (the real function's dead interactions do not all pair up into dead columns -- 58 dead lookups of eval_builtin_expr
                 # make 52 dead columns --, the stand-in's branch-by-branch ones do: the quota is the number of dead COLUMNS, which
                 # leaves the stand-in with a few live interactions more than the real function has)
-                t["dead_lookups"] = max(0, sparse[f]["dead_columns"] + DEAD_COLUMN_ADJUST.get(f, 0))
+                adjust = DEAD_COLUMN_ADJUST if sparsity in (True, "fib") else DEAD_COLUMN_ADJUST_MASTERMIND
+                t["dead_lookups"] = max(0, sparse[f]["dead_columns"] + adjust.get(f, 0))
                 if want is None:  # the selectors a real run takes, less the bottom frame's return
                     want = live = max(1, min(nb, sparse[f]["live_selectors"] - 1))
             emit = lambda s, f=f, base=base: emit_walker(f, s, pre[f], phase_pre[f], base)
@@ -794,4 +796,4 @@ def lurk_mix(eval_rows: int) -> Mix:
     for f, (frac, fixed) in lurk_fractions().items():
         counts[f] = max(2, int(eval_rows * frac)) if frac is not None else max(2, min(fixed, max(2, eval_rows // 2)))
     counts["eval"] = eval_rows
-    return build_mix("lurk-mix", list(LURK_FUNC_ORDER), counts, u64_owner="eval_binop_num", u64_every=2, fresh=LURK_FRESH)
+    return build_mix("lurk-mix", list(LURK_FUNC_ORDER), counts, u64_owner="eval_binop_num", u64_every=2, fresh=LURK_FRESH, sparsity="mastermind")

@@ -192,3 +192,24 @@ def test_fib_mix_is_not_sparser_than_the_real_machine(oracle):
         assert mix[c][0]["live_interactions"] >= real[c]["live_interactions"], (c, mix[c][0], real[c])
     # eval, the tallest chip, is the exception the others make up for (lurk_mix.py: DEAD_COLUMN_ADJUST)
     assert mix["eval"][0]["dead_columns"] <= real["eval"]["dead_columns"] + 4
+
+
+def test_lurk_mix_is_not_sparser_than_the_real_mastermind_machine(oracle):
+    """The same hold for BASELINE config 5: `lookup_sparsity_mastermind` (demo/mastermind.lurk under the reference's functions on the
+    oracle's traces) against lurk-mix's traces -- the share of dead permutation cells, weighted by the real run's padded heights, at
+    or below the real one; the tall chips per chip within reach (eval is the exception eval_builtin_expr makes up for, as on fib-mix)."""
+    import sys
+
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tools"))
+    import measure_lookup_sparsity as msp
+
+    real = SHAPE["lookup_sparsity_mastermind"]["real"]
+    rows = SHAPE["mastermind"]["rows"]
+    mix = msp.stand_in(1024, "lurk")
+    heights = {c: rows[c] for c in real if c in rows and c in mix}
+    share_real = msp.weighted({c: (real[c], 0) for c in heights}, heights)
+    share_mix = msp.weighted({c: mix[c] for c in heights}, heights)
+    assert share_real - 0.05 <= share_mix <= share_real + 0.002, (share_mix, share_real)
+    for c in ("eval_builtin_expr", "apply", "ingress", "eval_binop_num", "env_lookup", "hash4"):
+        assert mix[c][0]["dead_columns"] <= real[c]["dead_columns"], (c, mix[c][0], real[c])
+    assert mix["eval"][0]["dead_columns"] <= real["eval"]["dead_columns"] + 4

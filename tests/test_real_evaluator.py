@@ -178,3 +178,14 @@ def test_committed_lookup_sparsity_is_a_fresh_measurement():
     # the liveness pattern does not depend on N once every branch of the recursion has been taken
     again = msp.real_fib(sp["fib_n"] + 5)
     assert {c: s for c, (s, _) in again.items()} == sp["real"]
+
+
+def test_committed_mastermind_lookup_sparsity_is_a_fresh_measurement():
+    """... and the same table for demo/mastermind.lurk (`lookup_sparsity_mastermind`: what lurk-mix is dialled to), from a run of the
+    script under the reference's functions on the ORACLE's interpreter (its assertions hold there too)."""
+    import measure_lookup_sparsity as msp
+
+    with open(os.path.join(ROOT, "tests", "golden", "fib_shape.json")) as f:
+        sp = json.load(f)["lookup_sparsity_mastermind"]
+    got = msp.real_mastermind()
+    assert {c: s for c, (s, _) in got.items()} == sp["real"]

@@ -89,14 +89,59 @@ def real_fib(n):
     return oracle_machine(otop, q, witness, "lurk_main", q.public_values)
 
 
-def stand_in(eval_rows):
+def real_mastermind():
+    """The same table for BASELINE config 5's program (demo/mastermind.lurk folded into one expression, as
+    tests/test_real_evaluator.py evaluates it): the oracle's interpreter recurses deeply on it, hence the thread with a big stack."""
+    import threading
+
+    out = {}
+
+    def run():
+        import lurk_reference as lr
+        import measure_lurk_shape as ms
+        from lurk_amd import zstore as zs
+        from oracle import binding
+        from oracle import lair as ol
+        from test_lair_gpu import oracle_chip_callbacks
+
+        binding.build()
+        real = ms.RealLurk()
+        otop = ol.Toplevel(real.source, chips=ol.lurk_chips())
+        poseidon, witness = oracle_chip_callbacks(binding)
+        z = zs.ZStore(real.hasher)
+        zp = ms.intern_syntax(z, lr.read_lurk(lr.fold_repl_script(lr.demo_script("mastermind.lurk"))))
+        q = ol.QueryRecord(otop)
+        for name, ln in (("hash3", 24), ("hash4", 32), ("hash5", 40)):
+            i = otop.index[name]
+            for pre, dig in z.hashes.items():
+                if len(pre) == ln:
+                    q.inv[i][tuple(dig)] = tuple(pre)
+        args = [0] * 24
+        args[0] = zp.tag
+        args[8:16] = zp.digest
+        res = ol.execute(otop, "lurk_main", args, q, poseidon=poseidon)
+        t_digest = [int(x) for x in real.resolver.digest[("lurk", "t")]]
+        assert list(res) == [lr.enums()["Tag"]["Sym"]] + [0] * 7 + t_digest, "the script's assertions do not hold on the oracle's interpreter"
+        out.update(oracle_machine(otop, q, witness, "lurk_main", q.public_values))
+
+    sys.setrecursionlimit(1000000)
+    threading.stack_size(512 * 1024 * 1024)
+    th = threading.Thread(target=run)
+    th.start()
+    th.join()
+    threading.stack_size(0)
+    assert out, "the mastermind run failed"
+    return out
+
+
+def stand_in(eval_rows, workload="fib"):
     from lurk_amd.programs import lurk_mix as lm
     from oracle import binding
     from oracle import lair as ol
     from test_lair_gpu import oracle_chip_callbacks
 
     binding.build()
-    mix = lm.fib_mix(eval_rows)
+    mix = lm.fib_mix(eval_rows) if workload == "fib" else lm.lurk_mix(eval_rows)
     otop = ol.Toplevel(mix.source, chips=ol.lurk_chips())
     poseidon, witness = oracle_chip_callbacks(binding)
     q = ol.QueryRecord(otop)
@@ -140,7 +185,19 @@ def main():
     grow_mix = {c: v for c, v in mix.items() if c in heights}
     fr, fm = weighted(grow, heights), weighted(grow_mix, heights)
     print("dead share of the permutation-trace cells of the growing chips at 2^20 eval rows: real %.3f, fib-mix %.3f" % (fr, fm))
+    mm = real_mastermind() if "--mastermind" in sys.argv or "--write" in sys.argv else None
+    if mm:
+        mmix = stand_in(mm["eval"][1] // 8, "lurk")
+        print("mastermind (real | lurk-mix):")
+        for name in mm:
+            r, rows = mm[name]
+            m = mmix.get(name, ({"interactions": 0, "live_interactions": 0, "columns": 0, "dead_columns": 0}, 0))[0]
+            print("%-26s %6d | %5d %5d %5d %5d | %5d %5d %5d %5d" % (name, rows, r["interactions"], r["live_interactions"], r["columns"], r["dead_columns"],
+                                                                    m["interactions"], m["live_interactions"], m["columns"], m["dead_columns"]))
     if "--write" in sys.argv:
+        shape["lookup_sparsity_mastermind"] = {
+            "_about": "the same per-chip table for demo/mastermind.lurk (BASELINE config 5) on the oracle's traces: what lurk-mix is dialled to",
+            "real": {c: s for c, (s, _) in mm.items()}}
         shape["lookup_sparsity"] = {
             "_about": "tools/measure_lookup_sparsity.py on (fib %d), the reference's functions on the oracle's traces: per chip, interactions / interactions real on some row / permutation columns (batches of two) / columns with no real interaction / return selectors / selectors some row takes; the stand-ins are dialled to live_interactions and live_selectors (lurk_amd/programs/lurk_mix.py)" % n,
             "fib_n": n,
