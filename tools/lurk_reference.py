@@ -198,13 +198,14 @@ def read_lurk(text: str):
     pos = 0
 
     def atom(t):
-        if t.startswith("#0x"):  # big-num literal: base-p digits, little-endian (parser/syntax.rs:267-290)
-            v, digest = int(t[3:], 16), []
+        if t.startswith("#0x") or t.startswith("#c0x"):  # big-num / commitment literal: base-p digits, little-endian (parser/syntax.rs:267-290)
+            comm = t.startswith("#c0x")
+            v, digest = int(t[4 if comm else 3:], 16), []
             for _ in range(8):
                 digest.append(v % 2013265921)
                 v //= 2013265921
             assert v == 0, "digest literal too big"
-            return ("bignum", tuple(digest))
+            return ("comm" if comm else "bignum", tuple(digest))
         if re.fullmatch(r"\d+(u64)?", t):
             return zs.syn_u64(int(t.removesuffix("u64")))
         if re.fullmatch(r"\d+n", t):

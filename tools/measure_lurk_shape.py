@@ -66,6 +66,8 @@ def intern_syntax(z, syn):
         return z.char(syn[1])
     if k == "bignum":
         return z.big_num(syn[1])
+    if k == "comm":
+        return z.comm(syn[1])
     if k == "str":
         return z.intern_string(syn[1])
     if k == "sym":
@@ -143,6 +145,17 @@ class RealLurk:
         t = time.time()
         out = self.top.execute_by_name("lurk_main", args, q)
         return out, q, time.time() - t
+
+    def run_zptr(self, z, zp, env=None):
+        """`run_tests` of the reference's evaluator corpus (src/core/tests/mod.rs:28-56): the expression `zp` under the environment
+        `env` (a ZPtr; None: the empty one), every hash3 / hash4 / hash5 the store `z` knows injected as an inverse query;
+        returns (the 16 output lanes, QueryRecord)."""
+        q = self.lair.QueryRecord(self.top)
+        idx = {24: self.top.func_index("hash3"), 32: self.top.func_index("hash4"), 40: self.top.func_index("hash5")}
+        for pre, dig in z.hashes.items():
+            q.inject_inv_query(idx[len(pre)], list(pre), list(dig))
+        args = zp.flatten() + (list(env.digest) if env is not None else [0] * 8)
+        return self.top.execute_by_name("lurk_main", args, q), q
 
     def record_counts(self, q):
         rows = {n: q.num_func_queries(self.top.func_index(n)) for n in self.names}
