@@ -189,3 +189,12 @@ def test_committed_mastermind_lookup_sparsity_is_a_fresh_measurement():
         sp = json.load(f)["lookup_sparsity_mastermind"]
     got = msp.real_mastermind()
     assert {c: s for c, (s, _) in got.items()} == sp["real"]
+
+
+@pytest.mark.parametrize("script", ["mini-mastermind.lurk", "simple.lurk"])
+def test_smaller_demo_scripts_hold_under_the_real_evaluator(real, script):
+    """The demo scripts whose REPL commands the fold covers (`def`, `defrec`, `assert-eq`; the others drive the CLI: `prove`,
+    `verify`, `chain`, protocols): every assertion of the script holds under the reference's functions on the product's interpreter."""
+    out, _, _ = real.run(lr.fold_repl_script(lr.demo_script(script)))
+    t_digest = [int(x) for x in real.resolver.digest[("lurk", "t")]]
+    assert list(out) == [lr.enums()["Tag"]["Sym"]] + [0] * 7 + t_digest
