@@ -373,7 +373,7 @@ class Toplevel:
     # --- compile
     def _compile(self, idx, fe):
         body = self._expand_block(fe["body"], [], [0])
-        st = {"var": 0, "ret": 0, "link": {}}
+        st = {"var": 0, "ret": 0, "link": {}, "partial": fe["partial"]}
         for p in fe["params"]:
             st["link"][p] = list(range(st["var"], st["var"] + p[1]))
             st["var"] += p[1]
@@ -414,6 +414,8 @@ class Toplevel:
                 ops.append(("not", st["link"][inp[0]][0]))
                 self._new(out[0], st)
             elif kind in ("call", "preimg"):
+                if self.funcs_e[self.index[extra]]["partial"] and not st["partial"]:  # toplevel.rs:640-642,668-670: assert!(ctx.partial)
+                    raise ValueError(f"a total function may not call the partial function {extra}")
                 ops.append((kind, self.index[extra], self._flat(inp, st)))
                 for t in out:
                     self._new(t, st)
