@@ -198,3 +198,40 @@ def test_smaller_demo_scripts_hold_under_the_real_evaluator(real, script):
     out, _, _ = real.run(lr.fold_repl_script(lr.demo_script(script)))
     t_digest = [int(x) for x in real.resolver.digest[("lurk", "t")]]
     assert list(out) == [lr.enums()["Tag"]["Sym"]] + [0] * 7 + t_digest
+
+
+def test_ingress_egress_round_trip_on_the_reference_s_own_samples(real):
+    """`test_ingress_egress` (/root/reference/src/core/eval_direct.rs:2067-2123): thirteen pieces of Lurk data, read here from that
+    test at run time; `ingress` (digest -> pointers, through the injected hash4 preimages) followed by `egress` gives the tag and
+    the digest back -- on the reference's two functions under the product's compiler and interpreter."""
+    import re
+
+    import measure_lurk_shape as ms
+    from lurk_amd import zstore as zs
+
+    src = lr._read("src/core/eval_direct.rs")
+    codes = [bytes(c, "utf-8").decode("unicode_escape") for c in re.findall(r'assert_ingress_egress_correctness\("((?:[^"\\]|\\.)*)"\)', src)]
+    assert len(codes) >= 13
+    i4 = real.top.func_index("hash4")
+    for code in codes:
+        z = zs.ZStore(real.hasher)
+        if code == "~()":          # the root symbol, the root keyword, a symbol of the root package: reader forms of the full parser
+            zp = z.intern_symbol([])
+        elif code == "~:()":
+            zp = z.intern_symbol([], keyword=True)
+        elif code.startswith(".") and len(code) > 1:
+            zp = z.intern_symbol([code[1:]])
+        elif code == "()":
+            zp = z.nil
+        else:
+            zp = ms.intern_syntax(z, lr.read_lurk(code))
+        q = real.lair.QueryRecord(real.top)
+        for pre, dig in z.hashes.items():
+            if len(pre) == 32:
+                q.inject_inv_query(i4, list(pre), list(dig))
+        args = [0] * 16
+        args[0] = zp.tag
+        args[8:] = zp.digest
+        ptr = real.top.execute_by_name("ingress", args, q)
+        back = real.top.execute_by_name("egress", list(ptr), q)
+        assert list(back) == [zp.tag] + list(zp.digest), code
