@@ -706,6 +706,61 @@ int32_t lurkhip_reduce_sums_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, int64_t* l
  * this rank proved) -> total[4], the machine-wide sum on every rank: a consistent proof set gives zero. */
 int32_t lurkhip_reduce_sums(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* local_sums, int32_t n_sums, uint32_t* total);
 
+/* ------------------------------------------------------------------- multi-GPU: ONE shard over G ranks */
+/* `Shard::shard` (/root/reference/src/lair/execute.rs:186-241) only cuts an execution above 2^22 rows, so
+ * `machine.prove::<LocalProver>` (/root/reference/benches/fib.rs:124, /root/reference/src/core/cli/repl.rs:196) of anything
+ * smaller is ONE shard: shard -> rank leaves all GPUs but one idle.  These entry points let G = 2, 4, 8 .. ranks prove one shard
+ * together and return, on every rank, the words lurkhip_shard_prove returns on one (second bullet):
+ * coset LDEs on column tiles, ONE all-to-all to contiguous storage-row blocks (lurk_amd/csrc/split_plan.h), leaf hashing and tree
+ * levels on the rank's rows, the G subtree roots all-gathered and the top log2 G levels computed by every rank; permutation traces
+ * by row blocks with the block totals of the running sum all-gathered; quotient values on the rank's rows; opened values as partial
+ * sums all-reduced (64-bit lanes, reduced mod p locally); reduced openings row-local, all-gathered, FRI on every rank; query rows
+ * and paths from the rank that owns them.
+ *
+ * The collectives are callbacks so that the host decides what carries them: lurkhip_comm_split_vtable fills the struct for an
+ * RCCL communicator of this library (device buffers stay on the device, everything enqueued on the context's stream); a test
+ * fills it with functions that stage through host memory and torch.distributed's gloo.  Every callback returns 0 or a negative
+ * status; all ranks call the same collectives in the same order.  `*_dev` pointers are device memory of the calling rank and
+ * `hip_stream` the stream the buffers were produced on: an implementation that leaves the device synchronises it first and
+ * returns with the result in place. */
+typedef struct lurkhip_split_comm {
+    int32_t rank, world; /* world: a power of two >= 2 */
+    void* user;
+    /* rank d receives send_dev[send_off[d] .. send_off[d + 1]) of every rank s at recv_dev[recv_off[s] ..]; offsets in 32-bit words */
+    int32_t (*alltoallv_dev)(void* user, const uint32_t* send_dev, const uint64_t* send_off, uint32_t* recv_dev, const uint64_t* recv_off,
+                             void* hip_stream);
+    int32_t (*allgather_dev)(void* user, const uint32_t* send_dev, uint32_t* recv_dev, uint64_t words_per_rank, void* hip_stream);
+    int32_t (*allgather_host)(void* user, const void* send, void* recv, uint64_t bytes_per_rank);
+    int32_t (*allreduce_sum_u64_host)(void* user, uint64_t* buf, uint64_t n);
+} lurkhip_split_comm;
+/* the four collectives on an RCCL communicator of lurkhip_comm_create (ncclSend / ncclRecv pairs, ncclAllGather, ncclAllReduce on
+ * the context's stream; the host variants stage through the context's pool).  `out->user` refers to ctx and comm: both must
+ * outlive every key / shard made with it. */
+int32_t lurkhip_comm_split_vtable(lurkhip_ctx* ctx, lurkhip_comm* comm, lurkhip_split_comm* out);
+/* lurkhip_setup / lurkhip_shard_commit_pitched / lurkhip_shard_prove for one shard over comm->world ranks.  Every rank passes the
+ * same arguments (the traces are the same on every rank: main traces are generated whole by every rank in this version, 2 % of a
+ * step); chips of at least 2^split_min_log_n rows (>= log2 world) are cut, the shorter ones are proved whole by every rank.
+ * The struct is copied.  Roots, proofs and the challenger's final state are identical on every rank and equal to the one-rank
+ * entry points' (tests/test_split_gpu.py). */
+int32_t lurkhip_setup_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_prep,
+                            const uint32_t* const* prep_traces_dev, const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup,
+                            lurkhip_pk** out, uint32_t* root);
+int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_chips,
+                                   lurkhip_air* const* airs, const uint32_t* log_heights, const uint32_t* const* main_traces_dev,
+                                   const uint32_t* main_pitches, const int32_t* prep_indices, int32_t log_blowup, lurkhip_shard** out,
+                                   uint32_t* root);
+int32_t lurkhip_shard_prove_split(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
+                                  const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
+                                  lurkhip_proof** out);
+/* The index arithmetic of the two exchanges alone (host only; tests/test_split_plan.py runs it on host arrays over gloo with
+ * ragged widths).  Matrix i: 2^log_heights[i] x widths[i], kinds[i] = 0 every rank holds all rows, 1 rank r holds natural rows
+ * [r N / G, (r + 1) N / G), 2 chunk chunks[i] of a quotient of degree 2^lqds[i] held as the quotient kernel leaves it; n_next[i]
+ * next-row copies (of columns 0 ..) travel with exchange B.  Writes the plan as 64-bit words (layout: lurk_amd/split.py
+ * parse_plan) and returns their number, or a negative status; out may be NULL to size the buffer. */
+int64_t lurkhip_split_plan(int32_t world, int32_t rank, int32_t split_min_log_n, int32_t n_mats, const uint32_t* log_heights,
+                           const uint32_t* widths, const int32_t* kinds, const uint32_t* lqds, const uint32_t* chunks, const uint32_t* n_next,
+                           uint64_t* out, uint64_t capacity);
+
 /* ------------------------------------------------------------------- proof wire format */
 /* The reference's serialised proofs.  `CryptoProof { shard_proofs, verifier_version, depth }` with
  * `CryptoShardProof { commitment, opened_values, opening_proof, chip_ordering }` as `bincode::serialize` writes them

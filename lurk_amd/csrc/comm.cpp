@@ -24,6 +24,7 @@
 struct lurkhip_comm {
     ncclComm_t comm = nullptr;
     int rank = 0, world = 1;
+    lurkhip_ctx* split_ctx = nullptr;  // the context lurkhip_comm_split_vtable was asked for (pool and page-locked staging of the host collectives)
 };
 
 namespace lurkhip {
@@ -36,6 +37,11 @@ struct Rccl {
     ncclResult_t (*CommDestroy)(ncclComm_t) = nullptr;
     ncclResult_t (*AllGather)(const void*, void*, size_t, ncclDataType_t, ncclComm_t, hipStream_t) = nullptr;
     ncclResult_t (*AllReduce)(const void*, void*, size_t, ncclDataType_t, ncclRedOp_t, ncclComm_t, hipStream_t) = nullptr;
+    // one shard over several ranks (lurkhip_comm_split_vtable): the all-to-all is grouped point-to-point
+    ncclResult_t (*Send)(const void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*Recv)(void*, size_t, ncclDataType_t, int, ncclComm_t, hipStream_t) = nullptr;
+    ncclResult_t (*GroupStart)() = nullptr;
+    ncclResult_t (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(ncclResult_t) = nullptr;
     std::string why;
     std::string path;  // what was loaded (lurkhip_comm_library)
@@ -89,6 +95,10 @@ const Rccl& rccl() {
         r.CommDestroy = (decltype(r.CommDestroy))sym("ncclCommDestroy");
         r.AllGather = (decltype(r.AllGather))sym("ncclAllGather");
         r.AllReduce = (decltype(r.AllReduce))sym("ncclAllReduce");
+        r.Send = (decltype(r.Send))sym("ncclSend");
+        r.Recv = (decltype(r.Recv))sym("ncclRecv");
+        r.GroupStart = (decltype(r.GroupStart))sym("ncclGroupStart");
+        r.GroupEnd = (decltype(r.GroupEnd))sym("ncclGroupEnd");
         r.GetErrorString = (decltype(r.GetErrorString))sym("ncclGetErrorString");
     });
     return r;
@@ -262,6 +272,93 @@ int32_t lurkhip_reduce_sums_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, int64_t* l
     LH_RCCL(ctx, rccl().AllReduce(lanes_dev, lanes_dev, 4, ncclInt64, ncclSum, comm->comm, ctx->stream));
     hipLaunchKernelGGL(k_lanes_mod_p, dim3(1), dim3(64), 0, ctx->stream, (const long long*)lanes_dev, total_dev);
     LH_HIP(ctx, hipGetLastError());
+    return LURKHIP_OK;
+}
+
+// ---- the collectives of one shard over several ranks (include/lurkhip.h: lurkhip_split_comm) on this communicator
+namespace {
+int32_t sv_fail(lurkhip_comm* c, const char* what, ncclResult_t r) {
+    return set_error(c->split_ctx, LURKHIP_ERR_HIP, "%s failed on rank %d: %s", what, c->rank, rccl().GetErrorString ? rccl().GetErrorString(r) : "?");
+}
+int32_t sv_alltoallv_dev(void* user, const uint32_t* send, const uint64_t* soff, uint32_t* recv, const uint64_t* roff, void* stream) {
+    lurkhip_comm* c = (lurkhip_comm*)user;
+    const Rccl& r = rccl();
+    hipStream_t st = (hipStream_t)stream;
+    // this rank's own block stays on the device; the others as one group of sends and receives (xGMI is point to point: seven
+    // links per GPU, every pair its own)
+    const uint64_t own = soff[c->rank + 1] - soff[c->rank];
+    if (own && hipMemcpyAsync(recv + roff[c->rank], send + soff[c->rank], own * 4, hipMemcpyDeviceToDevice, st) != hipSuccess)
+        return set_error(c->split_ctx, LURKHIP_ERR_HIP, "all-to-all: the local block's copy failed");
+    ncclResult_t nr = r.GroupStart();
+    if (nr != ncclSuccess) return sv_fail(c, "ncclGroupStart", nr);
+    for (int k = 1; k < c->world && nr == ncclSuccess; k++) {
+        const int to = (c->rank + k) % c->world, from = (c->rank - k + c->world) % c->world;
+        const uint64_t ns = soff[to + 1] - soff[to], nrw = roff[from + 1] - roff[from];
+        if (ns) nr = r.Send(send + soff[to], ns, ncclUint32, to, c->comm, st);
+        if (nr == ncclSuccess && nrw) nr = r.Recv(recv + roff[from], nrw, ncclUint32, from, c->comm, st);
+    }
+    const ncclResult_t ne = r.GroupEnd();
+    if (nr != ncclSuccess) return sv_fail(c, "ncclSend / ncclRecv", nr);
+    if (ne != ncclSuccess) return sv_fail(c, "ncclGroupEnd", ne);
+    return 0;
+}
+int32_t sv_allgather_dev(void* user, const uint32_t* send, uint32_t* recv, uint64_t words, void* stream) {
+    lurkhip_comm* c = (lurkhip_comm*)user;
+    const ncclResult_t nr = rccl().AllGather(send, recv, words, ncclUint32, c->comm, (hipStream_t)stream);
+    return nr == ncclSuccess ? 0 : sv_fail(c, "ncclAllGather", nr);
+}
+// host buffers: staged through a pooled device block on the context's stream, waited for
+int32_t sv_allgather_host(void* user, const void* send, void* recv, uint64_t bytes) {
+    lurkhip_comm* c = (lurkhip_comm*)user;
+    lurkhip_ctx* ctx = c->split_ctx;
+    const uint64_t padded = (bytes + 3) & ~(uint64_t)3;
+    void* buf = nullptr;
+    LH_TRY(pool_alloc(ctx, padded * ((size_t)c->world + 1), &buf));
+    int32_t st = 0;
+    if (hipMemcpyAsync(buf, send, bytes, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = set_error(ctx, LURKHIP_ERR_HIP, "all-gather: upload failed");
+    if (st == 0) {
+        const ncclResult_t nr = rccl().AllGather(buf, (uint8_t*)buf + padded, padded / 4, ncclUint32, c->comm, ctx->stream);
+        if (nr != ncclSuccess) st = sv_fail(c, "ncclAllGather", nr);
+    }
+    std::vector<uint8_t> all(padded * (size_t)c->world);
+    if (st == 0 && (hipMemcpyAsync(all.data(), (uint8_t*)buf + padded, all.size(), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx) != hipSuccess))
+        st = set_error(ctx, LURKHIP_ERR_HIP, "all-gather: read-back failed");
+    for (int r = 0; r < c->world && st == 0; r++) memcpy((uint8_t*)recv + (size_t)r * bytes, all.data() + (size_t)r * padded, bytes);
+    pool_release(ctx, buf);
+    return st;
+}
+int32_t sv_allreduce_u64_host(void* user, uint64_t* data, uint64_t n) {
+    lurkhip_comm* c = (lurkhip_comm*)user;
+    lurkhip_ctx* ctx = c->split_ctx;
+    if (n == 0) return 0;
+    void* buf = nullptr;
+    LH_TRY(pool_alloc(ctx, n * 8, &buf));
+    int32_t st = 0;
+    if (hipMemcpyAsync(buf, data, n * 8, hipMemcpyHostToDevice, ctx->stream) != hipSuccess) st = set_error(ctx, LURKHIP_ERR_HIP, "all-reduce: upload failed");
+    if (st == 0) {
+        const ncclResult_t nr = rccl().AllReduce(buf, buf, n, ncclUint64, ncclSum, c->comm, ctx->stream);
+        if (nr != ncclSuccess) st = sv_fail(c, "ncclAllReduce", nr);
+    }
+    if (st == 0 && (hipMemcpyAsync(data, buf, n * 8, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess || stream_wait(ctx) != hipSuccess))
+        st = set_error(ctx, LURKHIP_ERR_HIP, "all-reduce: read-back failed");
+    pool_release(ctx, buf);
+    return st;
+}
+}  // namespace
+
+int32_t lurkhip_comm_split_vtable(lurkhip_ctx* ctx, lurkhip_comm* comm, lurkhip_split_comm* out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, comm && out, "null argument");
+    const Rccl& r = rccl();
+    if (!r.why.empty()) return set_error(ctx, LURKHIP_ERR_HIP, "%s", r.why.c_str());
+    comm->split_ctx = ctx;
+    out->rank = comm->rank;
+    out->world = comm->world;
+    out->user = comm;
+    out->alltoallv_dev = sv_alltoallv_dev;
+    out->allgather_dev = sv_allgather_dev;
+    out->allgather_host = sv_allgather_host;
+    out->allreduce_sum_u64_host = sv_allreduce_u64_host;
     return LURKHIP_OK;
 }
 

@@ -38,6 +38,20 @@ struct lurkhip_commitment {
     int early_level = -1;
     uint32_t* early_digests = nullptr;
     std::vector<void*> early_scratch;
+    // ---- a commitment made by G = 2^split_log_g ranks together (split.hip; 0: an ordinary commitment).  log_h / log_max stay the
+    // GLOBAL heights.  A matrix taller than G rows is "local": lde[i] holds only this rank's 2^(log_h[i] - split_log_g) storage rows,
+    // starting at global row split_rank << (log_h[i] - split_log_g); digests / level_off describe the LOCAL subtree over them
+    // (log_max - split_log_g levels).  The other matrices ("tiny", at most G rows) are whole on every rank and enter the tree in its
+    // top split_log_g levels, which every rank computes on the host from the all-gathered subtree roots.
+    int split_log_g = 0, split_rank = 0;
+    std::vector<uint32_t*> full_lde;                  // per matrix: the whole LDE when this rank has it (small chips: computed by every rank), else null
+    std::vector<uint32_t> next_off;                   // per matrix: words from a local row's first column to its next-row copies (0: none)
+    std::vector<std::vector<uint32_t>> top_levels_m;  // host, Montgomery: top_levels_m[t] = the G >> t final node digests t levels above the subtree roots
+    std::vector<std::vector<uint32_t>> tiny_rows_m;   // host, Montgomery: the tiny matrices' LDE rows (dense), empty for the others
+    lurkhip_commitment* aux = nullptr;                // owns the LDE buffers of the small chips' matrices
+    bool is_local(int m) const { return split_log_g > 0 && log_h[m] > split_log_g; }
+    int rows_log(int m) const { return is_local(m) ? log_h[m] - split_log_g : log_h[m]; }  // log2 of the rows at lde[m]
+    size_t row_base(int m) const { return is_local(m) ? (size_t)split_rank << rows_log(m) : 0; }  // global storage row of lde[m]'s first row
 };
 
 namespace lurkhip {
@@ -166,7 +180,10 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
                     bool padded_groups = false /* the prover's own commitments: height groups in one aligned-pitch buffer (lurkhip_commitment::pitch) */,
                     const uint32_t* src_pitches = nullptr /* words between rows of mats[i] (device matrices only; null: widths[i]) */,
                     const std::vector<ColumnRuns>* live_runs = nullptr /* per matrix: the ascending, disjoint (first column, width) runs outside
-                    which the matrix is identically zero -- those columns' extension is zero-filled instead of computed */);
+                    which the matrix is identically zero -- those columns' extension is zero-filled instead of computed */,
+                    bool lde_only = false /* stop after the extension: no tree, no root (split.hip hashes row blocks it receives from other ranks) */);
+// the Merkle tree over c's matrices as they are (build_tree: every level into c->digests / level_off)
+int32_t commitment_build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c);
 // Row pitches for the matrices of a commitment-to-be (the prover's own traces): the matrices of one height that the grouped LDE
 // takes become column ranges of ONE buffer [N][pitch], pitch = the group's width rounded up to a 128-byte line, when that costs at
 // most half more memory (transient scratch whose padding is never read); otherwise a matrix keeps its own dense buffer.

@@ -199,6 +199,8 @@ int32_t lde_batch(lurkhip_ctx* ctx, int log_n, int w, int log_blowup, int n_batc
 
 void free_commitment(lurkhip_ctx* ctx, lurkhip_commitment* c) {
     if (!c) return;
+    if (c->aux) free_commitment(ctx, c->aux);
+    c->aux = nullptr;
     for (void* p : c->early_scratch) pool_release(ctx, p);
     c->early_scratch.clear();
     if (c->early_level > 0) pool_release(ctx, c->early_digests);  // (an early sponge whose tree was never built)
@@ -560,6 +562,8 @@ int32_t commit_raw(lurkhip_ctx* ctx, const std::vector<uint32_t*>& mats, const s
     return LURKHIP_OK;
 }
 
+int32_t commitment_build_tree(lurkhip_ctx* ctx, lurkhip_commitment* c) { return build_tree(ctx, c); }
+
 int32_t commitment_root_m(lurkhip_ctx* ctx, const lurkhip_commitment* c, uint32_t* root_m) {
     void* pin = nullptr;
     LH_TRY(pinned_small(ctx, &pin));
@@ -629,7 +633,7 @@ void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widt
 int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mats, bool mats_on_host,
                     const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup, int32_t repr,
                     int32_t keep_coeffs, lurkhip_commitment** out, uint32_t* root, const uint32_t* shifts, bool raw, bool padded_groups,
-                    const uint32_t* src_pitches, const std::vector<ColumnRuns>* live_runs) {
+                    const uint32_t* src_pitches, const std::vector<ColumnRuns>* live_runs, bool lde_only) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_mats > 0 && mats && log_heights && widths && out, "bad commit arguments");
     LH_ARG(ctx, !src_pitches || !mats_on_host, "row pitches are for device-resident matrices");
@@ -889,7 +893,7 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     static const int early_mode = getenv("LURKHIP_EARLY_SPONGE") ? atoi(getenv("LURKHIP_EARLY_SPONGE")) : 0;
     static const bool early_on = early_mode != 0;
     int chain_log_n = -1;
-    if (early_on && lane.active && groups.size() >= 2) {
+    if (early_on && !lde_only && lane.active && groups.size() >= 2) {
         std::map<int, uint32_t> width_of;  // per height, grouped matrices only
         std::map<int, bool> all_grouped;
         for (int i = 0; i < n_mats; i++) {
@@ -1020,6 +1024,10 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
     for (void* u : uploads) pool_release(ctx, u);
     uploads.clear();
     span_end(ctx, "lde");
+    if (lde_only) {
+        *out = c;
+        return LURKHIP_OK;
+    }
     TRY_C(build_tree(ctx, c));
     if (root) {
         uint32_t r[8];

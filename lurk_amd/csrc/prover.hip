@@ -29,6 +29,7 @@
 #include "commit.h"
 #include "ctx.h"
 #include "fri.h"
+#include "split.h"
 #include "stark.h"
 
 using namespace lurkhip;
@@ -44,6 +45,7 @@ struct lurkhip_pk {
     std::vector<uint32_t> log_heights, widths;
     uint32_t root_m[8] = {};
     int log_blowup = 1;
+    SplitEnv split;                              // lurkhip_setup_split: the key's commitment is this rank's part of it
 };
 
 struct lurkhip_shard {
@@ -56,6 +58,7 @@ struct lurkhip_shard {
     lurkhip_commitment* main_commit = nullptr;
     uint32_t root_m[8] = {};
     int log_blowup = 1;
+    SplitEnv split;                              // lurkhip_shard_commit_split: one shard proved by several ranks together
 };
 
 struct lurkhip_proof {
@@ -259,6 +262,85 @@ int32_t lurkhip_shard_commit_pitched(lurkhip_ctx* ctx, int32_t n_chips, lurkhip_
     return LURKHIP_OK;
 }
 
+// ------------------------------------------------------------------ one shard over several ranks (include/lurkhip.h; split.hip)
+int32_t lurkhip_setup_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_prep,
+                            const uint32_t* const* prep_traces_dev, const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup,
+                            lurkhip_pk** out, uint32_t* root) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, out && n_prep >= 0 && (n_prep == 0 || (prep_traces_dev && log_heights && widths)), "bad setup arguments");
+    SplitEnv env;
+    LH_TRY(split_env_init(ctx, comm, split_min_log_n, &env));
+    auto* pk = new lurkhip_pk();
+    pk->log_blowup = log_blowup;
+    pk->split = env;
+    std::vector<SplitMat> sm;
+    for (int i = 0; i < n_prep; i++) {
+        if (i && log_heights[i] > log_heights[i - 1]) {
+            delete pk;
+            return set_error(ctx, LURKHIP_ERR_INVALID_ARG, "pass the preprocessed traces sorted by height, tallest first");
+        }
+        pk->traces.push_back(prep_traces_dev[i]);
+        pk->log_heights.push_back(log_heights[i]);
+        pk->widths.push_back(widths[i]);
+        sm.push_back(SplitMat{prep_traces_dev[i], log_heights[i], widths[i], widths[i], 0u, split::K_FULL, 0u, 0u, 0u, 0u});
+    }
+    if (n_prep > 0) {
+        const int32_t s = split_commit(ctx, env, n_prep, sm.data(), log_blowup, &pk->commit, pk->root_m);
+        if (s != LURKHIP_OK) {
+            delete pk;
+            return s;
+        }
+    }
+    if (root)
+        for (int i = 0; i < 8; i++) root[i] = bb::from_monty(pk->root_m[i]);
+    *out = pk;
+    return LURKHIP_OK;
+}
+
+int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_chips,
+                                   lurkhip_air* const* airs, const uint32_t* log_heights, const uint32_t* const* main_traces_dev,
+                                   const uint32_t* main_pitches, const int32_t* prep_indices, int32_t log_blowup, lurkhip_shard** out,
+                                   uint32_t* root) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, n_chips > 0 && airs && log_heights && main_traces_dev && out, "bad shard arguments");
+    SplitEnv env;
+    LH_TRY(split_env_init(ctx, comm, split_min_log_n, &env));
+    for (int i = 0; i < n_chips; i++) {
+        LH_ARG(ctx, airs[i] && (!main_pitches || main_pitches[i] >= air_of(airs[i]).width), "chip %d: row pitch below its width", i);
+        LH_ARG(ctx, !air_reads_prep_next(airs[i]), "chip %d reads a preprocessed column on the next row: not supported over several ranks", i);
+    }
+    auto* sh = new lurkhip_shard();
+    sh->log_blowup = log_blowup;
+    sh->split = env;
+    std::vector<int> order(n_chips);
+    std::iota(order.begin(), order.end(), 0);
+    std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_heights[a] > log_heights[b]; });
+    std::vector<SplitMat> sm;
+    for (int i : order) {
+        const lair::ChipAir& air = air_of(airs[i]);
+        sh->airs.push_back(airs[i]);
+        sh->machine_index.push_back(i);
+        sh->log_n.push_back(log_heights[i]);
+        sh->main.push_back(main_traces_dev[i]);
+        sh->prep_index.push_back(prep_indices ? prep_indices[i] : -1);
+        sh->main_pitch.push_back(main_pitches ? main_pitches[i] : air.width);
+        // the columns a chip's constraints read on the next row travel to the rank that owns the row (QuotientArgs::next_off)
+        sm.push_back(SplitMat{main_traces_dev[i], log_heights[i], air.width, sh->main_pitch.back(), 0u, split::K_FULL, 0u, 0u, air_next_columns(airs[i]),
+                              air.log_quotient_degree()});
+    }
+    span_begin(ctx, "commit_main");
+    const int32_t s = split_commit(ctx, env, n_chips, sm.data(), log_blowup, &sh->main_commit, sh->root_m);
+    span_end(ctx, "commit_main");
+    if (s != LURKHIP_OK) {
+        delete sh;
+        return s;
+    }
+    if (root)
+        for (int i = 0; i < 8; i++) root[i] = bb::from_monty(sh->root_m[i]);
+    *out = sh;
+    return LURKHIP_OK;
+}
+
 int32_t lurkhip_shard_free(lurkhip_ctx* ctx, lurkhip_shard* sh) {
     LH_CHECK_CTX_NOLOCK(ctx);
     if (!sh) return LURKHIP_OK;
@@ -284,6 +366,7 @@ struct OpenOut {
     std::vector<uint32_t> round_record_words, layer_record_words;
     std::vector<size_t> round_off, layer_off;  // word offsets into rec_host
     const uint32_t* rec_host = nullptr;        // page-locked staging of the context: read it before the next call on the context
+    std::vector<std::vector<uint32_t>> round_records;  // split commitments: round r's records assembled on the host (else empty: rec_host + round_off[r])
     size_t rec_words = 0;
     int log_max = 0;
     size_t n_layers = 0;
@@ -292,7 +375,13 @@ struct OpenOut {
 
 static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& prof, const std::vector<Round>& rounds,
                              const std::vector<ef>& pts, int log_blowup, Challenger& ch, uint32_t num_queries, uint32_t pow_bits,
-                             std::vector<lurkhip_commitment*>& to_free, std::vector<void*>& pooled, OpenOut& out) {
+                             std::vector<lurkhip_commitment*>& to_free, std::vector<void*>& pooled, OpenOut& out, const SplitEnv* sp = nullptr) {
+    // One shard over several ranks (sp): a commitment holds this rank's storage rows of every matrix taller than G rows
+    // (lurkhip_commitment::is_local).  A polynomial of degree < N is as well interpolated from its 2N values on the whole LDE coset
+    // as from the N on the low one, so every rank sums its rows against the weights of the 2N-point domain and the partial sums are
+    // all-reduced; the reduced openings are row-local and all-gathered; FRI then runs on every rank.
+    auto bary_log = [&](const lurkhip_commitment* c, int m) { return c->is_local(m) ? c->log_h[m] : c->log_h[m] - log_blowup; };
+    auto dot_rows = [&](const lurkhip_commitment* c, int m) { return (size_t)1 << (c->is_local(m) ? c->rows_log(m) : c->log_h[m] - log_blowup); };
     auto palloc = [&](size_t bytes, uint32_t** p) -> int32_t {
         void* v = nullptr;
         int32_t s = pool_alloc(ctx, bytes, &v);
@@ -345,7 +434,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         // per-block partial sums of every matrix in one buffer, summed by one launch at the end
         size_t partial_words = 0;
         for (const Round& r : rounds)
-            for (int m = 0; m < r.c->n_mats; m++) partial_words += column_dot_partial_words(r.c->width[m], (size_t)1 << (r.c->log_h[m] - log_blowup));
+            for (int m = 0; m < r.c->n_mats; m++) partial_words += column_dot_partial_words(r.c->width[m], dot_rows(r.c, m));
         uint32_t* partials = nullptr;
         PTRY(palloc(std::max<size_t>(partial_words, 4) * 4, &partials));
         std::vector<DotJob> jobs;
@@ -365,7 +454,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             for (const Round& r : rounds)
                 for (int m = 0; m < r.c->n_mats; m++)
                     for (int pt : r.points[m]) {
-                        PTRY(want(bary, 0, r.c->log_h[m] - log_blowup, pt));
+                        PTRY(want(bary, 0, bary_log(r.c, m), pt));
                         PTRY(want(denoms, 1, r.c->log_h[m], pt));
                     }
             PTRY(point_weights_batch(ctx, wjobs));
@@ -380,16 +469,19 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 const int log_n = r.c->log_h[m] - log_blowup;
                 const std::vector<int>& mp = r.points[m];
                 uint32_t *u0 = nullptr, *u1 = nullptr;
-                PTRY(get_weights(bary, 0, log_n, mp[0], &u0));
-                if (mp.size() > 1) PTRY(get_weights(bary, 0, log_n, mp[1], &u1));
+                PTRY(get_weights(bary, 0, bary_log(r.c, m), mp[0], &u0));
+                if (mp.size() > 1) PTRY(get_weights(bary, 0, bary_log(r.c, m), mp[1], &u1));
+                u0 += r.c->row_base(m) * 4;  // (this rank's rows of the table; 0 unless the commitment is split)
+                if (u1) u1 += r.c->row_base(m) * 4;
+                const size_t n_rows = dot_rows(r.c, m);
                 if (column_dot_is_narrow(r.c->width[m])) {
-                    narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], (size_t)1 << log_n, u0, u1, partials + at, r.c->pitch[m]});
+                    narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], n_rows, u0, u1, partials + at, r.c->pitch[m]});
                 } else {
                     const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N, (uint32_t)k);
-                    PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], r.c->pitch[m], (size_t)1 << log_n, u0, u1, partials + at));
+                    PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], r.c->pitch[m], n_rows, u0, u1, partials + at));
                 }
-                jobs.push_back(DotJob{partials + at, r.c->width[m], (size_t)1 << log_n, (uint32_t)dot_off[k], u1 != nullptr});
-                at += column_dot_partial_words(r.c->width[m], (size_t)1 << log_n);
+                jobs.push_back(DotJob{partials + at, r.c->width[m], n_rows, (uint32_t)dot_off[k], u1 != nullptr});
+                at += column_dot_partial_words(r.c->width[m], n_rows);
             }
         PTRY(column_dot_partial_batch(ctx, narrow));
         PTRY(lane.close());
@@ -399,6 +491,20 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     PTRY(host_staging(ctx, dot_words * 4, (void**)&dot_host));
     PHIP(hipMemcpyAsync(dot_host, dot_out, dot_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     PHIP(stream_wait(ctx));
+    if (sp) {
+        // the ranks' partial sums, as 64-bit lanes of Montgomery words (< p each: G of them cannot overflow), reduced mod p here;
+        // a matrix of at most G rows is whole on every rank: only rank 0's sum of it counts
+        std::vector<uint64_t> lanes(dot_words);
+        size_t k = 0;
+        for (const Round& r : rounds)
+            for (int m = 0; m < r.c->n_mats; m++, k++) {
+                const size_t n = (size_t)2 * r.c->width[m] * 4;
+                const bool mine = r.c->is_local(m) || sp->rank == 0;
+                for (size_t j = 0; j < n; j++) lanes[dot_off[k] + j] = mine ? dot_host[dot_off[k] + j] : 0u;
+            }
+        PTRY(split_allreduce_u64_host(ctx, *sp, lanes.data(), lanes.size()));
+        for (size_t j = 0; j < dot_words; j++) dot_host[j] = (uint32_t)(lanes[j] % bb::P);
+    }
     // phase 2: opened values on the host: y = (z^N - g^N) / (N g^(N-1)) * sum
     // per round, per matrix, per point: ys[c] (Montgomery)
     auto& opened = out.opened;
@@ -429,7 +535,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 const std::vector<int>& mp = r.points[m];
                 opened[ri][m].resize(mp.size());
                 for (size_t p = 0; p < mp.size(); p++) {
-                    const ef factor = factor_of(r.c->log_h[m] - log_blowup, mp[p]);
+                    const ef factor = factor_of(bary_log(r.c, m), mp[p]);
                     std::vector<ef>& ys = opened[ri][m][p];
                     ys.resize(w);
                     for (uint32_t c = 0; c < w; c++) {
@@ -511,12 +617,15 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 const std::vector<ef>& ys = opened[ri][m][p];
                 for (uint32_t c = 0; c < w; c++) reduced_ys[p] = bb::ef_add(reduced_ys[p], bb::ef_mul(alpha_pows_host[c], ys[c]));
             }
+            const uint32_t ro_rows = 1u << r.c->rows_log(m);  // (this rank's rows of the height; all of them unless the commitment is split)
             if (!ro[log_h]) {
-                PTRY(palloc(((size_t)16) << log_h, &ro[log_h]));
-                PHIP(hipMemsetAsync(ro[log_h], 0, ((size_t)16) << log_h, ctx->stream));
+                PTRY(palloc((size_t)16 * ro_rows, &ro[log_h]));
+                PHIP(hipMemsetAsync(ro[log_h], 0, (size_t)16 * ro_rows, ctx->stream));
             }
             PTRY(get_weights(denoms, 1, log_h, mp[0], &d0));
             if (mp.size() > 1) PTRY(get_weights(denoms, 1, log_h, mp[1], &d1));
+            d0 += r.c->row_base(m) * 4;
+            if (d1) d1 += r.c->row_base(m) * 4;
             // p3 keeps one alpha-power offset per LDE height (num_reduced[log_height]); fri_alpha_global: one for all heights
             uint64_t& offset = num_reduced[prof.fri_alpha_global ? 0 : log_h];
             const ef apow0 = ef_pow_host(alpha_fri, offset);
@@ -526,7 +635,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_rows(g));  // a different second point: its own launch
                 if (g.n_mats == 0) {
                     g = RowsArgs{};
-                    g.m_rows = 1u << log_h;
+                    g.m_rows = ro_rows;
                     g.alpha_pows = alpha_pows_c;
                     g.d0 = d0;
                     g.ro = ro[log_h];
@@ -543,7 +652,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                         g.wa = WideArgs{};
                         g.wa.mat = r.c->group_base[r.c->group[m]];
                         g.wa.w = r.c->pitch[m];
-                        g.wa.m_rows = 1u << log_h;
+                        g.wa.m_rows = ro_rows;
                         g.wa.alpha_pows = alpha_pows_c;
                         g.wa.d0 = d0;
                         g.wa.d1 = d1;
@@ -565,7 +674,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             } else if (w <= NARROW_MAX_W && alpha_pows_c) {
                 NarrowArgs& g = narrow[{log_h, mp[0]}];
                 if (g.n_mats && g.d1 && d1 && g.d1 != d1) PTRY(flush_narrow(g));  // a different second point: its own launch
-                if (g.n_mats == 0) g = NarrowArgs{{}, 0, 1u << log_h, alpha_pows_c, d0, nullptr, ro[log_h]};
+                if (g.n_mats == 0) g = NarrowArgs{{}, 0, ro_rows, alpha_pows_c, d0, nullptr, ro[log_h]};
                 if (d1) g.d1 = d1;  // one second point per height (the first point's successor on that domain)
                 g.m[g.n_mats++] = NarrowMat{r.c->lde[m], w, d1 ? 1u : 0u, reduced_ys[0], reduced_ys[1], apow0, apow1, r.c->pitch[m]};
                 if (g.n_mats == NARROW_MAX_MATS) PTRY(flush_narrow(g));
@@ -575,7 +684,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 WideArgs wa{};
                 wa.mat = r.c->lde[m];
                 wa.w = w;
-                wa.m_rows = 1u << log_h;
+                wa.m_rows = ro_rows;
                 wa.alpha_pows = alpha_pows_c;
                 wa.d0 = d0;
                 wa.d1 = d1;
@@ -597,7 +706,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 }
                 PTRY(reduce_openings_wide(ctx, wa));
             } else {
-                PTRY(reduce_openings(ctx, r.c->lde[m], w, 1u << log_h, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
+                PTRY(reduce_openings(ctx, r.c->lde[m], w, ro_rows, alpha_pows, alpha_pows_c, d0, d1, reduced_ys[0], reduced_ys[1], apow0, apow1, ro[log_h]));
             }
             offset += (uint64_t)mp.size() * w;
         }
@@ -615,6 +724,15 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         PTRY(flush_group(kv.second));
     }
     PTRY(ro_lane.close());
+    if (sp) {  // every rank's rows of the reduced openings -> the whole vectors on every rank
+        for (int lh = sp->log_g + 1; lh < 32; lh++) {
+            if (!ro[lh]) continue;
+            uint32_t* whole = nullptr;
+            PTRY(palloc((size_t)16 << lh, &whole));
+            PTRY(split_allgather_dev(ctx, *sp, ro[lh], whole, (uint64_t)4 << (lh - sp->log_g)));
+            ro[lh] = whole;
+        }
+    }
     span_end(ctx, "open");
 
     // ---- FRI commit phase
@@ -708,8 +826,42 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     layer_record_words.assign(layers.size(), 0);
     std::vector<std::vector<OpenMat>> round_mats(rounds.size());
     size_t rec_words = 0;
+    // A split commitment answers a query from the rank that owns its storage row: rows of the local matrices and the path inside
+    // the rank's subtree; the rows of the matrices of at most G rows and the top log2 G siblings are on every rank's host.
+    struct SplitRound {
+        std::vector<std::vector<uint32_t>> owned;  // per rank: the queries it answers
+        uint32_t local_words = 0;                  // words of a local record: local rows | local path
+        uint32_t local_rows_words = 0;
+        uint32_t* indices_dev = nullptr;
+    };
+    std::vector<SplitRound> split_rounds(rounds.size());
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         const lurkhip_commitment* c = rounds[ri].c;
+        if (c->split_log_g) {
+            SplitRound& sr = split_rounds[ri];
+            const uint32_t log_local = (uint32_t)(c->log_max - c->split_log_g);
+            uint32_t all_w = 0;
+            for (int m = 0; m < c->n_mats; m++) {
+                all_w += c->width[m];
+                if (c->is_local(m)) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->rows_log(m), c->pitch[m]});
+            }
+            PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, log_local, nullptr, num_queries, 0, nullptr, &sr.local_words));
+            sr.local_rows_words = sr.local_words - 8 * log_local;
+            round_record_words[ri] = all_w + 8 * (uint32_t)c->log_max;
+            sr.owned.assign((size_t)1 << c->split_log_g, {});
+            std::vector<uint32_t> mine;
+            for (uint32_t q = 0; q < num_queries; q++) {
+                const uint32_t ix = indices[q] >> (log_max - c->log_max);
+                sr.owned[ix >> log_local].push_back(q);
+                if ((int)(ix >> log_local) == c->split_rank) mine.push_back(ix & ((1u << log_local) - 1u));
+            }
+            if (!mine.empty()) {
+                PTRY(palloc(mine.size() * 4, &sr.indices_dev));
+                PTRY(upload_words(ctx, sr.indices_dev, mine.data(), mine.size()));
+            }
+            rec_words += mine.size() * sr.local_words;
+            continue;
+        }
         for (int m = 0; m < c->n_mats; m++) round_mats[ri].push_back(OpenMat{c->lde[m], c->width[m], (uint32_t)c->log_h[m], c->pitch[m]});
         PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &round_record_words[ri]));
         rec_words += (size_t)num_queries * round_record_words[ri];
@@ -731,6 +883,13 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         const lurkhip_commitment* c = rounds[ri].c;
         uint32_t rw = 0;
         round_off[ri] = rec_at;
+        if (c->split_log_g) {
+            const SplitRound& sr = split_rounds[ri];
+            const uint32_t n_mine = (uint32_t)sr.owned[(size_t)c->split_rank].size();
+            if (n_mine) PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)(c->log_max - c->split_log_g), sr.indices_dev, n_mine, 0, rec_dev + rec_at, &rw));
+            rec_at += (size_t)n_mine * sr.local_words;
+            continue;
+        }
         PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries, (uint32_t)(log_max - c->log_max),
                              rec_dev + rec_at, &rw));
         rec_at += (size_t)num_queries * rw;
@@ -751,6 +910,44 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         PHIP(hipMemcpyAsync((void*)rec_host, rec_dev, rec_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
     PHIP(stream_wait(ctx));
+    // the split rounds' records: every rank's answers gathered (padded to the largest count), then assembled query by query
+    out.round_records.assign(rounds.size(), {});
+    for (size_t ri = 0; ri < rounds.size() && sp; ri++) {
+        const lurkhip_commitment* c = rounds[ri].c;
+        if (!c->split_log_g) continue;
+        const SplitRound& sr = split_rounds[ri];
+        const int G = 1 << c->split_log_g;
+        const uint32_t log_local = (uint32_t)(c->log_max - c->split_log_g);
+        size_t most = 0;
+        for (const auto& o : sr.owned) most = std::max(most, o.size());
+        const size_t seg = std::max<size_t>(most * sr.local_words, 1);
+        std::vector<uint32_t> mine(seg, 0u), all(seg * (size_t)G);
+        const size_t n_mine = sr.owned[(size_t)c->split_rank].size();
+        if (n_mine) memcpy(mine.data(), rec_host + round_off[ri], n_mine * sr.local_words * 4);
+        PTRY(split_allgather_host(ctx, *sp, mine.data(), all.data(), seg * 4));
+        std::vector<uint32_t>& recs = out.round_records[ri];
+        recs.resize((size_t)num_queries * round_record_words[ri]);
+        for (int r = 0; r < G; r++)
+            for (size_t k = 0; k < sr.owned[(size_t)r].size(); k++) {
+                const uint32_t q = sr.owned[(size_t)r][k];
+                const uint32_t ix = indices[q] >> (log_max - c->log_max);
+                const uint32_t* loc = &all[(size_t)r * seg + k * sr.local_words];
+                uint32_t* o = &recs[(size_t)q * round_record_words[ri]];
+                memcpy(o, loc, (size_t)sr.local_rows_words * 4);
+                o += sr.local_rows_words;
+                for (int m = 0; m < c->n_mats; m++) {  // (after every local matrix in the committed order: the tree's heights descend)
+                    if (c->is_local(m)) continue;
+                    const uint32_t* row = c->tiny_rows_m[(size_t)m].data() + (size_t)(ix >> (c->log_max - c->log_h[m])) * c->width[m];
+                    for (uint32_t j = 0; j < c->width[m]; j++) *o++ = bb::from_monty(row[j]);
+                }
+                memcpy(o, loc + sr.local_rows_words, (size_t)8 * log_local * 4);
+                o += 8 * log_local;
+                for (int t = 0; t < c->split_log_g; t++) {
+                    const uint32_t* sib = &c->top_levels_m[(size_t)t][(size_t)(((ix >> log_local) >> t) ^ 1u) * 8];
+                    for (int j = 0; j < 8; j++) *o++ = bb::from_monty(sib[j]);
+                }
+            }
+    }
     span_end(ctx, "fri_query");
     out.rec_host = rec_host;
     out.rec_words = rec_words;
@@ -785,6 +982,14 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     }
 }
 
+int32_t lurkhip_shard_prove_split(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
+                                  const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
+                                  lurkhip_proof** out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, sh && sh->split.on(), "not a shard of lurkhip_shard_commit_split");
+    return lurkhip_shard_prove(ctx, pk, sh, chal, public_values, n_public, num_queries, pow_bits, out);
+}
+
 static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
                                 const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                                 lurkhip_proof** out) {
@@ -805,6 +1010,13 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     const lurkhip_protocol_profile prof = profile_of(ctx);
     Challenger& ch = chal->ch;
     const int n_chips = (int)sh->airs.size();
+    // One shard over several ranks (lurkhip_shard_commit_split): chips of at least 2^min_log_n rows are cut -- this rank computes
+    // their permutation rows for its block of trace rows and their quotient values for its block of LDE storage rows --, the shorter
+    // ones are proved whole by every rank; commitments are made by all ranks together (split.hip).  Every rank ends with the same words.
+    const SplitEnv* sp = sh->split.on() ? &sh->split : nullptr;
+    LH_ARG(ctx, pk->split.log_g == sh->split.log_g && pk->split.rank == sh->split.rank && pk->split.min_log_n == sh->split.min_log_n,
+           "the key and the shard were not made by the same set of ranks");
+    auto cut = [&](int i) { return sp != nullptr && (int)sh->log_n[i] >= sp->min_log_n; };
     const int log_blowup = sh->log_blowup;
     std::vector<lurkhip_commitment*> to_free;
     std::vector<void*> pooled;
@@ -887,7 +1099,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // columns out (commit_impl: live_runs) -- 42 % of the permutation cells of a real `(fib N)` shard.  LURKHIP_PERM_SPARSE_LDE=0: off.
     // (read per proof: a test switches it; LURKHIP_PERM_SPARSE_MIN_CELLS lowers the threshold below so that mid-sized test machines take the route)
     const char* sparse_env = getenv("LURKHIP_PERM_SPARSE_LDE");
-    const bool sparse_lde = sparse_env == nullptr || atoi(sparse_env) != 0;
+    const bool sparse_lde = (sparse_env == nullptr || atoi(sparse_env) != 0) && !sp;  // (split: a column's liveness would have to be agreed by all ranks)
     const char* min_cells_env = getenv("LURKHIP_PERM_SPARSE_MIN_CELLS");
     const uint64_t min_cells = min_cells_env ? (uint64_t)strtoull(min_cells_env, nullptr, 10) : ((uint64_t)1 << 22);
     uint32_t* live_dev = nullptr;
@@ -916,7 +1128,12 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // The permutation traces of one height are column ranges of one buffer with a 128-byte-aligned row pitch (plan_source_groups):
     // the first pass of their LDE then reads whole lines, like the main traces a caller lays out that way.
     std::vector<uint32_t> perm_pitch(n_chips), perm_col(n_chips);
-    {
+    if (sp) {  // a buffer per chip: a cut chip's holds this rank's block of rows only
+        for (int i = 0; i < n_chips; i++) {
+            perm_pitch[i] = perm_widths[i];
+            PTRY(palloc((((size_t)perm_pitch[i] << sh->log_n[i]) >> (cut(i) ? sp->log_g : 0)) * 4, &perm[i]));
+        }
+    } else {
         std::vector<int32_t> grp(n_chips);
         int32_t n_groups = 0;
         plan_source_groups(n_chips, sh->log_n.data(), perm_widths.data(), perm_pitch.data(), perm_col.data(), grp.data(), &n_groups);
@@ -930,6 +1147,14 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
+        if (cut(i)) {  // this rank's block of trace rows, its running sum from zero: the previous ranks' totals are added below
+            const size_t rows = h >> sp->log_g, r0 = (size_t)sp->rank * rows;
+            PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)rows, sh->main[i] + r0 * sh->main_pitch[i], prep ? prep + r0 * air_of(sh->airs[i]).prep_width : nullptr,
+                                        perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i], sh->main_pitch[i], perm_pitch[i], nullptr, /*starts_ready=*/true,
+                                        /*defer_scan=*/true));
+            PTRY(scan_ef_column(ctx, perm[i] + perm_widths[i] - 4, perm_pitch[i], rows));
+            continue;
+        }
         PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)h, sh->main[i], prep, perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i],
                                     sh->main_pitch[i], perm_pitch[i], live_dev ? live_dev + live_off[i] : nullptr, /*starts_ready=*/true,
                                     /*defer_scan=*/scan_is_one_chunk(h)));
@@ -939,7 +1164,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         std::vector<uint32_t*> cols;
         std::vector<uint32_t> strides, ns;
         for (int i = 0; i < n_chips; i++)
-            if (scan_is_one_chunk((size_t)1 << sh->log_n[i])) {
+            if (!cut(i) && scan_is_one_chunk((size_t)1 << sh->log_n[i])) {
                 cols.push_back(perm[i] + perm_widths[i] - 4);
                 strides.push_back(perm_pitch[i]);
                 ns.push_back(1u << sh->log_n[i]);
@@ -960,7 +1185,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             a.n = (uint32_t)std::min(GATHER_EF_MAX, n_chips - at);
             for (uint32_t k = 0; k < a.n; k++) {
                 const int i = at + (int)k;
-                a.src[k] = perm[i] + (((size_t)1 << sh->log_n[i]) - 1) * perm_pitch[i] + perm_widths[i] - 4;
+                a.src[k] = perm[i] + ((((size_t)1 << sh->log_n[i]) >> (cut(i) ? sp->log_g : 0)) - 1) * perm_pitch[i] + perm_widths[i] - 4;  // (a cut chip: the block's total)
             }
             hipLaunchKernelGGL(k_gather_ef, dim3(1), dim3(GATHER_EF_MAX * 4), 0, ctx->stream, a, cs_dev + (size_t)at * 4);
         }
@@ -985,6 +1210,27 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             }
         }
     }
+    if (sp) {
+        // the blocks' totals of every rank: a cut chip's running sum on this rank starts at the sum of the previous ranks' totals, its
+        // cumulative sum is the sum of all of them; the other chips' sums are every rank's own (equal) values
+        PHIP(stream_wait(ctx));
+        std::vector<uint32_t> all((size_t)n_chips * 4 * (size_t)sp->world());
+        PTRY(split_allgather_host(ctx, *sp, cs_host, all.data(), (uint64_t)n_chips * 16));
+        for (int i = 0; i < n_chips; i++) {
+            if (!cut(i)) {
+                cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
+                continue;
+            }
+            ef before = bb::ef_zero(), total = bb::ef_zero();
+            for (int r = 0; r < sp->world(); r++) {
+                const uint32_t* t = &all[((size_t)r * n_chips + i) * 4];
+                if (r == sp->rank) before = total;
+                total = bb::ef_add(total, ef{{t[0], t[1], t[2], t[3]}});
+            }
+            cumsum[i] = total;
+            if (sp->rank) PTRY(add_ef_to_column(ctx, perm[i] + perm_widths[i] - 4, perm_pitch[i], ((size_t)1 << sh->log_n[i]) >> sp->log_g, before.c));
+        }
+    }
     span_end(ctx, "permutation");
     // Round 5: the constraint-folding challenge on the device.  "Observe the permutation root, sample alpha" is what k_fri_challenge
     // does for a FRI layer; drawn there -- the host's transcript state uploaded as launch arguments --, alpha's powers are built
@@ -997,10 +1243,15 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // host waits for the permutation root the device is inside that commitment's chain of tree levels, and the quotient stage's
     // kernels (0.55 ms of kernel time on four lanes) take as long to run as to queue.  What a small proof waits for is the device.
     const char* dev_alpha_env = getenv("LURKHIP_DEV_ALPHA");
-    const bool dev_alpha = dev_alpha_env != nullptr && atoi(dev_alpha_env) != 0 && !prof.observe_chip_meta && !prof.constraint_alpha_ascending;
+    const bool dev_alpha = dev_alpha_env != nullptr && atoi(dev_alpha_env) != 0 && !prof.observe_chip_meta && !prof.constraint_alpha_ascending && !sp;
     lurkhip_commitment* perm_commit = nullptr;
     uint32_t perm_root_m[8];
     span_begin(ctx, "commit_perm");
+    if (sp) {
+        std::vector<SplitMat> sm(n_chips);
+        for (int i = 0; i < n_chips; i++) sm[i] = SplitMat{perm[i], sh->log_n[i], perm_widths[i], perm_pitch[i], 0u, cut(i) ? split::K_BLOCK : split::K_FULL, 0u, 0u, 0u, 0u};
+        PTRY(split_commit(ctx, *sp, n_chips, sm.data(), log_blowup, &perm_commit, perm_root_m));
+    } else
     PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
                      dev_alpha ? nullptr : perm_root_m, nullptr, false, /*padded_groups=*/true, perm_pitch.data(), live_dev ? &live_runs : nullptr));
     span_end(ctx, "commit_perm");
@@ -1027,7 +1278,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         PTRY(fri_challenge(ctx, ch_dev, root_dev, alpha_dev, root_copy_dev));
         PHIP(hipMemcpyAsync(root_alpha_host, root_copy_dev, 48, hipMemcpyDeviceToHost, ctx->stream));  // read with the quotient root
     } else {
-        for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
+        if (!sp)
+            for (int i = 0; i < n_chips; i++) cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
         ch.observe_digest_m(perm_root_m);
         if (prof.observe_chip_meta)  // ... and the cumulative sums before the constraint-folding challenge
             for (int i = 0; i < n_chips; i++) ch.observe_ef_m(cumsum[i]);
@@ -1038,6 +1290,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     std::vector<uint32_t*> qmats;
     std::vector<uint32_t> q_logn, q_widths, q_shifts;
     std::vector<int> q_chip;  // chip of each quotient chunk
+    std::vector<SplitMat> q_split;  // (sp) the chunks as split_commit takes them
     span_begin(ctx, "quotient_all");
     // tables a chip's quotient finds in the context's caches are written at first use on the stream that asks: ask on the main
     // stream, before the lanes fork (two chips of one height on two side lanes raced for the first proof of a context)
@@ -1065,20 +1318,40 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t qd = 1u << lqds[i];
         uint32_t* chunks = nullptr;
-        PTRY(palloc(h * qd * 16, &chunks));
-        const uint32_t* prep_lde = sh->prep_index[i] >= 0 ? pk->commit->lde[sh->prep_index[i]] : nullptr;
-        const uint32_t pitches[3] = {sh->main_commit->pitch[i], sh->prep_index[i] >= 0 ? pk->commit->pitch[sh->prep_index[i]] : 0u, perm_commit->pitch[i]};
-        PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], prep_lde, perm_commit->lde[i], perm_alpha, perm_beta, alpha,
-                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true, alpha_pows_all, public_m_dev,
-                           dev_alpha ? cs_dev + 4 * (size_t)i : nullptr));
+        const int pi = sh->prep_index[i];
+        const uint32_t pitches[3] = {sh->main_commit->pitch[i], pi >= 0 ? pk->commit->pitch[pi] : 0u, perm_commit->pitch[i]};
         const uint32_t wq = two_adic_generator_monty((int)(sh->log_n[i] + lqds[i]));
         const uint32_t wq_inv = pow_host(wq, bb::P - 2);
+        if (cut(i)) {
+            // this rank's storage rows of the LDEs are its rows of the quotient domain (the first N << lqd storage rows of the 2N)
+            const uint32_t log_rows = sh->log_n[i] + (uint32_t)log_blowup - (uint32_t)sp->log_g, rows = 1u << log_rows;
+            const uint64_t s_base = (uint64_t)sp->rank << log_rows, q_rows = (uint64_t)h << lqds[i];
+            const QuotientSplit qs{(uint32_t)s_base, s_base >= q_rows ? 0u : (uint32_t)std::min<uint64_t>(rows, q_rows - s_base), sh->main_commit->next_off[i], log_rows};
+            PTRY(palloc((size_t)rows * 16, &chunks));
+            PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], pi >= 0 ? pk->commit->lde[pi] : nullptr, perm_commit->lde[i], perm_alpha, perm_beta,
+                               alpha, cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true, alpha_pows_all, public_m_dev, nullptr,
+                               &qs));
+            for (uint32_t c = 0; c < qd; c++) {
+                q_split.push_back(SplitMat{chunks, sh->log_n[i], 4u, 4u, bb::from_monty(pow_host(wq_inv, c)), split::K_QUOTIENT, lqds[i], c, 0u, 0u});
+                q_chip.push_back(i);
+            }
+            continue;
+        }
+        PTRY(palloc(h * qd * 16, &chunks));
+        // (split, a chip that is not cut: every rank has its whole LDEs)
+        const uint32_t* main_lde = sp ? sh->main_commit->full_lde[i] : sh->main_commit->lde[i];
+        const uint32_t* perm_lde = sp ? perm_commit->full_lde[i] : perm_commit->lde[i];
+        const uint32_t* prep_lde = pi >= 0 ? (sp ? pk->commit->full_lde[pi] : pk->commit->lde[pi]) : nullptr;
+        PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], main_lde, prep_lde, perm_lde, perm_alpha, perm_beta, alpha,
+                           cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true, alpha_pows_all, public_m_dev,
+                           dev_alpha ? cs_dev + 4 * (size_t)i : nullptr));
         for (uint32_t c = 0; c < qd; c++) {
             qmats.push_back(chunks + (size_t)c * h * 4);
             q_logn.push_back(sh->log_n[i]);
             q_widths.push_back(4);
             q_shifts.push_back(bb::from_monty(pow_host(wq_inv, c)));  // generator / (generator * w_Q^c)
             q_chip.push_back(i);
+            if (sp) q_split.push_back(SplitMat{chunks + (size_t)c * h * 4, sh->log_n[i], 4u, 4u, q_shifts.back(), split::K_FULL, 0u, 0u, 0u, 0u});
         }
     }
     PTRY(lane.close());
@@ -1086,6 +1359,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     lurkhip_commitment* quot_commit = nullptr;
     uint32_t quot_root_m[8];
     span_begin(ctx, "commit_quotient");
+    if (sp) PTRY(split_commit(ctx, *sp, (int)q_split.size(), q_split.data(), log_blowup, &quot_commit, quot_root_m));
+    else
     PTRY(commit_impl(ctx, (int32_t)qmats.size(), qmats.data(), false, q_logn.data(), q_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0,
                      &quot_commit, quot_root_m, q_shifts.data(), false, /*padded_groups=*/true));
     span_end(ctx, "commit_quotient");
@@ -1137,13 +1412,13 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     {
         if (pts.empty()) pts.push_back(zeta);
         Round r{quot_commit, {}};
-        for (size_t m = 0; m < qmats.size(); m++) r.points.push_back({0});
+        for (size_t m = 0; m < q_chip.size(); m++) r.points.push_back({0});
         rounds.push_back(r);
     }
 
     // ---- p3 TwoAdicFriPcs::open (values at the points, reduced openings, FRI)
     OpenOut oo;
-    PTRY(pcs_open_impl(ctx, prof, rounds, pts, log_blowup, ch, num_queries, pow_bits, to_free, pooled, oo));
+    PTRY(pcs_open_impl(ctx, prof, rounds, pts, log_blowup, ch, num_queries, pow_bits, to_free, pooled, oo, sp));
     const auto& opened = oo.opened;
     const auto& layer_roots_m = oo.layer_roots_m;
     const ef final_poly = oo.final_poly;
@@ -1162,7 +1437,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     auto* proof = new lurkhip_proof();
     std::vector<uint32_t>& o = proof->words;
     o.insert(o.end(), {PROOF_MAGIC, (uint32_t)n_chips, (uint32_t)log_blowup, num_queries, pow_bits, n_public, (uint32_t)n_fri_layers,
-                       (uint32_t)log_max, (uint32_t)(pk->commit ? pk->traces.size() : 0), (uint32_t)qmats.size()});
+                       (uint32_t)log_max, (uint32_t)(pk->commit ? pk->traces.size() : 0), (uint32_t)q_chip.size()});
     for (int i = 0; i < n_chips; i++) {
         const lair::ChipAir& air = air_of(sh->airs[i]);
         o.insert(o.end(), {(uint32_t)sh->machine_index[i], sh->log_n[i], air.width, air.prep_width, perm_widths[i], 1u << lqds[i],
@@ -1186,7 +1461,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     for (size_t ri = 0; ri < rounds.size(); ri++) {
         o.push_back(round_record_words[ri]);
         const size_t n = (size_t)num_queries * round_record_words[ri];
-        o.insert(o.end(), rec_host + round_off[ri], rec_host + round_off[ri] + n);  // (canonical already: k_records_canonical)
+        if (!oo.round_records[ri].empty()) o.insert(o.end(), oo.round_records[ri].begin(), oo.round_records[ri].end());  // (a split commitment's, assembled on the host)
+        else o.insert(o.end(), rec_host + round_off[ri], rec_host + round_off[ri] + n);  // (canonical already: k_records_canonical)
     }
     for (size_t li = 0; li < n_fri_layers; li++) {
         o.push_back(layer_record_words[li]);

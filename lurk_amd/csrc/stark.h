@@ -47,6 +47,13 @@ int32_t scan_ef_columns_one_chunk(lurkhip_ctx* ctx, int n_cols, uint32_t* const*
 int32_t interaction_starts_batch(lurkhip_ctx* ctx, int n, lurkhip_air* const* airs, const bb::ef& alpha, const uint32_t* beta_pows, uint32_t* const* starts);
 
 uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd);  // stark.hip: written on the current stream at first use
+// One shard over several ranks: the quotient values of the n_rows storage rows from s_base on (stark_kernels.h: QuotientArgs::split).
+// The three LDE pointers point at storage row s_base; out_dev receives [2^log_rows][4] words in brev(local row) order.
+struct QuotientSplit {
+    uint32_t s_base, n_rows, next_off, log_rows;
+};
+uint32_t air_next_columns(const lurkhip_air* a);  // 1 + the highest main column the chip's constraints read on the next row (0: none)
+bool air_reads_prep_next(const lurkhip_air* a);
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev,
@@ -58,7 +65,8 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
                       order (ef_powers(.., centred = true, reversed = false)): one table for all chips of a proof; null: the call builds its own */,
                       const uint32_t* shared_public_m = nullptr /* the public values on the device, Montgomery; null: uploaded by the call */,
                       const uint32_t* cumsum_dev = nullptr /* the chip's cumulative sum on the device (4 words, Montgomery): read by the kernel
-                      instead of cumsum_m, which the host may not know yet (with shared_alpha_pows only) */);
+                      instead of cumsum_m, which the host may not know yet (with shared_alpha_pows only) */,
+                      const QuotientSplit* split = nullptr /* this rank's rows only (honest_running_sum required) */);
 int32_t ef_powers_dev(lurkhip_ctx* ctx, const uint32_t* base_dev /* 4 words, device */, uint32_t* out_dev, uint32_t count, bool centred, bool reversed = false);
 uint32_t air_total_constraints(const lurkhip_air* a);  // constraints + batch columns + the three running-sum constraints
 

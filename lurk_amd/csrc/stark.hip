@@ -735,12 +735,26 @@ uint32_t* selector_table_of(lurkhip_ctx* ctx, uint32_t log_n, uint32_t lqd) {
     return (uint32_t*)tbl;
 }
 
+uint32_t air_next_columns(const lurkhip_air* a) {
+    uint32_t n = 0;
+    for (const lair::Node& nd : a->air.nodes)
+        if (nd.kind == lair::N_MAIN_NEXT) n = std::max(n, nd.a + 1);
+    return n;
+}
+bool air_reads_prep_next(const lurkhip_air* a) {
+    for (const lair::Node& nd : a->air.nodes)
+        if (nd.kind == lair::N_PREP_NEXT) return true;
+    return false;
+}
+
 int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const uint32_t* main_lde_dev, const uint32_t* prep_lde_dev,
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
                       const uint32_t* shared_starts, const uint32_t* pitches, bool honest_running_sum, const uint32_t* shared_alpha_pows,
-                      const uint32_t* shared_public_m, const uint32_t* cumsum_dev) {
+                      const uint32_t* shared_public_m, const uint32_t* cumsum_dev, const QuotientSplit* split) {
     LH_ARG(ctx, !cumsum_dev || shared_alpha_pows, "a cumulative sum on the device goes with a shared table of alpha powers");
+    LH_ARG(ctx, !split || (honest_running_sum && getenv("LURKHIP_QUOTIENT_READ_NEXT_SUM") == nullptr), "a quotient on a rank's rows cannot read the next row's sums");
+    if (split && split->n_rows == 0) return LURKHIP_OK;  // the rank's rows lie outside this chip's quotient domain
     LH_ARG(ctx, a->air.prep_width == 0 || prep_lde_dev, "chip has preprocessed columns: pass their LDE");
     LH_ARG(ctx, a->air.num_public == 0 || public_values, "chip reads public values: pass them");
     const uint32_t lqd = a->air.log_quotient_degree();
@@ -840,7 +854,14 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
         q.regs_words = lay.regs_words;
         q.wp = lay.wp;
         q.staged = lay.staged ? 1 : 0;
-        const uint32_t rows = 1u << q.log_q;
+        if (split) {
+            q.split = 1;
+            q.s_base = split->s_base;
+            q.n_rows = split->n_rows;
+            q.next_off = split->next_off;
+            q.log_rows = split->log_rows;
+        }
+        const uint32_t rows = split ? split->n_rows : 1u << q.log_q;
         span_begin(ctx, "quotient", 2);
         if (jit.quotient) {
             void* params[] = {&q};

@@ -286,6 +286,12 @@ struct QuotientArgs {
     // cumulative_sum * trans_scale, trans_scale = -1 / (N w_N); null: the two fields above hold the values
     const uint32_t* cumsum_dev;
     uint32_t trans_scale;
+    // Round 6, one shard over several ranks (split.hip): the launch covers the n_rows storage rows from s_base on, of which the
+    // matrices hold exactly those (main / prep / perm point at storage row s_base); the few columns the AIR reads on the next row
+    // (nonce; is_real and ptr of a memory chip) travel as copies `next_off` words after the local row's first column, because the
+    // next row's storage row belongs to another rank; values go to out[brev(local row)][4], natural order inside the rank's
+    // sub-coset (split_plan.h: rows_of).  split = 0: the whole domain, as before.
+    uint32_t split, s_base, n_rows, next_off, log_rows;
 };
 
 struct QuotientSink {
@@ -390,21 +396,22 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const uint32_t wave = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6), lane = threadIdx.x & 63u;
     const uint32_t s_raw = blockIdx.x * 64u + lane;
     const uint32_t q = 1u << a.log_q;
-    const bool live = s_raw < q;
-    const uint32_t s = live ? s_raw : 0u;
+    const bool live = s_raw < (a.split ? a.n_rows : q);
+    const uint32_t sl = live ? s_raw : 0u;   // row of the launch's matrices
+    const uint32_t s = a.s_base + sl;        // storage row of the quotient domain (s_base = 0 unless split)
     const uint32_t lqd = a.log_q - a.log_n, qd = 1u << lqd;
     const uint32_t i = a.log_q ? (__brev(s) >> (32 - a.log_q)) : 0u;
     const uint32_t i_next = (i + qd) & (q - 1);
     const uint32_t s_next = a.log_q ? (__brev(i_next) >> (32 - a.log_q)) : 0u;
-    const uint32_t* main_l = a.main + (size_t)s * a.main_pitch;
-    const uint32_t* main_n = a.main + (size_t)s_next * a.main_pitch;
+    const uint32_t* main_l = a.main + (size_t)sl * a.main_pitch;
+    const uint32_t* main_n = a.split ? main_l + a.next_off : a.main + (size_t)s_next * a.main_pitch;
     uint32_t* tile_l = regs + a.regs_words;
     uint32_t* idx = tile_l + (a.staged ? 64u * a.wp : 0u);
     uint32_t* folds = idx + 64;  // [n_parts][64][4]
     if (a.staged) {
         // only the local rows are staged: the Lair AIRs read one or two columns of the next row (nonce, is_real, ptr),
         // which stay in global memory, and a second tile would halve the waves an LDS-bound CU can hold
-        if (wave == 0) idx[lane] = s;
+        if (wave == 0) idx[lane] = sl;
         __syncthreads();
         stage_rows(tile_l, a.wp, a.main, a.w, idx, 64u, a.main_pitch);
         __syncthreads();
@@ -428,9 +435,10 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
         is_last = bb::mul(zh, bb::inv(x_minus_last));
         is_trans = x_minus_last;
     }
-    airvm::Sources src{main_l, main_n, a.prep + (size_t)s * a.prep_pitch, a.prep + (size_t)s_next * a.prep_pitch, a.pub, {is_first, is_last, is_trans}};
-    const uint32_t* perm_l = a.perm + (size_t)s * a.perm_pitch;
-    const uint32_t* perm_n = a.perm + (size_t)s_next * a.perm_pitch;
+    // (split: no Lair AIR reads a preprocessed column on the next row -- the host refuses one that does --, and the running sum is honest)
+    airvm::Sources src{main_l, main_n, a.prep + (size_t)sl * a.prep_pitch, a.prep + (size_t)(a.split ? sl : s_next) * a.prep_pitch, a.pub, {is_first, is_last, is_trans}};
+    const uint32_t* perm_l = a.perm + (size_t)sl * a.perm_pitch;
+    const uint32_t* perm_n = a.perm + (size_t)(a.split ? sl : s_next) * a.perm_pitch;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.starts}, a.batch, perm_l};
     const uint32_t* prog = a.parts.prog[wave];
     const uint32_t first = prog[airp::H_FIRST_COLUMN];  // constraint piece: its first constraint; interaction piece: its first column
@@ -475,6 +483,7 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const ef quot = bb::ef_scale(folded, a.zh_inv[i & (qd - 1)]);
     const uint32_t chunk = i & (qd - 1), r = i >> lqd;
     uint4* dst = reinterpret_cast<uint4*>(a.out + ((size_t)chunk * ((size_t)1 << a.log_n) + r) * 4);
+    if (a.split) dst = reinterpret_cast<uint4*>(a.out + (size_t)(a.log_rows ? (__brev(sl) >> (32 - a.log_rows)) : 0u) * 4);
     *dst = make_uint4(quot.c[0], quot.c[1], quot.c[2], quot.c[3]);
 }
 
