@@ -266,6 +266,157 @@ def build_workload(name: str, world: int, log_rows: int):
     return mix.source, True, mix.entry, mix.main_args, "eval", desc
 
 
+XGMI_LINK_GBS = 153.0  # per link and direction, seven links per GPU (the task statement's figure; MI355X_MICROARCH.md)
+
+
+def split_intra(args, world, rank, device_index, distributed, oversubscribed):
+    """`--split intra`: ONE shard of 2^log_rows eval rows proved by all `world` ranks together (strong scaling).  A step = trace
+    generation (whole, on every rank in this version) + the shard proof made by the ranks together; every rank ends with the same
+    proof words, rank 0 verifies them after the timed region.  N = 1 runs the one-rank prover one proof at a time, so that the
+    N-rank lines divide by a number measured the same way."""
+    import torch
+    import torch.distributed as dist
+
+    import lurk_amd
+    from lurk_amd import lair, prover, split
+
+    ctx = lurk_amd.Context(device_index)
+    if args.profile != "default":
+        from lurk_amd.profile import ProtocolProfile
+
+        ProtocolProfile.preset(args.profile).install(ctx)
+    log_rows = args.log_rows if args.log_rows is not None else (18 if args.workload == "lurk-mix" else LOG_ROWS)
+    n = 1 << log_rows
+    source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, 1, log_rows)
+    top = lair.Toplevel(source, lurk_chips=lurk_chips)
+    # host side, once, on every rank: the traces of the one shard are generated whole by every rank (DESIGN.md 6)
+    t0 = time.perf_counter()
+    queries = lair.QueryRecord(top)
+    top.execute(top.func_index(entry), main_args, queries)
+    t_execute = time.perf_counter() - t0
+    assert queries.num_func_queries(top.func_index(eval_name)) == n
+    pv = queries.expect_public_values()
+    machine = prover.Machine(ctx, top, entry, len(pv))
+    vk_root = machine.setup()
+    prepared = machine.prepare_shard(lair.Shard.new(queries))
+    compiled = [] if args.no_compile else machine.compile_airs(prepared, min_log_rows=args.compile_min_log_rows)
+    if not args.no_compile and getattr(machine, "compile_failures", None):
+        raise SystemExit("bench.py: kernels that were to be compiled were not: " + "; ".join(f"{w}: {e}" for w, e in machine.compile_failures))
+    carrier, carrier_note, sp, comm_c = "one rank", None, None, None
+    if world > 1:
+        scomm = None
+        if not oversubscribed and not args.torch_collectives:
+            from lurk_amd.comm import bring_up
+
+            comm_c, carrier_note = bring_up(ctx)  # collectively, with a self-test; on failure every rank takes the host route together
+            if comm_c is not None:
+                scomm, carrier = split.RcclSplitComm(ctx, comm_c), "RCCL behind the C ABI (ncclSend / ncclRecv pairs, device buffers)"
+        if scomm is None:
+            group = None if oversubscribed else dist.new_group(backend="gloo")
+            scomm, carrier = split.TorchSplitComm(ctx, group), "torch.distributed gloo through host memory" + (" (several ranks share a device)" if oversubscribed else " (fall-back)")
+        sp = split.SplitProver(machine, scomm, args.split_min_log_rows)
+        assert sp.setup() == vk_root, "the ranks' verifying key differs from one rank's"
+
+    def step():
+        ctx.span_begin("trace_all")
+        traces = machine.run_prepared(prepared)
+        ctx.span_end("trace_all")
+        if sp is not None:
+            return sp.prove(traces, pv, args.queries, args.pow_bits)[0]
+        ch = prover.Challenger(ctx)
+        ch.observe(vk_root)
+        ch.observe([0])
+        handle, root = machine.commit_shard(traces)
+        ch.observe(root)
+        ch.observe(pv)
+        w = machine.prove_shard(handle, ch, pv, args.queries, args.pow_bits, parse=False)
+        machine.free_shard(handle)
+        return w
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    gc.collect()
+    gc.freeze()
+    fence()
+    for _ in range(args.warmup):
+        step()
+    # a short pass with the stage events on, for the per-rank stage table (outside the timed region)
+    ctx.profile_reset()
+    ctx.profile_enable(not args.no_spans)
+    n_span = max(2, min(4, args.steps))
+    for _ in range(n_span):
+        step()
+    fence()
+    ctx.profile_enable(False)
+    span_names = SPANS + ("split_exchange_a", "split_exchange_b")
+    stages = {k: round(v[0] / n_span, 3) for k, v in ((name, ctx.profile_read(name)) for name in span_names) if v[1]}
+    stats0 = np.zeros(3, dtype=np.uint64)
+    lurk_amd._native.lib.lurkhip_split_stats(ctx.handle, stats0.ctypes.data, 1)
+    fence()
+    t0 = time.perf_counter()
+    words = None
+    for _ in range(args.steps):
+        words = step()
+    fence()
+    dt = time.perf_counter() - t0
+    stats = np.zeros(3, dtype=np.uint64)
+    lurk_amd._native.lib.lurkhip_split_stats(ctx.handle, stats.ctypes.data, 0)
+    per_step = {"alltoall_bytes_sent_before_lde": int(stats[0]) // args.steps, "alltoall_bytes_sent_after_lde": int(stats[1]) // args.steps,
+                "alltoalls": int(stats[2]) // args.steps}
+    mine = {"rank": rank, "seconds": dt, "stages_ms": stages, **per_step, "proof_words": int(len(words)), "proof_crc": int(np.bitwise_xor.reduce(words.astype(np.uint32)))}
+    if distributed:
+        box = [None] * world
+        dist.all_gather_object(box, mine)
+    else:
+        box = [mine]
+    if rank == 0:
+        t_max = max(b["seconds"] for b in box)
+        verified = bool(machine.verify([words]))
+        identical = len({(b["proof_words"], b["proof_crc"]) for b in box}) == 1
+        sent = max(b["alltoall_bytes_sent_before_lde"] + b["alltoall_bytes_sent_after_lde"] for b in box)
+        per_link = sent / max(world - 1, 1)
+        line = {
+            "metric": "Lurk eval-steps proved/sec (fib trace) at 1/2/4/8 MI355X; bit-exact proof vs CPU", "value": n * args.steps / t_max, "unit": "eval-steps/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": t_max / args.steps * 1e3, "higher_is_better": True, "scaling": "strong",
+            "vs_baseline": None, "dtype": "u32", "data": "synthetic",
+            "config": {
+                "workload": f"{args.workload}: ONE shard of 2^{log_rows} eval rows (BASELINE configs[2]) proved by {world} rank(s) together (--split intra); "
+                            f"{args.queries} FRI queries, {args.pow_bits} PoW bits",
+                "workload_detail": workload_desc,
+                "split": {"min_log_rows": args.split_min_log_rows, "carrier": carrier, "carrier_note": carrier_note, "oversubscribed": bool(oversubscribed),
+                          "note": "chips of at least 2^min_log_rows rows: LDE on column tiles, ONE all-to-all to storage-row blocks per commitment (two for the permutation and "
+                                  "quotient commitments, whose rows are computed by row blocks), subtree roots all-gathered; main traces generated whole by every rank; FRI on every "
+                                  "rank from the all-gathered reduced openings (DESIGN.md 6)"},
+                "chips_compiled": len(compiled), "host_execute_s": t_execute,
+            },
+            "per_rank": [{k: b[k] for k in ("rank", "seconds", "stages_ms", "alltoall_bytes_sent_before_lde", "alltoall_bytes_sent_after_lde", "alltoalls")} for b in box],
+            "alltoall_bytes_per_rank_per_step": sent, "alltoall_bytes_per_link_per_step": per_link,
+            "xgmi_model_ms_per_step": per_link / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0,
+            "xgmi_model_note": f"bytes one rank sends to ONE peer per step / {XGMI_LINK_GBS} GB/s: the seven links of a GPU carry its seven peers' blocks side by side",
+            "proofs_identical_on_all_ranks": identical, "proof_verified": verified,
+            "roofline": None, "cpu_baseline": None,
+            "note": "roofline / cpu_baseline: see the N = 1 line of the default command (this mode adds no kernel: the same LDE, hashing and AIR kernels on a rank's share)",
+        }
+        if oversubscribed:
+            line["note"] += "; the ranks SHARE one device here: ms_per_step says nothing about scaling, only the stage spans, the bytes and the identity of the proofs do"
+        print(json.dumps(line))
+    if distributed:
+        dist.barrier()
+    if sp is not None:
+        sp.close()
+    if comm_c is not None:
+        comm_c.close()
+    machine.close()
+    ctx.close()
+    if distributed:
+        dist.destroy_process_group()
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -319,6 +470,12 @@ def main():
                          "resident set do not grow with N.  all: every rank executes the whole program (rounds 2-5)")
     ap.add_argument("--shards-per-rank", type=int, default=None,
                     help="distributed runs: shards of 2^log_rows / k eval rows, k per rank, dealt by work (default 2 when WORLD_SIZE > 1, else 1)")
+    ap.add_argument("--split", choices=("shards", "intra"), default="shards",
+                    help="how N > 1 ranks share the work.  shards (default): every rank proves its own shards of one N-times-larger execution (weak "
+                         "scaling, SURVEY.md 8e first bullet).  intra: ONE shard of 2^log_rows eval rows proved by all ranks together -- column-tile LDEs, "
+                         "one all-to-all to row blocks, subtree roots all-gathered (lurk_amd/split.py, csrc/split.hip): strong scaling, the case of "
+                         "every execution below the reference's default shard size of 2^22 rows")
+    ap.add_argument("--split-min-log-rows", type=int, default=12, help="--split intra: chips of at least 2^k rows are cut across the ranks, the shorter ones proved whole by every rank")
     args = ap.parse_args()
 
     import torch
@@ -368,6 +525,8 @@ def main():
     import lurk_amd
     from lurk_amd import lair, prover, shards
 
+    if args.split == "intra":
+        return split_intra(args, world, rank, device_index, distributed, oversubscribed)
     ctx = lurk_amd.Context(device_index)
     if args.profile != "default":
         from lurk_amd.profile import ProtocolProfile

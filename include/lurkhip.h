@@ -752,6 +752,9 @@ int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* c
 int32_t lurkhip_shard_prove_split(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
                                   const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                                   lurkhip_proof** out);
+/* out[0] / out[1] = bytes this rank has sent to other ranks in the all-to-alls before / after the LDEs, out[2] = the number of
+ * all-to-alls, since the context was created or last reset (the bench's bytes-per-link figure). */
+int32_t lurkhip_split_stats(lurkhip_ctx* ctx, uint64_t* out /* [3] */, int32_t reset);
 /* The index arithmetic of the two exchanges alone (host only; tests/test_split_plan.py runs it on host arrays over gloo with
  * ragged widths).  Matrix i: 2^log_heights[i] x widths[i], kinds[i] = 0 every rank holds all rows, 1 rank r holds natural rows
  * [r N / G, (r + 1) N / G), 2 chunk chunks[i] of a quotient of degree 2^lqds[i] held as the quotient kernel leaves it; n_next[i]

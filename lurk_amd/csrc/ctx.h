@@ -85,6 +85,9 @@ struct lurkhip_ctx {
     };
     std::map<std::string, Span> spans;
     std::vector<hipEvent_t> event_pool;
+    // one shard over several ranks (split.hip): words this rank sent to OTHER ranks in the all-to-alls before / after the LDEs, and
+    // the number of all-to-alls (lurkhip_split_stats)
+    uint64_t split_words_a = 0, split_words_b = 0, split_exchanges = 0;
 };
 
 namespace lurkhip {

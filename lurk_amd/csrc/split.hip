@@ -239,6 +239,8 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
         S_TRY(run_jobs(ctx, plan.a_pack, src, send, true, scratch));
         if (env.comm.alltoallv_dev(env.comm.user, send, plan.a_send_off.data(), recv, plan.a_recv_off.data(), (void*)ctx->stream) != 0)
             return done(set_error(ctx, LURKHIP_ERR_EXEC, "split: the all-to-all before the LDE failed on rank %d", rank));
+        ctx->split_words_a += plan.a_send_off.back() - (plan.a_send_off[(size_t)rank + 1] - plan.a_send_off[(size_t)rank]);
+        ctx->split_exchanges++;
         std::vector<BufRef> dst(plan.groups.size());
         for (size_t g = 0; g < plan.groups.size(); g++) {
             if (plan.slab_w[g]) S_TRY(salloc((size_t)plan.slab_w[g] << plan.groups[g].log_n, &slab[g]));
@@ -299,6 +301,8 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
         S_TRY(run_jobs(ctx, plan.b_pack, tile_out, send, true, scratch));
         if (env.comm.alltoallv_dev(env.comm.user, send, plan.b_send_off.data(), recv, plan.b_recv_off.data(), (void*)ctx->stream) != 0)
             return done(set_error(ctx, LURKHIP_ERR_EXEC, "split: the all-to-all after the LDE failed on rank %d", rank));
+        ctx->split_words_b += plan.b_send_off.back() - (plan.b_send_off[(size_t)rank + 1] - plan.b_send_off[(size_t)rank]);
+        ctx->split_exchanges++;
         std::vector<BufRef> dst(plan.groups.size());
         for (size_t g = 0; g < plan.groups.size(); g++) {
             const size_t words = (size_t)plan.groups[g].local_pitch * ((size_t)(2u << plan.groups[g].log_n) >> log_g);
@@ -455,6 +459,16 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
 }  // namespace lurkhip
 
 using namespace lurkhip;
+
+extern "C" int32_t lurkhip_split_stats(lurkhip_ctx* ctx, uint64_t* out, int32_t reset) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, out != nullptr, "null argument");
+    out[0] = ctx->split_words_a * 4;
+    out[1] = ctx->split_words_b * 4;
+    out[2] = ctx->split_exchanges;
+    if (reset) ctx->split_words_a = ctx->split_words_b = ctx->split_exchanges = 0;
+    return LURKHIP_OK;
+}
 
 extern "C" int64_t lurkhip_split_plan(int32_t world, int32_t rank, int32_t split_min_log_n, int32_t n_mats, const uint32_t* log_heights,
                                       const uint32_t* widths, const int32_t* kinds, const uint32_t* lqds, const uint32_t* chunks, const uint32_t* n_next,
