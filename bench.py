@@ -271,7 +271,7 @@ XGMI_LINK_GBS = 153.0  # per link and direction, seven links per GPU (the task s
 
 def split_intra(args, world, rank, device_index, distributed, oversubscribed):
     """`--split intra`: ONE shard of 2^log_rows eval rows proved by all `world` ranks together (strong scaling).  A step = trace
-    generation (whole, on every rank in this version) + the shard proof made by the ranks together; every rank ends with the same
+    generation (a cut chip's rows by blocks, one block per rank) + the shard proof made by the ranks together; every rank ends with the same
     proof words, rank 0 verifies them after the timed region.  N = 1 runs the one-rank prover one proof at a time, so that the
     N-rank lines divide by a number measured the same way."""
     import torch
@@ -289,7 +289,7 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
     n = 1 << log_rows
     source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, 1, log_rows)
     top = lair.Toplevel(source, lurk_chips=lurk_chips)
-    # host side, once, on every rank: the traces of the one shard are generated whole by every rank
+    # host side, once, on every rank: every rank holds the shard's kernel inputs and generates its own rows of them
     t0 = time.perf_counter()
     queries = lair.QueryRecord(top)
     top.execute(top.func_index(entry), main_args, queries)
@@ -317,12 +317,17 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
         sp = split.SplitProver(machine, scomm, args.split_min_log_rows)
         assert sp.setup() == vk_root, "the ranks' verifying key differs from one rank's"
 
+    block_bufs = sp.block_buffers(prepared) if sp is not None else None
+
     def step():
+        if sp is not None:  # every cut chip's trace: this rank's block of rows only
+            ctx.span_begin("trace_all")
+            blocks = sp.run_prepared_blocks(prepared, block_bufs)
+            ctx.span_end("trace_all")
+            return sp.prove(blocks, pv, args.queries, args.pow_bits, row_blocks=True)[0]
         ctx.span_begin("trace_all")
         traces = machine.run_prepared(prepared)
         ctx.span_end("trace_all")
-        if sp is not None:
-            return sp.prove(traces, pv, args.queries, args.pow_bits)[0]
         ch = prover.Challenger(ctx)
         ch.observe(vk_root)
         ch.observe([0])
@@ -389,9 +394,9 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
                             f"{args.queries} FRI queries, {args.pow_bits} PoW bits",
                 "workload_detail": workload_desc,
                 "split": {"min_log_rows": args.split_min_log_rows, "carrier": carrier, "carrier_note": carrier_note, "oversubscribed": bool(oversubscribed),
-                          "note": "chips of at least 2^min_log_rows rows: LDE on column tiles, ONE all-to-all to storage-row blocks per commitment (two for the permutation and "
-                                  "quotient commitments, whose rows are computed by row blocks), subtree roots all-gathered; main traces generated whole by every rank; FRI on every "
-                                  "rank from the all-gathered reduced openings (DESIGN.md 6)"},
+                          "note": "chips of at least 2^min_log_rows rows: traces, permutation rows and quotient values by row blocks, one block per rank; per commitment one all-to-all "
+                                  "rows -> column tiles, the LDE on the tiles, ONE all-to-all to storage-row blocks (the key's preprocessed traces are whole on every rank: the second "
+                                  "only), subtree roots all-gathered; FRI on every rank from the all-gathered reduced openings (DESIGN.md 6)"},
                 "chips_compiled": len(compiled), "host_execute_s": t_execute,
             },
             "per_rank": [{k: b[k] for k in ("rank", "seconds", "stages_ms", "alltoall_bytes_sent_before_lde", "alltoall_bytes_sent_after_lde", "alltoalls")} for b in box],
@@ -437,7 +442,8 @@ def main():
                          "GPU through RCCL at world 1: 47.9 against 46.4 ms per step -- phase 2 already keeps two shards in flight; off by default)")
     ap.add_argument("--rank-in-flight", type=int, default=None,
                     help="N > 1 (or --shards-per-rank > 1): machine proofs IN FLIGHT per rank, each on its own machine, contexts and communicator "
-                         "(shards.run_in_flight: a rank never idles at a collective).  Default 2; 1 = one machine proof at a time (rounds 2-4)")
+                         "(shards.run_in_flight: a rank never idles at a collective).  Default 2 on one device and over gloo, 1 with world > 1 on RCCL "
+                         "(two communicators driven from two threads are unordered between ranks: not validated on a multi-GPU box yet)")
     ap.add_argument("--rank-in-flight-lanes", type=int, choices=(1, 2), default=1,
                     help="with --rank-in-flight >= 2: streams per machine proof (1 = its shards one after the other on the machine's stream; 2 = two of its shards at a time)")
     ap.add_argument("--rank-pipeline-depth", type=int, default=2,
@@ -589,8 +595,10 @@ def main():
     shard_cost, assignment = host["shard_cost"], host["assignment"]
     n_shards = len(shard_cost)
     mine = assignment[rank]
-    if not mine:
-        raise SystemExit(f"rank {rank} holds no shard ({n_shards} shards over {world} ranks): nothing to time on it")
+    if any(not a for a in assignment):
+        # decided by EVERY rank from the broadcast assignment: a rank that left alone would leave its peers inside the next collective
+        # (scatter_prepared / bring_up) until the process group's timeout
+        raise SystemExit(f"{n_shards} shards over {world} ranks: rank(s) {[r for r, a in enumerate(assignment) if not a]} would hold none, nothing to time there")
     t0 = time.perf_counter()
     my_blobs = shards.scatter_prepared(machine, all_shards, assignment, device=dev) if scatter else {}
 
@@ -618,7 +626,14 @@ def main():
     perm_cols_per_eval_row = sum(4 * air.permutation_width << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     constraints_per_eval_row = sum(air.num_constraints << lg for pr in prepared_all for _, air, lg, _, _ in pr) / n
     multi = world > 1 or n_shards > 1
-    in_flight = 1 if (args.rank_pipeline or not multi) else (args.rank_in_flight if args.rank_in_flight is not None else 2)
+    # Machine proofs in flight per rank.  Two (each on its own communicator and host thread) is the measured optimum on one device,
+    # but across communicators nothing orders the collectives between ranks, and RCCL documents that as a deadlock hazard: the
+    # collective kernels block, and a device-wide synchronisation on one thread (a hipMalloc / hipFree of either allocator) can wait
+    # on the other communicator's kernel while the peer rank is in the mirror state.  It has only ever run at world 1 on RCCL and over
+    # gloo, so with world > 1 on RCCL the default is ONE proof in flight until a multi-GPU box has validated two;
+    # --rank-in-flight 2 asks for it explicitly.
+    rccl_multi = distributed and world > 1 and not oversubscribed
+    in_flight = 1 if (args.rank_pipeline or not multi) else (args.rank_in_flight if args.rank_in_flight is not None else (1 if rccl_multi else 2))
     one_lane = (args.rank_pipeline and args.rank_pipeline_one_lane) or (in_flight >= 2 and args.rank_in_flight_lanes == 1)
     lane_ctx = prover.lane_context(machine) if len(mine) > 1 and not one_lane else None  # the second proving lane of a rank with several shards
 
@@ -1032,6 +1047,16 @@ def main():
             else:
                 lde_pass_bytes += 3 * max(1, -(-log_n // ntt_log_tile)) * 2 * (1 << log_n) * w * 4
     lde_ms_step = rs["lde"][0] / rs_steps
+    # ... of which transformed: the permutation traces' identically-zero columns are left out of the LDE (their 12 w bytes stay in the
+    # algorithmic figure -- a property of the commitment, not of the route); the library says how many cells the last proof transformed
+    lde_alg_transformed = lde_alg_bytes
+    try:
+        pst = np.zeros(2, dtype=np.uint64)
+        lurk_amd._native.lib.lurkhip_prover_stats(ctx.handle, pst.ctypes.data)
+        if int(pst[0]):
+            lde_alg_transformed = lde_alg_bytes - 12 * (int(pst[0]) - int(pst[1])) * len(mine)
+    except Exception:
+        pass
     lde_alg = lde_alg_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     lde_pass = lde_pass_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     traffic, valu, lde_traffic = None, None, None
@@ -1082,6 +1107,24 @@ def main():
                     "source": src_v}
     except Exception:
         pass
+
+    # The whole step against the VALU peak: every kernel's SQ_INSTS_VALU x 64 lanes of one step from the
+    # committed PMC pass / this run's ms_per_step.  The count belongs to the sources of that pass: flagged when any of them changed.
+    step_block = None
+    try:
+        if pmc.get("log_rows") == log_rows and pmc.get("workload") == args.workload and pmc.get("step_valu_lane_insts"):
+            import hashlib
+
+            hs = hashlib.sha256()
+            for rel in pmc.get("step_kernel_sources", []):
+                with open(os.path.join(ROOT, rel), "rb") as fsrc:
+                    hs.update(fsrc.read())
+            step_block = {"valu_lane_insts_per_step": pmc["step_valu_lane_insts"], "unit": "T lane-instr/s", "peak": VALU_FULL_RATE,
+                          "sources_changed_since_pmc_pass": hs.hexdigest() != pmc.get("step_kernel_sources_sha256"),
+                          "source": "profiles/pmc_traffic.json: SQ_INSTS_VALU x 64 lanes summed over every kernel of one step (static) / ms_per_step of this run (live, "
+                                    "filled in below)"}
+    except Exception:
+        step_block = None
 
     # Extra (N = 1 only, never `value`): the host side of the path.  ONE execution of pipeline_shards x 2^log_rows eval rows,
     # sharded; (a) every shard's inputs staged beforehand (the resident-input reference), (b) streamed: a staging thread
@@ -1144,6 +1187,10 @@ def main():
         except Exception as e:
             host_pipeline = {"error": repr(e)}
 
+    if step_block is not None and ms_per_step > 0:
+        step_block["achieved"] = step_block["valu_lane_insts_per_step"] * len(mine) / (ms_per_step * 1e-3) / 1e12
+        step_block["frac"] = step_block["achieved"] / VALU_FULL_RATE
+        step_block["ms_per_step"] = ms_per_step
     if rank == 0:
         out = {
             "metric": "Lurk eval-steps proved/sec (fib trace)",
@@ -1246,11 +1293,21 @@ def main():
                 "hbm": {"bound": "hbm", "achieved": achieved, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": achieved / HBM_PEAK_GBS,
                         "note": "algorithmic bytes / summed HIP-event time of the hashing launches, measured live in this run"},
                 "traffic": traffic,
-                "also": {"kernel": "coset LDE (lde.hip: k_lde_in / k_lde_mid / k_lde_out per height group; ntt.hip for the shapes it does not take), all launches of a step", "bound": "hbm",
+                "also": {"kernel": "coset LDE (lde.hip: k_lde_in / k_lde_mid / k_lde_out per height group; ntt.hip for the shapes it does not take): the launches inside the `lde` spans "
+                                   "of a step's three commitments",
+                         "bound": "hbm",
                          "achieved": lde_alg, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": lde_alg / HBM_PEAK_GBS,
+                         "time_note": "ms_per_step is the HIP-event time of the `lde` spans (stages_ms.lde): the short height groups' launches run on a side stream UNDER the tall "
+                                      "groups', so the same kernels' durations summed by name in a rocprofv3 table (profiles/*_per_proof_kernel_stats.csv) come to more than the span",
                          "algorithmic_bytes_per_step": lde_alg_bytes, "algorithmic_bytes_rule": "SURVEY 8(d): 12 w B per trace row (read 4w, write 8w)",
+                         "algorithmic_bytes_transformed": lde_alg_transformed,
+                         "achieved_on_transformed": lde_alg_transformed / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0,
+                         "frac_on_transformed": (lde_alg_transformed / (lde_ms_step * 1e-3) / 1e9 / HBM_PEAK_GBS) if lde_ms_step > 0 else 0.0,
+                         "transformed_note": "12 w B per row of the columns whose extension is computed: the permutation traces' identically-zero columns (interactions no row of "
+                                             "the shard uses) are stored as zeros, not transformed -- the honest numerator for the kernels' own efficiency",
                          "pass_traffic_bytes_per_step": lde_pass_bytes, "pass_traffic_GBs": lde_pass, "ms_per_step": lde_ms_step,
                          "traffic": lde_traffic},
+                "step": step_block,
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,
                 "ms_per_step": hash_ms_step,

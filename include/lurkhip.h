@@ -457,6 +457,11 @@ int32_t lurkhip_func_trace_run_many(lurkhip_ctx* ctx, uint32_t n, const lurkhip_
 int32_t lurkhip_trace_group_layout(uint32_t n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitches,
                                    uint32_t* col_starts, int32_t* groups, int32_t* n_groups);
 int32_t lurkhip_func_trace_run_pitched(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, uint32_t out_pitch, int32_t repr);
+/* rows [first_row, first_row + n_rows) of the trace only, into out_dev[n_rows][out_pitch] (out_pitch 0: dense): a rank's block of
+ * rows of one shard proved by several ranks (lurkhip_shard_commit_split, main_row_blocks).  Bit-identical to the same rows of
+ * lurkhip_func_trace_run's matrix (tests/test_split_gpu.py). */
+int32_t lurkhip_func_trace_run_rows(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t first_row, uint32_t n_rows, uint32_t* out_dev,
+                                    uint32_t out_pitch, int32_t repr);
 int32_t lurkhip_func_trace_run_many_pitched(lurkhip_ctx* ctx, uint32_t n, const lurkhip_func_trace* const* ps, uint32_t* const* outs_dev,
                                             const uint32_t* out_pitches, int32_t repr);
 /* A prepared trace as bytes (round 5): the process that executed the program hands a shard's kernel inputs to the process
@@ -588,6 +593,10 @@ typedef struct lurkhip_proof lurkhip_proof;
 int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
                             const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                             lurkhip_proof** out);
+/* out[0] = base-field cells of the permutation traces of the context's last shard proof, out[1] = those of them in columns whose
+ * extension was computed (the identically-zero columns -- interactions no row of the shard uses -- are left out of the LDE and
+ * stored as zeros): what a bench's "algorithmic bytes" and "bytes transformed" differ by. */
+int32_t lurkhip_prover_stats(lurkhip_ctx* ctx, uint64_t* out /* [2] */);
 /* StarkMachine::verify on the HOST (no device, no context): rebuilds the transcript from the verifying key and the shard proofs
  * (in shard order), checks every Merkle opening, every FRI query with its proof of work, the constraint identity of every chip
  * at zeta -- evaluated from airs[machine index], the same AIR handles the prover was given -- and that the cumulative sums of all
@@ -737,18 +746,19 @@ typedef struct lurkhip_split_comm {
  * the context's stream; the host variants stage through the context's pool).  `out->user` refers to ctx and comm: both must
  * outlive every key / shard made with it. */
 int32_t lurkhip_comm_split_vtable(lurkhip_ctx* ctx, lurkhip_comm* comm, lurkhip_split_comm* out);
-/* lurkhip_setup / lurkhip_shard_commit_pitched / lurkhip_shard_prove for one shard over comm->world ranks.  Every rank passes the
- * same arguments (the traces are the same on every rank: main traces are generated whole by every rank in this version, 2 % of a
- * step); chips of at least 2^split_min_log_n rows (>= log2 world) are cut, the shorter ones are proved whole by every rank.
- * The struct is copied.  Roots, proofs and the challenger's final state are identical on every rank and equal to the one-rank
+/* lurkhip_setup / lurkhip_shard_commit_pitched / lurkhip_shard_prove for one shard over comm->world ranks.  Chips of at least
+ * 2^split_min_log_n rows (>= log2 world) are cut, the shorter ones are proved whole by every rank.  main_row_blocks = 0: every
+ * rank passes the same whole traces (2 % of a step's work, repeated on every rank); != 0: main_traces_dev[i] of a cut chip holds
+ * only this rank's block of rows [rank N / G, (rank + 1) N / G) (lurkhip_func_trace_run_rows), the other chips' their whole trace.
+ * The preprocessed traces are whole on every rank.  The struct is copied.  Roots, proofs and the challenger's final state are identical on every rank and equal to the one-rank
  * entry points' (tests/test_split_gpu.py). */
 int32_t lurkhip_setup_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_prep,
                             const uint32_t* const* prep_traces_dev, const uint32_t* log_heights, const uint32_t* widths, int32_t log_blowup,
                             lurkhip_pk** out, uint32_t* root);
 int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_chips,
                                    lurkhip_air* const* airs, const uint32_t* log_heights, const uint32_t* const* main_traces_dev,
-                                   const uint32_t* main_pitches, const int32_t* prep_indices, int32_t log_blowup, lurkhip_shard** out,
-                                   uint32_t* root);
+                                   const uint32_t* main_pitches, const int32_t* prep_indices, int32_t log_blowup, int32_t main_row_blocks,
+                                   lurkhip_shard** out, uint32_t* root);
 int32_t lurkhip_shard_prove_split(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* shard, lurkhip_challenger* challenger,
                                   const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                                   lurkhip_proof** out);

@@ -219,8 +219,10 @@ SIGNATURES = {
     "lurkhip_reduce_sums": (_i32, [_p, _p, _u32p, _i32, _u32p]),
     "lurkhip_comm_split_vtable": (_i32, [_p, _p, _p]),
     "lurkhip_setup_split": (_i32, [_p, _p, _i32, _i32, _p, _u32p, _u32p, _i32, C.POINTER(_p), _u32p]),
-    "lurkhip_shard_commit_split": (_i32, [_p, _p, _i32, _i32, _p, _u32p, _p, _u32p, _p, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_shard_commit_split": (_i32, [_p, _p, _i32, _i32, _p, _u32p, _p, _u32p, _p, _i32, _i32, C.POINTER(_p), _u32p]),
+    "lurkhip_func_trace_run_rows": (_i32, [_p, _p, C.c_uint32, C.c_uint32, _u32p, C.c_uint32, _i32]),
     "lurkhip_shard_prove_split": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
+    "lurkhip_prover_stats": (_i32, [_p, _p]),
     "lurkhip_split_stats": (_i32, [_p, _p, _i32]),
     "lurkhip_split_plan": (_i64, [_i32, _i32, _i32, _i32, _u32p, _u32p, _p, _u32p, _u32p, _u32p, _p, C.c_uint64]),
 }

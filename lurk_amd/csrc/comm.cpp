@@ -191,7 +191,8 @@ int32_t lurkhip_exchange_roots_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, const u
 static int32_t exchange_var(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local, int64_t n_total,
                             bool equal_counts, uint32_t* roots_out) {
     const int world = comm->world;
-    const bool args_ok = n_local >= 0 && n_local <= 4096 && roots_out && (n_local == 0 || (shard_indices && roots));
+    // (a negative n_total from the _var entry point is a bad argument like the others: this rank still enters both collectives, with -1)
+    const bool args_ok = n_local >= 0 && n_local <= 4096 && roots_out && (n_local == 0 || (shard_indices && roots)) && n_total >= -1;
     void* cnt = nullptr;  // world + 1 words: [0] mine, [1 ..] everybody's
     LH_TRY(pool_alloc(ctx, ((size_t)world + 1) * 4, &cnt));
     void *send = nullptr, *recv = nullptr;
@@ -262,8 +263,8 @@ int32_t lurkhip_exchange_roots(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint3
 int32_t lurkhip_exchange_roots_var(lurkhip_ctx* ctx, lurkhip_comm* comm, const uint32_t* shard_indices, const uint32_t* roots, int32_t n_local,
                                    int32_t n_total, uint32_t* roots_out) {
     LH_CHECK_CTX(ctx);
-    LH_ARG(ctx, comm != nullptr && n_total >= 0, "null communicator or negative shard count");
-    return exchange_var(ctx, comm, shard_indices, roots, n_local, n_total, false, roots_out);
+    LH_ARG(ctx, comm != nullptr, "null communicator");
+    return exchange_var(ctx, comm, shard_indices, roots, n_local, n_total < 0 ? -2 : n_total, false, roots_out);
 }
 
 int32_t lurkhip_reduce_sums_dev(lurkhip_ctx* ctx, lurkhip_comm* comm, int64_t* lanes_dev, uint32_t* total_dev) {

@@ -88,6 +88,9 @@ struct lurkhip_ctx {
     // one shard over several ranks (split.hip): words this rank sent to OTHER ranks in the all-to-alls before / after the LDEs, and
     // the number of all-to-alls (lurkhip_split_stats)
     uint64_t split_words_a = 0, split_words_b = 0, split_exchanges = 0;
+    // the last shard proof's permutation traces: cells in all, and in the columns whose LDE was computed (the identically-zero ones
+    // are left out: lurkhip_prover_stats -- the bench's "algorithmic bytes transformed")
+    uint64_t perm_cells = 0, perm_cells_transformed = 0;
 };
 
 namespace lurkhip {

@@ -48,8 +48,8 @@ int32_t trace_func_dev_pitched(lurkhip_ctx* ctx, const uint32_t* program_dev, co
                                const uint32_t* depths_dev, const void* meta_dev, const uint32_t* stream_dev, uint32_t* out_dev, int32_t repr,
                                uint32_t out_pitch);
 int32_t trace_mem_dev_pitched(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev, const uint32_t* provides_dev,
-                              uint32_t* out_dev, int32_t repr, uint32_t out_pitch);
-int32_t trace_bytes_dev_pitched(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr, uint32_t out_pitch);
+                              uint32_t* out_dev, int32_t repr, uint32_t out_pitch, uint32_t row0);
+int32_t trace_bytes_dev_pitched(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr, uint32_t out_pitch, uint32_t rows);
 // commit.hip: the layout lurkhip_trace_group_layout reports
 void plan_source_groups(int n, const uint32_t* log_heights, const uint32_t* widths, uint32_t* pitch, uint32_t* col_start, int32_t* group, int32_t* n_groups);
 }  // namespace lurkhip
@@ -739,13 +739,36 @@ int32_t lurkhip_func_trace_run(lurkhip_ctx* ctx, const lurkhip_func_trace* p, ui
     return lurkhip_func_trace_run_pitched(ctx, p, out_dev, 0, repr);
 }
 
+// Rows [first_row, first_row + n_rows) of the trace only, into out_dev[n_rows][out_pitch]: a rank's block of rows when several ranks
+// prove one shard together (include/lurkhip.h: lurkhip_shard_commit_split with main_row_blocks).  Every generator works row by row
+// from per-row inputs, so a block is the same kernels on offset pointers: padding rows keep their nonce (trace.rs:82-84: range.start
+// + i for ALL rows), a memory table its pointer column i + 1 (memory.rs:43-52).
+int32_t lurkhip_func_trace_run_rows(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t first_row, uint32_t n_rows, uint32_t* out_dev, uint32_t out_pitch,
+                                    int32_t repr) {
+    LH_CHECK_CTX(ctx);
+    if (!p || !out_dev) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
+    if ((uint64_t)first_row + n_rows > p->height) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "row block outside the trace");
+    const uint32_t r0 = std::min(first_row, p->n), real = std::min(first_row + n_rows, p->n) - r0;  // the block's real rows are r0 .. r0 + real
+    if (p->kind == 1)
+        return lurkhip::trace_mem_dev_pitched(ctx, p->mem_len, real, n_rows, (const uint32_t*)p->dev + (size_t)r0 * p->mem_len,
+                                              (const uint32_t*)p->dev + (size_t)p->n * p->mem_len + 2 * (size_t)r0, out_dev, repr, out_pitch, first_row);
+    if (p->kind == 2)
+        return lurkhip::trace_bytes_dev_pitched(ctx, p->is_real ? (const uint32_t*)p->dev + (size_t)first_row * 12 : nullptr, p->is_real ? 1 : 0, out_dev, repr, out_pitch, n_rows);
+    const uint8_t* d = (const uint8_t*)p->dev;
+    const uint32_t n_in = p->header[lair::TH_INPUT], n_out = p->header[lair::TH_OUTPUT];
+    return lurkhip::trace_func_dev_pitched(ctx, (const uint32_t*)(d + p->o_prog), p->header.data(), real, n_rows, p->start + first_row,
+                                           (const uint32_t*)(d + p->o_args) + (size_t)r0 * n_in, (const uint32_t*)(d + p->o_outs) + (size_t)r0 * n_out,
+                                           (const uint32_t*)(d + p->o_prov) + 2 * (size_t)r0, p->partial ? (const uint32_t*)(d + p->o_dep) + r0 : nullptr,
+                                           d + p->o_meta + (size_t)r0 * sizeof(lair::RowMeta), (const uint32_t*)(d + p->o_str), out_dev, repr, out_pitch);
+}
+
 int32_t lurkhip_func_trace_run_pitched(lurkhip_ctx* ctx, const lurkhip_func_trace* p, uint32_t* out_dev, uint32_t out_pitch, int32_t repr) {
     LH_CHECK_CTX(ctx);
     if (!p || !out_dev) return fail(ctx, LURKHIP_ERR_INVALID_ARG, "null argument");
     if (p->kind == 1)
         return lurkhip::trace_mem_dev_pitched(ctx, p->mem_len, p->n, p->height, (const uint32_t*)p->dev,
-                                              (const uint32_t*)p->dev + (size_t)p->n * p->mem_len, out_dev, repr, out_pitch);
-    if (p->kind == 2) return lurkhip::trace_bytes_dev_pitched(ctx, (const uint32_t*)p->dev, p->is_real ? 1 : 0, out_dev, repr, out_pitch);
+                                              (const uint32_t*)p->dev + (size_t)p->n * p->mem_len, out_dev, repr, out_pitch, 0);
+    if (p->kind == 2) return lurkhip::trace_bytes_dev_pitched(ctx, (const uint32_t*)p->dev, p->is_real ? 1 : 0, out_dev, repr, out_pitch, 65536);
     const uint8_t* d = (const uint8_t*)p->dev;
     return lurkhip::trace_func_dev_pitched(ctx, (const uint32_t*)(d + p->o_prog), p->header.data(), p->n, p->height, p->start,
                                            (const uint32_t*)(d + p->o_args), (const uint32_t*)(d + p->o_outs), (const uint32_t*)(d + p->o_prov),
@@ -796,11 +819,24 @@ int32_t lurkhip_func_trace_run_many_pitched(lurkhip_ctx* ctx, uint32_t n, const 
 }
 
 // ---- a prepared trace as bytes (round 5): the executing process hands a shard's kernel inputs to the process that proves it.
-// The handle IS one device block plus a few numbers, so the blob is: 24 words of header | the TH_WORDS program header (FuncChip) |
+// The handle IS one device block plus a few numbers, so the blob is: 28 words of header (the last four: the block's length and its checksum) | the TH_WORDS program header (FuncChip) |
 // the block.  Little-endian words; the block's own layout is lurkhip_func_trace_prepare's.
 namespace {
-constexpr uint32_t BLOB_MAGIC = 0x3154464cu;  // "LFT1"
-constexpr size_t BLOB_HEAD_WORDS = 24;
+constexpr uint32_t BLOB_MAGIC = 0x3254464cu;  // "LFT2" (round 6: the block's length and a checksum travel in the header)
+constexpr size_t BLOB_HEAD_WORDS = 28;
+// 64-bit multiply-xorshift fold of the block's words: a truncated or corrupted blob must not import cleanly
+uint64_t blob_checksum(const uint8_t* body, uint64_t bytes) {
+    uint64_t h = 0x9E3779B97F4A7C15ull ^ bytes;
+    const uint64_t n = bytes / 8;
+    for (uint64_t i = 0; i < n; i++) {
+        uint64_t v;
+        memcpy(&v, body + 8 * i, 8);
+        h = (h ^ v) * 0xD6E8FEB86659FD93ull;
+        h ^= h >> 32;
+    }
+    for (uint64_t i = 8 * n; i < bytes; i++) h = (h ^ body[i]) * 0x100000001B3ull;
+    return h;
+}
 }  // namespace
 
 int32_t lurkhip_func_trace_export_size(const lurkhip_func_trace* p, uint64_t* bytes) {
@@ -833,6 +869,8 @@ int32_t lurkhip_func_trace_export(lurkhip_ctx* ctx, const lurkhip_func_trace* p,
     LH_HIP(ctx, hipSetDevice(ctx->device));
     LH_HIP(ctx, hipStreamSynchronize(ctx->stream));  // the upload that filled the block (and anything still reading it)
     LH_HIP(ctx, hipMemcpy(body, p->dev, p->total, hipMemcpyDeviceToHost));
+    const uint64_t tail[2] = {(uint64_t)p->total, blob_checksum(body, p->total)};
+    memcpy(&w[24], tail, sizeof tail);  // words 24 .. 27
     return LURKHIP_OK;
 }
 
@@ -849,6 +887,12 @@ int32_t lurkhip_func_trace_import(lurkhip_ctx* ctx, const void* blob_host, uint6
         if (kind > 2 || hw > 4096 || (kind == 0 ? hw != lair::TH_WORDS : hw != 0) || bytes < (BLOB_HEAD_WORDS + hw) * 4)
             return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "prepared-trace blob: bad header");
         const uint64_t total = bytes - (BLOB_HEAD_WORDS + hw) * 4;
+        uint64_t tail[2];
+        memcpy(tail, &w[24], sizeof tail);
+        if (tail[0] != total) return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "prepared-trace blob: %llu bytes of block where the header says %llu (truncated?)",
+                                                        (unsigned long long)total, (unsigned long long)tail[0]);
+        if (blob_checksum((const uint8_t*)blob_host + (BLOB_HEAD_WORDS + hw) * 4, total) != tail[1])
+            return lurkhip::set_error(ctx, LURKHIP_ERR_INVALID_ARG, "prepared-trace blob: checksum mismatch");
         auto* p = new lurkhip_func_trace();
         p->kind = (int)kind;
         p->mem_len = w[2];
@@ -864,7 +908,13 @@ int32_t lurkhip_func_trace_import(lurkhip_ctx* ctx, const void* blob_host, uint6
         p->total = total;
         bool ok = p->n <= p->height && p->height > 0 && (p->height & (p->height - 1)) == 0 && p->width > 0 && total > 0;
         for (uint64_t o : offs) ok = ok && o <= total && o % 4 == 0;
-        if (kind == 0) ok = ok && p->header[lair::TH_MAGIC] == lair::TRACE_PROGRAM_MAGIC && p->header[lair::TH_WIDTH] == p->width;
+        if (kind == 0) {
+            ok = ok && p->header[lair::TH_MAGIC] == lair::TRACE_PROGRAM_MAGIC && p->header[lair::TH_WIDTH] == p->width;
+            // every section inside the block and ahead of the next one: the trace kernels read n rows of each
+            const uint64_t n = p->n, n_in = p->header[lair::TH_INPUT], n_out = p->header[lair::TH_OUTPUT];
+            ok = ok && offs[0] <= offs[1] && offs[1] + n * n_in * 4 <= offs[2] && offs[2] + n * n_out * 4 <= offs[3] && offs[3] + n * 8 <= offs[4] &&
+                 offs[4] + n * 4 <= offs[5] && offs[5] + n * sizeof(lair::RowMeta) <= offs[6] && offs[6] + (uint64_t)p->stream_words * 4 <= total;
+        }
         if (kind == 1) ok = ok && (p->mem_len == 2 || p->mem_len == 3 || p->mem_len == 4 || p->mem_len == 5 || p->mem_len == 6 || p->mem_len == 8) &&
                             p->width == 4 + p->mem_len && total >= ((uint64_t)p->n * (p->mem_len + 2)) * 4;
         if (kind == 2) ok = ok && p->width == 13 && p->height == 65536 && total >= (uint64_t)65536 * 12 * 4;

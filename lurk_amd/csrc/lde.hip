@@ -612,6 +612,8 @@ __global__ __launch_bounds__((lde_threads<LOG_R, LOG_C>()), 4) void k_lde_out(Ld
         const uint32_t* __restrict__ in = a.B + ((size_t)at.q * a.slabs << (a.log_n + SLAB_LOG_W)) + ((((size_t)at.hi << LOG_R) | (size_t)s) << SLAB_LOG_W);
         const OutRef o = locate_out(a, descs, at.vc);
         if constexpr (G::U >= 4 && LDE_SLAB_X4) {
+            // (the quad loads know nothing of dead columns: a dead column's slab offset is some live column's.  The variant is an A/B
+            // switch for dense groups only; launch_kind refuses it together with dead columns -- ADVICE round 5)
             walk_load_x4<G::U>(dst, in + slab_off(a, o.svc & ~3u), (size_t)G::S << SLAB_LOG_W, c & 3);
         } else {
             // A dead or padding column is the zero polynomial, and so is every butterfly of it: it loads nothing.  (The zeros are
@@ -959,6 +961,7 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
                   const uint32_t* src_pitches, const uint32_t* out_starts, uint32_t out_width) {
     LH_ARG(ctx, n_mats >= 1 && n_mats <= LDE_MAX_MATS && n_cls >= 1 && n_cls <= LDE_MAX_CLASSES, "LDE group shape");
     LH_ARG(ctx, log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N, "LDE group height 2^%d", log_n);
+    LH_ARG(ctx, !(LDE_SLAB_X4 && out_starts), "LDE group: the quad-load variant (LDE_SLAB_X4) does not leave dead columns out");
     const NttPlan* plan = nullptr;
     LH_TRY(get_ntt_plan(ctx, log_n, &plan));
     LdeArgs a{};

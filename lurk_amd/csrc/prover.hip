@@ -59,6 +59,7 @@ struct lurkhip_shard {
     uint32_t root_m[8] = {};
     int log_blowup = 1;
     SplitEnv split;                              // lurkhip_shard_commit_split: one shard proved by several ranks together
+    bool main_row_blocks = false;                // ... main[i] of a cut chip holds this rank's block of rows only
 };
 
 struct lurkhip_proof {
@@ -299,8 +300,8 @@ int32_t lurkhip_setup_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, in
 
 int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* comm, int32_t split_min_log_n, int32_t n_chips,
                                    lurkhip_air* const* airs, const uint32_t* log_heights, const uint32_t* const* main_traces_dev,
-                                   const uint32_t* main_pitches, const int32_t* prep_indices, int32_t log_blowup, lurkhip_shard** out,
-                                   uint32_t* root) {
+                                   const uint32_t* main_pitches, const int32_t* prep_indices, int32_t log_blowup, int32_t main_row_blocks,
+                                   lurkhip_shard** out, uint32_t* root) {
     LH_CHECK_CTX(ctx);
     LH_ARG(ctx, n_chips > 0 && airs && log_heights && main_traces_dev && out, "bad shard arguments");
     SplitEnv env;
@@ -312,6 +313,7 @@ int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* c
     auto* sh = new lurkhip_shard();
     sh->log_blowup = log_blowup;
     sh->split = env;
+    sh->main_row_blocks = main_row_blocks != 0;
     std::vector<int> order(n_chips);
     std::iota(order.begin(), order.end(), 0);
     std::stable_sort(order.begin(), order.end(), [&](int a, int b) { return log_heights[a] > log_heights[b]; });
@@ -325,8 +327,8 @@ int32_t lurkhip_shard_commit_split(lurkhip_ctx* ctx, const lurkhip_split_comm* c
         sh->prep_index.push_back(prep_indices ? prep_indices[i] : -1);
         sh->main_pitch.push_back(main_pitches ? main_pitches[i] : air.width);
         // the columns a chip's constraints read on the next row travel to the rank that owns the row (QuotientArgs::next_off)
-        sm.push_back(SplitMat{main_traces_dev[i], log_heights[i], air.width, sh->main_pitch.back(), 0u, split::K_FULL, 0u, 0u, air_next_columns(airs[i]),
-                              air.log_quotient_degree()});
+        const int kind = sh->main_row_blocks && (int)log_heights[i] >= env.min_log_n ? split::K_BLOCK : split::K_FULL;
+        sm.push_back(SplitMat{main_traces_dev[i], log_heights[i], air.width, sh->main_pitch.back(), 0u, kind, 0u, 0u, air_next_columns(airs[i]), air.log_quotient_degree()});
     }
     span_begin(ctx, "commit_main");
     const int32_t s = split_commit(ctx, env, n_chips, sm.data(), log_blowup, &sh->main_commit, sh->root_m);
@@ -982,6 +984,14 @@ int32_t lurkhip_shard_prove(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shar
     }
 }
 
+int32_t lurkhip_prover_stats(lurkhip_ctx* ctx, uint64_t* out) {
+    LH_CHECK_CTX(ctx);
+    LH_ARG(ctx, out != nullptr, "null argument");
+    out[0] = ctx->perm_cells;
+    out[1] = ctx->perm_cells_transformed;
+    return LURKHIP_OK;
+}
+
 int32_t lurkhip_shard_prove_split(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_shard* sh, lurkhip_challenger* chal,
                                   const uint32_t* public_values, uint32_t n_public, uint32_t num_queries, uint32_t pow_bits,
                                   lurkhip_proof** out) {
@@ -1149,7 +1159,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
         if (cut(i)) {  // this rank's block of trace rows, its running sum from zero: the previous ranks' totals are added below
             const size_t rows = h >> sp->log_g, r0 = (size_t)sp->rank * rows;
-            PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)rows, sh->main[i] + r0 * sh->main_pitch[i], prep ? prep + r0 * air_of(sh->airs[i]).prep_width : nullptr,
+            PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)rows, sh->main[i] + (sh->main_row_blocks ? 0 : r0) * sh->main_pitch[i], prep ? prep + r0 * air_of(sh->airs[i]).prep_width : nullptr,
                                         perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i], sh->main_pitch[i], perm_pitch[i], nullptr, /*starts_ready=*/true,
                                         /*defer_scan=*/true));
             PTRY(scan_ef_column(ctx, perm[i] + perm_widths[i] - 4, perm_pitch[i], rows));
@@ -1230,6 +1240,21 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             cumsum[i] = total;
             if (sp->rank) PTRY(add_ef_to_column(ctx, perm[i] + perm_widths[i] - 4, perm_pitch[i], ((size_t)1 << sh->log_n[i]) >> sp->log_g, before.c));
         }
+    }
+    {
+        uint64_t all = 0, live = 0;
+        for (int i = 0; i < n_chips; i++) {
+            const uint64_t rows = (uint64_t)1 << sh->log_n[i];
+            all += rows * perm_widths[i];
+            uint64_t w = perm_widths[i];
+            if (!live_runs.empty() && sh->log_n[i] > 10) {
+                w = 0;
+                for (const auto& r : live_runs[i]) w += r.second;
+            }
+            live += rows * w;
+        }
+        ctx->perm_cells = all;
+        ctx->perm_cells_transformed = live;
     }
     span_end(ctx, "permutation");
     // Round 5: the constraint-folding challenge on the device.  "Observe the permutation root, sample alpha" is what k_fri_challenge

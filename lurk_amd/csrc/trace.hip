@@ -196,8 +196,9 @@ __global__ __launch_bounds__(TBLOCK) void k_trace_func(TraceArgs a) {
 }
 
 // ---- MemChip (memory.rs:30-69): [is_real = 1, ptr = i + 1, last_nonce, last_count, values...] -----------
+// (row0: the table's row the launch starts at -- a rank's block of rows of one shard proved by several ranks, lurkhip_func_trace_run_rows)
 __global__ void k_trace_mem(const uint32_t* __restrict__ values, const uint32_t* __restrict__ provides, uint32_t len,
-                            uint32_t n_real, uint32_t height, uint32_t* __restrict__ out, int canonical, uint32_t pitch) {
+                            uint32_t n_real, uint32_t height, uint32_t* __restrict__ out, int canonical, uint32_t pitch, uint32_t row0) {
     const uint32_t width = 4 + len;
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (e >= (size_t)height * width) return;
@@ -205,7 +206,7 @@ __global__ void k_trace_mem(const uint32_t* __restrict__ values, const uint32_t*
     uint32_t v = 0;
     if (row < n_real) {
         if (c == 0) v = 1;
-        else if (c == 1) v = row + 1;
+        else if (c == 1) v = row0 + row + 1;
         else if (c < 4) v = provides[2 * (size_t)row + (c - 2)];
         else v = values[(size_t)row * len + (c - 4)];
     }
@@ -214,9 +215,9 @@ __global__ void k_trace_mem(const uint32_t* __restrict__ values, const uint32_t*
 
 // ---- BytesChip main trace (bytes/trace.rs:75-101): [is_real, 6 x (last_nonce, last_count)] ----------------
 // records: [65536][12] (range_u8, range_u16, less_than, and, xor, or) x (nonce, count); all-zero rows = never required
-__global__ void k_trace_bytes(const uint32_t* __restrict__ records, int is_real, uint32_t* __restrict__ out, int canonical, uint32_t pitch) {
+__global__ void k_trace_bytes(const uint32_t* __restrict__ records, int is_real, uint32_t* __restrict__ out, int canonical, uint32_t pitch, uint32_t rows) {
     size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (e >= (size_t)65536 * 13) return;
+    if (e >= (size_t)rows * 13) return;
     uint32_t row = (uint32_t)(e / 13), c = (uint32_t)(e - (size_t)row * 13);
     uint32_t v = 0;
     if (is_real) v = c == 0 ? 1u : records[(size_t)row * 12 + (c - 1)];
@@ -287,7 +288,7 @@ int32_t trace_func_dev_pitched(lurkhip_ctx* ctx, const uint32_t* program_dev, co
 }
 
 int32_t trace_mem_dev_pitched(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev,
-                              const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr, uint32_t out_pitch) {
+                              const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr, uint32_t out_pitch, uint32_t row0) {
     LH_CHECK_CTX(ctx);
     if (out_pitch == 0) out_pitch = 4 + len;
     LH_ARG(ctx, out_pitch >= 4 + len, "row pitch %u below the trace's width %u", out_pitch, 4 + len);
@@ -297,20 +298,21 @@ int32_t trace_mem_dev_pitched(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, u
     size_t total = (size_t)height * (4 + len);
     if (total == 0) return LURKHIP_OK;
     hipLaunchKernelGGL(k_trace_mem, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, values_dev, provides_dev, len,
-                       n_real, height, out_dev, repr == LURKHIP_REPR_CANONICAL, out_pitch);
+                       n_real, height, out_dev, repr == LURKHIP_REPR_CANONICAL, out_pitch, row0);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
 
-int32_t trace_bytes_dev_pitched(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr, uint32_t out_pitch) {
+int32_t trace_bytes_dev_pitched(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr, uint32_t out_pitch, uint32_t rows) {
     LH_CHECK_CTX(ctx);
     if (out_pitch == 0) out_pitch = 13;
     LH_ARG(ctx, out_pitch >= 13, "row pitch %u below the byte chip's width", out_pitch);
     LH_ARG(ctx, out_dev && (!is_real || records_dev), "null argument");
     LH_HIP(ctx, hipSetDevice(ctx->device));
-    size_t total = (size_t)65536 * 13;
+    size_t total = (size_t)rows * 13;
+    if (total == 0) return LURKHIP_OK;
     hipLaunchKernelGGL(k_trace_bytes, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, ctx->stream, records_dev, is_real, out_dev,
-                       repr == LURKHIP_REPR_CANONICAL, out_pitch);
+                       repr == LURKHIP_REPR_CANONICAL, out_pitch, rows);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }
@@ -328,11 +330,11 @@ int32_t lurkhip_trace_func_dev(lurkhip_ctx* ctx, const uint32_t* program_dev, co
 
 int32_t lurkhip_trace_mem_dev(lurkhip_ctx* ctx, uint32_t len, uint32_t n_real, uint32_t height, const uint32_t* values_dev,
                               const uint32_t* provides_dev, uint32_t* out_dev, int32_t repr) {
-    return lurkhip::trace_mem_dev_pitched(ctx, len, n_real, height, values_dev, provides_dev, out_dev, repr, 0);
+    return lurkhip::trace_mem_dev_pitched(ctx, len, n_real, height, values_dev, provides_dev, out_dev, repr, 0, 0);
 }
 
 int32_t lurkhip_trace_bytes_dev(lurkhip_ctx* ctx, const uint32_t* records_dev, int32_t is_real, uint32_t* out_dev, int32_t repr) {
-    return lurkhip::trace_bytes_dev_pitched(ctx, records_dev, is_real, out_dev, repr, 0);
+    return lurkhip::trace_bytes_dev_pitched(ctx, records_dev, is_real, out_dev, repr, 0, 65536);
 }
 
 int32_t lurkhip_trace_bytes_preprocessed_dev(lurkhip_ctx* ctx, uint32_t* out_dev, int32_t repr) {

@@ -294,6 +294,12 @@ class PreparedFuncTrace:
         ctx = ctx or self.ctx
         ctx.check(N.lib.lurkhip_func_trace_run_pitched(ctx.handle, self.handle, _addr(out_dev), _row_pitch(out_dev), repr))
 
+    def run_rows(self, first_row: int, n_rows: int, out_dev, repr: int = N.REPR_CANONICAL, ctx=None):
+        """Rows [first_row, first_row + n_rows) of the trace only, into out_dev[n_rows][..]: a rank's block when several ranks prove
+        one shard together (lurkhip_func_trace_run_rows)."""
+        ctx = ctx or self.ctx
+        ctx.check(N.lib.lurkhip_func_trace_run_rows(ctx.handle, self.handle, first_row, n_rows, _addr(out_dev), _row_pitch(out_dev), repr))
+
     def close(self):
         if self.handle:
             N.lib.lurkhip_func_trace_free(self.ctx.handle, self.handle)

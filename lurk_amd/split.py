@@ -185,8 +185,39 @@ class SplitProver:
         self.vk_root = [int(x) for x in root]
         return self.vk_root
 
-    def commit_shard(self, traces):
-        """traces: [(machine index, air, log_height, device trace)] as `Machine.run_prepared` returns them -- whole, on every rank."""
+    def block_buffers(self, prepared):
+        """Device tensors for `run_prepared_blocks`: a cut chip's holds this rank's block of rows, the others their whole trace."""
+        import torch
+
+        g = self.comm.world
+        out = []
+        for _, air, lg, t, p in prepared:
+            if p is None or lg < self.min_log_n:
+                out.append(t if p is None else torch.empty((1 << lg, p.width), dtype=torch.int32, device=f"cuda:{self.ctx.device}"))
+            else:
+                out.append(torch.empty(((1 << lg) // g, p.width), dtype=torch.int32, device=f"cuda:{self.ctx.device}"))
+        return out
+
+    def run_prepared_blocks(self, prepared, buffers=None):
+        """`Machine.run_prepared` for one shard over the ranks: every chip of at least 2^min_log_n rows generates only this rank's
+        block of rows [rank N / G, (rank + 1) N / G) (trace generation is row by row: the same kernels on offset inputs), the
+        shorter chips their whole trace.  Returns the list `commit_shard(.., row_blocks=True)` takes."""
+        buffers = buffers if buffers is not None else self.block_buffers(prepared)
+        g, r = self.comm.world, self.comm.rank
+        out = []
+        for (mi, air, lg, _, p), t in zip(prepared, buffers):
+            if p is not None:
+                if lg >= self.min_log_n:
+                    rows = (1 << lg) // g
+                    p.run_rows(r * rows, rows, t, repr=N.REPR_MONTY, ctx=self.ctx)
+                else:
+                    p.run(t, repr=N.REPR_MONTY, ctx=self.ctx)
+            out.append((mi, air, lg, t))
+        return out
+
+    def commit_shard(self, traces, row_blocks: bool = False):
+        """traces: [(machine index, air, log_height, device trace)] as `Machine.run_prepared` returns them -- whole, on every rank --,
+        or, with row_blocks, as `run_prepared_blocks` does."""
         n = len(traces)
         airs = (C.c_void_p * n)(*[a.handle.value for _, a, _, _ in traces])
         ptrs = (C.c_void_p * n)(*[t.data_ptr() for _, _, _, t in traces])
@@ -196,7 +227,7 @@ class SplitProver:
         h = C.c_void_p()
         root = np.zeros(8, dtype=np.uint32)
         self._check(N.lib.lurkhip_shard_commit_split(self.ctx.handle, C.byref(self.comm.struct), self.min_log_n, n, C.cast(airs, C.c_void_p), _addr(lh),
-                                                     C.cast(ptrs, C.c_void_p), _addr(pitches), _addr(prep_idx), 1, C.byref(h), _addr(root)))
+                                                     C.cast(ptrs, C.c_void_p), _addr(pitches), _addr(prep_idx), 1, 1 if row_blocks else 0, C.byref(h), _addr(root)))
         self._included[h.value] = [mi for mi, _, _, _ in traces]
         return h, [int(x) for x in root]
 
@@ -219,7 +250,7 @@ class SplitProver:
         self._included.pop(shard_handle.value, None)
         N.lib.lurkhip_shard_free(self.ctx.handle, shard_handle)
 
-    def prove(self, traces, public_values, num_queries=100, pow_bits=16, parse=False):
+    def prove(self, traces, public_values, num_queries=100, pow_bits=16, parse=False, row_blocks: bool = False):
         """One shard from its traces to its proof: the transcript `Machine.prove` builds for a one-shard execution."""
         from .prover import Challenger
 
@@ -228,7 +259,7 @@ class SplitProver:
         ch = Challenger(self.ctx)
         ch.observe(self.vk_root)
         ch.observe([0])
-        handle, root = self.commit_shard(traces)
+        handle, root = self.commit_shard(traces, row_blocks)
         try:
             ch.observe(root)
             ch.observe(public_values)

@@ -149,3 +149,23 @@ def test_a_sample_of_the_corpus_on_the_oracle_interpreter(real, corpus, oracle):
     threading.stack_size(0)
     assert not bad, bad
     assert checked[0] >= 8  # the vanish-and-balance check ran on at least eight of the sampled cases
+
+
+def test_translated_closures_run_in_a_sandbox():
+    """The closures are text from /root/reference (untrusted): what the regex translation produces is parsed and checked against a
+    whitelist of node types and names before it runs, and runs without builtins."""
+    import reference_corpus as rc
+
+    names = {"z", "ZPtr", "Tag"}
+    ok = rc.check_closure_source("def _f(z):\n    x = z.intern_u64(3)\n    return x\n", names)
+    assert ok is not None
+    for bad in (
+        "def _f(z):\n    return __import__('os').system('true')\n",           # unknown (dunder) name
+        "def _f(z):\n    return z.__class__\n",                                # underscore attribute
+        "def _f(z):\n    import os\n    return z\n",                           # statement outside the subset
+        "def _f(z):\n    return (lambda: z)()\n",                              # lambda
+        "def _f(z):\n    return open('/etc/passwd')\n",                        # a builtin the namespace does not hold
+        "def _g(z):\n    return z\n",                                          # another definition
+    ):
+        with pytest.raises(rc.Untranslatable):
+            rc.check_closure_source(bad, names)

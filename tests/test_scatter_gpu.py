@@ -89,3 +89,14 @@ def test_import_refuses_malformed_blobs(ctx):
     w = blob.copy().view(np.uint32)
     w[12] = 0xFFFFFFF0                            # an offset past the block
     assert refused(w.view(np.uint8))
+    # round 6: a truncated blob, a flipped word of the block, sections that overlap
+    assert refused(blob[:len(blob) - 64].copy())  # truncated: the header's length says so
+    bad = blob.copy()
+    bad[len(bad) // 2] ^= 0x40                    # one bit of the block: the checksum
+    assert refused(bad)
+    w = blob.copy().view(np.uint32)
+    w[14], w[15] = w[12], w[13]                   # the outputs' section starts where the arguments' does
+    assert refused(w.view(np.uint8))
+    w = blob.copy().view(np.uint32)
+    w[9] += 1 << 20                               # more stream words than the block holds
+    assert refused(w.view(np.uint8))

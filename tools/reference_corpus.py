@@ -13,6 +13,7 @@ results against the expected values: the evaluator, the interpreter, the reader 
 A closure this translator cannot express is reported as skipped, with the reason; it is never guessed.
 """
 import os
+import ast
 import re
 import sys
 
@@ -298,13 +299,48 @@ def to_python(closure: str, helpers, depth=0) -> str:
     return src
 
 
+# What a translated closure may consist of.  The closures are text read from /root/reference -- designated untrusted -- and the
+# translation is a handful of regular expressions: before anything is executed the result is parsed and every node checked against
+# this list, every name against the namespace the closures are given (plus the function's own parameter and locals), attribute
+# access against underscore names; it then runs without builtins (`|z| __import__('os').system(..)` must not run).
+_ALLOWED_NODES = (ast.Module, ast.FunctionDef, ast.arguments, ast.arg, ast.Return, ast.Assign, ast.Assert, ast.Expr, ast.Name, ast.Load, ast.Store,
+                  ast.Attribute, ast.Call, ast.keyword, ast.Constant, ast.List, ast.Tuple, ast.BinOp, ast.UnaryOp, ast.Compare, ast.BoolOp, ast.Subscript,
+                  ast.Slice, ast.Starred, ast.IfExp, ast.Add, ast.Sub, ast.Mult, ast.FloorDiv, ast.Mod, ast.Pow, ast.LShift, ast.RShift, ast.BitOr,
+                  ast.BitAnd, ast.BitXor, ast.USub, ast.Not, ast.Invert, ast.Eq, ast.NotEq, ast.Lt, ast.LtE, ast.Gt, ast.GtE, ast.And, ast.Or,
+                  ast.ListComp, ast.GeneratorExp, ast.comprehension)
+
+
+def check_closure_source(src: str, allowed_names):
+    try:
+        tree = ast.parse(src)
+    except SyntaxError as e:
+        raise Untranslatable(f"python syntax: {e.msg}: {src!r}") from e
+    local = set()
+    for node in ast.walk(tree):
+        if not isinstance(node, _ALLOWED_NODES):
+            raise Untranslatable(f"refused: {type(node).__name__} in a translated closure: {src!r}")
+        if isinstance(node, ast.arg):
+            local.add(node.arg)
+        if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Store):
+            local.add(node.id)
+    for node in ast.walk(tree):
+        if isinstance(node, ast.Name) and isinstance(node.ctx, ast.Load) and node.id not in allowed_names and node.id not in local:
+            raise Untranslatable(f"refused: unknown name {node.id!r} in a translated closure: {src!r}")
+        if isinstance(node, (ast.Name, ast.arg)) and (node.id if isinstance(node, ast.Name) else node.arg).startswith("__"):
+            raise Untranslatable(f"refused: dunder name in a translated closure: {src!r}")
+        if isinstance(node, ast.Attribute) and node.attr.startswith("_"):
+            raise Untranslatable(f"refused: attribute {node.attr!r} in a translated closure: {src!r}")
+        if isinstance(node, ast.FunctionDef) and (node.name != "_f" or node.decorator_list):
+            raise Untranslatable(f"refused: a definition other than the closure itself: {src!r}")
+    return tree
+
+
 def compile_closure(closure: str, helpers, z, hasher):
     ns = namespace(z, hasher)
     src = to_python(closure, helpers)
-    try:
-        code = compile(src, "<corpus closure>", "exec")
-    except SyntaxError as e:
-        raise Untranslatable(f"python syntax: {e.msg}: {src!r}") from e
+    tree = check_closure_source(src, set(ns))
+    code = compile(tree, "<corpus closure>", "exec")
+    ns["__builtins__"] = {}
     exec(code, ns)
     zw = ns["_Z"]()
     return lambda: ns["_f"](zw)

@@ -78,11 +78,21 @@ traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FE
 import hashlib
 import os
 
-HASH_SOURCES = ["lurk_amd/csrc/merkle.hip", "lurk_amd/csrc/poseidon2_dev.h", "lurk_amd/csrc/p16_coop.h", "lurk_amd/csrc/babybear.h", "lurk_amd/csrc/commit.h"]
+HASH_SOURCES = ["lurk_amd/csrc/merkle.hip", "lurk_amd/csrc/poseidon2_dev.h", "lurk_amd/csrc/p16_coop.h", "lurk_amd/csrc/babybear.h", "lurk_amd/csrc/merkle.h"]  # (the files whose code the hashing kernels contain; commit.h's host-side declarations are not among them: round 6)
 root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 h = hashlib.sha256()
 for rel in HASH_SOURCES:
     h.update(open(os.path.join(root, rel), "rb").read())
+# the whole step: every kernel's VALU instructions (bench.py: roofline.step), tied to every source a kernel of the step is made of
+import glob
+
+traffic["step_valu_lane_insts"] = sum(v["SQ_INSTS_VALU"] for v in tot.values()) * 64
+STEP_SOURCES = sorted(os.path.relpath(f, root) for pat in ("lurk_amd/csrc/*.hip", "lurk_amd/csrc/*.h", "lurk_amd/csrc/lair/trace_program.h") for f in glob.glob(os.path.join(root, pat)))
+hs = hashlib.sha256()
+for rel in STEP_SOURCES:
+    hs.update(open(os.path.join(root, rel), "rb").read())
+traffic["step_kernel_sources"] = STEP_SOURCES
+traffic["step_kernel_sources_sha256"] = hs.hexdigest()
 traffic["hash_kernel_sources"] = HASH_SOURCES
 traffic["hash_kernel_sources_sha256"] = h.hexdigest()
 json.dump(traffic, open(f"profiles/{prefix}_pmc_traffic.json", "w"), indent=1)
