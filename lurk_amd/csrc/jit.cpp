@@ -239,6 +239,20 @@ void emit_runner(std::ostringstream& o, const std::string& name, const std::vect
 
 std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
     std::ostringstream o;
+    // LURKHIP_JIT_DEFINES="NAME=VALUE,NAME=VALUE" (A/B hook): macros of the embedded headers for the compiled kernels (part of the
+    // source, hence of the code cache's key)
+    if (const char* defs = getenv("LURKHIP_JIT_DEFINES")) {
+        std::string d(defs);
+        size_t at = 0;
+        while (at < d.size()) {
+            size_t end = d.find(',', at);
+            if (end == std::string::npos) end = d.size();
+            const std::string item = d.substr(at, end - at);
+            const size_t eq = item.find('=');
+            if (eq != std::string::npos && eq > 0) o << "#define " << item.substr(0, eq) << " " << item.substr(eq + 1) << "\n";
+            at = end + 1;
+        }
+    }
     o << "#define LURKHIP_COMPILED_AIR 1\n#include \"stark_kernels.h\"\nnamespace lurkhip {\n";
     std::vector<std::string> perm, quot;
     for (size_t j = 0; j < prog.interaction_parts.size(); j++) {

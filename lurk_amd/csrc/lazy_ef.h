@@ -75,7 +75,12 @@ struct LazyEf {
 // Eight words of a power table (alpha^k / beta^t, written by an earlier kernel: constant for this one) at a wave-uniform
 // address.  Read through the constant address space so that the loads may be scalar ones even in a kernel that also stores
 // (the permutation rows: there they were 135 vector loads of one address each, behind the stores' possible aliases).
-#ifndef LURK_POWER_TABLES_GENERIC
+#if defined(LURK_AB_NO_SMEM)  // diagnostic (wrong values, same control flow): what the power tables' scalar loads cost
+__device__ __forceinline__ void load_w8(int32_t (&w)[8], const uint32_t* __restrict__ p) {
+#pragma unroll
+    for (int c = 0; c < 8; c++) w[c] = (int32_t)(uintptr_t)p + c;
+}
+#elif !defined(LURK_POWER_TABLES_GENERIC)
 __device__ __forceinline__ void load_w8(int32_t (&w)[8], const uint32_t* __restrict__ p) {
     const __attribute__((address_space(4))) uint32_t* cp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)p;
 #pragma unroll

@@ -1369,7 +1369,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         const uint32_t* prep_lde = pi >= 0 ? (sp ? pk->commit->full_lde[pi] : pk->commit->lde[pi]) : nullptr;
         PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], main_lde, prep_lde, perm_lde, perm_alpha, perm_beta, alpha,
                            cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true, alpha_pows_all, public_m_dev,
-                           dev_alpha ? cs_dev + 4 * (size_t)i : nullptr));
+                           dev_alpha ? cs_dev + 4 * (size_t)i : nullptr, nullptr, live_dev ? live_dev + live_off[i] : nullptr));
         for (uint32_t c = 0; c < qd; c++) {
             qmats.push_back(chunks + (size_t)c * h * 4);
             q_logn.push_back(sh->log_n[i]);

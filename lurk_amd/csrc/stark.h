@@ -66,7 +66,9 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
                       const uint32_t* shared_public_m = nullptr /* the public values on the device, Montgomery; null: uploaded by the call */,
                       const uint32_t* cumsum_dev = nullptr /* the chip's cumulative sum on the device (4 words, Montgomery): read by the kernel
                       instead of cumsum_m, which the host may not know yet (with shared_alpha_pows only) */,
-                      const QuotientSplit* split = nullptr /* this rank's rows only (honest_running_sum required) */);
+                      const QuotientSplit* split = nullptr /* this rank's rows only (honest_running_sum required) */,
+                      const uint32_t* col_live = nullptr /* device, one word per batch column as permutation_trace_impl left them (0: nobody computed
+                      the column: identically zero); the interaction waves step over those columns without reading their entries */);
 int32_t ef_powers_dev(lurkhip_ctx* ctx, const uint32_t* base_dev /* 4 words, device */, uint32_t* out_dev, uint32_t count, bool centred, bool reversed = false);
 uint32_t air_total_constraints(const lurkhip_air* a);  // constraints + batch columns + the three running-sum constraints
 

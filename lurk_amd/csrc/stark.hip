@@ -16,6 +16,7 @@
 //   last column = inclusive running sum over rows of the row's batch columns.
 #include <map>
 #include <mutex>
+#include <numeric>
 
 #include "air_vm.h"
 #include "babybear.h"
@@ -550,6 +551,30 @@ static PartLayout layout_parts(const std::vector<const std::vector<uint32_t>*>& 
         l.parts.reg_off[j] = off;
         if (!compiled) off += (*host[j])[airp::H_N_REGS] * 64u;
     }
+    // the pieces dealt to the waves so that the four SIMDs' loads are level (VmParts::piece_of): longest piece first, each to the
+    // least loaded SIMD that still has a wave free (SIMD s takes waves s, s + 4, ..); LURKHIP_BALANCE_WAVES=0: piece order (round 5)
+    {
+        const uint32_t n = l.parts.n_parts;
+        static const bool balance = getenv("LURKHIP_BALANCE_WAVES") == nullptr || atoi(getenv("LURKHIP_BALANCE_WAVES")) != 0;
+        for (uint32_t j = 0; j < n; j++) l.parts.piece_of[j] = (uint8_t)j;
+        if (balance && n > 4) {
+            std::vector<uint32_t> order(n);
+            std::iota(order.begin(), order.end(), 0u);
+            std::stable_sort(order.begin(), order.end(), [&](uint32_t x, uint32_t y) { return host[x]->size() > host[y]->size(); });
+            uint64_t load[4] = {0, 0, 0, 0};
+            uint32_t taken[4] = {0, 0, 0, 0};
+            for (uint32_t j : order) {
+                int best = -1;
+                for (int sd = 0; sd < 4; sd++) {
+                    const uint32_t cap = (n + 3u - (uint32_t)sd) / 4u;  // waves sd, sd + 4, .. below n
+                    if (taken[sd] < cap && (best < 0 || load[sd] < load[best])) best = sd;
+                }
+                l.parts.piece_of[(uint32_t)best + 4u * taken[best]] = (uint8_t)j;
+                taken[best]++;
+                load[best] += host[j]->size();
+            }
+        }
+    }
     l.regs_words = off;
     l.wp = w | 1u;
     const size_t fixed = (size_t)off + 64 + (size_t)host.size() * 512;  // row indices; per piece and lane one fold and one column sum
@@ -751,7 +776,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
                       const uint32_t* perm_lde_dev, const bb::ef& perm_alpha, const bb::ef& perm_beta, const bb::ef& alpha_m,
                       const bb::ef& cumsum_m, const uint32_t* public_values, uint32_t* out_dev, const uint32_t* shared_beta_pows,
                       const uint32_t* shared_starts, const uint32_t* pitches, bool honest_running_sum, const uint32_t* shared_alpha_pows,
-                      const uint32_t* shared_public_m, const uint32_t* cumsum_dev, const QuotientSplit* split) {
+                      const uint32_t* shared_public_m, const uint32_t* cumsum_dev, const QuotientSplit* split, const uint32_t* col_live) {
     LH_ARG(ctx, !cumsum_dev || shared_alpha_pows, "a cumulative sum on the device goes with a shared table of alpha powers");
     LH_ARG(ctx, !split || (honest_running_sum && getenv("LURKHIP_QUOTIENT_READ_NEXT_SUM") == nullptr), "a quotient on a rank's rows cannot read the next row's sums");
     if (split && split->n_rows == 0) return LURKHIP_OK;  // the rank's rows lie outside this chip's quotient domain
@@ -850,6 +875,7 @@ int32_t quotient_impl(lurkhip_ctx* ctx, lurkhip_air* a, uint32_t log_n, const ui
             q.trans_scale = neg_inv;
         }
         q.out = out_dev;
+        q.col_live = getenv("LURKHIP_QUOT_COL_LIVE") != nullptr && atoi(getenv("LURKHIP_QUOT_COL_LIVE")) == 0 ? nullptr : col_live;
         q.sel = selector_table_of(ctx, log_n, lqd);
         q.regs_words = lay.regs_words;
         q.wp = lay.wp;

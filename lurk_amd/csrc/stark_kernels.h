@@ -28,10 +28,18 @@ __device__ LURKHIP_SINK_OP ef sink_ef_mul(ef a, ef b) { return bb::ef_mul(a, b);
 // thrash L1: a workgroup's rows are hundreds of KB apart from lane to lane).  The (row, column) pairs are dealt to all the
 // threads of the workgroup and eight loads go out before the first is awaited: one load per trip, awaited on the spot, made
 // the staging a chain of n_rows memory round trips -- the longest phase of the permutation and quotient kernels.
+// LURK_STAGE_UR loads go out before the first is awaited (A/B: LURKHIP_JIT_DEFINES=LURK_STAGE_UR=16 for the compiled kernels).
+#ifndef LURK_STAGE_UR
+#define LURK_STAGE_UR 8
+#endif
+// How many batches ahead the quotient's interaction waves ask for their permutation-column entries (QuotientSink::batch_live).
+#ifndef LURK_QUOT_ENTRY_DEPTH
+#define LURK_QUOT_ENTRY_DEPTH 1
+#endif
 __device__ __forceinline__ void stage_rows(uint32_t* __restrict__ tile, uint32_t wp, const uint32_t* __restrict__ mat, uint32_t w,
                                            const uint32_t* __restrict__ idx, uint32_t n_rows, uint32_t pitch = 0 /* words between rows; 0: w */) {
     if (pitch == 0) pitch = w;
-    constexpr int UR = 8;
+    constexpr int UR = LURK_STAGE_UR;
     const uint32_t total = n_rows * w;  // < 2^24: the quotient e / w below is exact after one correction step
     const float inv_w = 1.0f / (float)w;
     for (uint32_t e0 = threadIdx.x; e0 < total; e0 += blockDim.x * UR) {
@@ -179,6 +187,11 @@ struct VmParts {
     const uint32_t* prog[MAX_VM_PARTS];
     uint32_t reg_off[MAX_VM_PARTS];  // word offset of the piece's register file regs[n_regs][64] in LDS
     uint32_t n_parts;
+    // Round 6: wave w runs piece piece_of[w].  The waves of a workgroup go to the CU's four SIMDs round robin (wave w -> SIMD w mod 4)
+    // and a SIMD issues for one wave at a time, so a workgroup lasts as long as its most loaded SIMD: the host deals the pieces to the
+    // waves so that the SIMDs' sums of piece lengths are level (stark.hip: balance_parts) -- in piece order the first SIMD of an
+    // eval_builtin_expr quotient workgroup carried 1823 program words against 1104 on the last.
+    uint8_t piece_of[MAX_VM_PARTS];
 };
 
 struct PermArgs {
@@ -220,14 +233,15 @@ __device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
         __syncthreads();
         main_l = tile + lane * a.wp;
     }
-    const uint32_t* prog = a.parts.prog[wave];
+    const uint32_t piece = __builtin_amdgcn_readfirstlane((uint32_t)a.parts.piece_of[wave]);
+    const uint32_t* prog = a.parts.prog[piece];
     airvm::Sources src{main_l, a.main + (size_t)nx * a.main_pitch, a.prep + (size_t)ic * a.pw, a.prep + (size_t)nx * a.pw, nullptr, {0u, 0u, 0u}};
     PermSink sink{LogupAccum{a.beta_pows, a.starts}, a.batch, a.out + (size_t)ic * a.out_pitch};
     sink.col = prog[airp::H_FIRST_COLUMN];
     sink.live = live;
     sink.col_live = a.col_live;
     sink.marker = lane == 0u;
-    Runner::run(prog, wave, src, lds + a.parts.reg_off[wave] + lane, sink);
+    Runner::run(prog, piece, src, lds + a.parts.reg_off[piece] + lane, sink);
     if (sink.acc.in_batch) sink.flush();
     if (a.parts.n_parts > 1) {
 #pragma unroll
@@ -292,6 +306,10 @@ struct QuotientArgs {
     // next row's storage row belongs to another rank; values go to out[brev(local row)][4], natural order inside the rank's
     // sub-coset (split_plan.h: rows_of).  split = 0: the whole domain, as before.
     uint32_t split, s_base, n_rows, next_off, log_rows;
+    // Round 6: one word per batch column, 0 = the permutation stage found no wave that computed it (stark_kernels.h: PermSink): the
+    // column is identically zero, and so are its interactions' multiplicities -- the quotient's interaction waves step over it without
+    // asking memory for its entry.  Null: every column is tested on the wave's own values (batch_live), as in round 5.
+    const uint32_t* col_live;
 };
 
 struct QuotientSink {
@@ -351,13 +369,33 @@ struct QuotientSink {
     // The column's entry is asked for one batch AHEAD (prefetch, then at every test): a lane's entries are perm_pitch words apart from
     // its neighbours', every load is a memory round trip of its own, and the test needs the value before anything else of the batch
     // has been issued -- loaded on the spot it exposed that latency once per batch (a dozen times per wave).
+    // Round 6: the wait that was left.  A shard's dead columns come in RUNS (the lookups of a never-taken branch are neighbours), a
+    // dead batch is a dozen instructions, and each one's test waited for its own entry -- a chain of dependent memory round trips,
+    // one per dead column, that the one-ahead request cannot cover (nothing runs between two of them).  The permutation stage already
+    // knows which columns nobody computed (col_live, one word per column): their entry is zero without asking memory (a scalar load of
+    // the flag), so a run of dead columns is a run of register-only tests.  (Measured first and rejected: more entries in flight -- LURK_QUOT_ENTRY_DEPTH 3 and 6: quotient_all
+    // 4.2 -> 4.7 ms; the compiler waits for ALL outstanding loads at the join of the live and dead paths.)
     uint4 next_e = make_uint4(0u, 0u, 0u, 0u), cur_e = make_uint4(0u, 0u, 0u, 0u);
+    const uint32_t* col_live = nullptr;
+    uint32_t last_col = 0;  // perm_w - 1: the running sum's column, the last of the row
     bool have_e = false;
-    __device__ __forceinline__ void prefetch() { next_e = *reinterpret_cast<const uint4*>(perm_l + 4 * col); }
+    __device__ __forceinline__ bool flagged_dead(uint32_t c) const {
+        if (col_live == nullptr || c >= last_col) return false;
+        const __attribute__((address_space(4))) uint32_t* lp = (const __attribute__((address_space(4))) uint32_t*)(uintptr_t)(col_live + c);  // wave-uniform
+        return *lp == 0u;
+    }
+    __device__ __forceinline__ void request(uint32_t c) {
+#ifndef LURK_AB_NO_ENTRY  // (diagnostic: what the entries' loads cost -- wrong values)
+        if (!flagged_dead(c)) next_e = *reinterpret_cast<const uint4*>(perm_l + 4 * c);  // (past a piece's last batch: the next piece's column or the running sum's -- valid, unused)
+#endif
+    }
+    __device__ __forceinline__ void prefetch() { request(col); }
     __device__ __forceinline__ bool batch_live(uint32_t mults_or) {
-        cur_e = next_e;
+        // (a flagged column's entry is zero on the whole coset -- the LDE of a zero column -- and is not read; the multiplicities are
+        // still tested on the wave's own points: they vanish on the trace domain, which says nothing about a product of columns elsewhere)
+        cur_e = flagged_dead(col) ? make_uint4(0u, 0u, 0u, 0u) : next_e;
         have_e = true;
-        next_e = *reinterpret_cast<const uint4*>(perm_l + 4 * (col + 1));  // (past a piece's last batch: the next piece's column or the running sum's -- valid, unused)
+        request(col + 1);
         return __builtin_amdgcn_ballot_w64((mults_or | cur_e.x | cur_e.y | cur_e.z | cur_e.w) != 0u) != 0ull;
     }
     __device__ __forceinline__ void skip_batch() {
@@ -413,13 +451,16 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
         // which stay in global memory, and a second tile would halve the waves an LDS-bound CU can hold
         if (wave == 0) idx[lane] = sl;
         __syncthreads();
+#ifndef LURK_AB_NO_STAGE  // (diagnostic: what staging the tile costs -- wrong values)
         stage_rows(tile_l, a.wp, a.main, a.w, idx, 64u, a.main_pitch);
+#endif
         __syncthreads();
         main_l = tile_l + lane * a.wp;
     }
     // selectors at x = g * w_Q^i (p3 TwoAdicMultiplicativeCoset::selectors_on_coset): the constraint wave needs them
     uint32_t is_first = 0, is_last = 0, is_trans = 0;
-    const bool cons_wave = wave < a.n_cons_parts;
+    const uint32_t piece = __builtin_amdgcn_readfirstlane((uint32_t)a.parts.piece_of[wave]);  // (VmParts: the pieces are dealt to the waves by length)
+    const bool cons_wave = piece < a.n_cons_parts;
     if (cons_wave && a.sel) {
         // (functions of the domain only: a table of the context -- per row they were a power ladder and two Fermat inversions,
         // some 660 instructions beside the two to three thousand of an eval row's constraints)
@@ -440,12 +481,19 @@ __device__ __forceinline__ void quotient_body(const QuotientArgs& a) {
     const uint32_t* perm_l = a.perm + (size_t)sl * a.perm_pitch;
     const uint32_t* perm_n = a.perm + (size_t)(a.split ? sl : s_next) * a.perm_pitch;
     QuotientSink sink{a.alpha_pows, a.k_total, LogupAccum{a.beta_pows, a.starts}, a.batch, perm_l};
-    const uint32_t* prog = a.parts.prog[wave];
+    const uint32_t* prog = a.parts.prog[piece];
     const uint32_t first = prog[airp::H_FIRST_COLUMN];  // constraint piece: its first constraint; interaction piece: its first column
     sink.col = cons_wave ? 0u : first;
+    sink.last_col = a.perm_w - 1;
+    sink.col_live = a.col_live;
     sink.prime(cons_wave ? first : a.n_cons + first);
     if (!cons_wave) sink.prefetch();
-    Runner::run(prog, wave, src, regs + a.parts.reg_off[wave] + lane, sink);
+#if defined(LURK_AB_NO_CONS)  // diagnostics (wrong values): the interaction waves alone / the constraint waves alone
+    if (!cons_wave)
+#elif defined(LURK_AB_NO_INTER)
+    if (cons_wave)
+#endif
+    Runner::run(prog, piece, src, regs + a.parts.reg_off[piece] + lane, sink);
     if (sink.acc.in_batch) sink.flush();
     // every batch column's entry of the local row was read by the piece that owns the column (QuotientSink::flush): the pieces
     // hand their sums over with their folds, so that the local row is read once (round 4: the quotient kernels fetched the
