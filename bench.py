@@ -248,9 +248,9 @@ def measured_shape(workload: str):
             "dead_permutation_cell_share_real": shape.get("lookup_sparsity", {}).get("dead_cell_share_at_2^20")}
 
 
-def build_workload(name: str, world: int, log_rows: int):
+def build_workload(name: str, world: int, log_rows: int, eval_rows: int | None = None):
     """(source, lurk_chips, entry, main args, eval function name, description)."""
-    n = 1 << log_rows
+    n = eval_rows if eval_rows else 1 << log_rows
     if name == "eval-only":
         from lurk_amd.programs import synth_eval as se
 
@@ -264,6 +264,135 @@ def build_workload(name: str, world: int, log_rows: int):
             "(tests/golden/fib_shape.json), partial eval, u64 extern chips"
             if name == "fib-mix" else "lurk-mix: all 39 Lurk functions at their measured shapes (widths 9 ... 815), 6 memory tables, byte table, entrypoint")
     return mix.source, True, mix.entry, mix.main_args, "eval", desc
+
+
+def poseidon2_bench(args, world, rank, device_index, distributed):
+    """BASELINE configs[1]: 2^log_n standalone Poseidon2-BabyBear hashes (`PoseidonChipset::hash`, /root/reference/src/core/poseidon.rs:30-38;
+    `Hasher::hash`, /root/reference/src/core/zstore.rs:241-248) per step through lurkhip_poseidon2_hash8_dev, inputs and digests resident in
+    HBM, canonical words (the ZStore's form).  N > 1: every rank hashes its own batch (no collective: the path does not exchange anything)."""
+    import torch
+    import torch.distributed as dist
+
+    import lurk_amd
+    from lurk_amd.poseidon import PoseidonChipset
+
+    P = 2013265921
+    ctx = lurk_amd.Context(device_index)
+    n = 1 << args.log_n
+    dev = torch.device("cuda", device_index)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(0x4C55524B + rank)  # "LURK" (SURVEY.md 8d)
+
+    def fence():
+        ctx.sync()
+        torch.cuda.synchronize()
+        if distributed:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    def measure(width, steps, warmup, what="hash"):
+        chip = PoseidonChipset(ctx, width)
+        x = torch.randint(0, P, (n, width), dtype=torch.int32, device=dev, generator=gen)
+        cols = 8 if what == "hash" else 8 + chip.num_cols()
+        out = torch.empty((n if what == "hash" else min(n, 1 << 20), cols), dtype=torch.int32, device=dev)
+        rows = out.shape[0]
+        run = (lambda: chip.hash_dev(x, out, rows)) if what == "hash" else (lambda: chip.witness_dev(x, out, rows))
+        torch.cuda.synchronize()
+        for _ in range(warmup):
+            run()
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(steps):
+            run()
+        fence()
+        dt = (time.perf_counter() - t0) / steps
+        sample = None
+        if what == "hash":  # parity of a sample against the oracle (the checker, after the timed region)
+            from oracle import binding as ob
+
+            k = 4096
+            xs = x[:k].cpu().numpy().view(np.uint32)
+            sample = bool(np.array_equal(out[:k].cpu().numpy().view(np.uint32), ob.p2_hash8(width, xs)))
+        del x, out
+        return dt, rows, sample
+
+    W = args.p2_width
+    dt, _, parity = measure(W, args.steps, args.warmup)
+    t_all = torch.tensor([dt], dtype=torch.float64)
+    if distributed:
+        t_dev = t_all.to(dev) if dist.get_backend() == "nccl" else t_all
+        dist.all_reduce(t_dev, op=dist.ReduceOp.MAX)
+        dt = float(t_dev.cpu()[0])
+    if rank == 0:
+        alg_bytes = (W + 8) * 4 * n  # SURVEY.md 8(d): (W + 8) * 4 B per permutation
+        hbm = alg_bytes / dt / 1e9
+        valu = None
+        try:
+            with open(os.path.join(ROOT, "profiles", "pmc_poseidon2.json")) as f:
+                pmc = json.load(f)
+            per_perm = pmc["valu_lane_insts_per_permutation"][str(W)]
+            rate = per_perm * n / dt / 1e12
+            valu = {"achieved": rate, "unit": "T lane-instr/s", "peak": VALU_FULL_RATE, "frac": rate / VALU_FULL_RATE, "valu_lane_insts_per_permutation": per_perm,
+                    "source": "profiles/pmc_poseidon2.json (rocprofv3 --pmc SQ_INSTS_VALU x 64 lanes / permutations, static) / this run's time (live)"}
+        except Exception:
+            pass
+        others = {}
+        for w2 in (16, 24, 32, 40):
+            if w2 != W:
+                d2, _, ok2 = measure(w2, max(3, args.steps // 4), 1)
+                others[f"hash8_w{w2}"] = {"ms_per_step": d2 * 1e3, "permutations_per_s": n / d2, "GBs_algorithmic": (w2 + 8) * 4 * n / d2 / 1e9, "parity_sample": ok2}
+        for w2 in (24, 32, 40):  # the wide witness of the hash chips' rows (/root/reference/src/core/poseidon.rs:65-72), 2^20 rows
+            d2, rows2, _ = measure(w2, 3, 1, what="witness")
+            cols2 = 8 + PoseidonChipset(ctx, w2).num_cols()
+            others[f"wide_witness_w{w2}"] = {"rows": rows2, "ms": d2 * 1e3, "rows_per_s": rows2 / d2, "GBs_algorithmic": (w2 + cols2) * 4 * rows2 / d2 / 1e9}
+        out = {
+            "metric": f"Poseidon2-BabyBear hashes/sec (width {W} -> 8 lanes), 2^{args.log_n} per step", "value": world * n / dt, "unit": "permutations/s",
+            "n_gpus": world, "steps": args.steps, "warmup": args.warmup, "ms_per_step": dt * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "u32", "data": "synthetic",
+            "config": {"workload": f"BASELINE configs[1]: standalone Poseidon2-BabyBear, 2^{args.log_n} permutations of width {W} per GPU through lurkhip_poseidon2_hash8_dev "
+                                   "(PoseidonChipset::hash, src/core/poseidon.rs:30-38; canonical words, inputs and digests resident in HBM)",
+                       "parity_sample_vs_oracle": parity, "other_shapes": others},
+            "roofline": {"bound": "int32-valu" if valu else "hbm", "kernel": "poseidon2.hip: the hash8 kernel (one permutation per lane, state in registers)",
+                         "achieved": valu["achieved"] if valu else hbm, "peak": VALU_FULL_RATE if valu else HBM_PEAK_GBS, "unit": "T lane-instr/s" if valu else "GB/s",
+                         "frac": valu["frac"] if valu else hbm / HBM_PEAK_GBS, "int32_valu": valu,
+                         "hbm": {"bound": "hbm", "achieved": hbm, "peak": HBM_PEAK_GBS, "unit": "GB/s", "frac": hbm / HBM_PEAK_GBS,
+                                 "algorithmic_bytes_per_step": alg_bytes, "rule": "SURVEY.md 8(d): (W + 8) * 4 B per permutation"},
+                         "traffic": None,
+                         "note": "instruction-bound: ~1.3 k modular multiplications per width-24 permutation against 128 B of traffic (SURVEY.md 8d); the HBM fraction is reported because the contract asks for it"},
+        }
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                from oracle import binding as ob
+                from lurk_amd import synth
+
+                cores = usable_cores()
+                ob.cpu_port_set_threads(cores)
+                k = 1 << 22
+                xs = synth.field_elements((k, W), seed=7)
+                kind_note = "oracle/cpu_port.c: cp_p2_hash8 (sixteen rows per AVX-512 register set, OpenMP over blocks)"
+                try:
+                    ob.cpu_port_p2_hash8(W, xs[:64])
+                    fn = lambda: ob.cpu_port_p2_hash8(W, xs)
+                except RuntimeError:
+                    k = 1 << 18
+                    xs = xs[:k]
+                    fn, cores, kind_note = (lambda: ob.p2_hash8(W, xs)), 1, "oracle/poseidon2.c (scalar, one thread: no AVX-512 on this host)"
+                fn()
+                reps, t0 = 0, time.perf_counter()
+                while reps < 3 or time.perf_counter() - t0 < 10.0:
+                    fn()
+                    reps += 1
+                dtc = (time.perf_counter() - t0) / reps
+                out["cpu_baseline"] = {"value": k / dtc, "unit": "permutations/s", "cores": cores, "kind": "port",
+                                       "sample": f"{reps} passes over 2^{k.bit_length() - 1} width-{W} preimages ({reps * dtc:.1f} s), {kind_note}; a port, not the reference's "
+                                                 "`Hasher::hash` (no Rust toolchain): never quote the ratio as 'vs the reference'"}
+            except Exception as e:
+                out["cpu_baseline"] = {"error": repr(e)}
+        print(json.dumps(out), flush=True)
+    if distributed:
+        dist.barrier()
+        dist.destroy_process_group()
+    ctx.close()
 
 
 XGMI_LINK_GBS = 153.0  # per link and direction, seven links per GPU (the task statement's figure; MI355X_MICROARCH.md)
@@ -427,7 +556,13 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=("fib-mix", "eval-only", "lurk-mix"), default="fib-mix")
+    ap.add_argument("--workload", choices=("fib-mix", "eval-only", "lurk-mix", "poseidon2"), default="fib-mix",
+                    help="fib-mix (default): BASELINE configs[2], the metric's workload; lurk-mix: configs[4]; poseidon2: configs[1], 2^--log-n standalone Poseidon2 hashes")
+    ap.add_argument("--eval-rows", type=int, default=None,
+                    help="N = 1: exactly this many eval rows instead of 2^--log-rows -- e.g. --workload lurk-mix --eval-rows 6867: the machine at the heights "
+                         "of the reference's demo/mastermind.lurk (tests/golden/fib_shape.json: mastermind), the REPL-sized proof of BASELINE configs[4]")
+    ap.add_argument("--log-n", type=int, default=24, help="--workload poseidon2: log2 of the permutations per step")
+    ap.add_argument("--p2-width", type=int, default=24, choices=(16, 24, 32, 40), help="--workload poseidon2: the headline width (24 = hash3, the commitment hash)")
     ap.add_argument("--log-rows", type=int, default=None, help="log2 of the eval rows per GPU (default 20; 18 for lurk-mix)")
     ap.add_argument("--queries", type=int, default=100)
     ap.add_argument("--pow-bits", type=int, default=16)
@@ -531,6 +666,8 @@ def main():
     import lurk_amd
     from lurk_amd import lair, prover, shards
 
+    if args.workload == "poseidon2":
+        return poseidon2_bench(args, world, rank, device_index, distributed)
     if args.split == "intra":
         return split_intra(args, world, rank, device_index, distributed, oversubscribed)
     ctx = lurk_amd.Context(device_index)
@@ -540,10 +677,15 @@ def main():
         ProtocolProfile.preset(args.profile).install(ctx)
     log_rows = args.log_rows if args.log_rows is not None else (18 if args.workload == "lurk-mix" else LOG_ROWS)
     n = 1 << log_rows
+    if args.eval_rows:
+        if world != 1 or args.shards_per_rank not in (None, 1):
+            raise SystemExit("--eval-rows is for one GPU and one shard")
+        n, log_rows = args.eval_rows, max(1, (args.eval_rows - 1).bit_length())
+        args.no_host_pipeline = args.no_second_profile = True
     dev = "cuda" if distributed and not oversubscribed else "cpu"
 
     # ---- host side, once: execute the ONE program (on rank 0, or on every rank with --execute-on all), flatten this rank's shards into HBM
-    source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, world, log_rows)
+    source, lurk_chips, entry, main_args, eval_name, workload_desc = build_workload(args.workload, world, log_rows, args.eval_rows)
     scatter = distributed and world > 1 and args.execute_on == "rank0"
     executes = not scatter or rank == 0
     top = lair.Toplevel(source, lurk_chips=lurk_chips)
@@ -1224,6 +1366,13 @@ def main():
                 "stages_ms": sequential["stages_ms"] if sequential else {k: v[0] / args.steps for k, v in spans.items() if v[1]},
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),
+                "eval_rows": n,
+                "workload_detail": (None if args.workload != "lurk-mix" else
+                                    ("lurk-mix at the REAL height of demo/mastermind.lurk (--eval-rows 6867: every tall chip at the padded height of the reference's own run, "
+                                     "tests/test_mix_programs.py::test_lurk_mix_at_the_real_mastermind_height; the REPL-sized proof of src/core/cli/repl.rs:164-207: proof_latency_ms is "
+                                     "the number that matters)" if args.eval_rows else
+                                     "lurk-mix scaled to 2^log_rows eval rows with the ingress-side chips at their measured (absolute) sizes: the irregular-width commitment of SURVEY.md 8(d) "
+                                     "row 5, NOT the mastermind run's height (that is --eval-rows 6867)")),
                 "shards": n_shards,
                 "executed_on": ("rank 0 (its shards' kernel inputs sent to their owners: shards.scatter_prepared)" if scatter else "every rank") if distributed else "this process",
                 "shards_per_rank": spr,

@@ -174,6 +174,21 @@ def cpu_port_set_threads(n: int) -> None:
     lib().cp_set_threads(int(n))
 
 
+def cpu_port_p2_hash8(width: int, states) -> np.ndarray:
+    """PoseidonChipset::hash of every row of `states` ([n][width], canonical) on all host cores, sixteen rows per AVX-512 register set
+    (oracle/cpu_port.c: cp_p2_hash8): the CPU leg of BASELINE config 2.  Raises when the CPU has no AVX-512."""
+    L = lib()
+    x = _u32(states)
+    n, w = x.shape
+    assert w == width
+    out = np.empty((n, 8), dtype=np.uint32)
+    L.cp_p2_hash8.restype = C.c_int
+    L.cp_p2_hash8.argtypes = [C.c_int, C.c_size_t, C.c_void_p, C.c_void_p]
+    if L.cp_p2_hash8(width, n, x.ctypes.data, out.ctypes.data) != 0:
+        raise RuntimeError("cp_p2_hash8: unknown width or no AVX-512 on this CPU")
+    return out
+
+
 def cpu_port_lde(mat, log_blowup=1) -> np.ndarray:
     L = lib()
     mat = _u32(mat)

@@ -325,6 +325,78 @@ static void perm16_v(vstate s) {
 static void perm16_v(vstate s) { perm16_v_generic(s); }
 #endif
 
+/* ---- BASELINE config 2 on the CPU: the batched hash of the Lurk chipset (/root/reference/src/core/poseidon.rs:30-38,61-63;
+ * /root/reference/src/core/zstore.rs:241-248) -- digest = the first 8 lanes of the width-W permutation of the W-lane preimage -- for
+ * W = 16 .. 48, sixteen states at a time (lane l of the sixteen states = one 512-bit register per state word; round structure of
+ * oracle/poseidon2.c: permute_rec, the tables of or_p2_lookup), OpenMP over blocks of sixteen rows.  bench.py --workload poseidon2
+ * times it as the "port" baseline; tests/test_cpu_port.py holds it against the scalar oracle.  Canonical words in and out.
+ * Returns 0, or -1 for an unknown width / a CPU without AVX-512 (the caller falls back to the scalar oracle). */
+#if defined(__x86_64__)
+#define P2_MAX_W 48
+static T512 void ext_layer_w(v16* s, int w) {
+    for (int b = 0; b < w; b += 4) {
+        const v16 x0 = s[b], x1 = s[b + 1], x2 = s[b + 2], x3 = s[b + 3];
+        const v16 t01 = v_add(x0, x1), t23 = v_add(x2, x3), t = v_add(t01, t23);
+        const v16 a = v_add(t, x1), c = v_add(t, x3);
+        s[b] = v_add(a, t01);
+        s[b + 1] = v_add(a, v_add(x2, x2));
+        s[b + 2] = v_add(c, t23);
+        s[b + 3] = v_add(c, v_add(x0, x0));
+    }
+    v16 sums[4] = {s[0], s[1], s[2], s[3]};
+    for (int i = 4; i < w; i++) sums[i & 3] = v_add(sums[i & 3], s[i]);
+    for (int i = 0; i < w; i++) s[i] = v_add(s[i], sums[i & 3]);
+}
+static T512 void hash8_block16(int w, int rp, const uint32_t* ext_m, const uint32_t* int_m, const uint32_t* diag_m, const uint32_t* in, uint32_t* out, size_t rows) {
+    v16 s[P2_MAX_W];
+    const v16 r2 = _mm512_set1_epi32((int)CP_R2), one = _mm512_set1_epi32(1);
+    /* row l of the block -> lane l: gather word i of each of the (up to) sixteen rows */
+    uint32_t idx[16];
+    for (int l = 0; l < 16; l++) idx[l] = (uint32_t)((size_t)l < rows ? l : 0) * (uint32_t)w;
+    const v16 vidx = _mm512_loadu_si512((const void*)idx);
+    for (int i = 0; i < w; i++) s[i] = v_mul(_mm512_i32gather_epi32(vidx, (const void*)(in + i), 4), r2); /* to Montgomery */
+    ext_layer_w(s, w);
+    for (int r = 0; r < 8; r++) {
+        if (r == 4) {
+            for (int q = 0; q < rp; q++) {
+                s[0] = v_pow7(v_add(s[0], _mm512_set1_epi32((int)int_m[q])));
+                v16 sum = s[0];
+                for (int i = 1; i < w; i++) sum = v_add(sum, s[i]);
+                for (int i = 0; i < w; i++) s[i] = v_add(sum, v_mul(_mm512_set1_epi32((int)diag_m[i]), s[i]));
+            }
+        }
+        for (int i = 0; i < w; i++) s[i] = v_pow7(v_add(s[i], _mm512_set1_epi32((int)ext_m[r * w + i])));
+        ext_layer_w(s, w);
+    }
+    uint32_t lanes[8][16];
+    for (int i = 0; i < 8; i++) _mm512_storeu_si512((void*)lanes[i], v_mul(s[i], one)); /* from Montgomery */
+    for (size_t l = 0; l < rows && l < 16; l++)
+        for (int i = 0; i < 8; i++) out[l * 8 + (size_t)i] = lanes[i][l];
+}
+int cp_p2_hash8(int width, size_t n, const uint32_t* in, uint32_t* out) {
+    or_p2_params p;
+    if (width < 4 || width > P2_MAX_W || (width & 3) || or_p2_lookup(width, &p) != 0) return -1;
+    if (!(__builtin_cpu_supports("avx512f") && __builtin_cpu_supports("avx512dq"))) return -1;
+    uint32_t ext_m[8 * P2_MAX_W], int_m[64], diag_m[P2_MAX_W];
+    if (p.rounds_p > 64) return -1;
+    for (int i = 0; i < 8 * width; i++) ext_m[i] = to_m(p.ext_rc[i]);
+    for (int i = 0; i < p.rounds_p; i++) int_m[i] = to_m(p.int_rc[i]);
+    for (int i = 0; i < width; i++) diag_m[i] = to_m(p.diag[i]);
+    const long blocks = (long)((n + 15) / 16);
+#pragma omp parallel for schedule(static)
+    for (long b = 0; b < blocks; b++) {
+        const size_t r0 = (size_t)b * 16;
+        hash8_block16(width, p.rounds_p, ext_m, int_m, diag_m, in + r0 * (size_t)width, out + r0 * 8, n - r0);
+    }
+    return 0;
+}
+#else
+int cp_p2_hash8(int width, size_t n, const uint32_t* in, uint32_t* out) {
+    (void)width, (void)n, (void)in, (void)out;
+    return -1;
+}
+#endif
+
 /* the sponges of rows row0 .. row0 + VL of the matrices which[0..nw), VL at a time */
 static void sponge_v(const uint32_t* const* mats, const uint32_t* widths, const int* which, int nw, size_t row0, uint32_t* out) {
     vstate s;

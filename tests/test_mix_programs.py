@@ -213,3 +213,40 @@ def test_lurk_mix_is_not_sparser_than_the_real_mastermind_machine(oracle):
     for c in ("eval_builtin_expr", "apply", "ingress", "eval_binop_num", "env_lookup", "hash4"):
         assert mix[c][0]["dead_columns"] <= real[c]["dead_columns"], (c, mix[c][0], real[c])
     assert mix["eval"][0]["dead_columns"] <= real["eval"]["dead_columns"] + 4
+
+
+def test_lurk_mix_at_the_real_mastermind_height():
+    """BASELINE config 5 at the height the real script has: `lurk_mix(6867)` -- the eval rows of the
+    reference's demo/mastermind.lurk under its own evaluator (tests/golden/fib_shape.json: mastermind.rows) -- chip by chip against
+    that run's PADDED heights.  Every chip the real run gives at least 64 rows has exactly the real padded height (eval 8192,
+    env_lookup 8192, eval_builtin_expr 4096, apply 4096, ingress 2048, hash4 2048, ...).  The others are never LIGHTER than real: the
+    generator's leaves are as tall as the walker that calls them (the u64 gadgets, equal_inner, eval_coroutine_expr: real 0 .. 62
+    rows, here up to 4096 rows of a 10-column chip) and the 13 functions mastermind never calls stay at a token height so that all
+    39 widths are proved.  In cells the stand-in is within +8 % of the real machine, main and permutation, and not below it."""
+    real, chips = SHAPE["mastermind"], SHAPE["chips"]
+    e = real["rows"]["eval"]
+    assert e == 6867
+    mix = lm.lurk_mix(e)
+    top = lair.Toplevel(mix.source, lurk_chips=True)
+    q = lair.QueryRecord(top)
+    top.execute_by_name(mix.entry, mix.main_args, q)
+
+    def padded(x):
+        return 0 if x == 0 else 1 << (max(x, 1) - 1).bit_length()
+
+    main = {"real": 0, "mix": 0}
+    perm = {"real": 0, "mix": 0}
+    for f in lm.LURK_FUNC_ORDER:
+        got, r = q.num_func_queries(top.func_index(f)), real["rows"].get(f, 0)
+        if r >= 64 and f != "equal_inner":
+            assert padded(got) == padded(r), (f, got, r)
+        assert padded(got) >= padded(r), (f, got, r)
+        assert padded(got) <= max(padded(r), 4096 if f == "eval_coroutine_expr" else 256), (f, got, r)
+        for acc, key, k in ((main, "width", 1), (perm, "permutation_width", 4)):
+            acc["real"] += padded(r) * chips[f][key] * k
+            acc["mix"] += padded(got) * chips[f][key] * k
+    for acc in (main, perm):
+        assert acc["real"] <= acc["mix"] <= 1.08 * acc["real"], acc
+    # the memory tables the run fills: 4- and 5-wide at the real padded heights
+    for ml in (4, 5):
+        assert padded(q.num_mem_queries(ml)) == padded(real["mem_rows"][str(ml)]), ml
