@@ -253,6 +253,13 @@ std::string jit_source(const lair::AirPrograms& prog, uint32_t batch) {
             at = end + 1;
         }
     }
+    // Round 6: code compiled at run time, on the target box, by whatever hiprtc is there, takes the CONTRACT-CLEAN spelling of the
+    // signed multiply-add (babybear.h: LURK_MAD_CARRY_DECLARED 3, an explicit `vcc` clobber) instead of the library's default, which
+    // overwrites an inline-assembly input operand and is only held by an A/B build of the ahead-of-time compiled library
+    // (tests/test_mad_ab_gpu.py).  Measured on the fib-mix step, alternating: quotient_all 4.29 / 4.28 ms with the trick, 4.38 / 4.39
+    // declared; permutation 1.96 either way; the step inside its noise (47.1 - 47.3 against 47.2 - 47.5 ms).  LURKHIP_JIT_DEFINES
+    // can still set it back to 0 for an A/B.
+    o << "#ifndef LURK_MAD_CARRY_DECLARED\n#define LURK_MAD_CARRY_DECLARED 3\n#endif\n";
     o << "#define LURKHIP_COMPILED_AIR 1\n#include \"stark_kernels.h\"\nnamespace lurkhip {\n";
     std::vector<std::string> perm, quot;
     for (size_t j = 0; j < prog.interaction_parts.size(); j++) {

@@ -226,7 +226,9 @@ struct Gen {
     }
 
     std::string source() {
-        o << "#define LURKHIP_COMPILED_TRACE 1\n#include \"trace_kernels.h\"\nnamespace lurkhip_trace {\n"
+        // (run-time compiled code takes the contract-clean multiply-add: jit.cpp, babybear.h LURK_MAD_CARRY_DECLARED 3)
+        o << "#ifndef LURK_MAD_CARRY_DECLARED\n#define LURK_MAD_CARRY_DECLARED 3\n#endif\n"
+          << "#define LURKHIP_COMPILED_TRACE 1\n#include \"trace_kernels.h\"\nnamespace lurkhip_trace {\n"
           << "__device__ __forceinline__ void jit_row(const TraceArgs& a, const uint32_t row_i, RowWriter& w) {\n";
         // the prologue of trace_row (trace.rs:82-131): nonce, outputs, provide record, depth bytes + 2 requires, inputs
         line(1, "w.put_int(0, a.nonce_start + row_i);");

@@ -2,7 +2,12 @@
 build hands the instruction's unused carry-out pair over as an *input* (no s_nop between products), the variant build
 (`make -C lurk_amd/csrc variant` -> liblurkhip_declared.so, -DLURK_MAD_CARRY_DECLARED=1) declares it as an output.  Every field
 multiplication of the hashing, NTT, AIR and opening kernels goes through that macro: both builds must produce the same
-hashes, commitments and proof words."""
+hashes, commitments and proof words.
+
+Round 6: the kernels compiled at RUN time, on the target box (hiprtc: the chips' permutation / quotient kernels, jit.cpp, and their
+trace kernels, trace_jit.cpp), no longer depend on the trick at all -- their generated source selects the contract-clean form with an
+explicit `vcc` clobber (LURK_MAD_CARRY_DECLARED 3; it costs the quotient 0.1 of its 4.3 ms, nothing measurable of the step).  What
+this A/B still guards is the ahead-of-time compiled library, built and tested here with the toolchain of this image."""
 import hashlib
 import json
 import os
