@@ -247,7 +247,54 @@ def read_lurk(text: str):
     return out
 
 
-def fold_repl_script(text: str) -> str:
+def repl_forms(text: str):
+    """The top-level forms of a REPL script: [(head or None for a bare expression, [argument texts], whole text)] -- `!(def f ..)` is
+    ("def", ["f", ".."], "!(def f ..)").  Text in, text out."""
+    toks = _TOKEN.findall(re.sub(r";[^\n]*", "", text))
+    pos = 0
+
+    def form():
+        nonlocal pos
+        t = toks[pos]
+        pos += 1
+        if t in ("(", "!("):
+            out = [t]
+            while toks[pos] != ")":
+                out += form()
+            pos += 1
+            return out + [")"]
+        if t == "'":
+            return [t] + form()
+        return [t]
+
+    def txt(fm):
+        return " ".join(fm).replace("( ", "(").replace(" )", ")").replace("' ", "'")
+
+    def split(fm):
+        kids, i, depth, cur = [], 1, 0, []
+        while i < len(fm) - 1:
+            t = fm[i]
+            cur.append(t)
+            depth += t in ("(", "!(")
+            depth -= t == ")"
+            if depth == 0 and t != "'":
+                kids.append(cur)
+                cur = []
+            i += 1
+        return kids
+
+    out = []
+    while pos < len(toks):
+        fm = form()
+        if fm[0] == "!(":
+            kids = split(fm)
+            out.append((txt(kids[0]), [txt(k) for k in kids[1:]], txt(fm)))
+        else:
+            out.append((None, [], txt(fm)))
+    return out
+
+
+def fold_repl_script(text: str, tail: str = "t") -> str:
     """A REPL script (`!(def ..)`, `!(defrec ..)`, `!(defq x !(transition s args..))`, `!(assert ..)`, `!(assert-eq a b)`, bare
     expressions: src/core/cli/meta.rs) as ONE Lurk expression with the same evaluation work: a definition becomes a `let` / `letrec`
     around everything after it, a chain transition the application `((cdr s) args..)` it performs, an assertion the expression it
@@ -297,7 +344,7 @@ def fold_repl_script(text: str) -> str:
     forms = []
     while pos < len(toks):
         forms.append(form())
-    out = "t"
+    out = tail  # (what the fold evaluates to when every assertion held: `t`, or the caller's final expression)
     for fm in reversed(forms):
         if fm[0] == "!(":
             kids = split(fm)
