@@ -616,6 +616,9 @@ def main():
                          "scaling, SURVEY.md 8e first bullet).  intra: ONE shard of 2^log_rows eval rows proved by all ranks together -- column-tile LDEs, "
                          "one all-to-all to row blocks, subtree roots all-gathered (lurk_amd/split.py, csrc/split.hip): strong scaling, the case of "
                          "every execution below the reference's default shard size of 2^22 rows")
+    ap.add_argument("--no-split-probe", action="store_true",
+                    help="N > 1: do not also measure --split intra in child processes (config.split_intra of the line)")
+    ap.add_argument("--split-probe-timeout", type=int, default=420)
     ap.add_argument("--split-min-log-rows", type=int, default=12, help="--split intra: chips of at least 2^k rows are cut across the ranks, the shorter ones proved whole by every rank")
     args = ap.parse_args()
 
@@ -1329,6 +1332,33 @@ def main():
         except Exception as e:
             host_pipeline = {"error": repr(e)}
 
+    # N > 1 on real devices: the same ranks also prove ONE 2^log_rows shard together (--split intra: strong scaling), in CHILD processes
+    # -- one per rank, their own process group on another port, a time limit -- so that whatever that path does on its first contact
+    # with a multi-GPU box (RCCL send / receive pairs have never run with world > 1) cannot take this line with it.  The child's line
+    # goes under config.split_intra.
+    split_probe = None
+    # (LURKHIP_SPLIT_PROBE_OVERSUB=1: also when the ranks share a device -- the rehearsal of the mechanism in the GPU suite)
+    if (distributed and world > 1 and (not oversubscribed or os.environ.get("LURKHIP_SPLIT_PROBE_OVERSUB") == "1") and not args.no_split_probe
+            and args.workload in ("fib-mix", "lurk-mix") and world & (world - 1) == 0 and os.environ.get("LURKHIP_BENCH_CHILD") != "1"):
+        import subprocess
+
+        fence()
+        env = dict(os.environ, LURKHIP_BENCH_CHILD="1", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 23))
+        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)  # (the children rendezvous among themselves: rank 0's child hosts the store)
+        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--split", "intra", "--steps", "6", "--warmup", "2", "--log-rows", str(log_rows),
+               "--workload", args.workload, "--queries", str(args.queries), "--pow-bits", str(args.pow_bits), "--no-cpu-baseline"]
+        cmd += ["--oversubscribe"] if oversubscribed else []
+        cmd += (["--no-compile"] if args.no_compile else []) + ["--compile-min-log-rows", str(args.compile_min_log_rows)]
+        t_probe = time.perf_counter()
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.split_probe_timeout, env=env)
+            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            split_probe = json.loads(lines[-1]) if lines else {"error": f"no line (exit code {r.returncode})", "stderr_tail": r.stderr[-600:]}
+        except subprocess.TimeoutExpired:
+            split_probe = {"error": f"timed out after {args.split_probe_timeout} s"}
+        except Exception as e:  # a reported extra, never a reason to lose the line
+            split_probe = {"error": repr(e)}
+        split_probe["probe_wall_s"] = time.perf_counter() - t_probe
     if step_block is not None and ms_per_step > 0:
         step_block["achieved"] = step_block["valu_lane_insts_per_step"] * len(mine) / (ms_per_step * 1e-3) / 1e12
         step_block["frac"] = step_block["achieved"] / VALU_FULL_RATE
@@ -1366,6 +1396,14 @@ def main():
                 "stages_ms": sequential["stages_ms"] if sequential else {k: v[0] / args.steps for k, v in spans.items() if v[1]},
                 "parity": "Poseidon2 / traces / AIR pinned by the reference's vectors and constraint property; commit / LogUp / quotient / FRI bit-exact vs the oracle and accepted by its verifier (upstream parity unpinned: sphinx / Plonky3 sources absent, tests/golden/upstream/ takes vectors)",
                 "proof_words": int(len(words)),
+                "split_intra": (None if split_probe is None else
+                                {k: split_probe.get(k) for k in ("error", "stderr_tail", "probe_wall_s", "value", "ms_per_step", "scaling", "n_gpus", "per_rank",
+                                                                 "alltoall_bytes_per_rank_per_step", "alltoall_bytes_per_link_per_step", "xgmi_model_ms_per_step",
+                                                                 "proofs_identical_on_all_ranks", "proof_verified") if k in split_probe}
+                                | ({"carrier": split_probe["config"]["split"]["carrier"], "carrier_note": split_probe["config"]["split"]["carrier_note"],
+                                    "note": "ONE shard of 2^log_rows eval rows proved by all ranks together (bench.py --split intra, measured by child processes of this run "
+                                            "after its timed region): strong scaling -- compare ms_per_step with the N = 1 line's proof_latency_ms"}
+                                   if "config" in split_probe else {})),
                 "eval_rows": n,
                 "workload_detail": (None if args.workload != "lurk-mix" else
                                     ("lurk-mix at the REAL height of demo/mastermind.lurk (--eval-rows 6867: every tall chip at the padded height of the reference's own run, "

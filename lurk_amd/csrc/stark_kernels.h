@@ -153,7 +153,9 @@ struct PermSink {
     __device__ __forceinline__ bool batch_live(uint32_t mults_or) const { return __builtin_amdgcn_ballot_w64(mults_or != 0u) != 0ull; }
     __device__ __forceinline__ void skip_batch() {
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
+#ifndef LURK_AB_PERM_NO_STORE  // (diagnostic: what the permutation rows' per-lane 16-byte stores cost -- no output)
         if (live) *dst = make_uint4(0u, 0u, 0u, 0u);
+#endif
         col++;
     }
     __device__ __forceinline__ void assert_zero(uint32_t) {}
@@ -164,7 +166,11 @@ struct PermSink {
     __device__ __forceinline__ void flush() {
         ef v = acc.in_batch == 1 ? bb::ef_scale(sink_ef_inv(acc.den), acc.m_first) : sink_ef_mul(acc.num, sink_ef_inv(acc.den));
         uint4* dst = reinterpret_cast<uint4*>(out_row + 4 * col);
+#ifndef LURK_AB_PERM_NO_STORE
         if (live) *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);
+#else
+        if (live && v.c[0] == 0x7fffffffu) *dst = make_uint4(v.c[0], v.c[1], v.c[2], v.c[3]);  // (keeps the value alive, never stores)
+#endif
         if (col_live && marker) col_live[col] = 1u;
         row_sum = bb::ef_add(row_sum, v);
         col++;
@@ -229,7 +235,9 @@ __device__ __forceinline__ void perm_rows_body(const PermArgs& a) {
         // interactions only read the local row
         if (wave == 0) idx[lane] = ic;
         __syncthreads();
+#ifndef LURK_AB_NO_STAGE
         stage_rows(tile, a.wp, a.main, a.w, idx, 64u, a.main_pitch);
+#endif
         __syncthreads();
         main_l = tile + lane * a.wp;
     }

@@ -196,6 +196,26 @@ def test_bench_eight_ranks_nine_shards_rehearsal():
     assert len(cfg["host_execute_s_per_rank"]) == 8 and len(cfg["end_to_end"]["peak_rss_mb_per_rank"]) == 8 and min(cfg["end_to_end"]["peak_rss_mb_per_rank"]) > 100
 
 
+def test_bench_n_ranks_also_probe_the_intra_shard_split(monkeypatch):
+    """Round 6: with N > 1 the bench's line also carries `config.split_intra` -- the same ranks proving ONE shard together
+    (`--split intra`), measured by child processes with their own process group on another port and a time limit, so that the split's
+    first contact with a multi-GPU box cannot take the driver's line with it.  Rehearsed here with the ranks sharing the box's device
+    (LURKHIP_SPLIT_PROBE_OVERSUB=1): the children rendezvous under torchrun's environment, every rank ends with the same verified proof,
+    the bytes of the all-to-alls are in the line."""
+    import torch
+
+    n = torch.cuda.device_count()
+    monkeypatch.setenv("LURKHIP_SPLIT_PROBE_OVERSUB", "1")
+    r = _bench("--gpus", "2", "--log-rows", "13", *(["--oversubscribe"] if n < 2 else []), timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    si = line["config"]["split_intra"]
+    assert si is not None and "error" not in si, si
+    assert si["scaling"] == "strong" and si["n_gpus"] == 2 and si["proofs_identical_on_all_ranks"] and si["proof_verified"]
+    assert si["alltoall_bytes_per_rank_per_step"] > 0 and len(si["per_rank"]) == 2 and si["per_rank"][1]["alltoalls"] == 5
+    assert line["scaling"] == "weak"  # (the line itself is still the shards -> ranks measurement)
+
+
 def test_bench_world_one_two_machine_proofs_in_flight_on_two_rccl_communicators():
     """torchrun with one rank, two shards: the N > 1 schedule on RCCL at world 1 -- two machine proofs in flight on two
     communicators behind the C ABI (csrc/comm.cpp: the counts' all-gather, the records' all-gather, the sums' all-reduce per proof,

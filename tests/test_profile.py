@@ -169,3 +169,23 @@ def test_sphinx_preset_takes_its_round_constants_from_a_vector_file(tmp_path):
     bad.write_text(json.dumps({"profile": {}}))
     with pytest.raises(ValueError):
         ProtocolProfile.sphinx(str(bad))
+
+
+def test_committed_pmc_pass_belongs_to_this_tree():
+    """bench.py prices the hashing launches' live time with the instruction count of the committed PMC pass (profiles/pmc_traffic.json)
+    and falls back to that pass's own rate when the hashing kernels' sources have changed since (round 5's driver line went out on the
+    fallback).  The committed pass must therefore be one of THIS tree: the SHA-256 over the files the hashing kernels are made of is
+    recomputed here -- a round that edits them re-runs tools/final_profiles.sh + tools/summarise_profiles.py before it is done."""
+    import hashlib
+    import json
+    import os
+
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    with open(os.path.join(root, "profiles", "pmc_traffic.json")) as f:
+        pmc = json.load(f)
+    assert "lurk_amd/csrc/commit.h" not in pmc["hash_kernel_sources"]  # (host-side declarations: not what the kernels are made of)
+    h = hashlib.sha256()
+    for rel in pmc["hash_kernel_sources"]:
+        with open(os.path.join(root, rel), "rb") as src:
+            h.update(src.read())
+    assert h.hexdigest() == pmc["hash_kernel_sources_sha256"], "the hashing kernels changed after the committed PMC pass: re-run the profiles"
