@@ -212,7 +212,7 @@ def test_bench_n_ranks_also_probe_the_intra_shard_split(monkeypatch):
     si = line["config"]["split_intra"]
     assert si is not None and "error" not in si, si
     assert si["scaling"] == "strong" and si["n_gpus"] == 2 and si["proofs_identical_on_all_ranks"] and si["proof_verified"]
-    assert si["alltoall_bytes_per_rank_per_step"] > 0 and len(si["per_rank"]) == 2 and si["per_rank"][1]["alltoalls"] == 5
+    assert si["alltoall_bytes_per_rank_per_step"] > 0 and len(si["per_rank"]) == 2 and si["per_rank"][1]["alltoalls"] == 6
     assert line["scaling"] == "weak"  # (the line itself is still the shards -> ranks measurement)
 
 
