@@ -249,12 +249,23 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
         S_TRY(run_jobs(ctx, plan.a_unpack, dst, recv, false, scratch));
     }
     span_end(ctx, "split_exchange_a");
-    // ---- 2. the LDE of this rank's tiles
+    // ---- 2. the LDE of this rank's tiles, and of the matrices that are not cut (whole, on every rank), in ONE call: the short
+    // matrices' passes -- latency-bound chains of a few workgroups -- go to the side lane under the tiles' (commit_impl)
     std::vector<BufRef> tile_out(plan.tiles.size() + plan.my_extras.size(), BufRef{nullptr, 0});
-    if (!plan.tiles.empty()) {
-        const size_t nt = plan.tiles.size();
+    std::vector<int> small;
+    for (int i = 0; i < n; i++)
+        if (plan.group_of[(size_t)i] < 0) small.push_back(i);
+    const size_t nt = plan.tiles.size();
+    if (nt + small.size() > 0) {
         std::vector<const uint32_t*> ptr(nt);
         std::vector<uint32_t> lh(nt), w(nt), sp(nt), sh(nt);
+        for (int i : small) {
+            ptr.push_back(mats[i].src);
+            lh.push_back(mats[i].log_n);
+            w.push_back(mats[i].width);
+            sp.push_back(mats[i].pitch);
+            sh.push_back(mats[i].shift ? mats[i].shift : bb::GEN);
+        }
         for (size_t k = 0; k < nt; k++) {
             const split::Tile& t = plan.tiles[k];
             const SplitMat& m = mats[t.mat];
@@ -269,10 +280,12 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
             w[k] = t.w;
             sh[k] = m.shift ? m.shift : bb::GEN;
         }
-        const int32_t st = commit_impl(ctx, (int32_t)nt, ptr.data(), false, lh.data(), w.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &tiles_c, nullptr, sh.data(), false,
-                                       /*padded_groups=*/true, sp.data(), nullptr, /*lde_only=*/true);
+        // (the tiles' LDE buffers stay with the commitment -- c->aux owns them with the short matrices' -- until it is freed: 1 / G of
+        // the LDE's memory more per commitment, against a second call whose short chains would run after the exchange instead of under it)
+        const int32_t st = commit_impl(ctx, (int32_t)ptr.size(), ptr.data(), false, lh.data(), w.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &c->aux, nullptr, sh.data(),
+                                       false, /*padded_groups=*/true, sp.data(), nullptr, /*lde_only=*/true);
         if (st != LURKHIP_OK) return done(st);
-        for (size_t k = 0; k < nt; k++) tile_out[k] = BufRef{tiles_c->lde[k], tiles_c->pitch[k]};
+        for (size_t k = 0; k < nt; k++) tile_out[k] = BufRef{c->aux->lde[k], c->aux->pitch[k]};
     }
     span_begin(ctx, "split_exchange_b");
     // ---- 3. next-row copies of the columns this rank holds
@@ -315,28 +328,9 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
         S_TRY(run_jobs(ctx, plan.b_unpack, dst, recv, false, scratch));
     }
     span_end(ctx, "split_exchange_b");
-    // the tiles' LDEs, the slabs and the exchange buffers are done with (stream-ordered releases)
+    // the slabs and the exchange buffers are done with (stream-ordered releases)
     for (void* p : scratch) pool_release(ctx, p);
     scratch.clear();
-    if (tiles_c) free_commitment(ctx, tiles_c);
-    tiles_c = nullptr;
-    // ---- the matrices that are not cut: their whole LDE on every rank
-    std::vector<int> small;
-    for (int i = 0; i < n; i++)
-        if (plan.group_of[(size_t)i] < 0) small.push_back(i);
-    if (!small.empty()) {
-        std::vector<const uint32_t*> ptr;
-        std::vector<uint32_t> lh, w, sp, sh;
-        for (int i : small) {
-            ptr.push_back(mats[i].src);
-            lh.push_back(mats[i].log_n);
-            w.push_back(mats[i].width);
-            sp.push_back(mats[i].pitch);
-            sh.push_back(mats[i].shift ? mats[i].shift : bb::GEN);
-        }
-        S_TRY(commit_impl(ctx, (int32_t)small.size(), ptr.data(), false, lh.data(), w.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &c->aux, nullptr, sh.data(), false,
-                          /*padded_groups=*/true, sp.data(), nullptr, /*lde_only=*/true));
-    }
     // ---- this rank's part of the commitment
     c->n_mats = n;
     c->log_blowup = log_blowup;
@@ -374,8 +368,9 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
             if (gr.extras[e].col == 0) c->next_off[(size_t)gr.extras[e].mat] = gr.W + (uint32_t)e - c->col_start[(size_t)gr.extras[e].mat];
     }
     std::map<int, int> small_group;  // group of c->aux -> group of c
-    for (size_t k = 0; k < small.size(); k++) {
-        const int i = small[k];
+    for (size_t ks = 0; ks < small.size(); ks++) {
+        const int i = small[ks];
+        const size_t k = nt + ks;  // (the short matrices follow the tiles in c->aux)
         const lurkhip_commitment* a = c->aux;
         c->full_lde[(size_t)i] = a->lde[k];
         c->pitch[(size_t)i] = a->pitch[k];
