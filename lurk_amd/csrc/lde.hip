@@ -954,6 +954,47 @@ bool lde_group_enabled() {
     return on;
 }
 
+// Round 6 (opt-in, measured slower: see lde_group): the dead columns of a sparse group zero-filled by ONE launch of this kernel, a job
+// per gap between the live runs, instead of being walked by the last pass -- k_lde_out's tiles are 32 columns of the OUTPUT layout, so
+// a tile of 20 live and 12 dead columns costs what 32 live ones cost (2.7 ms for the permutation commitment of a fib shard where the
+// live columns are 58 %); with this route the last pass walks the live columns like the first two and scatters to its entries' destinations.
+namespace {
+struct ZeroJob {
+    uint32_t* dst;
+    uint32_t dpitch, width, rows, first_block;
+};
+constexpr uint32_t ZERO_PER_BLOCK = 256 * 16;
+uint32_t zero_job_blocks(const ZeroJob& j) {  // (the kernel's own test for 16-byte stores)
+    const bool x4 = ((j.width | j.dpitch) & 3u) == 0 && ((uintptr_t)j.dst & 15u) == 0;
+    const uint64_t items = (uint64_t)j.rows * (x4 ? j.width >> 2 : j.width);
+    return (uint32_t)((items + ZERO_PER_BLOCK - 1) / ZERO_PER_BLOCK);
+}
+__global__ __launch_bounds__(256) void k_zero_jobs(const ZeroJob* __restrict__ jobs, uint32_t n_jobs) {
+    uint32_t lo = 0, hi = n_jobs;
+    while (hi - lo > 1) {
+        const uint32_t mid = (lo + hi) >> 1;
+        if (jobs[mid].first_block <= blockIdx.x) lo = mid;
+        else hi = mid;
+    }
+    const ZeroJob j = jobs[lo];
+    // (extension-field columns: the gaps are multiples of four words on 16-byte boundaries -- 16-byte stores; else word by word)
+    const bool x4 = ((j.width | j.dpitch) & 3u) == 0 && ((uintptr_t)j.dst & 15u) == 0;
+    const uint32_t w = x4 ? j.width >> 2 : j.width;
+    const uint32_t total = j.rows * w;  // (< 2^32: 2^21 rows of at most a few hundred columns)
+    const float inv_w = 1.0f / (float)w;
+    uint32_t idx = (blockIdx.x - j.first_block) * ZERO_PER_BLOCK + threadIdx.x;
+    for (int k = 0; k < 16; k++, idx += 256) {
+        if (idx >= total) break;
+        uint32_t r = (uint32_t)((float)idx * inv_w);
+        r += (r + 1u) * w <= idx ? 1u : 0u;
+        r -= r * w > idx ? 1u : 0u;
+        const uint32_t c = idx - r * w;
+        if (x4) *reinterpret_cast<uint4*>(j.dst + (size_t)r * j.dpitch + 4u * c) = make_uint4(0u, 0u, 0u, 0u);
+        else j.dst[(size_t)r * j.dpitch + c] = 0u;
+    }
+}
+}  // namespace
+
 bool lde_group_takes(int log_n) { return lde_group_enabled() && log_n >= LDE_GROUP_MIN_LOG_N && log_n <= LDE_GROUP_MAX_LOG_N; }
 
 int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const* evals, const uint32_t* widths, uint32_t* const* ldes,
@@ -964,6 +1005,25 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     LH_ARG(ctx, !(LDE_SLAB_X4 && out_starts), "LDE group: the quad-load variant (LDE_SLAB_X4) does not leave dead columns out");
     const NttPlan* plan = nullptr;
     LH_TRY(get_ntt_plan(ctx, log_n, &plan));
+    // the zero columns of a sparse group: walked by the last pass (default), or -- LURKHIP_LDE_SPARSE_OUT=1, measured and OFF -- filled by
+    // k_zero_jobs while the last pass walks the live columns only.  Alternating on the fib-mix step: `lde` 9.29 / 9.32 / 9.40 ms walked,
+    // 10.37 / 10.42 / 10.33 / 10.44 compact (the zero fill with 16-byte stores or without): a tile of 32 LIVE columns spans several runs
+    // whose destinations are not lined up with 128-byte lines, and what the pass saves in tiles it loses in scattered stores.
+    static const bool compact_out = getenv("LURKHIP_LDE_SPARSE_OUT") != nullptr && atoi(getenv("LURKHIP_LDE_SPARSE_OUT")) != 0;
+    std::vector<ZeroJob> zero_jobs;
+    if (out_starts && compact_out && log_n > 10) {
+        uint32_t blocks = 0;
+        for (int m = 0; m < n_mats; m++) {
+            const uint32_t end = out_starts[m] + widths[m], next = m + 1 < n_mats ? out_starts[m + 1] : out_width;
+            LH_ARG(ctx, next >= end, "LDE group: output columns of entry %d overlap the next entry's", m);
+            if (next == end) continue;
+            ZeroJob j{ldes[m] + widths[m], lde_pitches ? lde_pitches[m] : widths[m], next - end, 2u << log_n, blocks};
+            blocks += zero_job_blocks(j);
+            zero_jobs.push_back(j);
+        }
+        if (zero_jobs.empty()) zero_jobs.push_back(ZeroJob{nullptr, 0, 0, 0, 0});  // (marks the compact route even when nothing is dead)
+        out_starts = nullptr;  // the kernels see a dense group: entries side by side, each with its own destination
+    }
     LdeArgs a{};
     a.n_mats = (uint32_t)n_mats;
     uint32_t at = 0;
@@ -1041,6 +1101,17 @@ int32_t lde_group(lurkhip_ctx* ctx, int log_n, int n_mats, const uint32_t* const
     }
     pool_release(ctx, A);  // stream-ordered
     pool_release(ctx, B);
+    if (st == LURKHIP_OK && !zero_jobs.empty() && zero_jobs[0].dst != nullptr) {
+        void* tbl = nullptr;
+        LH_TRY(pool_alloc(ctx, zero_jobs.size() * sizeof(ZeroJob), &tbl));
+        static_assert(sizeof(ZeroJob) % 4 == 0, "uploaded as words");
+        st = upload_words(ctx, (uint32_t*)tbl, (const uint32_t*)zero_jobs.data(), zero_jobs.size() * sizeof(ZeroJob) / 4);
+        const ZeroJob& last = zero_jobs.back();
+        const uint32_t blocks = last.first_block + zero_job_blocks(last);
+        if (st == LURKHIP_OK) hipLaunchKernelGGL(k_zero_jobs, dim3(blocks), dim3(256), 0, ctx->stream, (const ZeroJob*)tbl, (uint32_t)zero_jobs.size());
+        pool_release(ctx, tbl);
+        if (st == LURKHIP_OK && hipGetLastError() != hipSuccess) st = set_error(ctx, LURKHIP_ERR_HIP, "k_zero_jobs launch failed");
+    }
     return st;
 }
 
