@@ -618,7 +618,7 @@ def main():
                          "every execution below the reference's default shard size of 2^22 rows")
     ap.add_argument("--no-split-probe", action="store_true",
                     help="N > 1: do not also measure --split intra in child processes (config.split_intra of the line)")
-    ap.add_argument("--split-probe-timeout", type=int, default=420)
+    ap.add_argument("--split-probe-timeout", type=int, default=240)
     ap.add_argument("--split-min-log-rows", type=int, default=12, help="--split intra: chips of at least 2^k rows are cut across the ranks, the shorter ones proved whole by every rank")
     args = ap.parse_args()
 
