@@ -118,7 +118,8 @@ int32_t reduce_openings(lurkhip_ctx* ctx, const uint32_t* mat, uint32_t w, uint3
                         const bb::ef& apow1, uint32_t* ro);
 // p3 fold_even_odd on 2^log_len bit-reversed evaluations (+ add[j] when given); out has 2^(log_len-1) elements
 int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint32_t* beta_dev /* 4 words, device */, const uint32_t* add,
-                 uint32_t* out);
+                 uint32_t* out, uint32_t pair_base = 0 /* a block of the layer: cur / add / out start at pair pair_base .. */,
+                 uint32_t n_pairs = 0 /* .. and hold n_pairs pairs (0: the whole layer) */);
 // Transcript state as the device keeps it during the FRI commit phase (challenger.h: Challenger, same semantics)
 struct DevChallenger {
     uint32_t state[16];

@@ -693,15 +693,16 @@ __global__ __launch_bounds__(256) void k_reduce_openings_narrow(NarrowArgs a) {
 // ---------------------------------------------------------------- FRI fold (p3 fold_even_odd)
 // out[j] = (1/2 + beta/2 * ginv^bitrev(j)) e[2j] + (1/2 - beta/2 * ginv^bitrev(j)) e[2j+1]  (+ add[j]),
 // ginv = (generator of the size-len subgroup)^-1; len = 2^log_len
+// (j_base, n_out: the launch folds the n_out pairs from pair j_base on, its buffers starting there -- a rank's block of a layer when
+// several ranks prove one shard together; 0 and half the length otherwise)
 __global__ __launch_bounds__(256) void k_fri_fold(const uint32_t* __restrict__ cur, int log_len, const uint32_t* __restrict__ beta_dev,
                                                    uint32_t ginv_m, uint32_t half_m, const uint32_t* __restrict__ add,
-                                                   uint32_t* __restrict__ out) {
+                                                   uint32_t* __restrict__ out, uint32_t j_base, uint32_t n_out) {
     const uint32_t j = blockIdx.x * blockDim.x + threadIdx.x;
-    const uint32_t half_len = 1u << (log_len - 1);
-    if (j >= half_len) return;
+    if (j >= n_out) return;
     // the layer's challenge was sampled on the device (k_fri_challenge): beta / 2
     const ef half_beta = bb::ef_scale(ef{{beta_dev[0], beta_dev[1], beta_dev[2], beta_dev[3]}}, half_m);
-    const ef power = bb::ef_scale(half_beta, bb::pow(ginv_m, brev_bits(j, log_len - 1)));
+    const ef power = bb::ef_scale(half_beta, bb::pow(ginv_m, brev_bits(j_base + j, log_len - 1)));
     const ef e0 = ef_load(cur + 8 * (size_t)j), e1 = ef_load(cur + 8 * (size_t)j + 4);
     ef r = bb::ef_add(bb::ef_mul(bb::ef_add_base(power, half_m), e0),
                       bb::ef_mul(bb::ef_add_base(bb::ef_sub(bb::ef_zero(), power), half_m), e1));
@@ -1180,11 +1181,12 @@ int32_t reduce_openings_narrow(lurkhip_ctx* ctx, const NarrowArgs& a) {
     return LURKHIP_OK;
 }
 
-int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint32_t* beta_dev, const uint32_t* add, uint32_t* out) {
+int32_t fri_fold(lurkhip_ctx* ctx, const uint32_t* cur, int log_len, const uint32_t* beta_dev, const uint32_t* add, uint32_t* out, uint32_t pair_base,
+                 uint32_t n_pairs) {
     const uint32_t half_m = bb::pow(bb::to_monty(2), bb::P - 2);
     const uint32_t ginv = bb::pow(two_adic_generator_monty(log_len), bb::P - 2);
-    const uint32_t half_len = 1u << (log_len - 1);
-    hipLaunchKernelGGL(k_fri_fold, dim3((half_len + 255) / 256), dim3(256), 0, ctx->stream, cur, log_len, beta_dev, ginv, half_m, add, out);
+    const uint32_t half_len = n_pairs ? n_pairs : 1u << (log_len - 1);
+    hipLaunchKernelGGL(k_fri_fold, dim3((half_len + 255) / 256), dim3(256), 0, ctx->stream, cur, log_len, beta_dev, ginv, half_m, add, out, pair_base, half_len);
     LH_HIP(ctx, hipGetLastError());
     return LURKHIP_OK;
 }

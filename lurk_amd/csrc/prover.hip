@@ -369,6 +369,7 @@ struct OpenOut {
     std::vector<size_t> round_off, layer_off;  // word offsets into rec_host
     const uint32_t* rec_host = nullptr;        // page-locked staging of the context: read it before the next call on the context
     std::vector<std::vector<uint32_t>> round_records;  // split commitments: round r's records assembled on the host (else empty: rec_host + round_off[r])
+    std::vector<std::vector<uint32_t>> layer_records;  // ... and the FRI layers that were folded on the ranks' row blocks
     size_t rec_words = 0;
     int log_max = 0;
     size_t n_layers = 0;
@@ -726,9 +727,18 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         PTRY(flush_group(kv.second));
     }
     PTRY(ro_lane.close());
-    if (sp) {  // every rank's rows of the reduced openings -> the whole vectors on every rank
+    // One shard over several ranks: the FIRST FRI layers stay on the ranks' row blocks -- a fold pairs adjacent storage rows, so a
+    // block folds into a block; a layer's tree is the ranks' subtrees under the top log2 G levels, its root reaches the (device-side)
+    // transcript through one all-gather of 32 bytes per rank and log2 G tiny compression launches, no host round trip -- while a
+    // rank's block has at least 2^fri_min_local pairs; then the folded vector is all-gathered and the remaining layers run on every
+    // rank.  (With every layer on every rank FRI was the largest part of a proof that did not shrink with the number of ranks.)
+    int k_dist = 0;
+    if (sp) {
+        static const int fri_min_local = getenv("LURKHIP_SPLIT_FRI_MIN_LOG") ? std::max(1, atoi(getenv("LURKHIP_SPLIT_FRI_MIN_LOG"))) : 10;
+        k_dist = std::max(0, std::min(log_global_max - log_blowup, log_global_max - sp->log_g - fri_min_local));
+        // the reduced openings the layers on every rank add in: the whole vectors; the distributed layers keep their rows of theirs
         for (int lh = sp->log_g + 1; lh < 32; lh++) {
-            if (!ro[lh]) continue;
+            if (!ro[lh] || (k_dist > 0 && lh >= log_global_max - k_dist)) continue;
             uint32_t* whole = nullptr;
             PTRY(palloc((size_t)16 << lh, &whole));
             PTRY(split_allgather_dev(ctx, *sp, ro[lh], whole, (uint64_t)4 << (lh - sp->log_g)));
@@ -763,8 +773,44 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     PTRY(palloc((size_t)std::max(n_layers, 1) * 32, &roots_dev));
     static_assert(sizeof(DevChallenger) % 4 == 0, "uploaded as words");
     PTRY(upload_words(ctx, (uint32_t*)ch_dev, (const uint32_t*)&hc, sizeof hc / 4));  // as launch arguments: no host wait
+    struct DistLayer {
+        lurkhip_commitment* local;  // the tree over this rank's pairs
+        uint32_t* top_dev;          // the top of the tree: [G][8] subtree roots, [G / 2][8], .. , [1][8]
+        int log_pairs;              // log2 of the layer's pairs (all ranks)
+    };
+    std::vector<DistLayer> dist_layers;
     for (int log_folded = log_max - 1, li = 0; log_folded >= log_blowup; log_folded--, li++) {
         lurkhip_commitment* lc = nullptr;
+        if (li < k_dist) {
+            const int log_local = log_folded - sp->log_g, G = sp->world();
+            PTRY(commit_raw(ctx, {current}, {log_local}, {8u}, &lc));
+            to_free.push_back(lc);
+            uint32_t* top = nullptr;
+            PTRY(palloc((size_t)(2 * G) * 32, &top));
+            PTRY(split_allgather_dev(ctx, *sp, lc->digests + lc->level_off[(size_t)lc->log_max] * 8, top, 8));
+            const P16Params* mp = nullptr;
+            PTRY(get_merkle_params(ctx, &mp));
+            uint32_t* level = top;
+            for (int nodes = G >> 1; nodes >= 1; nodes >>= 1) {
+                PTRY(merkle_level_digests(ctx, mp, level, (size_t)nodes, nullptr, level + (size_t)nodes * 16));
+                level += (size_t)nodes * 16;
+            }
+            PTRY(fri_challenge(ctx, ch_dev, level, betas_dev + 4 * li, roots_dev + 8 * li));
+            uint32_t* next = nullptr;
+            PTRY(palloc((size_t)16 << log_local, &next));
+            // (the layer's reduced openings: this rank's rows of them, or none at that height)
+            PTRY(fri_fold(ctx, current, log_folded + 1, betas_dev + 4 * li, ro[log_folded], next, (uint32_t)sp->rank << log_local, 1u << log_local));
+            current = next;
+            dist_layers.push_back(DistLayer{lc, top, log_folded});
+            layers.push_back(lc);
+            if (li + 1 == k_dist) {  // from here on every rank holds the whole vector
+                uint32_t* whole = nullptr;
+                PTRY(palloc((size_t)16 << log_folded, &whole));
+                PTRY(split_allgather_dev(ctx, *sp, current, whole, (uint64_t)4 << log_local));
+                current = whole;
+            }
+            continue;
+        }
         PTRY(commit_raw(ctx, {current}, {log_folded}, {8u}, &lc));
         to_free.push_back(lc);
         layers.push_back(lc);
@@ -868,8 +914,29 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         PTRY(gather_openings(ctx, round_mats[ri], c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0, nullptr, &round_record_words[ri]));
         rec_words += (size_t)num_queries * round_record_words[ri];
     }
+    std::vector<SplitRound> split_layers(dist_layers.size());  // (same bookkeeping as a split commitment's round: who answers which query)
     for (size_t li = 0; li < layers.size(); li++) {
         const lurkhip_commitment* c = layers[li];
+        if (li < dist_layers.size()) {
+            SplitRound& sl = split_layers[li];
+            const uint32_t log_local = (uint32_t)c->log_h[0];
+            PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, log_local}}, c->digests, c->level_off, log_local, nullptr, num_queries, 0, nullptr, &sl.local_words));
+            sl.local_rows_words = 8;
+            layer_record_words[li] = 8 + 8 * (uint32_t)dist_layers[li].log_pairs;
+            sl.owned.assign((size_t)sp->world(), {});
+            std::vector<uint32_t> mine;
+            for (uint32_t q = 0; q < num_queries; q++) {
+                const uint32_t pair = indices[q] >> (li + 1);
+                sl.owned[pair >> log_local].push_back(q);
+                if ((int)(pair >> log_local) == sp->rank) mine.push_back(pair & ((1u << log_local) - 1u));
+            }
+            if (!mine.empty()) {
+                PTRY(palloc(mine.size() * 4, &sl.indices_dev));
+                PTRY(upload_words(ctx, sl.indices_dev, mine.data(), mine.size()));
+            }
+            rec_words += mine.size() * sl.local_words;
+            continue;
+        }
         PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, nullptr, num_queries, 0,
                              nullptr, &layer_record_words[li]));
         rec_words += (size_t)num_queries * layer_record_words[li];
@@ -900,6 +967,15 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         const lurkhip_commitment* c = layers[li];
         uint32_t rw = 0;
         layer_off[li] = rec_at;
+        if (li < dist_layers.size()) {
+            const SplitRound& sl = split_layers[li];
+            const uint32_t n_mine = (uint32_t)sl.owned[(size_t)sp->rank].size();
+            if (n_mine)
+                PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, sl.indices_dev, n_mine, 0,
+                                     rec_dev + rec_at, &rw));
+            rec_at += (size_t)n_mine * sl.local_words;
+            continue;
+        }
         // index_i = index >> li, pair = index_i >> 1
         PTRY(gather_openings(ctx, {OpenMat{c->lde[0], 8, (uint32_t)c->log_h[0]}}, c->digests, c->level_off, (uint32_t)c->log_max, indices_dev, num_queries,
                              (uint32_t)li + 1, rec_dev + rec_at, &rw));
@@ -911,7 +987,41 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         hipLaunchKernelGGL(k_records_canonical, dim3((unsigned)std::min<size_t>((rec_words + 255) / 256, 2048)), dim3(256), 0, ctx->stream, rec_dev, rec_words);
         PHIP(hipMemcpyAsync((void*)rec_host, rec_dev, rec_words * 4, hipMemcpyDeviceToHost, ctx->stream));
     }
+    std::vector<std::vector<uint32_t>> tops_m(dist_layers.size());  // the distributed layers' top levels (Montgomery), for the paths
+    for (size_t li = 0; li < dist_layers.size(); li++) {
+        tops_m[li].resize((size_t)(2 * sp->world() - 1) * 8);
+        PHIP(hipMemcpyAsync(tops_m[li].data(), dist_layers[li].top_dev, tops_m[li].size() * 4, hipMemcpyDeviceToHost, ctx->stream));
+    }
     PHIP(stream_wait(ctx));
+    out.layer_records.assign(layers.size(), {});
+    for (size_t li = 0; li < dist_layers.size(); li++) {
+        const SplitRound& sl = split_layers[li];
+        const int G = sp->world();
+        const uint32_t log_local = (uint32_t)layers[li]->log_h[0];
+        size_t most = 0;
+        for (const auto& o : sl.owned) most = std::max(most, o.size());
+        const size_t seg = std::max<size_t>(most * sl.local_words, 1);
+        std::vector<uint32_t> mine(seg, 0u), all(seg * (size_t)G);
+        const size_t n_mine = sl.owned[(size_t)sp->rank].size();
+        if (n_mine) memcpy(mine.data(), rec_host + layer_off[li], n_mine * sl.local_words * 4);
+        PTRY(split_allgather_host(ctx, *sp, mine.data(), all.data(), seg * 4));
+        std::vector<uint32_t>& recs = out.layer_records[li];
+        recs.resize((size_t)num_queries * layer_record_words[li]);
+        for (int r = 0; r < G; r++)
+            for (size_t k = 0; k < sl.owned[(size_t)r].size(); k++) {
+                const uint32_t q = sl.owned[(size_t)r][k];
+                const uint32_t pair = indices[q] >> (li + 1);
+                uint32_t* o = &recs[(size_t)q * layer_record_words[li]];
+                memcpy(o, &all[(size_t)r * seg + k * sl.local_words], (size_t)sl.local_words * 4);  // the pair | the path inside the owner's subtree
+                o += sl.local_words;
+                size_t level = 0;  // word offset of top level t: G, G / 2, .. nodes of 8 words
+                for (int t = 0, nodes = G; t < sp->log_g; t++, nodes >>= 1) {
+                    const uint32_t* sib = &tops_m[li][level + (size_t)(((pair >> log_local) >> t) ^ 1u) * 8];
+                    for (int j = 0; j < 8; j++) *o++ = bb::from_monty(sib[j]);
+                    level += (size_t)nodes * 8;
+                }
+            }
+    }
     // the split rounds' records: every rank's answers gathered (padded to the largest count), then assembled query by query
     out.round_records.assign(rounds.size(), {});
     for (size_t ri = 0; ri < rounds.size() && sp; ri++) {
@@ -1492,7 +1602,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     for (size_t li = 0; li < n_fri_layers; li++) {
         o.push_back(layer_record_words[li]);
         const size_t n = (size_t)num_queries * layer_record_words[li];
-        o.insert(o.end(), rec_host + layer_off[li], rec_host + layer_off[li] + n);
+        if (!oo.layer_records[li].empty()) o.insert(o.end(), oo.layer_records[li].begin(), oo.layer_records[li].end());
+        else o.insert(o.end(), rec_host + layer_off[li], rec_host + layer_off[li] + n);
     }
     cleanup();
 #undef PTRY
