@@ -768,11 +768,13 @@ int32_t lurkhip_split_stats(lurkhip_ctx* ctx, uint64_t* out /* [3] */, int32_t r
 /* The index arithmetic of the two exchanges alone (host only; tests/test_split_plan.py runs it on host arrays over gloo with
  * ragged widths).  Matrix i: 2^log_heights[i] x widths[i], kinds[i] = 0 every rank holds all rows, 1 rank r holds natural rows
  * [r N / G, (r + 1) N / G), 2 chunk chunks[i] of a quotient of degree 2^lqds[i] held as the quotient kernel leaves it; n_next[i]
- * next-row copies (of columns 0 ..) travel with exchange B.  Writes the plan as 64-bit words (layout: lurk_amd/split.py
- * parse_plan) and returns their number, or a negative status; out may be NULL to size the buffer. */
+ * next-row copies (of columns 0 ..) travel with exchange B; run_counts[i] (first column, width) pairs of `runs`, taken in matrix
+ * order, are the columns of matrix i that are not identically zero (0 pairs, or run_counts NULL: all of them).  Writes the plan as
+ * 64-bit words (layout: lurk_amd/split.py parse_plan) and returns their number, or a negative status; out may be NULL to size the
+ * buffer. */
 int64_t lurkhip_split_plan(int32_t world, int32_t rank, int32_t split_min_log_n, int32_t n_mats, const uint32_t* log_heights,
                            const uint32_t* widths, const int32_t* kinds, const uint32_t* lqds, const uint32_t* chunks, const uint32_t* n_next,
-                           uint64_t* out, uint64_t capacity);
+                           const uint32_t* run_counts, const uint32_t* runs, uint64_t* out, uint64_t capacity);
 
 /* ------------------------------------------------------------------- proof wire format */
 /* The reference's serialised proofs.  `CryptoProof { shard_proofs, verifier_version, depth }` with

@@ -224,7 +224,7 @@ SIGNATURES = {
     "lurkhip_shard_prove_split": (_i32, [_p, _p, _p, _p, _u32p, C.c_uint32, C.c_uint32, C.c_uint32, C.POINTER(_p)]),
     "lurkhip_prover_stats": (_i32, [_p, _p]),
     "lurkhip_split_stats": (_i32, [_p, _p, _i32]),
-    "lurkhip_split_plan": (_i64, [_i32, _i32, _i32, _i32, _u32p, _u32p, _p, _u32p, _u32p, _u32p, _p, C.c_uint64]),
+    "lurkhip_split_plan": (_i64, [_i32, _i32, _i32, _i32, _u32p, _u32p, _p, _u32p, _u32p, _u32p, _u32p, _u32p, _p, C.c_uint64]),
 }
 
 

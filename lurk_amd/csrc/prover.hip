@@ -1219,7 +1219,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // columns out (commit_impl: live_runs) -- 42 % of the permutation cells of a real `(fib N)` shard.  LURKHIP_PERM_SPARSE_LDE=0: off.
     // (read per proof: a test switches it; LURKHIP_PERM_SPARSE_MIN_CELLS lowers the threshold below so that mid-sized test machines take the route)
     const char* sparse_env = getenv("LURKHIP_PERM_SPARSE_LDE");
-    const bool sparse_lde = (sparse_env == nullptr || atoi(sparse_env) != 0) && !sp;  // (split: a column's liveness would have to be agreed by all ranks)
+    const bool sparse_lde = sparse_env == nullptr || atoi(sparse_env) != 0;  // (split: a column is dead when every rank says so -- the flags travel with the blocks' totals below)
     const char* min_cells_env = getenv("LURKHIP_PERM_SPARSE_MIN_CELLS");
     const uint64_t min_cells = min_cells_env ? (uint64_t)strtoull(min_cells_env, nullptr, 10) : ((uint64_t)1 << 22);
     uint32_t* live_dev = nullptr;
@@ -1270,8 +1270,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         if (cut(i)) {  // this rank's block of trace rows, its running sum from zero: the previous ranks' totals are added below
             const size_t rows = h >> sp->log_g, r0 = (size_t)sp->rank * rows;
             PTRY(permutation_trace_impl(ctx, sh->airs[i], (uint32_t)rows, sh->main[i] + (sh->main_row_blocks ? 0 : r0) * sh->main_pitch[i], prep ? prep + r0 * air_of(sh->airs[i]).prep_width : nullptr,
-                                        perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i], sh->main_pitch[i], perm_pitch[i], nullptr, /*starts_ready=*/true,
-                                        /*defer_scan=*/true));
+                                        perm_alpha, perm_beta, perm[i], nullptr, beta_pows, chip_starts[i], sh->main_pitch[i], perm_pitch[i], live_dev ? live_dev + live_off[i] : nullptr,
+                                        /*starts_ready=*/true, /*defer_scan=*/true));
             PTRY(scan_ef_column(ctx, perm[i] + perm_widths[i] - 4, perm_pitch[i], rows));
             continue;
         }
@@ -1315,10 +1315,21 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     // the live batch columns as runs of base columns (the running-sum column is always live); this is the one place the proof
     // waits for the device between the main root and the permutation root
     std::vector<ColumnRuns> live_runs;
+    std::vector<uint32_t> gathered;  // (split) every rank's sums | live flags
     if (live_dev) {
-        const uint32_t* live_host = cs_host + (size_t)n_chips * 4;
+        uint32_t* live_host = cs_host + (size_t)n_chips * 4;
         PHIP(hipMemcpyAsync((void*)live_host, live_dev, live_off[n_chips] * 4, hipMemcpyDeviceToHost, ctx->stream));
         PHIP(stream_wait(ctx));
+        if (sp) {
+            // a cut chip's flags say what THIS rank's rows need: a column is left out of the exchanges and the LDE when no rank needs
+            // it, and the quotient kernels (whose storage rows are not the trace rows the flags were made from) read the agreed flags
+            const size_t per_rank = (size_t)n_chips * 4 + live_off[n_chips];
+            gathered.resize(per_rank * (size_t)sp->world());
+            PTRY(split_allgather_host(ctx, *sp, cs_host, gathered.data(), (uint64_t)per_rank * 4));
+            for (int r = 0; r < sp->world(); r++)
+                for (size_t c = 0; c < live_off[n_chips]; c++) live_host[c] |= gathered[(size_t)r * per_rank + (size_t)n_chips * 4 + c];
+            PTRY(upload_words(ctx, live_dev, live_host, live_off[n_chips]));
+        }
         live_runs.resize(n_chips);
         for (int i = 0; i < n_chips; i++) {
             const uint32_t pw = perm_widths[i] / 4;
@@ -1333,9 +1344,13 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     if (sp) {
         // the blocks' totals of every rank: a cut chip's running sum on this rank starts at the sum of the previous ranks' totals, its
         // cumulative sum is the sum of all of them; the other chips' sums are every rank's own (equal) values
-        PHIP(stream_wait(ctx));
-        std::vector<uint32_t> all((size_t)n_chips * 4 * (size_t)sp->world());
-        PTRY(split_allgather_host(ctx, *sp, cs_host, all.data(), (uint64_t)n_chips * 16));
+        const size_t per_rank = gathered.empty() ? (size_t)n_chips * 4 : gathered.size() / (size_t)sp->world();
+        if (gathered.empty()) {
+            PHIP(stream_wait(ctx));
+            gathered.resize(per_rank * (size_t)sp->world());
+            PTRY(split_allgather_host(ctx, *sp, cs_host, gathered.data(), (uint64_t)per_rank * 4));
+        }
+        const std::vector<uint32_t>& all = gathered;
         for (int i = 0; i < n_chips; i++) {
             if (!cut(i)) {
                 cumsum[i] = ef{{cs_host[4 * i], cs_host[4 * i + 1], cs_host[4 * i + 2], cs_host[4 * i + 3]}};
@@ -1343,7 +1358,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             }
             ef before = bb::ef_zero(), total = bb::ef_zero();
             for (int r = 0; r < sp->world(); r++) {
-                const uint32_t* t = &all[((size_t)r * n_chips + i) * 4];
+                const uint32_t* t = &all[(size_t)r * per_rank + (size_t)i * 4];
                 if (r == sp->rank) before = total;
                 total = bb::ef_add(total, ef{{t[0], t[1], t[2], t[3]}});
             }
@@ -1357,7 +1372,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             const uint64_t rows = (uint64_t)1 << sh->log_n[i];
             all += rows * perm_widths[i];
             uint64_t w = perm_widths[i];
-            if (!live_runs.empty() && sh->log_n[i] > 10) {
+            if (!live_runs.empty() && (sp ? cut(i) : sh->log_n[i] > 10)) {
                 w = 0;
                 for (const auto& r : live_runs[i]) w += r.second;
             }
@@ -1384,7 +1399,8 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     span_begin(ctx, "commit_perm");
     if (sp) {
         std::vector<SplitMat> sm(n_chips);
-        for (int i = 0; i < n_chips; i++) sm[i] = SplitMat{perm[i], sh->log_n[i], perm_widths[i], perm_pitch[i], 0u, cut(i) ? split::K_BLOCK : split::K_FULL, 0u, 0u, 0u, 0u};
+        for (int i = 0; i < n_chips; i++)
+            sm[i] = SplitMat{perm[i], sh->log_n[i], perm_widths[i], perm_pitch[i], 0u, cut(i) ? split::K_BLOCK : split::K_FULL, 0u, 0u, 0u, 0u, live_dev && cut(i) ? &live_runs[i] : nullptr};
         PTRY(split_commit(ctx, *sp, n_chips, sm.data(), log_blowup, &perm_commit, perm_root_m));
     } else
     PTRY(commit_impl(ctx, n_chips, perm.data(), false, sh->log_n.data(), perm_widths.data(), log_blowup, LURKHIP_REPR_MONTY, 0, &perm_commit,
@@ -1465,7 +1481,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
             PTRY(palloc((size_t)rows * 16, &chunks));
             PTRY(quotient_impl(ctx, sh->airs[i], sh->log_n[i], sh->main_commit->lde[i], pi >= 0 ? pk->commit->lde[pi] : nullptr, perm_commit->lde[i], perm_alpha, perm_beta,
                                alpha, cumsum[i], public_values, chunks, beta_pows, chip_starts[i], pitches, /*honest_running_sum=*/true, alpha_pows_all, public_m_dev, nullptr,
-                               &qs));
+                               &qs, live_dev ? live_dev + live_off[i] : nullptr));
             for (uint32_t c = 0; c < qd; c++) {
                 q_split.push_back(SplitMat{chunks, sh->log_n[i], 4u, 4u, bb::from_monty(pow_host(wq_inv, c)), split::K_QUOTIENT, lqds[i], c, 0u, 0u});
                 q_chip.push_back(i);

@@ -2,6 +2,7 @@
 #pragma once
 #include <stdint.h>
 
+#include <utility>
 #include <vector>
 
 #include "commit.h"
@@ -26,6 +27,8 @@ struct SplitMat {
     int kind;             // split::Kind (a matrix below 2^min_log_n rows is K_FULL)
     uint32_t lqd, chunk;  // K_QUOTIENT
     uint32_t n_next, next_lqd;
+    // the column runs outside which the matrix is zero on every rank (split::MatDesc::runs); null: every column
+    const std::vector<std::pair<uint32_t, uint32_t>>* runs = nullptr;
 };
 // p3 TwoAdicFriPcs::commit of `mats` by all ranks together: *out is this rank's part (lurkhip_commitment::split_log_g), root_m the
 // root every rank computes (Montgomery).

@@ -186,7 +186,8 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
         const SplitMat& m = mats[i];
         LH_ARG(ctx, m.width > 0 && m.pitch >= m.width && m.log_n + 1 <= (uint32_t)bb::TWO_ADICITY, "split: matrix %d has a bad shape", i);
         LH_ARG(ctx, (int)m.log_n >= env.min_log_n || m.kind == split::K_FULL, "split: matrix %d is below the cut and must be whole on every rank", i);
-        descs[(size_t)i] = split::MatDesc{m.log_n, m.width, m.kind, m.lqd, m.chunk, (int)m.log_n >= env.min_log_n ? m.n_next : 0u, m.next_lqd};
+        descs[(size_t)i] = split::MatDesc{m.log_n, m.width, m.kind, m.lqd, m.chunk, (int)m.log_n >= env.min_log_n ? m.n_next : 0u, m.next_lqd, {}};
+        if (m.runs && (int)m.log_n >= env.min_log_n) descs[(size_t)i].runs = *m.runs;
     }
     split::Plan plan;
     try {
@@ -323,6 +324,8 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
             S_TRY(pool_alloc(ctx, words * 4, &v));
             c->owned.push_back(v);
             local[g] = (uint32_t*)v;
+            // (columns no rank sends -- the dead ones every rank agreed on -- are the zeros of the LDE of a zero column)
+            if (plan.groups[g].sparse && hipMemsetAsync(v, 0, words * 4, ctx->stream) != hipSuccess) return done(set_error(ctx, LURKHIP_ERR_HIP, "split: zero-fill of a row block failed"));
             dst[g] = BufRef{local[g], plan.groups[g].local_pitch};
         }
         S_TRY(run_jobs(ctx, plan.b_unpack, dst, recv, false, scratch));
@@ -365,7 +368,7 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
             c->col_start[(size_t)i] = gr.col_start[k];
         }
         for (size_t e = 0; e < gr.extras.size(); e++)
-            if (gr.extras[e].col == 0) c->next_off[(size_t)gr.extras[e].mat] = gr.W + (uint32_t)e - c->col_start[(size_t)gr.extras[e].mat];
+            if (gr.extras[e].col == 0) c->next_off[(size_t)gr.extras[e].mat] = gr.W_local + (uint32_t)e - c->col_start[(size_t)gr.extras[e].mat];
     }
     std::map<int, int> small_group;  // group of c->aux -> group of c
     for (size_t ks = 0; ks < small.size(); ks++) {
@@ -467,14 +470,17 @@ extern "C" int32_t lurkhip_split_stats(lurkhip_ctx* ctx, uint64_t* out, int32_t 
 
 extern "C" int64_t lurkhip_split_plan(int32_t world, int32_t rank, int32_t split_min_log_n, int32_t n_mats, const uint32_t* log_heights,
                                       const uint32_t* widths, const int32_t* kinds, const uint32_t* lqds, const uint32_t* chunks, const uint32_t* n_next,
-                                      uint64_t* out, uint64_t capacity) {
+                                      const uint32_t* run_counts, const uint32_t* runs, uint64_t* out, uint64_t capacity) {
     if (n_mats <= 0 || !log_heights || !widths || !kinds) return LURKHIP_ERR_INVALID_ARG;
     int log_g = 0;
     while ((1 << log_g) < world) log_g++;
     if (world < 2 || (1 << log_g) != world) return LURKHIP_ERR_INVALID_ARG;
     std::vector<split::MatDesc> descs((size_t)n_mats);
     for (int i = 0; i < n_mats; i++)
-        descs[(size_t)i] = split::MatDesc{log_heights[i], widths[i], kinds[i], lqds ? lqds[i] : 0u, chunks ? chunks[i] : 0u, n_next ? n_next[i] : 0u, 1u};
+        descs[(size_t)i] = split::MatDesc{log_heights[i], widths[i], kinds[i], lqds ? lqds[i] : 0u, chunks ? chunks[i] : 0u, n_next ? n_next[i] : 0u, 1u, {}};
+    if (run_counts && runs)
+        for (int i = 0, at = 0; i < n_mats; i++)
+            for (uint32_t k = 0; k < run_counts[i]; k++, at++) descs[(size_t)i].runs.push_back({runs[2 * at], runs[2 * at + 1]});
     split::Plan p;
     try {
         p = split::make_plan(log_g, rank, split_min_log_n, descs);
@@ -495,7 +501,7 @@ extern "C" int64_t lurkhip_split_plan(int32_t world, int32_t rank, int32_t split
     o.push_back(p.groups.size());
     for (size_t g = 0; g < p.groups.size(); g++) {
         const split::Group& gr = p.groups[g];
-        o.insert(o.end(), {gr.log_n, gr.W, gr.local_pitch, (uint64_t)p.slab_w[g], gr.mats.size(), gr.extras.size()});
+        o.insert(o.end(), {gr.log_n, gr.W, gr.local_pitch, (uint64_t)p.slab_w[g], gr.mats.size(), gr.extras.size(), gr.W_local, gr.sparse ? 1u : 0u});
         for (size_t k = 0; k < gr.mats.size(); k++) o.insert(o.end(), {(uint64_t)gr.mats[k], gr.col_start[k]});
         for (uint32_t b : gr.bounds) o.push_back(b);
         for (const split::Extra& e : gr.extras) o.insert(o.end(), {(uint64_t)e.mat, e.col, e.vcol, (uint64_t)e.owner});

@@ -34,6 +34,10 @@ struct MatDesc {
     uint32_t lqd, chunk;  // K_QUOTIENT
     uint32_t n_next;      // next-row copies of columns 0 .. n_next - 1 travel with exchange B (main traces: lair::ChipAir's main_next columns)
     uint32_t next_lqd;    // ... on the quotient domain 2^(log_n + next_lqd)
+    // the ascending, disjoint (first column, width) runs outside which the matrix is identically zero on EVERY rank (the permutation
+    // traces' dead batch columns, agreed by all ranks): only these columns are transformed and exchanged, the others stay the zeros
+    // the rank's row block is filled with.  Empty: every column.
+    std::vector<std::pair<uint32_t, uint32_t>> runs;
 };
 
 struct RowSet {
@@ -71,14 +75,22 @@ struct Extra {
     int owner;       // the rank whose tile holds vcol
 };
 
+struct Segment {  // a live run of a matrix: columns [c0, c0 + w) of it = columns [vstart, vstart + w) of the group's virtual row
+    int mat;
+    uint32_t c0, w, vstart;
+};
+
 struct Group {
     uint32_t log_n = 0;
     std::vector<int> mats;            // committed order
-    std::vector<uint32_t> col_start;  // first column of mats[k] in the virtual row
-    uint32_t W = 0;
+    std::vector<uint32_t> col_start;  // first column of mats[k] in the rank's row block (every column of every matrix, dead ones too)
+    uint32_t W_local = 0;             // the matrices' widths side by side: the row block's columns (next-row copies follow them)
+    std::vector<Segment> segs;        // the virtual row the LDE and the exchanges see: live columns only
+    uint32_t W = 0;                   // its width
     std::vector<uint32_t> bounds;     // G + 1 column bounds
     std::vector<Extra> extras;
-    uint32_t local_pitch = 0;         // words between the rows of the rank's row block [2N / G][W + extras], a multiple of 32
+    uint32_t local_pitch = 0;         // words between the rows of the rank's row block [2N / G][W_local + extras], a multiple of 32
+    bool sparse = false;              // some column of some matrix is left out: the row block is zero-filled before exchange B lands in it
 };
 
 // One strided copy between a matrix-shaped buffer and a linear (send / receive) buffer.
@@ -143,22 +155,43 @@ inline Plan make_plan(int log_g, int rank, int min_log_n, const std::vector<MatD
         g.log_n = h;
         for (size_t i = 0; i < mats.size(); i++)
             if (mats[i].log_n == h) {
+                const MatDesc& m = mats[i];
                 p.group_of[i] = (int)p.groups.size();
                 g.mats.push_back((int)i);
-                g.col_start.push_back(g.W);
-                g.W += mats[i].width;
+                g.col_start.push_back(g.W_local);
+                g.W_local += m.width;
+                if (m.runs.empty()) {
+                    g.segs.push_back(Segment{(int)i, 0, m.width, g.W});
+                    g.W += m.width;
+                } else {
+                    uint32_t at = 0;
+                    for (const auto& r : m.runs) {
+                        if (r.first < at || r.second == 0 || r.first + r.second > m.width) throw std::runtime_error("split: malformed live runs");
+                        if (m.n_next) throw std::runtime_error("split: live runs and next-row copies on one matrix");
+                        g.segs.push_back(Segment{(int)i, r.first, r.second, g.W});
+                        g.W += r.second;
+                        at = r.first + r.second;
+                    }
+                    uint32_t covered = 0;
+                    for (const auto& r : m.runs) covered += r.second;
+                    g.sparse = g.sparse || covered < m.width;
+                }
             }
         g.bounds = column_bounds(g.W, G);
         for (size_t k = 0; k < g.mats.size(); k++) {
             const MatDesc& m = mats[(size_t)g.mats[k]];
             if (m.n_next > m.width) throw std::runtime_error("split: more next-row columns than columns");
+            if (m.n_next == 0) continue;
+            uint32_t vstart = 0;  // (a matrix with next-row copies has one segment: all of it)
+            for (const Segment& sg : g.segs)
+                if (sg.mat == g.mats[k]) vstart = sg.vstart;
             for (uint32_t c = 0; c < m.n_next; c++) {
-                Extra e{g.mats[k], c, g.col_start[k] + c, 0};
+                Extra e{g.mats[k], c, vstart + c, 0};
                 while (g.bounds[(size_t)e.owner + 1] <= e.vcol) e.owner++;
                 g.extras.push_back(e);
             }
         }
-        g.local_pitch = (g.W + (uint32_t)g.extras.size() + 31u) & ~31u;
+        g.local_pitch = (g.W_local + (uint32_t)g.extras.size() + 31u) & ~31u;
         p.groups.push_back(g);
     }
     // this rank's tiles
@@ -167,10 +200,9 @@ inline Plan make_plan(int log_g, int rank, int min_log_n, const std::vector<MatD
         const Group& g = p.groups[gi];
         const uint32_t lo = g.bounds[(size_t)rank], hi = g.bounds[(size_t)rank + 1];
         p.slab_w[gi] = hi - lo;
-        for (size_t k = 0; k < g.mats.size(); k++) {
-            const uint32_t m0 = g.col_start[k], m1 = m0 + mats[(size_t)g.mats[k]].width;
-            const uint32_t a = std::max(lo, m0), b = std::min(hi, m1);
-            if (a < b) p.tiles.push_back(Tile{(int)gi, g.mats[k], a - m0, b - a, a - lo});
+        for (const Segment& sg : g.segs) {
+            const uint32_t a = std::max(lo, sg.vstart), b = std::min(hi, sg.vstart + sg.w);
+            if (a < b) p.tiles.push_back(Tile{(int)gi, sg.mat, sg.c0 + (a - sg.vstart), b - a, a - lo});
         }
         for (size_t e = 0; e < g.extras.size(); e++)
             if (g.extras[e].owner == rank) p.my_extras.push_back((int)((gi << 16) | e));
@@ -182,14 +214,13 @@ inline Plan make_plan(int log_g, int rank, int min_log_n, const std::vector<MatD
         for (size_t gi = 0; gi < p.groups.size(); gi++) {
             const Group& g = p.groups[gi];
             const uint32_t lo = g.bounds[(size_t)d], hi = g.bounds[(size_t)d + 1];
-            for (size_t k = 0; k < g.mats.size(); k++) {
-                const MatDesc& m = mats[(size_t)g.mats[k]];
+            for (const Segment& sg : g.segs) {
+                const MatDesc& m = mats[(size_t)sg.mat];
                 if (m.kind == K_FULL) continue;
                 const RowSet rs = rows_of(m, s, log_g);
-                const uint32_t m0 = g.col_start[k], m1 = m0 + m.width;
-                const uint32_t a = std::max(lo, m0), b = std::min(hi, m1);
+                const uint32_t a = std::max(lo, sg.vstart), b = std::min(hi, sg.vstart + sg.w);
                 if (rs.count == 0 || a >= b) continue;
-                emit(gi, g.mats[k], rs, a - m0, b - a, a - lo, at);
+                emit(gi, sg.mat, rs, sg.c0 + (a - sg.vstart), b - a, a - lo, at);
                 at += (uint64_t)rs.count * (b - a);
             }
         }
@@ -244,10 +275,18 @@ inline Plan make_plan(int log_g, int rank, int min_log_n, const std::vector<MatD
         for (size_t gi = 0; gi < p.groups.size(); gi++) {
             const Group& g = p.groups[gi];
             const uint32_t l2 = (2u << g.log_n) >> log_g, ws = wsend(s, g), tw = g.bounds[(size_t)s + 1] - g.bounds[(size_t)s];
-            if (tw) p.b_unpack.push_back(Job{(int)gi, 0, g.bounds[(size_t)s], 1, at, ws, tw, l2});
+            // s's tile, segment by segment: virtual columns [lo, hi) land at their matrices' columns of the row block
+            const uint32_t lo = g.bounds[(size_t)s], hi = g.bounds[(size_t)s + 1];
+            for (const Segment& sg : g.segs) {
+                const uint32_t a = std::max(lo, sg.vstart), b = std::min(hi, sg.vstart + sg.w);
+                if (a >= b) continue;
+                size_t k = 0;
+                while (g.mats[k] != sg.mat) k++;
+                p.b_unpack.push_back(Job{(int)gi, 0, g.col_start[k] + sg.c0 + (a - sg.vstart), 1, at + (a - lo), ws, b - a, l2});
+            }
             uint32_t col = tw;
             for (size_t e = 0; e < g.extras.size(); e++)
-                if (g.extras[e].owner == s) p.b_unpack.push_back(Job{(int)gi, 0, g.W + (uint32_t)e, 1, at + col++, ws, 1, l2});
+                if (g.extras[e].owner == s) p.b_unpack.push_back(Job{(int)gi, 0, g.W_local + (uint32_t)e, 1, at + col++, ws, 1, l2});
             at += (uint64_t)l2 * ws;
         }
         p.b_recv_off[(size_t)s + 1] = at;

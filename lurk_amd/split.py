@@ -297,11 +297,11 @@ def parse_plan(words):
     world = take()
     plan = {"world": world, "groups": []}
     for _ in range(take()):
-        log_n, W, local_pitch, slab_w, n_mats, n_extras = take(6)
+        log_n, W, local_pitch, slab_w, n_mats, n_extras, W_local, sparse = take(8)
         mats = [tuple(take(2)) for _ in range(n_mats)]
         bounds = take(world + 1)
         extras = [tuple(take(4)) for _ in range(n_extras)]
-        plan["groups"].append(dict(log_n=log_n, W=W, local_pitch=local_pitch, slab_w=slab_w, mats=mats, bounds=bounds, extras=extras))
+        plan["groups"].append(dict(log_n=log_n, W=W, W_local=W_local, sparse=bool(sparse), local_pitch=local_pitch, slab_w=slab_w, mats=mats, bounds=bounds, extras=extras))
     plan["tiles"] = [dict(zip(("group", "mat", "c0", "w", "slab_col"), take(5))) for _ in range(take())]
     plan["my_extras"] = vec()
     plan["has_a"] = bool(take())
@@ -313,16 +313,18 @@ def parse_plan(words):
     return plan
 
 
-def split_plan(world, rank, min_log_n, log_heights, widths, kinds, lqds=None, chunks=None, n_next=None):
+def split_plan(world, rank, min_log_n, log_heights, widths, kinds, lqds=None, chunks=None, n_next=None, runs=None):
     n = len(widths)
     lh, ws = np.array(log_heights, dtype=np.uint32), np.array(widths, dtype=np.uint32)
     ks = np.array(kinds, dtype=np.int32)
     lq = np.array(lqds if lqds is not None else [0] * n, dtype=np.uint32)
     ck = np.array(chunks if chunks is not None else [0] * n, dtype=np.uint32)
     nx = np.array(n_next if n_next is not None else [0] * n, dtype=np.uint32)
-    need = N.lib.lurkhip_split_plan(world, rank, min_log_n, n, _addr(lh), _addr(ws), _addr(ks), _addr(lq), _addr(ck), _addr(nx), None, 0)
+    rc = np.array([len(r) for r in runs] if runs is not None else [0] * n, dtype=np.uint32)  # per matrix: its live (first column, width) runs
+    rr = np.array([x for r in (runs or []) for pair in r for x in pair] + [0], dtype=np.uint32)
+    need = N.lib.lurkhip_split_plan(world, rank, min_log_n, n, _addr(lh), _addr(ws), _addr(ks), _addr(lq), _addr(ck), _addr(nx), _addr(rc), _addr(rr), None, 0)
     if need < 0:
         raise N.LurkHipError(int(need), N.last_error(None))
     out = np.zeros(int(need), dtype=np.uint64)
-    N.lib.lurkhip_split_plan(world, rank, min_log_n, n, _addr(lh), _addr(ws), _addr(ks), _addr(lq), _addr(ck), _addr(nx), out.ctypes.data, int(need))
+    N.lib.lurkhip_split_plan(world, rank, min_log_n, n, _addr(lh), _addr(ws), _addr(ks), _addr(lq), _addr(ck), _addr(nx), _addr(rc), _addr(rr), out.ctypes.data, int(need))
     return parse_plan(out)

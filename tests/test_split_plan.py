@@ -22,7 +22,7 @@ K_FULL, K_BLOCK, K_QUOTIENT = 0, 1, 2
 # (log_n, width, kind, lqd, chunk, n_next): two tall groups with ragged widths, a group narrower than the ranks, quotient chunks of
 # both degrees, and matrices below the cut
 MATS = [
-    (7, 78, K_BLOCK, 0, 0, 0),
+    (7, 78, K_BLOCK, 0, 0, 0),      # a permutation trace with dead batch columns (RUNS below): only the live ones are exchanged
     (7, 13, K_BLOCK, 0, 0, 0),
     (4, 3, K_BLOCK, 0, 0, 0),       # a group of fewer columns than four ranks: some ranks transform nothing of it
     (6, 4, K_QUOTIENT, 1, 0, 0),
@@ -34,6 +34,15 @@ MATS = [
     (0, 11, K_FULL, 0, 0, 0),
 ]
 MIN_LOG_N = 4
+# per matrix: the (first column, width) runs that are not identically zero on every rank; []: all columns
+RUNS = [[(0, 5), (9, 20), (40, 38)], [(12, 1)], [], [], [], [], [], [], [], []]
+
+
+def live_mask(i):
+    m = np.zeros(MATS[i][1], dtype=bool)
+    for c0, w in RUNS[i] or [(0, MATS[i][1])]:
+        m[c0:c0 + w] = True
+    return m
 
 
 def brev(x, bits):
@@ -42,13 +51,13 @@ def brev(x, bits):
 
 def full_matrix(i):
     log_n, w = MATS[i][0], MATS[i][1]
-    return (np.arange((1 << log_n) * w, dtype=np.uint32).reshape(1 << log_n, w) * 7 + 1000003 * i) & 0x7FFFFFFF
+    return ((np.arange((1 << log_n) * w, dtype=np.uint32).reshape(1 << log_n, w) * 7 + 1000003 * i) & 0x7FFFFFFF) * live_mask(i).astype(np.uint32)
 
 
 def fake_lde(i):
     """any [2N][w] matrix stands for the LDE in exchange B, which only moves data"""
     log_n, w = MATS[i][0], MATS[i][1]
-    return (np.arange((2 << log_n) * w, dtype=np.uint32).reshape(2 << log_n, w) * 13 + 777 * i + 5) & 0x7FFFFFFF
+    return ((np.arange((2 << log_n) * w, dtype=np.uint32).reshape(2 << log_n, w) * 13 + 777 * i + 5) & 0x7FFFFFFF) * live_mask(i).astype(np.uint32)
 
 
 def local_rows(i, rank, log_g):
@@ -80,7 +89,7 @@ def local_rows(i, rank, log_g):
 
 def args():
     return dict(log_heights=[m[0] for m in MATS], widths=[m[1] for m in MATS], kinds=[m[2] for m in MATS], lqds=[m[3] for m in MATS],
-                chunks=[m[4] for m in MATS], n_next=[m[5] for m in MATS])
+                chunks=[m[4] for m in MATS], n_next=[m[5] for m in MATS], runs=RUNS)
 
 
 def run_pack(jobs, bufs, lin):
@@ -103,18 +112,23 @@ def check_rank(plan, rank, log_g, slabs, locals_):
     for gi, g in enumerate(plan["groups"]):
         lo, hi = g["bounds"][rank], g["bounds"][rank + 1]
         assert g["bounds"][0] == 0 and g["bounds"][-1] == g["W"] and all(a <= b for a, b in zip(g["bounds"], g["bounds"][1:]))
+        vstart = 0  # the virtual row the tiles are cut from: the live runs of the group's matrices, side by side
         for mat, col_start in g["mats"]:
             w, kind = MATS[mat][1], MATS[mat][2]
-            a, b = max(lo, col_start), min(hi, col_start + w)
-            if a < b and kind != K_FULL:
-                assert np.array_equal(slabs[gi][:, a - lo:b - lo], full_matrix(mat)[:, a - col_start:b - col_start]), (rank, gi, mat)
+            below = MATS[mat][0] < MIN_LOG_N
+            for c0, rw in (RUNS[mat] if RUNS[mat] and not below else [(0, w)]):
+                a, b = max(lo, vstart), min(hi, vstart + rw)
+                if a < b and kind != K_FULL:
+                    assert np.array_equal(slabs[gi][:, a - lo:b - lo], full_matrix(mat)[:, c0 + a - vstart:c0 + b - vstart]), (rank, gi, mat)
+                vstart += rw
             l2 = (2 << g["log_n"]) >> log_g
             assert np.array_equal(locals_[gi][:, col_start:col_start + w], fake_lde(mat)[rank * l2:(rank + 1) * l2]), (rank, gi, mat)
+        assert vstart == g["W"] and g["W"] <= g["W_local"] and g["sparse"] == (g["W"] < g["W_local"])
         for e, (mat, col, vcol, owner) in enumerate(g["extras"]):
             l2 = (2 << g["log_n"]) >> log_g
             assert g["bounds"][owner] <= vcol < g["bounds"][owner + 1]
-            assert np.array_equal(locals_[gi][:, g["W"] + e], next_copy(mat, col)[rank * l2:(rank + 1) * l2]), (rank, gi, mat, col)
-        assert g["local_pitch"] % 32 == 0 and g["local_pitch"] >= g["W"] + len(g["extras"])
+            assert np.array_equal(locals_[gi][:, g["W_local"] + e], next_copy(mat, col)[rank * l2:(rank + 1) * l2]), (rank, gi, mat, col)
+        assert g["local_pitch"] % 32 == 0 and g["local_pitch"] >= g["W_local"] + len(g["extras"])
 
 
 def next_copy(mat, col):
