@@ -396,6 +396,7 @@ def poseidon2_bench(args, world, rank, device_index, distributed):
 
 
 XGMI_LINK_GBS = 153.0  # per link and direction, seven links per GPU (the task statement's figure; MI355X_MICROARCH.md)
+SPLIT_COLLECTIVE_LATENCY_US = 50.0  # --split-turns' model: a small RCCL collective with its launch (an assumption, stated in the line)
 
 
 def split_intra(args, world, rank, device_index, distributed, oversubscribed):
@@ -502,7 +503,43 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
     lurk_amd._native.lib.lurkhip_split_stats(ctx.handle, stats.ctypes.data, 0)
     per_step = {"alltoall_bytes_sent_before_lde": int(stats[0]) // args.steps, "alltoall_bytes_sent_after_lde": int(stats[1]) // args.steps,
                 "alltoalls": int(stats[2]) // args.steps}
-    mine = {"rank": rank, "seconds": dt, "stages_ms": stages, **per_step, "proof_words": int(len(words)), "proof_crc": int(np.bitwise_xor.reduce(words.astype(np.uint32)))}
+    # ---- what the ranks' work would take on devices of their own (--split-turns): the ranks take turns between the collectives
+    turns, turn_stages = None, None
+    if args.split_turns and sp is not None and isinstance(scomm, split.TorchSplitComm):
+        n_turn = 5
+        segs = []
+        ctx.profile_reset()
+        ctx.profile_enable(not args.no_spans)  # (the stage events of a rank that has the device to itself: its kernels' own time)
+        for _ in range(n_turn):
+            scomm.begin_turns()
+            step()
+            segs.append(scomm.end_turns())
+        assert len({len(x) for x in segs}) == 1, "the proofs of one shard went through different numbers of collectives"
+        turns = [min(x[k] for x in segs) for k in range(len(segs[0]))]  # (the fastest of the five passes, segment by segment)
+        ctx.profile_enable(False)
+        turn_stages = {k: round(v[0] / n_turn, 3) for k, v in ((name, ctx.profile_read(name)) for name in SPANS) if v[1]}
+    one_rank_ms, one_rank_stages = None, None
+    if args.split_turns and sp is not None:
+        # the one-rank prover on the same shard, one proof at a time, alone on the device: what the split proof's time is divided by
+        fence()
+        if rank == 0:
+            sp_saved, ts = sp, []
+            sp = None
+            ctx.profile_reset()
+            ctx.profile_enable(not args.no_spans)
+            for _ in range(4):
+                ctx.sync()
+                t1 = time.perf_counter()
+                step()
+                ctx.sync()
+                ts.append(time.perf_counter() - t1)
+            sp = sp_saved
+            ctx.profile_enable(False)
+            one_rank_stages = {k: round(v[0] / 4, 3) for k, v in ((name, ctx.profile_read(name)) for name in SPANS) if v[1]}
+            one_rank_ms = min(ts[1:]) * 1e3
+        fence()
+    mine = {"rank": rank, "seconds": dt, "stages_ms": stages, "turn_segments_ms": None if turns is None else [round(t * 1e3, 4) for t in turns],
+            "turn_stages_ms": None if turns is None else turn_stages, **per_step, "proof_words": int(len(words)), "proof_crc": int(np.bitwise_xor.reduce(words.astype(np.uint32)))}
     if distributed:
         box = [None] * world
         dist.all_gather_object(box, mine)
@@ -536,6 +573,28 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
             "roofline": None, "cpu_baseline": None,
             "note": "roofline / cpu_baseline: see the N = 1 line of the default command (this mode adds no kernel: the same LDE, hashing and AIR kernels on a rank's share)",
         }
+        if box[0]["turn_segments_ms"] is not None:
+            segs = [b["turn_segments_ms"] for b in box]
+            n_seg = len(segs[0])
+            assert all(len(x) == n_seg for x in segs)
+            compute = sum(max(x[k] for x in segs) for k in range(n_seg))
+            n_coll = n_seg - 1
+            coll_ms = n_coll * SPLIT_COLLECTIVE_LATENCY_US * 1e-3 + per_link / (XGMI_LINK_GBS * 1e9) * 1e3
+            line["predicted"] = {
+                "what": "a MODEL from measurements on one device, not a multi-GPU measurement: the ranks took turns between the collectives (a token goes round: "
+                        "rank 0 works alone from one collective to its arrival at the next, then rank 1, ...), so a segment's time is what that rank's host and device "
+                        "work takes with the device to itself; a G-GPU proof lasts at least the sum over segments of the slowest rank's time, plus the collectives",
+                "segments": n_seg, "collectives_per_proof": n_coll,
+                "compute_ms": round(compute, 3), "slowest_rank_total_ms": round(max(sum(x) for x in segs), 3), "mean_rank_total_ms": round(sum(sum(x) for x in segs) / len(segs), 3),
+                "collectives_model_ms": round(coll_ms, 3),
+                "collectives_model": f"{n_coll} collectives x {SPLIT_COLLECTIVE_LATENCY_US} us + the bytes a rank sends to ONE peer per proof / {XGMI_LINK_GBS} GB/s",
+                "ms_per_proof": round(compute + coll_ms, 3), "one_rank_ms_per_proof": None if one_rank_ms is None else round(one_rank_ms, 3),
+                "speedup_over_one_rank": None if one_rank_ms is None else round(one_rank_ms / (compute + coll_ms), 3),
+                "segments_slowest_rank_ms": [round(max(x[k] for x in segs), 3) for k in range(n_seg)],
+                "stages_ms_rank0_taking_turns": box[0]["turn_stages_ms"], "stages_ms_one_rank": one_rank_stages,
+                "note": "every segment ends with the stream drained, which RCCL's device-side collectives do not need: conservative on that side; the xGMI figure is the "
+                        "link rate, not a measured all-to-all",
+            }
         if oversubscribed:
             line["note"] += "; the ranks SHARE one device here: ms_per_step says nothing about scaling, only the stage spans, the bytes and the identity of the proofs do"
         print(json.dumps(line))
@@ -619,6 +678,9 @@ def main():
     ap.add_argument("--no-split-probe", action="store_true",
                     help="N > 1: do not also measure --split intra in child processes (config.split_intra of the line)")
     ap.add_argument("--split-probe-timeout", type=int, default=240)
+    ap.add_argument("--split-turns", action="store_true",
+                    help="--split intra with --oversubscribe: after the timed steps, five proofs in which the ranks take turns between the collectives -- each "
+                         "rank's segments timed with the device to itself -- and the one-rank prover alone, for `predicted` (a labelled model of the G-GPU proof)")
     ap.add_argument("--split-min-log-rows", type=int, default=12, help="--split intra: chips of at least 2^k rows are cut across the ranks, the shorter ones proved whole by every rank")
     args = ap.parse_args()
 

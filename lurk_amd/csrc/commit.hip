@@ -849,7 +849,8 @@ int32_t commit_impl(lurkhip_ctx* ctx, int32_t n_mats, const uint32_t* const* mat
             for (int i : members) W += widths[i];
             const uint32_t Wp = (W + 31u) & ~31u;
             if (Wp == W && members.size() == 1) continue;
-            if (pad_mode == 1 && (Wp - W) * 8 > W) continue;
+            // (lde_only: a rank's column tiles of a split commitment -- a ragged share of the group's columns, a G-th of its memory: always)
+            if (pad_mode == 1 && !lde_only && (Wp - W) * 8 > W) continue;
             uint32_t* base = nullptr;
             TRY_C(pool_alloc(ctx, ((size_t)Wp << (hm.first + log_blowup)) * sizeof(uint32_t), (void**)&base));
             c->owned.push_back(base);

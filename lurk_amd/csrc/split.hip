@@ -231,6 +231,9 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
     span_begin(ctx, "split_exchange_a");
     // ---- 1. exchange A: rows -> column tiles
     std::vector<uint32_t*> slab(plan.groups.size(), nullptr);
+    // (rows of whole 128-byte lines: a rank's share of a group's columns is ragged, and the LDE's first pass reads unaligned row
+    // segments at half the rate -- lde.hip)
+    auto slab_pitch = [&](size_t g) { return (plan.slab_w[g] + 31u) & ~31u; };
     if (plan.has_a) {
         uint32_t *send = nullptr, *recv = nullptr;
         S_TRY(salloc(plan.a_send_off.back(), &send));
@@ -244,8 +247,8 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
         ctx->split_exchanges++;
         std::vector<BufRef> dst(plan.groups.size());
         for (size_t g = 0; g < plan.groups.size(); g++) {
-            if (plan.slab_w[g]) S_TRY(salloc((size_t)plan.slab_w[g] << plan.groups[g].log_n, &slab[g]));
-            dst[g] = BufRef{slab[g], plan.slab_w[g]};
+            if (plan.slab_w[g]) S_TRY(salloc((size_t)slab_pitch(g) << plan.groups[g].log_n, &slab[g]));
+            dst[g] = BufRef{slab[g], slab_pitch(g)};
         }
         S_TRY(run_jobs(ctx, plan.a_unpack, dst, recv, false, scratch));
     }
@@ -275,7 +278,7 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
                 sp[k] = m.pitch;
             } else {
                 ptr[k] = slab[(size_t)t.group] + t.slab_col;
-                sp[k] = plan.slab_w[(size_t)t.group];
+                sp[k] = slab_pitch((size_t)t.group);
             }
             lh[k] = m.log_n;
             w[k] = t.w;

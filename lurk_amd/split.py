@@ -56,10 +56,61 @@ class TorchSplitComm:
         self.error = None
         self._cb = (_A2A(self._alltoallv_dev), _AGD(self._allgather_dev), _AGH(self._allgather_host), _ARH(self._allreduce))  # kept alive
         self.struct = SplitCommStruct(self.rank, self.world, None, *self._cb)
+        self.turns = False
+        self.segments = []
+
+    # ---- taking turns (bench.py --split-turns): what a rank's work BETWEEN two collectives takes when it has the device to itself.
+    # Several ranks on one device run their kernels against each other and their clocks say nothing; here a token goes round instead:
+    # after a collective rank 0 works alone until it arrives at the next one, then rank 1 does, ... and the collective runs when the
+    # last rank has arrived.  segments[k] = this rank's seconds (host and device, the stream drained) between collectives k - 1 and k.
+    def _token(self, send: bool):
+        import torch
+        import torch.distributed as dist
+
+        t = torch.zeros(1, dtype=torch.int32)
+        peer = self.rank + 1 if send else self.rank - 1
+        peer = dist.get_global_rank(self.group, peer) if self.group is not None else peer
+        (dist.send if send else dist.recv)(t, peer, group=self.group)
+
+    def _segment_end(self):
+        import time
+
+        self.ctx.sync()
+        self.segments.append(time.perf_counter() - self._t_seg)
+        if self.rank + 1 < self.world:
+            self._token(True)
+
+    def _segment_begin(self):
+        import time
+
+        if self.rank > 0:
+            self._token(False)
+        self._t_seg = time.perf_counter()
+
+    def begin_turns(self):
+        import torch.distributed as dist
+
+        self.ctx.sync()
+        dist.barrier(group=self.group)
+        self.turns, self.segments = True, []
+        self._segment_begin()
+
+    def end_turns(self):
+        """-> this rank's segment times of the proof(s) since begin_turns (the last one: from the last collective to here)"""
+        import torch.distributed as dist
+
+        self._segment_end()
+        self.turns = False
+        dist.barrier(group=self.group)
+        return list(self.segments)
 
     def _guard(self, fn, *a):
         try:
+            if self.turns:
+                self._segment_end()
             fn(*a)
+            if self.turns:
+                self._segment_begin()
             return 0
         except BaseException as e:  # nothing unwinds into C; the library reports "collective failed", the cause is kept here
             self.error = e
