@@ -565,7 +565,8 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
                                   "only), subtree roots all-gathered; FRI on every rank from the all-gathered reduced openings (DESIGN.md 6)"},
                 "chips_compiled": len(compiled), "host_execute_s": t_execute,
             },
-            "per_rank": [{k: b[k] for k in ("rank", "seconds", "stages_ms", "alltoall_bytes_sent_before_lde", "alltoall_bytes_sent_after_lde", "alltoalls")} for b in box],
+            "per_rank": [{k: b[k] for k in ("rank", "seconds", "stages_ms", "alltoall_bytes_sent_before_lde", "alltoall_bytes_sent_after_lde", "alltoalls", "turn_segments_ms")
+                          if b.get(k) is not None} for b in box],
             "alltoall_bytes_per_rank_per_step": sent, "alltoall_bytes_per_link_per_step": per_link,
             "xgmi_model_ms_per_step": per_link / (XGMI_LINK_GBS * 1e9) * 1e3 if world > 1 else 0.0,
             "xgmi_model_note": f"bytes one rank sends to ONE peer per step / {XGMI_LINK_GBS} GB/s: the seven links of a GPU carry its seven peers' blocks side by side",

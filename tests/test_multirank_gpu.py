@@ -216,6 +216,23 @@ def test_bench_n_ranks_also_probe_the_intra_shard_split(monkeypatch):
     assert line["scaling"] == "weak"  # (the line itself is still the shards -> ranks measurement)
 
 
+def test_bench_split_turns_times_each_ranks_work_with_the_device_to_itself():
+    """`--split intra --oversubscribe --split-turns`: ranks that share the box's device take turns between the collectives (a token goes
+    round, lurk_amd/split.py: TorchSplitComm.begin_turns), so that a rank's segments are timed alone; the line carries `predicted`: the sum
+    over the segments of the slowest rank, the collectives at the xGMI link rate, the one-rank prover timed in the same process.  Every
+    rank went through the same collectives, the proofs are still the one-rank words."""
+    r = _bench("--gpus", "2", "--oversubscribe", "--split", "intra", "--split-turns", "--log-rows", "13", "--split-min-log-rows", "8", "--steps", "2")
+    assert r.returncode == 0, r.stderr[-3000:]
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["scaling"] == "strong" and line["proofs_identical_on_all_ranks"] and line["proof_verified"]
+    p = line["predicted"]
+    assert p["segments"] == p["collectives_per_proof"] + 1 == len(p["segments_slowest_rank_ms"])
+    assert all(len(b["turn_segments_ms"]) == p["segments"] for b in line["per_rank"]) and len(line["per_rank"]) == 2
+    assert 0 < p["mean_rank_total_ms"] <= p["slowest_rank_total_ms"] <= p["compute_ms"] < p["ms_per_proof"]
+    assert p["one_rank_ms_per_proof"] > 0 and abs(p["speedup_over_one_rank"] - p["one_rank_ms_per_proof"] / p["ms_per_proof"]) < 0.01
+    assert "MODEL" in p["what"]
+
+
 def test_bench_world_one_two_machine_proofs_in_flight_on_two_rccl_communicators():
     """torchrun with one rank, two shards: the N > 1 schedule on RCCL at world 1 -- two machine proofs in flight on two
     communicators behind the C ABI (csrc/comm.cpp: the counts' all-gather, the records' all-gather, the sums' all-reduce per proof,
