@@ -125,13 +125,41 @@ struct Plan {
     std::vector<Job> b_pack, b_unpack;
 };
 
-inline std::vector<uint32_t> column_bounds(uint32_t W, int G) {
-    // whole 32-column tiles while every rank still gets two of them (the LDE kernels' tile), else fours, else single columns
-    const uint32_t unit = W >= 64u * (uint32_t)G ? 32u : (W >= 8u * (uint32_t)G ? 4u : 1u);
-    const uint32_t units = W / unit;
+// The LDE kernels transform 32-column tiles: a rank pays a whole tile pass for any share of 32 columns.
+constexpr uint32_t LDE_TILE_COLS = 32;
+inline uint32_t tiles_of(uint32_t cols) { return (cols + LDE_TILE_COLS - 1) / LDE_TILE_COLS; }
+
+// `load` (G entries, updated): rows x tiles every rank has been given so far, by the groups before this one.
+inline std::vector<uint32_t> column_bounds(uint32_t W, int G, uint32_t log_n, std::vector<uint64_t>& load) {
     std::vector<uint32_t> b((size_t)G + 1);
-    for (int r = 0; r < G; r++) b[(size_t)r] = unit * (uint32_t)(((uint64_t)units * (uint64_t)r) / (uint64_t)G);
-    b[(size_t)G] = W;
+    if (W < LDE_TILE_COLS * (uint32_t)G) {
+        // A NARROW group -- fewer than one tile a rank (a height's quotient chunks, the short chips): an even share would be a few
+        // columns on EVERY rank, each of them paying the whole tile pass, group after group.  Whole tiles instead, to as many
+        // consecutive ranks as there are tiles, starting where the ranks have the least to do so far: the groups of a commitment
+        // spread over the ranks and run side by side.
+        const uint32_t units = tiles_of(W);
+        uint32_t best = 0;
+        uint64_t best_max = ~(uint64_t)0;
+        for (uint32_t start = 0; start + units <= (uint32_t)G; start++) {
+            uint64_t m = 0;
+            for (uint32_t k = 0; k < units; k++) m = std::max(m, load[(size_t)(start + k)]);
+            if (m < best_max) {
+                best_max = m;
+                best = start;
+            }
+        }
+        for (int r = 0; r <= G; r++) {
+            const uint32_t before = (uint32_t)r <= best ? 0u : std::min((uint32_t)r - best, units);  // tiles given to the ranks below r
+            b[(size_t)r] = std::min(W, before * LDE_TILE_COLS);
+        }
+    } else {
+        // whole 32-column tiles while every rank still gets two of them, else fours
+        const uint32_t unit = W >= 2 * LDE_TILE_COLS * (uint32_t)G ? LDE_TILE_COLS : 4u;
+        const uint32_t units = W / unit;
+        for (int r = 0; r < G; r++) b[(size_t)r] = unit * (uint32_t)(((uint64_t)units * (uint64_t)r) / (uint64_t)G);
+        b[(size_t)G] = W;
+    }
+    for (int r = 0; r < G; r++) load[(size_t)r] += (uint64_t)tiles_of(b[(size_t)r + 1] - b[(size_t)r]) << log_n;
     return b;
 }
 
@@ -150,6 +178,7 @@ inline Plan make_plan(int log_g, int rank, int min_log_n, const std::vector<MatD
     for (const MatDesc& m : mats)
         if ((int)m.log_n >= min_log_n && std::find(heights.begin(), heights.end(), m.log_n) == heights.end()) heights.push_back(m.log_n);
     std::sort(heights.rbegin(), heights.rend());
+    std::vector<uint64_t> load((size_t)G, 0);
     for (uint32_t h : heights) {
         Group g;
         g.log_n = h;
@@ -177,7 +206,7 @@ inline Plan make_plan(int log_g, int rank, int min_log_n, const std::vector<MatD
                     g.sparse = g.sparse || covered < m.width;
                 }
             }
-        g.bounds = column_bounds(g.W, G);
+        g.bounds = column_bounds(g.W, G, g.log_n, load);
         for (size_t k = 0; k < g.mats.size(); k++) {
             const MatDesc& m = mats[(size_t)g.mats[k]];
             if (m.n_next > m.width) throw std::runtime_error("split: more next-row columns than columns");
