@@ -405,7 +405,10 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
             max_w = std::max(max_w, r.c->width[m]);
             log_global_max = std::max(log_global_max, r.c->log_h[m]);
         }
-    const int side_lanes_wanted = log_global_max - log_blowup >= (int)SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : (int)lurkhip_ctx::N_SIDE;
+    // (one shard over several ranks: a rank's block of a matrix has 2^-log_g of its rows, and is short or tall by THAT -- a rank's share of
+    // a tall proof is a short proof's work)
+    const int lane_shift = log_blowup + (sp ? sp->log_g : 0);
+    const int side_lanes_wanted = log_global_max - lane_shift >= (int)SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : (int)lurkhip_ctx::N_SIDE;
     // caches keyed by (log size, point index)
     std::map<std::pair<int, int>, uint32_t*> bary, denoms;
     auto get_weights = [&](std::map<std::pair<int, int>, uint32_t*>& cache, int mode, int log_m, int pt, uint32_t** outp) -> int32_t {
@@ -480,7 +483,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 if (column_dot_is_narrow(r.c->width[m])) {
                     narrow.push_back(NarrowDot{r.c->lde[m], r.c->width[m], n_rows, u0, u1, partials + at, r.c->pitch[m]});
                 } else {
-                    const auto on_side = lane.on_side(log_n < SIDE_LANE_MAX_LOG_N, (uint32_t)k);
+                    const auto on_side = lane.on_side(log_n + log_blowup - lane_shift < SIDE_LANE_MAX_LOG_N, (uint32_t)k);
                     PTRY(column_dot_partial(ctx, r.c->lde[m], r.c->width[m], r.c->pitch[m], n_rows, u0, u1, partials + at));
                 }
                 jobs.push_back(DotJob{partials + at, r.c->width[m], n_rows, (uint32_t)dot_off[k], u1 != nullptr});
@@ -610,7 +613,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         const Round& r = rounds[ri];
         for (int m = 0; m < r.c->n_mats; m++, mat_k++) {
             const int log_h = r.c->log_h[m];
-            const auto on_side = ro_lane.on_side(log_h - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)log_h);  // one accumulator per height
+            const auto on_side = ro_lane.on_side(log_h - lane_shift < SIDE_LANE_MAX_LOG_N, (uint32_t)log_h);  // one accumulator per height
             const uint32_t w = r.c->width[m];
             const std::vector<int>& mp = r.points[m];
             uint32_t *d0 = nullptr, *d1 = nullptr;
@@ -715,15 +718,15 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         }
     }
     for (auto& kv : narrow) {
-        const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
+        const auto on_side = ro_lane.on_side(kv.first.first - lane_shift < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
         PTRY(flush_narrow(kv.second));
     }
     for (auto& kv : rows_groups) {
-        const auto on_side = ro_lane.on_side(kv.first.first - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
+        const auto on_side = ro_lane.on_side(kv.first.first - lane_shift < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.first.first);
         PTRY(flush_rows(kv.second));
     }
     for (auto& kv : group_wide) {
-        const auto on_side = ro_lane.on_side(kv.second.log_h - log_blowup < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.second.log_h);
+        const auto on_side = ro_lane.on_side(kv.second.log_h - lane_shift < SIDE_LANE_MAX_LOG_N, (uint32_t)kv.second.log_h);
         PTRY(flush_group(kv.second));
     }
     PTRY(ro_lane.close());
@@ -1206,12 +1209,13 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         }
     }
     // the short chips' launches (a few workgroups each: starts, interpreter rows, one-block scan) go to the side lane, under the
-    // tall chips' kernels
+    // tall chips' kernels (short by the rows THIS rank works on: a cut chip's block)
+    auto lane_log = [&](int i) { return (int)sh->log_n[i] - (cut(i) ? sp->log_g : 0); };
     SideLane lane(ctx);
     {
-        uint32_t tallest = 0;
-        for (int i = 0; i < n_chips; i++) tallest = std::max(tallest, sh->log_n[i]);
-        lane.want = tallest >= SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : lurkhip_ctx::N_SIDE;
+        int tallest = 0;
+        for (int i = 0; i < n_chips; i++) tallest = std::max(tallest, lane_log(i));
+        lane.want = tallest >= (int)SIDE_LANES_SHORT_PROOF_LOG_N ? 1 : lurkhip_ctx::N_SIDE;
     }
     // Round 5: which batch columns does anybody compute?  (stark_kernels.h: PermSink -- a compiled permutation kernel skips a batch
     // whose multiplicities are zero on all 64 rows of a wave; a column no wave marks is identically zero.)  One word per column,
@@ -1264,7 +1268,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
         }
     }
     for (int i = 0; i < n_chips; i++) {
-        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
+        const auto on_side = lane.on_side(lane_log(i) < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t* prep = sh->prep_index[i] >= 0 ? pk->traces[sh->prep_index[i]] : nullptr;
         if (cut(i)) {  // this rank's block of trace rows, its running sum from zero: the previous ranks' totals are added below
@@ -1465,7 +1469,7 @@ static int32_t shard_prove_impl(lurkhip_ctx* ctx, const lurkhip_pk* pk, lurkhip_
     }
     PTRY(lane.open());
     for (int i = 0; i < n_chips; i++) {
-        const auto on_side = lane.on_side((int)sh->log_n[i] < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
+        const auto on_side = lane.on_side(lane_log(i) < SIDE_LANE_MAX_LOG_N, (uint32_t)i);
         const size_t h = (size_t)1 << sh->log_n[i];
         const uint32_t qd = 1u << lqds[i];
         uint32_t* chunks = nullptr;
