@@ -200,14 +200,11 @@ int32_t split_commit(lurkhip_ctx* ctx, const SplitEnv& env, int n, const SplitMa
     const HostHasher H{*(const P16Params*)ctx->merkle_params_host};
 
     std::vector<void*> scratch;              // released (stream-ordered) on every way out
-    lurkhip_commitment* tiles_c = nullptr;   // the LDE of this rank's column tiles
     lurkhip_commitment* c = new lurkhip_commitment();
     auto done = [&](int32_t s) {
         if (s != LURKHIP_OK) (void)stream_wait(ctx);
         for (void* p : scratch) pool_release(ctx, p);
         scratch.clear();
-        if (tiles_c) free_commitment(ctx, tiles_c);
-        tiles_c = nullptr;
         if (s != LURKHIP_OK && c) {
             free_commitment(ctx, c);
             c = nullptr;
