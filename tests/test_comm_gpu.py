@@ -86,3 +86,41 @@ def test_rank_step_through_the_c_abi_collectives(ctx):
         assert with_comm.grand_sums == plain.grand_sums == [(0, 0, 0, 0)]
     finally:
         c.close()
+
+
+def test_split_vtable_callbacks_at_world_one(ctx, comm):
+    """The carrier of the split prover on RCCL (csrc/comm.cpp: lurkhip_comm_split_vtable -- grouped ncclSend / ncclRecv pairs, a device
+    all-gather, host all-gather and 64-bit all-reduce staged through the pool): the four callbacks called through the struct the
+    library is given, with the one rank this box's RCCL accepts.  What it can show here: librccl's ncclSend / ncclRecv /
+    ncclGroupStart / ncclGroupEnd resolve, an empty group is accepted, the own block of the all-to-all lands, the data types are
+    the 32- and 64-bit unsigned ones."""
+    import ctypes as C
+
+    import torch
+
+    from lurk_amd import split
+
+    sc = split.RcclSplitComm(ctx, comm)
+    st = sc.struct
+    assert (st.rank, st.world) == (0, 1)
+    n = 1000
+    send = torch.arange(n, dtype=torch.int32, device="cuda") * 3 + 1
+    recv = torch.zeros(n + 5, dtype=torch.int32, device="cuda")
+    soff = (C.c_uint64 * 2)(0, n)
+    roff = (C.c_uint64 * 2)(5, n + 5)  # (the receive offsets are the receiver's own: the block lands behind five words)
+    torch.cuda.synchronize()
+    assert st.alltoallv_dev(st.user, send.data_ptr(), soff, recv.data_ptr(), roff, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(recv[5:], send) and int(recv[:5].abs().sum()) == 0
+    out = torch.zeros(n, dtype=torch.int32, device="cuda")
+    assert st.allgather_dev(st.user, send.data_ptr(), out.data_ptr(), n, None) == 0
+    torch.cuda.synchronize()
+    assert torch.equal(out, send)
+    src = bytes(range(37))
+    dst = C.create_string_buffer(37)
+    assert st.allgather_host(st.user, src, dst, 37) == 0  # (a length that is no multiple of four: padded inside)
+    assert dst.raw == src
+    lanes = (C.c_uint64 * 3)(5, (1 << 63) + 9, 0xFFFFFFFF)
+    assert st.allreduce_sum_u64_host(st.user, lanes, 3) == 0
+    assert list(lanes) == [5, (1 << 63) + 9, 0xFFFFFFFF]
+    ctx.sync()
