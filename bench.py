@@ -229,6 +229,18 @@ def profiler_region(on: bool):
         (_ROCTX.roctxProfilerResume if on else _ROCTX.roctxProfilerPause)(0)
 
 
+def step_sources_changed(pmc) -> bool:
+    """True when a file a kernel of the step is made of differs from the tree profiles/pmc_traffic.json's PMC passes ran on (the
+    static instruction counts belong to those sources)."""
+    import hashlib
+
+    hs = hashlib.sha256()
+    for rel in pmc.get("step_kernel_sources", []):
+        with open(os.path.join(ROOT, rel), "rb") as fsrc:
+            hs.update(fsrc.read())
+    return hs.hexdigest() != pmc.get("step_kernel_sources_sha256")
+
+
 def measured_shape(workload: str):
     """What tools/measure_lurk_shape.py measured on the reference's own functions for the largest `(fib N)` it ran (unpadded rows;
     the fields above count the padded heights the prover works on)."""
@@ -1267,7 +1279,7 @@ def main():
         pass
     lde_alg = lde_alg_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
     lde_pass = lde_pass_bytes / (lde_ms_step * 1e-3) / 1e9 if lde_ms_step > 0 else 0.0
-    traffic, valu, lde_traffic = None, None, None
+    traffic, valu, lde_traffic, lde_valu = None, None, None, None
     try:  # HBM bytes / instruction counts of the same kernels from committed rocprofv3 PMC passes (NOT measured in this run)
         with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as f:
             pmc = json.load(f)
@@ -1278,6 +1290,15 @@ def main():
                        "note": "the re-fetches are L2 misses on lines shared by four consecutive 32-byte chunk loads of a lane's row, about 20 k cycles apart; the counter includes Infinity-Cache hits; the kernel is instruction-bound, not waiting for them (SQ_WAIT_ANY 5 %)"}
             lde_traffic = {"bytes_per_step": pmc["ntt_pass_bytes_per_step"], "over_algorithmic": pmc["ntt_pass_bytes_per_step"] / lde_alg_bytes if lde_alg_bytes else None,
                            "over_pass_model": pmc["ntt_pass_bytes_per_step"] / lde_pass_bytes if lde_pass_bytes else None, "source": src}
+            # the LDE is not a pure streaming kernel: 41 butterfly levels of 32-bit modular arithmetic per element are ~8 lane-instructions
+            # per byte of its nine transfers (half of them multiply-class, at half rate: ~12 full-rate equivalents) against the machine's
+            # 78.6 T / 8 TB/s = 9.8 -- its instruction rate is reported beside its bytes
+            if pmc.get("lde_valu_lane_insts_per_step") and lde_ms_step > 0 and not step_sources_changed(pmc):
+                li = pmc["lde_valu_lane_insts_per_step"] * len(mine)
+                lde_valu = {"valu_lane_insts_per_step": li, "achieved": li / (lde_ms_step * 1e-3) / 1e12, "unit": "T lane-instr/s", "peak": VALU_FULL_RATE,
+                            "frac": li / (lde_ms_step * 1e-3) / 1e12 / VALU_FULL_RATE,
+                            "lane_insts_per_pass_byte": li / lde_pass_bytes if lde_pass_bytes else None, "machine_balance_insts_per_byte": VALU_FULL_RATE * 1e12 / (HBM_PEAK_GBS * 1e9),
+                            "source": "profiles/pmc_traffic.json: SQ_INSTS_VALU x 64 lanes of the k_lde_* / k_ntt_pass launches of one step (static) / the `lde` spans' time of this run (live)"}
             mul_frac = pmc.get("merkle_hash_mul_class_frac", 0.6)
             # instruction-mix ceiling: add-class at the full rate, mul-class at half rate, no overlap between the classes
             ceiling = 1.0 / ((1 - mul_frac) / VALU_FULL_RATE + mul_frac / VALU_HALF_RATE)
@@ -1321,14 +1342,8 @@ def main():
     step_block = None
     try:
         if pmc.get("log_rows") == log_rows and pmc.get("workload") == args.workload and pmc.get("step_valu_lane_insts"):
-            import hashlib
-
-            hs = hashlib.sha256()
-            for rel in pmc.get("step_kernel_sources", []):
-                with open(os.path.join(ROOT, rel), "rb") as fsrc:
-                    hs.update(fsrc.read())
             step_block = {"valu_lane_insts_per_step": pmc["step_valu_lane_insts"], "unit": "T lane-instr/s", "peak": VALU_FULL_RATE,
-                          "sources_changed_since_pmc_pass": hs.hexdigest() != pmc.get("step_kernel_sources_sha256"),
+                          "sources_changed_since_pmc_pass": step_sources_changed(pmc),
                           "source": "profiles/pmc_traffic.json: SQ_INSTS_VALU x 64 lanes summed over every kernel of one step (static) / ms_per_step of this run (live, "
                                     "filled in below)"}
     except Exception:
@@ -1556,7 +1571,9 @@ def main():
                          "transformed_note": "12 w B per row of the columns whose extension is computed: the permutation traces' identically-zero columns (interactions no row of "
                                              "the shard uses) are stored as zeros, not transformed -- the honest numerator for the kernels' own efficiency",
                          "pass_traffic_bytes_per_step": lde_pass_bytes, "pass_traffic_GBs": lde_pass, "ms_per_step": lde_ms_step,
-                         "traffic": lde_traffic},
+                         "traffic": lde_traffic, "int32_valu": lde_valu,
+                         "bound_note": "neither roof is near: the pass traffic runs at pass_traffic_GBs of 8000 and the butterflies at int32_valu.frac of the VALU peak -- the "
+                                       "three kernels alternate memory phases and register phases in one or two workgroups a CU (DESIGN.md 3.3)"},
                 "step": step_block,
                 "algorithmic_bytes_per_step": hash_bytes_step,
                 "launches_per_step": hash_launches_step,

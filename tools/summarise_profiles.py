@@ -73,6 +73,7 @@ traffic = {"log_rows": 20, "workload": "fib-mix", "source": f"rocprofv3 --pmc FE
            "merkle_hash_fetch_bytes_reported": F, "merkle_hash_write_bytes_reported": W, "merkle_hash_bytes_per_step": 2 * F + W,
            "merkle_hash_valu_tinst_s": hv, "merkle_hash_valu_lane_insts_per_step": hash_lane_insts,
            "merkle_hash_algorithmic_bytes_per_step": bench["roofline"]["algorithmic_bytes_per_step"],  # the shapes the instruction count belongs to
+           "lde_valu_lane_insts_per_step": sum(tot[k]["SQ_INSTS_VALU"] for k in tot if k.startswith("k_ntt_pass") or k.startswith("k_lde_")) * 64,
            "lde_kernels": sorted(NTT), "merkle_hash_mul_class_frac": 0.6, "valu_full_rate_tinst_s": 78.6, "valu_half_rate_tinst_s": 39.3}
 # the instruction count belongs to these sources: bench.py recomputes the hash and stops using the count when they have changed
 import hashlib
