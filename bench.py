@@ -1437,34 +1437,6 @@ def main():
         except Exception as e:  # a reported extra, never a reason to lose the line
             split_probe = {"error": repr(e)}
         split_probe["probe_wall_s"] = time.perf_counter() - t_probe
-    # ... and, the same way (children, a time limit), the shards -> ranks step with phase 1 of machine proof j + 1 under phase 2 of
-    # proof j (--rank-pipeline: every collective on one thread of a rank, in one order on every rank, ONE communicator): with world > 1
-    # on RCCL the timed region above runs one proof at a time per rank -- the only schedule whose first contact with a multi-GPU box
-    # cannot hang on an interplay of collectives and a second stream's work --, which costs a rank the 5-6 % two proofs in flight buy
-    # on one device (tools/ab_rank_schedules.sh at world 1: 50.9 -> 48.1 ms).  The child's line goes under config.rank_pipeline_probe.
-    pipeline_probe = None
-    if (split_probe is not None or (distributed and world > 1 and not oversubscribed and os.environ.get("LURKHIP_BENCH_CHILD") != "1" and not args.no_split_probe)) \
-            and not args.rank_pipeline and (args.rank_in_flight or 1) < 2 and args.workload in ("fib-mix", "lurk-mix"):
-        import subprocess
-
-        fence()
-        env = dict(os.environ, LURKHIP_BENCH_CHILD="1", MASTER_PORT=str(int(os.environ.get("MASTER_PORT", "29500")) + 29))
-        env.pop("TORCHELASTIC_USE_AGENT_STORE", None)
-        cmd = [sys.executable, os.path.abspath(__file__), "--gpus", str(world), "--rank-pipeline", "--rank-pipeline-depth", "3", "--steps", str(max(4, min(args.steps, 12))),
-               "--warmup", "2", "--log-rows", str(log_rows), "--workload", args.workload, "--queries", str(args.queries), "--pow-bits", str(args.pow_bits),
-               "--no-cpu-baseline", "--no-host-pipeline", "--no-split-probe", "--shards-per-rank", str(spr)]
-        cmd += ["--oversubscribe"] if oversubscribed else []
-        cmd += (["--no-compile"] if args.no_compile else []) + ["--compile-min-log-rows", str(args.compile_min_log_rows)]
-        t_probe = time.perf_counter()
-        try:
-            r = subprocess.run(cmd, capture_output=True, text=True, timeout=args.split_probe_timeout, env=env)
-            lines = [l for l in r.stdout.splitlines() if l.startswith("{")]
-            pipeline_probe = json.loads(lines[-1]) if lines else {"error": f"no line (exit code {r.returncode})", "stderr_tail": r.stderr[-600:]}
-        except subprocess.TimeoutExpired:
-            pipeline_probe = {"error": f"timed out after {args.split_probe_timeout} s"}
-        except Exception as e:
-            pipeline_probe = {"error": repr(e)}
-        pipeline_probe["probe_wall_s"] = time.perf_counter() - t_probe
     if step_block is not None and ms_per_step > 0:
         step_block["achieved"] = step_block["valu_lane_insts_per_step"] * len(mine) / (ms_per_step * 1e-3) / 1e12
         step_block["frac"] = step_block["achieved"] / VALU_FULL_RATE
@@ -1510,14 +1482,6 @@ def main():
                                     "note": "ONE shard of 2^log_rows eval rows proved by all ranks together (bench.py --split intra, measured by child processes of this run "
                                             "after its timed region): strong scaling -- compare ms_per_step with the N = 1 line's proof_latency_ms"}
                                    if "config" in split_probe else {})),
-                "rank_pipeline_probe": (None if pipeline_probe is None else
-                                        {k: pipeline_probe.get(k) for k in ("error", "stderr_tail", "probe_wall_s", "value", "ms_per_step", "scaling", "n_gpus", "ranks", "steps")
-                                         if k in pipeline_probe}
-                                        | ({"rank_pipeline": pipeline_probe["config"].get("rank_pipeline"), "grand_sum_is_zero": pipeline_probe["config"].get("grand_sum_is_zero"),
-                                            "note": "the same shards -> ranks step with phase 1 of machine proof j + 1 under phase 2 of proof j on every rank (bench.py --rank-pipeline "
-                                                    "--rank-pipeline-depth 3, measured by child processes of this run after its timed region): what a rank's device does when it is not "
-                                                    "left idle in the latency chains; this line's own value is the one-proof-at-a-time schedule"}
-                                           if "config" in pipeline_probe else {})),
                 "eval_rows": n,
                 "workload_detail": (None if args.workload != "lurk-mix" else
                                     ("lurk-mix at the REAL height of demo/mastermind.lurk (--eval-rows 6867: every tall chip at the padded height of the reference's own run, "

@@ -214,10 +214,6 @@ def test_bench_n_ranks_also_probe_the_intra_shard_split(monkeypatch):
     assert si["scaling"] == "strong" and si["n_gpus"] == 2 and si["proofs_identical_on_all_ranks"] and si["proof_verified"]
     assert si["alltoall_bytes_per_rank_per_step"] > 0 and len(si["per_rank"]) == 2 and si["per_rank"][1]["alltoalls"] == 6
     assert line["scaling"] == "weak"  # (the line itself is still the shards -> ranks measurement)
-    # ... and the pipelined rank schedule (phase 1 of proof j + 1 under phase 2 of proof j, collectives on one thread), the same way
-    pp = line["config"]["rank_pipeline_probe"]
-    assert pp is not None and "error" not in pp, pp
-    assert pp["scaling"] == "weak" and pp["ranks"] == 2 and pp["value"] > 0 and pp["grand_sum_is_zero"] and "phase 1" in pp["rank_pipeline"]
 
 
 def test_bench_split_turns_times_each_ranks_work_with_the_device_to_itself():
