@@ -690,7 +690,7 @@ def main():
                          "every execution below the reference's default shard size of 2^22 rows")
     ap.add_argument("--no-split-probe", action="store_true",
                     help="N > 1: do not also measure --split intra in child processes (config.split_intra of the line)")
-    ap.add_argument("--split-probe-timeout", type=int, default=240)
+    ap.add_argument("--split-probe-timeout", type=int, default=150)
     ap.add_argument("--split-turns", action="store_true",
                     help="--split intra with --oversubscribe: after the timed steps, five proofs in which the ranks take turns between the collectives -- each "
                          "rank's segments timed with the device to itself -- and the one-rank prover alone, for `predicted` (a labelled model of the G-GPU proof)")
