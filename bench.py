@@ -453,6 +453,16 @@ def split_intra(args, world, rank, device_index, distributed, oversubscribed):
             comm_c, carrier_note = bring_up(ctx)  # collectively, with a self-test; on failure every rank takes the host route together
             if comm_c is not None:
                 scomm, carrier = split.RcclSplitComm(ctx, comm_c), "RCCL behind the C ABI (ncclSend / ncclRecv pairs, device buffers)"
+                # the four collectives once with known words, before anything is timed: a carrier that moves a block to the wrong place
+                # must not be found out by a proof that does not verify -- every rank goes to the host route together
+                bad = scomm.selftest()
+                flag = torch.tensor([0 if bad is None else 1], dtype=torch.int64, device="cuda")
+                dist.all_reduce(flag, op=dist.ReduceOp.MAX)
+                if int(flag.item()):
+                    carrier_note = f"RCCL carrier's self-test failed ({bad or 'on another rank'})"
+                    scomm = None
+                    comm_c.close()
+                    comm_c = None
         if scomm is None:
             group = None if oversubscribed else dist.new_group(backend="gloo")
             scomm, carrier = split.TorchSplitComm(ctx, group), "torch.distributed gloo through host memory" + (" (several ranks share a device)" if oversubscribed else " (fall-back)")

@@ -43,6 +43,9 @@ def main(n: int, share: bool):
 
             comm_c = Comm.from_process_group(ctx)          # this library's RCCL communicator (csrc/comm.cpp)
             comm = split.RcclSplitComm(ctx, comm_c)        # grouped ncclSend / ncclRecv pairs: device buffers stay on the devices
+            bad = comm.selftest()                          # the four collectives once, with known words
+            if bad is not None:
+                raise SystemExit(f"rank {rank}: the RCCL carrier's self-test failed: {bad}")
         sp = split.SplitProver(machine, comm, min_log_n=max(8, world.bit_length() - 1))  # chips of at least 2^8 rows are cut across the ranks
         sp.setup()
         blocks = sp.run_prepared_blocks(prepared)          # a cut chip's trace: this rank's block of rows only

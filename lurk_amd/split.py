@@ -40,6 +40,48 @@ class RcclSplitComm:
         self.rank, self.world = int(self.struct.rank), int(self.struct.world)
         self.bytes_sent = 0  # (not counted on this route)
 
+    def selftest(self):
+        return carrier_selftest(self)
+
+
+def carrier_selftest(self) -> str | None:
+    """The four collectives of a carrier (`RcclSplitComm`, `TorchSplitComm`) once, with known words (ragged blocks: rank r sends
+    100 + 7 d + r words to rank d): None when every word is where it belongs on THIS rank, else what was wrong.  Collective; the caller agrees on the outcome over its process group
+    (bench.py: every rank falls back to the host route together)."""
+    import torch
+
+    w, r, st = self.world, self.rank, self.struct
+    n_to = [100 + 7 * d + r for d in range(w)]
+    n_from = [100 + 7 * r + s for s in range(w)]
+    soff = (C.c_uint64 * (w + 1))(*np.concatenate([[0], np.cumsum(n_to)]).tolist())
+    roff = (C.c_uint64 * (w + 1))(*np.concatenate([[0], np.cumsum(n_from)]).tolist())
+    send = torch.cat([torch.arange(n, dtype=torch.int32) + (r * 1000 + d) * 10000 for d, n in enumerate(n_to)]).to(f"cuda:{self.ctx.device}")
+    recv = torch.zeros(sum(n_from), dtype=torch.int32, device=send.device)
+    torch.cuda.synchronize()
+    try:
+        if st.alltoallv_dev(st.user, send.data_ptr(), soff, recv.data_ptr(), roff, None) != 0:
+            return "all-to-all: " + N.last_error(self.ctx.handle)
+        torch.cuda.synchronize()
+        want = torch.cat([torch.arange(n, dtype=torch.int32) + (s * 1000 + r) * 10000 for s, n in enumerate(n_from)])
+        if not torch.equal(recv.cpu(), want):
+            return "all-to-all: a block arrived with other words"
+        mine = torch.full((5,), 17 + r, dtype=torch.int32, device=send.device)
+        got = torch.zeros(5 * w, dtype=torch.int32, device=send.device)
+        if st.allgather_dev(st.user, mine.data_ptr(), got.data_ptr(), 5, None) != 0:
+            return "device all-gather: " + N.last_error(self.ctx.handle)
+        torch.cuda.synchronize()
+        if got.cpu().tolist() != [17 + s for s in range(w) for _ in range(5)]:
+            return "device all-gather: wrong words"
+        src, dst = bytes([r + 1] * 6), C.create_string_buffer(6 * w)
+        if st.allgather_host(st.user, src, dst, 6) != 0 or dst.raw != b"".join(bytes([s + 1] * 6) for s in range(w)):
+            return "host all-gather failed"
+        lanes = (C.c_uint64 * 2)(r + 1, (1 << 40) + r)
+        if st.allreduce_sum_u64_host(st.user, lanes, 2) != 0 or list(lanes) != [w * (w + 1) // 2, w * (1 << 40) + w * (w - 1) // 2]:
+            return "64-bit all-reduce failed"
+    except Exception as e:  # noqa: BLE001
+        return repr(e)
+    return None
+
 
 class TorchSplitComm:
     """The collectives over a torch.distributed group through host memory (device blocks are read back on the context's stream,
@@ -103,6 +145,9 @@ class TorchSplitComm:
         self.turns = False
         dist.barrier(group=self.group)
         return list(self.segments)
+
+    def selftest(self):
+        return carrier_selftest(self)
 
     def _guard(self, fn, *a):
         try:

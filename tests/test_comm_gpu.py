@@ -124,3 +124,4 @@ def test_split_vtable_callbacks_at_world_one(ctx, comm):
     assert st.allreduce_sum_u64_host(st.user, lanes, 3) == 0
     assert list(lanes) == [5, (1 << 63) + 9, 0xFFFFFFFF]
     ctx.sync()
+    assert sc.selftest() is None  # (what bench.py --split intra runs on every rank before it trusts the carrier)
