@@ -997,17 +997,46 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
     }
     PHIP(stream_wait(ctx));
     out.layer_records.assign(layers.size(), {});
+    // The owners' answers of EVERY distributed layer and split round in ONE all-gather (a dozen 50 us collectives before): every rank
+    // knows who answers what, so the segments -- padded to the largest count of any rank -- lie at the same offsets for all.
+    std::vector<size_t> layer_seg(dist_layers.size(), 0), layer_at(dist_layers.size(), 0), round_seg(rounds.size(), 0), round_at(rounds.size(), 0);
+    size_t answers_words = 0;
+    std::vector<uint32_t> answers_mine, answers_all;
+    if (sp) {
+        auto seg_of = [](const SplitRound& r) {
+            size_t most = 0;
+            for (const auto& o : r.owned) most = std::max(most, o.size());
+            return most * r.local_words;
+        };
+        for (size_t li = 0; li < dist_layers.size(); li++) {
+            layer_seg[li] = seg_of(split_layers[li]);
+            layer_at[li] = answers_words;
+            answers_words += layer_seg[li];
+        }
+        for (size_t ri = 0; ri < rounds.size(); ri++) {
+            if (!rounds[ri].c->split_log_g) continue;
+            round_seg[ri] = seg_of(split_rounds[ri]);
+            round_at[ri] = answers_words;
+            answers_words += round_seg[ri];
+        }
+        answers_words = std::max<size_t>(answers_words, 1);
+        answers_mine.assign(answers_words, 0u);
+        answers_all.resize(answers_words * (size_t)sp->world());
+        for (size_t li = 0; li < dist_layers.size(); li++) {
+            const size_t n_mine = split_layers[li].owned[(size_t)sp->rank].size();
+            if (n_mine) memcpy(&answers_mine[layer_at[li]], rec_host + layer_off[li], n_mine * split_layers[li].local_words * 4);
+        }
+        for (size_t ri = 0; ri < rounds.size(); ri++) {
+            if (!rounds[ri].c->split_log_g) continue;
+            const size_t n_mine = split_rounds[ri].owned[(size_t)sp->rank].size();
+            if (n_mine) memcpy(&answers_mine[round_at[ri]], rec_host + round_off[ri], n_mine * split_rounds[ri].local_words * 4);
+        }
+        PTRY(split_allgather_host(ctx, *sp, answers_mine.data(), answers_all.data(), answers_words * 4));
+    }
     for (size_t li = 0; li < dist_layers.size(); li++) {
         const SplitRound& sl = split_layers[li];
         const int G = sp->world();
         const uint32_t log_local = (uint32_t)layers[li]->log_h[0];
-        size_t most = 0;
-        for (const auto& o : sl.owned) most = std::max(most, o.size());
-        const size_t seg = std::max<size_t>(most * sl.local_words, 1);
-        std::vector<uint32_t> mine(seg, 0u), all(seg * (size_t)G);
-        const size_t n_mine = sl.owned[(size_t)sp->rank].size();
-        if (n_mine) memcpy(mine.data(), rec_host + layer_off[li], n_mine * sl.local_words * 4);
-        PTRY(split_allgather_host(ctx, *sp, mine.data(), all.data(), seg * 4));
         std::vector<uint32_t>& recs = out.layer_records[li];
         recs.resize((size_t)num_queries * layer_record_words[li]);
         for (int r = 0; r < G; r++)
@@ -1015,7 +1044,7 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
                 const uint32_t q = sl.owned[(size_t)r][k];
                 const uint32_t pair = indices[q] >> (li + 1);
                 uint32_t* o = &recs[(size_t)q * layer_record_words[li]];
-                memcpy(o, &all[(size_t)r * seg + k * sl.local_words], (size_t)sl.local_words * 4);  // the pair | the path inside the owner's subtree
+                memcpy(o, &answers_all[(size_t)r * answers_words + layer_at[li] + k * sl.local_words], (size_t)sl.local_words * 4);  // the pair | the path inside the owner's subtree
                 o += sl.local_words;
                 size_t level = 0;  // word offset of top level t: G, G / 2, .. nodes of 8 words
                 for (int t = 0, nodes = G; t < sp->log_g; t++, nodes >>= 1) {
@@ -1033,20 +1062,13 @@ static int32_t pcs_open_impl(lurkhip_ctx* ctx, const lurkhip_protocol_profile& p
         const SplitRound& sr = split_rounds[ri];
         const int G = 1 << c->split_log_g;
         const uint32_t log_local = (uint32_t)(c->log_max - c->split_log_g);
-        size_t most = 0;
-        for (const auto& o : sr.owned) most = std::max(most, o.size());
-        const size_t seg = std::max<size_t>(most * sr.local_words, 1);
-        std::vector<uint32_t> mine(seg, 0u), all(seg * (size_t)G);
-        const size_t n_mine = sr.owned[(size_t)c->split_rank].size();
-        if (n_mine) memcpy(mine.data(), rec_host + round_off[ri], n_mine * sr.local_words * 4);
-        PTRY(split_allgather_host(ctx, *sp, mine.data(), all.data(), seg * 4));
         std::vector<uint32_t>& recs = out.round_records[ri];
         recs.resize((size_t)num_queries * round_record_words[ri]);
         for (int r = 0; r < G; r++)
             for (size_t k = 0; k < sr.owned[(size_t)r].size(); k++) {
                 const uint32_t q = sr.owned[(size_t)r][k];
                 const uint32_t ix = indices[q] >> (log_max - c->log_max);
-                const uint32_t* loc = &all[(size_t)r * seg + k * sr.local_words];
+                const uint32_t* loc = &answers_all[(size_t)r * answers_words + round_at[ri] + k * sr.local_words];
                 uint32_t* o = &recs[(size_t)q * round_record_words[ri]];
                 memcpy(o, loc, (size_t)sr.local_rows_words * 4);
                 o += sr.local_rows_words;
